@@ -1,0 +1,144 @@
+/*
+ * migan.h — C ABI of libmigan.so, the MI355X (gfx950) kernels behind the GAN training hot path.
+ *
+ * Boundary: the reference has no FFI; its "plugin interface" for this path is the
+ * torch.nn layer set that implementations/{dcgan,wgan_gp,cyclegan,pix2pix,srgan} construct, whose
+ * forward/backward PyTorch dispatches to ATen.  Each entry point below replaces one ATen op family on
+ * that path; the reference call site it serves is cited next to it (paths relative to the reference
+ * repo root).  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only: every pointer is a DEVICE pointer owned by the caller (torch's
+ *     caching allocator in our host code); the library never allocates, frees or synchronises, so every
+ *     launcher is legal inside hipGraph capture.  `stream` is a hipStream_t.
+ *   - all tensors are fp32.  4-D activations are NHWC ([N][H][W][C], torch.channels_last memory).
+ *   - return value: 0 on success, otherwise a hipError_t code (migan_error_string()).
+ *   - activation codes: 0 none, 1 LeakyReLU(slope), 2 ReLU, 3 Tanh, 4 Sigmoid.
+ *   - gather modes of the conv loaders: 0 zero padding, 1 reflection padding (nn.ReflectionPad2d folded
+ *     into the conv), 2 nearest-upsample x2 then zero padding (nn.Upsample(scale_factor=2) folded in).
+ */
+#ifndef MIGAN_H
+#define MIGAN_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* migan_version(void);
+const char* migan_error_string(int code);
+
+/* ---- Convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip) ----------
+ * nn.Conv2d forward: dcgan.py:55,59,62,78  cyclegan/models.py:28,32,50,60,75,82,106,118
+ *                    pix2pix/models.py:23,79,115,127  srgan/models.py:22,25,38,47,54,62,85,89,100
+ * nn.Linear forward (N=batch, H=W=1, R=S=1): dcgan.py:50,92  wgan_gp.py:46,56,73-77  gan.py:41-59
+ * x [N][Hi][Wi][Ci]; w_ohwi [Co][R][S][Ci]; bias [Co] or NULL; y [N][Ho][Wo][Co].
+ * pad_t/pad_l are the top/left zero (or reflection) pads in logical (upsampled, for gather 2)
+ * coordinates; bottom/right padding is implied by Ho/Wo.  Epilogue: y = act(conv + bias). */
+int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int Hi, int Wi,
+                     int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather,
+                     int act, float slope, void* stream);
+
+/* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
+ * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];
+ * w_ihwo [Ci][R][S][Co]; dx [N][Hi][Wi][Ci] = act(sum + bias) (bias/act used by the ConvTranspose role).
+ * stride 1 or 2 (dense per-parity tap lists, no zero-multiplies). */
+int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
+                       int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
+                       float slope, void* stream);
+
+/* Conv2d / Linear weight gradient (aten::convolution_backward grad_weight; aten::mm in AddmmBackward).
+ * Split-K over pixels + fixed-order reduction (deterministic).  dw_oihw has the torch parameter layout
+ * [Co][Ci][R][S].  ws must hold migan_conv2d_wgrad_workspace() bytes. */
+size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci);
+int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi,
+                       int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
+                       int gather, void* stream);
+
+/* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
+ * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:
+ * wgan_gp.py:49, gan.py:45;  nn.InstanceNorm2d(C): cyclegan/models.py:29,33,51,62,77,108
+ * pix2pix/models.py:25,40,117.   Data viewed as [G][P][C]: BatchNorm G=1,P=N*H*W; InstanceNorm G=N,P=H*W.
+ * migan_norm_stats: biased variance -> invstd = 1/sqrt(var+eps); running stats (G==1, non-NULL) updated
+ * with momentum and the unbiased variance, as torch does. */
+size_t migan_norm_workspace(int G, int P, int C);
+int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                     float momentum, float eps, int G, int P, int C, float* ws, size_t ws_bytes, void* stream);
+/* y = act((x-mean)*invstd*gamma+beta) [+ res]; gamma/beta/res may be NULL. */
+int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, const float* res, int G, int P, int C, int act, float slope,
+                     void* stream);
+/* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1. */
+int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float* dx, float* dgamma, float* dbeta, int G, int P, int C, int act,
+                   float slope, float* ws, size_t ws_bytes, void* stream);
+
+/* ---- Pointwise / index-remap kernels (csrc/eltwise.hip) ------------------------------------------------
+ * nn.LeakyReLU(0.2)/ReLU/Tanh/Sigmoid: dcgan.py:57,63,92  cyclegan/models.py:30,52,82,110 ... */
+int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
+int migan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope, void* stream);
+/* nn.PReLU() single shared slope: srgan/models.py:24,38,57.  ws: migan_reduce_workspace() bytes. */
+size_t migan_reduce_workspace(void);
+int migan_prelu_fwd(const float* x, const float* a, float* y, size_t n, void* stream);
+int migan_prelu_bwd(const float* x, const float* dy, const float* a, float* dx, float* da, float* ws, size_t n,
+                    void* stream);
+/* y = alpha*a + beta*b (b may be NULL): residual adds cyclegan/models.py:37, srgan/models.py:30,68;
+ * loss combinations dcgan.py:180, cyclegan.py:202. */
+int migan_axpby(const float* a, float alpha, const float* b, float beta, float* y, size_t n, void* stream);
+int migan_mul(const float* a, const float* b, float* y, size_t n, void* stream);
+/* nn.Dropout2d(0.25) dcgan.py:78: y[n][p][c] = x[n][p][c]*mask[n][c];  nn.Dropout(0.5) pix2pix/models.py:27,44
+ * uses migan_mul with a full-size mask.  migan_rand_mask draws mask = Bernoulli(1-p)/(1-p) with
+ * Philox4x32-10 at stream position *counter (device, advanced by the call; NULL = position 0). */
+int migan_mul_nc(const float* x, const float* mask, float* y, int N, int HW, int C, void* stream);
+int migan_rand_mask(float* mask, size_t n, float p, unsigned long long seed, unsigned long long* counter,
+                    void* stream);
+/* Standalone nn.ReflectionPad2d / nn.ZeroPad2d / nn.Upsample(scale_factor=2) (cyclegan/models.py:27,49,74,117,
+ * dcgan.py:54,58, pix2pix/models.py:77-78) and their backward (scatter of preimages, deterministic). */
+int migan_gather2d_fwd(const float* x, float* y, int N, int Hi, int Wi, int C, int Ho, int Wo, int pad_t,
+                       int pad_l, int mode, void* stream);
+int migan_gather2d_bwd(const float* dy, float* dx, int N, int Hi, int Wi, int C, int Ho, int Wo, int pad_t,
+                       int pad_l, int mode, void* stream);
+/* nn.PixelShuffle(r) srgan/models.py:56: small [N][H][W][C*r*r] <-> large [N][H*r][W*r][C];
+ * forward=1 reads small writes large, forward=0 the inverse (its backward). */
+int migan_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int r, int forward,
+                        void* stream);
+/* MaxPool2d(2,2) inside vgg19.features[:18] (srgan/models.py:11-12). */
+int migan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* torch.cat((a,b),1) pix2pix/models.py:50,132 (forward=1) and its backward split (forward=0). */
+int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca, int Cb, int forward, void* stream);
+/* [B][R][C] -> [B][C][R]: NCHW<->NHWC re-layout at the boundary with reference code (.view in
+ * dcgan.py:68,96). */
+int migan_transpose_batched(const float* src, float* dst, int B, int R, int Cc, void* stream);
+int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                    void* stream);
+
+/* ---- Reductions, losses, gradient penalty, optimiser (csrc/reduce_loss_adam.hip) -----------------------
+ * bias gradients: out[c] = sum_p x[p][c]. */
+size_t migan_colsum_workspace(size_t P, int C);
+int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, void* stream);
+/* kind 0 BCELoss (dcgan.py:103), 1 MSELoss (cyclegan.py:57), 2 L1Loss (cyclegan.py:58-59), 3 mean
+ * (wgan_gp.py:171,189).  Target is t[i] or the constant tconst when t==NULL.  out = mean over n.
+ * ws: migan_reduce_workspace() bytes.  bwd: dx = g[0]/n * dloss/dx. */
+int migan_loss_fwd(int kind, const float* x, const float* t, float tconst, float* out, size_t n, float* ws,
+                   size_t ws_bytes, void* stream);
+int migan_loss_bwd(int kind, const float* x, const float* t, float tconst, const float* g, float* dx, size_t n,
+                   void* stream);
+/* gradients.norm(2, dim=1) and its derivatives (wgan_gp.py:136-137). */
+int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream);
+int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D, void* stream);
+int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream);
+int migan_rowdot(const float* a, const float* c, float* out, int B, int D, void* stream);
+/* torch.optim.Adam(lr, betas) step for all tensors of one optimiser in one launch (dcgan.py:134-135,169,183).
+ * tab: device array of {float* p; const float* g; float* m; float* v; long long n}; blk: device array of
+ * {int tensor; int chunk} with chunk size migan_adam_chunk(); step: device float, incremented first.
+ * grads are multiplied by grad_scale (1/world_size after a summed all-reduce). */
+int migan_adam_chunk(void);
+int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, float lr, float b1, float b2,
+                    float eps, float grad_scale, void* stream);
+/* gradient bucket pack/unpack for the data-parallel all-reduce: tab = {float* ptr; long long off; long long n}. */
+int migan_pack(const void* tab, const void* blk, int nblocks, float* flat, int to_flat, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIGAN_H */

@@ -1,0 +1,516 @@
+"""ORACLE pinning + golden-vector generator (test infrastructure; run in the BUILD container only).
+
+    python -m oracle.pin_against_reference            # validates the restatement, rewrites tests/golden/*.npz
+
+The reference has no tests or golden vectors of its own ("parity unpinned by the
+reference itself"), so the oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF RUN HERE: this script
+imports the real classes from /root/reference (direct import for cyclegan/pix2pix models, AST extraction
+of the class/def nodes for the run-on-import scripts dcgan.py / wgan_gp.py / gan.py, a torchvision stub
+for srgan/models.py), and for every network checks, against oracle/reference_models.py:
+  1. identical state_dict keys and shapes,
+  2. bit-identical parameters after `torch.manual_seed(s)` + construction (+ the script's init function),
+  3. bit-identical forward outputs and parameter gradients on the same seeded inputs (train mode; dropout
+     masks are extracted from the reference run by forward hooks and replayed in the oracle),
+and `compute_gradient_penalty` (wgan_gp.py:119-138) against oracle.reference_steps.gradient_penalty.
+It then stores small golden fixtures (inputs, reference outputs, loss values, gradient digests) that the
+CPU and GPU test-suites replay on machines where /root/reference does not exist.
+Recorded environment: see "meta" inside each fixture (torch version, oneDNN flag).
+"""
+import ast
+import importlib.util
+import os
+import random
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import reference_models as M
+from . import reference_steps as S
+
+REF = os.environ.get("MIGAN_REFERENCE", "/root/reference")
+IMPL = os.path.join(REF, "implementations")
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ------------------------------------------------------------------------------------------- reference loaders
+def _install_torchvision_stub():
+    if "torchvision" in sys.modules:
+        return
+    tv = types.ModuleType("torchvision")
+    tv_models = types.ModuleType("torchvision.models")
+    tv_utils = types.ModuleType("torchvision.utils")
+    tv_tf = types.ModuleType("torchvision.transforms")
+
+    def vgg19(pretrained=False):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        return SimpleNamespace(features=nn.Sequential(*layers))
+
+    tv_models.vgg19 = vgg19
+    tv_utils.save_image = lambda *a, **k: None
+    tv_utils.make_grid = lambda *a, **k: None
+    tv.models, tv.utils, tv.transforms = tv_models, tv_utils, tv_tf
+    sys.modules.update({"torchvision": tv, "torchvision.models": tv_models, "torchvision.utils": tv_utils,
+                        "torchvision.transforms": tv_tf})
+
+
+def _import_file(name, path):
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _extract_defs(path, namespace):
+    """exec only the ClassDef / FunctionDef nodes of a run-on-import script."""
+    with open(path) as fh:
+        tree = ast.parse(fh.read())
+    keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef))]
+    code = compile(ast.Module(body=keep, type_ignores=[]), path, "exec")
+    exec(code, namespace)
+    return namespace
+
+
+def _script_ns(**extra):
+    import torch.nn.functional as F
+    from torch import autograd
+    from torch.autograd import Variable
+
+    ns = dict(nn=nn, torch=torch, np=np, F=F, autograd=autograd, Variable=Variable, Tensor=torch.FloatTensor)
+    ns.update(extra)
+    return ns
+
+
+def load_reference():
+    _install_torchvision_stub()
+    ref = SimpleNamespace()
+    ref.cyclegan = _import_file("ref_cyclegan_models", os.path.join(IMPL, "cyclegan", "models.py"))
+    ref.cyclegan_utils = _import_file("ref_cyclegan_utils", os.path.join(IMPL, "cyclegan", "utils.py"))
+    ref.pix2pix = _import_file("ref_pix2pix_models", os.path.join(IMPL, "pix2pix", "models.py"))
+    ref.srgan = _import_file("ref_srgan_models", os.path.join(IMPL, "srgan", "models.py"))
+
+    def dcgan(img_size, latent_dim=100, channels=1):
+        opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "dcgan", "dcgan.py"), _script_ns(opt=opt)))
+
+    def wgan_gp(img_size, latent_dim=100, channels=1):
+        opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
+        ns = _script_ns(opt=opt, img_shape=(channels, img_size, img_size))
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "wgan_gp", "wgan_gp.py"), ns))
+
+    def gan(img_size, latent_dim=100, channels=1):
+        opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
+        ns = _script_ns(opt=opt, img_shape=(channels, img_size, img_size))
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "gan", "gan.py"), ns))
+
+    ref.dcgan, ref.wgan_gp, ref.gan = dcgan, wgan_gp, gan
+    return ref
+
+
+# ------------------------------------------------------------------------------------------- comparison helpers
+def seed_all(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def check_same_params(a, b, what):
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys()), "%s: state_dict keys differ" % what
+    for k in sa:
+        assert sa[k].shape == sb[k].shape, "%s: shape of %s differs" % (what, k)
+        assert torch.equal(sa[k], sb[k]), "%s: seeded init of %s differs" % (what, k)
+
+
+def built_equal(make_ref, make_orc, what, seed=0, post=None):
+    seed_all(seed)
+    r = make_ref()
+    if post:
+        r.apply(post[0])
+    seed_all(seed)
+    o = make_orc()
+    if post:
+        o.apply(post[1])
+    check_same_params(r, o, what)
+    return r, o
+
+
+def hook_masks(model, store):
+    """Recover the dropout masks the reference drew (forward hooks on its Dropout/Dropout2d layers)."""
+    handles = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        if not mod.training or mod.p == 0:
+            return
+        if isinstance(mod, nn.Dropout2d):
+            fx, fo = x.flatten(2), out.flatten(2)
+            idx = fx.abs().argmax(2, keepdim=True)
+            den = fx.gather(2, idx)
+            m = torch.where(den != 0, fo.gather(2, idx) / den, torch.zeros_like(den)).squeeze(2)
+            keep = 1.0 / (1.0 - mod.p)
+            m = torch.where(m > 0.5 * keep, torch.full_like(m, keep), torch.zeros_like(m))
+        else:
+            keep = 1.0 / (1.0 - mod.p)
+            m = torch.where((x != 0) & (out != 0), torch.full_like(x, keep), torch.zeros_like(x))
+            # where x == 0 the mask value cannot influence forward or backward (see module docstring)
+        store.append(m.detach().clone())
+
+    for mod in model.modules():
+        if isinstance(mod, (nn.Dropout2d, nn.Dropout)):
+            handles.append(mod.register_forward_hook(hook))
+    return handles
+
+
+def fwd_bwd(model, inputs, out_weight_seed=123):
+    """Forward + backward of sum(out * w) with a fixed random w; returns output and grads."""
+    for p in model.parameters():
+        p.grad = None
+    out = model(*inputs)
+    g = torch.Generator().manual_seed(out_weight_seed)
+    w = torch.randn(out.shape, generator=g)
+    (out * w).sum().backward()
+    return out.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def compare_fwd_bwd(ref_model, orc_model, inputs, what, in_grad=False):
+    ins_r = [t.clone().requires_grad_(in_grad) for t in inputs]
+    ins_o = [t.clone().requires_grad_(in_grad) for t in inputs]
+    masks = []
+    hs = hook_masks(ref_model, masks)
+    seed_all(7)
+    out_r, g_r = fwd_bwd(ref_model, ins_r)
+    for h in hs:
+        h.remove()
+    with M.feed_masks(masks=[m.numpy() for m in masks]):
+        out_o, g_o = fwd_bwd(orc_model, ins_o)
+    assert torch.equal(out_r, out_o), "%s: forward differs (max %g)" % (what, (out_r - out_o).abs().max())
+    assert g_r.keys() == g_o.keys(), "%s: grad key sets differ" % what
+    for k in g_r:
+        assert torch.equal(g_r[k], g_o[k]), "%s: grad of %s differs" % (what, k)
+    if in_grad:
+        for a, b in zip(ins_r, ins_o):
+            assert torch.equal(a.grad, b.grad), "%s: input grad differs" % what
+    # BN running statistics / num_batches_tracked side effects
+    check_same_params(ref_model, orc_model, what + " (buffers after forward)")
+    return out_r, g_r, masks, [t.grad for t in ins_r] if in_grad else None
+
+
+def digest(t):
+    t = t.detach().double().flatten()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def head(t, n=16):
+    return t.detach().flatten()[:n].numpy().copy()
+
+
+def meta():
+    return np.array([torch.__version__, str(torch.backends.mkldnn.is_available()), "seed-init; see script"],
+                    dtype=object)
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    clean = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        clean[k] = np.asarray(v) if not (isinstance(v, np.ndarray) and v.dtype == object) else v.astype(str)
+    np.savez_compressed(path, **clean)
+    print("  wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def grads_digest(g):
+    keys = sorted(g)
+    return np.array(keys), np.stack([digest(g[k]) for k in keys]), np.stack(
+        [np.pad(head(g[k], 8), (0, 8 - min(8, g[k].numel()))) for k in keys])
+
+
+def masks_pack(masks):
+    return {"mask_%02d" % i: m.numpy() for i, m in enumerate(masks)}, len(masks)
+
+
+# ------------------------------------------------------------------------------------------- per-model pinning
+def pin_dcgan(ref):
+    print("dcgan (dcgan.py:36-99)")
+    ns = ref.dcgan(32)
+    G_r, G_o = built_equal(ns.Generator, lambda: M.DcganGenerator(32, 100, 1), "dcgan.G",
+                           post=(ns.weights_init_normal, M.init_normal_dcgan))
+    D_r, D_o = built_equal(ns.Discriminator, lambda: M.DcganDiscriminator(32, 1), "dcgan.D",
+                           post=(ns.weights_init_normal, M.init_normal_dcgan))
+    seed_all(1)
+    z = torch.tensor(np.random.normal(0, 1, (4, 100)), dtype=torch.float32)
+    img = torch.rand(4, 1, 32, 32) * 2 - 1
+    out_g, g_g, _, _ = compare_fwd_bwd(G_r, G_o, [z], "dcgan.G")
+    out_d, g_d, masks, gin = compare_fwd_bwd(D_r, D_o, [img], "dcgan.D", in_grad=True)
+    gk, gd, gh = grads_digest(g_g)
+    dk, dd, dh = grads_digest(g_d)
+    mp, nm = masks_pack(masks)
+    save("dcgan_32", meta=meta(), z=z, img=img, gen=out_g, d_out=out_d, d_in_grad=gin[0], g_keys=gk, g_digest=gd,
+         g_head=gh, d_keys=dk, d_digest=dd, d_head=dh, n_masks=nm,
+         g_bn_rm=G_r.state_dict()["conv_blocks.0.running_mean"], g_bn_rv=G_r.state_dict()["conv_blocks.3.running_var"],
+         **mp)
+
+
+def pin_mlp(ref):
+    print("wgan_gp (wgan_gp.py:42-83,119-138) and gan (gan.py:38-81)")
+    ns = ref.wgan_gp(32)
+    G_r, G_o = built_equal(ns.Generator, lambda: M.MlpGenerator((1, 32, 32), 100), "wgan_gp.G")
+    D_r, D_o = built_equal(ns.Discriminator, lambda: M.MlpCritic((1, 32, 32)), "wgan_gp.D")
+    seed_all(2)
+    z = torch.tensor(np.random.normal(0, 1, (8, 100)), dtype=torch.float32)
+    real = torch.rand(8, 1, 32, 32) * 2 - 1
+    out_g, g_g, _, _ = compare_fwd_bwd(G_r, G_o, [z], "wgan_gp.G")
+    out_d, g_d, _, _ = compare_fwd_bwd(D_r, D_o, [real], "wgan_gp.D")
+    # gradient penalty: reference function (draws alpha from np.random) vs oracle with the same alpha
+    fake = out_g.detach()
+    np.random.seed(5)
+    for p in D_r.parameters():
+        p.grad = None
+    gp_r = ns.compute_gradient_penalty(D_r, real, fake)
+    gp_r.backward()
+    np.random.seed(5)
+    alpha = torch.tensor(np.random.random((8, 1, 1, 1)), dtype=torch.float32)
+    for p in D_o.parameters():
+        p.grad = None
+    gp_o = S.gradient_penalty(D_o, real, fake, alpha)
+    gp_o.backward()
+    assert torch.equal(gp_r, gp_o), "gradient penalty value differs"
+    gp_grads = {}
+    for (k, a), (_, b) in zip(D_r.named_parameters(), D_o.named_parameters()):
+        assert (a.grad is None) == (b.grad is None), k
+        if a.grad is not None:
+            assert torch.equal(a.grad, b.grad), "gradient-penalty grad of %s differs" % k
+            gp_grads[k] = a.grad.clone()
+    gk, gd, gh = grads_digest(g_g)
+    dk, dd, dh = grads_digest(g_d)
+    pk, pd, ph = grads_digest(gp_grads)
+    save("wgan_gp_32", meta=meta(), z=z, real=real, gen=out_g, d_out=out_d, alpha=alpha, gp=gp_r.detach(), g_keys=gk,
+         g_digest=gd, g_head=gh, d_keys=dk, d_digest=dd, d_head=dh, gp_keys=pk, gp_digest=pd, gp_head=ph)
+
+    ns = ref.gan(28)
+    G_r, G_o = built_equal(ns.Generator, lambda: M.MlpGenerator((1, 28, 28), 100), "gan.G")
+    D_r, D_o = built_equal(ns.Discriminator, lambda: M.MlpCritic((1, 28, 28), sigmoid=True), "gan.D")
+    seed_all(3)
+    z = torch.tensor(np.random.normal(0, 1, (8, 100)), dtype=torch.float32)
+    out_g, g_g, _, _ = compare_fwd_bwd(G_r, G_o, [z], "gan.G")
+    out_d, g_d, _, _ = compare_fwd_bwd(D_r, D_o, [out_g], "gan.D")
+    gk, gd, gh = grads_digest(g_g)
+    save("gan_28", meta=meta(), z=z, gen=out_g, d_out=out_d, g_keys=gk, g_digest=gd, g_head=gh)
+
+
+def pin_cyclegan(ref):
+    print("cyclegan (cyclegan/models.py:6-122, utils.py:13-44)")
+    shape = (3, 32, 32)
+    G_r, G_o = built_equal(lambda: ref.cyclegan.GeneratorResNet(shape, 3), lambda: M.CycleGenerator(shape, 3),
+                           "cyclegan.G", post=(ref.cyclegan.weights_init_normal, M.init_normal_cyclegan))
+    D_r, D_o = built_equal(lambda: ref.cyclegan.Discriminator(shape), lambda: M.CycleDiscriminator(shape),
+                           "cyclegan.D", post=(ref.cyclegan.weights_init_normal, M.init_normal_cyclegan))
+    assert D_r.output_shape == D_o.output_shape
+    seed_all(4)
+    x = torch.rand(2, *shape) * 2 - 1
+    out_g, g_g, _, gin = compare_fwd_bwd(G_r, G_o, [x], "cyclegan.G", in_grad=True)
+    out_d, g_d, _, din = compare_fwd_bwd(D_r, D_o, [x], "cyclegan.D", in_grad=True)
+    # replay buffer + LR lambda (host-side index logic: bit-exact)
+    random.seed(11)
+    br, bo = ref.cyclegan_utils.ReplayBuffer(max_size=3), M.ReplayBuffer(max_size=3)
+    picks = []
+    for i in range(6):
+        batch = torch.full((2, 1, 2, 2), float(i)) + torch.tensor([0.0, 0.5]).view(2, 1, 1, 1)
+        st = random.getstate()
+        a = br.push_and_pop(batch)
+        random.setstate(st)
+        b = bo.push_and_pop(batch)
+        assert torch.equal(a, b), "ReplayBuffer differs"
+        picks.append(a[:, 0, 0, 0].numpy().copy())
+    lr_r = ref.cyclegan_utils.LambdaLR(200, 0, 100).step
+    lr_o = M.lambda_lr(200, 0, 100)
+    lrs = []
+    for e in (0, 50, 100, 101, 150, 199):
+        assert lr_r(e) == lr_o(e)
+        lrs.append(lr_o(e))
+    gk, gd, gh = grads_digest(g_g)
+    dk, dd, dh = grads_digest(g_d)
+    save("cyclegan_32", meta=meta(), x=x, gen=out_g, d_out=out_d, g_in_grad=gin[0], d_in_grad=din[0], g_keys=gk,
+         g_digest=gd, g_head=gh, d_keys=dk, d_digest=dd, d_head=dh, replay_picks=np.stack(picks),
+         lr_factors=np.array(lrs))
+
+
+def pin_pix2pix(ref):
+    print("pix2pix (pix2pix/models.py:6-133)")
+    G_r, G_o = built_equal(ref.pix2pix.GeneratorUNet, M.Pix2pixGenerator, "pix2pix.G",
+                           post=(ref.pix2pix.weights_init_normal, M.init_normal_dcgan))
+    D_r, D_o = built_equal(ref.pix2pix.Discriminator, M.Pix2pixDiscriminator, "pix2pix.D",
+                           post=(ref.pix2pix.weights_init_normal, M.init_normal_dcgan))
+    seed_all(5)
+    a = torch.rand(1, 3, 256, 256) * 2 - 1
+    b = torch.rand(1, 3, 256, 256) * 2 - 1
+    out_g, g_g, masks, _ = compare_fwd_bwd(G_r, G_o, [a], "pix2pix.G")
+    out_d, g_d, _, din = compare_fwd_bwd(D_r, D_o, [b, a], "pix2pix.D", in_grad=True)
+    gk, gd, gh = grads_digest(g_g)
+    dk, dd, dh = grads_digest(g_d)
+    # masks are large (elementwise): store the seed protocol instead of the masks; tests regenerate them by
+    # running the oracle with torch.manual_seed(7) (ElementDropout draws with torch.bernoulli -> recorded there)
+    save("pix2pix_256", meta=meta(), gen_digest=digest(out_g), gen_head=head(out_g, 64), d_out=out_d,
+         d_in_grad_digest=np.stack([digest(t) for t in din]), g_keys=gk, g_digest=gd, g_head=gh, d_keys=dk,
+         d_digest=dd, d_head=dh, mask_digest=np.stack([digest(m) for m in masks]))
+    return masks
+
+
+def pin_srgan(ref):
+    print("srgan (srgan/models.py:8-105; VGG19[:18] random-init via stub)")
+    G_r, G_o = built_equal(lambda: ref.srgan.GeneratorResNet(), lambda: M.SrganGenerator(), "srgan.G")
+    D_r, D_o = built_equal(lambda: ref.srgan.Discriminator(input_shape=(3, 32, 32)),
+                           lambda: M.SrganDiscriminator((3, 32, 32)), "srgan.D")
+    V_r, V_o = built_equal(lambda: ref.srgan.FeatureExtractor(), lambda: M.SrganFeatureExtractor(), "srgan.VGG")
+    assert D_r.output_shape == D_o.output_shape
+    seed_all(6)
+    lr = torch.randn(2, 3, 8, 8)
+    hr = torch.randn(2, 3, 32, 32)
+    out_g, g_g, _, _ = compare_fwd_bwd(G_r, G_o, [lr], "srgan.G")
+    out_d, g_d, _, din = compare_fwd_bwd(D_r, D_o, [hr], "srgan.D", in_grad=True)
+    V_r.eval()
+    V_o.eval()
+    out_v, g_v, _, vin = compare_fwd_bwd(V_r, V_o, [hr], "srgan.VGG", in_grad=True)
+    gk, gd, gh = grads_digest(g_g)
+    dk, dd, dh = grads_digest(g_d)
+    save("srgan_32", meta=meta(), lr=lr, hr=hr, gen=out_g, d_out=out_d, d_in_grad=din[0], vgg_digest=digest(out_v),
+         vgg_head=head(out_v, 64), vgg_in_grad=vin[0], g_keys=gk, g_digest=gd, g_head=gh, d_keys=dk, d_digest=dd,
+         d_head=dh)
+
+
+def pin_dropout_semantics():
+    print("dropout semantics (nn.Dropout2d / nn.Dropout vs injectable oracle layers)")
+    x = torch.rand(3, 5, 4, 4) + 0.5
+    for ref_cls, orc_cls in ((nn.Dropout2d, M.PlaneDropout), (nn.Dropout, M.ElementDropout)):
+        r, o = ref_cls(0.25), orc_cls(0.25)
+        masks = []
+        hs = hook_masks(r, masks)
+        torch.manual_seed(9)
+        y_r = r(x)
+        hs[0].remove()
+        with M.feed_masks(masks=[m.numpy() for m in masks]):
+            y_o = o(x)
+        assert torch.equal(y_r, y_o), "%s semantics differ" % ref_cls.__name__
+
+
+def pin_steps(ref):
+    """Loss traces of the restated loops driven with the REAL reference modules (3 steps each, tiny sizes)."""
+    print("loop traces (reference modules inside oracle.reference_steps)")
+    ns = ref.dcgan(32)
+    seed_all(0)
+    G, D = ns.Generator(), ns.Discriminator()
+    G.apply(ns.weights_init_normal)
+    D.apply(ns.weights_init_normal)
+    s_ref = SimpleNamespace(G=G, D=D, opt_G=S._adam(G.parameters()), opt_D=S._adam(D.parameters()),
+                            bce=torch.nn.BCELoss(), latent_dim=100)
+    seed_all(0)
+    s_orc = S.make_dcgan(32)
+    check_same_params(s_ref.G, s_orc.G, "dcgan loop G")
+    seed_all(21)
+    imgs = torch.rand(3, 8, 1, 32, 32) * 2 - 1
+    zs = torch.tensor(np.random.normal(0, 1, (3, 8, 100)), dtype=torch.float32)
+    trace, all_masks = [], []
+    for t in range(3):
+        masks = []
+        hs = hook_masks(s_ref.D, masks)
+        torch.manual_seed(100 + t)
+        o_r = S.dcgan_step(s_ref, imgs[t], zs[t])
+        for h in hs:
+            h.remove()
+        with M.feed_masks(masks=[m.numpy() for m in masks]):
+            o_o = S.dcgan_step(s_orc, imgs[t], zs[t])
+        assert torch.equal(o_r["g_loss"], o_o["g_loss"]) and torch.equal(o_r["d_loss"], o_o["d_loss"]), "dcgan loop"
+        trace.append([o_r["g_loss"].item(), o_r["d_loss"].item()])
+        all_masks.append(masks)
+    check_same_params(s_ref.G, s_orc.G, "dcgan loop G after 3 steps")
+    check_same_params(s_ref.D, s_orc.D, "dcgan loop D after 3 steps")
+    mp = {"mask_%d_%02d" % (t, i): m.numpy() for t, ms in enumerate(all_masks) for i, m in enumerate(ms)}
+    sd = s_ref.G.state_dict()
+    save("dcgan_32_loop", meta=meta(), imgs=imgs, zs=zs, trace=np.array(trace), masks_per_step=len(all_masks[0]),
+         g_final_digest=np.stack([digest(v.float()) for v in sd.values()]), g_final_keys=np.array(list(sd.keys())),
+         **mp)
+
+    ns = ref.wgan_gp(32)
+    seed_all(0)
+    G, D = ns.Generator(), ns.Discriminator()
+    s_ref = SimpleNamespace(G=G, D=D, opt_G=S._adam(G.parameters()), opt_D=S._adam(D.parameters()), latent_dim=100,
+                            lambda_gp=10, n_critic=5)
+    seed_all(0)
+    s_orc = S.make_wgan_gp(32)
+    seed_all(22)
+    reals = torch.rand(6, 8, 1, 32, 32) * 2 - 1
+    zs = torch.tensor(np.random.normal(0, 1, (6, 8, 100)), dtype=torch.float32)
+    alphas = torch.tensor(np.random.random((6, 8, 1, 1, 1)), dtype=torch.float32)
+    trace = []
+    for i in range(6):
+        o_r = S.wgan_gp_step(s_ref, reals[i], i, zs[i], alphas[i])
+        o_o = S.wgan_gp_step(s_orc, reals[i], i, zs[i], alphas[i])
+        assert torch.equal(o_r["d_loss"], o_o["d_loss"]), "wgan_gp loop"
+        trace.append([o_r["d_loss"].item(), o_r["gp"].item(), o_r.get("g_loss", torch.tensor(float("nan"))).item()])
+    check_same_params(s_ref.D, s_orc.D, "wgan_gp loop D after 6 iterations")
+    check_same_params(s_ref.G, s_orc.G, "wgan_gp loop G after 6 iterations")
+    sd = s_ref.D.state_dict()
+    save("wgan_gp_32_loop", meta=meta(), reals=reals, zs=zs, alphas=alphas, trace=np.array(trace),
+         d_final_digest=np.stack([digest(v.float()) for v in sd.values()]), d_final_keys=np.array(list(sd.keys())))
+
+    shape = (3, 32, 32)
+    seed_all(0)
+    nets = [ref.cyclegan.GeneratorResNet(shape, 2), ref.cyclegan.GeneratorResNet(shape, 2),
+            ref.cyclegan.Discriminator(shape), ref.cyclegan.Discriminator(shape)]
+    for n_ in nets:
+        n_.apply(ref.cyclegan.weights_init_normal)
+    import itertools
+    s_ref = SimpleNamespace(
+        G_AB=nets[0], G_BA=nets[1], D_A=nets[2], D_B=nets[3],
+        opt_G=S._adam(itertools.chain(nets[0].parameters(), nets[1].parameters())), opt_D_A=S._adam(nets[2].parameters()),
+        opt_D_B=S._adam(nets[3].parameters()), mse=torch.nn.MSELoss(), l1_cycle=torch.nn.L1Loss(),
+        l1_id=torch.nn.L1Loss(), buf_A=ref.cyclegan_utils.ReplayBuffer(), buf_B=ref.cyclegan_utils.ReplayBuffer(),
+        lambda_cyc=10.0, lambda_id=5.0)
+    seed_all(0)
+    s_orc = S.make_cyclegan(shape, 2)
+    seed_all(23)
+    A = torch.rand(3, 2, *shape) * 2 - 1
+    Bt = torch.rand(3, 2, *shape) * 2 - 1
+    trace = []
+    for t in range(3):
+        random.seed(50 + t)
+        o_r = S.cyclegan_step(s_ref, A[t], Bt[t])
+        random.seed(50 + t)
+        o_o = S.cyclegan_step(s_orc, A[t], Bt[t])
+        for k in o_r:
+            assert torch.equal(o_r[k], o_o[k]), "cyclegan loop %s" % k
+        trace.append([o_r[k].item() for k in ("loss_G", "loss_D", "loss_GAN", "loss_cycle", "loss_identity")])
+    check_same_params(s_ref.G_AB, s_orc.G_AB, "cyclegan loop G_AB after 3 steps")
+    save("cyclegan_32_loop", meta=meta(), A=A, B=Bt, trace=np.array(trace))
+
+
+def main():
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    torch.use_deterministic_algorithms(False)
+    ref = load_reference()
+    pin_dropout_semantics()
+    pin_dcgan(ref)
+    pin_mlp(ref)
+    pin_cyclegan(ref)
+    pin_srgan(ref)
+    pin_pix2pix(ref)
+    pin_steps(ref)
+    print("oracle pinned against the reference; fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+"""ORACLE (test infrastructure): CPU restatement of the reference training-loop bodies.
+
+Each `*_step` executes exactly one iteration of the corresponding script's inner loop on stock torch
+(forward, losses, backward, Adam), with the host RNG draws (`np.random`, `random`) in the reference's
+order, and without the logging / image-saving side effects.  Line references:
+  gan_step        implementations/gan/gan.py:121-161
+  dcgan_step      implementations/dcgan/dcgan.py:143-183
+  wgan_gp_step    implementations/wgan_gp/wgan_gp.py:119-138,146-193
+  cyclegan_step   implementations/cyclegan/cyclegan.py:159-239
+  pix2pix_step    implementations/pix2pix/pix2pix.py:123-172
+  srgan_step      implementations/srgan/srgan.py:97-145
+Pinned against the reference by oracle/pin_against_reference.py.
+"""
+import itertools
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import autograd
+
+from . import reference_models as M
+
+ADAM = dict(lr=2e-4, betas=(0.5, 0.999))  # every script's argparse defaults (dcgan.py:22-24)
+
+
+def _adam(params):
+    return torch.optim.Adam(params, **ADAM)
+
+
+def _f32(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32)  # Tensor(np.float64 array) -> fp32 (dcgan.py:160)
+
+
+# ------------------------------------------------------------------------------------------------ gan / dcgan
+def make_gan(img_size=28, latent_dim=100, channels=1):
+    shape = (channels, img_size, img_size)
+    G, D = M.MlpGenerator(shape, latent_dim), M.MlpCritic(shape, sigmoid=True)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()),
+                           bce=torch.nn.BCELoss(), latent_dim=latent_dim)
+
+
+def make_dcgan(img_size=32, latent_dim=100, channels=1):
+    G, D = M.DcganGenerator(img_size, latent_dim, channels), M.DcganDiscriminator(img_size, channels)
+    G.apply(M.init_normal_dcgan)
+    D.apply(M.init_normal_dcgan)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()),
+                           bce=torch.nn.BCELoss(), latent_dim=latent_dim)
+
+
+def dcgan_step(s, real_imgs, z=None):
+    """One generator + one discriminator update (also the gan.py loop body)."""
+    B = real_imgs.shape[0]
+    valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+    s.opt_G.zero_grad()
+    if z is None:
+        z = _f32(np.random.normal(0, 1, (B, s.latent_dim)))
+    gen = s.G(z)
+    g_loss = s.bce(s.D(gen), valid)
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    d_loss = (s.bce(s.D(real_imgs), valid) + s.bce(s.D(gen.detach()), fake)) / 2
+    d_loss.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+gan_step = dcgan_step
+
+
+# ------------------------------------------------------------------------------------------------ wgan_gp
+def make_wgan_gp(img_size=32, latent_dim=100, channels=1):
+    shape = (channels, img_size, img_size)
+    G, D = M.MlpGenerator(shape, latent_dim), M.MlpCritic(shape)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()),
+                           latent_dim=latent_dim, lambda_gp=10, n_critic=5)
+
+
+def gradient_penalty(D, real, fake, alpha=None):
+    B = real.size(0)
+    if alpha is None:
+        alpha = _f32(np.random.random((B, 1, 1, 1)))
+    mix = (alpha * real + ((1 - alpha) * fake)).requires_grad_(True)
+    out = D(mix)
+    grads = autograd.grad(outputs=out, inputs=mix, grad_outputs=torch.ones(B, 1), create_graph=True,
+                          retain_graph=True, only_inputs=True)[0]
+    grads = grads.view(B, -1)
+    return ((grads.norm(2, dim=1) - 1) ** 2).mean()
+
+
+def wgan_gp_step(s, real_imgs, i, z=None, alpha=None):
+    """Critic iteration i; the generator is updated when i % n_critic == 0 (same z)."""
+    B = real_imgs.shape[0]
+    s.opt_D.zero_grad()
+    if z is None:
+        z = _f32(np.random.normal(0, 1, (B, s.latent_dim)))
+    fake_imgs = s.G(z)
+    real_v, fake_v = s.D(real_imgs), s.D(fake_imgs)
+    gp = gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
+    d_loss = -torch.mean(real_v) + torch.mean(fake_v) + s.lambda_gp * gp
+    d_loss.backward()
+    s.opt_D.step()
+    s.opt_G.zero_grad()
+    out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
+    if i % s.n_critic == 0:
+        fake_imgs = s.G(z)
+        g_loss = -torch.mean(s.D(fake_imgs))
+        g_loss.backward()
+        s.opt_G.step()
+        out["g_loss"] = g_loss.detach()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ cyclegan
+def make_cyclegan(shape=(3, 64, 64), n_res=9):
+    G_AB, G_BA = M.CycleGenerator(shape, n_res), M.CycleGenerator(shape, n_res)
+    D_A, D_B = M.CycleDiscriminator(shape), M.CycleDiscriminator(shape)
+    for net in (G_AB, G_BA, D_A, D_B):
+        net.apply(M.init_normal_cyclegan)
+    return SimpleNamespace(
+        G_AB=G_AB, G_BA=G_BA, D_A=D_A, D_B=D_B,
+        opt_G=_adam(itertools.chain(G_AB.parameters(), G_BA.parameters())), opt_D_A=_adam(D_A.parameters()),
+        opt_D_B=_adam(D_B.parameters()), mse=torch.nn.MSELoss(), l1_cycle=torch.nn.L1Loss(),
+        l1_id=torch.nn.L1Loss(), buf_A=M.ReplayBuffer(), buf_B=M.ReplayBuffer(), lambda_cyc=10.0, lambda_id=5.0)
+
+
+def cyclegan_step(s, real_A, real_B):
+    B = real_A.size(0)
+    valid = _f32(np.ones((B, *s.D_A.output_shape)))
+    fake = _f32(np.zeros((B, *s.D_A.output_shape)))
+    s.G_AB.train()
+    s.G_BA.train()
+    s.opt_G.zero_grad()
+    loss_id = (s.l1_id(s.G_BA(real_A), real_A) + s.l1_id(s.G_AB(real_B), real_B)) / 2
+    fake_B = s.G_AB(real_A)
+    loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+    fake_A = s.G_BA(real_B)
+    loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+    loss_GAN = (loss_GAN_AB + loss_GAN_BA) / 2
+    loss_cycle = (s.l1_cycle(s.G_BA(fake_B), real_A) + s.l1_cycle(s.G_AB(fake_A), real_B)) / 2
+    loss_G = loss_GAN + s.lambda_cyc * loss_cycle + s.lambda_id * loss_id
+    loss_G.backward()
+    s.opt_G.step()
+
+    s.opt_D_A.zero_grad()
+    fake_A_ = s.buf_A.push_and_pop(fake_A)
+    loss_D_A = (s.mse(s.D_A(real_A), valid) + s.mse(s.D_A(fake_A_.detach()), fake)) / 2
+    loss_D_A.backward()
+    s.opt_D_A.step()
+
+    s.opt_D_B.zero_grad()
+    fake_B_ = s.buf_B.push_and_pop(fake_B)
+    loss_D_B = (s.mse(s.D_B(real_B), valid) + s.mse(s.D_B(fake_B_.detach()), fake)) / 2
+    loss_D_B.backward()
+    s.opt_D_B.step()
+    return {"loss_G": loss_G.detach(), "loss_D": ((loss_D_A + loss_D_B) / 2).detach(), "loss_GAN": loss_GAN.detach(),
+            "loss_cycle": loss_cycle.detach(), "loss_identity": loss_id.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ pix2pix
+def make_pix2pix(img_size=256):
+    G, D = M.Pix2pixGenerator(), M.Pix2pixDiscriminator()
+    G.apply(M.init_normal_dcgan)
+    D.apply(M.init_normal_dcgan)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()),
+                           mse=torch.nn.MSELoss(), l1=torch.nn.L1Loss(), lambda_pixel=100,
+                           patch=(1, img_size // 16, img_size // 16))
+
+
+def pix2pix_step(s, real_A, real_B):
+    """real_A = batch["B"], real_B = batch["A"] in the script (pix2pix.py:127-128); here: condition, target."""
+    B = real_A.size(0)
+    valid, fake = _f32(np.ones((B, *s.patch))), _f32(np.zeros((B, *s.patch)))
+    s.opt_G.zero_grad()
+    fake_B = s.G(real_A)
+    loss_GAN = s.mse(s.D(fake_B, real_A), valid)
+    loss_pixel = s.l1(fake_B, real_B)
+    loss_G = loss_GAN + s.lambda_pixel * loss_pixel
+    loss_G.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    loss_D = 0.5 * (s.mse(s.D(real_B, real_A), valid) + s.mse(s.D(fake_B.detach(), real_A), fake))
+    loss_D.backward()
+    s.opt_D.step()
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_pixel": loss_pixel.detach(),
+            "loss_GAN": loss_GAN.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ srgan
+def make_srgan(hr_shape=(96, 96), n_res=16):
+    G = M.SrganGenerator(n_residual_blocks=n_res)
+    D = M.SrganDiscriminator(input_shape=(3, *hr_shape))
+    V = M.SrganFeatureExtractor()
+    V.eval()
+    return SimpleNamespace(G=G, D=D, V=V, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()),
+                           mse=torch.nn.MSELoss(), l1=torch.nn.L1Loss())
+
+
+def srgan_step(s, imgs_lr, imgs_hr):
+    B = imgs_lr.size(0)
+    valid = _f32(np.ones((B, *s.D.output_shape)))
+    fake = _f32(np.zeros((B, *s.D.output_shape)))
+    s.opt_G.zero_grad()
+    gen_hr = s.G(imgs_lr)
+    loss_GAN = s.mse(s.D(gen_hr), valid)
+    loss_content = s.l1(s.V(gen_hr), s.V(imgs_hr).detach())
+    loss_G = loss_content + 1e-3 * loss_GAN
+    loss_G.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    loss_D = (s.mse(s.D(imgs_hr), valid) + s.mse(s.D(gen_hr.detach()), fake)) / 2
+    loss_D.backward()
+    s.opt_D.step()
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
+            "loss_GAN": loss_GAN.detach()}

@@ -1,0 +1,107 @@
+"""ctypes binding of libmigan.so (include/migan.h).
+
+There is NO fallback: if the HIP library cannot be built or loaded, importing this module raises.
+torch must be imported first so that libmigan.so binds to the SAME libamdhip64.so.7 instance that torch
+uses (streams and device pointers are only meaningful inside one HIP runtime); this is verified below.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_ulonglong, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL load, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_CSRC, "libmigan.so")
+
+
+def _ensure_built():
+    if os.path.exists(LIB_PATH) and not os.environ.get("MIGAN_REBUILD"):
+        return
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_migan_build", os.path.join(_CSRC, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build(force=bool(os.environ.get("MIGAN_REBUILD")), verbose=False)
+
+
+def _hip_runtime_copies():
+    seen = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    seen.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return seen
+
+
+_ensure_built()
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libmigan.so is missing and could not be built (%s)" % LIB_PATH)
+lib = ctypes.CDLL(LIB_PATH)
+_copies = _hip_runtime_copies()
+if len(_copies) > 1:
+    raise ImportError(
+        "two HIP runtimes are mapped in this process (%s): libmigan.so must share torch's libamdhip64; "
+        "import torch before pytorch_gan_amd" % sorted(_copies)
+    )
+
+P = c_void_p
+_SIGS = {
+    "migan_version": (c_char_p, []),
+    "migan_error_string": (c_char_p, [c_int]),
+    "migan_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 14 + [c_float, P]),
+    "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
+    "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
+    "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 13 + [P]),
+    "migan_norm_workspace": (c_size_t, [c_int] * 3),
+    "migan_norm_stats": (c_int, [P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, P, c_size_t, P]),
+    "migan_norm_apply": (c_int, [P] * 7 + [c_int] * 4 + [c_float, P]),
+    "migan_norm_bwd": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, P]),
+    "migan_act_fwd": (c_int, [P, P, c_size_t, c_int, c_float, P]),
+    "migan_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "migan_reduce_workspace": (c_size_t, []),
+    "migan_prelu_fwd": (c_int, [P, P, P, c_size_t, P]),
+    "migan_prelu_bwd": (c_int, [P, P, P, P, P, P, c_size_t, P]),
+    "migan_axpby": (c_int, [P, c_float, P, c_float, P, c_size_t, P]),
+    "migan_mul": (c_int, [P, P, P, c_size_t, P]),
+    "migan_mul_nc": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "migan_rand_mask": (c_int, [P, c_size_t, c_float, c_ulonglong, P, P]),
+    "migan_gather2d_fwd": (c_int, [P, P] + [c_int] * 9 + [P]),
+    "migan_gather2d_bwd": (c_int, [P, P] + [c_int] * 9 + [P]),
+    "migan_pixel_shuffle": (c_int, [P, P] + [c_int] * 6 + [P]),
+    "migan_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
+    "migan_maxpool2_bwd": (c_int, [P, P, P] + [c_int] * 4 + [P]),
+    "migan_cat_channels": (c_int, [P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "migan_transpose_batched": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "migan_permute4d": (c_int, [P, P] + [c_int] * 8 + [P]),
+    "migan_colsum_workspace": (c_size_t, [c_size_t, c_int]),
+    "migan_colsum": (c_int, [P, P, c_size_t, c_int, P, c_size_t, P]),
+    "migan_loss_fwd": (c_int, [c_int, P, P, c_float, P, c_size_t, P, c_size_t, P]),
+    "migan_loss_bwd": (c_int, [c_int, P, P, c_float, P, P, c_size_t, P]),
+    "migan_rownorm_fwd": (c_int, [P, P, c_int, c_int, P]),
+    "migan_rownorm_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
+    "migan_rowscale": (c_int, [P, P, P, c_int, c_int, P]),
+    "migan_rowdot": (c_int, [P, P, P, c_int, c_int, P]),
+    "migan_adam_chunk": (c_int, []),
+    "migan_adam_step": (c_int, [P, P, c_int, P, c_float, c_float, c_float, c_float, c_float, P]),
+    "migan_pack": (c_int, [P, P, c_int, P, c_int, c_float, P]),
+}
+EXPORTS = sorted(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here == header/library drift: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib.migan_error_string(int(code))
+        raise RuntimeError("libmigan %s failed: hipError %d (%s)" % (what, code, msg.decode() if msg else "?"))
+
+
+def version():
+    return lib.migan_version().decode()

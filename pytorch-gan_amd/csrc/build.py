@@ -1,0 +1,65 @@
+"""Build libmigan.so in-tree with plain hipcc for gfx950 (no torch headers, no cmake).
+
+    python pytorch-gan_amd/csrc/build.py [--force]
+
+The library has a pure C ABI (include/migan.h), so it is independent of the torch wheel's ROCm version;
+it only needs libamdhip64.so.7, which at run time resolves to the copy torch already loaded.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["conv_igemm.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip"]
+HEADERS = ["common.h"]
+OUT = os.path.join(HERE, "libmigan.so")
+STAMP = os.path.join(HERE, ".libmigan.stamp")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + ["build.py"]:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return OUT
+    if not os.path.exists(HIPCC):
+        if os.path.exists(OUT):
+            # No compiler on this box (e.g. a GPU runner without ROCm dev tools): use the shipped binary.
+            return OUT
+        raise RuntimeError("hipcc not found at %s and no prebuilt libmigan.so present" % HIPCC)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s" % src)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,59 @@
+// Shared device/host helpers for the migan HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define MIGAN_API extern "C" __attribute__((visibility("default")))
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Activation codes shared by every launcher (see include/migan.h).
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };
+// Gather modes of the implicit-GEMM loaders and of gather2d.
+enum { GATHER_ZERO = 0, GATHER_REFLECT = 1, GATHER_UP2 = 2 };
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case ACT_LRELU: return v > 0.f ? v : v * slope;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_TANH: return tanhf(v);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// d(act)/d(pre) expressed with the activation OUTPUT y (valid for all codes above;
+// LeakyReLU/ReLU: sign(y) == sign(pre) because slope >= 0).
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+    switch (act) {
+        case ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_TANH: return 1.f - y * y;
+        case ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+// Logical -> physical coordinate of the gather. v is a coordinate in the logical
+// (padded-free) extent L. Returns false when the tap reads a zero.
+__device__ __forceinline__ bool map_coord(int v, int L, int mode, int& src) {
+    if (mode == GATHER_REFLECT) {
+        if (v < 0) v = -v;
+        if (v >= L) v = 2 * L - 2 - v;
+        src = v;
+        return true;
+    }
+    if ((unsigned)v >= (unsigned)L) return false;
+    src = (mode == GATHER_UP2) ? (v >> 1) : v;
+    return true;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define HIP_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)

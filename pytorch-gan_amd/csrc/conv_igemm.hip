@@ -1,0 +1,636 @@
+// Tap-list implicit-GEMM convolution on the gfx950 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), NHWC activations, OHWI-style packed weights.
+//
+// One kernel family covers (reference call sites in SURVEY.md §2.3 / §8a K1-K3):
+//   * Conv2d forward            (dcgan.py:55,59,62,78; cyclegan/models.py:50,60,75,106;
+//                                pix2pix/models.py:23,115; srgan/models.py:22,38,54,62,85)
+//   * Conv2d dgrad == ConvTranspose2d forward (pix2pix/models.py:39), by stride-parity classes
+//   * Linear forward/dgrad      (1x1 "conv" on an (N,1,1,K) tensor; dcgan.py:50,92, wgan_gp.py:46-78)
+//   * Conv2d/Linear wgrad       (split-K over pixels, deterministic two-pass reduction)
+//
+// GEMM view (forward): M = N*Ho*Wo output pixels, N = Co, K = taps*Ci.  The A operand is never
+// materialised: every K-tile is gathered from the NHWC source through a per-tap (dh,dw) offset and
+// a coordinate map (zero pad / reflection pad / nearest-upsample x2), so ReflectionPad2d,
+// ZeroPad2d and Upsample(2) in front of a conv cost no HBM traffic.
+//
+// LDS image: both operand tiles are stored [k][row] (row contiguous, +1/+4 padded) and the MFMA
+// fragments are read with conflict-free ds_read_b32 (lanes 0-31 = 32 consecutive rows at k=2kp,
+// lanes 32-63 the same rows at k=2kp+1).  An fp32 MFMA occupies its SIMD for 64 cycles, so one
+// b32 read per operand per MFMA is far below the LDS issue budget (MI355X_MICROARCH.md §LDS).
+#include "common.h"
+
+#define MAX_TAPS 96
+#define MAX_CLS 4
+
+struct ConvGeom {
+    int N, Hi, Wi, Ci;   // physical source tensor (NHWC)
+    int HiL, WiL;        // logical gather extent (2*Hi for GATHER_UP2)
+    int Co;              // GEMM N
+    int HoF, WoF;        // full output extent
+    int ostep, istride;  // output sub-grid step (parity classes), source step per output index
+    int gather, ldw, ncls;
+    int act;
+    float slope;
+    int oh0[MAX_CLS], ow0[MAX_CLS], Ho[MAX_CLS], Wo[MAX_CLS], tapbeg[MAX_CLS], ntap[MAX_CLS];
+    int wofs[MAX_TAPS];
+    signed char dh[MAX_TAPS], dw[MAX_TAPS];
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
+__global__ __launch_bounds__(256) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
+                                                    const float* __restrict__ Bw,
+                                                    const float* __restrict__ bias,
+                                                    float* __restrict__ C) {
+    constexpr int BK = 32;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    constexpr int SM_A = BK * LDA, SM_B = BK * LDB;
+    __shared__ __attribute__((aligned(16))) int smem_i[SM_A + SM_B + 3 * MAX_TAPS + 3 * BM];
+    float* As = reinterpret_cast<float*>(smem_i);
+    float* Bs = As + SM_A;
+    int* s_wofs = smem_i + SM_A + SM_B;
+    int* s_dh = s_wofs + MAX_TAPS;
+    int* s_dw = s_dh + MAX_TAPS;
+    int* r_base = s_dw + MAX_TAPS;
+    int* r_ih = r_base + BM;
+    int* r_iw = r_ih + BM;
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int M = g.N * Ho * Wo;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int n0 = blockIdx.y * BN;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi;
+
+    for (int i = tid; i < ntap; i += 256) {
+        s_wofs[i] = g.wofs[tapbeg + i];
+        s_dh[i] = g.dh[tapbeg + i];
+        s_dw[i] = g.dw[tapbeg + i];
+    }
+    if (!FAST) {
+        for (int r = tid; r < BM; r += 256) {
+            int m = m0 + r;
+            int base = -1, ih = 0, iw = 0;
+            if (m < M) {
+                int n = m / (Ho * Wo);
+                int rem = m - n * Ho * Wo;
+                int oi = rem / Wo, oj = rem - oi * Wo;
+                base = n * Hi * Wi;
+                ih = oi * g.istride;
+                iw = oj * g.istride;
+            }
+            r_base[r] = base;
+            r_ih[r] = ih;
+            r_iw[r] = iw;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int KT;
+    if (FAST) KT = ntap * (Ci >> 5);
+    else KT = (ntap * Ci + BK - 1) / BK;
+
+    // ---------------- staging state ----------------
+    constexpr int NA = FAST ? BM / 32 : BM / 8;
+    constexpr int NB = FAST ? BN / 32 : BN / 8;
+    f32x4 ra4[FAST ? NA : 1], rb4[FAST ? NB : 1];
+    float ra1[FAST ? 1 : NA], rb1[FAST ? 1 : NB];
+    // FAST: thread owns k-quad kq of rows (tid>>3)+32j.   GENERIC: thread owns k = tid&31 of rows (tid>>5)+8j.
+    const int kq = tid & 7, frow = tid >> 3;
+    const int gk = tid & 31, grow = tid >> 5;
+    int a_base[FAST ? NA : 1], a_ih[FAST ? NA : 1], a_iw[FAST ? NA : 1];
+    unsigned avalid = 0;
+    if (FAST) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int m = m0 + frow + 32 * j;
+            a_base[j] = 0; a_ih[j] = 0; a_iw[j] = 0;
+            if (m < M) {
+                int n = m / (Ho * Wo);
+                int rem = m - n * Ho * Wo;
+                int oi = rem / Wo, oj = rem - oi * Wo;
+                a_base[j] = n * Hi * Wi;
+                a_ih[j] = oi * g.istride;
+                a_iw[j] = oj * g.istride;
+                avalid |= 1u << j;
+            }
+        }
+    }
+    const int tpt = Ci >> 5;  // FAST: K-tiles per tap
+
+    auto load_tile = [&](int kt) {
+        if (FAST) {
+            int t = kt / tpt;
+            int c0 = (kt - t * tpt) << 5;
+            int dh = s_dh[t], dw = s_dw[t], wo = s_wofs[t];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                int ihs, iws;
+                if (((avalid >> j) & 1u) && map_coord(a_ih[j] + dh, g.HiL, g.gather, ihs) &&
+                    map_coord(a_iw[j] + dw, g.WiL, g.gather, iws)) {
+                    const float* p = A + (size_t)(a_base[j] + ihs * Wi + iws) * Ci + c0 + kq * 4;
+                    v = *reinterpret_cast<const f32x4*>(p);
+                }
+                ra4[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                int n = n0 + frow + 32 * j;
+                if (n < g.Co) {
+                    const float* p = Bw + (size_t)n * g.ldw + wo + c0 + kq * 4;
+                    v = *reinterpret_cast<const f32x4*>(p);
+                }
+                rb4[j] = v;
+            }
+        } else {
+            int k = kt * BK + gk;
+            bool kval = k < ntap * Ci;
+            int t = kval ? k / Ci : 0;
+            int c = k - t * Ci;
+            int dh = s_dh[t], dw = s_dw[t], wo = s_wofs[t];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                int r = grow + 8 * j;
+                float v = 0.f;
+                int base = r_base[r];
+                int ihs, iws;
+                if (kval && base >= 0 && map_coord(r_ih[r] + dh, g.HiL, g.gather, ihs) &&
+                    map_coord(r_iw[r] + dw, g.WiL, g.gather, iws)) {
+                    v = A[(size_t)(base + ihs * Wi + iws) * Ci + c];
+                }
+                ra1[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int n = n0 + grow + 8 * j;
+                float v = 0.f;
+                if (kval && n < g.Co) v = Bw[(size_t)n * g.ldw + wo + c];
+                rb1[j] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if (FAST) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[(kq * 4 + e) * LDA + frow + 32 * j] = ra4[j][e];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[(kq * 4 + e) * LDB + frow + 32 * j] = rb4[j][e];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) As[gk * LDA + grow + 8 * j] = ra1[j];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) Bs[gk * LDB + grow + 8 * j] = rb1[j];
+        }
+    };
+
+    if (KT > 0) load_tile(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* ap = As + h * LDA + wm * (TM * 32) + l31;
+        const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---------------- epilogue: bias + activation + NHWC store ----------------
+    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int m = m0 + row;
+            if (m >= M) continue;
+            size_t opix;
+            if (linear_out) {
+                opix = (size_t)m;
+            } else {
+                int n = m / (Ho * Wo);
+                int rem = m - n * Ho * Wo;
+                int oi = rem / Wo, oj = rem - oi * Wo;
+                opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < g.Co) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[col];
+                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                      hipStream_t st) {
+    int maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        int m = g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return 0;
+    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, FAST>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                        hipStream_t st) {
+    bool fast = (g.Ci % 32 == 0) && (g.ldw % 4 == 0);
+    for (int t = 0; fast && t < MAX_TAPS; ++t) fast = (g.wofs[t] % 4 == 0);
+    long maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        long m = (long)g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+    }
+    if (fast) {
+        if (g.Co > 64) {
+            long blocks = (long)cdiv(maxM, 128) * cdiv(g.Co, 128) * g.ncls;
+            if (blocks < 384) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
+        }
+        if (g.Co > 32) {
+            long blocks = (long)cdiv(maxM, 128) * g.ncls;
+            if (blocks < 384) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+        }
+        return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+    }
+    if (g.Co > 64) return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
+    if (g.Co > 32) return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
+    return launch_cfg<128, 32, 4, 1, false>(g, A, Bw, bias, C, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: forward
+// ------------------------------------------------------------------------------------------------
+MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N,
+                               int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                               int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
+    if (R * S > MAX_TAPS || R * S < 1) return (int)hipErrorInvalidValue;
+    ConvGeom g = {};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
+    g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
+    g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
+    g.Co = Co; g.HoF = Ho; g.WoF = Wo;
+    g.ostep = 1; g.istride = stride; g.gather = gather; g.ldw = R * S * Ci; g.ncls = 1;
+    g.act = act; g.slope = slope;
+    g.oh0[0] = 0; g.ow0[0] = 0; g.Ho[0] = Ho; g.Wo[0] = Wo; g.tapbeg[0] = 0; g.ntap[0] = R * S;
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            int t = r * S + s;
+            g.dh[t] = (signed char)(r - pad_t);
+            g.dw[t] = (signed char)(s - pad_l);
+            g.wofs[t] = t * Ci;
+        }
+    return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: dgrad (zero-pad geometry of the forward conv).  dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][Co],
+// weights packed [Ci][R][S][Co].  stride s is decomposed into s*s output parity classes whose tap
+// lists are dense, so no multiply-by-zero work is issued (ConvTranspose2d(4,2,1) == 4 classes of
+// 2x2 taps).
+// ------------------------------------------------------------------------------------------------
+MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, float* dx,
+                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                 int stride, int pad_t, int pad_l, int act, float slope, void* stream) {
+    if (R * S > MAX_TAPS || stride < 1 || stride > 2) return (int)hipErrorInvalidValue;
+    ConvGeom g = {};
+    // roles: source = dy (Ho,Wo,Co), output = dx (Hi,Wi,Ci)
+    g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co; g.HiL = Ho; g.WiL = Wo;
+    g.Co = Ci; g.HoF = Hi; g.WoF = Wi;
+    g.ostep = stride; g.istride = 1; g.gather = GATHER_ZERO; g.ldw = R * S * Co;
+    g.ncls = stride * stride; g.act = act; g.slope = slope;
+    int tp = 0;
+    for (int ph = 0; ph < stride; ++ph)
+        for (int pw = 0; pw < stride; ++pw) {
+            int c = ph * stride + pw;
+            g.oh0[c] = ph; g.ow0[c] = pw;
+            g.Ho[c] = Hi > ph ? (Hi - ph + stride - 1) / stride : 0;
+            g.Wo[c] = Wi > pw ? (Wi - pw + stride - 1) / stride : 0;
+            g.tapbeg[c] = tp;
+            for (int r = 0; r < R; ++r) {
+                int eh = ph + pad_t - r;
+                if (eh % stride != 0) continue;
+                for (int s = 0; s < S; ++s) {
+                    int ew = pw + pad_l - s;
+                    if (ew % stride != 0) continue;
+                    g.dh[tp] = (signed char)(eh / stride);
+                    g.dw[tp] = (signed char)(ew / stride);
+                    g.wofs[tp] = (r * S + s) * Co;
+                    ++tp;
+                }
+            }
+            g.ntap[c] = tp - g.tapbeg[c];
+        }
+    return launch_igemm(g, dy, w_ihwo, bias, dx, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[co][t][ci] = sum_p dy[p][co] * gather(x)[p][t][ci];  GEMM M=Co, N=T*Ci, K=pixels.
+// Split-K over pixel ranges into a workspace, then a fixed-order reduction that also re-lays the
+// result out as OIHW (the torch parameter layout), so the run-to-run result is deterministic.
+// ------------------------------------------------------------------------------------------------
+struct WgradGeom {
+    int N, Hi, Wi, Ci, HiL, WiL;
+    int Ho, Wo, Co;
+    int R, S, stride, pad_t, pad_l, gather;
+    int splits, pix_per_split;  // pixels per split (multiple of 32)
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const float* __restrict__ X,
+                                                    const float* __restrict__ DY,
+                                                    float* __restrict__ part) {
+    constexpr int BK = 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // 2x2 waves
+    __shared__ __attribute__((aligned(16))) int smem_i[BK * LDA + BK * LDB + 4 * BK];
+    float* As = reinterpret_cast<float*>(smem_i);
+    float* Bs = As + BK * LDA;
+    int* r_base = smem_i + BK * LDA + BK * LDB;  // per K-row (pixel) gather info
+    int* r_ih = r_base + BK;
+    int* r_iw = r_ih + BK;
+
+    const int tid = threadIdx.x;
+    const int T = g.R * g.S;
+    const int Ncol = T * g.Ci;
+    const int Mpix = g.N * g.Ho * g.Wo;
+    const int co0 = blockIdx.x * BM, nc0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int p_begin = split * g.pix_per_split;
+    int p_end = p_begin + g.pix_per_split;
+    if (p_end > Mpix) p_end = Mpix;
+    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // VEC: thread owns float4 column-quad q of pixel rows (tid / QA) + j*(256/QA).
+    constexpr int QA = BM / 4, QB = BN / 4;
+    constexpr int NA = VEC ? (BK * QA) / 256 : (BK * BM) / 256;
+    constexpr int NB = VEC ? (BK * QB) / 256 : (BK * BN) / 256;
+    f32x4 ra4[VEC ? NA : 1], rb4[VEC ? NB : 1];
+    float ra1[VEC ? 1 : NA], rb1[VEC ? 1 : NB];
+
+    // column decode for B (fixed per thread)
+    int b_dh = 0, b_dw = 0, b_ci = 0;
+    bool b_colok = false;
+    const int qa = VEC ? tid % QA : tid % BM;
+    const int qb = VEC ? tid % QB : tid % BN;
+    {
+        int col = nc0 + (VEC ? qb * 4 : qb);
+        if (col < Ncol) {
+            int t = col / g.Ci;
+            b_ci = col - t * g.Ci;
+            int r = t / g.S, s = t - r * g.S;
+            b_dh = r - g.pad_t;
+            b_dw = s - g.pad_l;
+            b_colok = true;
+        }
+    }
+    const bool a_colok = (co0 + (VEC ? qa * 4 : qa)) < g.Co;
+
+    auto calc_rowinfo = [&](int kt) {
+        if (tid < BK) {
+            int p = p_begin + kt * BK + tid;
+            int base = -1, ih = 0, iw = 0;
+            if (p < p_end) {
+                int n = p / (g.Ho * g.Wo);
+                int rem = p - n * g.Ho * g.Wo;
+                int oi = rem / g.Wo, oj = rem - oi * g.Wo;
+                base = n * g.Hi * g.Wi;
+                ih = oi * g.stride;
+                iw = oj * g.stride;
+            }
+            r_base[tid] = base;
+            r_ih[tid] = ih;
+            r_iw[tid] = iw;
+        }
+    };
+    auto load_tile = [&](int kt) {
+        const int pt0 = p_begin + kt * BK;
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                int pl = tid / QA + j * (256 / QA);
+                int p = pt0 + pl;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_colok && p < p_end)
+                    v = *reinterpret_cast<const f32x4*>(DY + (size_t)p * g.Co + co0 + qa * 4);
+                ra4[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int pl = tid / QB + j * (256 / QB);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                int base = r_base[pl];
+                int ihs, iws;
+                if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
+                    map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
+                    v = *reinterpret_cast<const f32x4*>(X + (size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci);
+                rb4[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                int pl = tid / BM + j * (256 / BM);
+                int p = pt0 + pl;
+                float v = 0.f;
+                if (a_colok && p < p_end) v = DY[(size_t)p * g.Co + co0 + qa];
+                ra1[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int pl = tid / BN + j * (256 / BN);
+                float v = 0.f;
+                int base = r_base[pl];
+                int ihs, iws;
+                if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
+                    map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
+                    v = X[(size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci];
+                rb1[j] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                int pl = tid / QA + j * (256 / QA);
+                *reinterpret_cast<f32x4*>(As + pl * LDA + qa * 4) = ra4[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int pl = tid / QB + j * (256 / QB);
+                *reinterpret_cast<f32x4*>(Bs + pl * LDB + qb * 4) = rb4[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) As[(tid / BM + j * (256 / BM)) * LDA + qa] = ra1[j];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) Bs[(tid / BN + j * (256 / BN)) * LDB + qb] = rb1[j];
+        }
+    };
+
+    if (KT > 0) {
+        calc_rowinfo(0);
+        __syncthreads();
+        load_tile(0);
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();  // everyone done reading LDS tiles + rowinfo of the previous step
+        store_tile();
+        if (kt + 1 < KT) calc_rowinfo(kt + 1);
+        __syncthreads();
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const float* ap = As + h * LDA + wm * (TM * 32) + l31;
+        const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = part + (size_t)split * g.Co * Ncol;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co >= g.Co) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
+            }
+        }
+}
+
+// part[s][co][t*Ci+ci]  ->  dw[co][ci][t]  (OIHW), summed over s in fixed order.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
+                                    int Co, int T, int Ci) {
+    size_t total = (size_t)Co * T * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the OIHW output so that stores are coalesced
+        int t = (int)(i % T);
+        size_t r = i / T;
+        int ci = (int)(r % Ci);
+        int co = (int)(r / Ci);
+        size_t src = ((size_t)co * T + t) * Ci + ci;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + src];
+        dw[i] = s;
+    }
+}
+
+static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps) {
+    long Mpix = (long)N * Ho * Wo;
+    BMsel = (Co > 64 && Ncol > 64) ? 128 : 64;
+    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, BMsel);
+    long want = cdiv(1024, tiles);
+    long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
+    splits = cdiv(Mpix, pps);
+}
+
+MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci) {
+    int bm, splits, pps;
+    wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);
+    return (size_t)splits * Co * R * S * Ci * sizeof(float);
+}
+
+MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
+                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                 int stride, int pad_t, int pad_l, int gather, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    WgradGeom g = {};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
+    g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
+    g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
+    g.Ho = Ho; g.Wo = Wo; g.Co = Co; g.R = R; g.S = S; g.stride = stride;
+    g.pad_t = pad_t; g.pad_l = pad_l; g.gather = gather;
+    int Ncol = R * S * Ci, bm;
+    wgrad_plan(N, Ho, Wo, Co, Ncol, bm, g.splits, g.pix_per_split);
+    if ((size_t)g.splits * Co * Ncol * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
+    bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
+    if (bm == 128) {
+        dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
+        if (vec) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+    } else {
+        dim3 grid(cdiv(Co, 64), cdiv(Ncol, 64), g.splits);
+        if (vec) hipLaunchKernelGGL((wgrad_kernel<64, 64, true>), grid, dim3(256), 0, st, g, x, dy, ws);
+        else hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+    }
+    HIP_LAUNCH_CHECK();
+    size_t total = (size_t)Co * Ncol;
+    int blocks = cdiv((long)total, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw_oihw, g.splits, Co, R * S, Ci);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

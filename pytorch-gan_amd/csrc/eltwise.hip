@@ -1,0 +1,486 @@
+// HBM-bound pointwise / index-remap kernels of the GAN hot path (NHWC for 4-D tensors).
+// Reference layers: nn.LeakyReLU / ReLU / Tanh / Sigmoid / PReLU, nn.Dropout2d(0.25) (dcgan.py:78),
+// nn.Dropout(0.5) (pix2pix/models.py:27,44), nn.Upsample(scale_factor=2) (dcgan.py:54),
+// nn.ReflectionPad2d (cyclegan/models.py:27), nn.ZeroPad2d((1,0,1,0)) (cyclegan/models.py:117),
+// nn.PixelShuffle(2) (srgan/models.py:56), MaxPool2d(2,2) of VGG19 (srgan/models.py:11-12),
+// torch.cat(.,1) (pix2pix/models.py:50,132), residual adds (cyclegan/models.py:37, srgan/models.py:30,68).
+#include "common.h"
+
+static int grid_for(size_t nvec) {
+    size_t b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define GRID_STRIDE(i, n)                                                        \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);      \
+         i += (size_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------ activations
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act,
+                               float slope) {
+    size_t n4 = n / 4;
+    GRID_STRIDE(i, n4) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = act_apply(v[k], act, slope);
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+    size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) y[t] = act_apply(x[t], act, slope);
+}
+
+// dx = dy * act'(.) expressed through the activation output y
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                               float* __restrict__ dx, size_t n, int act, float slope) {
+    size_t n4 = n / 4;
+    GRID_STRIDE(i, n4) {
+        f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = d[k] * act_grad_from_out(v[k], act, slope);
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+    size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dx[t] = dy[t] * act_grad_from_out(y[t], act, slope);
+}
+
+MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,
+                       slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope,
+                            void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n,
+                       act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// PReLU with one shared slope (nn.PReLU(), srgan/models.py:24,38,57): y = x>0 ? x : a*x
+__global__ void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                 float* __restrict__ y, size_t n) {
+    const float s = a[0];
+    GRID_STRIDE(i, n) {
+        float v = x[i];
+        y[i] = v > 0.f ? v : s * v;
+    }
+}
+// dx = dy * (x>0 ? 1 : a);  per-block partial of da = sum(dy * x * [x<=0])
+__global__ void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                 const float* __restrict__ a, float* __restrict__ dx,
+                                 float* __restrict__ part, size_t n) {
+    __shared__ float red[256];
+    const float s = a[0];
+    float acc = 0.f;
+    GRID_STRIDE(i, n) {
+        float v = x[i], d = dy[i];
+        dx[i] = v > 0.f ? d : s * d;
+        if (!(v > 0.f)) acc += d * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
+                                    float scale) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+#define REDUCE_BLOCKS 1024
+MIGAN_API size_t migan_reduce_workspace() { return REDUCE_BLOCKS * sizeof(float); }
+
+MIGAN_API int migan_prelu_fwd(const float* x, const float* a, float* y, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_prelu_bwd(const float* x, const float* dy, const float* a, float* dx, float* da,
+                              float* ws, size_t n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = grid_for(n);
+    if (blocks > REDUCE_BLOCKS) blocks = REDUCE_BLOCKS;
+    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, dy, a, dx, ws, n);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, blocks, da, 1.f);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ y = alpha*a + beta*b, y = a*b
+__global__ void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                             float beta, float* __restrict__ y, size_t n) {
+    size_t n4 = n / 4;
+    GRID_STRIDE(i, n4) {
+        f32x4 u = reinterpret_cast<const f32x4*>(a)[i];
+        f32x4 o;
+        if (b) {
+            f32x4 v = reinterpret_cast<const f32x4*>(b)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = alpha * u[k] + beta * v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = alpha * u[k];
+        }
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+    size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) y[t] = alpha * a[t] + (b ? beta * b[t] : 0.f);
+}
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           size_t n) {
+    GRID_STRIDE(i, n) y[i] = a[i] * b[i];
+}
+// y[n][p][c] = x[n][p][c] * m[n][c]   (Dropout2d: one Bernoulli draw per (n,c) plane)
+__global__ void mul_nc_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                              float* __restrict__ y, int HW, int C, size_t total) {
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t n = i / ((size_t)HW * C);
+        y[i] = x[i] * m[n * C + c];
+    }
+}
+MIGAN_API int migan_axpby(const float* a, float alpha, const float* b, float beta, float* y, size_t n,
+                          void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, alpha, b,
+                       beta, y, n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_mul(const float* a, const float* b, float* y, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_mul_nc(const float* x, const float* m, float* y, int N, int HW, int C, void* stream) {
+    size_t total = (size_t)N * HW * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(mul_nc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, m, y, HW, C,
+                       total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ dropout masks (Philox4x32-10)
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3,
+                                             unsigned k0, unsigned k1) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    unsigned n1 = (unsigned)p1;
+    unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+// mask[i] = u_i < p ? 0 : 1/(1-p).  The stream position comes from a device counter so a captured
+// hipGraph draws fresh numbers on every replay; the counter is advanced by a trailing 1-thread kernel.
+__global__ void rand_mask_kernel(float* __restrict__ mask, size_t n, float p, unsigned long long seed,
+                                 const unsigned long long* __restrict__ counter) {
+    const unsigned long long off = counter ? counter[0] : 0ull;
+    const float keep = 1.f / (1.f - p);
+    size_t nq = (n + 3) / 4;
+    GRID_STRIDE(i, nq) {
+        unsigned long long ctr = off + i;
+        unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        unsigned rr[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            size_t e = i * 4 + k;
+            if (e < n) {
+                float u = (float)(rr[k] >> 8) * (1.0f / 16777216.0f);
+                mask[e] = u < p ? 0.f : keep;
+            }
+        }
+    }
+}
+__global__ void counter_add_kernel(unsigned long long* counter, unsigned long long inc) { counter[0] += inc; }
+
+MIGAN_API int migan_rand_mask(float* mask, size_t n, float p, unsigned long long seed,
+                              unsigned long long* counter, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rand_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, mask, n, p, seed, counter);
+    HIP_LAUNCH_CHECK();
+    if (counter) {
+        hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, st, counter, (unsigned long long)((n + 3) / 4));
+        HIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ gather2d: pad / upsample
+// y[n][oh][ow][c] = x[n][map(oh-pad_t)][map(ow-pad_l)][c] or 0
+__global__ void gather2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int C,
+                                    int Ho, int Wo, int pad_t, int pad_l, int mode, size_t total) {
+    const int HiL = mode == GATHER_UP2 ? 2 * Hi : Hi, WiL = mode == GATHER_UP2 ? 2 * Wi : Wi;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t r = i / C;
+        int ow = (int)(r % Wo); r /= Wo;
+        int oh = (int)(r % Ho);
+        size_t n = r / Ho;
+        int ih, iw;
+        float v = 0.f;
+        if (map_coord(oh - pad_t, HiL, mode, ih) && map_coord(ow - pad_l, WiL, mode, iw))
+            v = x[((n * Hi + ih) * Wi + iw) * C + c];
+        y[i] = v;
+    }
+}
+// preimages of a source coordinate h under the map, in padded-output coordinates
+__device__ __forceinline__ int preimages(int h, int H, int Hout, int pad, int mode, int* out) {
+    int cnt = 0;
+    if (mode == GATHER_UP2) {
+        for (int a = 0; a < 2; ++a) {
+            int o = 2 * h + a + pad;
+            if (o >= 0 && o < Hout) out[cnt++] = o;
+        }
+        return cnt;
+    }
+    int o = h + pad;
+    if (o >= 0 && o < Hout) out[cnt++] = o;
+    if (mode == GATHER_REFLECT) {
+        int o1 = pad - h;              // logical -h
+        if (h >= 1 && o1 >= 0 && o1 < Hout) out[cnt++] = o1;
+        int o2 = pad + 2 * (H - 1) - h;  // logical 2(H-1)-h
+        if (h <= H - 2 && o2 >= 0 && o2 < Hout) out[cnt++] = o2;
+    }
+    return cnt;
+}
+__global__ void gather2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
+                                    int C, int Ho, int Wo, int pad_t, int pad_l, int mode, size_t total) {
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t r = i / C;
+        int w = (int)(r % Wi); r /= Wi;
+        int h = (int)(r % Hi);
+        size_t n = r / Hi;
+        int ph[3], pw[3];
+        int nh = preimages(h, Hi, Ho, pad_t, mode, ph);
+        int nw = preimages(w, Wi, Wo, pad_l, mode, pw);
+        float s = 0.f;
+        for (int a = 0; a < nh; ++a)
+            for (int b = 0; b < nw; ++b) s += dy[((n * Ho + ph[a]) * Wo + pw[b]) * C + c];
+        dx[i] = s;
+    }
+}
+MIGAN_API int migan_gather2d_fwd(const float* x, float* y, int N, int Hi, int Wi, int C, int Ho, int Wo,
+                                 int pad_t, int pad_l, int mode, void* stream) {
+    size_t total = (size_t)N * Ho * Wo * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather2d_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi,
+                       C, Ho, Wo, pad_t, pad_l, mode, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_gather2d_bwd(const float* dy, float* dx, int N, int Hi, int Wi, int C, int Ho, int Wo,
+                                 int pad_t, int pad_l, int mode, void* stream) {
+    size_t total = (size_t)N * Hi * Wi * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather2d_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, Hi,
+                       Wi, C, Ho, Wo, pad_t, pad_l, mode, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ PixelShuffle(r), NHWC
+// out[n][h*r+i][w*r+j][c] = in[n][h][w][c*r*r + i*r + j]   (in has C*r*r channels, out has C)
+template <bool FWD>
+__global__ void pixel_shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C,
+                                     int r, size_t total) {
+    GRID_STRIDE(i, total) {  // i indexes the shuffled (large-spatial) tensor
+        int c = (int)(i % C);
+        size_t q = i / C;
+        int ow = (int)(q % (W * r)); q /= (W * r);
+        int oh = (int)(q % (H * r));
+        size_t n = q / (H * r);
+        int h = oh / r, ii = oh - h * r, w = ow / r, jj = ow - w * r;
+        size_t lo = ((n * H + h) * W + w) * ((size_t)C * r * r) + (size_t)c * r * r + ii * r + jj;
+        if (FWD) dst[i] = src[lo];
+        else dst[lo] = src[i];
+    }
+}
+MIGAN_API int migan_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C, int r, int forward,
+                                  void* stream) {
+    size_t total = (size_t)N * H * W * C * r * r;
+    if (total == 0) return 0;
+    if (forward)
+        hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           src, dst, H, W, C, r, total);
+    else
+        hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           src, dst, H, W, C, r, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ MaxPool2d(2,2), NHWC (H, W even)
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                    size_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t q = i / C;
+        int ow = (int)(q % Wo); q /= Wo;
+        int oh = (int)(q % Ho);
+        size_t n = q / Ho;
+        const float* p = x + ((n * H + 2 * oh) * W + 2 * ow) * C + c;
+        float m = p[0];
+        float v = p[C]; if (v > m) m = v;
+        v = p[(size_t)W * C]; if (v > m) m = v;
+        v = p[(size_t)W * C + C]; if (v > m) m = v;
+        y[i] = m;
+    }
+}
+// dx: first maximal element of each window (scan order h, w) receives dy (torch tie rule)
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int H, int W, int C, size_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t q = i / C;
+        int ow = (int)(q % Wo); q /= Wo;
+        int oh = (int)(q % Ho);
+        size_t n = q / Ho;
+        size_t b = ((n * H + 2 * oh) * W + 2 * ow) * C + c;
+        size_t o[4] = {b, b + C, b + (size_t)W * C, b + (size_t)W * C + C};
+        int arg = 0;
+        float m = x[o[0]];
+        for (int k = 1; k < 4; ++k) {
+            float v = x[o[k]];
+            if (v > m) { m = v; arg = k; }
+        }
+        float d = dy[i];
+        for (int k = 0; k < 4; ++k) dx[o[k]] = (k == arg) ? d : 0.f;
+    }
+}
+MIGAN_API int migan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C,
+                       total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                                 void* stream) {
+    size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H,
+                       W, C, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ channel concat / split (NHWC)
+// y[p][0:Ca] = a[p], y[p][Ca:Ca+Cb] = b[p]        (forward=1)   or the inverse scatter (forward=0)
+template <bool FWD>
+__global__ void cat_c_kernel(float* __restrict__ a, float* __restrict__ b, float* __restrict__ y, int Ca, int Cb,
+                             size_t total) {
+    const int C = Ca + Cb;
+    GRID_STRIDE(i, total) {
+        int c = (int)(i % C);
+        size_t p = i / C;
+        if (FWD) y[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
+        else {
+            if (c < Ca) a[p * Ca + c] = y[i];
+            else b[p * Cb + (c - Ca)] = y[i];
+        }
+    }
+}
+MIGAN_API int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca, int Cb, int forward,
+                                 void* stream) {
+    size_t total = P * (size_t)(Ca + Cb);
+    if (total == 0) return 0;
+    if (forward)
+        hipLaunchKernelGGL((cat_c_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                           Ca, Cb, total);
+    else
+        hipLaunchKernelGGL((cat_c_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+                           Ca, Cb, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ layout: NCHW <-> NHWC per image
+// src viewed as [B][R][Cc] -> dst [B][Cc][R]  (32x32 LDS tiles, both sides coalesced)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const size_t b = blockIdx.z;
+    const float* s = src + b * (size_t)R * Cc;
+    float* d = dst + b * (size_t)R * Cc;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        int r = r0 + k, c = c0 + tx;
+        if (r < R && c < Cc) tile[k][tx] = s[(size_t)r * Cc + c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        int c = c0 + k, r = r0 + tx;
+        if (r < R && c < Cc) d[(size_t)c * R + r] = tile[tx][k];
+    }
+}
+MIGAN_API int migan_transpose_batched(const float* src, float* dst, int B, int R, int Cc, void* stream) {
+    if ((size_t)B * R * Cc == 0) return 0;
+    // grid.y is limited to 65535 blocks: R up to 2M rows
+    dim3 grid(cdiv(Cc, 32), cdiv(R, 32), B);
+    if (grid.y > 65535 || grid.z > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// generic 4-D permute copy (weight packing; small tensors): dst = src.permute(p0,p1,p2,p3).contiguous()
+__global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
+                                int d3, int p0, int p1, int p2, int p3, size_t total) {
+    const int dims[4] = {d0, d1, d2, d3};
+    const size_t st[4] = {(size_t)d1 * d2 * d3, (size_t)d2 * d3, (size_t)d3, 1};
+    const int o0 = dims[p0], o1 = dims[p1], o2 = dims[p2], o3 = dims[p3];
+    (void)o0;
+    GRID_STRIDE(i, total) {
+        size_t q = i;
+        int i3 = (int)(q % o3); q /= o3;
+        int i2 = (int)(q % o2); q /= o2;
+        int i1 = (int)(q % o1);
+        int i0 = (int)(q / o1);
+        dst[i] = src[i0 * st[p0] + i1 * st[p1] + i2 * st[p2] + i3 * st[p3]];
+    }
+}
+MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2,
+                              int p3, void* stream) {
+    size_t total = (size_t)d0 * d1 * d2 * d3;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1,
+                       d2, d3, p0, p1, p2, p3, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,328 @@
+// BatchNorm2d/BatchNorm1d (train) and InstanceNorm2d, NHWC, fused with the following activation.
+// Reference semantics: torch.nn.BatchNorm2d(C[, eps]) as used in dcgan.py:53,56,60,80 (eps 1e-5 and
+// the positional eps=0.8), srgan/models.py:23,26,47,55,87,90, wgan_gp.py:49 (BatchNorm1d);
+// torch.nn.InstanceNorm2d(C) (affine=False, eps 1e-5) in cyclegan/models.py:29,33,51,62,77,108 and
+// pix2pix/models.py:25,40,117.  SURVEY.md Appendix B lists the exact formulas.
+//
+// Data is viewed as [G groups][P pixels][C channels]: BatchNorm has G=1,P=N*H*W; InstanceNorm has
+// G=N,P=H*W.  All kernels are HBM-bound; loads are 16 B/lane when C%4==0.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// stats pass 1: per (g, chunk, c) partial (sum, sumsq) [and for backward: sum(dyz), sum(dyz*xhat)]
+// thread layout: tx = tid % CTX walks channel vectors, ty = tid / CTX walks pixels.
+// ---------------------------------------------------------------------------------------------
+template <int VW, bool BWD>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float* __restrict__ part, int P, int C, int CTX,
+                                                           int chunk, int nchunks, int act, float slope) {
+    __shared__ float red[2][256 * VW];
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z, ck = blockIdx.y;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    const bool cok = c < C;
+    float s0[VW], s1[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) s0[v] = s1[v] = 0.f;
+    float mu[VW], is[VW], ga[VW], be[VW];
+    if (BWD && cok) {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            mu[v] = mean[(size_t)g * C + c + v];
+            is[v] = invstd[(size_t)g * C + c + v];
+            ga[v] = gamma ? gamma[c + v] : 1.f;
+            be[v] = beta ? beta[c + v] : 0.f;
+        }
+    }
+    int p0 = ck * chunk, p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    const float* xb = x + (size_t)g * P * C;
+    const float* dyb = BWD ? dy + (size_t)g * P * C : nullptr;
+    if (cok) {
+        for (int p = p0 + ty; p < p1; p += TY) {
+            float xv[VW], dv[VW];
+            if (VW == 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
+                xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
+                if (BWD) {
+                    f32x4 d = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + c);
+                    dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2]; dv[3] = d[3];
+                }
+            } else {
+                xv[0] = xb[(size_t)p * C + c];
+                if (BWD) dv[0] = dyb[(size_t)p * C + c];
+            }
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                if (BWD) {
+                    float xh = (xv[v] - mu[v]) * is[v];
+                    float z = xh * ga[v] + be[v];
+                    float d = dv[v];
+                    if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
+                    else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
+                    s0[v] += d;
+                    s1[v] += d * xh;
+                } else {
+                    s0[v] += xv[v];
+                    s1[v] += xv[v] * xv[v];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+        red[0][tid * VW + v] = s0[v];
+        red[1][tid * VW + v] = s1[v];
+    }
+    __syncthreads();
+    if (ty == 0 && cok) {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            float a = 0.f, b = 0.f;
+            for (int y = 0; y < TY; ++y) {
+                a += red[0][(y * CTX + tx) * VW + v];
+                b += red[1][(y * CTX + tx) * VW + v];
+            }
+            size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 2;
+            part[o] = a;
+            part[o + 1] = b;
+        }
+    }
+}
+
+// pass 2 (forward): merge chunks in double, write mean / invstd, update running stats.
+__global__ void norm_finalize_fwd_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                         float* __restrict__ invstd, float* running_mean,
+                                         float* running_var, int G, int P, int C, int nchunks, float eps,
+                                         float momentum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 2;
+        s += (double)part[o];
+        q += (double)part[o + 1];
+    }
+    double m = s / P;
+    double var = q / P - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && G == 1) {
+        double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// pass 2 (backward): merge chunks -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1.
+__global__ void norm_finalize_bwd_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                         float* dgamma, float* dbeta, int G, int C, int nchunks) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    int g = i / C, c = i - g * C;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 2;
+        a += (double)part[o];
+        b += (double)part[o + 1];
+    }
+    sums[(size_t)i * 2] = (float)a;
+    sums[(size_t)i * 2 + 1] = (float)b;
+    if (G == 1) {
+        if (dbeta) dbeta[c] = (float)a;
+        if (dgamma) dgamma[c] = (float)b;
+    }
+}
+
+// apply: y = act((x-mean)*invstd*gamma+beta) [+ res]
+template <int VW>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ res, int G, int P, int C,
+                                                         int act, float slope) {
+    const size_t per_g = (size_t)P * C;
+    const size_t total = (size_t)G * per_g / VW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t e = i * VW;
+        int g = (int)(e / per_g);
+        int c = (int)(e % C);
+        if (VW == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (res) r = *reinterpret_cast<const f32x4*>(res + e);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float sc = invstd[(size_t)g * C + c + k] * (gamma ? gamma[c + k] : 1.f);
+                float z = (v[k] - mean[(size_t)g * C + c + k]) * sc + (beta ? beta[c + k] : 0.f);
+                o[k] = act_apply(z, act, slope) + r[k];
+            }
+            *reinterpret_cast<f32x4*>(y + e) = o;
+        } else {
+            float sc = invstd[(size_t)g * C + c] * (gamma ? gamma[c] : 1.f);
+            float z = (x[e] - mean[(size_t)g * C + c]) * sc + (beta ? beta[c] : 0.f);
+            y[e] = act_apply(z, act, slope) + (res ? res[e] : 0.f);
+        }
+    }
+}
+
+// dx = gamma*invstd*(dyz - s0/P - xhat*s1/P); dyz = dy * act'(z)
+template <int VW>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ sums, int G, int P, int C, int act,
+    float slope) {
+    const size_t per_g = (size_t)P * C;
+    const size_t total = (size_t)G * per_g / VW;
+    const float invP = 1.f / (float)P;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t e = i * VW;
+        int g = (int)(e / per_g);
+        int c = (int)(e % C);
+        float xv[VW], dv[VW], ov[VW];
+        if (VW == 4) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(x + e);
+            f32x4 b = *reinterpret_cast<const f32x4*>(dy + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; }
+        } else {
+            xv[0] = x[e];
+            dv[0] = dy[e];
+        }
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            size_t gc = (size_t)g * C + c + k;
+            float is = invstd[gc], ga = gamma ? gamma[c + k] : 1.f;
+            float xh = (xv[k] - mean[gc]) * is;
+            float d = dv[k];
+            if (act != ACT_NONE) {
+                float z = xh * ga + (beta ? beta[c + k] : 0.f);
+                if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
+                else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
+            }
+            ov[k] = ga * is * (d - sums[gc * 2] * invP - xh * sums[gc * 2 + 1] * invP);
+        }
+        if (VW == 4) {
+            f32x4 o = {ov[0], ov[1], ov[2], ov[3]};
+            *reinterpret_cast<f32x4*>(dx + e) = o;
+        } else {
+            dx[e] = ov[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static void norm_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, int& nchunks, int& gx) {
+    VW = (C % 4 == 0) ? 4 : 1;
+    int cv = C / VW;
+    CTX = 1;
+    while (CTX < cv && CTX < 64) CTX <<= 1;
+    gx = cdiv(cv, CTX);
+    int TY = 256 / CTX;
+    // aim for ~2048 blocks total, at least 4 pixels per ty lane
+    long blocks_other = (long)gx * G;
+    long want = cdiv(2048, blocks_other);
+    long maxc = cdiv(P, (long)TY * 4);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    chunk = cdiv(P, want);
+    nchunks = cdiv(P, chunk);
+}
+
+MIGAN_API size_t migan_norm_workspace(int G, int P, int C) {
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    return ((size_t)G * nchunks * C * 2 + (size_t)G * C * 2) * sizeof(float);
+}
+
+static int grid_for(size_t nvec) {
+    size_t b = (nvec + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// Training-mode statistics: mean/invstd [G][C] (+ running stat update when G==1 and pointers given).
+MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean,
+                               float* running_var, float momentum, float eps, int G, int P, int C,
+                               float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
+    dim3 grid(gx, nchunks, G);
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_partial_kernel<4, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
+    else
+        hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, ws, mean,
+                       invstd, running_mean, running_var, G, P, C, nchunks, eps, momentum);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = act(norm(x)*gamma+beta) [+ res] with given statistics (train or eval).
+MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* res, int G, int P, int C,
+                               int act, float slope, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    size_t n = (size_t)G * P * C;
+    if (n == 0) return 0;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((norm_apply_kernel<4>), dim3(grid_for(n / 4)), dim3(256), 0, st, x, y, mean, invstd,
+                           gamma, beta, res, G, P, C, act, slope);
+    else
+        hipLaunchKernelGGL((norm_apply_kernel<1>), dim3(grid_for(n)), dim3(256), 0, st, x, y, mean, invstd,
+                           gamma, beta, res, G, P, C, act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of y = act(norm(x)*gamma+beta) through the batch statistics.
+MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                             int G, int P, int C, int act, float slope, float* ws, size_t ws_bytes,
+                             void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
+    float* sums = ws + (size_t)G * nchunks * C * 2;
+    dim3 grid(gx, nchunks, G);
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope);
+    else
+        hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, ws, sums,
+                       dgamma, dbeta, G, C, nchunks);
+    HIP_LAUNCH_CHECK();
+    size_t n = (size_t)G * P * C;
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), dim3(grid_for(n / 4)), dim3(256), 0, st, x, dy, dx, mean,
+                           invstd, gamma, beta, sums, G, P, C, act, slope);
+    else
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), dim3(grid_for(n)), dim3(256), 0, st, x, dy, dx, mean,
+                           invstd, gamma, beta, sums, G, P, C, act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,303 @@
+// Reductions, losses, gradient-penalty helpers and the fused multi-tensor Adam.
+// Reference semantics:
+//   torch.nn.BCELoss (dcgan.py:103; log clamped at -100, mean), torch.nn.MSELoss / L1Loss
+//   (cyclegan.py:57-59, pix2pix.py:50-51, srgan.py:71-72), torch.mean (wgan_gp.py:171,189),
+//   gradients.norm(2, dim=1) and ((.-1)**2).mean() (wgan_gp.py:136-137),
+//   torch.optim.Adam single-tensor arithmetic (dcgan.py:134-135).
+#include "common.h"
+
+#define REDUCE_BLOCKS 1024
+static int grid_for(size_t nvec, int cap = 4096) {
+    size_t b = (nvec + 255) / 256;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define GRID_STRIDE(i, n)                                                        \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);      \
+         i += (size_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+__global__ void final_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ out, double scale) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
+// ------------------------------------------------------------------ column sum: x[P][C] -> out[C]  (bias grads)
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, size_t P, int C,
+                                      size_t chunk) {
+    __shared__ float red[256];
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + tx;
+    size_t p0 = blockIdx.y * chunk, p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    float acc = 0.f;
+    if (c < C)
+        for (size_t p = p0 + ty; p < p1; p += 4) acc += x[p * C + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[tx] + red[64 + tx] + red[128 + tx] + red[192 + tx];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int nchunks) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunks; ++k) s += (double)part[(size_t)k * C + c];
+    out[c] = (float)s;
+}
+static void colsum_plan(size_t P, int C, size_t& chunk, int& nchunks) {
+    long gx = cdiv(C, 64);
+    long want = cdiv(1024, gx);
+    long maxc = cdiv((long)P, 16);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    chunk = (P + want - 1) / want;
+    if (chunk < 1) chunk = 1;
+    nchunks = (int)((P + chunk - 1) / chunk);
+    if (nchunks < 1) nchunks = 1;
+}
+MIGAN_API size_t migan_colsum_workspace(size_t P, int C) {
+    size_t chunk; int nchunks;
+    colsum_plan(P, C, chunk, nchunks);
+    return (size_t)nchunks * C * sizeof(float);
+}
+MIGAN_API int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    size_t chunk; int nchunks;
+    colsum_plan(P, C, chunk, nchunks);
+    if (ws_bytes < (size_t)nchunks * C * sizeof(float)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, x, ws, P, C, chunk);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, out, C, nchunks);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ losses (mean reduction)
+enum { LOSS_BCE = 0, LOSS_MSE = 1, LOSS_L1 = 2, LOSS_MEAN = 3 };
+__device__ __forceinline__ float loss_term(int kind, float x, float t) {
+    switch (kind) {
+        case LOSS_BCE: {
+            float lx = fmaxf(logf(x), -100.f), l1x = fmaxf(logf(1.f - x), -100.f);
+            return -(t * lx + (1.f - t) * l1x);
+        }
+        case LOSS_MSE: { float d = x - t; return d * d; }
+        case LOSS_L1: return fabsf(x - t);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float loss_grad(int kind, float x, float t) {
+    switch (kind) {
+        case LOSS_BCE: {
+            // torch: (x - t) / max((1-x)*x, 1e-12)
+            return (x - t) / fmaxf((1.f - x) * x, 1e-12f);
+        }
+        case LOSS_MSE: return 2.f * (x - t);
+        case LOSS_L1: { float d = x - t; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        default: return 1.f;
+    }
+}
+__global__ void loss_partial_kernel(int kind, const float* __restrict__ x, const float* __restrict__ t,
+                                    float tconst, float* __restrict__ part, size_t n) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    GRID_STRIDE(i, n) acc += loss_term(kind, x[i], t ? t[i] : tconst);
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// dx = g[0] * scale * dloss/dx
+__global__ void loss_bwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ t, float tconst,
+                                const float* __restrict__ g, float scale, float* __restrict__ dx, size_t n) {
+    const float gs = g[0] * scale;
+    GRID_STRIDE(i, n) dx[i] = gs * loss_grad(kind, x[i], t ? t[i] : tconst);
+}
+MIGAN_API int migan_loss_fwd(int kind, const float* x, const float* t, float tconst, float* out, size_t n, float* ws,
+                             size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0 || ws_bytes < REDUCE_BLOCKS * sizeof(float)) return (int)hipErrorInvalidValue;
+    int blocks = grid_for(n, REDUCE_BLOCKS);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, x, t, tconst, ws, n);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out, 1.0 / (double)n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_loss_bwd(int kind, const float* x, const float* t, float tconst, const float* g, float* dx,
+                             size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, t, tconst, g,
+                       (float)(1.0 / (double)n), dx, n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ row L2 norm (gradient penalty)
+// out[b] = ||x[b,:]||_2 ; one block per row
+__global__ void rownorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int D) {
+    __shared__ float red[256];
+    const float* r = x + (size_t)blockIdx.x * D;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) acc += r[i] * r[i];
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf(s);
+}
+// dx[b,:] = x[b,:] * (dn[b] / n[b])     (torch: zero where n == 0)
+__global__ void rownorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
+                                   const float* __restrict__ dn, float* __restrict__ dx, int D) {
+    const size_t b = blockIdx.x;
+    float n = nrm[b];
+    float sc = n > 0.f ? dn[b] / n : 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) dx[b * D + i] = x[b * D + i] * sc;
+}
+MIGAN_API int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D,
+                                void* stream) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, nrm, dn, dx, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+// d/dx of (x * s[b]) helpers for the double-backward of rownorm: y[b,:] = x[b,:]*s[b]; and
+// rowdot[b] = sum_i a[b,i]*c[b,i]
+__global__ void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y,
+                                int D) {
+    const size_t b = blockIdx.x;
+    float sc = s[b];
+    for (int i = threadIdx.x; i < D; i += 256) y[b * D + i] = x[b * D + i] * sc;
+}
+__global__ void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ c, float* __restrict__ out,
+                              int D) {
+    __shared__ float red[256];
+    const size_t b = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < D; i += 256) acc += a[b * D + i] * c[b * D + i];
+    float s = block_sum(acc, red);
+    if (threadIdx.x == 0) out[b] = s;
+}
+MIGAN_API int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rowscale_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, s, y, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_rowdot(const float* a, const float* c, float* out, int B, int D, void* stream) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, c, out, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused multi-tensor Adam
+// One launch updates every tensor of an optimizer.  `tab` holds per-tensor {param, grad, exp_avg,
+// exp_avg_sq, numel}; `blk` maps each block to (tensor, chunk).  `step` lives on the device so a captured
+// hipGraph advances it on replay.  Arithmetic follows torch/optim/adam.py::_single_tensor_adam:
+//   m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(1-b2^t) + eps; p += (-lr/(1-b1^t)) * m/denom
+struct AdamTensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+};
+struct AdamBlock {
+    int tensor;
+    int chunk;
+};
+#define ADAM_CHUNK 4096
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ tab,
+                                                   const AdamBlock* __restrict__ blk,
+                                                   const float* __restrict__ step, float lr, float b1, float b2,
+                                                   float eps, float grad_scale) {
+    const AdamBlock bi = blk[blockIdx.x];
+    const AdamTensor t = tab[bi.tensor];
+    const double st = (double)step[0];  // already incremented for this update
+    const double bc1 = 1.0 - pow((double)b1, st);
+    const double bc2 = 1.0 - pow((double)b2, st);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w = 1.f - b1;
+    long long i0 = (long long)bi.chunk * ADAM_CHUNK;
+    long long i1 = i0 + ADAM_CHUNK;
+    if (i1 > t.n) i1 = t.n;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        float g = t.g[i] * grad_scale;
+        float m = t.m[i], v = t.v[i];
+        // torch lerp: weight < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+        float d = g - m;
+        m = (w < 0.5f) ? m + w * d : g - d * (1.f - w);
+        v = v * b2 + (1.f - b2) * g * g;
+        float denom = sqrtf(v) / bc2_sqrt + eps;
+        t.p[i] = t.p[i] + (-step_size) * (m / denom);
+        t.m[i] = m;
+        t.v[i] = v;
+    }
+}
+__global__ void step_inc_kernel(float* step) { step[0] += 1.f; }
+
+MIGAN_API int migan_adam_chunk() { return ADAM_CHUNK; }
+MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, float lr, float b1,
+                              float b2, float eps, float grad_scale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+    HIP_LAUNCH_CHECK();
+    if (nblocks > 0) {
+        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, (const AdamTensor*)tab,
+                           (const AdamBlock*)blk, step, lr, b1, b2, eps, grad_scale);
+        HIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ multi-tensor pack / unpack (DP flat buckets)
+// Same table layout: copies tensor t (tab[t].g) <-> flat + off, where off = tab[t].m reinterpreted... kept
+// explicit instead: PackTensor {src/dst pointer, flat offset, numel}.
+struct PackTensor {
+    float* ptr;
+    long long off;
+    long long n;
+};
+__global__ __launch_bounds__(256) void pack_kernel(const PackTensor* __restrict__ tab,
+                                                   const AdamBlock* __restrict__ blk, float* __restrict__ flat,
+                                                   int to_flat, float scale) {
+    const AdamBlock bi = blk[blockIdx.x];
+    const PackTensor t = tab[bi.tensor];
+    long long i0 = (long long)bi.chunk * ADAM_CHUNK;
+    long long i1 = i0 + ADAM_CHUNK;
+    if (i1 > t.n) i1 = t.n;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (to_flat) flat[t.off + i] = t.ptr[i] * scale;
+        else t.ptr[i] = flat[t.off + i] * scale;
+    }
+}
+MIGAN_API int migan_pack(const void* tab, const void* blk, int nblocks, float* flat, int to_flat, float scale,
+                         void* stream) {
+    if (nblocks <= 0) return 0;
+    hipLaunchKernelGGL(pack_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const PackTensor*)tab,
+                       (const AdamBlock*)blk, flat, to_flat, scale);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+MIGAN_API const char* migan_version() { return "migan 0.1 gfx950"; }
+MIGAN_API const char* migan_error_string(int code) { return hipGetErrorString((hipError_t)code); }

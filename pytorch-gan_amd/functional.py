@@ -1,0 +1,742 @@
+"""torch.autograd.Function wrappers over the C ABI (include/migan.h).
+
+Every op here launches hand-written HIP kernels from libmigan.so on torch's current HIP stream.  There is
+no CPU or ATen fallback: CPU tensors raise.  4-D tensors are logical NCHW / physical NHWC
+(torch.channels_last); inputs that arrive NCHW-contiguous (e.g. from `.view` in dcgan.py:68) are re-laid
+out by migan_transpose_batched.
+
+Backward passes are themselves built from Functions where the reference needs a second derivative
+(Linear + LeakyReLU for wgan_gp.py:119-138), so `autograd.grad(..., create_graph=True)` works.
+"""
+import torch
+from torch.autograd import Function
+
+from ._lib import check, lib
+
+CL = torch.channels_last
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+GATHER_ZERO, GATHER_REFLECT, GATHER_UP2 = 0, 1, 2
+LOSS_BCE, LOSS_MSE, LOSS_L1, LOSS_MEAN = 0, 1, 2, 3
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _plain(t):
+    """Strip tensor subclasses (GanTensor / Parameter) without copying."""
+    if t is None or type(t) is torch.Tensor:
+        return t
+    with torch._C.DisableTorchFunctionSubclass():
+        return t.as_subclass(torch.Tensor)
+
+
+def _check_dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("pytorch_gan_amd: tensor is on %s; the HIP path has no CPU fallback" % t.device)
+    if t.dtype != torch.float32:
+        raise TypeError("pytorch_gan_amd: fp32 only (got %s)" % t.dtype)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _empty_nhwc(shape, ref):
+    return torch.empty(shape, device=ref.device, dtype=torch.float32, memory_format=CL)
+
+
+def to_nhwc(x):
+    """Dense channels_last copy of a 4-D tensor (no-op when it already is)."""
+    x = _plain(x)
+    _check_dev(x)
+    if x.is_contiguous(memory_format=CL):
+        return x
+    if not x.is_contiguous():
+        x = x.contiguous()
+    N, C, H, W = x.shape
+    y = _empty_nhwc(x.shape, x)
+    check(lib.migan_transpose_batched(x.data_ptr(), y.data_ptr(), N, C, H * W, _stream()), "transpose")
+    return y
+
+
+def to_nchw(x):
+    """Dense NCHW-contiguous copy of a 4-D tensor (no-op when it already is)."""
+    x = _plain(x)
+    _check_dev(x)
+    if x.is_contiguous():
+        return x
+    xs = to_nhwc(x)
+    N, C, H, W = xs.shape
+    y = torch.empty(xs.shape, device=xs.device, dtype=torch.float32)
+    check(lib.migan_transpose_batched(xs.data_ptr(), y.data_ptr(), N, H * W, C, _stream()), "transpose")
+    return y
+
+
+def canon(x):
+    """Canonical dense layout: channels_last for 4-D, contiguous otherwise."""
+    x = _plain(x)
+    _check_dev(x)
+    if x.dim() == 4:
+        return to_nhwc(x)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _permute4(w, perm):
+    w = _plain(w)
+    if not w.is_contiguous():
+        w = w.contiguous()
+    d = list(w.shape)
+    out = torch.empty([d[p] for p in perm], device=w.device, dtype=torch.float32)
+    check(lib.migan_permute4d(w.data_ptr(), out.data_ptr(), d[0], d[1], d[2], d[3], perm[0], perm[1], perm[2],
+                              perm[3], _stream()), "permute4d")
+    return out
+
+
+def _ws(nbytes, ref):
+    return torch.empty(max(int(nbytes) // 4, 1), device=ref.device, dtype=torch.float32)
+
+
+def _colsum(x2d_ptr_tensor, P, C):
+    out = torch.empty(C, device=x2d_ptr_tensor.device, dtype=torch.float32)
+    nb = lib.migan_colsum_workspace(P, C)
+    ws = _ws(nb, x2d_ptr_tensor)
+    check(lib.migan_colsum(x2d_ptr_tensor.data_ptr(), out.data_ptr(), P, C, ws.data_ptr(), nb, _stream()), "colsum")
+    return out
+
+
+def _act_bwd_raw(dy, y, act, slope):
+    dx = torch.empty_like(y)
+    check(lib.migan_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), act, slope, _stream()), "act_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- convolution
+def _conv_out(HL, pt, pb, R, stride):
+    return (HL + pt + pb - R) // stride + 1
+
+
+class _Conv2d(Function):
+    """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pads, gather, act, slope):
+        xs = to_nhwc(x)
+        w = _plain(w)
+        b = _plain(b)
+        _check_dev(w)
+        N, Ci, H, W = xs.shape
+        Co, Ciw, R, S = w.shape
+        if Ciw != Ci:
+            raise ValueError("conv2d: weight expects %d input channels, got %d" % (Ciw, Ci))
+        pt, pl, pb, pr = pads
+        HL, WL = (2 * H, 2 * W) if gather == GATHER_UP2 else (H, W)
+        if gather == GATHER_REFLECT and (max(pt, pb) >= H or max(pl, pr) >= W):
+            raise ValueError("reflection padding must be smaller than the input")
+        Ho, Wo = _conv_out(HL, pt, pb, R, stride), _conv_out(WL, pl, pr, S, stride)
+        if Ho <= 0 or Wo <= 0:
+            raise ValueError("conv2d: empty output")
+        wp = _permute4(w, (0, 2, 3, 1))
+        y = _empty_nhwc((N, Co, Ho, Wo), xs)
+        check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
+                                   stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
+        ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w, y = ctx.saved_tensors
+        N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = _act_bwd_raw(dy, y, act, slope)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = _permute4(w, (1, 2, 3, 0))
+            dx = _empty_nhwc((N, Ci, H, W), xs)
+            if gather == GATHER_ZERO:
+                check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
+                                             Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
+            else:
+                if gather == GATHER_REFLECT:
+                    Hp, Wp, gpt, gpl, dpt, dpl = H + pt + pb, W + pl + pr, pt, pl, 0, 0
+                else:
+                    Hp, Wp, gpt, gpl, dpt, dpl = 2 * H, 2 * W, 0, 0, pt, pl
+                tmp = _empty_nhwc((N, Ci, Hp, Wp), xs)
+                check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, tmp.data_ptr(), N, Hp, Wp, Ci, Ho, Wo,
+                                             Co, R, S, stride, dpt, dpl, 0, 0.0, st), "conv2d_dgrad")
+                check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
+                      "gather2d_bwd")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
+            ws = _ws(nb, xs)
+            check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
+                                         Ho, Wo, Co, R, S, stride, pt, pl, gather, st), "conv2d_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, N * Ho * Wo, Co)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0):
+    return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope))
+
+
+class _ConvTranspose2d(Function):
+    """nn.ConvTranspose2d(Cin, Cout, k, s, p) forward == dgrad of the (Cout -> Cin) conv (pix2pix/models.py:39)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope):
+        xs = to_nhwc(x)
+        w = _plain(w)
+        b = _plain(b)
+        N, Cin, Hin, Win = xs.shape
+        Cinw, Cout, R, S = w.shape
+        if Cinw != Cin:
+            raise ValueError("conv_transpose2d: weight expects %d input channels, got %d" % (Cinw, Cin))
+        Hout = (Hin - 1) * stride - 2 * pad + R
+        Wout = (Win - 1) * stride - 2 * pad + S
+        wp = _permute4(w, (1, 2, 3, 0))  # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
+        y = _empty_nhwc((N, Cout, Hout, Wout), xs)
+        check(lib.migan_conv2d_dgrad(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
+                                     Win, Cin, R, S, stride, pad, pad, act, slope, _stream()), "convT_fwd")
+        ctx.geom = (N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w, y = ctx.saved_tensors
+        N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope = ctx.geom
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = _act_bwd_raw(dy, y, act, slope)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wo = _permute4(w, (0, 2, 3, 1))  # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
+            dx = _empty_nhwc((N, Cin, Hin, Win), xs)
+            check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
+                                       Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            nb = lib.migan_conv2d_wgrad_workspace(N, Hin, Win, Cin, R, S, Cout)
+            ws = _ws(nb, xs)
+            check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout, Wout,
+                                         Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO, st), "convT_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, N * Hout * Wout, Cout)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_transpose2d(x, w, b=None, stride=2, pad=1, act=ACT_NONE, slope=0.0):
+    return _ConvTranspose2d.apply(x, w, b, int(stride), int(pad), int(act), float(slope))
+
+
+# ---------------------------------------------------------------------------------------------- GEMM primitives
+def _mm_nt_raw(a, b, bias, act=ACT_NONE, slope=0.0):
+    M, K = a.shape
+    Nn, Kb = b.shape
+    if K != Kb:
+        raise ValueError("mm_nt: inner dimensions differ (%d vs %d)" % (K, Kb))
+    out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+    check(lib.migan_conv2d_fwd(a.data_ptr(), b.data_ptr(), _ptr(bias), out.data_ptr(), M, 1, 1, K, 1, 1, Nn, 1, 1, 1,
+                               0, 0, GATHER_ZERO, act, slope, _stream()), "mm_nt")
+    return out
+
+
+class _Transpose(Function):
+    @staticmethod
+    def forward(ctx, a):
+        a = canon(a)
+        R, C = a.shape
+        out = torch.empty((C, R), device=a.device, dtype=torch.float32)
+        check(lib.migan_transpose_batched(a.data_ptr(), out.data_ptr(), 1, R, C, _stream()), "transpose")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Transpose.apply(g)
+
+
+class _MMNT(Function):
+    """a[M,K] @ b[N,K]^T + bias[N]  — nn.Linear forward (conv kernel, 1x1 geometry)."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias):
+        a, b, bias = canon(a), canon(b), _plain(bias)
+        ctx.save_for_backward(a, b)
+        ctx.has_bias = bias is not None
+        return _mm_nt_raw(a, b, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            da = mm_nn(g, b)
+        if ctx.needs_input_grad[1]:
+            db = _MMTN.apply(g, a)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gc = canon(g)
+            dbias = _colsum(gc, gc.shape[0], gc.shape[1])
+        return da, db, dbias
+
+
+class _MMTN(Function):
+    """a[P,M]^T @ b[P,N] -> [M,N]  — Linear weight gradient (split-K wgrad kernel)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = canon(a), canon(b)
+        P, M = a.shape
+        Pb, Nn = b.shape
+        if P != Pb:
+            raise ValueError("mm_tn: row counts differ")
+        out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+        nb = lib.migan_conv2d_wgrad_workspace(P, 1, 1, M, 1, 1, Nn)
+        ws = _ws(nb, a)
+        check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
+                                     M, 1, 1, 1, 0, 0, GATHER_ZERO, _stream()), "mm_tn")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _MMNT.apply(b, g, None)  # [P,N] @ [M,N]^T
+        if ctx.needs_input_grad[1]:
+            db = mm_nn(a, g)  # [P,M] @ [M,N]
+        return da, db
+
+
+def mm_nt(a, b, bias=None):
+    return _MMNT.apply(a, b, bias)
+
+
+def mm_nn(a, b):
+    return _MMNT.apply(a, _Transpose.apply(b), None)
+
+
+def linear(x, w, b=None):
+    if x.dim() != 2:
+        raise ValueError("linear: expected a 2-D input (the reference only feeds (B, features))")
+    return _MMNT.apply(x, w, b)
+
+
+# ---------------------------------------------------------------------------------------------- activations
+class _ActBwd(Function):
+    @staticmethod
+    def forward(ctx, g, y, act, slope):
+        g, y = canon(g), canon(y)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return _act_bwd_raw(g, y, act, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        if ctx.needs_input_grad[1] and ctx.act in (ACT_TANH, ACT_SIGMOID):
+            raise NotImplementedError("second derivative through tanh/sigmoid is not on the reference path")
+        return _ActBwd.apply(gg, y, ctx.act, ctx.slope), None, None, None
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        xs = canon(x)
+        y = torch.empty_like(xs)
+        check(lib.migan_act_fwd(xs.data_ptr(), y.data_ptr(), xs.numel(), act, slope, _stream()), "act_fwd")
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _ActBwd.apply(g, y, ctx.act, ctx.slope), None, None
+
+
+def activation(x, act, slope=0.0):
+    return _Act.apply(x, int(act), float(slope))
+
+
+class _PReLU(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        xs = canon(x)
+        a = _plain(a)
+        if a.numel() != 1:
+            raise ValueError("PReLU: only the single shared slope of nn.PReLU() is supported")
+        y = torch.empty_like(xs)
+        check(lib.migan_prelu_fwd(xs.data_ptr(), a.data_ptr(), y.data_ptr(), xs.numel(), _stream()), "prelu_fwd")
+        ctx.save_for_backward(xs, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, a = ctx.saved_tensors
+        g = canon(g)
+        dx = torch.empty_like(xs)
+        da = torch.empty_like(a)
+        ws = _ws(lib.migan_reduce_workspace(), xs)
+        check(lib.migan_prelu_bwd(xs.data_ptr(), g.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(),
+                                  ws.data_ptr(), xs.numel(), _stream()), "prelu_bwd")
+        return dx, da
+
+
+def prelu(x, a):
+    return _PReLU.apply(x, a)
+
+
+# ---------------------------------------------------------------------------------------------- normalisation
+class _Norm(Function):
+    """BatchNorm (G=1) / InstanceNorm (G=N) + fused activation + optional residual add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
+                slope):
+        xs = canon(x)
+        gamma, beta = _plain(gamma), _plain(beta)
+        if xs.dim() == 4:
+            N, C, H, W = xs.shape
+            G, P = (N, H * W) if instance else (1, N * H * W)
+        elif xs.dim() == 2:
+            G, P, C = 1, xs.shape[0], xs.shape[1]
+        else:
+            raise ValueError("norm: expected 2-D or 4-D input")
+        st = _stream()
+        if use_batch_stats:
+            if P <= 1 and not instance:
+                raise ValueError("Expected more than 1 value per channel when training")
+            mean = torch.empty(G * C, device=xs.device, dtype=torch.float32)
+            invstd = torch.empty_like(mean)
+            nb = lib.migan_norm_workspace(G, P, C)
+            ws = _ws(nb, xs)
+            check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
+                                       _ptr(running_var), momentum, eps, G, P, C, ws.data_ptr(), nb, st), "norm_stats")
+        else:
+            mean = _plain(running_mean)
+            invstd = torch.rsqrt(_plain(running_var) + eps)
+        rs = canon(res) if res is not None else None
+        y = torch.empty_like(xs)
+        check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                   _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
+        ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
+        ctx.save_for_backward(xs, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, gamma, beta, mean, invstd = ctx.saved_tensors
+        G, P, C, act, slope, batch_stats, affine, has_res = ctx.cfg
+        if not batch_stats:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
+        dy = canon(dy)
+        dx = torch.empty_like(xs)
+        dgamma = torch.empty(C, device=xs.device, dtype=torch.float32) if affine and G == 1 else None
+        dbeta = torch.empty_like(dgamma) if dgamma is not None else None
+        nb = lib.migan_norm_workspace(G, P, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_norm_bwd(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                 _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
+                                 ws.data_ptr(), nb, _stream()), "norm_bwd")
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None
+
+
+def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
+         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0):
+    return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
+                       float(eps), bool(instance), int(act), float(slope))
+
+
+# ---------------------------------------------------------------------------------------------- index remaps
+class _Gather2d(Function):
+    """Standalone ReflectionPad2d / ZeroPad2d / Upsample(scale_factor=2)."""
+
+    @staticmethod
+    def forward(ctx, x, pads, mode):
+        xs = to_nhwc(x)
+        N, C, H, W = xs.shape
+        pt, pl, pb, pr = pads
+        HL, WL = (2 * H, 2 * W) if mode == GATHER_UP2 else (H, W)
+        if mode == GATHER_REFLECT and (max(pt, pb) >= H or max(pl, pr) >= W):
+            raise ValueError("reflection padding must be smaller than the input")
+        Ho, Wo = HL + pt + pb, WL + pl + pr
+        y = _empty_nhwc((N, C, Ho, Wo), xs)
+        check(lib.migan_gather2d_fwd(xs.data_ptr(), y.data_ptr(), N, H, W, C, Ho, Wo, pt, pl, mode, _stream()), "gather2d")
+        ctx.geom = (N, H, W, C, Ho, Wo, pt, pl, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, Ho, Wo, pt, pl, mode = ctx.geom
+        dy = to_nhwc(dy)
+        dx = _empty_nhwc((N, C, H, W), dy)
+        check(lib.migan_gather2d_bwd(dy.data_ptr(), dx.data_ptr(), N, H, W, C, Ho, Wo, pt, pl, mode, _stream()),
+              "gather2d_bwd")
+        return dx, None, None
+
+
+def gather2d(x, pads, mode):
+    return _Gather2d.apply(x, tuple(int(p) for p in pads), int(mode))
+
+
+class _PixelShuffle(Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        xs = to_nhwc(x)
+        N, Crr, H, W = xs.shape
+        if Crr % (r * r):
+            raise ValueError("pixel_shuffle: channels not divisible by r^2")
+        C = Crr // (r * r)
+        y = _empty_nhwc((N, C, H * r, W * r), xs)
+        check(lib.migan_pixel_shuffle(xs.data_ptr(), y.data_ptr(), N, H, W, C, r, 1, _stream()), "pixel_shuffle")
+        ctx.geom = (N, H, W, C, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, r = ctx.geom
+        dy = to_nhwc(dy)
+        dx = _empty_nhwc((N, C * r * r, H, W), dy)
+        check(lib.migan_pixel_shuffle(dy.data_ptr(), dx.data_ptr(), N, H, W, C, r, 0, _stream()), "pixel_unshuffle")
+        return dx, None
+
+
+def pixel_shuffle(x, r):
+    return _PixelShuffle.apply(x, int(r))
+
+
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        xs = to_nhwc(x)
+        N, C, H, W = xs.shape
+        if H % 2 or W % 2:
+            raise ValueError("maxpool2: odd spatial size is not on the reference path")
+        y = _empty_nhwc((N, C, H // 2, W // 2), xs)
+        check(lib.migan_maxpool2_fwd(xs.data_ptr(), y.data_ptr(), N, H, W, C, _stream()), "maxpool2")
+        ctx.save_for_backward(xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xs,) = ctx.saved_tensors
+        N, C, H, W = xs.shape
+        dy = to_nhwc(dy)
+        dx = torch.empty_like(xs)
+        check(lib.migan_maxpool2_bwd(xs.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, C, _stream()), "maxpool2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _CatC(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = to_nhwc(a), to_nhwc(b)
+        N, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        if b.shape[0] != N or b.shape[2:] != a.shape[2:]:
+            raise ValueError("cat: shapes differ outside dim 1")
+        y = _empty_nhwc((N, Ca + Cb, H, W), a)
+        check(lib.migan_cat_channels(a.data_ptr(), b.data_ptr(), y.data_ptr(), N * H * W, Ca, Cb, 1, _stream()), "cat")
+        ctx.geom = (N, Ca, Cb, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, Ca, Cb, H, W = ctx.geom
+        dy = to_nhwc(dy)
+        da = _empty_nhwc((N, Ca, H, W), dy)
+        db = _empty_nhwc((N, Cb, H, W), dy)
+        check(lib.migan_cat_channels(da.data_ptr(), db.data_ptr(), dy.data_ptr(), N * H * W, Ca, Cb, 0, _stream()),
+              "split")
+        return da, db
+
+
+def cat_channels(a, b):
+    return _CatC.apply(a, b)
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a = canon(a)
+        b = canon(b) if b is not None else None
+        if b is not None and b.shape != a.shape:
+            raise ValueError("axpby: shapes differ (no broadcasting on this path)")
+        y = torch.empty_like(a)
+        check(lib.migan_axpby(a.data_ptr(), alpha, _ptr(b), beta, y.data_ptr(), a.numel(), _stream()), "axpby")
+        ctx.ab = (alpha, beta, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta, has_b = ctx.ab
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = g if alpha == 1.0 else _Axpby.apply(g, None, alpha, 0.0)
+        if has_b and ctx.needs_input_grad[1]:
+            gb = g if beta == 1.0 else _Axpby.apply(g, None, beta, 0.0)
+        return ga, gb, None, None
+
+
+def axpby(a, b=None, alpha=1.0, beta=1.0):
+    return _Axpby.apply(a, b, float(alpha), float(beta))
+
+
+def add(a, b):
+    return _Axpby.apply(a, b, 1.0, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------- dropout
+def rand_mask(shape, p, seed, counter, device):
+    """Bernoulli(1-p)/(1-p) mask from the device Philox stream (counter: device uint64 tensor or None)."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    mask = torch.empty(shape, device=device, dtype=torch.float32)
+    check(lib.migan_rand_mask(mask.data_ptr(), n, float(p), int(seed), _ptr(counter), _stream()), "rand_mask")
+    return mask
+
+
+class _MulMask(Function):
+    """y = x * mask; mask is [N,C] (Dropout2d: one draw per plane) or full-size (Dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        xs = canon(x)
+        mask = _plain(mask).contiguous()
+        y = torch.empty_like(xs)
+        ctx.per_plane = xs.dim() == 4 and mask.dim() == 2
+        if ctx.per_plane:
+            N, C, H, W = xs.shape
+            if tuple(mask.shape) != (N, C):
+                raise ValueError("dropout2d mask must be [N, C]")
+            check(lib.migan_mul_nc(xs.data_ptr(), mask.data_ptr(), y.data_ptr(), N, H * W, C, _stream()), "mul_nc")
+        else:
+            if mask.numel() != xs.numel():
+                raise ValueError("dropout mask must match the input")
+            if xs.dim() == 4:
+                mask = to_nhwc(mask.view(xs.shape)) if mask.shape == xs.shape else mask
+            check(lib.migan_mul(xs.data_ptr(), mask.data_ptr(), y.data_ptr(), xs.numel(), _stream()), "mul")
+        ctx.save_for_backward(mask)
+        ctx.shape4 = tuple(xs.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        g = canon(g)
+        dx = torch.empty_like(g)
+        if ctx.per_plane:
+            N, C, H, W = ctx.shape4
+            check(lib.migan_mul_nc(g.data_ptr(), mask.data_ptr(), dx.data_ptr(), N, H * W, C, _stream()), "mul_nc")
+        else:
+            check(lib.migan_mul(g.data_ptr(), mask.data_ptr(), dx.data_ptr(), g.numel(), _stream()), "mul")
+        return dx, None
+
+
+def mul_mask(x, mask):
+    return _MulMask.apply(x, mask)
+
+
+# ---------------------------------------------------------------------------------------------- losses
+class _Loss(Function):
+    """mean-reduced BCELoss / MSELoss / L1Loss / plain mean; target tensor or constant."""
+
+    @staticmethod
+    def forward(ctx, x, target, kind, tconst):
+        xs = canon(x)
+        t = None
+        if target is not None:
+            t = canon(target)
+            if t.shape != xs.shape:
+                raise ValueError("loss: target shape %s != input shape %s" % (tuple(t.shape), tuple(xs.shape)))
+        out = torch.empty((), device=xs.device, dtype=torch.float32)
+        nb = lib.migan_reduce_workspace()
+        ws = _ws(nb, xs)
+        check(lib.migan_loss_fwd(kind, xs.data_ptr(), _ptr(t), tconst, out.data_ptr(), xs.numel(), ws.data_ptr(), nb,
+                                 _stream()), "loss_fwd")
+        ctx.kind, ctx.tconst = kind, tconst
+        ctx.save_for_backward(xs, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, t = ctx.saved_tensors
+        g = _plain(g).contiguous()
+        dx = torch.empty_like(xs)
+        check(lib.migan_loss_bwd(ctx.kind, xs.data_ptr(), _ptr(t), ctx.tconst, g.data_ptr(), dx.data_ptr(), xs.numel(),
+                                 _stream()), "loss_bwd")
+        return dx, None, None, None
+
+
+def loss(kind, x, target=None, tconst=0.0):
+    return _Loss.apply(x, target, int(kind), float(tconst))
+
+
+def mean(x):
+    return _Loss.apply(x, None, LOSS_MEAN, 0.0)
+
+
+class _RowNorm(Function):
+    @staticmethod
+    def forward(ctx, x):
+        xs = canon(x)
+        B, D = xs.shape
+        out = torch.empty(B, device=xs.device, dtype=torch.float32)
+        check(lib.migan_rownorm_fwd(xs.data_ptr(), out.data_ptr(), B, D, _stream()), "rownorm")
+        ctx.save_for_backward(xs, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dn):
+        xs, nrm = ctx.saved_tensors
+        dn = _plain(dn).contiguous()
+        B, D = xs.shape
+        dx = torch.empty_like(xs)
+        check(lib.migan_rownorm_bwd(xs.data_ptr(), nrm.data_ptr(), dn.data_ptr(), dx.data_ptr(), B, D, _stream()),
+              "rownorm_bwd")
+        return dx
+
+
+def rownorm(x):
+    return _RowNorm.apply(x)
+
+
+def rowscale(x, s):
+    """y[b,:] = x[b,:]*s[b] (no autograd; used for the WGAN-GP interpolation of detached samples)."""
+    xs = canon(x)
+    B = xs.shape[0]
+    D = xs.numel() // B
+    y = torch.empty_like(xs)
+    s = _plain(s).reshape(B).contiguous()
+    check(lib.migan_rowscale(xs.data_ptr(), s.data_ptr(), y.data_ptr(), B, D, _stream()), "rowscale")
+    return y
+
+
+class _Relayout(Function):
+    """Differentiable NCHW<->NHWC re-layout (gradient passes through; layouts are free in autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, to_cl):
+        return to_nhwc(x) if to_cl else to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def relayout(x, channels_last):
+    return _Relayout.apply(x, bool(channels_last))

@@ -1,0 +1,442 @@
+"""Drop-in `torch.nn` layer set for the reference GAN model definitions, backed by libmigan.so.
+
+Usage mirrors the reference scripts:
+
+    import pytorch_gan_amd.nn as nn          # instead of `import torch.nn as nn`
+    nn.Conv2d(128, 128, 3, stride=1, padding=1); nn.BatchNorm2d(128, 0.8); nn.LeakyReLU(0.2, inplace=True) ...
+
+or, for a model that was already built from stock torch.nn layers (the reference's `Generator()`,
+`GeneratorResNet(...)`, ...):  `swap(model)` re-classes every supported leaf in place.  Parameters, buffers,
+`state_dict` keys/shapes, class-name substrings used by `weights_init_normal` (dcgan.py:36-42) and the
+module tree are unchanged.
+
+`Sequential` applies run-time peephole fusion over its unchanged child list:
+  [Upsample(2)] [ZeroPad2d|ReflectionPad2d] Conv2d [LeakyReLU|ReLU|Tanh|Sigmoid]  -> one conv launch
+  BatchNorm/InstanceNorm [LeakyReLU|ReLU]                                           -> stats + one apply pass
+"""
+import contextlib
+
+import torch
+import torch.nn as tnn
+
+from . import functional as F
+
+_FUSE = True
+
+
+def set_fusion(enabled):
+    """Enable/disable Sequential peephole fusion (both modes give the same results up to fp32 rounding)."""
+    global _FUSE
+    _FUSE = bool(enabled)
+
+
+# ----------------------------------------------------------------------------------------------- GanTensor
+class GanTensor(torch.Tensor):
+    """Marks a channels_last activation produced by this package.
+
+    The reference model code mixes raw tensor ops with layers: `out.view(B, -1)` (dcgan.py:96),
+    `x + self.block(x)` (cyclegan/models.py:37), `torch.add(out1, out2)` (srgan/models.py:68),
+    `torch.cat((x, skip), 1)` (pix2pix/models.py:50,132).  This subclass routes exactly those calls to
+    the HIP kernels (and makes `.view` legal on NHWC storage); every other op runs unchanged and
+    returns a plain tensor.
+    """
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        with torch._C.DisableTorchFunctionSubclass():
+            handler = _OVERRIDES.get(func)
+            if handler is not None:
+                out = handler(args, kwargs)
+                if out is not NotImplemented:
+                    return out
+            return func(*args, **kwargs)
+
+
+def _is_act4(t):
+    return isinstance(t, torch.Tensor) and t.dim() == 4 and t.is_cuda and t.dtype == torch.float32
+
+
+def _h_view(func):
+    def handler(args, kwargs):
+        x = args[0]
+        if _is_act4(x) and not x.is_contiguous():
+            return func(F.relayout(x, False), *args[1:], **kwargs)
+        return NotImplemented
+
+    return handler
+
+
+def _h_add(args, kwargs):
+    if len(args) != 2 or kwargs:
+        return NotImplemented
+    a, b = args
+    if _is_act4(a) and _is_act4(b) and a.shape == b.shape:
+        return _wrap(F.add(a, b))
+    return NotImplemented
+
+
+def _h_cat(args, kwargs):
+    tensors = args[0]
+    dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+    if dim != 1 or len(tensors) < 2 or not all(_is_act4(t) for t in tensors):
+        return NotImplemented
+    out = tensors[0]
+    for t in tensors[1:]:
+        out = F.cat_channels(out, t)
+    return _wrap(out)
+
+
+_OVERRIDES = {
+    torch.Tensor.view: _h_view(torch.Tensor.view),
+    torch.Tensor.reshape: _h_view(torch.Tensor.reshape),
+    torch.Tensor.flatten: _h_view(torch.Tensor.flatten),
+    torch.flatten: _h_view(torch.flatten),
+    torch.reshape: _h_view(torch.reshape),
+    torch.Tensor.add: _h_add,
+    torch.Tensor.__add__: _h_add,
+    torch.Tensor.__radd__: _h_add,
+    torch.add: _h_add,
+    torch.cat: _h_cat,
+}
+
+
+def _wrap(y):
+    if type(y) is torch.Tensor and y.dim() == 4 and not y.is_contiguous():
+        return y.as_subclass(GanTensor)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------- helpers
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def _act_of(m):
+    """(act code, slope) for activation modules that can ride in a conv / norm epilogue."""
+    if isinstance(m, tnn.LeakyReLU):
+        return F.ACT_LRELU, float(m.negative_slope)
+    if isinstance(m, tnn.ReLU):
+        return F.ACT_RELU, 0.0
+    if isinstance(m, tnn.Tanh):
+        return F.ACT_TANH, 0.0
+    if isinstance(m, tnn.Sigmoid):
+        return F.ACT_SIGMOID, 0.0
+    return None
+
+
+# ----------------------------------------------------------------------------------------------- layers
+class Conv2d(tnn.Conv2d):
+    def _check(self):
+        if self.groups != 1 or _pair(self.dilation) != (1, 1) or self.padding_mode != "zeros":
+            raise ValueError("Conv2d: groups/dilation/padding_mode outside the reference path")
+        s = _pair(self.stride)
+        if s[0] != s[1] or s[0] not in (1, 2):
+            raise ValueError("Conv2d: stride must be 1 or 2")
+        if isinstance(self.padding, str):
+            raise ValueError("Conv2d: string padding is not supported")
+        return s[0], _pair(self.padding)
+
+    def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0):
+        stride, (ph, pw) = self._check()
+        if gather == F.GATHER_REFLECT and (ph or pw):
+            raise ValueError("reflection gather cannot be combined with conv zero padding")
+        pads = (pre_pads[0] + ph, pre_pads[1] + pw, pre_pads[2] + ph, pre_pads[3] + pw)
+        return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope))
+
+    def forward(self, x):
+        return self.fused_forward(x)
+
+
+class ConvTranspose2d(tnn.ConvTranspose2d):
+    def forward(self, x, output_size=None, act=F.ACT_NONE, slope=0.0):
+        s, p = _pair(self.stride), _pair(self.padding)
+        if (self.groups != 1 or _pair(self.dilation) != (1, 1) or _pair(self.output_padding) != (0, 0)
+                or output_size is not None or s[0] != s[1] or p[0] != p[1] or s[0] not in (1, 2)):
+            raise ValueError("ConvTranspose2d: configuration outside the reference path")
+        return _wrap(F.conv_transpose2d(x, self.weight, self.bias, s[0], p[0], act, slope))
+
+
+class Linear(tnn.Linear):
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class _BatchNormMixin:
+    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None):
+        if self.momentum is None:
+            raise ValueError("BatchNorm: cumulative moving average (momentum=None) is not on the reference path")
+        use_batch = self.training or not self.track_running_stats
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        y = F.norm(x, self.weight if self.affine else None, self.bias if self.affine else None, res,
+                   rm if (self.training or not use_batch) else None, rv if (self.training or not use_batch) else None,
+                   use_batch, self.momentum, self.eps, False, act, slope)
+        return _wrap(y)
+
+    def forward(self, x):
+        self._check_input_dim(x)
+        return self.fused_forward(x)
+
+
+class BatchNorm2d(_BatchNormMixin, tnn.BatchNorm2d):
+    pass
+
+
+class BatchNorm1d(_BatchNormMixin, tnn.BatchNorm1d):
+    def _check_input_dim(self, x):
+        if x.dim() != 2:
+            raise ValueError("BatchNorm1d: expected (B, C) input on this path, got %dD" % x.dim())
+
+
+class InstanceNorm2d(tnn.InstanceNorm2d):
+    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None):
+        if self.affine or self.track_running_stats:
+            raise ValueError("InstanceNorm2d: affine/track_running_stats are not on the reference path")
+        if x.dim() != 4:
+            raise ValueError("InstanceNorm2d: expected 4D input")
+        return _wrap(F.norm(x, None, None, res, None, None, True, 0.1, self.eps, True, act, slope))
+
+    def forward(self, x):
+        return self.fused_forward(x)
+
+
+class LeakyReLU(tnn.LeakyReLU):
+    def forward(self, x):
+        return _wrap(F.activation(x, F.ACT_LRELU, self.negative_slope))
+
+
+class ReLU(tnn.ReLU):
+    def forward(self, x):
+        return _wrap(F.activation(x, F.ACT_RELU))
+
+
+class Tanh(tnn.Tanh):
+    def forward(self, x):
+        return _wrap(F.activation(x, F.ACT_TANH))
+
+
+class Sigmoid(tnn.Sigmoid):
+    def forward(self, x):
+        return _wrap(F.activation(x, F.ACT_SIGMOID))
+
+
+class PReLU(tnn.PReLU):
+    def forward(self, x):
+        return _wrap(F.prelu(x, self.weight))
+
+
+class Upsample(tnn.Upsample):
+    def _check(self):
+        sf = self.scale_factor
+        sf = sf if not isinstance(sf, (tuple, list)) else (sf[0] if sf[0] == sf[1] else None)
+        if self.size is not None or sf is None or float(sf) != 2.0 or self.mode != "nearest":
+            raise ValueError("Upsample: only scale_factor=2, mode='nearest' is on the reference path")
+
+    def forward(self, x):
+        self._check()
+        return _wrap(F.gather2d(x, (0, 0, 0, 0), F.GATHER_UP2))
+
+
+def _pads_tlbr(padding):
+    """torch pad order (left, right, top, bottom) -> (top, left, bottom, right)."""
+    if isinstance(padding, int):
+        return (padding,) * 4
+    l, r, t, b = padding
+    return (int(t), int(l), int(b), int(r))
+
+
+class ReflectionPad2d(tnn.ReflectionPad2d):
+    def forward(self, x):
+        return _wrap(F.gather2d(x, _pads_tlbr(self.padding), F.GATHER_REFLECT))
+
+
+class ZeroPad2d(tnn.ZeroPad2d):
+    def forward(self, x):
+        return _wrap(F.gather2d(x, _pads_tlbr(self.padding), F.GATHER_ZERO))
+
+
+class PixelShuffle(tnn.PixelShuffle):
+    def forward(self, x):
+        return _wrap(F.pixel_shuffle(x, self.upscale_factor))
+
+
+class MaxPool2d(tnn.MaxPool2d):
+    def forward(self, x):
+        if (_pair(self.kernel_size) != (2, 2) or _pair(self.stride) != (2, 2) or _pair(self.padding) != (0, 0)
+                or _pair(self.dilation) != (1, 1) or self.ceil_mode or self.return_indices):
+            raise ValueError("MaxPool2d: only kernel 2 / stride 2 (VGG19) is on the reference path")
+        return _wrap(F.maxpool2(x))
+
+
+# ---- dropout: device Philox stream for training runs, injected host masks for parity tests ---------
+class _DropoutRNG:
+    seed = 0x5EED
+    counters = {}
+    injected = None  # list of host/device masks consumed in call order (parity tests)
+
+    @classmethod
+    def counter(cls, device):
+        key = str(device)
+        if key not in cls.counters:
+            cls.counters[key] = torch.zeros(1, dtype=torch.int64, device=device)
+        return cls.counters[key]
+
+
+def manual_seed(seed):
+    """Seed the device dropout stream (independent of torch's generators)."""
+    _DropoutRNG.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    for c in _DropoutRNG.counters.values():
+        c.zero_()
+
+
+@contextlib.contextmanager
+def dropout_masks(masks):
+    """Feed pre-drawn masks (already scaled by 1/(1-p)) to the next Dropout/Dropout2d calls, in order."""
+    prev = _DropoutRNG.injected
+    _DropoutRNG.injected = list(masks)
+    try:
+        yield
+    finally:
+        _DropoutRNG.injected = prev
+
+
+def _next_mask(shape, p, device):
+    if _DropoutRNG.injected is not None:
+        if not _DropoutRNG.injected:
+            raise RuntimeError("dropout_masks(): more dropout calls than injected masks")
+        m = _DropoutRNG.injected.pop(0)
+        m = torch.as_tensor(m, dtype=torch.float32).to(device)
+        if tuple(m.shape) != tuple(shape):
+            raise ValueError("injected dropout mask has shape %s, expected %s" % (tuple(m.shape), tuple(shape)))
+        return m
+    return F.rand_mask(shape, p, _DropoutRNG.seed, _DropoutRNG.counter(device), device)
+
+
+class Dropout2d(tnn.Dropout2d):
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if x.dim() != 4:
+            raise ValueError("Dropout2d: expected 4D input")
+        mask = _next_mask((x.shape[0], x.shape[1]), self.p, x.device)
+        return _wrap(F.mul_mask(x, mask))
+
+
+class Dropout(tnn.Dropout):
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        mask = _next_mask(tuple(x.shape), self.p, x.device)
+        return _wrap(F.mul_mask(x, mask))
+
+
+# ---- losses (torch.nn.BCELoss / MSELoss / L1Loss with the default 'mean' reduction) ------------------
+class _MeanLoss(tnn.Module):
+    kind = None
+
+    def __init__(self, reduction="mean"):
+        super().__init__()
+        if reduction != "mean":
+            raise ValueError("only reduction='mean' is on the reference path")
+
+    def forward(self, x, target):
+        if target.requires_grad:
+            raise ValueError("loss target must not require grad (detach it, as the reference does)")
+        return F.loss(self.kind, x, target)
+
+
+class BCELoss(_MeanLoss):
+    kind = F.LOSS_BCE
+
+
+class MSELoss(_MeanLoss):
+    kind = F.LOSS_MSE
+
+
+class L1Loss(_MeanLoss):
+    kind = F.LOSS_L1
+
+
+# ----------------------------------------------------------------------------------------------- Sequential
+class Sequential(tnn.Sequential):
+    """nn.Sequential with run-time peephole fusion over the unchanged child list."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        if not _FUSE:
+            for m in mods:
+                x = m(x)
+            return x
+        i, n = 0, len(mods)
+        while i < n:
+            m = mods[i]
+            # -- [Upsample] [ZeroPad2d | ReflectionPad2d] Conv2d [act] ------------------------------------
+            j, gather, pre = i, F.GATHER_ZERO, (0, 0, 0, 0)
+            if isinstance(mods[j], Upsample) and j + 1 < n:
+                mods[j]._check()
+                gather, j = F.GATHER_UP2, j + 1
+            if j < n and isinstance(mods[j], ZeroPad2d) and j + 1 < n:
+                pre, j = _pads_tlbr(mods[j].padding), j + 1
+            elif j < n and isinstance(mods[j], ReflectionPad2d) and gather == F.GATHER_ZERO and j + 1 < n:
+                pre, gather, j = _pads_tlbr(mods[j].padding), F.GATHER_REFLECT, j + 1
+            if j < n and isinstance(mods[j], Conv2d) and not (gather == F.GATHER_REFLECT and any(_pair(mods[j].padding))):
+                act, slope, k = F.ACT_NONE, 0.0, j + 1
+                if k < n and _act_of(mods[k]) is not None and type(mods[k]) in _OURS:
+                    (act, slope), k = _act_of(mods[k]), k + 1
+                x = mods[j].fused_forward(x, pre, gather, act, slope)
+                i = k
+                continue
+            # -- Norm [LeakyReLU | ReLU] -------------------------------------------------------------------
+            if isinstance(m, (BatchNorm2d, BatchNorm1d, InstanceNorm2d)):
+                act, slope, k = F.ACT_NONE, 0.0, i + 1
+                if k < n and isinstance(mods[k], (LeakyReLU, ReLU)):
+                    (act, slope), k = _act_of(mods[k]), k + 1
+                if isinstance(m, (BatchNorm2d, BatchNorm1d)):
+                    m._check_input_dim(x)
+                x = m.fused_forward(x, act, slope)
+                i = k
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
+_SWAP = {
+    tnn.Conv2d: Conv2d, tnn.ConvTranspose2d: ConvTranspose2d, tnn.Linear: Linear, tnn.BatchNorm2d: BatchNorm2d,
+    tnn.BatchNorm1d: BatchNorm1d, tnn.InstanceNorm2d: InstanceNorm2d, tnn.LeakyReLU: LeakyReLU, tnn.ReLU: ReLU,
+    tnn.Tanh: Tanh, tnn.Sigmoid: Sigmoid, tnn.PReLU: PReLU, tnn.Upsample: Upsample,
+    tnn.ReflectionPad2d: ReflectionPad2d, tnn.ZeroPad2d: ZeroPad2d, tnn.PixelShuffle: PixelShuffle,
+    tnn.MaxPool2d: MaxPool2d, tnn.Dropout: Dropout, tnn.Dropout2d: Dropout2d, tnn.Sequential: Sequential,
+    tnn.BCELoss: BCELoss, tnn.MSELoss: MSELoss, tnn.L1Loss: L1Loss,
+}
+_OURS = set(_SWAP.values())
+
+
+def swap(module):
+    """Re-class every supported stock torch.nn leaf (and Sequential container) of `module` in place.
+
+    Unsupported layer types are left untouched only if they hold no parameters and are containers of the
+    reference (Generator, ResidualBlock, ...); an unsupported *leaf* raises, so a swapped model can never
+    silently run a layer on ATen.
+    """
+    for m in module.modules():
+        cls = type(m)
+        if cls in _SWAP:
+            if cls in (tnn.BCELoss, tnn.MSELoss, tnn.L1Loss) and m.reduction != "mean":
+                raise ValueError("swap: loss reduction %r is not supported" % m.reduction)
+            m.__class__ = _SWAP[cls]
+        elif cls in _OURS:
+            continue
+        elif cls.__module__.startswith("torch.nn") and len(list(m.children())) == 0:
+            raise NotImplementedError("swap: no HIP implementation for leaf layer %s" % cls.__name__)
+    return module
+
+
+# re-exports so that `import pytorch_gan_amd.nn as nn` covers what the reference model files touch
+Module = tnn.Module
+ModuleList = tnn.ModuleList
+Parameter = tnn.Parameter
+init = tnn.init
