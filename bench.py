@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""Headline benchmark: DCGAN 64x64, batch 128 per GPU, fp32 training step (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full iteration of the reference loop dcgan.py:143-183 (G forward/backward/Adam, three D
+forwards, D backward/Adam) on synthetic data resident in HBM, every op in libmigan.so.  The step is captured
+once as a hipGraph and replayed (N>1: graph segments with the RCCL all-reduce + fused Adam between them on a
+side stream).  Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline accounting.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+IMG, BATCH, LATENT, CH = 64, 128, 100, 1
+PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
+
+
+def dcgan_flops_per_image():
+    """Algorithmic FLOPs/img of one training step (step = 3*G_fwd + 8*D_fwd)."""
+    s = IMG // 4
+    g = 2 * LATENT * 128 * s * s + 2 * (2 * s) ** 2 * 128 * 128 * 9 + 2 * (4 * s) ** 2 * 64 * 128 * 9 \
+        + 2 * (4 * s) ** 2 * CH * 64 * 9
+    d, h, cin = 0, IMG, CH
+    for cout in (16, 32, 64, 128):
+        h //= 2
+        d += 2 * h * h * cout * cin * 9
+        cin = cout
+    d += 2 * 128 * h * h
+    return 3 * g + 8 * d
+
+
+def build_state(dp, seed):
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(seed)
+    G = models.DcganGenerator(IMG, LATENT, CH)
+    D = models.DcganDiscriminator(IMG, CH)
+    G.apply(models.init_normal_dcgan)   # dcgan.py:115-116
+    D.apply(models.init_normal_dcgan)
+    init = (copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict()))
+    G, D = G.cuda(), D.cuda()
+    if dp.world > 1:
+        dp.broadcast_parameters(G, D)
+    return steps.make_gan_state(G, D, LATENT, skip_dead_grads=True, dp=dp), init
+
+
+class ConvProfiler:
+    """Times every conv-family launch with HIP events on the launch stream and attributes it to the kernel
+    symbol the library will pick (migan_igemm_tile_code), with its algorithmic FLOPs."""
+
+    def __init__(self):
+        from pytorch_gan_amd._lib import lib
+
+        self.lib, self.records, self.orig = lib, [], {}
+
+    def _wrap(self, name, describe):
+        fn = getattr(self.lib, name)
+        self.orig[name] = fn
+
+        def wrapper(*a):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = fn(*a)
+            e1.record(st)
+            self.records.append((describe(a), e0, e1))
+            return rc
+
+        setattr(self.lib, name, wrapper)
+
+    def __enter__(self):
+        tc = self.lib.migan_igemm_tile_code
+
+        def fwd(a):
+            N, Hi, Wi, Ci, Ho, Wo, Co, R, S = a[4:13]
+            code = tc(N * Ho * Wo, Co, Ci, 1)
+            return ("igemm_%d" % code, 2.0 * N * Ho * Wo * Co * Ci * R * S)
+
+        def dgrad(a):
+            N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride = a[4:14]
+            ncls = stride * stride
+            maxm = N * ((Hi + stride - 1) // stride) * ((Wi + stride - 1) // stride)
+            code = tc(maxm, Ci, Co, ncls)
+            return ("igemm_%d" % code, 2.0 * N * Ho * Wo * Co * Ci * R * S)
+
+        def wgrad(a):
+            N, Hi, Wi, Ci, Ho, Wo, Co, R, S = a[5:14]
+            big = Co > 64 and R * S * Ci > 64
+            vec = Ci % 4 == 0 and Co % 4 == 0
+            return ("wgrad_%d_%s" % (128 if big else 64, "vec" if vec else "gen"), 2.0 * N * Ho * Wo * Co * Ci * R * S)
+
+        self._wrap("migan_conv2d_fwd", fwd)
+        self._wrap("migan_conv2d_dgrad", dgrad)
+        self._wrap("migan_conv2d_wgrad", wgrad)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.orig.items():
+            setattr(self.lib, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for (sym, flops), e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += ms
+            d["flops"] += flops
+        return agg
+
+
+def cpu_baseline(init, seconds_budget=25.0):
+    """The oracle (CPU restatement of dcgan.py:143-183 on stock torch) timed on this box's host cores,
+    starting from the same initial weights as the GPU run."""
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+
+    G, D = M.DcganGenerator(IMG, LATENT, CH), M.DcganDiscriminator(IMG, CH)
+    G.load_state_dict(init[0])
+    D.load_state_dict(init[1])
+    s = S.SimpleNamespace(G=G, D=D, opt_G=S._adam(G.parameters()), opt_D=S._adam(D.parameters()),
+                          bce=torch.nn.BCELoss(), latent_dim=LATENT)
+    threads = torch.get_num_threads()
+    torch.manual_seed(1)
+    np.random.seed(1)
+    imgs = torch.rand(BATCH, CH, IMG, IMG) * 2 - 1
+    S.dcgan_step(s, imgs)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        S.dcgan_step(s, imgs)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 20:
+            break
+    return {"value": round(BATCH * n / el, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d full dcgan steps (bs %d, %dx%d) after 1 warm-up, %.1f s, torch CPU fp32, %d threads"
+                      % (n, BATCH, IMG, IMG, el, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from pytorch_gan_amd import dp as dpmod
+    from pytorch_gan_amd import graph as gmod
+    from pytorch_gan_amd import steps
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    dp = dpmod.init_from_env()
+    world = dp.world
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)" % (args.gpus, world))
+    rank = dp.rank
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    state, init = build_state(dp, seed=0)
+    rng = np.random.RandomState(1234 + rank)
+    real = torch.from_numpy(rng.uniform(-1, 1, (BATCH, CH, IMG, IMG)).astype(np.float32)).to(dev)
+    nz = args.warmup + args.steps + 8
+    zs = torch.from_numpy(rng.normal(0, 1, (nz, BATCH, LATENT)).astype(np.float32)).to(dev)
+    z_static = zs[0].clone()
+
+    runner = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=not args.no_graph)
+    runner.prepare()
+
+    def one_step(i):
+        z_static.copy_(zs[i % nz])
+        return runner.run()
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v) for k, v in out.items() if k.endswith("loss")}
+    if not all(np.isfinite(v) for v in losses.values()):
+        raise SystemExit("non-finite loss in the timed region: %s" % losses)
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * BATCH * args.steps / elapsed
+    flops_img = dcgan_flops_per_image()
+    result = {
+        "metric": "training images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "implementations/dcgan 64x64 bs=128 per GPU fp32 (dcgan.py:143-183 full step)",
+                   "global_batch": world * BATCH, "parallelism": "dp%d" % world, "hipgraph": runner.graphed,
+                   "gflop_per_image": round(flops_img / 1e9, 4)},
+        "step_mfma_frac": round(flops_img * BATCH * args.steps / elapsed / (PEAK_TFLOPS * 1e12), 4),
+        "losses": losses,
+    }
+
+    if runner.capture_error:
+        result["config"]["hipgraph_error"] = runner.capture_error[:200]
+
+    if not args.no_roofline:
+        # per-kernel accounting: eager runs of the same step with HIP events (on the launch stream) around every
+        # conv-family launch; every rank runs the steps (collectives), rank 0 records
+        import contextlib
+
+        eager = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=False)
+        nprof, agg = 5, {}
+        with (ConvProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
+            for i in range(nprof):
+                z_static.copy_(zs[i])
+                eager.run()
+            torch.cuda.synchronize()
+            if rank == 0:
+                agg = prof.summary()
+        if agg:
+            dom = max(agg, key=lambda k: agg[k]["ms"])
+            d = agg[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // nprof,
+                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "all_conv_kernels": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "tflops": round(
+                    v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches_per_step": v["launches"] // nprof}
+                    for k, v in sorted(agg.items())},
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(init)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,7 @@ _SIGS = {
     "migan_error_string": (c_char_p, [c_int]),
     "migan_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 14 + [c_float, P]),
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
+    "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
     "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 13 + [P]),
     "migan_norm_workspace": (c_size_t, [c_int] * 3),

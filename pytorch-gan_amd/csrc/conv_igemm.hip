@@ -275,6 +275,29 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
     return 0;
 }
 
+// Tile selection (pure function of the GEMM shape; also exported for the bench's per-kernel accounting).
+// code = fast*1000000 + BM*1000 + BN
+static int igemm_select(long maxM, int Co, bool fast, int ncls) {
+    if (fast) {
+        if (Co > 64) {
+            long blocks = (long)cdiv(maxM, 128) * cdiv(Co, 128) * ncls;
+            return blocks < 384 ? 1064064 : 1128128;
+        }
+        if (Co > 32) {
+            long blocks = (long)cdiv(maxM, 128) * ncls;
+            return blocks < 384 ? 1064064 : 1128064;
+        }
+        return 1128032;
+    }
+    if (Co > 64) return 128128;
+    if (Co > 32) return 128064;
+    return 128032;
+}
+
+MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls) {
+    return igemm_select((long)maxM, Co, Ci_src % 32 == 0, ncls);
+}
+
 static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
                         hipStream_t st) {
     bool fast = (g.Ci % 32 == 0) && (g.ldw % 4 == 0);
@@ -284,22 +307,15 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
         long m = (long)g.N * g.Ho[c] * g.Wo[c];
         if (m > maxM) maxM = m;
     }
-    if (fast) {
-        if (g.Co > 64) {
-            long blocks = (long)cdiv(maxM, 128) * cdiv(g.Co, 128) * g.ncls;
-            if (blocks < 384) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-            return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
-        }
-        if (g.Co > 32) {
-            long blocks = (long)cdiv(maxM, 128) * g.ncls;
-            if (blocks < 384) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-            return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-        }
-        return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+    switch (igemm_select(maxM, g.Co, fast, g.ncls)) {
+        case 1128128: return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
+        case 1128064: return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+        case 1064064: return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+        case 1128032: return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+        case 128128: return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
+        case 128064: return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
+        default: return launch_cfg<128, 32, 4, 1, false>(g, A, Bw, bias, C, st);
     }
-    if (g.Co > 64) return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
-    if (g.Co > 32) return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
-    return launch_cfg<128, 32, 4, 1, false>(g, A, Bw, bias, C, st);
 }
 
 // ------------------------------------------------------------------------------------------------

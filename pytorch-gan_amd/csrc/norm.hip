@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     if (p1 > P) p1 = P;
     const float* xb = x + (size_t)g * P * C;
     const float* dyb = BWD ? dy + (size_t)g * P * C : nullptr;
+    // forward: sums are taken around the chunk's first pixel K (shifted data) so that E[x^2]-E[x]^2 does not
+    // cancel; the finalize kernel merges the per-chunk (n, mean, M2) triples in double (Chan et al.).
+    float shift[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) shift[v] = (!BWD && cok && p0 < P) ? xb[(size_t)p0 * C + c + v] : 0.f;
     if (cok) {
         for (int p = p0 + ty; p < p1; p += TY) {
             float xv[VW], dv[VW];
@@ -69,8 +74,9 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                     s0[v] += d;
                     s1[v] += d * xh;
                 } else {
-                    s0[v] += xv[v];
-                    s1[v] += xv[v] * xv[v];
+                    float d = xv[v] - shift[v];
+                    s0[v] += d;
+                    s1[v] += d * d;
                 }
             }
         }
@@ -89,51 +95,81 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                 a += red[0][(y * CTX + tx) * VW + v];
                 b += red[1][(y * CTX + tx) * VW + v];
             }
-            size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 2;
+            size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 3;
             part[o] = a;
             part[o + 1] = b;
+            part[o + 2] = shift[v];
         }
     }
 }
 
-// pass 2 (forward): merge chunks in double, write mean / invstd, update running stats.
-__global__ void norm_finalize_fwd_kernel(const float* __restrict__ part, float* __restrict__ mean,
-                                         float* __restrict__ invstd, float* running_mean,
-                                         float* running_var, int G, int P, int C, int nchunks, float eps,
-                                         float momentum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * C) return;
-    int g = i / C, c = i - g * C;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        size_t o = (((size_t)g * nchunks + k) * C + c) * 2;
-        s += (double)part[o];
-        q += (double)part[o + 1];
+// pass 2 (forward): ONE WAVE per (g,c) merges the per-chunk (n, mean, M2) triples in double (lanes stride over
+// chunks, then a butterfly of Chan merges), writes mean / invstd and updates the running statistics.
+__device__ __forceinline__ void chan_merge(double& n, double& m, double& M2, double n2, double m2, double M22) {
+    double nn = n + n2;
+    if (nn > 0.0 && n2 > 0.0) {
+        double delta = m2 - m;
+        m += delta * n2 / nn;
+        M2 += M22 + delta * delta * n * n2 / nn;
+        n = nn;
     }
-    double m = s / P;
-    double var = q / P - m * m;
-    if (var < 0.0) var = 0.0;
+}
+__global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __restrict__ part,
+                                                                float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* running_mean,
+                                                                float* running_var, int G, int P, int C,
+                                                                int nchunks, int chunk, float eps, float momentum) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= G * C) return;  // wave-uniform
+    const int g = i / C, c = i - g * C;
+    double n = 0.0, m = 0.0, M2 = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
+        int p0 = k * chunk, p1 = p0 + chunk;
+        if (p1 > P) p1 = P;
+        double nk = (double)(p1 - p0);
+        if (nk <= 0.0) continue;
+        double s = (double)part[o], q = (double)part[o + 1], K = (double)part[o + 2];
+        double M2k = q - s * s / nk;
+        if (M2k < 0.0) M2k = 0.0;
+        chan_merge(n, m, M2, nk, K + s / nk, M2k);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double n2 = __shfl_xor(n, off), m2 = __shfl_xor(m, off), M22 = __shfl_xor(M2, off);
+        if (n == 0.0) { n = n2; m = m2; M2 = M22; }
+        else chan_merge(n, m, M2, n2, m2, M22);
+    }
+    if (lane != 0) return;
+    double var = M2 / P;
     mean[i] = (float)m;
     invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean && G == 1) {
-        double unb = P > 1 ? var * ((double)P / (double)(P - 1)) : var;
+        double unb = P > 1 ? M2 / (double)(P - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
 }
 
-// pass 2 (backward): merge chunks -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1.
-__global__ void norm_finalize_bwd_kernel(const float* __restrict__ part, float* __restrict__ sums,
-                                         float* dgamma, float* dbeta, int G, int C, int nchunks) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// pass 2 (backward): one wave per (g,c) -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1.
+__global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __restrict__ part,
+                                                                float* __restrict__ sums, float* dgamma,
+                                                                float* dbeta, int G, int C, int nchunks) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= G * C) return;
-    int g = i / C, c = i - g * C;
+    const int g = i / C, c = i - g * C;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        size_t o = (((size_t)g * nchunks + k) * C + c) * 2;
+    for (int k = lane; k < nchunks; k += 64) {
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
         a += (double)part[o];
         b += (double)part[o + 1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane != 0) return;
     sums[(size_t)i * 2] = (float)a;
     sums[(size_t)i * 2 + 1] = (float)b;
     if (G == 1) {
@@ -235,7 +271,7 @@ static void norm_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, int& n
     int TY = 256 / CTX;
     // aim for ~2048 blocks total, at least 4 pixels per ty lane
     long blocks_other = (long)gx * G;
-    long want = cdiv(2048, blocks_other);
+    long want = cdiv(1024, blocks_other);
     long maxc = cdiv(P, (long)TY * 4);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
@@ -246,7 +282,7 @@ static void norm_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, int& n
 MIGAN_API size_t migan_norm_workspace(int G, int P, int C) {
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
-    return ((size_t)G * nchunks * C * 2 + (size_t)G * C * 2) * sizeof(float);
+    return ((size_t)G * nchunks * C * 3 + (size_t)G * C * 2) * sizeof(float);
 }
 
 static int grid_for(size_t nvec) {
@@ -272,8 +308,8 @@ MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, ws, mean,
-                       invstd, running_mean, running_var, G, P, C, nchunks, eps, momentum);
+    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
+                       invstd, running_mean, running_var, G, P, C, nchunks, chunk, eps, momentum);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -304,7 +340,7 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
-    float* sums = ws + (size_t)G * nchunks * C * 2;
+    float* sums = ws + (size_t)G * nchunks * C * 3;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
@@ -313,7 +349,7 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
         hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
                            beta, ws, P, C, CTX, chunk, nchunks, act, slope);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, ws, sums,
+    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
                        dgamma, dbeta, G, C, nchunks);
     HIP_LAUNCH_CHECK();
     size_t n = (size_t)G * P * C;

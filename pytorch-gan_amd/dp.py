@@ -1,0 +1,115 @@
+"""Single-node data parallelism for the GAN step: one process per GPU, RCCL over xGMI.
+
+The reference is single-process; this is the MI355X-native scaling layer (§8e):
+  * the minibatch is sharded over ranks (independent samples; every loss is a batch mean),
+  * each optimiser owns ONE flat fp32 gradient bucket (optim.Adam.flat_grad), so the exchange is a single
+    `all_reduce(SUM)` per network per step — G's after `loss_G.backward()`, D's after `loss_D.backward()`,
+  * the all-reduce and the fused Adam update run on a side HIP stream, overlapping the next independent
+    phase on the main stream (the D step consumes `gen.detach()` produced before the G update —
+    dcgan.py:179, cyclegan.py:216-217 — so G's reduce+update overlaps D's forward/backward),
+  * the 1/world_size averaging is folded into the Adam kernel (grad_scale).
+BatchNorm layers use per-rank batch statistics (standard data-parallel behaviour; documented deviation
+from a single-process global batch); InstanceNorm models shard with no semantic change.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class LocalStepper:
+    """world_size == 1: optimiser steps run in place on the current stream."""
+
+    world = 1
+    rank = 0
+
+    def begin_step(self):
+        pass
+
+    def step(self, opt):
+        opt.step()
+
+    def end_step(self):
+        pass
+
+
+class DataParallel:
+    def __init__(self, overlap=True, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DataParallel needs torch.distributed to be initialised (see init_from_env)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.cuda = torch.cuda.is_available() and dist.get_backend(group) == "nccl"
+        self.side = torch.cuda.Stream() if (self.cuda and overlap) else None
+        self._pending = []
+        self._segmenter = None  # set by graph.StepRunner while it records the step
+
+    # -- per-step protocol -------------------------------------------------------------------------
+    def begin_step(self):
+        """Main stream must see every update launched by the previous step before parameters are reused."""
+        self.end_step()
+
+    def step(self, opt):
+        """All-reduce opt.flat_grad (SUM) and apply the update with grads scaled by 1/world."""
+        if self._segmenter is not None:
+            # hipGraph recording: close the current compute segment; the exchange + update replay eagerly
+            self._segmenter.cut(lambda: self._step_now(opt))
+            return
+        self._step_now(opt)
+
+    def _step_now(self, opt):
+        scale = 1.0 / self.world
+        if self.side is None:
+            dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            opt.step(grad_scale=scale)
+            return
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            opt.step(grad_scale=scale)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._pending.append(done)
+
+    def end_step(self):
+        if self._pending:
+            main = torch.cuda.current_stream()
+            for ev in self._pending:
+                main.wait_event(ev)
+            self._pending = []
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def shard(self, t):
+        """This rank's slice of a global batch (dim 0), equal shards."""
+        n = t.shape[0]
+        if n % self.world:
+            raise ValueError("global batch %d is not divisible by world size %d" % (n, self.world))
+        per = n // self.world
+        return t[self.rank * per:(self.rank + 1) * per]
+
+    def broadcast_parameters(self, *modules):
+        """Make every replica start from rank 0's weights/buffers (the reference has a single copy)."""
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+
+def init_from_env(backend=None):
+    """One process per GPU as launched by torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return LocalStepper()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return DataParallel()

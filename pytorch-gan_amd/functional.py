@@ -268,10 +268,10 @@ class _MMNT(Function):
 
     @staticmethod
     def forward(ctx, a, b, bias):
-        a, b, bias = canon(a), canon(b), _plain(bias)
+        # save the ORIGINAL inputs: their autograd history is what makes the backward differentiable again
         ctx.save_for_backward(a, b)
         ctx.has_bias = bias is not None
-        return _mm_nt_raw(a, b, bias)
+        return _mm_nt_raw(canon(a), canon(b), _plain(bias))
 
     @staticmethod
     def backward(ctx, g):
@@ -292,6 +292,7 @@ class _MMTN(Function):
 
     @staticmethod
     def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)  # originals (see _MMNT.forward)
         a, b = canon(a), canon(b)
         P, M = a.shape
         Pb, Nn = b.shape
@@ -302,7 +303,6 @@ class _MMTN(Function):
         ws = _ws(nb, a)
         check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
                                      M, 1, 1, 1, 0, 0, GATHER_ZERO, _stream()), "mm_tn")
-        ctx.save_for_backward(a, b)
         return out
 
     @staticmethod

@@ -197,6 +197,8 @@ class InstanceNorm2d(tnn.InstanceNorm2d):
             raise ValueError("InstanceNorm2d: affine/track_running_stats are not on the reference path")
         if x.dim() != 4:
             raise ValueError("InstanceNorm2d: expected 4D input")
+        if x.shape[2] * x.shape[3] == 1 and self.training:
+            raise ValueError("Expected more than 1 spatial element when training, got input size %s" % (x.shape,))
         return _wrap(F.norm(x, None, None, res, None, None, True, 0.1, self.eps, True, act, slope))
 
     def forward(self, x):
@@ -430,6 +432,10 @@ def swap(module):
             m.__class__ = _SWAP[cls]
         elif cls in _OURS:
             continue
+        elif isinstance(m, tnn.Dropout2d):   # e.g. the oracle's mask-injectable subclasses
+            m.__class__ = Dropout2d
+        elif isinstance(m, tnn.Dropout) and type(m).forward is not tnn.Dropout.forward:
+            m.__class__ = Dropout
         elif cls.__module__.startswith("torch.nn") and len(list(m.children())) == 0:
             raise NotImplementedError("swap: no HIP implementation for leaf layer %s" % cls.__name__)
     return module

@@ -1,0 +1,283 @@
+"""The training-loop bodies on the HIP path: one function per reference script.
+
+Each `*_step` performs exactly the work of one iteration of the reference loop it cites — forwards, losses,
+backward, Adam — on device tensors, with every layer/loss/optimiser op running in libmigan.so.  Host RNG
+draws (z, alpha, replay-buffer picks) stay on the host as in the reference and are passed in / drawn with
+`np.random` / `random`, so a seeded run consumes the same random numbers as the reference.
+
+`skip_dead_grads=True` (default) does not compute gradients that the reference computes and then provably
+discards: the discriminator weight gradients during the generator step (zeroed by `optimizer_D.zero_grad()`
+at dcgan.py:175, cyclegan.py:211,228, srgan.py:135, pix2pix.py:158), the generator gradients inside the
+WGAN-GP critic step (wgan_gp.py:167,173 then zeroed at :176) and VGG weight gradients (srgan.py:128, never
+read).  Results are identical either way (tests run both).
+"""
+import contextlib
+import itertools
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import functional as F
+from . import nn as gnn
+from .dp import LocalStepper
+from .optim import Adam
+
+ADAM = dict(lr=2e-4, betas=(0.5, 0.999))
+
+
+def _dev(a, device):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).to(device)
+
+
+@contextlib.contextmanager
+def frozen(*modules, enabled=True):
+    """Temporarily mark parameters as not requiring grad (skips their wgrad kernels)."""
+    ps = [p for m in modules for p in m.parameters() if p.requires_grad] if enabled else []
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
+def half_sum(a, b):
+    """(a + b) / 2 as the reference writes it (bit-identical: scaling by 0.5 is exact)."""
+    return F.axpby(a, b, 0.5, 0.5)
+
+
+# ------------------------------------------------------------------------------------------------ dcgan / gan
+def make_gan_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
+    """G, D: swapped modules already on the GPU (dcgan.py:106-116 / gan.py:87-93)."""
+    return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
+                           bce=gnn.BCELoss(), latent_dim=latent_dim, skip=skip_dead_grads, labels={},
+                           dp=dp or LocalStepper())
+
+
+def _labels(s, shape, device):
+    key = (tuple(shape), str(device))
+    if key not in s.labels:
+        s.labels[key] = (torch.ones(shape, device=device), torch.zeros(shape, device=device))
+    return s.labels[key]
+
+
+def dcgan_step(s, real_imgs, z):
+    """dcgan.py:143-183 (and gan.py:121-161)."""
+    valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    with frozen(s.D, enabled=s.skip):
+        g_loss = s.bce(s.D(gen), valid)
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    real_loss = s.bce(s.D(real_imgs), valid)
+    fake_loss = s.bce(s.D(gen.detach()), fake)
+    d_loss = half_sum(real_loss, fake_loss)
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+gan_step = dcgan_step
+
+
+# ------------------------------------------------------------------------------------------------ wgan_gp
+def compute_gradient_penalty(D, real_samples, fake_samples, alpha=None):
+    """wgan_gp.py:119-138 on the HIP path: interpolation, D forward, differentiable backward
+    (create_graph=True through Linear/LeakyReLU Functions), row-wise L2 norm and mean((n-1)^2)."""
+    B = real_samples.size(0)
+    dev = real_samples.device
+    if alpha is None:
+        alpha = _dev(np.random.random((B, 1, 1, 1)), dev)
+    a = alpha.reshape(B)
+    mix = F.axpby(F.rowscale(real_samples, a), F.rowscale(fake_samples, 1 - a), 1.0, 1.0)
+    mix = mix.view(real_samples.shape).requires_grad_(True)
+    d_mix = D(mix)
+    ones = torch.ones(B, 1, device=dev)
+    grads = torch.autograd.grad(outputs=d_mix, inputs=mix, grad_outputs=ones, create_graph=True, retain_graph=True,
+                                only_inputs=True)[0]
+    norms = F.rownorm(grads.view(B, -1))
+    return F.loss(F.LOSS_MSE, norms, None, 1.0)
+
+
+def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
+    return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
+                           latent_dim=latent_dim, lambda_gp=10.0, n_critic=5, skip=skip_dead_grads,
+                           dp=dp or LocalStepper())
+
+
+def wgan_gp_step(s, real_imgs, i, z, alpha=None):
+    """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0."""
+    s.opt_D.zero_grad()
+    if s.skip:
+        with torch.no_grad():  # G grads from d_loss are discarded at wgan_gp.py:176
+            fake_imgs = s.G(z)
+    else:
+        fake_imgs = s.G(z)
+    real_v = s.D(real_imgs)
+    fake_v = s.D(fake_imgs)
+    gp = compute_gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
+    # d_loss = -mean(real) + mean(fake) + lambda_gp * gp
+    d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    s.opt_G.zero_grad()
+    out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
+    if i % s.n_critic == 0:
+        fake_imgs = s.G(z)
+        with frozen(s.D, enabled=s.skip):
+            g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
+        g_loss.backward()
+        s.dp.step(s.opt_G)
+        out["g_loss"] = g_loss.detach()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ cyclegan
+class ReplayBuffer:
+    """cyclegan/utils.py:13-33 with device-resident history (index logic identical, python `random`)."""
+
+    def __init__(self, max_size=50):
+        if max_size <= 0:
+            raise AssertionError("Empty buffer or trying to create a black hole. Be careful.")
+        self.max_size, self.data = max_size, []
+
+    def push_and_pop(self, batch):
+        out = []
+        for k in range(batch.shape[0]):
+            sample = batch.data[k:k + 1]
+            if len(self.data) < self.max_size:
+                self.data.append(sample)
+                out.append(sample)
+            elif random.uniform(0, 1) > 0.5:
+                j = random.randint(0, self.max_size - 1)
+                out.append(self.data[j].clone())
+                self.data[j] = sample
+            else:
+                out.append(sample)
+        return torch.cat(out)
+
+
+class LambdaLR:
+    """cyclegan/utils.py:36-44."""
+
+    def __init__(self, n_epochs, offset, decay_start_epoch):
+        if n_epochs - decay_start_epoch <= 0:
+            raise AssertionError("Decay must start before the training session ends!")
+        self.n_epochs, self.offset, self.decay_start_epoch = n_epochs, offset, decay_start_epoch
+
+    def step(self, epoch):
+        return 1.0 - max(0, epoch + self.offset - self.decay_start_epoch) / (self.n_epochs - self.decay_start_epoch)
+
+
+def make_cyclegan_state(G_AB, G_BA, D_A, D_B, skip_dead_grads=True, dp=None):
+    return SimpleNamespace(
+        G_AB=G_AB, G_BA=G_BA, D_A=D_A, D_B=D_B,
+        opt_G=Adam(itertools.chain(G_AB.parameters(), G_BA.parameters()), **ADAM),
+        opt_D_A=Adam(D_A.parameters(), **ADAM), opt_D_B=Adam(D_B.parameters(), **ADAM), mse=gnn.MSELoss(),
+        l1=gnn.L1Loss(), buf_A=ReplayBuffer(), buf_B=ReplayBuffer(), lambda_cyc=10.0, lambda_id=5.0,
+        skip=skip_dead_grads, labels={}, dp=dp or LocalStepper())
+
+
+def cyclegan_step(s, real_A, real_B):
+    """cyclegan.py:159-239."""
+    B = real_A.size(0)
+    valid, fake = _labels(s, (B, *s.D_A.output_shape), real_A.device)
+    s.G_AB.train()
+    s.G_BA.train()
+    s.opt_G.zero_grad()
+    loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
+    with frozen(s.D_A, s.D_B, enabled=s.skip):
+        fake_B = s.G_AB(real_A)
+        loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+        fake_A = s.G_BA(real_B)
+        loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+    loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
+    loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
+    loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
+    loss_G.backward()
+    s.dp.step(s.opt_G)
+
+    s.opt_D_A.zero_grad()
+    loss_real = s.mse(s.D_A(real_A), valid)
+    fake_A_ = s.buf_A.push_and_pop(fake_A)
+    loss_D_A = half_sum(loss_real, s.mse(s.D_A(fake_A_.detach()), fake))
+    loss_D_A.backward()
+    s.dp.step(s.opt_D_A)
+
+    s.opt_D_B.zero_grad()
+    loss_real = s.mse(s.D_B(real_B), valid)
+    fake_B_ = s.buf_B.push_and_pop(fake_B)
+    loss_D_B = half_sum(loss_real, s.mse(s.D_B(fake_B_.detach()), fake))
+    loss_D_B.backward()
+    s.dp.step(s.opt_D_B)
+    return {"loss_G": loss_G.detach(), "loss_D": half_sum(loss_D_A, loss_D_B).detach(), "loss_GAN": loss_GAN.detach(),
+            "loss_cycle": loss_cycle.detach(), "loss_identity": loss_id.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ pix2pix
+def make_pix2pix_state(G, D, img_size=256, skip_dead_grads=True, dp=None):
+    return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
+                           mse=gnn.MSELoss(), l1=gnn.L1Loss(), lambda_pixel=100.0,
+                           patch=(1, img_size // 16, img_size // 16), skip=skip_dead_grads, labels={},
+                           dp=dp or LocalStepper())
+
+
+def pix2pix_step(s, real_A, real_B):
+    """pix2pix.py:123-172 (real_A = condition image, real_B = target)."""
+    valid, fake = _labels(s, (real_A.size(0), *s.patch), real_A.device)
+    s.opt_G.zero_grad()
+    fake_B = s.G(real_A)
+    with frozen(s.D, enabled=s.skip):
+        loss_GAN = s.mse(s.D(fake_B, real_A), valid)
+    loss_pixel = s.l1(fake_B, real_B)
+    loss_G = F.axpby(loss_GAN, loss_pixel, 1.0, s.lambda_pixel)
+    loss_G.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    loss_real = s.mse(s.D(real_B, real_A), valid)
+    loss_fake = s.mse(s.D(fake_B.detach(), real_A), fake)
+    loss_D = half_sum(loss_real, loss_fake)
+    loss_D.backward()
+    s.dp.step(s.opt_D)
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_pixel": loss_pixel.detach(),
+            "loss_GAN": loss_GAN.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ srgan
+def make_srgan_state(G, D, V, skip_dead_grads=True, dp=None):
+    V.eval()
+    return SimpleNamespace(G=G, D=D, V=V, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
+                           mse=gnn.MSELoss(), l1=gnn.L1Loss(), skip=skip_dead_grads, labels={},
+                           dp=dp or LocalStepper())
+
+
+def srgan_step(s, imgs_lr, imgs_hr):
+    """srgan.py:97-145."""
+    valid, fake = _labels(s, (imgs_lr.size(0), *s.D.output_shape), imgs_lr.device)
+    s.opt_G.zero_grad()
+    gen_hr = s.G(imgs_lr)
+    with frozen(s.D, s.V, enabled=s.skip):
+        loss_GAN = s.mse(s.D(gen_hr), valid)
+        gen_features = s.V(gen_hr)
+        if s.skip:
+            with torch.no_grad():
+                real_features = s.V(imgs_hr)
+        else:
+            real_features = s.V(imgs_hr)
+    loss_content = s.l1(gen_features, real_features.detach())
+    loss_G = F.axpby(loss_content, loss_GAN, 1.0, 1e-3)
+    loss_G.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    loss_real = s.mse(s.D(imgs_hr), valid)
+    loss_fake = s.mse(s.D(gen_hr.detach()), fake)
+    loss_D = half_sum(loss_real, loss_fake)
+    loss_D.backward()
+    s.dp.step(s.opt_D)
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
+            "loss_GAN": loss_GAN.detach()}

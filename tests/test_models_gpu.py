@@ -1,0 +1,216 @@
+"""Module-level parity: a reference network (oracle restatement, pinned bit-exact against the reference) is
+deep-copied, swap()ped onto the HIP path and must reproduce the CPU forward output, every parameter
+gradient, input gradients and BatchNorm side effects; checked both with and without peephole fusion and
+against the committed golden fixtures generated from the real reference (tests/golden/)."""
+import numpy as np
+import pytest
+import torch
+
+from util import TOL_MODEL_FWD, TOL_MODEL_GRAD, assert_close, digest, gpu_copy, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import pytorch_gan_amd as pg
+
+    return pg
+
+
+def _seed(s):
+    import random
+
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def _fwd_bwd(model, inputs, w=None, ctx=None):
+    for p in model.parameters():
+        p.grad = None
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    if ctx is not None:
+        with ctx:
+            out = model(*ins)
+    else:
+        out = model(*ins)
+    if w is None:
+        g = torch.Generator().manual_seed(123)
+        w = torch.randn(out.shape, generator=g)
+    (out * w.to(device=out.device, dtype=out.dtype)).sum().backward()
+    return out.detach(), [t.grad for t in ins], w
+
+
+def _noise_aware(gpu, cpu32, cpu64, tol, what):
+    """The HIP result must be as close to the fp64 evaluation of the reference network as the reference's own
+    fp32 CPU path is (x8 slack), or within the stated relative tolerance — whichever is larger.  Needed because
+    some gradients are ill-conditioned in fp32 (e.g. conv bias in front of a norm layer is exactly 0 in exact
+    arithmetic; tiny-batch BatchNorm backward cancels heavily: the CPU fp32 path itself is 2e-3 off fp64)."""
+    g, c, t = gpu.detach().double().cpu(), cpu32.detach().double(), cpu64.detach().double()
+    err_g, err_c, ref = (g - t).norm().item(), (c - t).norm().item(), t.norm().item()
+    bound = tol * ref + 8.0 * err_c + 1e-12
+    assert err_g <= bound, "%s: |hip-f64| %.3e > bound %.3e (|cpu32-f64| %.3e, |f64| %.3e)" % (what, err_g, bound, err_c, ref)
+
+
+def _compare(pg, cpu_model, inputs, fused=True, tol_grad=TOL_MODEL_GRAD):
+    import copy
+
+    from oracle import reference_models as M
+
+    pg.set_fusion(fused)
+    try:
+        gmodel = gpu_copy(cpu_model)
+        model64 = copy.deepcopy(cpu_model).double()
+        rec = []
+        _seed(7)
+        out_c, gin_c, w = _fwd_bwd(cpu_model, inputs, ctx=M.feed_masks(record=rec))
+        masks = [m.numpy() for m in rec]
+        out_d, gin_d, _ = _fwd_bwd(model64, [t.double() for t in inputs], w, ctx=M.feed_masks(masks=masks))
+        out_g, gin_g, _ = _fwd_bwd(gmodel, [t.to(DEV) for t in inputs], w, ctx=pg.dropout_masks(masks))
+        assert_close(out_g, out_c, TOL_MODEL_FWD, "forward")
+        for a, b, d in zip(gin_g, gin_c, gin_d):
+            if b is not None:
+                _noise_aware(a, b, d, tol_grad, "input grad")
+        gp = dict(gmodel.named_parameters())
+        p64 = dict(model64.named_parameters())
+        for k, p in cpu_model.named_parameters():
+            if p.grad is None:
+                assert gp[k].grad is None or float(gp[k].grad.abs().max()) == 0.0, k
+                continue
+            _noise_aware(gp[k].grad, p.grad, p64[k].grad, tol_grad, "grad " + k)
+        gb = dict(gmodel.named_buffers())
+        for k, b in cpu_model.named_buffers():
+            if b.dtype.is_floating_point:
+                assert_close(gb[k], b, 1e-5, "buffer " + k)
+            else:
+                assert torch.equal(gb[k].cpu(), b), "buffer %s (bit-exact)" % k
+        assert list(gmodel.state_dict().keys()) == list(cpu_model.state_dict().keys())
+        return out_g, gmodel
+    finally:
+        pg.set_fusion(True)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_dcgan(pg, golden_dir, fused):
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "dcgan_32")
+    _seed(0)
+    G = M.DcganGenerator(32, 100, 1)
+    G.apply(M.init_normal_dcgan)
+    _seed(0)
+    D = M.DcganDiscriminator(32, 1)
+    D.apply(M.init_normal_dcgan)
+    z, img = torch.from_numpy(gold["z"]), torch.from_numpy(gold["img"])
+    out_g, _ = _compare(pg, G, [z], fused=fused)
+    assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "G vs golden (real reference output)")
+    _compare(pg, D, [img], fused=fused)
+    # D against the reference run recorded in the fixture (its own dropout masks)
+    Dg = gpu_copy(D)
+    masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))]
+    with pg.dropout_masks(masks):
+        d_out = Dg(img.to(DEV))
+    assert_close(d_out, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "D vs golden")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_mlp_gan_wgan(pg, golden_dir, fused):
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "wgan_gp_32")
+    _seed(0)
+    G = M.MlpGenerator((1, 32, 32), 100)
+    _seed(0)
+    D = M.MlpCritic((1, 32, 32))
+    out_g, _ = _compare(pg, G, [torch.from_numpy(gold["z"])], fused=fused)
+    assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "wgan G vs golden")
+    out_d, Dg = _compare(pg, D, [torch.from_numpy(gold["real"])], fused=fused)
+    assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "wgan D vs golden")
+    # gradient penalty on the HIP path vs the value/gradients produced by the reference function
+    from pytorch_gan_amd import steps
+
+    for p in Dg.parameters():
+        p.grad = None
+    real, fake, alpha = (torch.from_numpy(gold[k]).to(DEV) for k in ("real", "gen", "alpha"))
+    gp = steps.compute_gradient_penalty(Dg, real, fake, alpha)
+    gp.backward()
+    assert abs(gp.item() - float(gold["gp"])) <= 1e-5 * max(1.0, abs(float(gold["gp"])))
+    keys = [str(k) for k in gold["gp_keys"]]
+    named = dict(Dg.named_parameters())
+    for k, dg in zip(keys, gold["gp_digest"]):
+        mine = digest(named[k].grad)
+        assert abs(mine[2] - dg[2]) <= 1e-4 * max(dg[2], 1e-12), "GP grad energy of %s" % k
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_cyclegan(pg, golden_dir, fused):
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "cyclegan_32")
+    shape = (3, 32, 32)
+    _seed(0)
+    G = M.CycleGenerator(shape, 3)
+    G.apply(M.init_normal_cyclegan)
+    _seed(0)
+    D = M.CycleDiscriminator(shape)
+    D.apply(M.init_normal_cyclegan)
+    x = torch.from_numpy(gold["x"])
+    out_g, _ = _compare(pg, G, [x], fused=fused)
+    assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "cyclegan G vs golden")
+    out_d, _ = _compare(pg, D, [x], fused=fused)
+    assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "cyclegan D vs golden")
+
+
+def test_srgan(pg, golden_dir):
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "srgan_32")
+    _seed(0)
+    G = M.SrganGenerator()
+    _seed(0)
+    D = M.SrganDiscriminator((3, 32, 32))
+    _seed(0)
+    V = M.SrganFeatureExtractor()
+    V.eval()
+    lr, hr = torch.from_numpy(gold["lr"]), torch.from_numpy(gold["hr"])
+    out_g, _ = _compare(pg, G, [lr])
+    assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "srgan G vs golden")
+    out_d, _ = _compare(pg, D, [hr])
+    assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "srgan D vs golden")
+    out_v, _ = _compare(pg, V, [hr])
+    assert np.allclose(digest(out_v), gold["vgg_digest"], rtol=1e-4)
+
+
+def test_pix2pix(pg, golden_dir):
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "pix2pix_256")
+    _seed(0)
+    G = M.Pix2pixGenerator()
+    G.apply(M.init_normal_dcgan)
+    _seed(0)
+    D = M.Pix2pixDiscriminator()
+    D.apply(M.init_normal_dcgan)
+    _seed(5)
+    a = torch.rand(1, 3, 256, 256) * 2 - 1
+    b = torch.rand(1, 3, 256, 256) * 2 - 1
+    _compare(pg, G, [a])
+    out_d, _ = _compare(pg, D, [b, a])
+    assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "pix2pix D vs golden")
+
+
+def test_swap_keeps_tree_and_init(pg):
+    """weights_init_normal dispatches on class names and writes .weight.data (dcgan.py:36-42): must still work."""
+    from oracle import reference_models as M
+
+    G = M.DcganGenerator(32, 100, 1)
+    keys = list(G.state_dict().keys())
+    pg.swap(G)
+    assert list(G.state_dict().keys()) == keys
+    names = [type(m).__name__ for m in G.modules()]
+    assert "Conv2d" in names and "BatchNorm2d" in names and "Upsample" in names
+    G.apply(M.init_normal_dcgan)
+    with pytest.raises(NotImplementedError):
+        pg.swap(torch.nn.Sequential(torch.nn.GRU(4, 4)))

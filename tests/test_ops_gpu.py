@@ -1,0 +1,392 @@
+"""Per-op parity of the HIP kernels (through the C ABI + autograd wrappers) against torch CPU fp32.
+Shapes follow SURVEY.md Appendix A at reduced batch.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from util import TOL_FWD, TOL_WGRAD, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pg():
+    import pytorch_gan_amd as pg
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return pg
+
+
+def _leaf(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _ref_gather(x, pads, gather):
+    pt, pl, pb, pr = pads
+    if gather == 2:
+        x = TF.interpolate(x, scale_factor=2, mode="nearest")
+    if gather == 1:
+        return TF.pad(x, (pl, pr, pt, pb), mode="reflect")
+    return TF.pad(x, (pl, pr, pt, pb))
+
+
+CONV_CASES = [
+    # N, Ci, H, W, Co, k, stride, pads(t,l,b,r), gather, act, bias
+    (2, 128, 16, 16, 128, 3, 1, (1, 1, 1, 1), 0, 0, True),      # dcgan.py:55 / fast path 128x128 tile
+    (2, 128, 16, 16, 64, 3, 1, (1, 1, 1, 1), 2, 1, True),       # Upsample+conv+LeakyReLU fused (dcgan.py:58-61)
+    (2, 64, 16, 16, 1, 3, 1, (1, 1, 1, 1), 0, 3, True),         # dcgan.py:62 + Tanh, Co=1
+    (4, 1, 32, 32, 16, 3, 2, (1, 1, 1, 1), 0, 1, True),         # dcgan.py:78 first D block (Ci=1, generic path)
+    (4, 16, 16, 16, 32, 3, 2, (1, 1, 1, 1), 0, 0, True),        # Ci=16 generic
+    (2, 64, 16, 16, 128, 3, 2, (1, 1, 1, 1), 0, 0, True),       # cyclegan/models.py:60
+    (1, 256, 12, 12, 256, 3, 1, (1, 1, 1, 1), 1, 0, True),      # ResidualBlock: ReflectionPad2d(1)+conv
+    (1, 3, 20, 20, 64, 7, 1, (3, 3, 3, 3), 1, 0, True),         # c7s1-64 with reflection pad 3 (generic)
+    (1, 64, 20, 20, 3, 7, 1, (3, 3, 3, 3), 1, 3, True),         # c7s1-3 + Tanh
+    (2, 3, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 1, True),         # PatchGAN first block
+    (2, 64, 16, 16, 128, 4, 2, (1, 1, 1, 1), 0, 0, False),      # pix2pix UNetDown (bias=False)
+    (2, 512, 6, 6, 1, 4, 1, (2, 2, 1, 1), 0, 0, True),          # ZeroPad2d((1,0,1,0)) + Conv2d(512,1,4,padding=1)
+    (1, 128, 8, 8, 3, 4, 1, (2, 2, 1, 1), 2, 3, True),          # pix2pix final: Upsample+ZeroPad+conv+Tanh
+    (1, 3, 12, 12, 64, 9, 1, (4, 4, 4, 4), 0, 0, True),         # srgan conv1 9x9
+    (1, 64, 12, 12, 3, 9, 1, (4, 4, 4, 4), 0, 3, True),         # srgan conv3 9x9 + Tanh
+    (3, 32, 9, 7, 48, 3, 1, (1, 1, 1, 1), 0, 2, True),          # ragged sizes, M/N tails
+    (2, 96, 5, 5, 160, 3, 2, (1, 1, 1, 1), 0, 0, True),         # odd spatial with stride 2 (parity classes uneven)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(pg, case):
+    N, Ci, H, W, Co, k, stride, pads, gather, act, bias = case
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, k, k, seed=2, scale=0.2).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True) if bias else None
+    y_ref = TF.conv2d(_ref_gather(x, pads, gather), w, b, stride)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu, 3: torch.tanh}[act](y_ref)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+
+    xg = x.detach().to(DEV).requires_grad_(True)
+    wg = w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+    y = F.conv2d(xg, wg, bg, stride, pads, gather, act, 0.2)
+    assert y.shape == y_ref.shape
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "conv fwd")
+    assert_close(xg.grad, x.grad, TOL_FWD, "conv dgrad")
+    assert_close(wg.grad, w.grad, TOL_WGRAD, "conv wgrad")
+    if bias:
+        assert_close(bg.grad, b.grad, TOL_WGRAD, "conv bias grad")
+
+
+def test_conv2d_nchw_input_is_relaid(pg):
+    """An NCHW-contiguous activation (as produced by `.view` in dcgan.py:68) is accepted and re-laid out."""
+    F = pg.functional
+    x = _leaf(2, 64, 8, 8, seed=5)
+    w = _leaf(32, 64, 3, 3, seed=6, scale=0.1)
+    y = F.conv2d(x.to(DEV), w.to(DEV), None, 1, (1, 1, 1, 1))
+    assert_close(y, TF.conv2d(x, w, None, 1, 1), TOL_FWD, "nchw in")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 32, True), (1, 512, 1, 1, 512, False), (2, 128, 5, 7, 64, False)])
+def test_conv_transpose2d(pg, shape):
+    N, Cin, H, W, Cout, bias = shape
+    F = pg.functional
+    x = _leaf(N, Cin, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Cin, Cout, 4, 4, seed=2, scale=0.1).requires_grad_(True)
+    b = _leaf(Cout, seed=3).requires_grad_(True) if bias else None
+    y_ref = TF.conv_transpose2d(x, w, b, 2, 1)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+    y = F.conv_transpose2d(xg, wg, bg, 2, 1)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "convT fwd")
+    assert_close(xg.grad, x.grad, TOL_FWD, "convT dgrad")
+    assert_close(wg.grad, w.grad, TOL_WGRAD, "convT wgrad")
+    if bias:
+        assert_close(bg.grad, b.grad, TOL_WGRAD, "convT bias")
+
+
+@pytest.mark.parametrize("dims", [(128, 100, 8192), (64, 1024, 512), (64, 256, 1), (7, 33, 5), (128, 2048, 1)])
+def test_linear(pg, dims):
+    B, K, Nf = dims
+    F = pg.functional
+    x = _leaf(B, K, seed=1).requires_grad_(True)
+    w = _leaf(Nf, K, seed=2, scale=0.1).requires_grad_(True)
+    b = _leaf(Nf, seed=3).requires_grad_(True)
+    y_ref = TF.linear(x, w, b)
+    gy = _leaf(B, Nf, seed=4)
+    y_ref.backward(gy)
+    xg, wg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = F.linear(xg, wg, bg)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "linear fwd")
+    assert_close(xg.grad, x.grad, TOL_FWD, "linear dgrad")
+    assert_close(wg.grad, w.grad, TOL_WGRAD, "linear wgrad")
+    assert_close(bg.grad, b.grad, TOL_WGRAD, "linear bias")
+
+
+def test_linear_lrelu_double_backward(pg):
+    """The WGAN-GP pattern (wgan_gp.py:119-138): grad of D(x) w.r.t. x with create_graph, then backward of a
+    function of that grad into the weights."""
+    F = pg.functional
+    B = 16
+    x = _leaf(B, 64, seed=1)
+    W1, b1 = _leaf(48, 64, seed=2, scale=0.3), _leaf(48, seed=3)
+    W2, b2 = _leaf(1, 48, seed=4, scale=0.3), _leaf(1, seed=5)
+
+    def run(dev, lin, lrelu, norm_pen):
+        xs = x.detach().clone().to(dev).requires_grad_(True)
+        ps = [t.detach().clone().to(dev).requires_grad_(True) for t in (W1, b1, W2, b2)]
+        out = lin(lrelu(lin(xs, ps[0], ps[1])), ps[2], ps[3])
+        g = torch.autograd.grad(out, xs, torch.ones(B, 1, device=dev), create_graph=True, retain_graph=True)[0]
+        pen = norm_pen(g)
+        pen.backward()
+        return pen, ps
+
+    pen_r, ps_r = run("cpu", TF.linear, lambda t: TF.leaky_relu(t, 0.2), lambda g: ((g.norm(2, dim=1) - 1) ** 2).mean())
+    pen_g, ps_g = run(DEV, F.linear, lambda t: F.activation(t, F.ACT_LRELU, 0.2),
+                      lambda g: F.loss(F.LOSS_MSE, F.rownorm(g), None, 1.0))
+    assert abs(pen_r.item() - pen_g.item()) <= 1e-5 * max(1.0, abs(pen_r.item()))
+    assert_close(ps_g[0].grad, ps_r[0].grad, TOL_WGRAD, "dW1 of penalty")
+    assert_close(ps_g[2].grad, ps_r[2].grad, TOL_WGRAD, "dW2 of penalty")
+    assert ps_r[3].grad is None and ps_g[3].grad is None  # last-layer bias gets no gradient from the penalty
+    # hidden-layer bias: torch materialises exact zeros; the HIP path leaves it untouched (None == zeros in the
+    # optimiser's pre-zeroed flat bucket)
+    assert float(ps_r[1].grad.abs().max()) == 0.0
+    assert ps_g[1].grad is None or float(ps_g[1].grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [(8, 128, 16, 16, 0.8, 1), (8, 64, 8, 8, 1e-5, 0), (4, 32, 5, 3, 0.8, 2), (16, 10, 4, 4, 1e-5, 1)])
+def test_batchnorm2d_train(pg, cfg):
+    N, C, H, W, eps, act = cfg
+    F = pg.functional
+    x = (_leaf(N, C, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
+    gamma, beta = (_leaf(C, seed=2) + 1.5).requires_grad_(True), _leaf(C, seed=3).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y_ref = TF.batch_norm(x, rm, rv, gamma, beta, True, 0.1, eps)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y_ref)
+    gy = _leaf(N, C, H, W, seed=4)
+    y_ref.backward(gy)
+    xg, gg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    rmg, rvg = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = F.norm(xg, gg, bg, None, rmg, rvg, True, 0.1, eps, False, act, 0.2)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "bn fwd")
+    assert_close(xg.grad, x.grad, 2e-5, "bn dx")
+    assert_close(gg.grad, gamma.grad, TOL_WGRAD, "bn dgamma")
+    assert_close(bg.grad, beta.grad, TOL_WGRAD, "bn dbeta")
+    assert_close(rmg, rm, TOL_WGRAD, "running_mean")
+    assert_close(rvg, rv, TOL_WGRAD, "running_var")
+
+
+def test_batchnorm1d_and_eval(pg):
+    F = pg.functional
+    x = _leaf(64, 256, seed=1).requires_grad_(True)
+    gamma, beta = (_leaf(256, seed=2) + 1.5).requires_grad_(True), _leaf(256, seed=3).requires_grad_(True)
+    rm, rv = torch.zeros(256), torch.ones(256)
+    y_ref = TF.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 0.8)
+    y_ref.backward(_leaf(64, 256, seed=4))
+    xg, gg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    rmg, rvg = torch.zeros(256, device=DEV), torch.ones(256, device=DEV)
+    y = F.norm(xg, gg, bg, None, rmg, rvg, True, 0.1, 0.8)
+    y.backward(_leaf(64, 256, seed=4).to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "bn1d fwd")
+    assert_close(xg.grad, x.grad, 2e-5, "bn1d dx")
+    assert_close(rvg, rv, TOL_WGRAD, "bn1d running_var")
+    y_eval = F.norm(xg.detach(), gg.detach(), bg.detach(), None, rmg, rvg, False, 0.1, 0.8)
+    assert_close(y_eval, TF.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 0.8), TOL_FWD, "bn eval")
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 16, 16, 2), (2, 64, 9, 7, 1), (1, 512, 2, 2, 0), (3, 128, 1, 2, 0)])
+def test_instancenorm(pg, cfg):
+    N, C, H, W, act = cfg
+    F = pg.functional
+    x = (_leaf(N, C, H, W, seed=1) * 3 + 0.5).requires_grad_(True)
+    y_ref = TF.instance_norm(x, eps=1e-5)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y_ref)
+    gy = _leaf(N, C, H, W, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.norm(xg, None, None, None, None, None, True, 0.1, 1e-5, True, act, 0.2)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "in fwd")
+    if H * W > 1:
+        assert_close(xg.grad, x.grad, 5e-5, "in dx")
+
+
+def test_norm_residual(pg):
+    F = pg.functional
+    x, r = _leaf(2, 64, 8, 8, seed=1).requires_grad_(True), _leaf(2, 64, 8, 8, seed=2).requires_grad_(True)
+    y_ref = r + TF.instance_norm(x)
+    gy = _leaf(2, 64, 8, 8, seed=3)
+    y_ref.backward(gy)
+    xg, rg = x.detach().to(DEV).requires_grad_(True), r.detach().to(DEV).requires_grad_(True)
+    y = F.norm(xg, None, None, rg, None, None, True, 0.1, 1e-5, True)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "in+res fwd")
+    assert_close(rg.grad, r.grad, 1e-7, "res grad")
+    assert_close(xg.grad, x.grad, 5e-5, "in+res dx")
+
+
+@pytest.mark.parametrize("act", [1, 2, 3, 4])
+def test_activations(pg, act):
+    F = pg.functional
+    x = (_leaf(3, 5, 7, 9, seed=1) * 3).requires_grad_(True)
+    fn = {1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu, 3: torch.tanh, 4: torch.sigmoid}[act]
+    y_ref = fn(x)
+    gy = _leaf(3, 5, 7, 9, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.activation(xg, act, 0.2)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, 1e-6, "act fwd")
+    assert_close(xg.grad, x.grad, 2e-6, "act bwd")
+
+
+def test_prelu(pg):
+    F = pg.functional
+    x = _leaf(2, 64, 12, 12, seed=1).requires_grad_(True)
+    a = torch.tensor([0.25], requires_grad=True)
+    y_ref = TF.prelu(x, a)
+    gy = _leaf(2, 64, 12, 12, seed=2)
+    y_ref.backward(gy)
+    xg, ag = x.detach().to(DEV).requires_grad_(True), a.detach().to(DEV).requires_grad_(True)
+    y = F.prelu(xg, ag)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, 1e-7, "prelu fwd")
+    assert_close(xg.grad, x.grad, 1e-7, "prelu dx")
+    assert_close(ag.grad, a.grad, TOL_WGRAD, "prelu dslope")
+
+
+@pytest.mark.parametrize("cfg", [((3, 3, 3, 3), 1), ((1, 1, 1, 1), 1), ((1, 1, 0, 0), 0), ((0, 0, 0, 0), 2), ((2, 2, 1, 1), 2)])
+def test_gather2d(pg, cfg):
+    pads, mode = cfg
+    F = pg.functional
+    x = _leaf(2, 6, 9, 8, seed=1).requires_grad_(True)
+    y_ref = _ref_gather(x, pads, mode)
+    gy = _leaf(*y_ref.shape, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.gather2d(xg, pads, mode)
+    y.backward(gy.to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach()), "pad/upsample forward must be bit-exact (index remap)"
+    assert_close(xg.grad, x.grad, 1e-6, "gather bwd")
+
+
+def test_pixel_shuffle_maxpool_cat_add(pg):
+    F = pg.functional
+    x = _leaf(2, 16, 5, 6, seed=1).requires_grad_(True)
+    y_ref = TF.pixel_shuffle(x, 2)
+    gy = _leaf(*y_ref.shape, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.pixel_shuffle(xg, 2)
+    y.backward(gy.to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach()) and torch.equal(xg.grad.cpu(), x.grad), "PixelShuffle is an index map"
+
+    x = _leaf(2, 8, 6, 8, seed=3).requires_grad_(True)
+    y_ref = TF.max_pool2d(x, 2, 2)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.maxpool2(xg)
+    y.backward(gy.to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach()) and torch.equal(xg.grad.cpu(), x.grad), "MaxPool is selection"
+
+    a, b = _leaf(2, 5, 4, 4, seed=5).requires_grad_(True), _leaf(2, 3, 4, 4, seed=6).requires_grad_(True)
+    y_ref = torch.cat((a, b), 1)
+    gy = _leaf(*y_ref.shape, seed=7)
+    y_ref.backward(gy)
+    ag, bg = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = F.cat_channels(ag, bg)
+    y.backward(gy.to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach()) and torch.equal(ag.grad.cpu(), a.grad) and torch.equal(bg.grad.cpu(), b.grad)
+
+    s = F.add(ag.detach(), ag.detach())
+    assert torch.equal(s.cpu(), (a + a).detach())
+
+
+def test_dropout_masks(pg):
+    F = pg.functional
+    x = _leaf(4, 16, 8, 8, seed=1).requires_grad_(True)
+    m = (torch.rand(4, 16) > 0.25).float() / 0.75
+    y_ref = x * m[:, :, None, None]
+    gy = _leaf(4, 16, 8, 8, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = F.mul_mask(xg, m.to(DEV))
+    y.backward(gy.to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach()) and torch.equal(xg.grad.cpu(), x.grad)
+    # device Philox stream: keep-probability and scaling
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    mk = F.rand_mask((1 << 20,), 0.25, 1234, ctr, DEV)
+    vals = torch.unique(mk).cpu().tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.75) < 1e-6
+    assert abs((mk > 0).float().mean().item() - 0.75) < 3e-3
+    mk2 = F.rand_mask((1 << 20,), 0.25, 1234, ctr, DEV)
+    assert not torch.equal(mk, mk2), "counter must advance the stream"
+    assert int(ctr.item()) == 2 * (1 << 18)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_losses(pg, kind):
+    F = pg.functional
+    n = (64, 1) if kind == 0 else (2, 3, 33, 31)
+    x = _leaf(*n, seed=1)
+    if kind == 0:
+        x = torch.sigmoid(x * 4)
+        x[0, 0], x[1, 0] = 0.0, 1.0  # exercises the log clamp at -100
+    x = x.requires_grad_(True)
+    t = (torch.rand(*n) > 0.5).float() if kind == 0 else _leaf(*n, seed=2)
+    ref = [TF.binary_cross_entropy, TF.mse_loss, TF.l1_loss, lambda a, b: a.mean()][kind](x, t)
+    (ref * 1.7).backward()
+    xg = x.detach().to(DEV).requires_grad_(True)
+    out = F.loss(kind, xg, None if kind == 3 else t.to(DEV))
+    (F.axpby(out, None, 1.7, 0.0)).backward()
+    assert abs(out.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert_close(xg.grad, x.grad, 2e-6, "loss grad")
+
+
+def test_adam_matches_torch(pg):
+    ps = [_leaf(300, 70, seed=1), _leaf(5000, seed=2), _leaf(3, 3, 3, 3, seed=3)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    o_mine = pg.optim.Adam(mine, lr=2e-4, betas=(0.5, 0.999))
+    for step in range(5):
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+        for i, (r, m) in enumerate(zip(ref, mine)):
+            g = _leaf(*r.shape, seed=10 * step + i)
+            r.grad = g.clone()
+            m.grad.add_(g.to(DEV))
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        assert_close(m, r, 1e-7, "adam param")
+
+
+def test_gantensor_view_add_cat(pg):
+    nn = pg.nn
+    conv = nn.Conv2d(8, 16, 3, 1, 1).to(DEV)
+    x = _leaf(2, 8, 4, 4, seed=1).to(DEV)
+    y = conv(x)
+    assert isinstance(y, nn.GanTensor)
+    flat = y.view(y.shape[0], -1)  # dcgan.py:96 on NHWC storage
+    ref = TF.conv2d(x.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu(), 1, 1)
+    assert_close(flat, ref.view(2, -1), TOL_FWD, "view of NHWC activation")
+    s = y + y
+    assert isinstance(s, nn.GanTensor)
+    assert_close(s, 2 * ref, TOL_FWD, "residual add")
+    c = torch.cat((y, y), 1)
+    assert_close(c, torch.cat((ref, ref), 1), TOL_FWD, "cat")
+
+
+def test_cpu_tensor_raises(pg):
+    with pytest.raises(RuntimeError):
+        pg.functional.activation(torch.zeros(4), 1, 0.2)
