@@ -37,16 +37,16 @@ struct ConvGeom {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
-__global__ __launch_bounds__(256) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
+__global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
                                                     const float* __restrict__ Bw,
                                                     const float* __restrict__ bias,
                                                     float* __restrict__ C) {
     constexpr int BK = 32;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int LDK = BK + 1;  // [row][k] image, odd row stride: conflict-free b32 reads AND transposing writes
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "256-thread blocks");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
-    constexpr int SM_A = BK * LDA, SM_B = BK * LDB;
+    constexpr int SM_A = BM * LDK, SM_B = BN * LDK;
     __shared__ __attribute__((aligned(16))) int smem_i[SM_A + SM_B + 3 * MAX_TAPS + 3 * BM];
     float* As = reinterpret_cast<float*>(smem_i);
     float* Bs = As + SM_A;
@@ -193,16 +193,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvGeom g, const floa
 #pragma unroll
             for (int j = 0; j < NA; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[(kq * 4 + e) * LDA + frow + 32 * j] = ra4[j][e];
+                for (int e = 0; e < 4; ++e) As[(frow + 32 * j) * LDK + kq * 4 + e] = ra4[j][e];
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(kq * 4 + e) * LDB + frow + 32 * j] = rb4[j][e];
+                for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = rb4[j][e];
         } else {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) As[gk * LDA + grow + 8 * j] = ra1[j];
+            for (int j = 0; j < NA; ++j) As[(grow + 8 * j) * LDK + gk] = ra1[j];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) Bs[gk * LDB + grow + 8 * j] = rb1[j];
+            for (int j = 0; j < NB; ++j) Bs[(grow + 8 * j) * LDK + gk] = rb1[j];
         }
     };
 
@@ -212,15 +212,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ConvGeom g, const floa
         store_tile();
         __syncthreads();
         if (kt + 1 < KT) load_tile(kt + 1);
-        const float* ap = As + h * LDA + wm * (TM * 32) + l31;
-        const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
+        const float* ap = As + (wm * (TM * 32) + l31) * LDK + h;
+        const float* bp = Bs + (wn * (TN * 32) + l31) * LDK + h;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -600,6 +600,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     }
 }
 
+// Same reduction with ONE WAVE per output element (many splits, few outputs): lanes stride over the splits
+// in a fixed order, then a butterfly sum — still deterministic run to run.
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ part,
+                                                                float* __restrict__ dw, int splits, int Co, int T,
+                                                                int Ci) {
+    const size_t total = (size_t)Co * T * Ci;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= total) return;
+    int t = (int)(i % T);
+    size_t r = i / T;
+    int ci = (int)(r % Ci);
+    int co = (int)(r / Ci);
+    size_t src = ((size_t)co * T + t) * Ci + ci;
+    float s = 0.f;
+    for (int k = lane; k < splits; k += 64) s += part[(size_t)k * total + src];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) dw[i] = s;
+}
+static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, hipStream_t st) {
+    size_t total = (size_t)Co * T * Ci;
+    if (splits >= 16 && total * 64 <= (size_t)1 << 26) {
+        hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(cdiv((long)total * 64, 256)), dim3(256), 0, st, ws, dw, splits,
+                           Co, T, Ci);
+    } else {
+        int blocks = cdiv((long)total, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+    }
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps) {
     long Mpix = (long)N * Ho * Wo;
     BMsel = (Co > 64 && Ncol > 64) ? 128 : 64;
@@ -613,16 +647,121 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
     splits = cdiv(Mpix, pps);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Thin weight gradient (Co <= 4, stride 1, zero padding, R*S*Co <= 32): the GEMM has only Co useful
+// rows, so MFMA tiles would be >= 94% padding and the kernel is bound by reading x.  This VALU kernel
+// walks the INPUT pixels once (16 B/lane along channels): dW[co][t][ci] += x[q][ci] * dy[q + pad - t][co];
+// the 9..16 dy taps per pixel are wave-broadcast loads of a tiny tensor.  Partials per pixel chunk go
+// through the same fixed-order reduction as the MFMA path (dcgan.py:62 conv 64->1, PatchGAN heads
+// cyclegan/models.py:118, pix2pix/models.py:127, srgan/models.py:100).
+// ------------------------------------------------------------------------------------------------
+#define THIN_MAX_ACC 32
+#define THIN_CHUNKS 1024
+struct ThinGeom {
+    int N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, chunk, nchunks, CTX;
+};
+template <int CO>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const float* __restrict__ X,
+                                                         const float* __restrict__ DY, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int tid = threadIdx.x;
+    const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
+    const int T = g.R * g.S, NACC = T * CO;
+    const int c = (blockIdx.y * g.CTX + tx) * 4;
+    const bool cok = c < g.Ci;
+    f32x4 acc[THIN_MAX_ACC];
+#pragma unroll
+    for (int i = 0; i < THIN_MAX_ACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long P = (long)g.N * g.Hi * g.Wi;
+    long q0 = (long)blockIdx.x * g.chunk, q1 = q0 + g.chunk;
+    if (q1 > P) q1 = P;
+    if (cok) {
+        for (long q = q0 + ty; q < q1; q += TY) {
+            int n = (int)(q / (g.Hi * g.Wi));
+            int rem = (int)(q - (long)n * g.Hi * g.Wi);
+            int ih = rem / g.Wi, iw = rem - ih * g.Wi;
+            f32x4 xv = *reinterpret_cast<const f32x4*>(X + q * g.Ci + c);
+#pragma unroll
+            for (int t = 0; t < THIN_MAX_ACC / CO; ++t) {
+                if (t < T) {
+                    int r = t / g.S, s = t - r * g.S;
+                    int oh = ih + g.pad_t - r, ow = iw + g.pad_l - s;
+                    if ((unsigned)oh < (unsigned)g.Ho && (unsigned)ow < (unsigned)g.Wo) {
+                        const float* d = DY + ((long)(n * g.Ho + oh) * g.Wo + ow) * CO;
+#pragma unroll
+                        for (int co = 0; co < CO; ++co) {
+                            float dv = d[co];
+                            acc[t * CO + co] += xv * dv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // reduce over the TY pixel lanes through LDS, one accumulator slab at a time
+    float* out = part + (size_t)blockIdx.x * CO * T * g.Ci;
+    for (int a = 0; a < NACC; ++a) {
+        f32x4 v = acc[0];
+#pragma unroll
+        for (int i = 1; i < THIN_MAX_ACC; ++i)
+            if (i == a) v = acc[i];
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + tid * 4) = v;
+        __syncthreads();
+        if (ty == 0 && cok) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < TY; ++y) s += *reinterpret_cast<const f32x4*>(red + (y * g.CTX + tx) * 4);
+            int t = a / CO, co = a - t * CO;
+            *reinterpret_cast<f32x4*>(out + ((size_t)co * T + t) * g.Ci + c) = s;
+        }
+    }
+}
+
+static bool thin_wgrad_ok(int Co, int R, int S, int Ci, int stride, int gather) {
+    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R * S * Co <= THIN_MAX_ACC && Ci % 4 == 0 && Ci >= 16;
+}
+static void thin_plan(int N, int Hi, int Wi, int Ci, ThinGeom& g) {
+    int cv = Ci / 4;
+    g.CTX = 1;
+    while (g.CTX < cv && g.CTX < 64) g.CTX <<= 1;
+    long P = (long)N * Hi * Wi;
+    int TY = 256 / g.CTX;
+    long gy = cdiv(cv, g.CTX);
+    long want = cdiv(THIN_CHUNKS, gy);
+    long maxc = cdiv(P, (long)TY * 4);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    g.chunk = (int)cdiv(P, want);
+    g.nchunks = cdiv(P, g.chunk);
+}
+
 MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);
-    return (size_t)splits * Co * R * S * Ci * sizeof(float);
+    size_t nsplit = (size_t)splits;
+    if (Co <= 4 && nsplit < THIN_CHUNKS) nsplit = THIN_CHUNKS;  // upper bound of the thin path's chunk count
+    return nsplit * Co * R * S * Ci * sizeof(float);
 }
 
 MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
                                  int stride, int pad_t, int pad_l, int gather, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (thin_wgrad_ok(Co, R, S, Ci, stride, gather)) {
+        ThinGeom tg = {N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, 0, 0, 0};
+        thin_plan(N, Hi, Wi, Ci, tg);
+        if ((size_t)tg.nchunks * Co * R * S * Ci * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
+        dim3 grid(tg.nchunks, cdiv(Ci / 4, tg.CTX));
+        size_t lds = 256 * 4 * sizeof(float);
+        switch (Co) {
+            case 1: hipLaunchKernelGGL((thin_wgrad_kernel<1>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+            case 2: hipLaunchKernelGGL((thin_wgrad_kernel<2>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+            case 3: hipLaunchKernelGGL((thin_wgrad_kernel<3>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+            default: hipLaunchKernelGGL((thin_wgrad_kernel<4>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+        }
+        HIP_LAUNCH_CHECK();
+        return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, st);
+    }
     WgradGeom g = {};
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
     g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
@@ -643,10 +782,5 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
-    size_t total = (size_t)Co * Ncol;
-    int blocks = cdiv((long)total, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw_oihw, g.splits, Co, R * S, Ci);
-    HIP_LAUNCH_CHECK();
-    return 0;
+    return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, st);
 }

@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Per-shape timing of the conv-family launchers (C ABI called directly, HIP events on the launch stream).
+
+    python tools/conv_microbench.py [--shapes dcgan|cyclegan|srgan] [--iters 20] [--only fwd,dgrad,wgrad]
+
+Prints one line per (layer, direction): time, algorithmic TFLOP/s, fraction of the 157.3 TF fp32-MFMA peak.
+Used for tuning and as the target command of the rocprofv3 --pmc passes (profiles/).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+# name, N, Ci, H, W, Co, k, stride, pad, gather(0 zero,1 reflect,2 up2)
+SHAPES = {
+    "dcgan": [
+        ("G.conv1 up2 128->128 @32", 128, 128, 16, 16, 128, 3, 1, 1, 2),
+        ("G.conv2 up2 128->64 @64", 128, 128, 32, 32, 64, 3, 1, 1, 2),
+        ("G.conv3 64->1 @64", 128, 64, 64, 64, 1, 3, 1, 1, 0),
+        ("D.conv1 1->16 s2", 128, 1, 64, 64, 16, 3, 2, 1, 0),
+        ("D.conv2 16->32 s2", 128, 16, 32, 32, 32, 3, 2, 1, 0),
+        ("D.conv3 32->64 s2", 128, 32, 16, 16, 64, 3, 2, 1, 0),
+        ("D.conv4 64->128 s2", 128, 64, 8, 8, 128, 3, 2, 1, 0),
+    ],
+    "cyclegan": [
+        ("c7s1-64 3->64 reflect", 8, 3, 256, 256, 64, 7, 1, 3, 1),
+        ("d128 64->128 s2", 8, 64, 256, 256, 128, 3, 2, 1, 0),
+        ("d256 128->256 s2", 8, 128, 128, 128, 256, 3, 2, 1, 0),
+        ("R256 reflect 256->256 @64", 8, 256, 64, 64, 256, 3, 1, 1, 1),
+        ("u128 up2 256->128 @128", 8, 256, 64, 64, 128, 3, 1, 1, 2),
+        ("u64 up2 128->64 @256", 8, 128, 128, 128, 64, 3, 1, 1, 2),
+        ("c7s1-3 64->3 reflect", 8, 64, 256, 256, 3, 7, 1, 3, 1),
+        ("D.c1 3->64 k4s2", 8, 3, 256, 256, 64, 4, 2, 1, 0),
+        ("D.c2 64->128 k4s2", 8, 64, 128, 128, 128, 4, 2, 1, 0),
+        ("D.c3 128->256 k4s2", 8, 128, 64, 64, 256, 4, 2, 1, 0),
+        ("D.c4 256->512 k4s2", 8, 256, 32, 32, 512, 4, 2, 1, 0),
+    ],
+    "srgan": [
+        ("res 64->64 @96", 16, 64, 96, 96, 64, 3, 1, 1, 0),
+        ("up 64->256 @192", 16, 64, 192, 192, 256, 3, 1, 1, 0),
+        ("conv3 9x9 64->3 @384", 16, 64, 384, 384, 3, 9, 1, 4, 0),
+        ("vgg 64->64 @384", 16, 64, 384, 384, 64, 3, 1, 1, 0),
+        ("vgg 256->256 @96", 16, 256, 96, 96, 256, 3, 1, 1, 0),
+        ("D 512->512 s2 @48", 16, 512, 48, 48, 512, 3, 2, 1, 0),
+    ],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="dcgan")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="fwd,dgrad,wgrad")
+    ap.add_argument("--match", default="")
+    args = ap.parse_args()
+    import pytorch_gan_amd  # noqa: F401
+    from pytorch_gan_amd._lib import check, lib
+
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    only = set(args.only.split(","))
+    for name, N, Ci, H, W, Co, k, s, p, gth in SHAPES[args.shapes]:
+        if args.match and args.match not in name:
+            continue
+        HL, WL = (2 * H, 2 * W) if gth == 2 else (H, W)
+        Ho, Wo = (HL + 2 * p - k) // s + 1, (WL + 2 * p - k) // s + 1
+        flops = 2.0 * N * Ho * Wo * Co * Ci * k * k
+        x = torch.rand(N * H * W * Ci, device=dev) * 2 - 1
+        w = (torch.rand(Co * k * k * Ci, device=dev) * 2 - 1) * 0.05
+        y = torch.empty(N * Ho * Wo * Co, device=dev)
+        dy = torch.rand(N * Ho * Wo * Co, device=dev) * 2 - 1
+        # dgrad of a gathered conv targets the logical (padded / upsampled) extent, as functional.py does
+        if gth == 1:
+            Hd, Wd, pd = H + 2 * p, W + 2 * p, 0
+        elif gth == 2:
+            Hd, Wd, pd = HL, WL, p
+        else:
+            Hd, Wd, pd = H, W, p
+        dx = torch.empty(N * Hd * Wd * Ci, device=dev)
+        dw = torch.empty_like(w)
+        nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
+        ws = torch.empty(max(nb // 4, 1), device=dev)
+        calls = {
+            "fwd": lambda: lib.migan_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), N, H, W, Ci, Ho, Wo, Co,
+                                                k, k, s, p, p, gth, 0, 0.0, st),
+            "dgrad": lambda: lib.migan_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
+                                                    Wo, Co, k, k, s, pd, pd, 0, 0.0, st),
+            "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
+                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, st),
+        }
+        for d in ("fwd", "dgrad", "wgrad"):
+            if d not in only:
+                continue
+            fn = calls[d]
+            for _ in range(3):
+                check(fn(), d)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            tf = flops / (ms * 1e-3) / 1e12
+            print("%-28s %-5s %9.1f us  %7.2f TF  %5.1f%%  (%.2f GFLOP)" % (name, d, ms * 1e3, tf, 100 * tf / 157.3, flops / 1e9),
+                  flush=True)
+
+
+if __name__ == "__main__":
+    main()
