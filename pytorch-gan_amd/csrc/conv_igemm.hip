@@ -18,6 +18,7 @@
 // lanes 32-63 the same rows at k=2kp+1).  An fp32 MFMA occupies its SIMD for 64 cycles, so one
 // b32 read per operand per MFMA is far below the LDS issue budget (MI355X_MICROARCH.md §LDS).
 #include "common.h"
+#include <stdlib.h>
 
 #define MAX_TAPS 96
 #define MAX_CLS 4
@@ -36,7 +37,7 @@ struct ConvGeom {
     signed char dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, int VAR = 0>
 __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
                                                     const float* __restrict__ Bw,
                                                     const float* __restrict__ bias,
@@ -206,26 +207,65 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
         }
     };
 
+    if constexpr ((VAR & 12) != 0) {
+        // experiment: de-phase the co-resident workgroups of a CU so their MFMA phases do not run in lockstep
+        int j = (VAR & 4) ? ((blockIdx.x >> 8) & 3) : ((blockIdx.x >> 3) & 3);
+        for (int d = 0; d < j; ++d) __builtin_amdgcn_s_sleep(64);
+    }
     if (KT > 0) load_tile(0);
     for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if ((VAR & 32) == 0 || kt == 0) {  // ablation bit 32: keep only the first LDS fill
+            __syncthreads();
+            store_tile();
+            __syncthreads();
+        }
+        if ((VAR & 16) == 0) {  // ablation bit 16: no global loads in the loop
+            if (kt + 1 < KT) load_tile(kt + 1);
+        }
         const float* ap = As + (wm * (TM * 32) + l31) * LDK + h;
         const float* bp = Bs + (wn * (TN * 32) + l31) * LDK + h;
+        if constexpr ((VAR & 2) != 0) {
+            // fragment double-buffering: the LDS reads of k-pair kp+1 are issued before the MFMAs of k-pair kp
+            float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float a[TM], b[TN];
+            for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32 * LDK];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
+            for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32 * LDK];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                const int cur = kp & 1, nxt = cur ^ 1;
+                if (kp + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(kp + 1) * 2 + i * 32 * LDK];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(kp + 1) * 2 + j * 32 * LDK];
+                }
+                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < BK / 2; ++kp) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
+                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
+            }
         }
     }
 
@@ -260,7 +300,239 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+// ------------------------------------------------------------------------------------------------
+// Pipelined fast path (source channels % 32 == 0).  Same tiles and LDS image as igemm_kernel<.., true>, but
+//  * the gather is BRANCH-FREE (coordinates clamped into the tensor, loads unconditional, padding taps and
+//    tail rows zeroed by a per-tile mask when the tile is written to LDS), so the whole K-step is one basic
+//    block, and
+//  * the NA+NB global loads of K-tile kt+1 are issued one per k-pair INSIDE the MFMA stream of tile kt
+//    (address VALU + global_load in the 64-cycle shadow of the previous MFMAs) instead of as one serial
+//    ~2000-cycle burst per wave.  Ablation on MI355X (profiles/r01_igemm_ablation.txt): the un-interleaved
+//    load burst cost 20 % of the kernel although 4 workgroups/CU were resident.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& src) {
+    int r = v < 0 ? -v : v;
+    r = r >= L ? 2 * L - 2 - r : r;
+    bool inr = (unsigned)v < (unsigned)L;
+    int s = mode == GATHER_REFLECT ? r : (mode == GATHER_UP2 ? (v >> 1) : v);
+    s = s < 0 ? 0 : s;
+    s = s > Lphys - 1 ? Lphys - 1 : s;
+    src = s;
+    return mode == GATHER_REFLECT ? true : inr;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
+    const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
+    float* __restrict__ C) {
+    constexpr int BK = 32, LDK = BK + 1;
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int NA = BM / 32, NB = BN / 32, NL = NA + NB;
+    static_assert(WAVES_M * WAVES_N == 4 && NL <= BK / 2, "tile shape");
+    constexpr int SM_A = BM * LDK, SM_B = BN * LDK;
+    __shared__ __attribute__((aligned(16))) int smem_i[SM_A + SM_B + 3 * MAX_TAPS];
+    float* As = reinterpret_cast<float*>(smem_i);
+    float* Bs = As + SM_A;
+    int* s_wofs = smem_i + SM_A + SM_B;
+    int* s_dh = s_wofs + MAX_TAPS;
+    int* s_dw = s_dh + MAX_TAPS;
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int M = g.N * Ho * Wo;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int n0 = blockIdx.y * BN;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
+    for (int i = tid; i < ntap; i += 256) {
+        s_wofs[i] = g.wofs[tapbeg + i];
+        s_dh[i] = g.dh[tapbeg + i];
+        s_dw[i] = g.dw[tapbeg + i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int kq = tid & 7, frow = tid >> 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tpt = Ci >> 5;
+    const int KT = ntap * tpt;
+    if (KT == 0) {
+        // empty tap list (e.g. a stride-2 parity class of a 1x1 conv): the output is bias/activation only
+    }
+    // per-row gather state
+    int a_base[NA], a_pos[NA];
+    unsigned rowok = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + frow + 32 * j;
+        a_base[j] = 0;
+        a_pos[j] = 0;
+        if (m < M) {
+            int n = m / (Ho * Wo);
+            int rem = m - n * Ho * Wo;
+            int oi = rem / Wo, oj = rem - oi * Wo;
+            a_base[j] = n * Hi * Wi;
+            a_pos[j] = ((oi * g.istride) << 16) | (oj * g.istride);
+            rowok |= 1u << j;
+        }
+    }
+    int b_off[NB];
+    unsigned colok = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int n = n0 + frow + 32 * j;
+        if (n < g.Co) colok |= 1u << j;
+        n = n < g.Co ? n : g.Co - 1;
+        b_off[j] = n * g.ldw + kq * 4;
+    }
+    f32x4 ra[NA], rb[NB];
+    unsigned okA = 0;  // validity of the A rows of the tile currently held in ra[]
+
+    // scalar parameters of the tile being fetched
+    int f_dh = 0, f_dw = 0, f_wo = 0, f_c0 = 0;
+    auto tile_params = [&](int kt) {
+        int t = kt / tpt;
+        f_c0 = (kt - t * tpt) << 5;
+        f_dh = s_dh[t];
+        f_dw = s_dw[t];
+        f_wo = s_wofs[t];
+    };
+#define IGEMM_ISSUE(idx)                                                                               \
+    do {                                                                                               \
+        if ((idx) < NA) {                                                                              \
+            constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
+            int ihs, iws;                                                                              \
+            bool ok = (rowok >> jj) & 1u;                                                              \
+            ok &= map_bf((a_pos[jj] >> 16) + f_dh, g.HiL, Hi, mode, ihs);                              \
+            ok &= map_bf((a_pos[jj] & 0xffff) + f_dw, g.WiL, Wi, mode, iws);                           \
+            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(a_base[jj] + ihs * Wi + iws) * Ci +  \
+                                                     f_c0 + kq * 4);                                   \
+            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                       \
+        } else {                                                                                       \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                         \
+            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(b_off[jj] + f_wo + f_c0));         \
+        }                                                                                              \
+    } while (0)
+
+    if (KT > 0) {
+        tile_params(0);
+        if (0 < NL) IGEMM_ISSUE(0);
+        if (1 < NL) IGEMM_ISSUE(1);
+        if (2 < NL) IGEMM_ISSUE(2);
+        if (3 < NL) IGEMM_ISSUE(3);
+        if (4 < NL) IGEMM_ISSUE(4);
+        if (5 < NL) IGEMM_ISSUE(5);
+        if (6 < NL) IGEMM_ISSUE(6);
+        if (7 < NL) IGEMM_ISSUE(7);
+    }
+    const float* ap = As + (wm * (TM * 32) + l31) * LDK + h;
+    const float* bp = Bs + (wn * (TN * 32) + l31) * LDK + h;
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool ok = (okA >> j) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? ra[j][e] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool ok = (colok >> j) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? rb[j][e] : 0.f;
+        }
+        __syncthreads();
+        tile_params(kt + 1 < KT ? kt + 1 : kt);  // the last iteration refetches its own tile (harmless, branch-free)
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            if ((kp & 1) == 0 && (kp >> 1) < NL) {
+                // make the tap offsets opaque here so this slot's address arithmetic cannot be hoisted into one
+                // serial burst in front of the first MFMA
+                asm volatile("" : "+v"(f_dh), "+v"(f_dw));
+                switch (kp >> 1) {
+                    case 0: IGEMM_ISSUE(0); break;
+                    case 1: IGEMM_ISSUE(1); break;
+                    case 2: IGEMM_ISSUE(2); break;
+                    case 3: IGEMM_ISSUE(3); break;
+                    case 4: IGEMM_ISSUE(4); break;
+                    case 5: IGEMM_ISSUE(5); break;
+                    case 6: IGEMM_ISSUE(6); break;
+                    default: IGEMM_ISSUE(7); break;
+                }
+            }
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep each load-issue slot between its neighbouring MFMA groups
+        }
+    }
+#undef IGEMM_ISSUE
+
+    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int m = m0 + row;
+            if (m >= M) continue;
+            size_t opix;
+            if (linear_out) {
+                opix = (size_t)m;
+            } else {
+                int n = m / (Ho * Wo);
+                int rem = m - n * Ho * Wo;
+                int oi = rem / Wo, oj = rem - oi * Wo;
+                opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < g.Co) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[col];
+                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                       hipStream_t st) {
+    int maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        int m = g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return 0;
+    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST, int VAR = 0>
 static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
                       hipStream_t st) {
     int maxM = 0;
@@ -270,7 +542,7 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, FAST>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, FAST, VAR>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -307,11 +579,31 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
         long m = (long)g.N * g.Ho[c] * g.Wo[c];
         if (m > maxM) maxM = m;
     }
+    static const int var = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
     switch (igemm_select(maxM, g.Co, fast, g.ncls)) {
-        case 1128128: return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
-        case 1128064: return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-        case 1064064: return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-        case 1128032: return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+        case 1128128:
+            if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
+            if (var == 2) return launch_cfg<128, 128, 2, 2, true, 2>(g, A, Bw, bias, C, st);
+            if (var == 3) return launch_cfg<128, 128, 2, 2, true, 3>(g, A, Bw, bias, C, st);
+            if (var == 4) return launch_cfg<128, 128, 2, 2, true, 4>(g, A, Bw, bias, C, st);
+            if (var == 8) return launch_cfg<128, 128, 2, 2, true, 8>(g, A, Bw, bias, C, st);
+            if (var == 16) return launch_cfg<128, 128, 2, 2, true, 16>(g, A, Bw, bias, C, st);
+            if (var == 32) return launch_cfg<128, 128, 2, 2, true, 32>(g, A, Bw, bias, C, st);
+            if (var == 48) return launch_cfg<128, 128, 2, 2, true, 48>(g, A, Bw, bias, C, st);
+            if (var == 100) return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
+            return launch_pipe<128, 128, 2, 2>(g, A, Bw, bias, C, st);
+        case 1128064:
+            if (var == 1) return launch_cfg<128, 64, 2, 2, true, 1>(g, A, Bw, bias, C, st);
+            if (var == 2) return launch_cfg<128, 64, 2, 2, true, 2>(g, A, Bw, bias, C, st);
+            if (var == 3) return launch_cfg<128, 64, 2, 2, true, 3>(g, A, Bw, bias, C, st);
+            if (var == 100) return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            return launch_pipe<128, 64, 2, 2>(g, A, Bw, bias, C, st);
+        case 1064064:
+            if (var == 100) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            return launch_pipe<64, 64, 2, 2>(g, A, Bw, bias, C, st);
+        case 1128032:
+            if (var == 100) return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+            return launch_pipe<128, 32, 4, 1>(g, A, Bw, bias, C, st);
         case 128128: return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
         case 128064: return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
         default: return launch_cfg<128, 32, 4, 1, false>(g, A, Bw, bias, C, st);
@@ -660,31 +952,40 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
 struct ThinGeom {
     int N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, chunk, nchunks, CTX;
 };
-template <int CO>
+template <int CO, int KS>  // KS = square kernel size (compile time: tap offsets fold to constants)
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const float* __restrict__ X,
                                                          const float* __restrict__ DY, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int tid = threadIdx.x;
     const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
-    const int T = g.R * g.S, NACC = T * CO;
+    constexpr int T = KS * KS, NACC = T * CO;
+    static_assert(NACC <= THIN_MAX_ACC, "too many accumulators");
     const int c = (blockIdx.y * g.CTX + tx) * 4;
     const bool cok = c < g.Ci;
     f32x4 acc[THIN_MAX_ACC];
 #pragma unroll
     for (int i = 0; i < THIN_MAX_ACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const long P = (long)g.N * g.Hi * g.Wi;
-    long q0 = (long)blockIdx.x * g.chunk, q1 = q0 + g.chunk;
+    const int P = g.N * g.Hi * g.Wi;
+    int q0 = blockIdx.x * g.chunk, q1 = q0 + g.chunk;
     if (q1 > P) q1 = P;
-    if (cok) {
-        for (long q = q0 + ty; q < q1; q += TY) {
-            int n = (int)(q / (g.Hi * g.Wi));
-            int rem = (int)(q - (long)n * g.Hi * g.Wi);
-            int ih = rem / g.Wi, iw = rem - ih * g.Wi;
-            f32x4 xv = *reinterpret_cast<const f32x4*>(X + q * g.Ci + c);
+    if (cok && q0 + ty < q1) {
+        // (n, ih, iw) of the walking pixel is carried incrementally: no integer division in the loop
+        int q = q0 + ty;
+        int n = q / (g.Hi * g.Wi);
+        int rem = q - n * g.Hi * g.Wi;
+        int ih = rem / g.Wi, iw = rem - ih * g.Wi;
+        for (; q < q1; q += TY, iw += TY) {
+            while (iw >= g.Wi) {
+                iw -= g.Wi;
+                if (++ih >= g.Hi) { ih = 0; ++n; }
+            }
+            f32x4 xv = *reinterpret_cast<const f32x4*>(X + (size_t)q * g.Ci + c);
 #pragma unroll
-            for (int t = 0; t < THIN_MAX_ACC / CO; ++t) {
-                if (t < T) {
-                    int r = t / g.S, s = t - r * g.S;
+            for (int t = 0; t < T; ++t) {
+                {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int r = t / KS, s = t % KS;
                     int oh = ih + g.pad_t - r, ow = iw + g.pad_l - s;
                     if ((unsigned)oh < (unsigned)g.Ho && (unsigned)ow < (unsigned)g.Wo) {
                         const float* d = DY + ((long)(n * g.Ho + oh) * g.Wo + ow) * CO;
@@ -718,7 +1019,24 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const
 }
 
 static bool thin_wgrad_ok(int Co, int R, int S, int Ci, int stride, int gather) {
-    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R * S * Co <= THIN_MAX_ACC && Ci % 4 == 0 && Ci >= 16;
+    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R == S && (S == 1 || S == 3 || (S == 4 && Co <= 2)) &&
+           Ci % 4 == 0 && Ci >= 16;
+}
+template <int KS>
+static void launch_thin(int Co, dim3 grid, size_t lds, hipStream_t st, const ThinGeom& tg, const float* x,
+                        const float* dy, float* ws) {
+    switch (Co) {
+        case 1: hipLaunchKernelGGL((thin_wgrad_kernel<1, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+        case 2: hipLaunchKernelGGL((thin_wgrad_kernel<2, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+        case 3:
+            if constexpr (KS * KS * 3 <= THIN_MAX_ACC)
+                hipLaunchKernelGGL((thin_wgrad_kernel<3, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
+            break;
+        default:
+            if constexpr (KS * KS * 4 <= THIN_MAX_ACC)
+                hipLaunchKernelGGL((thin_wgrad_kernel<4, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
+            break;
+    }
 }
 static void thin_plan(int N, int Hi, int Wi, int Ci, ThinGeom& g) {
     int cv = Ci / 4;
@@ -753,12 +1071,9 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         if ((size_t)tg.nchunks * Co * R * S * Ci * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
         dim3 grid(tg.nchunks, cdiv(Ci / 4, tg.CTX));
         size_t lds = 256 * 4 * sizeof(float);
-        switch (Co) {
-            case 1: hipLaunchKernelGGL((thin_wgrad_kernel<1>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-            case 2: hipLaunchKernelGGL((thin_wgrad_kernel<2>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-            case 3: hipLaunchKernelGGL((thin_wgrad_kernel<3>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-            default: hipLaunchKernelGGL((thin_wgrad_kernel<4>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-        }
+        if (S == 1) launch_thin<1>(Co, grid, lds, st, tg, x, dy, ws);
+        else if (S == 3) launch_thin<3>(Co, grid, lds, st, tg, x, dy, ws);
+        else launch_thin<4>(Co, grid, lds, st, tg, x, dy, ws);
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, st);
     }
