@@ -1,0 +1,152 @@
+"""Data-parallel logic on the CPU (gloo, world_size 2): sharding + ONE summed all-reduce of the flat gradient
+bucket per optimiser + 1/world scaling in the update reproduces the single-process full-batch step
+(SURVEY.md §8e).  The HIP optimiser needs a GPU, so a flat-bucket stand-in with the same interface
+(`flat_grad`, `step(grad_scale)`) drives `pytorch_gan_amd.dp.DataParallel` here; the real optimiser's bucket
+layout is covered by the GPU tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FlatSGD:
+    """Same contract as optim.Adam: grads are views of one flat buffer; step() applies grad_scale."""
+
+    def __init__(self, params, lr=0.1):
+        self.params = list(params)
+        self.lr = lr
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def step(self, grad_scale=1.0):
+        with torch.no_grad():
+            for p in self.params:
+                p.add_(p.grad, alpha=-self.lr * grad_scale)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import reference_models as M
+    from pytorch_gan_amd import dp as dpmod
+
+    dp = dpmod.init_from_env(backend="gloo")
+    assert isinstance(dp, dpmod.DataParallel) and dp.world == world and dp.rank == rank
+    torch.manual_seed(0)
+    D = M.MlpCritic((1, 8, 8))          # no BatchNorm: shards are exactly independent samples
+    G = M.CycleDiscriminator((3, 32, 32))  # InstanceNorm: per-sample statistics, also exactly shardable
+    if rank == 1:  # replicas start from rank 0's weights
+        with torch.no_grad():
+            for p in list(D.parameters()) + list(G.parameters()):
+                p.add_(1.0)
+    dp.broadcast_parameters(D, G)
+    opt_D, opt_G = FlatSGD(D.parameters()), FlatSGD(G.parameters())
+    g = torch.Generator().manual_seed(5)
+    xb = torch.rand(8, 1, 8, 8, generator=g)       # global batches, identical on every rank (host RNG is shared)
+    yb = torch.rand(4, 3, 32, 32, generator=g)
+    dp.begin_step()
+    opt_D.zero_grad()
+    (-torch.mean(D(dp.shard(xb)))).backward()      # every loss on the path is a batch mean
+    dp.step(opt_D)
+    opt_G.zero_grad()
+    torch.nn.functional.mse_loss(G(dp.shard(yb)), torch.ones(4 // world, 1, 2, 2)).backward()
+    dp.step(opt_G)
+    dp.end_step()
+    state = {k: v.clone() for k, v in list(D.state_dict().items()) + [("G." + k, v) for k, v in G.state_dict().items()]}
+    if rank == 0:
+        torch.save(state, out)
+    # every rank must hold identical parameters after the update
+    flat = torch.cat([v.flatten() for v in state.values()])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_full_batch(tmp_path):
+    sys.path.insert(0, ROOT)
+    from oracle import reference_models as M
+
+    out = str(tmp_path / "dp_state.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-process reference on the full batch
+    torch.manual_seed(0)
+    D = M.MlpCritic((1, 8, 8))
+    G = M.CycleDiscriminator((3, 32, 32))
+    opt_D, opt_G = FlatSGD(D.parameters()), FlatSGD(G.parameters())
+    g = torch.Generator().manual_seed(5)
+    xb = torch.rand(8, 1, 8, 8, generator=g)
+    yb = torch.rand(4, 3, 32, 32, generator=g)
+    opt_D.zero_grad()
+    (-torch.mean(D(xb))).backward()
+    opt_D.step()
+    opt_G.zero_grad()
+    torch.nn.functional.mse_loss(G(yb), torch.ones(4, 1, 2, 2)).backward()
+    opt_G.step()
+    want = {k: v for k, v in list(D.state_dict().items()) + [("G." + k, v) for k, v in G.state_dict().items()]}
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.allclose(got[k], want[k], rtol=1e-5, atol=1e-6), k
+
+
+def test_shard_rejects_ragged_batch():
+    sys.path.insert(0, ROOT)
+    from pytorch_gan_amd import dp as dpmod
+
+    class Fake(dpmod.DataParallel):
+        def __init__(self):
+            self.world, self.rank = 3, 1
+
+    d = Fake()
+    assert d.shard(torch.arange(6)).tolist() == [2, 3]
+    try:
+        d.shard(torch.arange(8))
+    except ValueError:
+        return
+    raise AssertionError("ragged global batch must be rejected")
+
+
+def test_local_stepper_is_default():
+    sys.path.insert(0, ROOT)
+    from pytorch_gan_amd import dp as dpmod
+
+    os.environ.pop("WORLD_SIZE", None)
+    s = dpmod.init_from_env()
+    assert isinstance(s, dpmod.LocalStepper) and s.world == 1
+    calls = []
+
+    class Opt:
+        def step(self):
+            calls.append(1)
+
+    s.begin_step()
+    s.step(Opt())
+    s.end_step()
+    assert calls == [1]
+    assert np.isfinite(1.0)
