@@ -398,36 +398,41 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
         b_off[j] = n * g.ldw + kq * 4;
     }
     f32x4 ra[NA], rb[NB];
-    unsigned okA = 0;  // validity of the A rows of the tile currently held in ra[]
-
-    // scalar parameters of the tile being fetched
-    int f_dh = 0, f_dw = 0, f_wo = 0, f_c0 = 0;
-    auto tile_params = [&](int kt) {
-        int t = kt / tpt;
-        f_c0 = (kt - t * tpt) << 5;
-        f_dh = s_dh[t];
-        f_dw = s_dw[t];
+    // Incremental addressing: the expensive part of the gather (coordinate map of the tap, pixel offset) is
+    // recomputed only when the fetch position moves to the next tap (every Ci/32 K-tiles, in a uniform branch);
+    // inside a tap the next K-tile is the same pixels 32 channels further on: one add per load.
+    int a_off[NA];          // element offset of this thread's 16 B of row j at channel 0 of the fetch tap
+    unsigned okA = 0;       // validity (row in range and tap not in the zero padding) for the fetch tap
+    int f_t = 0, f_c0 = 0, f_wo = 0;
+    auto setup_tap = [&](int t) {
+        const int dh = s_dh[t], dw = s_dw[t];
         f_wo = s_wofs[t];
+        okA = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            int ihs, iws;
+            bool ok = (rowok >> j) & 1u;
+            ok &= map_bf((a_pos[j] >> 16) + dh, g.HiL, Hi, mode, ihs);
+            ok &= map_bf((a_pos[j] & 0xffff) + dw, g.WiL, Wi, mode, iws);
+            a_off[j] = (a_base[j] + ihs * Wi + iws) * Ci + kq * 4;
+            okA |= ok ? (1u << j) : 0u;
+        }
     };
 #define IGEMM_ISSUE(idx)                                                                               \
     do {                                                                                               \
         if ((idx) < NA) {                                                                              \
             constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
-            int ihs, iws;                                                                              \
-            bool ok = (rowok >> jj) & 1u;                                                              \
-            ok &= map_bf((a_pos[jj] >> 16) + f_dh, g.HiL, Hi, mode, ihs);                              \
-            ok &= map_bf((a_pos[jj] & 0xffff) + f_dw, g.WiL, Wi, mode, iws);                           \
-            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(a_base[jj] + ihs * Wi + iws) * Ci +  \
-                                                     f_c0 + kq * 4);                                   \
-            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                       \
+            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(unsigned)(a_off[jj] + f_c0));        \
         } else {                                                                                       \
-            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                         \
-            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(b_off[jj] + f_wo + f_c0));         \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
+            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(unsigned)(b_off[jj] + f_wo + f_c0)); \
         }                                                                                              \
     } while (0)
 
+    unsigned okS = 0;  // validity mask of the tile currently staged in ra[] (written to LDS next)
     if (KT > 0) {
-        tile_params(0);
+        setup_tap(0);
+        okS = okA;
         if (0 < NL) IGEMM_ISSUE(0);
         if (1 < NL) IGEMM_ISSUE(1);
         if (2 < NL) IGEMM_ISSUE(2);
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const bool ok = (okA >> j) & 1u;
+            const bool ok = (okS >> j) & 1u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) As[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? ra[j][e] : 0.f;
         }
@@ -454,13 +459,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
             for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? rb[j][e] : 0.f;
         }
         __syncthreads();
-        tile_params(kt + 1 < KT ? kt + 1 : kt);  // the last iteration refetches its own tile (harmless, branch-free)
+        if (kt + 1 < KT) {  // move the fetch position to tile kt+1 (the last iteration refetches its own tile)
+            f_c0 += 32;
+            if (f_c0 == Ci) {
+                f_c0 = 0;
+                setup_tap(++f_t);
+            }
+        }
+        okS = okA;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
                 // make the tap offsets opaque here so this slot's address arithmetic cannot be hoisted into one
                 // serial burst in front of the first MFMA
-                asm volatile("" : "+v"(f_dh), "+v"(f_dw));
+                asm volatile("" : "+s"(f_c0));
                 switch (kp >> 1) {
                     case 0: IGEMM_ISSUE(0); break;
                     case 1: IGEMM_ISSUE(1); break;
@@ -517,6 +529,245 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Double-buffered fast path.  tools/mfma_loop_probe.hip (profiles/r01_mfma_loop_probe.txt) shows that ONE wave
+// per SIMD already drives the fp32 matrix pipe at 94-98 % when its stream is dense in MFMAs, while FOUR
+// MFMA-issuing waves per SIMD arbitrate at only ~77 %.  So this kernel runs 2 workgroups per CU and removes
+// the serial sections from the K-loop instead of hiding them behind occupancy:
+//   * two LDS buffers; while tile kt is multiplied out of buf[cur], the register-staged tile kt+1 is written
+//     into buf[cur^1] during k-pairs 0..NL-1 and the global loads of tile kt+2 are issued during k-pairs
+//     NL..2NL-1 (one slot per k-pair, inside the MFMA stream), and there is ONE barrier per K-tile;
+//   * loads are branch-free (see igemm_pipe_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void igemm_db_kernel(const ConvGeom g, const float* __restrict__ A,
+                                                          const float* __restrict__ Bw,
+                                                          const float* __restrict__ bias, float* __restrict__ C) {
+    constexpr int BK = 32, LDK = BK + 1;
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int NA = BM / 32, NB = BN / 32, NL = NA + NB;
+    static_assert(WAVES_M * WAVES_N == 4 && 2 * NL <= BK / 2, "tile shape");
+    constexpr int SM_A = BM * LDK, SM_B = BN * LDK, SM_T = SM_A + SM_B;
+    __shared__ __attribute__((aligned(16))) int smem_i[2 * SM_T + 3 * MAX_TAPS];
+    float* S0 = reinterpret_cast<float*>(smem_i);
+    int* s_wofs = smem_i + 2 * SM_T;
+    int* s_dh = s_wofs + MAX_TAPS;
+    int* s_dw = s_dh + MAX_TAPS;
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int M = g.N * Ho * Wo;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int n0 = blockIdx.y * BN;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
+    for (int i = tid; i < ntap; i += 256) {
+        s_wofs[i] = g.wofs[tapbeg + i];
+        s_dh[i] = g.dh[tapbeg + i];
+        s_dw[i] = g.dw[tapbeg + i];
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int kq = tid & 7, frow = tid >> 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tpt = Ci >> 5;
+    const int KT = ntap * tpt;
+    int a_base[NA], a_pos[NA];
+    unsigned rowok = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int m = m0 + frow + 32 * j;
+        a_base[j] = 0;
+        a_pos[j] = 0;
+        if (m < M) {
+            int n = m / (Ho * Wo);
+            int rem = m - n * Ho * Wo;
+            int oi = rem / Wo, oj = rem - oi * Wo;
+            a_base[j] = n * Hi * Wi;
+            a_pos[j] = ((oi * g.istride) << 16) | (oj * g.istride);
+            rowok |= 1u << j;
+        }
+    }
+    int b_off[NB];
+    unsigned colok = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int n = n0 + frow + 32 * j;
+        if (n < g.Co) colok |= 1u << j;
+        n = n < g.Co ? n : g.Co - 1;
+        b_off[j] = n * g.ldw + kq * 4;
+    }
+    f32x4 ra[NA], rb[NB];
+    unsigned okA = 0;
+    int f_dh = 0, f_dw = 0, f_wo = 0, f_c0 = 0;
+    auto tile_params = [&](int kt) {
+        int t = kt / tpt;
+        f_c0 = (kt - t * tpt) << 5;
+        f_dh = s_dh[t];
+        f_dw = s_dw[t];
+        f_wo = s_wofs[t];
+    };
+#define DB_ISSUE(idx)                                                                                  \
+    do {                                                                                               \
+        if ((idx) < NA) {                                                                              \
+            constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
+            int ihs, iws;                                                                              \
+            bool ok = (rowok >> jj) & 1u;                                                              \
+            ok &= map_bf((a_pos[jj] >> 16) + f_dh, g.HiL, Hi, mode, ihs);                              \
+            ok &= map_bf((a_pos[jj] & 0xffff) + f_dw, g.WiL, Wi, mode, iws);                           \
+            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(a_base[jj] + ihs * Wi + iws) * Ci +  \
+                                                     f_c0 + kq * 4);                                   \
+            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                       \
+        } else {                                                                                       \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
+            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(b_off[jj] + f_wo + f_c0));         \
+        }                                                                                              \
+    } while (0)
+#define DB_WRITE(idx, dst)                                                                             \
+    do {                                                                                               \
+        if ((idx) < NA) {                                                                              \
+            constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
+            const bool ok = (okA >> jj) & 1u;                                                          \
+            float* d_ = (dst) + (frow + 32 * jj) * LDK + kq * 4;                                       \
+            d_[0] = ok ? ra[jj][0] : 0.f; d_[1] = ok ? ra[jj][1] : 0.f;                                \
+            d_[2] = ok ? ra[jj][2] : 0.f; d_[3] = ok ? ra[jj][3] : 0.f;                                \
+        } else {                                                                                       \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
+            const bool ok = (colok >> jj) & 1u;                                                        \
+            float* d_ = (dst) + SM_A + (frow + 32 * jj) * LDK + kq * 4;                                \
+            d_[0] = ok ? rb[jj][0] : 0.f; d_[1] = ok ? rb[jj][1] : 0.f;                                \
+            d_[2] = ok ? rb[jj][2] : 0.f; d_[3] = ok ? rb[jj][3] : 0.f;                                \
+        }                                                                                              \
+    } while (0)
+#define DB_FOR_SLOTS(OP)                                                       \
+    do {                                                                       \
+        if (0 < NL) OP(0); if (1 < NL) OP(1); if (2 < NL) OP(2); if (3 < NL) OP(3); \
+        if (4 < NL) OP(4); if (5 < NL) OP(5); if (6 < NL) OP(6); if (7 < NL) OP(7); \
+    } while (0)
+
+    // prologue: tile 0 -> buf 0, tile 1 staged in registers
+    if (KT > 0) {
+        tile_params(0);
+#define OP_I(i) DB_ISSUE(i)
+        DB_FOR_SLOTS(OP_I);
+#define OP_W0(i) DB_WRITE(i, S0)
+        DB_FOR_SLOTS(OP_W0);
+        tile_params(KT > 1 ? 1 : 0);
+        DB_FOR_SLOTS(OP_I);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        float* cur = S0 + (kt & 1) * SM_T;
+        float* nxt = S0 + ((kt & 1) ^ 1) * SM_T;
+        const float* ap = cur + (wm * (TM * 32) + l31) * LDK + h;
+        const float* bp = cur + SM_A + (wn * (TN * 32) + l31) * LDK + h;
+        tile_params(kt + 2 < KT ? kt + 2 : KT - 1);  // tail iterations refetch the last tile (harmless, branch-free)
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            if (kp < NL) {
+                // staged tile kt+1 -> the other LDS buffer (its previous readers passed the barrier of tile kt-1)
+                switch (kp) {
+                    case 0: DB_WRITE(0, nxt); break;
+                    case 1: DB_WRITE(1, nxt); break;
+                    case 2: DB_WRITE(2, nxt); break;
+                    case 3: DB_WRITE(3, nxt); break;
+                    case 4: DB_WRITE(4, nxt); break;
+                    case 5: DB_WRITE(5, nxt); break;
+                    case 6: DB_WRITE(6, nxt); break;
+                    default: DB_WRITE(7, nxt); break;
+                }
+            } else if (kp < 2 * NL) {
+                asm volatile("" : "+v"(f_dh), "+v"(f_dw));
+                switch (kp - NL) {
+                    case 0: DB_ISSUE(0); break;
+                    case 1: DB_ISSUE(1); break;
+                    case 2: DB_ISSUE(2); break;
+                    case 3: DB_ISSUE(3); break;
+                    case 4: DB_ISSUE(4); break;
+                    case 5: DB_ISSUE(5); break;
+                    case 6: DB_ISSUE(6); break;
+                    default: DB_ISSUE(7); break;
+                }
+            }
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#undef DB_ISSUE
+#undef DB_WRITE
+#undef DB_FOR_SLOTS
+#undef OP_I
+#undef OP_W0
+
+    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int m = m0 + row;
+            if (m >= M) continue;
+            size_t opix;
+            if (linear_out) {
+                opix = (size_t)m;
+            } else {
+                int n = m / (Ho * Wo);
+                int rem = m - n * Ho * Wo;
+                int oi = rem / Wo, oj = rem - oi * Wo;
+                opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < g.Co) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[col];
+                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_db(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                     hipStream_t st) {
+    int maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        int m = g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return 0;
+    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    hipLaunchKernelGGL((igemm_db_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
                        hipStream_t st) {
@@ -551,13 +802,16 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
 // code = fast*1000000 + BM*1000 + BN
 static int igemm_select(long maxM, int Co, bool fast, int ncls) {
     if (fast) {
-        if (Co > 64) {
-            long blocks = (long)cdiv(maxM, 128) * cdiv(Co, 128) * ncls;
-            return blocks < 384 ? 1064064 : 1128128;
-        }
+        // candidates from the most MFMA-efficient tile down; take the first one that fills the chip
+        // (>= 896 workgroups ~ 256 CUs x 4 resident), else the one with the most workgroups
         if (Co > 32) {
-            long blocks = (long)cdiv(maxM, 128) * ncls;
-            return blocks < 384 ? 1064064 : 1128064;
+            long b128 = (long)cdiv(maxM, 128) * cdiv(Co, 128) * ncls;
+            long b64n = (long)cdiv(maxM, 128) * cdiv(Co, 64) * ncls;
+            long b64 = (long)cdiv(maxM, 64) * cdiv(Co, 64) * ncls;
+            if (Co > 64 && b128 >= 896) return 1128128;
+            if (b64n >= 896) return 1128064;
+            if (Co > 64 && b128 >= 512 && b64 < 1792) return 1128128;
+            return b64n >= 512 ? 1128064 : 1064064;
         }
         return 1128032;
     }
@@ -591,12 +845,14 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
             if (var == 32) return launch_cfg<128, 128, 2, 2, true, 32>(g, A, Bw, bias, C, st);
             if (var == 48) return launch_cfg<128, 128, 2, 2, true, 48>(g, A, Bw, bias, C, st);
             if (var == 100) return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
+            if (var == 300) return launch_db<128, 128, 2, 2>(g, A, Bw, bias, C, st);
             return launch_pipe<128, 128, 2, 2>(g, A, Bw, bias, C, st);
         case 1128064:
             if (var == 1) return launch_cfg<128, 64, 2, 2, true, 1>(g, A, Bw, bias, C, st);
             if (var == 2) return launch_cfg<128, 64, 2, 2, true, 2>(g, A, Bw, bias, C, st);
             if (var == 3) return launch_cfg<128, 64, 2, 2, true, 3>(g, A, Bw, bias, C, st);
             if (var == 100) return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            if (var == 300) return launch_db<128, 64, 2, 2>(g, A, Bw, bias, C, st);
             return launch_pipe<128, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1064064:
             if (var == 100) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
@@ -686,7 +942,20 @@ struct WgradGeom {
     int Ho, Wo, Co;
     int R, S, stride, pad_t, pad_l, gather;
     int splits, pix_per_split;  // pixels per split (multiple of 32)
+    int tiles_m, tiles_n;       // tile grid of the pipelined kernel (1-D XCD-aware launch)
+    unsigned mg_hw, mg_w;       // magic multipliers / shifts for p / (Ho*Wo) and rem / Wo (pipelined kernel)
+    int sh_hw, sh_w;
 };
+
+// q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
+static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
+    s = 0;
+    while ((1ull << s) < d) ++s;
+    m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+__device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
+    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
+}
 
 template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const float* __restrict__ X,
@@ -874,54 +1143,219 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
         }
 }
 
-// part[s][co][t*Ci+ci]  ->  dw[co][ci][t]  (OIHW), summed over s in fixed order.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
-                                    int Co, int T, int Ci) {
-    size_t total = (size_t)Co * T * Ci;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        // i indexes the OIHW output so that stores are coalesced
-        int t = (int)(i % T);
-        size_t r = i / T;
-        int ci = (int)(r % Ci);
-        int co = (int)(r / Ci);
-        size_t src = ((size_t)co * T + t) * Ci + ci;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + src];
-        dw[i] = s;
+// ------------------------------------------------------------------------------------------------
+// Pipelined wgrad (Co % 4 == 0 and Ci % 4 == 0): same tiling and [k][row] LDS image as wgrad_kernel, but the
+// pixel -> (n, oi, oj) decode uses multiply-shift division per thread (no LDS row-info pass, no extra barrier
+// dependency), the gather is branch-free and the loads of K-tile kt+1 are issued one per k-pair inside the MFMA
+// stream of tile kt (see igemm_pipe_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int ABL = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_kernel(
+    const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
+    constexpr int BK = 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int QA = BM / 4, QB = BN / 4;
+    constexpr int NA = (BK * QA) / 256, NB = (BK * QB) / 256, NL = NA + NB;
+    static_assert(NL <= BK / 2, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int T = g.R * g.S;
+    const int Ncol = T * g.Ci;
+    const int Mpix = g.N * g.Ho * g.Wo;
+    // XCD-aware block order (workgroup b runs on XCD b % 8): the tiles of ONE split run back-to-back on ONE XCD, so
+    // the dy / x pixel range they all re-read is served by that XCD's L2 instead of 8 separate L2s + Infinity Cache.
+    int split, tile;
+    {
+        const int tiles = g.tiles_m * g.tiles_n;
+        if (g.splits % 8 == 0) {
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+            const int sg = k / tiles;
+            tile = k - sg * tiles;
+            split = sg * 8 + xcd;
+        } else {
+            split = blockIdx.x / tiles;
+            tile = blockIdx.x - split * tiles;
+        }
     }
+    const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
+    const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
+    int p_end = p_begin + g.pix_per_split;
+    if (p_end > Mpix) p_end = Mpix;
+    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int qa = tid % QA, qb = tid % QB;
+    const int plA = tid / QA, plB = tid / QB;
+    // fixed column of the gathered operand
+    int b_dh = 0, b_dw = 0, b_ci = 0;
+    bool b_colok = false;
+    {
+        int col = nc0 + qb * 4;
+        if (col < Ncol) {
+            int t = col / g.Ci;
+            b_ci = col - t * g.Ci;
+            int r = t / g.S, s = t - r * g.S;
+            b_dh = r - g.pad_t;
+            b_dw = s - g.pad_l;
+            b_colok = true;
+        }
+    }
+    const bool a_colok = (co0 + qa * 4) < g.Co;
+    const int a_col = a_colok ? co0 + qa * 4 : 0;
+    const int HoWo = g.Ho * g.Wo;
+    f32x4 ra[NA], rb[NB];
+    unsigned okA = 0, okB = 0;
+    int f_pt0 = p_begin;
+
+#define WGRAD_ISSUE(idx)                                                                                  \
+    do {                                                                                                  \
+        if ((idx) < NA) {                                                                                 \
+            constexpr int jj = (idx) < NA ? (idx) : 0;                                                    \
+            int p = f_pt0 + plA + jj * (256 / QA);                                                        \
+            bool ok = a_colok && p < p_end;                                                               \
+            p = p < p_end ? p : p_end - 1;                                                                \
+            ra[jj] = *reinterpret_cast<const f32x4*>(DY + (size_t)p * g.Co + a_col);                      \
+            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                          \
+        } else {                                                                                          \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                         \
+            int p = f_pt0 + plB + jj * (256 / QB);                                                        \
+            bool ok = b_colok && p < p_end;                                                               \
+            p = p < p_end ? p : p_end - 1;                                                                \
+            int n = fastdiv(p, g.mg_hw, g.sh_hw);                                                         \
+            int rem = p - n * HoWo;                                                                       \
+            int oi = fastdiv(rem, g.mg_w, g.sh_w);                                                        \
+            int oj = rem - oi * g.Wo;                                                                     \
+            int ihs, iws;                                                                                 \
+            ok &= map_bf(oi * g.stride + b_dh, g.HiL, g.Hi, g.gather, ihs);                               \
+            ok &= map_bf(oj * g.stride + b_dw, g.WiL, g.Wi, g.gather, iws);                               \
+            rb[jj] = *reinterpret_cast<const f32x4*>(X + (size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + \
+                                                     b_ci);                                               \
+            okB = ok ? (okB | (1u << jj)) : (okB & ~(1u << jj));                                          \
+        }                                                                                                 \
+    } while (0)
+
+    if (KT > 0) {
+        if (0 < NL) WGRAD_ISSUE(0);
+        if (1 < NL) WGRAD_ISSUE(1);
+        if (2 < NL) WGRAD_ISSUE(2);
+        if (3 < NL) WGRAD_ISSUE(3);
+        if (4 < NL) WGRAD_ISSUE(4);
+        if (5 < NL) WGRAD_ISSUE(5);
+        if (6 < NL) WGRAD_ISSUE(6);
+        if (7 < NL) WGRAD_ISSUE(7);
+    }
+    const float* ap = As + h * LDA + wm * (TM * 32) + l31;
+    const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) {
+        if ((ABL & 2) == 0 || kt == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            *reinterpret_cast<f32x4*>(As + (plA + j * (256 / QA)) * LDA + qa * 4) = ((okA >> j) & 1u) ? ra[j] : zero4;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<f32x4*>(Bs + (plB + j * (256 / QB)) * LDB + qb * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
+        __syncthreads();
+        }
+        f_pt0 = p_begin + (kt + 1 < KT ? kt + 1 : kt) * BK;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            if ((ABL & 1) == 0 && (kp & 1) == 0 && (kp >> 1) < NL) {
+                asm volatile("" : "+s"(f_pt0));
+                switch (kp >> 1) {
+                    case 0: WGRAD_ISSUE(0); break;
+                    case 1: WGRAD_ISSUE(1); break;
+                    case 2: WGRAD_ISSUE(2); break;
+                    case 3: WGRAD_ISSUE(3); break;
+                    case 4: WGRAD_ISSUE(4); break;
+                    case 5: WGRAD_ISSUE(5); break;
+                    case 6: WGRAD_ISSUE(6); break;
+                    default: WGRAD_ISSUE(7); break;
+                }
+            }
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef WGRAD_ISSUE
+    float* out = part + (size_t)split * g.Co * Ncol;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co >= g.Co) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
+            }
+        }
 }
 
-// Same reduction with ONE WAVE per output element (many splits, few outputs): lanes stride over the splits
-// in a fixed order, then a butterfly sum — still deterministic run to run.
-__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ part,
-                                                                float* __restrict__ dw, int splits, int Co, int T,
-                                                                int Ci) {
+// part[s][co][t*Ci+ci]  ->  dw[co][ci][t]  (OIHW), summed over s in a fixed order (deterministic).
+// Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
+// `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
+// split loop (LDS combine in fixed order) when there are many splits and few outputs.
+template <int GROUPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int splits, int Co, int T, int Ci) {
+    constexpr int OUTS = 256 / GROUPS;
+    __shared__ float red[256];
     const size_t total = (size_t)Co * T * Ci;
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (i >= total) return;
-    int t = (int)(i % T);
-    size_t r = i / T;
-    int ci = (int)(r % Ci);
-    int co = (int)(r / Ci);
-    size_t src = ((size_t)co * T + t) * Ci + ci;
+    const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
+    const size_t src = (size_t)blockIdx.x * OUTS + lo;
     float s = 0.f;
-    for (int k = lane; k < splits; k += 64) s += part[(size_t)k * total + src];
+    if (src < total)
+        for (int k = grp; k < splits; k += GROUPS) s += part[(size_t)k * total + src];
+    if (GROUPS > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (grp == 0) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) dw[i] = s;
+            for (int q = 1; q < GROUPS; ++q) s += red[q * OUTS + lo];
+        }
+    }
+    if (grp == 0 && src < total) {
+        int ci = (int)(src % Ci);
+        size_t r = src / Ci;
+        int t = (int)(r % T);
+        int co = (int)(r / T);
+        dw[((size_t)co * Ci + ci) * T + t] = s;
+    }
 }
 static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, hipStream_t st) {
-    size_t total = (size_t)Co * T * Ci;
-    if (splits >= 16 && total * 64 <= (size_t)1 << 26) {
-        hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3(cdiv((long)total * 64, 256)), dim3(256), 0, st, ws, dw, splits,
-                           Co, T, Ci);
-    } else {
-        int blocks = cdiv((long)total, 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
-    }
+    long total = (long)Co * T * Ci;
+    if (splits >= 64 && total < (1 << 16))
+        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+    else if (splits >= 16 && total < (1 << 20))
+        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(cdiv(total, 64)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+    else
+        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -937,6 +1371,9 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
     if (want > 512) want = 512;
     pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
     splits = cdiv(Mpix, pps);
+    // XCD-aware launch order wants a multiple of 8 splits (one split per XCD at a time); the padding splits have
+    // empty pixel ranges and write zero slabs
+    if (splits > 4) splits = cdiv(splits, 8) * 8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1087,6 +1524,30 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     wgrad_plan(N, Ho, Wo, Co, Ncol, bm, g.splits, g.pix_per_split);
     if ((size_t)g.splits * Co * Ncol * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
     bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
+    fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
+    fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
+    static const int wvar = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // 100 = old kernel
+    if (vec && wvar != 100) {
+        if (bm == 128) {
+            g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
+            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+            if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
+            else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
+            else if (wvar == 3) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
+            else
+            hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
+        } else if (Ncol >= 128 && wvar != 64) {
+            g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
+            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+            hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
+        } else {
+            g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
+            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+            hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64>), grid, dim3(256), 0, st, g, x, dy, ws);
+        }
+        HIP_LAUNCH_CHECK();
+        return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, st);
+    }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
         if (vec) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
