@@ -48,7 +48,8 @@ int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, 
 
 /* Which tile configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
  * Co columns and a source with Ci_src channels: fast*1000000 + BM*1000 + BN ("fast" = vectorised NHWC loader,
- * Ci_src % 32 == 0).  Pure function; used by bench.py to attribute launches to kernel symbols. */
+ * Ci_src % 32 == 0); 4000 = the thin-N VALU kernel (Co <= 4).  Pure function; used by bench.py to attribute
+ * launches to kernel symbols. */
 int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls);
 
 /* Conv2d / Linear weight gradient (aten::convolution_backward grad_weight; aten::mm in AddmmBackward).

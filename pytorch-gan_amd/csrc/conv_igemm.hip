@@ -821,7 +821,142 @@ static int igemm_select(long maxM, int Co, bool fast, int ncls) {
 }
 
 MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls) {
+    if (Co <= 4 && Ci_src % 4 == 0 && Ci_src >= 8) return 4000;  // thin_conv_kernel (VALU direct conv)
     return igemm_select((long)maxM, Co, Ci_src % 32 == 0, ncls);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thin-N direct convolution (GEMM N = output channels <= 4, source channels % 4 == 0): image-output convs
+// (dcgan.py:62 64->1, cyclegan/models.py:82 7x7 64->3, srgan/models.py:62 9x9 64->3, PatchGAN heads 512->1,
+// pix2pix/models.py:79 128->3) and dgrads INTO 1/3-channel images.  An MFMA tile would be >= 87 % padding,
+// and the fp32 VALU has the same peak as the fp32 MFMA, so this is a VALU kernel: one output pixel per lane,
+// the source window of an output tile (with halo, already padded / reflected / upsampled) is staged once in LDS
+// per channel chunk with coalesced 16 B loads, each lane walks its window with conflict-free ds_read_b128, and
+// the <= 4 weight rows are wave-uniform (scalar loads).  Same ConvGeom tap lists / parity classes as the igemm.
+// ------------------------------------------------------------------------------------------------
+struct ThinConv {
+    int TH, TW, CC, logQ;        // output tile (TH*TW == 256), channel chunk, log2(CC/4)
+    int SH, SW;                  // staged window extent (logical source coordinates)
+    int dhmin[MAX_CLS], dwmin[MAX_CLS];
+    int tiles_w[MAX_CLS], tiles[MAX_CLS];
+};
+template <int CO>
+__global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const ThinConv tc,
+                                                        const float* __restrict__ A, const float* __restrict__ Bw,
+                                                        const float* __restrict__ bias, float* __restrict__ C) {
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z, n = blockIdx.y;
+    if ((int)blockIdx.x >= tc.tiles[cls]) return;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int tile_r = blockIdx.x / tc.tiles_w[cls], tile_c = blockIdx.x - tile_r * tc.tiles_w[cls];
+    const int oi0 = tile_r * tc.TH, oj0 = tile_c * tc.TW;
+    const int ti = tid / tc.TW, tj = tid - ti * tc.TW;
+    const int oi = oi0 + ti, oj = oj0 + tj;
+    const bool valid = oi < Ho && oj < Wo;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int LDC = tc.CC + 4, Q = tc.CC >> 2;
+    const int vh0 = oi0 * g.istride + tc.dhmin[cls], vw0 = oj0 * g.istride + tc.dwmin[cls];
+    const float* Ab = A + (size_t)n * g.Hi * g.Wi * g.Ci;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const int px_off = (ti * g.istride - tc.dhmin[cls]) * tc.SW + (tj * g.istride - tc.dwmin[cls]);
+
+    for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
+        __syncthreads();
+        for (int sr = 0; sr < tc.SH; ++sr) {
+            int ihs;
+            const bool rok = map_coord(vh0 + sr, g.HiL, g.gather, ihs);
+            for (int i = tid; i < tc.SW * Q; i += 256) {
+                const int sc = i >> tc.logQ, q = i & (Q - 1);
+                int iws;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (rok && map_coord(vw0 + sc, g.WiL, g.gather, iws))
+                    v = *reinterpret_cast<const f32x4*>(Ab + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + q * 4);
+                *reinterpret_cast<f32x4*>(win + (size_t)(sr * tc.SW + sc) * LDC + q * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            for (int t = 0; t < ntap; ++t) {
+                const int dh = g.dh[tapbeg + t], dw = g.dw[tapbeg + t];
+                const float* xr = win + (size_t)(px_off + dh * tc.SW + dw) * LDC;
+                const float* wr = Bw + g.wofs[tapbeg + t] + c0;
+                for (int c = 0; c < tc.CC; c += 4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+                    for (int k = 0; k < CO; ++k) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (size_t)k * g.ldw + c);  // wave-uniform
+                        acc[k] = fmaf(xv[0], wv[0], acc[k]);
+                        acc[k] = fmaf(xv[1], wv[1], acc[k]);
+                        acc[k] = fmaf(xv[2], wv[2], acc[k]);
+                        acc[k] = fmaf(xv[3], wv[3], acc[k]);
+                    }
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+#pragma unroll
+    for (int k = 0; k < CO; ++k) {
+        float v = acc[k];
+        if (bias) v += bias[k];
+        C[opix * g.Co + k] = act_apply(v, g.act, g.slope);
+    }
+}
+
+static bool thin_conv_plan(const ConvGeom& g, ThinConv& tc, size_t& lds_bytes, int& max_tiles) {
+    if (g.Co > 4 || g.Ci % 4 != 0 || g.Ci < 8 || g.ldw % 4 != 0) return false;
+    for (int t = 0; t < MAX_TAPS; ++t)
+        if (g.wofs[t] % 4 != 0) return false;
+    int wmax = 0;
+    for (int c = 0; c < g.ncls; ++c) wmax = g.Wo[c] > wmax ? g.Wo[c] : wmax;
+    tc.TW = wmax > 16 ? 32 : (wmax > 8 ? 16 : 8);
+    tc.TH = 256 / tc.TW;
+    int ehmax = 0, ewmax = 0;
+    max_tiles = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        int dh0 = 127, dh1 = -128, dw0 = 127, dw1 = -128;
+        for (int t = 0; t < g.ntap[c]; ++t) {
+            int dh = g.dh[g.tapbeg[c] + t], dw = g.dw[g.tapbeg[c] + t];
+            dh0 = dh < dh0 ? dh : dh0; dh1 = dh > dh1 ? dh : dh1;
+            dw0 = dw < dw0 ? dw : dw0; dw1 = dw > dw1 ? dw : dw1;
+        }
+        if (g.ntap[c] == 0) dh0 = dh1 = dw0 = dw1 = 0;
+        tc.dhmin[c] = dh0; tc.dwmin[c] = dw0;
+        ehmax = dh1 - dh0 > ehmax ? dh1 - dh0 : ehmax;
+        ewmax = dw1 - dw0 > ewmax ? dw1 - dw0 : ewmax;
+        tc.tiles_w[c] = cdiv(g.Wo[c], tc.TW);
+        tc.tiles[c] = tc.tiles_w[c] * cdiv(g.Ho[c], tc.TH);
+        max_tiles = tc.tiles[c] > max_tiles ? tc.tiles[c] : max_tiles;
+    }
+    tc.SH = (tc.TH - 1) * g.istride + ehmax + 1;
+    tc.SW = (tc.TW - 1) * g.istride + ewmax + 1;
+    // largest power-of-two channel chunk (>= 8 channels) dividing Ci whose window fits in 64 KB of LDS
+    int cc = 8;
+    for (int cand = 16; cand <= 256; cand <<= 1)
+        if (g.Ci % cand == 0 && (size_t)tc.SH * tc.SW * (cand + 4) * 4 <= 64 * 1024) cc = cand;
+    if (g.Ci % cc != 0 || (size_t)tc.SH * tc.SW * (cc + 4) * 4 > 64 * 1024) return false;
+    tc.CC = cc;
+    tc.logQ = 0;
+    while ((1 << tc.logQ) < cc / 4) ++tc.logQ;
+    lds_bytes = (size_t)tc.SH * tc.SW * (cc + 4) * 4;
+    return max_tiles > 0;
+}
+
+static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, int max_tiles, const float* A,
+                            const float* Bw, const float* bias, float* C, hipStream_t st) {
+    dim3 grid(max_tiles, g.N, g.ncls);
+    switch (g.Co) {
+        case 1: hipLaunchKernelGGL((thin_conv_kernel<1>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        case 2: hipLaunchKernelGGL((thin_conv_kernel<2>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        case 3: hipLaunchKernelGGL((thin_conv_kernel<3>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        default: hipLaunchKernelGGL((thin_conv_kernel<4>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+    }
+    HIP_LAUNCH_CHECK();
+    return 0;
 }
 
 static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
@@ -834,6 +969,13 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
         if (m > maxM) maxM = m;
     }
     static const int var = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
+    if (g.Co <= 4 && var != 100) {
+        ThinConv tc = {};
+        size_t lds = 0;
+        int max_tiles = 0;
+        if (g.N <= 65535 && thin_conv_plan(g, tc, lds, max_tiles))
+            return launch_thin_conv(g, tc, lds, max_tiles, A, Bw, bias, C, st);
+    }
     switch (igemm_select(maxM, g.Co, fast, g.ncls)) {
         case 1128128:
             if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
@@ -1490,11 +1632,144 @@ static void thin_plan(int N, int Hi, int Wi, int Ci, ThinGeom& g) {
     g.nchunks = cdiv(P, g.chunk);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled thin weight gradient (Co <= 4, ANY kernel size / stride / gather): the 7x7 and 9x9 image-output convs
+// (cyclegan/models.py:82, srgan/models.py:62) have 49 / 81 taps x 3 output channels, too many accumulators for
+// thin_wgrad_kernel and a 95 %-padding MFMA tile otherwise.  A persistent workgroup walks output tiles; per tile
+// and channel chunk the source window (with halo; padded / reflected / upsampled at staging, like
+// thin_conv_kernel) and the tile's dy values are staged in LDS; thread (q, tg) owns channel quad q and the taps
+// t = tg, tg+NG, ... and accumulates dW[co][t][4q..4q+3] over the tile's pixels.  One partial slab per
+// workgroup, reduced by the common fixed-order reduction.
+// ------------------------------------------------------------------------------------------------
+#define TWG_MAX_TPT 6   // taps per thread (81 taps / 16 tap groups)
+struct ThinWgradTile {
+    int NG, TPT, nblocks, ntiles_img, ntiles;  // tap groups, taps per thread, persistent blocks, tiles
+};
+template <int CO>
+__global__ __launch_bounds__(256) void thin_wgrad_tile_kernel(const ConvGeom g, const ThinConv tc,
+                                                              const ThinWgradTile tw, const float* __restrict__ X,
+                                                              const float* __restrict__ DY, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float win[];  // window [SH*SW][CC+4] then dy [256][CO]
+    const int tid = threadIdx.x;
+    const int LDC = tc.CC + 4, Q = tc.CC >> 2;
+    float* dys = win + (size_t)tc.SH * tc.SW * LDC;
+    const int q = tid & (Q - 1), tg = tid >> tc.logQ;
+    const int T = g.ntap[0];
+    const int Ho = g.Ho[0], Wo = g.Wo[0];
+    float* out = part + (size_t)blockIdx.x * CO * T * g.Ci;
+    int t_dh[TWG_MAX_TPT], t_dw[TWG_MAX_TPT];
+#pragma unroll
+    for (int k = 0; k < TWG_MAX_TPT; ++k) {
+        int t = tg + k * tw.NG;
+        bool ok = k < tw.TPT && t < T;
+        t_dh[k] = ok ? g.dh[t] - tc.dhmin[0] : -1;  // -1 marks an unused slot
+        t_dw[k] = ok ? g.dw[t] - tc.dwmin[0] : 0;
+    }
+    for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
+        f32x4 acc[TWG_MAX_TPT][CO];
+#pragma unroll
+        for (int k = 0; k < TWG_MAX_TPT; ++k)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = blockIdx.x; tile < tw.ntiles; tile += tw.nblocks) {
+            const int n = tile / tw.ntiles_img, ti_ = tile - n * tw.ntiles_img;
+            const int tile_r = ti_ / tc.tiles_w[0], tile_c = ti_ - tile_r * tc.tiles_w[0];
+            const int oi0 = tile_r * tc.TH, oj0 = tile_c * tc.TW;
+            const int vh0 = oi0 * g.istride + tc.dhmin[0], vw0 = oj0 * g.istride + tc.dwmin[0];
+            const float* Xb = X + (size_t)n * g.Hi * g.Wi * g.Ci;
+            __syncthreads();
+            for (int sr = 0; sr < tc.SH; ++sr) {
+                int ihs;
+                const bool rok = map_coord(vh0 + sr, g.HiL, g.gather, ihs);
+                for (int i = tid; i < tc.SW * Q; i += 256) {
+                    const int sc = i >> tc.logQ, qq = i & (Q - 1);
+                    int iws;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (rok && map_coord(vw0 + sc, g.WiL, g.gather, iws))
+                        v = *reinterpret_cast<const f32x4*>(Xb + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + qq * 4);
+                    *reinterpret_cast<f32x4*>(win + (size_t)(sr * tc.SW + sc) * LDC + qq * 4) = v;
+                }
+            }
+            {   // dy of the tile: thread <-> pixel, zero outside the image
+                const int pi = tid / tc.TW, pj = tid - pi * tc.TW;
+                const bool v = (oi0 + pi) < Ho && (oj0 + pj) < Wo;
+                const float* d = DY + (((size_t)n * Ho + oi0 + pi) * Wo + oj0 + pj) * CO;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) dys[tid * CO + c] = v ? d[c] : 0.f;
+            }
+            __syncthreads();
+            for (int pi = 0; pi < tc.TH; ++pi) {
+                for (int pj = 0; pj < tc.TW; ++pj) {
+                    float dv[CO];
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) dv[c] = dys[(pi * tc.TW + pj) * CO + c];  // wave-uniform broadcast
+                    const float* xb = win + (size_t)((pi * g.istride) * tc.SW + pj * g.istride) * LDC + q * 4;
+#pragma unroll
+                    for (int k = 0; k < TWG_MAX_TPT; ++k) {
+                        if (t_dh[k] >= 0) {
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)(t_dh[k] * tc.SW + t_dw[k]) * LDC);
+#pragma unroll
+                            for (int c = 0; c < CO; ++c) acc[k][c] += xv * dv[c];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TWG_MAX_TPT; ++k) {
+            int t = tg + k * tw.NG;
+            if (t_dh[k] >= 0) {
+#pragma unroll
+                for (int c = 0; c < CO; ++c)
+                    *reinterpret_cast<f32x4*>(out + ((size_t)c * T + t) * g.Ci + c0 + q * 4) = acc[k][c];
+            }
+        }
+    }
+}
+
+// plan + launch; returns false when the configuration is not covered (caller falls through to the MFMA path)
+static bool thin_wgrad_tile_plan(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                                 int pad_t, int pad_l, int gather, ConvGeom& g, ThinConv& tc, ThinWgradTile& tw,
+                                 size_t& lds) {
+    if (Co > 4 || Ci % 4 != 0 || Ci < 16 || R * S > MAX_TAPS || N > 65535) return false;
+    g = ConvGeom{};
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
+    g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
+    g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
+    g.Co = Co; g.HoF = Ho; g.WoF = Wo; g.ostep = 1; g.istride = stride; g.gather = gather; g.ldw = R * S * Ci;
+    g.ncls = 1; g.Ho[0] = Ho; g.Wo[0] = Wo; g.ntap[0] = R * S;
+    for (int r = 0; r < R; ++r)
+        for (int s2 = 0; s2 < S; ++s2) {
+            g.dh[r * S + s2] = (signed char)(r - pad_t);
+            g.dw[r * S + s2] = (signed char)(s2 - pad_l);
+            g.wofs[r * S + s2] = (r * S + s2) * Ci;
+        }
+    size_t l0 = 0;
+    int max_tiles = 0;
+    if (!thin_conv_plan(g, tc, l0, max_tiles)) return false;
+    // the tile kernel also keeps 256*Co dy values in LDS; shrink the channel chunk if needed (64 KB budget)
+    while ((size_t)tc.SH * tc.SW * (tc.CC + 4) * 4 + 256 * 4 * 4 > 64 * 1024 && tc.CC > 8) {
+        tc.CC >>= 1;
+        tc.logQ -= 1;
+    }
+    if (Ci % tc.CC != 0) return false;
+    lds = (size_t)tc.SH * tc.SW * (tc.CC + 4) * 4 + 256 * 4 * 4;
+    if (lds > 64 * 1024) return false;
+    int Q = tc.CC / 4;
+    tw.NG = 256 / Q;
+    tw.TPT = cdiv(R * S, tw.NG);
+    if (tw.TPT > TWG_MAX_TPT) return false;
+    tw.ntiles_img = tc.tiles[0];
+    tw.ntiles = tw.ntiles_img * N;
+    tw.nblocks = tw.ntiles < 512 ? tw.ntiles : 512;
+    return true;
+}
+
 MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);
     size_t nsplit = (size_t)splits;
-    if (Co <= 4 && nsplit < THIN_CHUNKS) nsplit = THIN_CHUNKS;  // upper bound of the thin path's chunk count
+    if (Co <= 4 && nsplit < THIN_CHUNKS) nsplit = THIN_CHUNKS;  // upper bound of the thin paths' slab counts
     return nsplit * Co * R * S * Ci * sizeof(float);
 }
 
@@ -1513,6 +1788,24 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else launch_thin<4>(Co, grid, lds, st, tg, x, dy, ws);
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, st);
+    }
+    if (Co <= 4) {
+        ConvGeom cg;
+        ThinConv tc = {};
+        ThinWgradTile tw = {};
+        size_t lds = 0;
+        if (thin_wgrad_tile_plan(N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, cg, tc, tw, lds) &&
+            (size_t)tw.nblocks * Co * R * S * Ci * sizeof(float) <= ws_bytes) {
+            dim3 grid(tw.nblocks);
+            switch (Co) {
+                case 1: hipLaunchKernelGGL((thin_wgrad_tile_kernel<1>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                case 2: hipLaunchKernelGGL((thin_wgrad_tile_kernel<2>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                case 3: hipLaunchKernelGGL((thin_wgrad_tile_kernel<3>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                default: hipLaunchKernelGGL((thin_wgrad_tile_kernel<4>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+            }
+            HIP_LAUNCH_CHECK();
+            return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, st);
+        }
     }
     WgradGeom g = {};
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
