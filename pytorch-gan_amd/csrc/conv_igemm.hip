@@ -821,7 +821,9 @@ static int igemm_select(long maxM, int Co, bool fast, int ncls) {
 }
 
 MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls) {
-    if (Co <= 4 && Ci_src % 4 == 0 && Ci_src >= 8) return 4000;  // thin_conv_kernel (VALU direct conv)
+    // thin_conv_kernel (VALU direct conv); bench.py passes maxM = N*Ho*Wo, so the per-image pixel rule of
+    // launch_igemm is approximated by maxM >= 8192 here (accounting only)
+    if (Co <= 4 && Ci_src % 4 == 0 && Ci_src >= 8 && maxM >= 8192) return 4000;
     return igemm_select((long)maxM, Co, Ci_src % 32 == 0, ncls);
 }
 
@@ -969,7 +971,7 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
         if (m > maxM) maxM = m;
     }
     static const int var = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
-    if (g.Co <= 4 && var != 100) {
+    if (g.Co <= 4 && var != 100 && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
         ThinConv tc = {};
         size_t lds = 0;
         int max_tiles = 0;
@@ -1829,7 +1831,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             else if (wvar == 3) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
             else
             hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
-        } else if (Ncol >= 128 && wvar != 64) {
+        } else if (Ncol >= 128 && wvar == 65) {  // experimental: needs a tile-aware split plan to pay off
             g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
             dim3 grid(g.tiles_m * g.tiles_n * g.splits);
             hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
