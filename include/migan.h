@@ -60,6 +60,21 @@ int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* w
                        int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
                        int gather, void* stream);
 
+/* Phase-collapsed nn.Upsample(scale_factor=2) -> nn.Conv2d(Ci, Co, 3, stride=1, padding=1)
+ * (dcgan.py:54-55,58-59; cyclegan/models.py:74-75): the 4 output phases are 2x2 convs of the un-upsampled input with
+ * pre-summed weights -> 16/36 of the dense FLOPs in forward, dgrad and wgrad, no upsampled intermediate.
+ * migan_upconv3x3_pack: w_oihw [Co][Ci][3][3] -> wf [Co][16][Ci] (forward) and wd [Ci][16][Co] (dgrad).
+ * x [N][H][W][Ci], y / dy [N][2H][2W][Co].  wgrad needs Co % 4 == 0 and Ci % 4 == 0 (else use
+ * migan_conv2d_wgrad with gather mode 2, which computes the same gradient densely). */
+int migan_upconv3x3_pack(const float* w_oihw, float* wf, float* wd, int Co, int Ci, void* stream);
+int migan_upconv3x3_fwd(const float* x, const float* wf, const float* bias, float* y, int N, int H, int W, int Ci,
+                        int Co, int act, float slope, void* stream);
+int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx, int N, int H, int W, int Ci, int Co,
+                          void* stream);
+size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci);
+int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H,
+                          int W, int Ci, int Co, void* stream);
+
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:
  * wgan_gp.py:49, gan.py:45;  nn.InstanceNorm2d(C): cyclegan/models.py:29,33,51,62,77,108

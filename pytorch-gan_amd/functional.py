@@ -185,6 +185,75 @@ def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=AC
     return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope))
 
 
+class _UpConv3x3(Function):
+    """Upsample(scale_factor=2) -> Conv2d(3x3, stride 1, padding 1) in its phase-collapsed form (2.25x fewer FLOPs)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        xs = to_nhwc(x)
+        w, b = _plain(w), _plain(b)
+        N, Ci, H, W = xs.shape
+        Co = w.shape[0]
+        if tuple(w.shape) != (Co, Ci, 3, 3):
+            raise ValueError("upconv3x3: weight must be (Co, %d, 3, 3)" % Ci)
+        wc = w if w.is_contiguous() else w.contiguous()
+        wf = torch.empty(Co * 16 * Ci, device=xs.device, dtype=torch.float32)
+        wd = torch.empty_like(wf)
+        st = _stream()
+        check(lib.migan_upconv3x3_pack(wc.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, st), "upconv_pack")
+        y = _empty_nhwc((N, Co, 2 * H, 2 * W), xs)
+        check(lib.migan_upconv3x3_fwd(xs.data_ptr(), wf.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Co, act, slope,
+                                      st), "upconv_fwd")
+        ctx.geom = (N, H, W, Ci, Co, act, slope)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(xs, w, wd, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w, wd, y = ctx.saved_tensors
+        N, H, W, Ci, Co, act, slope = ctx.geom
+        dy = to_nhwc(dy)
+        if act != ACT_NONE:
+            dy = _act_bwd_raw(dy, y, act, slope)
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_nhwc((N, Ci, H, W), xs)
+            check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
+                  "upconv_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            if Co % 4 == 0 and Ci % 4 == 0:
+                nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
+                ws = _ws(nb, xs)
+                check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
+                                                Ci, Co, st), "upconv_wgrad")
+            else:  # same gradient through the dense gathered wgrad
+                nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
+                ws = _ws(nb, xs)
+                check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
+                                             2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, st), "conv2d_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy, N * 4 * H * W, Co)
+        return dx, dw, db, None, None
+
+
+_UPCONV_COLLAPSE = True
+
+
+def set_upconv_collapse(enabled):
+    """Use the phase-collapsed kernels for Upsample(2)->Conv3x3(p=1) (default) or the dense gathered conv."""
+    global _UPCONV_COLLAPSE
+    _UPCONV_COLLAPSE = bool(enabled)
+
+
+def upconv3x3(x, w, b=None, act=ACT_NONE, slope=0.0):
+    if _UPCONV_COLLAPSE:
+        return _UpConv3x3.apply(x, w, b, int(act), float(slope))
+    return conv2d(x, w, b, 1, (1, 1, 1, 1), GATHER_UP2, act, slope)
+
+
 class _ConvTranspose2d(Function):
     """nn.ConvTranspose2d(Cin, Cout, k, s, p) forward == dgrad of the (Cout -> Cin) conv (pix2pix/models.py:39)."""
 

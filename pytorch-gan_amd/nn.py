@@ -142,6 +142,9 @@ class Conv2d(tnn.Conv2d):
         if gather == F.GATHER_REFLECT and (ph or pw):
             raise ValueError("reflection gather cannot be combined with conv zero padding")
         pads = (pre_pads[0] + ph, pre_pads[1] + pw, pre_pads[2] + ph, pre_pads[3] + pw)
+        if (gather == F.GATHER_UP2 and stride == 1 and pads == (1, 1, 1, 1)
+                and tuple(self.weight.shape[2:]) == (3, 3)):
+            return _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope))  # phase-collapsed Upsample+Conv3x3
         return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope))
 
     def forward(self, x):

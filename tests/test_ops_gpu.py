@@ -390,3 +390,35 @@ def test_gantensor_view_add_cat(pg):
 def test_cpu_tensor_raises(pg):
     with pytest.raises(RuntimeError):
         pg.functional.activation(torch.zeros(4), 1, 0.2)
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 16, 16, 128, 0, True), (2, 128, 8, 12, 64, 1, True), (1, 256, 6, 5, 128, 2, False),
+                                 (2, 32, 7, 9, 20, 0, True), (1, 64, 4, 4, 3, 3, True)])
+def test_upconv3x3_phase_collapsed(pg, cfg):
+    """Upsample(2) -> Conv3x3(p=1) in the phase-collapsed form (dcgan.py:54-55,58-59; cyclegan/models.py:74-75)
+    against the dense reference: forward, dgrad, wgrad (collapsed when Co%4==0 and Ci%4==0, dense fallback else)."""
+    N, Ci, H, W, Co, act, bias = cfg
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True) if bias else None
+    y_ref = TF.conv2d(TF.interpolate(x, scale_factor=2, mode="nearest"), w, b, 1, 1)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu, 3: torch.tanh}[act](y_ref)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+    y = F.upconv3x3(xg, wg, bg, act, 0.2)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "upconv fwd")
+    assert_close(xg.grad, x.grad, TOL_FWD, "upconv dgrad")
+    assert_close(wg.grad, w.grad, TOL_WGRAD, "upconv wgrad")
+    if bias:
+        assert_close(bg.grad, b.grad, TOL_WGRAD, "upconv bias")
+    # the dense gathered path must agree too (set_upconv_collapse(False))
+    F.set_upconv_collapse(False)
+    try:
+        y2 = F.upconv3x3(xg.detach(), wg.detach(), bg.detach() if bias else None, act, 0.2)
+    finally:
+        F.set_upconv_collapse(True)
+    assert_close(y2, y_ref, TOL_FWD, "dense up2 conv")
