@@ -321,7 +321,7 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
     return mode == GATHER_REFLECT ? true : inr;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int tpt = Ci >> 5;
+    const int tpt = KTAIL ? (Ci + 31) >> 5 : Ci >> 5;  // K-tiles per tap (KTAIL: the last one is partly masked)
     const int KT = ntap * tpt;
     if (KT == 0) {
         // empty tap list (e.g. a stride-2 parity class of a 1x1 conv): the output is bias/activation only
@@ -404,6 +404,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     int a_off[NA];          // element offset of this thread's 16 B of row j at channel 0 of the fetch tap
     unsigned okA = 0;       // validity (row in range and tap not in the zero padding) for the fetch tap
     int f_t = 0, f_c0 = 0, f_wo = 0;
+    // KTAIL (Ci % 32 != 0, Ci % 4 == 0): the last K-tile of a tap holds Ci % 32 channels; threads whose 4 channels lie
+    // beyond Ci read the tap's last 4 channels instead (valid memory) and are masked when the tile is written to LDS.
+    int f_cv = 0;           // per-thread channel offset of the fetch tile (clamped), relative to kq*4
+    bool f_cok = true;      // this thread's 4 channels of the fetch tile are < Ci
+    auto set_chunk = [&]() {
+        if (KTAIL) {
+            const int c = f_c0 + kq * 4;
+            f_cok = c < Ci;
+            f_cv = (f_cok ? c : Ci - 4) - kq * 4;
+        }
+    };
     auto setup_tap = [&](int t) {
         const int dh = s_dh[t], dw = s_dw[t];
         f_wo = s_wofs[t];
@@ -422,17 +433,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     do {                                                                                               \
         if ((idx) < NA) {                                                                              \
             constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
-            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(unsigned)(a_off[jj] + f_c0));        \
+            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(unsigned)(a_off[jj] + (KTAIL ? f_cv : f_c0))); \
         } else {                                                                                       \
             constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
-            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(unsigned)(b_off[jj] + f_wo + f_c0)); \
+            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(unsigned)(b_off[jj] + f_wo + (KTAIL ? f_cv : f_c0))); \
         }                                                                                              \
     } while (0)
 
     unsigned okS = 0;  // validity mask of the tile currently staged in ra[] (written to LDS next)
+    unsigned colokS = colok;
     if (KT > 0) {
         setup_tap(0);
-        okS = okA;
+        set_chunk();
+        okS = f_cok ? okA : 0u;
+        colokS = f_cok ? colok : 0u;
         if (0 < NL) IGEMM_ISSUE(0);
         if (1 < NL) IGEMM_ISSUE(1);
         if (2 < NL) IGEMM_ISSUE(2);
@@ -454,19 +468,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const bool ok = (colok >> j) & 1u;
+            const bool ok = ((KTAIL ? colokS : colok) >> j) & 1u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? rb[j][e] : 0.f;
         }
         __syncthreads();
         if (kt + 1 < KT) {  // move the fetch position to tile kt+1 (the last iteration refetches its own tile)
             f_c0 += 32;
-            if (f_c0 == Ci) {
+            if (KTAIL ? f_c0 >= Ci : f_c0 == Ci) {
                 f_c0 = 0;
                 setup_tap(++f_t);
             }
+            set_chunk();
         }
-        okS = okA;
+        okS = f_cok ? okA : 0u;
+        if (KTAIL) colokS = f_cok ? colok : 0u;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
@@ -778,7 +794,10 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    if (g.Ci % 32 == 0)
+        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    else
+        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -797,6 +816,9 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// MFMA fast path: 16-byte channel vectors; Ci % 32 != 0 runs the K-tail variant (last K-tile of each tap masked)
+static inline bool igemm_fast_ci(int Ci) { return Ci % 4 == 0 && Ci >= 8; }
 
 // Tile selection (pure function of the GEMM shape; also exported for the bench's per-kernel accounting).
 // code = fast*1000000 + BM*1000 + BN
@@ -824,7 +846,7 @@ MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls
     // thin_conv_kernel (VALU direct conv); bench.py passes maxM = N*Ho*Wo, so the per-image pixel rule of
     // launch_igemm is approximated by maxM >= 8192 here (accounting only)
     if (Co <= 4 && Ci_src % 4 == 0 && Ci_src >= 8 && maxM >= 8192) return 4000;
-    return igemm_select((long)maxM, Co, Ci_src % 32 == 0, ncls);
+    return igemm_select((long)maxM, Co, igemm_fast_ci(Ci_src), ncls);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -961,16 +983,142 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-K direct kernel (taps * Ci <= 16, Co % 4 == 0): first-layer convs of 1-channel images (dcgan.py:82
+// Conv2d(1,16,3,2,1)), the dgrad of an image-output conv INTO its Co-channel input (dcgan.py:62) and the dgrad of
+// Linear(K,1) (an outer product, dcgan.py:92).  With K <= 16 an MFMA K-tile would be >= 50-97 % zero padding and
+// the op is bound by WRITING the output, so: one thread = one pixel x 4 output channels, the <= 16 gathered
+// source values are shared through L1 by the Co/4 threads of the pixel, the store is a coalesced 16 B vector.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, const float* __restrict__ A,
+                                                          const float* __restrict__ Bw,
+                                                          const float* __restrict__ bias, float* __restrict__ C) {
+    const int cls = blockIdx.y;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int M = g.N * Ho * Wo;
+    const int cq_n = g.Co >> 2;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int Ci = g.Ci;
+    const long total = (long)M * cq_n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / cq_n);
+        const int co = (int)(i - (long)m * cq_n) * 4;
+        const int n = m / (Ho * Wo);
+        const int rem = m - n * Ho * Wo;
+        const int oi = rem / Wo, oj = rem - oi * Wo;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bias) acc = *reinterpret_cast<const f32x4*>(bias + co);
+        const float* w0 = Bw + (size_t)co * g.ldw;
+        for (int t = 0; t < ntap; ++t) {
+            int ihs, iws;
+            bool ok = map_bf(oi * g.istride + g.dh[tapbeg + t], g.HiL, g.Hi, g.gather, ihs);
+            ok &= map_bf(oj * g.istride + g.dw[tapbeg + t], g.WiL, g.Wi, g.gather, iws);
+            if (!ok) continue;
+            const float* ap = A + (size_t)((n * g.Hi + ihs) * g.Wi + iws) * Ci;
+            const float* wp = w0 + g.wofs[tapbeg + t];
+            for (int c = 0; c < Ci; ++c) {
+                const float a = ap[c];
+                acc[0] += a * wp[c];
+                acc[1] += a * wp[g.ldw + c];
+                acc[2] += a * wp[2 * g.ldw + c];
+                acc[3] += a * wp[3 * g.ldw + c];
+            }
+        }
+        const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
+        *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
+    }
+}
+
+static bool smallk_ok(const ConvGeom& g) {
+    if (g.Co % 4 != 0) return false;
+    for (int c = 0; c < g.ncls; ++c)
+        if (g.ntap[c] * g.Ci > 16) return false;
+    return true;
+}
+
+static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C,
+                         hipStream_t st) {
+    if (maxM == 0) return 0;
+    long blocks = cdiv(maxM * (g.Co >> 2), 256L);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(smallk_conv_kernel, dim3((unsigned)blocks, g.ncls), dim3(256), 0, st, g, A, Bw, bias, C);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Long-K GEMV (1 tap at offset 0, i.e. Linear / 1x1 conv; Co <= 4; few output pixels): the validity heads
+// Linear(128*ds^2, 1) (dcgan.py:92, wgan_gp.py:88).  A 128x32 MFMA tile would leave ONE workgroup walking the
+// whole K serially; here one wave owns one output row and its 64 lanes stride K with 16 B loads.
+// ------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
+                                                        const float* __restrict__ bias, float* __restrict__ C,
+                                                        int M, int K, int ldw, int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* a = A + (size_t)m * K;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + k);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(Bw + (size_t)c * ldw + k);
+            acc[c] += av[0] * wv[0] + av[1] * wv[1] + av[2] * wv[2] + av[3] * wv[3];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        float v = acc[c];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) C[(size_t)m * CO + c] = act_apply(v + (bias ? bias[c] : 0.f), act, slope);
+    }
+}
+
+static bool gemv_ok(const ConvGeom& g, long maxM) {
+    return g.ncls == 1 && g.ntap[0] == 1 && g.dh[0] == 0 && g.dw[0] == 0 && g.wofs[0] == 0 && g.istride == 1 &&
+           g.ostep == 1 && g.gather == GATHER_ZERO && g.Hi == g.Ho[0] && g.Wi == g.Wo[0] && g.Co <= 4 &&
+           g.Ci % 4 == 0 && g.ldw % 4 == 0 && g.Ci >= 256 && maxM <= 16384;
+}
+
+static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* Bw, const float* bias, float* C,
+                       hipStream_t st) {
+    if (M == 0) return 0;
+    dim3 grid((unsigned)cdiv(M, 4L));
+#define GEMV_CASE(CO_)                                                                                          \
+    case CO_:                                                                                                   \
+        hipLaunchKernelGGL(gemv_rows_kernel<CO_>, grid, dim3(256), 0, st, A, Bw, bias, C, (int)M, g.Ci, g.ldw,  \
+                           g.act, g.slope);                                                                     \
+        break;
+    switch (g.Co) {
+        GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4)
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef GEMV_CASE
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
                         hipStream_t st) {
-    bool fast = (g.Ci % 32 == 0) && (g.ldw % 4 == 0);
+    bool fast = igemm_fast_ci(g.Ci) && (g.ldw % 4 == 0);
     for (int t = 0; fast && t < MAX_TAPS; ++t) fast = (g.wofs[t] % 4 == 0);
     long maxM = 0;
     for (int c = 0; c < g.ncls; ++c) {
         long m = (long)g.N * g.Ho[c] * g.Wo[c];
         if (m > maxM) maxM = m;
     }
-    static const int var = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
+    static const int var_env = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
+    const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
+    if (var != 100 && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
+    if (var != 100 && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
     if (g.Co <= 4 && var != 100 && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
         ThinConv tc = {};
         size_t lds = 0;
@@ -1336,6 +1484,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_ke
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    // DYS (phase-collapsed up-conv): blockIdx.y = output phase (a, b); it fixes the padding and the dy sub-lattice
+    const int cls = DYS ? (int)blockIdx.y : 0;
+    const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
+    const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1356,8 +1508,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_ke
             int t = col / g.Ci;
             b_ci = col - t * g.Ci;
             int r = t / g.S, s = t - r * g.S;
-            b_dh = r - g.pad_t;
-            b_dw = s - g.pad_l;
+            b_dh = r - pad_t;
+            b_dw = s - pad_l;
             b_colok = true;
         }
     }
@@ -1380,7 +1532,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_ke
                 int rem_ = p - n_ * HoWo;                                                                 \
                 int oi_ = fastdiv(rem_, g.mg_w, g.sh_w);                                                  \
                 int oj_ = rem_ - oi_ * g.Wo;                                                              \
-                p = (n_ * g.dy_H + g.dy_oh0 + oi_ * g.dy_step) * g.dy_W + g.dy_ow0 + oj_ * g.dy_step;     \
+                p = (n_ * g.dy_H + dy_oh0 + oi_ * 2) * g.dy_W + dy_ow0 + oj_ * 2;                        \
             }                                                                                             \
             ra[jj] = *reinterpret_cast<const f32x4*>(DY + (size_t)p * g.Co + a_col);                      \
             okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                          \
@@ -1456,7 +1608,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_ke
         }
     }
 #undef WGRAD_ISSUE
-    float* out = part + (size_t)split * g.Co * Ncol;
+    float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1514,10 +1666,10 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     return 0;
 }
 
-static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps) {
+static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
     long Mpix = (long)N * Ho * Wo;
     BMsel = (Co > 64 && Ncol > 64) ? 128 : 64;
-    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, BMsel);
+    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, BMsel) * ncls;
     long want = cdiv(1024, tiles);
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
     if (want > maxs) want = maxs;
@@ -1637,11 +1789,13 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
 
 MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci) {
     int bm, splits, pps;
-    wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps);
+    wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4);
     return (size_t)4 * splits * Co * 4 * Ci * sizeof(float);
 }
 
 // dw_oihw[Co][Ci][3][3] from x[N][H][W][Ci] and dy[N][2H][2W][Co]   (requires Co % 4 == 0 and Ci % 4 == 0)
+// ONE launch covers the 4 phase classes (grid.y), so the split-K factor - and with it the partial-sum traffic of the
+// un-collapsing reduction - is 4x smaller than with one launch per phase.
 MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                     int N, int H, int W, int Ci, int Co, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -1651,26 +1805,20 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     g.N = N; g.Hi = H; g.Wi = W; g.Ci = Ci; g.HiL = H; g.WiL = W;
     g.Ho = H; g.Wo = W; g.Co = Co; g.R = 2; g.S = 2; g.stride = 1; g.gather = GATHER_ZERO;
     int Ncol = 4 * Ci, bm;
-    wgrad_plan(N, H, W, Co, Ncol, bm, g.splits, g.pix_per_split);
+    wgrad_plan(N, H, W, Co, Ncol, bm, g.splits, g.pix_per_split, 4);
     fastdiv_magic((unsigned)(H * W), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)W, g.mg_w, g.sh_w);
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
-    const size_t cls_stride = (size_t)g.splits * Co * Ncol;
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b) {
-            g.pad_t = 1 - a; g.pad_l = 1 - b; g.dy_oh0 = a; g.dy_ow0 = b;
-            float* out = ws + (size_t)(a * 2 + b) * cls_stride;
-            if (bm == 128) {
-                g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
-                hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256),
-                                   0, st, g, x, dy, out);
-            } else {
-                g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
-                hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256),
-                                   0, st, g, x, dy, out);
-            }
-            HIP_LAUNCH_CHECK();
-        }
+    if (bm == 128) {
+        g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
+        hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
+                           0, st, g, x, dy, ws);
+    } else {
+        g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
+        hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
+                           0, st, g, x, dy, ws);
+    }
+    HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
     int blocks = cdiv((long)total, 256);
     if (blocks > 4096) blocks = 4096;

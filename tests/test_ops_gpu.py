@@ -52,6 +52,10 @@ CONV_CASES = [
     (1, 64, 12, 12, 3, 9, 1, (4, 4, 4, 4), 0, 3, True),         # srgan conv3 9x9 + Tanh
     (3, 32, 9, 7, 48, 3, 1, (1, 1, 1, 1), 0, 2, True),          # ragged sizes, M/N tails
     (2, 96, 5, 5, 160, 3, 2, (1, 1, 1, 1), 0, 0, True),         # odd spatial with stride 2 (parity classes uneven)
+    (2, 40, 10, 10, 72, 3, 1, (1, 1, 1, 1), 0, 1, True),        # Ci % 32 != 0: K-tail variant, 2 chunks per tap
+    (2, 8, 12, 12, 24, 4, 2, (1, 1, 1, 1), 1, 0, True),         # Ci = 8: K-tail with a single masked chunk, reflect
+    (2, 100, 6, 6, 36, 3, 1, (1, 1, 1, 1), 0, 0, False),        # Ci = 100 (4 chunks, tail of 4 channels)
+    (3, 1, 14, 14, 8, 3, 1, (1, 1, 1, 1), 0, 2, True),          # small-K direct kernel, stride 1
 ]
 
 
