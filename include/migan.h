@@ -48,17 +48,20 @@ int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, 
 
 /* Which tile configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
  * Co columns and a source with Ci_src channels: fast*1000000 + BM*1000 + BN ("fast" = vectorised NHWC loader,
- * Ci_src % 32 == 0); 4000 = the thin-N VALU kernel (Co <= 4).  Pure function; used by bench.py to attribute
+ * Ci_src % 4 == 0 and >= 8); 4000 = the thin-N VALU kernel (Co <= 4).  Pure function; used by bench.py to attribute
  * launches to kernel symbols. */
 int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls);
 
 /* Conv2d / Linear weight gradient (aten::convolution_backward grad_weight; aten::mm in AddmmBackward).
  * Split-K over pixels + fixed-order reduction (deterministic).  dw_oihw has the torch parameter layout
- * [Co][Ci][R][S].  ws must hold migan_conv2d_wgrad_workspace() bytes. */
+ * [Co][Ci][R][S].  ws must hold migan_conv2d_wgrad_workspace() bytes.  accumulate != 0: dw += gradient (the
+ * final reduction adds into the caller's buffer - what autograd's AccumulateGrad does with a separate
+ * aten::add launch per parameter; used to write straight into the optimiser's flat gradient bucket).  The same
+ * flag exists on migan_upconv3x3_wgrad, migan_colsum (bias gradients) and migan_norm_bwd (dgamma/dbeta). */
 size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci);
 int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi,
                        int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
-                       int gather, void* stream);
+                       int gather, int accumulate, void* stream);
 
 /* Phase-collapsed nn.Upsample(scale_factor=2) -> nn.Conv2d(Ci, Co, 3, stride=1, padding=1)
  * (dcgan.py:54-55,58-59; cyclegan/models.py:74-75): the 4 output phases are 2x2 convs of the un-upsampled input with
@@ -73,17 +76,18 @@ int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx, int N, in
                           void* stream);
 size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci);
 int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H,
-                          int W, int Ci, int Co, void* stream);
+                          int W, int Ci, int Co, int accumulate, void* stream);
 
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:
  * wgan_gp.py:49, gan.py:45;  nn.InstanceNorm2d(C): cyclegan/models.py:29,33,51,62,77,108
  * pix2pix/models.py:25,40,117.   Data viewed as [G][P][C]: BatchNorm G=1,P=N*H*W; InstanceNorm G=N,P=H*W.
  * migan_norm_stats: biased variance -> invstd = 1/sqrt(var+eps); running stats (G==1, non-NULL) updated
- * with momentum and the unbiased variance, as torch does. */
+ * with momentum and the unbiased variance, as torch does; num_batches_tracked (int64 scalar, may be NULL) += 1. */
 size_t migan_norm_workspace(int G, int P, int C);
 int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                     float momentum, float eps, int G, int P, int C, float* ws, size_t ws_bytes, void* stream);
+                     long long* num_batches_tracked, float momentum, float eps, int G, int P, int C, float* ws,
+                     size_t ws_bytes, void* stream);
 /* y = act((x-mean)*invstd*gamma+beta) [+ res]; gamma/beta/res may be NULL. */
 int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const float* res, int G, int P, int C, int act, float slope,
@@ -91,7 +95,7 @@ int migan_norm_apply(const float* x, float* y, const float* mean, const float* i
 /* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1. */
 int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                    const float* beta, float* dx, float* dgamma, float* dbeta, int G, int P, int C, int act,
-                   float slope, float* ws, size_t ws_bytes, void* stream);
+                   float slope, float* ws, size_t ws_bytes, int accumulate, void* stream);
 
 /* ---- Pointwise / index-remap kernels (csrc/eltwise.hip) ------------------------------------------------
  * nn.LeakyReLU(0.2)/ReLU/Tanh/Sigmoid: dcgan.py:57,63,92  cyclegan/models.py:30,52,82,110 ... */
@@ -108,7 +112,9 @@ int migan_axpby(const float* a, float alpha, const float* b, float beta, float* 
 int migan_mul(const float* a, const float* b, float* y, size_t n, void* stream);
 /* nn.Dropout2d(0.25) dcgan.py:78: y[n][p][c] = x[n][p][c]*mask[n][c];  nn.Dropout(0.5) pix2pix/models.py:27,44
  * uses migan_mul with a full-size mask.  migan_rand_mask draws mask = Bernoulli(1-p)/(1-p) with
- * Philox4x32-10 at stream position *counter (device, advanced by the call; NULL = position 0). */
+ * Philox4x32-10 at stream position counter[0] (device; NULL = position 0).  counter points to TWO 64-bit words
+ * {position, ticket}, both zero-initialised by the caller: the kernel's last-arriving block advances the position
+ * and resets the ticket, so the stream moves on graph replay without a second launch. */
 int migan_mul_nc(const float* x, const float* mask, float* y, int N, int HW, int C, void* stream);
 int migan_rand_mask(float* mask, size_t n, float p, unsigned long long seed, unsigned long long* counter,
                     void* stream);
@@ -136,7 +142,8 @@ int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3
 /* ---- Reductions, losses, gradient penalty, optimiser (csrc/reduce_loss_adam.hip) -----------------------
  * bias gradients: out[c] = sum_p x[p][c]. */
 size_t migan_colsum_workspace(size_t P, int C);
-int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, void* stream);
+int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, int accumulate,
+                 void* stream);
 /* kind 0 BCELoss (dcgan.py:103), 1 MSELoss (cyclegan.py:57), 2 L1Loss (cyclegan.py:58-59), 3 mean
  * (wgan_gp.py:171,189).  Target is t[i] or the constant tconst when t==NULL.  out = mean over n.
  * ws: migan_reduce_workspace() bytes.  bwd: dx = g[0]/n * dloss/dx. */

@@ -990,41 +990,54 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
 // the op is bound by WRITING the output, so: one thread = one pixel x 4 output channels, the <= 16 gathered
 // source values are shared through L1 by the Co/4 threads of the pixel, the store is a coalesced 16 B vector.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, const float* __restrict__ A,
-                                                          const float* __restrict__ Bw,
+struct SmallK {
+    int dh[16], dw[16], c[16], wofs[16];  // flattened k = (tap, channel) -> tap offset, source channel, weight offset
+};
+// thread = (pixel, 4 output channels); K and the whole gather are compile-time unrolled and branch-free, so the K
+// source loads of a pixel are in flight together.  FIXED: the thread count is a multiple of Co/4, so a thread keeps
+// its 4xK weights in registers while it strides over pixels.
+template <int K, bool FIXED>
+__global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, const SmallK sk,
+                                                          const float* __restrict__ A, const float* __restrict__ Bw,
                                                           const float* __restrict__ bias, float* __restrict__ C) {
-    const int cls = blockIdx.y;
-    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int Ho = g.Ho[0], Wo = g.Wo[0];
     const int M = g.N * Ho * Wo;
     const int cq_n = g.Co >> 2;
-    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
-    const int Ci = g.Ci;
     const long total = (long)M * cq_n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float w[K][4];
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_w = [&](int co) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[k][e] = Bw[(size_t)(co + e) * g.ldw + sk.wofs[k]];
+        if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+    };
+    if (FIXED && i < total) load_w((int)(i % cq_n) * 4);
+    for (; i < total; i += stride) {
         const int m = (int)(i / cq_n);
         const int co = (int)(i - (long)m * cq_n) * 4;
+        if (!FIXED) load_w(co);
         const int n = m / (Ho * Wo);
         const int rem = m - n * Ho * Wo;
         const int oi = rem / Wo, oj = rem - oi * Wo;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (bias) acc = *reinterpret_cast<const f32x4*>(bias + co);
-        const float* w0 = Bw + (size_t)co * g.ldw;
-        for (int t = 0; t < ntap; ++t) {
+        float a[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             int ihs, iws;
-            bool ok = map_bf(oi * g.istride + g.dh[tapbeg + t], g.HiL, g.Hi, g.gather, ihs);
-            ok &= map_bf(oj * g.istride + g.dw[tapbeg + t], g.WiL, g.Wi, g.gather, iws);
-            if (!ok) continue;
-            const float* ap = A + (size_t)((n * g.Hi + ihs) * g.Wi + iws) * Ci;
-            const float* wp = w0 + g.wofs[tapbeg + t];
-            for (int c = 0; c < Ci; ++c) {
-                const float a = ap[c];
-                acc[0] += a * wp[c];
-                acc[1] += a * wp[g.ldw + c];
-                acc[2] += a * wp[2 * g.ldw + c];
-                acc[3] += a * wp[3 * g.ldw + c];
-            }
+            bool ok = map_bf(oi * g.istride + sk.dh[k], g.HiL, g.Hi, g.gather, ihs);
+            ok &= map_bf(oj * g.istride + sk.dw[k], g.WiL, g.Wi, g.gather, iws);
+            const float v = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + sk.c[k]];
+            a[k] = ok ? v : 0.f;
         }
-        const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+        f32x4 acc = b4;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(a[k], w[k][e], acc[e]);
+        const size_t opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
@@ -1033,18 +1046,42 @@ __global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, cons
 }
 
 static bool smallk_ok(const ConvGeom& g) {
-    if (g.Co % 4 != 0) return false;
-    for (int c = 0; c < g.ncls; ++c)
-        if (g.ntap[c] * g.Ci > 16) return false;
-    return true;
+    const int K = g.ntap[0] * g.Ci;
+    return g.ncls == 1 && g.Co % 4 == 0 && K >= 1 && K <= 16;
+}
+
+template <int K>
+static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, const float* A, const float* Bw,
+                            const float* bias, float* C, hipStream_t st) {
+    const int cq_n = g.Co >> 2;
+    long blocks = cdiv(maxM * cq_n, 256L);
+    if (blocks > 8192) blocks = 8192;
+    if (256 % cq_n == 0)
+        hipLaunchKernelGGL((smallk_conv_kernel<K, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+    else
+        hipLaunchKernelGGL((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
 }
 
 static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C,
                          hipStream_t st) {
     if (maxM == 0) return 0;
-    long blocks = cdiv(maxM * (g.Co >> 2), 256L);
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(smallk_conv_kernel, dim3((unsigned)blocks, g.ncls), dim3(256), 0, st, g, A, Bw, bias, C);
+    SmallK sk = {};
+    const int K = g.ntap[0] * g.Ci;
+    for (int t = 0, k = 0; t < g.ntap[0]; ++t)
+        for (int c = 0; c < g.Ci; ++c, ++k) {
+            sk.dh[k] = g.dh[g.tapbeg[0] + t];
+            sk.dw[k] = g.dw[g.tapbeg[0] + t];
+            sk.c[k] = c;
+            sk.wofs[k] = g.wofs[g.tapbeg[0] + t] + c;
+        }
+#define SMALLK_CASE(K_) case K_: launch_smallk_k<K_>(g, sk, maxM, A, Bw, bias, C, st); break;
+    switch (K) {
+        SMALLK_CASE(1) SMALLK_CASE(2) SMALLK_CASE(3) SMALLK_CASE(4) SMALLK_CASE(5) SMALLK_CASE(6) SMALLK_CASE(7)
+        SMALLK_CASE(8) SMALLK_CASE(9) SMALLK_CASE(10) SMALLK_CASE(11) SMALLK_CASE(12) SMALLK_CASE(13)
+        SMALLK_CASE(14) SMALLK_CASE(15) SMALLK_CASE(16)
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef SMALLK_CASE
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1629,7 +1666,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_ke
 // split loop (LDS combine in fixed order) when there are many splits and few outputs.
 template <int GROUPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int splits, int Co, int T, int Ci) {
+                                                           int splits, int Co, int T, int Ci, int accum) {
     constexpr int OUTS = 256 / GROUPS;
     __shared__ float red[256];
     const size_t total = (size_t)Co * T * Ci;
@@ -1651,17 +1688,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         size_t r = src / Ci;
         int t = (int)(r % T);
         int co = (int)(r / T);
-        dw[((size_t)co * Ci + ci) * T + t] = s;
+        float* o = dw + ((size_t)co * Ci + ci) * T + t;
+        *o = accum ? *o + s : s;
     }
 }
-static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, hipStream_t st) {
+static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, int accum,
+                               hipStream_t st) {
     long total = (long)Co * T * Ci;
     if (splits >= 64 && total < (1 << 16))
-        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
+                           accum);
     else if (splits >= 16 && total < (1 << 20))
-        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(cdiv(total, 64)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(cdiv(total, 64)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
+                           accum);
     else
-        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
+                           accum);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1765,25 +1807,38 @@ MIGAN_API int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx,
 }
 
 // part[cls][split][co][tap*Ci+ci] (tap = ih*2+iw) -> dw[co][ci][r][s] = sum_{a,b} sum_split part[a,b][.][co][tap(a,r),(b,s)][ci]
+// 4 split-lanes per output (fixed-order LDS combine -> deterministic); reads coalesced along ci.
 __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* __restrict__ part,
-                                                                  float* __restrict__ dw, int splits, int Co, int Ci) {
+                                                                  float* __restrict__ dw, int splits, int Co, int Ci,
+                                                                  int accum) {
+    constexpr int GROUPS = 4, OUTS = 256 / GROUPS;
+    __shared__ float red[256];
     const size_t slab = (size_t)Co * 4 * Ci;  // one (class, split) slab
     const size_t total = (size_t)Co * Ci * 9;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // walk in [co][rs][ci] order so the partial reads are coalesced along ci
-        int ci = (int)(i % Ci);
+    const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
+    const size_t i = (size_t)blockIdx.x * OUTS + lo;  // [co][rs][ci] order
+    int ci = 0, rs = 0, co = 0;
+    float acc = 0.f;
+    if (i < total) {
+        ci = (int)(i % Ci);
         size_t r_ = i / Ci;
-        int rs = (int)(r_ % 9);
-        int co = (int)(r_ / 9);
-        int r = rs / 3, q = rs - r * 3;
-        float acc = 0.f;
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b) {
-                int tap = up_idx(a, r) * 2 + up_idx(b, q);
-                const float* src = part + (size_t)(a * 2 + b) * splits * slab + ((size_t)co * 4 + tap) * Ci + ci;
-                for (int k = 0; k < splits; ++k) acc += src[(size_t)k * slab];
-            }
-        dw[((size_t)co * Ci + ci) * 9 + rs] = acc;
+        rs = (int)(r_ % 9);
+        co = (int)(r_ / 9);
+        const int r = rs / 3, q = rs - r * 3;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            const int tap = up_idx(ab >> 1, r) * 2 + up_idx(ab & 1, q);
+            const float* src = part + (size_t)ab * splits * slab + ((size_t)co * 4 + tap) * Ci + ci;
+            for (int k = grp; k < splits; k += GROUPS) acc += src[(size_t)k * slab];
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0 && i < total) {
+#pragma unroll
+        for (int q = 1; q < GROUPS; ++q) acc += red[q * OUTS + lo];
+        float* o = dw + ((size_t)co * Ci + ci) * 9 + rs;
+        *o = accum ? *o + acc : acc;
     }
 }
 
@@ -1797,7 +1852,7 @@ MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, in
 // ONE launch covers the 4 phase classes (grid.y), so the split-K factor - and with it the partial-sum traffic of the
 // un-collapsing reduction - is 4x smaller than with one launch per phase.
 MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
-                                    int N, int H, int W, int Ci, int Co, void* stream) {
+                                    int N, int H, int W, int Ci, int Co, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (Co % 4 != 0 || Ci % 4 != 0) return (int)hipErrorInvalidValue;
     if (ws_bytes < migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)) return (int)hipErrorInvalidValue;
@@ -1820,9 +1875,8 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     }
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
-    int blocks = cdiv((long)total, 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, dw_oihw, g.splits, Co, Ci);
+    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(cdiv((long)total, 64)), dim3(256), 0, st, ws, dw_oihw, g.splits,
+                       Co, Ci, accumulate);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -2084,7 +2138,7 @@ MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int
 
 MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                 int stride, int pad_t, int pad_l, int gather, void* stream) {
+                                 int stride, int pad_t, int pad_l, int gather, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (thin_wgrad_ok(Co, R, S, Ci, stride, gather)) {
         ThinGeom tg = {N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, 0, 0, 0};
@@ -2096,7 +2150,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else if (S == 3) launch_thin<3>(Co, grid, lds, st, tg, x, dy, ws);
         else launch_thin<4>(Co, grid, lds, st, tg, x, dy, ws);
         HIP_LAUNCH_CHECK();
-        return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, st);
+        return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st);
     }
     if (Co <= 4) {
         ConvGeom cg;
@@ -2113,7 +2167,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
                 default: hipLaunchKernelGGL((thin_wgrad_tile_kernel<4>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
             }
             HIP_LAUNCH_CHECK();
-            return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, st);
+            return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, accumulate, st);
         }
     }
     WgradGeom g = {};
@@ -2148,7 +2202,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64>), grid, dim3(256), 0, st, g, x, dy, ws);
         }
         HIP_LAUNCH_CHECK();
-        return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, st);
+        return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st);
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
@@ -2160,5 +2214,5 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
-    return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, st);
+    return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st);
 }

@@ -195,10 +195,13 @@ __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigne
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 // mask[i] = u_i < p ? 0 : 1/(1-p).  The stream position comes from a device counter so a captured
-// hipGraph draws fresh numbers on every replay; the counter is advanced by a trailing 1-thread kernel.
+// hipGraph draws fresh numbers on every replay.  counter[0] = position, counter[1] = arrival ticket (zero at rest):
+// every block reads the position BEFORE it takes a ticket, and the block that takes the LAST ticket advances the
+// position and resets the ticket - so no separate counter-update launch is needed.
 __global__ void rand_mask_kernel(float* __restrict__ mask, size_t n, float p, unsigned long long seed,
-                                 const unsigned long long* __restrict__ counter) {
-    const unsigned long long off = counter ? counter[0] : 0ull;
+                                 unsigned long long* counter) {
+    const unsigned long long off = counter ? __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0ull;
     const float keep = 1.f / (1.f - p);
     size_t nq = (n + 3) / 4;
     GRID_STRIDE(i, nq) {
@@ -221,8 +224,18 @@ __global__ void rand_mask_kernel(float* __restrict__ mask, size_t n, float p, un
             }
         }
     }
+    if (counter) {
+        __syncthreads();  // all threads of this block have read the position
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned long long t = atomicAdd(counter + 1, 1ull);
+            if (t == (unsigned long long)gridDim.x - 1) {
+                counter[1] = 0ull;
+                __hip_atomic_store(counter, off + nq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
-__global__ void counter_add_kernel(unsigned long long* counter, unsigned long long inc) { counter[0] += inc; }
 
 MIGAN_API int migan_rand_mask(float* mask, size_t n, float p, unsigned long long seed,
                               unsigned long long* counter, void* stream) {
@@ -230,10 +243,6 @@ MIGAN_API int migan_rand_mask(float* mask, size_t n, float p, unsigned long long
     if (n == 0) return 0;
     hipLaunchKernelGGL(rand_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, mask, n, p, seed, counter);
     HIP_LAUNCH_CHECK();
-    if (counter) {
-        hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, st, counter, (unsigned long long)((n + 3) / 4));
-        HIP_LAUNCH_CHECK();
-    }
     return 0;
 }
 

@@ -117,8 +117,9 @@ __device__ __forceinline__ void chan_merge(double& n, double& m, double& M2, dou
 __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* running_mean,
-                                                                float* running_var, int G, int P, int C,
-                                                                int nchunks, int chunk, float eps, float momentum) {
+                                                                float* running_var, long long* nbt, int G, int P,
+                                                                int C, int nchunks, int chunk, float eps,
+                                                                float momentum) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= G * C) return;  // wave-uniform
     const int g = i / C, c = i - g * C;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
         else chan_merge(n, m, M2, n2, m2, M22);
     }
     if (lane != 0) return;
+    if (i == 0 && nbt) nbt[0] += 1;  // BatchNorm's num_batches_tracked
     double var = M2 / P;
     mean[i] = (float)m;
     invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
 // pass 2 (backward): one wave per (g,c) -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1.
 __global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ sums, float* dgamma,
-                                                                float* dbeta, int G, int C, int nchunks) {
+                                                                float* dbeta, int G, int C, int nchunks,
+                                                                int accum) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= G * C) return;
     const int g = i / C, c = i - g * C;
@@ -173,66 +176,91 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __r
     sums[(size_t)i * 2] = (float)a;
     sums[(size_t)i * 2 + 1] = (float)b;
     if (G == 1) {
-        if (dbeta) dbeta[c] = (float)a;
-        if (dgamma) dgamma[c] = (float)b;
+        if (dbeta) dbeta[c] = accum ? dbeta[c] + (float)a : (float)a;
+        if (dgamma) dgamma[c] = accum ? dgamma[c] + (float)b : (float)b;
     }
 }
 
 // apply: y = act((x-mean)*invstd*gamma+beta) [+ res]
+// Thread layout as in the statistics pass: tx owns VW fixed channels (its scale/shift live in registers, so the
+// loop body is load - fma - act - store with no per-element parameter gathers or index divisions), ty strides over
+// the pixels of the block's chunk.  A wave's accesses are contiguous runs of CTX*VW floats per pixel.
 template <int VW>
 __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         const float* __restrict__ res, int G, int P, int C,
-                                                         int act, float slope) {
-    const size_t per_g = (size_t)P * C;
-    const size_t total = (size_t)G * per_g / VW;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        size_t e = i * VW;
-        int g = (int)(e / per_g);
-        int c = (int)(e % C);
+                                                         const float* __restrict__ res, int P, int C, int CTX,
+                                                         int chunk, int act, float slope) {
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    if (c >= C) return;
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+        const float is = invstd[(size_t)g * C + c + v], mu = mean[(size_t)g * C + c + v];
+        sc[v] = is * (gamma ? gamma[c + v] : 1.f);
+        sh[v] = (beta ? beta[c + v] : 0.f) - mu * sc[v];
+    }
+    const int p0 = blockIdx.y * chunk;
+    int p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    const size_t base = (size_t)g * P * C + c;
+#pragma unroll 4
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const size_t e = base + (size_t)p * C;
         if (VW == 4) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
             f32x4 r = {0.f, 0.f, 0.f, 0.f};
             if (res) r = *reinterpret_cast<const f32x4*>(res + e);
             f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float sc = invstd[(size_t)g * C + c + k] * (gamma ? gamma[c + k] : 1.f);
-                float z = (v[k] - mean[(size_t)g * C + c + k]) * sc + (beta ? beta[c + k] : 0.f);
-                o[k] = act_apply(z, act, slope) + r[k];
-            }
+            for (int k = 0; k < 4; ++k) o[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act, slope) + r[k];
             *reinterpret_cast<f32x4*>(y + e) = o;
         } else {
-            float sc = invstd[(size_t)g * C + c] * (gamma ? gamma[c] : 1.f);
-            float z = (x[e] - mean[(size_t)g * C + c]) * sc + (beta ? beta[c] : 0.f);
-            y[e] = act_apply(z, act, slope) + (res ? res[e] : 0.f);
+            y[e] = act_apply(fmaf(x[e], sc[0], sh[0]), act, slope) + (res ? res[e] : 0.f);
         }
     }
 }
 
-// dx = gamma*invstd*(dyz - s0/P - xhat*s1/P); dyz = dy * act'(z)
+// dx = gamma*invstd*(dyz - s0/P - xhat*s1/P); dyz = dy * act'(z)        (same thread layout as norm_apply_kernel)
 template <int VW>
 __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ sums, int G, int P, int C, int act,
+    const float* __restrict__ beta, const float* __restrict__ sums, int P, int C, int CTX, int chunk, int act,
     float slope) {
-    const size_t per_g = (size_t)P * C;
-    const size_t total = (size_t)G * per_g / VW;
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    if (c >= C) return;
     const float invP = 1.f / (float)P;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        size_t e = i * VW;
-        int g = (int)(e / per_g);
-        int c = (int)(e % C);
+    float mu[VW], is[VW], ga[VW], be[VW], k0[VW], k1[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+        const size_t gc = (size_t)g * C + c + v;
+        mu[v] = mean[gc];
+        is[v] = invstd[gc];
+        ga[v] = gamma ? gamma[c + v] : 1.f;
+        be[v] = beta ? beta[c + v] : 0.f;
+        k0[v] = sums[gc * 2] * invP;
+        k1[v] = sums[gc * 2 + 1] * invP;
+    }
+    const int p0 = blockIdx.y * chunk;
+    int p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    const size_t base = (size_t)g * P * C + c;
+#pragma unroll 4
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const size_t e = base + (size_t)p * C;
         float xv[VW], dv[VW], ov[VW];
         if (VW == 4) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(x + e);
-            f32x4 b = *reinterpret_cast<const f32x4*>(dy + e);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + e);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(dy + e);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; }
         } else {
@@ -241,19 +269,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
         }
 #pragma unroll
         for (int k = 0; k < VW; ++k) {
-            size_t gc = (size_t)g * C + c + k;
-            float is = invstd[gc], ga = gamma ? gamma[c + k] : 1.f;
-            float xh = (xv[k] - mean[gc]) * is;
+            const float xh = (xv[k] - mu[k]) * is[k];
             float d = dv[k];
             if (act != ACT_NONE) {
-                float z = xh * ga + (beta ? beta[c + k] : 0.f);
+                const float z = xh * ga[k] + be[k];
                 if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
                 else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
             }
-            ov[k] = ga * is * (d - sums[gc * 2] * invP - xh * sums[gc * 2 + 1] * invP);
+            ov[k] = ga[k] * is[k] * (d - k0[k] - xh * k1[k]);
         }
         if (VW == 4) {
-            f32x4 o = {ov[0], ov[1], ov[2], ov[3]};
+            const f32x4 o = {ov[0], ov[1], ov[2], ov[3]};
             *reinterpret_cast<f32x4*>(dx + e) = o;
         } else {
             dx[e] = ov[0];
@@ -285,17 +311,23 @@ MIGAN_API size_t migan_norm_workspace(int G, int P, int C) {
     return ((size_t)G * nchunks * C * 3 + (size_t)G * C * 2) * sizeof(float);
 }
 
-static int grid_for(size_t nvec) {
-    size_t b = (nvec + 255) / 256;
-    if (b > 4096) b = 4096;
-    if (b < 1) b = 1;
-    return (int)b;
+// pixel chunking of the streaming apply kernels: ~4096 blocks, >= 8 pixels per ty lane
+static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3& grid) {
+    int nchunks_stats, chunk_stats, gx;
+    norm_plan(G, P, C, VW, CTX, chunk_stats, nchunks_stats, gx);
+    int TY = 256 / CTX;
+    long want = cdiv(4096, (long)gx * G);
+    long maxc = cdiv(P, (long)TY * 8);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    chunk = cdiv(P, want);
+    grid = dim3(gx, cdiv(P, chunk), G);
 }
 
 // Training-mode statistics: mean/invstd [G][C] (+ running stat update when G==1 and pointers given).
 MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean,
-                               float* running_var, float momentum, float eps, int G, int P, int C,
-                               float* ws, size_t ws_bytes, void* stream) {
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                               int G, int P, int C, float* ws, size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
@@ -309,7 +341,7 @@ MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
-                       invstd, running_mean, running_var, G, P, C, nchunks, chunk, eps, momentum);
+                       invstd, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps, momentum);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -319,14 +351,16 @@ MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, cons
                                const float* gamma, const float* beta, const float* res, int G, int P, int C,
                                int act, float slope, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    size_t n = (size_t)G * P * C;
-    if (n == 0) return 0;
-    if (C % 4 == 0)
-        hipLaunchKernelGGL((norm_apply_kernel<4>), dim3(grid_for(n / 4)), dim3(256), 0, st, x, y, mean, invstd,
-                           gamma, beta, res, G, P, C, act, slope);
+    if ((size_t)G * P * C == 0) return 0;
+    int VW, CTX, chunk;
+    dim3 grid;
+    apply_plan(G, P, C, VW, CTX, chunk, grid);
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_apply_kernel<4>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
+                           CTX, chunk, act, slope);
     else
-        hipLaunchKernelGGL((norm_apply_kernel<1>), dim3(grid_for(n)), dim3(256), 0, st, x, y, mean, invstd,
-                           gamma, beta, res, G, P, C, act, slope);
+        hipLaunchKernelGGL((norm_apply_kernel<1>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
+                           CTX, chunk, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -335,7 +369,7 @@ MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, cons
 MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
                              int G, int P, int C, int act, float slope, float* ws, size_t ws_bytes,
-                             void* stream) {
+                             int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
@@ -350,15 +384,17 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
                            beta, ws, P, C, CTX, chunk, nchunks, act, slope);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
-                       dgamma, dbeta, G, C, nchunks);
+                       dgamma, dbeta, G, C, nchunks, accumulate);
     HIP_LAUNCH_CHECK();
-    size_t n = (size_t)G * P * C;
+    int VW2, CTX2, chunk2;
+    dim3 grid2;
+    apply_plan(G, P, C, VW2, CTX2, chunk2, grid2);
     if (VW == 4)
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), dim3(grid_for(n / 4)), dim3(256), 0, st, x, dy, dx, mean,
-                           invstd, gamma, beta, sums, G, P, C, act, slope);
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid2, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+                           sums, P, C, CTX2, chunk2, act, slope);
     else
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), dim3(grid_for(n)), dim3(256), 0, st, x, dy, dx, mean,
-                           invstd, gamma, beta, sums, G, P, C, act, slope);
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid2, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+                           sums, P, C, CTX2, chunk2, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -55,14 +55,14 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __rest
     if (ty == 0 && c < C) part[(size_t)blockIdx.y * C + c] = red[tx] + red[64 + tx] + red[128 + tx] + red[192 + tx];
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                           int C, int nchunks) {
+                                                           int C, int nchunks, int accum) {
     const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;  // one wave per channel
     if (c >= C) return;
     double s = 0.0;
     for (int k = lane; k < nchunks; k += 64) s += (double)part[(size_t)k * C + c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) out[c] = (float)s;
+    if (lane == 0) out[c] = accum ? out[c] + (float)s : (float)s;
 }
 static void colsum_plan(size_t P, int C, size_t& chunk, int& nchunks) {
     long gx = cdiv(C, 64);
@@ -80,14 +80,15 @@ MIGAN_API size_t migan_colsum_workspace(size_t P, int C) {
     colsum_plan(P, C, chunk, nchunks);
     return (size_t)nchunks * C * sizeof(float);
 }
-MIGAN_API int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, void* stream) {
+MIGAN_API int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     size_t chunk; int nchunks;
     colsum_plan(P, C, chunk, nchunks);
     if (ws_bytes < (size_t)nchunks * C * sizeof(float)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, x, ws, P, C, chunk);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, ws, out, C, nchunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, ws, out, C, nchunks,
+                       accumulate);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -97,12 +97,38 @@ def _ws(nbytes, ref):
     return torch.empty(max(int(nbytes) // 4, 1), device=ref.device, dtype=torch.float32)
 
 
-def _colsum(x2d_ptr_tensor, P, C):
-    out = torch.empty(C, device=x2d_ptr_tensor.device, dtype=torch.float32)
+_DIRECT_GRAD = True
+
+
+def set_direct_grad(enabled):
+    """Parameter gradients are reduced straight INTO an existing contiguous `param.grad` (the optimiser's flat
+    bucket) by the wgrad / bias / norm reductions, instead of being returned to autograd, which would launch one
+    `aten::add` per parameter per backward pass (AccumulateGrad).  `param.grad` holds the same values either way.
+    Disable before calling `torch.autograd.grad(..., params)` (it would see no gradient for those inputs)."""
+    global _DIRECT_GRAD
+    _DIRECT_GRAD = bool(enabled)
+
+
+def _grad_slot(p):
+    """The buffer a first-order backward may accumulate this leaf's gradient into directly, or None."""
+    if not _DIRECT_GRAD or p is None or torch.is_grad_enabled():  # create_graph backward: stay differentiable
+        return None
+    if not (p.is_leaf and p.requires_grad):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.device != p.device or g.shape != p.shape or not g.is_contiguous():
+        return None
+    return g
+
+
+def _colsum(x2d_ptr_tensor, P, C, slot=None):
+    """Column sums of a [P][C] matrix; with `slot` the result is ADDED into it and None is returned."""
+    out = torch.empty(C, device=x2d_ptr_tensor.device, dtype=torch.float32) if slot is None else slot
     nb = lib.migan_colsum_workspace(P, C)
     ws = _ws(nb, x2d_ptr_tensor)
-    check(lib.migan_colsum(x2d_ptr_tensor.data_ptr(), out.data_ptr(), P, C, ws.data_ptr(), nb, _stream()), "colsum")
-    return out
+    check(lib.migan_colsum(x2d_ptr_tensor.data_ptr(), out.data_ptr(), P, C, ws.data_ptr(), nb,
+                           0 if slot is None else 1, _stream()), "colsum")
+    return out if slot is None else None
 
 
 def _act_bwd_raw(dy, y, act, slope):
@@ -122,6 +148,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pads, gather, act, slope):
         xs = to_nhwc(x)
+        w_in, b_in = w, b
         w = _plain(w)
         b = _plain(b)
         _check_dev(w)
@@ -142,6 +169,7 @@ class _Conv2d(Function):
                                    stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
         ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
         ctx.has_bias = b is not None
+        ctx.params = (w_in, b_in)
         ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
         return y
 
@@ -171,13 +199,17 @@ class _Conv2d(Function):
                 check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
                       "gather2d_bwd")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            slot = _grad_slot(ctx.params[0])
+            dw = torch.empty_like(w) if slot is None else slot
             nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
             ws = _ws(nb, xs)
             check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                         Ho, Wo, Co, R, S, stride, pt, pl, gather, st), "conv2d_wgrad")
+                                         Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1, st),
+                  "conv2d_wgrad")
+            if slot is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * Ho * Wo, Co)
+            db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
         return dx, dw, db, None, None, None, None, None
 
 
@@ -191,6 +223,7 @@ class _UpConv3x3(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
         xs = to_nhwc(x)
+        ctx.params = (w, b)
         w, b = _plain(w), _plain(b)
         N, Ci, H, W = xs.shape
         Co = w.shape[0]
@@ -223,19 +256,23 @@ class _UpConv3x3(Function):
             check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
                   "upconv_dgrad")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            slot = _grad_slot(ctx.params[0])
+            dw = torch.empty_like(w) if slot is None else slot
+            acc = 0 if slot is None else 1
             if Co % 4 == 0 and Ci % 4 == 0:
                 nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
                 ws = _ws(nb, xs)
                 check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
-                                                Ci, Co, st), "upconv_wgrad")
+                                                Ci, Co, acc, st), "upconv_wgrad")
             else:  # same gradient through the dense gathered wgrad
                 nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
                 ws = _ws(nb, xs)
                 check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                             2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, st), "conv2d_wgrad")
+                                             2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, st), "conv2d_wgrad")
+            if slot is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * 4 * H * W, Co)
+            db = _colsum(dy, N * 4 * H * W, Co, _grad_slot(ctx.params[1]))
         return dx, dw, db, None, None
 
 
@@ -260,6 +297,7 @@ class _ConvTranspose2d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act, slope):
         xs = to_nhwc(x)
+        ctx.params = (w, b)
         w = _plain(w)
         b = _plain(b)
         N, Cin, Hin, Win = xs.shape
@@ -292,13 +330,17 @@ class _ConvTranspose2d(Function):
             check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
                                        Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            slot = _grad_slot(ctx.params[0])
+            dw = torch.empty_like(w) if slot is None else slot
             nb = lib.migan_conv2d_wgrad_workspace(N, Hin, Win, Cin, R, S, Cout)
             ws = _ws(nb, xs)
             check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout, Wout,
-                                         Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO, st), "convT_wgrad")
+                                         Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO,
+                                         0 if slot is None else 1, st), "convT_wgrad")
+            if slot is not None:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * Hout * Wout, Cout)
+            db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
         return dx, dw, db, None, None, None, None
 
 
@@ -340,6 +382,7 @@ class _MMNT(Function):
         # save the ORIGINAL inputs: their autograd history is what makes the backward differentiable again
         ctx.save_for_backward(a, b)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         return _mm_nt_raw(canon(a), canon(b), _plain(bias))
 
     @staticmethod
@@ -349,11 +392,29 @@ class _MMNT(Function):
         if ctx.needs_input_grad[0]:
             da = mm_nn(g, b)
         if ctx.needs_input_grad[1]:
-            db = _MMTN.apply(g, a)
+            slot = _grad_slot(b)
+            if slot is not None:  # first-order backward of a Linear weight: reduce straight into weight.grad
+                _mm_tn_raw(canon(g), canon(a), slot, 1)
+            else:
+                db = _MMTN.apply(g, a)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gc = canon(g)
-            dbias = _colsum(gc, gc.shape[0], gc.shape[1])
+            dbias = _colsum(gc, gc.shape[0], gc.shape[1], _grad_slot(ctx.bias_param))
         return da, db, dbias
+
+
+def _mm_tn_raw(a, b, out=None, accumulate=0):
+    P, M = a.shape
+    Pb, Nn = b.shape
+    if P != Pb:
+        raise ValueError("mm_tn: row counts differ")
+    if out is None:
+        out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+    nb = lib.migan_conv2d_wgrad_workspace(P, 1, 1, M, 1, 1, Nn)
+    ws = _ws(nb, a)
+    check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
+                                 M, 1, 1, 1, 0, 0, GATHER_ZERO, accumulate, _stream()), "mm_tn")
+    return out
 
 
 class _MMTN(Function):
@@ -362,17 +423,7 @@ class _MMTN(Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.save_for_backward(a, b)  # originals (see _MMNT.forward)
-        a, b = canon(a), canon(b)
-        P, M = a.shape
-        Pb, Nn = b.shape
-        if P != Pb:
-            raise ValueError("mm_tn: row counts differ")
-        out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
-        nb = lib.migan_conv2d_wgrad_workspace(P, 1, 1, M, 1, 1, Nn)
-        ws = _ws(nb, a)
-        check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
-                                     M, 1, 1, 1, 0, 0, GATHER_ZERO, _stream()), "mm_tn")
-        return out
+        return _mm_tn_raw(canon(a), canon(b))
 
     @staticmethod
     def backward(ctx, g):
@@ -470,8 +521,9 @@ class _Norm(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
-                slope):
+                slope, nbt=None):
         xs = canon(x)
+        ctx.params = (gamma, beta)
         gamma, beta = _plain(gamma), _plain(beta)
         if xs.dim() == 4:
             N, C, H, W = xs.shape
@@ -489,7 +541,8 @@ class _Norm(Function):
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
             check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
-                                       _ptr(running_var), momentum, eps, G, P, C, ws.data_ptr(), nb, st), "norm_stats")
+                                       _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb, st),
+                  "norm_stats")
         else:
             mean = _plain(running_mean)
             invstd = torch.rsqrt(_plain(running_var) + eps)
@@ -509,20 +562,30 @@ class _Norm(Function):
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
         dy = canon(dy)
         dx = torch.empty_like(xs)
-        dgamma = torch.empty(C, device=xs.device, dtype=torch.float32) if affine and G == 1 else None
-        dbeta = torch.empty_like(dgamma) if dgamma is not None else None
+        dgamma = dbeta = None
+        acc = 0
+        if affine and G == 1:
+            sg, sb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+                dgamma, dbeta, acc = sg, sb, 1
+            else:
+                dgamma = torch.empty(C, device=xs.device, dtype=torch.float32)
+                dbeta = torch.empty_like(dgamma)
         nb = lib.migan_norm_workspace(G, P, C)
         ws = _ws(nb, xs)
         check(lib.migan_norm_bwd(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                  _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
-                                 ws.data_ptr(), nb, _stream()), "norm_bwd")
-        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None
+                                 ws.data_ptr(), nb, acc, _stream()), "norm_bwd")
+        if acc:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
 
 
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
-         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0):
+         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None):
+    """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself."""
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
-                       float(eps), bool(instance), int(act), float(slope))
+                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked)
 
 
 # ---------------------------------------------------------------------------------------------- index remaps

@@ -172,11 +172,12 @@ class _BatchNormMixin:
         use_batch = self.training or not self.track_running_stats
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
+        nbt = None
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+            nbt = self.num_batches_tracked  # incremented by the statistics kernel (no separate aten::add launch)
         y = F.norm(x, self.weight if self.affine else None, self.bias if self.affine else None, res,
                    rm if (self.training or not use_batch) else None, rv if (self.training or not use_batch) else None,
-                   use_batch, self.momentum, self.eps, False, act, slope)
+                   use_batch, self.momentum, self.eps, False, act, slope, nbt)
         return _wrap(y)
 
     def forward(self, x):
@@ -286,7 +287,7 @@ class _DropoutRNG:
     def counter(cls, device):
         key = str(device)
         if key not in cls.counters:
-            cls.counters[key] = torch.zeros(1, dtype=torch.int64, device=device)
+            cls.counters[key] = torch.zeros(2, dtype=torch.int64, device=device)  # [stream position, ticket]
         return cls.counters[key]
 
 

@@ -327,14 +327,14 @@ def test_dropout_masks(pg):
     y.backward(gy.to(DEV))
     assert torch.equal(y.cpu(), y_ref.detach()) and torch.equal(xg.grad.cpu(), x.grad)
     # device Philox stream: keep-probability and scaling
-    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ctr = torch.zeros(2, dtype=torch.int64, device=DEV)  # {stream position, arrival ticket}
     mk = F.rand_mask((1 << 20,), 0.25, 1234, ctr, DEV)
     vals = torch.unique(mk).cpu().tolist()
     assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.75) < 1e-6
     assert abs((mk > 0).float().mean().item() - 0.75) < 3e-3
     mk2 = F.rand_mask((1 << 20,), 0.25, 1234, ctr, DEV)
     assert not torch.equal(mk, mk2), "counter must advance the stream"
-    assert int(ctr.item()) == 2 * (1 << 18)
+    assert ctr.cpu().tolist() == [2 * (1 << 18), 0], "position advanced by the last block, ticket back at rest"
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
@@ -426,3 +426,41 @@ def test_upconv3x3_phase_collapsed(pg, cfg):
     finally:
         F.set_upconv_collapse(True)
     assert_close(y2, y_ref, TOL_FWD, "dense up2 conv")
+
+
+def test_direct_grad_accumulation(pg):
+    """With a pre-allocated contiguous `.grad` (the optimiser's flat bucket) the wgrad / bias / norm reductions ADD
+    into it in place (functional.set_direct_grad); the values must equal autograd's AccumulateGrad result, twice in a
+    row (two backward passes accumulate, as the D step of dcgan.py:170-174 does)."""
+    F = pg.functional
+    nn = pg.nn
+    torch.manual_seed(0)
+    net = nn.Sequential(
+        nn.Conv2d(8, 16, 3, 1, 1), nn.BatchNorm2d(16), nn.LeakyReLU(0.2),
+        nn.Upsample(scale_factor=2), nn.Conv2d(16, 12, 3, stride=1, padding=1), nn.ReLU(),
+        nn.ConvTranspose2d(12, 8, 4, 2, 1), nn.Conv2d(8, 3, 3, 1, 1),
+    ).to(DEV)
+    lin = nn.Linear(3 * 16 * 16, 5).to(DEV)
+    params = list(net.parameters()) + list(lin.parameters())
+    x = _leaf(3, 8, 4, 4, seed=1).to(DEV)
+
+    def run():
+        out = lin(net(x).reshape(3, -1))
+        (out * out).mean().backward()
+
+    results = {}
+    for direct in (False, True):
+        F.set_direct_grad(direct)
+        try:
+            for i, p in enumerate(params):
+                p.grad = torch.full_like(p, 0.25 * (i % 3))  # pre-existing gradient content to accumulate onto
+            ptrs = [p.grad.data_ptr() for p in params]
+            run()
+            run()
+            if direct:
+                assert [p.grad.data_ptr() for p in params] == ptrs, "direct accumulation must not replace .grad"
+            results[direct] = [p.grad.detach().clone() for p in params]
+        finally:
+            F.set_direct_grad(True)
+    for p, a, b in zip(params, results[False], results[True]):
+        assert_close(b, a, TOL_WGRAD, "direct grad %s" % (tuple(p.shape),))

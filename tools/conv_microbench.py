@@ -89,7 +89,7 @@ def main():
             "dgrad": lambda: lib.migan_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
                                                     Wo, Co, k, k, s, pd, pd, 0, 0.0, st),
             "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
-                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, st),
+                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, st),
         }
         for d in ("fwd", "dgrad", "wgrad"):
             if d not in only:
