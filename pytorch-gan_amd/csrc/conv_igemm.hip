@@ -1045,6 +1045,83 @@ __global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, cons
     }
 }
 
+// Tiled variant for Co/4 dividing 256 (the common case): a block owns PB = 64 consecutive output pixels.  Their K
+// gathered source values are computed ONCE (cooperatively, staged in LDS) instead of once per channel quad, each
+// thread keeps its 4xK weights in registers and produces its quad for 256/(Co/4)-strided pixels of the tile; the
+// tile's output is one contiguous run of 64*Co floats.
+template <int K>
+__global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, const SmallK sk,
+                                                          const float* __restrict__ A, const float* __restrict__ Bw,
+                                                          const float* __restrict__ bias, float* __restrict__ C) {
+    constexpr int PB = 64;
+    __shared__ float a_s[PB * K];
+    __shared__ int s_dh[K], s_dw[K], s_c[K];
+    if (threadIdx.x < K) {
+        s_dh[threadIdx.x] = sk.dh[threadIdx.x];
+        s_dw[threadIdx.x] = sk.dw[threadIdx.x];
+        s_c[threadIdx.x] = sk.c[threadIdx.x];
+    }
+    const int Ho = g.Ho[0], Wo = g.Wo[0];
+    const int M = g.N * Ho * Wo;
+    const int cq_n = g.Co >> 2;
+    const int rows = 256 / cq_n;  // pixel lanes per block
+    const int tid = threadIdx.x;
+    const int cq = tid % cq_n, pl = tid / cq_n;
+    const int co = cq * 4;
+    float w[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[k][e] = Bw[(size_t)(co + e) * g.ldw + sk.wofs[k]];
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+    const bool linear_out = g.ostep == 1;
+    const int ntiles = (M + PB - 1) / PB;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * PB;
+        __syncthreads();
+        for (int idx = tid; idx < PB * K; idx += 256) {
+            const int p = idx / K, k = idx - p * K;
+            const int m = m0 + p;
+            float v = 0.f;
+            if (m < M) {
+                const int n = m / (Ho * Wo);
+                const int rem = m - n * Ho * Wo;
+                const int oi = rem / Wo, oj = rem - oi * Wo;
+                int ihs, iws;
+                bool ok = map_bf(oi * g.istride + s_dh[k], g.HiL, g.Hi, g.gather, ihs);
+                ok &= map_bf(oj * g.istride + s_dw[k], g.WiL, g.Wi, g.gather, iws);
+                const float t = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + s_c[k]];
+                v = ok ? t : 0.f;
+            }
+            a_s[idx] = v;
+        }
+        __syncthreads();
+        for (int p = pl; p < PB; p += rows) {
+            const int m = m0 + p;
+            if (m >= M) break;
+            f32x4 acc = b4;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float a = a_s[p * K + k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[k][e], acc[e]);
+            }
+            size_t opix = (size_t)m;
+            if (!linear_out) {
+                const int n = m / (Ho * Wo);
+                const int rem = m - n * Ho * Wo;
+                const int oi = rem / Wo, oj = rem - oi * Wo;
+                opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
+            *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
+        }
+    }
+}
+
 static bool smallk_ok(const ConvGeom& g) {
     const int K = g.ntap[0] * g.Ci;
     return g.ncls == 1 && g.Co % 4 == 0 && K >= 1 && K <= 16;
@@ -1056,9 +1133,11 @@ static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, cons
     const int cq_n = g.Co >> 2;
     long blocks = cdiv(maxM * cq_n, 256L);
     if (blocks > 8192) blocks = 8192;
-    if (256 % cq_n == 0)
-        hipLaunchKernelGGL((smallk_conv_kernel<K, true>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
-    else
+    if (256 % cq_n == 0) {
+        long tiles = cdiv(maxM, 64L);
+        if (tiles > 8192) tiles = 8192;
+        hipLaunchKernelGGL((smallk_tile_kernel<K>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+    } else
         hipLaunchKernelGGL((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
 }
 
@@ -1185,9 +1264,11 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
             return launch_pipe<128, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1064064:
             if (var == 100) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
+            if (var == 300) return launch_db<64, 64, 2, 2>(g, A, Bw, bias, C, st);
             return launch_pipe<64, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1128032:
             if (var == 100) return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
+            if (var == 300) return launch_db<128, 32, 4, 1>(g, A, Bw, bias, C, st);
             return launch_pipe<128, 32, 4, 1>(g, A, Bw, bias, C, st);
         case 128128: return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
         case 128064: return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
@@ -1708,10 +1789,20 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     return 0;
 }
 
+static int wgrad_var() {
+    static const int v = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // tuning knob (A/B runs)
+    return v;
+}
+// tile shape: 128x128 when both GEMM dims exceed 64; 64x128 for 32 < Co <= 64 with a wide column side (2 MFMAs per 3
+// LDS fragment reads instead of 1 per 2); else 64x64.  BNsel is returned through BMsel's companion wgrad_bn().
+static int wgrad_bn(int Co, int Ncol) {
+    if (Co > 64 && Ncol > 64) return 128;
+    return (Co > 32 && Ncol >= 128 && wgrad_var() != 64) ? 128 : 64;
+}
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
     long Mpix = (long)N * Ho * Wo;
     BMsel = (Co > 64 && Ncol > 64) ? 128 : 64;
-    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, BMsel) * ncls;
+    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, wgrad_bn(Co, Ncol)) * ncls;
     long want = cdiv(1024, tiles);
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
     if (want > maxs) want = maxs;
@@ -1867,6 +1958,10 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     if (bm == 128) {
         g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
         hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
+                           0, st, g, x, dy, ws);
+    } else if (wgrad_bn(Co, Ncol) == 128) {
+        g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
+        hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
                            0, st, g, x, dy, ws);
     } else {
         g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
@@ -2182,7 +2277,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
     fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
-    static const int wvar = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // 100 = old kernel
+    const int wvar = wgrad_var();  // 100 = old kernel
     if (vec && wvar != 100) {
         if (bm == 128) {
             g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
@@ -2192,7 +2287,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             else if (wvar == 3) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
             else
             hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
-        } else if (Ncol >= 128 && wvar == 65) {  // experimental: needs a tile-aware split plan to pay off
+        } else if (wgrad_bn(Co, Ncol) == 128) {
             g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
             dim3 grid(g.tiles_m * g.tiles_n * g.splits);
             hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128>), grid, dim3(256), 0, st, g, x, dy, ws);

@@ -44,11 +44,12 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     if (p1 > P) p1 = P;
     const float* xb = x + (size_t)g * P * C;
     const float* dyb = BWD ? dy + (size_t)g * P * C : nullptr;
-    // forward: sums are taken around the chunk's first pixel K (shifted data) so that E[x^2]-E[x]^2 does not
-    // cancel; the finalize kernel merges the per-chunk (n, mean, M2) triples in double (Chan et al.).
+    // forward: sums are taken around K = the group's FIRST pixel (shifted-data algorithm: one sample of the
+    // distribution as the origin keeps E[d^2]-E[d]^2 free of catastrophic cancellation); every chunk uses the same
+    // K, so the finalize kernel only adds the partial sums (in double).
     float shift[VW];
 #pragma unroll
-    for (int v = 0; v < VW; ++v) shift[v] = (!BWD && cok && p0 < P) ? xb[(size_t)p0 * C + c + v] : 0.f;
+    for (int v = 0; v < VW; ++v) shift[v] = (!BWD && cok) ? xb[c + v] : 0.f;
     if (cok) {
         for (int p = p0 + ty; p < p1; p += TY) {
             float xv[VW], dv[VW];
@@ -103,17 +104,8 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     }
 }
 
-// pass 2 (forward): ONE WAVE per (g,c) merges the per-chunk (n, mean, M2) triples in double (lanes stride over
-// chunks, then a butterfly of Chan merges), writes mean / invstd and updates the running statistics.
-__device__ __forceinline__ void chan_merge(double& n, double& m, double& M2, double n2, double m2, double M22) {
-    double nn = n + n2;
-    if (nn > 0.0 && n2 > 0.0) {
-        double delta = m2 - m;
-        m += delta * n2 / nn;
-        M2 += M22 + delta * delta * n * n2 / nn;
-        n = nn;
-    }
-}
+// pass 2 (forward): ONE WAVE per (g,c) adds the per-chunk (sum d, sum d^2) pairs in double (lanes stride over
+// chunks, butterfly reduce), writes mean / invstd and updates the running statistics.
 __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* running_mean,
@@ -123,26 +115,24 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= G * C) return;  // wave-uniform
     const int g = i / C, c = i - g * C;
-    double n = 0.0, m = 0.0, M2 = 0.0;
+    double sd = 0.0, sq = 0.0;
     for (int k = lane; k < nchunks; k += 64) {
         size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
-        int p0 = k * chunk, p1 = p0 + chunk;
-        if (p1 > P) p1 = P;
-        double nk = (double)(p1 - p0);
-        if (nk <= 0.0) continue;
-        double s = (double)part[o], q = (double)part[o + 1], K = (double)part[o + 2];
-        double M2k = q - s * s / nk;
-        if (M2k < 0.0) M2k = 0.0;
-        chan_merge(n, m, M2, nk, K + s / nk, M2k);
+        sd += (double)part[o];
+        sq += (double)part[o + 1];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        double n2 = __shfl_xor(n, off), m2 = __shfl_xor(m, off), M22 = __shfl_xor(M2, off);
-        if (n == 0.0) { n = n2; m = m2; M2 = M22; }
-        else chan_merge(n, m, M2, n2, m2, M22);
+        sd += __shfl_xor(sd, off);
+        sq += __shfl_xor(sq, off);
     }
     if (lane != 0) return;
     if (i == 0 && nbt) nbt[0] += 1;  // BatchNorm's num_batches_tracked
+    const double K = (double)part[(((size_t)g * nchunks) * C + c) * 3 + 2];
+    const double md = sd / P;
+    double M2 = sq - sd * md;
+    if (M2 < 0.0) M2 = 0.0;
+    const double m = K + md;
     double var = M2 / P;
     mean[i] = (float)m;
     invstd[i] = (float)(1.0 / sqrt(var + (double)eps));

@@ -23,6 +23,52 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", "0"))  # 0 off, 1 on, n>1: only dy.numel() <= n
+_SIDE_STREAMS = {}
+
+
+def set_wgrad_overlap(enabled):
+    """Run the weight-gradient chain of a conv backward (wgrad, split-K reduction, bias column sums) on a side
+    stream concurrently with its dgrad (they only share the read-only dy); the two streams join before backward
+    returns.  Captured into a hipGraph this becomes two parallel branches, so the short reduction kernels no longer
+    sit on the critical path."""
+    global _OVERLAP_WGRAD
+    _OVERLAP_WGRAD = int(enabled)
+
+
+class _Fork:
+    """fork(): side stream waits for the current one and becomes current;  join(): current waits for the side."""
+
+    def __init__(self, device, enabled, numel=0):
+        self.on = (bool(enabled) and _OVERLAP_WGRAD != 0 and not torch.is_grad_enabled()
+                   and (_OVERLAP_WGRAD == 1 or numel <= _OVERLAP_WGRAD))
+        if self.on:
+            self.main = torch.cuda.current_stream(device)
+            key = (device.index, self.main.cuda_stream)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+            self.side = _SIDE_STREAMS[key]
+            self.ctx = None
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        # Every side-stream use starts by waiting for the main stream and ends with the main stream waiting for it, so
+        # buffers from either stream's allocator pool are never recycled under a kernel that still reads them.
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 def _plain(t):
     """Strip tensor subclasses (GanTensor / Parameter) without copying."""
     if t is None or type(t) is torch.Tensor:
@@ -180,8 +226,23 @@ class _Conv2d(Function):
         dy = to_nhwc(dy)
         if act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
-        st = _stream()
         dx = dw = db = None
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        with fork:
+            st = _stream()
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.params[0])
+                dw = torch.empty_like(w) if slot is None else slot
+                nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
+                ws = _ws(nb, xs)
+                check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
+                                             Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1, st),
+                      "conv2d_wgrad")
+                if slot is not None:
+                    dw = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
+        st = _stream()
         if ctx.needs_input_grad[0]:
             wt = _permute4(w, (1, 2, 3, 0))
             dx = _empty_nhwc((N, Ci, H, W), xs)
@@ -198,18 +259,7 @@ class _Conv2d(Function):
                                              Co, R, S, stride, dpt, dpl, 0, 0.0, st), "conv2d_dgrad")
                 check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
                       "gather2d_bwd")
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(ctx.params[0])
-            dw = torch.empty_like(w) if slot is None else slot
-            nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
-            ws = _ws(nb, xs)
-            check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                         Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1, st),
-                  "conv2d_wgrad")
-            if slot is not None:
-                dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
+        fork.join()
         return dx, dw, db, None, None, None, None, None
 
 
@@ -249,30 +299,33 @@ class _UpConv3x3(Function):
         dy = to_nhwc(dy)
         if act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
-        st = _stream()
         dx = dw = db = None
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        with fork:
+            st = _stream()
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.params[0])
+                dw = torch.empty_like(w) if slot is None else slot
+                acc = 0 if slot is None else 1
+                if Co % 4 == 0 and Ci % 4 == 0:
+                    nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
+                    ws = _ws(nb, xs)
+                    check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
+                                                    W, Ci, Co, acc, st), "upconv_wgrad")
+                else:  # same gradient through the dense gathered wgrad
+                    nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
+                    ws = _ws(nb, xs)
+                    check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
+                                                 Ci, 2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, st), "conv2d_wgrad")
+                if slot is not None:
+                    dw = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _colsum(dy, N * 4 * H * W, Co, _grad_slot(ctx.params[1]))
         if ctx.needs_input_grad[0]:
             dx = _empty_nhwc((N, Ci, H, W), xs)
-            check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
+            check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, _stream()),
                   "upconv_dgrad")
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(ctx.params[0])
-            dw = torch.empty_like(w) if slot is None else slot
-            acc = 0 if slot is None else 1
-            if Co % 4 == 0 and Ci % 4 == 0:
-                nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
-                ws = _ws(nb, xs)
-                check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
-                                                Ci, Co, acc, st), "upconv_wgrad")
-            else:  # same gradient through the dense gathered wgrad
-                nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
-                ws = _ws(nb, xs)
-                check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                             2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, st), "conv2d_wgrad")
-            if slot is not None:
-                dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * 4 * H * W, Co, _grad_slot(ctx.params[1]))
+        fork.join()
         return dx, dw, db, None, None
 
 
@@ -322,25 +375,29 @@ class _ConvTranspose2d(Function):
         dy = to_nhwc(dy)
         if act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
-        st = _stream()
         dx = dw = db = None
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        with fork:
+            st = _stream()
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.params[0])
+                dw = torch.empty_like(w) if slot is None else slot
+                nb = lib.migan_conv2d_wgrad_workspace(N, Hin, Win, Cin, R, S, Cout)
+                ws = _ws(nb, xs)
+                check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout,
+                                             Wout, Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO,
+                                             0 if slot is None else 1, st), "convT_wgrad")
+                if slot is not None:
+                    dw = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
+        st = _stream()
         if ctx.needs_input_grad[0]:
             wo = _permute4(w, (0, 2, 3, 1))  # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
             dx = _empty_nhwc((N, Cin, Hin, Win), xs)
             check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
                                        Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(ctx.params[0])
-            dw = torch.empty_like(w) if slot is None else slot
-            nb = lib.migan_conv2d_wgrad_workspace(N, Hin, Win, Cin, R, S, Cout)
-            ws = _ws(nb, xs)
-            check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout, Wout,
-                                         Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO,
-                                         0 if slot is None else 1, st), "convT_wgrad")
-            if slot is not None:
-                dw = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
+        fork.join()
         return dx, dw, db, None, None, None, None
 
 
@@ -389,17 +446,20 @@ class _MMNT(Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         da = db = dbias = None
+        fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel())
+        gc, ac = canon(g), canon(a)  # on the main stream: both branches read them
+        with fork:
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(b)
+                if slot is not None:  # first-order backward of a Linear weight: reduce straight into weight.grad
+                    _mm_tn_raw(gc, ac, slot, 1)
+                else:
+                    db = _MMTN.apply(g, a)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dbias = _colsum(gc, gc.shape[0], gc.shape[1], _grad_slot(ctx.bias_param))
         if ctx.needs_input_grad[0]:
             da = mm_nn(g, b)
-        if ctx.needs_input_grad[1]:
-            slot = _grad_slot(b)
-            if slot is not None:  # first-order backward of a Linear weight: reduce straight into weight.grad
-                _mm_tn_raw(canon(g), canon(a), slot, 1)
-            else:
-                db = _MMTN.apply(g, a)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gc = canon(g)
-            dbias = _colsum(gc, gc.shape[0], gc.shape[1], _grad_slot(ctx.bias_param))
+        fork.join()
         return da, db, dbias
 
 

@@ -91,8 +91,24 @@ def main():
             "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
                                                     W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, st),
         }
-        for d in ("fwd", "dgrad", "wgrad"):
-            if d not in only:
+        dirs = ["fwd", "dgrad", "wgrad"]
+        if gth == 2 and k == 3 and s == 1 and p == 1 and Co % 4 == 0 and Ci % 4 == 0:
+            # phase-collapsed Upsample(2)->Conv3x3 (what the product path runs); TF stays ALGORITHMIC (dense FLOPs)
+            wf = torch.empty(Co * 16 * Ci, device=dev)
+            wd = torch.empty_like(wf)
+            check(lib.migan_upconv3x3_pack(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, st), "pack")
+            dxs = torch.empty(N * H * W * Ci, device=dev)
+            nbu = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
+            wsu = torch.empty(max(nbu // 4, 1), device=dev)
+            calls["ufwd"] = lambda: lib.migan_upconv3x3_fwd(x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), N, H, W, Ci,
+                                                            Co, 0, 0.0, st)
+            calls["udgrad"] = lambda: lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dxs.data_ptr(), N, H, W,
+                                                                Ci, Co, st)
+            calls["uwgrad"] = lambda: lib.migan_upconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                                                                wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, st)
+            dirs += ["ufwd", "udgrad", "uwgrad"]
+        for d in dirs:
+            if d.lstrip("u") not in only:
                 continue
             fn = calls[d]
             for _ in range(3):
@@ -106,7 +122,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
             tf = flops / (ms * 1e-3) / 1e12
-            print("%-28s %-5s %9.1f us  %7.2f TF  %5.1f%%  (%.2f GFLOP)" % (name, d, ms * 1e3, tf, 100 * tf / 157.3, flops / 1e9),
+            print("%-28s %-6s %9.1f us  %7.2f TF  %5.1f%%  (%.2f GFLOP)" % (name, d, ms * 1e3, tf, 100 * tf / 157.3, flops / 1e9),
                   flush=True)
 
 
