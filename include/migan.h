@@ -37,6 +37,14 @@ const char* migan_error_string(int code);
 int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int Hi, int Wi,
                      int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather,
                      int act, float slope, void* stream);
+/* Conv2d -> activation -> nn.Dropout2d(p) (the discriminator block of dcgan.py:77-78) in one launch:
+ * y = act(conv(x)+bias) * mask[n][co], mask from migan_rand_mask.  Co % 4 == 0.  Backward of the act+mask pair:
+ * migan_act_bwd_nc (dx = dy * mask[n][c] * act'(y), y = the masked output). */
+int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc, float* y,
+                             int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t,
+                             int pad_l, int gather, int act, float slope, void* stream);
+int migan_act_bwd_nc(const float* dy, const float* y, const float* mask_nc, float* dx, int N, int HW, int C, int act,
+                     float slope, void* stream);
 
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];

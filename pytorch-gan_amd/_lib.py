@@ -54,6 +54,8 @@ _SIGS = {
     "migan_version": (c_char_p, []),
     "migan_error_string": (c_char_p, [c_int]),
     "migan_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 14 + [c_float, P]),
+    "migan_conv2d_dropout_fwd": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P]),
+    "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),

@@ -32,6 +32,7 @@ struct ConvGeom {
     int gather, ldw, ncls;
     int act;
     float slope;
+    const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
     int oh0[MAX_CLS], ow0[MAX_CLS], Ho[MAX_CLS], Wo[MAX_CLS], tapbeg[MAX_CLS], ntap[MAX_CLS];
     int wofs[MAX_TAPS];
     signed char dh[MAX_TAPS], dw[MAX_TAPS];
@@ -293,7 +294,9 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
                 if (col < g.Co) {
                     float v = acc[i][j][r];
                     if (bias) v += bias[col];
-                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                    float o = act_apply(v, g.act, g.slope);
+                    if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    C[opix * g.Co + col] = o;
                 }
             }
         }
@@ -538,7 +541,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                 if (col < g.Co) {
                     float v = acc[i][j][r];
                     if (bias) v += bias[col];
-                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                    float o = act_apply(v, g.act, g.slope);
+                    if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    C[opix * g.Co + col] = o;
                 }
             }
         }
@@ -762,7 +767,9 @@ __global__ __launch_bounds__(256, 2) void igemm_db_kernel(const ConvGeom g, cons
                 if (col < g.Co) {
                     float v = acc[i][j][r];
                     if (bias) v += bias[col];
-                    C[opix * g.Co + col] = act_apply(v, g.act, g.slope);
+                    float o = act_apply(v, g.act, g.slope);
+                    if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    C[opix * g.Co + col] = o;
                 }
             }
         }
@@ -927,7 +934,9 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const 
     for (int k = 0; k < CO; ++k) {
         float v = acc[k];
         if (bias) v += bias[k];
-        C[opix * g.Co + k] = act_apply(v, g.act, g.slope);
+        float o = act_apply(v, g.act, g.slope);
+        if (g.oscale) o *= g.oscale[(size_t)n * g.Co + k];
+        C[opix * g.Co + k] = o;
     }
 }
 
@@ -1041,6 +1050,11 @@ __global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, cons
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
+        if (g.oscale) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * g.Co + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+        }
         *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
     }
 }
@@ -1117,6 +1131,11 @@ __global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, cons
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
+            if (g.oscale) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)(m / (Ho * Wo)) * g.Co + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+            }
             *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
         }
     }
@@ -1201,7 +1220,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 static bool gemv_ok(const ConvGeom& g, long maxM) {
     return g.ncls == 1 && g.ntap[0] == 1 && g.dh[0] == 0 && g.dw[0] == 0 && g.wofs[0] == 0 && g.istride == 1 &&
            g.ostep == 1 && g.gather == GATHER_ZERO && g.Hi == g.Ho[0] && g.Wi == g.Wo[0] && g.Co <= 4 &&
-           g.Ci % 4 == 0 && g.ldw % 4 == 0 && g.Ci >= 256 && maxM <= 16384;
+           g.Ci % 4 == 0 && g.ldw % 4 == 0 && g.Ci >= 256 && maxM <= 16384 && g.oscale == nullptr;
 }
 
 static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* Bw, const float* bias, float* C,
@@ -1279,7 +1298,7 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
 // ------------------------------------------------------------------------------------------------
 // C ABI: forward
 // ------------------------------------------------------------------------------------------------
-MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N,
+static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, const float* oscale, float* y, int N,
                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                                int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
     if (R * S > MAX_TAPS || R * S < 1) return (int)hipErrorInvalidValue;
@@ -1289,7 +1308,7 @@ MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float*
     g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
     g.Co = Co; g.HoF = Ho; g.WoF = Wo;
     g.ostep = 1; g.istride = stride; g.gather = gather; g.ldw = R * S * Ci; g.ncls = 1;
-    g.act = act; g.slope = slope;
+    g.act = act; g.slope = slope; g.oscale = oscale;
     g.oh0[0] = 0; g.ow0[0] = 0; g.Ho[0] = Ho; g.Wo[0] = Wo; g.tapbeg[0] = 0; g.ntap[0] = R * S;
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {
@@ -1299,6 +1318,22 @@ MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float*
             g.wofs[t] = t * Ci;
         }
     return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
+}
+
+MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N,
+                               int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                               int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
+    return conv2d_fwd_impl(x, w_ohwi, bias, nullptr, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, act,
+                           slope, stream);
+}
+// y = act(conv(x) + bias) * mask[n][co]: the Conv2d -> LeakyReLU -> Dropout2d block of dcgan.py:78 in one launch
+MIGAN_API int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc,
+                                       float* y, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                       int stride, int pad_t, int pad_l, int gather, int act, float slope,
+                                       void* stream) {
+    if (!mask_nc || Co % 4 != 0) return (int)hipErrorInvalidValue;
+    return conv2d_fwd_impl(x, w_ohwi, bias, mask_nc, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, act,
+                           slope, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2056,8 +2091,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const
 }
 
 static bool thin_wgrad_ok(int Co, int R, int S, int Ci, int stride, int gather) {
-    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R == S && (S == 1 || S == 3 || (S == 4 && Co <= 2)) &&
-           Ci % 4 == 0 && Ci >= 16;
+    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R == S && (S == 1 || S == 3 || S == 4) &&
+           R * S * Co <= THIN_MAX_ACC && Ci % 4 == 0 && Ci >= 16;  // one f32x4 accumulator per (tap, co)
 }
 template <int KS>
 static void launch_thin(int Co, dim3 grid, size_t lds, hipStream_t st, const ThinGeom& tg, const float* x,
@@ -2279,6 +2314,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
     const int wvar = wgrad_var();  // 100 = old kernel
     if (vec && wvar != 100) {
+
         if (bm == 128) {
             g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
             dim3 grid(g.tiles_m * g.tiles_n * g.splits);

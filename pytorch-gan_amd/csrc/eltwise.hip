@@ -48,6 +48,36 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     if (t < n) dx[t] = dy[t] * act_grad_from_out(y[t], act, slope);
 }
 
+// dx[n][p][c] = dy * mask[n][c] * act'(y): backward of act -> Dropout2d in one pass (y is the masked output; where the
+// mask is 0 the result is 0, elsewhere y keeps the sign the activation derivative needs).  C % 4 == 0.
+__global__ void act_bwd_nc_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                  const float* __restrict__ mask, float* __restrict__ dx, int HW, int C, size_t n4,
+                                  int act, float slope) {
+    const size_t per_img = (size_t)HW * C / 4;
+    const int cq = C / 4;
+    GRID_STRIDE(i, n4) {
+        const size_t img = i / per_img;
+        const int c4 = (int)(i % cq);
+        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 m = reinterpret_cast<const f32x4*>(mask)[img * cq + c4];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = d[k] * m[k] * act_grad_from_out(v[k], act, slope);
+        reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+}
+MIGAN_API int migan_act_bwd_nc(const float* dy, const float* y, const float* mask, float* dx, int N, int HW, int C,
+                               int act, float slope, void* stream) {
+    size_t total = (size_t)N * HW * C;
+    if (total == 0) return 0;
+    if (C % 4 != 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(act_bwd_nc_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx,
+                       HW, C, total / 4, act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,

@@ -192,7 +192,7 @@ class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pads, gather, act, slope):
+    def forward(ctx, x, w, b, stride, pads, gather, act, slope, mask=None):
         xs = to_nhwc(x)
         w_in, b_in = w, b
         w = _plain(w)
@@ -211,20 +211,33 @@ class _Conv2d(Function):
             raise ValueError("conv2d: empty output")
         wp = _permute4(w, (0, 2, 3, 1))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
-        check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
-                                   stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
+        if mask is None:
+            check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
+                                       S, stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
+        else:  # fused Dropout2d: y = act(conv) * mask[n][co]
+            mask = _plain(mask)
+            if tuple(mask.shape) != (N, Co) or not mask.is_contiguous() or Co % 4 != 0:
+                raise ValueError("conv2d: dropout mask must be a contiguous (N, Co) tensor with Co % 4 == 0")
+            check(lib.migan_conv2d_dropout_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), mask.data_ptr(), y.data_ptr(), N, H,
+                                               W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, _stream()),
+                  "conv2d_dropout_fwd")
         ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w_in, b_in)
-        ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(xs, w, y if (act != ACT_NONE or mask is not None) else None, mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xs, w, y = ctx.saved_tensors
+        xs, w, y, mask = ctx.saved_tensors
         N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
         dy = to_nhwc(dy)
-        if act != ACT_NONE:
+        if mask is not None:
+            g = torch.empty_like(y)
+            check(lib.migan_act_bwd_nc(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), N, Ho * Wo, Co, act,
+                                       slope, _stream()), "act_bwd_nc")
+            dy = g
+        elif act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
         dx = dw = db = None
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
@@ -236,8 +249,8 @@ class _Conv2d(Function):
                 nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
                 ws = _ws(nb, xs)
                 check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                             Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1, st),
-                      "conv2d_wgrad")
+                                             Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1,
+                                             st), "conv2d_wgrad")
                 if slot is not None:
                     dw = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -260,11 +273,13 @@ class _Conv2d(Function):
                 check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
                       "gather2d_bwd")
         fork.join()
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0):
-    return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope))
+def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None):
+    """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue."""
+    return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope),
+                         dropout_mask)
 
 
 class _UpConv3x3(Function):
@@ -601,8 +616,8 @@ class _Norm(Function):
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
             check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
-                                       _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb, st),
-                  "norm_stats")
+                                       _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb,
+                                       st), "norm_stats")
         else:
             mean = _plain(running_mean)
             invstd = torch.rsqrt(_plain(running_var) + eps)

@@ -137,15 +137,21 @@ class Conv2d(tnn.Conv2d):
             raise ValueError("Conv2d: string padding is not supported")
         return s[0], _pair(self.padding)
 
-    def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0):
+    def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0, dropout=None):
+        """`dropout`: a following training-mode Dropout2d module whose mask multiply rides in the conv epilogue."""
         stride, (ph, pw) = self._check()
         if gather == F.GATHER_REFLECT and (ph or pw):
             raise ValueError("reflection gather cannot be combined with conv zero padding")
         pads = (pre_pads[0] + ph, pre_pads[1] + pw, pre_pads[2] + ph, pre_pads[3] + pw)
         if (gather == F.GATHER_UP2 and stride == 1 and pads == (1, 1, 1, 1)
                 and tuple(self.weight.shape[2:]) == (3, 3)):
-            return _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope))  # phase-collapsed Upsample+Conv3x3
-        return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope))
+            y = _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope))  # phase-collapsed Upsample+Conv3x3
+            return dropout(y) if dropout is not None else y
+        if dropout is not None and self.out_channels % 4 == 0:
+            mask = _next_mask((x.shape[0], self.out_channels), dropout.p, x.device)
+            return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, mask))
+        y = _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope))
+        return dropout(y) if dropout is not None else y
 
     def forward(self, x):
         return self.fused_forward(x)
@@ -392,7 +398,10 @@ class Sequential(tnn.Sequential):
                 act, slope, k = F.ACT_NONE, 0.0, j + 1
                 if k < n and _act_of(mods[k]) is not None and type(mods[k]) in _OURS:
                     (act, slope), k = _act_of(mods[k]), k + 1
-                x = mods[j].fused_forward(x, pre, gather, act, slope)
+                drop = None
+                if k < n and type(mods[k]) is Dropout2d and mods[k].training and 0.0 < mods[k].p < 1.0 and x.dim() == 4:
+                    drop, k = mods[k], k + 1
+                x = mods[j].fused_forward(x, pre, gather, act, slope, drop)
                 i = k
                 continue
             # -- Norm [LeakyReLU | ReLU] -------------------------------------------------------------------

@@ -464,3 +464,30 @@ def test_direct_grad_accumulation(pg):
             F.set_direct_grad(True)
     for p, a, b in zip(params, results[False], results[True]):
         assert_close(b, a, TOL_WGRAD, "direct grad %s" % (tuple(p.shape),))
+
+
+@pytest.mark.parametrize("cfg", [(4, 1, 16, 16, 16, 2), (3, 16, 10, 10, 32, 2), (2, 32, 9, 9, 64, 1), (2, 64, 8, 8, 4, 1)])
+def test_conv_lrelu_dropout2d_fused(pg, cfg):
+    """Conv2d -> LeakyReLU -> Dropout2d (dcgan.py:77-78) with the mask multiply in the conv epilogue and the
+    act'+mask product in one backward kernel, against torch with the same injected mask."""
+    N, Ci, H, W, Co, stride = cfg
+    nn = pg.nn
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, 3, 3, seed=2, scale=0.3).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True)
+    mask = (torch.rand(N, Co, generator=torch.Generator().manual_seed(5)) > 0.25).float() / 0.75
+    y_ref = TF.leaky_relu(TF.conv2d(x, w, b, stride, 1), 0.2) * mask[:, :, None, None]
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    net = nn.Sequential(nn.Conv2d(Ci, Co, 3, stride, 1), nn.LeakyReLU(0.2, inplace=True), nn.Dropout2d(0.25)).to(DEV)
+    with torch.no_grad():
+        net[0].weight.copy_(w)
+        net[0].bias.copy_(b)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    with pg.dropout_masks([mask]):
+        y = net(xg)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "fused dropout fwd")
+    assert_close(xg.grad, x.grad, TOL_FWD, "fused dropout dgrad")
+    assert_close(net[0].weight.grad, w.grad, TOL_WGRAD, "fused dropout wgrad")
+    assert_close(net[0].bias.grad, b.grad, TOL_WGRAD, "fused dropout bias")
