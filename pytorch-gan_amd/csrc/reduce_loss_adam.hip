@@ -125,6 +125,20 @@ __global__ void loss_partial_kernel(int kind, const float* __restrict__ x, const
     float s = block_sum(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
+// n <= 16384 (the (B,1) validity vectors of dcgan.py:165, PatchGAN maps): one block does the whole mean
+__global__ void loss_small_kernel(int kind, const float* __restrict__ x, const float* __restrict__ t, float tconst,
+                                  float* __restrict__ out, int n) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)loss_term(kind, x[i], t ? t[i] : tconst);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)n);
+}
 // dx = g[0] * scale * dloss/dx
 __global__ void loss_bwd_kernel(int kind, const float* __restrict__ x, const float* __restrict__ t, float tconst,
                                 const float* __restrict__ g, float scale, float* __restrict__ dx, size_t n) {
@@ -135,6 +149,11 @@ MIGAN_API int migan_loss_fwd(int kind, const float* x, const float* t, float tco
                              size_t ws_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n == 0 || ws_bytes < REDUCE_BLOCKS * sizeof(float)) return (int)hipErrorInvalidValue;
+    if (n <= 16384) {
+        hipLaunchKernelGGL(loss_small_kernel, dim3(1), dim3(256), 0, st, kind, x, t, tconst, out, (int)n);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     int blocks = grid_for(n, REDUCE_BLOCKS);
     hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, x, t, tconst, ws, n);
     HIP_LAUNCH_CHECK();

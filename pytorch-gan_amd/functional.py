@@ -144,6 +144,36 @@ def _ws(nbytes, ref):
 
 
 _DIRECT_GRAD = True
+_WEIGHT_CACHE = False
+
+
+def set_weight_cache(enabled):
+    """Re-use the packed (OHWI / IHWO / phase-collapsed) copies of a weight between calls until its optimiser steps.
+
+    Only parameters owned by `pytorch_gan_amd.optim.Adam` take part (it stamps them with an epoch that `step()`
+    advances; `copy_`/`load_state_dict` are caught through the tensor version).  In-place edits through `.data` are
+    NOT visible to the stamp, so this is off by default and switched on by `steps.make_*_state`, whose loop bodies
+    only change weights through the optimiser.  One discriminator is applied three times per DCGAN step with the
+    same weights: its packs are built once instead of three times (and once instead of three times for dgrad)."""
+    global _WEIGHT_CACHE
+    _WEIGHT_CACHE = bool(enabled)
+
+
+def _packed(param, w, kind, make):
+    """`make()` -> packed tensor (or tuple of tensors) of plain weight `w`; cached on the Parameter object `param`."""
+    if not _WEIGHT_CACHE or param is None:
+        return make()
+    ep = getattr(param, "_migan_epoch", None)
+    if ep is None:
+        return make()
+    stamp = (ep, w._version, w.data_ptr())
+    cache = param.__dict__.setdefault("_migan_pack", {})
+    hit = cache.get(kind)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    t = make()
+    cache[kind] = (stamp, t)
+    return t
 
 
 def set_direct_grad(enabled):
@@ -209,7 +239,7 @@ class _Conv2d(Function):
         Ho, Wo = _conv_out(HL, pt, pb, R, stride), _conv_out(WL, pl, pr, S, stride)
         if Ho <= 0 or Wo <= 0:
             raise ValueError("conv2d: empty output")
-        wp = _permute4(w, (0, 2, 3, 1))
+        wp = _packed(w_in, w, "ohwi", lambda: _permute4(w, (0, 2, 3, 1)))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
         if mask is None:
             check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
@@ -257,7 +287,7 @@ class _Conv2d(Function):
                 db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
         st = _stream()
         if ctx.needs_input_grad[0]:
-            wt = _permute4(w, (1, 2, 3, 0))
+            wt = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
             dx = _empty_nhwc((N, Ci, H, W), xs)
             if gather == GATHER_ZERO:
                 check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
@@ -374,7 +404,8 @@ class _ConvTranspose2d(Function):
             raise ValueError("conv_transpose2d: weight expects %d input channels, got %d" % (Cinw, Cin))
         Hout = (Hin - 1) * stride - 2 * pad + R
         Wout = (Win - 1) * stride - 2 * pad + S
-        wp = _permute4(w, (1, 2, 3, 0))  # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
+        # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
+        wp = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
         y = _empty_nhwc((N, Cout, Hout, Wout), xs)
         check(lib.migan_conv2d_dgrad(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
                                      Win, Cin, R, S, stride, pad, pad, act, slope, _stream()), "convT_fwd")
@@ -408,7 +439,8 @@ class _ConvTranspose2d(Function):
                 db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
         st = _stream()
         if ctx.needs_input_grad[0]:
-            wo = _permute4(w, (0, 2, 3, 1))  # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
+            # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
+            wo = _packed(ctx.params[0], w, "ohwi", lambda: _permute4(w, (0, 2, 3, 1)))
             dx = _empty_nhwc((N, Cin, Hin, Win), xs)
             check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
                                        Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")
@@ -598,6 +630,9 @@ class _Norm(Function):
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
                 slope, nbt=None):
         xs = canon(x)
+        # an NCHW-contiguous input (e.g. `out.view(B, 128, s, s)`, dcgan.py:68) gets its gradient back in NCHW through
+        # the HIP transpose, instead of autograd's ViewBackward materialising it with an ATen strided copy
+        ctx.x_nchw = x.dim() == 4 and x.is_contiguous() and not x.is_contiguous(memory_format=CL)
         ctx.params = (gamma, beta)
         gamma, beta = _plain(gamma), _plain(beta)
         if xs.dim() == 4:
@@ -653,6 +688,8 @@ class _Norm(Function):
                                  ws.data_ptr(), nb, acc, _stream()), "norm_bwd")
         if acc:
             dgamma = dbeta = None
+        if ctx.x_nchw:
+            dx = to_nchw(dx)
         return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
 
 

@@ -61,6 +61,8 @@ class Adam:
         self._blk = _to_device_bytes(blk, dev)
         self._nblocks = len(blks)
         self._ptrs = [p.data_ptr() for p in self.params]
+        for p in self.params:
+            p._migan_epoch = 0  # advanced by step(): lets functional.set_weight_cache re-use packed weight copies
 
     def _attach(self):
         for p, o in zip(self.params, self.offsets):
@@ -91,6 +93,8 @@ class Adam:
         check(lib.migan_adam_step(self._tab.data_ptr(), self._blk.data_ptr(), self._nblocks, self.step_t.data_ptr(),
                                   float(g0["lr"]), float(b1), float(b2), float(g0["eps"]), float(grad_scale),
                                   torch.cuda.current_stream().cuda_stream), "adam_step")
+        for p in self.params:
+            p._migan_epoch += 1
 
     def state_dict(self):
         return {"step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),

@@ -52,6 +52,7 @@ def half_sum(a, b):
 # ------------------------------------------------------------------------------------------------ dcgan / gan
 def make_gan_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
     """G, D: swapped modules already on the GPU (dcgan.py:106-116 / gan.py:87-93)."""
+    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            bce=gnn.BCELoss(), latent_dim=latent_dim, skip=skip_dead_grads, labels={},
                            dp=dp or LocalStepper())
@@ -105,6 +106,7 @@ def compute_gradient_penalty(D, real_samples, fake_samples, alpha=None):
 
 
 def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
+    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            latent_dim=latent_dim, lambda_gp=10.0, n_critic=5, skip=skip_dead_grads,
                            dp=dp or LocalStepper())
@@ -175,6 +177,7 @@ class LambdaLR:
 
 
 def make_cyclegan_state(G_AB, G_BA, D_A, D_B, skip_dead_grads=True, dp=None):
+    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(
         G_AB=G_AB, G_BA=G_BA, D_A=D_A, D_B=D_B,
         opt_G=Adam(itertools.chain(G_AB.parameters(), G_BA.parameters()), **ADAM),
@@ -221,6 +224,7 @@ def cyclegan_step(s, real_A, real_B):
 
 # ------------------------------------------------------------------------------------------------ pix2pix
 def make_pix2pix_state(G, D, img_size=256, skip_dead_grads=True, dp=None):
+    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            mse=gnn.MSELoss(), l1=gnn.L1Loss(), lambda_pixel=100.0,
                            patch=(1, img_size // 16, img_size // 16), skip=skip_dead_grads, labels={},
@@ -251,6 +255,7 @@ def pix2pix_step(s, real_A, real_B):
 # ------------------------------------------------------------------------------------------------ srgan
 def make_srgan_state(G, D, V, skip_dead_grads=True, dp=None):
     V.eval()
+    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, V=V, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            mse=gnn.MSELoss(), l1=gnn.L1Loss(), skip=skip_dead_grads, labels={},
                            dp=dp or LocalStepper())

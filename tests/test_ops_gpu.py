@@ -165,15 +165,17 @@ def test_linear_lrelu_double_backward(pg):
     assert ps_g[1].grad is None or float(ps_g[1].grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", [(8, 128, 16, 16, 0.8, 1), (8, 64, 8, 8, 1e-5, 0), (4, 32, 5, 3, 0.8, 2), (16, 10, 4, 4, 1e-5, 1)])
+# the last two are HBM-sized (> 2^21 elements, 1024 statistic chunks)
+@pytest.mark.parametrize("cfg", [(8, 128, 16, 16, 0.8, 1), (8, 64, 8, 8, 1e-5, 0), (4, 32, 5, 3, 0.8, 2), (16, 10, 4, 4, 1e-5, 1),
+                                 (8, 64, 72, 72, 1e-5, 0), (6, 10, 200, 190, 0.8, 0)])  # big ones without activation (kink flips)
 def test_batchnorm2d_train(pg, cfg):
     N, C, H, W, eps, act = cfg
     F = pg.functional
     x = (_leaf(N, C, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
     gamma, beta = (_leaf(C, seed=2) + 1.5).requires_grad_(True), _leaf(C, seed=3).requires_grad_(True)
     rm, rv = torch.zeros(C), torch.ones(C)
-    y_ref = TF.batch_norm(x, rm, rv, gamma, beta, True, 0.1, eps)
-    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y_ref)
+    z_ref = TF.batch_norm(x, rm, rv, gamma, beta, True, 0.1, eps)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](z_ref)
     gy = _leaf(N, C, H, W, seed=4)
     y_ref.backward(gy)
     xg, gg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
@@ -181,7 +183,11 @@ def test_batchnorm2d_train(pg, cfg):
     y = F.norm(xg, gg, bg, None, rmg, rvg, True, 0.1, eps, False, act, 0.2)
     y.backward(gy.to(DEV))
     assert_close(y, y_ref, TOL_FWD, "bn fwd")
-    assert_close(xg.grad, x.grad, 2e-5, "bn dx")
+    # The fused activation derivative is taken from the recomputed pre-activation; an element within rounding of the
+    # kink may land on the other side than torch's stored output (1 of 2.6M elements moves rel_fro by 4e-4), so such
+    # elements are excluded from the dx comparison.
+    keep = (z_ref.detach().abs() > 1e-5).float()
+    assert_close(xg.grad.cpu() * keep, x.grad * keep, 2e-5, "bn dx")
     assert_close(gg.grad, gamma.grad, TOL_WGRAD, "bn dgamma")
     assert_close(bg.grad, beta.grad, TOL_WGRAD, "bn dbeta")
     assert_close(rmg, rm, TOL_WGRAD, "running_mean")
@@ -206,13 +212,14 @@ def test_batchnorm1d_and_eval(pg):
     assert_close(y_eval, TF.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 0.8), TOL_FWD, "bn eval")
 
 
-@pytest.mark.parametrize("cfg", [(2, 256, 16, 16, 2), (2, 64, 9, 7, 1), (1, 512, 2, 2, 0), (3, 128, 1, 2, 0)])
+@pytest.mark.parametrize("cfg", [(2, 256, 16, 16, 2), (2, 64, 9, 7, 1), (1, 512, 2, 2, 0), (3, 128, 1, 2, 0),
+                                 (2, 64, 160, 128, 2)])  # last: HBM-sized
 def test_instancenorm(pg, cfg):
     N, C, H, W, act = cfg
     F = pg.functional
     x = (_leaf(N, C, H, W, seed=1) * 3 + 0.5).requires_grad_(True)
-    y_ref = TF.instance_norm(x, eps=1e-5)
-    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y_ref)
+    z_ref = TF.instance_norm(x, eps=1e-5)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](z_ref)
     gy = _leaf(N, C, H, W, seed=2)
     y_ref.backward(gy)
     xg = x.detach().to(DEV).requires_grad_(True)
@@ -220,7 +227,8 @@ def test_instancenorm(pg, cfg):
     y.backward(gy.to(DEV))
     assert_close(y, y_ref, TOL_FWD, "in fwd")
     if H * W > 1:
-        assert_close(xg.grad, x.grad, 5e-5, "in dx")
+        keep = (z_ref.detach().abs() > 1e-5).float()  # pre-activations at the kink: see test_batchnorm2d_train
+        assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "in dx")
 
 
 def test_norm_residual(pg):
