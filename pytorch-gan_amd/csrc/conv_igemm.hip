@@ -1597,8 +1597,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
 // dependency), the gather is branch-free and the loads of K-tile kt+1 are issued one per k-pair inside the MFMA
 // stream of tile kt (see igemm_pipe_kernel).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int ABL = 0, bool DYS = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void wgrad_pipe_kernel(
+template <int BM, int BN, int ABL = 0, bool DYS = false, int OCC = 4>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_kernel(
     const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
     constexpr int BK = 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -1992,6 +1992,10 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
     if (bm == 128) {
         g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
+        if (wgrad_var() == 33)  // A/B knob: 3 workgroups/CU (168 VGPRs, no spill) instead of 4 (128 VGPRs, 4 spilled)
+            hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true, 3>), dim3(g.tiles_m * g.tiles_n * g.splits, 4),
+                               dim3(256), 0, st, g, x, dy, ws);
+        else
         hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
                            0, st, g, x, dy, ws);
     } else if (wgrad_bn(Co, Ncol) == 128) {
@@ -2321,6 +2325,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
             else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
             else if (wvar == 3) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
+            else if (wvar == 33) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, false, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
             else
             hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
         } else if (wgrad_bn(Co, Ncol) == 128) {
