@@ -113,7 +113,9 @@ class ConvProfiler:
 
         def up_wgrad(a):
             N, H, W, Ci, Co = a[5:10]
-            return ("upconv_wgrad_%d" % (128 if (Co > 64 and 4 * Ci > 64) else 64), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            bm = 128 if (Co > 64 and 4 * Ci > 64) else 64          # wgrad_plan / wgrad_bn of conv_igemm.hip
+            bn = 128 if (bm == 128 or (Co > 32 and 4 * Ci >= 128)) else 64
+            return ("upconv_wgrad_%dx%d" % (bm, bn), 2.0 * N * 4 * H * W * Co * Ci * 9)
 
         self._wrap("migan_conv2d_fwd", fwd)
         self._wrap("migan_conv2d_dgrad", dgrad)
@@ -137,6 +139,35 @@ class ConvProfiler:
             d["ms"] += ms
             d["flops"] += flops
         return agg
+
+
+def kernel_symbol(name):
+    """Device kernel symbol (as rocprofv3 prints it) behind a ConvProfiler group name."""
+    tiles = {"1128128": "128, 128, 2, 2", "1128064": "128, 64, 2, 2", "1064064": "64, 64, 2, 2",
+             "1128032": "128, 32, 4, 1"}
+    if name.startswith("upconv_wgrad_"):
+        bm, bn = name[len("upconv_wgrad_"):].split("x")
+        return "wgrad_pipe_kernel<%s, %s, 0, true, 4>" % (bm, bn)
+    for code, t in tiles.items():
+        if name.endswith("igemm_" + code):
+            return "igemm_pipe_kernel<%s, false>" % t
+    return name
+
+
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE); None when that kernel was not
+    profiled.  The PMC passes cannot run inside bench.py (counter collection serialises the graph)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    ent = tab.get(symbol)
+    if not ent:
+        return None, None
+    return ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (%s)" % ent.get("source", "rocprofv3 --pmc")
 
 
 def cpu_baseline(init, seconds_budget=25.0):
@@ -262,9 +293,15 @@ def main():
             d = agg[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             collapsed = dom.startswith("upconv")
+            symbol = kernel_symbol(dom)
+            traffic, traffic_src = pmc_traffic(symbol)
             result["roofline"] = {
-                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "bound": "mfma", "kernel": dom, "symbol": symbol, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "note": ("achieved = the reference's dense FLOPs per launch / measured launch time (SURVEY 8d); the "
+                         "phase-collapsed Upsample+Conv3x3 kernels execute 16/36 of those FLOPs, so frac can exceed 1 "
+                         "while executed_frac is the matrix-pipe utilisation; a wgrad launch = main kernel + split-K "
+                         "reduction") if collapsed else "achieved = dense 2*M*N*K of the layer / measured launch time",
                 # `achieved` counts the reference's dense FLOPs (Upsample x2 -> Conv3x3 on the upsampled grid); the
                 # phase-collapsed kernels execute 16/36 of them, so `executed` is the matrix-pipe rate actually sustained
                 "executed": round(ach * (16.0 / 36.0 if collapsed else 1.0), 2),

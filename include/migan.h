@@ -69,7 +69,14 @@ int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls);
 size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci);
 int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi,
                        int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
-                       int gather, int accumulate, void* stream);
+                       int gather, int accumulate, float* db, int db_accumulate, void* stream);
+/* db != NULL: the bias gradient db[Co] = sum over pixels of dy (aten::convolution_backward grad_bias / the sum in
+ * AddmmBackward) is produced by the same launches - the column-tile-0 workgroups sum their dy tiles, which are already
+ * in LDS as the A operand, and the reduction launch adds the per-split slabs - instead of by a separate two-launch
+ * column sum that re-reads dy from HBM.  Only where migan_conv2d_wgrad_fuses_bias() returns 1 (MFMA path).  On MI355X
+ * this measured no faster than migan_colsum (the column-0 workgroups become the tail of the launch), so the host
+ * mirror passes NULL unless MIGAN_FUSE_BIAS=1. */
+int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int gather);
 
 /* Phase-collapsed nn.Upsample(scale_factor=2) -> nn.Conv2d(Ci, Co, 3, stride=1, padding=1)
  * (dcgan.py:54-55,58-59; cyclegan/models.py:74-75): the 4 output phases are 2x2 convs of the un-upsampled input with
@@ -84,7 +91,7 @@ int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx, int N, in
                           void* stream);
 size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci);
 int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H,
-                          int W, int Ci, int Co, int accumulate, void* stream);
+                          int W, int Ci, int Co, int accumulate, float* db, int db_accumulate, void* stream);
 
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:

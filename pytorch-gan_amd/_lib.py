@@ -59,12 +59,13 @@ _SIGS = {
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
-    "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P]),
+    "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P]),
+    "migan_conv2d_wgrad_fuses_bias": (c_int, [c_int] * 6),
     "migan_upconv3x3_pack": (c_int, [P, P, P, c_int, c_int, P]),
     "migan_upconv3x3_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "migan_upconv3x3_dgrad": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "migan_upconv3x3_wgrad_workspace": (c_size_t, [c_int] * 5),
-    "migan_upconv3x3_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 6 + [P]),
+    "migan_upconv3x3_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 6 + [P, c_int, P]),
     "migan_norm_workspace": (c_size_t, [c_int] * 3),
     "migan_norm_stats": (c_int, [P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, P, c_size_t, P]),
     "migan_norm_apply": (c_int, [P] * 7 + [c_int] * 4 + [c_float, P]),

@@ -1393,6 +1393,12 @@ struct WgradGeom {
     // dy may be a strided sub-grid of a larger gradient tensor (phase classes of the collapsed Upsample+Conv):
     // pixel (n, oi, oj) of this GEMM lives at dy[n][dy_oh0 + oi*dy_step][dy_ow0 + oj*dy_step]
     int dy_H, dy_W, dy_oh0, dy_ow0, dy_step;
+    // optional fused bias gradient: the blocks of column-tile 0 also sum their dy tiles over pixels (the A operand is
+    // already in LDS) into bpart[cls*splits + split][Co]; the reduction launch adds the slabs.  NULL: not requested.
+    // Measured on MI355X: no faster than the separate column-sum launches (the column-0 blocks become the critical
+    // path of a one-wave launch; spreading the rows over all column tiles costs every block more than it saves), so
+    // the host mirror leaves it off by default (MIGAN_FUSE_BIAS=1 enables it).
+    float* bpart;
 };
 
 // q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
@@ -1720,6 +1726,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
     const float* ap = As + h * LDA + wm * (TM * 32) + l31;
     const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
+    float bsum = 0.f;
     for (int kt = 0; kt < KT; ++kt) {
         if ((ABL & 2) == 0 || kt == 0) {
         __syncthreads();
@@ -1730,6 +1738,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
         for (int j = 0; j < NB; ++j)
             *reinterpret_cast<f32x4*>(Bs + (plB + j * (256 / QB)) * LDB + qb * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
         __syncthreads();
+        }
+        if (bias_blk && tid < BM) {  // column sums of the (masked) dy tile: conflict-free, consecutive lanes = consecutive co
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) s_ += As[k * LDA + tid];
+            bsum += s_;
         }
         f_pt0 = p_begin + (kt + 1 < KT ? kt + 1 : kt) * BK;
 #pragma unroll
@@ -1761,6 +1775,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
         }
     }
 #undef WGRAD_ISSUE
+    if (bias_blk && tid < BM && co0 + tid < g.Co)
+        g.bpart[((size_t)cls * g.splits + split) * g.Co + co0 + tid] = bsum;
     float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1780,11 +1796,30 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
 // Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
 // `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
 // split loop (LDS combine in fixed order) when there are many splits and few outputs.
+// bias slabs [nslab][Co] -> db[co] (fixed order, double accumulation); run by the trailing blocks of the reduce launches
+__device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bpart, float* __restrict__ db, int nslab,
+                                                 int Co, int accum, int blk) {
+    const int co = blk * 256 + threadIdx.x;
+    if (co >= Co) return;
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += (double)bpart[(size_t)k * Co + co];
+    db[co] = accum ? db[co] + (float)s : (float)s;
+}
+struct BiasRed {
+    const float* bpart;  // NULL: no bias work
+    float* db;
+    int nslab, accum, main_blocks;
+};
 template <int GROUPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int splits, int Co, int T, int Ci, int accum) {
+                                                           int splits, int Co, int T, int Ci, int accum,
+                                                           const BiasRed br) {
     constexpr int OUTS = 256 / GROUPS;
     __shared__ float red[256];
+    if ((int)blockIdx.x >= br.main_blocks) {  // block-uniform
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x - br.main_blocks);
+        return;
+    }
     const size_t total = (size_t)Co * T * Ci;
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
     const size_t src = (size_t)blockIdx.x * OUTS + lo;
@@ -1809,17 +1844,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, int accum,
-                               hipStream_t st) {
+                               hipStream_t st, BiasRed br = BiasRed{}) {
     long total = (long)Co * T * Ci;
-    if (splits >= 64 && total < (1 << 16))
-        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(cdiv(total, 16)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
-                           accum);
-    else if (splits >= 16 && total < (1 << 20))
-        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(cdiv(total, 64)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
-                           accum);
-    else
-        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(cdiv(total, 256)), dim3(256), 0, st, ws, dw, splits, Co, T, Ci,
-                           accum);
+    const int extra = br.bpart ? cdiv(Co, 256) : 0;
+    if (splits >= 64 && total < (1 << 16)) {
+        br.main_blocks = cdiv(total, 16);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+                           T, Ci, accum, br);
+    } else if (splits >= 16 && total < (1 << 20)) {
+        br.main_blocks = cdiv(total, 64);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+                           T, Ci, accum, br);
+    } else {
+        br.main_blocks = cdiv(total, 256);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+                           T, Ci, accum, br);
+    }
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1936,9 +1976,13 @@ MIGAN_API int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx,
 // 4 split-lanes per output (fixed-order LDS combine -> deterministic); reads coalesced along ci.
 __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                   float* __restrict__ dw, int splits, int Co, int Ci,
-                                                                  int accum) {
+                                                                  int accum, const BiasRed br) {
     constexpr int GROUPS = 4, OUTS = 256 / GROUPS;
     __shared__ float red[256];
+    if ((int)blockIdx.x >= br.main_blocks) {  // block-uniform: trailing blocks reduce the bias slabs
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x - br.main_blocks);
+        return;
+    }
     const size_t slab = (size_t)Co * 4 * Ci;  // one (class, split) slab
     const size_t total = (size_t)Co * Ci * 9;
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
@@ -1971,14 +2015,15 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
 MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4);
-    return (size_t)4 * splits * Co * 4 * Ci * sizeof(float);
+    return ((size_t)4 * splits * Co * 4 * Ci + (size_t)4 * splits * Co) * sizeof(float);  // partials + bias slabs
 }
 
 // dw_oihw[Co][Ci][3][3] from x[N][H][W][Ci] and dy[N][2H][2W][Co]   (requires Co % 4 == 0 and Ci % 4 == 0)
 // ONE launch covers the 4 phase classes (grid.y), so the split-K factor - and with it the partial-sum traffic of the
 // un-collapsing reduction - is 4x smaller than with one launch per phase.
 MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
-                                    int N, int H, int W, int Ci, int Co, int accumulate, void* stream) {
+                                    int N, int H, int W, int Ci, int Co, int accumulate, float* db, int db_accumulate,
+                                    void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (Co % 4 != 0 || Ci % 4 != 0) return (int)hipErrorInvalidValue;
     if (ws_bytes < migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)) return (int)hipErrorInvalidValue;
@@ -1990,6 +2035,8 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     fastdiv_magic((unsigned)(H * W), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)W, g.mg_w, g.sh_w);
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
+    float* bpart = ws + (size_t)4 * g.splits * Co * Ncol;
+    g.bpart = db ? bpart : nullptr;
     if (bm == 128) {
         g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
         if (wgrad_var() == 33)  // A/B knob: 3 workgroups/CU (168 VGPRs, no spill) instead of 4 (128 VGPRs, 4 spilled)
@@ -2009,8 +2056,9 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     }
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
-    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(cdiv((long)total, 64)), dim3(256), 0, st, ws, dw_oihw, g.splits,
-                       Co, Ci, accumulate);
+    BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64)};
+    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + (db ? cdiv(Co, 256) : 0)), dim3(256), 0, st, ws,
+                       dw_oihw, g.splits, Co, Ci, accumulate, br);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -2267,13 +2315,22 @@ MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int
     wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);
     size_t nsplit = (size_t)splits;
     if (Co <= 4 && nsplit < THIN_CHUNKS) nsplit = THIN_CHUNKS;  // upper bound of the thin paths' slab counts
-    return nsplit * Co * R * S * Ci * sizeof(float);
+    return (nsplit * Co * R * S * Ci + nsplit * Co) * sizeof(float);  // partials + bias slabs
+}
+
+// 1 when migan_conv2d_wgrad computes the bias gradient (column sums of dy) inside the wgrad launch for this geometry
+// (the MFMA path with 16-byte channel vectors); 0: the caller runs migan_colsum for it.
+MIGAN_API int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int gather) {
+    if (thin_wgrad_ok(Co, R, S, Ci, stride, gather) || Co <= 4) return 0;
+    return (Ci % 4 == 0 && Co % 4 == 0 && wgrad_var() != 100) ? 1 : 0;
 }
 
 MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                 int stride, int pad_t, int pad_l, int gather, int accumulate, void* stream) {
+                                 int stride, int pad_t, int pad_l, int gather, int accumulate, float* db,
+                                 int db_accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (db && !migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather)) return (int)hipErrorInvalidValue;
     if (thin_wgrad_ok(Co, R, S, Ci, stride, gather)) {
         ThinGeom tg = {N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, 0, 0, 0};
         thin_plan(N, Hi, Wi, Ci, tg);
@@ -2312,8 +2369,9 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     g.pad_t = pad_t; g.pad_l = pad_l; g.gather = gather;
     int Ncol = R * S * Ci, bm;
     wgrad_plan(N, Ho, Wo, Co, Ncol, bm, g.splits, g.pix_per_split);
-    if ((size_t)g.splits * Co * Ncol * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
+    if (((size_t)g.splits * Co * Ncol + (size_t)g.splits * Co) * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
     bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
+    g.bpart = db ? ws + (size_t)g.splits * Co * Ncol : nullptr;
     fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
     const int wvar = wgrad_var();  // 100 = old kernel
@@ -2338,7 +2396,8 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64>), grid, dim3(256), 0, st, g, x, dy, ws);
         }
         HIP_LAUNCH_CHECK();
-        return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st);
+        return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st,
+                                   BiasRed{g.bpart, db, g.splits, db_accumulate, 0});
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);

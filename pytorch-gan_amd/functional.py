@@ -145,6 +145,17 @@ def _ws(nbytes, ref):
 
 _DIRECT_GRAD = True
 _WEIGHT_CACHE = False
+# bias gradient inside the wgrad launches (include/migan.h): measured no faster than the column-sum launches -> opt-in
+_FUSE_BIAS = __import__("os").environ.get("MIGAN_FUSE_BIAS", "0") == "1"
+
+
+def _bias_out(param, C, ref):
+    """(buffer, accumulate flag, value to return to autograd) for a bias gradient produced by a wgrad launch."""
+    slot = _grad_slot(param)
+    if slot is not None:
+        return slot, 1, None
+    t = torch.empty(C, device=ref.device, dtype=torch.float32)
+    return t, 0, t
 
 
 def set_weight_cache(enabled):
@@ -270,6 +281,7 @@ class _Conv2d(Function):
         elif act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()
@@ -278,12 +290,16 @@ class _Conv2d(Function):
                 dw = torch.empty_like(w) if slot is None else slot
                 nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
                 ws = _ws(nb, xs)
+                dbp, dba = None, 0
+                if want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather):
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                    dbp, want_db = dbt.data_ptr(), False
                 check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
                                              Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1,
-                                             st), "conv2d_wgrad")
+                                             dbp, dba, st), "conv2d_wgrad")
                 if slot is not None:
                     dw = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:
                 db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
         st = _stream()
         if ctx.needs_input_grad[0]:
@@ -345,6 +361,7 @@ class _UpConv3x3(Function):
         if act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()
@@ -355,16 +372,21 @@ class _UpConv3x3(Function):
                 if Co % 4 == 0 and Ci % 4 == 0:
                     nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
                     ws = _ws(nb, xs)
+                    dbp, dba = None, 0
+                    if want_db and _FUSE_BIAS:
+                        dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                        dbp, want_db = dbt.data_ptr(), False
                     check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
-                                                    W, Ci, Co, acc, st), "upconv_wgrad")
+                                                    W, Ci, Co, acc, dbp, dba, st), "upconv_wgrad")
                 else:  # same gradient through the dense gathered wgrad
                     nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
                     ws = _ws(nb, xs)
                     check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
-                                                 Ci, 2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, st), "conv2d_wgrad")
+                                                 Ci, 2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, None, 0, st),
+                          "conv2d_wgrad")
                 if slot is not None:
                     dw = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:
                 db = _colsum(dy, N * 4 * H * W, Co, _grad_slot(ctx.params[1]))
         if ctx.needs_input_grad[0]:
             dx = _empty_nhwc((N, Ci, H, W), xs)
@@ -432,7 +454,7 @@ class _ConvTranspose2d(Function):
                 ws = _ws(nb, xs)
                 check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout,
                                              Wout, Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO,
-                                             0 if slot is None else 1, st), "convT_wgrad")
+                                             0 if slot is None else 1, None, 0, st), "convT_wgrad")
                 if slot is not None:
                     dw = None
             if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -496,13 +518,19 @@ class _MMNT(Function):
         fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel())
         gc, ac = canon(g), canon(a)  # on the main stream: both branches read them
         with fork:
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 slot = _grad_slot(b)
                 if slot is not None:  # first-order backward of a Linear weight: reduce straight into weight.grad
-                    _mm_tn_raw(gc, ac, slot, 1)
+                    dbuf = None
+                    if want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(gc.shape[1], 1, 1, ac.shape[1], 1,
+                                                                                   GATHER_ZERO):
+                        dbt, dba, dbias = _bias_out(ctx.bias_param, gc.shape[1], gc)
+                        dbuf, want_db = (dbt, dba), False
+                    _mm_tn_raw(gc, ac, slot, 1, dbuf)
                 else:
                     db = _MMTN.apply(g, a)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:
                 dbias = _colsum(gc, gc.shape[0], gc.shape[1], _grad_slot(ctx.bias_param))
         if ctx.needs_input_grad[0]:
             da = mm_nn(g, b)
@@ -510,7 +538,8 @@ class _MMNT(Function):
         return da, db, dbias
 
 
-def _mm_tn_raw(a, b, out=None, accumulate=0):
+def _mm_tn_raw(a, b, out=None, accumulate=0, dbuf=None):
+    """a[P,M]^T @ b[P,N] -> out[M,N]; dbuf = (tensor[M], accumulate): also the column sums of `a` (a Linear's bias grad)."""
     P, M = a.shape
     Pb, Nn = b.shape
     if P != Pb:
@@ -520,7 +549,8 @@ def _mm_tn_raw(a, b, out=None, accumulate=0):
     nb = lib.migan_conv2d_wgrad_workspace(P, 1, 1, M, 1, 1, Nn)
     ws = _ws(nb, a)
     check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
-                                 M, 1, 1, 1, 0, 0, GATHER_ZERO, accumulate, _stream()), "mm_tn")
+                                 M, 1, 1, 1, 0, 0, GATHER_ZERO, accumulate, dbuf[0].data_ptr() if dbuf else None,
+                                 dbuf[1] if dbuf else 0, _stream()), "mm_tn")
     return out
 
 

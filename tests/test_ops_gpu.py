@@ -499,3 +499,30 @@ def test_conv_lrelu_dropout2d_fused(pg, cfg):
     assert_close(xg.grad, x.grad, TOL_FWD, "fused dropout dgrad")
     assert_close(net[0].weight.grad, w.grad, TOL_WGRAD, "fused dropout wgrad")
     assert_close(net[0].bias.grad, b.grad, TOL_WGRAD, "fused dropout bias")
+
+
+def test_bias_grad_fused_into_wgrad(pg):
+    """Opt-in path (MIGAN_FUSE_BIAS=1): the bias gradient comes out of the wgrad launches (db argument of
+    migan_conv2d_wgrad / migan_upconv3x3_wgrad) instead of migan_colsum; same values, with and without .grad slots."""
+    F, nn = pg.functional, pg.nn
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(8, 16, 3, 2, 1), nn.ReLU(), nn.Upsample(scale_factor=2),
+                        nn.Conv2d(16, 12, 3, stride=1, padding=1)).to(DEV)
+    lin = nn.Linear(12 * 8 * 8, 8).to(DEV)
+    params = list(net.parameters()) + list(lin.parameters())
+    x = _leaf(5, 8, 8, 8, seed=1).to(DEV)
+    res = {}
+    for fused in (False, True):
+        for slots in (False, True):
+            F._FUSE_BIAS = fused
+            try:
+                for p in params:
+                    p.grad = torch.full_like(p, 0.5) if slots else None
+                out = lin(net(x).reshape(5, -1))
+                (out * out).mean().backward()
+                res[(fused, slots)] = [p.grad.detach().clone() for p in params]
+            finally:
+                F._FUSE_BIAS = False
+    for slots in (False, True):
+        for p, a, b in zip(params, res[(False, slots)], res[(True, slots)]):
+            assert_close(b, a, TOL_WGRAD, "fused bias %s slots=%s" % (tuple(p.shape), slots))

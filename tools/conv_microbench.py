@@ -89,7 +89,7 @@ def main():
             "dgrad": lambda: lib.migan_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
                                                     Wo, Co, k, k, s, pd, pd, 0, 0.0, st),
             "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
-                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, st),
+                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, None, 0, st),
         }
         dirs = ["fwd", "dgrad", "wgrad"]
         if gth == 2 and k == 3 and s == 1 and p == 1 and Co % 4 == 0 and Ci % 4 == 0:
@@ -105,7 +105,7 @@ def main():
             calls["udgrad"] = lambda: lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dxs.data_ptr(), N, H, W,
                                                                 Ci, Co, st)
             calls["uwgrad"] = lambda: lib.migan_upconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                                                wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, st)
+                                                                wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, None, 0, st)
             dirs += ["ufwd", "udgrad", "uwgrad"]
         for d in dirs:
             if d.lstrip("u") not in only:
