@@ -38,6 +38,16 @@ struct ConvGeom {
     signed char dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
+// q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
+static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
+    s = 0;
+    while ((1ull << s) < d) ++s;
+    m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+__device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
+    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, int VAR = 0>
 __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
                                                     const float* __restrict__ Bw,
@@ -868,6 +878,8 @@ MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls
 struct ThinConv {
     int TH, TW, CC, logQ;        // output tile (TH*TW == 256), channel chunk, log2(CC/4)
     int SH, SW;                  // staged window extent (logical source coordinates)
+    unsigned mgSW;               // fastdiv magic for / SW
+    int shSW;
     int dhmin[MAX_CLS], dwmin[MAX_CLS];
     int tiles_w[MAX_CLS], tiles[MAX_CLS];
 };
@@ -896,17 +908,29 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const 
 
     for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
         __syncthreads();
-        for (int sr = 0; sr < tc.SH; ++sr) {
-            int ihs;
-            const bool rok = map_coord(vh0 + sr, g.HiL, g.gather, ihs);
-            for (int i = tid; i < tc.SW * Q; i += 256) {
-                const int sc = i >> tc.logQ, q = i & (Q - 1);
-                int iws;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (rok && map_coord(vw0 + sc, g.WiL, g.gather, iws))
-                    v = *reinterpret_cast<const f32x4*>(Ab + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + q * 4);
-                *reinterpret_cast<f32x4*>(win + (size_t)(sr * tc.SW + sc) * LDC + q * 4) = v;
+        // stage the window: flattened over (window pixel, channel quad), 4 independent branch-free loads per thread
+        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load)
+        const int total = tc.SH * tc.SW * Q;
+        for (int base = 0; base < total; base += 1024) {
+            f32x4 v[4];
+            int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + u * 256 + tid;
+                const bool in = e < total;
+                const int ec = in ? e : total - 1;
+                const int q = ec & (Q - 1), pidx = ec >> tc.logQ;
+                const int sr = fastdiv(pidx, tc.mgSW, tc.shSW), sc = pidx - sr * tc.SW;
+                int ihs, iws;
+                bool ok = map_bf(vh0 + sr, g.HiL, g.Hi, g.gather, ihs);
+                ok &= map_bf(vw0 + sc, g.WiL, g.Wi, g.gather, iws);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(Ab + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + q * 4);
+                v[u] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
+                off[u] = in ? pidx * LDC + q * 4 : -1;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (off[u] >= 0) *reinterpret_cast<f32x4*>(win + off[u]) = v[u];
         }
         __syncthreads();
         if (valid) {
@@ -967,6 +991,7 @@ static bool thin_conv_plan(const ConvGeom& g, ThinConv& tc, size_t& lds_bytes, i
     }
     tc.SH = (tc.TH - 1) * g.istride + ehmax + 1;
     tc.SW = (tc.TW - 1) * g.istride + ewmax + 1;
+    fastdiv_magic((unsigned)tc.SW, tc.mgSW, tc.shSW);
     // largest power-of-two channel chunk (>= 8 channels) dividing Ci whose window fits in 64 KB of LDS
     int cc = 8;
     for (int cand = 16; cand <= 256; cand <<= 1)
@@ -1001,6 +1026,8 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
 // ------------------------------------------------------------------------------------------------
 struct SmallK {
     int dh[16], dw[16], c[16], wofs[16];  // flattened k = (tap, channel) -> tap offset, source channel, weight offset
+    unsigned mg_hw, mg_w;                 // fastdiv magics for / (Ho*Wo) and / Wo
+    int sh_hw, sh_w;
 };
 // thread = (pixel, 4 output channels); K and the whole gather are compile-time unrolled and branch-free, so the K
 // source loads of a pixel are in flight together.  FIXED: the thread count is a multiple of Co/4, so a thread keeps
@@ -1067,7 +1094,8 @@ template <int K>
 __global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, const SmallK sk,
                                                           const float* __restrict__ A, const float* __restrict__ Bw,
                                                           const float* __restrict__ bias, float* __restrict__ C) {
-    constexpr int PB = 64;
+    constexpr int PB = 128;                       // output pixels per tile
+    constexpr int IT = (PB * K + 255) / 256;      // gathered values per thread per tile
     __shared__ float a_s[PB * K];
     __shared__ int s_dh[K], s_dw[K], s_c[K];
     if (threadIdx.x < K) {
@@ -1094,21 +1122,30 @@ __global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, cons
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * PB;
         __syncthreads();
-        for (int idx = tid; idx < PB * K; idx += 256) {
-            const int p = idx / K, k = idx - p * K;
-            const int m = m0 + p;
-            float v = 0.f;
-            if (m < M) {
-                const int n = m / (Ho * Wo);
+        {   // gather: IT independent branch-free loads per thread (clamped coordinates, validity folded into the value)
+            float v[IT];
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const int idx = tid + u * 256;
+                const int ic = idx < PB * K ? idx : PB * K - 1;
+                const int p = ic / K, k = ic - p * K;
+                int m = m0 + p;
+                const bool in = m < M;
+                m = in ? m : M - 1;
+                const int n = fastdiv(m, sk.mg_hw, sk.sh_hw);
                 const int rem = m - n * Ho * Wo;
-                const int oi = rem / Wo, oj = rem - oi * Wo;
+                const int oi = fastdiv(rem, sk.mg_w, sk.sh_w), oj = rem - oi * Wo;
                 int ihs, iws;
                 bool ok = map_bf(oi * g.istride + s_dh[k], g.HiL, g.Hi, g.gather, ihs);
                 ok &= map_bf(oj * g.istride + s_dw[k], g.WiL, g.Wi, g.gather, iws);
                 const float t = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + s_c[k]];
-                v = ok ? t : 0.f;
+                v[u] = (ok && in) ? t : 0.f;
             }
-            a_s[idx] = v;
+#pragma unroll
+            for (int u = 0; u < IT; ++u) {
+                const int idx = tid + u * 256;
+                if (idx < PB * K) a_s[idx] = v[u];
+            }
         }
         __syncthreads();
         for (int p = pl; p < PB; p += rows) {
@@ -1122,17 +1159,19 @@ __global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, cons
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[k][e], acc[e]);
             }
             size_t opix = (size_t)m;
-            if (!linear_out) {
-                const int n = m / (Ho * Wo);
+            int n = 0;
+            if (!linear_out || g.oscale) {
+                n = fastdiv(m, sk.mg_hw, sk.sh_hw);
                 const int rem = m - n * Ho * Wo;
-                const int oi = rem / Wo, oj = rem - oi * Wo;
-                opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
+                const int oi = fastdiv(rem, sk.mg_w, sk.sh_w), oj = rem - oi * Wo;
+                if (!linear_out)
+                    opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
             }
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
             if (g.oscale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)(m / (Ho * Wo)) * g.Co + co);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * g.Co + co);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] *= sc[e];
             }
@@ -1153,7 +1192,7 @@ static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, cons
     long blocks = cdiv(maxM * cq_n, 256L);
     if (blocks > 8192) blocks = 8192;
     if (256 % cq_n == 0) {
-        long tiles = cdiv(maxM, 64L);
+        long tiles = cdiv(maxM, 128L);
         if (tiles > 8192) tiles = 8192;
         hipLaunchKernelGGL((smallk_tile_kernel<K>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
     } else
@@ -1172,6 +1211,8 @@ static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const flo
             sk.c[k] = c;
             sk.wofs[k] = g.wofs[g.tapbeg[0] + t] + c;
         }
+    fastdiv_magic((unsigned)(g.Ho[0] * g.Wo[0]), sk.mg_hw, sk.sh_hw);
+    fastdiv_magic((unsigned)g.Wo[0], sk.mg_w, sk.sh_w);
 #define SMALLK_CASE(K_) case K_: launch_smallk_k<K_>(g, sk, maxM, A, Bw, bias, C, st); break;
     switch (K) {
         SMALLK_CASE(1) SMALLK_CASE(2) SMALLK_CASE(3) SMALLK_CASE(4) SMALLK_CASE(5) SMALLK_CASE(6) SMALLK_CASE(7)
@@ -1401,15 +1442,6 @@ struct WgradGeom {
     float* bpart;
 };
 
-// q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
-static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
-    s = 0;
-    while ((1ull << s) < d) ++s;
-    m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
-}
-__device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
-    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
-}
 
 template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const float* __restrict__ X,
@@ -2104,23 +2136,25 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const
                 if (++ih >= g.Hi) { ih = 0; ++n; }
             }
             f32x4 xv = *reinterpret_cast<const f32x4*>(X + (size_t)q * g.Ci + c);
+            // branch-free taps: clamped coordinates, unconditional (wave-broadcast) loads, validity folded into the
+            // value - all T*CO loads of a pixel are in flight together instead of one latency per tap
+            float dv[NACC];
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                {
-                    constexpr int dummy = 0;
-                    (void)dummy;
-                    const int r = t / KS, s = t % KS;
-                    int oh = ih + g.pad_t - r, ow = iw + g.pad_l - s;
-                    if ((unsigned)oh < (unsigned)g.Ho && (unsigned)ow < (unsigned)g.Wo) {
-                        const float* d = DY + ((long)(n * g.Ho + oh) * g.Wo + ow) * CO;
+                const int r = t / KS, s = t % KS;
+                const int oh = ih + g.pad_t - r, ow = iw + g.pad_l - s;
+                const bool ok = (unsigned)oh < (unsigned)g.Ho && (unsigned)ow < (unsigned)g.Wo;
+                const int ohc = oh < 0 ? 0 : (oh > g.Ho - 1 ? g.Ho - 1 : oh);
+                const int owc = ow < 0 ? 0 : (ow > g.Wo - 1 ? g.Wo - 1 : ow);
+                const float* d = DY + ((long)(n * g.Ho + ohc) * g.Wo + owc) * CO;
 #pragma unroll
-                        for (int co = 0; co < CO; ++co) {
-                            float dv = d[co];
-                            acc[t * CO + co] += xv * dv;
-                        }
-                    }
+                for (int co = 0; co < CO; ++co) {
+                    const float v = d[co];
+                    dv[t * CO + co] = ok ? v : 0.f;
                 }
             }
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] += xv * dv[a];
         }
     }
     // reduce over the TY pixel lanes through LDS, one accumulator slab at a time
@@ -2223,16 +2257,29 @@ __global__ __launch_bounds__(256) void thin_wgrad_tile_kernel(const ConvGeom g, 
             const int vh0 = oi0 * g.istride + tc.dhmin[0], vw0 = oj0 * g.istride + tc.dwmin[0];
             const float* Xb = X + (size_t)n * g.Hi * g.Wi * g.Ci;
             __syncthreads();
-            for (int sr = 0; sr < tc.SH; ++sr) {
-                int ihs;
-                const bool rok = map_coord(vh0 + sr, g.HiL, g.gather, ihs);
-                for (int i = tid; i < tc.SW * Q; i += 256) {
-                    const int sc = i >> tc.logQ, qq = i & (Q - 1);
-                    int iws;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (rok && map_coord(vw0 + sc, g.WiL, g.gather, iws))
-                        v = *reinterpret_cast<const f32x4*>(Xb + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + qq * 4);
-                    *reinterpret_cast<f32x4*>(win + (size_t)(sr * tc.SW + sc) * LDC + qq * 4) = v;
+            {   // window staging: 4 independent branch-free loads per thread in flight (see thin_conv_kernel)
+                const int total = tc.SH * tc.SW * Q;
+                for (int base = 0; base < total; base += 1024) {
+                    f32x4 v[4];
+                    int off[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = base + u * 256 + tid;
+                        const bool in = e < total;
+                        const int ec = in ? e : total - 1;
+                        const int qq = ec & (Q - 1), pidx = ec >> tc.logQ;
+                        const int sr = fastdiv(pidx, tc.mgSW, tc.shSW), sc = pidx - sr * tc.SW;
+                        int ihs, iws;
+                        bool ok = map_bf(vh0 + sr, g.HiL, g.Hi, g.gather, ihs);
+                        ok &= map_bf(vw0 + sc, g.WiL, g.Wi, g.gather, iws);
+                        const f32x4 t4 =
+                            *reinterpret_cast<const f32x4*>(Xb + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + qq * 4);
+                        v[u] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
+                        off[u] = in ? pidx * LDC + qq * 4 : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (off[u] >= 0) *reinterpret_cast<f32x4*>(win + off[u]) = v[u];
                 }
             }
             {   // dy of the tile: thread <-> pixel, zero outside the image
