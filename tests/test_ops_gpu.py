@@ -56,6 +56,7 @@ CONV_CASES = [
     (2, 8, 12, 12, 24, 4, 2, (1, 1, 1, 1), 1, 0, True),         # Ci = 8: K-tail with a single masked chunk, reflect
     (2, 100, 6, 6, 36, 3, 1, (1, 1, 1, 1), 0, 0, False),        # Ci = 100 (4 chunks, tail of 4 channels)
     (3, 1, 14, 14, 8, 3, 1, (1, 1, 1, 1), 0, 2, True),          # small-K direct kernel, stride 1
+    (2, 32, 448, 448, 48, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 401k-pixel GEMM (3136 M-tiles), N tail; no act (kink flips)
 ]
 
 

@@ -28,7 +28,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a hipGraph, 0: eager launches; "
+                    "default: graph for the launch-bound workloads (pix2pix, wgan_gp)")
     args = ap.parse_args()
+    from pytorch_gan_amd import graph as gmod
     from pytorch_gan_amd import models, steps
 
     torch.manual_seed(0)
@@ -72,6 +75,28 @@ def main():
         fn = lambda i: steps.wgan_gp_step(s, real, i, zs[i % 64], alphas[i % 64])  # noqa: E731
     else:
         raise SystemExit("unknown workload " + w)
+    use_graph = args.graph == 1 or (args.graph < 0 and w in ("pix2pix", "wgan_gp"))
+    graphed, capture_error = False, None
+    if use_graph:
+        # static input buffers + captured step(s); WGAN-GP has two step shapes (critic only / critic + generator)
+        if w == "wgan_gp":
+            z_s, a_s = zs[0].clone(), alphas[0].clone()
+            runners = {True: gmod.StepRunner(lambda: steps.wgan_gp_step(s, real, 0, z_s, a_s), s.dp),
+                       False: gmod.StepRunner(lambda: steps.wgan_gp_step(s, real, 1, z_s, a_s), s.dp)}
+            for r in runners.values():
+                r.prepare()
+
+            def fn(i):  # noqa: F811
+                z_s.copy_(zs[i % 64])
+                a_s.copy_(alphas[i % 64])
+                return runners[i % s.n_critic == 0].run()
+            graphed = all(r.graphed for r in runners.values())
+            capture_error = next((r.capture_error for r in runners.values() if r.capture_error), None)
+        else:
+            eager_fn = fn
+            runner = gmod.StepRunner(lambda: eager_fn(0), s.dp).prepare()
+            fn = lambda i: runner.run()  # noqa: E731
+            graphed, capture_error = runner.graphed, runner.capture_error
     for i in range(args.warmup):
         out = fn(i)
     torch.cuda.synchronize()
@@ -86,7 +111,8 @@ def main():
     print(json.dumps({"workload": w, "batch": B, "images_per_s": round(ips, 3), "ms_per_step": round(1e3 * el / args.steps, 3),
                       "step_tflops": round(ips * GFLOP_PER_IMG[w] * 1e9 / 1e12, 2),
                       "step_mfma_frac": round(ips * GFLOP_PER_IMG[w] * 1e9 / PEAK, 4), "steps": args.steps,
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "losses": losses}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "losses": losses,
+                      "hipgraph": graphed, **({"hipgraph_error": capture_error[:160]} if capture_error else {})}))
 
 
 if __name__ == "__main__":
