@@ -312,6 +312,15 @@ def main():
                     v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches_per_step": v["launches"] // nprof}
                     for k, v in sorted(agg.items())},
             }
+    if world > 1:
+        # replicas must have stayed identical: same initial weights + summed gradients -> same updates on every rank
+        chk = torch.stack([torch.cat([p.detach().double().flatten() for p in m.parameters()]).abs().sum()
+                           for m in (state.G, state.D)]).to(dev)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(allc, chk)
+        if not all(torch.equal(allc[0], c) for c in allc):
+            raise SystemExit("data-parallel replicas diverged: %s" % [c.tolist() for c in allc])
+        result["config"]["replicas_identical"] = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(init)
     if rank == 0:

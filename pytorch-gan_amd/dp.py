@@ -40,7 +40,9 @@ class DataParallel:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.cuda = torch.cuda.is_available() and dist.get_backend(group) == "nccl"
+        # side-stream overlap whenever the buckets live on a GPU (RCCL in production; gloo stages CUDA tensors through
+        # the host, which is how the 2-rank control flow is exercised on a single-GPU box)
+        self.cuda = torch.cuda.is_available() and dist.get_backend(group) in ("nccl", "gloo")
         self.side = torch.cuda.Stream() if (self.cuda and overlap) else None
         self._pending = []
         self._segmenter = None  # set by graph.StepRunner while it records the step
@@ -105,9 +107,10 @@ def init_from_env(backend=None):
         return LocalStepper()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local)
+        backend = os.environ.get("MIGAN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        # MIGAN_DP_SINGLE_DEVICE=1 (test mode, with MIGAN_DP_BACKEND=gloo): every rank drives cuda:0
+        torch.cuda.set_device(0 if os.environ.get("MIGAN_DP_SINGLE_DEVICE") == "1" else local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():

@@ -233,3 +233,31 @@ def test_bench_config_one_step_matches_oracle():
     assert err < 2e-5, err
     valid, fake = s_gpu.labels[((128, 1), str(imgs.to(DEV).device))]
     assert torch.equal(valid.cpu(), torch.ones(128, 1)) and torch.equal(fake.cpu(), torch.zeros(128, 1))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 control flow of bench.py end to end on the single GPU of the test box: two torch.distributed.run
+    ranks drive cuda:0 with the gloo backend (RCCL refuses two ranks on one device); the step is segmented at every
+    dp.step(), the bucket all-reduce + fused Adam run on the side stream between graph segments, and bench.py itself
+    asserts that both replicas hold bit-identical parameters after the timed steps."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MIGAN_DP_BACKEND="gloo", MIGAN_DP_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 256 and res["scaling"] == "weak"
+    assert res["config"]["replicas_identical"] is True and res["config"]["hipgraph"] is True
+    assert all(np.isfinite(v) for v in res["losses"].values())
