@@ -113,8 +113,9 @@ class ConvProfiler:
 
         def up_wgrad(a):
             N, H, W, Ci, Co = a[5:10]
-            bm = 128 if (Co > 64 and 4 * Ci > 64) else 64          # wgrad_plan / wgrad_bn of conv_igemm.hip
-            bn = 128 if (bm == 128 or (Co > 32 and 4 * Ci >= 128)) else 64
+            ncol = 4 * Ci                                            # wgrad_plan / wgrad_bn of conv_igemm.hip
+            bm = 128 if (Co > 128 and ncol > 64 and N * H * W * 4 > 16384) else 64
+            bn = 128 if ((Co > 64 and ncol > 64) or (Co > 32 and ncol >= 128)) else 64
             return ("upconv_wgrad_%dx%d" % (bm, bn), 2.0 * N * 4 * H * W * Co * Ci * 9)
 
         self._wrap("migan_conv2d_fwd", fwd)
@@ -147,7 +148,7 @@ def kernel_symbol(name):
              "1128032": "128, 32, 4, 1"}
     if name.startswith("upconv_wgrad_"):
         bm, bn = name[len("upconv_wgrad_"):].split("x")
-        return "wgrad_pipe_kernel<%s, %s, 0, true, 4>" % (bm, bn)
+        return "wgrad_inc_kernel<%s, %s, true>" % (bm, bn)
     for code, t in tiles.items():
         if name.endswith("igemm_" + code):
             return "igemm_pipe_kernel<%s, false>" % t

@@ -1824,6 +1824,221 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad with INCREMENTAL addressing (zero-padding gather, all tensors < 2^31 elements): wgrad_pipe_kernel spends
+// 190-260 VALU instructions per K-tile per wave on pixel decode (its forward sibling: ~20), because each of its NA+NB
+// loads belongs to a different pixel.  Here a thread owns ONE pixel row of the K-tile (row = tid / 8) and loads that
+// pixel's column quads cq0 + 8*jj of both operands, so
+//   * the pixel -> (n, oi, oj) decode happens once per thread at kernel start; a K-tile step (+32 pixels) is a carry
+//     update of (oi, oj) plus `base += D0 + carry ? D1 : 0 + carry2 ? D2 : 0` on two linear element offsets
+//     (x: ((n*Hi + oi*s)*Wi + oj*s)*Ci,  dy: pixel*Co or its strided phase view);
+//   * a load is `base + constant column offset` and two range compares of the tap-shifted coordinates.
+// LDS image, MFMA loop, split-K layout and epilogue are those of wgrad_pipe_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool DYS>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_kernel(
+    const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
+    constexpr int BK = 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int NA = BM / 32, NB = BN / 32, NL = NA + NB;
+    static_assert(NL <= BK / 2, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x;
+    const int T = g.R * g.S;
+    const int Ncol = T * g.Ci;
+    const int HoWo = g.Ho * g.Wo;
+    const int Mpix = g.N * HoWo;
+    int split, tile;  // XCD-aware block order, see wgrad_pipe_kernel
+    {
+        const int tiles = g.tiles_m * g.tiles_n;
+        if (g.splits % 8 == 0) {
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+            const int sg = k / tiles;
+            tile = k - sg * tiles;
+            split = sg * 8 + xcd;
+        } else {
+            split = blockIdx.x / tiles;
+            tile = blockIdx.x - split * tiles;
+        }
+    }
+    const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
+    const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
+    int p_end = p_begin + g.pix_per_split;
+    if (p_end > Mpix) p_end = Mpix;
+    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cls = DYS ? (int)blockIdx.y : 0;
+    const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
+    const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- load mapping: pixel row of the K-tile and first column quad of this thread
+    const int row = tid >> 3, cq0 = tid & 7;
+    const int a_c0 = co0 + cq0 * 4;  // dy columns a_c0 + 32*jj
+    unsigned a_colok = 0, b_colok = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a_colok |= (a_c0 + 32 * j < g.Co) ? (1u << j) : 0u;
+    int b_tap[NB], b_off[NB];  // (dh << 16 | dw & 0xffff), linear element offset of the column's tap + channel
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = nc0 + (cq0 + 8 * j) * 4;
+        b_tap[j] = 0;
+        b_off[j] = 0;
+        if (col < Ncol) {
+            const int t = col / g.Ci, ci = col - t * g.Ci;
+            const int r = t / g.S, s_ = t - r * g.S;
+            const int dh = r - pad_t, dw = s_ - pad_l;
+            b_tap[j] = (dh << 16) | (dw & 0xffff);
+            b_off[j] = (dh * g.Wi + dw) * g.Ci + ci;
+            b_colok |= 1u << j;
+        }
+    }
+    // ---- pixel state of the FETCH position (starts at the first K-tile)
+    int f_p = p_begin + row;
+    int f_oi, f_oj, f_bx, f_ba;
+    {
+        const int pc = f_p < Mpix ? f_p : (Mpix > 0 ? Mpix - 1 : 0);
+        const int n = fastdiv(pc, g.mg_hw, g.sh_hw);
+        const int rem = pc - n * HoWo;
+        f_oi = fastdiv(rem, g.mg_w, g.sh_w);
+        f_oj = rem - f_oi * g.Wo;
+        f_bx = ((n * g.Hi + f_oi * g.stride) * g.Wi + f_oj * g.stride) * g.Ci;
+        f_ba = DYS ? ((n * g.dy_H + dy_oh0 + 2 * f_oi) * g.dy_W + dy_ow0 + 2 * f_oj) * g.Co : pc * g.Co;
+    }
+    // +32 pixels = (d_n images, d_oi rows, d_oj columns) + carries   (block-uniform scalars)
+    const int d_n = BK / HoWo, r32 = BK - d_n * HoWo;
+    const int d_oi = r32 / g.Wo, d_oj = r32 - d_oi * g.Wo;
+    const int DX0 = (d_n * g.Hi * g.Wi + d_oi * g.stride * g.Wi + d_oj * g.stride) * g.Ci;
+    const int DX1 = (g.stride * g.Wi - g.Wo * g.stride) * g.Ci;           // oj wrapped: oi + 1, oj - Wo
+    const int DX2 = (g.Hi * g.Wi - g.Ho * g.stride * g.Wi) * g.Ci;        // oi wrapped: n + 1, oi - Ho
+    const int DA0 = DYS ? (d_n * g.dy_H * g.dy_W + d_oi * 2 * g.dy_W + d_oj * 2) * g.Co : BK * g.Co;
+    const int DA1 = DYS ? (2 * g.dy_W - 2 * g.Wo) * g.Co : 0;
+    const int DA2 = DYS ? (g.dy_H * g.dy_W - 2 * g.Ho * g.dy_W) * g.Co : 0;
+
+    f32x4 ra[NA], rb[NB];
+    unsigned okA = 0, okB = 0;
+
+#define WGI_ISSUE(idx)                                                                                     \
+    do {                                                                                                   \
+        const bool pix_ok = f_p < p_end;                                                                   \
+        if ((idx) < NA) {                                                                                  \
+            constexpr int jj = (idx) < NA ? (idx) : 0;                                                     \
+            const bool ok = pix_ok && ((a_colok >> jj) & 1u);                                              \
+            const int off = ok ? f_ba + a_c0 + 32 * jj : 0;                                                \
+            ra[jj] = *reinterpret_cast<const f32x4*>(DY + (size_t)(unsigned)off);                          \
+            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                           \
+        } else {                                                                                           \
+            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                          \
+            const int ih = f_oi * g.stride + (b_tap[jj] >> 16);                                            \
+            const int iw = f_oj * g.stride + (int)(short)(b_tap[jj] & 0xffff);                             \
+            const bool ok = pix_ok && ((b_colok >> jj) & 1u) && (unsigned)ih < (unsigned)g.Hi &&           \
+                            (unsigned)iw < (unsigned)g.Wi;                                                 \
+            const int off = ok ? f_bx + b_off[jj] : 0;                                                     \
+            rb[jj] = *reinterpret_cast<const f32x4*>(X + (size_t)(unsigned)off);                           \
+            okB = ok ? (okB | (1u << jj)) : (okB & ~(1u << jj));                                           \
+        }                                                                                                  \
+    } while (0)
+
+    if (KT > 0) {
+        if (0 < NL) WGI_ISSUE(0);
+        if (1 < NL) WGI_ISSUE(1);
+        if (2 < NL) WGI_ISSUE(2);
+        if (3 < NL) WGI_ISSUE(3);
+        if (4 < NL) WGI_ISSUE(4);
+        if (5 < NL) WGI_ISSUE(5);
+        if (6 < NL) WGI_ISSUE(6);
+        if (7 < NL) WGI_ISSUE(7);
+    }
+    const float* ap = As + h * LDA + wm * (TM * 32) + l31;
+    const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
+    float bsum = 0.f;
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            *reinterpret_cast<f32x4*>(As + row * LDA + (cq0 + 8 * j) * 4) = ((okA >> j) & 1u) ? ra[j] : zero4;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            *reinterpret_cast<f32x4*>(Bs + row * LDB + (cq0 + 8 * j) * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
+        __syncthreads();
+        if (bias_blk && tid < BM) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) s_ += As[k * LDA + tid];
+            bsum += s_;
+        }
+        if (kt + 1 < KT) {  // move the fetch position one K-tile on (the last iteration refetches its own tile)
+            f_p += BK;
+            f_oj += d_oj;
+            const bool c1 = f_oj >= g.Wo;
+            f_oj -= c1 ? g.Wo : 0;
+            f_oi += d_oi + (c1 ? 1 : 0);
+            const bool c2 = f_oi >= g.Ho;
+            f_oi -= c2 ? g.Ho : 0;
+            f_bx += DX0 + (c1 ? DX1 : 0) + (c2 ? DX2 : 0);
+            f_ba += DA0 + (c1 ? DA1 : 0) + (c2 ? DA2 : 0);
+        }
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            if ((kp & 1) == 0 && (kp >> 1) < NL) {
+                asm volatile("" : "+v"(f_bx));  // keep this slot's address arithmetic in its slot
+                switch (kp >> 1) {
+                    case 0: WGI_ISSUE(0); break;
+                    case 1: WGI_ISSUE(1); break;
+                    case 2: WGI_ISSUE(2); break;
+                    case 3: WGI_ISSUE(3); break;
+                    case 4: WGI_ISSUE(4); break;
+                    case 5: WGI_ISSUE(5); break;
+                    case 6: WGI_ISSUE(6); break;
+                    default: WGI_ISSUE(7); break;
+                }
+            }
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef WGI_ISSUE
+    if (bias_blk && tid < BM && co0 + tid < g.Co)
+        g.bpart[((size_t)cls * g.splits + split) * g.Co + co0 + tid] = bsum;
+    float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (co >= g.Co) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
+            }
+        }
+}
+
 // part[s][co][t*Ci+ci]  ->  dw[co][ci][t]  (OIHW), summed over s in a fixed order (deterministic).
 // Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
 // `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
@@ -1908,7 +2123,10 @@ static int wgrad_bn(int Co, int Ncol) {
 }
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
     long Mpix = (long)N * Ho * Wo;
-    BMsel = (Co > 64 && Ncol > 64) ? 128 : 64;
+    // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
+    // the split-K factor fills the chip (measured: G.conv1 up-conv wgrad 209 -> 186 us, PatchGAN 4x4 s2 wgrads -10 %,
+    // while Conv2d(64,256) on 590k pixels prefers 128x128)
+    BMsel = (Co > 128 && Ncol > 64 && Mpix * ncls > 16384) ? 128 : 64;
     long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, wgrad_bn(Co, Ncol)) * ncls;
     long want = cdiv(1024, tiles);
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
@@ -2069,23 +2287,18 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
     float* bpart = ws + (size_t)4 * g.splits * Co * Ncol;
     g.bpart = db ? bpart : nullptr;
-    if (bm == 128) {
-        g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
-        if (wgrad_var() == 33)  // A/B knob: 3 workgroups/CU (168 VGPRs, no spill) instead of 4 (128 VGPRs, 4 spilled)
-            hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true, 3>), dim3(g.tiles_m * g.tiles_n * g.splits, 4),
-                               dim3(256), 0, st, g, x, dy, ws);
-        else
-        hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
-                           0, st, g, x, dy, ws);
-    } else if (wgrad_bn(Co, Ncol) == 128) {
-        g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
-        hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
-                           0, st, g, x, dy, ws);
-    } else {
-        g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
-        hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64, 0, true>), dim3(g.tiles_m * g.tiles_n * g.splits, 4), dim3(256),
-                           0, st, g, x, dy, ws);
-    }
+    const bool inc = wgrad_var() != 200 && (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31);
+#define UPW_LAUNCH(BM_, BN_)                                                                                       \
+    do {                                                                                                           \
+        g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
+        dim3 grid_(g.tiles_m * g.tiles_n * g.splits, 4);                                                           \
+        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+        else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+    } while (0)
+    if (bm == 128) UPW_LAUNCH(128, 128);
+    else if (wgrad_bn(Co, Ncol) == 128) UPW_LAUNCH(64, 128);
+    else UPW_LAUNCH(64, 64);
+#undef UPW_LAUNCH
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
     BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64)};
@@ -2424,24 +2637,33 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     const int wvar = wgrad_var();  // 100 = old kernel
     if (vec && wvar != 100) {
 
+        // incremental-addressing kernel for the plain zero-padding gather; the decode-per-load kernel keeps the
+        // reflect / upsample gathers (and MIGAN_WGRAD_VAR=200 forces it for A/B runs)
+        const bool inc = gather == GATHER_ZERO && wvar != 200 && wvar != 1 && wvar != 2 && wvar != 3 &&
+                         (size_t)N * Hi * Wi * Ci < (1ull << 31) && (size_t)N * Ho * Wo * Co < (1ull << 31);
+#define WG_LAUNCH(BM_, BN_)                                                                                        \
+    do {                                                                                                           \
+        g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
+        dim3 grid_(g.tiles_m * g.tiles_n * g.splits);                                                              \
+        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws);   \
+        else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
+    } while (0)
         if (bm == 128) {
-            g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
-            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
-            if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
-            else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
-            else if (wvar == 3) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
-            else if (wvar == 33) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 0, false, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
-            else
-            hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
+            if (wvar == 1 || wvar == 2 || wvar == 3) {
+                g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
+                dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+                if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
+                else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
+                else hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
+            } else {
+                WG_LAUNCH(128, 128);
+            }
         } else if (wgrad_bn(Co, Ncol) == 128) {
-            g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 128);
-            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
-            hipLaunchKernelGGL((wgrad_pipe_kernel<64, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
+            WG_LAUNCH(64, 128);
         } else {
-            g.tiles_m = cdiv(Co, 64); g.tiles_n = cdiv(Ncol, 64);
-            dim3 grid(g.tiles_m * g.tiles_n * g.splits);
-            hipLaunchKernelGGL((wgrad_pipe_kernel<64, 64>), grid, dim3(256), 0, st, g, x, dy, ws);
+            WG_LAUNCH(64, 64);
         }
+#undef WG_LAUNCH
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st,
                                    BiasRed{g.bpart, db, g.splits, db_accumulate, 0});
