@@ -105,18 +105,18 @@ class ConvProfiler:
         # upsampled grid; the kernels execute 16/36 of them
         def up_fwd(a):
             N, H, W, Ci, Co = a[4:9]
-            return ("upconv_fwd_igemm_%d" % tc(N * H * W, Co, Ci, 4), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            return ("upconv_fwd_igemm_%d[%d->%d@%d]" % (tc(N * H * W, Co, Ci, 4), Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
 
         def up_dgrad(a):
             N, H, W, Ci, Co = a[3:8]
-            return ("upconv_dgrad_igemm_%d" % tc(N * H * W, Ci, Co, 1), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            return ("upconv_dgrad_igemm_%d[%d->%d@%d]" % (tc(N * H * W, Ci, Co, 1), Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
 
         def up_wgrad(a):
             N, H, W, Ci, Co = a[5:10]
             ncol = 4 * Ci                                            # wgrad_plan / wgrad_bn of conv_igemm.hip
             bm = 128 if (Co > 128 and ncol > 64 and N * H * W * 4 > 16384) else 64
             bn = 128 if ((Co > 64 and ncol > 64) or (Co > 32 and ncol >= 128)) else 64
-            return ("upconv_wgrad_%dx%d" % (bm, bn), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            return ("upconv_wgrad_%dx%d[%d->%d@%d]" % (bm, bn, Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
 
         self._wrap("migan_conv2d_fwd", fwd)
         self._wrap("migan_conv2d_dgrad", dgrad)
@@ -146,17 +146,19 @@ def kernel_symbol(name):
     """Device kernel symbol (as rocprofv3 prints it) behind a ConvProfiler group name."""
     tiles = {"1128128": "128, 128, 2, 2", "1128064": "128, 64, 2, 2", "1064064": "64, 64, 2, 2",
              "1128032": "128, 32, 4, 1"}
-    if name.startswith("upconv_wgrad_"):
-        bm, bn = name[len("upconv_wgrad_"):].split("x")
-        return "wgrad_inc_kernel<%s, %s, true>" % (bm, bn)
+    base = name.split("[")[0]  # "[Ci->Co@size]" layer tag of the up-conv groups
+    if base.startswith("upconv_wgrad_"):
+        bm, bn = base[len("upconv_wgrad_"):].split("x")
+        return "wgrad_inc_kernel<%s, %s, true, false>" % (bm, bn)
     for code, t in tiles.items():
-        if name.endswith("igemm_" + code):
+        if base.endswith("igemm_" + code):
             return "igemm_pipe_kernel<%s, false>" % t
     return name
 
 
 def pmc_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of a ConvProfiler group (kernel + layer shape) from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json:
     FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE); None when that kernel was not
     profiled.  The PMC passes cannot run inside bench.py (counter collection serialises the graph)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
@@ -295,7 +297,7 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             collapsed = dom.startswith("upconv")
             symbol = kernel_symbol(dom)
-            traffic, traffic_src = pmc_traffic(symbol)
+            traffic, traffic_src = pmc_traffic(dom)
             result["roofline"] = {
                 "bound": "mfma", "kernel": dom, "symbol": symbol, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

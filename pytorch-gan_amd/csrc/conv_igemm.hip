@@ -1835,7 +1835,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
 //   * a load is `base + constant column offset` and two range compares of the tap-shifted coordinates.
 // LDS image, MFMA loop, split-K layout and epilogue are those of wgrad_pipe_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool DYS>
+// REFL (ReflectionPad2d folded into the gather, cyclegan/models.py:27-35): the mirrored coordinate is not linear in
+// (oi, oj), so only the image base n*Hi*Wi*Ci is carried and the in-image offset is rebuilt per load (~12 VALU).
+template <int BM, int BN, bool DYS, bool REFL = false>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_kernel(
     const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
     constexpr int BK = 32;
@@ -1902,7 +1904,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
             const int r = t / g.S, s_ = t - r * g.S;
             const int dh = r - pad_t, dw = s_ - pad_l;
             b_tap[j] = (dh << 16) | (dw & 0xffff);
-            b_off[j] = (dh * g.Wi + dw) * g.Ci + ci;
+            b_off[j] = REFL ? ci : (dh * g.Wi + dw) * g.Ci + ci;
             b_colok |= 1u << j;
         }
     }
@@ -1915,15 +1917,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
         const int rem = pc - n * HoWo;
         f_oi = fastdiv(rem, g.mg_w, g.sh_w);
         f_oj = rem - f_oi * g.Wo;
-        f_bx = ((n * g.Hi + f_oi * g.stride) * g.Wi + f_oj * g.stride) * g.Ci;
+        f_bx = REFL ? n * g.Hi * g.Wi * g.Ci : ((n * g.Hi + f_oi * g.stride) * g.Wi + f_oj * g.stride) * g.Ci;
         f_ba = DYS ? ((n * g.dy_H + dy_oh0 + 2 * f_oi) * g.dy_W + dy_ow0 + 2 * f_oj) * g.Co : pc * g.Co;
     }
     // +32 pixels = (d_n images, d_oi rows, d_oj columns) + carries   (block-uniform scalars)
     const int d_n = BK / HoWo, r32 = BK - d_n * HoWo;
     const int d_oi = r32 / g.Wo, d_oj = r32 - d_oi * g.Wo;
-    const int DX0 = (d_n * g.Hi * g.Wi + d_oi * g.stride * g.Wi + d_oj * g.stride) * g.Ci;
-    const int DX1 = (g.stride * g.Wi - g.Wo * g.stride) * g.Ci;           // oj wrapped: oi + 1, oj - Wo
-    const int DX2 = (g.Hi * g.Wi - g.Ho * g.stride * g.Wi) * g.Ci;        // oi wrapped: n + 1, oi - Ho
+    const int DX0 = REFL ? d_n * g.Hi * g.Wi * g.Ci
+                         : (d_n * g.Hi * g.Wi + d_oi * g.stride * g.Wi + d_oj * g.stride) * g.Ci;
+    const int DX1 = REFL ? 0 : (g.stride * g.Wi - g.Wo * g.stride) * g.Ci;                  // oj wrapped: oi + 1, oj - Wo
+    const int DX2 = REFL ? g.Hi * g.Wi * g.Ci : (g.Hi * g.Wi - g.Ho * g.stride * g.Wi) * g.Ci;  // oi wrapped: n + 1
     const int DA0 = DYS ? (d_n * g.dy_H * g.dy_W + d_oi * 2 * g.dy_W + d_oj * 2) * g.Co : BK * g.Co;
     const int DA1 = DYS ? (2 * g.dy_W - 2 * g.Wo) * g.Co : 0;
     const int DA2 = DYS ? (g.dy_H * g.dy_W - 2 * g.Ho * g.dy_W) * g.Co : 0;
@@ -1942,11 +1945,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
             okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                           \
         } else {                                                                                           \
             constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                          \
-            const int ih = f_oi * g.stride + (b_tap[jj] >> 16);                                            \
-            const int iw = f_oj * g.stride + (int)(short)(b_tap[jj] & 0xffff);                             \
-            const bool ok = pix_ok && ((b_colok >> jj) & 1u) && (unsigned)ih < (unsigned)g.Hi &&           \
-                            (unsigned)iw < (unsigned)g.Wi;                                                 \
-            const int off = ok ? f_bx + b_off[jj] : 0;                                                     \
+            int ih = f_oi * g.stride + (b_tap[jj] >> 16);                                                  \
+            int iw = f_oj * g.stride + (int)(short)(b_tap[jj] & 0xffff);                                   \
+            bool ok = pix_ok && ((b_colok >> jj) & 1u);                                                    \
+            int off;                                                                                       \
+            if (REFL) {                                                                                    \
+                ih = ih < 0 ? -ih : ih;                                                                    \
+                ih = ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih;                                                  \
+                iw = iw < 0 ? -iw : iw;                                                                    \
+                iw = iw >= g.Wi ? 2 * g.Wi - 2 - iw : iw;                                                  \
+                off = ok ? f_bx + (ih * g.Wi + iw) * g.Ci + b_off[jj] : 0;                                 \
+            } else {                                                                                       \
+                ok = ok && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;                 \
+                off = ok ? f_bx + b_off[jj] : 0;                                                           \
+            }                                                                                              \
             rb[jj] = *reinterpret_cast<const f32x4*>(X + (size_t)(unsigned)off);                           \
             okB = ok ? (okB | (1u << jj)) : (okB & ~(1u << jj));                                           \
         }                                                                                                  \
@@ -2637,15 +2649,18 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     const int wvar = wgrad_var();  // 100 = old kernel
     if (vec && wvar != 100) {
 
-        // incremental-addressing kernel for the plain zero-padding gather; the decode-per-load kernel keeps the
-        // reflect / upsample gathers (and MIGAN_WGRAD_VAR=200 forces it for A/B runs)
-        const bool inc = gather == GATHER_ZERO && wvar != 200 && wvar != 1 && wvar != 2 && wvar != 3 &&
+        // incremental-addressing kernel for the zero-padding and reflection gathers; the decode-per-load kernel keeps
+        // the (rarely used, dense) upsample gather (and MIGAN_WGRAD_VAR=200 forces it for A/B runs)
+        const bool inc = gather != GATHER_UP2 && wvar != 200 && wvar != 1 && wvar != 2 && wvar != 3 &&
                          (size_t)N * Hi * Wi * Ci < (1ull << 31) && (size_t)N * Ho * Wo * Co < (1ull << 31);
+        const bool refl = gather == GATHER_REFLECT;
 #define WG_LAUNCH(BM_, BN_)                                                                                        \
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(g.tiles_m * g.tiles_n * g.splits);                                                              \
-        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws);   \
+        if (inc && refl)                                                                                           \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
+        else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
         if (bm == 128) {

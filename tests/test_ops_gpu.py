@@ -56,6 +56,9 @@ CONV_CASES = [
     (2, 8, 12, 12, 24, 4, 2, (1, 1, 1, 1), 1, 0, True),         # Ci = 8: K-tail with a single masked chunk, reflect
     (2, 100, 6, 6, 36, 3, 1, (1, 1, 1, 1), 0, 0, False),        # Ci = 100 (4 chunks, tail of 4 channels)
     (3, 1, 14, 14, 8, 3, 1, (1, 1, 1, 1), 0, 2, True),          # small-K direct kernel, stride 1
+    (2, 64, 20, 18, 32, 3, 1, (1, 1, 1, 1), 1, 2, True),        # reflect pad 1, ragged spatial (carry logic of wgrad_inc)
+    (2, 64, 11, 13, 64, 7, 1, (3, 3, 3, 3), 1, 0, False),       # reflect pad 3, 7x7 (49 taps), 64x128 wgrad tiles
+    (5, 32, 6, 6, 160, 4, 2, (1, 1, 1, 1), 0, 0, True),         # 4x4 s2 with Ho*Wo = 9 < 32: several images per K-tile
     (2, 32, 448, 448, 48, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 401k-pixel GEMM (3136 M-tiles), N tail; no act (kink flips)
 ]
 
