@@ -152,7 +152,9 @@ def kernel_symbol(name):
         return "wgrad_inc_kernel<%s, %s, true, false>" % (bm, bn)
     for code, t in tiles.items():
         if base.endswith("igemm_" + code):
-            return "igemm_pipe_kernel<%s, false>" % t
+            # <.., KTAIL, TAPIN>: the collapsed forward (4 classes x 4 taps) runs the tap-inner K order on the small tiles
+            tapin = base.startswith("upconv_fwd_") and code != "1128128"
+            return "igemm_pipe_kernel<%s, false, %s>" % (t, "true" if tapin else "false")
     return name
 
 

@@ -18,6 +18,7 @@
 // lanes 32-63 the same rows at k=2kp+1).  An fp32 MFMA occupies its SIMD for 64 cycles, so one
 // b32 read per operand per MFMA is far below the LDS issue budget (MI355X_MICROARCH.md §LDS).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #define MAX_TAPS 96
@@ -334,7 +335,12 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
     return mode == GATHER_REFLECT ? true : inr;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false>
+// TAPIN (every class has exactly 4 taps, >= 2 K-tiles per tap; small tiles only): the K loop runs channel-chunk outer /
+// tap inner, so the 4 taps' A tiles of one 32-channel chunk - which overlap by all but one pixel column/row - are
+// fetched back to back and hit in L2, instead of each tap re-reading the whole pixel range Ci/32 K-tiles later when
+// the per-XCD L2 has long been overwritten (rocprofv3 FETCH_SIZE on the collapsed DCGAN G.conv2 forward: 1056 MB for a
+// 67 MB input with the tap-outer order).  The 4 taps' offsets/masks are kept in registers (set up once).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
@@ -414,9 +420,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     // Incremental addressing: the expensive part of the gather (coordinate map of the tap, pixel offset) is
     // recomputed only when the fetch position moves to the next tap (every Ci/32 K-tiles, in a uniform branch);
     // inside a tap the next K-tile is the same pixels 32 channels further on: one add per load.
-    int a_off[NA];          // element offset of this thread's 16 B of row j at channel 0 of the fetch tap
-    unsigned okA = 0;       // validity (row in range and tap not in the zero padding) for the fetch tap
-    int f_t = 0, f_c0 = 0, f_wo = 0;
+    constexpr int NT = TAPIN ? 4 : 1;  // tap slots held in registers
+    int a_off[NT][NA];      // element offset of this thread's 16 B of row j at channel 0 of the slot's tap
+    unsigned okA[NT];       // validity (row in range and tap not in the zero padding) for the slot's tap
+    int f_wo[NT];
+    int f_t = 0, f_c0 = 0;
     // KTAIL (Ci % 32 != 0, Ci % 4 == 0): the last K-tile of a tap holds Ci % 32 channels; threads whose 4 channels lie
     // beyond Ci read the tap's last 4 channels instead (valid memory) and are masked when the tile is written to LDS.
     int f_cv = 0;           // per-thread channel offset of the fetch tile (clamped), relative to kq*4
@@ -428,37 +436,39 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
             f_cv = (f_cok ? c : Ci - 4) - kq * 4;
         }
     };
-    auto setup_tap = [&](int t) {
+    auto setup_tap = [&](int t, int (&aoff)[NA], unsigned& oka, int& wo) {
         const int dh = s_dh[t], dw = s_dw[t];
-        f_wo = s_wofs[t];
-        okA = 0;
+        wo = s_wofs[t];
+        oka = 0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             int ihs, iws;
             bool ok = (rowok >> j) & 1u;
             ok &= map_bf((a_pos[j] >> 16) + dh, g.HiL, Hi, mode, ihs);
             ok &= map_bf((a_pos[j] & 0xffff) + dw, g.WiL, Wi, mode, iws);
-            a_off[j] = (a_base[j] + ihs * Wi + iws) * Ci + kq * 4;
-            okA |= ok ? (1u << j) : 0u;
+            aoff[j] = (a_base[j] + ihs * Wi + iws) * Ci + kq * 4;
+            oka |= ok ? (1u << j) : 0u;
         }
     };
 #define IGEMM_ISSUE(idx)                                                                               \
     do {                                                                                               \
         if ((idx) < NA) {                                                                              \
             constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
-            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(unsigned)(a_off[jj] + (KTAIL ? f_cv : f_c0))); \
+            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(unsigned)(a_off[NXT][jj] + (KTAIL ? f_cv : f_c0))); \
         } else {                                                                                       \
             constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
-            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(unsigned)(b_off[jj] + f_wo + (KTAIL ? f_cv : f_c0))); \
+            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(unsigned)(b_off[jj] + f_wo[NXT] + (KTAIL ? f_cv : f_c0))); \
         }                                                                                              \
     } while (0)
 
     unsigned okS = 0;  // validity mask of the tile currently staged in ra[] (written to LDS next)
     unsigned colokS = colok;
     if (KT > 0) {
-        setup_tap(0);
+        constexpr int NXT = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < NT; ++s_) setup_tap(s_, a_off[s_], okA[s_], f_wo[s_]);
         set_chunk();
-        okS = f_cok ? okA : 0u;
+        okS = f_cok ? okA[0] : 0u;
         colokS = f_cok ? colok : 0u;
         if (0 < NL) IGEMM_ISSUE(0);
         if (1 < NL) IGEMM_ISSUE(1);
@@ -471,7 +481,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     }
     const float* ap = As + (wm * (TM * 32) + l31) * LDK + h;
     const float* bp = Bs + (wn * (TN * 32) + l31) * LDK + h;
-    for (int kt = 0; kt < KT; ++kt) {
+    // one K-tile: stage the loaded tile into LDS, move the fetch position to tile kt+1 (tap slot NXT), multiply
+    auto k_tile = [&](int kt, auto nxt_c) {
+        constexpr int NXT = decltype(nxt_c)::value;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -486,15 +498,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
             for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? rb[j][e] : 0.f;
         }
         __syncthreads();
-        if (kt + 1 < KT) {  // move the fetch position to tile kt+1 (the last iteration refetches its own tile)
-            f_c0 += 32;
-            if (KTAIL ? f_c0 >= Ci : f_c0 == Ci) {
-                f_c0 = 0;
-                setup_tap(++f_t);
+        if (kt + 1 < KT) {  // move the fetch position to tile kt+1 (the last iteration refetches a valid tile)
+            if (TAPIN) {
+                if (NXT == 0) f_c0 += 32;  // the 4 taps of this chunk are done: next channel chunk
+            } else {
+                f_c0 += 32;
+                if (KTAIL ? f_c0 >= Ci : f_c0 == Ci) {
+                    f_c0 = 0;
+                    setup_tap(++f_t, a_off[0], okA[0], f_wo[0]);
+                }
             }
             set_chunk();
         }
-        okS = f_cok ? okA : 0u;
+        okS = f_cok ? okA[NXT] : 0u;
         if (KTAIL) colokS = f_cok ? colok : 0u;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
@@ -525,6 +541,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep each load-issue slot between its neighbouring MFMA groups
         }
+    };
+    if (TAPIN) {
+        for (int kt = 0; kt < KT; kt += 4) {  // KT = 4 taps x K-tiles per tap
+            k_tile(kt, std::integral_constant<int, 1 % NT>{});
+            k_tile(kt + 1, std::integral_constant<int, 2 % NT>{});
+            k_tile(kt + 2, std::integral_constant<int, 3 % NT>{});
+            k_tile(kt + 3, std::integral_constant<int, 0>{});
+        }
+    } else {
+        for (int kt = 0; kt < KT; ++kt) k_tile(kt, std::integral_constant<int, 0>{});
     }
 #undef IGEMM_ISSUE
 
@@ -811,6 +837,21 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    // tap-inner K order: small tiles, every class exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad) and at
+    // least 2 K-tiles per tap
+    static const int tapin_env = getenv("MIGAN_IGEMM_TAPIN") ? atoi(getenv("MIGAN_IGEMM_TAPIN")) : 1;
+    bool tapin = tapin_env != 0 && BM * BN < 16384 && g.Ci >= 64;
+    for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
+    if constexpr (BM * BN < 16384) {
+        if (tapin) {
+            if (g.Ci % 32 == 0)
+                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+            else
+                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+            HIP_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (g.Ci % 32 == 0)
         hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     else

@@ -409,7 +409,8 @@ def test_cpu_tensor_raises(pg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 128, 16, 16, 128, 0, True), (2, 128, 8, 12, 64, 1, True), (1, 256, 6, 5, 128, 2, False),
-                                 (2, 32, 7, 9, 20, 0, True), (1, 64, 4, 4, 3, 3, True)])
+                                 (2, 32, 7, 9, 20, 0, True), (1, 64, 4, 4, 3, 3, True),
+                                 (8, 128, 48, 48, 64, 0, True)])  # last: 128x64 tiles, tap-inner K order
 def test_upconv3x3_phase_collapsed(pg, cfg):
     """Upsample(2) -> Conv3x3(p=1) in the phase-collapsed form (dcgan.py:54-55,58-59; cyclegan/models.py:74-75)
     against the dense reference: forward, dgrad, wgrad (collapsed when Co%4==0 and Ci%4==0, dense fallback else)."""
