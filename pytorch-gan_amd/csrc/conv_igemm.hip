@@ -1345,6 +1345,7 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
     }
     switch (igemm_select(maxM, g.Co, fast, g.ncls)) {
         case 1128128:
+#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
             if (var == 2) return launch_cfg<128, 128, 2, 2, true, 2>(g, A, Bw, bias, C, st);
             if (var == 3) return launch_cfg<128, 128, 2, 2, true, 3>(g, A, Bw, bias, C, st);
@@ -1355,21 +1356,28 @@ static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, cons
             if (var == 48) return launch_cfg<128, 128, 2, 2, true, 48>(g, A, Bw, bias, C, st);
             if (var == 100) return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
             if (var == 300) return launch_db<128, 128, 2, 2>(g, A, Bw, bias, C, st);
+#endif
             return launch_pipe<128, 128, 2, 2>(g, A, Bw, bias, C, st);
         case 1128064:
+#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 1) return launch_cfg<128, 64, 2, 2, true, 1>(g, A, Bw, bias, C, st);
             if (var == 2) return launch_cfg<128, 64, 2, 2, true, 2>(g, A, Bw, bias, C, st);
             if (var == 3) return launch_cfg<128, 64, 2, 2, true, 3>(g, A, Bw, bias, C, st);
             if (var == 100) return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
             if (var == 300) return launch_db<128, 64, 2, 2>(g, A, Bw, bias, C, st);
+#endif
             return launch_pipe<128, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1064064:
+#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 100) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
             if (var == 300) return launch_db<64, 64, 2, 2>(g, A, Bw, bias, C, st);
+#endif
             return launch_pipe<64, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1128032:
+#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 100) return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
             if (var == 300) return launch_db<128, 32, 4, 1>(g, A, Bw, bias, C, st);
+#endif
             return launch_pipe<128, 32, 4, 1>(g, A, Bw, bias, C, st);
         case 128128: return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
         case 128064: return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
@@ -2687,8 +2695,12 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     g.bpart = db ? ws + (size_t)g.splits * Co * Ncol : nullptr;
     fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
-    const int wvar = wgrad_var();  // 100 = old kernel
+    const int wvar = wgrad_var();  // 100 = old kernel (only in -DMIGAN_ABLATION builds)
+#ifdef MIGAN_ABLATION
     if (vec && wvar != 100) {
+#else
+    if (vec) {
+#endif
 
         // incremental-addressing kernel for the zero-padding and reflection gathers; the decode-per-load kernel keeps
         // the (rarely used, dense) upsample gather (and MIGAN_WGRAD_VAR=200 forces it for A/B runs)
@@ -2705,13 +2717,16 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
         if (bm == 128) {
+#ifdef MIGAN_ABLATION
             if (wvar == 1 || wvar == 2 || wvar == 3) {
                 g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
                 dim3 grid(g.tiles_m * g.tiles_n * g.splits);
                 if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
                 else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
                 else hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
-            } else {
+            } else
+#endif
+            {
                 WG_LAUNCH(128, 128);
             }
         } else if (wgrad_bn(Co, Ncol) == 128) {
@@ -2726,12 +2741,18 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
+#ifdef MIGAN_ABLATION
         if (vec) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
-        else hipLaunchKernelGGL((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        else
+#endif
+        hipLaunchKernelGGL((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     } else {
         dim3 grid(cdiv(Co, 64), cdiv(Ncol, 64), g.splits);
+#ifdef MIGAN_ABLATION
         if (vec) hipLaunchKernelGGL((wgrad_kernel<64, 64, true>), grid, dim3(256), 0, st, g, x, dy, ws);
-        else hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        else
+#endif
+        hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
     return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st);
