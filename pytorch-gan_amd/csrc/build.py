@@ -17,6 +17,8 @@ OUT = os.path.join(HERE, "libmigan.so")
 STAMP = os.path.join(HERE, ".libmigan.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc"]
+# e.g. MIGAN_CFLAGS=-DMIGAN_ABLATION also compiles the A/B kernel variants selected by MIGAN_IGEMM_VAR / MIGAN_WGRAD_VAR
+FLAGS += os.environ.get("MIGAN_CFLAGS", "").split()
 
 
 def _digest():
@@ -24,6 +26,7 @@ def _digest():
     for f in SOURCES + HEADERS + ["build.py"]:
         with open(os.path.join(HERE, f), "rb") as fh:
             h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
