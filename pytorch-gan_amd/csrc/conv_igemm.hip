@@ -35,6 +35,10 @@ struct ConvGeom {
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
     int oh0[MAX_CLS], ow0[MAX_CLS], Ho[MAX_CLS], Wo[MAX_CLS], tapbeg[MAX_CLS], ntap[MAX_CLS];
+    // fastdiv magics per class for m / (Ho*Wo) and rem / Wo (filled by launch_igemm): the pixel decode of the pipelined
+    // kernel's prologue and strided epilogue costs ~8 instead of ~80 VALU instructions per row
+    unsigned mg_hw[MAX_CLS], mg_w[MAX_CLS];
+    int sh_hw[MAX_CLS], sh_w[MAX_CLS];
     int wofs[MAX_TAPS];
     signed char dh[MAX_TAPS], dw[MAX_TAPS];
 };
@@ -399,9 +403,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
         a_base[j] = 0;
         a_pos[j] = 0;
         if (m < M) {
-            int n = m / (Ho * Wo);
+            int n = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
             int rem = m - n * Ho * Wo;
-            int oi = rem / Wo, oj = rem - oi * Wo;
+            int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
             a_base[j] = n * Hi * Wi;
             a_pos[j] = ((oi * g.istride) << 16) | (oj * g.istride);
             rowok |= 1u << j;
@@ -563,13 +567,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
             int m = m0 + row;
             if (m >= M) continue;
             size_t opix;
-            if (linear_out) {
+            int n_img = 0;
+            if (linear_out && !g.oscale) {
                 opix = (size_t)m;
             } else {
-                int n = m / (Ho * Wo);
-                int rem = m - n * Ho * Wo;
-                int oi = rem / Wo, oj = rem - oi * Wo;
-                opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+                n_img = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
+                int rem = m - n_img * Ho * Wo;
+                int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
+                opix = ((size_t)n_img * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                     float v = acc[i][j][r];
                     if (bias) v += bias[col];
                     float o = act_apply(v, g.act, g.slope);
-                    if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
                     C[opix * g.Co + col] = o;
                 }
             }
@@ -1323,8 +1328,14 @@ static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* B
     return 0;
 }
 
-static int launch_igemm(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
                         hipStream_t st) {
+    ConvGeom g = g_in;
+    for (int c = 0; c < g.ncls; ++c) {
+        const unsigned hw = (unsigned)(g.Ho[c] * g.Wo[c]), w = (unsigned)g.Wo[c];
+        fastdiv_magic(hw ? hw : 1u, g.mg_hw[c], g.sh_hw[c]);
+        fastdiv_magic(w ? w : 1u, g.mg_w[c], g.sh_w[c]);
+    }
     bool fast = igemm_fast_ci(g.Ci) && (g.ldw % 4 == 0);
     for (int t = 0; fast && t < MAX_TAPS; ++t) fast = (g.wofs[t] % 4 == 0);
     long maxM = 0;
