@@ -17,6 +17,18 @@ static int grid_for(size_t nvec) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);      \
          i += (size_t)gridDim.x * blockDim.x)
 
+// q = i / d, returns i % d.  Flat indices are size_t for safety, but every tensor of the path has < 2^32 elements: take
+// the 32-bit divide (~10x fewer instructions than the emulated 64-bit one) whenever the value fits.
+__device__ __forceinline__ unsigned divmod(size_t i, unsigned d, size_t& q) {
+    if (i <= 0xffffffffull) {
+        const unsigned iu = (unsigned)i, qq = iu / d;
+        q = qq;
+        return iu - qq * d;
+    }
+    q = i / d;
+    return (unsigned)(i - q * d);
+}
+
 // ------------------------------------------------------------------ activations
 __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act,
                                float slope) {
@@ -56,8 +68,9 @@ __global__ void act_bwd_nc_kernel(const float* __restrict__ dy, const float* __r
     const size_t per_img = (size_t)HW * C / 4;
     const int cq = C / 4;
     GRID_STRIDE(i, n4) {
-        const size_t img = i / per_img;
-        const int c4 = (int)(i % cq);
+        size_t img, tmp_;
+        divmod(i, (unsigned)per_img, img);
+        const int c4 = (int)divmod(i, (unsigned)cq, tmp_);
         const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
         const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
         const f32x4 m = reinterpret_cast<const f32x4*>(mask)[img * cq + c4];
@@ -185,8 +198,9 @@ __global__ void mul_kernel(const float* __restrict__ a, const float* __restrict_
 __global__ void mul_nc_kernel(const float* __restrict__ x, const float* __restrict__ m,
                               float* __restrict__ y, int HW, int C, size_t total) {
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t n = i / ((size_t)HW * C);
+        size_t pix, n;
+        const int c = (int)divmod(i, (unsigned)C, pix);
+        divmod(pix, (unsigned)HW, n);
         y[i] = x[i] * m[n * C + c];
     }
 }
@@ -282,11 +296,10 @@ __global__ void gather2d_fwd_kernel(const float* __restrict__ x, float* __restri
                                     int Ho, int Wo, int pad_t, int pad_l, int mode, size_t total) {
     const int HiL = mode == GATHER_UP2 ? 2 * Hi : Hi, WiL = mode == GATHER_UP2 ? 2 * Wi : Wi;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t r = i / C;
-        int ow = (int)(r % Wo); r /= Wo;
-        int oh = (int)(r % Ho);
-        size_t n = r / Ho;
+        size_t r, n;
+        const int c = (int)divmod(i, (unsigned)C, r);
+        const int ow = (int)divmod(r, (unsigned)(Wo), r);
+        const int oh = (int)divmod(r, (unsigned)(Ho), n);
         int ih, iw;
         float v = 0.f;
         if (map_coord(oh - pad_t, HiL, mode, ih) && map_coord(ow - pad_l, WiL, mode, iw))
@@ -317,11 +330,10 @@ __device__ __forceinline__ int preimages(int h, int H, int Hout, int pad, int mo
 __global__ void gather2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi,
                                     int C, int Ho, int Wo, int pad_t, int pad_l, int mode, size_t total) {
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t r = i / C;
-        int w = (int)(r % Wi); r /= Wi;
-        int h = (int)(r % Hi);
-        size_t n = r / Hi;
+        size_t r, n;
+        const int c = (int)divmod(i, (unsigned)C, r);
+        const int w = (int)divmod(r, (unsigned)(Wi), r);
+        const int h = (int)divmod(r, (unsigned)(Hi), n);
         int ph[3], pw[3];
         int nh = preimages(h, Hi, Ho, pad_t, mode, ph);
         int nw = preimages(w, Wi, Wo, pad_l, mode, pw);
@@ -356,11 +368,10 @@ template <bool FWD>
 __global__ void pixel_shuffle_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C,
                                      int r, size_t total) {
     GRID_STRIDE(i, total) {  // i indexes the shuffled (large-spatial) tensor
-        int c = (int)(i % C);
-        size_t q = i / C;
-        int ow = (int)(q % (W * r)); q /= (W * r);
-        int oh = (int)(q % (H * r));
-        size_t n = q / (H * r);
+        size_t q, n;
+        const int c = (int)divmod(i, (unsigned)C, q);
+        const int ow = (int)divmod(q, (unsigned)((W * r)), q);
+        const int oh = (int)divmod(q, (unsigned)((H * r)), n);
         int h = oh / r, ii = oh - h * r, w = ow / r, jj = ow - w * r;
         size_t lo = ((n * H + h) * W + w) * ((size_t)C * r * r) + (size_t)c * r * r + ii * r + jj;
         if (FWD) dst[i] = src[lo];
@@ -386,11 +397,10 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
                                     size_t total) {
     const int Ho = H / 2, Wo = W / 2;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t q = i / C;
-        int ow = (int)(q % Wo); q /= Wo;
-        int oh = (int)(q % Ho);
-        size_t n = q / Ho;
+        size_t q, n;
+        const int c = (int)divmod(i, (unsigned)C, q);
+        const int ow = (int)divmod(q, (unsigned)(Wo), q);
+        const int oh = (int)divmod(q, (unsigned)(Ho), n);
         const float* p = x + ((n * H + 2 * oh) * W + 2 * ow) * C + c;
         float m = p[0];
         float v = p[C]; if (v > m) m = v;
@@ -404,11 +414,10 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ dx, int H, int W, int C, size_t total) {
     const int Ho = H / 2, Wo = W / 2;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t q = i / C;
-        int ow = (int)(q % Wo); q /= Wo;
-        int oh = (int)(q % Ho);
-        size_t n = q / Ho;
+        size_t q, n;
+        const int c = (int)divmod(i, (unsigned)C, q);
+        const int ow = (int)divmod(q, (unsigned)(Wo), q);
+        const int oh = (int)divmod(q, (unsigned)(Ho), n);
         size_t b = ((n * H + 2 * oh) * W + 2 * ow) * C + c;
         size_t o[4] = {b, b + C, b + (size_t)W * C, b + (size_t)W * C + C};
         int arg = 0;
@@ -446,8 +455,8 @@ __global__ void cat_c_kernel(float* __restrict__ a, float* __restrict__ b, float
                              size_t total) {
     const int C = Ca + Cb;
     GRID_STRIDE(i, total) {
-        int c = (int)(i % C);
-        size_t p = i / C;
+        size_t p;
+        const int c = (int)divmod(i, (unsigned)C, p);
         if (FWD) y[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
         else {
             if (c < Ca) a[p * Ca + c] = y[i];
@@ -506,11 +515,11 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
     const int o0 = dims[p0], o1 = dims[p1], o2 = dims[p2], o3 = dims[p3];
     (void)o0;
     GRID_STRIDE(i, total) {
-        size_t q = i;
-        int i3 = (int)(q % o3); q /= o3;
-        int i2 = (int)(q % o2); q /= o2;
-        int i1 = (int)(q % o1);
-        int i0 = (int)(q / o1);
+        size_t q, q0;
+        const int i3 = (int)divmod(i, (unsigned)o3, q);
+        const int i2 = (int)divmod(q, (unsigned)o2, q);
+        const int i1 = (int)divmod(q, (unsigned)o1, q0);
+        const int i0 = (int)q0;
         dst[i] = src[i0 * st[p0] + i1 * st[p1] + i2 * st[p2] + i3 * st[p3]];
     }
 }
