@@ -896,8 +896,7 @@ static int igemm_select(long maxM, int Co, bool fast, int ncls) {
             if (Co > 64 && b128 >= 896) return 1128128;
             if (b64n >= 896) return 1128064;
             if (Co > 64 && b128 >= 512 && b64 < 1792) return 1128128;
-            static const int t64 = getenv("MIGAN_IGEMM_T64") ? atoi(getenv("MIGAN_IGEMM_T64")) : 512;  // A/B knob
-            return b64n >= t64 ? 1128064 : 1064064;
+            return b64n >= 512 ? 1128064 : 1064064;
         }
         return 1128032;
     }
