@@ -10,10 +10,16 @@ Design for MI355X: all gradients of one optimiser live in ONE flat fp32 buffer (
 RCCL call on `flat_grad`, and the update is a single kernel that reads a device-side pointer table.  The
 step counter lives on the device so the whole training step can be captured in a hipGraph.
 """
+import itertools
+
 import numpy as np
 import torch
 
 from ._lib import check, lib
+
+# Weight epochs (functional.set_weight_cache): process-wide unique, never re-used stamps, so a cached pack made under one
+# optimiser can never match a parameter that a later optimiser object has updated in between.
+_EPOCH = itertools.count(1)
 
 _ADAM_T = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8")])
 _BLK_T = np.dtype([("tensor", "<i4"), ("chunk", "<i4")])
@@ -62,7 +68,7 @@ class Adam:
         self._nblocks = len(blks)
         self._ptrs = [p.data_ptr() for p in self.params]
         for p in self.params:
-            p._migan_epoch = 0  # advanced by step(): lets functional.set_weight_cache re-use packed weight copies
+            p._migan_epoch = next(_EPOCH)  # renewed by step(): lets functional.set_weight_cache re-use packed weights
 
     def _attach(self):
         for p, o in zip(self.params, self.offsets):
@@ -93,8 +99,9 @@ class Adam:
         check(lib.migan_adam_step(self._tab.data_ptr(), self._blk.data_ptr(), self._nblocks, self.step_t.data_ptr(),
                                   float(g0["lr"]), float(b1), float(b2), float(g0["eps"]), float(grad_scale),
                                   torch.cuda.current_stream().cuda_stream), "adam_step")
+        ep = next(_EPOCH)
         for p in self.params:
-            p._migan_epoch += 1
+            p._migan_epoch = ep
 
     def state_dict(self):
         return {"step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
