@@ -2497,6 +2497,81 @@ static void thin_plan(int N, int Hi, int Wi, int Ci, ThinGeom& g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small weight gradient (Co * taps * Ci <= 256 outputs, Co <= 64, taps * Ci <= 64): the first conv of a 1-channel
+// image (dcgan.py:82, Conv2d(1, 16, 3, 2, 1): 144 numbers reduced from 131 072 output pixels), where an MFMA tile
+// would be > 97 % padding and the scalar-gather wgrad_kernel spends 40 us on 10 MB.  A block walks chunks of 128
+// output pixels: their dy rows (contiguous) and their taps*Ci gathered source values (branch-free, 4 loads in flight)
+// are staged in LDS once, then thread o = (co, tap, ci) accumulates sum_p dy[p][co] * x[p][tap, ci] from LDS
+// (wave-broadcast reads).  One partial slab per block for the common fixed-order reduction.
+// ------------------------------------------------------------------------------------------------
+struct SmallWgrad {
+    int N, Hi, Wi, Ci, HiL, WiL, Ho, Wo, Co, S, T, stride, pad_t, pad_l, gather, nchunk;
+    unsigned mg_hw, mg_w, mg_k;  // fastdiv magics: / (Ho*Wo), / Wo, / (T*Ci)
+    int sh_hw, sh_w, sh_k;
+};
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const SmallWgrad g, const float* __restrict__ X,
+                                                          const float* __restrict__ DY, float* __restrict__ part) {
+    constexpr int PB = 128;
+    extern __shared__ __attribute__((aligned(16))) float sw_lds[];
+    const int K = g.T * g.Ci, nout = g.Co * K;
+    float* dys = sw_lds;             // [PB][Co]
+    float* xs = sw_lds + PB * g.Co;  // [PB][K]
+    __shared__ int k_dh[64], k_dw[64], k_ci[64];
+    const int tid = threadIdx.x;
+    if (tid < K) {
+        const int t = tid / g.Ci;
+        k_ci[tid] = tid - t * g.Ci;
+        k_dh[tid] = t / g.S - g.pad_t;
+        k_dw[tid] = t % g.S - g.pad_l;
+    }
+    const bool act = tid < nout;
+    const int oc = act ? tid : 0;
+    const int o_co = fastdiv(oc, g.mg_k, g.sh_k), o_k = oc - o_co * K;
+    const int Mpix = g.N * g.Ho * g.Wo;
+    const long dy_total = (long)Mpix * g.Co;
+    float acc = 0.f;
+    for (int chunk = blockIdx.x; chunk < g.nchunk; chunk += gridDim.x) {
+        const int p0 = chunk * PB;
+        __syncthreads();
+        {   // dy rows of the chunk: one contiguous run of PB*Co floats
+            const long base = (long)p0 * g.Co;
+            for (int i = tid; i < PB * g.Co; i += 256) dys[i] = base + i < dy_total ? DY[base + i] : 0.f;
+        }
+        for (int b = 0; b < PB * K; b += 1024) {  // gathered source values, 4 branch-free loads in flight
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b + u * 256 + tid;
+                const int ic = idx < PB * K ? idx : PB * K - 1;
+                const int p = fastdiv(ic, g.mg_k, g.sh_k), k = ic - p * K;
+                int m = p0 + p;
+                const bool in = m < Mpix;
+                m = in ? m : Mpix - 1;
+                const int n = fastdiv(m, g.mg_hw, g.sh_hw);
+                const int rem = m - n * g.Ho * g.Wo;
+                const int oi = fastdiv(rem, g.mg_w, g.sh_w), oj = rem - oi * g.Wo;
+                int ihs, iws;
+                bool ok = map_bf(oi * g.stride + k_dh[k], g.HiL, g.Hi, g.gather, ihs);
+                ok &= map_bf(oj * g.stride + k_dw[k], g.WiL, g.Wi, g.gather, iws);
+                const float t = X[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + k_ci[k]];
+                v[u] = (ok && in) ? t : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b + u * 256 + tid;
+                if (idx < PB * K) xs[idx] = v[u];
+            }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll 8
+            for (int p = 0; p < PB; ++p) acc = fmaf(dys[p * g.Co + o_co], xs[p * K + o_k], acc);
+        }
+    }
+    if (act) part[(size_t)blockIdx.x * nout + tid] = acc;  // slab layout [co][t][ci] == thread order
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tiled thin weight gradient (Co <= 4, ANY kernel size / stride / gather): the 7x7 and 9x9 image-output convs
 // (cyclegan/models.py:82, srgan/models.py:62) have 49 / 81 taps x 3 output channels, too many accumulators for
 // thin_wgrad_kernel and a 95 %-padding MFMA tile otherwise.  A persistent workgroup walks output tiles; per tile
@@ -2646,7 +2721,8 @@ MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int
     int bm, splits, pps;
     wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);
     size_t nsplit = (size_t)splits;
-    if (Co <= 4 && nsplit < THIN_CHUNKS) nsplit = THIN_CHUNKS;  // upper bound of the thin paths' slab counts
+    if ((Co <= 4 || Co * R * S * Ci <= 256) && nsplit < THIN_CHUNKS)
+        nsplit = THIN_CHUNKS;  // upper bound of the thin / small paths' slab counts
     return (nsplit * Co * R * S * Ci + nsplit * Co) * sizeof(float);  // partials + bias slabs
 }
 
@@ -2674,6 +2750,24 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else launch_thin<4>(Co, grid, lds, st, tg, x, dy, ws);
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st);
+    }
+    static const int small_on = getenv("MIGAN_SMALL_WGRAD") ? atoi(getenv("MIGAN_SMALL_WGRAD")) : 1;  // A/B knob
+    if (small_on && Co * R * S * Ci <= 256 && Co <= 64 && R * S * Ci <= 64 && !(Co % 4 == 0 && Ci % 4 == 0)) {
+        SmallWgrad sg = {N, Hi, Wi, Ci, gather == GATHER_UP2 ? 2 * Hi : Hi, gather == GATHER_UP2 ? 2 * Wi : Wi,
+                         Ho, Wo, Co, S, R * S, stride, pad_t, pad_l, gather, 0, 0, 0, 0, 0, 0, 0};
+        const long Mpix = (long)N * Ho * Wo;
+        sg.nchunk = (int)cdiv(Mpix, 128L);
+        int nblk = sg.nchunk < 1024 ? sg.nchunk : 1024;
+        if (nblk < 1) nblk = 1;
+        fastdiv_magic((unsigned)(Ho * Wo), sg.mg_hw, sg.sh_hw);
+        fastdiv_magic((unsigned)Wo, sg.mg_w, sg.sh_w);
+        fastdiv_magic((unsigned)(R * S * Ci), sg.mg_k, sg.sh_k);
+        if ((size_t)nblk * Co * R * S * Ci * sizeof(float) <= ws_bytes && Mpix > 0) {
+            const size_t lds = (size_t)128 * (Co + R * S * Ci) * sizeof(float);
+            hipLaunchKernelGGL(small_wgrad_kernel, dim3(nblk), dim3(256), lds, st, sg, x, dy, ws);
+            HIP_LAUNCH_CHECK();
+            return launch_wgrad_reduce(ws, dw_oihw, nblk, Co, R * S, Ci, accumulate, st);
+        }
     }
     if (Co <= 4) {
         ConvGeom cg;
