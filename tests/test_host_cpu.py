@@ -83,3 +83,89 @@ def test_bench_symbols_and_traffic_table():
     assert bench.pmc_traffic("no_such_kernel") == (None, None)
     # 3 G forwards-equivalents + 8 D forwards-equivalents: 2.811 GFLOP per image
     assert abs(bench.dcgan_flops_per_image() / 1e9 - 2.8107) < 1e-3
+
+
+def test_sequential_fusion_plan(monkeypatch):
+    """Which launcher families nn.Sequential routes the reference's layer patterns to (no kernels run: the functional
+    entry points are replaced by recorders that only produce tensors of the right shape)."""
+    import pytorch_gan_amd.functional as F
+    import pytorch_gan_amd.nn as nn
+
+    calls = []
+
+    def out_hw(h, w, k, stride, pads, gather):
+        hl, wl = (2 * h, 2 * w) if gather == F.GATHER_UP2 else (h, w)
+        return (hl + pads[0] + pads[2] - k) // stride + 1, (wl + pads[1] + pads[3] - k) // stride + 1
+
+    def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=0, act=0, slope=0.0, dropout_mask=None):
+        calls.append(("conv2d", tuple(pads), gather, act, dropout_mask is not None))
+        ho, wo = out_hw(x.shape[2], x.shape[3], w.shape[2], stride, pads, gather)
+        return torch.zeros(x.shape[0], w.shape[0], ho, wo)
+
+    def upconv3x3(x, w, b=None, act=0, slope=0.0):
+        calls.append(("upconv3x3", act))
+        return torch.zeros(x.shape[0], w.shape[0], 2 * x.shape[2], 2 * x.shape[3])
+
+    def norm(x, gamma=None, beta=None, res=None, rm=None, rv=None, use_batch_stats=True, momentum=0.1, eps=1e-5,
+             instance=False, act=0, slope=0.0, num_batches_tracked=None):
+        calls.append(("norm", bool(instance), act, float(eps), num_batches_tracked is not None))
+        return torch.zeros_like(x)
+
+    def activation(x, act, slope=0.0):
+        calls.append(("activation", act))
+        return torch.zeros_like(x)
+
+    def gather2d(x, pads, mode):
+        calls.append(("gather2d", tuple(pads), mode))
+        h, w = out_hw(x.shape[2], x.shape[3], 1, 1, pads, mode)
+        return torch.zeros(x.shape[0], x.shape[1], h, w)
+
+    for name, fn in dict(conv2d=conv2d, upconv3x3=upconv3x3, norm=norm, activation=activation, gather2d=gather2d).items():
+        monkeypatch.setattr(F, name, fn)
+    monkeypatch.setattr(nn, "_next_mask", lambda shape, p, device: torch.ones(shape))
+
+    # DCGAN discriminator block (dcgan.py:77-80): Conv -> LeakyReLU -> Dropout2d -> BatchNorm2d(out, 0.8)
+    blk = nn.Sequential(nn.Conv2d(16, 32, 3, 2, 1), nn.LeakyReLU(0.2, inplace=True), nn.Dropout2d(0.25),
+                        nn.BatchNorm2d(32, 0.8))
+    y = blk(torch.zeros(2, 16, 8, 8))
+    assert tuple(y.shape) == (2, 32, 4, 4)
+    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_LRELU, True), ("norm", False, F.ACT_NONE, 0.8, True)]
+
+    # DCGAN generator block (dcgan.py:54-57): Upsample -> Conv3x3 -> BatchNorm -> LeakyReLU  = collapsed up-conv + fused norm
+    calls.clear()
+    blk = nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(8, 8, 3, stride=1, padding=1), nn.BatchNorm2d(8, 0.8),
+                        nn.LeakyReLU(0.2, inplace=True))
+    y = blk(torch.zeros(2, 8, 4, 4))
+    assert tuple(y.shape) == (2, 8, 8, 8)
+    assert calls == [("upconv3x3", F.ACT_NONE), ("norm", False, F.ACT_LRELU, 0.8, True)]
+
+    # CycleGAN residual block body (cyclegan/models.py:27-35): ReflectionPad -> Conv -> InstanceNorm -> ReLU -> ...
+    calls.clear()
+    blk = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(8, 8, 3), nn.InstanceNorm2d(8), nn.ReLU(inplace=True),
+                        nn.ReflectionPad2d(1), nn.Conv2d(8, 8, 3), nn.InstanceNorm2d(8))
+    y = blk(torch.zeros(1, 8, 6, 6))
+    assert tuple(y.shape) == (1, 8, 6, 6)
+    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False), ("norm", True, F.ACT_RELU, 1e-5, False),
+                     ("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False), ("norm", True, F.ACT_NONE, 1e-5, False)]
+
+    # PatchGAN tail (cyclegan/models.py:117-118): ZeroPad2d((1,0,1,0)) -> Conv2d(C, 1, 4, padding=1): pads fold into the conv
+    calls.clear()
+    blk = nn.Sequential(nn.ZeroPad2d((1, 0, 1, 0)), nn.Conv2d(8, 1, 4, padding=1))
+    y = blk(torch.zeros(1, 8, 6, 6))
+    assert tuple(y.shape) == (1, 1, 6, 6)
+    assert calls == [("conv2d", (2, 2, 1, 1), F.GATHER_ZERO, F.ACT_NONE, False)]
+
+    # eval mode: Dropout2d is the identity, BatchNorm uses running statistics (no batch-stat kernel, no counter)
+    calls.clear()
+    blk = nn.Sequential(nn.Conv2d(4, 8, 3, 2, 1), nn.LeakyReLU(0.2), nn.Dropout2d(0.25), nn.BatchNorm2d(8)).eval()
+    blk(torch.zeros(1, 4, 4, 4))
+    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_LRELU, False), ("norm", False, F.ACT_NONE, 1e-5, False)]
+
+    # fusion off: every layer is its own launch family
+    calls.clear()
+    nn.set_fusion(False)
+    try:
+        nn.Sequential(nn.ZeroPad2d((1, 0, 1, 0)), nn.Conv2d(8, 1, 4, padding=1))(torch.zeros(1, 8, 6, 6))
+    finally:
+        nn.set_fusion(True)
+    assert [c[0] for c in calls] == ["gather2d", "conv2d"]
