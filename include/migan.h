@@ -170,16 +170,16 @@ int migan_loss_bwd(int kind, const float* x, const float* t, float tconst, const
 int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream);
 int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D, void* stream);
 int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream);
-int migan_rowdot(const float* a, const float* c, float* out, int B, int D, void* stream);
-/* torch.optim.Adam(lr, betas) step for all tensors of one optimiser in one launch (dcgan.py:134-135,169,183).
+/* torch.optim.Adam(lr, betas) step for all tensors of one optimiser in ONE launch (dcgan.py:134-135,169,183).
  * tab: device array of {float* p; const float* g; float* m; float* v; long long n}; blk: device array of
- * {int tensor; int chunk} with chunk size migan_adam_chunk(); step: device float, incremented first.
- * grads are multiplied by grad_scale (1/world_size after a summed all-reduce). */
+ * {int tensor; int chunk} with chunk size migan_adam_chunk(); step: device float holding the number of updates done
+ * (torch keeps Adam's step as an fp32 tensor as well): every block computes with step+1 and the last block to finish
+ * publishes it, so a captured hipGraph advances it on replay; ticket: device uint32, zero-initialised by the caller.
+ * lr_dev: optional device float that overrides `lr` (learning-rate schedules under graph replay,
+ * cyclegan.py:95-103,275-277).  grads are multiplied by grad_scale (1/world_size after a summed all-reduce). */
 int migan_adam_chunk(void);
-int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, float lr, float b1, float b2,
-                    float eps, float grad_scale, void* stream);
-/* gradient bucket pack/unpack for the data-parallel all-reduce: tab = {float* ptr; long long off; long long n}. */
-int migan_pack(const void* tab, const void* blk, int nblocks, float* flat, int to_flat, float scale, void* stream);
+int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, unsigned* ticket,
+                    const float* lr_dev, float lr, float b1, float b2, float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

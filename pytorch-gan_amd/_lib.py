@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(_CSRC, "libmigan.so")
 
 
 def _ensure_built():
-    if os.path.exists(LIB_PATH) and not os.environ.get("MIGAN_REBUILD"):
-        return
+    # always ask build.py: it compares a digest of the sources and flags with the stamp of the existing binary (cheap),
+    # rebuilds under a file lock when they differ, and keeps a shipped binary where there is no compiler
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("_migan_build", os.path.join(_CSRC, "build.py"))
@@ -94,10 +94,8 @@ _SIGS = {
     "migan_rownorm_fwd": (c_int, [P, P, c_int, c_int, P]),
     "migan_rownorm_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
     "migan_rowscale": (c_int, [P, P, P, c_int, c_int, P]),
-    "migan_rowdot": (c_int, [P, P, P, c_int, c_int, P]),
     "migan_adam_chunk": (c_int, []),
-    "migan_adam_step": (c_int, [P, P, c_int, P, c_float, c_float, c_float, c_float, c_float, P]),
-    "migan_pack": (c_int, [P, P, c_int, P, c_int, c_float, P]),
+    "migan_adam_step": (c_int, [P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
 }
 EXPORTS = sorted(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

@@ -30,37 +30,64 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    dig = _digest()
-    if not force and os.path.exists(OUT) and os.path.exists(STAMP):
+def _up_to_date(dig):
+    if os.path.exists(OUT) and os.path.exists(STAMP):
         with open(STAMP) as fh:
-            if fh.read().strip() == dig:
-                return OUT
+            return fh.read().strip() == dig
+    return False
+
+
+def build(force=False, verbose=True):
+    """Rebuild libmigan.so when the digest of the sources / flags changed (cheap compare otherwise).  Concurrent callers
+    (N ranks of torch.distributed.run on a fresh checkout) serialise on a lock file; objects and the library are written
+    under process-unique names and moved into place atomically, so nobody can load a half-written library."""
+    import fcntl
+
+    dig = _digest()
+    if not force and _up_to_date(dig):
+        return OUT
     if not os.path.exists(HIPCC):
         if os.path.exists(OUT):
             # No compiler on this box (e.g. a GPU runner without ROCm dev tools): use the shipped binary.
             return OUT
         raise RuntimeError("hipcc not found at %s and no prebuilt libmigan.so present" % HIPCC)
-    objs = []
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(HERE, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            sys.stderr.write(out.decode())
-            raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    with open(STAMP, "w") as fh:
-        fh.write(dig)
+    with open(os.path.join(HERE, ".libmigan.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date(dig):  # another rank built it while we waited
+                return OUT
+            tag = ".%d" % os.getpid()
+            objs, procs = [], []
+            for src in SOURCES:
+                obj = os.path.join(HERE, src.replace(".hip", ".o"))
+                cmd = [HIPCC] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj + tag]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+                objs.append(obj)
+            failed = None
+            for src, p in procs:
+                out, _ = p.communicate()
+                if p.returncode != 0 and failed is None:
+                    sys.stderr.write(out.decode())
+                    failed = src
+            if failed:
+                for o in objs:
+                    if os.path.exists(o + tag):
+                        os.remove(o + tag)
+                raise RuntimeError("hipcc failed on %s" % failed)
+            for o in objs:
+                os.replace(o + tag, o)
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT + tag] + objs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(OUT + tag, OUT)
+            with open(STAMP + tag, "w") as fh:
+                fh.write(dig)
+            os.replace(STAMP + tag, STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 

@@ -201,22 +201,12 @@ MIGAN_API int migan_rownorm_bwd(const float* x, const float* nrm, const float* d
     HIP_LAUNCH_CHECK();
     return 0;
 }
-// d/dx of (x * s[b]) helpers for the double-backward of rownorm: y[b,:] = x[b,:]*s[b]; and
-// rowdot[b] = sum_i a[b,i]*c[b,i]
+// y[b,:] = x[b,:]*s[b]  (WGAN-GP interpolation of detached samples, wgan_gp.py:125)
 __global__ void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y,
                                 int D) {
     const size_t b = blockIdx.x;
     float sc = s[b];
     for (int i = threadIdx.x; i < D; i += 256) y[b * D + i] = x[b * D + i] * sc;
-}
-__global__ void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ c, float* __restrict__ out,
-                              int D) {
-    __shared__ float red[256];
-    const size_t b = blockIdx.x;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < D; i += 256) acc += a[b * D + i] * c[b * D + i];
-    float s = block_sum(acc, red);
-    if (threadIdx.x == 0) out[b] = s;
 }
 MIGAN_API int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream) {
     if (B == 0) return 0;
@@ -224,13 +214,6 @@ MIGAN_API int migan_rowscale(const float* x, const float* s, float* y, int B, in
     HIP_LAUNCH_CHECK();
     return 0;
 }
-MIGAN_API int migan_rowdot(const float* a, const float* c, float* out, int B, int D, void* stream) {
-    if (B == 0) return 0;
-    hipLaunchKernelGGL(rowdot_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, c, out, D);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
 // ------------------------------------------------------------------ fused multi-tensor Adam
 // One launch updates every tensor of an optimizer.  `tab` holds per-tensor {param, grad, exp_avg,
 // exp_avg_sq, numel}; `blk` maps each block to (tensor, chunk).  `step` lives on the device so a captured
@@ -249,12 +232,17 @@ struct AdamBlock {
 };
 #define ADAM_CHUNK 4096
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ tab,
-                                                   const AdamBlock* __restrict__ blk,
-                                                   const float* __restrict__ step, float lr, float b1, float b2,
-                                                   float eps, float grad_scale) {
+                                                   const AdamBlock* __restrict__ blk, float* __restrict__ step,
+                                                   unsigned* __restrict__ ticket, const float* __restrict__ lr_dev,
+                                                   float lr_host, float b1, float b2, float eps, float grad_scale) {
     const AdamBlock bi = blk[blockIdx.x];
     const AdamTensor t = tab[bi.tensor];
-    const double st = (double)step[0];  // already incremented for this update
+    // Every block reads the OLD counter and computes with old + 1; the last block to finish publishes old + 1 (no
+    // block reads `step` after its first instruction, and the next launch is a kernel boundary away), so the step
+    // counter needs no launch of its own and still advances under hipGraph replay.
+    const float st_f = step[0] + 1.f;
+    const double st = (double)st_f;
+    const float lr = lr_dev ? lr_dev[0] : lr_host;  // device scalar: a captured graph follows LambdaLR (cyclegan.py:275-277)
     const double bc1 = 1.0 - pow((double)b1, st);
     const double bc2 = 1.0 - pow((double)b2, st);
     const float step_size = (float)((double)lr / bc1);
@@ -275,50 +263,33 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict_
         t.m[i] = m;
         t.v[i] = v;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned arrived = atomicAdd(ticket, 1u);
+        if (arrived == gridDim.x - 1) {
+            step[0] = st_f;
+            ticket[0] = 0u;
+        }
+    }
 }
 __global__ void step_inc_kernel(float* step) { step[0] += 1.f; }
 
 MIGAN_API int migan_adam_chunk() { return ADAM_CHUNK; }
-MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, float lr, float b1,
-                              float b2, float eps, float grad_scale, void* stream) {
+// `step`: device float (torch keeps Adam's step as an fp32 tensor too), `ticket`: device uint32 (zero-initialised),
+// `lr_dev`: optional device float overriding `lr` (so a captured hipGraph sees learning-rate schedules).
+MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, unsigned* ticket,
+                              const float* lr_dev, float lr, float b1, float b2, float eps, float grad_scale,
+                              void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
-    HIP_LAUNCH_CHECK();
-    if (nblocks > 0) {
+    if (nblocks > 0 && ticket) {
         hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, (const AdamTensor*)tab,
-                           (const AdamBlock*)blk, step, lr, b1, b2, eps, grad_scale);
+                           (const AdamBlock*)blk, step, ticket, lr_dev, lr, b1, b2, eps, grad_scale);
+        HIP_LAUNCH_CHECK();
+    } else {
+        if (nblocks > 0) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
         HIP_LAUNCH_CHECK();
     }
-    return 0;
-}
-
-// ------------------------------------------------------------------ multi-tensor pack / unpack (DP flat buckets)
-// Same table layout: copies tensor t (tab[t].g) <-> flat + off, where off = tab[t].m reinterpreted... kept
-// explicit instead: PackTensor {src/dst pointer, flat offset, numel}.
-struct PackTensor {
-    float* ptr;
-    long long off;
-    long long n;
-};
-__global__ __launch_bounds__(256) void pack_kernel(const PackTensor* __restrict__ tab,
-                                                   const AdamBlock* __restrict__ blk, float* __restrict__ flat,
-                                                   int to_flat, float scale) {
-    const AdamBlock bi = blk[blockIdx.x];
-    const PackTensor t = tab[bi.tensor];
-    long long i0 = (long long)bi.chunk * ADAM_CHUNK;
-    long long i1 = i0 + ADAM_CHUNK;
-    if (i1 > t.n) i1 = t.n;
-    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-        if (to_flat) flat[t.off + i] = t.ptr[i] * scale;
-        else t.ptr[i] = flat[t.off + i] * scale;
-    }
-}
-MIGAN_API int migan_pack(const void* tab, const void* blk, int nblocks, float* flat, int to_flat, float scale,
-                         void* stream) {
-    if (nblocks <= 0) return 0;
-    hipLaunchKernelGGL(pack_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const PackTensor*)tab,
-                       (const AdamBlock*)blk, flat, to_flat, scale);
-    HIP_LAUNCH_CHECK();
     return 0;
 }
 

@@ -29,6 +29,9 @@ class LocalStepper:
     def step(self, opt):
         opt.step()
 
+    def wait(self, opt=None):
+        pass
+
     def end_step(self):
         pass
 
@@ -44,19 +47,28 @@ class DataParallel:
         # the host, which is how the 2-rank control flow is exercised on a single-GPU box)
         self.cuda = torch.cuda.is_available() and dist.get_backend(group) in ("nccl", "gloo")
         self.side = torch.cuda.Stream() if (self.cuda and overlap) else None
-        self._pending = []
+        self._pending = []      # optimisers with an update in flight on the side stream (event in opt.pending)
         self._segmenter = None  # set by graph.StepRunner while it records the step
 
     # -- per-step protocol -------------------------------------------------------------------------
+    # Ordering rule: `step(opt)` returns while the all-reduce + Adam of `opt` may still run on the side stream.  The
+    # main stream has to wait for that update before it next READS those parameters (a forward/backward of that
+    # network) or touches the bucket.  `opt.zero_grad()` / `opt.step()` wait by themselves; parameter reads are covered
+    # by `wait(opt)` — the step bodies in steps.py call it where the reference reuses a network right after its update
+    # (wgan_gp.py:179-186) — and by `begin_step()` at the top of every iteration.
     def begin_step(self):
         """Main stream must see every update launched by the previous step before parameters are reused."""
-        self.end_step()
+        if self._segmenter is None:  # while recording, graph.StepRunner.run() issues the step-boundary wait itself
+            self._wait_now(None)
 
     def step(self, opt):
         """All-reduce opt.flat_grad (SUM) and apply the update with grads scaled by 1/world."""
         if self._segmenter is not None:
-            # hipGraph recording: close the current compute segment; the exchange + update replay eagerly
+            # hipGraph recording: close the current compute segment; the exchange + update replay eagerly.  The update
+            # itself does not run while recording, but the recorded segments after it must not re-use weight packs made
+            # before it (functional.weight_cache_scope): renew the epoch stamps as the real step would
             self._segmenter.cut(lambda: self._step_now(opt))
+            opt.bump_epoch()
             return
         self._step_now(opt)
 
@@ -66,6 +78,7 @@ class DataParallel:
             dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             opt.step(grad_scale=scale)
             return
+        opt.wait_pending()
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
@@ -75,14 +88,29 @@ class DataParallel:
             opt.step(grad_scale=scale)
             done = torch.cuda.Event()
             done.record(self.side)
-        self._pending.append(done)
+        opt.pending = done
+        if opt not in self._pending:
+            self._pending.append(opt)
+
+    def wait(self, opt=None):
+        """Main stream waits for the in-flight update of `opt` (all optimisers when None)."""
+        if self._segmenter is not None:
+            self._segmenter.cut(lambda: self._wait_now(opt))
+            return
+        self._wait_now(opt)
+
+    def _wait_now(self, opt):
+        if opt is None:
+            for o in self._pending:
+                o.wait_pending()
+            self._pending = []
+        else:
+            opt.wait_pending()
+            if opt in self._pending:
+                self._pending.remove(opt)
 
     def end_step(self):
-        if self._pending:
-            main = torch.cuda.current_stream()
-            for ev in self._pending:
-                main.wait_event(ev)
-            self._pending = []
+        self._wait_now(None)
 
     # -- helpers -----------------------------------------------------------------------------------
     def shard(self, t):

@@ -144,7 +144,7 @@ def _ws(nbytes, ref):
 
 
 _DIRECT_GRAD = True
-_WEIGHT_CACHE = False
+_WEIGHT_CACHE = True   # only effective inside weight_cache_scope()
 # bias gradient inside the wgrad launches (include/migan.h): measured no faster than the column-sum launches -> opt-in
 _FUSE_BIAS = __import__("os").environ.get("MIGAN_FUSE_BIAS", "0") == "1"
 
@@ -159,25 +159,43 @@ def _bias_out(param, C, ref):
 
 
 def set_weight_cache(enabled):
-    """Re-use the packed (OHWI / IHWO / phase-collapsed) copies of a weight between calls until its optimiser steps.
-
-    Only parameters owned by `pytorch_gan_amd.optim.Adam` take part (it stamps them with an epoch that `step()`
-    advances; `copy_`/`load_state_dict` are caught through the tensor version).  In-place edits through `.data` are
-    NOT visible to the stamp, so this is off by default and switched on by `steps.make_*_state`, whose loop bodies
-    only change weights through the optimiser.  One discriminator is applied three times per DCGAN step with the
-    same weights: its packs are built once instead of three times (and once instead of three times for dgrad)."""
+    """Globally enable/disable the step-scoped re-use of packed weights (see weight_cache_scope)."""
     global _WEIGHT_CACHE
     _WEIGHT_CACHE = bool(enabled)
 
 
+_CACHE_SCOPE = None          # token of the training-step invocation in progress (None: no caching)
+_SCOPE_IDS = __import__("itertools").count(1)
+
+
+@__import__("contextlib").contextmanager
+def weight_cache_scope():
+    """Inside this scope the packed (OHWI / IHWO / phase-collapsed) copies of a weight are re-used between calls
+    until its optimiser steps: a discriminator applied three times per DCGAN step is packed once (and once for dgrad).
+
+    The scope is ONE invocation of a `steps.*_step` body, where weights change only through `optim.Adam.step()`
+    (which renews the parameter's epoch stamp).  Cached packs never outlive the scope, so edits between steps that
+    no stamp can see — `weights_init_normal` writing `m.weight.data` (dcgan.py:36-42), `load_state_dict`, an optimiser
+    update replayed from a hipGraph — can not be served a stale pack; a capture and the eager steps around it never
+    share entries either (the captured step is one scope, every eager step another)."""
+    global _CACHE_SCOPE
+    prev = _CACHE_SCOPE
+    if prev is None:
+        _CACHE_SCOPE = next(_SCOPE_IDS)
+    try:
+        yield
+    finally:
+        _CACHE_SCOPE = prev
+
+
 def _packed(param, w, kind, make):
     """`make()` -> packed tensor (or tuple of tensors) of plain weight `w`; cached on the Parameter object `param`."""
-    if not _WEIGHT_CACHE or param is None:
+    if not _WEIGHT_CACHE or param is None or _CACHE_SCOPE is None:
         return make()
     ep = getattr(param, "_migan_epoch", None)
     if ep is None:
         return make()
-    stamp = (ep, w._version, w.data_ptr())
+    stamp = (_CACHE_SCOPE, ep, w._version, w.data_ptr())
     cache = param.__dict__.setdefault("_migan_pack", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == stamp:

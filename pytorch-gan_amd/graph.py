@@ -8,8 +8,19 @@ so the step is recorded once with torch.cuda.CUDAGraph (hipGraph on ROCm) and re
 world_size == 1: one graph for the whole step (forward, backward, Adam of G and D).
 world_size  > 1: the step is cut at every `dp.step(opt)`; the compute segments are graphs, and the RCCL
 all-reduce + fused Adam run eagerly between them on the side stream (no collective inside a capture).
+
+What a capture freezes, and how the step bodies deal with it:
+  * scalar kernel arguments — the learning rate is therefore read from a device scalar (optim.Adam.lr_t) that
+    `run()` refreshes from `param_groups` before every replay, so LambdaLR schedules keep working;
+  * host control flow and host RNG — `steps.wgan_gp_step` has two shapes (critic only / critic + generator):
+    use `steps.WganGpRunner`, which captures both; `steps.ReplayBuffer` draws from python `random` and keeps
+    references to samples, so it refuses to run under capture (the CycleGAN step replays eagerly; its launches are
+    large enough not to be host-bound);
+  * packed-weight cache entries never cross a capture boundary (functional.weight_cache_scope).
 """
 import torch
+
+from .optim import sync_all_lr
 
 
 class _Segmenter:
@@ -33,6 +44,15 @@ class _Segmenter:
         self.end()
         self.segments.append(("eager", eager_fn))
         self.begin()
+
+    def abort(self, exc):
+        """Close an open capture after an exception inside the recorded step (leaves no stream in capture mode)."""
+        if self._cm is not None:
+            cm, self._cm, self._g = self._cm, None, None
+            try:
+                cm.__exit__(type(exc), exc, exc.__traceback__)
+            except Exception:
+                pass
 
 
 class StepRunner:
@@ -81,6 +101,9 @@ class StepRunner:
             seg.begin()
             self.out = self.fn()
             seg.end()
+        except BaseException as e:
+            seg.abort(e)
+            raise
         finally:
             if multi:
                 self.dp._segmenter = None
@@ -91,6 +114,7 @@ class StepRunner:
         if not self.graphed:
             self.out = self._eager()
             return self.out
+        sync_all_lr()  # captured Adam launches read lr from a device scalar: push host-side schedule changes first
         self.dp.begin_step()
         for kind, item in self._segments:
             if kind == "graph":

@@ -44,6 +44,18 @@ def frozen(*modules, enabled=True):
             p.requires_grad_(True)
 
 
+def _scoped(fn):
+    """Run a step body inside functional.weight_cache_scope(): packed weights are re-used within ONE step only."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        with F.weight_cache_scope():
+            return fn(*a, **kw)
+
+    return wrapper
+
+
 def half_sum(a, b):
     """(a + b) / 2 as the reference writes it (bit-identical: scaling by 0.5 is exact)."""
     return F.axpby(a, b, 0.5, 0.5)
@@ -52,7 +64,6 @@ def half_sum(a, b):
 # ------------------------------------------------------------------------------------------------ dcgan / gan
 def make_gan_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
     """G, D: swapped modules already on the GPU (dcgan.py:106-116 / gan.py:87-93)."""
-    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            bce=gnn.BCELoss(), latent_dim=latent_dim, skip=skip_dead_grads, labels={},
                            dp=dp or LocalStepper())
@@ -65,9 +76,11 @@ def _labels(s, shape, device):
     return s.labels[key]
 
 
+@_scoped
 def dcgan_step(s, real_imgs, z):
     """dcgan.py:143-183 (and gan.py:121-161)."""
     valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.dp.begin_step()
     s.opt_G.zero_grad()
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
@@ -106,14 +119,15 @@ def compute_gradient_penalty(D, real_samples, fake_samples, alpha=None):
 
 
 def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
-    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            latent_dim=latent_dim, lambda_gp=10.0, n_critic=5, skip=skip_dead_grads,
                            dp=dp or LocalStepper())
 
 
+@_scoped
 def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0."""
+    s.dp.begin_step()
     s.opt_D.zero_grad()
     if s.skip:
         with torch.no_grad():  # G grads from d_loss are discarded at wgan_gp.py:176
@@ -130,6 +144,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     s.opt_G.zero_grad()
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
     if i % s.n_critic == 0:
+        s.dp.wait(s.opt_D)  # the generator step reads the critic that was just updated (wgan_gp.py:186)
         fake_imgs = s.G(z)
         with frozen(s.D, enabled=s.skip):
             g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
@@ -137,6 +152,52 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
         s.dp.step(s.opt_G)
         out["g_loss"] = g_loss.detach()
     return out
+
+
+class WganGpRunner:
+    """`wgan_gp_step` replayed as hipGraphs.  The loop body has two shapes — critic only, and critic + generator when
+    `i % n_critic == 0` (wgan_gp.py:179) — and a capture freezes host control flow, so both shapes are captured once
+    over static input buffers and `run(i, ...)` replays the one iteration i needs.  The step is ~100 dependent small
+    launches (Linear / LeakyReLU / double-backward chain at batch 64): replay removes the host launch cost.
+    `prepare()` executes `2 * warmup` real iterations (they update the networks like any other iteration)."""
+
+    def __init__(self, s, batch, img_shape, use_graph=True, warmup=2):
+        from .graph import StepRunner
+
+        dev = next(s.G.parameters()).device
+        self.s = s
+        self.real = torch.zeros(batch, *img_shape, device=dev)
+        self.z = torch.zeros(batch, s.latent_dim, device=dev)
+        self.alpha = torch.zeros(batch, 1, 1, 1, device=dev)
+        self.runners = {
+            True: StepRunner(lambda: wgan_gp_step(s, self.real, 0, self.z, self.alpha), s.dp, use_graph, warmup),
+            False: StepRunner(lambda: wgan_gp_step(s, self.real, 1, self.z, self.alpha), s.dp, use_graph, warmup),
+        }
+
+    def prepare(self, real, z, alpha):
+        self._load(real, z, alpha)
+        for r in self.runners.values():
+            r.prepare()
+        return self
+
+    @property
+    def graphed(self):
+        return all(r.graphed for r in self.runners.values())
+
+    @property
+    def capture_error(self):
+        return next((r.capture_error for r in self.runners.values() if r.capture_error), None)
+
+    def _load(self, real, z, alpha):
+        if real is not None:
+            self.real.copy_(real)
+        self.z.copy_(z)
+        self.alpha.copy_(alpha.reshape(self.alpha.shape))
+
+    def run(self, i, real, z, alpha):
+        """Iteration i on (real, z, alpha); pass real=None to keep the batch already in the static buffer."""
+        self._load(real, z, alpha)
+        return self.runners[i % self.s.n_critic == 0].run()
 
 
 # ------------------------------------------------------------------------------------------------ cyclegan
@@ -149,6 +210,9 @@ class ReplayBuffer:
         self.max_size, self.data = max_size, []
 
     def push_and_pop(self, batch):
+        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ReplayBuffer draws from the host RNG and keeps sample references: it cannot be "
+                               "captured into a hipGraph (run cyclegan_step eagerly)")
         out = []
         for k in range(batch.shape[0]):
             sample = batch.data[k:k + 1]
@@ -177,7 +241,6 @@ class LambdaLR:
 
 
 def make_cyclegan_state(G_AB, G_BA, D_A, D_B, skip_dead_grads=True, dp=None):
-    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(
         G_AB=G_AB, G_BA=G_BA, D_A=D_A, D_B=D_B,
         opt_G=Adam(itertools.chain(G_AB.parameters(), G_BA.parameters()), **ADAM),
@@ -186,12 +249,14 @@ def make_cyclegan_state(G_AB, G_BA, D_A, D_B, skip_dead_grads=True, dp=None):
         skip=skip_dead_grads, labels={}, dp=dp or LocalStepper())
 
 
+@_scoped
 def cyclegan_step(s, real_A, real_B):
     """cyclegan.py:159-239."""
     B = real_A.size(0)
     valid, fake = _labels(s, (B, *s.D_A.output_shape), real_A.device)
     s.G_AB.train()
     s.G_BA.train()
+    s.dp.begin_step()
     s.opt_G.zero_grad()
     loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
     with frozen(s.D_A, s.D_B, enabled=s.skip):
@@ -224,16 +289,17 @@ def cyclegan_step(s, real_A, real_B):
 
 # ------------------------------------------------------------------------------------------------ pix2pix
 def make_pix2pix_state(G, D, img_size=256, skip_dead_grads=True, dp=None):
-    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            mse=gnn.MSELoss(), l1=gnn.L1Loss(), lambda_pixel=100.0,
                            patch=(1, img_size // 16, img_size // 16), skip=skip_dead_grads, labels={},
                            dp=dp or LocalStepper())
 
 
+@_scoped
 def pix2pix_step(s, real_A, real_B):
     """pix2pix.py:123-172 (real_A = condition image, real_B = target)."""
     valid, fake = _labels(s, (real_A.size(0), *s.patch), real_A.device)
+    s.dp.begin_step()
     s.opt_G.zero_grad()
     fake_B = s.G(real_A)
     with frozen(s.D, enabled=s.skip):
@@ -255,15 +321,16 @@ def pix2pix_step(s, real_A, real_B):
 # ------------------------------------------------------------------------------------------------ srgan
 def make_srgan_state(G, D, V, skip_dead_grads=True, dp=None):
     V.eval()
-    F.set_weight_cache(True)  # weights change only through these optimisers below
     return SimpleNamespace(G=G, D=D, V=V, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM),
                            mse=gnn.MSELoss(), l1=gnn.L1Loss(), skip=skip_dead_grads, labels={},
                            dp=dp or LocalStepper())
 
 
+@_scoped
 def srgan_step(s, imgs_lr, imgs_hr):
     """srgan.py:97-145."""
     valid, fake = _labels(s, (imgs_lr.size(0), *s.D.output_shape), imgs_lr.device)
+    s.dp.begin_step()
     s.opt_G.zero_grad()
     gen_hr = s.G(imgs_lr)
     with frozen(s.D, s.V, enabled=s.skip):

@@ -11,6 +11,9 @@ sys.path.insert(0, ROOT)
 
 
 def test_weight_cache_stamps():
+    """Packed weights are re-used only inside ONE weight_cache_scope() (= one training-step body) and only while the
+    optimiser epoch, the tensor version and the storage are unchanged; nothing cached survives the scope, so writes no
+    stamp can see (`m.weight.data.normal_()` of weights_init_normal, dcgan.py:36-42; a graph-replayed Adam) are safe."""
     import pytorch_gan_amd.functional as F
     from pytorch_gan_amd import optim
 
@@ -21,27 +24,36 @@ def test_weight_cache_stamps():
         return torch.full((1,), float(len(calls)))
 
     w = torch.zeros(4)
-    F.set_weight_cache(True)
-    try:
-        assert F._packed(w, w, "k", make) is not F._packed(w, w, "k", make)  # no optimiser epoch -> never cached
-        assert len(calls) == 2
-        w._migan_epoch = next(optim._EPOCH)
+    w._migan_epoch = next(optim._EPOCH)
+    assert F._packed(w, w, "k", make) is not F._packed(w, w, "k", make)       # outside a scope: never cached
+    assert len(calls) == 2
+    with F.weight_cache_scope():
+        v = torch.zeros(4)
+        assert F._packed(v, v, "k", make) is not F._packed(v, v, "k", make)   # no optimiser epoch -> never cached
+        n0 = len(calls)
         a = F._packed(w, w, "k", make)
-        assert F._packed(w, w, "k", make) is a and len(calls) == 3            # same stamp -> hit
+        assert F._packed(w, w, "k", make) is a and len(calls) == n0 + 1       # same stamp -> hit
+        with F.weight_cache_scope():                                          # nested scope == the outer one
+            assert F._packed(w, w, "k", make) is a
         assert F._packed(w, w, "other", make) is not a                        # cache is per pack kind
         w._migan_epoch = next(optim._EPOCH)                                   # an optimiser step
         b = F._packed(w, w, "k", make)
         assert b is not a
-        w.add_(1.0)                                                            # version bump (copy_/load_state_dict)
-        assert F._packed(w, w, "k", make) is not b
+        w.add_(1.0)                                                           # version bump (copy_/load_state_dict)
+        c = F._packed(w, w, "k", make)
+        assert c is not b
         e1, e2 = next(optim._EPOCH), next(optim._EPOCH)
-        assert e2 > e1 > w._migan_epoch                                        # stamps are never re-used
-    finally:
+        assert e2 > e1 > w._migan_epoch                                       # stamps are never re-used
+    with F.weight_cache_scope():
+        w.data.fill_(3.0)                                                     # invisible to epoch AND version ...
+        d = F._packed(w, w, "k", make)
+        assert d is not c                                                     # ... but a new step never sees old packs
+        assert F._packed(w, w, "k", make) is d
         F.set_weight_cache(False)
-    n = len(calls)
-    F._packed(w, w, "k", make)
-    F._packed(w, w, "k", make)
-    assert len(calls) == n + 2                                                 # cache off: always repack
+        try:
+            assert F._packed(w, w, "k", make) is not d                        # globally off: always repack
+        finally:
+            F.set_weight_cache(True)
 
 
 def test_grad_slot_rules():
