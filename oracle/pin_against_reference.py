@@ -362,11 +362,15 @@ def pin_pix2pix(ref):
     out_d, g_d, _, din = compare_fwd_bwd(D_r, D_o, [b, a], "pix2pix.D", in_grad=True)
     gk, gd, gh = grads_digest(g_g)
     dk, dd, dh = grads_digest(g_d)
-    # masks are large (elementwise): store the seed protocol instead of the masks; tests regenerate them by
-    # running the oracle with torch.manual_seed(7) (ElementDropout draws with torch.bernoulli -> recorded there)
+    # the element-wise dropout masks the reference drew (nn.Dropout(0.5) in UNetDown/UNetUp, pix2pix/models.py:27,44) as
+    # packed keep-bits: the oracle's own draws under the same seed are NOT the same stream as nn.Dropout's, so the GPU
+    # tests replay exactly these masks to compare against gen_digest / g_digest
+    bits = {"mask_bits_%02d" % i: np.packbits((m > 0).numpy().reshape(-1)) for i, m in enumerate(masks)}
     save("pix2pix_256", meta=meta(), gen_digest=digest(out_g), gen_head=head(out_g, 64), d_out=out_d,
          d_in_grad_digest=np.stack([digest(t) for t in din]), g_keys=gk, g_digest=gd, g_head=gh, d_keys=dk,
-         d_digest=dd, d_head=dh, mask_digest=np.stack([digest(m) for m in masks]))
+         d_digest=dd, d_head=dh, mask_digest=np.stack([digest(m) for m in masks]),
+         mask_shapes=np.array([list(m.shape) for m in masks], dtype=np.int64),
+         mask_keep=np.array([float(m.max()) for m in masks]), **bits)
     return masks
 
 

@@ -1,0 +1,173 @@
+"""Step parity at the sizes BASELINE.json quotes (configs[2..4]): one full training step of the HIP path against the
+oracle run on the GPU box's host cores, starting from identical weights and the same host-drawn random numbers.
+
+  cyclegan  256x256, batch 8, 9 residual blocks   (cyclegan.py:159-239)
+  srgan     96 -> 384, batch 16, 16 residual blocks (srgan.py:97-145)
+  wgan_gp   32x32, batch 64, six critic iterations (wgan_gp.py:146-193)
+
+(dcgan 64x64 batch 128 and pix2pix 256x256 batch 1 run at size in test_steps_gpu.py.)  What is compared: every loss of
+the step (the forward path of all networks, |d| <= 2e-4*max(1,|loss|)); the parameter gradients that are still in the
+optimiser buckets after the step (rel-Frobenius over the whole network: the matrix kernels at M = 524 288 / 2 359 296
+pixels, split-K reductions, norm backward); the updated weights (Adam).  The oracle steps take tens of seconds of CPU
+time on the 128-core bench box; they need ~30 GB of host memory and are skipped — loudly — on a smaller host."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from util import gpu_copy, rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LR = 2e-4
+
+
+def _seed(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def _need_host_gb(gb):
+    import psutil
+
+    avail = psutil.virtual_memory().available / 2 ** 30
+    if avail < gb:
+        pytest.skip("oracle step needs ~%d GB of host memory, %.0f GB available" % (gb, avail))
+
+
+def _loss_close(a, b, what, tol=2e-4):
+    a, b = float(a), float(b)
+    assert abs(a - b) <= tol * max(1.0, abs(b)), "%s: hip %.7f vs oracle %.7f" % (what, a, b)
+
+
+def _net_grad_close(gmod, cmod, tol, what):
+    """Whole-network gradient: rel-Frobenius of the concatenated parameter gradients (and no parameter without one)."""
+    num = den = 0.0
+    for (k, p), (_, q) in zip(cmod.named_parameters(), gmod.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), "%s %s: gradient presence differs" % (what, k)
+        if p.grad is None:
+            continue
+        d = (q.grad.detach().double().cpu() - p.grad.detach().double())
+        num += float((d * d).sum())
+        den += float((p.grad.detach().double() ** 2).sum())
+    r = (num / max(den, 1e-300)) ** 0.5
+    assert r <= tol, "%s: whole-network gradient rel_fro %.3e > %.1e" % (what, r, tol)
+    return r
+
+
+def _weights_close(gmod, cmod, nsteps, what):
+    for (k, p), (_, q) in zip(cmod.named_parameters(), gmod.named_parameters()):
+        d = (q.detach().cpu() - p.detach()).abs()
+        assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())
+        if p.dim() > 1:  # bias in front of a norm layer: exactly-zero true gradient -> Adam amplifies rounding noise
+            assert d.mean().item() <= 0.05 * nsteps * LR, "%s %s: mean |dw| %.3e" % (what, k, d.mean().item())
+
+
+def test_cyclegan_256_bs8_step():
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _need_host_gb(64)
+    shape = (3, 256, 256)
+    _seed(0)
+    s_cpu = S.make_cyclegan(shape, 9)
+    s_gpu = steps.make_cyclegan_state(gpu_copy(s_cpu.G_AB), gpu_copy(s_cpu.G_BA), gpu_copy(s_cpu.D_A),
+                                      gpu_copy(s_cpu.D_B), skip_dead_grads=True)
+    _seed(11)
+    A = torch.rand(8, *shape) * 2 - 1
+    B = torch.rand(8, *shape) * 2 - 1
+    random.seed(5)
+    o_g = steps.cyclegan_step(s_gpu, A.to(DEV), B.to(DEV))
+    torch.cuda.synchronize()
+    random.seed(5)
+    o_c = S.cyclegan_step(s_cpu, A, B)
+    for k in ("loss_G", "loss_D", "loss_GAN", "loss_cycle", "loss_identity"):
+        _loss_close(o_g[k], o_c[k], k)
+    # gradients still in the buckets: G (both generators) from loss_G, D_A / D_B from their own losses
+    for name in ("G_AB", "G_BA", "D_A", "D_B"):
+        _net_grad_close(getattr(s_gpu, name), getattr(s_cpu, name), 5e-3, "cyclegan " + name)
+        _weights_close(getattr(s_gpu, name), getattr(s_cpu, name), 1, "cyclegan " + name)
+    # replay buffers: 8 samples pushed into each, identical index logic
+    assert len(s_gpu.buf_A.data) == len(s_cpu.buf_A.data) == 8
+    assert rel_fro(torch.cat(s_gpu.buf_A.data), torch.cat(s_cpu.buf_A.data)) < 2e-5
+
+
+def test_srgan_96_384_bs16_step():
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _need_host_gb(64)
+    _seed(0)
+    s_cpu = S.make_srgan((384, 384), n_res=16)
+    s_gpu = steps.make_srgan_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), gpu_copy(s_cpu.V))
+    _seed(12)
+    lr, hr = torch.randn(16, 3, 96, 96), torch.randn(16, 3, 384, 384)
+    o_g = steps.srgan_step(s_gpu, lr.to(DEV), hr.to(DEV))
+    torch.cuda.synchronize()
+    o_c = S.srgan_step(s_cpu, lr, hr)
+    for k in ("loss_G", "loss_D", "loss_content", "loss_GAN"):
+        _loss_close(o_g[k], o_c[k], k)
+    _net_grad_close(s_gpu.G, s_cpu.G, 5e-3, "srgan G")
+    _net_grad_close(s_gpu.D, s_cpu.D, 5e-3, "srgan D")
+    _weights_close(s_gpu.G, s_cpu.G, 1, "srgan G")
+    _weights_close(s_gpu.D, s_cpu.D, 1, "srgan D")
+    # BatchNorm side effects at size: running statistics of the generator
+    for (k, b), (_, c) in zip(s_cpu.G.named_buffers(), s_gpu.G.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert rel_fro(c, b) < 1e-4, k
+        else:
+            assert int(b) == int(c), k
+
+
+def test_wgan_gp_bs64_six_iterations():
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_wgan_gp(32)
+    s_gpu = steps.make_wgan_gp_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D))
+    _seed(13)
+    for i in range(6):
+        real = torch.rand(64, 1, 32, 32) * 2 - 1
+        z = torch.tensor(np.random.normal(0, 1, (64, 100)), dtype=torch.float32)
+        alpha = torch.tensor(np.random.random((64, 1, 1, 1)), dtype=torch.float32)
+        o_c = S.wgan_gp_step(s_cpu, real, i, z, alpha)
+        o_g = steps.wgan_gp_step(s_gpu, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+        _loss_close(o_g["d_loss"], o_c["d_loss"], "d_loss iter %d" % i, 1e-4)
+        _loss_close(o_g["gp"], o_c["gp"], "gp iter %d" % i, 1e-4)
+        assert ("g_loss" in o_g) == ("g_loss" in o_c) == (i % 5 == 0)
+        if "g_loss" in o_c:
+            _loss_close(o_g["g_loss"], o_c["g_loss"], "g_loss iter %d" % i, 1e-4)
+    _weights_close(s_gpu.D, s_cpu.D, 6, "critic")
+    _weights_close(s_gpu.G, s_cpu.G, 2, "generator")
+
+
+def test_wgan_gp_graph_runner_matches_eager():
+    """steps.WganGpRunner (two captured hipGraphs: critic-only / critic+generator) against the eager loop body."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    base = S.make_wgan_gp(32)
+    s_e = steps.make_wgan_gp_state(gpu_copy(base.G), gpu_copy(base.D))
+    s_g = steps.make_wgan_gp_state(gpu_copy(base.G), gpu_copy(base.D))
+    _seed(14)
+    reals = (torch.rand(12, 64, 1, 32, 32) * 2 - 1).to(DEV)
+    zs = torch.randn(12, 64, 100).to(DEV)
+    alphas = torch.rand(12, 64, 1, 1, 1).to(DEV)
+    runner = steps.WganGpRunner(s_g, 64, (1, 32, 32), warmup=1).prepare(reals[0], zs[0], alphas[0])
+    assert runner.graphed, runner.capture_error
+    # prepare() ran one warm-up iteration of each shape on (reals[0], zs[0], alphas[0]): mirror them on the eager twin
+    steps.wgan_gp_step(s_e, reals[0], 0, zs[0], alphas[0])
+    steps.wgan_gp_step(s_e, reals[0], 1, zs[0], alphas[0])
+    for i in range(1, 12):
+        o_g = runner.run(i, reals[i], zs[i], alphas[i])
+        o_e = steps.wgan_gp_step(s_e, reals[i], i, zs[i], alphas[i])
+        torch.cuda.synchronize()
+        assert ("g_loss" in o_g) == ("g_loss" in o_e) == (i % 5 == 0)
+        for k in o_e:
+            _loss_close(o_g[k], o_e[k], "%s iter %d" % (k, i), 1e-5)
+    for p, q in zip(s_g.D.parameters(), s_e.D.parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=2 * LR)

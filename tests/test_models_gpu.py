@@ -54,7 +54,29 @@ def _noise_aware(gpu, cpu32, cpu64, tol, what):
     assert err_g <= bound, "%s: |hip-f64| %.3e > bound %.3e (|cpu32-f64| %.3e, |f64| %.3e)" % (what, err_g, bound, err_c, ref)
 
 
-def _compare(pg, cpu_model, inputs, fused=True, tol_grad=TOL_MODEL_GRAD):
+def _digest_vs_golden(gmodel, cpu_model, model64, keys, gold_digest, what):
+    """Parameter-gradient digests (sum |g|, sum g^2 per tensor) recorded from the REAL reference (tests/golden/*:
+    `*_keys`, `*_digest`; same seeded weights, inputs, output weighting and dropout masks as `_compare` uses) against the
+    HIP gradients.  Noise-aware like `_noise_aware`: a conv bias in front of a norm layer has an exactly-zero true
+    gradient, so its digest is rounding noise on every implementation (the reference's own fp32 run differs from the
+    oracle's fp64 evaluation by 100 % there); the noise scale is taken from the two CPU fp32 runs vs fp64."""
+    gp, cp, dp = dict(gmodel.named_parameters()), dict(cpu_model.named_parameters()), dict(model64.named_parameters())
+    seen = strict = 0
+    for k, gd in zip([str(x) for x in keys], gold_digest):
+        if gp[k].grad is None:
+            continue
+        mine, c32, d64 = digest(gp[k].grad), digest(cp[k].grad), digest(dp[k].grad)
+        for j, tol in ((1, 5e-3), (2, 1e-2)):
+            noise = max(abs(c32[j] - d64[j]), abs(gd[j] - d64[j]))
+            bound = tol * abs(gd[j]) + 8.0 * noise + 1e-12
+            assert abs(mine[j] - gd[j]) <= bound, "%s %s digest[%d]: hip %.6e golden %.6e f64 %.6e cpu32 %.6e" % (
+                what, k, j, mine[j], gd[j], d64[j], c32[j])
+            strict += noise <= tol * abs(gd[j])
+        seen += 1
+    assert seen >= 1 and strict >= seen, "%s: only %d of %d digests were compared at the stated tolerance" % (what, strict, 2 * seen)
+
+
+def _compare(pg, cpu_model, inputs, fused=True, tol_grad=TOL_MODEL_GRAD, gold=None, masks=None):
     import copy
 
     from oracle import reference_models as M
@@ -63,10 +85,13 @@ def _compare(pg, cpu_model, inputs, fused=True, tol_grad=TOL_MODEL_GRAD):
     try:
         gmodel = gpu_copy(cpu_model)
         model64 = copy.deepcopy(cpu_model).double()
-        rec = []
         _seed(7)
-        out_c, gin_c, w = _fwd_bwd(cpu_model, inputs, ctx=M.feed_masks(record=rec))
-        masks = [m.numpy() for m in rec]
+        if masks is None:  # the oracle draws (and records) the masks all three evaluations share
+            rec = []
+            out_c, gin_c, w = _fwd_bwd(cpu_model, inputs, ctx=M.feed_masks(record=rec))
+            masks = [m.numpy() for m in rec]
+        else:              # masks recorded from the real reference run (golden fixture)
+            out_c, gin_c, w = _fwd_bwd(cpu_model, inputs, ctx=M.feed_masks(masks=masks))
         out_d, gin_d, _ = _fwd_bwd(model64, [t.double() for t in inputs], w, ctx=M.feed_masks(masks=masks))
         out_g, gin_g, _ = _fwd_bwd(gmodel, [t.to(DEV) for t in inputs], w, ctx=pg.dropout_masks(masks))
         assert_close(out_g, out_c, TOL_MODEL_FWD, "forward")
@@ -87,6 +112,8 @@ def _compare(pg, cpu_model, inputs, fused=True, tol_grad=TOL_MODEL_GRAD):
             else:
                 assert torch.equal(gb[k].cpu(), b), "buffer %s (bit-exact)" % k
         assert list(gmodel.state_dict().keys()) == list(cpu_model.state_dict().keys())
+        if gold is not None:
+            _digest_vs_golden(gmodel, cpu_model, model64, gold[0], gold[1], gold[2])
         return out_g, gmodel
     finally:
         pg.set_fusion(True)
@@ -104,12 +131,13 @@ def test_dcgan(pg, golden_dir, fused):
     D = M.DcganDiscriminator(32, 1)
     D.apply(M.init_normal_dcgan)
     z, img = torch.from_numpy(gold["z"]), torch.from_numpy(gold["img"])
-    out_g, _ = _compare(pg, G, [z], fused=fused)
+    out_g, _ = _compare(pg, G, [z], fused=fused, gold=(gold["g_keys"], gold["g_digest"], "dcgan G"))
     assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "G vs golden (real reference output)")
-    _compare(pg, D, [img], fused=fused)
+    masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))]  # Dropout2d masks the real reference drew
+    _compare(pg, D, [img], fused=fused, gold=(gold["d_keys"], gold["d_digest"], "dcgan D"), masks=masks)
+    _compare(pg, D, [img], fused=fused)  # and with masks drawn by the oracle
     # D against the reference run recorded in the fixture (its own dropout masks)
     Dg = gpu_copy(D)
-    masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))]
     with pg.dropout_masks(masks):
         d_out = Dg(img.to(DEV))
     assert_close(d_out, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "D vs golden")
@@ -124,9 +152,9 @@ def test_mlp_gan_wgan(pg, golden_dir, fused):
     G = M.MlpGenerator((1, 32, 32), 100)
     _seed(0)
     D = M.MlpCritic((1, 32, 32))
-    out_g, _ = _compare(pg, G, [torch.from_numpy(gold["z"])], fused=fused)
+    out_g, _ = _compare(pg, G, [torch.from_numpy(gold["z"])], fused=fused, gold=(gold["g_keys"], gold["g_digest"], "wgan G"))
     assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "wgan G vs golden")
-    out_d, Dg = _compare(pg, D, [torch.from_numpy(gold["real"])], fused=fused)
+    out_d, Dg = _compare(pg, D, [torch.from_numpy(gold["real"])], fused=fused, gold=(gold["d_keys"], gold["d_digest"], "wgan D"))
     assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "wgan D vs golden")
     # gradient penalty on the HIP path vs the value/gradients produced by the reference function
     from pytorch_gan_amd import steps
@@ -157,9 +185,9 @@ def test_cyclegan(pg, golden_dir, fused):
     D = M.CycleDiscriminator(shape)
     D.apply(M.init_normal_cyclegan)
     x = torch.from_numpy(gold["x"])
-    out_g, _ = _compare(pg, G, [x], fused=fused)
+    out_g, _ = _compare(pg, G, [x], fused=fused, gold=(gold["g_keys"], gold["g_digest"], "cyclegan G"))
     assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "cyclegan G vs golden")
-    out_d, _ = _compare(pg, D, [x], fused=fused)
+    out_d, _ = _compare(pg, D, [x], fused=fused, gold=(gold["d_keys"], gold["d_digest"], "cyclegan D"))
     assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "cyclegan D vs golden")
 
 
@@ -175,9 +203,9 @@ def test_srgan(pg, golden_dir):
     V = M.SrganFeatureExtractor()
     V.eval()
     lr, hr = torch.from_numpy(gold["lr"]), torch.from_numpy(gold["hr"])
-    out_g, _ = _compare(pg, G, [lr])
+    out_g, _ = _compare(pg, G, [lr], gold=(gold["g_keys"], gold["g_digest"], "srgan G"))
     assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "srgan G vs golden")
-    out_d, _ = _compare(pg, D, [hr])
+    out_d, _ = _compare(pg, D, [hr], gold=(gold["d_keys"], gold["d_digest"], "srgan D"))
     assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "srgan D vs golden")
     out_v, _ = _compare(pg, V, [hr])
     assert np.allclose(digest(out_v), gold["vgg_digest"], rtol=1e-4)
@@ -196,8 +224,17 @@ def test_pix2pix(pg, golden_dir):
     _seed(5)
     a = torch.rand(1, 3, 256, 256) * 2 - 1
     b = torch.rand(1, 3, 256, 256) * 2 - 1
-    _compare(pg, G, [a])
-    out_d, _ = _compare(pg, D, [b, a])
+    # the element-dropout masks the real reference drew (packed keep-bits in the fixture)
+    masks = []
+    for i, (shp, keep) in enumerate(zip(gold["mask_shapes"], gold["mask_keep"])):
+        n = int(np.prod(shp))
+        bits = np.unpackbits(gold["mask_bits_%02d" % i])[:n].reshape([int(v) for v in shp])
+        masks.append(bits.astype(np.float32) * np.float32(keep))
+    out_g, _ = _compare(pg, G, [a], gold=(gold["g_keys"], gold["g_digest"], "pix2pix G"), masks=masks)
+    # U-Net output of the REAL reference (54 M parameters, element dropout masks regenerated from the recorded seed)
+    assert np.allclose(digest(out_g), gold["gen_digest"], rtol=1e-4), (digest(out_g), gold["gen_digest"])
+    assert np.allclose(out_g.flatten()[:64].cpu().numpy(), gold["gen_head"], rtol=1e-3, atol=1e-5)
+    out_d, _ = _compare(pg, D, [b, a], gold=(gold["d_keys"], gold["d_digest"], "pix2pix D"))
     assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "pix2pix D vs golden")
 
 

@@ -26,6 +26,10 @@ def rel_fro(a, b):
 
 def assert_close(a, b, tol, what=""):
     r = rel_fro(a, b)
+    log = __import__("os").environ.get("MIGAN_TEST_ERRLOG")  # measured errors, for calibrating the stated tolerances
+    if log:
+        with open(log, "a") as fh:
+            fh.write("%-28s tol %.1e  rel_fro %.3e  shape %s\n" % (what, tol, r, tuple(a.shape)))
     assert r <= tol, "%s: rel_fro %.3e > %.1e" % (what, r, tol)
     return r
 
