@@ -1,18 +1,31 @@
 #!/usr/bin/env python
-"""Headline benchmark: DCGAN 64x64, batch 128 per GPU, fp32 training step (BASELINE.json configs[1]).
+"""Headline benchmark: training images/sec of the GAN hot path on MI355X (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload dcgan|cyclegan|srgan|wgan_gp|pix2pix]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one full iteration of the reference loop dcgan.py:143-183 (G forward/backward/Adam, three D
-forwards, D backward/Adam) on synthetic data resident in HBM, every op in libmigan.so.  The step is captured
-once as a hipGraph and replayed (N>1: graph segments with the RCCL all-reduce + fused Adam between them on a
-side stream).  Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline accounting.
+Default workload = BASELINE.json configs[1]: DCGAN 64x64, batch 128 per GPU, fp32.  One "step" = one full iteration of
+the reference loop (dcgan.py:143-183: G forward/backward/Adam, three D forwards, D backward/Adam) on synthetic data
+resident in HBM, every op in libmigan.so.  Launch-bound steps are captured once as hipGraphs and replayed (N>1: graph
+segments with the RCCL all-reduce + fused Adam between them on a side stream).
+
+Timing: W warm-up steps, then R >= 1 blocks of EXACTLY K steps, each block bracketed by barrier + synchronize on both
+sides and reduced with MAX over ranks; R is chosen so that the blocks cover >= --min-seconds (default 2 s).  `value` is
+computed from the MEDIAN block (`ms_per_step`); the minimum and every block time are reported next to it.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant conv kernel of the timed workload, measured live with
+HIP events on the launch stream: `frac` = EXECUTED FLOPs / time / peak (what the matrix pipe did), `frac_dense` = the
+reference's dense 2*M*N*K / time / peak (exceeds 1 where the phase-collapsed Upsample+Conv kernels skip
+20/36 of the dense work).  At N=1 the other BASELINE configs (cyclegan 256x256 bs 8, srgan 96->384 bs 16, wgan_gp bs 64)
+are measured briefly after the headline run and reported under `extra`; `cpu_baseline` is the oracle loop timed on this
+box's host cores (bounded sample).  See DESIGN.md §Measurement.
 """
 import argparse
+import contextlib
 import copy
 import json
 import os
+import random
 import sys
 import time
 
@@ -25,6 +38,8 @@ import torch  # noqa: E402
 
 IMG, BATCH, LATENT, CH = 64, 128, 100, 1
 PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
+UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapsed Upsample(2)+Conv3x3 kernels
+PROFILE_ROUND = "r02"
 
 
 def dcgan_flops_per_image():
@@ -41,10 +56,46 @@ def dcgan_flops_per_image():
     return 3 * g + 8 * d
 
 
-def build_state(dp, seed):
+def dcgan_upconv_flops_per_image():
+    """Dense FLOPs/img per step spent in the two Upsample+Conv3x3 layers (fwd + dgrad + wgrad)."""
+    s = IMG // 4
+    return 3 * (2 * (2 * s) ** 2 * 128 * 128 * 9 + 2 * (4 * s) ** 2 * 64 * 128 * 9)
+
+
+# Per-image algorithmic GFLOP of one training step (SURVEY.md §8d) and the share of it inside Upsample+Conv3x3 layers
+# (fwd+dgrad+wgrad; CycleGAN: u128 + u64 = 154.62 GFLOP per G forward at bs 8, 18 G-forward equivalents per step).
+GFLOP_PER_IMG = {"dcgan": dcgan_flops_per_image() / 1e9, "cyclegan": 2097.99, "srgan": 541.43, "pix2pix": 65.52,
+                 "wgan_gp": 0.0219}
+UPCONV_GFLOP_PER_IMG = {"dcgan": dcgan_upconv_flops_per_image() / 1e9, "cyclegan": 18 * 154.62 / 8, "srgan": 0.0,
+                        "pix2pix": 0.0, "wgan_gp": 0.0}
+WORKLOAD_NAME = {
+    "dcgan": "implementations/dcgan 64x64 bs=128 per GPU fp32 (dcgan.py:143-183 full step)",
+    "cyclegan": "implementations/cyclegan 256x256 bs=8 per GPU fp32, ResNet-9 G + PatchGAN D (cyclegan.py:159-239 full step)",
+    "srgan": "implementations/srgan 96->384 bs=16 per GPU fp32 (srgan.py:97-145 full step)",
+    "wgan_gp": "implementations/wgan_gp 32x32 bs=64 per GPU fp32, one critic iteration incl. gradient penalty; generator "
+               "update every 5th (wgan_gp.py:146-193)",
+    "pix2pix": "implementations/pix2pix 256x256 bs=1 per GPU fp32 (pix2pix.py:123-172 full step)",
+}
+
+
+def executed_gflop_per_image(w):
+    return GFLOP_PER_IMG[w] - UPCONV_GFLOP_PER_IMG[w] * (1.0 - UP_EXEC)
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """name, per-GPU batch, `run(i)` = one training step on static device inputs, `init` = initial CPU state dicts."""
+
+    def __init__(self, name, batch, run, state, init=None, graphed=False, capture_error=None, nets=()):
+        self.name, self.batch, self.run, self.state, self.init = name, batch, run, state, init
+        self.graphed, self.capture_error, self.nets = graphed, capture_error, nets
+
+
+def build_dcgan(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import graph as gmod
     from pytorch_gan_amd import models, steps
 
-    torch.manual_seed(seed)
+    torch.manual_seed(0)
     G = models.DcganGenerator(IMG, LATENT, CH)
     D = models.DcganDiscriminator(IMG, CH)
     G.apply(models.init_normal_dcgan)   # dcgan.py:115-116
@@ -53,12 +104,187 @@ def build_state(dp, seed):
     G, D = G.cuda(), D.cuda()
     if dp.world > 1:
         dp.broadcast_parameters(G, D)
-    return steps.make_gan_state(G, D, LATENT, skip_dead_grads=True, dp=dp), init
+    state = steps.make_gan_state(G, D, LATENT, skip_dead_grads=True, dp=dp)
+    batch = args.batch or BATCH
+    rng = np.random.RandomState(1234 + rank)
+    real = torch.from_numpy(rng.uniform(-1, 1, (batch, CH, IMG, IMG)).astype(np.float32)).to(dev)
+    nz = min(nsteps, 64) + 8
+    zs = torch.from_numpy(rng.normal(0, 1, (nz, batch, LATENT)).astype(np.float32)).to(dev)
+    z_static = zs[0].clone()
+    runner = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=not args.no_graph)
+    runner.prepare()
+
+    def run(i):
+        z_static.copy_(zs[i % nz])
+        return runner.run()
+
+    w = Workload("dcgan", batch, run, state, init, runner.graphed, runner.capture_error, (G, D))
+    w.eager = lambda: steps.dcgan_step(state, real, z_static)
+    return w
 
 
+def build_cyclegan(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    random.seed(0)
+    shape = (3, 256, 256)
+    nets = [models.CycleGenerator(shape, 9), models.CycleGenerator(shape, 9), models.CycleDiscriminator(shape),
+            models.CycleDiscriminator(shape)]
+    for n in nets:
+        n.apply(models.init_normal_cyclegan)   # cyclegan.py:79-83
+    nets = [n.to(dev) for n in nets]
+    if dp.world > 1:
+        dp.broadcast_parameters(*nets)
+    state = steps.make_cyclegan_state(*nets, dp=dp)
+    batch = args.batch or 8
+    rng = np.random.RandomState(4321 + rank)
+    a = torch.from_numpy(rng.uniform(-1, 1, (batch, *shape)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, (batch, *shape)).astype(np.float32)).to(dev)
+
+    def run(i):   # eager: the replay buffer draws from the host RNG between the generator and discriminator phases
+        dp.begin_step()
+        out = steps.cyclegan_step(state, a, b)
+        dp.end_step()
+        return out
+
+    # replay buffers warm (>= 50 entries) before timing, so the picks and clones of the timed steps are
+    # those of a run in steady state
+    while len(state.buf_A.data) < state.buf_A.max_size:
+        run(0)
+    w = Workload("cyclegan", batch, run, state, None, False, None, tuple(nets))
+    w.eager = lambda: steps.cyclegan_step(state, a, b)
+    return w
+
+
+def build_srgan(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    G, D, V = models.SrganGenerator(), models.SrganDiscriminator((3, 384, 384)), models.SrganFeatureExtractor()
+    G, D, V = G.to(dev), D.to(dev), V.to(dev)
+    if dp.world > 1:
+        dp.broadcast_parameters(G, D, V)
+    state = steps.make_srgan_state(G, D, V, dp=dp)
+    batch = args.batch or 16
+    g = torch.Generator().manual_seed(99 + rank)
+    lr = torch.randn(batch, 3, 96, 96, generator=g).to(dev)
+    hr = torch.randn(batch, 3, 384, 384, generator=g).to(dev)
+
+    def run(i):
+        dp.begin_step()
+        out = steps.srgan_step(state, lr, hr)
+        dp.end_step()
+        return out
+
+    w = Workload("srgan", batch, run, state, None, False, None, (G, D))
+    w.eager = lambda: steps.srgan_step(state, lr, hr)
+    return w
+
+
+def build_wgan_gp(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    G, D = models.MlpGenerator((1, 32, 32), 100).to(dev), models.MlpCritic((1, 32, 32)).to(dev)
+    if dp.world > 1:
+        dp.broadcast_parameters(G, D)
+    state = steps.make_wgan_gp_state(G, D, dp=dp)
+    batch = args.batch or 64
+    rng = np.random.RandomState(777 + rank)
+    real = torch.from_numpy(rng.uniform(-1, 1, (batch, 1, 32, 32)).astype(np.float32)).to(dev)
+    zs = torch.from_numpy(rng.normal(0, 1, (64, batch, 100)).astype(np.float32)).to(dev)
+    alphas = torch.from_numpy(rng.random_sample((64, batch, 1, 1, 1)).astype(np.float32)).to(dev)
+    runner = steps.WganGpRunner(state, batch, (1, 32, 32), use_graph=not args.no_graph).prepare(real, zs[0], alphas[0])
+
+    def run(i):
+        return runner.run(i, None, zs[i % 64], alphas[i % 64])
+
+    w = Workload("wgan_gp", batch, run, state, None, runner.graphed, runner.capture_error, (G, D))
+    w.eager = lambda: steps.wgan_gp_step(state, real, 1, zs[0], alphas[0])
+    return w
+
+
+def build_pix2pix(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import graph as gmod
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    G, D = models.Pix2pixGenerator(), models.Pix2pixDiscriminator()
+    G.apply(models.init_normal_dcgan)
+    D.apply(models.init_normal_dcgan)
+    G, D = G.to(dev), D.to(dev)
+    if dp.world > 1:
+        dp.broadcast_parameters(G, D)
+    state = steps.make_pix2pix_state(G, D, 256, dp=dp)
+    batch = args.batch or 1
+    rng = np.random.RandomState(555 + rank)
+    a = torch.from_numpy(rng.uniform(-1, 1, (batch, 3, 256, 256)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, (batch, 3, 256, 256)).astype(np.float32)).to(dev)
+    runner = gmod.StepRunner(lambda: steps.pix2pix_step(state, a, b), dp, use_graph=not args.no_graph).prepare()
+    w = Workload("pix2pix", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, (G, D))
+    w.eager = lambda: steps.pix2pix_step(state, a, b)
+    return w
+
+
+BUILDERS = {"dcgan": build_dcgan, "cyclegan": build_cyclegan, "srgan": build_srgan, "wgan_gp": build_wgan_gp,
+            "pix2pix": build_pix2pix}
+
+
+# ------------------------------------------------------------------------------------------------ timing
+def timed_blocks(w, world, dev, steps, warmup, min_seconds, max_blocks=200):
+    """W warm-up steps, then blocks of exactly `steps` steps (barrier + synchronize on both sides, MAX over ranks) until
+    `min_seconds` of timed work; returns the block times in seconds and the last step's outputs."""
+    import torch.distributed as dist
+
+    for i in range(warmup):
+        out = w.run(i)
+    done, blocks, out = warmup, [], None
+    while True:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = w.run(done + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        done += steps
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append(el)
+        total = sum(blocks)
+        more = total < min_seconds and len(blocks) < max_blocks
+        if world > 1:   # every rank must take the same decision
+            flag = torch.tensor([1.0 if more else 0.0], device=dev)
+            dist.broadcast(flag, src=0)
+            more = bool(flag.item() > 0.5)
+        if not more:
+            return blocks, out
+
+
+def summarise(name, batch, world, steps, blocks):
+    med = float(np.median(blocks))
+    ips = world * batch * steps / med
+    return {
+        "images_per_s": round(ips, 3), "ms_per_step": round(1e3 * med / steps, 4),
+        "ms_per_step_min": round(1e3 * min(blocks) / steps, 4), "ms_per_step_max": round(1e3 * max(blocks) / steps, 4),
+        "blocks": len(blocks), "timed_seconds": round(sum(blocks), 3),
+        "step_executed_frac": round(ips * executed_gflop_per_image(name) * 1e9 / (PEAK_TFLOPS * 1e12 * world), 4),
+        "step_dense_frac": round(ips * GFLOP_PER_IMG[name] * 1e9 / (PEAK_TFLOPS * 1e12 * world), 4),
+    }
+
+
+# ------------------------------------------------------------------------------------------------ per-kernel roofline
 class ConvProfiler:
-    """Times every conv-family launch with HIP events on the launch stream and attributes it to the kernel
-    symbol the library will pick (migan_igemm_tile_code), with its algorithmic FLOPs."""
+    """Times every conv-family launch with HIP events on the launch stream and attributes it to the kernel the library
+    picks (migan_igemm_tile_code), with its dense (reference) and executed FLOPs."""
 
     def __init__(self):
         from pytorch_gan_amd._lib import lib
@@ -83,42 +309,47 @@ class ConvProfiler:
     def __enter__(self):
         tc = self.lib.migan_igemm_tile_code
 
+        def shape(N, Ci, Co, Ho, R, s):
+            return "[%dx %d->%d k%d%s @%d]" % (N, Ci, Co, R, "s2" if s == 2 else "", Ho)
+
         def fwd(a):
-            N, Hi, Wi, Ci, Ho, Wo, Co, R, S = a[4:13]
+            N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride = a[4:14]
             code = tc(N * Ho * Wo, Co, Ci, 1)
-            return ("igemm_%d" % code, 2.0 * N * Ho * Wo * Co * Ci * R * S)
+            f = 2.0 * N * Ho * Wo * Co * Ci * R * S
+            return ("fwd_igemm_%d%s" % (code, shape(N, Ci, Co, Ho, R, stride)), f, f)
 
         def dgrad(a):
             N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride = a[4:14]
             ncls = stride * stride
             maxm = N * ((Hi + stride - 1) // stride) * ((Wi + stride - 1) // stride)
             code = tc(maxm, Ci, Co, ncls)
-            return ("igemm_%d" % code, 2.0 * N * Ho * Wo * Co * Ci * R * S)
+            f = 2.0 * N * Ho * Wo * Co * Ci * R * S
+            return ("dgrad_igemm_%d%s" % (code, shape(N, Ci, Co, Ho, R, stride)), f, f)
 
         def wgrad(a):
-            N, Hi, Wi, Ci, Ho, Wo, Co, R, S = a[5:14]
-            big = Co > 64 and R * S * Ci > 64
-            vec = Ci % 4 == 0 and Co % 4 == 0
-            return ("wgrad_%d_%s" % (128 if big else 64, "vec" if vec else "gen"), 2.0 * N * Ho * Wo * Co * Ci * R * S)
+            N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride = a[5:15]
+            f = 2.0 * N * Ho * Wo * Co * Ci * R * S
+            return ("wgrad%s" % shape(N, Ci, Co, Ho, R, stride), f, f)
 
-        # phase-collapsed Upsample(2)->Conv3x3: ALGORITHMIC FLOPs stay the reference's dense 2*M*N*K on the
-        # upsampled grid; the kernels execute 16/36 of them
+        # phase-collapsed Upsample(2)->Conv3x3: dense FLOPs are the reference's 2*M*N*K on the upsampled grid (SURVEY.md
+        # 8d); the kernels execute 16/36 of them
         def up_fwd(a):
             N, H, W, Ci, Co = a[4:9]
-            return ("upconv_fwd_igemm_%d[%d->%d@%d]" % (tc(N * H * W, Co, Ci, 4), Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            f = 2.0 * N * 4 * H * W * Co * Ci * 9
+            return ("upconv_fwd[%dx %d->%d @%d]" % (N, Ci, Co, 2 * H), f, f * UP_EXEC)
 
         def up_dgrad(a):
             N, H, W, Ci, Co = a[3:8]
-            return ("upconv_dgrad_igemm_%d[%d->%d@%d]" % (tc(N * H * W, Ci, Co, 1), Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            f = 2.0 * N * 4 * H * W * Co * Ci * 9
+            return ("upconv_dgrad[%dx %d->%d @%d]" % (N, Ci, Co, 2 * H), f, f * UP_EXEC)
 
         def up_wgrad(a):
             N, H, W, Ci, Co = a[5:10]
-            ncol = 4 * Ci                                            # wgrad_plan / wgrad_bn of conv_igemm.hip
-            bm = 128 if (Co > 128 and ncol > 64 and N * H * W * 4 > 16384) else 64
-            bn = 128 if ((Co > 64 and ncol > 64) or (Co > 32 and ncol >= 128)) else 64
-            return ("upconv_wgrad_%dx%d[%d->%d@%d]" % (bm, bn, Ci, Co, 2 * H), 2.0 * N * 4 * H * W * Co * Ci * 9)
+            f = 2.0 * N * 4 * H * W * Co * Ci * 9
+            return ("upconv_wgrad[%dx %d->%d @%d]" % (N, Ci, Co, 2 * H), f, f * UP_EXEC)
 
         self._wrap("migan_conv2d_fwd", fwd)
+        self._wrap("migan_conv2d_dropout_fwd", lambda a: fwd(a[:3] + a[4:]))
         self._wrap("migan_conv2d_dgrad", dgrad)
         self._wrap("migan_conv2d_wgrad", wgrad)
         self._wrap("migan_upconv3x3_fwd", up_fwd)
@@ -133,46 +364,68 @@ class ConvProfiler:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for (sym, flops), e0, e1 in self.records:
+        for (sym, dense, execd), e0, e1 in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "dense": 0.0, "exec": 0.0})
             d["launches"] += 1
             d["ms"] += ms
-            d["flops"] += flops
+            d["dense"] += dense
+            d["exec"] += execd
         return agg
 
 
-def kernel_symbol(name):
-    """Device kernel symbol (as rocprofv3 prints it) behind a ConvProfiler group name."""
-    tiles = {"1128128": "128, 128, 2, 2", "1128064": "128, 64, 2, 2", "1064064": "64, 64, 2, 2",
-             "1128032": "128, 32, 4, 1"}
-    base = name.split("[")[0]  # "[Ci->Co@size]" layer tag of the up-conv groups
-    if base.startswith("upconv_wgrad_"):
-        bm, bn = base[len("upconv_wgrad_"):].split("x")
-        return "wgrad_inc_kernel<%s, %s, true, false>" % (bm, bn)
-    for code, t in tiles.items():
-        if base.endswith("igemm_" + code):
-            # <.., KTAIL, TAPIN>: the collapsed forward (4 classes x 4 taps) runs the tap-inner K order on the small tiles
-            tapin = base.startswith("upconv_fwd_") and code != "1128128"
-            return "igemm_pipe_kernel<%s, false, %s>" % (t, "true" if tapin else "false")
-    return name
-
-
-def pmc_traffic(symbol):
-    """HBM bytes per launch of a ConvProfiler group (kernel + layer shape) from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE); None when that kernel was not
-    profiled.  The PMC passes cannot run inside bench.py (counter collection serialises the graph)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+def pmc_table():
+    """Committed rocprofv3 --pmc results for this build (tools/collect_profiles.py): HBM-side bytes per launch
+    (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, separate passes) and MFMA-busy cycles,
+    keyed by the roofline group names used here.  The PMC passes cannot run inside bench.py (counter collection
+    serialises the launches), so they are taken on `bench.py --no-graph` by tools/round_measure.sh and committed."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_kernels.json" % PROFILE_ROUND)
     try:
         with open(path) as f:
-            tab = json.load(f)
+            return json.load(f), os.path.relpath(path, ROOT)
     except (OSError, ValueError):
-        return None, None
-    ent = tab.get(symbol)
-    if not ent:
-        return None, None
-    return ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (%s)" % ent.get("source", "rocprofv3 --pmc")
+        return {}, None
+
+
+def roofline(w, rank, nprof):
+    """Eager runs of the timed step with HIP events (on the launch stream) around every conv-family launch; every rank
+    runs the steps (collectives), rank 0 records."""
+    agg = {}
+    with (ConvProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
+        for i in range(nprof):
+            w.state.dp.begin_step()
+            w.eager()
+            w.state.dp.end_step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            agg = prof.summary()
+    if not agg:
+        return None
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    sec = d["ms"] * 1e-3
+    ach = d["exec"] / sec / 1e12
+    dense = d["dense"] / sec / 1e12
+    tab, src = pmc_table()
+    ent = tab.get(dom, {})
+    out = {
+        "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / PEAK_TFLOPS, 4), "achieved_dense": round(dense, 2), "frac_dense": round(dense / PEAK_TFLOPS, 4),
+        "traffic": ent.get("hbm_bytes_per_launch"), "traffic_source": src if ent else None,
+        "symbol": ent.get("symbol"), "mfma_busy_frac": ent.get("mfma_busy_frac"),
+        "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // nprof,
+        "executed_gflop_per_launch": round(d["exec"] / d["launches"] / 1e9, 3),
+        "dense_gflop_per_launch": round(d["dense"] / d["launches"] / 1e9, 3),
+        "note": "achieved/frac = FLOPs the kernel EXECUTES / launch time (HIP events on the launch stream, eager run of "
+                "the timed step; a wgrad launch = main kernel + split-K reduction); *_dense = the reference's dense "
+                "2*M*N*K (SURVEY 8d), above 1 where the phase-collapsed Upsample+Conv3x3 kernels skip 20/36 of it",
+        "conv_kernels": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "executed_tflops": round(v["exec"] / (v["ms"] * 1e-3) / 1e12, 2),
+                             "frac": round(v["exec"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS, 3),
+                             "launches_per_step": v["launches"] // nprof}
+                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:24]},
+        "conv_ms_per_step": round(sum(v["ms"] for v in agg.values()) / nprof, 4),
+    }
+    return out
 
 
 def cpu_baseline(init, seconds_budget=25.0):
@@ -203,19 +456,36 @@ def cpu_baseline(init, seconds_budget=25.0):
                       % (n, BATCH, IMG, IMG, el, threads)}
 
 
+def replicas_identical(w, world, dev):
+    """Same initial weights + summed gradients -> same updates on every rank."""
+    chk = torch.stack([torch.cat([p.detach().double().flatten() for p in m.parameters()]).abs().sum()
+                       for m in w.nets]).to(dev)
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    torch.distributed.all_gather(allc, chk)
+    if not all(torch.equal(allc[0], c) for c in allc):
+        raise SystemExit("data-parallel replicas diverged: %s" % [c.tolist() for c in allc])
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="dcgan", choices=sorted(BUILDERS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE config's)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total batch, sharded over the ranks (must be divisible by --gpus)")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much is timed")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the brief runs of the other BASELINE configs (N=1)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N>1: BatchNorm statistics over the global batch (the reference's single-process semantics)")
     args = ap.parse_args()
 
     from pytorch_gan_amd import dp as dpmod
-    from pytorch_gan_amd import graph as gmod
-    from pytorch_gan_amd import steps
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -225,109 +495,69 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)" % (args.gpus, world))
     rank = dp.rank
     dev = torch.device("cuda", torch.cuda.current_device())
+    scaling = "weak"
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not divisible by %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
+        scaling = "strong"
+    if args.sync_bn and world > 1:
+        dp.enable_sync_batchnorm()
 
-    state, init = build_state(dp, seed=0)
-    rng = np.random.RandomState(1234 + rank)
-    real = torch.from_numpy(rng.uniform(-1, 1, (BATCH, CH, IMG, IMG)).astype(np.float32)).to(dev)
-    nz = args.warmup + args.steps + 8
-    zs = torch.from_numpy(rng.normal(0, 1, (nz, BATCH, LATENT)).astype(np.float32)).to(dev)
-    z_static = zs[0].clone()
-
-    runner = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=not args.no_graph)
-    runner.prepare()
-
-    def one_step(i):
-        z_static.copy_(zs[i % nz])
-        return runner.run()
-
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    losses = {k: float(v) for k, v in out.items() if k.endswith("loss")}
+    name = args.workload
+    w = BUILDERS[name](dp, rank, dev, args, args.warmup + args.steps)
+    blocks, out = timed_blocks(w, world, dev, args.steps, args.warmup, args.min_seconds)
+    losses = {k: float(v) for k, v in out.items() if "loss" in k}
     if not all(np.isfinite(v) for v in losses.values()):
         raise SystemExit("non-finite loss in the timed region: %s" % losses)
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * BATCH * args.steps / elapsed
-    flops_img = dcgan_flops_per_image()
+    summ = summarise(name, w.batch, world, args.steps, blocks)
     result = {
-        "metric": "training images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "implementations/dcgan 64x64 bs=128 per GPU fp32 (dcgan.py:143-183 full step)",
-                   "global_batch": world * BATCH, "parallelism": "dp%d" % world, "hipgraph": runner.graphed,
-                   "gflop_per_image": round(flops_img / 1e9, 4)},
-        "step_mfma_frac": round(flops_img * BATCH * args.steps / elapsed / (PEAK_TFLOPS * 1e12), 4),
+        "metric": "training images/sec", "value": round(summ["images_per_s"], 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": summ["ms_per_step"], "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOAD_NAME[name], "global_batch": world * w.batch, "parallelism": "dp%d" % world,
+                   "hipgraph": w.graphed, "gflop_per_image": round(GFLOP_PER_IMG[name], 4),
+                   "executed_gflop_per_image": round(executed_gflop_per_image(name), 4),
+                   "sync_batchnorm": bool(args.sync_bn and world > 1)},
+        "timing": {"rule": "median over blocks of exactly --steps steps, each bracketed by barrier+synchronize, MAX over ranks",
+                   "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
+                   "ms_per_step_min": summ["ms_per_step_min"], "ms_per_step_max": summ["ms_per_step_max"],
+                   "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in blocks[:64]]},
+        "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
         "losses": losses,
     }
-
-    if runner.capture_error:
-        result["config"]["hipgraph_error"] = runner.capture_error[:200]
-
+    if w.capture_error:
+        result["config"]["hipgraph_error"] = w.capture_error[:200]
     if not args.no_roofline:
-        # per-kernel accounting: eager runs of the same step with HIP events (on the launch stream) around every
-        # conv-family launch; every rank runs the steps (collectives), rank 0 records
-        import contextlib
-
-        eager = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=False)
-        nprof, agg = 5, {}
-        with (ConvProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
-            for i in range(nprof):
-                z_static.copy_(zs[i])
-                eager.run()
-            torch.cuda.synchronize()
-            if rank == 0:
-                agg = prof.summary()
-        if agg:
-            dom = max(agg, key=lambda k: agg[k]["ms"])
-            d = agg[dom]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            collapsed = dom.startswith("upconv")
-            symbol = kernel_symbol(dom)
-            traffic, traffic_src = pmc_traffic(dom)
-            result["roofline"] = {
-                "bound": "mfma", "kernel": dom, "symbol": symbol, "achieved": round(ach, 2), "peak": PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "note": ("achieved = the reference's dense FLOPs per launch / measured launch time (SURVEY 8d); the "
-                         "phase-collapsed Upsample+Conv3x3 kernels execute 16/36 of those FLOPs, so frac can exceed 1 "
-                         "while executed_frac is the matrix-pipe utilisation; a wgrad launch = main kernel + split-K "
-                         "reduction") if collapsed else "achieved = dense 2*M*N*K of the layer / measured launch time",
-                # `achieved` counts the reference's dense FLOPs (Upsample x2 -> Conv3x3 on the upsampled grid); the
-                # phase-collapsed kernels execute 16/36 of them, so `executed` is the matrix-pipe rate actually sustained
-                "executed": round(ach * (16.0 / 36.0 if collapsed else 1.0), 2),
-                "executed_frac": round(ach * (16.0 / 36.0 if collapsed else 1.0) / PEAK_TFLOPS, 4),
-                "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // nprof,
-                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
-                "all_conv_kernels": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "tflops": round(
-                    v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches_per_step": v["launches"] // nprof}
-                    for k, v in sorted(agg.items())},
-            }
+        rf = roofline(w, rank, 5 if name in ("dcgan", "wgan_gp", "pix2pix") else 2)
+        if rf:
+            result["roofline"] = rf
     if world > 1:
-        # replicas must have stayed identical: same initial weights + summed gradients -> same updates on every rank
-        chk = torch.stack([torch.cat([p.detach().double().flatten() for p in m.parameters()]).abs().sum()
-                           for m in (state.G, state.D)]).to(dev)
-        allc = [torch.zeros_like(chk) for _ in range(world)]
-        torch.distributed.all_gather(allc, chk)
-        if not all(torch.equal(allc[0], c) for c in allc):
-            raise SystemExit("data-parallel replicas diverged: %s" % [c.tolist() for c in allc])
-        result["config"]["replicas_identical"] = True
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(init)
+        result["config"]["replicas_identical"] = replicas_identical(w, world, dev)
+    if rank == 0 and world == 1 and name == "dcgan" and not args.no_extra:
+        # the other GPU configs of BASELINE.json, briefly (north_star names CycleGAN 256x256 bs 8 as the second target)
+        init = w.init
+        del w, out
+        torch.cuda.empty_cache()
+        extra = {}
+        for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10)):
+            try:
+                ow = BUILDERS[other](dp, rank, dev, argparse.Namespace(batch=0, no_graph=False), k + wu)
+                ob, oo = timed_blocks(ow, 1, dev, k, wu, 1.0, max_blocks=10)
+                e = summarise(other, ow.batch, 1, k, ob)
+                e.update(workload=WORKLOAD_NAME[other], steps=k, warmup=wu, hipgraph=ow.graphed,
+                         peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                         losses={kk: float(v) for kk, v in oo.items() if "loss" in kk})
+                extra[other] = e
+                del ow, oo
+            except Exception as ex:  # the headline line must survive a failure here
+                extra[other] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
+            torch.cuda.empty_cache()
+        result["extra"] = extra
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(init)
+    elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(w.init)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

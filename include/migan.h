@@ -69,14 +69,24 @@ int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls);
 size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci);
 int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi,
                        int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
-                       int gather, int accumulate, float* db, int db_accumulate, void* stream);
+                       int gather, int accumulate, float* db, int db_accumulate, const float* db_slabs, int db_nslab,
+                       void* stream);
 /* db != NULL: the bias gradient db[Co] = sum over pixels of dy (aten::convolution_backward grad_bias / the sum in
- * AddmmBackward) is produced by the same launches - the column-tile-0 workgroups sum their dy tiles, which are already
- * in LDS as the A operand, and the reduction launch adds the per-split slabs - instead of by a separate two-launch
- * column sum that re-reads dy from HBM.  Only where migan_conv2d_wgrad_fuses_bias() returns 1 (MFMA path).  On MI355X
- * this measured no faster than migan_colsum (the column-0 workgroups become the tail of the launch), so the host
- * mirror passes NULL unless MIGAN_FUSE_BIAS=1. */
+ * AddmmBackward) comes out of the wgrad's fixed-order reduction launch instead of a separate two-launch column sum
+ * that re-reads dy from HBM:
+ *   db_slabs != NULL: db_nslab x [Co] per-block column sums of dy, written by the streaming kernel that PRODUCED dy
+ *     (migan_norm_bwd / migan_norm_bwd_apply / migan_act_bwd_colsum, csum argument); any wgrad path accepts them.
+ *   db_slabs == NULL: the column-tile-0 workgroups of the MFMA wgrad sum their dy tiles (already in LDS as the A
+ *     operand) - only where migan_conv2d_wgrad_fuses_bias() returns 1; measured no faster than migan_colsum on MI355X
+ *     (those workgroups become the tail of the launch), so the host mirror uses it only with MIGAN_FUSE_BIAS=1. */
 int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int gather);
+/* Input gradient of nn.ReflectionPad2d(1) -> nn.Conv2d(Ci, Co, 3) (cyclegan/models.py:26-35) straight into
+ * dx [N][H][W][Ci] from dy [N][H][W][Co], w_ihwo [Ci][3][3][Co]: the ordinary pad-1 dgrad plus a second small launch
+ * that ADDS the terms of the reflected ring onto rows/columns 1 and H-2 (no (H+2)x(W+2) intermediate, no fold pass, and
+ * the GEMM keeps M = N*H*W rows).  Needs H, W >= 4, Co % 4 == 0, Co >= 8, Ci > 4; otherwise returns an error and the
+ * caller runs migan_conv2d_dgrad on the padded extent + migan_gather2d_bwd. */
+int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                                void* stream);
 
 /* Phase-collapsed nn.Upsample(scale_factor=2) -> nn.Conv2d(Ci, Co, 3, stride=1, padding=1)
  * (dcgan.py:54-55,58-59; cyclegan/models.py:74-75): the 4 output phases are 2x2 convs of the un-upsampled input with
@@ -91,7 +101,8 @@ int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx, int N, in
                           void* stream);
 size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci);
 int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H,
-                          int W, int Ci, int Co, int accumulate, float* db, int db_accumulate, void* stream);
+                          int W, int Ci, int Co, int accumulate, float* db, int db_accumulate, const float* db_slabs,
+                          int db_nslab, void* stream);
 
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:
@@ -107,10 +118,37 @@ int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_
 int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const float* res, int G, int P, int C, int act, float slope,
                      void* stream);
-/* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1. */
+/* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1.
+ * csum (optional): migan_norm_colsum_slabs(G,P,C) x [C] per-block column sums of dx - the bias gradient of the conv in
+ * front of the norm layer is reduced from them inside that conv's wgrad launch (migan_conv2d_wgrad db_slabs). */
+int migan_norm_colsum_slabs(int G, int P, int C);
 int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                    const float* beta, float* dx, float* dgamma, float* dbeta, int G, int P, int C, int act,
-                   float slope, float* ws, size_t ws_bytes, int accumulate, void* stream);
+                   float slope, float* ws, size_t ws_bytes, int accumulate, float* csum, void* stream);
+/* The two halves of migan_norm_bwd, for cross-replica BatchNorm (data parallel): sums [G][C][2] =
+ * (sum dyz, sum dyz*xhat) over this rank's pixels are all-reduced (SUM) between them and P_total = world * P. */
+int migan_norm_bwd_sums(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, float* sums, float* dgamma, float* dbeta, int G, int P, int C, int act,
+                        float slope, float* ws, size_t ws_bytes, int accumulate, void* stream);
+int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, const float* sums, int G, int P, int C, int act,
+                         float slope, long long P_total, float* csum, void* stream);
+/* Cross-replica BatchNorm forward: migan_norm_moments = this rank's mean and BIASED variance [C] (no eps, no running
+ * statistics); after an all_gather into [world][2][C], migan_norm_sync_finalize combines the equal shards (Chan, in
+ * double) into the global-batch mean / invstd and updates the running statistics with the global unbiased variance -
+ * the statistics the single-process reference computes on the whole batch (dcgan.py:53-60, srgan/models.py:23-26). */
+int migan_norm_moments(const float* x, float* mean, float* var, int G, int P, int C, float* ws, size_t ws_bytes,
+                       void* stream);
+int migan_norm_sync_finalize(const float* gathered, int world, long long P_local, float* mean, float* invstd,
+                             float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                             float eps, int C, void* stream);
+/* eval-mode BatchNorm: invstd[c] = 1/sqrt(running_var[c] + eps). */
+int migan_rsqrt_eps(const float* var, float* invstd, int C, float eps, void* stream);
+/* Backward of `activation [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y)
+ * (mask_gc may be NULL, act may be 0, y = the layer output) AND migan_norm_colsum_slabs(G,P,C) x [C] column-sum slabs
+ * of dx for the conv's bias gradient (dcgan.py:62-63,78: Conv->Tanh, Conv->LeakyReLU->Dropout2d). */
+int migan_act_bwd_colsum(const float* dy, const float* y, const float* mask_gc, float* dx, float* csum, int G, int P,
+                         int C, int act, float slope, void* stream);
 
 /* ---- Pointwise / index-remap kernels (csrc/eltwise.hip) ------------------------------------------------
  * nn.LeakyReLU(0.2)/ReLU/Tanh/Sigmoid: dcgan.py:57,63,92  cyclegan/models.py:30,52,82,110 ... */

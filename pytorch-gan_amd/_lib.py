@@ -59,17 +59,25 @@ _SIGS = {
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
-    "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P]),
+    "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P, c_int, P]),
+    "migan_conv2d_dgrad_reflect1": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "migan_conv2d_wgrad_fuses_bias": (c_int, [c_int] * 6),
     "migan_upconv3x3_pack": (c_int, [P, P, P, c_int, c_int, P]),
     "migan_upconv3x3_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),
     "migan_upconv3x3_dgrad": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "migan_upconv3x3_wgrad_workspace": (c_size_t, [c_int] * 5),
-    "migan_upconv3x3_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 6 + [P, c_int, P]),
+    "migan_upconv3x3_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 6 + [P, c_int, P, c_int, P]),
     "migan_norm_workspace": (c_size_t, [c_int] * 3),
     "migan_norm_stats": (c_int, [P, P, P, P, P, P, c_float, c_float, c_int, c_int, c_int, P, c_size_t, P]),
     "migan_norm_apply": (c_int, [P] * 7 + [c_int] * 4 + [c_float, P]),
-    "migan_norm_bwd": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, c_int, P]),
+    "migan_norm_colsum_slabs": (c_int, [c_int] * 3),
+    "migan_norm_bwd": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, c_int, P, P]),
+    "migan_norm_bwd_sums": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, c_int, P]),
+    "migan_norm_bwd_apply": (c_int, [P] * 8 + [c_int] * 4 + [c_float, ctypes.c_longlong, P, P]),
+    "migan_norm_moments": (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "migan_norm_sync_finalize": (c_int, [P, c_int, ctypes.c_longlong, P, P, P, P, P, c_float, c_float, c_int, P]),
+    "migan_rsqrt_eps": (c_int, [P, P, c_int, c_float, P]),
+    "migan_act_bwd_colsum": (c_int, [P] * 5 + [c_int] * 4 + [c_float, P]),
     "migan_act_fwd": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "migan_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
     "migan_reduce_workspace": (c_size_t, []),

@@ -20,9 +20,10 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <math.h>
 
 #define MAX_TAPS 96
-#define MAX_CLS 4
+#define MAX_CLS 16
 
 struct ConvGeom {
     int N, Hi, Wi, Ci;   // physical source tensor (NHWC)
@@ -31,6 +32,7 @@ struct ConvGeom {
     int HoF, WoF;        // full output extent
     int ostep, istride;  // output sub-grid step (parity classes), source step per output index
     int gather, ldw, ncls;
+    int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
@@ -40,7 +42,7 @@ struct ConvGeom {
     unsigned mg_hw[MAX_CLS], mg_w[MAX_CLS];
     int sh_hw[MAX_CLS], sh_w[MAX_CLS];
     int wofs[MAX_TAPS];
-    signed char dh[MAX_TAPS], dw[MAX_TAPS];
+    short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
 };
 
 // q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
                     if (bias) v += bias[col];
                     float o = act_apply(v, g.act, g.slope);
                     if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
                 }
             }
@@ -584,6 +587,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                     if (bias) v += bias[col];
                     float o = act_apply(v, g.act, g.slope);
                     if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
+                    if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
                 }
             }
@@ -810,6 +814,7 @@ __global__ __launch_bounds__(256, 2) void igemm_db_kernel(const ConvGeom g, cons
                     if (bias) v += bias[col];
                     float o = act_apply(v, g.act, g.slope);
                     if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
+                    if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
                 }
             }
@@ -1345,9 +1350,9 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     }
     static const int var_env = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
     const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
-    if (var != 100 && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
-    if (var != 100 && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
-    if (g.Co <= 4 && var != 100 && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
+    if (var != 100 && !g.accum && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
+    if (var != 100 && !g.accum && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
+    if (g.Co <= 4 && var != 100 && !g.accum && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
         ThinConv tc = {};
         size_t lds = 0;
         int max_tiles = 0;
@@ -1414,8 +1419,8 @@ static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bia
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {
             int t = r * S + s;
-            g.dh[t] = (signed char)(r - pad_t);
-            g.dw[t] = (signed char)(s - pad_l);
+            g.dh[t] = (short)(r - pad_t);
+            g.dw[t] = (short)(s - pad_l);
             g.wofs[t] = t * Ci;
         }
     return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
@@ -1467,8 +1472,8 @@ MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const flo
                 for (int s = 0; s < S; ++s) {
                     int ew = pw + pad_l - s;
                     if (ew % stride != 0) continue;
-                    g.dh[tp] = (signed char)(eh / stride);
-                    g.dw[tp] = (signed char)(ew / stride);
+                    g.dh[tp] = (short)(eh / stride);
+                    g.dw[tp] = (short)(ew / stride);
                     g.wofs[tp] = (r * S + s) * Co;
                     ++tp;
                 }
@@ -1476,6 +1481,59 @@ MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const flo
             g.ntap[c] = tp - g.tapbeg[c];
         }
     return launch_igemm(g, dy, w_ihwo, bias, dx, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input gradient of  nn.ReflectionPad2d(1) -> nn.Conv2d(C, K, 3)  (the two convs of every CycleGAN ResidualBlock,
+// cyclegan/models.py:26-35) WITHOUT the padded (H+2) x (W+2) intermediate.  With xp = reflect-pad(x):
+//     dx[q] = sum over padded positions i with refl(i) = q of dxp[i],   dxp = zero-pad dgrad of the conv.
+// Every interior position maps to itself, and only the ring i = -1 / i = H folds back, onto rows/columns 1 and H-2:
+//   launch 1: the ordinary pad-1 dgrad straight into dx  (M = N*H*W: e.g. exactly 1024 128x64 workgroups for
+//             8 x 256 x 64 x 64, where the padded 66 x 66 extent gave 1092 = one wave of the chip + a 7 % tail that cost
+//             20 % of the launch, plus a 35.7 MB intermediate and a fold pass);
+//   launch 2: the folded ring terms ADDED into rows/columns 1 and H-2 - 16 disjoint rectangular classes whose tap lists
+//             are the conv taps that reach the ring: 3 taps per edge pixel, 7 per corner, ~1 % of the work of launch 1.
+// Returns hipErrorInvalidValue for geometries outside this case (caller uses migan_conv2d_dgrad + migan_gather2d_bwd).
+// ------------------------------------------------------------------------------------------------
+MIGAN_API int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci,
+                                          int Co, void* stream) {
+    if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
+    int rc = migan_conv2d_dgrad(dy, w_ihwo, nullptr, dx, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.f, stream);
+    if (rc) return rc;
+    ConvGeom g = {};
+    g.N = N; g.Hi = H; g.Wi = W; g.Ci = Co; g.HiL = H; g.WiL = W;  // source = dy (same extent as dx for 3x3 / pad 1)
+    g.Co = Ci; g.HoF = H; g.WoF = W; g.ostep = 1; g.istride = 1; g.gather = GATHER_ZERO; g.ldw = 9 * Co;
+    g.accum = 1;
+    int tp = 0, c = 0;
+    // Rows (and columns alike) fall into 5 segments: {0}, {1}, [2, H-3], {H-2}, {H-1}.  Segment {1} also receives the ring
+    // row i = -1, reached by conv tap r = 0 only, which reads dy row 0 = q - 1; segment {H-2} receives ring row i = H,
+    // reached by r = 2, reading dy row H-1 = q + 1; the other segments have no ring term.  One class per (row segment,
+    // column segment) pair with at least one ring term: 16 disjoint rectangles.  Tap list of a class = ring-row x interior
+    // columns (3 taps), interior rows x ring-column (3 taps), ring-row x ring-column (1 tap), as applicable.  The kernels
+    // form the source coordinate as (class-local output index) + tap offset, so the class origin is folded into the offsets.
+    const int seg0[5] = {0, 1, 2, H - 2, H - 1}, segn_h[5] = {1, 1, H - 4, 1, 1};
+    const int segw0[5] = {0, 1, 2, W - 2, W - 1}, segn_w[5] = {1, 1, W - 4, 1, 1};
+    const int ring_tap[5] = {-1, 0, -1, 2, -1};   // conv tap index (r or s) that reaches the ring, -1: none
+    const int ring_off[5] = {0, -1, 0, +1, 0};    // its source offset relative to q
+    for (int a = 0; a < 5; ++a)
+        for (int b2 = 0; b2 < 5; ++b2) {
+            if (ring_tap[a] < 0 && ring_tap[b2] < 0) continue;
+            g.oh0[c] = seg0[a]; g.ow0[c] = segw0[b2];
+            g.Ho[c] = segn_h[a] > 0 ? segn_h[a] : 0; g.Wo[c] = segn_w[b2] > 0 ? segn_w[b2] : 0;
+            g.tapbeg[c] = tp;
+            auto add_tap = [&](int dh, int dw, int r, int s_) {
+                g.dh[tp] = (short)(dh + g.oh0[c]); g.dw[tp] = (short)(dw + g.ow0[c]); g.wofs[tp] = (r * 3 + s_) * Co; ++tp;
+            };
+            if (ring_tap[a] >= 0)
+                for (int s_ = 0; s_ < 3; ++s_) add_tap(ring_off[a], 1 - s_, ring_tap[a], s_);
+            if (ring_tap[b2] >= 0)
+                for (int r = 0; r < 3; ++r) add_tap(1 - r, ring_off[b2], r, ring_tap[b2]);
+            if (ring_tap[a] >= 0 && ring_tap[b2] >= 0) add_tap(ring_off[a], ring_off[b2], ring_tap[a], ring_tap[b2]);
+            g.ntap[c] = tp - g.tapbeg[c];
+            ++c;
+        }
+    g.ncls = c;  // 16
+    return launch_igemm(g, dy, w_ihwo, nullptr, dx, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1716,16 +1774,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
     // the dy / x pixel range they all re-read is served by that XCD's L2 instead of 8 separate L2s + Infinity Cache.
     int split, tile;
     {
+        // workgroup b runs on XCD b % 8: XCD x takes the x-th CONTIGUOUS eighth of the split-major (split, tile) list, so
+        // the tiles of one split - which all re-read that split's dy / x pixel range - run on one XCD (two at a seam)
         const int tiles = g.tiles_m * g.tiles_n;
-        if (g.splits % 8 == 0) {
-            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-            const int sg = k / tiles;
-            tile = k - sg * tiles;
-            split = sg * 8 + xcd;
-        } else {
-            split = blockIdx.x / tiles;
-            tile = blockIdx.x - split * tiles;
-        }
+        const int total = tiles * g.splits, per = (total + 7) >> 3;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int lin = xcd * per + k;
+        if (k >= per || lin >= total) return;
+        split = lin / tiles;
+        tile = lin - split * tiles;
     }
     const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
     const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
@@ -1916,16 +1973,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
     const int Mpix = g.N * HoWo;
     int split, tile;  // XCD-aware block order, see wgrad_pipe_kernel
     {
+        // workgroup b runs on XCD b % 8: XCD x takes the x-th CONTIGUOUS eighth of the split-major (split, tile) list, so
+        // the tiles of one split - which all re-read that split's dy / x pixel range - run on one XCD (two at a seam)
         const int tiles = g.tiles_m * g.tiles_n;
-        if (g.splits % 8 == 0) {
-            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-            const int sg = k / tiles;
-            tile = k - sg * tiles;
-            split = sg * 8 + xcd;
-        } else {
-            split = blockIdx.x / tiles;
-            tile = blockIdx.x - split * tiles;
-        }
+        const int total = tiles * g.splits, per = (total + 7) >> 3;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int lin = xcd * per + k;
+        if (k >= per || lin >= total) return;
+        split = lin / tiles;
+        tile = lin - split * tiles;
     }
     const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
     const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
@@ -2115,14 +2171,25 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
 // Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
 // `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
 // split loop (LDS combine in fixed order) when there are many splits and few outputs.
-// bias slabs [nslab][Co] -> db[co] (fixed order, double accumulation); run by the trailing blocks of the reduce launches
+// bias slabs [nslab][Co] -> db[co] (fixed order); run by the trailing blocks of the reduce launches.  A block owns
+// BIAS_CB channels; its 256 / BIAS_CB slab-lanes each add every (256 / BIAS_CB)-th slab in double, then lane 0 adds the
+// lanes in order: the slabs of the streaming backward kernels number in the thousands (one per block of the pass).
+#define BIAS_CB 16
 __device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bpart, float* __restrict__ db, int nslab,
                                                  int Co, int accum, int blk) {
-    const int co = blk * 256 + threadIdx.x;
-    if (co >= Co) return;
+    constexpr int LANES = 256 / BIAS_CB;
+    __shared__ double bred[256];
+    const int cl = threadIdx.x % BIAS_CB, ln = threadIdx.x / BIAS_CB;
+    const int co = blk * BIAS_CB + cl;
     double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += (double)bpart[(size_t)k * Co + co];
-    db[co] = accum ? db[co] + (float)s : (float)s;
+    if (co < Co)
+        for (int k = ln; k < nslab; k += LANES) s += (double)bpart[(size_t)k * Co + co];
+    bred[threadIdx.x] = s;
+    __syncthreads();
+    if (ln == 0 && co < Co) {
+        for (int q = 1; q < LANES; ++q) s += bred[q * BIAS_CB + cl];
+        db[co] = accum ? db[co] + (float)s : (float)s;
+    }
 }
 struct BiasRed {
     const float* bpart;  // NULL: no bias work
@@ -2165,7 +2232,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, int accum,
                                hipStream_t st, BiasRed br = BiasRed{}) {
     long total = (long)Co * T * Ci;
-    const int extra = br.bpart ? cdiv(Co, 256) : 0;
+    const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
     if (splits >= 64 && total < (1 << 16)) {
         br.main_blocks = cdiv(total, 16);
         hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
@@ -2193,23 +2260,57 @@ static int wgrad_bn(int Co, int Ncol) {
     if (Co > 64 && Ncol > 64) return 128;
     return (Co > 32 && Ncol >= 128 && wgrad_var() != 64) ? 128 : 64;
 }
+// Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
+static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 3 : (bm * bn >= 8192 ? 4 : 7); }
+
+// Split-K factor.  The launch is tiles * splits workgroups on 256 CUs x occ resident slots: a count just above a whole
+// number of waves leaves a tail that runs at a fraction of the chip (R256 wgrad, cyclegan/models.py:28: 36 tiles x 32
+// splits = 1152 blocks on 768 slots = 1.5 waves), and every split costs a slab of partial sums that the reduction
+// re-reads.  First-order time model, minimised over the split count:
+//   t(s) = (KT + c0) * t1 * [floor(W) * occ + max(frac(W) * occ, lone)]  +  s * outputs * 8 B / 3 TB/s
+// W = tiles * s / slots (waves), KT = K-tiles per block, t1 = MFMA time of one block K-tile, c0 = prologue + epilogue in
+// K-tile units, `lone` = a partly filled CU cannot go faster than ~1.3 block-steps (latency no longer hidden).
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
+    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 2;  // 1 = round-1 rule
     long Mpix = (long)N * Ho * Wo;
     // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
     // the split-K factor fills the chip (measured: G.conv1 up-conv wgrad 209 -> 186 us, PatchGAN 4x4 s2 wgrads -10 %,
     // while Conv2d(64,256) on 590k pixels prefers 128x128)
     BMsel = (Co > 128 && Ncol > 64 && Mpix * ncls > 16384) ? 128 : 64;
-    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, wgrad_bn(Co, Ncol)) * ncls;
-    long want = cdiv(1024, tiles);
+    const int bn = wgrad_bn(Co, Ncol);
+    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, bn) * ncls;
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
-    if (want > maxs) want = maxs;
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
+    if (maxs > 512) maxs = 512;
+    if (maxs < 1) maxs = 1;
+    if (plan_env == 1) {
+        long want = cdiv(1024, tiles);
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
+        splits = cdiv(Mpix, pps);
+        if (splits > 4) splits = cdiv(splits, 8) * 8;  // round-1 launch order: whole splits per XCD, padded with empty ones
+        return;
+    }
+    const int occ = wgrad_occ(BMsel, bn);
+    const double slots = 256.0 * occ;
+    const double t1 = (double)(BMsel * bn / 4) / 2.4e9 / 0.8;  // seconds per block K-tile at 80 % of the MFMA rate
+    const double c0 = 6.0, lone = 1.3;
+    const double out_bytes = (double)Co * Ncol * ncls * 8.0;
+    double best = 1e30;
+    long best_s = 1;
+    for (long s_ = 1; s_ <= maxs; ++s_) {
+        const long pp = cdiv(cdiv(Mpix, s_), 32) * 32;
+        const long sp = cdiv(Mpix, pp);  // the split count this request really produces
+        if (sp != s_) continue;
+        const double W = tiles * (double)sp / slots;
+        const double fl = floor(W), fr = W - fl;
+        const double kt = (double)pp / 32.0;
+        double t = (kt + c0) * t1 * (fl * occ + (fr > 1e-9 ? (fr * occ > lone ? fr * occ : lone) : 0.0));
+        t += sp * out_bytes / 3.0e12 + (sp > 1 ? 4e-6 : 0.0);
+        if (t < best) { best = t; best_s = sp; }
+    }
+    pps = (int)(cdiv(cdiv(Mpix, best_s), 32) * 32);
     splits = cdiv(Mpix, pps);
-    // XCD-aware launch order wants a multiple of 8 splits (one split per XCD at a time); the padding splits have
-    // empty pixel ranges and write zero slabs
-    if (splits > 4) splits = cdiv(splits, 8) * 8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2269,8 +2370,8 @@ MIGAN_API int migan_upconv3x3_fwd(const float* x, const float* wf, const float* 
             for (int ih = 0; ih < 2; ++ih)
                 for (int iw = 0; iw < 2; ++iw) {
                     int slot = (c * 2 + ih) * 2 + iw;
-                    g.dh[slot] = (signed char)(a - 1 + ih);
-                    g.dw[slot] = (signed char)(b - 1 + iw);
+                    g.dh[slot] = (short)(a - 1 + ih);
+                    g.dw[slot] = (short)(b - 1 + iw);
                     g.wofs[slot] = slot * Ci;
                 }
         }
@@ -2287,8 +2388,8 @@ MIGAN_API int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx,
     g.oh0[0] = 0; g.ow0[0] = 0; g.Ho[0] = H; g.Wo[0] = W; g.tapbeg[0] = 0; g.ntap[0] = 16;
     for (int slot = 0; slot < 16; ++slot) {
         int iw = slot & 1, ih = (slot >> 1) & 1, b = (slot >> 2) & 1, a = slot >> 3;
-        g.dh[slot] = (signed char)(2 - a - 2 * ih);
-        g.dw[slot] = (signed char)(2 - b - 2 * iw);
+        g.dh[slot] = (short)(2 - a - 2 * ih);
+        g.dw[slot] = (short)(2 - b - 2 * iw);
         g.wofs[slot] = slot * Co;
     }
     return launch_igemm(g, dy, wd, nullptr, dx, (hipStream_t)stream);
@@ -2345,7 +2446,7 @@ MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, in
 // un-collapsing reduction - is 4x smaller than with one launch per phase.
 MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                     int N, int H, int W, int Ci, int Co, int accumulate, float* db, int db_accumulate,
-                                    void* stream) {
+                                    const float* db_slabs, int db_nslab, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (Co % 4 != 0 || Ci % 4 != 0) return (int)hipErrorInvalidValue;
     if (ws_bytes < migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)) return (int)hipErrorInvalidValue;
@@ -2358,12 +2459,12 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     fastdiv_magic((unsigned)W, g.mg_w, g.sh_w);
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
     float* bpart = ws + (size_t)4 * g.splits * Co * Ncol;
-    g.bpart = db ? bpart : nullptr;
+    g.bpart = (db && !db_slabs) ? bpart : nullptr;  // in-kernel column sums only when no external slabs are given
     const bool inc = wgrad_var() != 200 && (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31);
 #define UPW_LAUNCH(BM_, BN_)                                                                                       \
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
-        dim3 grid_(g.tiles_m * g.tiles_n * g.splits, 4);                                                           \
+        dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8, 4);                                                           \
         if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
@@ -2374,7 +2475,8 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
     BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64)};
-    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + (db ? cdiv(Co, 256) : 0)), dim3(256), 0, st, ws,
+    if (db && db_slabs) { br.bpart = db_slabs; br.nslab = db_nslab; }
+    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + (br.bpart ? cdiv(Co, BIAS_CB) : 0)), dim3(256), 0, st, ws,
                        dw_oihw, g.splits, Co, Ci, accumulate, br);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -2692,8 +2794,8 @@ static bool thin_wgrad_tile_plan(int N, int Hi, int Wi, int Ci, int Ho, int Wo, 
     g.ncls = 1; g.Ho[0] = Ho; g.Wo[0] = Wo; g.ntap[0] = R * S;
     for (int r = 0; r < R; ++r)
         for (int s2 = 0; s2 < S; ++s2) {
-            g.dh[r * S + s2] = (signed char)(r - pad_t);
-            g.dw[r * S + s2] = (signed char)(s2 - pad_l);
+            g.dh[r * S + s2] = (short)(r - pad_t);
+            g.dw[r * S + s2] = (short)(s2 - pad_l);
             g.wofs[r * S + s2] = (r * S + s2) * Ci;
         }
     size_t l0 = 0;
@@ -2736,9 +2838,12 @@ MIGAN_API int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int st
 MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
                                  int stride, int pad_t, int pad_l, int gather, int accumulate, float* db,
-                                 int db_accumulate, void* stream) {
+                                 int db_accumulate, const float* db_slabs, int db_nslab, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (db && !migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather)) return (int)hipErrorInvalidValue;
+    if (db && !db_slabs && !migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather)) return (int)hipErrorInvalidValue;
+    // external bias slabs (per-block column sums of dy written by the kernel that produced dy): every path below ends in
+    // a fixed-order reduction launch whose trailing blocks add them into db
+    const BiasRed ext = (db && db_slabs) ? BiasRed{db_slabs, db, db_nslab, db_accumulate, 0} : BiasRed{};
     if (thin_wgrad_ok(Co, R, S, Ci, stride, gather)) {
         ThinGeom tg = {N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, 0, 0, 0};
         thin_plan(N, Hi, Wi, Ci, tg);
@@ -2749,7 +2854,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else if (S == 3) launch_thin<3>(Co, grid, lds, st, tg, x, dy, ws);
         else launch_thin<4>(Co, grid, lds, st, tg, x, dy, ws);
         HIP_LAUNCH_CHECK();
-        return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st);
+        return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st, ext);
     }
     static const int small_on = getenv("MIGAN_SMALL_WGRAD") ? atoi(getenv("MIGAN_SMALL_WGRAD")) : 1;  // A/B knob
     if (small_on && Co * R * S * Ci <= 256 && Co <= 64 && R * S * Ci <= 64 && !(Co % 4 == 0 && Ci % 4 == 0)) {
@@ -2766,7 +2871,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             const size_t lds = (size_t)128 * (Co + R * S * Ci) * sizeof(float);
             hipLaunchKernelGGL(small_wgrad_kernel, dim3(nblk), dim3(256), lds, st, sg, x, dy, ws);
             HIP_LAUNCH_CHECK();
-            return launch_wgrad_reduce(ws, dw_oihw, nblk, Co, R * S, Ci, accumulate, st);
+            return launch_wgrad_reduce(ws, dw_oihw, nblk, Co, R * S, Ci, accumulate, st, ext);
         }
     }
     if (Co <= 4) {
@@ -2784,7 +2889,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
                 default: hipLaunchKernelGGL((thin_wgrad_tile_kernel<4>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
             }
             HIP_LAUNCH_CHECK();
-            return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, accumulate, st);
+            return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, accumulate, st, ext);
         }
     }
     WgradGeom g = {};
@@ -2797,7 +2902,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     wgrad_plan(N, Ho, Wo, Co, Ncol, bm, g.splits, g.pix_per_split);
     if (((size_t)g.splits * Co * Ncol + (size_t)g.splits * Co) * sizeof(float) > ws_bytes) return (int)hipErrorInvalidValue;
     bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
-    g.bpart = db ? ws + (size_t)g.splits * Co * Ncol : nullptr;
+    g.bpart = (db && !db_slabs) ? ws + (size_t)g.splits * Co * Ncol : nullptr;
     fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
     const int wvar = wgrad_var();  // 100 = old kernel (only in -DMIGAN_ABLATION builds)
@@ -2815,7 +2920,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
 #define WG_LAUNCH(BM_, BN_)                                                                                        \
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
-        dim3 grid_(g.tiles_m * g.tiles_n * g.splits);                                                              \
+        dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);                                                              \
         if (inc && refl)                                                                                           \
             hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
         else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
@@ -2825,7 +2930,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
 #ifdef MIGAN_ABLATION
             if (wvar == 1 || wvar == 2 || wvar == 3) {
                 g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
-                dim3 grid(g.tiles_m * g.tiles_n * g.splits);
+                dim3 grid(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);
                 if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
                 else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
                 else hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
@@ -2842,7 +2947,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
 #undef WG_LAUNCH
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st,
-                                   BiasRed{g.bpart, db, g.splits, db_accumulate, 0});
+                                   ext.bpart ? ext : BiasRed{g.bpart, db, g.splits, db_accumulate, 0});
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
@@ -2860,5 +2965,5 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
-    return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st);
+    return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st, ext);
 }

@@ -8,6 +8,25 @@
 // G=N,P=H*W.  All kernels are HBM-bound; loads are 16 B/lane when C%4==0.
 #include "common.h"
 
+// Per-block column sums: thread (tx, ty) holds the sums of its VW channels over its pixel lane; the ty lanes are added
+// in a fixed order through LDS and lane ty == 0 writes slab[(g * gridDim.y + chunk)][c .. c+VW).
+template <int VW>
+__device__ __forceinline__ void colsum_slab_store(const float (&cs)[VW], float* red, float* __restrict__ csum, int tid,
+                                                  int tx, int CTX, int TY, bool cok, int c, int C) {
+#pragma unroll
+    for (int v = 0; v < VW; ++v) red[tid * VW + v] = cs[v];
+    __syncthreads();
+    if (tid / CTX == 0 && cok) {
+        float* out = csum + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c;
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            float a = 0.f;
+            for (int y = 0; y < TY; ++y) a += red[(y * CTX + tx) * VW + v];
+            out[v] = a;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stats pass 1: per (g, chunk, c) partial (sum, sumsq) [and for backward: sum(dyz), sum(dyz*xhat)]
 // thread layout: tx = tid % CTX walks channel vectors, ty = tid / CTX walks pixels.
@@ -108,7 +127,8 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
 // chunks, butterfly reduce), writes mean / invstd and updates the running statistics.
 __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ mean,
-                                                                float* __restrict__ invstd, float* running_mean,
+                                                                float* __restrict__ invstd, float* __restrict__ var_out,
+                                                                float* running_mean,
                                                                 float* running_var, long long* nbt, int G, int P,
                                                                 int C, int nchunks, int chunk, float eps,
                                                                 float momentum) {
@@ -135,7 +155,8 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
     const double m = K + md;
     double var = M2 / P;
     mean[i] = (float)m;
-    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (invstd) invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (var_out) var_out[i] = (float)var;
     if (running_mean && G == 1) {
         double unb = P > 1 ? M2 / (double)(P - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
@@ -222,26 +243,28 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, int P, int C, int CTX, int chunk, int act,
-    float slope) {
+    float slope, float invP, float* __restrict__ csum) {
+    __shared__ float red[256 * VW];
     const int tid = threadIdx.x;
     const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
     const int g = blockIdx.z;
     const int c = (blockIdx.x * CTX + tx) * VW;
-    if (c >= C) return;
-    const float invP = 1.f / (float)P;
-    float mu[VW], is[VW], ga[VW], be[VW], k0[VW], k1[VW];
+    const bool cok = c < C;
+    if (!cok && !csum) return;
+    float mu[VW], is[VW], ga[VW], be[VW], k0[VW], k1[VW], cs[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) {
-        const size_t gc = (size_t)g * C + c + v;
+        cs[v] = 0.f;
+        const size_t gc = (size_t)g * C + (cok ? c + v : 0);
         mu[v] = mean[gc];
         is[v] = invstd[gc];
-        ga[v] = gamma ? gamma[c + v] : 1.f;
-        be[v] = beta ? beta[c + v] : 0.f;
+        ga[v] = (gamma && cok) ? gamma[c + v] : 1.f;
+        be[v] = (beta && cok) ? beta[c + v] : 0.f;
         k0[v] = sums[gc * 2] * invP;
         k1[v] = sums[gc * 2 + 1] * invP;
     }
     const int p0 = blockIdx.y * chunk;
-    int p1 = p0 + chunk;
+    int p1 = cok ? p0 + chunk : p0;
     if (p1 > P) p1 = P;
     const size_t base = (size_t)g * P * C + c;
 #pragma unroll 4
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
                 else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
             }
             ov[k] = ga[k] * is[k] * (d - k0[k] - xh * k1[k]);
+            cs[k] += ov[k];
         }
         if (VW == 4) {
             const f32x4 o = {ov[0], ov[1], ov[2], ov[3]};
@@ -275,6 +299,58 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
             dx[e] = ov[0];
         }
     }
+    if (csum) colsum_slab_store<VW>(cs, red, csum, tid, tx, CTX, TY, cok, c, C);
+}
+
+// dx = dy * [mask[g][c]] * act'(y) (y = the activation output, masked when a Dropout2d mask is given) AND the
+// per-block column sums of dx: the backward of `Conv2d -> act [-> Dropout2d]` produces the gradient the conv's dgrad /
+// wgrad consume and the slabs its bias gradient is reduced from in ONE pass over dy (a separate two-launch column sum
+// re-read the tensor this kernel had just written).  Same thread layout as norm_apply_kernel.
+template <int VW>
+__global__ __launch_bounds__(256) void act_bwd_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const float* __restrict__ mask, float* __restrict__ dx,
+                                                             float* __restrict__ csum, int P, int C, int CTX, int chunk,
+                                                             int act, float slope) {
+    __shared__ float red[256 * VW];
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    const bool cok = c < C;
+    float mk[VW], cs[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+        cs[v] = 0.f;
+        mk[v] = (mask && cok) ? mask[(size_t)g * C + c + v] : 1.f;
+    }
+    const int p0 = blockIdx.y * chunk;
+    int p1 = cok ? p0 + chunk : p0;
+    if (p1 > P) p1 = P;
+    const size_t base = (size_t)g * P * C + c;
+#pragma unroll 4
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const size_t e = base + (size_t)p * C;
+        if (VW == 4) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + e);
+            f32x4 o;
+            if (act != ACT_NONE) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = d[k] * mk[k] * act_grad_from_out(v[k], act, slope);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = d[k] * mk[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs[k] += o[k];
+            *reinterpret_cast<f32x4*>(dx + e) = o;
+        } else {
+            const float o = dy[e] * mk[0] * (act != ACT_NONE ? act_grad_from_out(y[e], act, slope) : 1.f);
+            cs[0] += o;
+            dx[e] = o;
+        }
+    }
+    colsum_slab_store<VW>(cs, red, csum, tid, tx, CTX, TY, cok, c, C);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,11 +390,9 @@ static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3&
     grid = dim3(gx, cdiv(P, chunk), G);
 }
 
-// Training-mode statistics: mean/invstd [G][C] (+ running stat update when G==1 and pointers given).
-MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean,
-                               float* running_var, long long* num_batches_tracked, float momentum, float eps,
-                               int G, int P, int C, float* ws, size_t ws_bytes, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int norm_stats_impl(const float* x, float* mean, float* invstd, float* var_out, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float momentum, float eps, int G, int P,
+                           int C, float* ws, size_t ws_bytes, hipStream_t st) {
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
@@ -331,7 +405,61 @@ MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
-                       invstd, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps, momentum);
+                       invstd, var_out, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps,
+                       momentum);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Training-mode statistics: mean/invstd [G][C] (+ running stat update when G==1 and pointers given).
+MIGAN_API int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                               int G, int P, int C, float* ws, size_t ws_bytes, void* stream) {
+    return norm_stats_impl(x, mean, invstd, nullptr, running_mean, running_var, num_batches_tracked, momentum, eps, G, P,
+                           C, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Local moments only (mean and BIASED variance of this rank's shard): first half of cross-replica BatchNorm.
+MIGAN_API int migan_norm_moments(const float* x, float* mean, float* var, int G, int P, int C, float* ws,
+                                 size_t ws_bytes, void* stream) {
+    return norm_stats_impl(x, mean, nullptr, var, nullptr, nullptr, nullptr, 0.f, 0.f, G, P, C, ws, ws_bytes,
+                           (hipStream_t)stream);
+}
+
+// Second half: `gathered` = [world][2][C] (mean, biased variance) of `world` EQUAL shards of P_local pixels each
+// (all_gather of the migan_norm_moments outputs).  Chan's parallel combination in double -> global-batch mean / invstd,
+// running statistics updated with the global unbiased variance: exactly what the single-process reference computes on
+// the whole batch (dcgan.py:53-60, srgan/models.py:23-26, wgan_gp.py:49).
+__global__ void norm_sync_finalize_kernel(const float* __restrict__ gathered, int world, double P_local,
+                                          float* __restrict__ mean, float* __restrict__ invstd, float* running_mean,
+                                          float* running_var, long long* nbt, float momentum, float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double m = 0.0;
+    for (int r = 0; r < world; ++r) m += (double)gathered[((size_t)r * 2) * C + c];
+    m /= world;
+    double M2 = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double mr = (double)gathered[((size_t)r * 2) * C + c], vr = (double)gathered[((size_t)r * 2 + 1) * C + c];
+        M2 += P_local * (vr + (mr - m) * (mr - m));
+    }
+    const double Pt = P_local * world;
+    const double var = M2 / Pt;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = Pt > 1.0 ? M2 / (Pt - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+MIGAN_API int migan_norm_sync_finalize(const float* gathered, int world, long long P_local, float* mean, float* invstd,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       float momentum, float eps, int C, void* stream) {
+    if (world < 1 || C < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_sync_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
+                       (double)P_local, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -355,16 +483,26 @@ MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, cons
     return 0;
 }
 
-// Backward of y = act(norm(x)*gamma+beta) through the batch statistics.
-MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
-                             const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                             int G, int P, int C, int act, float slope, float* ws, size_t ws_bytes,
-                             int accumulate, void* stream) {
+// Number of [C]-slabs of per-block column sums the streaming backward kernels (migan_norm_bwd / migan_norm_bwd_apply /
+// migan_act_bwd_colsum) write for a [G][P][C] view.
+MIGAN_API int migan_norm_colsum_slabs(int G, int P, int C) {
+    if ((size_t)G * P * C == 0) return 0;
+    int VW, CTX, chunk;
+    dim3 grid;
+    apply_plan(G, P, C, VW, CTX, chunk, grid);
+    return (int)(grid.y * grid.z);
+}
+
+// Backward, first half: sums[G][C][2] = (sum dyz, sum dyz*xhat) over this rank's pixels (dyz = dy * act'(z));
+// dgamma/dbeta [C] written (or accumulated) when G == 1.
+MIGAN_API int migan_norm_bwd_sums(const float* x, const float* dy, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int G,
+                                  int P, int C, int act, float slope, float* ws, size_t ws_bytes, int accumulate,
+                                  void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
-    if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
-    float* sums = ws + (size_t)G * nchunks * C * 3;
+    if (ws_bytes < (size_t)G * nchunks * C * 3 * sizeof(float)) return (int)hipErrorInvalidValue;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
@@ -376,15 +514,75 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
     hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
                        dgamma, dbeta, G, C, nchunks, accumulate);
     HIP_LAUNCH_CHECK();
-    int VW2, CTX2, chunk2;
-    dim3 grid2;
-    apply_plan(G, P, C, VW2, CTX2, chunk2, grid2);
+    return 0;
+}
+
+// Backward, second half: dx = gamma*invstd*(dyz - sums0/P_total - xhat*sums1/P_total).  P_total = the number of pixels
+// the sums cover: P, or world*P after the sums were all-reduced for cross-replica BatchNorm.  csum (optional):
+// migan_norm_colsum_slabs() x [C] per-block column sums of dx, from which the preceding conv's bias gradient is
+// reduced inside its wgrad launch (migan_conv2d_wgrad db_slabs).
+MIGAN_API int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, const float* sums, int G, int P, int C,
+                                   int act, float slope, long long P_total, float* csum, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)G * P * C == 0) return 0;
+    int VW, CTX, chunk;
+    dim3 grid;
+    apply_plan(G, P, C, VW, CTX, chunk, grid);
+    const float invP = (float)(1.0 / (double)(P_total > 0 ? P_total : P));
     if (VW == 4)
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid2, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX2, chunk2, act, slope);
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+                           sums, P, C, CTX, chunk, act, slope, invP, csum);
     else
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid2, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX2, chunk2, act, slope);
+        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+                           sums, P, C, CTX, chunk, act, slope, invP, csum);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of y = act(norm(x)*gamma+beta) through the batch statistics (both halves; ws as migan_norm_workspace()).
+MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                             int G, int P, int C, int act, float slope, float* ws, size_t ws_bytes,
+                             int accumulate, float* csum, void* stream) {
+    if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    float* sums = ws + (size_t)G * nchunks * C * 3;
+    int rc = migan_norm_bwd_sums(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, act, slope, ws, ws_bytes,
+                                 accumulate, stream);
+    if (rc) return rc;
+    return migan_norm_bwd_apply(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act, slope, P, csum, stream);
+}
+
+// Backward of `act [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y) (mask may
+// be NULL, act may be 0) plus migan_norm_colsum_slabs(G, P, C) x [C] per-block column sums of dx (see above).
+MIGAN_API int migan_act_bwd_colsum(const float* dy, const float* y, const float* mask_gc, float* dx, float* csum, int G,
+                                   int P, int C, int act, float slope, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)G * P * C == 0) return 0;
+    if (!csum) return (int)hipErrorInvalidValue;
+    int VW, CTX, chunk;
+    dim3 grid;
+    apply_plan(G, P, C, VW, CTX, chunk, grid);
+    if (VW == 4)
+        hipLaunchKernelGGL((act_bwd_colsum_kernel<4>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
+                           act, slope);
+    else
+        hipLaunchKernelGGL((act_bwd_colsum_kernel<1>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
+                           act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// eval-mode BatchNorm: invstd[c] = 1/sqrt(running_var[c] + eps)  (cyclegan/pix2pix sample paths call .eval() models)
+__global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restrict__ invstd, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = (float)(1.0 / sqrt((double)var[c] + (double)eps));
+}
+MIGAN_API int migan_rsqrt_eps(const float* var, float* invstd, int C, float eps, void* stream) {
+    if (C <= 0) return 0;
+    hipLaunchKernelGGL(rsqrt_eps_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, var, invstd, C, eps);
     HIP_LAUNCH_CHECK();
     return 0;
 }

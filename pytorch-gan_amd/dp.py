@@ -8,8 +8,10 @@ The reference is single-process; this is the MI355X-native sca
     phase on the main stream (the D step consumes `gen.detach()` produced before the G update —
     dcgan.py:179, cyclegan.py:216-217 — so G's reduce+update overlaps D's forward/backward),
   * the 1/world_size averaging is folded into the Adam kernel (grad_scale).
-BatchNorm layers use per-rank batch statistics (standard data-parallel behaviour; documented deviation
-from a single-process global batch); InstanceNorm models shard with no semantic change.
+BatchNorm layers use per-rank batch statistics by default (standard data-parallel behaviour); with
+`enable_sync_batchnorm()` they use the statistics of the global batch, which restores the single-process
+semantics of the reference for the BatchNorm models.  InstanceNorm models shard with no
+semantic change either way.
 """
 import os
 
@@ -22,6 +24,7 @@ class LocalStepper:
 
     world = 1
     rank = 0
+    segment = False  # graph.StepRunner: one graph for the whole step
 
     def begin_step(self):
         pass
@@ -47,6 +50,9 @@ class DataParallel:
         # the host, which is how the 2-rank control flow is exercised on a single-GPU box)
         self.cuda = torch.cuda.is_available() and dist.get_backend(group) in ("nccl", "gloo")
         self.side = torch.cuda.Stream() if (self.cuda and overlap) else None
+        self.segment = True     # graph.StepRunner cuts the captured step at every step(): the collective replays eagerly
+        self.graph_ok = True    # False while cross-replica BatchNorm is on (collectives inside forward/backward)
+        self.sync_bn = None
         self._pending = []      # optimisers with an update in flight on the side stream (event in opt.pending)
         self._segmenter = None  # set by graph.StepRunner while it records the step
 
@@ -112,6 +118,26 @@ class DataParallel:
     def end_step(self):
         self._wait_now(None)
 
+    # -- cross-replica BatchNorm -------------------------------------------------------------------
+    def enable_sync_batchnorm(self):
+        """BatchNorm statistics (forward) and batch sums (backward) over the GLOBAL batch: with equal shards the N-rank
+        step then computes what the single-process reference computes on the whole batch for the BatchNorm models
+        (dcgan.py:53-60, srgan/models.py:23-26,47,87-90, wgan_gp.py:49), instead of per-rank statistics.  Costs one
+        all_gather of 2*C floats per BatchNorm forward and one all_reduce of 2*C floats per backward; these run inside
+        forward/backward, so the step can no longer be captured into hipGraphs (graph.StepRunner runs it eagerly)."""
+        from . import functional as F
+
+        self.sync_bn = _SyncBN(self)
+        self.graph_ok = False
+        F.set_sync_batchnorm(self.sync_bn)
+        return self.sync_bn
+
+    def disable_sync_batchnorm(self):
+        from . import functional as F
+
+        self.sync_bn, self.graph_ok = None, True
+        F.set_sync_batchnorm(None)
+
     # -- helpers -----------------------------------------------------------------------------------
     def shard(self, t):
         """This rank's slice of a global batch (dim 0), equal shards."""
@@ -126,6 +152,31 @@ class DataParallel:
         for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
+
+
+class _SyncBN:
+    """The two collectives of cross-replica BatchNorm, on the current stream (functional._Norm calls them)."""
+
+    def __init__(self, dp):
+        self.dp, self.world = dp, dp.world
+
+    def all_gather(self, t):
+        """[K] per rank -> [world * K], rank-major."""
+        k = t.numel()
+        if dist.get_backend(self.dp.group) == "nccl":
+            out = torch.empty(self.world * k, device=t.device, dtype=t.dtype)
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.dp.group)
+            return out
+        # gloo (CPU tests, 2-ranks-on-one-GPU test mode): a summed all-reduce of a buffer in which every rank filled only
+        # its own slot is the same gather, on the collective every backend implements for every device
+        out = torch.zeros(self.world * k, device=t.device, dtype=t.dtype)
+        out[self.dp.rank * k:(self.dp.rank + 1) * k] = t.reshape(-1)
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.dp.group)
+        return out
+
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.group)
+        return t
 
 
 def init_from_env(backend=None):

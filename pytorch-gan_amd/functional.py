@@ -236,6 +236,38 @@ def _colsum(x2d_ptr_tensor, P, C, slot=None):
     return out if slot is None else None
 
 
+_COLSUM_FUSE = __import__("os").environ.get("MIGAN_COLSUM_FUSE", "1") == "1"  # A/B knob
+
+
+def _attach_colsum(t, slabs, nslab, C):
+    """Remember that `slabs` ([nslab][C], written by the kernel that produced `t`) hold per-block column sums of `t`."""
+    t._migan_colsum = (slabs, nslab, C, t.data_ptr(), t._version)
+    return t
+
+
+def _colsum_side(t, C):
+    """(slabs, nslab) when the kernel that produced gradient `t` also left its column-sum slabs (and `t` is still that
+    data), else None.  autograd hands a Function's returned gradient object to the next node as is when nothing is
+    accumulated into it; pointer, version and width are checked anyway."""
+    side = getattr(t, "_migan_colsum", None)
+    if side is None or not _COLSUM_FUSE:
+        return None
+    slabs, nslab, c, ptr, ver = side
+    if c != C or ptr != t.data_ptr() or ver != t._version or not t.is_contiguous(memory_format=CL):
+        return None
+    return slabs, nslab
+
+
+def _act_bwd_colsum(dy, y, mask, N, HW, C, act, slope):
+    """dx = dy * mask[n][c] * act'(y) and its column-sum slabs in one pass (backward of conv -> act [-> Dropout2d])."""
+    g = torch.empty_like(dy)
+    nslab = lib.migan_norm_colsum_slabs(N, HW, C)
+    slabs = torch.empty(max(nslab * C, 1), device=dy.device, dtype=torch.float32)
+    check(lib.migan_act_bwd_colsum(dy.data_ptr(), _ptr(y), _ptr(mask), g.data_ptr(), slabs.data_ptr(), N, HW, C, act,
+                                   slope, _stream()), "act_bwd_colsum")
+    return g, (slabs, nslab)
+
+
 def _act_bwd_raw(dy, y, act, slope):
     dx = torch.empty_like(y)
     check(lib.migan_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), act, slope, _stream()), "act_bwd")
@@ -291,15 +323,24 @@ class _Conv2d(Function):
         xs, w, y, mask = ctx.saved_tensors
         N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
         dy = to_nhwc(dy)
-        if mask is not None:
-            g = torch.empty_like(y)
-            check(lib.migan_act_bwd_nc(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), N, Ho * Wo, Co, act,
-                                       slope, _stream()), "act_bwd_nc")
-            dy = g
-        elif act != ACT_NONE:
-            dy = _act_bwd_raw(dy, y, act, slope)
-        dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
+        # (this conv's activation backward, or the norm layer behind the conv) and reduced inside the wgrad launch
+        side = None
+        fuse_db = want_db and _COLSUM_FUSE and ctx.needs_input_grad[1]
+        if mask is not None or act != ACT_NONE:
+            if fuse_db:
+                dy, side = _act_bwd_colsum(dy, y, mask, N, Ho * Wo, Co, act, slope)
+            elif mask is not None:
+                g = torch.empty_like(y)
+                check(lib.migan_act_bwd_nc(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), N, Ho * Wo, Co, act,
+                                           slope, _stream()), "act_bwd_nc")
+                dy = g
+            else:
+                dy = _act_bwd_raw(dy, y, act, slope)
+        elif fuse_db:
+            side = _colsum_side(dy, Co)
+        dx = dw = db = None
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()
@@ -308,13 +349,16 @@ class _Conv2d(Function):
                 dw = torch.empty_like(w) if slot is None else slot
                 nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
                 ws = _ws(nb, xs)
-                dbp, dba = None, 0
-                if want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather):
+                dbp, dba, sl, nsl = None, 0, None, 0
+                if want_db and side is not None:
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                    dbp, want_db, sl, nsl = dbt.data_ptr(), False, side[0].data_ptr(), side[1]
+                elif want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather):
                     dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
                     dbp, want_db = dbt.data_ptr(), False
                 check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
                                              Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1,
-                                             dbp, dba, st), "conv2d_wgrad")
+                                             dbp, dba, sl, nsl, st), "conv2d_wgrad")
                 if slot is not None:
                     dw = None
             if want_db:
@@ -326,6 +370,11 @@ class _Conv2d(Function):
             if gather == GATHER_ZERO:
                 check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
                                              Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
+            elif (gather == GATHER_REFLECT and _REFLECT1 and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
+                  and H >= 4 and W >= 4 and Co % 4 == 0 and Co >= 8 and Ci > 4):
+                # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
+                check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
+                      "conv2d_dgrad_reflect1")
             else:
                 if gather == GATHER_REFLECT:
                     Hp, Wp, gpt, gpl, dpt, dpl = H + pt + pb, W + pl + pr, pt, pl, 0, 0
@@ -338,6 +387,9 @@ class _Conv2d(Function):
                       "gather2d_bwd")
         fork.join()
         return dx, dw, db, None, None, None, None, None, None
+
+
+_REFLECT1 = __import__("os").environ.get("MIGAN_REFLECT1", "1") == "1"  # A/B knob: 0 = padded extent + fold pass
 
 
 def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None):
@@ -376,10 +428,17 @@ class _UpConv3x3(Function):
         xs, w, wd, y = ctx.saved_tensors
         N, H, W, Ci, Co, act, slope = ctx.geom
         dy = to_nhwc(dy)
-        if act != ACT_NONE:
-            dy = _act_bwd_raw(dy, y, act, slope)
-        dx = dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        side = None
+        fuse_db = want_db and _COLSUM_FUSE and ctx.needs_input_grad[1]
+        if act != ACT_NONE:
+            if fuse_db:
+                dy, side = _act_bwd_colsum(dy, y, None, N, 4 * H * W, Co, act, slope)
+            else:
+                dy = _act_bwd_raw(dy, y, act, slope)
+        elif fuse_db:
+            side = _colsum_side(dy, Co)
+        dx = dw = db = None
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()
@@ -387,21 +446,24 @@ class _UpConv3x3(Function):
                 slot = _grad_slot(ctx.params[0])
                 dw = torch.empty_like(w) if slot is None else slot
                 acc = 0 if slot is None else 1
+                dbp, dba, sl, nsl = None, 0, None, 0
+                if want_db and side is not None:
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                    dbp, want_db, sl, nsl = dbt.data_ptr(), False, side[0].data_ptr(), side[1]
                 if Co % 4 == 0 and Ci % 4 == 0:
                     nb = lib.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
                     ws = _ws(nb, xs)
-                    dbp, dba = None, 0
                     if want_db and _FUSE_BIAS:
                         dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
                         dbp, want_db = dbt.data_ptr(), False
                     check(lib.migan_upconv3x3_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
-                                                    W, Ci, Co, acc, dbp, dba, st), "upconv_wgrad")
+                                                    W, Ci, Co, acc, dbp, dba, sl, nsl, st), "upconv_wgrad")
                 else:  # same gradient through the dense gathered wgrad
                     nb = lib.migan_conv2d_wgrad_workspace(N, 2 * H, 2 * W, Co, 3, 3, Ci)
                     ws = _ws(nb, xs)
                     check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W,
-                                                 Ci, 2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, None, 0, st),
-                          "conv2d_wgrad")
+                                                 Ci, 2 * H, 2 * W, Co, 3, 3, 1, 1, 1, GATHER_UP2, acc, dbp, dba, sl, nsl,
+                                                 st), "conv2d_wgrad")
                 if slot is not None:
                     dw = None
             if want_db:
@@ -472,10 +534,10 @@ class _ConvTranspose2d(Function):
                 ws = _ws(nb, xs)
                 check(lib.migan_conv2d_wgrad(dy.data_ptr(), xs.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, Hout,
                                              Wout, Cout, Hin, Win, Cin, R, S, stride, pad, pad, GATHER_ZERO,
-                                             0 if slot is None else 1, None, 0, st), "convT_wgrad")
+                                             0 if slot is None else 1, None, 0, None, 0, st), "convT_wgrad")
                 if slot is not None:
                     dw = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if ctx.has_bias and ctx.needs_input_grad[2]:  # (the reference's ConvTranspose2d layers have bias=False)
                 db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
         st = _stream()
         if ctx.needs_input_grad[0]:
@@ -568,7 +630,7 @@ def _mm_tn_raw(a, b, out=None, accumulate=0, dbuf=None):
     ws = _ws(nb, a)
     check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,
                                  M, 1, 1, 1, 0, 0, GATHER_ZERO, accumulate, dbuf[0].data_ptr() if dbuf else None,
-                                 dbuf[1] if dbuf else 0, _stream()), "mm_tn")
+                                 dbuf[1] if dbuf else 0, None, 0, _stream()), "mm_tn")
     return out
 
 
@@ -671,6 +733,17 @@ def prelu(x, a):
 
 
 # ---------------------------------------------------------------------------------------------- normalisation
+# Cross-replica BatchNorm (data parallel): set by dp.DataParallel.enable_sync_batchnorm().  An object with
+#   world, all_gather(tensor[K]) -> tensor[world*K], all_reduce_sum(tensor) (in place)
+# None: BatchNorm statistics are those of the local batch (the only mode for world size 1).
+_SYNC_BN = None
+
+
+def set_sync_batchnorm(sync):
+    global _SYNC_BN
+    _SYNC_BN = sync
+
+
 class _Norm(Function):
     """BatchNorm (G=1) / InstanceNorm (G=N) + fused activation + optional residual add."""
 
@@ -691,24 +764,38 @@ class _Norm(Function):
         else:
             raise ValueError("norm: expected 2-D or 4-D input")
         st = _stream()
+        sync = _SYNC_BN if (use_batch_stats and not instance and _SYNC_BN is not None and _SYNC_BN.world > 1) else None
         if use_batch_stats:
-            if P <= 1 and not instance:
+            if P <= 1 and not instance and sync is None:
                 raise ValueError("Expected more than 1 value per channel when training")
             mean = torch.empty(G * C, device=xs.device, dtype=torch.float32)
             invstd = torch.empty_like(mean)
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
-            check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
-                                       _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb,
-                                       st), "norm_stats")
+            if sync is None:
+                check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
+                                           _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb,
+                                           st), "norm_stats")
+            else:
+                # statistics of the GLOBAL batch, as the single-process reference computes them: local moments ->
+                # all_gather of 2*C floats -> Chan combination (+ running statistics) on every rank
+                mom = torch.empty(2 * C, device=xs.device, dtype=torch.float32)
+                check(lib.migan_norm_moments(xs.data_ptr(), mom.data_ptr(), mom.data_ptr() + 4 * C, 1, P, C,
+                                             ws.data_ptr(), nb, st), "norm_moments")
+                allm = sync.all_gather(mom)
+                check(lib.migan_norm_sync_finalize(allm.data_ptr(), sync.world, P, mean.data_ptr(), invstd.data_ptr(),
+                                                   _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, C,
+                                                   st), "norm_sync_finalize")
         else:
             mean = _plain(running_mean)
-            invstd = torch.rsqrt(_plain(running_var) + eps)
+            invstd = torch.empty_like(mean)  # eval mode: invstd = 1/sqrt(running_var + eps)
+            check(lib.migan_rsqrt_eps(_plain(running_var).data_ptr(), invstd.data_ptr(), C, eps, st), "rsqrt_eps")
         rs = canon(res) if res is not None else None
         y = torch.empty_like(xs)
         check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                    _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
         ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
+        ctx.sync = sync
         ctx.save_for_backward(xs, gamma, beta, mean, invstd)
         return y
 
@@ -731,13 +818,34 @@ class _Norm(Function):
                 dbeta = torch.empty_like(dgamma)
         nb = lib.migan_norm_workspace(G, P, C)
         ws = _ws(nb, xs)
-        check(lib.migan_norm_bwd(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                 _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
-                                 ws.data_ptr(), nb, acc, _stream()), "norm_bwd")
+        # column-sum slabs of dx: the bias gradient of the conv in front of this layer is reduced from them inside that
+        # conv's wgrad launch (4-D activations only; a Linear in front of BatchNorm1d has a per-feature bias)
+        slabs, nslab = None, 0
+        if xs.dim() == 4 and _COLSUM_FUSE and not ctx.x_nchw:
+            nslab = lib.migan_norm_colsum_slabs(G, P, C)
+            slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
+        st = _stream()
+        if ctx.sync is None:
+            check(lib.migan_norm_bwd(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                     _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
+                                     ws.data_ptr(), nb, acc, _ptr(slabs), st), "norm_bwd")
+        else:
+            # cross-replica BatchNorm: the two batch sums cover the global batch (all-reduce of 2*C floats); dgamma/dbeta
+            # stay local sums - they are summed over ranks with the rest of the gradient bucket
+            sums = torch.empty(2 * C, device=xs.device, dtype=torch.float32)
+            check(lib.migan_norm_bwd_sums(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                          _ptr(beta), sums.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
+                                          ws.data_ptr(), nb, acc, st), "norm_bwd_sums")
+            ctx.sync.all_reduce_sum(sums)
+            check(lib.migan_norm_bwd_apply(xs.data_ptr(), dy.data_ptr(), dx.data_ptr(), mean.data_ptr(),
+                                           invstd.data_ptr(), _ptr(gamma), _ptr(beta), sums.data_ptr(), G, P, C, act,
+                                           slope, P * ctx.sync.world, _ptr(slabs), st), "norm_bwd_apply")
         if acc:
             dgamma = dbeta = None
         if ctx.x_nchw:
             dx = to_nchw(dx)
+        elif slabs is not None:
+            _attach_colsum(dx, slabs, nslab, C)
         return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
 
 

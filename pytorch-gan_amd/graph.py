@@ -82,6 +82,9 @@ class StepRunner:
         torch.cuda.synchronize()
         if not self.use_graph:
             return self
+        if not getattr(self.dp, "graph_ok", True):
+            self.capture_error = "not captured: cross-replica BatchNorm runs collectives inside forward/backward"
+            return self
         try:
             self._capture(side)
             self.graphed = True
@@ -94,7 +97,7 @@ class StepRunner:
 
     def _capture(self, stream):
         seg = _Segmenter(torch.cuda.graph_pool_handle(), stream)
-        multi = getattr(self.dp, "world", 1) > 1
+        multi = getattr(self.dp, "segment", getattr(self.dp, "world", 1) > 1)  # DataParallel: collectives between segments
         if multi:
             self.dp._segmenter = seg
         try:

@@ -1,0 +1,112 @@
+"""Worker processes of tests/test_dp_gpu.py (one per rank, started with torch.distributed.run or directly).
+
+    python tests/dp_worker.py nccl1 <out.json>     world_size 1, backend nccl (= RCCL): side-stream all-reduce + graph segments
+    python tests/dp_worker.py syncbn <out.pt>      N ranks (gloo, all on cuda:0): cross-replica BatchNorm DCGAN step
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def _seed(s):
+    torch.manual_seed(s)
+    np.random.seed(s)
+
+
+def nccl1(out):
+    """K12 with world size 1: the RCCL process group, the side-stream all-reduce + fused Adam, and the segmented hipGraph
+    replay all execute; results must equal the LocalStepper (no collective) run."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import dp as dpmod
+    from pytorch_gan_amd import graph, steps
+    from util import gpu_copy
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    dp = dpmod.DataParallel()
+    assert dp.world == 1 and dp.side is not None and dist.get_backend() == "nccl"
+    _seed(0)
+    base = S.make_dcgan(32)
+    for m in base.D.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    s_dp = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D), dp=dp)
+    s_lo = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D))
+    _seed(2)
+    imgs = (torch.rand(8, 1, 32, 32) * 2 - 1).cuda()
+    zs = torch.randn(10, 8, 100).cuda()
+    res = {"eager": [], "graph": []}
+    for i in range(3):   # eager: bucket all-reduce + Adam on the side stream, begin_step/wait ordering
+        a = steps.dcgan_step(s_dp, imgs, zs[i])
+        b = steps.dcgan_step(s_lo, imgs, zs[i])
+        torch.cuda.synchronize()
+        res["eager"].append([float(a["g_loss"]), float(b["g_loss"]), float(a["d_loss"]), float(b["d_loss"])])
+    z_static = zs[3].clone()
+    runner = graph.StepRunner(lambda: steps.dcgan_step(s_dp, imgs, z_static), dp, use_graph=True, warmup=1).prepare()
+    steps.dcgan_step(s_lo, imgs, zs[3])  # mirror the runner's warm-up step
+    res["graphed"], res["segments"] = runner.graphed, len(runner._segments or [])
+    res["capture_error"] = runner.capture_error
+    for i in range(4, 8):
+        z_static.copy_(zs[i])
+        a = runner.run()
+        b = steps.dcgan_step(s_lo, imgs, zs[i])
+        torch.cuda.synchronize()
+        res["graph"].append([float(a["g_loss"]), float(b["g_loss"]), float(a["d_loss"]), float(b["d_loss"])])
+    res["max_param_diff"] = max(float((p - q).abs().max()) for p, q in zip(s_dp.G.parameters(), s_lo.G.parameters()))
+    dist.destroy_process_group()
+    json.dump(res, open(out, "w"))
+    del pg
+
+
+def syncbn(out):
+    """Every rank runs HALF of a DCGAN batch with cross-replica BatchNorm on; rank 0 stores losses, G/D gradients and the
+    BatchNorm running statistics for comparison with the single-process full-batch step."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import dp as dpmod
+    from pytorch_gan_amd import steps
+    from util import gpu_copy
+
+    dp = dpmod.init_from_env()
+    sync = os.environ.get("MIGAN_TEST_SYNCBN", "1") == "1"
+    if sync:
+        dp.enable_sync_batchnorm()
+    _seed(0)
+    base = S.make_dcgan(32)
+    for m in base.D.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0   # device dropout streams would differ between the sharded and the full-batch run
+    s = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D), dp=dp)
+    _seed(9)
+    imgs = (torch.rand(16, 1, 32, 32) * 2 - 1).cuda()
+    z = torch.randn(16, 100).cuda()
+    o = steps.dcgan_step(s, dp.shard(imgs), dp.shard(z))
+    dp.end_step()
+    torch.cuda.synchronize()
+    # the logged loss of a rank is the mean over its shard: average over ranks = the full-batch mean
+    losses = torch.stack([o["g_loss"], o["d_loss"]]).clone()
+    dist.all_reduce(losses)
+    losses /= dp.world
+    if dp.rank == 0:
+        torch.save({"losses": losses.cpu(),
+                    "G": {k: v.detach().cpu() for k, v in s.G.state_dict().items()},
+                    "D": {k: v.detach().cpu() for k, v in s.D.state_dict().items()},
+                    "gG": s.opt_G.flat_grad.cpu() / dp.world, "gD": s.opt_D.flat_grad.cpu() / dp.world}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+    del pg
+
+
+if __name__ == "__main__":
+    {"nccl1": nccl1, "syncbn": syncbn}[sys.argv[1]](sys.argv[2])

@@ -67,6 +67,21 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(5)
     xb = torch.rand(8, 1, 8, 8, generator=g)       # global batches, identical on every rank (host RNG is shared)
     yb = torch.rand(4, 3, 32, 32, generator=g)
+    # cross-replica BatchNorm protocol (host side): gather of the per-rank moments + Chan combination == moments of the
+    # whole batch; all-reduced backward sums == sums over the whole batch
+    sync = dp.enable_sync_batchnorm()
+    assert dp.graph_ok is False
+    feat = torch.rand(8, 6, generator=torch.Generator().manual_seed(11)) * 3 + 5
+    mine = dp.shard(feat)
+    mom = torch.cat([mine.mean(0), mine.var(0, unbiased=False)])
+    allm = sync.all_gather(mom).view(world, 2, 6).double()
+    m = allm[:, 0].mean(0)
+    var = (allm[:, 1] + (allm[:, 0] - m) ** 2).mean(0)   # equal shards: what migan_norm_sync_finalize computes
+    assert torch.allclose(m, feat.double().mean(0), atol=1e-6) and torch.allclose(var, feat.double().var(0, unbiased=False), atol=1e-6)
+    sums = sync.all_reduce_sum(mine.sum(0).clone())
+    assert torch.allclose(sums, feat.sum(0), atol=1e-5)
+    dp.disable_sync_batchnorm()
+    assert dp.graph_ok is True
     dp.begin_step()
     opt_D.zero_grad()
     (-torch.mean(D(dp.shard(xb)))).backward()      # every loss on the path is a batch mean

@@ -1,0 +1,84 @@
+"""Data-parallel path on the GPU box (one MI355X): the RCCL process group at world size 1 (K12 executes: side-stream
+all-reduce of the flat bucket, fused Adam, segmented hipGraph replay), and cross-replica BatchNorm with two gloo ranks
+driving the same GPU against the single-process full-batch step."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import gpu_copy
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_world1_side_stream_and_graph_segments(tmp_path):
+    out = str(tmp_path / "nccl1.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, WORKER, "nccl1", out], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    assert res["graphed"], res["capture_error"]
+    assert res["segments"] == 5  # graph | all-reduce+Adam(G) | graph | all-reduce+Adam(D) | graph
+    for row in res["eager"] + res["graph"]:
+        assert abs(row[0] - row[1]) <= 1e-5 * max(1, abs(row[1])) and abs(row[2] - row[3]) <= 1e-5 * max(1, abs(row[3])), row
+    assert res["max_param_diff"] <= 4e-4
+
+
+def _run_ranks(mode, out, world, extra_env=None):
+    env = dict(os.environ, MIGAN_DP_BACKEND="gloo", MIGAN_DP_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), WORKER, mode, out]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return torch.load(out)
+
+
+def test_cross_replica_batchnorm_equals_full_batch(tmp_path):
+    """2 ranks x 8 samples with enable_sync_batchnorm() == 1 process x 16 samples: losses, gradients (after the 1/world
+    averaging) and BatchNorm running statistics; with per-rank statistics (the default) they differ measurably."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    got = _run_ranks("syncbn", str(tmp_path / "sync.pt"), 2)
+    local = _run_ranks("syncbn", str(tmp_path / "local.pt"), 2, {"MIGAN_TEST_SYNCBN": "0"})
+    torch.manual_seed(0)
+    np.random.seed(0)
+    base = S.make_dcgan(32)
+    for m in base.D.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    s = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D))
+    torch.manual_seed(9)
+    np.random.seed(9)
+    imgs = (torch.rand(16, 1, 32, 32) * 2 - 1).cuda()
+    z = torch.randn(16, 100).cuda()
+    o = steps.dcgan_step(s, imgs, z)
+    torch.cuda.synchronize()
+    want = torch.stack([o["g_loss"], o["d_loss"]]).cpu()
+    assert torch.allclose(got["losses"], want, rtol=2e-5, atol=1e-6), (got["losses"], want)
+    for name, opt in (("gG", s.opt_G), ("gD", s.opt_D)):
+        a, b = got[name].double(), opt.flat_grad.cpu().double()
+        assert float((a - b).norm() / b.norm()) < 2e-4, name
+    for net, sd in (("G", s.G.state_dict()), ("D", s.D.state_dict())):
+        for k, v in sd.items():
+            if "running" in k:
+                assert torch.allclose(got[net][k], v.cpu(), rtol=1e-4, atol=1e-6), (net, k)
+            elif k.endswith("num_batches_tracked"):
+                assert int(got[net][k]) == int(v)
+    # per-rank statistics are a different computation: the running variance of the first generator BatchNorm differs
+    k = "conv_blocks.0.running_var"
+    assert not torch.allclose(local["G"][k], s.G.state_dict()[k].cpu(), rtol=1e-4, atol=1e-6)

@@ -531,3 +531,119 @@ def test_bias_grad_fused_into_wgrad(pg):
     for slots in (False, True):
         for p, a, b in zip(params, res[(False, slots)], res[(True, slots)]):
             assert_close(b, a, TOL_WGRAD, "fused bias %s slots=%s" % (tuple(p.shape), slots))
+
+
+# ------------------------------------------------------------------------------------------------ round-2 kernels
+@pytest.mark.parametrize("case", [(2, 8, 5, 4, 16), (1, 256, 12, 12, 256), (2, 64, 20, 18, 32), (3, 32, 4, 7, 40)])
+def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
+    """ReflectionPad2d(1)+Conv3x3 input gradient: the direct form (pad-1 dgrad + added ring terms, no padded
+    intermediate; cyclegan/models.py:26-35) against torch CPU and against the padded-extent + fold path it replaces."""
+    N, Ci, H, W, Co = case
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+    y_ref = TF.conv2d(TF.pad(x, (1, 1, 1, 1), mode="reflect"), w, None, 1)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    outs = []
+    for direct in (True, False):
+        monkeypatch.setattr(F, "_REFLECT1", direct)
+        xg = x.detach().to(DEV).requires_grad_(True)
+        wg = w.detach().to(DEV).requires_grad_(True)
+        y = F.conv2d(xg, wg, None, 1, (1, 1, 1, 1), F.GATHER_REFLECT)
+        y.backward(gy.to(DEV))
+        assert_close(xg.grad, x.grad, TOL_FWD, "reflect dgrad direct=%s" % direct)
+        outs.append(xg.grad.clone())
+    assert_close(outs[0], outs[1], 2e-6, "direct vs padded+fold")
+
+
+@pytest.mark.parametrize("cfg", [(1, 128 * 16 * 16, 128, 1, True), (8, 64 * 64, 256, 2, False), (4, 33 * 7, 12, 0, False),
+                                 (2, 50, 3, 0, False), (3, 129, 1, 0, False)])
+def test_norm_bwd_column_sum_slabs(pg, cfg):
+    """migan_norm_bwd's per-block column sums of dx (the bias gradient of the conv in front of the norm layer is reduced
+    from them inside that conv's wgrad launch) equal the column sums of the dx it wrote, for BatchNorm (G=1) and
+    InstanceNorm (G>1) views, vector and scalar channel counts."""
+    from pytorch_gan_amd._lib import check, lib
+
+    G, P, C, act, affine = cfg
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(G, P, C, generator=g).to(DEV)
+    dy = torch.randn(G, P, C, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV) if affine else None
+    beta = torch.randn(C, generator=g).to(DEV) if affine else None
+    mean, invstd = torch.empty(G * C, device=DEV), torch.empty(G * C, device=DEV)
+    nb = lib.migan_norm_workspace(G, P, C)
+    ws = torch.empty(nb // 4 + 1, device=DEV)
+    check(lib.migan_norm_stats(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), None, None, None, 0.1, 1e-5, G, P, C,
+                               ws.data_ptr(), nb, st))
+    dx = torch.empty_like(x)
+    nslab = lib.migan_norm_colsum_slabs(G, P, C)
+    slabs = torch.full((nslab, C), float("nan"), device=DEV)
+    dg, db = (torch.empty(C, device=DEV), torch.empty(C, device=DEV)) if G == 1 else (None, None)
+    P_ = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    check(lib.migan_norm_bwd(x.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), P_(gamma), P_(beta),
+                             dx.data_ptr(), P_(dg), P_(db), G, P, C, act, 0.2, ws.data_ptr(), nb, 0, slabs.data_ptr(), st))
+    got = slabs.double().sum(0).cpu()
+    want = dx.double().sum((0, 1)).cpu()
+    scale = dx.double().abs().sum((0, 1)).cpu()
+    assert torch.isfinite(slabs).all()
+    assert ((got - want).abs() <= 2e-6 * scale + 1e-9).all(), (got - want).abs().max()
+    # and dx itself is unchanged by asking for the slabs
+    dx2 = torch.empty_like(x)
+    check(lib.migan_norm_bwd(x.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), P_(gamma), P_(beta),
+                             dx2.data_ptr(), P_(dg), P_(db), G, P, C, act, 0.2, ws.data_ptr(), nb, 0, None, st))
+    assert torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("cfg", [(4, 16 * 16, 32, 1, True), (128, 64 * 64, 1, 3, False), (2, 9, 12, 0, True), (3, 100, 3, 4, False)])
+def test_act_bwd_colsum(pg, cfg):
+    """Backward of conv -> act [-> Dropout2d] in one pass: dx bit-identical to the separate kernels, slabs = column sums."""
+    from pytorch_gan_amd._lib import check, lib
+
+    N, HW, C, act, masked = cfg
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+    y = torch.tanh(torch.randn(N, HW, C, generator=g)).to(DEV) if act in (3, 4) else torch.randn(N, HW, C, generator=g).to(DEV)
+    if act == 4:
+        y = y * 0.5 + 0.5
+    dy = torch.randn(N, HW, C, generator=g).to(DEV)
+    mask = ((torch.rand(N, C, generator=g) > 0.25).float() / 0.75).to(DEV) if masked else None
+    dx = torch.empty_like(dy)
+    nslab = lib.migan_norm_colsum_slabs(N, HW, C)
+    slabs = torch.full((nslab, C), float("nan"), device=DEV)
+    check(lib.migan_act_bwd_colsum(dy.data_ptr(), y.data_ptr(), None if mask is None else mask.data_ptr(), dx.data_ptr(),
+                                   slabs.data_ptr(), N, HW, C, act, 0.2, st))
+    ref = torch.empty_like(dy)
+    if masked and C % 4 == 0:
+        check(lib.migan_act_bwd_nc(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), ref.data_ptr(), N, HW, C, act, 0.2, st))
+    else:
+        check(lib.migan_act_bwd(dy.data_ptr(), y.data_ptr(), ref.data_ptr(), dy.numel(), act, 0.2, st))
+        if masked:
+            ref = ref * mask[:, None, :]
+    assert torch.equal(dx, ref)
+    got, want = slabs.double().sum(0).cpu(), dx.double().sum((0, 1)).cpu()
+    assert ((got - want).abs() <= 2e-6 * dx.double().abs().sum((0, 1)).cpu() + 1e-9).all()
+
+
+def test_conv_bias_grad_via_norm_slabs_equals_colsum(pg, monkeypatch):
+    """Conv2d(bias) -> InstanceNorm/BatchNorm: the conv's bias gradient reduced from the norm backward's slabs inside the
+    wgrad launch equals the one from the separate column-sum launches (both are rounding noise around an exactly-zero
+    true gradient, so they are compared with each other at the scale of sum|dy|)."""
+    F = pg.functional
+    x = _leaf(4, 32, 16, 16, seed=1).to(DEV)
+    w = _leaf(64, 32, 3, 3, seed=2, scale=0.2).to(DEV)
+    gy = _leaf(4, 64, 16, 16, seed=4).to(DEV)
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(F, "_COLSUM_FUSE", fuse)
+        for inst in (False, True):
+            b = _leaf(64, seed=3).to(DEV).requires_grad_(True)
+            wg = w.clone().requires_grad_(True)
+            y = F.norm(F.conv2d(x, wg, b, 1, (1, 1, 1, 1)), instance=inst, act=F.ACT_RELU)
+            y.backward(gy)
+            res[(fuse, inst)] = (b.grad.clone(), wg.grad.clone())
+    for inst in (False, True):
+        (b1, w1), (b0, w0) = res[(True, inst)], res[(False, inst)]
+        assert torch.equal(w1, w0)
+        assert (b1 - b0).abs().max().item() <= 1e-5 * gy.abs().sum().item() / 64

@@ -89,9 +89,17 @@ def main():
             "dgrad": lambda: lib.migan_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
                                                     Wo, Co, k, k, s, pd, pd, 0, 0.0, st),
             "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
-                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, None, 0, st),
+                                                    W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, None, 0, None, 0, st),
         }
         dirs = ["fwd", "dgrad", "wgrad"]
+        if gth == 1 and k == 3 and s == 1 and p == 1 and Co % 4 == 0 and Co >= 8 and Ci > 4:
+            # ReflectionPad2d(1)+Conv3x3 input gradient straight into H x W (pad-1 dgrad + added ring terms); "dgrad" above
+            # is the padded-extent launch it replaces (which additionally needs the fold pass, timed as "fold")
+            dxr = torch.empty(N * H * W * Ci, device=dev)
+            calls["rdgrad"] = lambda: lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), w.data_ptr(), dxr.data_ptr(), N, H, W,
+                                                                      Ci, Co, st)
+            calls["fold"] = lambda: lib.migan_gather2d_bwd(dx.data_ptr(), dxr.data_ptr(), N, H, W, Ci, Hd, Wd, p, p, 1, st)
+            dirs += ["rdgrad", "fold"]
         if gth == 2 and k == 3 and s == 1 and p == 1 and Co % 4 == 0 and Ci % 4 == 0:
             # phase-collapsed Upsample(2)->Conv3x3 (what the product path runs); TF stays ALGORITHMIC (dense FLOPs)
             wf = torch.empty(Co * 16 * Ci, device=dev)
@@ -105,10 +113,10 @@ def main():
             calls["udgrad"] = lambda: lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dxs.data_ptr(), N, H, W,
                                                                 Ci, Co, st)
             calls["uwgrad"] = lambda: lib.migan_upconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                                                                wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, None, 0, st)
+                                                                wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, None, 0, None, 0, st)
             dirs += ["ufwd", "udgrad", "uwgrad"]
         for d in dirs:
-            if d.lstrip("u") not in only:
+            if d.lstrip("ur") not in only and not (d == "fold" and "dgrad" in only):
                 continue
             fn = calls[d]
             for _ in range(3):
