@@ -198,12 +198,26 @@ size_t migan_colsum_workspace(size_t P, int C);
 int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, int accumulate,
                  void* stream);
 /* kind 0 BCELoss (dcgan.py:103), 1 MSELoss (cyclegan.py:57), 2 L1Loss (cyclegan.py:58-59), 3 mean
- * (wgan_gp.py:171,189).  Target is t[i] or the constant tconst when t==NULL.  out = mean over n.
+ * (wgan_gp.py:171,189), 4 BCEWithLogitsLoss (relativistic_gan.py:95: (1-t)*x - log_sigmoid(x)).  Target is t[i] or the constant tconst when t==NULL.  out = mean over n.
  * ws: migan_reduce_workspace() bytes.  bwd: dx = g[0]/n * dloss/dx. */
 int migan_loss_fwd(int kind, const float* x, const float* t, float tconst, float* out, size_t n, float* ws,
                    size_t ws_bytes, void* stream);
 int migan_loss_bwd(int kind, const float* x, const float* t, float tconst, const float* g, float* dx, size_t n,
                    void* stream);
+/* ---- Layers of the DCGAN-block clones, SURVEY.md 8f F2 (csrc/classify.hip) --------------------------------------
+ * nn.Embedding(V, D) (acgan.py:50): y[i] = w[idx[i]]; backward dw[v] (+)= sum_{i: idx[i]==v} dy[i] in index order
+ * (deterministic).  idx: int64 device tensor. */
+int migan_embedding_fwd(const float* w, const long long* idx, float* y, int n, int D, int V, void* stream);
+int migan_embedding_bwd(const float* dy, const long long* idx, float* dw, int n, int D, int V, int accumulate,
+                        void* stream);
+/* nn.Softmax over the class dim of [B][C] (acgan.py:100) and its backward dx = y*(dy - sum_c dy*y). */
+int migan_softmax_fwd(const float* x, float* y, int B, int C, void* stream);
+int migan_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, void* stream);
+/* nn.CrossEntropyLoss() (mean) on logits [B][C] with int64 class targets (acgan.py:113).  ws: 2*B floats; its second
+ * half (ws + B, the row logsumexp values) is the `lse` argument of the backward: dx = g/B * (softmax(x) - onehot). */
+int migan_cross_entropy_fwd(const float* x, const long long* target, float* out, float* ws, int B, int C, void* stream);
+int migan_cross_entropy_bwd(const float* x, const long long* target, const float* lse, const float* g, float* dx, int B,
+                            int C, void* stream);
 /* gradients.norm(2, dim=1) and its derivatives (wgan_gp.py:136-137). */
 int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream);
 int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D, void* stream);

@@ -99,6 +99,12 @@ _SIGS = {
     "migan_colsum": (c_int, [P, P, c_size_t, c_int, P, c_size_t, c_int, P]),
     "migan_loss_fwd": (c_int, [c_int, P, P, c_float, P, c_size_t, P, c_size_t, P]),
     "migan_loss_bwd": (c_int, [c_int, P, P, c_float, P, P, c_size_t, P]),
+    "migan_embedding_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "migan_embedding_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "migan_softmax_fwd": (c_int, [P, P, c_int, c_int, P]),
+    "migan_softmax_bwd": (c_int, [P, P, P, c_int, c_int, P]),
+    "migan_cross_entropy_fwd": (c_int, [P, P, P, P, c_int, c_int, P]),
+    "migan_cross_entropy_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P]),
     "migan_rownorm_fwd": (c_int, [P, P, c_int, c_int, P]),
     "migan_rownorm_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
     "migan_rowscale": (c_int, [P, P, P, c_int, c_int, P]),

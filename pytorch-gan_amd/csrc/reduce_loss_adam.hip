@@ -1,6 +1,6 @@
 // Reductions, losses, gradient-penalty helpers and the fused multi-tensor Adam.
 // Reference semantics:
-//   torch.nn.BCELoss (dcgan.py:103; log clamped at -100, mean), torch.nn.MSELoss / L1Loss
+//   torch.nn.BCELoss (dcgan.py:103; log clamped at -100, mean), BCEWithLogitsLoss (relativistic_gan.py:95), MSELoss / L1Loss
 //   (cyclegan.py:57-59, pix2pix.py:50-51, srgan.py:71-72), torch.mean (wgan_gp.py:171,189),
 //   gradients.norm(2, dim=1) and ((.-1)**2).mean() (wgan_gp.py:136-137),
 //   torch.optim.Adam single-tensor arithmetic (dcgan.py:134-135).
@@ -94,7 +94,7 @@ MIGAN_API int migan_colsum(const float* x, float* out, size_t P, int C, float* w
 }
 
 // ------------------------------------------------------------------ losses (mean reduction)
-enum { LOSS_BCE = 0, LOSS_MSE = 1, LOSS_L1 = 2, LOSS_MEAN = 3 };
+enum { LOSS_BCE = 0, LOSS_MSE = 1, LOSS_L1 = 2, LOSS_MEAN = 3, LOSS_BCE_LOGITS = 4 };
 __device__ __forceinline__ float loss_term(int kind, float x, float t) {
     switch (kind) {
         case LOSS_BCE: {
@@ -103,6 +103,8 @@ __device__ __forceinline__ float loss_term(int kind, float x, float t) {
         }
         case LOSS_MSE: { float d = x - t; return d * d; }
         case LOSS_L1: return fabsf(x - t);
+        case LOSS_BCE_LOGITS:  // torch: (1 - t) * x - log_sigmoid(x), log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+            return (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
         default: return x;
     }
 }
@@ -114,6 +116,7 @@ __device__ __forceinline__ float loss_grad(int kind, float x, float t) {
         }
         case LOSS_MSE: return 2.f * (x - t);
         case LOSS_L1: { float d = x - t; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        case LOSS_BCE_LOGITS: return 1.f / (1.f + expf(-x)) - t;  // sigmoid(x) - t
         default: return 1.f;
     }
 }

@@ -16,7 +16,7 @@ from ._lib import check, lib
 CL = torch.channels_last
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 GATHER_ZERO, GATHER_REFLECT, GATHER_UP2 = 0, 1, 2
-LOSS_BCE, LOSS_MSE, LOSS_L1, LOSS_MEAN = 0, 1, 2, 3
+LOSS_BCE, LOSS_MSE, LOSS_L1, LOSS_MEAN, LOSS_BCE_LOGITS = 0, 1, 2, 3, 4
 
 
 def _stream():
@@ -1088,6 +1088,133 @@ def loss(kind, x, target=None, tconst=0.0):
 
 def mean(x):
     return _Loss.apply(x, None, LOSS_MEAN, 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- DCGAN-block clones (F2)
+class _Embedding(Function):
+    """nn.Embedding lookup (acgan.py:50): y[i] = weight[idx[i]]."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        w = _plain(weight)
+        _check_dev(w)
+        if idx.dtype != torch.int64 or not idx.is_cuda:
+            raise TypeError("embedding: indices must be an int64 tensor on the GPU (the reference passes LongTensor labels)")
+        flat = idx.reshape(-1).contiguous()
+        V, D = w.shape
+        y = torch.empty(flat.numel(), D, device=w.device, dtype=torch.float32)
+        check(lib.migan_embedding_fwd(w.data_ptr(), flat.data_ptr(), y.data_ptr(), flat.numel(), D, V, _stream()),
+              "embedding_fwd")
+        ctx.save_for_backward(flat)
+        ctx.wshape, ctx.ishape, ctx.param = (V, D), tuple(idx.shape), weight
+        return y.view(*idx.shape, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (flat,) = ctx.saved_tensors
+        V, D = ctx.wshape
+        dy = canon(dy.reshape(-1, D))
+        slot = _grad_slot(ctx.param)
+        dw = torch.empty(V, D, device=dy.device, dtype=torch.float32) if slot is None else slot
+        check(lib.migan_embedding_bwd(dy.data_ptr(), flat.data_ptr(), dw.data_ptr(), flat.numel(), D, V,
+                                      0 if slot is None else 1, _stream()), "embedding_bwd")
+        return None, (dw if slot is None else None)
+
+
+def embedding(idx, weight):
+    return _Embedding.apply(idx, weight)
+
+
+class _Softmax(Function):
+    """Softmax over the class dimension of a (B, C) tensor (nn.Softmax() of acgan.py:100)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xs = canon(x)
+        if xs.dim() != 2:
+            raise ValueError("softmax: expected (B, classes) input on this path")
+        y = torch.empty_like(xs)
+        check(lib.migan_softmax_fwd(xs.data_ptr(), y.data_ptr(), xs.shape[0], xs.shape[1], _stream()), "softmax_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = canon(dy)
+        dx = torch.empty_like(y)
+        check(lib.migan_softmax_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.shape[0], y.shape[1], _stream()),
+              "softmax_bwd")
+        return dx
+
+
+def softmax(x):
+    return _Softmax.apply(x)
+
+
+class _CrossEntropy(Function):
+    """nn.CrossEntropyLoss() (mean) on (B, C) scores with int64 class targets (acgan.py:113,175-176)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        xs = canon(x)
+        if xs.dim() != 2 or target.dim() != 1 or target.shape[0] != xs.shape[0]:
+            raise ValueError("cross_entropy: expected (B, C) scores and (B,) class indices")
+        if target.dtype != torch.int64 or not target.is_cuda:
+            raise TypeError("cross_entropy: targets must be an int64 tensor on the GPU")
+        t = target.contiguous()
+        B, C = xs.shape
+        out = torch.empty((), device=xs.device, dtype=torch.float32)
+        ws = torch.empty(2 * B, device=xs.device, dtype=torch.float32)
+        check(lib.migan_cross_entropy_fwd(xs.data_ptr(), t.data_ptr(), out.data_ptr(), ws.data_ptr(), B, C, _stream()),
+              "cross_entropy_fwd")
+        ctx.save_for_backward(xs, t, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, t, ws = ctx.saved_tensors
+        B, C = xs.shape
+        g = _plain(g).contiguous()
+        dx = torch.empty_like(xs)
+        check(lib.migan_cross_entropy_bwd(xs.data_ptr(), t.data_ptr(), ws.data_ptr() + 4 * B, g.data_ptr(), dx.data_ptr(),
+                                          B, C, _stream()), "cross_entropy_bwd")
+        return dx, None
+
+
+def cross_entropy(x, target):
+    return _CrossEntropy.apply(x, target)
+
+
+class _Mul(Function):
+    """Elementwise product of two same-shape tensors (`torch.mul(self.label_emb(labels), noise)`, acgan.py:61)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = canon(a), canon(b)
+        if a.shape != b.shape:
+            raise ValueError("mul: shapes differ (no broadcasting on this path)")
+        y = torch.empty_like(a)
+        check(lib.migan_mul(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mul")
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = canon(g)
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            check(lib.migan_mul(g.data_ptr(), b.data_ptr(), ga.data_ptr(), a.numel(), _stream()), "mul")
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(b)
+            check(lib.migan_mul(g.data_ptr(), a.data_ptr(), gb.data_ptr(), a.numel(), _stream()), "mul")
+        return ga, gb
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
 
 
 class _RowNorm(Function):

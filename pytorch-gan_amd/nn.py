@@ -76,6 +76,16 @@ def _h_add(args, kwargs):
     return NotImplemented
 
 
+def _h_mul(args, kwargs):
+    if len(args) != 2 or kwargs:
+        return NotImplemented
+    a, b = args
+    ok = lambda t: isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32  # noqa: E731
+    if ok(a) and ok(b) and a.shape == b.shape:
+        return _wrap(F.mul(a, b))
+    return NotImplemented
+
+
 def _h_cat(args, kwargs):
     tensors = args[0]
     dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
@@ -97,6 +107,10 @@ _OVERRIDES = {
     torch.Tensor.__add__: _h_add,
     torch.Tensor.__radd__: _h_add,
     torch.add: _h_add,
+    torch.mul: _h_mul,
+    torch.Tensor.mul: _h_mul,
+    torch.Tensor.__mul__: _h_mul,
+    torch.Tensor.__rmul__: _h_mul,
     torch.cat: _h_cat,
 }
 
@@ -372,6 +386,44 @@ class L1Loss(_MeanLoss):
     kind = F.LOSS_L1
 
 
+class BCEWithLogitsLoss(_MeanLoss):
+    """relativistic_gan.py:95 (no weight / pos_weight, mean reduction)."""
+    kind = F.LOSS_BCE_LOGITS
+
+    def __init__(self, weight=None, reduction="mean", pos_weight=None):
+        super().__init__(reduction)
+        if weight is not None or pos_weight is not None:
+            raise ValueError("BCEWithLogitsLoss: weight / pos_weight are not on the reference path")
+
+
+class CrossEntropyLoss(tnn.Module):
+    """acgan.py:113 `torch.nn.CrossEntropyLoss()`: class-index targets, mean reduction, no weights / smoothing."""
+
+    def __init__(self, weight=None, ignore_index=-100, reduction="mean", label_smoothing=0.0):
+        super().__init__()
+        if weight is not None or reduction != "mean" or label_smoothing != 0.0:
+            raise ValueError("CrossEntropyLoss: only the default configuration is on the reference path")
+
+    def forward(self, x, target):
+        return F.cross_entropy(x, target)
+
+
+# ---- layers of the DCGAN-block clones (SURVEY.md 8f F2) ---------------------------------------------------------------
+class Embedding(tnn.Embedding):
+    def forward(self, idx):
+        if self.padding_idx is not None or self.max_norm is not None or self.sparse or self.scale_grad_by_freq:
+            raise ValueError("Embedding: padding_idx / max_norm / sparse / scale_grad_by_freq are not on the reference path")
+        y = F.embedding(idx, self.weight)
+        return y.as_subclass(GanTensor) if type(y) is torch.Tensor else y  # routes `torch.mul(emb, noise)` (acgan.py:61)
+
+
+class Softmax(tnn.Softmax):
+    def forward(self, x):
+        if x.dim() != 2 or self.dim not in (None, 1, -1):  # nn.Softmax() on (B, classes): implicit dim = 1
+            raise ValueError("Softmax: only the class dimension of a (B, classes) tensor is on the reference path")
+        return F.softmax(x)
+
+
 # ----------------------------------------------------------------------------------------------- Sequential
 class Sequential(tnn.Sequential):
     """nn.Sequential with run-time peephole fusion over the unchanged child list."""
@@ -425,7 +477,8 @@ _SWAP = {
     tnn.Tanh: Tanh, tnn.Sigmoid: Sigmoid, tnn.PReLU: PReLU, tnn.Upsample: Upsample,
     tnn.ReflectionPad2d: ReflectionPad2d, tnn.ZeroPad2d: ZeroPad2d, tnn.PixelShuffle: PixelShuffle,
     tnn.MaxPool2d: MaxPool2d, tnn.Dropout: Dropout, tnn.Dropout2d: Dropout2d, tnn.Sequential: Sequential,
-    tnn.BCELoss: BCELoss, tnn.MSELoss: MSELoss, tnn.L1Loss: L1Loss,
+    tnn.BCELoss: BCELoss, tnn.MSELoss: MSELoss, tnn.L1Loss: L1Loss, tnn.BCEWithLogitsLoss: BCEWithLogitsLoss,
+    tnn.CrossEntropyLoss: CrossEntropyLoss, tnn.Embedding: Embedding, tnn.Softmax: Softmax,
 }
 _OURS = set(_SWAP.values())
 
@@ -440,8 +493,12 @@ def swap(module):
     for m in module.modules():
         cls = type(m)
         if cls in _SWAP:
-            if cls in (tnn.BCELoss, tnn.MSELoss, tnn.L1Loss) and m.reduction != "mean":
-                raise ValueError("swap: loss reduction %r is not supported" % m.reduction)
+            if cls in (tnn.BCELoss, tnn.MSELoss, tnn.L1Loss, tnn.BCEWithLogitsLoss, tnn.CrossEntropyLoss):
+                if m.reduction != "mean":
+                    raise ValueError("swap: loss reduction %r is not supported" % m.reduction)
+                if getattr(m, "weight", None) is not None or getattr(m, "pos_weight", None) is not None \
+                        or getattr(m, "label_smoothing", 0.0) != 0.0:
+                    raise ValueError("swap: loss weights / label smoothing are not on the reference path")
             m.__class__ = _SWAP[cls]
         elif cls in _OURS:
             continue

@@ -647,3 +647,71 @@ def test_conv_bias_grad_via_norm_slabs_equals_colsum(pg, monkeypatch):
         (b1, w1), (b0, w0) = res[(True, inst)], res[(False, inst)]
         assert torch.equal(w1, w0)
         assert (b1 - b0).abs().max().item() <= 1e-5 * gy.abs().sum().item() / 64
+
+
+# ------------------------------------------------------------------------------------------------ F2: DCGAN-block clones
+def test_embedding_mul_softmax_cross_entropy(pg):
+    """acgan.py:50,61,100,113: label embedding * noise -> ... -> Linear+Softmax scores -> CrossEntropyLoss, against stock
+    torch on the CPU, forward and all gradients (embedding gradient = deterministic scatter-add; label tensors bit-exact)."""
+    import pytorch_gan_amd.nn as gnn
+
+    g = torch.Generator().manual_seed(0)
+    B, V, D, C = 64, 10, 100, 10
+    emb_c = torch.nn.Embedding(V, D)
+    lin_c = torch.nn.Linear(D, C)
+    labels = torch.randint(0, V, (B,), generator=g)
+    targets = torch.randint(0, C, (B,), generator=g)
+    noise = torch.randn(B, D, generator=g)
+    x_c = torch.mul(emb_c(labels), noise)
+    p_c = torch.nn.Softmax(dim=1)(lin_c(x_c))
+    loss_c = torch.nn.CrossEntropyLoss()(p_c, targets)   # the reference feeds softmax outputs to CrossEntropyLoss
+    loss_c.backward()
+
+    emb_g, lin_g = gnn.Embedding(V, D).to(DEV), gnn.Linear(D, C).to(DEV)
+    emb_g.load_state_dict(emb_c.state_dict())
+    lin_g.load_state_dict(lin_c.state_dict())
+    x_g = torch.mul(emb_g(labels.to(DEV)), noise.to(DEV))
+    p_g = gnn.Softmax()(lin_g(x_g))
+    loss_g = gnn.CrossEntropyLoss()(p_g, targets.to(DEV))
+    loss_g.backward()
+    assert_close(x_g, x_c, 1e-7, "embedding*noise")
+    assert_close(p_g, p_c, TOL_FWD, "softmax")
+    assert abs(float(loss_g) - float(loss_c)) <= 1e-6 * max(1.0, abs(float(loss_c)))
+    assert_close(emb_g.weight.grad, emb_c.weight.grad, TOL_WGRAD, "embedding grad")
+    assert_close(lin_g.weight.grad, lin_c.weight.grad, TOL_WGRAD, "linear grad through softmax+CE")
+    assert_close(lin_g.bias.grad, lin_c.bias.grad, TOL_WGRAD, "bias grad through softmax+CE")
+    # rows of the embedding gradient for labels that do not occur are exactly zero
+    absent = [v for v in range(V) if v not in set(labels.tolist())]
+    assert all(float(emb_g.weight.grad[v].abs().max()) == 0.0 for v in absent)
+
+
+@pytest.mark.parametrize("n", [64, 40000])
+def test_bce_with_logits(pg, n):
+    """relativistic_gan.py:95 BCEWithLogitsLoss (mean), incl. large |logits| (no overflow: log_sigmoid form)."""
+    import pytorch_gan_amd.nn as gnn
+
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(n, 1, generator=g) * 6).requires_grad_(True)
+    with torch.no_grad():
+        x[:4, 0] = torch.tensor([80.0, -80.0, 0.0, 1e-8])
+    t = (torch.rand(n, 1, generator=g) > 0.5).float()
+    ref = torch.nn.BCEWithLogitsLoss()(x, t)
+    ref.backward()
+    xg = x.detach().to(DEV).requires_grad_(True)
+    out = gnn.BCEWithLogitsLoss()(xg, t.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert_close(xg.grad, x.grad, 2e-6, "bce_with_logits grad")
+
+
+def test_swap_dcgan_block_clone_layers(pg):
+    """swap() re-classes the four extra leaf types of the DCGAN-block clones (acgan / relativistic_gan)."""
+    import pytorch_gan_amd.nn as gnn
+
+    m = torch.nn.ModuleDict({"emb": torch.nn.Embedding(10, 8), "aux": torch.nn.Sequential(torch.nn.Linear(8, 10), torch.nn.Softmax()),
+                             "ce": torch.nn.CrossEntropyLoss(), "bcel": torch.nn.BCEWithLogitsLoss()})
+    pg.swap(m)
+    assert type(m["emb"]) is gnn.Embedding and type(m["aux"][1]) is gnn.Softmax
+    assert type(m["ce"]) is gnn.CrossEntropyLoss and type(m["bcel"]) is gnn.BCEWithLogitsLoss
+    with pytest.raises(ValueError):
+        pg.swap(torch.nn.CrossEntropyLoss(label_smoothing=0.1))
