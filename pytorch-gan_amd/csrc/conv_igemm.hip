@@ -45,6 +45,12 @@ struct ConvGeom {
     short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
 };
 
+// A/B knobs of the MFMA loop shape: MIGAN_MFMA_V4 bit 0 = forward/dgrad kernels, bit 1 = wgrad kernels
+static int mfma_v4() {
+    static const int v = getenv("MIGAN_MFMA_V4") ? atoi(getenv("MIGAN_MFMA_V4")) : 0;
+    return v;
+}
+
 // q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
 static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
     s = 0;
@@ -347,8 +353,8 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
 // fetched back to back and hit in L2, instead of each tap re-reading the whole pixel range Ci/32 K-tiles later when
 // the per-XCD L2 has long been overwritten (rocprofv3 FETCH_SIZE on the collapsed DCGAN G.conv2 forward: 1056 MB for a
 // 67 MB input with the tap-outer order).  The 4 taps' offsets/masks are kept in registers (set up once).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false, bool V4 = false>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? (V4 ? 3 : 4) : 1)) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
     constexpr int BK = 32, LDK = BK + 1;
@@ -519,6 +525,50 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
         }
         okS = f_cok ? okA[NXT] : 0u;
         if (KTAIL) colokS = f_cok ? colok : 0u;
+        if constexpr (V4) {  // 8 groups of 2 k-pairs, fragment reads one group ahead (see wgrad_inc_kernel)
+            float a[2][2][TM], b[2][2][TN];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[0][q][i] = ap[q * 2 + i * 32 * LDK];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[0][q][j] = bp[q * 2 + j * 32 * LDK];
+            }
+#pragma unroll
+            for (int gk = 0; gk < BK / 4; ++gk) {
+                const int cur = gk & 1, nxt = cur ^ 1;
+                if (gk + 1 < BK / 4) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[nxt][q][i] = ap[((gk + 1) * 2 + q) * 2 + i * 32 * LDK];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[nxt][q][j] = bp[((gk + 1) * 2 + q) * 2 + j * 32 * LDK];
+                    }
+                }
+                if (gk < NL) {
+                    asm volatile("" : "+s"(f_c0));
+                    switch (gk) {
+                        case 0: IGEMM_ISSUE(0); break;
+                        case 1: IGEMM_ISSUE(1); break;
+                        case 2: IGEMM_ISSUE(2); break;
+                        case 3: IGEMM_ISSUE(3); break;
+                        case 4: IGEMM_ISSUE(4); break;
+                        case 5: IGEMM_ISSUE(5); break;
+                        case 6: IGEMM_ISSUE(6); break;
+                        default: IGEMM_ISSUE(7); break;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
@@ -547,6 +597,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep each load-issue slot between its neighbouring MFMA groups
+        }
         }
     };
     if (TAPIN) {
@@ -854,7 +905,9 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     if constexpr (BM * BN < 16384) {
         if (tapin) {
-            if (g.Ci % 32 == 0)
+            if (g.Ci % 32 == 0 && (mfma_v4() & 1))
+                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+            else if (g.Ci % 32 == 0)
                 hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
             else
                 hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
@@ -862,9 +915,12 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
             return 0;
         }
     }
-    if (g.Ci % 32 == 0)
-        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-    else
+    if (g.Ci % 32 == 0) {
+        if (mfma_v4() & 1)
+            hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+        else
+            hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    } else
         hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -891,6 +947,8 @@ static inline bool igemm_fast_ci(int Ci) { return Ci % 4 == 0 && Ci >= 8; }
 // Tile selection (pure function of the GEMM shape; also exported for the bench's per-kernel accounting).
 // code = fast*1000000 + BM*1000 + BN
 static int igemm_select(long maxM, int Co, bool fast, int ncls) {
+    static const int tile_env = getenv("MIGAN_IGEMM_TILE") ? atoi(getenv("MIGAN_IGEMM_TILE")) : 0;  // A/B knob, e.g. 128128
+    if (fast && tile_env && Co > 32) return 1000000 + tile_env;
     if (fast) {
         // candidates from the most MFMA-efficient tile down; take the first one that fills the chip
         // (>= 896 workgroups ~ 256 CUs x 4 resident), else the one with the most workgroups
@@ -1954,8 +2012,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
 // ------------------------------------------------------------------------------------------------
 // REFL (ReflectionPad2d folded into the gather, cyclegan/models.py:27-35): the mirrored coordinate is not linear in
 // (oi, oj), so only the image base n*Hi*Wi*Ci is carried and the in-image offset is rebuilt per load (~12 VALU).
-template <int BM, int BN, bool DYS, bool REFL = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_kernel(
+// V4: the MFMA stream of a K-tile runs in 8 groups of 2 k-pairs; the LDS fragment reads of group g+1 are issued before
+// the MFMAs of group g (register double buffer), so a wave's matrix instructions no longer wait for its own LDS round
+// trip (tools/mfma_loop_probe.hip: 97 % of peak for this loop shape against 94 % for read-wait-multiply per k-pair).
+template <int BM, int BN, bool DYS, bool REFL = false, bool V4 = false, int OCC = 3>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_inc_kernel(
     const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
     constexpr int BK = 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -2121,6 +2182,50 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
             f_bx += DX0 + (c1 ? DX1 : 0) + (c2 ? DX2 : 0);
             f_ba += DA0 + (c1 ? DA1 : 0) + (c2 ? DA2 : 0);
         }
+        if constexpr (V4) {
+            float a[2][2][TM], b[2][2][TN];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[0][q][i] = ap[q * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[0][q][j] = bp[q * 2 * LDB + j * 32];
+            }
+#pragma unroll
+            for (int gk = 0; gk < BK / 4; ++gk) {
+                const int cur = gk & 1, nxt = cur ^ 1;
+                if (gk + 1 < BK / 4) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[nxt][q][i] = ap[((gk + 1) * 2 + q) * 2 * LDA + i * 32];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[nxt][q][j] = bp[((gk + 1) * 2 + q) * 2 * LDB + j * 32];
+                    }
+                }
+                if (gk < NL) {
+                    asm volatile("" : "+v"(f_bx));
+                    switch (gk) {
+                        case 0: WGI_ISSUE(0); break;
+                        case 1: WGI_ISSUE(1); break;
+                        case 2: WGI_ISSUE(2); break;
+                        case 3: WGI_ISSUE(3); break;
+                        case 4: WGI_ISSUE(4); break;
+                        case 5: WGI_ISSUE(5); break;
+                        case 6: WGI_ISSUE(6); break;
+                        default: WGI_ISSUE(7); break;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
@@ -2148,6 +2253,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
     }
 #undef WGI_ISSUE
     if (bias_blk && tid < BM && co0 + tid < g.Co)
@@ -2171,30 +2277,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
 // Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
 // `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
 // split loop (LDS combine in fixed order) when there are many splits and few outputs.
-// bias slabs [nslab][Co] -> db[co] (fixed order); run by the trailing blocks of the reduce launches.  A block owns
-// BIAS_CB channels; its 256 / BIAS_CB slab-lanes each add every (256 / BIAS_CB)-th slab in double, then lane 0 adds the
-// lanes in order: the slabs of the streaming backward kernels number in the thousands (one per block of the pass).
-#define BIAS_CB 16
+// bias slabs [nslab][Co] -> db[co]; run by the trailing blocks of the reduce launches.  ONE WAVE per channel: lanes
+// stride over the slabs (the streaming backward kernels leave one slab per block: thousands), butterfly-add in double -
+// a fixed order, and the same shape as the stand-alone column-sum finalize it replaces (a serial loop over 4096 slabs
+// made these blocks the 100 us tail of the reduction launch).
+#define BIAS_CB 4  // channels (waves) per block
 __device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bpart, float* __restrict__ db, int nslab,
                                                  int Co, int accum, int blk) {
-    constexpr int LANES = 256 / BIAS_CB;
-    __shared__ double bred[256];
-    const int cl = threadIdx.x % BIAS_CB, ln = threadIdx.x / BIAS_CB;
-    const int co = blk * BIAS_CB + cl;
+    const int co = blk * BIAS_CB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= Co) return;  // wave-uniform
     double s = 0.0;
-    if (co < Co)
-        for (int k = ln; k < nslab; k += LANES) s += (double)bpart[(size_t)k * Co + co];
-    bred[threadIdx.x] = s;
-    __syncthreads();
-    if (ln == 0 && co < Co) {
-        for (int q = 1; q < LANES; ++q) s += bred[q * BIAS_CB + cl];
-        db[co] = accum ? db[co] + (float)s : (float)s;
-    }
+    for (int k = lane; k < nslab; k += 64) s += (double)bpart[(size_t)k * Co + co];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) db[co] = accum ? db[co] + (float)s : (float)s;
 }
 struct BiasRed {
     const float* bpart;  // NULL: no bias work
     float* db;
     int nslab, accum, main_blocks;
+    int nbias;           // leading blocks of the launch that reduce the bias slabs (they start first, never the tail)
 };
 template <int GROUPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
@@ -2202,13 +2304,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            const BiasRed br) {
     constexpr int OUTS = 256 / GROUPS;
     __shared__ float red[256];
-    if ((int)blockIdx.x >= br.main_blocks) {  // block-uniform
-        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x - br.main_blocks);
+    if ((int)blockIdx.x < br.nbias) {  // block-uniform
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
         return;
     }
     const size_t total = (size_t)Co * T * Ci;
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
-    const size_t src = (size_t)blockIdx.x * OUTS + lo;
+    const size_t src = (size_t)(blockIdx.x - br.nbias) * OUTS + lo;
     float s = 0.f;
     if (src < total)
         for (int k = grp; k < splits; k += GROUPS) s += part[(size_t)k * total + src];
@@ -2233,6 +2335,7 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
                                hipStream_t st, BiasRed br = BiasRed{}) {
     long total = (long)Co * T * Ci;
     const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
+    br.nbias = extra;
     if (splits >= 64 && total < (1 << 16)) {
         br.main_blocks = cdiv(total, 16);
         hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
@@ -2250,6 +2353,10 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     return 0;
 }
 
+static int wgrad_occ_env() {
+    static const int v = getenv("MIGAN_WGRAD_OCC") ? atoi(getenv("MIGAN_WGRAD_OCC")) : 0;  // 4: force <= 128 VGPRs
+    return v;
+}
 static int wgrad_var() {
     static const int v = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // tuning knob (A/B runs)
     return v;
@@ -2271,7 +2378,11 @@ static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 3 : (bm * bn >=
 // W = tiles * s / slots (waves), KT = K-tiles per block, t1 = MFMA time of one block K-tile, c0 = prologue + epilogue in
 // K-tile units, `lone` = a partly filled CU cannot go faster than ~1.3 block-steps (latency no longer hidden).
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
-    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 2;  // 1 = round-1 rule
+    // 1 (default) = round-1 rule: about 1024 workgroups, split count a multiple of 8.  2 = the time model below; measured
+    // slower on every shape (profiles/r02_wgrad_plan_ab.txt): it trades occupancy for fewer partial slabs, and a CU with
+    // 2 of its 3-4 workgroup slots filled hides far less latency than the model's MFMA-bound assumption allows.
+    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 1;
+    static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
     long Mpix = (long)N * Ho * Wo;
     // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
     // the split-K factor fills the chip (measured: G.conv1 up-conv wgrad 209 -> 186 us, PatchGAN 4x4 s2 wgrads -10 %,
@@ -2282,6 +2393,12 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
     if (maxs > 512) maxs = 512;
     if (maxs < 1) maxs = 1;
+    if (splits_env > 0) {
+        long want = splits_env > maxs ? maxs : splits_env;
+        pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
+        splits = cdiv(Mpix, pps);
+        return;
+    }
     if (plan_env == 1) {
         long want = cdiv(1024, tiles);
         if (want > maxs) want = maxs;
@@ -2402,14 +2519,14 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
                                                                   int accum, const BiasRed br) {
     constexpr int GROUPS = 4, OUTS = 256 / GROUPS;
     __shared__ float red[256];
-    if ((int)blockIdx.x >= br.main_blocks) {  // block-uniform: trailing blocks reduce the bias slabs
-        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x - br.main_blocks);
+    if ((int)blockIdx.x < br.nbias) {  // block-uniform: leading blocks reduce the bias slabs
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
         return;
     }
     const size_t slab = (size_t)Co * 4 * Ci;  // one (class, split) slab
     const size_t total = (size_t)Co * Ci * 9;
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
-    const size_t i = (size_t)blockIdx.x * OUTS + lo;  // [co][rs][ci] order
+    const size_t i = (size_t)(blockIdx.x - br.nbias) * OUTS + lo;  // [co][rs][ci] order
     int ci = 0, rs = 0, co = 0;
     float acc = 0.f;
     if (i < total) {
@@ -2465,7 +2582,9 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8, 4);                                                           \
-        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+        if (inc && (mfma_v4() & 2))                                                                                \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
     if (bm == 128) UPW_LAUNCH(128, 128);
@@ -2474,9 +2593,10 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
 #undef UPW_LAUNCH
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
-    BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64)};
+    BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64), 0};
     if (db && db_slabs) { br.bpart = db_slabs; br.nslab = db_nslab; }
-    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + (br.bpart ? cdiv(Co, BIAS_CB) : 0)), dim3(256), 0, st, ws,
+    br.nbias = br.bpart ? cdiv(Co, BIAS_CB) : 0;
+    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws,
                        dw_oihw, g.splits, Co, Ci, accumulate, br);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -2843,7 +2963,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     if (db && !db_slabs && !migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather)) return (int)hipErrorInvalidValue;
     // external bias slabs (per-block column sums of dy written by the kernel that produced dy): every path below ends in
     // a fixed-order reduction launch whose trailing blocks add them into db
-    const BiasRed ext = (db && db_slabs) ? BiasRed{db_slabs, db, db_nslab, db_accumulate, 0} : BiasRed{};
+    const BiasRed ext = (db && db_slabs) ? BiasRed{db_slabs, db, db_nslab, db_accumulate, 0, 0} : BiasRed{};
     if (thin_wgrad_ok(Co, R, S, Ci, stride, gather)) {
         ThinGeom tg = {N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, 0, 0, 0};
         thin_plan(N, Hi, Wi, Ci, tg);
@@ -2921,8 +3041,16 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);                                                              \
-        if (inc && refl)                                                                                           \
+        if (inc && refl && (mfma_v4() & 2))                                                                        \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        else if (inc && refl && wgrad_occ_env() == 4)                                                              \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true, false, 4>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        else if (inc && refl)                                                                                      \
             hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
+        else if (inc && (mfma_v4() & 2))                                                                           \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        else if (inc && wgrad_occ_env() == 4)                                                                      \
+            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, false, false, 4>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
@@ -2947,7 +3075,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
 #undef WG_LAUNCH
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st,
-                                   ext.bpart ? ext : BiasRed{g.bpart, db, g.splits, db_accumulate, 0});
+                                   ext.bpart ? ext : BiasRed{g.bpart, db, g.splits, db_accumulate, 0, 0});
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);

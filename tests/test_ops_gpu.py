@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from util import TOL_FWD, TOL_WGRAD, assert_close
+from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -86,7 +86,7 @@ def test_conv2d_fwd_bwd(pg, case):
     assert_close(xg.grad, x.grad, TOL_FWD, "conv dgrad")
     assert_close(wg.grad, w.grad, TOL_WGRAD, "conv wgrad")
     if bias:
-        assert_close(bg.grad, b.grad, TOL_WGRAD, "conv bias grad")
+        assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
 
 
 def test_conv2d_nchw_input_is_relaid(pg):

@@ -1,5 +1,5 @@
 """Shared helpers for the parity tests.  Stated fp32 tolerances:
-   per-op forward / dgrad  rel_fro <= 2e-6 (we allow 5e-6 for long reductions, K up to 5184),
+   per-op forward / dgrad  rel_fro <= 2e-6 (3e-6 allowed: long reductions, K up to 5184, measured 2.3e-6),
    wgrad / statistics over >=1e5 terms  rel_fro <= 1e-5, whole-model forward rel_fro <= 1e-5,
    whole-model gradients rel_fro <= 5e-3 (two fp32 evaluations of a LeakyReLU/ReLU/MaxPool network may
    take different branches for elements within rounding of 0; ONE flipped element of an N-element activation
@@ -10,9 +10,13 @@ import copy
 import numpy as np
 import torch
 
-TOL_FWD = 5e-6
-TOL_WGRAD = 2e-5
-TOL_MODEL_FWD = 2e-5
+# measured on MI355X against torch CPU fp32 (gpurun_out/r2a/test_errors.log, 456 comparisons): conv/linear forward <= 1.9e-6,
+# dgrad <= 2.3e-6 (K = 5184 terms; the CPU fp32 result is itself ~1e-6 from fp64), weight gradients <= 2.4e-6, bias
+# gradients (column sums over up to 4e5 pixels) <= 1.0e-5, whole-model forward <= 3.4e-6
+TOL_FWD = 3e-6
+TOL_WGRAD = 1e-5
+TOL_BIAS = 2e-5
+TOL_MODEL_FWD = 1e-5
 TOL_MODEL_GRAD = 5e-3  # see test_models_gpu._noise_aware: activation sign-decision flips
 
 
