@@ -154,6 +154,20 @@ int migan_act_bwd_colsum(const float* dy, const float* y, const float* mask_gc, 
  * nn.LeakyReLU(0.2)/ReLU/Tanh/Sigmoid: dcgan.py:57,63,92  cyclegan/models.py:30,52,82,110 ... */
 int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
 int migan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope, void* stream);
+/* Second-order terms for the conv-critic gradient penalties (dragan.py:144-167, stargan.py:142-161,
+ * dualgan.py:116-135), where autograd.grad(..., create_graph=True) differentiates the backward pass again:
+ * migan_act_bwd2: out = gg * g * d f'(y)/dy (tanh, sigmoid; zero for LeakyReLU/ReLU).
+ * migan_norm_bwd2 (csrc/norm.hip): with d = gradient w.r.t. the norm output (first backward), u = gradient w.r.t. the
+ * first backward's dx: gd = d(L)/d(d), gx = d(L)/d(x), dgamma (G == 1) - formulas in norm.hip.  ws: migan_norm_workspace2.
+ * migan_dragan_interp: alpha*X + (1-alpha)*(X + 0.5*std(X)*noise) with std from the device scalar var_biased (the biased
+ * variance over all n elements, migan_norm_moments on the flattened tensor) - dragan.py:147-149 without a host sync. */
+int migan_act_bwd2(const float* g, const float* gg, const float* y, float* out, size_t n, int act, void* stream);
+size_t migan_norm_workspace2(int G, int P, int C);
+int migan_norm_bwd2(const float* x, const float* d, const float* u, const float* mean, const float* invstd,
+                    const float* gamma, float* gd, float* gx, float* dgamma, int dgamma_accumulate, int G, int P, int C,
+                    float* ws, size_t ws_bytes, void* stream);
+int migan_dragan_interp(const float* x, const float* alpha, const float* noise, const float* var_biased, float* out,
+                        size_t n, void* stream);
 /* nn.PReLU() single shared slope: srgan/models.py:24,38,57.  ws: migan_reduce_workspace() bytes. */
 size_t migan_reduce_workspace(void);
 int migan_prelu_fwd(const float* x, const float* a, float* y, size_t n, void* stream);

@@ -114,7 +114,12 @@ def load_reference():
         ns = _script_ns(opt=opt, img_shape=(channels, img_size, img_size))
         return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "gan", "gan.py"), ns))
 
-    ref.dcgan, ref.wgan_gp, ref.gan = dcgan, wgan_gp, gan
+    def dragan(img_size, latent_dim=100, channels=1):
+        opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
+        ns = _script_ns(opt=opt, lambda_gp=10)
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "dragan", "dragan.py"), ns))
+
+    ref.dcgan, ref.wgan_gp, ref.gan, ref.dragan = dcgan, wgan_gp, gan, dragan
     return ref
 
 
@@ -310,6 +315,50 @@ def pin_mlp(ref):
     out_d, g_d, _, _ = compare_fwd_bwd(D_r, D_o, [out_g], "gan.D")
     gk, gd, gh = grads_digest(g_g)
     save("gan_28", meta=meta(), z=z, gen=out_g, d_out=out_d, g_keys=gk, g_digest=gd, g_head=gh)
+
+
+def pin_dragan(ref):
+    """the conv-critic gradient penalty (double backward through Conv2d / LeakyReLU / Dropout2d /
+    BatchNorm2d(eps .8) / Linear / Sigmoid) of dragan.py:144-167, extracted from the script by AST."""
+    print("dragan (dragan.py:46-99,144-167)")
+    ns = ref.dragan(32)
+    built_equal(ns.Generator, lambda: M.DcganGenerator(32, 100, 1), "dragan.G",
+                post=(ns.weights_init_normal, M.init_normal_dcgan))
+    D_r, D_o = built_equal(ns.Discriminator, lambda: M.DcganDiscriminator(32, 1), "dragan.D",
+                           post=(ns.weights_init_normal, M.init_normal_dcgan))
+    seed_all(4)
+    X = torch.rand(8, 1, 32, 32) * 2 - 1
+    for p in D_r.parameters():
+        p.grad = None
+    masks = []
+    hs = hook_masks(D_r, masks)
+    np.random.seed(5)
+    torch.manual_seed(6)
+    gp_r = ns.compute_gradient_penalty(D_r, X)   # draws alpha (numpy), noise (torch), then the Dropout2d masks (torch)
+    for h in hs:
+        h.remove()
+    gp_r.backward()
+    np.random.seed(5)
+    torch.manual_seed(6)
+    alpha = torch.tensor(np.random.random(size=tuple(X.shape)), dtype=torch.float32)
+    noise = torch.rand(X.size())
+    for p in D_o.parameters():
+        p.grad = None
+    with M.feed_masks(masks=[m.numpy() for m in masks]):
+        gp_o = S.dragan_gradient_penalty(D_o, X, alpha, noise, 10)
+    gp_o.backward()
+    assert torch.equal(gp_r, gp_o), "dragan gradient penalty differs (%r vs %r)" % (gp_r.item(), gp_o.item())
+    grads = {}
+    for (k, a), (_, b) in zip(D_r.named_parameters(), D_o.named_parameters()):
+        assert (a.grad is None) == (b.grad is None), k
+        if a.grad is not None:
+            assert torch.equal(a.grad, b.grad), "dragan penalty grad of %s differs" % k
+            grads[k] = a.grad.clone()
+    check_same_params(D_r, D_o, "dragan.D (BatchNorm buffers after the penalty forward)")
+    pk, pd, ph = grads_digest(grads)
+    mp, nm = masks_pack(masks)
+    save("dragan_32", meta=meta(), X=X, alpha=alpha, noise=noise, gp=gp_r.detach(), gp_keys=pk, gp_digest=pd, gp_head=ph,
+         n_masks=nm, **mp)
 
 
 def pin_cyclegan(ref):
@@ -509,6 +558,7 @@ def main():
     pin_dropout_semantics()
     pin_dcgan(ref)
     pin_mlp(ref)
+    pin_dragan(ref)
     pin_cyclegan(ref)
     pin_srgan(ref)
     pin_pix2pix(ref)

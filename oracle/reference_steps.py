@@ -9,6 +9,7 @@ order, and without the logging / image-saving side effects.  Line references:
   cyclegan_step   implementations/cyclegan/cyclegan.py:159-239
   pix2pix_step    implementations/pix2pix/pix2pix.py:123-172
   srgan_step      implementations/srgan/srgan.py:97-145
+  dragan_step     implementations/dragan/dragan.py:144-167,176-217   (conv-critic gradient penalty)
 Pinned against the reference by oracle/pin_against_reference.py.
 """
 import itertools
@@ -109,6 +110,51 @@ def wgan_gp_step(s, real_imgs, i, z=None, alpha=None):
         s.opt_G.step()
         out["g_loss"] = g_loss.detach()
     return out
+
+
+# ------------------------------------------------------------------------------------------------ dragan (8f F1)
+def make_dragan(img_size=32, latent_dim=100, channels=1):
+    """dragan.py:46-99,115-120: the generator / discriminator classes are those of dcgan.py (same layer lists)."""
+    s = make_dcgan(img_size, latent_dim, channels)
+    s.lambda_gp = 10
+    return s
+
+
+def dragan_gradient_penalty(D, X, alpha=None, noise=None, lambda_gp=10):
+    """dragan.py:144-167.  alpha ~ np.random.random(X.shape), noise ~ torch.rand(X.size()) when not given (the
+    reference's draw order); the gradient norm is taken over dim 1 - the CHANNEL dimension of the (B, C, H, W)
+    gradient - as the reference writes it."""
+    if alpha is None:
+        alpha = _f32(np.random.random(size=tuple(X.shape)))
+    if noise is None:
+        noise = torch.rand(X.size())
+    interpolates = alpha * X + ((1 - alpha) * (X + 0.5 * X.std() * noise))
+    interpolates = interpolates.detach().requires_grad_(True)
+    d_interpolates = D(interpolates)
+    fake = torch.ones(X.shape[0], 1, dtype=X.dtype)
+    gradients = autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=fake, create_graph=True,
+                              retain_graph=True, only_inputs=True)[0]
+    return lambda_gp * ((gradients.norm(2, dim=1) - 1) ** 2).mean()
+
+
+def dragan_step(s, real_imgs, z=None, alpha=None, noise=None):
+    """dragan.py:176-217.  Quirk kept: d_loss is computed (its two discriminator forwards update the BatchNorm running
+    statistics and consume Dropout2d draws) but only gradient_penalty.backward() feeds optimizer_D.step()."""
+    B = real_imgs.shape[0]
+    valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+    s.opt_G.zero_grad()
+    if z is None:
+        z = _f32(np.random.normal(0, 1, (B, s.latent_dim)))
+    gen = s.G(z)
+    g_loss = s.bce(s.D(gen), valid)
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    d_loss = (s.bce(s.D(real_imgs), valid) + s.bce(s.D(gen.detach()), fake)) / 2
+    gp = dragan_gradient_penalty(s.D, real_imgs.data, alpha, noise, s.lambda_gp)
+    gp.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gp": gp.detach(), "gen_imgs": gen.detach()}
 
 
 # ------------------------------------------------------------------------------------------------ cyclegan

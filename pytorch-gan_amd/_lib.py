@@ -80,6 +80,10 @@ _SIGS = {
     "migan_act_bwd_colsum": (c_int, [P] * 5 + [c_int] * 4 + [c_float, P]),
     "migan_act_fwd": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "migan_act_bwd": (c_int, [P, P, P, c_size_t, c_int, c_float, P]),
+    "migan_act_bwd2": (c_int, [P, P, P, P, c_size_t, c_int, P]),
+    "migan_norm_workspace2": (c_size_t, [c_int] * 3),
+    "migan_norm_bwd2": (c_int, [P] * 9 + [c_int] * 4 + [P, c_size_t, P]),
+    "migan_dragan_interp": (c_int, [P, P, P, P, P, c_size_t, P]),
     "migan_reduce_workspace": (c_size_t, []),
     "migan_prelu_fwd": (c_int, [P, P, P, c_size_t, P]),
     "migan_prelu_bwd": (c_int, [P, P, P, P, P, P, c_size_t, P]),

@@ -45,12 +45,6 @@ struct ConvGeom {
     short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
 };
 
-// A/B knobs of the MFMA loop shape: MIGAN_MFMA_V4 bit 0 = forward/dgrad kernels, bit 1 = wgrad kernels
-static int mfma_v4() {
-    static const int v = getenv("MIGAN_MFMA_V4") ? atoi(getenv("MIGAN_MFMA_V4")) : 0;
-    return v;
-}
-
 // q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
 static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
     s = 0;
@@ -353,8 +347,8 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
 // fetched back to back and hit in L2, instead of each tap re-reading the whole pixel range Ci/32 K-tiles later when
 // the per-XCD L2 has long been overwritten (rocprofv3 FETCH_SIZE on the collapsed DCGAN G.conv2 forward: 1056 MB for a
 // 67 MB input with the tap-outer order).  The 4 taps' offsets/masks are kept in registers (set up once).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false, bool V4 = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? (V4 ? 3 : 4) : 1)) void igemm_pipe_kernel(
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
     constexpr int BK = 32, LDK = BK + 1;
@@ -525,50 +519,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? (V4 ? 3 : 4) : 1)) void ig
         }
         okS = f_cok ? okA[NXT] : 0u;
         if (KTAIL) colokS = f_cok ? colok : 0u;
-        if constexpr (V4) {  // 8 groups of 2 k-pairs, fragment reads one group ahead (see wgrad_inc_kernel)
-            float a[2][2][TM], b[2][2][TN];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[0][q][i] = ap[q * 2 + i * 32 * LDK];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[0][q][j] = bp[q * 2 + j * 32 * LDK];
-            }
-#pragma unroll
-            for (int gk = 0; gk < BK / 4; ++gk) {
-                const int cur = gk & 1, nxt = cur ^ 1;
-                if (gk + 1 < BK / 4) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) a[nxt][q][i] = ap[((gk + 1) * 2 + q) * 2 + i * 32 * LDK];
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) b[nxt][q][j] = bp[((gk + 1) * 2 + q) * 2 + j * 32 * LDK];
-                    }
-                }
-                if (gk < NL) {
-                    asm volatile("" : "+s"(f_c0));
-                    switch (gk) {
-                        case 0: IGEMM_ISSUE(0); break;
-                        case 1: IGEMM_ISSUE(1); break;
-                        case 2: IGEMM_ISSUE(2); break;
-                        case 3: IGEMM_ISSUE(3); break;
-                        case 4: IGEMM_ISSUE(4); break;
-                        case 5: IGEMM_ISSUE(5); break;
-                        case 6: IGEMM_ISSUE(6); break;
-                        default: IGEMM_ISSUE(7); break;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
@@ -597,7 +547,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? (V4 ? 3 : 4) : 1)) void ig
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep each load-issue slot between its neighbouring MFMA groups
-        }
         }
     };
     if (TAPIN) {
@@ -905,9 +854,7 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     if constexpr (BM * BN < 16384) {
         if (tapin) {
-            if (g.Ci % 32 == 0 && (mfma_v4() & 1))
-                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-            else if (g.Ci % 32 == 0)
+            if (g.Ci % 32 == 0)
                 hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
             else
                 hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
@@ -915,12 +862,9 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
             return 0;
         }
     }
-    if (g.Ci % 32 == 0) {
-        if (mfma_v4() & 1)
-            hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-        else
-            hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-    } else
+    if (g.Ci % 32 == 0)
+        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    else
         hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -946,7 +890,7 @@ static inline bool igemm_fast_ci(int Ci) { return Ci % 4 == 0 && Ci >= 8; }
 
 // Tile selection (pure function of the GEMM shape; also exported for the bench's per-kernel accounting).
 // code = fast*1000000 + BM*1000 + BN
-static int igemm_select(long maxM, int Co, bool fast, int ncls) {
+static int igemm_select(long maxM, int Co, bool fast, int ncls, long K = 0) {
     static const int tile_env = getenv("MIGAN_IGEMM_TILE") ? atoi(getenv("MIGAN_IGEMM_TILE")) : 0;  // A/B knob, e.g. 128128
     if (fast && tile_env && Co > 32) return 1000000 + tile_env;
     if (fast) {
@@ -956,10 +900,17 @@ static int igemm_select(long maxM, int Co, bool fast, int ncls) {
             long b128 = (long)cdiv(maxM, 128) * cdiv(Co, 128) * ncls;
             long b64n = (long)cdiv(maxM, 128) * cdiv(Co, 64) * ncls;
             long b64 = (long)cdiv(maxM, 64) * cdiv(Co, 64) * ncls;
-            if (Co > 64 && b128 >= 896) return 1128128;
+            // a few workgroups more than one wave of the chip (1024 resident 128x128 workgroups) leave a tail that runs at
+            // a fraction of the occupancy: SRGAN D Conv2d(512,512,3,2,1) dgrad, 1152 workgroups, 449 us -> 404 us with
+            // the half-width tile (profiles/r02_tile_sweep.txt)
+            const bool tail128 = b128 > 1024 && b128 <= 1280;
+            if (Co > 64 && b128 >= 896 && !tail128) return 1128128;
             if (b64n >= 896) return 1128064;
             if (Co > 64 && b128 >= 512 && b64 < 1792) return 1128128;
-            return b64n >= 512 ? 1128064 : 1064064;
+            // long-K GEMMs with few rows (SRGAN D 512->512 @24x24, K = 4608): 576 half-width workgroups leave the chip
+            // 2.25-deep; the 64x64 tile doubles them (479 -> 418 us)
+            if (b64n >= 512 && !(K >= 4096 && b64n < 768)) return 1128064;
+            return 1064064;
         }
         return 1128032;
     }
@@ -1417,7 +1368,9 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
         if (g.N <= 65535 && thin_conv_plan(g, tc, lds, max_tiles))
             return launch_thin_conv(g, tc, lds, max_tiles, A, Bw, bias, C, st);
     }
-    switch (igemm_select(maxM, g.Co, fast, g.ncls)) {
+    int ktaps = 0;
+    for (int c = 0; c < g.ncls; ++c) ktaps = g.ntap[c] > ktaps ? g.ntap[c] : ktaps;
+    switch (igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci)) {
         case 1128128:
 #ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
@@ -2012,11 +1965,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
 // ------------------------------------------------------------------------------------------------
 // REFL (ReflectionPad2d folded into the gather, cyclegan/models.py:27-35): the mirrored coordinate is not linear in
 // (oi, oj), so only the image base n*Hi*Wi*Ci is carried and the in-image offset is rebuilt per load (~12 VALU).
-// V4: the MFMA stream of a K-tile runs in 8 groups of 2 k-pairs; the LDS fragment reads of group g+1 are issued before
-// the MFMAs of group g (register double buffer), so a wave's matrix instructions no longer wait for its own LDS round
-// trip (tools/mfma_loop_probe.hip: 97 % of peak for this loop shape against 94 % for read-wait-multiply per k-pair).
-template <int BM, int BN, bool DYS, bool REFL = false, bool V4 = false, int OCC = 3>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_inc_kernel(
+template <int BM, int BN, bool DYS, bool REFL = false>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_kernel(
     const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
     constexpr int BK = 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -2182,50 +2132,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_inc_k
             f_bx += DX0 + (c1 ? DX1 : 0) + (c2 ? DX2 : 0);
             f_ba += DA0 + (c1 ? DA1 : 0) + (c2 ? DA2 : 0);
         }
-        if constexpr (V4) {
-            float a[2][2][TM], b[2][2][TN];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[0][q][i] = ap[q * 2 * LDA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[0][q][j] = bp[q * 2 * LDB + j * 32];
-            }
-#pragma unroll
-            for (int gk = 0; gk < BK / 4; ++gk) {
-                const int cur = gk & 1, nxt = cur ^ 1;
-                if (gk + 1 < BK / 4) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) a[nxt][q][i] = ap[((gk + 1) * 2 + q) * 2 * LDA + i * 32];
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) b[nxt][q][j] = bp[((gk + 1) * 2 + q) * 2 * LDB + j * 32];
-                    }
-                }
-                if (gk < NL) {
-                    asm volatile("" : "+v"(f_bx));
-                    switch (gk) {
-                        case 0: WGI_ISSUE(0); break;
-                        case 1: WGI_ISSUE(1); break;
-                        case 2: WGI_ISSUE(2); break;
-                        case 3: WGI_ISSUE(3); break;
-                        case 4: WGI_ISSUE(4); break;
-                        case 5: WGI_ISSUE(5); break;
-                        case 6: WGI_ISSUE(6); break;
-                        default: WGI_ISSUE(7); break;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             if ((kp & 1) == 0 && (kp >> 1) < NL) {
@@ -2252,7 +2158,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_inc_k
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
         }
     }
 #undef WGI_ISSUE
@@ -2353,10 +2258,6 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     return 0;
 }
 
-static int wgrad_occ_env() {
-    static const int v = getenv("MIGAN_WGRAD_OCC") ? atoi(getenv("MIGAN_WGRAD_OCC")) : 0;  // 4: force <= 128 VGPRs
-    return v;
-}
 static int wgrad_var() {
     static const int v = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // tuning knob (A/B runs)
     return v;
@@ -2370,18 +2271,35 @@ static int wgrad_bn(int Co, int Ncol) {
 // Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
 static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 3 : (bm * bn >= 8192 ? 4 : 7); }
 
-// Split-K factor.  The launch is tiles * splits workgroups on 256 CUs x occ resident slots: a count just above a whole
-// number of waves leaves a tail that runs at a fraction of the chip (R256 wgrad, cyclegan/models.py:28: 36 tiles x 32
-// splits = 1152 blocks on 768 slots = 1.5 waves), and every split costs a slab of partial sums that the reduction
-// re-reads.  First-order time model, minimised over the split count:
-//   t(s) = (KT + c0) * t1 * [floor(W) * occ + max(frac(W) * occ, lone)]  +  s * outputs * 8 B / 3 TB/s
-// W = tiles * s / slots (waves), KT = K-tiles per block, t1 = MFMA time of one block K-tile, c0 = prologue + epilogue in
-// K-tile units, `lone` = a partly filled CU cannot go faster than ~1.3 block-steps (latency no longer hidden).
+// Split-K factor.  The launch is tiles * splits equal workgroups on 256 CUs x occ resident slots.  Measured on MI355X
+// (profiles/r02_wgrad_split_sweep.txt): what decides the time is how EVENLY the workgroups fall on the CUs - R256 wgrad
+// (cyclegan/models.py:28; 36 tiles, 3 slots per CU): 21 splits = 756 workgroups = one full wave 374 us, 24 splits = 864
+// (a wave + 1/8) 444 us, 32 splits (the round-1 rule "about 1024 workgroups") 410-455 us, 64 splits = 3 full waves 379 us;
+// Conv2d(64,128,3,2,1) with 10 tiles: 240 workgroups (one per CU) 296 us, 320 (a quarter of the CUs get two) 351 us.
+// So: time model with CU-granular balance, minimised over the split count.
+//   a CU that runs j workgroups side by side advances all of them one K-tile in j * t1 / eff(j)  (eff = share of the
+//   MFMA rate j resident workgroups sustain: 1 -> .45, 2 -> .65, 3 -> .75, >= 4 -> .80);
+//   full waves: floor(W) * (KT + c0) * occ * t1 / eff(occ);  the rest r workgroups: j = ceil(r / 256) on the busiest CU;
+//   + the partial-sum slabs the reduction re-reads: s * outputs * 8 B at 3 TB/s.
+static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int occ, double out_bytes) {
+    static const double eff[5] = {0.45, 0.45, 0.65, 0.75, 0.80};
+    const double t1 = (double)bm * bn * 64.0 / (157.3e12 / 256.0);  // one workgroup K-tile at the MFMA peak of one CU
+    const double c0 = 4.0;                                          // prologue + epilogue in K-tile units
+    const long pp = cdiv(cdiv(Mpix, s_), 32) * 32;
+    const double kt = (double)pp / 32.0 + c0;
+    const long blocks = tiles * s_, slots = 256L * occ;
+    const long full = blocks / slots, rem = blocks - full * slots;
+    const int jo = occ > 4 ? 4 : occ;
+    double t = (double)full * kt * t1 * occ / eff[jo];
+    if (rem > 0) {
+        const long j = cdiv(rem, 256);
+        t += kt * t1 * (double)j / eff[j > 4 ? 4 : j];
+    }
+    return t + (double)s_ * out_bytes / 3.0e12 + (s_ > 1 ? 4e-6 : 0.0);
+}
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
-    // 1 (default) = round-1 rule: about 1024 workgroups, split count a multiple of 8.  2 = the time model below; measured
-    // slower on every shape (profiles/r02_wgrad_plan_ab.txt): it trades occupancy for fewer partial slabs, and a CU with
-    // 2 of its 3-4 workgroup slots filled hides far less latency than the model's MFMA-bound assumption allows.
-    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 1;
+    // 3 (default) = the balance model above; 1 = round-1 rule: about 1024 workgroups, split count a multiple of 8
+    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 3;
     static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
     long Mpix = (long)N * Ho * Wo;
     // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
@@ -2409,22 +2327,14 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
         return;
     }
     const int occ = wgrad_occ(BMsel, bn);
-    const double slots = 256.0 * occ;
-    const double t1 = (double)(BMsel * bn / 4) / 2.4e9 / 0.8;  // seconds per block K-tile at 80 % of the MFMA rate
-    const double c0 = 6.0, lone = 1.3;
     const double out_bytes = (double)Co * Ncol * ncls * 8.0;
     double best = 1e30;
     long best_s = 1;
     for (long s_ = 1; s_ <= maxs; ++s_) {
         const long pp = cdiv(cdiv(Mpix, s_), 32) * 32;
-        const long sp = cdiv(Mpix, pp);  // the split count this request really produces
-        if (sp != s_) continue;
-        const double W = tiles * (double)sp / slots;
-        const double fl = floor(W), fr = W - fl;
-        const double kt = (double)pp / 32.0;
-        double t = (kt + c0) * t1 * (fl * occ + (fr > 1e-9 ? (fr * occ > lone ? fr * occ : lone) : 0.0));
-        t += sp * out_bytes / 3.0e12 + (sp > 1 ? 4e-6 : 0.0);
-        if (t < best) { best = t; best_s = sp; }
+        if (cdiv(Mpix, pp) != s_) continue;  // the split count this request really produces
+        const double t = wgrad_model(tiles, s_, Mpix, BMsel, bn, occ, out_bytes);
+        if (t < best) { best = t; best_s = s_; }
     }
     pps = (int)(cdiv(cdiv(Mpix, best_s), 32) * 32);
     splits = cdiv(Mpix, pps);
@@ -2582,9 +2492,7 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8, 4);                                                           \
-        if (inc && (mfma_v4() & 2))                                                                                \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
-        else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
     if (bm == 128) UPW_LAUNCH(128, 128);
@@ -3041,16 +2949,8 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);                                                              \
-        if (inc && refl && (mfma_v4() & 2))                                                                        \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
-        else if (inc && refl && wgrad_occ_env() == 4)                                                              \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true, false, 4>), grid_, dim3(256), 0, st, g, x, dy, ws); \
-        else if (inc && refl)                                                                                      \
+        if (inc && refl)                                                                                           \
             hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
-        else if (inc && (mfma_v4() & 2))                                                                           \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws); \
-        else if (inc && wgrad_occ_env() == 4)                                                                      \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, false, false, 4>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)

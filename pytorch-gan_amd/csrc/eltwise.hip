@@ -91,6 +91,48 @@ MIGAN_API int migan_act_bwd_nc(const float* dy, const float* y, const float* mas
     return 0;
 }
 
+// Second derivative through the activation backward (gradient penalties differentiate dx = g * f'(y) again):
+// out = gg * g * d f'(y)/dy, with f' expressed through the output y: tanh 1 - y^2 -> -2y, sigmoid y(1-y) -> 1 - 2y;
+// zero for the piecewise-linear activations (dragan.py:91-92 ends in Sigmoid).
+__global__ void act_bwd2_kernel(const float* __restrict__ g, const float* __restrict__ gg, const float* __restrict__ y,
+                                float* __restrict__ out, size_t n, int act) {
+    GRID_STRIDE(i, n) {
+        const float v = y[i];
+        const float d2 = act == ACT_TANH ? -2.f * v : (act == ACT_SIGMOID ? 1.f - 2.f * v : 0.f);
+        out[i] = gg[i] * g[i] * d2;
+    }
+}
+MIGAN_API int migan_act_bwd2(const float* g, const float* gg, const float* y, float* out, size_t n, int act,
+                             void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, gg, y, out, n, act);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// DRAGAN interpolation (dragan.py:147-149): out = alpha*X + (1 - alpha)*(X + 0.5*std(X)*noise), std = the UNBIASED
+// standard deviation over all n elements of X, given as device scalars mean/var (biased variance from
+// migan_norm_moments on the flattened tensor) so that no host sync is needed.
+__global__ void dragan_interp_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                     const float* __restrict__ noise, const float* __restrict__ var,
+                                     float* __restrict__ out, size_t n) {
+    const double nn = (double)n;
+    const float sd = (float)sqrt((double)var[0] * (nn > 1.0 ? nn / (nn - 1.0) : 1.0));
+    const float hs = 0.5f * sd;
+    GRID_STRIDE(i, n) {
+        const float a = alpha[i], xv = x[i];
+        out[i] = a * xv + (1.f - a) * (xv + hs * noise[i]);
+    }
+}
+MIGAN_API int migan_dragan_interp(const float* x, const float* alpha, const float* noise, const float* var_biased,
+                                  float* out, size_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dragan_interp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, noise,
+                       var_biased, out, n);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,

@@ -586,3 +586,203 @@ MIGAN_API int migan_rsqrt_eps(const float* var, float* invstd, int C, float eps,
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Second-order backward of the normalisation (conv-critic gradient penalties: dragan.py:144-167 back-propagates through
+// autograd.grad of a BatchNorm discriminator, dualgan.py:116-135 through InstanceNorm).  First-order backward, per
+// (g, c) over P pixels, xh = (x - mean) * invstd, a = gamma * invstd:
+//     dx = a * (d - m1 - xh * m2),   m1 = mean(d),  m2 = mean(d * xh)          (d = gradient w.r.t. the norm output)
+// Given u = gradient w.r.t. dx, with Su = sum u, Sux = sum u*xh, Sud = sum u*d, Q = Sud - m1*Su - m2*Sux:
+//     g_d = a * (u - Su/P - xh * Sux/P)                                       (the operator is self-adjoint)
+//     g_x = -gamma * invstd^2 * ( xh * Q/P + Sux/P * (d - m1 - xh*m2) + m2 * (u - Su/P - xh*Sux/P) )
+//     g_gamma = invstd * Q      (G == 1)
+// Pass 1 (norm_bwd2_partial_kernel) = 5 sums per (g, chunk, c): Su, Sux, Sud, sum d, sum d*xh; pass 2 finalises them in
+// double (one wave per (g,c)); pass 3 streams x, d, u once and writes g_d and g_x.
+// ---------------------------------------------------------------------------------------------
+template <int VW>
+__global__ __launch_bounds__(256) void norm_bwd2_partial_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                                const float* __restrict__ u,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ part,
+                                                                int P, int C, int CTX, int chunk, int nchunks) {
+    __shared__ float red[5][256 * VW];
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z, ck = blockIdx.y;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    const bool cok = c < C;
+    float s[5][VW], mu[VW], is[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s[q][v] = 0.f;
+        mu[v] = cok ? mean[(size_t)g * C + c + v] : 0.f;
+        is[v] = cok ? invstd[(size_t)g * C + c + v] : 0.f;
+    }
+    int p0 = ck * chunk, p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    const size_t base = (size_t)g * P * C + c;
+    if (cok) {
+        for (int p = p0 + ty; p < p1; p += TY) {
+            const size_t e = base + (size_t)p * C;
+            float xv[VW], dv[VW], uv[VW];
+            if (VW == 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(x + e), b = *reinterpret_cast<const f32x4*>(d + e),
+                            cc = *reinterpret_cast<const f32x4*>(u + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; uv[k] = cc[k]; }
+            } else {
+                xv[0] = x[e]; dv[0] = d[e]; uv[0] = u[e];
+            }
+#pragma unroll
+            for (int v = 0; v < VW; ++v) {
+                const float xh = (xv[v] - mu[v]) * is[v];
+                s[0][v] += uv[v];
+                s[1][v] += uv[v] * xh;
+                s[2][v] += uv[v] * dv[v];
+                s[3][v] += dv[v];
+                s[4][v] += dv[v] * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int v = 0; v < VW; ++v) red[q][tid * VW + v] = s[q][v];
+    __syncthreads();
+    if (ty == 0 && cok) {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < TY; ++y)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) a[q] += red[q][(y * CTX + tx) * VW + v];
+            const size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 5;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) part[o + q] = a[q];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void norm_bwd2_finalize_kernel(const float* __restrict__ part, float* __restrict__ sums,
+                                                                 const float* __restrict__ invstd, float* dgamma, int G,
+                                                                 int C, int nchunks, int accum) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int k = lane; k < nchunks; k += 64) {
+        const size_t o = (((size_t)g * nchunks + k) * C + c) * 5;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) a[q] += (double)part[o + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off);
+    if (lane != 0) return;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) sums[(size_t)i * 5 + q] = (float)a[q];
+    (void)invstd; (void)dgamma; (void)accum;  // g_gamma is written by norm_bwd2_apply_kernel (it needs 1/P)
+}
+template <int VW>
+__global__ __launch_bounds__(256) void norm_bwd2_apply_kernel(const float* __restrict__ x, const float* __restrict__ d,
+                                                              const float* __restrict__ u, float* __restrict__ gd,
+                                                              float* __restrict__ gx, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ sums, float* dgamma, int dg_accum,
+                                                              int P, int C, int CTX, int chunk, float invP) {
+    const int tid = threadIdx.x;
+    const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
+    const int g = blockIdx.z;
+    const int c = (blockIdx.x * CTX + tx) * VW;
+    if (c >= C) return;
+    float mu[VW], is[VW], ga[VW], su[VW], sux[VW], m1[VW], m2[VW], q[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+        const size_t gc = (size_t)g * C + c + v;
+        mu[v] = mean[gc];
+        is[v] = invstd[gc];
+        ga[v] = gamma ? gamma[c + v] : 1.f;
+        su[v] = sums[gc * 5] * invP;
+        sux[v] = sums[gc * 5 + 1] * invP;
+        m1[v] = sums[gc * 5 + 3] * invP;
+        m2[v] = sums[gc * 5 + 4] * invP;
+        const float Q = sums[gc * 5 + 2] - m1[v] * sums[gc * 5] - m2[v] * sums[gc * 5 + 1];
+        q[v] = Q * invP;
+        if (dgamma && blockIdx.y == 0 && ty == 0) {  // one thread per channel (G == 1 only)
+            const float gg = is[v] * Q;
+            dgamma[c + v] = dg_accum ? dgamma[c + v] + gg : gg;
+        }
+    }
+    const int p0 = blockIdx.y * chunk;
+    int p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    const size_t base = (size_t)g * P * C + c;
+#pragma unroll 2
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const size_t e = base + (size_t)p * C;
+        float xv[VW], dv[VW], uv[VW], od[VW], ox[VW];
+        if (VW == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + e), b = *reinterpret_cast<const f32x4*>(d + e),
+                        cc = *reinterpret_cast<const f32x4*>(u + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; uv[k] = cc[k]; }
+        } else {
+            xv[0] = x[e]; dv[0] = d[e]; uv[0] = u[e];
+        }
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            const float tu = uv[k] - su[k] - xh * sux[k];
+            const float td = dv[k] - m1[k] - xh * m2[k];
+            od[k] = ga[k] * is[k] * tu;
+            ox[k] = -ga[k] * is[k] * is[k] * (xh * q[k] + sux[k] * td + m2[k] * tu);
+        }
+        if (VW == 4) {
+            if (gd) *reinterpret_cast<f32x4*>(gd + e) = f32x4{od[0], od[1], od[2], od[3]};
+            if (gx) *reinterpret_cast<f32x4*>(gx + e) = f32x4{ox[0], ox[1], ox[2], ox[3]};
+        } else {
+            if (gd) gd[e] = od[0];
+            if (gx) gx[e] = ox[0];
+        }
+    }
+}
+// ws: migan_norm_workspace2(G,P,C) bytes.  gd / gx / dgamma may be NULL (not needed).
+MIGAN_API size_t migan_norm_workspace2(int G, int P, int C) {
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    return ((size_t)G * nchunks * C * 5 + (size_t)G * C * 5) * sizeof(float);
+}
+MIGAN_API int migan_norm_bwd2(const float* x, const float* d, const float* u, const float* mean, const float* invstd,
+                              const float* gamma, float* gd, float* gx, float* dgamma, int dgamma_accumulate, int G, int P,
+                              int C, float* ws, size_t ws_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)G * P * C == 0) return 0;
+    if (ws_bytes < migan_norm_workspace2(G, P, C)) return (int)hipErrorInvalidValue;
+    int VW, CTX, chunk, nchunks, gxb;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gxb);
+    float* sums = ws + (size_t)G * nchunks * C * 5;
+    dim3 grid(gxb, nchunks, G);
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_bwd2_partial_kernel<4>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
+    else
+        hipLaunchKernelGGL((norm_bwd2_partial_kernel<1>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_bwd2_finalize_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums, invstd,
+                       nullptr, G, C, nchunks, 0);
+    HIP_LAUNCH_CHECK();
+    int VW2, CTX2, chunk2;
+    dim3 grid2;
+    apply_plan(G, P, C, VW2, CTX2, chunk2, grid2);
+    float* dgm = (G == 1) ? dgamma : nullptr;
+    const float invP = (float)(1.0 / (double)P);
+    if (VW == 4)
+        hipLaunchKernelGGL((norm_bwd2_apply_kernel<4>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
+                           dgm, dgamma_accumulate, P, C, CTX2, chunk2, invP);
+    else
+        hipLaunchKernelGGL((norm_bwd2_apply_kernel<1>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
+                           dgm, dgamma_accumulate, P, C, CTX2, chunk2, invP);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

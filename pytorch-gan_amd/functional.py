@@ -23,15 +23,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", "0"))  # 0 off, 1 on, n>1: only dy.numel() <= n
+# 0 off, 1 always, n > 1: only for gradients of at least n elements (default 4 Mi: measured +2.5 % on the CycleGAN step -
+# the wave tails of a layer's wgrad and dgrad launches fill each other - and neutral on the launch-bound DCGAN step)
+_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", str(1 << 22)))
 _SIDE_STREAMS = {}
 
 
 def set_wgrad_overlap(enabled):
     """Run the weight-gradient chain of a conv backward (wgrad, split-K reduction, bias column sums) on a side
     stream concurrently with its dgrad (they only share the read-only dy); the two streams join before backward
-    returns.  Captured into a hipGraph this becomes two parallel branches, so the short reduction kernels no longer
-    sit on the critical path."""
+    returns.  Captured into a hipGraph this becomes two parallel branches.  `enabled`: False/0 off, True/1 always,
+    n > 1 only for gradients of at least n elements."""
     global _OVERLAP_WGRAD
     _OVERLAP_WGRAD = int(enabled)
 
@@ -41,7 +43,7 @@ class _Fork:
 
     def __init__(self, device, enabled, numel=0):
         self.on = (bool(enabled) and _OVERLAP_WGRAD != 0 and not torch.is_grad_enabled()
-                   and (_OVERLAP_WGRAD == 1 or numel <= _OVERLAP_WGRAD))
+                   and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
         if self.on:
             self.main = torch.cuda.current_stream(device)
             key = (device.index, self.main.cuda_stream)
@@ -279,6 +281,76 @@ def _conv_out(HL, pt, pb, R, stride):
     return (HL + pt + pb - R) // stride + 1
 
 
+_INPUT_GRAD_ONLY = False
+
+
+def _first_order_only(what):
+    """Backward passes made of raw kernel launches record no graph: refuse to run under create_graph=True instead of
+    silently returning a gradient that cannot be differentiated again."""
+    if torch.is_grad_enabled():
+        raise NotImplementedError("%s: double backward (create_graph=True) is not implemented for this op - the reference "
+                                  "only differentiates twice through Conv2d / Linear / BatchNorm / InstanceNorm / "
+                                  "activations / Dropout2d (gradient penalties)" % what)
+
+
+@__import__("contextlib").contextmanager
+def input_grad_only():
+    """Inside this scope a differentiable (create_graph=True) backward computes input gradients only - the case of the
+    gradient penalties, `autograd.grad(outputs=D(x), inputs=x, create_graph=True)` (wgan_gp.py:128-135,
+    dragan.py:156-163): autograd calls every node's backward in full, and without this hint each conv / linear would also
+    run the weight-gradient kernels whose results that call discards."""
+    global _INPUT_GRAD_ONLY
+    prev, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_GRAD_ONLY = prev
+
+
+class _ConvDgradFn(Function):
+    """dx = dgrad(dy, w) of a zero-padded conv as a differentiable op: its backward is a conv forward (w.r.t. dy) and a
+    weight gradient with the incoming gradient in the place of x (w.r.t. w) - the second-order terms of the conv-critic
+    gradient penalties, built from the first-order kernels."""
+
+    @staticmethod
+    def forward(ctx, dy, w, geom):
+        N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl = geom
+        dy = to_nhwc(dy)
+        wp = _plain(w)
+        wt = _permute4(wp, (1, 2, 3, 0))
+        dx = _empty_nhwc((N, Ci, H, W), dy)
+        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
+                                     stride, pt, pl, 0, 0.0, _stream()), "conv2d_dgrad")
+        ctx.geom = geom
+        ctx.save_for_backward(dy, wp)
+        ctx.param = w
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl = ctx.geom
+        g = to_nhwc(g)
+        st = _stream()
+        g_dy = g_w = None
+        if ctx.needs_input_grad[0]:   # d/d(dy): the forward conv applied to g
+            wo = _permute4(w, (0, 2, 3, 1))
+            g_dy = _empty_nhwc((N, Co, Ho, Wo), g)
+            check(lib.migan_conv2d_fwd(g.data_ptr(), wo.data_ptr(), None, g_dy.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
+                                       stride, pt, pl, GATHER_ZERO, 0, 0.0, st), "conv2d_fwd (dgrad of dgrad)")
+        if ctx.needs_input_grad[1]:   # d/dw: wgrad with g in the place of x
+            slot = _grad_slot(ctx.param)
+            g_w = torch.empty_like(w) if slot is None else slot
+            nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
+            ws = _ws(nb, g)
+            check(lib.migan_conv2d_wgrad(g.data_ptr(), dy.data_ptr(), g_w.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci, Ho, Wo,
+                                         Co, R, S, stride, pt, pl, GATHER_ZERO, 0 if slot is None else 1, None, 0, None, 0,
+                                         st), "conv2d_wgrad (wgrad of dgrad)")
+            if slot is not None:
+                g_w = None
+        return g_dy, g_w, None
+
+
 class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
@@ -322,6 +394,8 @@ class _Conv2d(Function):
     def backward(ctx, dy):
         xs, w, y, mask = ctx.saved_tensors
         N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
+        if torch.is_grad_enabled():
+            return _Conv2d._backward_differentiable(ctx, dy, xs, w, y, mask)
         dy = to_nhwc(dy)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
@@ -392,6 +466,43 @@ class _Conv2d(Function):
 _REFLECT1 = __import__("os").environ.get("MIGAN_REFLECT1", "1") == "1"  # A/B knob: 0 = padded extent + fold pass
 
 
+def _conv2d_backward_differentiable(ctx, dy, xs, w, y, mask):
+    """Backward of _Conv2d recorded as differentiable ops (autograd.grad(..., create_graph=True), the conv-critic gradient
+    penalties of dragan.py:144-167 / stargan.py:142-161): activation' and the Dropout2d mask through _ActBwd / _MulMask,
+    the input gradient through _ConvDgradFn.  Weight and bias gradients of THIS backward are produced by the ordinary
+    kernels (not differentiable again: the reference never differentiates a weight gradient) and skipped entirely inside
+    `input_grad_only()`."""
+    N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
+    if gather != GATHER_ZERO:
+        raise NotImplementedError("double backward through a reflection-padded / upsampled conv is not on the reference path")
+    g = dy
+    if act != ACT_NONE:
+        # dx = dy * act'(y): y is the (masked) layer output; where the Dropout2d mask is 0 the product with the mask below
+        # is 0 whatever act' evaluates to
+        g = _ActBwd.apply(g, y, act, slope)
+    if mask is not None:
+        g = _MulMask.apply(g, mask)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        dx = _ConvDgradFn.apply(g, ctx.params[0], (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl))
+    if not _INPUT_GRAD_ONLY:
+        with torch.no_grad():
+            gd = to_nhwc(g.detach())
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(w)
+                nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, R, S, Ci)
+                ws = _ws(nb, xs)
+                check(lib.migan_conv2d_wgrad(xs.data_ptr(), gd.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci, Ho,
+                                             Wo, Co, R, S, stride, pt, pl, gather, 0, None, 0, None, 0, _stream()),
+                      "conv2d_wgrad")
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _colsum(gd, N * Ho * Wo, Co, None)
+    return dx, dw, db, None, None, None, None, None, None
+
+
+_Conv2d._backward_differentiable = staticmethod(_conv2d_backward_differentiable)
+
+
 def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None):
     """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue."""
     return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope),
@@ -425,6 +536,7 @@ class _UpConv3x3(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('Upsample+Conv3x3')
         xs, w, wd, y = ctx.saved_tensors
         N, H, W, Ci, Co, act, slope = ctx.geom
         dy = to_nhwc(dy)
@@ -518,6 +630,7 @@ class _ConvTranspose2d(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('ConvTranspose2d')
         xs, w, y = ctx.saved_tensors
         N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope = ctx.geom
         dy = to_nhwc(dy)
@@ -673,15 +786,20 @@ class _ActBwd(Function):
     def forward(ctx, g, y, act, slope):
         g, y = canon(g), canon(y)
         ctx.act, ctx.slope = act, slope
-        ctx.save_for_backward(y)
+        ctx.save_for_backward(g, y)
         return _act_bwd_raw(g, y, act, slope)
 
     @staticmethod
     def backward(ctx, gg):
-        (y,) = ctx.saved_tensors
+        g, y = ctx.saved_tensors
+        gy = None
         if ctx.needs_input_grad[1] and ctx.act in (ACT_TANH, ACT_SIGMOID):
-            raise NotImplementedError("second derivative through tanh/sigmoid is not on the reference path")
-        return _ActBwd.apply(gg, y, ctx.act, ctx.slope), None, None, None
+            # dx = g * f'(y) also depends on y (dragan.py:92 ends the critic in a Sigmoid): d/dy = gg * g * f''
+            ggc = canon(gg)
+            gy = torch.empty_like(y)
+            check(lib.migan_act_bwd2(g.data_ptr(), ggc.data_ptr(), y.data_ptr(), gy.data_ptr(), y.numel(), ctx.act,
+                                     _stream()), "act_bwd2")
+        return _ActBwd.apply(gg, y, ctx.act, ctx.slope), gy, None, None
 
 
 class _Act(Function):
@@ -718,6 +836,7 @@ class _PReLU(Function):
 
     @staticmethod
     def backward(ctx, g):
+        _first_order_only('PReLU')
         xs, a = ctx.saved_tensors
         g = canon(g)
         dx = torch.empty_like(xs)
@@ -796,15 +915,19 @@ class _Norm(Function):
                                    _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
         ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
         ctx.sync = sync
-        ctx.save_for_backward(xs, gamma, beta, mean, invstd)
+        # x itself is saved next to its dense copy: a differentiable backward (gradient penalties) needs the input WITH its
+        # autograd history (same storage when x already is dense NHWC)
+        ctx.save_for_backward(xs, gamma, beta, mean, invstd, x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xs, gamma, beta, mean, invstd = ctx.saved_tensors
+        xs, gamma, beta, mean, invstd, x_in = ctx.saved_tensors
         G, P, C, act, slope, batch_stats, affine, has_res = ctx.cfg
         if not batch_stats:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
+        if torch.is_grad_enabled():
+            return _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in)
         dy = canon(dy)
         dx = torch.empty_like(xs)
         dgamma = dbeta = None
@@ -849,6 +972,83 @@ class _Norm(Function):
         return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
 
 
+class _NormBwdFn(Function):
+    """dx of the normalisation backward as a differentiable op (inputs: the norm input x, the gradient d w.r.t. the norm
+    output, gamma); its own backward is migan_norm_bwd2 (formulas in csrc/norm.hip).  mean / invstd are the statistics of
+    x from the forward pass: their dependence on x is part of those formulas."""
+
+    @staticmethod
+    def forward(ctx, x, d, gamma, mean, invstd, cfg):
+        G, P, C = cfg
+        xs, ds = canon(x), canon(d)
+        ctx.x_nchw = x.dim() == 4 and x.is_contiguous() and not x.is_contiguous(memory_format=CL)
+        gm = _plain(gamma)
+        dx = torch.empty_like(xs)
+        nb = lib.migan_norm_workspace(G, P, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_norm_bwd(xs.data_ptr(), ds.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gm), None,
+                                 dx.data_ptr(), None, None, G, P, C, ACT_NONE, 0.0, ws.data_ptr(), nb, 0, None, _stream()),
+              "norm_bwd")
+        ctx.cfg = cfg
+        ctx.gamma_param = gamma
+        ctx.save_for_backward(xs, ds, gm, mean, invstd)
+        return to_nchw(dx) if ctx.x_nchw else dx
+
+    @staticmethod
+    def backward(ctx, u):
+        _first_order_only("normalisation (third derivative)")
+        xs, ds, gm, mean, invstd = ctx.saved_tensors
+        G, P, C = ctx.cfg
+        u = canon(u)
+        if u.dim() == 4 and ctx.x_nchw:
+            u = to_nhwc(u)
+        gx = torch.empty_like(xs) if ctx.needs_input_grad[0] else None
+        gd = torch.empty_like(xs) if ctx.needs_input_grad[1] else None
+        gg, acc = None, 0
+        if gm is not None and ctx.needs_input_grad[2] and G == 1:
+            slot = _grad_slot(ctx.gamma_param)
+            gg, acc = (slot, 1) if slot is not None else (torch.empty(C, device=xs.device, dtype=torch.float32), 0)
+        nb = lib.migan_norm_workspace2(G, P, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_norm_bwd2(xs.data_ptr(), ds.data_ptr(), u.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gm),
+                                  _ptr(gd), _ptr(gx), _ptr(gg), acc, G, P, C, ws.data_ptr(), nb, _stream()), "norm_bwd2")
+        if gx is not None and ctx.x_nchw:
+            gx = to_nchw(gx)
+        return gx, gd, (None if acc else gg), None, None, None
+
+
+def _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in):
+    """_Norm.backward recorded as differentiable ops (create_graph=True: dragan.py:156-163 through BatchNorm2d(C, 0.8),
+    dualgan.py through InstanceNorm2d).  The fused LeakyReLU/ReLU is un-fused: its derivative comes from the recomputed
+    layer output, a constant of the second differentiation (piecewise-linear activations only)."""
+    G, P, C, act, slope, batch_stats, affine, has_res = ctx.cfg
+    if ctx.sync is not None:
+        raise NotImplementedError("double backward through cross-replica BatchNorm is not implemented")
+    g = dy
+    if act != ACT_NONE:
+        if act not in (ACT_LRELU, ACT_RELU):
+            raise NotImplementedError("norm: fused activation %d has no second derivative path" % act)
+        with torch.no_grad():
+            y_out = torch.empty_like(xs)
+            check(lib.migan_norm_apply(xs.data_ptr(), y_out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                       _ptr(beta), None, G, P, C, act, slope, _stream()), "norm_apply")
+        g = _ActBwd.apply(g, y_out, act, slope)
+    dx = _NormBwdFn.apply(x_in, g, ctx.params[0] if affine else None, mean, invstd, (G, P, C))
+    dgamma = dbeta = None
+    if affine and G == 1 and not _INPUT_GRAD_ONLY and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+        with torch.no_grad():  # first-order parameter gradients of THIS backward (not differentiable again)
+            gd = canon(g.detach())
+            dgamma = torch.empty(C, device=xs.device, dtype=torch.float32)
+            dbeta = torch.empty_like(dgamma)
+            sums = torch.empty(2 * C, device=xs.device, dtype=torch.float32)
+            nb = lib.migan_norm_workspace(G, P, C)
+            ws = _ws(nb, xs)
+            check(lib.migan_norm_bwd_sums(xs.data_ptr(), gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                          _ptr(beta), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), G, P, C, ACT_NONE,
+                                          0.0, ws.data_ptr(), nb, 0, _stream()), "norm_bwd_sums")
+    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
+
+
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
          eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None):
     """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself."""
@@ -876,6 +1076,7 @@ class _Gather2d(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('pad/upsample')
         N, H, W, C, Ho, Wo, pt, pl, mode = ctx.geom
         dy = to_nhwc(dy)
         dx = _empty_nhwc((N, C, H, W), dy)
@@ -903,6 +1104,7 @@ class _PixelShuffle(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('PixelShuffle')
         N, H, W, C, r = ctx.geom
         dy = to_nhwc(dy)
         dx = _empty_nhwc((N, C * r * r, H, W), dy)
@@ -928,6 +1130,7 @@ class _MaxPool2(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('MaxPool2d')
         (xs,) = ctx.saved_tensors
         N, C, H, W = xs.shape
         dy = to_nhwc(dy)
@@ -955,6 +1158,7 @@ class _CatC(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('cat')
         N, Ca, Cb, H, W = ctx.geom
         dy = to_nhwc(dy)
         da = _empty_nhwc((N, Ca, H, W), dy)
@@ -1037,6 +1241,8 @@ class _MulMask(Function):
     @staticmethod
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
+        if torch.is_grad_enabled():  # create_graph: the mask multiply is linear, its backward is the same op
+            return _MulMask.apply(g, mask), None
         g = canon(g)
         dx = torch.empty_like(g)
         if ctx.per_plane:
@@ -1074,6 +1280,7 @@ class _Loss(Function):
 
     @staticmethod
     def backward(ctx, g):
+        _first_order_only('loss')
         xs, t = ctx.saved_tensors
         g = _plain(g).contiguous()
         dx = torch.empty_like(xs)
@@ -1111,6 +1318,7 @@ class _Embedding(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('Embedding')
         (flat,) = ctx.saved_tensors
         V, D = ctx.wshape
         dy = canon(dy.reshape(-1, D))
@@ -1140,6 +1348,7 @@ class _Softmax(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only('Softmax')
         (y,) = ctx.saved_tensors
         dy = canon(dy)
         dx = torch.empty_like(y)
@@ -1173,6 +1382,7 @@ class _CrossEntropy(Function):
 
     @staticmethod
     def backward(ctx, g):
+        _first_order_only('CrossEntropyLoss')
         xs, t, ws = ctx.saved_tensors
         B, C = xs.shape
         g = _plain(g).contiguous()
@@ -1201,6 +1411,7 @@ class _Mul(Function):
 
     @staticmethod
     def backward(ctx, g):
+        _first_order_only('mul')
         a, b = ctx.saved_tensors
         g = canon(g)
         ga = gb = None
@@ -1229,6 +1440,7 @@ class _RowNorm(Function):
 
     @staticmethod
     def backward(ctx, dn):
+        _first_order_only('row norm')
         xs, nrm = ctx.saved_tensors
         dn = _plain(dn).contiguous()
         B, D = xs.shape
@@ -1240,6 +1452,25 @@ class _RowNorm(Function):
 
 def rownorm(x):
     return _RowNorm.apply(x)
+
+
+def dragan_interpolate(x, alpha, noise):
+    """alpha*X + (1-alpha)*(X + 0.5*X.std()*noise) (dragan.py:149; no autograd: the result becomes the leaf the penalty
+    differentiates with respect to).  X.std() = unbiased std over all elements, computed on the device."""
+    xs, a, nz = canon(x), canon(alpha), canon(noise)
+    if a.shape != xs.shape or nz.shape != xs.shape:
+        raise ValueError("dragan_interpolate: alpha and noise must have the shape of X")
+    n = xs.numel()
+    mom = torch.empty(2, device=xs.device, dtype=torch.float32)
+    nb = lib.migan_norm_workspace(1, n, 1)
+    ws = _ws(nb, xs)
+    st = _stream()
+    check(lib.migan_norm_moments(xs.data_ptr(), mom.data_ptr(), mom.data_ptr() + 4, 1, n, 1, ws.data_ptr(), nb, st),
+          "norm_moments")
+    out = torch.empty_like(xs)
+    check(lib.migan_dragan_interp(xs.data_ptr(), a.data_ptr(), nz.data_ptr(), mom.data_ptr() + 4, out.data_ptr(), n, st),
+          "dragan_interp")
+    return out
 
 
 def rowscale(x, s):

@@ -154,6 +154,55 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ dragan (8f F1)
+def compute_gradient_penalty_dragan(D, X, alpha=None, noise=None, lambda_gp=10.0):
+    """dragan.py:144-167 on the HIP path: the conv-critic gradient penalty.  `autograd.grad(..., create_graph=True)` runs
+    the differentiable backward of Conv2d / LeakyReLU / Dropout2d / BatchNorm2d / Linear / Sigmoid (functional.py), the
+    gradient norm is taken over the channel dimension as the reference writes it (`norm(2, dim=1)` of a (B, C, H, W)
+    tensor), and the interpolation uses the unbiased std of all of X without a host sync.
+    Host draws when not given: alpha ~ np.random.random(X.shape), then noise ~ torch.rand(X.size()) (reference order)."""
+    X = F.canon(X)
+    dev = X.device
+    B, C, H, W = X.shape
+    if alpha is None:
+        alpha = _dev(np.random.random(size=tuple(X.shape)), dev)
+    if noise is None:
+        noise = torch.rand(X.size()).to(dev)
+    interp = F.dragan_interpolate(X, alpha, noise).requires_grad_(True)
+    with F.input_grad_only():
+        d_interp = D(interp)
+        ones = torch.ones(B, 1, device=dev)
+        grads = torch.autograd.grad(outputs=d_interp, inputs=interp, grad_outputs=ones, create_graph=True,
+                                    retain_graph=True, only_inputs=True)[0]
+    # norm over dim 1 (channels): in NHWC memory the channel vector of a pixel is contiguous -> rows of a (B*H*W, C) view
+    norms = F.rownorm(F.relayout(grads, True).permute(0, 2, 3, 1).reshape(B * H * W, C))
+    return F.axpby(F.loss(F.LOSS_MSE, norms, None, 1.0), None, float(lambda_gp), 0.0)
+
+
+@_scoped
+def dragan_step(s, real_imgs, z, alpha=None, noise=None):
+    """dragan.py:176-217 (state from make_gan_state; s.lambda_gp defaults to 10).  Quirk kept: d_loss is computed - its
+    discriminator forwards update BatchNorm running statistics and consume Dropout2d draws - but only
+    gradient_penalty.backward() feeds optimizer_D.step()."""
+    valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    with frozen(s.D, enabled=s.skip):
+        g_loss = s.bce(s.D(gen), valid)
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    with torch.no_grad() if s.skip else contextlib.nullcontext():  # d_loss is never back-propagated (dragan.py:211-217)
+        real_loss = s.bce(s.D(real_imgs), valid)
+        fake_loss = s.bce(s.D(gen.detach()), fake)
+        d_loss = half_sum(real_loss, fake_loss)
+    gp = compute_gradient_penalty_dragan(s.D, real_imgs.data, alpha, noise, getattr(s, "lambda_gp", 10.0))
+    gp.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gp": gp.detach(), "gen_imgs": gen.detach()}
+
+
 class WganGpRunner:
     """`wgan_gp_step` replayed as hipGraphs.  The loop body has two shapes — critic only, and critic + generator when
     `i % n_critic == 0` (wgan_gp.py:179) — and a capture freezes host control flow, so both shapes are captured once

@@ -251,3 +251,53 @@ def test_swap_keeps_tree_and_init(pg):
     G.apply(M.init_normal_dcgan)
     with pytest.raises(NotImplementedError):
         pg.swap(torch.nn.Sequential(torch.nn.GRU(4, 4)))
+
+
+def test_dragan_gradient_penalty_vs_reference(pg, golden_dir):
+    """dragan.py:144-167 on the HIP path - double backward through Conv2d / LeakyReLU / Dropout2d /
+    BatchNorm2d(eps .8) / Linear / Sigmoid - against the value and the discriminator gradients recorded from the REAL
+    reference function (tests/golden/dragan_32.npz; same X, alpha, noise and Dropout2d masks) and against the oracle."""
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    gold = load_golden(golden_dir, "dragan_32")
+    _seed(0)
+    M.DcganGenerator(32, 100, 1).apply(M.init_normal_dcgan)   # the pin script builds G first (same RNG consumption)
+    _seed(0)
+    D = M.DcganDiscriminator(32, 1)
+    D.apply(M.init_normal_dcgan)
+    X, alpha, noise = (torch.from_numpy(gold[k]) for k in ("X", "alpha", "noise"))
+    masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))]
+    import copy
+
+    D64 = copy.deepcopy(D).double()
+    Dg = gpu_copy(D)
+    for p in D.parameters():
+        p.grad = None
+    with M.feed_masks(masks=masks):
+        gp_c = S.dragan_gradient_penalty(D, X, alpha, noise, 10)
+    gp_c.backward()
+    assert abs(float(gp_c) - float(gold["gp"])) <= 1e-6 * abs(float(gold["gp"]))
+    with M.feed_masks(masks=masks):
+        gp_d = S.dragan_gradient_penalty(D64, X.double(), alpha.double(), noise.double(), 10)
+    gp_d.backward()
+    for p in Dg.parameters():
+        p.grad = None
+    with pg.dropout_masks(masks):
+        gp_g = steps.compute_gradient_penalty_dragan(Dg, X.to(DEV), alpha.to(DEV), noise.to(DEV), 10)
+    gp_g.backward()
+    assert abs(float(gp_g) - float(gold["gp"])) <= 2e-5 * abs(float(gold["gp"])), (float(gp_g), float(gold["gp"]))
+    gp_, cp_, dp_ = dict(Dg.named_parameters()), dict(D.named_parameters()), dict(D64.named_parameters())
+    keys = [str(k) for k in gold["gp_keys"]]
+    for k, gd in zip(keys, gold["gp_digest"]):
+        assert np.allclose(digest(cp_[k].grad), gd, rtol=1e-3, atol=1e-9 + 1e-3 * abs(gd[1])), k
+        _noise_aware(gp_[k].grad, cp_[k].grad, dp_[k].grad, TOL_MODEL_GRAD, "dragan penalty grad " + k)
+    # parameters the penalty does not reach have no gradient on either side
+    for k, p in cp_.items():
+        if p.grad is None:
+            assert gp_[k].grad is None or float(gp_[k].grad.abs().max()) == 0.0, k
+    # BatchNorm side effects of the penalty's discriminator forward
+    for (k, b), (_, c) in zip(D.named_buffers(), Dg.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert_close(c, b, 1e-5, "dragan buffer " + k)

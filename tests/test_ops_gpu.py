@@ -715,3 +715,102 @@ def test_swap_dcgan_block_clone_layers(pg):
     assert type(m["ce"]) is gnn.CrossEntropyLoss and type(m["bcel"]) is gnn.BCEWithLogitsLoss
     with pytest.raises(ValueError):
         pg.swap(torch.nn.CrossEntropyLoss(label_smoothing=0.1))
+
+
+# ------------------------------------------------------------------------------------------------ F1: double backward
+def _gp_like(y, x, params, seed):
+    """A gradient-penalty-shaped scalar: g = d(sum(y*v))/dx with create_graph, loss = sum(g^2 * c) -> backward."""
+    gen = torch.Generator().manual_seed(seed)
+    v = torch.randn(y.shape, generator=gen).to(y.device)
+    (g,) = torch.autograd.grad((y * v).sum(), x, create_graph=True)
+    c = torch.rand(g.shape, generator=gen).to(y.device) + 0.5
+    loss = (g * g * c).sum()
+    for p in params:
+        p.grad = None
+    loss.backward()
+    return g.detach(), loss.detach()
+
+
+@pytest.mark.parametrize("case", [(4, 8, 16, 16, 16, 3, 2, 1, 1, False), (2, 16, 12, 12, 32, 4, 2, 1, 1, True),
+                                  (3, 3, 16, 16, 16, 4, 2, 1, 1, False), (2, 32, 9, 9, 64, 3, 1, 1, 0, False)])
+def test_conv_double_backward(pg, case):
+    """dgrad-of-dgrad (= conv forward) and wgrad-of-dgrad through Conv2d [+ LeakyReLU + Dropout2d mask]: the second-order
+    terms of the conv-critic gradient penalties (dragan.py:77-78, stargan/models.py:92-101), against torch CPU fp64."""
+    N, Ci, H, W, Co, k, stride, pad, act, masked = case
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).double().requires_grad_(True)
+    w = _leaf(Co, Ci, k, k, seed=2, scale=0.3).double().requires_grad_(True)
+    b = _leaf(Co, seed=3).double().requires_grad_(True)
+    mask = ((torch.rand(N, Co, generator=torch.Generator().manual_seed(9)) > 0.25).double() / 0.75) if masked else None
+    y = TF.conv2d(x, w, b, stride, pad)
+    if act:
+        y = TF.leaky_relu(y, 0.2)
+    if masked:
+        y = y * mask[:, :, None, None]
+    g_ref, loss_ref = _gp_like(y, x, [w, b], 7)
+    xg = x.detach().float().to(DEV).requires_grad_(True)
+    wg = w.detach().float().to(DEV).requires_grad_(True)
+    bg = b.detach().float().to(DEV).requires_grad_(True)
+    yg = F.conv2d(xg, wg, bg, stride, (pad,) * 4, F.GATHER_ZERO, act, 0.2, None if mask is None else mask.float().to(DEV))
+    g_gpu, loss_gpu = _gp_like(yg, xg, [wg, bg], 7)
+    assert_close(g_gpu, g_ref.float(), TOL_FWD, "first-order input gradient (create_graph)")
+    assert abs(float(loss_gpu) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert_close(wg.grad, w.grad.float(), TOL_WGRAD, "d(penalty)/dw through dgrad")
+    assert bg.grad is None or float(bg.grad.abs().max()) == 0.0   # the penalty does not depend on the bias
+    with F.input_grad_only():   # the hint skips the (discarded) first-order weight-gradient kernels, same result
+        xg2 = x.detach().float().to(DEV).requires_grad_(True)
+        wg2 = w.detach().float().to(DEV).requires_grad_(True)
+        yg2 = F.conv2d(xg2, wg2, None, stride, (pad,) * 4, F.GATHER_ZERO, act, 0.2, None if mask is None else mask.float().to(DEV))
+        _gp_like(yg2, xg2, [wg2], 7)
+    assert_close(wg2.grad, w.grad.float(), TOL_WGRAD, "d(penalty)/dw with input_grad_only")
+
+
+@pytest.mark.parametrize("cfg", [(False, 8, 32, 7, 7, 0.8, 0), (False, 4, 16, 8, 8, 1e-5, 1), (True, 3, 12, 6, 5, 1e-5, 0),
+                                 (True, 2, 64, 4, 4, 1e-5, 2)])
+def test_norm_double_backward(pg, cfg):
+    """BatchNorm2d(C, 0.8) (dragan.py:80) / InstanceNorm2d (dualgan) under create_graph=True: migan_norm_bwd2 against
+    torch CPU fp64 autograd through batch_norm / instance_norm (+ fused LeakyReLU / ReLU)."""
+    inst, N, C, H, W, eps, act = cfg
+    F = pg.functional
+    x = _leaf(N, C, H, W, seed=1).double().requires_grad_(True)
+    gamma = None if inst else (_leaf(C, seed=2) * 0.3 + 1.0).double().requires_grad_(True)
+    beta = None if inst else _leaf(C, seed=3).double().requires_grad_(True)
+    if inst:
+        y = TF.instance_norm(x, eps=eps)
+    else:
+        y = TF.batch_norm(x, None, None, gamma, beta, True, 0.1, eps)
+    y = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y)
+    params = [] if inst else [gamma, beta]
+    g_ref, loss_ref = _gp_like(y, x, params, 11)
+    (gx_ref,) = [x.grad.clone()] if x.grad is not None else [None]
+    xg = x.detach().float().to(DEV).requires_grad_(True)
+    gg = None if inst else gamma.detach().float().to(DEV).requires_grad_(True)
+    bgm = None if inst else beta.detach().float().to(DEV).requires_grad_(True)
+    yg = F.norm(xg, gg, bgm, None, None, None, True, 0.1, eps, inst, act, 0.2)
+    g_gpu, loss_gpu = _gp_like(yg, xg, [] if inst else [gg, bgm], 11)
+    assert_close(g_gpu, g_ref.float(), 1e-5, "norm first-order dx (create_graph)")
+    assert abs(float(loss_gpu) - float(loss_ref)) <= 2e-5 * abs(float(loss_ref))
+    assert_close(xg.grad, x.grad.float(), 2e-5, "d(penalty)/dx through the norm backward")
+    if not inst:
+        assert_close(gg.grad, gamma.grad.float(), 2e-5, "d(penalty)/dgamma")
+
+
+@pytest.mark.parametrize("act", [3, 4])
+def test_activation_second_derivative(pg, act):
+    """Tanh / Sigmoid under create_graph=True (dragan.py:92: the critic ends in Sigmoid)."""
+    F = pg.functional
+    x = (_leaf(6, 40, seed=1) * 2).double().requires_grad_(True)
+    y = torch.tanh(x) if act == 3 else torch.sigmoid(x)
+    g_ref, loss_ref = _gp_like(y, x, [], 5)
+    xg = x.detach().float().to(DEV).requires_grad_(True)
+    g_gpu, loss_gpu = _gp_like(F.activation(xg, act), xg, [], 5)
+    assert_close(g_gpu, g_ref.float(), 2e-6, "act first-order")
+    assert_close(xg.grad, x.grad.float(), 5e-6, "act second-order")
+
+
+def test_raw_backward_refuses_create_graph(pg):
+    F = pg.functional
+    x = _leaf(2, 8, 6, 6, seed=1).to(DEV).requires_grad_(True)
+    y = F.maxpool2(x)
+    with pytest.raises(NotImplementedError):
+        torch.autograd.grad(y.sum(), x, create_graph=True)

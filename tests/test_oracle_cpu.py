@@ -205,3 +205,23 @@ def test_pix2pix_shapes_and_keys():
     assert "down1.model.0.weight" in G.state_dict() and "final.2.weight" in G.state_dict()
     assert G.up1.model[0].weight.shape == (512, 512, 4, 4)  # ConvTranspose2d weight is (Cin, Cout, kh, kw)
     assert "model.12.weight" in D.state_dict() and "model.12.bias" not in D.state_dict()
+
+
+def test_dragan_penalty_against_reference_fixture(golden_dir):
+    """the restated dragan.py:144-167 reproduces the value and the discriminator gradients recorded from
+    the real reference function (same X, alpha, noise and Dropout2d masks)."""
+    gold = load_golden(golden_dir, "dragan_32")
+    _seed(0)
+    M.DcganGenerator(32, 100, 1).apply(M.init_normal_dcgan)
+    _seed(0)
+    D = M.DcganDiscriminator(32, 1)
+    D.apply(M.init_normal_dcgan)
+    masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))]
+    with M.feed_masks(masks=masks):
+        gp = S.dragan_gradient_penalty(D, torch.from_numpy(gold["X"]), torch.from_numpy(gold["alpha"]),
+                                       torch.from_numpy(gold["noise"]), 10)
+    gp.backward()
+    assert abs(gp.item() - float(gold["gp"])) <= 1e-6 * abs(float(gold["gp"]))
+    named = dict(D.named_parameters())
+    for k, d in zip([str(k) for k in gold["gp_keys"]], gold["gp_digest"]):
+        assert np.allclose(digest(named[k].grad), d, rtol=1e-3, atol=1e-9 + 1e-3 * abs(d[1])), k

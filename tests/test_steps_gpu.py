@@ -368,3 +368,34 @@ def test_bench_two_ranks_on_one_gpu():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 256 and res["scaling"] == "weak"
     assert res["config"]["replicas_identical"] is True and res["config"]["hipgraph"] is True
     assert all(np.isfinite(v) for v in res["losses"].values())
+
+
+def test_dragan_steps():
+    """dragan.py:176-217: two iterations against the oracle, Dropout2d masks replayed, host draws
+    (z, alpha, noise) shared; the discriminator is trained by the gradient penalty alone (reference quirk)."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_dragan(32)
+    s_gpu = steps.make_gan_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=True)
+    _seed(8)
+    for t in range(2):
+        imgs = torch.rand(8, 1, 32, 32) * 2 - 1
+        z = torch.tensor(np.random.normal(0, 1, (8, 100)), dtype=torch.float32)
+        alpha = torch.tensor(np.random.random(size=(8, 1, 32, 32)), dtype=torch.float32)
+        noise = torch.rand(8, 1, 32, 32)
+        rec = []
+        with M.feed_masks(record=rec):
+            o_c = S.dragan_step(s_cpu, imgs, z, alpha, noise)
+        with pg.dropout_masks([m.numpy() for m in rec]):
+            o_g = steps.dragan_step(s_gpu, imgs.to(DEV), z.to(DEV), alpha.to(DEV), noise.to(DEV))
+        for k in ("g_loss", "d_loss", "gp"):
+            _loss_close(o_g[k], o_c[k], "%s step %d" % (k, t), 2e-4)
+    _params_close(s_gpu.D, s_cpu.D, 2, "dragan D (trained by the penalty)")
+    _params_close(s_gpu.G, s_cpu.G, 2, "dragan G")
+    nb_g = [int(v) for k, v in s_gpu.D.state_dict().items() if k.endswith("num_batches_tracked")]
+    nb_c = [int(v) for k, v in s_cpu.D.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert nb_g == nb_c == [8, 8, 8]   # 4 discriminator forwards per step (G step, real, fake, penalty)
