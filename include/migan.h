@@ -46,6 +46,35 @@ int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, const float* b
 int migan_act_bwd_nc(const float* dy, const float* y, const float* mask_nc, float* dx, int N, int HW, int C, int act,
                      float slope, void* stream);
 
+/* The same launches with the statistics of the normalisation layer BEHIND the conv taken in the conv's epilogue
+ * (dcgan.py:55-56,78-80, cyclegan/models.py:28-29, srgan/models.py:22-23: Conv2d -> [act -> Dropout2d ->] BatchNorm /
+ * InstanceNorm): every output tile leaves (mean, M2, count) per column in `stats` ([groups][chunks][Co][3] floats,
+ * groups = N for instance != 0 else 1, chunks from the *_stats_chunks query; 0 = geometry not on the pipelined MFMA
+ * kernel, use the plain launch), and migan_norm_stats_from_conv combines them (Chan, in double) into mean / invstd +
+ * running statistics - the norm layer's own pass over the conv output disappears.  mask_nc may be NULL. */
+int migan_conv2d_stats_chunks(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t,
+                              int pad_l, int gather, int instance);
+int migan_conv2d_fwd_stats(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc, float* y, int N,
+                           int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
+                           int gather, int act, float slope, float* stats, int stats_chunks, int instance, void* stream);
+int migan_upconv3x3_stats_chunks(int N, int H, int W, int Ci, int Co, int instance);
+int migan_upconv3x3_fwd_stats(const float* x, const float* wf, const float* bias, float* y, int N, int H, int W, int Ci,
+                              int Co, int act, float slope, float* stats, int stats_chunks, int instance, void* stream);
+int migan_norm_stats_from_conv(const float* part, int nchunks, float* mean, float* invstd, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps, int G, int C,
+                               void* stream);
+
+/* Skinny GEMMs (csrc/skinny_mm.hip): nn.Linear forward / input gradient at <= 64 rows - the MLP critic and generator
+ * of wgan_gp.py:42-83 / gan.py:38-81 at the reference batch size.  v_mfma_f32_16x16x4_f32 fed straight from 16-byte
+ * global loads (no LDS, no barrier), N/16 (N/32) workgroups; the NN form reads w in its stored [N][K] layout, so the
+ * input gradient needs no transposed weight copy.  *_ok() = 1 when the shape qualifies (M <= 64, N % 16 == 0,
+ * K % 16 == 0, K >= 32  /  R % 16 == 0, Nc % 32 == 0); otherwise use migan_conv2d_fwd with 1x1 geometry. */
+int migan_skinny_nt_ok(int M, int N, int K);
+int migan_skinny_nn_ok(int M, int R, int Nc);
+int migan_skinny_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int act, float slope,
+                    void* stream);
+int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int Nc, void* stream);
+
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];
  * w_ihwo [Ci][R][S][Co]; dx [N][Hi][Wi][Ci] = act(sum + bias) (bias/act used by the ConvTranspose role).

@@ -55,6 +55,15 @@ _SIGS = {
     "migan_error_string": (c_char_p, [c_int]),
     "migan_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 14 + [c_float, P]),
     "migan_conv2d_dropout_fwd": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P]),
+    "migan_conv2d_stats_chunks": (c_int, [c_int] * 14),
+    "migan_conv2d_fwd_stats": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P, c_int, c_int, P]),
+    "migan_upconv3x3_stats_chunks": (c_int, [c_int] * 6),
+    "migan_upconv3x3_fwd_stats": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P, c_int, c_int, P]),
+    "migan_norm_stats_from_conv": (c_int, [P, c_int, P, P, P, P, P, c_float, c_float, c_int, c_int, P]),
+    "migan_skinny_nt_ok": (c_int, [c_int] * 3),
+    "migan_skinny_nn_ok": (c_int, [c_int] * 3),
+    "migan_skinny_nt": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
+    "migan_skinny_nn": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),

@@ -36,6 +36,12 @@ struct ConvGeom {
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
+    // optional per-tile output statistics for the normalisation layer behind the conv (BatchNorm / InstanceNorm):
+    // stats[((group * stats_chunks + chunk) * Co + col) * 3 + {0,1,2}] = (mean, M2, count) of this tile's rows of column col,
+    // combined by migan_norm_stats_from_conv (Chan) - the norm layer's own statistics pass over the tensor disappears.
+    // stats_inst = 0: one group (BatchNorm), chunk = cls * gridDim.x + tile;  1: group = image (InstanceNorm; Ho*Wo % BM == 0)
+    float* stats;
+    int stats_inst, stats_chunks;
     int oh0[MAX_CLS], ow0[MAX_CLS], Ho[MAX_CLS], Wo[MAX_CLS], tapbeg[MAX_CLS], ntap[MAX_CLS];
     // fastdiv magics per class for m / (Ho*Wo) and rem / Wo (filled by launch_igemm): the pixel decode of the pipelined
     // kernel's prologue and strided epilogue costs ~8 instead of ~80 VALU instructions per row
@@ -347,7 +353,7 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
 // fetched back to back and hit in L2, instead of each tap re-reading the whole pixel range Ci/32 K-tiles later when
 // the per-XCD L2 has long been overwritten (rocprofv3 FETCH_SIZE on the collapsed DCGAN G.conv2 forward: 1056 MB for a
 // 67 MB input with the tap-outer order).  The 4 taps' offsets/masks are kept in registers (set up once).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false, bool STATS = false>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
@@ -368,8 +374,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
     const int Ho = g.Ho[cls], Wo = g.Wo[cls];
     const int M = g.N * Ho * Wo;
     const int m0 = blockIdx.x * BM;
-    if (m0 >= M) return;
     const int n0 = blockIdx.y * BN;
+    if (m0 >= M) {
+        // a class smaller than the largest one (odd extents): this tile has no rows; BatchNorm statistics still expect
+        // an (empty) entry for the chunk
+        if (STATS && g.stats && !g.stats_inst && tid < BN && n0 + tid < g.Co) {
+            float* sp = g.stats + (((size_t)cls * gridDim.x + blockIdx.x) * g.Co + n0 + tid) * 3;
+            sp[0] = 0.f; sp[1] = 0.f; sp[2] = 0.f;
+        }
+        return;
+    }
     const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
     const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
     for (int i = tid; i < ntap; i += 256) {
@@ -589,8 +603,60 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_ke
                     if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
                     if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
+                    if (STATS) acc[i][j][r] = o;  // kept for the statistics below
                 }
             }
+        }
+    }
+    if constexpr (STATS) {  // per-tile (mean, M2, count) of every output column (see ConvGeom::stats)
+        const int nvalid = M - m0 < BM ? M - m0 : BM;
+        float* red = As;  // [WAVES_M][BN], the K loop is done with the LDS tiles after the barrier
+        __syncthreads();
+        float mean_c[TN];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < nvalid) {
+                            const float d = pass == 0 ? acc[i][j][r] : acc[i][j][r] - mean_c[j];
+                            sacc += pass == 0 ? d : d * d;
+                        }
+                    }
+                sacc += __shfl_xor(sacc, 32);
+                if (h == 0) red[wm * BN + wn * (TN * 32) + j * 32 + l31] = sacc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < WAVES_M; ++q) t += red[q * BN + wn * (TN * 32) + j * 32 + l31];
+                if (pass == 0) mean_c[j] = t / (float)nvalid;
+                else if (wm == 0 && h == 0) {
+                    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                    if (col < g.Co) {
+                        size_t chunk, grp = 0;
+                        if (g.stats_inst) {
+                            const int hw = Ho * Wo;
+                            grp = (size_t)(m0 / hw);
+                            chunk = (size_t)cls * (hw / BM) + (size_t)((m0 - (int)grp * hw) / BM);
+                        } else {
+                            chunk = (size_t)cls * gridDim.x + blockIdx.x;
+                        }
+                        float* sp = g.stats + ((grp * g.stats_chunks + chunk) * g.Co + col) * 3;
+                        sp[0] = mean_c[j];
+                        sp[1] = t;
+                        sp[2] = (float)nvalid;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -852,20 +918,20 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     static const int tapin_env = getenv("MIGAN_IGEMM_TAPIN") ? atoi(getenv("MIGAN_IGEMM_TAPIN")) : 1;
     bool tapin = tapin_env != 0 && BM * BN < 16384 && g.Ci >= 64;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
+    const bool ktail = g.Ci % 32 != 0, stats = g.stats != nullptr;
+#define PIPE_LAUNCH(KT_, TI_, ST_) \
+    hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_>), grid, dim3(256), 0, st, g, A, Bw, bias, C)
     if constexpr (BM * BN < 16384) {
         if (tapin) {
-            if (g.Ci % 32 == 0)
-                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-            else
-                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+            if (ktail) { if (stats) PIPE_LAUNCH(true, true, true); else PIPE_LAUNCH(true, true, false); }
+            else { if (stats) PIPE_LAUNCH(false, true, true); else PIPE_LAUNCH(false, true, false); }
             HIP_LAUNCH_CHECK();
             return 0;
         }
     }
-    if (g.Ci % 32 == 0)
-        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-    else
-        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    if (ktail) { if (stats) PIPE_LAUNCH(true, false, true); else PIPE_LAUNCH(true, false, false); }
+    else { if (stats) PIPE_LAUNCH(false, false, true); else PIPE_LAUNCH(false, false, false); }
+#undef PIPE_LAUNCH
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1342,9 +1408,37 @@ static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* B
     return 0;
 }
 
+// Number of statistics chunks per group the pipelined kernel will write for this launch (ConvGeom::stats), or 0 when the
+// launch takes another kernel (small-K, GEMV, thin-N, scalar-gather) or - for InstanceNorm groups - a tile would straddle
+// two images.  Mirrors the routing of launch_igemm.
+static int igemm_stats_chunks(const ConvGeom& g, int instance) {
+    bool fast = igemm_fast_ci(g.Ci) && (g.ldw % 4 == 0);
+    for (int t = 0; fast && t < MAX_TAPS; ++t) fast = (g.wofs[t] % 4 == 0);
+    long maxM = 0;
+    int ktaps = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        long m = (long)g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+        ktaps = g.ntap[c] > ktaps ? g.ntap[c] : ktaps;
+    }
+    if (!fast || g.accum || maxM == 0 || g.Co <= 4 || smallk_ok(g) || gemv_ok(g, maxM)) return 0;
+    const int code = igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci);
+    const int bm = code == 1064064 ? 64 : 128;
+    if (!instance) return g.ncls * cdiv(maxM, bm);
+    const int hw = g.Ho[0] * g.Wo[0];
+    for (int c = 0; c < g.ncls; ++c)
+        if (g.Ho[c] * g.Wo[c] != hw) return 0;
+    if (hw % bm != 0) return 0;
+    return g.ncls * (hw / bm);
+}
+
 static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
                         hipStream_t st) {
     ConvGeom g = g_in;
+    if (g.stats) {
+        const int ch = igemm_stats_chunks(g, g.stats_inst);
+        if (ch == 0 || ch != g.stats_chunks) return (int)hipErrorInvalidValue;  // caller must size the buffer from the query
+    }
     for (int c = 0; c < g.ncls; ++c) {
         const unsigned hw = (unsigned)(g.Ho[c] * g.Wo[c]), w = (unsigned)g.Wo[c];
         fastdiv_magic(hw ? hw : 1u, g.mg_hw[c], g.sh_hw[c]);
@@ -1415,17 +1509,26 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
 // ------------------------------------------------------------------------------------------------
 // C ABI: forward
 // ------------------------------------------------------------------------------------------------
+static int conv2d_geom(ConvGeom& g, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                       int pad_t, int pad_l, int gather);
 static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, const float* oscale, float* y, int N,
                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                               int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
-    if (R * S > MAX_TAPS || R * S < 1) return (int)hipErrorInvalidValue;
+                               int pad_t, int pad_l, int gather, int act, float slope, void* stream,
+                               float* stats = nullptr, int stats_chunks = 0, int stats_inst = 0) {
     ConvGeom g = {};
+    if (int rc = conv2d_geom(g, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather)) return rc;
+    g.act = act; g.slope = slope; g.oscale = oscale;
+    g.stats = stats; g.stats_chunks = stats_chunks; g.stats_inst = stats_inst;
+    return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
+}
+static int conv2d_geom(ConvGeom& g, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                       int pad_t, int pad_l, int gather) {
+    if (R * S > MAX_TAPS || R * S < 1) return (int)hipErrorInvalidValue;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
     g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
     g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
     g.Co = Co; g.HoF = Ho; g.WoF = Wo;
     g.ostep = 1; g.istride = stride; g.gather = gather; g.ldw = R * S * Ci; g.ncls = 1;
-    g.act = act; g.slope = slope; g.oscale = oscale;
     g.oh0[0] = 0; g.ow0[0] = 0; g.Ho[0] = Ho; g.Wo[0] = Wo; g.tapbeg[0] = 0; g.ntap[0] = R * S;
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {
@@ -1434,7 +1537,26 @@ static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bia
             g.dw[t] = (short)(s - pad_l);
             g.wofs[t] = t * Ci;
         }
-    return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
+    return 0;
+}
+// How many per-tile statistics chunks per group migan_conv2d_fwd_stats will write for this geometry (the caller sizes the
+// buffer: groups * chunks * Co * 3 floats; groups = N for instance != 0, else 1); 0 = this geometry does not run on the
+// pipelined MFMA kernel (or a tile would straddle two images): use migan_conv2d_fwd and migan_norm_stats.
+MIGAN_API int migan_conv2d_stats_chunks(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                                        int pad_t, int pad_l, int gather, int instance) {
+    ConvGeom g = {};
+    if (conv2d_geom(g, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather)) return 0;
+    return igemm_stats_chunks(g, instance);
+}
+// migan_conv2d_fwd / migan_conv2d_dropout_fwd (mask_nc may be NULL) that also leaves the per-tile (mean, M2, count) of its
+// output for the BatchNorm / InstanceNorm layer that follows (dcgan.py:78-80, cyclegan/models.py:28-29, srgan/models.py:22-23).
+MIGAN_API int migan_conv2d_fwd_stats(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc,
+                                     float* y, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                     int stride, int pad_t, int pad_l, int gather, int act, float slope, float* stats,
+                                     int stats_chunks, int instance, void* stream) {
+    if (!stats || stats_chunks <= 0 || (mask_nc && Co % 4 != 0)) return (int)hipErrorInvalidValue;
+    return conv2d_fwd_impl(x, w_ohwi, bias, mask_nc, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, act,
+                           slope, stream, stats, stats_chunks, instance);
 }
 
 MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N,
@@ -2384,12 +2506,34 @@ MIGAN_API int migan_upconv3x3_pack(const float* w_oihw, float* wf, float* wd, in
 }
 
 // y[N][2H][2W][Co] = act(conv3x3(up2(x)) + bias)
+static void upconv_fwd_geom(ConvGeom& g, int N, int H, int W, int Ci, int Co);
 MIGAN_API int migan_upconv3x3_fwd(const float* x, const float* wf, const float* bias, float* y, int N, int H,
                                   int W, int Ci, int Co, int act, float slope, void* stream) {
     ConvGeom g = {};
+    upconv_fwd_geom(g, N, H, W, Ci, Co);
+    g.act = act; g.slope = slope;
+    return launch_igemm(g, x, wf, bias, y, (hipStream_t)stream);
+}
+// the same with the statistics output of migan_conv2d_fwd_stats (dcgan.py:54-56: Upsample, Conv2d, BatchNorm2d)
+MIGAN_API int migan_upconv3x3_stats_chunks(int N, int H, int W, int Ci, int Co, int instance) {
+    ConvGeom g = {};
+    upconv_fwd_geom(g, N, H, W, Ci, Co);
+    return igemm_stats_chunks(g, instance);
+}
+MIGAN_API int migan_upconv3x3_fwd_stats(const float* x, const float* wf, const float* bias, float* y, int N, int H, int W,
+                                        int Ci, int Co, int act, float slope, float* stats, int stats_chunks, int instance,
+                                        void* stream) {
+    if (!stats || stats_chunks <= 0) return (int)hipErrorInvalidValue;
+    ConvGeom g = {};
+    upconv_fwd_geom(g, N, H, W, Ci, Co);
+    g.act = act; g.slope = slope;
+    g.stats = stats; g.stats_chunks = stats_chunks; g.stats_inst = instance;
+    return launch_igemm(g, x, wf, bias, y, (hipStream_t)stream);
+}
+static void upconv_fwd_geom(ConvGeom& g, int N, int H, int W, int Ci, int Co) {
     g.N = N; g.Hi = H; g.Wi = W; g.Ci = Ci; g.HiL = H; g.WiL = W;
     g.Co = Co; g.HoF = 2 * H; g.WoF = 2 * W; g.ostep = 2; g.istride = 1; g.gather = GATHER_ZERO;
-    g.ldw = 16 * Ci; g.ncls = 4; g.act = act; g.slope = slope;
+    g.ldw = 16 * Ci; g.ncls = 4;
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) {
             int c = a * 2 + b;
@@ -2402,7 +2546,6 @@ MIGAN_API int migan_upconv3x3_fwd(const float* x, const float* wf, const float* 
                     g.wofs[slot] = slot * Ci;
                 }
         }
-    return launch_igemm(g, x, wf, bias, y, (hipStream_t)stream);
 }
 
 // dx[N][H][W][Ci] from dy[N][2H][2W][Co]

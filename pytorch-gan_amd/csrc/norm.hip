@@ -786,3 +786,58 @@ MIGAN_API int migan_norm_bwd2(const float* x, const float* d, const float* u, co
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Statistics from the per-tile (mean, M2, count) triples a conv kernel left in its epilogue (migan_conv2d_fwd_stats):
+// Chan's parallel combination in double, ONE WAVE per (g, c): pass 1 total count and mean, pass 2
+// M2 = sum_t (M2_t + n_t * (mean_t - mean)^2).  Replaces the statistics pass over the conv output
+// (norm_partial_kernel<.., false> + norm_finalize_fwd_kernel) by this finalize alone.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_finalize_chan_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                                 float* __restrict__ invstd, float* running_mean,
+                                                                 float* running_var, long long* nbt, int G, int C,
+                                                                 int nchunks, float eps, float momentum) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    double n = 0.0, sm = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        const size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
+        const double nt = (double)part[o + 2];
+        n += nt;
+        sm += nt * (double)part[o];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off);
+        sm += __shfl_xor(sm, off);
+    }
+    const double m = n > 0.0 ? sm / n : 0.0;
+    double M2 = 0.0;
+    for (int k = lane; k < nchunks; k += 64) {
+        const size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
+        const double nt = (double)part[o + 2], d = (double)part[o] - m;
+        M2 += (double)part[o + 1] + nt * d * d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) M2 += __shfl_xor(M2, off);
+    if (lane != 0) return;
+    if (i == 0 && nbt) nbt[0] += 1;
+    const double var = n > 0.0 ? M2 / n : 0.0;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && G == 1) {
+        const double unb = n > 1.0 ? M2 / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+MIGAN_API int migan_norm_stats_from_conv(const float* part, int nchunks, float* mean, float* invstd, float* running_mean,
+                                         float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                         int G, int C, void* stream) {
+    if (G < 1 || C < 1 || nchunks < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_finalize_chan_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, (hipStream_t)stream, part,
+                       mean, invstd, running_mean, running_var, num_batches_tracked, G, C, nchunks, eps, momentum);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -23,9 +23,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# 0 off, 1 always, n > 1: only for gradients of at least n elements (default 4 Mi: measured +2.5 % on the CycleGAN step -
-# the wave tails of a layer's wgrad and dgrad launches fill each other - and neutral on the launch-bound DCGAN step)
-_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", str(1 << 22)))
+# 0 off (default), 1 always, n > 1: only for gradients of at least n elements.  Measured (profiles/r02_ab.txt): with the
+# round-1 split-K plan the wave tails of a layer's wgrad and dgrad launches filled each other (+2.5 % on the CycleGAN step);
+# with the balanced plan the tails are gone (+0.3 %), and the captured DCGAN step is 4 % slower with the two branches.
+_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", "0"))
 _SIDE_STREAMS = {}
 
 
@@ -355,7 +356,7 @@ class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pads, gather, act, slope, mask=None):
+    def forward(ctx, x, w, b, stride, pads, gather, act, slope, mask=None, stats_buf=None, stats_chunks=0, stats_inst=0):
         xs = to_nhwc(x)
         w_in, b_in = w, b
         w = _plain(w)
@@ -374,13 +375,18 @@ class _Conv2d(Function):
             raise ValueError("conv2d: empty output")
         wp = _packed(w_in, w, "ohwi", lambda: _permute4(w, (0, 2, 3, 1)))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
-        if mask is None:
-            check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
-                                       S, stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
-        else:  # fused Dropout2d: y = act(conv) * mask[n][co]
+        if mask is not None:
             mask = _plain(mask)
             if tuple(mask.shape) != (N, Co) or not mask.is_contiguous() or Co % 4 != 0:
                 raise ValueError("conv2d: dropout mask must be a contiguous (N, Co) tensor with Co % 4 == 0")
+        if stats_buf is not None:  # per-tile statistics for the norm layer behind this conv, from the conv epilogue
+            check(lib.migan_conv2d_fwd_stats(xs.data_ptr(), wp.data_ptr(), _ptr(b), _ptr(mask), y.data_ptr(), N, H, W, Ci,
+                                             Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, stats_buf.data_ptr(),
+                                             stats_chunks, stats_inst, _stream()), "conv2d_fwd_stats")
+        elif mask is None:
+            check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
+                                       S, stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
+        else:  # fused Dropout2d: y = act(conv) * mask[n][co]
             check(lib.migan_conv2d_dropout_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), mask.data_ptr(), y.data_ptr(), N, H,
                                                W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, _stream()),
                   "conv2d_dropout_fwd")
@@ -460,7 +466,7 @@ class _Conv2d(Function):
                 check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
                       "gather2d_bwd")
         fork.join()
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 _REFLECT1 = __import__("os").environ.get("MIGAN_REFLECT1", "1") == "1"  # A/B knob: 0 = padded extent + fold pass
@@ -497,23 +503,58 @@ def _conv2d_backward_differentiable(ctx, dy, xs, w, y, mask):
                       "conv2d_wgrad")
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = _colsum(gd, N * Ho * Wo, Co, None)
-    return dx, dw, db, None, None, None, None, None, None
+    return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 _Conv2d._backward_differentiable = staticmethod(_conv2d_backward_differentiable)
 
 
-def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None):
-    """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue."""
-    return _Conv2d.apply(x, w, b, int(stride), tuple(int(p) for p in pads), int(gather), int(act), float(slope),
-                         dropout_mask)
+_CONV_STATS = __import__("os").environ.get("MIGAN_CONV_STATS", "1") == "1"  # A/B knob
+
+
+def _attach_stats(y, buf, chunks, inst, G, P, C):
+    y._migan_stats = (buf, chunks, inst, G, P, C, y.data_ptr(), y._version)
+    return y
+
+
+def _stats_side(x, inst, G, P, C):
+    """(buffer, chunks) when the conv that produced `x` left its per-tile statistics for exactly this normalisation."""
+    side = getattr(x, "_migan_stats", None)
+    if side is None or not _CONV_STATS:
+        return None
+    buf, chunks, sinst, sG, sP, sC, ptr, ver = side
+    if (sinst, sG, sP, sC) != (int(inst), G, P, C) or ptr != x.data_ptr() or ver != x._version:
+        return None
+    return buf, chunks
+
+
+def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None,
+           stats=None):
+    """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue.
+    `stats` ("batch" | "instance"): the conv epilogue also leaves per-tile statistics of its output for the BatchNorm /
+    InstanceNorm layer that follows (picked up by `norm()`; ignored where the geometry does not support it)."""
+    stride, pads = int(stride), tuple(int(p) for p in pads)
+    if stats is not None and _CONV_STATS and x.dim() == 4:
+        inst = 1 if stats == "instance" else 0
+        N, Ci, H, W = x.shape
+        Co, _, R, S = w.shape
+        HL, WL = (2 * H, 2 * W) if gather == GATHER_UP2 else (H, W)
+        Ho, Wo = _conv_out(HL, pads[0], pads[2], R, stride), _conv_out(WL, pads[1], pads[3], S, stride)
+        chunks = lib.migan_conv2d_stats_chunks(N, H, W, Ci, Ho, Wo, Co, R, S, stride, pads[0], pads[1], int(gather), inst) \
+            if Ho > 0 and Wo > 0 else 0
+        if chunks > 0:
+            G = N if inst else 1
+            buf = torch.empty(G * chunks * Co * 3, device=x.device, dtype=torch.float32)
+            y = _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask, buf, chunks, inst)
+            return _attach_stats(y, buf, chunks, inst, G, (Ho * Wo) if inst else N * Ho * Wo, Co)
+    return _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask)
 
 
 class _UpConv3x3(Function):
     """Upsample(scale_factor=2) -> Conv2d(3x3, stride 1, padding 1) in its phase-collapsed form (2.25x fewer FLOPs)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope):
+    def forward(ctx, x, w, b, act, slope, stats_buf=None, stats_chunks=0, stats_inst=0):
         xs = to_nhwc(x)
         ctx.params = (w, b)
         w, b = _plain(w), _plain(b)
@@ -527,8 +568,12 @@ class _UpConv3x3(Function):
         st = _stream()
         check(lib.migan_upconv3x3_pack(wc.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, st), "upconv_pack")
         y = _empty_nhwc((N, Co, 2 * H, 2 * W), xs)
-        check(lib.migan_upconv3x3_fwd(xs.data_ptr(), wf.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Co, act, slope,
-                                      st), "upconv_fwd")
+        if stats_buf is not None:
+            check(lib.migan_upconv3x3_fwd_stats(xs.data_ptr(), wf.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Co, act,
+                                                slope, stats_buf.data_ptr(), stats_chunks, stats_inst, st), "upconv_fwd_stats")
+        else:
+            check(lib.migan_upconv3x3_fwd(xs.data_ptr(), wf.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Co, act, slope,
+                                          st), "upconv_fwd")
         ctx.geom = (N, H, W, Ci, Co, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(xs, w, wd, y if act != ACT_NONE else None)
@@ -585,7 +630,7 @@ class _UpConv3x3(Function):
             check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, _stream()),
                   "upconv_dgrad")
         fork.join()
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 _UPCONV_COLLAPSE = True
@@ -597,10 +642,20 @@ def set_upconv_collapse(enabled):
     _UPCONV_COLLAPSE = bool(enabled)
 
 
-def upconv3x3(x, w, b=None, act=ACT_NONE, slope=0.0):
+def upconv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, stats=None):
     if _UPCONV_COLLAPSE:
+        if stats is not None and _CONV_STATS and x.dim() == 4:
+            inst = 1 if stats == "instance" else 0
+            N, Ci, H, W = x.shape
+            Co = w.shape[0]
+            chunks = lib.migan_upconv3x3_stats_chunks(N, H, W, Ci, Co, inst)
+            if chunks > 0:
+                G = N if inst else 1
+                buf = torch.empty(G * chunks * Co * 3, device=x.device, dtype=torch.float32)
+                y = _UpConv3x3.apply(x, w, b, int(act), float(slope), buf, chunks, inst)
+                return _attach_stats(y, buf, chunks, inst, G, (4 * H * W) if inst else N * 4 * H * W, Co)
         return _UpConv3x3.apply(x, w, b, int(act), float(slope))
-    return conv2d(x, w, b, 1, (1, 1, 1, 1), GATHER_UP2, act, slope)
+    return conv2d(x, w, b, 1, (1, 1, 1, 1), GATHER_UP2, act, slope, None, stats)
 
 
 class _ConvTranspose2d(Function):
@@ -674,9 +729,47 @@ def _mm_nt_raw(a, b, bias, act=ACT_NONE, slope=0.0):
     if K != Kb:
         raise ValueError("mm_nt: inner dimensions differ (%d vs %d)" % (K, Kb))
     out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+    if _SKINNY and lib.migan_skinny_nt_ok(M, Nn, K):  # <= 64 rows: latency-bound, MFMA 16x16x4 straight from L2
+        check(lib.migan_skinny_nt(a.data_ptr(), b.data_ptr(), _ptr(bias), out.data_ptr(), M, Nn, K, act, slope, _stream()),
+              "skinny_nt")
+        return out
     check(lib.migan_conv2d_fwd(a.data_ptr(), b.data_ptr(), _ptr(bias), out.data_ptr(), M, 1, 1, K, 1, 1, Nn, 1, 1, 1,
                                0, 0, GATHER_ZERO, act, slope, _stream()), "mm_nt")
     return out
+
+
+_SKINNY = __import__("os").environ.get("MIGAN_SKINNY", "1") == "1"  # A/B knob
+
+
+class _MMNN(Function):
+    """a[M,R] @ b[R,N] — the Linear input gradient dy @ W with W in its stored layout.  <= 64 rows: skinny kernel, no
+    transposed copy of W; otherwise transpose + the tiled kernel.  Backward is built from differentiable Functions."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        ac, bc = canon(a), canon(b)
+        M, R = ac.shape
+        Rb, Nn = bc.shape
+        if R != Rb:
+            raise ValueError("mm_nn: inner dimensions differ (%d vs %d)" % (R, Rb))
+        if _SKINNY and lib.migan_skinny_nn_ok(M, R, Nn):
+            out = torch.empty((M, Nn), device=ac.device, dtype=torch.float32)
+            check(lib.migan_skinny_nn(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), M, R, Nn, _stream()), "skinny_nn")
+            return out
+        bt = torch.empty((Nn, R), device=bc.device, dtype=torch.float32)
+        check(lib.migan_transpose_batched(bc.data_ptr(), bt.data_ptr(), 1, R, Nn, _stream()), "transpose")
+        return _mm_nt_raw(ac, bt, None)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _MMNT.apply(g, b, None)   # [M,N] @ [R,N]^T
+        if ctx.needs_input_grad[1]:
+            db = _MMTN.apply(a, g)         # [M,R]^T @ [M,N]
+        return da, db
 
 
 class _Transpose(Function):
@@ -716,8 +809,10 @@ class _MMNT(Function):
                 slot = _grad_slot(b)
                 if slot is not None:  # first-order backward of a Linear weight: reduce straight into weight.grad
                     dbuf = None
-                    if want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(gc.shape[1], 1, 1, ac.shape[1], 1,
-                                                                                   GATHER_ZERO):
+                    # few rows (the MLP critic at batch 64): the bias gradient inside the wgrad launch saves two latency-bound
+                    # column-sum launches per layer; for large P it stays opt-in (the column-0 workgroups become the tail)
+                    if want_db and (_FUSE_BIAS or gc.shape[0] <= 256) and lib.migan_conv2d_wgrad_fuses_bias(
+                            gc.shape[1], 1, 1, ac.shape[1], 1, GATHER_ZERO):
                         dbt, dba, dbias = _bias_out(ctx.bias_param, gc.shape[1], gc)
                         dbuf, want_db = (dbt, dba), False
                     _mm_tn_raw(gc, ac, slot, 1, dbuf)
@@ -771,7 +866,7 @@ def mm_nt(a, b, bias=None):
 
 
 def mm_nn(a, b):
-    return _MMNT.apply(a, _Transpose.apply(b), None)
+    return _MMNN.apply(a, b)
 
 
 def linear(x, w, b=None):
@@ -891,7 +986,12 @@ class _Norm(Function):
             invstd = torch.empty_like(mean)
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
-            if sync is None:
+            side = _stats_side(x, instance, G, P, C) if sync is None else None
+            if side is not None:  # per-tile (mean, M2, count) left by the conv epilogue: no pass over the tensor
+                check(lib.migan_norm_stats_from_conv(side[0].data_ptr(), side[1], mean.data_ptr(), invstd.data_ptr(),
+                                                     _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, G, C,
+                                                     st), "norm_stats_from_conv")
+            elif sync is None:
                 check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
                                            _ptr(running_var), _ptr(nbt), momentum, eps, G, P, C, ws.data_ptr(), nb,
                                            st), "norm_stats")

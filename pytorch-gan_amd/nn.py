@@ -151,20 +151,25 @@ class Conv2d(tnn.Conv2d):
             raise ValueError("Conv2d: string padding is not supported")
         return s[0], _pair(self.padding)
 
-    def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0, dropout=None):
-        """`dropout`: a following training-mode Dropout2d module whose mask multiply rides in the conv epilogue."""
+    def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0, dropout=None,
+                      stats=None):
+        """`dropout`: a following training-mode Dropout2d module whose mask multiply rides in the conv epilogue.
+        `stats` ("batch" / "instance"): a normalisation layer consumes this output next - its statistics are taken in the
+        conv epilogue (only where everything in between is fused into this launch)."""
         stride, (ph, pw) = self._check()
         if gather == F.GATHER_REFLECT and (ph or pw):
             raise ValueError("reflection gather cannot be combined with conv zero padding")
         pads = (pre_pads[0] + ph, pre_pads[1] + pw, pre_pads[2] + ph, pre_pads[3] + pw)
         if (gather == F.GATHER_UP2 and stride == 1 and pads == (1, 1, 1, 1)
                 and tuple(self.weight.shape[2:]) == (3, 3)):
-            y = _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope))  # phase-collapsed Upsample+Conv3x3
+            # phase-collapsed Upsample+Conv3x3
+            y = _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope, stats if dropout is None else None))
             return dropout(y) if dropout is not None else y
         if dropout is not None and self.out_channels % 4 == 0:
             mask = _next_mask((x.shape[0], self.out_channels), dropout.p, x.device)
-            return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, mask))
-        y = _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope))
+            return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, mask, stats))
+        y = _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, None,
+                           stats if dropout is None else None))
         return dropout(y) if dropout is not None else y
 
     def forward(self, x):
@@ -453,7 +458,12 @@ class Sequential(tnn.Sequential):
                 drop = None
                 if k < n and type(mods[k]) is Dropout2d and mods[k].training and 0.0 < mods[k].p < 1.0 and x.dim() == 4:
                     drop, k = mods[k], k + 1
-                x = mods[j].fused_forward(x, pre, gather, act, slope, drop)
+                stats = None  # the next module normalises this output: statistics from the conv epilogue
+                if k < n and type(mods[k]) is InstanceNorm2d:
+                    stats = "instance"
+                elif k < n and type(mods[k]) is BatchNorm2d and (mods[k].training or not mods[k].track_running_stats):
+                    stats = "batch"
+                x = mods[j].fused_forward(x, pre, gather, act, slope, drop, stats)
                 i = k
                 continue
             # -- Norm [LeakyReLU | ReLU] -------------------------------------------------------------------

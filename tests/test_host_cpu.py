@@ -112,13 +112,13 @@ def test_sequential_fusion_plan(monkeypatch):
         hl, wl = (2 * h, 2 * w) if gather == F.GATHER_UP2 else (h, w)
         return (hl + pads[0] + pads[2] - k) // stride + 1, (wl + pads[1] + pads[3] - k) // stride + 1
 
-    def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=0, act=0, slope=0.0, dropout_mask=None):
-        calls.append(("conv2d", tuple(pads), gather, act, dropout_mask is not None))
+    def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=0, act=0, slope=0.0, dropout_mask=None, stats=None):
+        calls.append(("conv2d", tuple(pads), gather, act, dropout_mask is not None) + ((stats,) if stats else ()))
         ho, wo = out_hw(x.shape[2], x.shape[3], w.shape[2], stride, pads, gather)
         return torch.zeros(x.shape[0], w.shape[0], ho, wo)
 
-    def upconv3x3(x, w, b=None, act=0, slope=0.0):
-        calls.append(("upconv3x3", act))
+    def upconv3x3(x, w, b=None, act=0, slope=0.0, stats=None):
+        calls.append(("upconv3x3", act) + ((stats,) if stats else ()))
         return torch.zeros(x.shape[0], w.shape[0], 2 * x.shape[2], 2 * x.shape[3])
 
     def norm(x, gamma=None, beta=None, res=None, rm=None, rv=None, use_batch_stats=True, momentum=0.1, eps=1e-5,
@@ -144,7 +144,8 @@ def test_sequential_fusion_plan(monkeypatch):
                         nn.BatchNorm2d(32, 0.8))
     y = blk(torch.zeros(2, 16, 8, 8))
     assert tuple(y.shape) == (2, 32, 4, 4)
-    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_LRELU, True), ("norm", False, F.ACT_NONE, 0.8, True)]
+    # ... and the BatchNorm statistics are requested from the conv epilogue
+    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_LRELU, True, "batch"), ("norm", False, F.ACT_NONE, 0.8, True)]
 
     # DCGAN generator block (dcgan.py:54-57): Upsample -> Conv3x3 -> BatchNorm -> LeakyReLU  = collapsed up-conv + fused norm
     calls.clear()
@@ -152,7 +153,7 @@ def test_sequential_fusion_plan(monkeypatch):
                         nn.LeakyReLU(0.2, inplace=True))
     y = blk(torch.zeros(2, 8, 4, 4))
     assert tuple(y.shape) == (2, 8, 8, 8)
-    assert calls == [("upconv3x3", F.ACT_NONE), ("norm", False, F.ACT_LRELU, 0.8, True)]
+    assert calls == [("upconv3x3", F.ACT_NONE, "batch"), ("norm", False, F.ACT_LRELU, 0.8, True)]
 
     # CycleGAN residual block body (cyclegan/models.py:27-35): ReflectionPad -> Conv -> InstanceNorm -> ReLU -> ...
     calls.clear()
@@ -160,8 +161,8 @@ def test_sequential_fusion_plan(monkeypatch):
                         nn.ReflectionPad2d(1), nn.Conv2d(8, 8, 3), nn.InstanceNorm2d(8))
     y = blk(torch.zeros(1, 8, 6, 6))
     assert tuple(y.shape) == (1, 8, 6, 6)
-    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False), ("norm", True, F.ACT_RELU, 1e-5, False),
-                     ("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False), ("norm", True, F.ACT_NONE, 1e-5, False)]
+    assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False, "instance"), ("norm", True, F.ACT_RELU, 1e-5, False),
+                     ("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False, "instance"), ("norm", True, F.ACT_NONE, 1e-5, False)]
 
     # PatchGAN tail (cyclegan/models.py:117-118): ZeroPad2d((1,0,1,0)) -> Conv2d(C, 1, 4, padding=1): pads fold into the conv
     calls.clear()

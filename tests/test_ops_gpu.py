@@ -754,7 +754,7 @@ def test_conv_double_backward(pg, case):
     yg = F.conv2d(xg, wg, bg, stride, (pad,) * 4, F.GATHER_ZERO, act, 0.2, None if mask is None else mask.float().to(DEV))
     g_gpu, loss_gpu = _gp_like(yg, xg, [wg, bg], 7)
     assert_close(g_gpu, g_ref.float(), TOL_FWD, "first-order input gradient (create_graph)")
-    assert abs(float(loss_gpu) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert abs(float(loss_gpu) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)), (float(loss_gpu), float(loss_ref))
     assert_close(wg.grad, w.grad.float(), TOL_WGRAD, "d(penalty)/dw through dgrad")
     assert bg.grad is None or float(bg.grad.abs().max()) == 0.0   # the penalty does not depend on the bias
     with F.input_grad_only():   # the hint skips the (discarded) first-order weight-gradient kernels, same result
@@ -814,3 +814,95 @@ def test_raw_backward_refuses_create_graph(pg):
     y = F.maxpool2(x)
     with pytest.raises(NotImplementedError):
         torch.autograd.grad(y.sum(), x, create_graph=True)
+
+
+# ------------------------------------------------------------------------------------------------ conv-epilogue statistics
+@pytest.mark.parametrize("cfg", [
+    # N, Ci, H, W, Co, k, stride, pad, inst, masked, up
+    (8, 128, 16, 16, 128, 3, 1, 1, False, False, True),    # dcgan.py:54-56 Upsample+Conv+BatchNorm (4 phase classes, 128x128)
+    (8, 128, 16, 16, 64, 3, 1, 1, False, False, True),     # dcgan.py:58-60 (128x64 tap-inner kernel)
+    (16, 16, 16, 16, 32, 3, 2, 1, False, True, False),     # dcgan.py:78-80 Conv+LeakyReLU+Dropout2d+BN, Ci=16 (K-tail), 64x64 tile
+    (5, 32, 9, 7, 48, 3, 1, 1, False, False, False),       # ragged: 315 rows, partial last tile, Co tail
+    (2, 64, 16, 16, 64, 3, 1, 1, True, False, False),      # InstanceNorm: groups = images, 256 pixels = 2-4 tiles per image
+    (2, 256, 16, 16, 256, 3, 1, 1, True, False, False),    # cyclegan residual conv geometry (reflect handled below)
+    (3, 32, 6, 6, 32, 3, 1, 1, True, False, False),        # InstanceNorm with 36 pixels per image: NOT supported -> fallback
+])
+def test_conv_epilogue_statistics(pg, cfg, monkeypatch):
+    """Conv -> [act -> Dropout2d ->] BatchNorm / InstanceNorm with the statistics taken in the conv epilogue (per-tile
+    mean / M2 / count + Chan combination) against the norm layer's own statistics pass: outputs, running statistics and
+    all gradients agree to fp32 rounding."""
+    N, Ci, H, W, Co, k, stride, pad, inst, masked, up = cfg
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).to(DEV)
+    w = _leaf(Co, Ci, k, k, seed=2, scale=0.2).to(DEV)
+    b = _leaf(Co, seed=3).to(DEV)
+    mask = ((torch.rand(N, Co, generator=torch.Generator().manual_seed(4)) > 0.25).float() / 0.75).to(DEV) if masked else None
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "_CONV_STATS", on)
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        gamma = None if inst else (torch.ones(Co, device=DEV) * 1.5).requires_grad_(True)
+        beta = None if inst else torch.zeros(Co, device=DEV).requires_grad_(True)
+        kind = "instance" if inst else "batch"
+        if up:
+            y = F.upconv3x3(xg, wg, b, F.ACT_NONE, 0.0, kind)
+        else:
+            gather = F.GATHER_REFLECT if (inst and Ci == 256) else F.GATHER_ZERO
+            y = F.conv2d(xg, wg, b, stride, (pad,) * 4, gather, F.ACT_LRELU if masked else F.ACT_NONE, 0.2, mask, kind)
+        used = hasattr(y, "_migan_stats")
+        z = F.norm(y, gamma, beta, None, None if inst else rm, None if inst else rv, True, 0.1, 0.8 if masked else 1e-5, inst,
+                   F.ACT_LRELU, 0.2, None if inst else nbt)
+        gz = _leaf(*z.shape, seed=6).to(DEV)
+        z.backward(gz)
+        res[on] = (z.detach(), xg.grad, wg.grad, rm, rv, int(nbt), used)
+    assert res[False][6] is False
+    supported = not (inst and (H * W) % 64 != 0)
+    assert res[True][6] is supported
+    assert_close(res[True][0], res[False][0], 2e-6, "norm output, conv-epilogue statistics vs statistics pass")
+    assert_close(res[True][1], res[False][1], 2e-5, "dx")
+    assert_close(res[True][2], res[False][2], 2e-5, "dw")
+    if not inst:
+        assert_close(res[True][3], res[False][3], 2e-6, "running_mean")
+        assert_close(res[True][4], res[False][4], 2e-6, "running_var")
+        assert res[True][5] == res[False][5] == 1
+
+
+@pytest.mark.parametrize("dims", [(64, 1024, 512, 1), (64, 128, 256, 0), (33, 512, 1024, 3), (64, 1024, 1024, 0), (16, 48, 32, 0),
+                                  (64, 144, 80, 1)])
+def test_skinny_linear(pg, dims, monkeypatch):
+    """<= 64-row Linear forward / input gradient on the skinny MFMA kernels (wgan_gp.py:46-56,73-77 at batch 64) against
+    torch CPU and against the tiled kernels they replace."""
+    B, K, Nf, act = dims
+    F = pg.functional
+    from pytorch_gan_amd._lib import lib
+
+    assert lib.migan_skinny_nt_ok(B, Nf, K) == 1 and (Nf % 16 != 0 or lib.migan_skinny_nn_ok(B, Nf, K) == (1 if K % 32 == 0 else 0))
+    x = _leaf(B, K, seed=1).requires_grad_(True)
+    w = _leaf(Nf, K, seed=2, scale=0.1).requires_grad_(True)
+    b = _leaf(Nf, seed=3).requires_grad_(True)
+    y_ref = TF.linear(x, w, b)
+    gy = _leaf(B, Nf, seed=4)
+    y_ref.backward(gy)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "_SKINNY", on)
+        xg, wg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+        y = F.linear(xg, wg, bg)
+        y.backward(gy.to(DEV))
+        assert_close(y, y_ref, TOL_FWD, "skinny=%s linear fwd" % on)
+        assert_close(xg.grad, x.grad, TOL_FWD, "skinny=%s linear dgrad" % on)
+        assert_close(wg.grad, w.grad, TOL_WGRAD, "linear wgrad")
+        assert_close(bg.grad, b.grad, TOL_BIAS, "linear bias (inside the wgrad launch for few rows)")
+        outs[on] = (y.detach(), xg.grad)
+    assert_close(outs[True][0], outs[False][0], 2e-6, "skinny vs tiled fwd")
+    assert_close(outs[True][1], outs[False][1], 2e-6, "skinny vs tiled dgrad")
+    # fused activation epilogue of the forward kernel (C ABI)
+    if act:
+        st = torch.cuda.current_stream().cuda_stream
+        xa, wa, ba = x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV)
+        out = torch.empty(B, Nf, device=DEV)
+        assert lib.migan_skinny_nt(xa.data_ptr(), wa.data_ptr(), ba.data_ptr(), out.data_ptr(), B, Nf, K, act, 0.2, st) == 0
+        ref = {1: lambda t: TF.leaky_relu(t, 0.2), 3: torch.tanh}[act](y_ref.detach())
+        assert_close(out, ref, TOL_FWD, "skinny fused act")
