@@ -150,7 +150,7 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
 
     # replay buffers warm (>= 50 entries) before timing, so the picks and clones of the timed steps are
     # those of a run in steady state
-    while len(state.buf_A.data) < state.buf_A.max_size:
+    while len(state.buf_A) < state.buf_A.max_size:
         run(0)
     w = Workload("cyclegan", batch, run, state, None, False, None, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)

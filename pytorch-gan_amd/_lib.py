@@ -106,6 +106,7 @@ _SIGS = {
     "migan_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
     "migan_maxpool2_bwd": (c_int, [P, P, P] + [c_int] * 4 + [P]),
     "migan_cat_channels": (c_int, [P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "migan_select_rows": (c_int, [P, P, P, P, P, c_int, c_size_t, P]),
     "migan_transpose_batched": (c_int, [P, P, c_int, c_int, c_int, P]),
     "migan_permute4d": (c_int, [P, P] + [c_int] * 8 + [P]),
     "migan_colsum_workspace": (c_size_t, [c_size_t, c_int]),

@@ -549,6 +549,35 @@ MIGAN_API int migan_transpose_batched(const float* src, float* dst, int B, int R
     return 0;
 }
 
+// Row gather from two sources: dst[k][:] = sel[k] >= 0 ? a[sel[k]][:] : b[-1 - sel[k]][:]  (rows of D floats).
+// Device-resident CycleGAN image history (cyclegan/utils.py:13-33): out[k] is either the new sample batch[k] or an old
+// pool entry, and the pool update pool[j] = batch[k] is the same kernel with the roles swapped - two launches per
+// push_and_pop instead of per-sample clones and a torch.cat.
+__global__ void select_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst,
+                                   const int* __restrict__ sel, const int* __restrict__ dst_row, size_t D) {
+    const int k = blockIdx.y;
+    const int sidx = sel[k];
+    const float* src = sidx >= 0 ? a + (size_t)sidx * D : b + (size_t)(-1 - sidx) * D;
+    float* out = dst + (size_t)(dst_row ? dst_row[k] : k) * D;
+    const size_t n4 = D / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = src[i];
+}
+// n rows; sel / dst_row are device int32 arrays (dst_row NULL: dst row k).  Rows must be 16-byte aligned (D % 4 == 0 or
+// the scalar tail path handles the remainder only when the row starts are aligned, i.e. D % 4 == 0 for row > 0).
+MIGAN_API int migan_select_rows(const float* a, const float* b, float* dst, const int* sel, const int* dst_row, int n,
+                                size_t D, void* stream) {
+    if (n <= 0 || D == 0) return 0;
+    if (D % 4 != 0 || n > 65535) return (int)hipErrorInvalidValue;
+    size_t bx = (D / 4 + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream, a, b, dst, sel, dst_row, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // generic 4-D permute copy (weight packing; small tensors): dst = src.permute(p0,p1,p2,p3).contiguous()
 __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
                                 int d3, int p0, int p1, int p2, int p3, size_t total) {

@@ -251,17 +251,63 @@ class WganGpRunner:
 
 # ------------------------------------------------------------------------------------------------ cyclegan
 class ReplayBuffer:
-    """cyclegan/utils.py:13-33 with device-resident history (index logic identical, python `random`)."""
+    """cyclegan/utils.py:13-33 with a DEVICE-resident history: the index logic and the python `random`
+    draws are the reference's, bit for bit; the samples live in one pool tensor [max_size][C][H][W] on the GPU and a call
+    is two kernel launches - one gathers the returned batch from old pool entries and new samples, one writes the new
+    samples into the pool - instead of per-sample clones and a torch.cat.  CPU tensors (the oracle comparison of the index
+    logic) take the reference's list path."""
 
     def __init__(self, max_size=50):
         if max_size <= 0:
             raise AssertionError("Empty buffer or trying to create a black hole. Be careful.")
         self.max_size, self.data = max_size, []
+        self.pool, self.count = None, 0
+
+    def __len__(self):
+        return self.count if self.pool is not None else len(self.data)
 
     def push_and_pop(self, batch):
-        if batch.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("ReplayBuffer draws from the host RNG and keeps sample references: it cannot be "
-                               "captured into a hipGraph (run cyclegan_step eagerly)")
+        if not batch.is_cuda:
+            return self._push_and_pop_host(batch)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ReplayBuffer draws from the host RNG: it cannot be captured into a hipGraph (run "
+                               "cyclegan_step eagerly)")
+        x = F.canon(batch.data)
+        B = x.shape[0]
+        D = x[0].numel()
+        if self.pool is None or self.pool.shape[1:] != x.shape[1:]:
+            self.pool = torch.empty((self.max_size, *x.shape[1:]), device=x.device, dtype=torch.float32,
+                                    memory_format=torch.channels_last if x.dim() == 4 else torch.contiguous_format)
+            self.count = 0
+        # the reference loop, on indices: where each returned element comes from, and what each pool slot holds afterwards
+        out_src = []                      # per returned element: pool slot j >= 0 (its CURRENT content) or new sample -1-k
+        slot_src = {}                     # pool slot -> new sample k written to it in this call (last write wins)
+        for k in range(B):
+            if self.count < self.max_size:
+                slot_src[self.count] = k
+                self.count += 1
+                out_src.append(-1 - k)
+            elif random.uniform(0, 1) > 0.5:
+                j = random.randint(0, self.max_size - 1)
+                # the slot may already have been replaced earlier in this call: then its content is that new sample
+                out_src.append(-1 - slot_src[j] if j in slot_src else j)
+                slot_src[j] = k
+            else:
+                out_src.append(-1 - k)
+        out = torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        sel = torch.tensor(out_src, dtype=torch.int32).to(x.device)
+        F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), out.data_ptr(), sel.data_ptr(), None, B, D, st),
+                "select_rows")
+        if slot_src:
+            slots = sorted(slot_src)
+            upd = torch.tensor([-1 - slot_src[j] for j in slots] + slots, dtype=torch.int32).to(x.device)
+            n = len(slots)
+            F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), self.pool.data_ptr(), upd.data_ptr(),
+                                            upd.data_ptr() + 4 * n, n, D, st), "select_rows")
+        return out
+
+    def _push_and_pop_host(self, batch):
         out = []
         for k in range(batch.shape[0]):
             sample = batch.data[k:k + 1]
@@ -275,6 +321,12 @@ class ReplayBuffer:
             else:
                 out.append(sample)
         return torch.cat(out)
+
+    def samples(self):
+        """The stored history as a list of (1, C, H, W) tensors, oldest slot first (tests)."""
+        if self.pool is not None:
+            return [self.pool[i:i + 1] for i in range(self.count)]
+        return list(self.data)
 
 
 class LambdaLR:

@@ -90,8 +90,8 @@ def test_cyclegan_256_bs8_step():
         _net_grad_close(getattr(s_gpu, name), getattr(s_cpu, name), 5e-3, "cyclegan " + name)
         _weights_close(getattr(s_gpu, name), getattr(s_cpu, name), 1, "cyclegan " + name)
     # replay buffers: 8 samples pushed into each, identical index logic
-    assert len(s_gpu.buf_A.data) == len(s_cpu.buf_A.data) == 8
-    assert rel_fro(torch.cat(s_gpu.buf_A.data), torch.cat(s_cpu.buf_A.data)) < 2e-5
+    assert len(s_gpu.buf_A) == len(s_cpu.buf_A.data) == 8
+    assert rel_fro(torch.cat(s_gpu.buf_A.samples()), torch.cat(s_cpu.buf_A.data)) < 2e-5
 
 
 def test_srgan_96_384_bs16_step():

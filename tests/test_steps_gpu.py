@@ -230,8 +230,8 @@ def test_cyclegan_steps():
             for n in ("G_AB", "G_BA", "D_A", "D_B"):
                 _params_close(getattr(s_gpu, n), getattr(s_cpu, n), 2, "cyclegan " + n)
     # replay buffers: same number of samples, same contents up to the trajectory separation
-    assert len(s_gpu.buf_A.data) == len(s_cpu.buf_A.data) == buf
-    assert len(s_gpu.buf_B.data) == len(s_cpu.buf_B.data) == buf
+    assert len(s_gpu.buf_A) == len(s_cpu.buf_A.data) == buf
+    assert len(s_gpu.buf_B) == len(s_cpu.buf_B.data) == buf
 
 
 def test_dcgan_loss_trace_20_steps(golden_dir):
@@ -401,3 +401,24 @@ def test_dragan_steps():
     nb_g = [int(v) for k, v in s_gpu.D.state_dict().items() if k.endswith("num_batches_tracked")]
     nb_c = [int(v) for k, v in s_cpu.D.state_dict().items() if k.endswith("num_batches_tracked")]
     assert nb_g == nb_c == [8, 8, 8]   # 4 discriminator forwards per step (G step, real, fake, penalty)
+
+
+def test_device_replay_buffer_matches_reference_logic():
+    """the device-resident ReplayBuffer (pool tensor + two row-select launches) returns, call after call,
+    exactly the samples the reference's list-based buffer (cyclegan/utils.py:13-33, restated in the oracle) returns under
+    the same python `random` stream - including a slot replaced twice within one call - and holds the same history."""
+    from oracle import reference_models as M
+    from pytorch_gan_amd import steps
+
+    for max_size, B in ((3, 2), (5, 8), (50, 8)):
+        ref, dev = M.ReplayBuffer(max_size), steps.ReplayBuffer(max_size)
+        g = torch.Generator().manual_seed(max_size)
+        for call in range(12):
+            batch = torch.rand(B, 3, 8, 8, generator=g)
+            random.seed(1000 + call)
+            want = ref.push_and_pop(batch)
+            random.seed(1000 + call)
+            got = dev.push_and_pop(batch.to(DEV))
+            assert got.shape == want.shape and torch.equal(got.cpu(), want), (max_size, call)
+        assert len(dev) == len(ref.data)
+        assert torch.equal(torch.cat(dev.samples()).cpu(), torch.cat(ref.data))
