@@ -7,7 +7,8 @@
 //   * the k order inside a 16-deep chunk is permuted (MFMA step s takes k = 4*(lane>>4) + s from every lane's float4),
 //     identically for both operands, so one float4 per lane feeds four MFMA steps;
 //   * two independent accumulators per wave (16x16x4 has a 40-cycle dependent latency against a 32-cycle issue);
-//   * N/16 (N/32) workgroups of 4 waves = 4 row groups: 32-64 workgroups instead of 8.
+//   * N/16 (N/32) workgroups of 4 row groups x up to 4 K-slices (16 waves): 32-64 workgroups instead of 8, and a
+//     4x shorter dependent chain per wave.
 // The NN form reads W in its stored [N][K] layout, so the input gradient needs no transposed weight copy.
 #include "common.h"
 
@@ -15,20 +16,44 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// C[M][N] = act(A[M][K] * W[N][K]^T + bias);  M <= 64, N % 16 == 0, K % 16 == 0
-__global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, float* __restrict__ C, int M,
-                                                        int N, int K, int act, float slope) {
+// The reduction dimension is cut into KS slices handled by KS groups of 4 waves (256 * KS threads): a wave's serial chain
+// of dependent load -> MFMA rounds is what bounds these launches (first version, one slice: 16 rounds of ~0.8 us for
+// K = 1024, 14.5 us per launch), and each round issues all its loads (128 k = 16 float4 per lane) before the MFMAs.
+// The KS partial tiles are combined through LDS in a fixed order (deterministic).
+
+// C[M][N] = act(A[M][K] * W[N][K]^T + bias);  M <= 64, N % 16 == 0, K % (16 * KS) == 0
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ C, int M,
+                                                             int N, int K, int act, float slope) {
+    __shared__ f32x4 part[KS > 1 ? (KS - 1) * 256 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = wave & 3, ks = wave >> 2;
     const int rr = lane & 15, kq = lane >> 4;
-    const int r0 = wave * 16, col0 = blockIdx.x * 16;
-    if (r0 >= M) return;  // wave-uniform; no barriers in this kernel
+    const int r0 = rg * 16, col0 = blockIdx.x * 16;
+    const int Kslice = K / KS;
     const int arow = r0 + rr < M ? r0 + rr : M - 1;
-    const float* ap = A + (size_t)arow * K + kq * 4;
-    const float* wp = W + (size_t)(col0 + rr) * K + kq * 4;
+    const float* ap = A + (size_t)arow * K + ks * Kslice + kq * 4;
+    const float* wp = W + (size_t)(col0 + rr) * K + ks * Kslice + kq * 4;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int k0 = 0;
-    for (; k0 + 64 <= K; k0 += 64) {  // 8 independent 16-byte loads in flight per lane, then 16 MFMAs
+    for (; k0 + 128 <= Kslice; k0 += 128) {  // 16 independent 16-byte loads in flight per lane, then 32 MFMAs
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 * u);
+            b[u] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * u);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every load of the round is issued before its first MFMA
+#pragma unroll
+        for (int u = 0; u < 8; u += 2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = mfma16(a[u][s], b[u][s], acc0);
+                acc1 = mfma16(a[u + 1][s], b[u + 1][s], acc1);
+            }
+    }
+    for (; k0 + 64 <= Kslice; k0 += 64) {
         f32x4 a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -43,51 +68,63 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const float* __restrict_
                 acc1 = mfma16(a[u + 1][s], b[u + 1][s], acc1);
             }
     }
-    for (; k0 < K; k0 += 16) {
+    for (; k0 < Kslice; k0 += 16) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + k0), b0 = *reinterpret_cast<const f32x4*>(wp + k0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc0 = mfma16(a0[s], b0[s], acc0);
+    }
+    f32x4 acc = acc0 + acc1;
+    if (KS > 1) {
+        if (ks > 0) part[(ks - 1) * 256 + rg * 64 + lane] = acc;
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) acc += part[(q - 1) * 256 + rg * 64 + lane];
     }
     const int col = col0 + rr;
     const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = r0 + kq * 4 + r;
-        if (row < M) C[(size_t)row * N + col] = act_apply(acc0[r] + acc1[r] + bv, act, slope);
+        if (row < M) C[(size_t)row * N + col] = act_apply(acc[r] + bv, act, slope);
     }
 }
 
-// C[M][Nc] = A[M][R] * W[R][Nc];  M <= 64, R % 16 == 0, Nc % 32 == 0.  Tile j of a wave holds columns col0 + 2*(lane&15) + j.
-__global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                        float* __restrict__ C, int M, int R, int Nc) {
+// C[M][Nc] = A[M][R] * W[R][Nc];  M <= 64, R % (16 * KS) == 0, Nc % 32 == 0.  Tile j of a wave holds columns col0 + 2*(lane&15) + j.
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                             float* __restrict__ C, int M, int R, int Nc) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ f32x4 part[KS > 1 ? 2 * (KS - 1) * 256 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = wave & 3, ks = wave >> 2;
     const int cc = lane & 15, kq = lane >> 4;
-    const int r0 = wave * 16, col0 = blockIdx.x * 32;
-    if (r0 >= M) return;
+    const int r0 = rg * 16, col0 = blockIdx.x * 32;
+    const int Rslice = R / KS;
     const int arow = r0 + cc < M ? r0 + cc : M - 1;
-    const float* ap = A + (size_t)arow * R + kq * 4;
-    const float* wp = W + (size_t)(kq * 4) * Nc + col0 + 2 * cc;
+    const float* ap = A + (size_t)arow * R + ks * Rslice + kq * 4;
+    const float* wp = W + (size_t)(ks * Rslice + kq * 4) * Nc + col0 + 2 * cc;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int n0 = 0;
-    for (; n0 + 32 <= R; n0 += 32) {  // 2 + 8 independent loads in flight per lane, then 16 MFMAs
-        f32x4 a[2];
-        f32x2 b[2][4];
+    for (; n0 + 64 <= Rslice; n0 += 64) {  // 4 + 16 independent loads in flight per lane, then 32 MFMAs
+        f32x4 a[4];
+        f32x2 b[4][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             a[u] = *reinterpret_cast<const f32x4*>(ap + n0 + 16 * u);
 #pragma unroll
             for (int s = 0; s < 4; ++s) b[u][s] = *reinterpret_cast<const f32x2*>(wp + (size_t)(n0 + 16 * u + s) * Nc);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 acc0 = mfma16(a[u][s], b[u][s][0], acc0);
                 acc1 = mfma16(a[u][s], b[u][s][1], acc1);
             }
     }
-    for (; n0 < R; n0 += 16) {
+    for (; n0 < Rslice; n0 += 16) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(ap + n0);
         f32x2 b[4];
 #pragma unroll
@@ -96,6 +133,19 @@ __global__ __launch_bounds__(256) void skinny_nn_kernel(const float* __restrict_
         for (int s = 0; s < 4; ++s) {
             acc0 = mfma16(a[s], b[s][0], acc0);
             acc1 = mfma16(a[s], b[s][1], acc1);
+        }
+    }
+    if (KS > 1) {
+        if (ks > 0) {
+            part[((ks - 1) * 256 + rg * 64 + lane) * 2] = acc0;
+            part[((ks - 1) * 256 + rg * 64 + lane) * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+            acc0 += part[((q - 1) * 256 + rg * 64 + lane) * 2];
+            acc1 += part[((q - 1) * 256 + rg * 64 + lane) * 2 + 1];
         }
     }
 #pragma unroll
@@ -116,14 +166,26 @@ MIGAN_API int migan_skinny_nn_ok(int M, int R, int Nc) { return M >= 1 && M <= 6
 MIGAN_API int migan_skinny_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int act,
                               float slope, void* stream) {
     if (!migan_skinny_nt_ok(M, N, K)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(skinny_nt_kernel, dim3(N / 16), dim3(256), 0, (hipStream_t)stream, a, w, bias, c, M, N, K, act, slope);
+    hipStream_t st = (hipStream_t)stream;
+    if (K % 64 == 0 && K >= 256)
+        hipLaunchKernelGGL(skinny_nt_kernel<4>, dim3(N / 16), dim3(1024), 0, st, a, w, bias, c, M, N, K, act, slope);
+    else if (K % 32 == 0 && K >= 64)
+        hipLaunchKernelGGL(skinny_nt_kernel<2>, dim3(N / 16), dim3(512), 0, st, a, w, bias, c, M, N, K, act, slope);
+    else
+        hipLaunchKernelGGL(skinny_nt_kernel<1>, dim3(N / 16), dim3(256), 0, st, a, w, bias, c, M, N, K, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 // nn.Linear input gradient for <= 64 rows: dx[M][K] = dy[M][N] w[N][K]  (w in its stored layout; Nc = K, R = N)
 MIGAN_API int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int Nc, void* stream) {
     if (!migan_skinny_nn_ok(M, R, Nc)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(skinny_nn_kernel, dim3(Nc / 32), dim3(256), 0, (hipStream_t)stream, a, w, c, M, R, Nc);
+    hipStream_t st = (hipStream_t)stream;
+    if (R % 64 == 0 && R >= 256)
+        hipLaunchKernelGGL(skinny_nn_kernel<4>, dim3(Nc / 32), dim3(1024), 0, st, a, w, c, M, R, Nc);
+    else if (R % 32 == 0 && R >= 64)
+        hipLaunchKernelGGL(skinny_nn_kernel<2>, dim3(Nc / 32), dim3(512), 0, st, a, w, c, M, R, Nc);
+    else
+        hipLaunchKernelGGL(skinny_nn_kernel<1>, dim3(Nc / 32), dim3(256), 0, st, a, w, c, M, R, Nc);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -509,7 +509,11 @@ def _conv2d_backward_differentiable(ctx, dy, xs, w, y, mask):
 _Conv2d._backward_differentiable = staticmethod(_conv2d_backward_differentiable)
 
 
-_CONV_STATS = __import__("os").environ.get("MIGAN_CONV_STATS", "1") == "1"  # A/B knob
+# Statistics of the following norm layer from the conv epilogue: implemented, parity-tested, and measured SLOWER than the
+# norm layer's own statistics pass (profiles/r02_ab.txt: DCGAN step 3.93 -> 4.12 ms, CycleGAN 173.3 -> 174.5 ms; the
+# two-pass per-tile reduction in the epilogue of every conv workgroup costs more than one streaming pass at 5 TB/s saves),
+# so it is opt-in: MIGAN_CONV_STATS=1.
+_CONV_STATS = __import__("os").environ.get("MIGAN_CONV_STATS", "0") == "1"
 
 
 def _attach_stats(y, buf, chunks, inst, G, P, C):

@@ -334,6 +334,62 @@ def dropout_masks(masks):
         _DropoutRNG.injected = prev
 
 
+class _MaskPlan:
+    """All dropout masks of one training step from ONE launch.  A step (functional.weight_cache_scope: one `steps.*_step`
+    body) asks for the same masks in the same order every iteration - dcgan.py:77-80: four Dropout2d(0.25) layers x three
+    discriminator forwards - so the sequence recorded in one step becomes the plan of the next: its first request draws
+    every mask of the plan into one flat buffer (one Philox launch instead of twelve), later requests are views.  A
+    request that departs from the plan (other shape / p, different p values in one step) falls back to its own launch."""
+
+    plans = {}   # device -> instance
+
+    def __init__(self):
+        self.scope, self.seq, self.plan, self.buf, self.offsets, self.pos = None, [], None, None, None, 0
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls.plans:
+            cls.plans[key] = cls()
+        return cls.plans[key]
+
+    def next(self, shape, p, device):
+        scope = F._CACHE_SCOPE
+        if scope is None or not _BATCH_MASKS:
+            return None
+        shape = tuple(int(v) for v in shape)
+        if scope != self.scope:  # a new step: what the last one asked for is the plan
+            if self.scope is not None and self.seq and len({q for _, q in self.seq}) == 1 \
+                    and all(_numel(sh) % 4 == 0 for sh, _ in self.seq):
+                self.plan = tuple(self.seq)
+            self.scope, self.seq, self.buf, self.pos = scope, [], None, 0
+            if self.plan is not None and self.plan[0] == (shape, p):
+                self.offsets, total = [], 0
+                for sh, _ in self.plan:
+                    self.offsets.append(total)
+                    total += _numel(sh)
+                self.buf = F.rand_mask((total,), p, _DropoutRNG.seed, _DropoutRNG.counter(device), device)
+        self.seq.append((shape, p))
+        if self.buf is None:
+            return None
+        if self.pos < len(self.plan) and self.plan[self.pos] == (shape, p):
+            o = self.offsets[self.pos]
+            self.pos += 1
+            return self.buf[o:o + _numel(shape)].view(shape)
+        self.buf = None  # departed from the plan: individual launches for the rest of this step
+        return None
+
+
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n
+
+
+_BATCH_MASKS = __import__("os").environ.get("MIGAN_BATCH_MASKS", "1") == "1"  # A/B knob
+
+
 def _next_mask(shape, p, device):
     if _DropoutRNG.injected is not None:
         if not _DropoutRNG.injected:
@@ -342,6 +398,9 @@ def _next_mask(shape, p, device):
         m = torch.as_tensor(m, dtype=torch.float32).to(device)
         if tuple(m.shape) != tuple(shape):
             raise ValueError("injected dropout mask has shape %s, expected %s" % (tuple(m.shape), tuple(shape)))
+        return m
+    m = _MaskPlan.get(device).next(shape, float(p), device)
+    if m is not None:
         return m
     return F.rand_mask(shape, p, _DropoutRNG.seed, _DropoutRNG.counter(device), device)
 

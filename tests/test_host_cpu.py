@@ -185,3 +185,43 @@ def test_sequential_fusion_plan(monkeypatch):
     finally:
         nn.set_fusion(True)
     assert [c[0] for c in calls] == ["gather2d", "conv2d"]
+
+
+def test_dropout_mask_plan(monkeypatch):
+    """One Philox launch per training step for all dropout masks: the sequence one step asks for is the plan of the next
+    (views of one flat buffer); departures from the plan fall back to single launches (no kernels run here)."""
+    import pytorch_gan_amd.functional as F
+    import pytorch_gan_amd.nn as nn
+
+    calls = []
+
+    def fake(shape, p, seed, counter, device):
+        calls.append(tuple(shape))
+        return torch.arange(float(nn._numel(shape))).view(shape)
+
+    monkeypatch.setattr(F, "rand_mask", fake)
+    monkeypatch.setattr(nn._DropoutRNG, "counter", classmethod(lambda cls, d: None))
+    monkeypatch.setattr(nn._MaskPlan, "plans", {})
+
+    def step(shapes, p=0.25):
+        with F.weight_cache_scope():
+            return [nn._next_mask(s, p, "cpu") for s in shapes]
+
+    seq = [(4, 16), (4, 32), (4, 16), (4, 32)]
+    step(seq)
+    assert calls == seq                                   # first step: recorded, single launches
+    calls.clear()
+    out = step(seq)
+    assert calls == [(384,)]                              # second step: one launch for all four
+    assert [tuple(o.shape) for o in out] == seq and [o.flatten()[0].item() for o in out] == [0.0, 64.0, 192.0, 256.0]
+    calls.clear()
+    step(seq + [(4, 8)])
+    assert calls == [(384,), (4, 8)]                      # an extra request: its own launch ...
+    calls.clear()
+    step(seq + [(4, 8)])
+    assert calls == [(416,)]                              # ... and part of the next plan
+    calls.clear()
+    step([(4, 32)])
+    assert calls == [(4, 32)]                             # different first request: no batch
+    calls.clear()
+    assert nn._next_mask((4, 16), 0.25, "cpu") is not None and calls == [(4, 16)]   # outside a step: never batched

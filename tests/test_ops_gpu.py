@@ -760,7 +760,8 @@ def test_conv_double_backward(pg, case):
     with F.input_grad_only():   # the hint skips the (discarded) first-order weight-gradient kernels, same result
         xg2 = x.detach().float().to(DEV).requires_grad_(True)
         wg2 = w.detach().float().to(DEV).requires_grad_(True)
-        yg2 = F.conv2d(xg2, wg2, None, stride, (pad,) * 4, F.GATHER_ZERO, act, 0.2, None if mask is None else mask.float().to(DEV))
+        yg2 = F.conv2d(xg2, wg2, b.detach().float().to(DEV), stride, (pad,) * 4, F.GATHER_ZERO, act, 0.2,
+                       None if mask is None else mask.float().to(DEV))
         _gp_like(yg2, xg2, [wg2], 7)
     assert_close(wg2.grad, w.grad.float(), TOL_WGRAD, "d(penalty)/dw with input_grad_only")
 
