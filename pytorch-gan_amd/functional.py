@@ -770,7 +770,7 @@ class _MMNN(Function):
         a, b = ctx.saved_tensors
         da = db = None
         if ctx.needs_input_grad[0]:
-            da = _MMNT.apply(g, b, None)   # [M,N] @ [R,N]^T
+            da = _MMNT.apply(g, b, None, ACT_NONE, 0.0)   # [M,N] @ [R,N]^T
         if ctx.needs_input_grad[1]:
             db = _MMTN.apply(a, g)         # [M,R]^T @ [M,N]
         return da, db
@@ -794,16 +794,20 @@ class _MMNT(Function):
     """a[M,K] @ b[N,K]^T + bias[N]  — nn.Linear forward (conv kernel, 1x1 geometry)."""
 
     @staticmethod
-    def forward(ctx, a, b, bias):
+    def forward(ctx, a, b, bias, act=ACT_NONE, slope=0.0):
         # save the ORIGINAL inputs: their autograd history is what makes the backward differentiable again
-        ctx.save_for_backward(a, b)
         ctx.has_bias = bias is not None
         ctx.bias_param = bias
-        return _mm_nt_raw(canon(a), canon(b), _plain(bias))
+        ctx.act, ctx.slope = act, slope
+        y = _mm_nt_raw(canon(a), canon(b), _plain(bias), act, slope)
+        ctx.save_for_backward(a, b, y if act != ACT_NONE else None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        a, b = ctx.saved_tensors
+        a, b, y = ctx.saved_tensors
+        if ctx.act != ACT_NONE:  # fused activation epilogue (Linear -> LeakyReLU / Tanh / Sigmoid): differentiable act'
+            g = _ActBwd.apply(g, y, ctx.act, ctx.slope)
         da = db = dbias = None
         fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel())
         gc, ac = canon(g), canon(a)  # on the main stream: both branches read them
@@ -827,7 +831,7 @@ class _MMNT(Function):
         if ctx.needs_input_grad[0]:
             da = mm_nn(g, b)
         fork.join()
-        return da, db, dbias
+        return da, db, dbias, None, None
 
 
 def _mm_tn_raw(a, b, out=None, accumulate=0, dbuf=None):
@@ -859,24 +863,25 @@ class _MMTN(Function):
         a, b = ctx.saved_tensors
         da = db = None
         if ctx.needs_input_grad[0]:
-            da = _MMNT.apply(b, g, None)  # [P,N] @ [M,N]^T
+            da = _MMNT.apply(b, g, None, ACT_NONE, 0.0)  # [P,N] @ [M,N]^T
         if ctx.needs_input_grad[1]:
             db = mm_nn(a, g)  # [P,M] @ [M,N]
         return da, db
 
 
 def mm_nt(a, b, bias=None):
-    return _MMNT.apply(a, b, bias)
+    return _MMNT.apply(a, b, bias, ACT_NONE, 0.0)
 
 
 def mm_nn(a, b):
     return _MMNN.apply(a, b)
 
 
-def linear(x, w, b=None):
+def linear(x, w, b=None, act=ACT_NONE, slope=0.0):
+    """`act`: a following LeakyReLU / ReLU / Tanh / Sigmoid in the GEMM epilogue (wgan_gp.py:46-56,73-77)."""
     if x.dim() != 2:
         raise ValueError("linear: expected a 2-D input (the reference only feeds (B, features))")
-    return _MMNT.apply(x, w, b)
+    return _MMNT.apply(x, w, b, int(act), float(slope))
 
 
 # ---------------------------------------------------------------------------------------------- activations

@@ -186,8 +186,8 @@ class ConvTranspose2d(tnn.ConvTranspose2d):
 
 
 class Linear(tnn.Linear):
-    def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+    def forward(self, x, act=F.ACT_NONE, slope=0.0):
+        return F.linear(x, self.weight, self.bias, act, slope)
 
 
 class _BatchNormMixin:
@@ -524,6 +524,13 @@ class Sequential(tnn.Sequential):
                     stats = "batch"
                 x = mods[j].fused_forward(x, pre, gather, act, slope, drop, stats)
                 i = k
+                continue
+            # -- Linear [LeakyReLU | ReLU | Tanh | Sigmoid] ------------------------------------------------
+            if type(m) is Linear and i + 1 < n and _act_of(mods[i + 1]) is not None and type(mods[i + 1]) in _OURS \
+                    and x.dim() == 2:
+                act, slope = _act_of(mods[i + 1])
+                x = m(x, act, slope)
+                i += 2
                 continue
             # -- Norm [LeakyReLU | ReLU] -------------------------------------------------------------------
             if isinstance(m, (BatchNorm2d, BatchNorm1d, InstanceNorm2d)):

@@ -159,6 +159,19 @@ def test_linear_lrelu_double_backward(pg):
     pen_r, ps_r = run("cpu", TF.linear, lambda t: TF.leaky_relu(t, 0.2), lambda g: ((g.norm(2, dim=1) - 1) ** 2).mean())
     pen_g, ps_g = run(DEV, F.linear, lambda t: F.activation(t, F.ACT_LRELU, 0.2),
                       lambda g: F.loss(F.LOSS_MSE, F.rownorm(g), None, 1.0))
+    # the same with LeakyReLU in the GEMM epilogue (what nn.Sequential does with Linear -> LeakyReLU, wgan_gp.py:73-77)
+    fused_first = [True]
+
+    def lin_fused(t, w, b):
+        if fused_first[0]:
+            fused_first[0] = False
+            return F.linear(t, w, b, F.ACT_LRELU, 0.2)
+        return F.linear(t, w, b)
+
+    pen_f, ps_f = run(DEV, lin_fused, lambda t: t, lambda g: F.loss(F.LOSS_MSE, F.rownorm(g), None, 1.0))
+    assert abs(pen_f.item() - pen_g.item()) <= 1e-6 * max(1.0, abs(pen_g.item()))
+    assert_close(ps_f[0].grad, ps_g[0].grad, 1e-6, "dW1 of penalty, fused vs separate activation")
+    assert_close(ps_f[2].grad, ps_g[2].grad, 1e-6, "dW2 of penalty, fused vs separate activation")
     assert abs(pen_r.item() - pen_g.item()) <= 1e-5 * max(1.0, abs(pen_r.item()))
     assert_close(ps_g[0].grad, ps_r[0].grad, TOL_WGRAD, "dW1 of penalty")
     assert_close(ps_g[2].grad, ps_r[2].grad, TOL_WGRAD, "dW2 of penalty")
