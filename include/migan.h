@@ -74,6 +74,12 @@ int migan_skinny_nn_ok(int M, int R, int Nc);
 int migan_skinny_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int act, float slope,
                     void* stream);
 int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int Nc, void* stream);
+/* nn.Linear weight + bias gradient at <= 64 rows: dw[N][K] (+)= dy[M][N]^T x[M][K], db[N] (+)= column sums of dy (db may
+ * be NULL) in ONE launch straight into the caller's buffers (no split-K slabs, no reduction, no column-sum launches).
+ * N % 16 == 0, K % 64 == 0. */
+int migan_skinny_tn_ok(int M, int N, int K);
+int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
+                    int db_accumulate, void* stream);
 
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];

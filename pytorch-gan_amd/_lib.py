@@ -64,6 +64,8 @@ _SIGS = {
     "migan_skinny_nn_ok": (c_int, [c_int] * 3),
     "migan_skinny_nt": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "migan_skinny_nn": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "migan_skinny_tn_ok": (c_int, [c_int] * 3),
+    "migan_skinny_tn": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),

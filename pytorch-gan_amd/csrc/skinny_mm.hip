@@ -158,6 +158,70 @@ __global__ __launch_bounds__(256 * KS) void skinny_nn_kernel(const float* __rest
     }
 }
 
+// dW[N][K] (+)= dy[M][N]^T * x[M][K]  (+ optionally db[N] (+)= column sums of dy);  M <= 64, N % 16 == 0, K % 64 == 0.
+// The nn.Linear weight (and bias) gradient at <= 64 rows: the reduction dimension is the 64 rows, so there is nothing to
+// split - a wave owns a 16 (n) x 64 (k) output tile (4 accumulators; tile t holds columns k0 + 4*(lane&15) + t), walks
+// the rows 4 at a time (one 4-byte dy load + one 16-byte x load per lane per step) and writes - or adds into the
+// optimiser's gradient bucket - directly: no partial slabs, no reduction launch, no separate column-sum launches.
+__global__ __launch_bounds__(256) void skinny_tn_kernel(const float* __restrict__ DY, const float* __restrict__ X,
+                                                        float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                        int K, int accum, int db_accum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ii = lane & 15, kq = lane >> 4;
+    const int ktiles = K / 64;
+    const int wt = blockIdx.x * 4 + wave;          // wave tile index: n-tile major
+    const int nt = wt / ktiles, kt = wt - nt * ktiles;
+    if (nt * 16 >= N) return;
+    const int n0 = nt * 16, k0 = kt * 64;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a[16];
+    f32x4 b[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {   // all 32 loads of the tile in flight together
+        const int m = 4 * s + kq;
+        const int mc = m < M ? m : M - 1;
+        const float av = DY[(size_t)mc * N + n0 + ii];
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(X + (size_t)mc * K + k0 + 4 * ii);
+        a[s] = m < M ? av : 0.f;
+        b[s] = bv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float colsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        colsum += a[s];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(a[s], b[s][t], acc[t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + kq * 4 + r;
+        float* o = dW + (size_t)n * K + k0 + 4 * ii;
+        f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        if (accum) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
+    if (db && kt == 0) {  // wave-uniform: the first k-tile of each n-tile also owns the bias gradient
+        colsum += __shfl_xor(colsum, 16);
+        colsum += __shfl_xor(colsum, 32);
+        if (kq == 0) db[n0 + ii] = db_accum ? db[n0 + ii] + colsum : colsum;
+    }
+}
+MIGAN_API int migan_skinny_tn_ok(int M, int N, int K) { return M >= 1 && M <= 64 && N % 16 == 0 && K % 64 == 0; }
+// nn.Linear weight / bias gradient for <= 64 rows (wgan_gp.py:46-78 at batch 64): dw[N][K] (+)= dy[M][N]^T x[M][K],
+// db[N] (+)= sum_m dy[m][n] (db may be NULL)
+MIGAN_API int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
+                              int db_accumulate, void* stream) {
+    if (!migan_skinny_tn_ok(M, N, K)) return (int)hipErrorInvalidValue;
+    const int wave_tiles = (N / 16) * (K / 64);
+    hipLaunchKernelGGL(skinny_tn_kernel, dim3((wave_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, M, N,
+                       K, accumulate, db_accumulate);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // 1 when the skinny kernels take the shape (else the caller uses migan_conv2d_fwd / migan_transpose_batched + migan_conv2d_fwd)
 MIGAN_API int migan_skinny_nt_ok(int M, int N, int K) { return M >= 1 && M <= 64 && N % 16 == 0 && K % 16 == 0 && K >= 32; }
 MIGAN_API int migan_skinny_nn_ok(int M, int R, int Nc) { return M >= 1 && M <= 64 && R % 16 == 0 && Nc % 32 == 0 && R >= 16; }

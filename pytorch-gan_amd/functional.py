@@ -842,6 +842,10 @@ def _mm_tn_raw(a, b, out=None, accumulate=0, dbuf=None):
         raise ValueError("mm_tn: row counts differ")
     if out is None:
         out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+    if _SKINNY and lib.migan_skinny_tn_ok(P, M, Nn):  # <= 64 rows: one direct launch, weight AND bias gradient
+        check(lib.migan_skinny_tn(a.data_ptr(), b.data_ptr(), out.data_ptr(), dbuf[0].data_ptr() if dbuf else None, P, M, Nn,
+                                  accumulate, dbuf[1] if dbuf else 0, _stream()), "skinny_tn")
+        return out
     nb = lib.migan_conv2d_wgrad_workspace(P, 1, 1, M, 1, 1, Nn)
     ws = _ws(nb, a)
     check(lib.migan_conv2d_wgrad(b.data_ptr(), a.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, P, 1, 1, Nn, 1, 1,

@@ -920,3 +920,17 @@ def test_skinny_linear(pg, dims, monkeypatch):
         assert lib.migan_skinny_nt(xa.data_ptr(), wa.data_ptr(), ba.data_ptr(), out.data_ptr(), B, Nf, K, act, 0.2, st) == 0
         ref = {1: lambda t: TF.leaky_relu(t, 0.2), 3: torch.tanh}[act](y_ref.detach())
         assert_close(out, ref, TOL_FWD, "skinny fused act")
+    # weight + bias gradient in one direct launch (C ABI), overwrite and accumulate-into-bucket modes
+    if lib.migan_skinny_tn_ok(B, Nf, K):
+        st = torch.cuda.current_stream().cuda_stream
+        g_d, x_d = gy.to(DEV), x.detach().to(DEV)
+        dw = torch.full((Nf, K), 7.0, device=DEV)
+        dbv = torch.full((Nf,), 7.0, device=DEV)
+        assert lib.migan_skinny_tn(g_d.data_ptr(), x_d.data_ptr(), dw.data_ptr(), dbv.data_ptr(), B, Nf, K, 0, 0, st) == 0
+        assert_close(dw, w.grad, TOL_WGRAD, "skinny_tn dw")
+        assert_close(dbv, b.grad, TOL_BIAS, "skinny_tn db")
+        assert lib.migan_skinny_tn(g_d.data_ptr(), x_d.data_ptr(), dw.data_ptr(), dbv.data_ptr(), B, Nf, K, 1, 1, st) == 0
+        assert_close(dw, 2 * w.grad, TOL_WGRAD, "skinny_tn dw accumulate")
+        assert_close(dbv, 2 * b.grad, TOL_BIAS, "skinny_tn db accumulate")
+    else:
+        assert Nf % 16 != 0 or K % 64 != 0
