@@ -123,6 +123,32 @@ int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int 
 int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                 void* stream);
 
+/* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
+ * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz
+ * expansion: the kernel column s moves into the GEMM N dimension (Co' = S*Co rounded up to 4 columns, 84 % of a 32-wide
+ * tile for 9x9 instead of 9 %), P[n][h][u][(s,co)] = R x 1 convolution of x, y = act(bias + sum_s P[..][map(w+s-pad_l)][(s,co)]).
+ * Backward: q = transposed expansion of dy; dw = wgrad of the R x 1 conv + fold; dx = dgrad of the R x 1 conv.
+ *   pack:  w_oihw [Co][Ci][R][S] -> wt [Co'][R][Ci] and wd [Ci][R][Co'] (Co' = migan_thin_toeplitz_cols)
+ *   fwd:   ws >= migan_thin_toeplitz_workspace(N, Ho, Wi, Co, S) bytes (the P buffer; q has the same size)
+ *   wgrad: ws >= migan_thin_toeplitz_wgrad_workspace(); accumulate != 0: dw += gradient
+ *   dgrad: ws >= migan_thin_toeplitz_dgrad_workspace() (row-padded intermediate, reflection padding only)
+ * The bias gradient is the column sum of dy (migan_colsum).  gather: 0 zero padding, 1 reflection padding. */
+int migan_thin_toeplitz_ok(int Co, int R, int S, int Ci, int stride, int gather);
+int migan_thin_toeplitz_cols(int Co, int S);
+size_t migan_thin_toeplitz_workspace(int N, int Ho, int Wi, int Co, int S);
+int migan_thin_toeplitz_pack(const float* w_oihw, float* wt, float* wd, int Co, int Ci, int R, int S, void* stream);
+int migan_thin_toeplitz_fwd(const float* x, const float* wt, const float* bias, float* y, float* ws, size_t ws_bytes, int N,
+                            int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather,
+                            int act, float slope, void* stream);
+int migan_thin_toeplitz_expand(const float* dy, float* q, int N, int Ho, int Wo, int Co, int Wi, int S, int pad_l, int gather,
+                               void* stream);
+size_t migan_thin_toeplitz_wgrad_workspace(int N, int Ho, int Wi, int Ci, int Co, int R, int S);
+int migan_thin_toeplitz_wgrad(const float* x, const float* q, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi, int Wi,
+                              int Ci, int Ho, int Co, int R, int S, int pad_t, int gather, int accumulate, void* stream);
+size_t migan_thin_toeplitz_dgrad_workspace(int N, int Hi, int Wi, int Ci, int Ho, int R, int gather);
+int migan_thin_toeplitz_dgrad(const float* q, const float* wd, float* dx, float* ws, size_t ws_bytes, int N, int Hi, int Wi,
+                              int Ci, int Ho, int Co, int R, int S, int pad_t, int gather, void* stream);
+
 /* Phase-collapsed nn.Upsample(scale_factor=2) -> nn.Conv2d(Ci, Co, 3, stride=1, padding=1)
  * (dcgan.py:54-55,58-59; cyclegan/models.py:74-75): the 4 output phases are 2x2 convs of the un-upsampled input with
  * pre-summed weights -> 16/36 of the dense FLOPs in forward, dgrad and wgrad, no upsampled intermediate.

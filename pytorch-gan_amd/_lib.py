@@ -64,6 +64,16 @@ _SIGS = {
     "migan_skinny_nn_ok": (c_int, [c_int] * 3),
     "migan_skinny_nt": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "migan_skinny_nn": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "migan_thin_toeplitz_ok": (c_int, [c_int] * 6),
+    "migan_thin_toeplitz_cols": (c_int, [c_int] * 2),
+    "migan_thin_toeplitz_workspace": (c_size_t, [c_int] * 5),
+    "migan_thin_toeplitz_pack": (c_int, [P, P, P] + [c_int] * 4 + [P]),
+    "migan_thin_toeplitz_fwd": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 13 + [c_float, P]),
+    "migan_thin_toeplitz_expand": (c_int, [P, P] + [c_int] * 8 + [P]),
+    "migan_thin_toeplitz_wgrad_workspace": (c_size_t, [c_int] * 7),
+    "migan_thin_toeplitz_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 11 + [P]),
+    "migan_thin_toeplitz_dgrad_workspace": (c_size_t, [c_int] * 7),
+    "migan_thin_toeplitz_dgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 10 + [P]),
     "migan_skinny_tn_ok": (c_int, [c_int] * 3),
     "migan_skinny_tn": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),

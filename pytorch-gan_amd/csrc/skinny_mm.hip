@@ -7,8 +7,11 @@
 //   * the k order inside a 16-deep chunk is permuted (MFMA step s takes k = 4*(lane>>4) + s from every lane's float4),
 //     identically for both operands, so one float4 per lane feeds four MFMA steps;
 //   * two independent accumulators per wave (16x16x4 has a 40-cycle dependent latency against a 32-cycle issue);
-//   * N/16 (N/32) workgroups of 4 row groups x up to 4 K-slices (16 waves): 32-64 workgroups instead of 8, and a
-//     4x shorter dependent chain per wave.
+//   * a workgroup is ONE 16-row group x one 16 (32)-column tile, its waves are up to 8 K-slices: (N/16) x (M/16)
+//     workgroups = 128-256 for the critic layers, so every CU pulls a share of the (L2-resident) operands - the second
+//     version (4 row groups x 4 slices in one 1024-thread workgroup, N/16 = 32 workgroups) was bound by the L2 -> CU
+//     bandwidth of the 32 CUs it ran on (13.4 us per launch, profiles/r02_wgan_kernel_stats.txt) - and the dependent
+//     chain per wave is one or two load rounds.
 // The NN form reads W in its stored [N][K] layout, so the input gradient needs no transposed weight copy.
 #include "common.h"
 
@@ -16,19 +19,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// The reduction dimension is cut into KS slices handled by KS groups of 4 waves (256 * KS threads): a wave's serial chain
+// The reduction dimension is cut into KS slices, one wave each (64 * KS threads): a wave's serial chain
 // of dependent load -> MFMA rounds is what bounds these launches (first version, one slice: 16 rounds of ~0.8 us for
 // K = 1024, 14.5 us per launch), and each round issues all its loads (128 k = 16 float4 per lane) before the MFMAs.
 // The KS partial tiles are combined through LDS in a fixed order (deterministic).
 
 // C[M][N] = act(A[M][K] * W[N][K]^T + bias);  M <= 64, N % 16 == 0, K % (16 * KS) == 0
 template <int KS>
-__global__ __launch_bounds__(256 * KS) void skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(64 * KS) void skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M,
                                                              int N, int K, int act, float slope) {
-    __shared__ f32x4 part[KS > 1 ? (KS - 1) * 256 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = wave & 3, ks = wave >> 2;
+    __shared__ f32x4 part[KS > 1 ? (KS - 1) * 64 : 1];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int rg = blockIdx.y;
     const int rr = lane & 15, kq = lane >> 4;
     const int r0 = rg * 16, col0 = blockIdx.x * 16;
     const int Kslice = K / KS;
@@ -75,11 +78,11 @@ __global__ __launch_bounds__(256 * KS) void skinny_nt_kernel(const float* __rest
     }
     f32x4 acc = acc0 + acc1;
     if (KS > 1) {
-        if (ks > 0) part[(ks - 1) * 256 + rg * 64 + lane] = acc;
+        if (ks > 0) part[(ks - 1) * 64 + lane] = acc;
         __syncthreads();
         if (ks > 0) return;
 #pragma unroll
-        for (int q = 1; q < KS; ++q) acc += part[(q - 1) * 256 + rg * 64 + lane];
+        for (int q = 1; q < KS; ++q) acc += part[(q - 1) * 64 + lane];
     }
     const int col = col0 + rr;
     const float bv = bias ? bias[col] : 0.f;
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(256 * KS) void skinny_nt_kernel(const float* __rest
 
 // C[M][Nc] = A[M][R] * W[R][Nc];  M <= 64, R % (16 * KS) == 0, Nc % 32 == 0.  Tile j of a wave holds columns col0 + 2*(lane&15) + j.
 template <int KS>
-__global__ __launch_bounds__(256 * KS) void skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(64 * KS) void skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                              float* __restrict__ C, int M, int R, int Nc) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __shared__ f32x4 part[KS > 1 ? 2 * (KS - 1) * 256 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = wave & 3, ks = wave >> 2;
+    __shared__ f32x4 part[KS > 1 ? 2 * (KS - 1) * 64 : 1];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int rg = blockIdx.y;
     const int cc = lane & 15, kq = lane >> 4;
     const int r0 = rg * 16, col0 = blockIdx.x * 32;
     const int Rslice = R / KS;
@@ -137,15 +140,15 @@ __global__ __launch_bounds__(256 * KS) void skinny_nn_kernel(const float* __rest
     }
     if (KS > 1) {
         if (ks > 0) {
-            part[((ks - 1) * 256 + rg * 64 + lane) * 2] = acc0;
-            part[((ks - 1) * 256 + rg * 64 + lane) * 2 + 1] = acc1;
+            part[((ks - 1) * 64 + lane) * 2] = acc0;
+            part[((ks - 1) * 64 + lane) * 2 + 1] = acc1;
         }
         __syncthreads();
         if (ks > 0) return;
 #pragma unroll
         for (int q = 1; q < KS; ++q) {
-            acc0 += part[((q - 1) * 256 + rg * 64 + lane) * 2];
-            acc1 += part[((q - 1) * 256 + rg * 64 + lane) * 2 + 1];
+            acc0 += part[((q - 1) * 64 + lane) * 2];
+            acc1 += part[((q - 1) * 64 + lane) * 2 + 1];
         }
     }
 #pragma unroll
@@ -231,12 +234,15 @@ MIGAN_API int migan_skinny_nt(const float* a, const float* w, const float* bias,
                               float slope, void* stream) {
     if (!migan_skinny_nt_ok(M, N, K)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    if (K % 64 == 0 && K >= 256)
-        hipLaunchKernelGGL(skinny_nt_kernel<4>, dim3(N / 16), dim3(1024), 0, st, a, w, bias, c, M, N, K, act, slope);
+    const dim3 grid(N / 16, (M + 15) / 16);
+    if (K % 128 == 0 && K >= 1024)
+        hipLaunchKernelGGL(skinny_nt_kernel<8>, grid, dim3(512), 0, st, a, w, bias, c, M, N, K, act, slope);
+    else if (K % 64 == 0 && K >= 256)
+        hipLaunchKernelGGL(skinny_nt_kernel<4>, grid, dim3(256), 0, st, a, w, bias, c, M, N, K, act, slope);
     else if (K % 32 == 0 && K >= 64)
-        hipLaunchKernelGGL(skinny_nt_kernel<2>, dim3(N / 16), dim3(512), 0, st, a, w, bias, c, M, N, K, act, slope);
+        hipLaunchKernelGGL(skinny_nt_kernel<2>, grid, dim3(128), 0, st, a, w, bias, c, M, N, K, act, slope);
     else
-        hipLaunchKernelGGL(skinny_nt_kernel<1>, dim3(N / 16), dim3(256), 0, st, a, w, bias, c, M, N, K, act, slope);
+        hipLaunchKernelGGL(skinny_nt_kernel<1>, grid, dim3(64), 0, st, a, w, bias, c, M, N, K, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -244,12 +250,15 @@ MIGAN_API int migan_skinny_nt(const float* a, const float* w, const float* bias,
 MIGAN_API int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int Nc, void* stream) {
     if (!migan_skinny_nn_ok(M, R, Nc)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    if (R % 64 == 0 && R >= 256)
-        hipLaunchKernelGGL(skinny_nn_kernel<4>, dim3(Nc / 32), dim3(1024), 0, st, a, w, c, M, R, Nc);
+    const dim3 grid(Nc / 32, (M + 15) / 16);
+    if (R % 128 == 0 && R >= 512)
+        hipLaunchKernelGGL(skinny_nn_kernel<8>, grid, dim3(512), 0, st, a, w, c, M, R, Nc);
+    else if (R % 64 == 0 && R >= 256)
+        hipLaunchKernelGGL(skinny_nn_kernel<4>, grid, dim3(256), 0, st, a, w, c, M, R, Nc);
     else if (R % 32 == 0 && R >= 64)
-        hipLaunchKernelGGL(skinny_nn_kernel<2>, dim3(Nc / 32), dim3(512), 0, st, a, w, c, M, R, Nc);
+        hipLaunchKernelGGL(skinny_nn_kernel<2>, grid, dim3(128), 0, st, a, w, c, M, R, Nc);
     else
-        hipLaunchKernelGGL(skinny_nn_kernel<1>, dim3(Nc / 32), dim3(256), 0, st, a, w, c, M, R, Nc);
+        hipLaunchKernelGGL(skinny_nn_kernel<1>, grid, dim3(64), 0, st, a, w, c, M, R, Nc);
     HIP_LAUNCH_CHECK();
     return 0;
 }

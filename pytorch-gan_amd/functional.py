@@ -379,7 +379,15 @@ class _Conv2d(Function):
             mask = _plain(mask)
             if tuple(mask.shape) != (N, Co) or not mask.is_contiguous() or Co % 4 != 0:
                 raise ValueError("conv2d: dropout mask must be a contiguous (N, Co) tensor with Co % 4 == 0")
-        if stats_buf is not None:  # per-tile statistics for the norm layer behind this conv, from the conv epilogue
+        toep = (_TOEPLITZ and mask is None and stats_buf is None and Co <= 4 and N * Ho * Wo >= _TOEP_MIN_PIXELS
+                and lib.migan_thin_toeplitz_ok(Co, R, S, Ci, stride, gather) == 1)
+        if toep:  # image-output 7x7 / 9x9 conv: width-Toeplitz expansion onto the MFMA kernels (csrc/thin_toeplitz.hip)
+            wtd = _packed(w_in, w, "toep", lambda: _toep_pack(w))
+            nb = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, S)
+            ws = _ws(nb, xs)
+            check(lib.migan_thin_toeplitz_fwd(xs.data_ptr(), wtd.data_ptr(), _ptr(b), y.data_ptr(), ws.data_ptr(), nb, N, H, W,
+                                              Ci, Ho, Wo, Co, R, S, pt, pl, gather, act, slope, _stream()), "thin_toeplitz_fwd")
+        elif stats_buf is not None:  # per-tile statistics for the norm layer behind this conv, from the conv epilogue
             check(lib.migan_conv2d_fwd_stats(xs.data_ptr(), wp.data_ptr(), _ptr(b), _ptr(mask), y.data_ptr(), N, H, W, Ci,
                                              Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, stats_buf.data_ptr(),
                                              stats_chunks, stats_inst, _stream()), "conv2d_fwd_stats")
@@ -393,6 +401,7 @@ class _Conv2d(Function):
         ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w_in, b_in)
+        ctx.toep = toep
         ctx.save_for_backward(xs, w, y if (act != ACT_NONE or mask is not None) else None, mask)
         return y
 
@@ -407,7 +416,7 @@ class _Conv2d(Function):
         # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
         # (this conv's activation backward, or the norm layer behind the conv) and reduced inside the wgrad launch
         side = None
-        fuse_db = want_db and _COLSUM_FUSE and ctx.needs_input_grad[1]
+        fuse_db = want_db and _COLSUM_FUSE and ctx.needs_input_grad[1] and not ctx.toep
         if mask is not None or act != ACT_NONE:
             if fuse_db:
                 dy, side = _act_bwd_colsum(dy, y, mask, N, Ho * Wo, Co, act, slope)
@@ -421,6 +430,8 @@ class _Conv2d(Function):
         elif fuse_db:
             side = _colsum_side(dy, Co)
         dx = dw = db = None
+        if ctx.toep:
+            return _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db)
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()
@@ -467,6 +478,52 @@ class _Conv2d(Function):
                       "gather2d_bwd")
         fork.join()
         return dx, dw, db, None, None, None, None, None, None, None, None, None
+
+
+# A/B knob: 0 = the direct VALU kernels (thin_conv_kernel / thin_wgrad_tile_kernel) for the 7x7 / 9x9 image-output convs
+_TOEPLITZ = __import__("os").environ.get("MIGAN_TOEPLITZ", "1") == "1"
+_TOEP_MIN_PIXELS = 65536  # below this the two extra streaming launches outweigh the GEMM's gain
+
+
+def _toep_pack(w):
+    """[wt | wd] of migan_thin_toeplitz_pack in one buffer (one packed-weight cache entry)."""
+    Co, Ci, R, S = w.shape
+    n = lib.migan_thin_toeplitz_cols(Co, S) * R * Ci
+    buf = torch.empty(2 * n, device=w.device, dtype=torch.float32)
+    check(lib.migan_thin_toeplitz_pack(w.data_ptr(), buf.data_ptr(), buf.data_ptr() + 4 * n, Co, Ci, R, S, _stream()),
+          "thin_toeplitz_pack")
+    return buf
+
+
+def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
+    """First-order backward of a conv that ran through the width-Toeplitz expansion: dy (already through the activation
+    backward) is expanded once into q, which both the weight and the input gradient GEMMs consume."""
+    N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
+    st = _stream()
+    dx = dw = db = None
+    nq = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, S)
+    q = _ws(nq, xs)
+    check(lib.migan_thin_toeplitz_expand(dy.data_ptr(), q.data_ptr(), N, Ho, Wo, Co, W, S, pl, gather, st), "thin_toeplitz_expand")
+    if ctx.needs_input_grad[1]:
+        slot = _grad_slot(ctx.params[0])
+        dw = torch.empty_like(w) if slot is None else slot
+        nb = lib.migan_thin_toeplitz_wgrad_workspace(N, Ho, W, Ci, Co, R, S)
+        ws = _ws(nb, xs)
+        check(lib.migan_thin_toeplitz_wgrad(xs.data_ptr(), q.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci, Ho, Co, R,
+                                            S, pt, gather, 0 if slot is None else 1, st), "thin_toeplitz_wgrad")
+        if slot is not None:
+            dw = None
+    if want_db:
+        db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
+    if ctx.needs_input_grad[0]:
+        wtd = _packed(ctx.params[0], w, "toep", lambda: _toep_pack(w))
+        n = lib.migan_thin_toeplitz_cols(Co, S) * R * Ci
+        dx = _empty_nhwc((N, Ci, H, W), xs)
+        nb = lib.migan_thin_toeplitz_dgrad_workspace(N, H, W, Ci, Ho, R, gather)
+        ws = _ws(nb, xs)
+        check(lib.migan_thin_toeplitz_dgrad(q.data_ptr(), wtd.data_ptr() + 4 * n, dx.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
+                                            Ho, Co, R, S, pt, gather, st), "thin_toeplitz_dgrad")
+    return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 _REFLECT1 = __import__("os").environ.get("MIGAN_REFLECT1", "1") == "1"  # A/B knob: 0 = padded extent + fold pass

@@ -32,7 +32,10 @@ class _Segmenter:
 
     def begin(self):
         self._g = torch.cuda.CUDAGraph()
-        self._cm = torch.cuda.graph(self._g, pool=self.pool, stream=self.stream)
+        # thread_local: the RCCL watchdog thread polls its work events (hipEventQuery) while this thread records - under the
+        # default "global" mode that query fails with hipErrorStreamCaptureUnsupported and takes the process down
+        # (seen 2 runs in 5 with backend nccl, gpurun r2c/r2e)
+        self._cm = torch.cuda.graph(self._g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local")
         self._cm.__enter__()
 
     def end(self):

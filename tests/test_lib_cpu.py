@@ -136,3 +136,16 @@ def test_replay_buffer_and_lambda_lr_match_oracle():
     assert all(lam(e) == mine.step(e) for e in range(0, 200, 7))
     with pytest.raises(AssertionError):
         steps.LambdaLR(100, 0, 100)
+
+
+def test_thin_toeplitz_applicability():
+    """Pure host functions of the C ABI (no launch): where the width-Toeplitz expansion applies, and its buffer sizes."""
+    from pytorch_gan_amd._lib import lib
+
+    assert lib.migan_thin_toeplitz_ok(3, 3, 3, 64, 1, 0) == 0    # 3x3: 9 of 32 columns - stays on the direct kernel
+    assert lib.migan_thin_toeplitz_ok(3, 7, 7, 64, 2, 0) == 0    # stride 2
+    assert lib.migan_thin_toeplitz_ok(3, 7, 7, 3, 1, 0) == 0     # 3 source channels
+    assert lib.migan_thin_toeplitz_ok(3, 7, 7, 64, 1, 2) == 0    # upsampling gather
+    assert lib.migan_thin_toeplitz_ok(8, 7, 7, 64, 1, 0) == 0
+    assert lib.migan_thin_toeplitz_cols(3, 9) == 28 and lib.migan_thin_toeplitz_cols(3, 7) == 24
+    assert lib.migan_thin_toeplitz_workspace(16, 384, 384, 3, 9) == 16 * 384 * 384 * 28 * 4

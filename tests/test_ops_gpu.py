@@ -89,6 +89,53 @@ def test_conv2d_fwd_bwd(pg, case):
         assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
 
 
+TOEP_CASES = [
+    # N, Ci, H, W, (Co, R, S), pads(t,l,b,r), gather, act, bias
+    (1, 64, 20, 20, (3, 7, 7), (3, 3, 3, 3), 1, 3, True),     # cyclegan/models.py:82 c7s1-3: ReflectionPad2d(3) + 7x7 + Tanh
+    (2, 64, 12, 12, (3, 9, 9), (4, 4, 4, 4), 0, 3, True),     # srgan/models.py:62 conv3 9x9 + Tanh
+    (2, 32, 70, 75, (3, 7, 7), (3, 3, 3, 3), 0, 0, True),     # W > 64: two column tiles per row, ragged second tile
+    (1, 16, 10, 67, (4, 5, 5), (2, 1, 2, 3), 0, 1, False),    # Co = 4, asymmetric zero padding
+    (1, 16, 9, 12, (3, 7, 7), (3, 2, 3, 1), 1, 0, True),      # reflection, asymmetric, Wo < W
+    (2, 24, 11, 13, (3, 3, 7), (1, 3, 1, 3), 1, 2, True),     # R != S, Ci % 32 != 0
+]
+
+
+@pytest.mark.parametrize("case", TOEP_CASES)
+def test_thin_toeplitz_conv(pg, case, monkeypatch):
+    """Thin-N conv through the width-Toeplitz expansion (csrc/thin_toeplitz.hip) against torch CPU and against the direct
+    VALU kernels it replaces; forward, input, weight and bias gradients."""
+    N, Ci, H, W, (Co, R, S), pads, gather, act, bias = case
+    F = pg.functional
+    from pytorch_gan_amd._lib import lib
+
+    assert lib.migan_thin_toeplitz_ok(Co, R, S, Ci, 1, gather) == 1
+    monkeypatch.setattr(F, "_TOEP_MIN_PIXELS", 0)
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, R, S, seed=2, scale=0.2).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True) if bias else None
+    y_ref = TF.conv2d(_ref_gather(x, pads, gather), w, b, 1)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu, 3: torch.tanh}[act](y_ref)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(F, "_TOEPLITZ", on)
+        xg = x.detach().to(DEV).requires_grad_(True)
+        wg = w.detach().to(DEV).requires_grad_(True)
+        bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+        y = F.conv2d(xg, wg, bg, 1, pads, gather, act, 0.2)
+        assert y.grad_fn.toep is on
+        y.backward(gy.to(DEV))
+        assert_close(y, y_ref, TOL_FWD, "toeplitz=%s fwd" % on)
+        assert_close(xg.grad, x.grad, TOL_FWD, "toeplitz=%s dgrad" % on)
+        assert_close(wg.grad, w.grad, TOL_WGRAD, "toeplitz=%s wgrad" % on)
+        if bias:
+            assert_close(bg.grad, b.grad, TOL_BIAS, "toeplitz=%s bias grad" % on)
+        outs[on] = (y.detach(), xg.grad, wg.grad)
+    for a, c, what in zip(outs[True], outs[False], ("fwd", "dgrad", "wgrad")):
+        assert_close(a, c, 4e-6, "toeplitz vs direct " + what)
+
+
 def test_conv2d_nchw_input_is_relaid(pg):
     """An NCHW-contiguous activation (as produced by `.view` in dcgan.py:68) is accepted and re-laid out."""
     F = pg.functional

@@ -115,8 +115,36 @@ def main():
             calls["uwgrad"] = lambda: lib.migan_upconv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
                                                                 wsu.data_ptr(), nbu, N, H, W, Ci, Co, 0, None, 0, None, 0, st)
             dirs += ["ufwd", "udgrad", "uwgrad"]
+        if lib.migan_thin_toeplitz_ok(Co, k, k, Ci, s, gth) == 1:
+            # width-Toeplitz expansion of the thin-N conv (what the product path runs above 64k pixels): tfwd = R x 1 GEMM +
+            # diagonal sum; texpand = dy -> q (shared by both gradients); twgrad / tdgrad consume q
+            cop = lib.migan_thin_toeplitz_cols(Co, k)
+            wtd = torch.empty(2 * cop * k * Ci, device=dev)
+            check(lib.migan_thin_toeplitz_pack(w.data_ptr(), wtd.data_ptr(), wtd.data_ptr() + 4 * cop * k * Ci, Co, Ci, k, k, st),
+                  "tpack")
+            nbp = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, k)
+            pq = torch.empty(nbp // 4, device=dev)
+            nbw = lib.migan_thin_toeplitz_wgrad_workspace(N, Ho, W, Ci, Co, k, k)
+            wsw = torch.empty(max(nbw // 4, 1), device=dev)
+            nbd = lib.migan_thin_toeplitz_dgrad_workspace(N, H, W, Ci, Ho, k, gth)
+            wsd = torch.empty(max(nbd // 4, 1), device=dev)
+            dxt = torch.empty(N * H * W * Ci, device=dev)
+            calls["tfwd"] = lambda: lib.migan_thin_toeplitz_fwd(x.data_ptr(), wtd.data_ptr(), None, y.data_ptr(), pq.data_ptr(),
+                                                                nbp, N, H, W, Ci, Ho, Wo, Co, k, k, p, p, gth, 0, 0.0, st)
+            calls["texpand"] = lambda: lib.migan_thin_toeplitz_expand(dy.data_ptr(), pq.data_ptr(), N, Ho, Wo, Co, W, k, p, gth, st)
+            calls["twgrad"] = lambda: lib.migan_thin_toeplitz_wgrad(x.data_ptr(), pq.data_ptr(), dw.data_ptr(), wsw.data_ptr(), nbw,
+                                                                    N, H, W, Ci, Ho, Co, k, k, p, gth, 0, st)
+            calls["tdgrad"] = lambda: lib.migan_thin_toeplitz_dgrad(pq.data_ptr(), wtd.data_ptr() + 4 * cop * k * Ci, dxt.data_ptr(),
+                                                                    wsd.data_ptr(), nbd, N, H, W, Ci, Ho, Co, k, k, p, gth, st)
+            dirs += ["tfwd", "texpand", "twgrad", "tdgrad"]
         for d in dirs:
-            if d.lstrip("ur") not in only and not (d == "fold" and "dgrad" in only):
+            if d == "texpand":
+                if not ({"wgrad", "dgrad"} & only):
+                    continue
+            elif d[0] == "t" and d[1:] in ("fwd", "wgrad", "dgrad"):
+                if d[1:] not in only:
+                    continue
+            elif d.lstrip("ur") not in only and not (d == "fold" and "dgrad" in only):
                 continue
             fn = calls[d]
             for _ in range(3):
