@@ -454,30 +454,37 @@ class _Conv2d(Function):
                     dw = None
             if want_db:
                 db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
-        st = _stream()
         if ctx.needs_input_grad[0]:
-            wt = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
-            dx = _empty_nhwc((N, Ci, H, W), xs)
-            if gather == GATHER_ZERO:
-                check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
-                                             Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
-            elif (gather == GATHER_REFLECT and _REFLECT1 and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
-                  and H >= 4 and W >= 4 and Co % 4 == 0 and Co >= 8 and Ci > 4):
-                # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
-                check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
-                      "conv2d_dgrad_reflect1")
-            else:
-                if gather == GATHER_REFLECT:
-                    Hp, Wp, gpt, gpl, dpt, dpl = H + pt + pb, W + pl + pr, pt, pl, 0, 0
-                else:
-                    Hp, Wp, gpt, gpl, dpt, dpl = 2 * H, 2 * W, 0, 0, pt, pl
-                tmp = _empty_nhwc((N, Ci, Hp, Wp), xs)
-                check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, tmp.data_ptr(), N, Hp, Wp, Ci, Ho, Wo,
-                                             Co, R, S, stride, dpt, dpl, 0, 0.0, st), "conv2d_dgrad")
-                check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
-                      "gather2d_bwd")
+            dx = _conv2d_dgrad_raw(ctx, dy, xs, w)
         fork.join()
         return dx, dw, db, None, None, None, None, None, None, None, None, None
+
+
+def _conv2d_dgrad_raw(ctx, dy, xs, w):
+    """Input gradient of _Conv2d on the generic kernels (dy already through the activation backward)."""
+    N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
+    st = _stream()
+    wt = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
+    dx = _empty_nhwc((N, Ci, H, W), xs)
+    if gather == GATHER_ZERO:
+        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
+                                     Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
+    elif (gather == GATHER_REFLECT and _REFLECT1 and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
+          and H >= 4 and W >= 4 and Co % 4 == 0 and Co >= 8 and Ci > 4):
+        # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
+        check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
+              "conv2d_dgrad_reflect1")
+    else:
+        if gather == GATHER_REFLECT:
+            Hp, Wp, gpt, gpl, dpt, dpl = H + pt + pb, W + pl + pr, pt, pl, 0, 0
+        else:
+            Hp, Wp, gpt, gpl, dpt, dpl = 2 * H, 2 * W, 0, 0, pt, pl
+        tmp = _empty_nhwc((N, Ci, Hp, Wp), xs)
+        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, tmp.data_ptr(), N, Hp, Wp, Ci, Ho, Wo,
+                                     Co, R, S, stride, dpt, dpl, 0, 0.0, st), "conv2d_dgrad")
+        check(lib.migan_gather2d_bwd(tmp.data_ptr(), dx.data_ptr(), N, H, W, Ci, Hp, Wp, gpt, gpl, gather, st),
+              "gather2d_bwd")
+    return dx
 
 
 # A/B knob: 0 = the direct VALU kernels (thin_conv_kernel / thin_wgrad_tile_kernel) for the 7x7 / 9x9 image-output convs
@@ -515,7 +522,11 @@ def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
             dw = None
     if want_db:
         db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
-    if ctx.needs_input_grad[0]:
+    if ctx.needs_input_grad[0] and gather != GATHER_ZERO:
+        # reflection padding: the expansion's input gradient needs a row-padded intermediate + fold and measured slower
+        # than the direct kernel (c7s1-3: 294 vs 208 us, profiles/r02_conv_microbench.txt)
+        dx = _conv2d_dgrad_raw(ctx, dy, xs, w)
+    elif ctx.needs_input_grad[0]:
         wtd = _packed(ctx.params[0], w, "toep", lambda: _toep_pack(w))
         n = lib.migan_thin_toeplitz_cols(Co, S) * R * Ci
         dx = _empty_nhwc((N, Ci, H, W), xs)
