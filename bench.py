@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: training images/sec of the GAN hot path on MI355X (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W [--workload dcgan|cyclegan|srgan|wgan_gp|pix2pix]
+    python bench.py --gpus N --steps K --warmup W [--workload dcgan|cyclegan|srgan|wgan_gp|pix2pix|esrgan]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Default workload = BASELINE.json configs[1]: DCGAN 64x64, batch 128 per GPU, fp32.  One "step" = one full iteration of
@@ -62,12 +62,34 @@ def dcgan_upconv_flops_per_image():
     return 3 * (2 * (2 * s) ** 2 * 128 * 128 * 9 + 2 * (4 * s) ** 2 * 64 * 128 * 9)
 
 
+def esrgan_flops_per_image(hr=256, blocks=23):
+    """Algorithmic FLOPs per image of one full (post warm-up) ESRGAN step, esrgan.py:101-174 at its defaults (hr 256, 23 RRDB):
+    3 G (fwd + dgrad + wgrad) + 9 D (detached fwd; fwd + dgrad in the G step; 2 x (fwd + dgrad + wgrad)) + 3 VGG19[:35]."""
+    lr = hr // 4
+    conv = lambda hw, ci, co: 2.0 * hw * hw * ci * co * 9  # noqa: E731
+    dense = sum(conv(lr, 64 * i, 64) for i in range(1, 6))
+    g = conv(lr, 3, 64) + 3 * blocks * dense + conv(lr, 64, 64) + conv(lr, 64, 256) + conv(2 * lr, 64, 256) \
+        + conv(hr, 64, 64) + conv(hr, 64, 3)
+    d, c, h = 0.0, 3, hr
+    for co in (64, 128, 256, 512):
+        d += conv(h, c, co) + conv(h // 2, co, co)
+        c, h = co, h // 2
+    d += conv(h, 512, 1)
+    v, c, h = 0.0, 3, hr
+    for stage, (co, n) in enumerate(((64, 2), (128, 2), (256, 4), (512, 4), (512, 4))):
+        for _ in range(n):
+            v += conv(h, c, co)
+            c = co
+        h //= 2
+    return 3 * g + 9 * d + 3 * v
+
+
 # Per-image algorithmic GFLOP of one training step (SURVEY.md §8d) and the share of it inside Upsample+Conv3x3 layers
 # (fwd+dgrad+wgrad; CycleGAN: u128 + u64 = 154.62 GFLOP per G forward at bs 8, 18 G-forward equivalents per step).
 GFLOP_PER_IMG = {"dcgan": dcgan_flops_per_image() / 1e9, "cyclegan": 2097.99, "srgan": 541.43, "pix2pix": 65.52,
-                 "wgan_gp": 0.0219}
+                 "wgan_gp": 0.0219, "esrgan": esrgan_flops_per_image() / 1e9}
 UPCONV_GFLOP_PER_IMG = {"dcgan": dcgan_upconv_flops_per_image() / 1e9, "cyclegan": 18 * 154.62 / 8, "srgan": 0.0,
-                        "pix2pix": 0.0, "wgan_gp": 0.0}
+                        "pix2pix": 0.0, "wgan_gp": 0.0, "esrgan": 0.0}
 WORKLOAD_NAME = {
     "dcgan": "implementations/dcgan 64x64 bs=128 per GPU fp32 (dcgan.py:143-183 full step)",
     "cyclegan": "implementations/cyclegan 256x256 bs=8 per GPU fp32, ResNet-9 G + PatchGAN D (cyclegan.py:159-239 full step)",
@@ -75,6 +97,7 @@ WORKLOAD_NAME = {
     "wgan_gp": "implementations/wgan_gp 32x32 bs=64 per GPU fp32, one critic iteration incl. gradient penalty; generator "
                "update every 5th (wgan_gp.py:146-193)",
     "pix2pix": "implementations/pix2pix 256x256 bs=1 per GPU fp32 (pix2pix.py:123-172 full step)",
+    "esrgan": "implementations/esrgan 64->256 bs=4 per GPU fp32, 23 RRDB, relativistic step after warm-up (esrgan.py:101-174)",
 }
 
 
@@ -182,6 +205,31 @@ def build_srgan(dp, rank, dev, args, nsteps):
     return w
 
 
+def build_esrgan(dp, rank, dev, args, nsteps):
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    G, D, V = models.EsrganGenerator(3, 64, 23), models.EsrganDiscriminator((3, 256, 256)), models.EsrganFeatureExtractor()
+    G, D, V = G.to(dev), D.to(dev), V.to(dev)
+    if dp.world > 1:
+        dp.broadcast_parameters(G, D, V)
+    state = steps.make_esrgan_state(G, D, V, dp=dp, warmup_batches=0)  # timed steps are the full relativistic step
+    batch = args.batch or 4
+    g = torch.Generator().manual_seed(99 + rank)
+    lr = torch.randn(batch, 3, 64, 64, generator=g).to(dev)
+    hr = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
+
+    def run(i):
+        dp.begin_step()
+        out = steps.esrgan_step(state, lr, hr, i)
+        dp.end_step()
+        return out
+
+    w = Workload("esrgan", batch, run, state, None, False, None, (G, D))
+    w.eager = lambda: steps.esrgan_step(state, lr, hr, 0)
+    return w
+
+
 def build_wgan_gp(dp, rank, dev, args, nsteps):
     from pytorch_gan_amd import models, steps
 
@@ -228,7 +276,7 @@ def build_pix2pix(dp, rank, dev, args, nsteps):
 
 
 BUILDERS = {"dcgan": build_dcgan, "cyclegan": build_cyclegan, "srgan": build_srgan, "wgan_gp": build_wgan_gp,
-            "pix2pix": build_pix2pix}
+            "pix2pix": build_pix2pix, "esrgan": build_esrgan}
 
 
 # ------------------------------------------------------------------------------------------------ timing

@@ -229,6 +229,9 @@ int migan_norm_bwd2(const float* x, const float* d, const float* u, const float*
                     float* ws, size_t ws_bytes, void* stream);
 int migan_dragan_interp(const float* x, const float* alpha, const float* noise, const float* var_biased, float* out,
                         size_t n, void* stream);
+/* Relativistic average GAN logits (esrgan.py:137,165-166: pred_fake - pred_real.mean(0, keepdim=True)):
+ * y[n][p] = alpha*a[n][p] + beta*mean_m b[m][p] over [N][P] tensors; a may be NULL (the backward into b). */
+int migan_batch_mean_axpy(const float* a, const float* b, float* y, int N, size_t P, float alpha, float beta, void* stream);
 /* nn.PReLU() single shared slope: srgan/models.py:24,38,57.  ws: migan_reduce_workspace() bytes. */
 size_t migan_reduce_workspace(void);
 int migan_prelu_fwd(const float* x, const float* a, float* y, size_t n, void* stream);

@@ -99,6 +99,7 @@ def load_reference():
     ref.cyclegan_utils = _import_file("ref_cyclegan_utils", os.path.join(IMPL, "cyclegan", "utils.py"))
     ref.pix2pix = _import_file("ref_pix2pix_models", os.path.join(IMPL, "pix2pix", "models.py"))
     ref.srgan = _import_file("ref_srgan_models", os.path.join(IMPL, "srgan", "models.py"))
+    ref.esrgan = _import_file("ref_esrgan_models", os.path.join(IMPL, "esrgan", "models.py"))
 
     def dcgan(img_size, latent_dim=100, channels=1):
         opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
@@ -445,6 +446,57 @@ def pin_srgan(ref):
          d_head=dh)
 
 
+def pin_esrgan(ref):
+    print("esrgan (esrgan/models.py:8-130; VGG19[:35] random-init via stub; loop esrgan.py:101-174)")
+    G_r, G_o = built_equal(lambda: ref.esrgan.GeneratorRRDB(3, filters=64, num_res_blocks=2),
+                           lambda: M.EsrganGenerator(3, filters=64, num_res_blocks=2), "esrgan.G")
+    D_r, D_o = built_equal(lambda: ref.esrgan.Discriminator(input_shape=(3, 32, 32)),
+                           lambda: M.EsrganDiscriminator((3, 32, 32)), "esrgan.D")
+    V_r, V_o = built_equal(lambda: ref.esrgan.FeatureExtractor(), lambda: M.EsrganFeatureExtractor(), "esrgan.VGG")
+    assert D_r.output_shape == D_o.output_shape
+    seed_all(8)
+    lr = torch.randn(2, 3, 8, 8)
+    hr = torch.randn(2, 3, 32, 32)
+    out_g, g_g, _, _ = compare_fwd_bwd(G_r, G_o, [lr], "esrgan.G")
+    out_d, g_d, _, din = compare_fwd_bwd(D_r, D_o, [hr], "esrgan.D", in_grad=True)
+    V_r.eval()
+    V_o.eval()
+    out_v, g_v, _, vin = compare_fwd_bwd(V_r, V_o, [hr], "esrgan.VGG", in_grad=True)
+    gk, gd, gh = grads_digest(g_g)
+    # the loop body (warm-up step, then two full relativistic steps) with the REAL reference modules inside the restatement
+    seed_all(0)
+    Gr = ref.esrgan.GeneratorRRDB(3, filters=64, num_res_blocks=1)
+    Dr = ref.esrgan.Discriminator(input_shape=(3, 32, 32))
+    Vr = ref.esrgan.FeatureExtractor()
+    Vr.eval()
+    adam = lambda p: torch.optim.Adam(p, lr=2e-4, betas=(0.9, 0.999))  # noqa: E731
+    s_ref = SimpleNamespace(G=Gr, D=Dr, V=Vr, opt_G=adam(Gr.parameters()), opt_D=adam(Dr.parameters()),
+                            bce_logits=torch.nn.BCEWithLogitsLoss(), l1_content=torch.nn.L1Loss(), l1_pixel=torch.nn.L1Loss(),
+                            warmup_batches=1, lambda_adv=5e-3, lambda_pixel=1e-2)
+    seed_all(0)
+    s_orc = S.make_esrgan((32, 32), n_res=1)
+    s_orc.warmup_batches = 1
+    check_same_params(s_ref.G, s_orc.G, "esrgan loop G")
+    check_same_params(s_ref.V, s_orc.V, "esrgan loop VGG")
+    seed_all(24)
+    lrs = torch.randn(3, 2, 3, 8, 8)
+    hrs = torch.randn(3, 2, 3, 32, 32)
+    trace = []
+    keys = ("loss_G", "loss_D", "loss_content", "loss_GAN", "loss_pixel")
+    for t in range(3):
+        o_r = S.esrgan_step(s_ref, lrs[t], hrs[t], t)
+        o_o = S.esrgan_step(s_orc, lrs[t], hrs[t], t)
+        assert o_r.keys() == o_o.keys() and (len(o_r) == 1) == (t == 0)
+        for k in o_r:
+            assert torch.equal(o_r[k], o_o[k]), "esrgan loop %s" % k
+        trace.append([o_r[k].item() if k in o_r else float("nan") for k in keys])
+    check_same_params(s_ref.G, s_orc.G, "esrgan loop G after 3 steps")
+    check_same_params(s_ref.D, s_orc.D, "esrgan loop D after 3 steps")
+    save("esrgan_32", meta=meta(), lr=lr, hr=hr, gen=out_g, d_out=out_d, d_in_grad=din[0], vgg_digest=digest(out_v),
+         vgg_head=head(out_v, 64), vgg_in_grad=vin[0], g_keys=gk, g_digest=gd, g_head=gh,
+         loop_lr=lrs, loop_hr=hrs, loop_trace=np.array(trace), loop_keys=np.array(keys))
+
+
 def pin_dropout_semantics():
     print("dropout semantics (nn.Dropout2d / nn.Dropout vs injectable oracle layers)")
     x = torch.rand(3, 5, 4, 4) + 0.5
@@ -555,12 +607,16 @@ def main():
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
     torch.use_deterministic_algorithms(False)
     ref = load_reference()
+    if "--only" in sys.argv:  # regenerate one family's fixture without touching the others
+        globals()["pin_" + sys.argv[sys.argv.index("--only") + 1]](ref)
+        return
     pin_dropout_semantics()
     pin_dcgan(ref)
     pin_mlp(ref)
     pin_dragan(ref)
     pin_cyclegan(ref)
     pin_srgan(ref)
+    pin_esrgan(ref)
     pin_pix2pix(ref)
     pin_steps(ref)
     print("oracle pinned against the reference; fixtures written to", GOLD)

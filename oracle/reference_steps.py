@@ -10,6 +10,7 @@ order, and without the logging / image-saving side effects.  Line references:
   pix2pix_step    implementations/pix2pix/pix2pix.py:123-172
   srgan_step      implementations/srgan/srgan.py:97-145
   dragan_step     implementations/dragan/dragan.py:144-167,176-217   (conv-critic gradient penalty)
+  esrgan_step     implementations/esrgan/esrgan.py:101-174           (relativistic average GAN + warm-up)
 Pinned against the reference by oracle/pin_against_reference.py.
 """
 import itertools
@@ -259,3 +260,51 @@ def srgan_step(s, imgs_lr, imgs_hr):
     s.opt_D.step()
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ esrgan
+def make_esrgan(hr_shape=(64, 64), n_res=23, filters=64):
+    """esrgan.py:60-83: GeneratorRRDB(channels, 64, residual_blocks), Discriminator, VGG19[:35] in eval mode,
+    Adam(lr 2e-4, betas (0.9, 0.999)) - this script's --b1 default is 0.9 (esrgan.py:40)."""
+    G = M.EsrganGenerator(3, filters=filters, num_res_blocks=n_res)
+    D = M.EsrganDiscriminator(input_shape=(3, *hr_shape))
+    V = M.EsrganFeatureExtractor()
+    V.eval()
+    adam = lambda p: torch.optim.Adam(p, lr=2e-4, betas=(0.9, 0.999))  # noqa: E731
+    return SimpleNamespace(G=G, D=D, V=V, opt_G=adam(G.parameters()), opt_D=adam(D.parameters()),
+                           bce_logits=torch.nn.BCEWithLogitsLoss(), l1_content=torch.nn.L1Loss(), l1_pixel=torch.nn.L1Loss(),
+                           warmup_batches=500, lambda_adv=5e-3, lambda_pixel=1e-2)
+
+
+def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
+    """esrgan.py:101-174.  During warm-up (batches_done < warmup_batches) only the pixel loss trains G (esrgan.py:123-131)."""
+    B = imgs_lr.size(0)
+    valid = _f32(np.ones((B, *s.D.output_shape)))
+    fake = _f32(np.zeros((B, *s.D.output_shape)))
+    s.opt_G.zero_grad()
+    gen_hr = s.G(imgs_lr)
+    loss_pixel = s.l1_pixel(gen_hr, imgs_hr)
+    if batches_done < s.warmup_batches:
+        loss_pixel.backward()
+        s.opt_G.step()
+        return {"loss_pixel": loss_pixel.detach()}
+    pred_real = s.D(imgs_hr).detach()
+    pred_fake = s.D(gen_hr)
+    loss_GAN = s.bce_logits(pred_fake - pred_real.mean(0, keepdim=True), valid)
+    gen_features = s.V(gen_hr)
+    real_features = s.V(imgs_hr).detach()
+    loss_content = s.l1_content(gen_features, real_features)
+    loss_G = loss_content + s.lambda_adv * loss_GAN + s.lambda_pixel * loss_pixel
+    loss_G.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    pred_real = s.D(imgs_hr)
+    pred_fake = s.D(gen_hr.detach())
+    loss_real = s.bce_logits(pred_real - pred_fake.mean(0, keepdim=True), valid)
+    loss_fake = s.bce_logits(pred_fake - pred_real.mean(0, keepdim=True), fake)
+    loss_D = (loss_real + loss_fake) / 2
+    loss_D.backward()
+    s.opt_D.step()
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
+            "loss_GAN": loss_GAN.detach(), "loss_pixel": loss_pixel.detach()}
+

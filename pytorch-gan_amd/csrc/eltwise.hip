@@ -133,6 +133,27 @@ MIGAN_API int migan_dragan_interp(const float* x, const float* alpha, const floa
     return 0;
 }
 
+// y[n][p] = alpha * a[n][p] + beta * mean_m b[m][p]   (a may be NULL).  The relativistic average GAN logits of
+// esrgan.py:137,165-166 / relativistic_gan.py:149-158: D(x) - mean over the batch of D(other), forward (alpha 1, beta -1)
+// and the backward into `other` (a NULL, beta -1: the negated batch mean of the upstream gradient, broadcast).
+__global__ void batch_mean_axpy_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int N,
+                                       size_t P, float alpha, float beta) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float m = 0.f;
+    for (int n = 0; n < N; ++n) m += b[(size_t)n * P + p];
+    m = beta * (m / (float)N);
+    for (int n = 0; n < N; ++n) y[(size_t)n * P + p] = (a ? alpha * a[(size_t)n * P + p] : 0.f) + m;
+}
+MIGAN_API int migan_batch_mean_axpy(const float* a, const float* b, float* y, int N, size_t P, float alpha, float beta,
+                                    void* stream) {
+    if (N <= 0 || P == 0) return 0;
+    hipLaunchKernelGGL(batch_mean_axpy_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, N, P,
+                       alpha, beta);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,

@@ -1384,6 +1384,39 @@ def add(a, b):
     return _Axpby.apply(a, b, 1.0, 1.0)
 
 
+class _SubBatchMean(Function):
+    """a - b.mean(0, keepdim=True): the relativistic average logits of esrgan.py:137,165-166 in one launch."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = canon(a), canon(b)
+        if a.shape != b.shape or a.stride() != b.stride():
+            raise ValueError("sub_batch_mean: operands must have the same shape and layout")
+        y = torch.empty_like(a)
+        N = a.shape[0]
+        check(lib.migan_batch_mean_axpy(a.data_ptr(), b.data_ptr(), y.data_ptr(), N, a.numel() // N, 1.0, -1.0, _stream()),
+              "batch_mean_axpy")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        _first_order_only("sub_batch_mean")
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = g
+        if ctx.needs_input_grad[1]:
+            gc = canon(g)
+            gb = torch.empty_like(gc)
+            N = gc.shape[0]
+            check(lib.migan_batch_mean_axpy(None, gc.data_ptr(), gb.data_ptr(), N, gc.numel() // N, 0.0, -1.0, _stream()),
+                  "batch_mean_axpy")
+        return ga, gb
+
+
+def sub_batch_mean(a, b):
+    return _SubBatchMean.apply(a, b)
+
+
 # ---------------------------------------------------------------------------------------------- dropout
 def rand_mask(shape, p, seed, counter, device):
     """Bernoulli(1-p)/(1-p) mask from the device Philox stream (counter: device uint64 tensor or None)."""

@@ -1,6 +1,6 @@
 """The reference networks defined directly on the HIP layer set.
 
-These are the `nn.Module` trees of implementations/{dcgan,wgan_gp,gan,cyclegan,pix2pix,srgan} written against
+These are the `nn.Module` trees of implementations/{dcgan,wgan_gp,gan,cyclegan,pix2pix,srgan,esrgan} written against
 `pytorch_gan_amd.nn` (the drop-in for `torch.nn`), so constructing them needs no `swap()`.  Attribute names,
 layer order and constructor arguments follow the reference files cited per class, hence `state_dict()` keys and
 shapes are interchangeable with the reference's checkpoints (cyclegan.py:73-78,279-284).  A model built from
@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import functional as F
 from . import nn
 
 
@@ -334,3 +335,82 @@ class SrganDiscriminator(nn.Module):
 
     def forward(self, img):
         return self.model(img)
+
+
+# --------------------------------------------------------------------------------------------- esrgan
+def vgg19_features(n):
+    """torchvision vgg19 cfg 'E' features, children [:n]; n = 35 ends at conv5_4 before its ReLU (esrgan/models.py:12)."""
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+    layers, cin = [], 3
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return layers[:n]
+
+
+class EsrganFeatureExtractor(nn.Module):
+    """esrgan/models.py:8-15."""
+
+    def __init__(self):
+        super().__init__()
+        self.vgg19_54 = nn.Sequential(*vgg19_features(35))
+
+    def forward(self, img):
+        return self.vgg19_54(img)
+
+
+class EsrganDenseBlock(nn.Module):
+    """esrgan/models.py:18-45 DenseResidualBlock; `out.mul(res_scale) + x` is one axpby launch here."""
+
+    def __init__(self, filters, res_scale=0.2):
+        super().__init__()
+        self.res_scale = res_scale
+        for i in range(1, 6):
+            specs = [("conv", i * filters, filters, 3, 1, 1)] + ([("lrelu", 0.01)] if i < 5 else [])
+            setattr(self, "b%d" % i, _build(specs))
+
+    def forward(self, x):
+        inputs = x
+        for i in range(1, 6):
+            out = getattr(self, "b%d" % i)(inputs)
+            if i < 5:
+                inputs = torch.cat([inputs, out], 1)
+        return nn._wrap(F.axpby(out, x, self.res_scale, 1.0))
+
+
+class EsrganRRDB(nn.Module):
+    """esrgan/models.py:48-57 ResidualInResidualDenseBlock."""
+
+    def __init__(self, filters, res_scale=0.2):
+        super().__init__()
+        self.res_scale = res_scale
+        self.dense_blocks = nn.Sequential(EsrganDenseBlock(filters), EsrganDenseBlock(filters), EsrganDenseBlock(filters))
+
+    def forward(self, x):
+        return nn._wrap(F.axpby(self.dense_blocks(x), x, self.res_scale, 1.0))
+
+
+class EsrganGenerator(nn.Module):
+    """esrgan/models.py:60-94 GeneratorRRDB (also the network of the inference entry point test_on_image.py:24-37)."""
+
+    def __init__(self, channels=3, filters=64, num_res_blocks=16, num_upsample=2):
+        super().__init__()
+        self.conv1 = nn.Conv2d(channels, filters, kernel_size=3, stride=1, padding=1)
+        self.res_blocks = nn.Sequential(*[EsrganRRDB(filters) for _ in range(num_res_blocks)])
+        self.conv2 = nn.Conv2d(filters, filters, kernel_size=3, stride=1, padding=1)
+        self.upsampling = _build([("conv", filters, filters * 4, 3, 1, 1), ("lrelu", 0.01), ("shuffle", 2)] * num_upsample)
+        self.conv3 = _build([("conv", filters, filters, 3, 1, 1), ("lrelu", 0.01), ("conv", filters, channels, 3, 1, 1)])
+
+    def forward(self, x):
+        out1 = self.conv1(x)
+        out2 = self.conv2(self.res_blocks(out1))
+        return self.conv3(self.upsampling(torch.add(out1, out2)))
+
+
+class EsrganDiscriminator(SrganDiscriminator):
+    """esrgan/models.py:97-130: layer for layer the SRGAN discriminator; its output is used as logits
+    (BCEWithLogitsLoss on relativistic differences, esrgan.py:137,165-166)."""
+

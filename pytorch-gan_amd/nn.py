@@ -83,6 +83,10 @@ def _h_mul(args, kwargs):
     ok = lambda t: isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32  # noqa: E731
     if ok(a) and ok(b) and a.shape == b.shape:
         return _wrap(F.mul(a, b))
+    if ok(b) and isinstance(a, (int, float)):
+        a, b = b, a
+    if ok(a) and isinstance(b, (int, float)) and not isinstance(b, bool):  # out.mul(self.res_scale), esrgan/models.py:45,57
+        return _wrap(F.axpby(a, None, float(b), 0.0))
     return NotImplemented
 
 

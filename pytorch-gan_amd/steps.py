@@ -454,3 +454,62 @@ def srgan_step(s, imgs_lr, imgs_hr):
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ esrgan
+def make_esrgan_state(G, D, V, skip_dead_grads=True, dp=None, warmup_batches=500, lambda_adv=5e-3, lambda_pixel=1e-2):
+    """esrgan.py:60-83; Adam betas (0.9, 0.999) are this script's defaults (esrgan.py:40-41)."""
+    V.eval()
+    adam = dict(lr=2e-4, betas=(0.9, 0.999))
+    return SimpleNamespace(G=G, D=D, V=V, opt_G=Adam(G.parameters(), **adam), opt_D=Adam(D.parameters(), **adam),
+                           bce_logits=gnn.BCEWithLogitsLoss(), l1_content=gnn.L1Loss(), l1_pixel=gnn.L1Loss(),
+                           warmup_batches=warmup_batches, lambda_adv=lambda_adv, lambda_pixel=lambda_pixel,
+                           skip=skip_dead_grads, labels={}, dp=dp or LocalStepper())
+
+
+@_scoped
+def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
+    """esrgan.py:101-174: pixel-loss warm-up, then the relativistic average GAN step.  `pred - other.mean(0, keepdim=True)`
+    is one launch (functional.sub_batch_mean); with skip_dead_grads the D / VGG weight gradients of the G step and the
+    graph of D(real) (detached by the reference, esrgan.py:133) are not computed."""
+    valid, fake = _labels(s, (imgs_lr.size(0), *s.D.output_shape), imgs_lr.device)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen_hr = s.G(imgs_lr)
+    loss_pixel = s.l1_pixel(gen_hr, imgs_hr)
+    if batches_done < s.warmup_batches:
+        loss_pixel.backward()
+        s.dp.step(s.opt_G)
+        return {"loss_pixel": loss_pixel.detach()}
+    with frozen(s.D, s.V, enabled=s.skip):
+        if s.skip:
+            with torch.no_grad():
+                pred_real = s.D(imgs_hr)
+                real_features = s.V(imgs_hr)
+        else:
+            pred_real = s.D(imgs_hr).detach()
+            real_features = s.V(imgs_hr).detach()
+        pred_fake = s.D(gen_hr)
+        loss_GAN = s.bce_logits(F.sub_batch_mean(pred_fake, pred_real), valid)
+        loss_content = s.l1_content(s.V(gen_hr), real_features)
+    loss_G = F.axpby(F.axpby(loss_content, loss_GAN, 1.0, s.lambda_adv), loss_pixel, 1.0, s.lambda_pixel)
+    loss_G.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    pred_real = s.D(imgs_hr)
+    pred_fake = s.D(gen_hr.detach())
+    loss_real = s.bce_logits(F.sub_batch_mean(pred_real, pred_fake), valid)
+    loss_fake = s.bce_logits(F.sub_batch_mean(pred_fake, pred_real), fake)
+    loss_D = half_sum(loss_real, loss_fake)
+    loss_D.backward()
+    s.dp.step(s.opt_D)
+    return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
+            "loss_GAN": loss_GAN.detach(), "loss_pixel": loss_pixel.detach()}
+
+
+@torch.no_grad()
+def esrgan_upscale(G, image):
+    """test_on_image.py:24-37, the reference's only inference entry point: generator.eval(); sr = generator(image) under
+    no_grad (de-normalisation and the PNG write stay with the caller)."""
+    G.eval()
+    return G(image)

@@ -108,7 +108,10 @@ def test_product_models_match_reference_trees():
              (PM.CycleDiscriminator((3, 32, 32)), OM.CycleDiscriminator((3, 32, 32))),
              (PM.Pix2pixDiscriminator(), OM.Pix2pixDiscriminator()), (PM.SrganGenerator(), OM.SrganGenerator()),
              (PM.SrganDiscriminator((3, 32, 32)), OM.SrganDiscriminator((3, 32, 32))),
-             (PM.SrganFeatureExtractor(), OM.SrganFeatureExtractor())]
+             (PM.SrganFeatureExtractor(), OM.SrganFeatureExtractor()),
+             (PM.EsrganGenerator(3, 64, 2), OM.EsrganGenerator(3, 64, 2)),
+             (PM.EsrganDiscriminator((3, 32, 32)), OM.EsrganDiscriminator((3, 32, 32))),
+             (PM.EsrganFeatureExtractor(), OM.EsrganFeatureExtractor())]
     for a, b in pairs:
         sa, sb = a.state_dict(), b.state_dict()
         assert list(sa.keys()) == list(sb.keys())

@@ -211,6 +211,68 @@ def test_srgan(pg, golden_dir):
     assert np.allclose(digest(out_v), gold["vgg_digest"], rtol=1e-4)
 
 
+def test_esrgan(pg, golden_dir):
+    """esrgan/models.py:8-130: RRDB generator (channel concatenations, `out.mul(0.2) + x` through the
+    GanTensor handlers, LeakyReLU(0.01), PixelShuffle), discriminator logits and VGG19[:35], swapped from the oracle
+    restatement; outputs and gradient digests against the fixture recorded from the reference's own modules."""
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "esrgan_32")
+    _seed(0)
+    G = M.EsrganGenerator(3, filters=64, num_res_blocks=2)
+    _seed(0)
+    D = M.EsrganDiscriminator((3, 32, 32))
+    _seed(0)
+    V = M.EsrganFeatureExtractor()
+    V.eval()
+    lr, hr = torch.from_numpy(gold["lr"]), torch.from_numpy(gold["hr"])
+    out_g, _ = _compare(pg, G, [lr], gold=(gold["g_keys"], gold["g_digest"], "esrgan G"))
+    assert_close(out_g, torch.from_numpy(gold["gen"]), TOL_MODEL_FWD, "esrgan G vs golden")
+    out_d, _ = _compare(pg, D, [hr])
+    assert_close(out_d, torch.from_numpy(gold["d_out"]), TOL_MODEL_FWD, "esrgan D vs golden")
+    out_v, _ = _compare(pg, V, [hr])
+    assert np.allclose(digest(out_v), gold["vgg_digest"], rtol=1e-4)
+
+
+def test_product_models_equal_swapped_oracle(pg):
+    """pytorch_gan_amd.models (networks written directly on the HIP layer set) against swap(oracle network) with the same
+    state_dict: same kernels underneath, so outputs agree to rounding (the ESRGAN blocks fuse `out*0.2 + x` into one
+    launch, the swapped reference code runs it as two)."""
+    from oracle import reference_models as OM
+    from pytorch_gan_amd import models as PM
+
+    _seed(3)
+    z = torch.randn(8, 100)
+    img1 = torch.rand(8, 1, 32, 32) * 2 - 1
+    img3 = torch.rand(2, 3, 32, 32) * 2 - 1
+    lr = torch.randn(2, 3, 8, 8)
+    cases = [
+        (PM.DcganGenerator(32), OM.DcganGenerator(32), [z]),
+        (PM.DcganDiscriminator(32), OM.DcganDiscriminator(32), [img1]),
+        (PM.MlpGenerator(), OM.MlpGenerator(), [z]),
+        (PM.MlpCritic(), OM.MlpCritic(), [img1]),
+        (PM.CycleGenerator((3, 32, 32), 2), OM.CycleGenerator((3, 32, 32), 2), [img3]),
+        (PM.CycleDiscriminator((3, 32, 32)), OM.CycleDiscriminator((3, 32, 32)), [img3]),
+        (PM.Pix2pixDiscriminator(), OM.Pix2pixDiscriminator(), [img3, img3.flip(0)]),
+        (PM.SrganGenerator(n_residual_blocks=2), OM.SrganGenerator(n_residual_blocks=2), [lr]),
+        (PM.SrganDiscriminator((3, 32, 32)), OM.SrganDiscriminator((3, 32, 32)), [img3]),
+        (PM.SrganFeatureExtractor(), OM.SrganFeatureExtractor(), [img3]),
+        (PM.EsrganGenerator(3, 64, 2), OM.EsrganGenerator(3, 64, 2), [lr]),
+        (PM.EsrganDiscriminator((3, 32, 32)), OM.EsrganDiscriminator((3, 32, 32)), [img3]),
+        (PM.EsrganFeatureExtractor(), OM.EsrganFeatureExtractor(), [img3]),
+    ]
+    for prod, orc, ins in cases:
+        prod.load_state_dict(orc.state_dict())
+        prod, sw = prod.to(DEV), gpu_copy(orc)
+        prod.eval()   # no dropout draws, running statistics: the comparison is of the layer wiring
+        sw.eval()
+        with torch.no_grad():
+            a = prod(*[t.to(DEV) for t in ins])
+            b = sw(*[t.to(DEV) for t in ins])
+        assert a.shape == b.shape
+        assert_close(a, b, 2e-6, type(prod).__name__ + " product vs swapped oracle")
+
+
 def test_pix2pix(pg, golden_dir):
     from oracle import reference_models as M
 

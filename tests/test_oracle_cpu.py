@@ -155,6 +155,42 @@ def test_srgan_against_reference_fixture(golden_dir):
     assert D.output_shape == (1, 2, 2)
 
 
+def test_esrgan_against_reference_fixture(golden_dir):
+    """esrgan/models.py:8-130 and the loop body esrgan.py:101-174 (one warm-up step, two relativistic steps) against the
+    fixture recorded with the reference's own modules."""
+    gold = load_golden(golden_dir, "esrgan_32")
+    _seed(0)
+    G = M.EsrganGenerator(3, filters=64, num_res_blocks=2)
+    _seed(0)
+    D = M.EsrganDiscriminator((3, 32, 32))
+    _seed(0)
+    V = M.EsrganFeatureExtractor()
+    V.eval()
+    lr, hr = torch.from_numpy(gold["lr"]), torch.from_numpy(gold["hr"])
+    out, grads, _ = _fwd_bwd(G, [lr])
+    _close(out, gold["gen"])
+    _check_grads(grads, gold["g_keys"], gold["g_digest"], tol=2e-2)
+    out, grads, gin = _fwd_bwd(D, [hr])
+    _close(out, gold["d_out"])
+    out, _, gin = _fwd_bwd(V, [hr])
+    assert np.allclose(digest(out), gold["vgg_digest"], rtol=1e-5)
+    _close(gin[0], gold["vgg_in_grad"], 5e-3)
+    assert len(list(V.vgg19_54.children())) == 35 and isinstance(V.vgg19_54[34], torch.nn.Conv2d)  # conv5_4, no ReLU
+    _seed(0)
+    s = S.make_esrgan((32, 32), n_res=1)
+    s.warmup_batches = 1
+    lrs, hrs = torch.from_numpy(gold["loop_lr"]), torch.from_numpy(gold["loop_hr"])
+    keys = [str(k) for k in gold["loop_keys"]]
+    for t in range(3):
+        o = S.esrgan_step(s, lrs[t], hrs[t], t)
+        assert (len(o) == 1) == (t == 0)   # warm-up iteration reports the pixel loss only
+        for j, k in enumerate(keys):
+            if k in o:
+                assert abs(float(o[k]) - float(gold["loop_trace"][t][j])) <= 1e-5 * max(1.0, abs(float(gold["loop_trace"][t][j]))), (t, k)
+            else:
+                assert np.isnan(gold["loop_trace"][t][j])
+
+
 def test_loop_traces_against_reference_fixture(golden_dir):
     """The restated loops, driven from the same seeds, reproduce the traces recorded with the REAL reference
     modules inside the same loop (dcgan 3 steps, wgan_gp 6 critic iterations, cyclegan 3 steps)."""
