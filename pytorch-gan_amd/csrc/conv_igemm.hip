@@ -353,8 +353,12 @@ __device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& s
 // fetched back to back and hit in L2, instead of each tap re-reading the whole pixel range Ci/32 K-tiles later when
 // the per-XCD L2 has long been overwritten (rocprofv3 FETCH_SIZE on the collapsed DCGAN G.conv2 forward: 1056 MB for a
 // 67 MB input with the tap-outer order).  The 4 taps' offsets/masks are kept in registers (set up once).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false, bool STATS = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : 1)) void igemm_pipe_kernel(
+// OCC: waves per SIMD the register allocation is held to (0 = unconstrained).  The 128x64 tile compiles to 98-112
+// registers = 4 workgroups per CU unconstrained and to <= 96 = 5 per CU with OCC 5: GEMMs whose tile count lies just above
+// one 1024-workgroup wave of the chip (SRGAN 64->64 @96x96: 1152 tiles) then run in ONE wave of 1280 slots instead of a
+// full wave plus a 12 % tail at a fraction of the occupancy.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool KTAIL = false, bool TAPIN = false, bool STATS = false, int OCC = 0>
+__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void igemm_pipe_kernel(
     const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw, const float* __restrict__ bias,
     float* __restrict__ C) {
     constexpr int BK = 32, LDK = BK + 1;
@@ -919,8 +923,20 @@ static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const
     bool tapin = tapin_env != 0 && BM * BN < 16384 && g.Ci >= 64;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     const bool ktail = g.Ci % 32 != 0, stats = g.stats != nullptr;
-#define PIPE_LAUNCH(KT_, TI_, ST_) \
-    hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_>), grid, dim3(256), 0, st, g, A, Bw, bias, C)
+    // 128x64: 5 workgroups per CU (see OCC above) except the K-tail + tap-inner variant, which would spill
+    static const int occ5_env = getenv("MIGAN_IGEMM_OCC5") ? atoi(getenv("MIGAN_IGEMM_OCC5")) : 1;  // A/B knob
+    const bool occ5 = BM * BN == 8192 && occ5_env != 0 && !(ktail && tapin);
+#define PIPE_LAUNCH(KT_, TI_, ST_)                                                                                          \
+    do {                                                                                                                    \
+        if constexpr (BM * BN == 8192 && !(KT_ && TI_)) {                                                                   \
+            if (occ5) {                                                                                                     \
+                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_, 5>), grid, dim3(256), 0, st, g, A, Bw,  \
+                                   bias, C);                                                                                \
+                break;                                                                                                      \
+            }                                                                                                               \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_>), grid, dim3(256), 0, st, g, A, Bw, bias, C);   \
+    } while (0)
     if constexpr (BM * BN < 16384) {
         if (tapin) {
             if (ktail) { if (stats) PIPE_LAUNCH(true, true, true); else PIPE_LAUNCH(true, true, false); }
