@@ -396,6 +396,29 @@ class ConvProfiler:
             f = 2.0 * N * 4 * H * W * Co * Ci * 9
             return ("upconv_wgrad[%dx %d->%d @%d]" % (N, Ci, Co, 2 * H), f, f * UP_EXEC)
 
+        # width-Toeplitz thin-N path (csrc/thin_toeplitz.hip) and the reflect-1 input gradient: FLOPs of the layer as the
+        # reference specifies it (the expansion executes S*Co' / (S*Co) of them on the matrix pipe; reported as dense = executed)
+        def toep(kind, off):
+            def describe(a):
+                N, Hi, Wi, Ci, Ho = a[off:off + 5]
+                if kind == "fwd":
+                    Wo, Co, R, S = a[off + 5:off + 9]
+                else:
+                    Co, R, S = a[off + 5:off + 8]
+                    Wo = Wi
+                f = 2.0 * N * Ho * Wo * Co * Ci * R * S
+                return ("toeplitz_%s%s" % (kind, shape(N, Ci, Co, Ho, R, 1)), f, f)
+            return describe
+
+        def reflect1(a):
+            N, H, W, Ci, Co = a[3:8]
+            f = 2.0 * N * H * W * Co * Ci * 9
+            return ("dgrad_reflect1" + shape(N, Ci, Co, H, 3, 1), f, f)
+
+        self._wrap("migan_thin_toeplitz_fwd", toep("fwd", 6))
+        self._wrap("migan_thin_toeplitz_wgrad", toep("wgrad", 5))
+        self._wrap("migan_thin_toeplitz_dgrad", toep("dgrad", 5))
+        self._wrap("migan_conv2d_dgrad_reflect1", reflect1)
         self._wrap("migan_conv2d_fwd", fwd)
         self._wrap("migan_conv2d_dropout_fwd", lambda a: fwd(a[:3] + a[4:]))
         self._wrap("migan_conv2d_dgrad", dgrad)

@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--match", default="")
+    ap.add_argument("--dirs", default="", help="exact direction names (fwd,ufwd,rdgrad,twgrad,...) instead of --only's families")
+    ap.add_argument("--pmc-log", default="", help="write one JSON line per timed (layer, direction) and launch a 1-element "
+                                                  "axpby marker kernel in front of each, so that a rocprofv3 --pmc pass over "
+                                                  "this command can be cut into per-direction segments (tools/pmc_kernels.py)")
     args = ap.parse_args()
     import pytorch_gan_amd  # noqa: F401
     from pytorch_gan_amd._lib import check, lib
@@ -62,6 +66,9 @@ def main():
     dev = "cuda:0"
     st = torch.cuda.current_stream().cuda_stream
     only = set(args.only.split(","))
+    exact = set(args.dirs.split(",")) if args.dirs else None
+    marker = torch.zeros(4, device=dev)
+    plog = open(args.pmc_log, "w") if args.pmc_log else None
     for name, N, Ci, H, W, Co, k, s, p, gth in SHAPES[args.shapes]:
         if args.match and args.match not in name:
             continue
@@ -138,7 +145,10 @@ def main():
                                                                     wsd.data_ptr(), nbd, N, H, W, Ci, Ho, Co, k, k, p, gth, st)
             dirs += ["tfwd", "texpand", "twgrad", "tdgrad"]
         for d in dirs:
-            if d == "texpand":
+            if exact is not None:
+                if d not in exact:
+                    continue
+            elif d == "texpand":
                 if not ({"wgrad", "dgrad"} & only):
                     continue
             elif d[0] == "t" and d[1:] in ("fwd", "wgrad", "dgrad"):
@@ -147,6 +157,15 @@ def main():
             elif d.lstrip("ur") not in only and not (d == "fold" and "dgrad" in only):
                 continue
             fn = calls[d]
+            if plog:
+                import json
+
+                check(lib.migan_axpby(marker.data_ptr(), 1.0, None, 0.0, marker.data_ptr(), 1, st), "marker")
+                up = d in ("ufwd", "udgrad", "uwgrad")
+                plog.write(json.dumps({"layer": name, "dir": d, "calls": 3 + args.iters, "N": N, "Ci": Ci, "H": H, "W": W, "Co": Co,
+                                       "k": k, "stride": s, "gather": gth, "Ho": Ho, "dense_flops": flops,
+                                       "executed_flops": flops * (16.0 / 36.0 if up else 1.0)}) + "\n")
+                plog.flush()
             for _ in range(3):
                 check(fn(), d)
             torch.cuda.synchronize()

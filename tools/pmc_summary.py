@@ -36,8 +36,9 @@ def main():
                                                                           "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM") if c in vals]
             print("   of WAVE_CYCLES: " + ", ".join(parts))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
-            # MFMA_BUSY counts cycles summed over SIMDs... report against 1024 SIMDs x GUI_ACTIVE
-            print("   mfma_busy / (1024 SIMD x GRBM_GUI_ACTIVE) = %.3f" % (vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"])))
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (64 per v_mfma_f32_32x32x2_f32: r01_pmc_igemm128.txt);
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs -> busy fraction of the matrix pipes = BUSY / (1024 * GUI_ACTIVE / 8)
+            print("   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE) = %.3f" % (vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * vals["GRBM_GUI_ACTIVE"])))
         if "SQ_INST_LEVEL_VMEM" in vals and vals.get("SQ_INSTS_VMEM_RD"):
             print("   mean VMEM latency ~ %.0f cycles (INST_LEVEL_VMEM / INSTS_VMEM_RD)" % (vals["SQ_INST_LEVEL_VMEM"] / vals["SQ_INSTS_VMEM_RD"]))
         if "TCC_HIT_sum" in vals:
