@@ -275,6 +275,10 @@ int migan_select_rows(const float* a, const float* b, float* dst, const int* sel
 int migan_transpose_batched(const float* src, float* dst, int B, int R, int Cc, void* stream);
 int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                     void* stream);
+/* Multi-tensor migan_permute4d: one launch for a table of permute copies (all weight packs of a training step).
+ * entries: device array of { const float* src; float* dst; int d[4]; int p[4]; long long n; } (56 bytes each, dst = src viewed
+ * as d[0..3] and permuted by p); blocks: device array of { int entry; int chunk; }, ceil(n / 4096) consecutive chunks per entry. */
+int migan_multi_permute4d(const void* entries, const void* blocks, int nblocks, void* stream);
 
 /* ---- Reductions, losses, gradient penalty, optimiser (csrc/reduce_loss_adam.hip) -----------------------
  * bias gradients: out[c] = sum_p x[p][c]. */

@@ -192,12 +192,12 @@ def weight_cache_scope():
 
 
 def _packed(param, w, kind, make):
-    """`make()` -> packed tensor (or tuple of tensors) of plain weight `w`; cached on the Parameter object `param`."""
-    if not _WEIGHT_CACHE or param is None or _CACHE_SCOPE is None:
+    """`make()` -> packed tensor (or tuple of tensors) of plain weight `w`; cached on the Parameter object `param`.
+    A parameter without an optimiser stamp (the frozen VGG of srgan.py:60-62) is cached for the scope as well: inside a step
+    body nothing but `optim.Adam.step()` writes weights."""
+    if not _WEIGHT_CACHE or param is None or _CACHE_SCOPE is None or not isinstance(param, torch.nn.Parameter):
         return make()
     ep = getattr(param, "_migan_epoch", None)
-    if ep is None:
-        return make()
     stamp = (_CACHE_SCOPE, ep, w._version, w.data_ptr())
     cache = param.__dict__.setdefault("_migan_pack", {})
     hit = cache.get(kind)
@@ -206,6 +206,81 @@ def _packed(param, w, kind, make):
     t = make()
     cache[kind] = (stamp, t)
     return t
+
+
+_BATCH_PACKS = __import__("os").environ.get("MIGAN_BATCH_PACKS", "1") == "1"  # A/B knob: 0 = one permute launch per pack
+
+
+class _PackPlan:
+    """All permute-type weight packs (OHWI for forward / wgrad-of-dgrad, IHWO for dgrad) of one training step from ONE launch.
+    A step body (weight_cache_scope) asks for the same packs every iteration, so the requests recorded in one step are the
+    plan of the next: on its first request the new scope runs migan_multi_permute4d over the whole plan into one arena and
+    pre-fills the per-parameter cache entries `_packed` looks up (same stamps, so a weight whose optimiser steps later in
+    the scope is simply re-packed by its own launch when it is next used).  Device tables and the arena are rebuilt only
+    when the set of (parameter storage, shape, permutation) changes, so a captured hipGraph replays the one launch."""
+
+    plans = {}
+
+    def __init__(self):
+        self.scope, self.seq, self.sig, self.entries, self.tab, self.blk, self.arena, self.nblocks = None, {}, None, [], None, None, None, 0
+
+    @classmethod
+    def get(cls, device):
+        key = str(device)
+        if key not in cls.plans:
+            cls.plans[key] = cls()
+        return cls.plans[key]
+
+    def note(self, param, w, kind, perm):
+        scope = _CACHE_SCOPE
+        if scope is None or not (_BATCH_PACKS and _WEIGHT_CACHE) or not isinstance(param, torch.nn.Parameter) or w.dim() != 4:
+            return
+        if scope != self.scope:
+            prev, self.scope, self.seq = self.seq, scope, {}
+            if prev:
+                self._prefill(prev, w.device)
+        self.seq[(id(param), kind)] = (__import__("weakref").ref(param), kind, tuple(perm))
+
+    def _prefill(self, prev, device):
+        import numpy as np
+
+        live = []
+        for ref, kind, perm in prev.values():
+            p = ref()
+            if p is not None and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
+                live.append((p, kind, perm))
+        if not live:
+            return
+        sig = tuple((p.data_ptr(), tuple(p.shape), kind, perm) for p, kind, perm in live)
+        if sig != self.sig:
+            if torch.cuda.is_current_stream_capturing():  # tables need a host->device copy: not inside a capture
+                return
+            total = sum(p.numel() for p, _, _ in live)
+            self.arena = torch.empty(total, device=device, dtype=torch.float32)
+            ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("d", "<i4", 4), ("p", "<i4", 4), ("n", "<i8")]))
+            blocks, off = [], 0
+            for i, (p, kind, perm) in enumerate(live):
+                n = p.numel()
+                ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, tuple(p.shape), perm, n)
+                blocks += [(i, c) for c in range((n + 4095) // 4096)]
+                off += n
+            self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
+            self.blk = torch.tensor(blocks, dtype=torch.int32).to(device)
+            self.nblocks, self.sig = len(blocks), sig
+        check(lib.migan_multi_permute4d(self.tab.data_ptr(), self.blk.data_ptr(), self.nblocks, _stream()), "multi_permute4d")
+        off = 0
+        for p, kind, perm in live:
+            n = p.numel()
+            view = self.arena[off:off + n].view([p.shape[i] for i in perm])
+            off += n
+            stamp = (_CACHE_SCOPE, getattr(p, "_migan_epoch", None), p._version, p.data_ptr())
+            p.__dict__.setdefault("_migan_pack", {})[kind] = (stamp, view)
+
+
+def _packed_perm(param, w, kind, perm):
+    """Cached `w.permute(perm).contiguous()` (weight pack), produced by the step's one multi-tensor launch when planned."""
+    _PackPlan.get(w.device).note(param, w, kind, perm)
+    return _packed(param, w, kind, lambda: _permute4(w, perm))
 
 
 def set_direct_grad(enabled):
@@ -373,7 +448,7 @@ class _Conv2d(Function):
         Ho, Wo = _conv_out(HL, pt, pb, R, stride), _conv_out(WL, pl, pr, S, stride)
         if Ho <= 0 or Wo <= 0:
             raise ValueError("conv2d: empty output")
-        wp = _packed(w_in, w, "ohwi", lambda: _permute4(w, (0, 2, 3, 1)))
+        wp = _packed_perm(w_in, w, "ohwi", (0, 2, 3, 1))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
         if mask is not None:
             mask = _plain(mask)
@@ -464,7 +539,7 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w):
     """Input gradient of _Conv2d on the generic kernels (dy already through the activation backward)."""
     N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
     st = _stream()
-    wt = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
+    wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
     dx = _empty_nhwc((N, Ci, H, W), xs)
     if gather == GATHER_ZERO:
         check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
@@ -746,7 +821,7 @@ class _ConvTranspose2d(Function):
         Hout = (Hin - 1) * stride - 2 * pad + R
         Wout = (Win - 1) * stride - 2 * pad + S
         # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
-        wp = _packed(ctx.params[0], w, "ihwo", lambda: _permute4(w, (1, 2, 3, 0)))
+        wp = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
         y = _empty_nhwc((N, Cout, Hout, Wout), xs)
         check(lib.migan_conv2d_dgrad(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
                                      Win, Cin, R, S, stride, pad, pad, act, slope, _stream()), "convT_fwd")
@@ -782,7 +857,7 @@ class _ConvTranspose2d(Function):
         st = _stream()
         if ctx.needs_input_grad[0]:
             # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
-            wo = _packed(ctx.params[0], w, "ohwi", lambda: _permute4(w, (0, 2, 3, 1)))
+            wo = _packed_perm(ctx.params[0], w, "ohwi", (0, 2, 3, 1))
             dx = _empty_nhwc((N, Cin, Hin, Win), xs)
             check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
                                        Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")

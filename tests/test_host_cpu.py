@@ -23,13 +23,15 @@ def test_weight_cache_stamps():
         calls.append(1)
         return torch.full((1,), float(len(calls)))
 
-    w = torch.zeros(4)
+    w = torch.nn.Parameter(torch.zeros(4))
     w._migan_epoch = next(optim._EPOCH)
     assert F._packed(w, w, "k", make) is not F._packed(w, w, "k", make)       # outside a scope: never cached
     assert len(calls) == 2
     with F.weight_cache_scope():
         v = torch.zeros(4)
-        assert F._packed(v, v, "k", make) is not F._packed(v, v, "k", make)   # no optimiser epoch -> never cached
+        assert F._packed(v, v, "k", make) is not F._packed(v, v, "k", make)   # not a Parameter (an activation) -> never cached
+        frozen = torch.nn.Parameter(torch.zeros(4))                           # no optimiser (the VGG of srgan.py:60-62):
+        assert F._packed(frozen, frozen, "k", make) is F._packed(frozen, frozen, "k", make)   # cached for this scope only
         n0 = len(calls)
         a = F._packed(w, w, "k", make)
         assert F._packed(w, w, "k", make) is a and len(calls) == n0 + 1       # same stamp -> hit
@@ -39,7 +41,8 @@ def test_weight_cache_stamps():
         w._migan_epoch = next(optim._EPOCH)                                   # an optimiser step
         b = F._packed(w, w, "k", make)
         assert b is not a
-        w.add_(1.0)                                                           # version bump (copy_/load_state_dict)
+        with torch.no_grad():
+            w.add_(1.0)                                                       # version bump (copy_/load_state_dict)
         c = F._packed(w, w, "k", make)
         assert c is not b
         e1, e2 = next(optim._EPOCH), next(optim._EPOCH)

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close
+from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close, rel_fro
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -134,6 +134,69 @@ def test_thin_toeplitz_conv(pg, case, monkeypatch):
         outs[on] = (y.detach(), xg.grad, wg.grad)
     for a, c, what in zip(outs[True], outs[False], ("fwd", "dgrad", "wgrad")):
         assert_close(a, c, 4e-6, "toeplitz vs direct " + what)
+
+
+def test_pack_plan_one_launch_per_step(pg, monkeypatch):
+    """functional._PackPlan: the OHWI / IHWO weight packs a step asked for are produced by ONE migan_multi_permute4d launch
+    at the start of the next step; a weight whose optimiser steps in the middle of a step is re-packed on its next use."""
+    F = pg.functional
+    from pytorch_gan_amd import optim
+    from pytorch_gan_amd._lib import lib
+
+    w1 = torch.nn.Parameter(_leaf(32, 16, 3, 3, seed=1, scale=0.1).to(DEV))
+    w2 = torch.nn.Parameter(_leaf(8, 32, 4, 4, seed=2, scale=0.1).to(DEV))
+    opt = optim.Adam([w1, w2], lr=1e-2)
+    x = _leaf(2, 16, 12, 12, seed=3)
+    singles, multis = [], []
+    orig_p, orig_m = lib.migan_permute4d, lib.migan_multi_permute4d
+    monkeypatch.setattr(lib, "migan_permute4d", lambda *a: (singles.append(1), orig_p(*a))[1])
+    monkeypatch.setattr(lib, "migan_multi_permute4d", lambda *a: (multis.append(a[2]), orig_m(*a))[1])
+
+    def net(xin, a, b):
+        return F.conv2d(F.conv2d(xin, a, None, 1, (1, 1, 1, 1), 0, 1, 0.2), b, None, 2, (1, 1, 1, 1))
+
+    def ref(a, b):
+        xr = x.clone().requires_grad_(True)
+        y = TF.conv2d(TF.leaky_relu(TF.conv2d(xr, a.detach().cpu(), None, 1, 1), 0.2), b.detach().cpu(), None, 2, 1)
+        y.sum().backward()
+        return y.detach(), xr.grad
+
+    def step(update_in_the_middle=False):
+        with F.weight_cache_scope():
+            opt.zero_grad()
+            xg = x.to(DEV).requires_grad_(True)
+            y = net(xg, w1, w2)
+            y.sum().backward()
+            if update_in_the_middle:
+                opt.step()          # new weights, new epoch: the pre-filled packs of this scope are stale now
+                y2 = net(x.to(DEV), w1, w2)
+                return y.detach(), xg.grad, y2.detach()
+            return y.detach(), xg.grad
+
+    y_ref, g_ref = ref(w1, w2)
+    y, g = step()
+    assert len(singles) == 4 and not multis          # first step: nothing planned yet
+    assert_close(y, y_ref, TOL_FWD, "step 1 fwd")
+    singles.clear()
+    y, g = step()
+    assert len(multis) == 1 and not singles          # second step: one launch for all four packs
+    assert_close(y, y_ref, TOL_FWD, "planned packs fwd")
+    assert_close(g, g_ref, TOL_FWD, "planned packs dgrad")
+    singles.clear()
+    multis.clear()
+    y, g, y_after = step(update_in_the_middle=True)
+    assert len(multis) == 1 and len(singles) == 2    # the two OHWI packs are redone after the update
+    y_new, _ = ref(w1, w2)
+    assert_close(y_after, y_new, TOL_FWD, "forward after a mid-step optimiser update")
+    assert rel_fro(y_new, y_ref) > 1e-3                # (the update did change the output)
+    singles.clear()
+    multis.clear()
+    monkeypatch.setattr(F, "_BATCH_PACKS", False)
+    y_off, g_off = step()
+    assert not multis and len(singles) == 4
+    monkeypatch.setattr(F, "_BATCH_PACKS", True)
+    y_on, g_on = step()
+    assert torch.equal(y_on, y_off) and torch.equal(g_on, g_off)
 
 
 def test_conv2d_nchw_input_is_relaid(pg):
