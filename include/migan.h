@@ -276,9 +276,24 @@ int migan_transpose_batched(const float* src, float* dst, int B, int R, int Cc, 
 int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                     void* stream);
 /* Multi-tensor migan_permute4d: one launch for a table of permute copies (all weight packs of a training step).
- * entries: device array of { const float* src; float* dst; int d[4]; int p[4]; long long n; } (56 bytes each, dst = src viewed
- * as d[0..3] and permuted by p); blocks: device array of { int entry; int chunk; }, ceil(n / 4096) consecutive chunks per entry. */
+ * entries: device array of { const float* src; float* dst; unsigned o1, o2, o3, pad; long long s[4]; long long n; } (72 bytes):
+ * dst is contiguous with extents (n/(o1*o2*o3), o1, o2, o3) and dst[i0][i1][i2][i3] = src[i0*s[0] + i1*s[1] + i2*s[2] + i3*s[3]];
+ * blocks: device array of { int entry; int chunk; }, ceil(n / 4096) consecutive chunks per entry. */
 int migan_multi_permute4d(const void* entries, const void* blocks, int nblocks, void* stream);
+
+/* ---- Input pipeline on the device (csrc/image_pipeline.hip) ------------------------------
+ * What the reference's DataLoader workers compute per image between the decoded uint8 bitmap and the fp32 batch
+ * (cyclegan.py:111-117, srgan/datasets.py:16-33, dcgan.py:120-131, pix2pix/datasets.py), bit-exact with Pillow + torchvision.
+ * migan_resample_u8: ONE separable pass of Pillow's 8-bit ImagingResample over a batch [N][Hi][Wi][C] (C <= 4): axis 1 resamples
+ *   the width (run first, as Pillow does), axis 0 the height.  kk [out][ksize] int32 coefficients (22 fractional bits) and
+ *   bounds [out][2] (first source index, tap count) as Pillow's precompute_coeffs + normalize_coeffs_8bpc produce them
+ *   (pytorch_gan_amd.data.pil_resample_coeffs); the pass output is rounded to uint8 like Pillow's intermediate image.
+ * migan_u8_to_f32: crop window (crop_yx [N][2], NULL = corner) + horizontal flip (flip [N], NULL = none) + ToTensor (/255) +
+ *   Normalize ((x - mean[c]) / std[c]; mean/std both NULL = ToTensor only) -> fp32 [N][h][w][C] (nchw 0) or [N][C][h][w]. */
+int migan_resample_u8(const unsigned char* src, unsigned char* dst, const int* kk, const int* bounds, int ksize, int N, int Hi,
+                      int Wi, int C, int out, int axis, void* stream);
+int migan_u8_to_f32(const unsigned char* src, float* dst, const int* crop_yx, const unsigned char* flip, const float* mean,
+                    const float* stdv, int N, int Hi, int Wi, int C, int h, int w, int nchw, void* stream);
 
 /* ---- Reductions, losses, gradient penalty, optimiser (csrc/reduce_loss_adam.hip) -----------------------
  * bias gradients: out[c] = sum_p x[p][c]. */

@@ -74,6 +74,8 @@ _SIGS = {
     "migan_thin_toeplitz_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 11 + [P]),
     "migan_thin_toeplitz_dgrad_workspace": (c_size_t, [c_int] * 7),
     "migan_thin_toeplitz_dgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 10 + [P]),
+    "migan_resample_u8": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
+    "migan_u8_to_f32": (c_int, [P] * 6 + [c_int] * 7 + [P]),
     "migan_multi_permute4d": (c_int, [P, P, c_int, P]),
     "migan_batch_mean_axpy": (c_int, [P, P, P, c_int, c_size_t, c_float, c_float, P]),
     "migan_skinny_tn_ok": (c_int, [c_int] * 3),

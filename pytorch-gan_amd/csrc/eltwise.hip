@@ -631,8 +631,8 @@ MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int 
 struct PackEntry {
     const float* src;
     float* dst;
-    int d[4];  // source dims
-    int p[4];  // destination dim i = source dim p[i]
+    unsigned o1, o2, o3, pad;  // destination extents of dims 1..3 (dim 0 is the quotient)
+    long long s[4];            // source element stride of destination dim 0..3
     long long n;
 };
 struct PackBlock {
@@ -642,23 +642,24 @@ struct PackBlock {
 #define PACK_CHUNK 4096
 __global__ __launch_bounds__(256) void multi_permute4_kernel(const PackEntry* __restrict__ tab, const PackBlock* __restrict__ blk) {
     const PackBlock b = blk[blockIdx.x];
-    const PackEntry e = tab[b.entry];
-    const size_t st[4] = {(size_t)e.d[1] * e.d[2] * e.d[3], (size_t)e.d[2] * e.d[3], (size_t)e.d[3], 1};
-    const unsigned o1 = (unsigned)e.d[e.p[1]], o2 = (unsigned)e.d[e.p[2]], o3 = (unsigned)e.d[e.p[3]];
-    const size_t s0 = st[e.p[0]], s1 = st[e.p[1]], s2 = st[e.p[2]], s3 = st[e.p[3]];
-    const size_t base = (size_t)b.chunk * PACK_CHUNK;
+    const PackEntry* e = tab + b.entry;  // block-uniform: scalar loads, no per-thread copy of the entry
+    const float* __restrict__ src = e->src;
+    float* __restrict__ dst = e->dst;
+    const unsigned o1 = e->o1, o2 = e->o2, o3 = e->o3;
+    const size_t s0 = (size_t)e->s[0], s1 = (size_t)e->s[1], s2 = (size_t)e->s[2], s3 = (size_t)e->s[3];
+    const size_t n = (size_t)e->n, base = (size_t)b.chunk * PACK_CHUNK;
 #pragma unroll 4
     for (int k = threadIdx.x; k < PACK_CHUNK; k += 256) {
         const size_t i = base + k;
-        if (i >= (size_t)e.n) break;
+        if (i >= n) break;
         size_t q, q0;
-        const int i3 = (int)divmod(i, o3, q);
-        const int i2 = (int)divmod(q, o2, q);
-        const int i1 = (int)divmod(q, o1, q0);
-        e.dst[i] = e.src[q0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+        const unsigned i3 = divmod(i, o3, q);
+        const unsigned i2 = divmod(q, o2, q);
+        const unsigned i1 = divmod(q, o1, q0);
+        dst[i] = src[q0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
     }
 }
-// entries / blocks: device arrays of PackEntry {src, dst, d[4], p[4], n} (56 bytes) and PackBlock {entry, chunk}; the caller lists
+// entries / blocks: device arrays of PackEntry (72 bytes, see include/migan.h) and PackBlock {entry, chunk}; the caller lists
 // ceil(n / 4096) blocks per entry
 MIGAN_API int migan_multi_permute4d(const void* entries, const void* blocks, int nblocks, void* stream) {
     if (nblocks <= 0) return 0;

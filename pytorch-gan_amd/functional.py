@@ -209,6 +209,10 @@ def _packed(param, w, kind, make):
 
 
 _BATCH_PACKS = __import__("os").environ.get("MIGAN_BATCH_PACKS", "1") == "1"  # A/B knob: 0 = one permute launch per pack
+# only weights up to this many elements go through the plan: the plan saves launch latency, and a large pack written at the
+# start of the step has left the MALL by the time its conv runs (pix2pix, 54 M parameters: 8.65 -> 9.50 ms with every
+# weight planned, profiles/r02_ab.txt)
+_BATCH_PACKS_MAX = int(__import__("os").environ.get("MIGAN_BATCH_PACKS_MAX", str(1 << 20)))
 
 
 class _PackPlan:
@@ -233,7 +237,8 @@ class _PackPlan:
 
     def note(self, param, w, kind, perm):
         scope = _CACHE_SCOPE
-        if scope is None or not (_BATCH_PACKS and _WEIGHT_CACHE) or not isinstance(param, torch.nn.Parameter) or w.dim() != 4:
+        if scope is None or not (_BATCH_PACKS and _WEIGHT_CACHE) or not isinstance(param, torch.nn.Parameter) or w.dim() != 4 \
+                or w.numel() > _BATCH_PACKS_MAX:
             return
         if scope != self.scope:
             prev, self.scope, self.seq = self.seq, scope, {}
@@ -257,11 +262,14 @@ class _PackPlan:
                 return
             total = sum(p.numel() for p, _, _ in live)
             self.arena = torch.empty(total, device=device, dtype=torch.float32)
-            ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("d", "<i4", 4), ("p", "<i4", 4), ("n", "<i8")]))
+            ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("o", "<u4", 4), ("s", "<i8", 4), ("n", "<i8")]))
             blocks, off = [], 0
             for i, (p, kind, perm) in enumerate(live):
                 n = p.numel()
-                ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, tuple(p.shape), perm, n)
+                d = tuple(p.shape)
+                st = (d[1] * d[2] * d[3], d[2] * d[3], d[3], 1)
+                ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, (d[perm[1]], d[perm[2]], d[perm[3]], 0),
+                          tuple(st[q] for q in perm), n)
                 blocks += [(i, c) for c in range((n + 4095) // 4096)]
                 off += n
             self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
