@@ -33,6 +33,11 @@ struct ConvGeom {
     int ostep, istride;  // output sub-grid step (parity classes), source step per output index
     int gather, ldw, ncls;
     int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
+    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe): swz != 0 -> 1-D grid of 8 * per * ntn * ncls
+    // workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's CONTIGUOUS eighth of the
+    // image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of adjacent rows, the
+    // N-tiles, the 4 phase classes of an up-conv - runs back to back on ONE XCD and finds it in that XCD's L2
+    int swz, mtiles, ntn, per;
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
@@ -374,16 +379,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void
     int* s_dw = s_dh + MAX_TAPS;
 
     const int tid = threadIdx.x;
-    const int cls = blockIdx.z;
+    int cls = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    if (g.swz) {  // block-uniform (scalar) decode, see ConvGeom::swz
+        int k = (int)(blockIdx.x >> 3);
+        cls = k % g.ncls;
+        k /= g.ncls;
+        by = k % g.ntn;
+        k /= g.ntn;
+        bx = (int)(blockIdx.x & 7) * g.per + k;
+        if (bx >= g.mtiles) return;
+    }
+    const int mtiles = g.swz ? g.mtiles : (int)gridDim.x;
     const int Ho = g.Ho[cls], Wo = g.Wo[cls];
     const int M = g.N * Ho * Wo;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int m0 = bx * BM;
+    const int n0 = by * BN;
     if (m0 >= M) {
         // a class smaller than the largest one (odd extents): this tile has no rows; BatchNorm statistics still expect
         // an (empty) entry for the chunk
         if (STATS && g.stats && !g.stats_inst && tid < BN && n0 + tid < g.Co) {
-            float* sp = g.stats + (((size_t)cls * gridDim.x + blockIdx.x) * g.Co + n0 + tid) * 3;
+            float* sp = g.stats + (((size_t)cls * mtiles + bx) * g.Co + n0 + tid) * 3;
             sp[0] = 0.f; sp[1] = 0.f; sp[2] = 0.f;
         }
         return;
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void
                             grp = (size_t)(m0 / hw);
                             chunk = (size_t)cls * (hw / BM) + (size_t)((m0 - (int)grp * hw) / BM);
                         } else {
-                            chunk = (size_t)cls * gridDim.x + blockIdx.x;
+                            chunk = (size_t)cls * mtiles + bx;
                         }
                         float* sp = g.stats + ((grp * g.stats_chunks + chunk) * g.Co + col) * 3;
                         sp[0] = mean_c[j];
@@ -908,15 +923,26 @@ static int launch_db(const ConvGeom& g, const float* A, const float* Bw, const f
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_pipe(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
                        hipStream_t st) {
     int maxM = 0;
-    for (int c = 0; c < g.ncls; ++c) {
-        int m = g.N * g.Ho[c] * g.Wo[c];
+    for (int c = 0; c < g_in.ncls; ++c) {
+        int m = g_in.N * g_in.Ho[c] * g_in.Wo[c];
         if (m > maxM) maxM = m;
     }
     if (maxM == 0) return 0;
-    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    dim3 grid(cdiv(maxM, BM), cdiv(g_in.Co, BN), g_in.ncls);
+    static const int xcd_env = getenv("MIGAN_IGEMM_XCD") ? atoi(getenv("MIGAN_IGEMM_XCD")) : 1;  // A/B knob
+    ConvGeom gs;
+    if (xcd_env != 0) {
+        gs = g_in;
+        gs.swz = 1;
+        gs.mtiles = (int)grid.x;
+        gs.ntn = (int)grid.y;
+        gs.per = (gs.mtiles + 7) >> 3;
+        grid = dim3((unsigned)(8 * gs.per * gs.ntn * gs.ncls), 1, 1);
+    }
+    const ConvGeom& g = xcd_env != 0 ? gs : g_in;
     // tap-inner K order: small tiles, every class exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad) and at
     // least 2 K-tiles per tap
     static const int tapin_env = getenv("MIGAN_IGEMM_TAPIN") ? atoi(getenv("MIGAN_IGEMM_TAPIN")) : 1;

@@ -224,9 +224,11 @@ class _PackPlan:
     when the set of (parameter storage, shape, permutation) changes, so a captured hipGraph replays the one launch."""
 
     plans = {}
+    keep_alive = []   # (table, blocks, arena) of plans a captured hipGraph still launches
 
     def __init__(self):
-        self.scope, self.seq, self.sig, self.entries, self.tab, self.blk, self.arena, self.nblocks = None, {}, None, [], None, None, None, 0
+        self.scope, self.seq, self.sig, self.tab, self.blk, self.arena, self.nblocks = None, {}, None, None, None, None, 0
+        self.captured = False
 
     @classmethod
     def get(cls, device):
@@ -257,9 +259,13 @@ class _PackPlan:
         if not live:
             return
         sig = tuple((p.data_ptr(), tuple(p.shape), kind, perm) for p, kind, perm in live)
+        capturing = torch.cuda.is_current_stream_capturing()
         if sig != self.sig:
-            if torch.cuda.is_current_stream_capturing():  # tables need a host->device copy: not inside a capture
+            if capturing:  # tables need a host->device copy: not inside a capture
                 return
+            if self.captured:  # a live hipGraph replays a launch that reads these tables and writes this arena: never free them
+                _PackPlan.keep_alive.append((self.tab, self.blk, self.arena))
+                self.captured = False
             total = sum(p.numel() for p, _, _ in live)
             self.arena = torch.empty(total, device=device, dtype=torch.float32)
             ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("o", "<u4", 4), ("s", "<i8", 4), ("n", "<i8")]))
@@ -275,6 +281,7 @@ class _PackPlan:
             self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
             self.blk = torch.tensor(blocks, dtype=torch.int32).to(device)
             self.nblocks, self.sig = len(blocks), sig
+        self.captured = self.captured or capturing
         check(lib.migan_multi_permute4d(self.tab.data_ptr(), self.blk.data_ptr(), self.nblocks, _stream()), "multi_permute4d")
         off = 0
         for p, kind, perm in live:

@@ -163,7 +163,7 @@ class CycleResidualBlock(nn.Module):
                              ("rpad", 1), ("conv", c, c, 3, 1, 0), ("in2", c)])
 
     def forward(self, x):
-        return x + self.block(x)
+        return self.block(x, res=x)   # x + self.block(x), the add inside the last InstanceNorm launch
 
 
 class CycleGenerator(nn.Module):
@@ -299,7 +299,7 @@ class SrganResidualBlock(nn.Module):
                                   ("conv", c, c, 3, 1, 1), ("bn2", c, 0.8)])
 
     def forward(self, x):
-        return x + self.conv_block(x)
+        return self.conv_block(x, res=x)   # x + self.conv_block(x), the add inside the last BatchNorm launch
 
 
 class SrganGenerator(nn.Module):

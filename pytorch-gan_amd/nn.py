@@ -496,12 +496,14 @@ class Softmax(tnn.Softmax):
 class Sequential(tnn.Sequential):
     """nn.Sequential with run-time peephole fusion over the unchanged child list."""
 
-    def forward(self, x):
+    def forward(self, x, res=None):
+        """`res` (extension, used by pytorch_gan_amd.models): a residual added to the output - `x + self.block(x)` of
+        cyclegan/models.py:37 and srgan/models.py:31 - inside the final normalisation launch when the chain ends in one."""
         mods = list(self._modules.values())
         if not _FUSE:
             for m in mods:
                 x = m(x)
-            return x
+            return x if res is None else x + res
         i, n = 0, len(mods)
         while i < n:
             m = mods[i]
@@ -543,12 +545,15 @@ class Sequential(tnn.Sequential):
                     (act, slope), k = _act_of(mods[k]), k + 1
                 if isinstance(m, (BatchNorm2d, BatchNorm1d)):
                     m._check_input_dim(x)
-                x = m.fused_forward(x, act, slope)
+                if res is not None and k == n and act == F.ACT_NONE and x.dim() == 4 and res.shape == x.shape:
+                    x, res = m.fused_forward(x, act, slope, res), None   # y = norm(x) + res in the apply kernel
+                else:
+                    x = m.fused_forward(x, act, slope)
                 i = k
                 continue
             x = m(x)
             i += 1
-        return x
+        return x if res is None else x + res
 
 
 _SWAP = {

@@ -271,6 +271,30 @@ def test_product_models_equal_swapped_oracle(pg):
             b = sw(*[t.to(DEV) for t in ins])
         assert a.shape == b.shape
         assert_close(a, b, 2e-6, type(prod).__name__ + " product vs swapped oracle")
+        if any(isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)) for m in prod.modules()):
+            continue
+        # training mode, forward + backward: the product blocks fuse the residual add into the last norm launch
+        # (Sequential(..., res=x)) and the ESRGAN blocks `out*0.2 + x` into one axpby - gradients must not notice
+        prod.train()
+        sw.train()
+        g = torch.Generator().manual_seed(5)
+        wgt = None
+        grads = []
+        for net in (prod, sw):
+            for p_ in net.parameters():
+                p_.grad = None
+            xin = [t.to(DEV).requires_grad_(True) for t in ins]
+            out = net(*xin)
+            if wgt is None:
+                wgt = torch.randn(out.shape, generator=g).to(DEV)
+            (out * wgt).sum().backward()
+            grads.append(([t.grad for t in xin], [p_.grad for p_ in net.parameters()], out.detach()))
+        assert_close(grads[0][2], grads[1][2], 2e-6, type(prod).__name__ + " train-mode forward")
+        for ga, gb in zip(grads[0][0], grads[1][0]):
+            assert_close(ga, gb, 2e-5, type(prod).__name__ + " input gradient, product vs swapped oracle")
+        num = sum(float(((ga - gb).double() ** 2).sum()) for ga, gb in zip(grads[0][1], grads[1][1]) if ga is not None)
+        den = sum(float((gb.double() ** 2).sum()) for gb in grads[1][1] if gb is not None)
+        assert (num / max(den, 1e-300)) ** 0.5 < 2e-5, type(prod).__name__ + " parameter gradients"
 
 
 def test_pix2pix(pg, golden_dir):
