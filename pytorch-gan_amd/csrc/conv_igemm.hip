@@ -33,10 +33,13 @@ struct ConvGeom {
     int ostep, istride;  // output sub-grid step (parity classes), source step per output index
     int gather, ldw, ncls;
     int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
-    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe): swz != 0 -> 1-D grid of 8 * per * ntn * ncls
-    // workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's CONTIGUOUS eighth of the
-    // image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of adjacent rows, the
-    // N-tiles, the 4 phase classes of an up-conv - runs back to back on ONE XCD and finds it in that XCD's L2
+    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe; opt-in, MIGAN_IGEMM_XCD=1): swz != 0 -> 1-D grid of
+    // 8 * per * ntn * ncls workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's
+    // CONTIGUOUS eighth of the image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of
+    // adjacent rows, the N-tiles, the 4 phase classes of an up-conv - runs back to back on ONE XCD and finds it in that
+    // XCD's L2.  Measured (profiles/r02_ab.txt, r02_conv_microbench.txt): no layer gains more than 2 %, the stride-2
+    // parity-class dgrads lose 40 % (classes with 4/2/2/1 taps interleaved on one XCD), whole steps lose 2-3 % - the L2
+    // misses of these kernels are served by the MALL and are not what limits them.  Default off.
     int swz, mtiles, ntn, per;
     int act;
     float slope;
@@ -932,7 +935,7 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g_in.Co, BN), g_in.ncls);
-    static const int xcd_env = getenv("MIGAN_IGEMM_XCD") ? atoi(getenv("MIGAN_IGEMM_XCD")) : 1;  // A/B knob
+    static const int xcd_env = getenv("MIGAN_IGEMM_XCD") ? atoi(getenv("MIGAN_IGEMM_XCD")) : 0;  // opt-in: measured no gain (profiles/r02_ab.txt)
     ConvGeom gs;
     if (xcd_env != 0) {
         gs = g_in;

@@ -35,8 +35,9 @@ def write(name, parts):
         print("wrote", name)
 
 
-def stats(db, top=40, steps=None):
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), db, str(top)] + ([str(steps)] if steps else [])
+def stats(db, top=40, steps=None, by_grid=False):
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), db, str(top)] + ([str(steps)] if steps else []) \
+        + (["--by-grid"] if by_grid else [])
     return subprocess.run(cmd, capture_output=True, text=True).stdout
 
 
@@ -49,7 +50,8 @@ def main():
         ("weight gradient, planner 3 = balance model, default (gpu_run3)", "r2c/mb_wgrad_plan3.txt"),
         ("weight gradient, planner 1 = round-1 rule, for comparison (gpu_run3)", "r2c/mb_wgrad_plan1.txt"),
         ("thin-N image-output convs: direct VALU kernels vs width-Toeplitz expansion (gpu_run6)", "r2f/mb_thin.txt"),
-        ("thin-N after the BM=32 weight-gradient tile (final run)", "final/mb_thin.txt"),
+        ("128x64 tile at 5 workgroups/CU vs 4 (gpu_run8; MIGAN_IGEMM_OCC5)", "r2h/mb_occ5.txt"),
+        ("XCD-contiguous tile order vs plain (gpu_run12; MIGAN_IGEMM_XCD)", "r2l/mb_xcd.txt"),
         ("all shapes, final build (final run)", "final/conv_microbench.txt"),
     ])
     write("r02_ab.txt", [
@@ -69,6 +71,12 @@ def main():
         ("gpu_run5 other workloads", "r2e/others.txt"),
         ("gpu_run6: width-Toeplitz thin-N convs", "r2f/toep_ab.txt"),
         ("gpu_run6 wgan_gp: skinny GEMMs v3 (one row group per workgroup)", "r2f/wgan.txt"),
+        ("gpu_run7 pix2pix: mask plan (box check after a slow-box reading)", "r2g/pix2pix_ab.txt"),
+        ("gpu_run7 esrgan first line", "r2g/esrgan.txt"),
+        ("gpu_run8: igemm 128x64 tile at 5 workgroups/CU", "r2h/occ5_ab.txt"),
+        ("gpu_run10: pack plan, every weight planned", "r2j/packs_ab.txt"),
+        ("gpu_run11: pack plan with the 1M-element cap (default), off, and uncapped", "r2k/packs_ab.txt"),
+        ("gpu_run12: XCD-contiguous tile order of the forward/dgrad implicit GEMM (rejected, opt-in)", "r2l/xcd_ab.txt"),
         ("final run A/B", "final/ab.txt"),
     ])
     write("r02_tile_sweep.txt", [("MIGAN_IGEMM_TILE sweep over the layer shapes (gpu_run2)", "r2b/sweep_variants.txt")])
@@ -89,10 +97,30 @@ def main():
             print("wrote r02_%s_kernel_stats.txt" % tag)
     for f in sorted(glob.glob(os.path.join(G, "final", "*_results.db"))):
         tag = os.path.basename(f).replace("_results.db", "")
-        open(os.path.join(P, "r02_final_%s_kernel_stats.txt" % tag), "w").write(
-            "# rocprofv3 --kernel-trace --stats of the final build's bench.py --workload %s [gpurun_out/final]\n" % tag + stats(f, 45))
+        steps = {"dcgan": 25, "cyclegan": 5, "srgan": 5}.get(tag)   # timed + warm-up steps of tools/round_measure.sh
+        head = ("# rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --steps K --warmup 2 --no-graph (tools/round_measure.sh,\n"
+                "# final build; eager launches so that every kernel is a dispatch), summarised by tools/rocpd_stats.py --by-grid: one row per\n"
+                "# (symbol, launch grid) = per layer shape.  [gpurun_out/final/%s_results.db]\n" % (tag, tag))
+        open(os.path.join(P, "r02_final_%s_kernel_stats.txt" % tag), "w").write(head + stats(f, 60, steps, True))
         print("wrote r02_final_%s_kernel_stats.txt" % tag)
+    b = os.path.join(G, "final", "bench.json")
+    if os.path.exists(b):
+        import json
 
+        line = open(b).readline()
+        json.dump(json.loads(line), open(os.path.join(P, "r02_final_bench.json"), "w"), indent=1)
+        print("wrote r02_final_bench.json")
+    o = os.path.join(G, "final", "bench_others.jsonl")
+    if os.path.exists(o):
+        import json
+
+        json.dump([json.loads(l) for l in open(o) if l.strip()], open(os.path.join(P, "r02_final_bench_others.json"), "w"), indent=1)
+        print("wrote r02_final_bench_others.json")
+    t = os.path.join(G, "final", "pytest_gpu.log")
+    if os.path.exists(t):
+        open(os.path.join(P, "r02_final_pytest_gpu.txt"), "w").write("# python -m pytest tests -m gpu -q on the GPU box (tools/round_measure.sh)\n"
+                                                                      + "".join(open(t).readlines()[-6:]))
+        print("wrote r02_final_pytest_gpu.txt")
 
 if __name__ == "__main__":
     main()
