@@ -179,6 +179,16 @@ int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_
 int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const float* res, int G, int P, int C, int act, float slope,
                      void* stream);
+/* nn.BatchNorm2d -> nn.PReLU() (srgan/models.py:23-24,55-57; single learnable slope prelu_weight[0] on the device) fused:
+ * forward in the apply launch; backward as migan_norm_bwd plus dprelu[0] (+)= sum dy*min(z,0) taken as a third sum of the
+ * statistics pass - the PReLU layer costs no pass of its own over the tensor.  ws: migan_norm_workspace_prelu() bytes. */
+int migan_norm_apply_prelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const float* res, const float* prelu_weight, int G, int P, int C, void* stream);
+size_t migan_norm_workspace_prelu(int G, int P, int C);
+int migan_norm_bwd_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const float* prelu_weight, float* dx, float* dgamma, float* dbeta, float* dprelu,
+                         int G, int P, int C, float* ws, size_t ws_bytes, int accumulate, int dprelu_accumulate, float* csum,
+                         void* stream);
 /* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1.
  * csum (optional): migan_norm_colsum_slabs(G,P,C) x [C] per-block column sums of dx - the bias gradient of the conv in
  * front of the norm layer is reduced from them inside that conv's wgrad launch (migan_conv2d_wgrad db_slabs). */

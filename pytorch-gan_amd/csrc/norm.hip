@@ -39,16 +39,24 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ part, int P, int C, int CTX,
-                                                           int chunk, int nchunks, int act, float slope) {
-    __shared__ float red[2][256 * VW];
+                                                           int chunk, int nchunks, int act, float slope,
+                                                           const float* __restrict__ slope_ptr) {
+    // slope_ptr (backward only): nn.PReLU()'s single learnable slope (srgan/models.py:24,57) fused behind the norm -
+    // LeakyReLU with the slope read from the device, plus a third sum per (g, chunk, c): sum dy * min(z, 0) = d(loss)/d(slope)
+    __shared__ float red[BWD ? 3 : 2][256 * VW];
+    const bool prelu = BWD && slope_ptr != nullptr;
+    if (prelu) {
+        slope = *slope_ptr;
+        act = ACT_LRELU;
+    }
     const int tid = threadIdx.x;
     const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
     const int g = blockIdx.z, ck = blockIdx.y;
     const int c = (blockIdx.x * CTX + tx) * VW;
     const bool cok = c < C;
-    float s0[VW], s1[VW];
+    float s0[VW], s1[VW], s2[VW];
 #pragma unroll
-    for (int v = 0; v < VW; ++v) s0[v] = s1[v] = 0.f;
+    for (int v = 0; v < VW; ++v) s0[v] = s1[v] = s2[v] = 0.f;
     float mu[VW], is[VW], ga[VW], be[VW];
     if (BWD && cok) {
 #pragma unroll
@@ -89,6 +97,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                     float xh = (xv[v] - mu[v]) * is[v];
                     float z = xh * ga[v] + be[v];
                     float d = dv[v];
+                    if (prelu) s2[v] += z > 0.f ? 0.f : d * z;
                     if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
                     else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
                     s0[v] += d;
@@ -105,20 +114,22 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     for (int v = 0; v < VW; ++v) {
         red[0][tid * VW + v] = s0[v];
         red[1][tid * VW + v] = s1[v];
+        if (BWD) red[2][tid * VW + v] = s2[v];
     }
     __syncthreads();
     if (ty == 0 && cok) {
 #pragma unroll
         for (int v = 0; v < VW; ++v) {
-            float a = 0.f, b = 0.f;
+            float a = 0.f, b = 0.f, c2 = 0.f;
             for (int y = 0; y < TY; ++y) {
                 a += red[0][(y * CTX + tx) * VW + v];
                 b += red[1][(y * CTX + tx) * VW + v];
+                if (BWD) c2 += red[2][(y * CTX + tx) * VW + v];
             }
             size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 3;
             part[o] = a;
             part[o + 1] = b;
-            part[o + 2] = shift[v];
+            part[o + 2] = BWD ? c2 : shift[v];
         }
     }
 }
@@ -168,28 +179,45 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
 __global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ sums, float* dgamma,
                                                                 float* dbeta, int G, int C, int nchunks,
-                                                                int accum) {
+                                                                int accum, float* __restrict__ dslope_gc) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= G * C) return;
     const int g = i / C, c = i - g * C;
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, s = 0.0;
     for (int k = lane; k < nchunks; k += 64) {
         size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
         a += (double)part[o];
         b += (double)part[o + 1];
+        if (dslope_gc) s += (double)part[o + 2];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
         b += __shfl_xor(b, off);
+        if (dslope_gc) s += __shfl_xor(s, off);
     }
     if (lane != 0) return;
+    if (dslope_gc) dslope_gc[i] = (float)s;  // per (g, c) PReLU-slope partials, summed by sum_small_kernel
     sums[(size_t)i * 2] = (float)a;
     sums[(size_t)i * 2 + 1] = (float)b;
     if (G == 1) {
         if (dbeta) dbeta[c] = accum ? dbeta[c] + (float)a : (float)a;
         if (dgamma) dgamma[c] = accum ? dgamma[c] + (float)b : (float)b;
     }
+}
+
+// out[0] (+)= sum of n floats, one block, fixed order (the PReLU slope gradient from its per-(g,c) partials)
+__global__ __launch_bounds__(256) void sum_small_kernel(const float* __restrict__ v, int n, float* __restrict__ out, int accum) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)v[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s_ = 128; s_ > 0; s_ >>= 1) {
+        if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = accum ? out[0] + (float)red[0] : (float)red[0];
 }
 
 // apply: y = act((x-mean)*invstd*gamma+beta) [+ res]
@@ -203,7 +231,12 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ res, int P, int C, int CTX,
-                                                         int chunk, int act, float slope) {
+                                                         int chunk, int act, float slope,
+                                                         const float* __restrict__ slope_ptr) {
+    if (slope_ptr) {  // fused nn.PReLU(): LeakyReLU with the learnable slope read from the device
+        slope = *slope_ptr;
+        act = ACT_LRELU;
+    }
     const int tid = threadIdx.x;
     const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
     const int g = blockIdx.z;
@@ -243,8 +276,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, int P, int C, int CTX, int chunk, int act,
-    float slope, float invP, float* __restrict__ csum) {
+    float slope, float invP, float* __restrict__ csum, const float* __restrict__ slope_ptr) {
     __shared__ float red[256 * VW];
+    if (slope_ptr) {
+        slope = *slope_ptr;
+        act = ACT_LRELU;
+    }
     const int tid = threadIdx.x;
     const int tx = tid % CTX, ty = tid / CTX, TY = 256 / CTX;
     const int g = blockIdx.z;
@@ -399,10 +436,10 @@ static int norm_stats_impl(const float* x, float* mean, float* invstd, float* va
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr);
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f);
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
                        invstd, var_out, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps,
@@ -465,22 +502,34 @@ MIGAN_API int migan_norm_sync_finalize(const float* gathered, int world, long lo
 }
 
 // y = act(norm(x)*gamma+beta) [+ res] with given statistics (train or eval).
-MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, const float* res, int G, int P, int C,
-                               int act, float slope, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int norm_apply_impl(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, const float* res, int G, int P, int C, int act, float slope,
+                           const float* slope_ptr, hipStream_t st) {
     if ((size_t)G * P * C == 0) return 0;
     int VW, CTX, chunk;
     dim3 grid;
     apply_plan(G, P, C, VW, CTX, chunk, grid);
     if (VW == 4)
         hipLaunchKernelGGL((norm_apply_kernel<4>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
-                           CTX, chunk, act, slope);
+                           CTX, chunk, act, slope, slope_ptr);
     else
         hipLaunchKernelGGL((norm_apply_kernel<1>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
-                           CTX, chunk, act, slope);
+                           CTX, chunk, act, slope, slope_ptr);
     HIP_LAUNCH_CHECK();
     return 0;
+}
+MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* res, int G, int P, int C,
+                               int act, float slope, void* stream) {
+    return norm_apply_impl(x, y, mean, invstd, gamma, beta, res, G, P, C, act, slope, nullptr, (hipStream_t)stream);
+}
+// y = PReLU(norm(x)*gamma+beta) [+ res]: nn.BatchNorm2d -> nn.PReLU() of srgan/models.py:23-24,55-57 in the apply launch;
+// prelu_weight is the layer's single learnable slope on the device (num_parameters = 1)
+MIGAN_API int migan_norm_apply_prelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, const float* res, const float* prelu_weight, int G, int P, int C,
+                                     void* stream) {
+    if (!prelu_weight) return (int)hipErrorInvalidValue;
+    return norm_apply_impl(x, y, mean, invstd, gamma, beta, res, G, P, C, ACT_LRELU, 0.f, prelu_weight, (hipStream_t)stream);
 }
 
 // Number of [C]-slabs of per-block column sums the streaming backward kernels (migan_norm_bwd / migan_norm_bwd_apply /
@@ -495,36 +544,41 @@ MIGAN_API int migan_norm_colsum_slabs(int G, int P, int C) {
 
 // Backward, first half: sums[G][C][2] = (sum dyz, sum dyz*xhat) over this rank's pixels (dyz = dy * act'(z));
 // dgamma/dbeta [C] written (or accumulated) when G == 1.
-MIGAN_API int migan_norm_bwd_sums(const float* x, const float* dy, const float* mean, const float* invstd,
-                                  const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int G,
-                                  int P, int C, int act, float slope, float* ws, size_t ws_bytes, int accumulate,
-                                  void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int norm_bwd_sums_impl(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* sums, float* dgamma, float* dbeta, int G, int P, int C, int act,
+                              float slope, float* ws, size_t ws_bytes, int accumulate, const float* slope_ptr,
+                              float* dslope_gc, hipStream_t st) {
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     if (ws_bytes < (size_t)G * nchunks * C * 3 * sizeof(float)) return (int)hipErrorInvalidValue;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
-                           beta, ws, P, C, CTX, chunk, nchunks, act, slope);
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr);
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
-                           beta, ws, P, C, CTX, chunk, nchunks, act, slope);
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
-                       dgamma, dbeta, G, C, nchunks, accumulate);
+                       dgamma, dbeta, G, C, nchunks, accumulate, dslope_gc);
     HIP_LAUNCH_CHECK();
     return 0;
+}
+MIGAN_API int migan_norm_bwd_sums(const float* x, const float* dy, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, float* sums, float* dgamma, float* dbeta, int G,
+                                  int P, int C, int act, float slope, float* ws, size_t ws_bytes, int accumulate,
+                                  void* stream) {
+    return norm_bwd_sums_impl(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, act, slope, ws, ws_bytes,
+                              accumulate, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // Backward, second half: dx = gamma*invstd*(dyz - sums0/P_total - xhat*sums1/P_total).  P_total = the number of pixels
 // the sums cover: P, or world*P after the sums were all-reduced for cross-replica BatchNorm.  csum (optional):
 // migan_norm_colsum_slabs() x [C] per-block column sums of dx, from which the preceding conv's bias gradient is
 // reduced inside its wgrad launch (migan_conv2d_wgrad db_slabs).
-MIGAN_API int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
-                                   const float* gamma, const float* beta, const float* sums, int G, int P, int C,
-                                   int act, float slope, long long P_total, float* csum, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int norm_bwd_apply_impl(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* sums, int G, int P, int C, int act,
+                               float slope, long long P_total, float* csum, const float* slope_ptr, hipStream_t st) {
     if ((size_t)G * P * C == 0) return 0;
     int VW, CTX, chunk;
     dim3 grid;
@@ -532,12 +586,18 @@ MIGAN_API int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, c
     const float invP = (float)(1.0 / (double)(P_total > 0 ? P_total : P));
     if (VW == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX, chunk, act, slope, invP, csum);
+                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr);
     else
         hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX, chunk, act, slope, invP, csum);
+                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr);
     HIP_LAUNCH_CHECK();
     return 0;
+}
+MIGAN_API int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, const float* sums, int G, int P, int C,
+                                   int act, float slope, long long P_total, float* csum, void* stream) {
+    return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act, slope, P_total, csum, nullptr,
+                               (hipStream_t)stream);
 }
 
 // Backward of y = act(norm(x)*gamma+beta) through the batch statistics (both halves; ws as migan_norm_workspace()).
@@ -553,6 +613,33 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
                                  accumulate, stream);
     if (rc) return rc;
     return migan_norm_bwd_apply(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act, slope, P, csum, stream);
+}
+
+// Backward of y = PReLU(norm(x)*gamma+beta): as migan_norm_bwd with the slope read from the device, plus the slope's own
+// gradient dprelu[0] (+)= sum dy * min(z, 0) - a third sum of the statistics pass, so the PReLU layer costs no pass of its
+// own over the tensor (srgan/models.py:23-24: 16 residual blocks + 2 up-sampling stages per generator step).
+// ws: migan_norm_workspace_prelu() bytes.
+MIGAN_API size_t migan_norm_workspace_prelu(int G, int P, int C) {
+    return migan_norm_workspace(G, P, C) + (size_t)G * C * sizeof(float);
+}
+MIGAN_API int migan_norm_bwd_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, const float* prelu_weight, float* dx, float* dgamma, float* dbeta,
+                                   float* dprelu, int G, int P, int C, float* ws, size_t ws_bytes, int accumulate,
+                                   int dprelu_accumulate, float* csum, void* stream) {
+    if (!prelu_weight || ws_bytes < migan_norm_workspace_prelu(G, P, C)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
+    float* sums = ws + (size_t)G * nchunks * C * 3;
+    float* dsl = ws + migan_norm_workspace(G, P, C) / sizeof(float);
+    int rc = norm_bwd_sums_impl(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, ACT_LRELU, 0.f, ws,
+                                migan_norm_workspace(G, P, C), accumulate, prelu_weight, dprelu ? dsl : nullptr, st);
+    if (rc) return rc;
+    if (dprelu) {
+        hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, st, dsl, G * C, dprelu, dprelu_accumulate);
+        HIP_LAUNCH_CHECK();
+    }
+    return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, ACT_LRELU, 0.f, P, csum, prelu_weight, st);
 }
 
 // Backward of `act [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y) (mask may

@@ -1134,7 +1134,13 @@ class _Norm(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
-                slope, nbt=None):
+                slope, nbt=None, prelu=None):
+        # prelu: the weight of an nn.PReLU() (one shared slope) behind the norm layer (srgan/models.py:23-24,55-57): applied in
+        # the norm's apply launch, differentiated inside the norm's backward launches (csrc/norm.hip)
+        ctx.prelu = prelu
+        pw = _plain(prelu)
+        if pw is not None and (pw.numel() != 1 or act != ACT_NONE):
+            raise ValueError("norm: fused PReLU needs num_parameters == 1 and no other fused activation")
         xs = canon(x)
         # an NCHW-contiguous input (e.g. `out.view(B, 128, s, s)`, dcgan.py:68) gets its gradient back in NCHW through
         # the HIP transpose, instead of autograd's ViewBackward materialising it with an ATen strided copy
@@ -1182,8 +1188,14 @@ class _Norm(Function):
             check(lib.migan_rsqrt_eps(_plain(running_var).data_ptr(), invstd.data_ptr(), C, eps, st), "rsqrt_eps")
         rs = canon(res) if res is not None else None
         y = torch.empty_like(xs)
-        check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                   _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
+        if pw is None:
+            check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                       _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
+        else:
+            if sync is not None:
+                raise NotImplementedError("norm: fused PReLU under cross-replica BatchNorm (nn.Sequential does not fuse it)")
+            check(lib.migan_norm_apply_prelu(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                             _ptr(beta), _ptr(rs), pw.data_ptr(), G, P, C, st), "norm_apply_prelu")
         ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
         ctx.sync = sync
         # x itself is saved next to its dense copy: a differentiable backward (gradient penalties) needs the input WITH its
@@ -1198,6 +1210,8 @@ class _Norm(Function):
         if not batch_stats:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
         if torch.is_grad_enabled():
+            if ctx.prelu is not None:
+                raise NotImplementedError("double backward through a fused BatchNorm+PReLU is not on the reference path")
             return _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in)
         dy = canon(dy)
         dx = torch.empty_like(xs)
@@ -1219,7 +1233,21 @@ class _Norm(Function):
             nslab = lib.migan_norm_colsum_slabs(G, P, C)
             slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
         st = _stream()
-        if ctx.sync is None:
+        dprelu = None
+        if ctx.prelu is not None:
+            pw = _plain(ctx.prelu)
+            pslot = _grad_slot(ctx.prelu) if ctx.needs_input_grad[13] else None
+            want_dp = ctx.needs_input_grad[13]
+            dpt = pslot if pslot is not None else (torch.empty(1, device=xs.device, dtype=torch.float32) if want_dp else None)
+            nbp = lib.migan_norm_workspace_prelu(G, P, C)
+            wsp = _ws(nbp, xs)
+            check(lib.migan_norm_bwd_prelu(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                           _ptr(beta), pw.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
+                                           wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, _ptr(slabs), st),
+                  "norm_bwd_prelu")
+            if want_dp and pslot is None:
+                dprelu = dpt.view(ctx.prelu.shape)
+        elif ctx.sync is None:
             check(lib.migan_norm_bwd(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                      _ptr(beta), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), G, P, C, act, slope,
                                      ws.data_ptr(), nb, acc, _ptr(slabs), st), "norm_bwd")
@@ -1240,7 +1268,7 @@ class _Norm(Function):
             dx = to_nchw(dx)
         elif slabs is not None:
             _attach_colsum(dx, slabs, nslab, C)
-        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, dprelu
 
 
 class _NormBwdFn(Function):
@@ -1317,14 +1345,15 @@ def _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in):
             check(lib.migan_norm_bwd_sums(xs.data_ptr(), gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                           _ptr(beta), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), G, P, C, ACT_NONE,
                                           0.0, ws.data_ptr(), nb, 0, _stream()), "norm_bwd_sums")
-    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None
+    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None
 
 
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
-         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None):
-    """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself."""
+         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None, prelu=None):
+    """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself; `prelu`: weight of
+    an nn.PReLU() (single slope) applied behind the normalisation inside the same launches."""
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
-                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked)
+                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu)
 
 
 # ---------------------------------------------------------------------------------------------- index remaps

@@ -24,6 +24,9 @@ from . import functional as F
 _FUSE = True
 
 
+_PRELU_FUSE = __import__("os").environ.get("MIGAN_NO_PRELU_FUSE", "0") != "1"  # A/B knob: 1 = PReLU as its own launches
+
+
 def set_fusion(enabled):
     """Enable/disable Sequential peephole fusion (both modes give the same results up to fp32 rounding)."""
     global _FUSE
@@ -195,7 +198,7 @@ class Linear(tnn.Linear):
 
 
 class _BatchNormMixin:
-    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None):
+    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None, prelu=None):
         if self.momentum is None:
             raise ValueError("BatchNorm: cumulative moving average (momentum=None) is not on the reference path")
         use_batch = self.training or not self.track_running_stats
@@ -206,7 +209,7 @@ class _BatchNormMixin:
             nbt = self.num_batches_tracked  # incremented by the statistics kernel (no separate aten::add launch)
         y = F.norm(x, self.weight if self.affine else None, self.bias if self.affine else None, res,
                    rm if (self.training or not use_batch) else None, rv if (self.training or not use_batch) else None,
-                   use_batch, self.momentum, self.eps, False, act, slope, nbt)
+                   use_batch, self.momentum, self.eps, False, act, slope, nbt, prelu)
         return _wrap(y)
 
     def forward(self, x):
@@ -545,6 +548,17 @@ class Sequential(tnn.Sequential):
                     (act, slope), k = _act_of(mods[k]), k + 1
                 if isinstance(m, (BatchNorm2d, BatchNorm1d)):
                     m._check_input_dim(x)
+                # BatchNorm2d [PixelShuffle] PReLU (srgan/models.py:23-24, 55-57): the single-slope PReLU commutes with the
+                # shuffle, so it is applied (and differentiated) inside the norm launches and the shuffle moves behind it
+                if _PRELU_FUSE and act == F.ACT_NONE and type(m) is BatchNorm2d and x.dim() == 4 \
+                        and (m.training or not m.track_running_stats) and not (F._SYNC_BN is not None and F._SYNC_BN.world > 1):
+                    q = k + 1 if (k < n and type(mods[k]) is PixelShuffle) else k
+                    if q < n and type(mods[q]) is PReLU and mods[q].num_parameters == 1:
+                        x = m.fused_forward(x, F.ACT_NONE, 0.0, None, mods[q].weight)
+                        if q > k:
+                            x = mods[k](x)
+                        i = q + 1
+                        continue
                 if res is not None and k == n and act == F.ACT_NONE and x.dim() == 4 and res.shape == x.shape:
                     x, res = m.fused_forward(x, act, slope, res), None   # y = norm(x) + res in the apply kernel
                 else:

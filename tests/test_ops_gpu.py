@@ -402,6 +402,65 @@ def test_prelu(pg):
     assert_close(ag.grad, a.grad, TOL_WGRAD, "prelu dslope")
 
 
+@pytest.mark.parametrize("cfg", [(4, 64, 12, 12, 0.8, False), (2, 256, 9, 7, 1e-5, True), (3, 10, 5, 4, 0.8, False)])
+def test_batchnorm_prelu_fused(pg, cfg):
+    """nn.BatchNorm2d -> nn.PReLU() in the norm launches (srgan/models.py:23-24,55-57): forward, dx, dgamma, dbeta and the
+    slope gradient (a third sum of the norm's statistics pass) against torch; with and without the residual add; and the
+    Sequential route BatchNorm2d -> PixelShuffle -> PReLU (PReLU applied before the shuffle) against the unfused modules."""
+    N, C, H, W, eps, with_res = cfg
+    F = pg.functional
+    x = (_leaf(N, C, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
+    gamma = (_leaf(C, seed=2) * 0.5 + 1.0).requires_grad_(True)
+    beta = (_leaf(C, seed=3) * 0.5).requires_grad_(True)
+    a = torch.tensor([0.25], requires_grad=True)
+    r = _leaf(N, C, H, W, seed=4).requires_grad_(True) if with_res else None
+    y_ref = TF.prelu(TF.batch_norm(x, None, None, gamma, beta, True, 0.1, eps), a)
+    if with_res:
+        y_ref = y_ref + r
+    gy = _leaf(N, C, H, W, seed=5)
+    y_ref.backward(gy)
+    xg, gg, bg, ag = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta, a))
+    rg = r.detach().to(DEV).requires_grad_(True) if with_res else None
+    y = F.norm(xg, gg, bg, rg, None, None, True, 0.1, eps, False, 0, 0.0, None, ag)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "bn+prelu fwd")
+    pre = TF.batch_norm(x.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, eps)
+    keep = (pre.abs() > 1e-5).float()   # the kink: a pre-activation within rounding of 0 may land on the other branch
+    assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "bn+prelu dx")
+    assert_close(gg.grad, gamma.grad, 2e-5, "bn+prelu dgamma")
+    assert_close(bg.grad, beta.grad, 2e-5, "bn+prelu dbeta")
+    assert_close(ag.grad, a.grad, 2e-5, "bn+prelu dslope")
+    if with_res:
+        assert_close(rg.grad, r.grad, 1e-7, "bn+prelu residual grad")
+
+
+def test_sequential_bn_shuffle_prelu_equals_unfused(pg):
+    import copy
+
+    nn = pg.nn
+    torch.manual_seed(3)
+    seq = nn.Sequential(nn.Conv2d(16, 64, 3, 1, 1), nn.BatchNorm2d(64), nn.PixelShuffle(upscale_factor=2), nn.PReLU()).to(DEV)
+    ref = copy.deepcopy(seq)
+    x = _leaf(2, 16, 10, 10, seed=7).to(DEV)
+    gy = _leaf(2, 16, 20, 20, seed=8).to(DEV)
+    outs = []
+    for m, fused in ((seq, True), (ref, False)):
+        pg.set_fusion(fused)
+        try:
+            xin = x.clone().requires_grad_(True)
+            y = m(xin)
+            y.backward(gy)
+            outs.append((y.detach(), xin.grad, [p.grad.clone() for p in m.parameters()]))
+        finally:
+            pg.set_fusion(True)
+    assert_close(outs[0][0], outs[1][0], 2e-6, "bn->shuffle->prelu fwd, fused vs modules")
+    assert_close(outs[0][1], outs[1][1], 2e-5, "input gradient")
+    for ga, gb, (k, _) in zip(outs[0][2], outs[1][2], seq.named_parameters()):
+        if k == "0.bias":   # conv bias in front of BatchNorm: exactly-zero true gradient, rounding noise on both sides
+            continue
+        assert_close(ga, gb, 5e-5, "gradient of " + k)
+
+
 @pytest.mark.parametrize("cfg", [((3, 3, 3, 3), 1), ((1, 1, 1, 1), 1), ((1, 1, 0, 0), 0), ((0, 0, 0, 0), 2), ((2, 2, 1, 1), 2)])
 def test_gather2d(pg, cfg):
     pads, mode = cfg
