@@ -100,6 +100,15 @@ def load_reference():
     ref.pix2pix = _import_file("ref_pix2pix_models", os.path.join(IMPL, "pix2pix", "models.py"))
     ref.srgan = _import_file("ref_srgan_models", os.path.join(IMPL, "srgan", "models.py"))
     ref.esrgan = _import_file("ref_esrgan_models", os.path.join(IMPL, "esrgan", "models.py"))
+    ref.stargan = _import_file("ref_stargan_models", os.path.join(IMPL, "stargan", "models.py"))
+    ref.dualgan = _import_file("ref_dualgan_models", os.path.join(IMPL, "dualgan", "models.py"))
+
+    def script_defs(name):
+        ns = _script_ns(cuda=False)
+        ns["Tensor"] = ns["FloatTensor"] = torch.FloatTensor
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, name, name + ".py"), ns))
+
+    ref.stargan_script, ref.dualgan_script = (lambda: script_defs("stargan")), (lambda: script_defs("dualgan"))
 
     def dcgan(img_size, latent_dim=100, channels=1):
         opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels)
@@ -362,6 +371,40 @@ def pin_dragan(ref):
          n_masks=nm, **mp)
 
 
+def pin_critic_gp(ref):
+    """SURVEY.md 8f F1, the other two conv-critic penalties: stargan.py:142-161 (critic of stargan/models.py:87-115) and
+    dualgan.py:116-135 (dualgan/models.py:102-123, BatchNorm2d(C, 0.8) inside the differentiated path)."""
+    print("stargan / dualgan critic gradient penalty")
+    out = {}
+    for name, make_r, make_o in (
+            ("stargan", lambda: ref.stargan.Discriminator((3, 32, 32), 5, 4), lambda: M.StarganDiscriminator((3, 32, 32), 5, 4)),
+            ("dualgan", lambda: ref.dualgan.Discriminator(3), lambda: M.DualganDiscriminator(3))):
+        D_r, D_o = built_equal(make_r, make_o, name + ".D")
+        fn = getattr(ref, name + "_script")().compute_gradient_penalty
+        seed_all(31)
+        real = torch.rand(4, 3, 32, 32) * 2 - 1
+        fake = torch.rand(4, 3, 32, 32) * 2 - 1
+        np.random.seed(9)
+        gp_r = fn(D_r, real, fake)
+        gp_r.backward()
+        np.random.seed(9)
+        alpha = torch.tensor(np.random.random((4, 1, 1, 1)), dtype=torch.float32)
+        gp_o = S.critic_gradient_penalty(D_o, real, fake, alpha)
+        gp_o.backward()
+        assert torch.equal(gp_r, gp_o), "%s gradient penalty differs (%r vs %r)" % (name, gp_r.item(), gp_o.item())
+        grads = {}
+        for (k, a), (_, b) in zip(D_r.named_parameters(), D_o.named_parameters()):
+            assert (a.grad is None) == (b.grad is None), k
+            if a.grad is not None:
+                assert torch.equal(a.grad, b.grad), "%s penalty grad of %s differs" % (name, k)
+                grads[k] = a.grad.clone()
+        check_same_params(D_r, D_o, name + ".D (buffers after the penalty forward)")
+        pk, pd, ph = grads_digest(grads)
+        out.update({name + "_real": real, name + "_fake": fake, name + "_alpha": alpha, name + "_gp": gp_r.detach(),
+                    name + "_keys": pk, name + "_digest": pd, name + "_head": ph})
+    save("critic_gp_32", meta=meta(), **out)
+
+
 def pin_cyclegan(ref):
     print("cyclegan (cyclegan/models.py:6-122, utils.py:13-44)")
     shape = (3, 32, 32)
@@ -614,6 +657,7 @@ def main():
     pin_dcgan(ref)
     pin_mlp(ref)
     pin_dragan(ref)
+    pin_critic_gp(ref)
     pin_cyclegan(ref)
     pin_srgan(ref)
     pin_esrgan(ref)

@@ -502,3 +502,43 @@ class EsrganDiscriminator(SrganDiscriminator):
     """esrgan/models.py:97-130: layer for layer the SRGAN discriminator (3x3 s1 / s2 pairs, BatchNorm2d, LeakyReLU(0.2),
     3x3 -> 1 patch logits); kept as its own class so class-name matches and state_dict keys follow the reference file."""
 
+
+# --------------------------------------------------------------------------------------------- stargan / dualgan critics (8f F1)
+class StarganDiscriminator(nn.Module):
+    """stargan/models.py:87-115: n_strided x [Conv4x4 s2 p1, LeakyReLU(0.01)], then a 3x3 patch head and a class head."""
+
+    def __init__(self, img_shape=(3, 128, 128), c_dim=5, n_strided=6):
+        super().__init__()
+        channels, img_size, _ = img_shape
+        specs, cin, cout = [], channels, 64
+        for _ in range(n_strided):
+            specs += [("conv", cin, cout, 4, 2, 1), ("lrelu", 0.01)]
+            cin, cout = cout, cout * 2
+        self.model = _build(specs)
+        self.out1 = nn.Conv2d(cin, 1, 3, padding=1, bias=False)
+        self.out2 = nn.Conv2d(cin, c_dim, img_size // 2 ** n_strided, bias=False)
+
+    def forward(self, img):
+        f = self.model(img)
+        out_cls = self.out2(f)
+        return self.out1(f), out_cls.view(out_cls.size(0), -1)
+
+
+class DualganDiscriminator(nn.Module):
+    """dualgan/models.py:102-123: 3 x [Conv4x4 s2 p1, (BatchNorm2d(C, 0.8)), LeakyReLU(0.2)], ZeroPad2d((1,0,1,0)), Conv4x4."""
+
+    def __init__(self, in_channels=3):
+        super().__init__()
+        specs, cin = [], in_channels
+        for i, cout in enumerate((64, 128, 256)):
+            specs.append(("conv", cin, cout, 4, 2, 1))
+            if i != 0:
+                specs.append(("bn2", cout, 0.8))
+            specs.append(("lrelu", 0.2, True))
+            cin = cout
+        specs += [("zpad", (1, 0, 1, 0)), ("conv", 256, 1, 4, 1, 0)]
+        self.model = _build(specs)
+
+    def forward(self, img):
+        return self.model(img)
+

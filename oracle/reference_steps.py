@@ -113,6 +113,23 @@ def wgan_gp_step(s, real_imgs, i, z=None, alpha=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ stargan / dualgan (8f F1)
+def critic_gradient_penalty(D, real_samples, fake_samples, alpha=None):
+    """stargan.py:142-161 and dualgan.py:116-135 (the same function; stargan's critic returns (out_adv, out_cls) and the
+    penalty uses out_adv): alpha ~ np.random.random((B, 1, 1, 1)), gradient of the critic output w.r.t. the interpolate,
+    per-sample L2 norm over all pixels."""
+    if alpha is None:
+        alpha = _f32(np.random.random((real_samples.size(0), 1, 1, 1)))
+    interpolates = (alpha * real_samples + ((1 - alpha) * fake_samples)).requires_grad_(True)
+    out = D(interpolates)
+    d_interpolates = out[0] if isinstance(out, tuple) else out
+    fake = _f32(np.ones(d_interpolates.shape))
+    gradients = autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=fake, create_graph=True,
+                              retain_graph=True, only_inputs=True)[0]
+    gradients = gradients.view(gradients.size(0), -1)
+    return ((gradients.norm(2, dim=1) - 1) ** 2).mean()
+
+
 # ------------------------------------------------------------------------------------------------ dragan (8f F1)
 def make_dragan(img_size=32, latent_dim=100, channels=1):
     """dragan.py:46-99,115-120: the generator / discriminator classes are those of dcgan.py (same layer lists)."""

@@ -101,20 +101,34 @@ gan_step = dcgan_step
 
 # ------------------------------------------------------------------------------------------------ wgan_gp
 def compute_gradient_penalty(D, real_samples, fake_samples, alpha=None):
-    """wgan_gp.py:119-138 on the HIP path: interpolation, D forward, differentiable backward
-    (create_graph=True through Linear/LeakyReLU Functions), row-wise L2 norm and mean((n-1)^2)."""
+    """wgan_gp.py:119-138 - and the same function of stargan.py:142-161 / dualgan.py:116-135 on their conv critics - on the HIP
+    path: interpolation, D forward, differentiable backward (create_graph=True through the Linear / Conv2d / LeakyReLU /
+    BatchNorm Functions), per-sample L2 norm and mean((n-1)^2).  A critic that returns a tuple (stargan's (out_adv, out_cls),
+    stargan/models.py:110-115) is differentiated through its first output, as the reference does."""
     B = real_samples.size(0)
     dev = real_samples.device
     if alpha is None:
         alpha = _dev(np.random.random((B, 1, 1, 1)), dev)
     a = alpha.reshape(B)
+    if real_samples.dim() == 4:  # one memory layout for both operands of the row-scaled sum
+        real_samples, fake_samples = F.canon(real_samples), F.canon(fake_samples)
     mix = F.axpby(F.rowscale(real_samples, a), F.rowscale(fake_samples, 1 - a), 1.0, 1.0)
     mix = mix.view(real_samples.shape).requires_grad_(True)
     d_mix = D(mix)
-    ones = torch.ones(B, 1, device=dev)
-    grads = torch.autograd.grad(outputs=d_mix, inputs=mix, grad_outputs=ones, create_graph=True, retain_graph=True,
-                                only_inputs=True)[0]
-    norms = F.rownorm(grads.view(B, -1))
+    if isinstance(d_mix, tuple):
+        d_mix = d_mix[0]
+    ones = torch.ones(d_mix.shape, device=dev)
+    conv_critic = d_mix.dim() == 4
+    with F.input_grad_only() if conv_critic else contextlib.nullcontext():
+        grads = torch.autograd.grad(outputs=d_mix, inputs=mix, grad_outputs=ones, create_graph=True, retain_graph=True,
+                                    only_inputs=True)[0]
+    if grads.dim() == 4 and not grads.is_contiguous():
+        # the per-sample norm runs over all of C*H*W: any order of the sample's elements will do, so the NHWC storage is
+        # viewed as rows directly (no re-layout launch inside the differentiated graph)
+        rows = grads.permute(0, 2, 3, 1).reshape(B, -1)
+    else:
+        rows = grads.view(B, -1)
+    norms = F.rownorm(rows)
     return F.loss(F.LOSS_MSE, norms, None, 1.0)
 
 

@@ -387,3 +387,47 @@ def test_dragan_gradient_penalty_vs_reference(pg, golden_dir):
     for (k, b), (_, c) in zip(D.named_buffers(), Dg.named_buffers()):
         if b.dtype.is_floating_point:
             assert_close(c, b, 1e-5, "dragan buffer " + k)
+
+
+@pytest.mark.parametrize("name", ["stargan", "dualgan"])
+def test_conv_critic_gradient_penalty_vs_reference(pg, golden_dir, name):
+    """SURVEY.md 8f F1, the other two scripts: compute_gradient_penalty of stargan.py:142-161 (critic stargan/models.py:87-115:
+    Conv4x4 s2 + LeakyReLU(0.01), tuple output) and dualgan.py:116-135 (dualgan/models.py:102-123: BatchNorm2d(C, 0.8) and a
+    ZeroPad2d inside the twice-differentiated path) on the HIP path against the value and the critic gradients recorded from
+    the REAL reference functions (tests/golden/critic_gp_32.npz) and against the oracle's fp64 evaluation."""
+    import copy
+
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    gold = load_golden(golden_dir, "critic_gp_32")
+    _seed(0)
+    D = M.StarganDiscriminator((3, 32, 32), 5, 4) if name == "stargan" else M.DualganDiscriminator(3)
+    real, fake, alpha = (torch.from_numpy(gold["%s_%s" % (name, k)]) for k in ("real", "fake", "alpha"))
+    D64 = copy.deepcopy(D).double()
+    Dg = gpu_copy(D)
+    gp_c = S.critic_gradient_penalty(D, real, fake, alpha)
+    gp_c.backward()
+    want = float(gold[name + "_gp"])
+    assert abs(float(gp_c.detach()) - want) <= 1e-6 * abs(want)
+    gp_d = S.critic_gradient_penalty(D64, real.double(), fake.double(), alpha.double())
+    gp_d.backward()
+    for p in Dg.parameters():
+        p.grad = None
+    gp_g = steps.compute_gradient_penalty(Dg, real.to(DEV), fake.to(DEV), alpha.to(DEV))
+    gp_g.backward()
+    assert abs(float(gp_g.detach()) - want) <= 2e-5 * abs(want), (float(gp_g.detach()), want)
+    gp_, cp_, dp_ = dict(Dg.named_parameters()), dict(D.named_parameters()), dict(D64.named_parameters())
+    keys = [str(k) for k in gold[name + "_keys"]]
+    assert len(keys) >= 6
+    for k, gd in zip(keys, gold[name + "_digest"]):
+        assert np.allclose(digest(cp_[k].grad), gd, rtol=1e-3, atol=1e-9 + 1e-3 * abs(gd[1])), k
+        _noise_aware(gp_[k].grad, cp_[k].grad, dp_[k].grad, TOL_MODEL_GRAD, "%s penalty grad %s" % (name, k))
+    for k, p in cp_.items():   # stargan's class head (out2) is not on the penalty's path: no gradient on either side
+        if p.grad is None:
+            assert gp_[k].grad is None or float(gp_[k].grad.abs().max()) == 0.0, k
+    for (k, b), (_, c) in zip(D.named_buffers(), Dg.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert_close(c, b, 1e-5, "%s buffer %s" % (name, k))
+
