@@ -381,9 +381,27 @@ def pin_critic_gp(ref):
             ("dualgan", lambda: ref.dualgan.Discriminator(3), lambda: M.DualganDiscriminator(3))):
         D_r, D_o = built_equal(make_r, make_o, name + ".D")
         fn = getattr(ref, name + "_script")().compute_gradient_penalty
-        seed_all(31)
-        real = torch.rand(4, 3, 32, 32) * 2 - 1
-        fake = torch.rand(4, 3, 32, 32) * 2 - 1
+        # inputs whose LeakyReLU pre-activations all stay clear of the kink: an element within rounding of 0 takes the other
+        # branch on another implementation (GPU accumulation order) and moves the twice-differentiated gradients by ~1 %, which
+        # says nothing about either implementation (the first draw, seed 31, has one such element in the dualgan critic)
+        for data_seed in range(31, 80):
+            seed_all(data_seed)
+            real = torch.rand(4, 3, 32, 32) * 2 - 1
+            fake = torch.rand(4, 3, 32, 32) * 2 - 1
+            np.random.seed(9)
+            alpha = torch.tensor(np.random.random((4, 1, 1, 1)), dtype=torch.float32)
+            margins = []
+            import copy as _copy
+            D64 = _copy.deepcopy(D_o).double()
+            hooks = [m.register_forward_pre_hook(lambda mod, inp: margins.append(float(inp[0].abs().min() / inp[0].pow(2).mean().sqrt())))
+                     for m in D64.modules() if isinstance(m, nn.LeakyReLU)]
+            with torch.no_grad():
+                D64((alpha * real + (1 - alpha) * fake).double())
+            for h in hooks:
+                h.remove()
+            if min(margins) > 2e-5:
+                break
+        print("  %s: data seed %d, smallest |pre-activation| / rms over the LeakyReLU inputs = %.2e" % (name, data_seed, min(margins)))
         np.random.seed(9)
         gp_r = fn(D_r, real, fake)
         gp_r.backward()
@@ -400,7 +418,8 @@ def pin_critic_gp(ref):
                 grads[k] = a.grad.clone()
         check_same_params(D_r, D_o, name + ".D (buffers after the penalty forward)")
         pk, pd, ph = grads_digest(grads)
-        out.update({name + "_real": real, name + "_fake": fake, name + "_alpha": alpha, name + "_gp": gp_r.detach(),
+        out.update({name + "_kink_margin": np.float64(min(margins)),
+                    name + "_real": real, name + "_fake": fake, name + "_alpha": alpha, name + "_gp": gp_r.detach(),
                     name + "_keys": pk, name + "_digest": pd, name + "_head": ph})
     save("critic_gp_32", meta=meta(), **out)
 

@@ -402,6 +402,10 @@ def test_conv_critic_gradient_penalty_vs_reference(pg, golden_dir, name):
     from pytorch_gan_amd import steps
 
     gold = load_golden(golden_dir, "critic_gp_32")
+    # the fixture inputs were drawn so that no LeakyReLU pre-activation lies within 2e-5 (relative to the layer rms) of the kink:
+    # an element within rounding of 0 takes the other branch on another implementation and moves these twice-differentiated
+    # gradients by ~1 % (measured with the first draw: 0.8 % on model.0.weight from ONE element of 114 k) - DESIGN.md 4
+    assert float(gold[name + "_kink_margin"]) > 2e-5
     _seed(0)
     D = M.StarganDiscriminator((3, 32, 32), 5, 4) if name == "stargan" else M.DualganDiscriminator(3)
     real, fake, alpha = (torch.from_numpy(gold["%s_%s" % (name, k)]) for k in ("real", "fake", "alpha"))
