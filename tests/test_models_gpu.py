@@ -429,6 +429,11 @@ def test_conv_critic_gradient_penalty_vs_reference(pg, golden_dir, name):
     assert len(keys) >= 6
     for k, gd in zip(keys, gold[name + "_digest"]):
         assert np.allclose(digest(cp_[k].grad), gd, rtol=1e-3, atol=1e-9 + 1e-3 * abs(gd[1])), k
+        if gp_[k].grad is None:
+            # the last layer's bias does not enter dD/dx: torch hands back a zero tensor, the HIP Functions no gradient at all
+            # (under optim.Adam the parameter's .grad is a zeroed slot of the flat bucket either way)
+            assert float(cp_[k].grad.abs().max()) == 0.0, k
+            continue
         _noise_aware(gp_[k].grad, cp_[k].grad, dp_[k].grad, TOL_MODEL_GRAD, "%s penalty grad %s" % (name, k))
     for k, p in cp_.items():   # stargan's class head (out2) is not on the penalty's path: no gradient on either side
         if p.grad is None:
