@@ -129,6 +129,11 @@ def load_reference():
         ns = _script_ns(opt=opt, lambda_gp=10)
         return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "dragan", "dragan.py"), ns))
 
+    def acgan(img_size, latent_dim=100, channels=1, n_classes=10):
+        opt = SimpleNamespace(img_size=img_size, latent_dim=latent_dim, channels=channels, n_classes=n_classes)
+        return SimpleNamespace(**_extract_defs(os.path.join(IMPL, "acgan", "acgan.py"), _script_ns(opt=opt)))
+
+    ref.acgan = acgan
     ref.dcgan, ref.wgan_gp, ref.gan, ref.dragan = dcgan, wgan_gp, gan, dragan
     return ref
 
@@ -559,6 +564,50 @@ def pin_esrgan(ref):
          loop_lr=lrs, loop_hr=hrs, loop_trace=np.array(trace), loop_keys=np.array(keys))
 
 
+def pin_acgan(ref):
+    """acgan.py:46-107 (Embedding * noise generator, two-headed discriminator with nn.Softmax()) and three
+    iterations of its loop (acgan.py:167-222) with the REAL reference classes inside the restated loop."""
+    import warnings
+
+    print("acgan (acgan.py:46-107,167-222)")
+    ns = ref.acgan(32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # nn.Softmax() without dim
+        seed_all(0)
+        G, D = ns.Generator(), ns.Discriminator()
+        G.apply(ns.weights_init_normal)
+        D.apply(ns.weights_init_normal)
+        s_ref = SimpleNamespace(G=G, D=D, opt_G=S._adam(G.parameters()), opt_D=S._adam(D.parameters()), bce=torch.nn.BCELoss(),
+                                ce=torch.nn.CrossEntropyLoss(), latent_dim=100, n_classes=10)
+        seed_all(0)
+        s_orc = S.make_acgan(32)
+        check_same_params(s_ref.G, s_orc.G, "acgan G")
+        check_same_params(s_ref.D, s_orc.D, "acgan D")
+        seed_all(41)
+        imgs = torch.rand(3, 8, 1, 32, 32) * 2 - 1
+        labels = torch.tensor(np.random.randint(0, 10, (3, 8)), dtype=torch.long)
+        zs = torch.tensor(np.random.normal(0, 1, (3, 8, 100)), dtype=torch.float32)
+        gls = torch.tensor(np.random.randint(0, 10, (3, 8)), dtype=torch.long)
+        trace, all_masks = [], []
+        for t in range(3):
+            masks = []
+            hs = hook_masks(s_ref.D, masks)
+            torch.manual_seed(200 + t)
+            o_r = S.acgan_step(s_ref, imgs[t], labels[t], zs[t], gls[t])
+            for h in hs:
+                h.remove()
+            with M.feed_masks(masks=[m.numpy() for m in masks]):
+                o_o = S.acgan_step(s_orc, imgs[t], labels[t], zs[t], gls[t])
+            assert torch.equal(o_r["g_loss"], o_o["g_loss"]) and torch.equal(o_r["d_loss"], o_o["d_loss"]), "acgan loop"
+            trace.append([o_r["g_loss"].item(), o_r["d_loss"].item()])
+            all_masks.append(masks)
+    check_same_params(s_ref.G, s_orc.G, "acgan G after 3 steps")
+    check_same_params(s_ref.D, s_orc.D, "acgan D after 3 steps")
+    mp = {"mask_%d_%02d" % (t, i): m.numpy() for t, ms in enumerate(all_masks) for i, m in enumerate(ms)}
+    save("acgan_32_loop", meta=meta(), imgs=imgs, labels=labels, zs=zs, gen_labels=gls, trace=np.array(trace),
+         masks_per_step=len(all_masks[0]), **mp)
+
+
 def pin_dropout_semantics():
     print("dropout semantics (nn.Dropout2d / nn.Dropout vs injectable oracle layers)")
     x = torch.rand(3, 5, 4, 4) + 0.5
@@ -680,6 +729,7 @@ def main():
     pin_cyclegan(ref)
     pin_srgan(ref)
     pin_esrgan(ref)
+    pin_acgan(ref)
     pin_pix2pix(ref)
     pin_steps(ref)
     print("oracle pinned against the reference; fixtures written to", GOLD)

@@ -11,6 +11,7 @@ order, and without the logging / image-saving side effects.  Line references:
   srgan_step      implementations/srgan/srgan.py:97-145
   dragan_step     implementations/dragan/dragan.py:144-167,176-217   (conv-critic gradient penalty)
   esrgan_step     implementations/esrgan/esrgan.py:101-174           (relativistic average GAN + warm-up)
+  acgan_step      implementations/acgan/acgan.py:167-222             (label-conditioned DCGAN, auxiliary classifier)
 Pinned against the reference by oracle/pin_against_reference.py.
 """
 import itertools
@@ -324,4 +325,42 @@ def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
     s.opt_D.step()
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach(), "loss_pixel": loss_pixel.detach()}
+
+
+# ------------------------------------------------------------------------------------------------ acgan (8f F2)
+def make_acgan(img_size=32, latent_dim=100, channels=1, n_classes=10):
+    """acgan.py:110-125,151-152: BCELoss + CrossEntropyLoss, weights_init_normal on both networks (it touches Conv and
+    BatchNorm2d layers only: the Embedding and Linear layers keep torch's default init)."""
+    G, D = M.AcganGenerator(img_size, latent_dim, channels, n_classes), M.AcganDiscriminator(img_size, channels, n_classes)
+    G.apply(M.init_normal_dcgan)
+    D.apply(M.init_normal_dcgan)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()), bce=torch.nn.BCELoss(),
+                           ce=torch.nn.CrossEntropyLoss(), latent_dim=latent_dim, n_classes=n_classes)
+
+
+def acgan_step(s, real_imgs, labels, z=None, gen_labels=None):
+    """acgan.py:167-222.  Quirk kept: CrossEntropyLoss is fed the Softmax OUTPUT of the class head (a log-softmax of
+    probabilities).  Host draws when not given, in the reference's order: z ~ np.random.normal, gen_labels ~ np.random.randint.
+    The class accuracy print-out (acgan.py:216-219) is logging and is not restated."""
+    B = real_imgs.shape[0]
+    valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+    s.opt_G.zero_grad()
+    if z is None:
+        z = _f32(np.random.normal(0, 1, (B, s.latent_dim)))
+    if gen_labels is None:
+        gen_labels = torch.tensor(np.random.randint(0, s.n_classes, B), dtype=torch.long)
+    gen_imgs = s.G(z, gen_labels)
+    validity, pred_label = s.D(gen_imgs)
+    g_loss = 0.5 * (s.bce(validity, valid) + s.ce(pred_label, gen_labels))
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    real_pred, real_aux = s.D(real_imgs)
+    d_real_loss = (s.bce(real_pred, valid) + s.ce(real_aux, labels)) / 2
+    fake_pred, fake_aux = s.D(gen_imgs.detach())
+    d_fake_loss = (s.bce(fake_pred, fake) + s.ce(fake_aux, gen_labels)) / 2
+    d_loss = (d_real_loss + d_fake_loss) / 2
+    d_loss.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen_imgs.detach()}
 

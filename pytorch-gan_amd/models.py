@@ -414,3 +414,44 @@ class EsrganDiscriminator(SrganDiscriminator):
     """esrgan/models.py:97-130: layer for layer the SRGAN discriminator; its output is used as logits
     (BCEWithLogitsLoss on relativistic differences, esrgan.py:137,165-166)."""
 
+
+# --------------------------------------------------------------------------------------------- acgan (SURVEY.md 8f F2)
+class AcganGenerator(nn.Module):
+    """acgan/acgan.py:46-73: the DCGAN generator behind label_emb(labels) * noise."""
+
+    def __init__(self, img_size=32, latent_dim=100, channels=1, n_classes=10):
+        super().__init__()
+        self.label_emb = nn.Embedding(n_classes, latent_dim)
+        self.init_size = img_size // 4
+        self.l1 = _build([("lin", latent_dim, 128 * self.init_size ** 2)])
+        self.conv_blocks = _build([
+            ("bn2", 128), ("up2",), ("conv", 128, 128, 3, 1, 1), ("bn2", 128, 0.8), ("lrelu", 0.2, True),
+            ("up2",), ("conv", 128, 64, 3, 1, 1), ("bn2", 64, 0.8), ("lrelu", 0.2, True),
+            ("conv", 64, channels, 3, 1, 1), ("tanh",)])
+
+    def forward(self, noise, labels):
+        out = self.l1(torch.mul(self.label_emb(labels), noise))
+        return self.conv_blocks(out.view(out.shape[0], 128, self.init_size, self.init_size))
+
+
+class AcganDiscriminator(nn.Module):
+    """acgan/acgan.py:76-107: DCGAN discriminator blocks, a Sigmoid validity head and a Softmax class head."""
+
+    def __init__(self, img_size=32, channels=1, n_classes=10):
+        super().__init__()
+        specs, cin = [], channels
+        for cout, bn in ((16, False), (32, True), (64, True), (128, True)):
+            specs += [("conv", cin, cout, 3, 2, 1), ("lrelu", 0.2, True), ("drop2", 0.25)]
+            if bn:
+                specs.append(("bn2", cout, 0.8))
+            cin = cout
+        self.conv_blocks = _build(specs)
+        feat = 128 * (img_size // 16) ** 2
+        self.adv_layer = _build([("lin", feat, 1), ("sigmoid",)])
+        self.aux_layer = nn.Sequential(nn.Linear(feat, n_classes), nn.Softmax(dim=1))
+
+    def forward(self, img):
+        out = self.conv_blocks(img)
+        out = out.view(out.shape[0], -1)
+        return self.adv_layer(out), self.aux_layer(out)
+

@@ -527,3 +527,36 @@ def esrgan_upscale(G, image):
     no_grad (de-normalisation and the PNG write stay with the caller)."""
     G.eval()
     return G(image)
+
+
+# ------------------------------------------------------------------------------------------------ acgan (SURVEY.md 8f F2)
+def make_acgan_state(G, D, latent_dim=100, n_classes=10, skip_dead_grads=True, dp=None):
+    """acgan.py:110-152: BCELoss for validity, CrossEntropyLoss for the auxiliary class head, Adam(2e-4, (0.5, 0.999))."""
+    return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM), bce=gnn.BCELoss(),
+                           ce=gnn.CrossEntropyLoss(), latent_dim=latent_dim, n_classes=n_classes, skip=skip_dead_grads,
+                           labels={}, dp=dp or LocalStepper())
+
+
+@_scoped
+def acgan_step(s, real_imgs, labels, z, gen_labels):
+    """acgan.py:167-222.  labels / gen_labels: int64 class indices on the device; z: (B, latent_dim).  The reference's quirk is
+    kept: CrossEntropyLoss consumes the Softmax output of the class head."""
+    valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen_imgs = s.G(z, gen_labels)
+    with frozen(s.D, enabled=s.skip):
+        validity, pred_label = s.D(gen_imgs)
+        g_loss = half_sum(s.bce(validity, valid), s.ce(pred_label, gen_labels))
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    real_pred, real_aux = s.D(real_imgs)
+    d_real_loss = half_sum(s.bce(real_pred, valid), s.ce(real_aux, labels))
+    fake_pred, fake_aux = s.D(gen_imgs.detach())
+    d_fake_loss = half_sum(s.bce(fake_pred, fake), s.ce(fake_aux, gen_labels))
+    d_loss = half_sum(d_real_loss, d_fake_loss)
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen_imgs.detach()}
+

@@ -111,7 +111,8 @@ def test_product_models_match_reference_trees():
              (PM.SrganFeatureExtractor(), OM.SrganFeatureExtractor()),
              (PM.EsrganGenerator(3, 64, 2), OM.EsrganGenerator(3, 64, 2)),
              (PM.EsrganDiscriminator((3, 32, 32)), OM.EsrganDiscriminator((3, 32, 32))),
-             (PM.EsrganFeatureExtractor(), OM.EsrganFeatureExtractor())]
+             (PM.EsrganFeatureExtractor(), OM.EsrganFeatureExtractor()),
+             (PM.AcganGenerator(32), OM.AcganGenerator(32)), (PM.AcganDiscriminator(32), OM.AcganDiscriminator(32))]
     for a, b in pairs:
         sa, sb = a.state_dict(), b.state_dict()
         assert list(sa.keys()) == list(sb.keys())

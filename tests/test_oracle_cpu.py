@@ -207,6 +207,21 @@ def test_conv_critic_penalties_against_reference_fixture(golden_dir):
     assert dict(M.StarganDiscriminator((3, 32, 32), 5, 4).named_parameters())["out2.weight"].shape == (5, 512, 2, 2)
 
 
+def test_acgan_loop_against_reference_fixture(golden_dir):
+    """acgan.py:46-107,167-222 restated: three iterations reproduce the losses recorded with the reference's own Generator /
+    Discriminator classes inside the loop (same images, labels, z, generated labels and Dropout2d masks)."""
+    gold = load_golden(golden_dir, "acgan_32_loop")
+    _seed(0)
+    s = S.make_acgan(32)
+    n = int(gold["masks_per_step"])
+    for t in range(3):
+        masks = [gold["mask_%d_%02d" % (t, i)] for i in range(n)]
+        with M.feed_masks(masks=masks):
+            o = S.acgan_step(s, torch.from_numpy(gold["imgs"][t]), torch.from_numpy(gold["labels"][t]),
+                             torch.from_numpy(gold["zs"][t]), torch.from_numpy(gold["gen_labels"][t]))
+        assert abs(float(o["g_loss"]) - gold["trace"][t][0]) <= 1e-6 and abs(float(o["d_loss"]) - gold["trace"][t][1]) <= 1e-6, t
+
+
 def test_loop_traces_against_reference_fixture(golden_dir):
     """The restated loops, driven from the same seeds, reproduce the traces recorded with the REAL reference
     modules inside the same loop (dcgan 3 steps, wgan_gp 6 critic iterations, cyclegan 3 steps)."""

@@ -346,6 +346,37 @@ def test_esrgan_steps():
     assert rel_fro(sr, want) < 1e-5
 
 
+def test_acgan_steps(golden_dir):
+    """SURVEY.md 8f F2 (acgan.py:167-222): Embedding * noise generator, two-headed discriminator (Sigmoid validity, Softmax
+    classes fed to CrossEntropyLoss as the reference does), three iterations from the fixture's inputs and Dropout2d masks
+    against the losses recorded with the REAL reference classes and against the oracle's weights."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+    from util import load_golden
+
+    gold = load_golden(golden_dir, "acgan_32_loop")
+    _seed(0)
+    s_cpu = S.make_acgan(32)
+    s_gpu = steps.make_acgan_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=False)
+    n = int(gold["masks_per_step"])
+    for t in range(3):
+        masks = [gold["mask_%d_%02d" % (t, i)] for i in range(n)]
+        ins = [torch.from_numpy(gold[k][t]) for k in ("imgs", "labels", "zs", "gen_labels")]
+        with M.feed_masks(masks=masks):
+            o_c = S.acgan_step(s_cpu, *ins)
+        with pg.dropout_masks(masks):
+            o_g = steps.acgan_step(s_gpu, *[x.to(DEV) for x in ins])
+        for j, k in enumerate(("g_loss", "d_loss")):
+            _loss_close(o_g[k], gold["trace"][t][j], "%s step %d vs the reference trace" % (k, t), 2e-4)
+            _loss_close(o_g[k], o_c[k], "%s step %d vs the oracle" % (k, t), 2e-4)
+        if t == 0:
+            assert rel_fro(o_g["gen_imgs"], o_c["gen_imgs"]) < 2e-5
+    _params_close(s_gpu.G, s_cpu.G, 3, "acgan G")
+    _params_close(s_gpu.D, s_cpu.D, 3, "acgan D")
+
+
 def test_bench_config_one_step_matches_oracle():
     """BASELINE.json configs[1] at FULL size (DCGAN 64x64, batch 128): one step against the oracle, plus
     size-independent properties: valid/fake labels are exact 1/0, generator output is bounded by tanh."""
