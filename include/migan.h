@@ -288,7 +288,7 @@ int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3
 /* Multi-tensor migan_permute4d: one launch for a table of permute copies (all weight packs of a training step).
  * entries: device array of { const float* src; float* dst; unsigned o1, o2, o3, pad; long long s[4]; long long n; } (72 bytes):
  * dst is contiguous with extents (n/(o1*o2*o3), o1, o2, o3) and dst[i0][i1][i2][i3] = src[i0*s[0] + i1*s[1] + i2*s[2] + i3*s[3]];
- * blocks: device array of { int entry; int chunk; }, ceil(n / 4096) consecutive chunks per entry. */
+ * blocks: device array of { int entry; int chunk; }, ceil(n / 1024) consecutive chunks per entry. */
 int migan_multi_permute4d(const void* entries, const void* blocks, int nblocks, void* stream);
 
 /* ---- Input pipeline on the device (csrc/image_pipeline.hip) ------------------------------

@@ -276,7 +276,7 @@ class _PackPlan:
                 st = (d[1] * d[2] * d[3], d[2] * d[3], d[3], 1)
                 ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, (d[perm[1]], d[perm[2]], d[perm[3]], 0),
                           tuple(st[q] for q in perm), n)
-                blocks += [(i, c) for c in range((n + 4095) // 4096)]
+                blocks += [(i, c) for c in range((n + 1023) // 1024)]
                 off += n
             self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
             self.blk = torch.tensor(blocks, dtype=torch.int32).to(device)
