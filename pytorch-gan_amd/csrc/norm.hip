@@ -126,10 +126,9 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                 b += red[1][(y * CTX + tx) * VW + v];
                 if (BWD) c2 += red[2][(y * CTX + tx) * VW + v];
             }
-            // chunk-minor layout [g][c][chunk][3]: the finalize wave of (g, c) then reads one contiguous run instead of nchunks
-            // words scattered C*12 bytes apart (1024 chunks on the DCGAN generator tensors: 6.9 us per finalize launch,
-            // 24 launches per step, profiles/r02_final_dcgan_kernel_stats.txt)
-            size_t o = (((size_t)g * C + c + v) * nchunks + ck) * 3;
+            // (a chunk-minor layout - contiguous reads for the finalize wave, scattered writes here - was measured: finalize
+            // 6.9 -> 6.3 us, this kernel 13.4 -> 14.9 us; a wash, the finalize launches sit on the ~5 us small-kernel floor)
+            size_t o = (((size_t)g * nchunks + ck) * C + c + v) * 3;
             part[o] = a;
             part[o + 1] = b;
             part[o + 2] = BWD ? c2 : shift[v];
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
     const int g = i / C, c = i - g * C;
     double sd = 0.0, sq = 0.0;
     for (int k = lane; k < nchunks; k += 64) {
-        size_t o = (((size_t)g * C + c) * nchunks + k) * 3;
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
         sd += (double)part[o];
         sq += (double)part[o + 1];
     }
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __r
     }
     if (lane != 0) return;
     if (i == 0 && nbt) nbt[0] += 1;  // BatchNorm's num_batches_tracked
-    const double K = (double)part[(((size_t)g * C + c) * nchunks) * 3 + 2];
+    const double K = (double)part[(((size_t)g * nchunks) * C + c) * 3 + 2];
     const double md = sd / P;
     double M2 = sq - sd * md;
     if (M2 < 0.0) M2 = 0.0;
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __r
     const int g = i / C, c = i - g * C;
     double a = 0.0, b = 0.0, s = 0.0;
     for (int k = lane; k < nchunks; k += 64) {
-        size_t o = (((size_t)g * C + c) * nchunks + k) * 3;
+        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
         a += (double)part[o];
         b += (double)part[o + 1];
         if (dslope_gc) s += (double)part[o + 2];
