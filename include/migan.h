@@ -181,14 +181,18 @@ int migan_norm_apply(const float* x, float* y, const float* mean, const float* i
                      void* stream);
 /* nn.BatchNorm2d -> nn.PReLU() (srgan/models.py:23-24,55-57; single learnable slope prelu_weight[0] on the device) fused:
  * forward in the apply launch; backward as migan_norm_bwd plus dprelu[0] (+)= sum dy*min(z,0) taken as a third sum of the
- * statistics pass - the PReLU layer costs no pass of its own over the tensor.  ws: migan_norm_workspace_prelu() bytes. */
+ * statistics pass - the PReLU layer costs no pass of its own over the tensor.  ws: migan_norm_workspace_prelu() bytes.
+ * shuffle_H, shuffle_W > 0 (0 = off): nn.PixelShuffle(2) between the two (srgan/models.py:55-57) as the STORE index map of the
+ * apply launch and the LOAD index map of dy in the backward launches: x is [N][H][W][C] (G = 1, P = N*H*W, C % 4 == 0, no
+ * residual), y and dy are [N][2H][2W][C/4]; prelu_weight may be NULL then (shuffle without PReLU). */
 int migan_norm_apply_prelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
-                           const float* beta, const float* res, const float* prelu_weight, int G, int P, int C, void* stream);
+                           const float* beta, const float* res, const float* prelu_weight, int G, int P, int C, int shuffle_H,
+                           int shuffle_W, void* stream);
 size_t migan_norm_workspace_prelu(int G, int P, int C);
 int migan_norm_bwd_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const float* prelu_weight, float* dx, float* dgamma, float* dbeta, float* dprelu,
                          int G, int P, int C, float* ws, size_t ws_bytes, int accumulate, int dprelu_accumulate, float* csum,
-                         void* stream);
+                         int shuffle_H, int shuffle_W, void* stream);
 /* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1.
  * csum (optional): migan_norm_colsum_slabs(G,P,C) x [C] per-block column sums of dx - the bias gradient of the conv in
  * front of the norm layer is reduced from them inside that conv's wgrad launch (migan_conv2d_wgrad db_slabs). */

@@ -76,9 +76,9 @@ _SIGS = {
     "migan_thin_toeplitz_dgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 10 + [P]),
     "migan_resample_u8": (c_int, [P, P, P, P] + [c_int] * 7 + [P]),
     "migan_u8_to_f32": (c_int, [P] * 6 + [c_int] * 7 + [P]),
-    "migan_norm_apply_prelu": (c_int, [P] * 8 + [c_int] * 3 + [P]),
+    "migan_norm_apply_prelu": (c_int, [P] * 8 + [c_int] * 5 + [P]),
     "migan_norm_workspace_prelu": (c_size_t, [c_int] * 3),
-    "migan_norm_bwd_prelu": (c_int, [P] * 11 + [c_int] * 3 + [P, c_size_t, c_int, c_int, P, P]),
+    "migan_norm_bwd_prelu": (c_int, [P] * 11 + [c_int] * 3 + [P, c_size_t, c_int, c_int, P, c_int, c_int, P]),
     "migan_multi_permute4d": (c_int, [P, P, c_int, P]),
     "migan_batch_mean_axpy": (c_int, [P, P, P, c_int, c_size_t, c_float, c_float, P]),
     "migan_skinny_tn_ok": (c_int, [c_int] * 3),

@@ -52,6 +52,16 @@ __device__ __forceinline__ bool map_coord(int v, int L, int mode, int& src) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
+static inline void fastdiv_magic(unsigned d, unsigned& m, int& s) {
+    s = 0;
+    while ((1ull << s) < d) ++s;
+    m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+__device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
+    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
+}
+
 #define HIP_LAUNCH_CHECK()                         \
     do {                                           \
         hipError_t e__ = hipGetLastError();        \

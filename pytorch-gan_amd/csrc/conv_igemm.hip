@@ -59,15 +59,6 @@ struct ConvGeom {
     short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
 };
 
-// q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
-static void fastdiv_magic(unsigned d, unsigned& m, int& s) {
-    s = 0;
-    while ((1ull << s) < d) ++s;
-    m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
-}
-__device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
-    return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
-}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, int VAR = 0>
 __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,

@@ -8,6 +8,35 @@
 // G=N,P=H*W.  All kernels are HBM-bound; loads are 16 B/lane when C%4==0.
 #include "common.h"
 
+// nn.PixelShuffle(2) behind the normalisation (srgan/models.py:53-57: Conv -> BatchNorm2d -> PixelShuffle -> PReLU) as the
+// STORE index map of the apply kernel and the LOAD index map of dy in the backward kernels: a thread's 4 consecutive channels
+// c = 4*co + 2*i + j of input pixel (n, h, w) are channel co of the 4 output pixels (n, 2h+i, 2w+j) - per instruction the
+// lanes of a wave (consecutive co) still touch consecutive addresses.  No shuffled copy of the 604 MB tensor in either
+// direction.  on == 0: plain [g][p][c] indexing.
+struct PShuf {
+    int on, H, W, Co;
+    unsigned mg_hw, mg_w;
+    int sh_hw, sh_w;
+};
+__device__ __forceinline__ size_t pshuf_base(const PShuf& s, int p, int co) {  // element index of (i, j) = (0, 0)
+    const int n = fastdiv(p, s.mg_hw, s.sh_hw);
+    const int rem = p - n * s.H * s.W;
+    const int h = fastdiv(rem, s.mg_w, s.sh_w), w = rem - h * s.W;
+    return ((size_t)(n * 2 * s.H + 2 * h) * (2 * s.W) + 2 * w) * s.Co + co;
+}
+__device__ __forceinline__ size_t pshuf_off(const PShuf& s, int k) {  // offset of sub-pixel k = 2*i + j from pshuf_base
+    return ((size_t)(k >> 1) * (2 * s.W) + (k & 1)) * s.Co;
+}
+static PShuf pshuf_make(int H, int W, int C) {
+    PShuf s = {};
+    if (H > 0 && W > 0) {
+        s.on = 1; s.H = H; s.W = W; s.Co = C / 4;
+        fastdiv_magic((unsigned)(H * W), s.mg_hw, s.sh_hw);
+        fastdiv_magic((unsigned)W, s.mg_w, s.sh_w);
+    }
+    return s;
+}
+
 // Per-block column sums: thread (tx, ty) holds the sums of its VW channels over its pixel lane; the ty lanes are added
 // in a fixed order through LDS and lane ty == 0 writes slab[(g * gridDim.y + chunk)][c .. c+VW).
 template <int VW>
@@ -40,7 +69,7 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            float* __restrict__ part, int P, int C, int CTX,
                                                            int chunk, int nchunks, int act, float slope,
-                                                           const float* __restrict__ slope_ptr) {
+                                                           const float* __restrict__ slope_ptr, const PShuf ps) {
     // slope_ptr (backward only): nn.PReLU()'s single learnable slope (srgan/models.py:24,57) fused behind the norm -
     // LeakyReLU with the slope read from the device, plus a third sum per (g, chunk, c): sum dy * min(z, 0) = d(loss)/d(slope)
     __shared__ float red[BWD ? 3 : 2][256 * VW];
@@ -84,8 +113,14 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                 f32x4 t = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
                 xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
                 if (BWD) {
-                    f32x4 d = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + c);
-                    dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2]; dv[3] = d[3];
+                    if (ps.on) {
+                        const size_t q = pshuf_base(ps, p, c >> 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dv[k] = dy[q + pshuf_off(ps, k)];
+                    } else {
+                        f32x4 d = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + c);
+                        dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2]; dv[3] = d[3];
+                    }
                 }
             } else {
                 xv[0] = xb[(size_t)p * C + c];
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ res, int P, int C, int CTX,
                                                          int chunk, int act, float slope,
-                                                         const float* __restrict__ slope_ptr) {
+                                                         const float* __restrict__ slope_ptr, const PShuf ps) {
     if (slope_ptr) {  // fused nn.PReLU(): LeakyReLU with the learnable slope read from the device
         slope = *slope_ptr;
         act = ACT_LRELU;
@@ -265,7 +300,13 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act, slope) + r[k];
-            *reinterpret_cast<f32x4*>(y + e) = o;
+            if (ps.on) {
+                const size_t q = pshuf_base(ps, p, c >> 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[q + pshuf_off(ps, k)] = o[k];
+            } else {
+                *reinterpret_cast<f32x4*>(y + e) = o;
+            }
         } else {
             y[e] = act_apply(fmaf(x[e], sc[0], sh[0]), act, slope) + (res ? res[e] : 0.f);
         }
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ sums, int P, int C, int CTX, int chunk, int act,
-    float slope, float invP, float* __restrict__ csum, const float* __restrict__ slope_ptr) {
+    float slope, float invP, float* __restrict__ csum, const float* __restrict__ slope_ptr, const PShuf ps) {
     __shared__ float red[256 * VW];
     if (slope_ptr) {
         slope = *slope_ptr;
@@ -312,9 +353,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(
         float xv[VW], dv[VW], ov[VW];
         if (VW == 4) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(x + e);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(dy + e);
+            if (ps.on) {
+                const size_t q = pshuf_base(ps, p, c >> 2);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; }
+                for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = dy[q + pshuf_off(ps, k)]; }
+            } else {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(dy + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xv[k] = a[k]; dv[k] = b[k]; }
+            }
         } else {
             xv[0] = x[e];
             dv[0] = dy[e];
@@ -438,10 +485,10 @@ static int norm_stats_impl(const float* x, float* mean, float* invstd, float* va
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr);
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr, PShuf{});
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr);
+                           nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr, PShuf{});
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
                        invstd, var_out, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps,
@@ -506,17 +553,18 @@ MIGAN_API int migan_norm_sync_finalize(const float* gathered, int world, long lo
 // y = act(norm(x)*gamma+beta) [+ res] with given statistics (train or eval).
 static int norm_apply_impl(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, const float* res, int G, int P, int C, int act, float slope,
-                           const float* slope_ptr, hipStream_t st) {
+                           const float* slope_ptr, hipStream_t st, const PShuf ps = PShuf{}) {
     if ((size_t)G * P * C == 0) return 0;
     int VW, CTX, chunk;
     dim3 grid;
     apply_plan(G, P, C, VW, CTX, chunk, grid);
+    if (ps.on && (VW != 4 || G != 1 || res)) return (int)hipErrorInvalidValue;
     if (VW == 4)
         hipLaunchKernelGGL((norm_apply_kernel<4>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
-                           CTX, chunk, act, slope, slope_ptr);
+                           CTX, chunk, act, slope, slope_ptr, ps);
     else
         hipLaunchKernelGGL((norm_apply_kernel<1>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
-                           CTX, chunk, act, slope, slope_ptr);
+                           CTX, chunk, act, slope, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -527,11 +575,15 @@ MIGAN_API int migan_norm_apply(const float* x, float* y, const float* mean, cons
 }
 // y = PReLU(norm(x)*gamma+beta) [+ res]: nn.BatchNorm2d -> nn.PReLU() of srgan/models.py:23-24,55-57 in the apply launch;
 // prelu_weight is the layer's single learnable slope on the device (num_parameters = 1)
+// shuffle_H, shuffle_W > 0: additionally nn.PixelShuffle(2) (srgan/models.py:56) - x is [N][H][W][C] with P = N*H*W, G = 1,
+// C % 4 == 0, no residual, and y is written as [N][2H][2W][C/4] (see PShuf); prelu_weight may then be NULL (shuffle only)
 MIGAN_API int migan_norm_apply_prelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                                      const float* beta, const float* res, const float* prelu_weight, int G, int P, int C,
-                                     void* stream) {
-    if (!prelu_weight) return (int)hipErrorInvalidValue;
-    return norm_apply_impl(x, y, mean, invstd, gamma, beta, res, G, P, C, ACT_LRELU, 0.f, prelu_weight, (hipStream_t)stream);
+                                     int shuffle_H, int shuffle_W, void* stream) {
+    const bool shuf = shuffle_H > 0 && shuffle_W > 0;
+    if ((!prelu_weight && !shuf) || (shuf && (P % (shuffle_H * shuffle_W) != 0))) return (int)hipErrorInvalidValue;
+    return norm_apply_impl(x, y, mean, invstd, gamma, beta, res, G, P, C, prelu_weight ? ACT_LRELU : ACT_NONE, 0.f, prelu_weight,
+                           (hipStream_t)stream, shuf ? pshuf_make(shuffle_H, shuffle_W, C) : PShuf{});
 }
 
 // Number of [C]-slabs of per-block column sums the streaming backward kernels (migan_norm_bwd / migan_norm_bwd_apply /
@@ -549,17 +601,18 @@ MIGAN_API int migan_norm_colsum_slabs(int G, int P, int C) {
 static int norm_bwd_sums_impl(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, float* sums, float* dgamma, float* dbeta, int G, int P, int C, int act,
                               float slope, float* ws, size_t ws_bytes, int accumulate, const float* slope_ptr,
-                              float* dslope_gc, hipStream_t st) {
+                              float* dslope_gc, hipStream_t st, const PShuf ps = PShuf{}) {
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     if (ws_bytes < (size_t)G * nchunks * C * 3 * sizeof(float)) return (int)hipErrorInvalidValue;
+    if (ps.on && (VW != 4 || G != 1)) return (int)hipErrorInvalidValue;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
         hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
-                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr);
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr, ps);
     else
         hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
-                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr);
+                           beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
                        dgamma, dbeta, G, C, nchunks, accumulate, dslope_gc);
@@ -580,18 +633,20 @@ MIGAN_API int migan_norm_bwd_sums(const float* x, const float* dy, const float* 
 // reduced inside its wgrad launch (migan_conv2d_wgrad db_slabs).
 static int norm_bwd_apply_impl(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const float* sums, int G, int P, int C, int act,
-                               float slope, long long P_total, float* csum, const float* slope_ptr, hipStream_t st) {
+                               float slope, long long P_total, float* csum, const float* slope_ptr, hipStream_t st,
+                               const PShuf ps = PShuf{}) {
     if ((size_t)G * P * C == 0) return 0;
     int VW, CTX, chunk;
     dim3 grid;
     apply_plan(G, P, C, VW, CTX, chunk, grid);
+    if (ps.on && (VW != 4 || G != 1)) return (int)hipErrorInvalidValue;
     const float invP = (float)(1.0 / (double)(P_total > 0 ? P_total : P));
     if (VW == 4)
         hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr);
+                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr, ps);
     else
         hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
-                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr);
+                           sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -627,21 +682,25 @@ MIGAN_API size_t migan_norm_workspace_prelu(int G, int P, int C) {
 MIGAN_API int migan_norm_bwd_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, const float* prelu_weight, float* dx, float* dgamma, float* dbeta,
                                    float* dprelu, int G, int P, int C, float* ws, size_t ws_bytes, int accumulate,
-                                   int dprelu_accumulate, float* csum, void* stream) {
-    if (!prelu_weight || ws_bytes < migan_norm_workspace_prelu(G, P, C)) return (int)hipErrorInvalidValue;
+                                   int dprelu_accumulate, float* csum, int shuffle_H, int shuffle_W, void* stream) {
+    const bool shuf = shuffle_H > 0 && shuffle_W > 0;
+    if ((!prelu_weight && !shuf) || ws_bytes < migan_norm_workspace_prelu(G, P, C)) return (int)hipErrorInvalidValue;
+    const PShuf ps = shuf ? pshuf_make(shuffle_H, shuffle_W, C) : PShuf{};
+    const int act_ = prelu_weight ? ACT_LRELU : ACT_NONE;
     hipStream_t st = (hipStream_t)stream;
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     float* sums = ws + (size_t)G * nchunks * C * 3;
     float* dsl = ws + migan_norm_workspace(G, P, C) / sizeof(float);
-    int rc = norm_bwd_sums_impl(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, ACT_LRELU, 0.f, ws,
-                                migan_norm_workspace(G, P, C), accumulate, prelu_weight, dprelu ? dsl : nullptr, st);
+    int rc = norm_bwd_sums_impl(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, act_, 0.f, ws,
+                                migan_norm_workspace(G, P, C), accumulate, prelu_weight,
+                                (dprelu && prelu_weight) ? dsl : nullptr, st, ps);
     if (rc) return rc;
-    if (dprelu) {
+    if (dprelu && prelu_weight) {
         hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, st, dsl, G * C, dprelu, dprelu_accumulate);
         HIP_LAUNCH_CHECK();
     }
-    return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, ACT_LRELU, 0.f, P, csum, prelu_weight, st);
+    return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act_, 0.f, P, csum, prelu_weight, st, ps);
 }
 
 // Backward of `act [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y) (mask may

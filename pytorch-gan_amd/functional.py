@@ -1134,13 +1134,19 @@ class _Norm(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
-                slope, nbt=None, prelu=None):
+                slope, nbt=None, prelu=None, shuffle=0):
         # prelu: the weight of an nn.PReLU() (one shared slope) behind the norm layer (srgan/models.py:23-24,55-57): applied in
         # the norm's apply launch, differentiated inside the norm's backward launches (csrc/norm.hip)
+        # shuffle = 2: nn.PixelShuffle(2) between the two (srgan/models.py:55-57): the output is written - and its gradient
+        # read - through the shuffle's index map; no shuffled copy exists in either direction
         ctx.prelu = prelu
         pw = _plain(prelu)
         if pw is not None and (pw.numel() != 1 or act != ACT_NONE):
             raise ValueError("norm: fused PReLU needs num_parameters == 1 and no other fused activation")
+        if shuffle not in (0, 2) or (shuffle and (x.dim() != 4 or instance or res is not None or act != ACT_NONE
+                                                 or x.shape[1] % 4 != 0)):
+            raise ValueError("norm: fused PixelShuffle is upscale_factor 2 behind a BatchNorm2d with C % 4 == 0")
+        ctx.shuffle = None
         xs = canon(x)
         # an NCHW-contiguous input (e.g. `out.view(B, 128, s, s)`, dcgan.py:68) gets its gradient back in NCHW through
         # the HIP transpose, instead of autograd's ViewBackward materialising it with an ATen strided copy
@@ -1187,15 +1193,21 @@ class _Norm(Function):
             invstd = torch.empty_like(mean)  # eval mode: invstd = 1/sqrt(running_var + eps)
             check(lib.migan_rsqrt_eps(_plain(running_var).data_ptr(), invstd.data_ptr(), C, eps, st), "rsqrt_eps")
         rs = canon(res) if res is not None else None
-        y = torch.empty_like(xs)
-        if pw is None:
+        if shuffle:
+            y = _empty_nhwc((N, C // 4, 2 * H, 2 * W), xs)
+            ctx.shuffle = (H, W)
+        else:
+            y = torch.empty_like(xs)
+        if pw is None and not shuffle:
             check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                        _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
         else:
             if sync is not None:
-                raise NotImplementedError("norm: fused PReLU under cross-replica BatchNorm (nn.Sequential does not fuse it)")
+                raise NotImplementedError("norm: fused PReLU / PixelShuffle under cross-replica BatchNorm (nn.Sequential does "
+                                          "not fuse them then)")
+            sh, sw = ctx.shuffle or (0, 0)
             check(lib.migan_norm_apply_prelu(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                             _ptr(beta), _ptr(rs), pw.data_ptr(), G, P, C, st), "norm_apply_prelu")
+                                             _ptr(beta), _ptr(rs), _ptr(pw), G, P, C, sh, sw, st), "norm_apply_prelu")
         ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
         ctx.sync = sync
         # x itself is saved next to its dense copy: a differentiable backward (gradient penalties) needs the input WITH its
@@ -1210,8 +1222,8 @@ class _Norm(Function):
         if not batch_stats:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
         if torch.is_grad_enabled():
-            if ctx.prelu is not None:
-                raise NotImplementedError("double backward through a fused BatchNorm+PReLU is not on the reference path")
+            if ctx.prelu is not None or ctx.shuffle:
+                raise NotImplementedError("double backward through a fused BatchNorm [+PixelShuffle] +PReLU is not on the reference path")
             return _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in)
         dy = canon(dy)
         dx = torch.empty_like(xs)
@@ -1234,16 +1246,17 @@ class _Norm(Function):
             slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
         st = _stream()
         dprelu = None
-        if ctx.prelu is not None:
+        if ctx.prelu is not None or ctx.shuffle:
             pw = _plain(ctx.prelu)
-            pslot = _grad_slot(ctx.prelu) if ctx.needs_input_grad[13] else None
-            want_dp = ctx.needs_input_grad[13]
+            want_dp = pw is not None and ctx.needs_input_grad[13]
+            pslot = _grad_slot(ctx.prelu) if want_dp else None
+            sh, sw = ctx.shuffle or (0, 0)
             dpt = pslot if pslot is not None else (torch.empty(1, device=xs.device, dtype=torch.float32) if want_dp else None)
             nbp = lib.migan_norm_workspace_prelu(G, P, C)
             wsp = _ws(nbp, xs)
             check(lib.migan_norm_bwd_prelu(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                           _ptr(beta), pw.data_ptr(), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
-                                           wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, _ptr(slabs), st),
+                                           _ptr(beta), _ptr(pw), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
+                                           wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, _ptr(slabs), sh, sw, st),
                   "norm_bwd_prelu")
             if want_dp and pslot is None:
                 dprelu = dpt.view(ctx.prelu.shape)
@@ -1268,7 +1281,7 @@ class _Norm(Function):
             dx = to_nchw(dx)
         elif slabs is not None:
             _attach_colsum(dx, slabs, nslab, C)
-        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, dprelu
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, dprelu, None
 
 
 class _NormBwdFn(Function):
@@ -1345,15 +1358,16 @@ def _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in):
             check(lib.migan_norm_bwd_sums(xs.data_ptr(), gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                           _ptr(beta), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), G, P, C, ACT_NONE,
                                           0.0, ws.data_ptr(), nb, 0, _stream()), "norm_bwd_sums")
-    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None
+    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None, None
 
 
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
-         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None, prelu=None):
+         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0):
     """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself; `prelu`: weight of
-    an nn.PReLU() (single slope) applied behind the normalisation inside the same launches."""
+    an nn.PReLU() (single slope) applied behind the normalisation inside the same launches; `shuffle` = 2: nn.PixelShuffle(2)
+    as the store index map of the same launches (output (N, C/4, 2H, 2W))."""
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
-                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu)
+                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu, int(shuffle))
 
 
 # ---------------------------------------------------------------------------------------------- index remaps

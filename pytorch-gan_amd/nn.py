@@ -25,6 +25,7 @@ _FUSE = True
 
 
 _PRELU_FUSE = __import__("os").environ.get("MIGAN_NO_PRELU_FUSE", "0") != "1"  # A/B knob: 1 = PReLU as its own launches
+_SHUFFLE_FUSE = __import__("os").environ.get("MIGAN_NO_SHUFFLE_FUSE", "0") != "1"  # A/B knob: 1 = PixelShuffle as its own launches
 
 
 def set_fusion(enabled):
@@ -198,7 +199,7 @@ class Linear(tnn.Linear):
 
 
 class _BatchNormMixin:
-    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None, prelu=None):
+    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None, prelu=None, shuffle=0):
         if self.momentum is None:
             raise ValueError("BatchNorm: cumulative moving average (momentum=None) is not on the reference path")
         use_batch = self.training or not self.track_running_stats
@@ -209,7 +210,7 @@ class _BatchNormMixin:
             nbt = self.num_batches_tracked  # incremented by the statistics kernel (no separate aten::add launch)
         y = F.norm(x, self.weight if self.affine else None, self.bias if self.affine else None, res,
                    rm if (self.training or not use_batch) else None, rv if (self.training or not use_batch) else None,
-                   use_batch, self.momentum, self.eps, False, act, slope, nbt, prelu)
+                   use_batch, self.momentum, self.eps, False, act, slope, nbt, prelu, shuffle)
         return _wrap(y)
 
     def forward(self, x):
@@ -554,9 +555,12 @@ class Sequential(tnn.Sequential):
                         and (m.training or not m.track_running_stats) and not (F._SYNC_BN is not None and F._SYNC_BN.world > 1):
                     q = k + 1 if (k < n and type(mods[k]) is PixelShuffle) else k
                     if q < n and type(mods[q]) is PReLU and mods[q].num_parameters == 1:
-                        x = m.fused_forward(x, F.ACT_NONE, 0.0, None, mods[q].weight)
-                        if q > k:
-                            x = mods[k](x)
+                        if q > k and mods[k].upscale_factor == 2 and x.shape[1] % 4 == 0 and _SHUFFLE_FUSE:
+                            x = m.fused_forward(x, F.ACT_NONE, 0.0, None, mods[q].weight, 2)   # shuffle = store index map
+                        else:
+                            x = m.fused_forward(x, F.ACT_NONE, 0.0, None, mods[q].weight)
+                            if q > k:
+                                x = mods[k](x)
                         i = q + 1
                         continue
                 if res is not None and k == n and act == F.ACT_NONE and x.dim() == 4 and res.shape == x.shape:

@@ -131,8 +131,11 @@ def test_sequential_fusion_plan(monkeypatch):
         return torch.zeros(x.shape[0], w.shape[0], 2 * x.shape[2], 2 * x.shape[3])
 
     def norm(x, gamma=None, beta=None, res=None, rm=None, rv=None, use_batch_stats=True, momentum=0.1, eps=1e-5,
-             instance=False, act=0, slope=0.0, num_batches_tracked=None, prelu=None):
-        calls.append(("norm", bool(instance), act, float(eps), num_batches_tracked is not None) + (("prelu",) if prelu is not None else ()))
+             instance=False, act=0, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0):
+        calls.append(("norm", bool(instance), act, float(eps), num_batches_tracked is not None) + (("prelu",) if prelu is not None else ())
+                     + (("shuffle", shuffle) if shuffle else ()))
+        if shuffle:
+            return torch.zeros(x.shape[0], x.shape[1] // (shuffle * shuffle), x.shape[2] * shuffle, x.shape[3] * shuffle)
         return torch.zeros_like(x)
 
     def activation(x, act, slope=0.0):
@@ -181,7 +184,8 @@ def test_sequential_fusion_plan(monkeypatch):
     assert calls == [("conv2d", (2, 2, 1, 1), F.GATHER_ZERO, F.ACT_NONE, False)]
 
     # SRGAN residual block head and up-sampling stage (srgan/models.py:22-24, 53-57): the single-slope PReLU rides in the
-    # BatchNorm launches; behind a PixelShuffle it is applied BEFORE the shuffle (it commutes with the permutation)
+    # BatchNorm launches; a PixelShuffle(2) between them becomes the store index map of the same launches (PReLU commutes
+    # with the permutation)
     calls.clear()
     monkeypatch.setattr(F, "pixel_shuffle", lambda x, r: (calls.append(("shuffle", r)), torch.zeros(x.shape[0], x.shape[1] // (r * r), x.shape[2] * r, x.shape[3] * r))[1])
     monkeypatch.setattr(F, "prelu", lambda x, w: (calls.append(("prelu",)), torch.zeros_like(x))[1])
@@ -190,8 +194,12 @@ def test_sequential_fusion_plan(monkeypatch):
     y = blk(torch.zeros(2, 8, 4, 4))
     assert tuple(y.shape) == (2, 4, 8, 8)
     assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_NONE, False, "batch"), ("norm", False, F.ACT_NONE, 0.8, True, "prelu"),
-                     ("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_NONE, False, "batch"), ("norm", False, F.ACT_NONE, 1e-5, True, "prelu"),
-                     ("shuffle", 2)]
+                     ("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_NONE, False, "batch"),
+                     ("norm", False, F.ACT_NONE, 1e-5, True, "prelu", "shuffle", 2)]
+    # other upscale factors keep the shuffle as its own launch behind the fused BatchNorm+PReLU
+    calls.clear()
+    y = nn.Sequential(nn.BatchNorm2d(18), nn.PixelShuffle(upscale_factor=3), nn.PReLU())(torch.zeros(2, 18, 4, 4))
+    assert tuple(y.shape) == (2, 2, 12, 12) and calls == [("norm", False, F.ACT_NONE, 1e-5, True, "prelu"), ("shuffle", 3)]
     # a per-channel PReLU (num_parameters = C) is not the reference's layer: stays a separate launch
     calls.clear()
     nn.Sequential(nn.BatchNorm2d(8), nn.PReLU(8))(torch.zeros(2, 8, 4, 4))

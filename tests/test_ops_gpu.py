@@ -434,6 +434,35 @@ def test_batchnorm_prelu_fused(pg, cfg):
         assert_close(rg.grad, r.grad, 1e-7, "bn+prelu residual grad")
 
 
+@pytest.mark.parametrize("cfg", [(3, 16, 5, 7, True), (2, 256, 12, 12, True), (2, 8, 6, 4, False)])
+def test_batchnorm_shuffle_prelu_vs_torch(pg, cfg):
+    """BatchNorm2d -> PixelShuffle(2) -> PReLU (srgan/models.py:55-57) with the shuffle as the store / gradient-load index map of
+    the norm launches, against torch's three ops; ragged H != W; and the shuffle alone (no PReLU)."""
+    N, C, H, W, with_prelu = cfg
+    F = pg.functional
+    x = (_leaf(N, C, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
+    gamma = (_leaf(C, seed=2) * 0.5 + 1.0).requires_grad_(True)
+    beta = (_leaf(C, seed=3) * 0.5).requires_grad_(True)
+    a = torch.tensor([0.25], requires_grad=True)
+    y_ref = TF.pixel_shuffle(TF.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5), 2)
+    if with_prelu:
+        y_ref = TF.prelu(y_ref, a)
+    gy = _leaf(N, C // 4, 2 * H, 2 * W, seed=5)
+    y_ref.backward(gy)
+    xg, gg, bg, ag = (t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta, a))
+    y = F.norm(xg, gg, bg, None, None, None, True, 0.1, 1e-5, False, 0, 0.0, None, ag if with_prelu else None, 2)
+    assert y.shape == y_ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "bn+shuffle+prelu fwd")
+    pre = TF.batch_norm(x.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5)
+    keep = (pre.abs() > 1e-5).float() if with_prelu else torch.ones_like(pre)
+    assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "bn+shuffle+prelu dx")
+    assert_close(gg.grad, gamma.grad, 2e-5, "dgamma")
+    assert_close(bg.grad, beta.grad, 2e-5, "dbeta")
+    if with_prelu:
+        assert_close(ag.grad, a.grad, 2e-5, "dslope")
+
+
 def test_sequential_bn_shuffle_prelu_equals_unfused(pg):
     import copy
 
@@ -453,6 +482,7 @@ def test_sequential_bn_shuffle_prelu_equals_unfused(pg):
             outs.append((y.detach(), xin.grad, [p.grad.clone() for p in m.parameters()]))
         finally:
             pg.set_fusion(True)
+    assert outs[0][0].shape == (2, 16, 20, 20) and outs[0][0].is_contiguous(memory_format=torch.channels_last)
     assert_close(outs[0][0], outs[1][0], 2e-6, "bn->shuffle->prelu fwd, fused vs modules")
     assert_close(outs[0][1], outs[1][1], 2e-5, "input gradient")
     for ga, gb, (k, _) in zip(outs[0][2], outs[1][2], seq.named_parameters()):
