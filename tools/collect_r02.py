@@ -78,6 +78,8 @@ def main():
         ("gpu_run11: pack plan with the 1M-element cap (default), off, and uncapped", "r2k/packs_ab.txt"),
         ("gpu_run12: XCD-contiguous tile order of the forward/dgrad implicit GEMM (rejected, opt-in)", "r2l/xcd_ab.txt"),
         ("gpu_run13: BatchNorm+PReLU fusion (srgan lines: fused, then MIGAN_NO_PRELU_FUSE=1; twice)", "r2m/prelu_ab.txt"),
+        ("gpu_run16: dcgan after the 1024-element pack chunks (slow box)", "r2p/dcgan.txt"),
+        ("gpu_run17: PixelShuffle as the norm launches' index map (srgan, fused / MIGAN_NO_SHUFFLE_FUSE=1, twice)", "r2q/shuffle_ab.txt"),
         ("final run A/B", "final/ab.txt"),
     ])
     write("r02_tile_sweep.txt", [("MIGAN_IGEMM_TILE sweep over the layer shapes (gpu_run2)", "r2b/sweep_variants.txt")])
