@@ -434,6 +434,32 @@ def test_bench_two_ranks_on_one_gpu():
     assert all(np.isfinite(v) for v in res["losses"].values())
 
 
+def test_bench_cyclegan_strong_scaling_two_ranks_on_one_gpu():
+    """SURVEY.md 8e's data-parallel showcase (config 4: the global batch of cyclegan.py sharded over the ranks, InstanceNorm
+    shards exactly): bench.py --workload cyclegan --global-batch 2 with two ranks on the test box's single GPU (gloo) - three
+    optimisers' buckets all-reduced per step, per-rank device replay buffers, bit-identical replicas asserted by bench.py."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MIGAN_DP_BACKEND="gloo", MIGAN_DP_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cyclegan",
+           "--global-batch", "2", "--steps", "2", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 and res["scaling"] == "strong"
+    assert res["config"]["replicas_identical"] is True
+    assert all(np.isfinite(v) for v in res["losses"].values())
+
+
 def test_dragan_steps():
     """dragan.py:176-217: two iterations against the oracle, Dropout2d masks replayed, host draws
     (z, alpha, noise) shared; the discriminator is trained by the gradient penalty alone (reference quirk)."""
