@@ -41,6 +41,7 @@ struct ConvGeom {
     // parity-class dgrads lose 40 % (classes with 4/2/2/1 taps interleaved on one XCD), whole steps lose 2-3 % - the L2
     // misses of these kernels are served by the MALL and are not what limits them.  Default off.
     int swz, mtiles, ntn, per;
+    int prio;            // MIGAN_MFMA_PRIO=1 (A/B knob): s_setprio 1 while a wave is in its MFMA stream, 0 around the LDS fill
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void
             for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = ok ? rb[j][e] : 0.f;
         }
         __syncthreads();
+        if (g.prio) __builtin_amdgcn_s_setprio(1);
         if (kt + 1 < KT) {  // move the fetch position to tile kt+1 (the last iteration refetches a valid tile)
             if (TAPIN) {
                 if (NXT == 0) f_c0 += 32;  // the 4 taps of this chunk are done: next channel chunk
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // keep each load-issue slot between its neighbouring MFMA groups
         }
+        if (g.prio) __builtin_amdgcn_s_setprio(0);
     };
     if (TAPIN) {
         for (int kt = 0; kt < KT; kt += 4) {  // KT = 4 taps x K-tiles per tap
@@ -926,17 +929,23 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g_in.Co, BN), g_in.ncls);
+    static const int prio_env = getenv("MIGAN_MFMA_PRIO") ? atoi(getenv("MIGAN_MFMA_PRIO")) : 0;
     static const int xcd_env = getenv("MIGAN_IGEMM_XCD") ? atoi(getenv("MIGAN_IGEMM_XCD")) : 0;  // opt-in: measured no gain (profiles/r02_ab.txt)
     ConvGeom gs;
+    if (prio_env != 0 && xcd_env == 0) {
+        gs = g_in;
+        gs.prio = 1;
+    }
     if (xcd_env != 0) {
         gs = g_in;
+        gs.prio = prio_env != 0;
         gs.swz = 1;
         gs.mtiles = (int)grid.x;
         gs.ntn = (int)grid.y;
         gs.per = (gs.mtiles + 7) >> 3;
         grid = dim3((unsigned)(8 * gs.per * gs.ntn * gs.ncls), 1, 1);
     }
-    const ConvGeom& g = xcd_env != 0 ? gs : g_in;
+    const ConvGeom& g = (xcd_env != 0 || prio_env != 0) ? gs : g_in;
     // tap-inner K order: small tiles, every class exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad) and at
     // least 2 K-tiles per tap
     static const int tapin_env = getenv("MIGAN_IGEMM_TAPIN") ? atoi(getenv("MIGAN_IGEMM_TAPIN")) : 1;
