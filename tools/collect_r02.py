@@ -52,6 +52,7 @@ def main():
         ("thin-N image-output convs: direct VALU kernels vs width-Toeplitz expansion (gpu_run6)", "r2f/mb_thin.txt"),
         ("128x64 tile at 5 workgroups/CU vs 4 (gpu_run8; MIGAN_IGEMM_OCC5)", "r2h/mb_occ5.txt"),
         ("XCD-contiguous tile order vs plain (gpu_run12; MIGAN_IGEMM_XCD)", "r2l/mb_xcd.txt"),
+        ("s_setprio around the MFMA stream vs none (gpu_run19; MIGAN_MFMA_PRIO)", "r2r/mb_prio.txt"),
         ("all shapes, final build (final run)", "final/conv_microbench.txt"),
     ])
     write("r02_ab.txt", [
@@ -80,6 +81,8 @@ def main():
         ("gpu_run13: BatchNorm+PReLU fusion (srgan lines: fused, then MIGAN_NO_PRELU_FUSE=1; twice)", "r2m/prelu_ab.txt"),
         ("gpu_run16: dcgan after the 1024-element pack chunks (slow box)", "r2p/dcgan.txt"),
         ("gpu_run17: PixelShuffle as the norm launches' index map (srgan, fused / MIGAN_NO_SHUFFLE_FUSE=1, twice)", "r2q/shuffle_ab.txt"),
+        ("gpu_run19: s_setprio 1 around the MFMA stream of igemm_pipe (MIGAN_MFMA_PRIO), first box", "r2r/prio_ab.txt"),
+        ("gpu_run20: the same, second box, order reversed and repeated", "r2s/prio_ab2.txt"),
         ("final run A/B", "final/ab.txt"),
     ])
     write("r02_tile_sweep.txt", [("MIGAN_IGEMM_TILE sweep over the layer shapes (gpu_run2)", "r2b/sweep_variants.txt")])
