@@ -122,6 +122,10 @@ int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int 
  * caller runs migan_conv2d_dgrad on the padded extent + migan_gather2d_bwd. */
 int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                 void* stream);
+/* Its second launch alone (dx must already hold the pad-1 input gradient of migan_conv2d_dgrad): a latency-bound launch of
+ * mostly tiny workgroups that a caller may overlap with independent work on another stream. */
+int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                                     void* stream);
 
 /* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
  * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz

@@ -1673,11 +1673,26 @@ MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const flo
 //             are the conv taps that reach the ring: 3 taps per edge pixel, 7 per corner, ~1 % of the work of launch 1.
 // Returns hipErrorInvalidValue for geometries outside this case (caller uses migan_conv2d_dgrad + migan_gather2d_bwd).
 // ------------------------------------------------------------------------------------------------
+static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                               void* stream);
 MIGAN_API int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci,
                                           int Co, void* stream) {
     if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
     int rc = migan_conv2d_dgrad(dy, w_ihwo, nullptr, dx, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.f, stream);
     if (rc) return rc;
+    return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream);
+}
+// The second launch of migan_conv2d_dgrad_reflect1 alone: ADDS the mirrored-ring terms onto a dx that already holds the
+// pad-1 input gradient (migan_conv2d_dgrad(..., 3, 3, 1, 1, 1, ...)).  It is 512 mostly tiny workgroups whose critical path is
+// the 7-tap corner classes (56 dependent K-tiles, 64 us at 2 workgroups per CU): a caller with other independent work for
+// the chip - the weight gradient of the same layer - can put this launch on a second stream (functional.py does).
+MIGAN_API int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci,
+                                               int Co, void* stream) {
+    if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
+    return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream);
+}
+static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                               void* stream) {
     ConvGeom g = {};
     g.N = N; g.Hi = H; g.Wi = W; g.Ci = Co; g.HiL = H; g.WiL = W;  // source = dy (same extent as dx for 3x3 / pad 1)
     g.Co = Ci; g.HoF = H; g.WoF = W; g.ostep = 1; g.istride = 1; g.gather = GATHER_ZERO; g.ldw = 9 * Co;

@@ -523,6 +523,13 @@ class _Conv2d(Function):
         if ctx.toep:
             return _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db)
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        # ReflectionPad2d(1)+Conv3x3 with both gradients wanted: the input gradient's main launch goes FIRST, its ring
+        # correction (a latency-bound launch of tiny workgroups, 64 us on CycleGAN's R256) runs on the side stream underneath
+        # the weight-gradient launch that follows on this stream
+        ring = None
+        if (_RING_OVERLAP and not fork.on and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _reflect1_applies(ctx.geom)
+                and not torch.cuda.is_current_stream_capturing()):
+            dx, ring = _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=True)
         with fork:
             st = _stream()
             if ctx.needs_input_grad[1]:
@@ -544,23 +551,47 @@ class _Conv2d(Function):
                     dw = None
             if want_db:
                 db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
-        if ctx.needs_input_grad[0]:
+        if ring is not None:
+            ring()   # this stream waits for the ring correction before dx leaves the Function
+        elif ctx.needs_input_grad[0]:
             dx = _conv2d_dgrad_raw(ctx, dy, xs, w)
         fork.join()
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def _conv2d_dgrad_raw(ctx, dy, xs, w):
-    """Input gradient of _Conv2d on the generic kernels (dy already through the activation backward)."""
+_RING_OVERLAP = __import__("os").environ.get("MIGAN_RING_OVERLAP", "1") == "1"  # A/B knob
+
+
+def _reflect1_applies(geom):
+    N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = geom
+    return (gather == GATHER_REFLECT and _REFLECT1 and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
+            and H >= 4 and W >= 4 and Co % 4 == 0 and Co >= 8 and Ci > 4)
+
+
+def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
+    """Input gradient of _Conv2d on the generic kernels (dy already through the activation backward).
+    ring_on_side (reflect-1 geometry only): returns (dx, join) - the pad-1 launch is queued on the current stream, the ring
+    correction on the side stream; join() makes the current stream wait for it."""
     N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
     st = _stream()
     wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
     dx = _empty_nhwc((N, Ci, H, W), xs)
+    if ring_on_side:
+        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.0,
+                                     st), "conv2d_dgrad")
+        main = torch.cuda.current_stream(xs.device)
+        key = (xs.device.index, main.cuda_stream)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(xs.device)
+        side = _SIDE_STREAMS[key]
+        side.wait_stream(main)
+        check(lib.migan_conv2d_dgrad_reflect1_ring(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, side.cuda_stream),
+              "conv2d_dgrad_reflect1_ring")
+        return dx, (lambda: main.wait_stream(side))
     if gather == GATHER_ZERO:
         check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
                                      Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
-    elif (gather == GATHER_REFLECT and _REFLECT1 and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
-          and H >= 4 and W >= 4 and Co % 4 == 0 and Co >= 8 and Ci > 4):
+    elif _reflect1_applies(ctx.geom):
         # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
         check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
               "conv2d_dgrad_reflect1")
