@@ -587,7 +587,12 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
         side.wait_stream(main)
         check(lib.migan_conv2d_dgrad_reflect1_ring(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, side.cuda_stream),
               "conv2d_dgrad_reflect1_ring")
-        return dx, (lambda: main.wait_stream(side))
+        # the closure keeps dy / wt alive until the join: they were allocated on `main`, and a tensor dropped before the
+        # side-stream launch has run would be handed to the next main-stream allocation (the wgrad workspace) under it
+        def join(_keep=(dy, wt, dx)):
+            main.wait_stream(side)
+
+        return dx, join
     if gather == GATHER_ZERO:
         check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
                                      Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
