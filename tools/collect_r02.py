@@ -83,6 +83,7 @@ def main():
         ("gpu_run17: PixelShuffle as the norm launches' index map (srgan, fused / MIGAN_NO_SHUFFLE_FUSE=1, twice)", "r2q/shuffle_ab.txt"),
         ("gpu_run19: s_setprio 1 around the MFMA stream of igemm_pipe (MIGAN_MFMA_PRIO), first box", "r2r/prio_ab.txt"),
         ("gpu_run20: the same, second box, order reversed and repeated", "r2s/prio_ab2.txt"),
+        ("gpu_run21: reflect-1 ring correction on a side stream under the wgrad (cyclegan, on / off, twice)", "r2t/ring_ab.txt"),
         ("final run A/B", "final/ab.txt"),
     ])
     write("r02_tile_sweep.txt", [("MIGAN_IGEMM_TILE sweep over the layer shapes (gpu_run2)", "r2b/sweep_variants.txt")])
