@@ -600,7 +600,12 @@ def main():
     if w.capture_error:
         result["config"]["hipgraph_error"] = w.capture_error[:200]
     if not args.no_roofline:
-        rf = roofline(w, rank, 5 if name in ("dcgan", "wgan_gp", "pix2pix") else 2)
+        try:
+            rf = roofline(w, rank, 5 if name in ("dcgan", "wgan_gp", "pix2pix") else 2)
+        except Exception as ex:  # the headline line must survive a failure of the per-kernel accounting
+            if world > 1:
+                raise          # ranks must stay in lock step (the eager profiling steps contain collectives)
+            rf = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         if rf:
             result["roofline"] = rf
     if world > 1:
