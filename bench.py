@@ -527,6 +527,13 @@ def cpu_baseline(init, seconds_budget=25.0):
                       % (n, BATCH, IMG, IMG, el, threads)}
 
 
+def _safe_cpu_baseline(init):
+    try:
+        return cpu_baseline(init)
+    except Exception as ex:  # reported baseline only: never at the price of the measured line
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
+
 def replicas_identical(w, world, dev):
     """Same initial weights + summed gradients -> same updates on every rank."""
     chk = torch.stack([torch.cat([p.detach().double().flatten() for p in m.parameters()]).abs().sum()
@@ -631,9 +638,9 @@ def main():
             torch.cuda.empty_cache()
         result["extra"] = extra
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(init)
+            result["cpu_baseline"] = _safe_cpu_baseline(init)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(w.init)
+        result["cpu_baseline"] = _safe_cpu_baseline(w.init)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
