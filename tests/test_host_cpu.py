@@ -92,6 +92,9 @@ def test_bench_flop_accounting_and_pmc_table():
     assert abs(bench.UPCONV_GFLOP_PER_IMG["cyclegan"] - 347.9) < 0.1
     assert abs(bench.executed_gflop_per_image("cyclegan") - (2097.99 - 347.9 * 20 / 36)) < 0.1
     assert bench.executed_gflop_per_image("srgan") == bench.GFLOP_PER_IMG["srgan"]
+    # esrgan.py defaults (hr 256, 23 RRDB): 3 G + 9 D + 3 VGG19[:35] forward-equivalents; G forward = 324.0, D 12.31, VGG 50.96 GFLOP
+    assert abs(bench.GFLOP_PER_IMG["esrgan"] - 1235.58) < 0.05
+    assert abs(bench.esrgan_flops_per_image(256, 23) / 1e9 - (3 * 324.00 + 9 * 12.308 + 3 * 50.96)) < 1.0
     s = bench.summarise("dcgan", 128, 1, 20, [0.08, 0.07, 0.09])
     assert s["ms_per_step"] == 4.0 and s["ms_per_step_min"] == 3.5 and s["blocks"] == 3
     assert abs(s["images_per_s"] - 32000.0) < 1e-6
