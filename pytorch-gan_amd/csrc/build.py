@@ -11,8 +11,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv_igemm.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "image_pipeline.hip"]
-HEADERS = ["common.h"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "image_pipeline.hip"]
+HEADERS = ["common.h", "conv_geom.h"]
 OUT = os.path.join(HERE, "libmigan.so")
 STAMP = os.path.join(HERE, ".libmigan.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,574 @@
+// LDS-DMA implicit-GEMM convolution for gfx950 (v_mfma_f32_32x32x2_f32): the main loop of the forward / input-gradient
+// conv kernels rebuilt on `buffer_load_dwordx4 ... lds` (16 B per lane straight from HBM/L2 into LDS, no staging
+// registers, no ds_write pass), two LDS stages, ONE barrier per K-tile, MFMA fragments by ds_read_b128 on an
+// XOR-swizzled, k-permuted image.  Same ConvGeom tap lists / parity classes / coordinate maps and the same epilogue as
+// igemm_pipe_kernel (conv_igemm.hip), which stays the path for shapes this kernel does not take.
+//
+// Reference call sites served: every Conv2d / ConvTranspose2d / conv input gradient with source channels % 4 == 0 and
+// >= 32 (dcgan.py:55,59; cyclegan/models.py:28-33,60,75,106-118; pix2pix/models.py:23,39; srgan/models.py:22,38,54,85).
+//
+// LDS image of one operand tile ([rows][BK = 32 floats], 8 chunks of 16 B per row): chunk (row, kc) lives at chunk index
+// row * 8 + (kc ^ ((row >> 1) & 7)).  The LDS-DMA writes lane l of instruction X at byte X * 1024 + l * 16 (wave-uniform
+// base + lane * 16 is the only destination form the hardware has), so lane l fetches row X * 8 + (l >> 3), chunk
+// kc = (l & 7) ^ f(row): the swizzle is applied on the per-lane SOURCE address and again on the read
+// (cdna_hip_programming.md rule 21).  A ds_read_b128 of one chunk column by 32 consecutive rows is then conflict-free
+// (its 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} touch 16 distinct 16-B slots of the 256-B bank row).
+// k-permutation: lanes 0-31 read chunk 2q, lanes 32-63 chunk 2q+1; MFMA step e of group q multiplies k = 8q + e (lower
+// half-wave) and k = 8q + 4 + e (upper) - any bijection of k is a valid order for a sum, and A and B use the same one.
+//
+// Zero padding, rows beyond M, columns beyond Co and the channel tail of a tap are all "offset outside the buffer":
+// the buffer descriptor's range check returns 0 for them, so the gather needs no select and no zero page.
+#include "conv_geom.h"
+#include <type_traits>
+#include <stdlib.h>
+
+#define DMA_SENT 0x80000000u  // voffset beyond any buffer this kernel accepts (tensors < 2 GiB)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p, unsigned bytes) {
+    // wave-uniform by construction (kernel arguments): no waterfall loop around the buffer ops
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// TAPS_IN: 1 = tap-outer K order (tap, then 32-channel chunks), 4 = channel-chunk outer / tap inner for classes of
+// exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad): the 4 taps' A tiles of one channel chunk overlap by all
+// but one pixel row/column and are fetched back to back (L2 hits) - see igemm_pipe_kernel.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int TAPS_IN, bool KTAIL, int OCC>
+__global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, const float* __restrict__ A,
+                                                             const float* __restrict__ Bw,
+                                                             const float* __restrict__ bias, float* __restrict__ C,
+                                                             unsigned a_bytes, unsigned b_bytes) {
+    constexpr int CPR = BK / 4;                 // 16-B chunks per row
+    constexpr int RPI = 64 / CPR;               // rows per DMA instruction (1 KiB)
+    constexpr int SH = CPR == 8 ? 1 : 2;        // swizzle: f(row) = (row >> SH) & (CPR - 1)
+    constexpr int NQ = BK / 8;                  // fragment groups (8 k values: 4 MFMA steps) per K-tile
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int IA = BM / RPI / 4, IB = BN / RPI / 4;  // DMA instructions per wave per K-tile
+    static_assert(BK == 32 || BK == 16, "BK");
+    static_assert(IA >= 1 && IB >= 1, "tile too small for the DMA mapping");
+    constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[2 * ST_FL];
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
+    const int M = g.N * Ho * Wo;
+    const int m0 = bx * BM, n0 = by * BN;
+    if (m0 >= M) return;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const __amdgpu_buffer_rsrc_t rA = dma_rsrc(A, a_bytes), rB = dma_rsrc(Bw, b_bytes);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tpt = KTAIL ? (Ci + BK - 1) / BK : Ci / BK;  // K-tiles per tap
+    const int KT = ntap * tpt;
+
+    // ---- DMA lane mapping: instruction X = wave * I + i covers rows X*RPI .. X*RPI+RPI-1; this lane: row X*RPI + lane / CPR,
+    // chunk kc = (lane % CPR) ^ f(row)
+    const int lrow = lane / CPR;
+    int a_base[IA], a_pos[IA], a_kc[IA];
+    unsigned rowok = 0;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int X = wave * IA + i;
+        const int m = m0 + X * RPI + lrow;
+        a_kc[i] = ((lane % CPR) ^ (((X * RPI + lrow) >> SH) & (CPR - 1))) * 4;
+        a_base[i] = 0;
+        a_pos[i] = 0;
+        if (m < M) {
+            const int n = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
+            const int rem = m - n * Ho * Wo;
+            const int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
+            a_base[i] = n * Hi * Wi;
+            a_pos[i] = ((oi * g.istride) << 16) | (oj * g.istride);
+            rowok |= 1u << i;
+        }
+    }
+    unsigned b_off[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int X = wave * IB + j;
+        const int n = n0 + X * RPI + lrow;
+        const int kc = ((lane % CPR) ^ (((X * RPI + lrow) >> SH) & (CPR - 1))) * 4;
+        b_off[j] = n < g.Co ? (unsigned)(n * g.ldw + kc) * 4u : DMA_SENT;
+    }
+    unsigned a_off[TAPS_IN][IA];  // byte offset of this lane's chunk of row i at channel 0 of the slot's tap (or DMA_SENT)
+    int f_wo[TAPS_IN];
+    auto setup_tap = [&](int t, unsigned (&aoff)[IA], int& wo) {
+        // wave-uniform index into the kernel-argument tables: scalar loads, and a provably uniform soffset for the DMA
+        const int dh = g.dh[tapbeg + t], dw = g.dw[tapbeg + t];
+        wo = g.wofs[tapbeg + t];
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            int ihs, iws;
+            bool ok = (rowok >> i) & 1u;
+            ok &= map_bf((a_pos[i] >> 16) + dh, g.HiL, Hi, mode, ihs);
+            ok &= map_bf((a_pos[i] & 0xffff) + dw, g.WiL, Wi, mode, iws);
+            aoff[i] = ok ? (unsigned)((a_base[i] + ihs * Wi + iws) * Ci + a_kc[i]) * 4u : DMA_SENT;
+        }
+    };
+    int f_t = 0, f_c0 = 0;  // fetch position: tap (tap-outer order) and channel chunk
+    // issue the DMA of the K-tile at the fetch position (tap slot `slot`) into LDS stage `st`
+    auto issue = [&](int st, int slot_rt, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        (void)slot_rt;
+        const unsigned soA = (unsigned)f_c0 * 4u, soB = (unsigned)(f_wo[SL] + f_c0) * 4u;
+        float* base = smem + st * ST_FL;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            unsigned vo = a_off[SL][i];
+            if (KTAIL) vo = (f_c0 + a_kc[i] < Ci) ? vo : DMA_SENT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(base + (wave * IA + i) * 256), 16, (int)vo, (int)soA,
+                                                     0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < IB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16,
+                                                     (int)b_off[j], (int)soB, 0, 0);
+    };
+
+    // ---- fragment read addresses: row = w * T * 32 + i * 32 + l31, chunk (2q + h) ^ f(l31)
+    const int fx = (l31 >> SH) & (CPR - 1);
+    int a_rd[NQ], b_rd[NQ];  // float offsets of the chunk groups q within a stage (tile i adds i * 32 * BK)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = ((2 * q + h) ^ fx) * 4;
+        a_rd[q] = (wm * (TM * 32) + l31) * BK + c;
+        b_rd[q] = A_FL + (wn * (TN * 32) + l31) * BK + c;
+    }
+
+    if (KT > 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < TAPS_IN; ++s_) setup_tap(s_, a_off[s_], f_wo[s_]);
+        issue(0, 0, std::integral_constant<int, 0>{});
+    }
+    auto advance = [&](auto nxt_c) {  // move the fetch position one K-tile on; NXT = tap slot of the new position
+        constexpr int NXT = decltype(nxt_c)::value;
+        if (TAPS_IN > 1) {
+            if (NXT == 0) f_c0 += BK;
+        } else {
+            f_c0 += BK;
+            if (KTAIL ? f_c0 >= Ci : f_c0 == Ci) {
+                f_c0 = 0;
+                setup_tap(++f_t, a_off[0], f_wo[0]);
+            }
+        }
+    };
+    auto k_tile = [&](int kt, auto nxt_c) {
+        constexpr int NXT = decltype(nxt_c)::value;
+        const int cur = kt & 1;
+        // tile kt is in LDS stage cur (DMA drained + barrier at the end of the previous iteration / prologue)
+        if (kt + 1 < KT) {
+            advance(nxt_c);
+            issue(cur ^ 1, 0, std::integral_constant<int, NXT>{});
+        }
+        const float* sb = smem + cur * ST_FL;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sb + a_rd[q] + i * 32 * BK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sb + b_rd[q] + j * 32 * BK);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // (the compiler drains the LDS-DMA queue, vmcnt(0), in front of the barrier)
+    };
+    if (KT > 0) __syncthreads();
+    if (TAPS_IN > 1) {
+        for (int kt = 0; kt < KT; kt += 4) {
+            k_tile(kt, std::integral_constant<int, 1 % TAPS_IN>{});
+            k_tile(kt + 1, std::integral_constant<int, 2 % TAPS_IN>{});
+            k_tile(kt + 2, std::integral_constant<int, 3 % TAPS_IN>{});
+            k_tile(kt + 3, std::integral_constant<int, 0>{});
+        }
+    } else {
+        for (int kt = 0; kt < KT; ++kt) k_tile(kt, std::integral_constant<int, 0>{});
+    }
+
+    // ---- epilogue (igemm_pipe_kernel's): bias + activation + optional [N][Co] mask, strided class scatter, accumulate
+    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + row;
+            if (m >= M) continue;
+            size_t opix;
+            int n_img = 0;
+            if (linear_out && !g.oscale) {
+                opix = (size_t)m;
+            } else {
+                n_img = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
+                const int rem = m - n_img * Ho * Wo;
+                const int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
+                opix = ((size_t)n_img * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (col < g.Co) {
+                    float v = acc[i][j][r];
+                    if (bias) v += bias[col];
+                    float o = act_apply(v, g.act, g.slope);
+                    if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
+                    if (g.accum) o += C[opix * g.Co + col];
+                    C[opix * g.Co + col] = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BK, int OCC>
+static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, unsigned a_bytes,
+                          unsigned b_bytes, long maxM, hipStream_t st) {
+    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
+    bool tapin = true;
+    for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
+    static const int tapin_env = getenv("MIGAN_DMA_TAPIN") ? atoi(getenv("MIGAN_DMA_TAPIN")) : 1;
+    tapin = tapin && tapin_env != 0;
+    const bool ktail = g.Ci % BK != 0;
+#define DMA_LAUNCH(TI_, KT_)                                                                                         \
+    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
+                       a_bytes, b_bytes)
+    if (tapin) {
+        if (ktail) DMA_LAUNCH(4, true); else DMA_LAUNCH(4, false);
+    } else {
+        if (ktail) DMA_LAUNCH(1, true); else DMA_LAUNCH(1, false);
+    }
+#undef DMA_LAUNCH
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tile choice for the LDS-DMA kernels.  Co-resident workgroups of a CU share its matrix pipes, so what matters is the
+// number of tiles a CU has to work through (T / 256, rounded up for the last CU to finish), the padding of the tile grid
+// and how dense a wave's MFMA stream is between two barriers (eff: 64 MFMAs per K-tile and wave for 128x128 / 256x64, 32
+// for 128x64, 16 for 64x64 and 128x32).  MIGAN_DMA_TILE=BBBNNN forces a tile (A/B knob).
+struct DmaCand { int bm, bn; double eff; };
+static const DmaCand kDmaCands[] = {{128, 128, 1.00}, {128, 64, 0.97}, {64, 64, 0.93}, {128, 32, 0.70}};
+static int dma_select(long maxM, int Co, int ncls) {
+    // MIGAN_DMA_TILE=KKBBBNNN forces a tile for launches with at least 256 such tiles (A/B knob)
+    static const int tile_env = getenv("MIGAN_DMA_TILE") ? atoi(getenv("MIGAN_DMA_TILE")) : 0;
+    if (tile_env) {
+        const int bm = (tile_env / 1000) % 1000, bn = tile_env % 1000;
+        if ((long)cdiv(maxM, bm) * cdiv(Co, bn) * ncls >= 256) return tile_env;
+    }
+    double best = -1.0, bestT = 0.0;
+    int code = 0;
+    for (const DmaCand& c : kDmaCands) {
+        const long tm = cdiv(maxM, c.bm), tn = cdiv(Co, c.bn);
+        const double T = (double)tm * tn * ncls;
+        const double util = ((double)maxM / (tm * c.bm)) * ((double)Co / (tn * c.bn));
+        const double per_cu = T / 256.0;
+        const double balance = per_cu / (double)(long)(per_cu + 0.999999);
+        const double score = c.eff * util * balance;
+        if (score > best * 1.0001) {
+            best = score;
+            bestT = T;
+            code = c.bm * 1000 + c.bn;
+        }
+    }
+    // BK = 16 halves the LDS stage: 4-8 instead of 2-5 workgroups per CU cover each other's barriers, prologues and
+    // epilogues (profiles/r03_dma_tile_sweep.txt: +4...13 % on every layer with >= 2 tiles per CU); a workgroup alone on
+    // its CU wants the longer MFMA run between barriers of BK = 32 (PatchGAN 256->512 @16x16: 87 vs 110 us)
+    const int bk = (bestT >= 512.0 && code != 128032) ? 16 : 32;
+    return bk * 1000000 + code;
+}
+
+// Returns -2 when this geometry is not taken by the LDS-DMA kernels (the caller falls through to igemm_pipe_kernel),
+// otherwise the launch status.
+int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
+    if (g.stats || g.swz) return -2;
+    if (g.Ci % 4 != 0 || g.Ci < 32 || g.ldw % 4 != 0 || g.Co <= 4) return -2;
+    for (int c = 0; c < g.ncls; ++c)
+        for (int t = 0; t < g.ntap[c]; ++t)
+            if (g.wofs[g.tapbeg[c] + t] % 4 != 0) return -2;
+    const size_t a_bytes = (size_t)g.N * g.Hi * g.Wi * g.Ci * 4, b_bytes = (size_t)g.Co * g.ldw * 4;
+    if (a_bytes >= 0x7ffffff0ull || b_bytes >= 0x7ffffff0ull) return -2;
+    long maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        const long m = (long)g.N * g.Ho[c] * g.Wo[c];
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return 0;
+    const unsigned ab = (unsigned)a_bytes, bb = (unsigned)b_bytes;
+    switch (dma_select(maxM, g.Co, g.ncls)) {
+#define DMA_CASE(BK_, BM_, BN_, WM_, WN_, OCC_) \
+    case BK_ * 1000000 + BM_ * 1000 + BN_:      \
+        return launch_dma_cfg<BM_, BN_, WM_, WN_, BK_, OCC_>(g, A, Bw, bias, C, ab, bb, maxM, st)
+        DMA_CASE(32, 128, 128, 2, 2, 2);
+        DMA_CASE(32, 128, 64, 2, 2, 3);
+        DMA_CASE(32, 64, 64, 2, 2, 5);
+        DMA_CASE(32, 128, 32, 4, 1, 4);
+        DMA_CASE(16, 128, 128, 2, 2, 4);
+        DMA_CASE(16, 128, 64, 2, 2, 5);
+        DMA_CASE(16, 64, 64, 2, 2, 8);
+#undef DMA_CASE
+        default: return -2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the same LDS-DMA main loop.  GEMM M = Co (rows of dy), N = taps*Ci (columns of the gathered x),
+// K = pixels; split-K slabs, XCD-aware block order, bias column sums and the slab layout are wgrad_inc_kernel's
+// (conv_igemm.hip), whose fixed-order reduction launch follows unchanged.
+//
+// LDS image of one K-tile: A [32 pixels][BM] and B [32 pixels][BN], rows contiguous - exactly what a DMA of NHWC data
+// produces (a lane fetches 16 B = 4 channels of one pixel; one instruction = 64/(B/4) whole pixel rows), no swizzle: the
+// MFMA fragment of k-pair kp is read along the ROW (lanes 0-31: 32 consecutive 4/8-byte items of pixel 2kp, lanes 32-63
+// of pixel 2kp+1 - conflict-free).  A ds_read_b64 feeds TWO row blocks: accumulator tile e of a wave holds the rows
+// co = base + 2*i + e (i = MFMA row), so the two floats a lane reads are the A operands of two MFMAs; columns alike.
+// Each wave owns the 8 consecutive pixels P0 + 8*wave .. +7 of a K-tile; with Wo % 8 == 0 they lie in one image row, so
+// the pixel decode (n, oi, oj) is WAVE-UNIFORM (scalar unit) and a lane's gather address is scalar base + lane constant.
+// Shapes with Wo % 8 != 0 (a few pixels per image: latency-bound anyway) stay on wgrad_inc_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int T> struct FragT;
+template <> struct FragT<1> { typedef float type; };
+template <> struct FragT<2> { typedef f32x2 type; };
+__device__ __forceinline__ float frag_get(float v, int) { return v; }
+__device__ __forceinline__ float frag_get(f32x2 v, int e) { return v[e]; }
+
+template <int BM, int BN, bool DYS, bool REFL, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, const float* __restrict__ X,
+                                                             const float* __restrict__ DY, float* __restrict__ part,
+                                                             unsigned x_bytes, unsigned dy_bytes) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int CPA = BM / 4, CPB = BN / 4;      // 16-B chunks per pixel row
+    constexpr int RPA = 64 / CPA, RPB = 64 / CPB;  // pixel rows per DMA instruction
+    constexpr int IA = 8 / RPA, IB = 8 / RPB;      // DMA instructions per wave per K-tile (8 pixel rows per wave)
+    constexpr int A_FL = BK * BM, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+    static_assert(TM >= 1 && TM <= 2 && TN >= 1 && TN <= 2, "tile shape");
+    __shared__ __attribute__((aligned(16))) float smem[2 * ST_FL];
+
+    const int tid = threadIdx.x;
+    const int T = g.R * g.S;
+    const int Ncol = T * g.Ci;
+    const int HoWo = g.Ho * g.Wo;
+    const int Mpix = g.N * HoWo;
+    int split, tile;  // XCD-aware block order, see wgrad_pipe_kernel
+    {
+        const int tiles = g.tiles_m * g.tiles_n;
+        const int total = tiles * g.splits, per = (total + 7) >> 3;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int lin = xcd * per + k;
+        if (k >= per || lin >= total) return;
+        split = lin / tiles;
+        tile = lin - split * tiles;
+    }
+    const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
+    const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
+    int p_end = p_begin + g.pix_per_split;
+    if (p_end > Mpix) p_end = Mpix;
+    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cls = DYS ? (int)blockIdx.y : 0;
+    const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
+    const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
+    const __amdgpu_buffer_rsrc_t rX = dma_rsrc(X, x_bytes), rD = dma_rsrc(DY, dy_bytes);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- lane constants of the DMA mapping
+    const int cqa = lane % CPA, pra = lane / CPA;
+    const int cqb = lane % CPB, prb = lane / CPB;
+    const bool a_colok = co0 + cqa * 4 < g.Co;
+    int a_lc[IA];  // byte offset of this lane's dy chunk relative to the group's first pixel
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+        const int pr = pra + j * RPA;
+        a_lc[j] = ((DYS ? 2 * pr : pr) * g.Co + co0 + cqa * 4) * 4;
+    }
+    int b_dh = 0, b_dw = 0, b_ci = 0;
+    bool b_colok = false;
+    {
+        const int col = nc0 + cqb * 4;
+        if (col < Ncol) {
+            const int t = col / g.Ci;
+            b_ci = col - t * g.Ci;
+            const int r = t / g.S, s_ = t - r * g.S;
+            b_dh = r - pad_t;
+            b_dw = s_ - pad_l;
+            b_colok = true;
+        }
+    }
+    int b_lc[IB];   // zero-pad gather: byte offset relative to the group's first source pixel (may be negative)
+    int b_dwp[IB];  // dw + pr * stride: column offset of this lane's pixel relative to the group's first source column
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+        const int pr = prb + j * RPB;
+        b_dwp[j] = b_dw + pr * g.stride;
+        b_lc[j] = ((b_dh * g.Wi + b_dwp[j]) * g.Ci + b_ci) * 4;
+    }
+
+    // issue the DMA of the K-tile whose first pixel is P0 into LDS stage st
+    auto issue = [&](int st, int P0) {
+        const int pg = P0 + 8 * wave;  // this wave's 8 pixels (one image row: Wo % 8 == 0), wave-uniform
+        const bool gok = pg < p_end;
+        const int pc = gok ? pg : 0;
+        const int n = fastdiv(pc, g.mg_hw, g.sh_hw);
+        const int rem = pc - n * HoWo;
+        const int oi = fastdiv(rem, g.mg_w, g.sh_w), oj = rem - oi * g.Wo;
+        float* base = smem + st * ST_FL;
+        const int ab = DYS ? ((n * g.dy_H + dy_oh0 + 2 * oi) * g.dy_W + dy_ow0 + 2 * oj) * g.Co * 4 : pc * g.Co * 4;
+#pragma unroll
+        for (int j = 0; j < IA; ++j) {
+            const unsigned vo = (gok && a_colok) ? (unsigned)(ab + a_lc[j]) : DMA_SENT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rD, (lds_void_t*)(base + (wave * IA + j) * 256), 16, (int)vo, 0, 0, 0);
+        }
+        const int ih = oi * g.stride + b_dh;
+        if (REFL) {
+            int ihr = ih < 0 ? -ih : ih;
+            ihr = ihr >= g.Hi ? 2 * g.Hi - 2 - ihr : ihr;
+            const int rowb = (n * g.Hi + ihr) * g.Wi;
+#pragma unroll
+            for (int j = 0; j < IB; ++j) {
+                int iw = oj * g.stride + b_dwp[j];
+                iw = iw < 0 ? -iw : iw;
+                iw = iw >= g.Wi ? 2 * g.Wi - 2 - iw : iw;
+                const unsigned vo = (gok && b_colok) ? (unsigned)(((rowb + iw) * g.Ci + b_ci) * 4) : DMA_SENT;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16, (int)vo,
+                                                         0, 0, 0);
+            }
+        } else {
+            const int xb = ((n * g.Hi + oi * g.stride) * g.Wi + oj * g.stride) * g.Ci * 4;
+            const bool okh = gok && b_colok && (unsigned)ih < (unsigned)g.Hi;
+#pragma unroll
+            for (int j = 0; j < IB; ++j) {
+                const bool ok = okh && (unsigned)(oj * g.stride + b_dwp[j]) < (unsigned)g.Wi;
+                const unsigned vo = ok ? (unsigned)(xb + b_lc[j]) : DMA_SENT;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16, (int)vo,
+                                                         0, 0, 0);
+            }
+        }
+    };
+
+    const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
+    float bsum = 0.f;
+    const int a_rd = h * BM + wm * (TM * 32) + TM * l31;
+    const int b_rd = A_FL + h * BN + wn * (TN * 32) + TN * l31;
+    typedef typename FragT<TM>::type fa_t;
+    typedef typename FragT<TN>::type fb_t;
+    if (KT > 0) {
+        issue(0, p_begin);
+        __syncthreads();
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) issue(cur ^ 1, p_begin + (kt + 1) * BK);
+        const float* sb = smem + cur * ST_FL;
+        if (bias_blk && tid < BM) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) s_ += sb[k * BM + tid];
+            bsum += s_;
+        }
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const fa_t a = *reinterpret_cast<const fa_t*>(sb + a_rd + kp * 2 * BM);
+            const fb_t b = *reinterpret_cast<const fb_t*>(sb + b_rd + kp * 2 * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_get(a, i), frag_get(b, j), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (bias_blk && tid < BM && co0 + tid < g.Co)
+        g.bpart[((size_t)cls * g.splits + split) * g.Co + co0 + tid] = bsum;
+    // slab [cls][split][co][col]; accumulator tile (e, e') of a wave: co = base + TM*i + e, col = base + TN*l31 + e'
+    float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
+#pragma unroll
+    for (int e = 0; e < TM; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = co0 + wm * (TM * 32) + TM * i + e;
+            if (co >= g.Co) continue;
+            const int col = nc0 + wn * (TN * 32) + TN * l31;
+            float* o = out + (size_t)co * Ncol + col;
+            if (TN == 2) {
+                if (col + 1 < Ncol) {
+                    f32x2 v = {acc[e][0][r], acc[e][TN - 1][r]};
+                    *reinterpret_cast<f32x2*>(o) = v;
+                } else if (col < Ncol) {
+                    o[0] = acc[e][0][r];
+                }
+            } else if (col < Ncol) {
+                o[0] = acc[e][0][r];
+            }
+        }
+}
+
+// Returns -2 when the LDS-DMA weight-gradient kernel does not take this geometry (caller: wgrad_inc_kernel).
+// bm / bn = the tile the caller's plan chose (128x128, 64x128, 64x64); grid_y = 4 for the phase-collapsed up-conv.
+int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* x, const float* dy, float* ws,
+                     hipStream_t st) {
+    static const int env = getenv("MIGAN_DMA_WGRAD") ? atoi(getenv("MIGAN_DMA_WGRAD")) : 1;
+    if (env == 0) return -2;
+    if (g.Wo % 8 != 0 || g.Ci % 4 != 0 || g.Co % 4 != 0 || g.gather == GATHER_UP2 || g.pix_per_split % 32 != 0) return -2;
+    const size_t xb = (size_t)g.N * g.Hi * g.Wi * g.Ci * 4;
+    const size_t db = dys ? (size_t)g.N * g.dy_H * g.dy_W * g.Co * 4 : (size_t)g.N * g.Ho * g.Wo * g.Co * 4;
+    if (xb >= 0x7ffffff0ull || db >= 0x7ffffff0ull) return -2;
+    const bool refl = g.gather == GATHER_REFLECT;
+    if (dys && refl) return -2;
+    const int Ncol = g.R * g.S * g.Ci;
+    WgradGeom gg = g;
+    gg.tiles_m = cdiv(g.Co, bm);
+    gg.tiles_n = cdiv(Ncol, bn);
+    dim3 grid(cdiv(gg.tiles_m * gg.tiles_n * gg.splits, 8) * 8, dys ? 4 : 1);
+#define WGD(BM_, BN_, OCC_)                                                                                              \
+    do {                                                                                                                 \
+        if (dys) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+                                    (unsigned)xb, (unsigned)db);                                                         \
+        else if (refl) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, false, true, OCC_>), grid, dim3(256), 0, st, gg, x,   \
+                                          dy, ws, (unsigned)xb, (unsigned)db);                                           \
+        else hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, false, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+                                (unsigned)xb, (unsigned)db);                                                             \
+    } while (0)
+    if (bm == 128 && bn == 128) WGD(128, 128, 2);
+    else if (bm == 64 && bn == 128) WGD(64, 128, 3);
+    else if (bm == 64 && bn == 64) WGD(64, 64, 5);
+    else return -2;
+#undef WGD
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -22,43 +22,7 @@
 #include <stdlib.h>
 #include <math.h>
 
-#define MAX_TAPS 96
-#define MAX_CLS 16
-
-struct ConvGeom {
-    int N, Hi, Wi, Ci;   // physical source tensor (NHWC)
-    int HiL, WiL;        // logical gather extent (2*Hi for GATHER_UP2)
-    int Co;              // GEMM N
-    int HoF, WoF;        // full output extent
-    int ostep, istride;  // output sub-grid step (parity classes), source step per output index
-    int gather, ldw, ncls;
-    int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
-    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe; opt-in, MIGAN_IGEMM_XCD=1): swz != 0 -> 1-D grid of
-    // 8 * per * ntn * ncls workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's
-    // CONTIGUOUS eighth of the image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of
-    // adjacent rows, the N-tiles, the 4 phase classes of an up-conv - runs back to back on ONE XCD and finds it in that
-    // XCD's L2.  Measured (profiles/r02_ab.txt, r02_conv_microbench.txt): no layer gains more than 2 %, the stride-2
-    // parity-class dgrads lose 40 % (classes with 4/2/2/1 taps interleaved on one XCD), whole steps lose 2-3 % - the L2
-    // misses of these kernels are served by the MALL and are not what limits them.  Default off.
-    int swz, mtiles, ntn, per;
-    int prio;            // MIGAN_MFMA_PRIO=1 (A/B knob): s_setprio 1 while a wave is in its MFMA stream, 0 around the LDS fill
-    int act;
-    float slope;
-    const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
-    // optional per-tile output statistics for the normalisation layer behind the conv (BatchNorm / InstanceNorm):
-    // stats[((group * stats_chunks + chunk) * Co + col) * 3 + {0,1,2}] = (mean, M2, count) of this tile's rows of column col,
-    // combined by migan_norm_stats_from_conv (Chan) - the norm layer's own statistics pass over the tensor disappears.
-    // stats_inst = 0: one group (BatchNorm), chunk = cls * gridDim.x + tile;  1: group = image (InstanceNorm; Ho*Wo % BM == 0)
-    float* stats;
-    int stats_inst, stats_chunks;
-    int oh0[MAX_CLS], ow0[MAX_CLS], Ho[MAX_CLS], Wo[MAX_CLS], tapbeg[MAX_CLS], ntap[MAX_CLS];
-    // fastdiv magics per class for m / (Ho*Wo) and rem / Wo (filled by launch_igemm): the pixel decode of the pipelined
-    // kernel's prologue and strided epilogue costs ~8 instead of ~80 VALU instructions per row
-    unsigned mg_hw[MAX_CLS], mg_w[MAX_CLS];
-    int sh_hw[MAX_CLS], sh_w[MAX_CLS];
-    int wofs[MAX_TAPS];
-    short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
-};
+#include "conv_geom.h"
 
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, int VAR = 0>
@@ -337,16 +301,6 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
 //    ~2000-cycle burst per wave.  Ablation on MI355X (profiles/r01_igemm_ablation.txt): the un-interleaved
 //    load burst cost 20 % of the kernel although 4 workgroups/CU were resident.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool map_bf(int v, int L, int Lphys, int mode, int& src) {
-    int r = v < 0 ? -v : v;
-    r = r >= L ? 2 * L - 2 - r : r;
-    bool inr = (unsigned)v < (unsigned)L;
-    int s = mode == GATHER_REFLECT ? r : (mode == GATHER_UP2 ? (v >> 1) : v);
-    s = s < 0 ? 0 : s;
-    s = s > Lphys - 1 ? Lphys - 1 : s;
-    src = s;
-    return mode == GATHER_REFLECT ? true : inr;
-}
 
 // TAPIN (every class has exactly 4 taps, >= 2 K-tiles per tap; small tiles only): the K loop runs channel-chunk outer /
 // tap inner, so the 4 taps' A tiles of one 32-channel chunk - which overlap by all but one pixel column/row - are
@@ -1477,6 +1431,12 @@ static int igemm_stats_chunks(const ConvGeom& g, int instance) {
     return g.ncls * (hw / bm);
 }
 
+int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                     hipStream_t st);  // conv_dma.hip
+
+int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* x, const float* dy, float* ws,
+                     hipStream_t st);  // conv_dma.hip
+
 static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
                         hipStream_t st) {
     ConvGeom g = g_in;
@@ -1509,7 +1469,14 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     }
     int ktaps = 0;
     for (int c = 0; c < g.ncls; ++c) ktaps = g.ntap[c] > ktaps ? g.ntap[c] : ktaps;
-    switch (igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci)) {
+    const int tile_code = igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci);
+    // LDS-DMA main loop (conv_dma.hip) for the shapes it takes; MIGAN_DMA=0 keeps the register-staged kernels (A/B knob)
+    static const int dma_env = getenv("MIGAN_DMA") ? atoi(getenv("MIGAN_DMA")) : 1;
+    if (fast && dma_env != 0 && var == 0) {
+        const int rc = launch_igemm_dma(g, A, Bw, bias, C, st);
+        if (rc != -2) return rc;
+    }
+    switch (tile_code) {
         case 1128128:
 #ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
             if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
@@ -1734,24 +1701,6 @@ static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, 
 // Split-K over pixel ranges into a workspace, then a fixed-order reduction that also re-lays the
 // result out as OIHW (the torch parameter layout), so the run-to-run result is deterministic.
 // ------------------------------------------------------------------------------------------------
-struct WgradGeom {
-    int N, Hi, Wi, Ci, HiL, WiL;
-    int Ho, Wo, Co;
-    int R, S, stride, pad_t, pad_l, gather;
-    int splits, pix_per_split;  // pixels per split (multiple of 32)
-    int tiles_m, tiles_n;       // tile grid of the pipelined kernel (1-D XCD-aware launch)
-    unsigned mg_hw, mg_w;       // magic multipliers / shifts for p / (Ho*Wo) and rem / Wo (pipelined kernel)
-    int sh_hw, sh_w;
-    // dy may be a strided sub-grid of a larger gradient tensor (phase classes of the collapsed Upsample+Conv):
-    // pixel (n, oi, oj) of this GEMM lives at dy[n][dy_oh0 + oi*dy_step][dy_ow0 + oj*dy_step]
-    int dy_H, dy_W, dy_oh0, dy_ow0, dy_step;
-    // optional fused bias gradient: the blocks of column-tile 0 also sum their dy tiles over pixels (the A operand is
-    // already in LDS) into bpart[cls*splits + split][Co]; the reduction launch adds the slabs.  NULL: not requested.
-    // Measured on MI355X: no faster than the separate column-sum launches (the column-0 blocks become the critical
-    // path of a one-wave launch; spreading the rows over all column tiles costs every block more than it saves), so
-    // the host mirror leaves it off by default (MIGAN_FUSE_BIAS=1 enables it).
-    float* bpart;
-};
 
 
 template <int BM, int BN, bool VEC>
@@ -2698,9 +2647,15 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
         if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
-    if (bm == 128) UPW_LAUNCH(128, 128);
-    else if (wgrad_bn(Co, Ncol) == 128) UPW_LAUNCH(64, 128);
-    else UPW_LAUNCH(64, 64);
+    const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
+    const int rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, true, x, dy, ws, st) : -2;  // LDS-DMA main loop (conv_dma.hip)
+    if (rc_dma == -2) {
+        if (bm == 128) UPW_LAUNCH(128, 128);
+        else if (bn_sel == 128) UPW_LAUNCH(64, 128);
+        else UPW_LAUNCH(64, 64);
+    } else if (rc_dma != 0) {
+        return rc_dma;
+    }
 #undef UPW_LAUNCH
     HIP_LAUNCH_CHECK();
     size_t total = (size_t)Co * Ci * 9;
@@ -3157,7 +3112,11 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
         else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
-        if (bm == 128) {
+        const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
+        const int rc_dma = (inc && wvar == 0) ? launch_wgrad_dma(g, bm, bn_sel, false, x, dy, ws, st) : -2;
+        if (rc_dma != -2) {
+            if (rc_dma != 0) return rc_dma;
+        } else if (bm == 128) {
 #ifdef MIGAN_ABLATION
             if (wvar == 1 || wvar == 2 || wvar == 3) {
                 g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);

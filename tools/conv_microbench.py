@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="fwd,dgrad,wgrad")
     ap.add_argument("--match", default="")
+    ap.add_argument("--repeat", type=int, default=1, help="time every direction this many times; print min and median")
     ap.add_argument("--dirs", default="", help="exact direction names (fwd,ufwd,rdgrad,twgrad,...) instead of --only's families")
     ap.add_argument("--pmc-log", default="", help="write one JSON line per timed (layer, direction) and launch a 1-element "
                                                   "axpby marker kernel in front of each, so that a rocprofv3 --pmc pass over "
@@ -169,14 +170,22 @@ def main():
             for _ in range(3):
                 check(fn(), d)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / args.iters
+            times = []
+            for _rep in range(max(1, args.repeat)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1) / args.iters)
+            times.sort()
+            ms = times[0]
             tf = flops / (ms * 1e-3) / 1e12
+            if args.repeat > 1:
+                print("%-28s %-6s %9.1f us  %7.2f TF  %5.1f%%  median %9.1f us" % (name, d, ms * 1e3, tf, 100 * tf / 157.3,
+                                                                                  times[len(times) // 2] * 1e3), flush=True)
+                continue
             print("%-28s %-6s %9.1f us  %7.2f TF  %5.1f%%  (%.2f GFLOP)" % (name, d, ms * 1e3, tf, 100 * tf / 157.3, flops / 1e9),
                   flush=True)
 
