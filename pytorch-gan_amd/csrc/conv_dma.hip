@@ -287,7 +287,10 @@ static int dma_select(long maxM, int Co, int ncls) {
         const double util = ((double)maxM / (tm * c.bm)) * ((double)Co / (tn * c.bn));
         const double per_cu = T / 256.0;
         const double balance = per_cu / (double)(long)(per_cu + 0.999999);
-        const double score = c.eff * util * balance;
+        // a workgroup alone on its CU exposes its prologue, epilogue and every barrier (PatchGAN 128->256 @32x32: 84 us with
+        // one 128x64 tile per CU, 76 us with two 64x64)
+        const double occ = per_cu <= 1.0 ? 0.90 : (per_cu <= 2.0 ? 0.97 : 1.0);
+        const double score = c.eff * util * balance * occ;
         if (score > best * 1.0001) {
             best = score;
             bestT = T;
@@ -356,15 +359,16 @@ template <> struct FragT<2> { typedef f32x2 type; };
 __device__ __forceinline__ float frag_get(float v, int) { return v; }
 __device__ __forceinline__ float frag_get(f32x2 v, int e) { return v[e]; }
 
-template <int BM, int BN, bool DYS, bool REFL, int OCC>
+template <int BM, int BN, int BK, bool DYS, bool REFL, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, const float* __restrict__ X,
                                                              const float* __restrict__ DY, float* __restrict__ part,
                                                              unsigned x_bytes, unsigned dy_bytes) {
-    constexpr int BK = 32;
     constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
     constexpr int CPA = BM / 4, CPB = BN / 4;      // 16-B chunks per pixel row
     constexpr int RPA = 64 / CPA, RPB = 64 / CPB;  // pixel rows per DMA instruction
-    constexpr int IA = 8 / RPA, IB = 8 / RPB;      // DMA instructions per wave per K-tile (8 pixel rows per wave)
+    constexpr int PPW = BK / 4;                    // consecutive pixel rows of a K-tile owned by one wave (8 or 4)
+    constexpr int IA = PPW / RPA, IB = PPW / RPB;  // DMA instructions per wave per K-tile
+    static_assert((BK == 32 || BK == 16) && IA >= 1 && IB >= 1, "BK");
     constexpr int A_FL = BK * BM, B_FL = BK * BN, ST_FL = A_FL + B_FL;
     static_assert(TM >= 1 && TM <= 2 && TN >= 1 && TN <= 2, "tile shape");
     __shared__ __attribute__((aligned(16))) float smem[2 * ST_FL];
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, 
 
     // issue the DMA of the K-tile whose first pixel is P0 into LDS stage st
     auto issue = [&](int st, int P0) {
-        const int pg = P0 + 8 * wave;  // this wave's 8 pixels (one image row: Wo % 8 == 0), wave-uniform
+        const int pg = P0 + PPW * wave;  // this wave's PPW pixels (one image row: Wo % 8 == 0), wave-uniform
         const bool gok = pg < p_end;
         const int pc = gok ? pg : 0;
         const int n = fastdiv(pc, g.mg_hw, g.sh_hw);
@@ -555,19 +559,31 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
     gg.tiles_m = cdiv(g.Co, bm);
     gg.tiles_n = cdiv(Ncol, bn);
     dim3 grid(cdiv(gg.tiles_m * gg.tiles_n * gg.splits, 8) * 8, dys ? 4 : 1);
-#define WGD(BM_, BN_, OCC_)                                                                                              \
+#define WGD(BM_, BN_, BK_, OCC_)                                                                                             \
     do {                                                                                                                 \
-        if (dys) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+        if (dys) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
                                     (unsigned)xb, (unsigned)db);                                                         \
-        else if (refl) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, false, true, OCC_>), grid, dim3(256), 0, st, gg, x,   \
+        else if (refl) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, false, true, OCC_>), grid, dim3(256), 0, st, gg, x,   \
                                           dy, ws, (unsigned)xb, (unsigned)db);                                           \
-        else hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, false, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+        else hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, false, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
                                 (unsigned)xb, (unsigned)db);                                                             \
     } while (0)
-    if (bm == 128 && bn == 128) WGD(128, 128, 2);
-    else if (bm == 64 && bn == 128) WGD(64, 128, 3);
-    else if (bm == 64 && bn == 64) WGD(64, 64, 5);
-    else return -2;
+    // 128x128: BK = 16 (32 KB of LDS, 4-5 workgroups per CU); the narrower tiles: BK = 32 (3 / 5 per CU) - measured
+    // per layer in profiles/r03_wgrad_dma.txt (differences <= 3 %); MIGAN_DMA_WGRAD_BK=16|32 forces one (A/B knob).
+    // wgrad_occ() in conv_igemm.hip (the split planner's slot count) follows this choice.
+    static const int bk_env = getenv("MIGAN_DMA_WGRAD_BK") ? atoi(getenv("MIGAN_DMA_WGRAD_BK")) : 0;
+    const int bk = bk_env ? bk_env : (bm == 128 ? 16 : 32);
+    if (bk == 32) {
+        if (bm == 128 && bn == 128) WGD(128, 128, 32, 2);
+        else if (bm == 64 && bn == 128) WGD(64, 128, 32, 3);
+        else if (bm == 64 && bn == 64) WGD(64, 64, 32, 5);
+        else return -2;
+    } else {
+        if (bm == 128 && bn == 128) WGD(128, 128, 16, 4);
+        else if (bm == 64 && bn == 128) WGD(64, 128, 16, 6);
+        else if (bm == 64 && bn == 64) WGD(64, 64, 16, 8);
+        else return -2;
+    }
 #undef WGD
     HIP_LAUNCH_CHECK();
     return 0;

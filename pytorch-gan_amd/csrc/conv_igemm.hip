@@ -20,6 +20,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 #include <math.h>
 
 #include "conv_geom.h"
@@ -2400,7 +2401,16 @@ static int wgrad_bn(int Co, int Ncol) {
     return (Co > 32 && Ncol >= 128 && wgrad_var() != 64) ? 128 : 64;
 }
 // Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
-static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 3 : (bm * bn >= 8192 ? 4 : 7); }
+// LDS-DMA kernels (conv_dma.hip): 4 (128x128, BK = 16) / 3 / 5 (BK = 32), LDS bound; MIGAN_WGRAD_OCCS=a,b,c overrides (sweeps).
+static int wgrad_occ(int bm, int bn) {
+    static int occs[3] = {0, 0, 0};
+    if (occs[0] == 0) {
+        int a = 4, b = 3, c = 5;
+        if (const char* e = getenv("MIGAN_WGRAD_OCCS")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        occs[2] = c; occs[1] = b; occs[0] = a;
+    }
+    return bm * bn >= 16384 ? occs[0] : (bm * bn >= 8192 ? occs[1] : occs[2]);
+}
 
 // Split-K factor.  The launch is tiles * splits equal workgroups on 256 CUs x occ resident slots.  Measured on MI355X
 // (profiles/r02_wgrad_split_sweep.txt): what decides the time is how EVENLY the workgroups fall on the CUs - R256 wgrad
