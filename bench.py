@@ -563,6 +563,20 @@ def main():
                     help="N>1: BatchNorm statistics over the global batch (the reference's single-process semantics)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+        # (the contract's launch line); rank 0's JSON line is this process's output, its status our exit status
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     from pytorch_gan_amd import dp as dpmod
 
     if not torch.cuda.is_available():

@@ -89,6 +89,22 @@ int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, 
                        int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
                        float slope, void* stream);
 
+/* Split-K variants for under-filled GEMMs (csrc/conv_dma.hip): a few output pixels against a long K - the inner U-Net
+ * levels of pix2pix/models.py:62-78 (1-64 pixels, 16.8-33.5 MB of weights per layer), the PatchGAN heads
+ * cyclegan/models.py:106-118, the discriminator of dcgan.py:77-92.  K is cut over up to 512 workgroups; every slice leaves
+ * its 64x64 partial tile in a slab of `ws`, and the last slice to arrive at the tile's ticket adds the slabs in slice order
+ * (deterministic) and applies bias / activation / mask.  `ws` = migan_conv_splitk_workspace() bytes, zeroed ONCE by the caller
+ * (tickets return to zero after every launch), not shared by launches that may overlap (one per stream); NULL = no split.
+ * mask_nc: optional [N][Co] multiplier (the fused nn.Dropout2d of migan_conv2d_dropout_fwd) or NULL. */
+size_t migan_conv_splitk_workspace(void);
+int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls);  /* 1: a workspace would be used */
+int migan_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc, float* y, int N,
+                        int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
+                        int gather, int act, float slope, float* ws, size_t ws_bytes, void* stream);
+int migan_conv2d_dgrad_ws(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
+                          int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
+                          float slope, float* ws, size_t ws_bytes, void* stream);
+
 /* Which tile configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
  * Co columns and a source with Ci_src channels: fast*1000000 + BM*1000 + BN ("fast" = vectorised NHWC loader,
  * Ci_src % 4 == 0 and >= 8); 4000 = the thin-N VALU kernel (Co <= 4).  Pure function; used by bench.py to attribute

@@ -85,6 +85,10 @@ _SIGS = {
     "migan_skinny_tn": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),
     "migan_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P]),
+    "migan_conv_splitk_workspace": (c_size_t, []),
+    "migan_conv_splitk_applies": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
+    "migan_conv2d_fwd_ws": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P, c_size_t, P]),
+    "migan_conv2d_dgrad_ws": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P, c_size_t, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
     "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P, c_int, P]),

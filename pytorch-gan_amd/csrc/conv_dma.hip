@@ -21,6 +21,7 @@
 #include "conv_geom.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <math.h>
 
 #define DMA_SENT 0x80000000u  // voffset beyond any buffer this kernel accepts (tensors < 2 GiB)
 
@@ -34,11 +35,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p, unsign
 // TAPS_IN: 1 = tap-outer K order (tap, then 32-channel chunks), 4 = channel-chunk outer / tap inner for classes of
 // exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad): the 4 taps' A tiles of one channel chunk overlap by all
 // but one pixel row/column and are fetched back to back (L2 hits) - see igemm_pipe_kernel.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int TAPS_IN, bool KTAIL, int OCC>
+// NS: LDS stages.  2 = tile kt+1 is fetched while tile kt is multiplied, `vmcnt(0)` + barrier per K-tile (what the
+// compiler emits for __syncthreads() with an LDS-DMA in flight) - right whenever several workgroups share a CU.  NS > 2:
+// NS-1 tiles in flight, COUNTED `s_waitcnt vmcnt((NS-2) * loads per tile)` + raw s_barrier, so the DMA queue is never
+// drained - for launches with one workgroup per CU (few tiles, long K), where the fetch latency of every K-tile is
+// otherwise exposed (cdna_hip_programming.md, "Pipelining across barriers").
+// SPLITK: blockIdx.z = class * splits + slice; a slice multiplies the K-tiles [slice * KT / splits, (slice+1) * KT / splits)
+// and leaves its raw accumulators in a slab of the caller's workspace; the last slice to arrive at the tile's ticket
+// (agent-scope release / acquire, cdna_hip_programming.md Guideline 16) adds the slabs in slice order - a fixed order, so
+// the result is deterministic - and runs the epilogue.  The ticket resets itself; the workspace needs zeroing once.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int TAPS_IN, bool KTAIL, int OCC, int NS = 2, bool SPLITK = false>
 __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, const float* __restrict__ A,
                                                              const float* __restrict__ Bw,
                                                              const float* __restrict__ bias, float* __restrict__ C,
-                                                             unsigned a_bytes, unsigned b_bytes) {
+                                                             unsigned a_bytes, unsigned b_bytes, int splits = 1,
+                                                             float* __restrict__ sk_ws = nullptr) {
     constexpr int CPR = BK / 4;                 // 16-B chunks per row
     constexpr int RPI = 64 / CPR;               // rows per DMA instruction (1 KiB)
     constexpr int SH = CPR == 8 ? 1 : 2;        // swizzle: f(row) = (row >> SH) & (CPR - 1)
@@ -49,10 +60,12 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     static_assert(IA >= 1 && IB >= 1, "tile too small for the DMA mapping");
     constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile shape");
-    __shared__ __attribute__((aligned(16))) float smem[2 * ST_FL];
+    static_assert(NS >= 2 && NS <= 4 && (!SPLITK || TAPS_IN == 1), "pipeline depth / split-K");
+    __shared__ __attribute__((aligned(16))) float smem[NS * ST_FL];
 
     const int tid = threadIdx.x;
-    const int cls = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    const int cls = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    const int slice = SPLITK ? (int)blockIdx.z - cls * splits : 0;
     const int Ho = g.Ho[cls], Wo = g.Wo[cls];
     const int M = g.N * Ho * Wo;
     const int m0 = bx * BM, n0 = by * BN;
@@ -75,7 +88,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int tpt = KTAIL ? (Ci + BK - 1) / BK : Ci / BK;  // K-tiles per tap
-    const int KT = ntap * tpt;
+    const int KT_all = ntap * tpt;
+    const int kt_begin = SPLITK ? (int)((long)slice * KT_all / splits) : 0;
+    const int KT = (SPLITK ? (int)((long)(slice + 1) * KT_all / splits) : KT_all) - kt_begin;  // K-tiles of this workgroup
 
     // ---- DMA lane mapping: instruction X = wave * I + i covers rows X*RPI .. X*RPI+RPI-1; this lane: row X*RPI + lane / CPR,
     // chunk kc = (lane % CPR) ^ f(row)
@@ -110,7 +125,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     int f_wo[TAPS_IN];
     auto setup_tap = [&](int t, unsigned (&aoff)[IA], int& wo) {
         // wave-uniform index into the kernel-argument tables: scalar loads, and a provably uniform soffset for the DMA
-        const int dh = g.dh[tapbeg + t], dw = g.dw[tapbeg + t];
+        const int dhw = g.dhw[tapbeg + t];
+        const int dh = dhw >> 16, dw = (int)(short)(dhw & 0xffff);
         wo = g.wofs[tapbeg + t];
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
@@ -121,24 +137,25 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             aoff[i] = ok ? (unsigned)((a_base[i] + ihs * Wi + iws) * Ci + a_kc[i]) * 4u : DMA_SENT;
         }
     };
-    int f_t = 0, f_c0 = 0;  // fetch position: tap (tap-outer order) and channel chunk
-    // issue the DMA of the K-tile at the fetch position (tap slot `slot`) into LDS stage `st`
-    auto issue = [&](int st, int slot_rt, auto slot_c) {
+    int f_t = SPLITK ? kt_begin / tpt : 0, f_c0 = SPLITK ? (kt_begin - f_t * tpt) * BK : 0;  // fetch position: tap, channel chunk
+    // issue the DMA of the K-tile at the fetch position (tap slot `slot`) into LDS stage `st`; live = false (NS > 2, past
+    // the last tile): the same instruction count with every lane out of range, so the counted waits stay uniform
+    auto issue = [&](int st, bool live, auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
-        (void)slot_rt;
         const unsigned soA = (unsigned)f_c0 * 4u, soB = (unsigned)(f_wo[SL] + f_c0) * 4u;
         float* base = smem + st * ST_FL;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             unsigned vo = a_off[SL][i];
             if (KTAIL) vo = (f_c0 + a_kc[i] < Ci) ? vo : DMA_SENT;
+            if (NS > 2) vo = live ? vo : DMA_SENT;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void_t*)(base + (wave * IA + i) * 256), 16, (int)vo, (int)soA,
                                                      0, 0);
         }
 #pragma unroll
         for (int j = 0; j < IB; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16,
-                                                     (int)b_off[j], (int)soB, 0, 0);
+                                                     (int)((NS > 2 && !live) ? DMA_SENT : b_off[j]), (int)soB, 0, 0);
     };
 
     // ---- fragment read addresses: row = w * T * 32 + i * 32 + l31, chunk (2q + h) ^ f(l31)
@@ -151,11 +168,6 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
         b_rd[q] = A_FL + (wn * (TN * 32) + l31) * BK + c;
     }
 
-    if (KT > 0) {
-#pragma unroll
-        for (int s_ = 0; s_ < TAPS_IN; ++s_) setup_tap(s_, a_off[s_], f_wo[s_]);
-        issue(0, 0, std::integral_constant<int, 0>{});
-    }
     auto advance = [&](auto nxt_c) {  // move the fetch position one K-tile on; NXT = tap slot of the new position
         constexpr int NXT = decltype(nxt_c)::value;
         if (TAPS_IN > 1) {
@@ -164,19 +176,12 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             f_c0 += BK;
             if (KTAIL ? f_c0 >= Ci : f_c0 == Ci) {
                 f_c0 = 0;
-                setup_tap(++f_t, a_off[0], f_wo[0]);
+                ++f_t;
+                if (NS == 2 || f_t < ntap) setup_tap(f_t, a_off[0], f_wo[0]);
             }
         }
     };
-    auto k_tile = [&](int kt, auto nxt_c) {
-        constexpr int NXT = decltype(nxt_c)::value;
-        const int cur = kt & 1;
-        // tile kt is in LDS stage cur (DMA drained + barrier at the end of the previous iteration / prologue)
-        if (kt + 1 < KT) {
-            advance(nxt_c);
-            issue(cur ^ 1, 0, std::integral_constant<int, NXT>{});
-        }
-        const float* sb = smem + cur * ST_FL;
+    auto multiply = [&](const float* sb) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             f32x4 a[TM], b[TN];
@@ -192,18 +197,104 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // (the compiler drains the LDS-DMA queue, vmcnt(0), in front of the barrier)
     };
-    if (KT > 0) __syncthreads();
-    if (TAPS_IN > 1) {
-        for (int kt = 0; kt < KT; kt += 4) {
-            k_tile(kt, std::integral_constant<int, 1 % TAPS_IN>{});
-            k_tile(kt + 1, std::integral_constant<int, 2 % TAPS_IN>{});
-            k_tile(kt + 2, std::integral_constant<int, 3 % TAPS_IN>{});
-            k_tile(kt + 3, std::integral_constant<int, 0>{});
+    if constexpr (NS == 2) {
+        if (KT > 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < TAPS_IN; ++s_) setup_tap(s_, a_off[s_], f_wo[s_]);
+            issue(0, true, std::integral_constant<int, 0>{});
+        }
+        auto k_tile = [&](int kt, auto nxt_c) {
+            constexpr int NXT = decltype(nxt_c)::value;
+            const int cur = kt & 1;
+            // tile kt is in LDS stage cur (DMA drained + barrier at the end of the previous iteration / prologue)
+            if (kt + 1 < KT) {
+                advance(nxt_c);
+                issue(cur ^ 1, true, std::integral_constant<int, NXT>{});
+            }
+            multiply(smem + cur * ST_FL);
+            __syncthreads();  // (the compiler drains the LDS-DMA queue, vmcnt(0), in front of the barrier)
+        };
+        if (KT > 0) __syncthreads();
+        if (TAPS_IN > 1) {
+            for (int kt = 0; kt < KT; kt += 4) {
+                k_tile(kt, std::integral_constant<int, 1 % TAPS_IN>{});
+                k_tile(kt + 1, std::integral_constant<int, 2 % TAPS_IN>{});
+                k_tile(kt + 2, std::integral_constant<int, 3 % TAPS_IN>{});
+                k_tile(kt + 3, std::integral_constant<int, 0>{});
+            }
+        } else {
+            for (int kt = 0; kt < KT; ++kt) k_tile(kt, std::integral_constant<int, 0>{});
         }
     } else {
-        for (int kt = 0; kt < KT; ++kt) k_tile(kt, std::integral_constant<int, 0>{});
+        static_assert(NS == 2 || TAPS_IN == 1, "deep pipeline: tap-outer order only");
+        constexpr int IPT = IA + IB;  // DMA instructions per K-tile and wave
+        if (KT > 0) {
+            setup_tap(f_t, a_off[0], f_wo[0]);
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t) {  // tiles 0 .. NS-2 into stages 0 .. NS-2
+                if (t > 0) advance(std::integral_constant<int, 0>{});
+                issue(t, t < KT, std::integral_constant<int, 0>{});
+            }
+        }
+        int st_c = 0, st_f = NS - 1;  // stage multiplied this iteration / stage refilled this iteration
+        for (int kt = 0; kt < KT; ++kt) {
+            // this wave's part of tile kt has landed once at most the NS-2 younger tiles' loads are outstanding; the barrier
+            // makes every wave's part visible and says that everybody is done reading the stage refilled below
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * IPT) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            advance(std::integral_constant<int, 0>{});
+            issue(st_f, kt + NS - 1 < KT, std::integral_constant<int, 0>{});
+            multiply(smem + st_c * ST_FL);
+            st_c = st_c + 1 == NS ? 0 : st_c + 1;
+            st_f = st_f + 1 == NS ? 0 : st_f + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dead tail fetches (all lanes out of range) before the LDS is reused
+    }
+
+    if constexpr (SPLITK) {
+        // slab layout: value (i, j, r) of thread tid at ((i * TN + j) * 16 + r) * 256 + tid: every store is one coalesced 1 KiB
+        const int tile_id = (cls * (int)gridDim.y + by) * (int)gridDim.x + bx;
+        unsigned* tickets = reinterpret_cast<unsigned*>(sk_ws);
+        float* slabs = sk_ws + 1024;
+        constexpr int SLAB = BM * BN;
+        float* mine = slabs + ((size_t)tile_id * splits + slice) * SLAB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(tickets + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reinterpret_cast<unsigned*>(smem)[0] = t;
+        }
+        __syncthreads();
+        const bool last = reinterpret_cast<unsigned*>(smem)[0] == (unsigned)(splits - 1);
+        if (!last) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tickets + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // at rest again
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const float* sl = slabs + (size_t)tile_id * splits * SLAB;
+        for (int s_ = 0; s_ < splits; ++s_, sl += SLAB)  // slice order: a fixed summation order whoever arrives last
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * TN + j) * 16 + r) * 256 + tid];
     }
 
     // ---- epilogue (igemm_pipe_kernel's): bias + activation + optional [N][Co] mask, strided class scatter, accumulate
@@ -304,9 +395,53 @@ static int dma_select(long maxM, int Co, int ncls) {
     return bk * 1000000 + code;
 }
 
+// Under-filled launches (at most one 64x64 tile per CU): 64x64x32 tiles, four LDS stages with counted waits (three
+// K-tiles in flight per workgroup), and - when the caller supplies a workspace - split-K over up to 512 workgroups with the
+// in-kernel ticket reduction.  Serves the DCGAN discriminator convs (dcgan.py:78-80: 64 tiles, K = 576), PatchGAN heads
+// (cyclegan/models.py:106-118) and the inner U-Net levels of pix2pix (pix2pix/models.py:62-71: 1-64 pixels, 16.8-33.5 MB of
+// weights per layer - a weight-streaming GEMM that needs every CU pulling on HBM).
+#define DMA_SK_TICKETS 1024                   // u32 tickets at the head of the workspace (one per output tile)
+#define DMA_SK_MAX_SLABS 1024                 // 64x64 fp32 slabs behind them
+size_t igemm_dma_splitk_ws_bytes() { return (size_t)DMA_SK_TICKETS * 4 + (size_t)DMA_SK_MAX_SLABS * 64 * 64 * 4; }
+
+static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, unsigned ab,
+                            unsigned bb, long maxM, float* ws, size_t ws_bytes, hipStream_t st) {
+    const bool ktail = g.Ci % 32 != 0;
+    const int tpt = (g.Ci + 31) / 32;
+    const long tm = cdiv(maxM, 64), tn = cdiv(g.Co, 64);
+    const long T = tm * tn * g.ncls;
+    int minKT = 1 << 30;
+    for (int c = 0; c < g.ncls; ++c)
+        if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * tpt < minKT) minKT = g.ntap[c] * tpt;
+    static const int sk_env = getenv("MIGAN_DMA_SPLITK") ? atoi(getenv("MIGAN_DMA_SPLITK")) : 1;  // 0: off, >1: forced
+    int S = 1;
+    if (ws && sk_env != 0 && T <= DMA_SK_TICKETS && ws_bytes >= igemm_dma_splitk_ws_bytes()) {
+        // a slice costs ~0.5 us per K-tile (one 64x64x32 MFMA tile per wave), the last arriver ~0.16 us per 16 KB slab it
+        // adds: S ~ sqrt(3 * KT), at most two workgroups per CU and at least 4 K-tiles per slice
+        S = (int)(sqrt(3.0 * (double)minKT) + 0.5);
+        if (S > 512 / T) S = (int)(512 / T);
+        if (S > minKT / 4) S = minKT / 4;
+        if (sk_env > 1) S = sk_env;
+        if (S > 64) S = 64;
+        if ((long)S * T > DMA_SK_MAX_SLABS) S = (int)(DMA_SK_MAX_SLABS / T);
+        if (S > minKT) S = minKT;
+        if (S < 1) S = 1;
+    }
+    dim3 grid((unsigned)tm, (unsigned)tn, (unsigned)(g.ncls * S));
+#define DMA_SMALL(KT_, SK_)                                                                                             \
+    hipLaunchKernelGGL((igemm_dma_kernel<64, 64, 2, 2, 32, 1, KT_, 2, 4, SK_>), grid, dim3(256), 0, st, g, A, Bw, bias, \
+                       C, ab, bb, S, ws)
+    if (S < 2) return -2;  // not worth cutting: the ordinary tiles
+    if (ktail) DMA_SMALL(true, true); else DMA_SMALL(false, true);
+#undef DMA_SMALL
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // Returns -2 when this geometry is not taken by the LDS-DMA kernels (the caller falls through to igemm_pipe_kernel),
 // otherwise the launch status.
-int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
+int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, float* ws,
+                     size_t ws_bytes, hipStream_t st) {
     if (g.stats || g.swz) return -2;
     if (g.Ci % 4 != 0 || g.Ci < 32 || g.ldw % 4 != 0 || g.Co <= 4) return -2;
     for (int c = 0; c < g.ncls; ++c)
@@ -321,6 +456,18 @@ int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const f
     }
     if (maxM == 0) return 0;
     const unsigned ab = (unsigned)a_bytes, bb = (unsigned)b_bytes;
+    // split-K pays when the chip is badly under-filled and K is long (profiles/r03_splitk.txt: pix2pix inner levels
+    // 164 -> 31 us, DCGAN D.conv4 19 -> 15 us; at 128+ tiles or < 16 K-tiles the slab traffic and the ticket cost more)
+    if (ws) {
+        const long T64 = (long)cdiv(maxM, 64) * cdiv(g.Co, 64) * g.ncls;
+        int minKT = 1 << 30;
+        for (int c = 0; c < g.ncls; ++c)
+            if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * ((g.Ci + 31) / 32) < minKT) minKT = g.ntap[c] * ((g.Ci + 31) / 32);
+        if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64)) {
+            const int rc = launch_dma_small(g, A, Bw, bias, C, ab, bb, maxM, ws, ws_bytes, st);
+            if (rc != -2) return rc;
+        }
+    }
     switch (dma_select(maxM, g.Co, g.ncls)) {
 #define DMA_CASE(BK_, BM_, BN_, WM_, WN_, OCC_) \
     case BK_ * 1000000 + BM_ * 1000 + BN_:      \

@@ -39,6 +39,9 @@ struct ConvGeom {
     int sh_hw[MAX_CLS], sh_w[MAX_CLS];
     int wofs[MAX_TAPS];
     short dh[MAX_TAPS], dw[MAX_TAPS];  // source offset of a tap relative to the CLASS-LOCAL output index times istride
+    // (dh << 16) | (dw & 0xffff), filled by launch_igemm for the LDS-DMA kernels: a dword table is read with scalar loads
+    // (a 16-bit element of a kernel argument costs a vector global_load and a vmcnt wait that drains the DMA queue)
+    int dhw[MAX_TAPS];
 };
 
 // Branch-free coordinate map of the gather: v = logical coordinate (output index * stride + tap offset), L = logical

@@ -1432,14 +1432,15 @@ static int igemm_stats_chunks(const ConvGeom& g, int instance) {
     return g.ncls * (hw / bm);
 }
 
-int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
-                     hipStream_t st);  // conv_dma.hip
+int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, float* ws,
+                     size_t ws_bytes, hipStream_t st);  // conv_dma.hip
+size_t igemm_dma_splitk_ws_bytes();             // conv_dma.hip
 
 int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* x, const float* dy, float* ws,
                      hipStream_t st);  // conv_dma.hip
 
 static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
-                        hipStream_t st) {
+                        hipStream_t st, float* sk_ws = nullptr, size_t sk_bytes = 0) {
     ConvGeom g = g_in;
     if (g.stats) {
         const int ch = igemm_stats_chunks(g, g.stats_inst);
@@ -1471,10 +1472,11 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     int ktaps = 0;
     for (int c = 0; c < g.ncls; ++c) ktaps = g.ntap[c] > ktaps ? g.ntap[c] : ktaps;
     const int tile_code = igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci);
+    for (int t = 0; t < MAX_TAPS; ++t) g.dhw[t] = ((int)g.dh[t] << 16) | ((int)g.dw[t] & 0xffff);
     // LDS-DMA main loop (conv_dma.hip) for the shapes it takes; MIGAN_DMA=0 keeps the register-staged kernels (A/B knob)
     static const int dma_env = getenv("MIGAN_DMA") ? atoi(getenv("MIGAN_DMA")) : 1;
     if (fast && dma_env != 0 && var == 0) {
-        const int rc = launch_igemm_dma(g, A, Bw, bias, C, st);
+        const int rc = launch_igemm_dma(g, A, Bw, bias, C, sk_ws, sk_bytes, st);
         if (rc != -2) return rc;
     }
     switch (tile_code) {
@@ -1527,12 +1529,13 @@ static int conv2d_geom(ConvGeom& g, int N, int Hi, int Wi, int Ci, int Ho, int W
 static int conv2d_fwd_impl(const float* x, const float* w_ohwi, const float* bias, const float* oscale, float* y, int N,
                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                                int pad_t, int pad_l, int gather, int act, float slope, void* stream,
-                               float* stats = nullptr, int stats_chunks = 0, int stats_inst = 0) {
+                               float* stats = nullptr, int stats_chunks = 0, int stats_inst = 0, float* sk_ws = nullptr,
+                               size_t sk_bytes = 0) {
     ConvGeom g = {};
     if (int rc = conv2d_geom(g, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather)) return rc;
     g.act = act; g.slope = slope; g.oscale = oscale;
     g.stats = stats; g.stats_chunks = stats_chunks; g.stats_inst = stats_inst;
-    return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream);
+    return launch_igemm(g, x, w_ohwi, bias, y, (hipStream_t)stream, sk_ws, sk_bytes);
 }
 static int conv2d_geom(ConvGeom& g, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
                        int pad_t, int pad_l, int gather) {
@@ -1578,6 +1581,27 @@ MIGAN_API int migan_conv2d_fwd(const float* x, const float* w_ohwi, const float*
     return conv2d_fwd_impl(x, w_ohwi, bias, nullptr, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, act,
                            slope, stream);
 }
+// Split-K workspace of the *_ws entry points: [1024 u32 tickets][up to 1024 64x64 fp32 slabs].  The caller zeroes it ONCE
+// (the tickets return to zero at the end of every launch) and must not share it between launches that may run
+// concurrently (one workspace per stream).
+MIGAN_API size_t migan_conv_splitk_workspace(void) { return igemm_dma_splitk_ws_bytes(); }
+// 1 when a conv / dgrad whose largest parity class has maxM output pixels would be cut along K given a workspace (the host
+// mirror allocates its per-stream workspace only then)
+MIGAN_API int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls) {
+    if (Ci_src % 4 != 0 || Ci_src < 32 || Co <= 4 || maxM <= 0) return 0;
+    return (long)cdiv((long)maxM, 64) * cdiv(Co, 64) * ncls <= 128 ? 1 : 0;
+}
+// migan_conv2d_fwd / migan_conv2d_dropout_fwd (mask_nc may be NULL) with a split-K workspace: under-filled GEMMs - a few
+// pixels against megabytes of weights (pix2pix/models.py:62-71), PatchGAN heads, the DCGAN discriminator - are cut along K
+// over up to 512 workgroups and reduced in-kernel in a fixed order (deterministic).  ws == NULL: same as the plain entry.
+MIGAN_API int migan_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc, float* y,
+                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
+                                  int pad_t, int pad_l, int gather, int act, float slope, float* ws, size_t ws_bytes,
+                                  void* stream) {
+    if (mask_nc && Co % 4 != 0) return (int)hipErrorInvalidValue;
+    return conv2d_fwd_impl(x, w_ohwi, bias, mask_nc, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, gather, act,
+                           slope, stream, nullptr, 0, 0, ws, ws_bytes);
+}
 // y = act(conv(x) + bias) * mask[n][co]: the Conv2d -> LeakyReLU -> Dropout2d block of dcgan.py:78 in one launch
 MIGAN_API int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc,
                                        float* y, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
@@ -1594,9 +1618,26 @@ MIGAN_API int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, cons
 // lists are dense, so no multiply-by-zero work is issued (ConvTranspose2d(4,2,1) == 4 classes of
 // 2x2 taps).
 // ------------------------------------------------------------------------------------------------
+static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
+                             int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
+                             float slope, void* stream, float* sk_ws, size_t sk_bytes);
 MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, float* dx,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
                                  int stride, int pad_t, int pad_l, int act, float slope, void* stream) {
+    return conv2d_dgrad_impl(dy, w_ihwo, bias, dx, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, act, slope, stream,
+                             nullptr, 0);
+}
+// migan_conv2d_dgrad with a split-K workspace (see migan_conv2d_fwd_ws): nn.ConvTranspose2d(512, 512, 4, 2, 1) on 1-64
+// pixels (pix2pix/models.py:39,72-78) streams 16.8-33.5 MB of weights through every CU instead of 8-16 workgroups.
+MIGAN_API int migan_conv2d_dgrad_ws(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi,
+                                    int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
+                                    int act, float slope, float* ws, size_t ws_bytes, void* stream) {
+    return conv2d_dgrad_impl(dy, w_ihwo, bias, dx, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, act, slope, stream,
+                             ws, ws_bytes);
+}
+static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
+                             int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
+                             float slope, void* stream, float* sk_ws, size_t sk_bytes) {
     if (R * S > MAX_TAPS || stride < 1 || stride > 2) return (int)hipErrorInvalidValue;
     ConvGeom g = {};
     // roles: source = dy (Ho,Wo,Co), output = dx (Hi,Wi,Ci)
@@ -1626,7 +1667,7 @@ MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const flo
             }
             g.ntap[c] = tp - g.tapbeg[c];
         }
-    return launch_igemm(g, dy, w_ihwo, bias, dx, (hipStream_t)stream);
+    return launch_igemm(g, dy, w_ihwo, bias, dx, (hipStream_t)stream, sk_ws, sk_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------

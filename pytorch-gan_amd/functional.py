@@ -142,6 +142,26 @@ def _permute4(w, perm):
     return out
 
 
+_SK_WS = {}
+
+
+def _splitk_ws(ref, max_m, Co, Ci_src, ncls=1):
+    """(pointer, bytes) of the split-K workspace of the conv / dgrad launch about to be issued on the current stream, or
+    (None, 0) when the launch would not use one.  One persistent zero-initialised buffer per (device, stream): the tickets
+    at its head return to zero at the end of every launch, and launches of one stream cannot overlap."""
+    if not _SPLITK or lib.migan_conv_splitk_applies(int(max_m), int(Co), int(Ci_src), int(ncls)) != 1:
+        return None, 0
+    key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
+    ws = _SK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(lib.migan_conv_splitk_workspace() // 4, device=ref.device, dtype=torch.float32)
+        _SK_WS[key] = ws
+    return ws.data_ptr(), ws.numel() * 4
+
+
+_SPLITK = __import__("os").environ.get("MIGAN_SPLITK", "1") == "1"  # A/B knob
+
+
 def _ws(nbytes, ref):
     return torch.empty(max(int(nbytes) // 4, 1), device=ref.device, dtype=torch.float32)
 
@@ -410,8 +430,9 @@ class _ConvDgradFn(Function):
         wp = _plain(w)
         wt = _permute4(wp, (1, 2, 3, 0))
         dx = _empty_nhwc((N, Ci, H, W), dy)
-        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
-                                     stride, pt, pl, 0, 0.0, _stream()), "conv2d_dgrad")
+        skp, skb = _splitk_ws(dy, N * -(-H // stride) * -(-W // stride), Ci, Co, stride * stride)
+        check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S,
+                                        stride, pt, pl, 0, 0.0, skp, skb, _stream()), "conv2d_dgrad")
         ctx.geom = geom
         ctx.save_for_backward(dy, wp)
         ctx.param = w
@@ -481,13 +502,11 @@ class _Conv2d(Function):
             check(lib.migan_conv2d_fwd_stats(xs.data_ptr(), wp.data_ptr(), _ptr(b), _ptr(mask), y.data_ptr(), N, H, W, Ci,
                                              Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, stats_buf.data_ptr(),
                                              stats_chunks, stats_inst, _stream()), "conv2d_fwd_stats")
-        elif mask is None:
-            check(lib.migan_conv2d_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
-                                       S, stride, pt, pl, gather, act, slope, _stream()), "conv2d_fwd")
-        else:  # fused Dropout2d: y = act(conv) * mask[n][co]
-            check(lib.migan_conv2d_dropout_fwd(xs.data_ptr(), wp.data_ptr(), _ptr(b), mask.data_ptr(), y.data_ptr(), N, H,
-                                               W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, gather, act, slope, _stream()),
-                  "conv2d_dropout_fwd")
+        else:  # mask: fused Dropout2d, y = act(conv) * mask[n][co]
+            skp, skb = _splitk_ws(xs, N * Ho * Wo, Co, Ci)
+            check(lib.migan_conv2d_fwd_ws(xs.data_ptr(), wp.data_ptr(), _ptr(b), _ptr(mask), y.data_ptr(), N, H, W, Ci, Ho,
+                                          Wo, Co, R, S, stride, pt, pl, gather, act, slope, skp, skb, _stream()),
+                  "conv2d_fwd" if mask is None else "conv2d_dropout_fwd")
         ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w_in, b_in)
@@ -594,8 +613,9 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
 
         return dx, join
     if gather == GATHER_ZERO:
-        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
-                                     Co, R, S, stride, pt, pl, 0, 0.0, st), "conv2d_dgrad")
+        skp, skb = _splitk_ws(dy, N * -(-H // stride) * -(-W // stride), Ci, Co, stride * stride)
+        check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
+                                        Co, R, S, stride, pt, pl, 0, 0.0, skp, skb, st), "conv2d_dgrad")
     elif _reflect1_applies(ctx.geom):
         # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
         check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
@@ -874,8 +894,9 @@ class _ConvTranspose2d(Function):
         # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
         wp = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
         y = _empty_nhwc((N, Cout, Hout, Wout), xs)
-        check(lib.migan_conv2d_dgrad(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
-                                     Win, Cin, R, S, stride, pad, pad, act, slope, _stream()), "convT_fwd")
+        skp, skb = _splitk_ws(xs, N * -(-Hout // stride) * -(-Wout // stride), Cout, Cin, stride * stride)
+        check(lib.migan_conv2d_dgrad_ws(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
+                                        Win, Cin, R, S, stride, pad, pad, act, slope, skp, skb, _stream()), "convT_fwd")
         ctx.geom = (N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope)
         ctx.has_bias = b is not None
         ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
@@ -910,8 +931,9 @@ class _ConvTranspose2d(Function):
             # [Cin][R][S][Cout]: OHWI of the conv Cout->Cin
             wo = _packed_perm(ctx.params[0], w, "ohwi", (0, 2, 3, 1))
             dx = _empty_nhwc((N, Cin, Hin, Win), xs)
-            check(lib.migan_conv2d_fwd(dy.data_ptr(), wo.data_ptr(), None, dx.data_ptr(), N, Hout, Wout, Cout, Hin, Win,
-                                       Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, st), "convT_dgrad")
+            skp, skb = _splitk_ws(dy, N * Hin * Win, Cin, Cout)
+            check(lib.migan_conv2d_fwd_ws(dy.data_ptr(), wo.data_ptr(), None, None, dx.data_ptr(), N, Hout, Wout, Cout, Hin,
+                                          Win, Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, skp, skb, st), "convT_dgrad")
         fork.join()
         return dx, dw, db, None, None, None, None
 

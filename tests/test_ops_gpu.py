@@ -60,6 +60,14 @@ CONV_CASES = [
     (2, 64, 11, 13, 64, 7, 1, (3, 3, 3, 3), 1, 0, False),       # reflect pad 3, 7x7 (49 taps), 64x128 wgrad tiles
     (5, 32, 6, 6, 160, 4, 2, (1, 1, 1, 1), 0, 0, True),         # 4x4 s2 with Ho*Wo = 9 < 32: several images per K-tile
     (2, 32, 448, 448, 48, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 401k-pixel GEMM (3136 M-tiles), N tail; no act (kink flips)
+    # under-filled GEMMs (pix2pix/models.py:62-71): M = 1, 4, 16, 64 output pixels against K = 8192 / 4096 / 2048:
+    # LDS-DMA kernel with four stages, split-K over up to 64 slices, in-kernel ticket reduction + epilogue
+    (1, 512, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 1, False),       # M = 1
+    (1, 512, 4, 4, 512, 4, 2, (1, 1, 1, 1), 0, 0, True),        # M = 4
+    (1, 256, 8, 8, 512, 4, 2, (1, 1, 1, 1), 0, 2, True),        # M = 16
+    (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 1, False),     # M = 64
+    (3, 72, 8, 8, 96, 3, 1, (1, 1, 1, 1), 0, 0, True),          # split-K with a K-tail (Ci % 32 != 0), ragged N, M = 192
+    (8, 64, 8, 8, 128, 3, 2, (1, 1, 1, 1), 0, 1, True),         # dcgan.py:78 last D block shape (M = 128, K = 576)
 ]
 
 
@@ -87,6 +95,23 @@ def test_conv2d_fwd_bwd(pg, case):
     assert_close(wg.grad, w.grad, TOL_WGRAD, "conv wgrad")
     if bias:
         assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
+
+
+def test_splitk_conv_is_deterministic(pg):
+    """The in-kernel split-K reduction adds the slabs in slice order whoever arrives last: two runs are bit-identical, and
+    the tickets are back at zero afterwards (pix2pix/models.py:66 geometry: 4 output pixels, K = 8192)."""
+    F = pg.functional
+    x = _leaf(1, 512, 4, 4, seed=11).to(DEV)
+    w = _leaf(512, 512, 4, 4, seed=12, scale=0.05).to(DEV)
+    outs = [F.conv2d(x, w, None, 2, (1, 1, 1, 1), 0, 0, 0.0).clone() for _ in range(4)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    assert F._SK_WS, "the split-K workspace was not requested"
+    for ws in F._SK_WS.values():
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
+    ref = TF.conv2d(x.cpu(), w.cpu(), None, 2, 1)
+    assert_close(outs[0], ref, TOL_FWD, "split-K conv")
 
 
 TOEP_CASES = [

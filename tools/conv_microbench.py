@@ -38,6 +38,24 @@ SHAPES = {
         ("D.c3 128->256 k4s2", 8, 128, 64, 64, 256, 4, 2, 1, 0),
         ("D.c4 256->512 k4s2", 8, 256, 32, 32, 512, 4, 2, 1, 0),
     ],
+    # pix2pix/models.py:62-78 at 256x256, bs 1: "dgrad" of a down-conv row is also the ConvTranspose2d forward of the same
+    # geometry (UNetUp), e.g. "u2" = ConvTranspose2d(1024, 512, 4, 2, 1) on 2x2
+    "pix2pix": [
+        ("d2 64->128 @128", 1, 64, 128, 128, 128, 4, 2, 1, 0),
+        ("d3 128->256 @64", 1, 128, 64, 64, 256, 4, 2, 1, 0),
+        ("d4 256->512 @32", 1, 256, 32, 32, 512, 4, 2, 1, 0),
+        ("d5 512->512 @16", 1, 512, 16, 16, 512, 4, 2, 1, 0),
+        ("d6 512->512 @8", 1, 512, 8, 8, 512, 4, 2, 1, 0),
+        ("d7 512->512 @4", 1, 512, 4, 4, 512, 4, 2, 1, 0),
+        ("d8 512->512 @2", 1, 512, 2, 2, 512, 4, 2, 1, 0),
+        ("u2 512<-1024 @4", 1, 512, 4, 4, 1024, 4, 2, 1, 0),
+        ("u3 512<-1024 @8", 1, 512, 8, 8, 1024, 4, 2, 1, 0),
+        ("u4 512<-1024 @16", 1, 512, 16, 16, 1024, 4, 2, 1, 0),
+        ("u5 256<-1024 @32", 1, 256, 32, 32, 1024, 4, 2, 1, 0),
+        ("u6 128<-512 @64", 1, 128, 64, 64, 512, 4, 2, 1, 0),
+        ("u7 64<-256 @128", 1, 64, 128, 128, 256, 4, 2, 1, 0),
+        ("D.c4 256->512 @32", 1, 256, 32, 32, 512, 4, 2, 1, 0),
+    ],
     "srgan": [
         ("res 64->64 @96", 16, 64, 96, 96, 64, 3, 1, 1, 0),
         ("up 64->256 @192", 16, 64, 192, 192, 256, 3, 1, 1, 0),
@@ -91,11 +109,14 @@ def main():
         dw = torch.empty_like(w)
         nb = lib.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
         ws = torch.empty(max(nb // 4, 1), device=dev)
+        skb = lib.migan_conv_splitk_workspace() if os.environ.get("MIGAN_SPLITK", "1") == "1" else 0
+        sk = torch.zeros(max(skb // 4, 1), device=dev)
+        skp = sk.data_ptr() if skb else None
         calls = {
-            "fwd": lambda: lib.migan_conv2d_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), N, H, W, Ci, Ho, Wo, Co,
-                                                k, k, s, p, p, gth, 0, 0.0, st),
-            "dgrad": lambda: lib.migan_conv2d_dgrad(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
-                                                    Wo, Co, k, k, s, pd, pd, 0, 0.0, st),
+            "fwd": lambda: lib.migan_conv2d_fwd_ws(x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), N, H, W, Ci, Ho, Wo,
+                                                   Co, k, k, s, p, p, gth, 0, 0.0, skp, skb, st),
+            "dgrad": lambda: lib.migan_conv2d_dgrad_ws(dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho,
+                                                       Wo, Co, k, k, s, pd, pd, 0, 0.0, skp, skb, st),
             "wgrad": lambda: lib.migan_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H,
                                                     W, Ci, Ho, Wo, Co, k, k, s, p, p, gth, 0, None, 0, None, 0, st),
         }
