@@ -173,73 +173,86 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
 
 // pass 2 (forward): ONE WAVE per (g,c) adds the per-chunk (sum d, sum d^2) pairs in double (lanes stride over
 // chunks, butterfly reduce), writes mean / invstd and updates the running statistics.
+// chain (BatchNorm over G consecutive sub-batches in one launch - e.g. D(real) and D(fake) of dcgan.py:176-177 run as one
+// batch of 2 x 128): one wave per channel walks the groups in order and applies the G running-statistics updates one after
+// the other, exactly as G separate forward calls would; num_batches_tracked grows by G.
 __global__ __launch_bounds__(256) void norm_finalize_fwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ mean,
                                                                 float* __restrict__ invstd, float* __restrict__ var_out,
                                                                 float* running_mean,
                                                                 float* running_var, long long* nbt, int G, int P,
                                                                 int C, int nchunks, int chunk, float eps,
-                                                                float momentum) {
-    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (i >= G * C) return;  // wave-uniform
-    const int g = i / C, c = i - g * C;
-    double sd = 0.0, sq = 0.0;
-    for (int k = lane; k < nchunks; k += 64) {
-        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
-        sd += (double)part[o];
-        sq += (double)part[o + 1];
-    }
+                                                                float momentum, int chain) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= (chain ? C : G * C)) return;  // wave-uniform
+    const int g0 = chain ? 0 : w / C, c = chain ? w : w - g0 * C, g1 = chain ? G : g0 + 1;
+    for (int g = g0; g < g1; ++g) {
+        const int i = g * C + c;
+        double sd = 0.0, sq = 0.0;
+        for (int k = lane; k < nchunks; k += 64) {
+            size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
+            sd += (double)part[o];
+            sq += (double)part[o + 1];
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sd += __shfl_xor(sd, off);
-        sq += __shfl_xor(sq, off);
-    }
-    if (lane != 0) return;
-    if (i == 0 && nbt) nbt[0] += 1;  // BatchNorm's num_batches_tracked
-    const double K = (double)part[(((size_t)g * nchunks) * C + c) * 3 + 2];
-    const double md = sd / P;
-    double M2 = sq - sd * md;
-    if (M2 < 0.0) M2 = 0.0;
-    const double m = K + md;
-    double var = M2 / P;
-    mean[i] = (float)m;
-    if (invstd) invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-    if (var_out) var_out[i] = (float)var;
-    if (running_mean && G == 1) {
-        double unb = P > 1 ? M2 / (double)(P - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        for (int off = 32; off > 0; off >>= 1) {
+            sd += __shfl_xor(sd, off);
+            sq += __shfl_xor(sq, off);
+        }
+        if (lane != 0) continue;
+        if (c == 0 && nbt && (chain || g == 0)) nbt[0] += 1;  // BatchNorm's num_batches_tracked
+        const double K = (double)part[(((size_t)g * nchunks) * C + c) * 3 + 2];
+        const double md = sd / P;
+        double M2 = sq - sd * md;
+        if (M2 < 0.0) M2 = 0.0;
+        const double m = K + md;
+        double var = M2 / P;
+        mean[i] = (float)m;
+        if (invstd) invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (var_out) var_out[i] = (float)var;
+        if (running_mean && (G == 1 || chain)) {
+            double unb = P > 1 ? M2 / (double)(P - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
     }
 }
 
-// pass 2 (backward): one wave per (g,c) -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1.
+// pass 2 (backward): one wave per (g,c) -> sums[g][c][2] = (sum dyz, sum dyz*xhat); dgamma/dbeta for G==1, or summed over the
+// groups in group order when chain != 0 (see the forward kernel).
 __global__ __launch_bounds__(256) void norm_finalize_bwd_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ sums, float* dgamma,
                                                                 float* dbeta, int G, int C, int nchunks,
-                                                                int accum, float* __restrict__ dslope_gc) {
-    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (i >= G * C) return;
-    const int g = i / C, c = i - g * C;
-    double a = 0.0, b = 0.0, s = 0.0;
-    for (int k = lane; k < nchunks; k += 64) {
-        size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
-        a += (double)part[o];
-        b += (double)part[o + 1];
-        if (dslope_gc) s += (double)part[o + 2];
-    }
+                                                                int accum, float* __restrict__ dslope_gc, int chain) {
+    const int w = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= (chain ? C : G * C)) return;
+    const int g0 = chain ? 0 : w / C, c = chain ? w : w - g0 * C, g1 = chain ? G : g0 + 1;
+    float ta = 0.f, tb = 0.f;
+    for (int g = g0; g < g1; ++g) {
+        const int i = g * C + c;
+        double a = 0.0, b = 0.0, s = 0.0;
+        for (int k = lane; k < nchunks; k += 64) {
+            size_t o = (((size_t)g * nchunks + k) * C + c) * 3;
+            a += (double)part[o];
+            b += (double)part[o + 1];
+            if (dslope_gc) s += (double)part[o + 2];
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off);
-        b += __shfl_xor(b, off);
-        if (dslope_gc) s += __shfl_xor(s, off);
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off);
+            b += __shfl_xor(b, off);
+            if (dslope_gc) s += __shfl_xor(s, off);
+        }
+        if (lane != 0) continue;
+        if (dslope_gc) dslope_gc[i] = (float)s;  // per (g, c) PReLU-slope partials, summed by sum_small_kernel
+        sums[(size_t)i * 2] = (float)a;
+        sums[(size_t)i * 2 + 1] = (float)b;
+        ta += (float)a;  // fp32 sum over the groups = what accumulating G separate backward calls into .grad does
+        tb += (float)b;
     }
-    if (lane != 0) return;
-    if (dslope_gc) dslope_gc[i] = (float)s;  // per (g, c) PReLU-slope partials, summed by sum_small_kernel
-    sums[(size_t)i * 2] = (float)a;
-    sums[(size_t)i * 2 + 1] = (float)b;
-    if (G == 1) {
-        if (dbeta) dbeta[c] = accum ? dbeta[c] + (float)a : (float)a;
-        if (dgamma) dgamma[c] = accum ? dgamma[c] + (float)b : (float)b;
+    if (lane == 0 && (G == 1 || chain)) {
+        if (dbeta) dbeta[c] = accum ? dbeta[c] + ta : ta;
+        if (dgamma) dgamma[c] = accum ? dgamma[c] + tb : tb;
     }
 }
 
@@ -490,9 +503,10 @@ static int norm_stats_impl(const float* x, float* mean, float* invstd, float* va
         hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr, PShuf{});
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, mean,
+    const int chain = (G > 1 && running_mean != nullptr) ? 1 : 0;  // BatchNorm over G sub-batches (InstanceNorm has no running stats)
+    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, mean,
                        invstd, var_out, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps,
-                       momentum);
+                       momentum, chain);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -614,8 +628,9 @@ static int norm_bwd_sums_impl(const float* x, const float* dy, const float* mean
         hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
                            beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums,
-                       dgamma, dbeta, G, C, nchunks, accumulate, dslope_gc);
+    const int chain = (G > 1 && (dgamma != nullptr || dbeta != nullptr)) ? 1 : 0;  // BatchNorm over G sub-batches
+    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, sums,
+                       dgamma, dbeta, G, C, nchunks, accumulate, dslope_gc, chain);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -8,6 +8,8 @@ out by migan_transpose_batched.
 Backward passes are themselves built from Functions where the reference needs a second derivative
 (Linear + LeakyReLU for wgan_gp.py:119-138), so `autograd.grad(..., create_graph=True)` works.
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 
@@ -1220,6 +1222,14 @@ class _Norm(Function):
             raise ValueError("norm: expected 2-D or 4-D input")
         st = _stream()
         sync = _SYNC_BN if (use_batch_stats and not instance and _SYNC_BN is not None and _SYNC_BN.world > 1) else None
+        # batch_groups(k): this BatchNorm call stands for k calls on k consecutive sub-batches (statistics, running-statistics
+        # updates and num_batches_tracked per sub-batch, in order) - [G = k][P / k][C] in the kernels' group view
+        ctx.bn_groups = 1
+        if _BN_GROUPS > 1 and use_batch_stats and not instance:
+            if sync is not None or shuffle or pw is not None or xs.shape[0] % _BN_GROUPS != 0:
+                raise NotImplementedError("batch_groups: plain BatchNorm on a batch divisible by the group count only")
+            ctx.bn_groups = G = _BN_GROUPS
+            P //= G
         if use_batch_stats:
             if P <= 1 and not instance and sync is None:
                 raise ValueError("Expected more than 1 value per channel when training")
@@ -1227,7 +1237,7 @@ class _Norm(Function):
             invstd = torch.empty_like(mean)
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
-            side = _stats_side(x, instance, G, P, C) if sync is None else None
+            side = _stats_side(x, instance, G, P, C) if (sync is None and ctx.bn_groups == 1) else None
             if side is not None:  # per-tile (mean, M2, count) left by the conv epilogue: no pass over the tensor
                 check(lib.migan_norm_stats_from_conv(side[0].data_ptr(), side[1], mean.data_ptr(), invstd.data_ptr(),
                                                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, G, C,
@@ -1280,6 +1290,8 @@ class _Norm(Function):
         if not batch_stats:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
         if torch.is_grad_enabled():
+            if ctx.bn_groups > 1:
+                raise NotImplementedError("double backward through batch_groups() BatchNorm is not on the reference path")
             if ctx.prelu is not None or ctx.shuffle:
                 raise NotImplementedError("double backward through a fused BatchNorm [+PixelShuffle] +PReLU is not on the reference path")
             return _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in)
@@ -1287,7 +1299,7 @@ class _Norm(Function):
         dx = torch.empty_like(xs)
         dgamma = dbeta = None
         acc = 0
-        if affine and G == 1:
+        if affine and (G == 1 or ctx.bn_groups > 1):
             sg, sb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
                 dgamma, dbeta, acc = sg, sb, 1
@@ -1417,6 +1429,22 @@ def _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in):
                                           _ptr(beta), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), G, P, C, ACT_NONE,
                                           0.0, ws.data_ptr(), nb, 0, _stream()), "norm_bwd_sums")
     return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None, None
+
+
+_BN_GROUPS = 1
+
+
+@contextlib.contextmanager
+def batch_groups(k):
+    """Inside: a training-mode BatchNorm call on a batch of k * n samples behaves as k calls on its k consecutive
+    sub-batches of n samples (per-sub-batch statistics; the k running-statistics updates applied in order).  Lets a step
+    run D(real) and D(fake) (dcgan.py:176-177) as ONE pass over cat(real, fake) with the reference's numerics."""
+    global _BN_GROUPS
+    prev, _BN_GROUPS = _BN_GROUPS, int(k)
+    try:
+        yield
+    finally:
+        _BN_GROUPS = prev
 
 
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
@@ -1565,6 +1593,19 @@ class _Axpby(Function):
         if has_b and ctx.needs_input_grad[1]:
             gb = g if beta == 1.0 else _Axpby.apply(g, None, beta, 0.0)
         return ga, gb, None, None
+
+
+def copy_into(dst, src):
+    """dst[...] = src for a dense destination (e.g. a batch slice of an NHWC buffer) without autograd history: one HIP launch."""
+    src = canon(src.detach())
+    if dst.numel() != src.numel() or dst.requires_grad:
+        raise ValueError("copy_into: size mismatch or destination requires grad")
+    if dst.dim() == 4 and not (dst.is_contiguous(memory_format=CL) or dst.is_contiguous()):
+        raise ValueError("copy_into: destination must be dense")
+    if dst.dim() == 4 and dst.shape[1] != 1 and dst.is_contiguous(memory_format=CL) != src.is_contiguous(memory_format=CL):
+        raise ValueError("copy_into: source and destination layouts differ")
+    check(lib.migan_axpby(src.data_ptr(), 1.0, None, 0.0, dst.data_ptr(), src.numel(), _stream()), "copy_into")
+    return dst
 
 
 def axpby(a, b=None, alpha=1.0, beta=1.0):

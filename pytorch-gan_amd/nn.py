@@ -342,6 +342,24 @@ def dropout_masks(masks):
         _DropoutRNG.injected = prev
 
 
+@contextlib.contextmanager
+def paired_batches(module):
+    """`module(cat(a, b))` inside this context stands for `module(a)` followed by `module(b)` (steps.dcgan_step runs the
+    discriminator on real and generated images as one batch): BatchNorm layers keep per-half statistics
+    (functional.batch_groups(2)), and masks injected with dropout_masks() - which arrive in the reference's call order,
+    all layers of the first forward, then all layers of the second - are re-paired layer by layer."""
+    inj = _DropoutRNG.injected
+    if inj is not None:
+        k = sum(1 for m in module.modules() if isinstance(m, (tnn.Dropout, tnn.Dropout2d)) and m.training and m.p > 0.0)
+        if len(inj) < 2 * k:
+            raise RuntimeError("dropout_masks(): a paired forward needs %d masks, %d left" % (2 * k, len(inj)))
+        first, second = inj[:k], inj[k:2 * k]
+        inj[:2 * k] = [torch.cat([torch.as_tensor(a, dtype=torch.float32), torch.as_tensor(b, dtype=torch.float32)])
+                       for a, b in zip(first, second)]
+    with F.batch_groups(2):
+        yield
+
+
 class _MaskPlan:
     """All dropout masks of one training step from ONE launch.  A step (functional.weight_cache_scope: one `steps.*_step`
     body) asks for the same masks in the same order every iteration - dcgan.py:77-80: four Dropout2d(0.25) layers x three

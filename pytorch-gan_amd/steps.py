@@ -13,6 +13,7 @@ read).  Results are identical either way (tests run both).
 """
 import contextlib
 import itertools
+import os
 import random
 from types import SimpleNamespace
 
@@ -56,6 +57,13 @@ def _scoped(fn):
     return wrapper
 
 
+_PAIR_D = os.environ.get("MIGAN_PAIR_D", "1") == "1"  # A/B knob: run D(real), D(fake) as one batch (dcgan_step)
+
+
+def _sync_bn(s):
+    return getattr(s.dp, "sync_bn", None) is not None
+
+
 def half_sum(a, b):
     """(a + b) / 2 as the reference writes it (bit-identical: scaling by 0.5 is exact)."""
     return F.axpby(a, b, 0.5, 0.5)
@@ -88,9 +96,24 @@ def dcgan_step(s, real_imgs, z):
     g_loss.backward()
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
-    real_loss = s.bce(s.D(real_imgs), valid)
-    fake_loss = s.bce(s.D(gen.detach()), fake)
-    d_loss = half_sum(real_loss, fake_loss)
+    if _PAIR_D and real_imgs.shape == gen.shape and not _sync_bn(s):
+        # D(real) and D(fake) of dcgan.py:176-177 as ONE pass over cat(real, fake): per-half BatchNorm statistics (and
+        # running-statistics updates in the reference's order), one launch per layer instead of two in forward and backward;
+        # mean BCE over the 2n rows against (valid | fake) == (real_loss + fake_loss) / 2
+        n = real_imgs.shape[0]
+        both = torch.empty((2 * n,) + tuple(real_imgs.shape[1:]), device=real_imgs.device, dtype=torch.float32,
+                           memory_format=torch.channels_last)
+        F.copy_into(both[:n], real_imgs)
+        F.copy_into(both[n:], gen.detach())
+        key = ("pair", n, str(real_imgs.device))
+        if key not in s.labels:
+            s.labels[key] = torch.cat([valid, fake])
+        with gnn.paired_batches(s.D):
+            d_loss = s.bce(s.D(both), s.labels[key])
+    else:
+        real_loss = s.bce(s.D(real_imgs), valid)
+        fake_loss = s.bce(s.D(gen.detach()), fake)
+        d_loss = half_sum(real_loss, fake_loss)
     d_loss.backward()
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
