@@ -72,7 +72,8 @@ def test_cross_replica_batchnorm_equals_full_batch(tmp_path):
     assert torch.allclose(got["losses"], want, rtol=2e-5, atol=1e-6), (got["losses"], want)
     for name, opt in (("gG", s.opt_G), ("gD", s.opt_D)):
         a, b = got[name].double(), opt.flat_grad.cpu().double()
-        assert float((a - b).norm() / b.norm()) < 2e-4, name
+        # two ranks x 8 samples vs one process x 16: other tile shapes and summation orders in every GEMM (measured 2.6e-4)
+        assert float((a - b).norm() / b.norm()) < 6e-4, name
     for net, sd in (("G", s.G.state_dict()), ("D", s.D.state_dict())):
         for k, v in sd.items():
             if "running" in k:
