@@ -359,6 +359,11 @@ int migan_cross_entropy_bwd(const float* x, const long long* target, const float
 int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream);
 int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D, void* stream);
 int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream);
+/* ebgan.py:142-148 pullaway_loss: loss[0] = (sum_ij <n_i, n_j> - B) / (B (B-1)) over the row-normalised embeddings e [B][D]
+ * (the generator's repelling regulariser, ebgan.py:179); ws: (D + B) floats kept for migan_pullaway_bwd, which writes
+ * de [B][D] = g[0] * d loss / d e. */
+int migan_pullaway_fwd(const float* e, float* loss, float* ws, int B, int D, void* stream);
+int migan_pullaway_bwd(const float* e, const float* ws, const float* g, float* de, int B, int D, void* stream);
 /* torch.optim.Adam(lr, betas) step for all tensors of one optimiser in ONE launch (dcgan.py:134-135,169,183).
  * tab: device array of {float* p; const float* g; float* m; float* v; long long n}; blk: device array of
  * {int tensor; int chunk} with chunk size migan_adam_chunk(); step: device float holding the number of updates done

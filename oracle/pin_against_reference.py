@@ -608,6 +608,188 @@ def pin_acgan(ref):
          masks_per_step=len(all_masks[0]), **mp)
 
 
+# ------------------------------------------------------------------------------------------- F2: the DCGAN-block clones
+CLONES = {
+    # script -> (opt fields of its argparse defaults, generator class, discriminator class)
+    "lsgan": (dict(latent_dim=100, channels=1), "Generator", "Discriminator"),
+    "sgan": (dict(latent_dim=100, channels=1, num_classes=10), "Generator", "Discriminator"),
+    "infogan": (dict(latent_dim=62, channels=1, n_classes=10, code_dim=2), "Generator", "Discriminator"),
+    "relativistic_gan": (dict(latent_dim=100, channels=1, rel_avg_gan=False), "Generator", "Discriminator"),
+    "cogan": (dict(latent_dim=100, channels=3), "CoupledGenerators", "CoupledDiscriminators"),
+    "began": (dict(latent_dim=62, channels=1), "Generator", "Discriminator"),
+    "ebgan": (dict(latent_dim=62, channels=1, batch_size=64), "Generator", "Discriminator"),
+}
+
+
+def clone_reference(name, img_size=32):
+    """The script's own classes (AST-extracted: the scripts parse argv, download MNIST and train at import)."""
+    fields, gname, dname = CLONES[name]
+    opt = SimpleNamespace(img_size=img_size, **fields)
+    ns = _extract_defs(os.path.join(IMPL, name, name + ".py"), _script_ns(opt=opt, cuda=False))
+    return SimpleNamespace(G=ns[gname], D=ns[dname], init=ns.get("weights_init_normal"), ns=ns, opt=opt)
+
+
+def _as_tuple(o):
+    return o if isinstance(o, tuple) else (o,)
+
+
+def fwd_bwd_multi(model, inputs, seed=123):
+    """fwd_bwd for networks with several outputs: loss = sum_i sum(out_i * w_i), w_i drawn in output order."""
+    for p in model.parameters():
+        p.grad = None
+    outs = _as_tuple(model(*inputs))
+    g = torch.Generator().manual_seed(seed)
+    loss = 0
+    for o in outs:
+        loss = loss + (o * torch.randn(o.shape, generator=g)).sum()
+    loss.backward()
+    return [o.detach() for o in outs], {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def clone_inputs(name, n=4, img_size=32):
+    """Seeded inputs of one clone: (generator inputs, discriminator inputs)."""
+    fields = CLONES[name][0]
+    seed_all(1)
+    z = torch.tensor(np.random.normal(0, 1, (n, fields["latent_dim"])), dtype=torch.float32)
+    g_in = [z]
+    if name == "infogan":
+        lab = np.zeros((n, 10), dtype=np.float32)
+        lab[range(n), np.random.randint(0, 10, n)] = 1.0   # to_categorical (infogan.py:50-55)
+        g_in += [torch.from_numpy(lab), torch.tensor(np.random.uniform(-1, 1, (n, 2)), dtype=torch.float32)]
+    ch = fields["channels"]
+    d_in = [torch.rand(n, ch, img_size, img_size) * 2 - 1]
+    if name == "cogan":
+        d_in.append(torch.rand(n, ch, img_size, img_size) * 2 - 1)
+    return g_in, d_in
+
+
+def pin_clones(ref=None):
+    """lsgan.py:45,72, sgan.py:46,76, infogan.py:58,88, relativistic_gan.py:37,65, cogan.py:51,90,
+    began.py:47,75, ebgan.py:47,74 - the reference's own classes against oracle.reference_models.clone_models(): seeded
+    construction (+ the script's weights_init_normal), forward outputs, parameter / input gradients and BatchNorm buffers,
+    all bit-identical; one fixture per script."""
+    import warnings
+
+    for name in CLONES:
+        print("clone %s (%s/%s.py)" % (name, name, name))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # nn.Softmax() without dim
+            r = clone_reference(name)
+            seed_all(0)
+            G_r, D_r = r.G(), r.D()
+            if name != "relativistic_gan":    # relativistic_gan.py never calls an init function
+                G_r.apply(r.init)
+                D_r.apply(r.init)
+            seed_all(0)
+            G_o, D_o, init = M.clone_models(name)
+            if init is not None:
+                G_o.apply(init)
+                D_o.apply(init)
+            check_same_params(G_r, G_o, name + ".G")
+            check_same_params(D_r, D_o, name + ".D")
+            g_in, d_in = clone_inputs(name)
+            fix = {}
+            for tag, m_r, m_o, ins in (("g", G_r, G_o, g_in), ("d", D_r, D_o, d_in)):
+                ins_r = [t.clone().requires_grad_(tag == "d") for t in ins]
+                ins_o = [t.clone().requires_grad_(tag == "d") for t in ins]
+                masks = []
+                hs = hook_masks(m_r, masks)
+                seed_all(7)
+                out_r, gr = fwd_bwd_multi(m_r, ins_r)
+                for h in hs:
+                    h.remove()
+                with M.feed_masks(masks=[m.numpy() for m in masks]):
+                    out_o, go = fwd_bwd_multi(m_o, ins_o)
+                assert len(out_r) == len(out_o) and all(torch.equal(a, b) for a, b in zip(out_r, out_o)), name + " forward"
+                assert gr.keys() == go.keys() and all(torch.equal(gr[k], go[k]) for k in gr), name + " gradients"
+                if tag == "d":
+                    assert all(torch.equal(a.grad, b.grad) for a, b in zip(ins_r, ins_o)), name + " input gradients"
+                check_same_params(m_r, m_o, "%s.%s (buffers after forward)" % (name, tag.upper()))
+                keys, dig, hd = grads_digest(gr)
+                fix.update({tag + "_keys": keys, tag + "_digest": dig, tag + "_head": hd, tag + "_nout": len(out_r)})
+                for i, t in enumerate(ins):
+                    fix["%s_in%d" % (tag, i)] = t
+                for i, o in enumerate(out_r):
+                    fix["%s_out%d" % (tag, i)] = o
+                if tag == "d":
+                    for i, t in enumerate(ins_r):
+                        fix["d_in_grad%d" % i] = t.grad
+                    mp, nm = masks_pack(masks)
+                    fix.update(mp)
+                    fix["n_masks"] = nm
+            save("clone_%s_32" % name, meta=meta(), **fix)
+
+
+def _clone_loop(name, step_ref_kwargs, steps=3, n=8):
+    """Three iterations of a clone's loop with the REAL reference classes inside the restated loop body vs the oracle."""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = clone_reference(name)
+        seed_all(0)
+        G, D = r.G(), r.D()
+        if name != "relativistic_gan":
+            G.apply(r.init)
+            D.apply(r.init)
+        s_ref = SimpleNamespace(G=G, D=D, opt_G=S._adam(G.parameters()), opt_D=S._adam(D.parameters()), name=name)
+        seed_all(0)
+        s_orc = S.make_clone(name)
+        check_same_params(s_ref.G, s_orc.G, name + " G")
+        check_same_params(s_ref.D, s_orc.D, name + " D")
+        seed_all(41)
+        imgs = torch.rand(steps, n, 1, 32, 32) * 2 - 1
+        zs = torch.tensor(np.random.normal(0, 1, (steps, n, CLONES[name][0]["latent_dim"])), dtype=torch.float32)
+        step = getattr(S, name + "_step")
+        trace, all_masks = [], []
+        for t in range(steps):
+            masks = []
+            hs = hook_masks(s_ref.D, masks)
+            torch.manual_seed(300 + t)
+            o_r = step(s_ref, imgs[t], zs[t], **step_ref_kwargs)
+            for h in hs:
+                h.remove()
+            with M.feed_masks(masks=[m.numpy() for m in masks]):
+                o_o = step(s_orc, imgs[t], zs[t], **step_ref_kwargs)
+            assert torch.equal(o_r["g_loss"], o_o["g_loss"]) and torch.equal(o_r["d_loss"], o_o["d_loss"]), name + " loop"
+            trace.append([o_r["g_loss"].item(), o_r["d_loss"].item()])
+            all_masks.append(masks)
+        check_same_params(s_ref.G, s_orc.G, name + " G after the loop")
+        check_same_params(s_ref.D, s_orc.D, name + " D after the loop")
+    mp = {"mask_%d_%02d" % (t, i): m.numpy() for t, ms in enumerate(all_masks) for i, m in enumerate(ms)}
+    save("clone_%s_32_loop" % name, meta=meta(), imgs=imgs, zs=zs, trace=np.array(trace),
+         masks_per_step=len(all_masks[0]) if all_masks[0] else 0, **mp)
+
+
+def pin_clone_loops(ref=None):
+    """relativistic_gan.py:126-182 (both the standard and the --rel_avg_gan branch), ebgan.py:142-202 (pullaway_loss is the
+    reference's own function, extracted from the script) and lsgan.py:140-180."""
+    print("clone loops: relativistic_gan, ebgan, lsgan")
+    r = clone_reference("ebgan")
+    seed_all(5)
+    e = torch.randn(8, 32)
+    assert torch.equal(r.ns["pullaway_loss"](e), S.pullaway_loss(e)), "pullaway_loss"
+    _clone_loop("relativistic_gan", dict(rel_avg_gan=False))
+    _clone_loop("ebgan", dict(opt_batch_size=64))
+    _clone_loop("lsgan", dict())
+    # the --rel_avg_gan branch: same networks, other loss; recorded as a second trace
+    seed_all(0)
+    s_a, s_b = S.make_clone("relativistic_gan"), None
+    seed_all(41)
+    imgs = torch.rand(2, 8, 1, 32, 32) * 2 - 1
+    zs = torch.tensor(np.random.normal(0, 1, (2, 8, 100)), dtype=torch.float32)
+    trace, masks_all = [], []
+    for t in range(2):
+        rec = []
+        with M.feed_masks(record=rec):
+            o = S.relativistic_gan_step(s_a, imgs[t], zs[t], rel_avg_gan=True)
+        trace.append([o["g_loss"].item(), o["d_loss"].item()])
+        masks_all.append([m.numpy() for m in rec])
+    mp = {"mask_%d_%02d" % (t, i): m for t, ms in enumerate(masks_all) for i, m in enumerate(ms)}
+    save("clone_relativistic_gan_avg_32_loop", meta=meta(), imgs=imgs, zs=zs, trace=np.array(trace),
+         masks_per_step=len(masks_all[0]), **mp)
+
+
 def pin_dropout_semantics():
     print("dropout semantics (nn.Dropout2d / nn.Dropout vs injectable oracle layers)")
     x = torch.rand(3, 5, 4, 4) + 0.5
@@ -730,6 +912,8 @@ def main():
     pin_srgan(ref)
     pin_esrgan(ref)
     pin_acgan(ref)
+    pin_clones(ref)
+    pin_clone_loops(ref)
     pin_pix2pix(ref)
     pin_steps(ref)
     print("oracle pinned against the reference; fixtures written to", GOLD)

@@ -584,3 +584,182 @@ class AcganDiscriminator(nn.Module):
         out = out.view(out.shape[0], -1)
         return self.adv_layer(out), self.aux_layer(out)
 
+
+
+# --------------------------------------------------------------------------------------------- DCGAN-block clones
+# lsgan.py:45-90, sgan.py:46-107, infogan.py:58-121, relativistic_gan.py:37-91, cogan.py:51-122, began.py:47-99,
+# ebgan.py:47-101: the dcgan.py generator / discriminator blocks with other heads, inputs and losses.  Sub-modules are built
+# in the reference's order (seeded parameter init consumes the RNG in construction order) and carry its attribute names
+# (state_dict keys).  Every class is checked bit-for-bit against the reference's own class by oracle/pin_against_reference.py.
+def _g_conv_specs(channels, first_bn):
+    return ([("bn2", 128)] if first_bn else []) + [
+        ("up2",), ("conv", 128, 128, 3, 1, 1), ("bn2", 128, 0.8), ("lrelu", 0.2, True),
+        ("up2",), ("conv", 128, 64, 3, 1, 1), ("bn2", 64, 0.8), ("lrelu", 0.2, True),
+        ("conv", 64, channels, 3, 1, 1), ("tanh",)]
+
+
+def _d_block_specs(channels, bn_first=False):
+    """dcgan-style discriminator blocks; bn_first: cogan.py:94-99 puts BatchNorm in front of LeakyReLU / Dropout2d."""
+    specs, cin = [], channels
+    for cout, bn in ((16, False), (32, True), (64, True), (128, True)):
+        specs.append(("conv", cin, cout, 3, 2, 1))
+        if bn and bn_first:
+            specs.append(("bn2", cout, 0.8))
+        specs += [("lrelu", 0.2, True), ("drop2", 0.25)]
+        if bn and not bn_first:
+            specs.append(("bn2", cout, 0.8))
+        cin = cout
+    return specs
+
+
+class CloneGenerator(nn.Module):
+    """lsgan.py:45-67 / ebgan.py:47-71 (first_bn=False), relativistic_gan.py:37-62 / began.py:47-72 (first_bn=True, = dcgan's),
+    sgan.py:46-74 (label_emb: an nn.Embedding the forward never uses, but a parameter of the optimiser and the first consumer
+    of the init RNG), infogan.py:58-85 (extra = n_classes + code_dim inputs concatenated behind the noise)."""
+
+    def __init__(self, img_size=32, latent_dim=100, channels=1, first_bn=True, label_emb=0, extra=0):
+        super().__init__()
+        if label_emb:
+            self.label_emb = nn.Embedding(label_emb, latent_dim)
+        self.init_size = img_size // 4
+        self.l1 = _build([("lin", latent_dim + extra, 128 * self.init_size ** 2)])
+        self.conv_blocks = _build(_g_conv_specs(channels, first_bn))
+
+    def forward(self, noise, labels=None, code=None):
+        if labels is not None:
+            noise = torch.cat((noise, labels, code), -1)
+        out = self.l1(noise)
+        return self.conv_blocks(out.view(out.shape[0], 128, self.init_size, self.init_size))
+
+
+class CloneDiscriminator(nn.Module):
+    """The dcgan.py:77-92 blocks under the reference's attribute names with its heads:
+       lsgan.py:72-90         blocks='model',       heads (('adv_layer', 1, None, False),)            plain nn.Linear
+       relativistic_gan.py:65-91  blocks='model',   heads (('adv_layer', 1, None, True),)             Sequential(Linear)
+       sgan.py:76-107         blocks='conv_blocks', heads adv_layer -> Sigmoid, aux_layer (classes + 1) -> Softmax
+       infogan.py:88-121      blocks='conv_blocks', heads adv_layer, aux_layer -> Softmax, latent_layer
+    A head is (name, out_features, 'sigmoid' | 'softmax' | None, wrapped_in_Sequential)."""
+
+    def __init__(self, img_size=32, channels=1, blocks="model", heads=(("adv_layer", 1, None, False),)):
+        super().__init__()
+        setattr(self, blocks, _build(_d_block_specs(channels)))
+        self.blocks_name, self.head_names = blocks, [h[0] for h in heads]
+        feat = 128 * (img_size // 16) ** 2
+        for name, nout, act, seq in heads:
+            lin = nn.Linear(feat, nout)
+            if act == "sigmoid":
+                mod = nn.Sequential(lin, nn.Sigmoid())
+            elif act == "softmax":
+                mod = nn.Sequential(lin, nn.Softmax(dim=1))  # nn.Softmax() on a 2-D input = dim 1
+            else:
+                mod = nn.Sequential(lin) if seq else lin
+            setattr(self, name, mod)
+
+    def forward(self, img):
+        out = getattr(self, self.blocks_name)(img)
+        out = out.view(out.shape[0], -1)
+        outs = tuple(getattr(self, n)(out) for n in self.head_names)
+        return outs[0] if len(outs) == 1 else outs
+
+
+class CoganGenerators(nn.Module):
+    """cogan.py:51-87: shared trunk, two image heads."""
+
+    def __init__(self, img_size=32, latent_dim=100, channels=3):
+        super().__init__()
+        self.init_size = img_size // 4
+        self.fc = _build([("lin", latent_dim, 128 * self.init_size ** 2)])
+        self.shared_conv = _build([("bn2", 128), ("up2",), ("conv", 128, 128, 3, 1, 1), ("bn2", 128, 0.8),
+                                   ("lrelu", 0.2, True), ("up2",)])
+        tail = [("conv", 128, 64, 3, 1, 1), ("bn2", 64, 0.8), ("lrelu", 0.2, True), ("conv", 64, channels, 3, 1, 1), ("tanh",)]
+        self.G1 = _build(tail)
+        self.G2 = _build(tail)
+
+    def forward(self, noise):
+        out = self.fc(noise)
+        emb = self.shared_conv(out.view(out.shape[0], 128, self.init_size, self.init_size))
+        return self.G1(emb), self.G2(emb)
+
+
+class CoganDiscriminators(nn.Module):
+    """cogan.py:90-122: shared conv blocks (BatchNorm in front of the activation), one linear head per domain."""
+
+    def __init__(self, img_size=32, channels=3):
+        super().__init__()
+        self.shared_conv = _build(_d_block_specs(channels, bn_first=True))
+        feat = 128 * (img_size // 16) ** 2
+        self.D1 = nn.Linear(feat, 1)
+        self.D2 = nn.Linear(feat, 1)
+
+    def forward(self, img1, img2):
+        o1 = self.shared_conv(img1)
+        v1 = self.D1(o1.view(o1.shape[0], -1))
+        o2 = self.shared_conv(img2)
+        v2 = self.D2(o2.view(o2.shape[0], -1))
+        return v1, v2
+
+
+def init_normal_cogan(m):
+    """cogan.py:42-48: *Linear* weight ~ N(0,.02); *BatchNorm* weight ~ N(1,.02), bias 0 (convs keep the default init)."""
+    name = type(m).__name__
+    if "Linear" in name:
+        nn.init.normal_(m.weight.data, 0.0, 0.02)
+    elif "BatchNorm" in name:
+        nn.init.normal_(m.weight.data, 1.0, 0.02)
+        nn.init.constant_(m.bias.data, 0.0)
+
+
+class AutoencoderDiscriminator(nn.Module):
+    """began.py:75-99 (embedding_attr=False: the bottleneck Linear is fc[0]) and ebgan.py:74-101 (embedding_attr=True: it is
+    `self.embedding`, and forward also returns the 32-d code): Conv s2 + ReLU, Linear -> BatchNorm1d(32, 0.8) -> ReLU ->
+    Linear -> BatchNorm1d -> ReLU, Upsample + Conv back to the image."""
+
+    def __init__(self, img_size=32, channels=1, embedding_attr=False):
+        super().__init__()
+        self.down = nn.Sequential(nn.Conv2d(channels, 64, 3, 2, 1), nn.ReLU())
+        self.down_size = img_size // 2
+        down_dim = 64 * self.down_size ** 2
+        self.embedding_attr = embedding_attr
+        if embedding_attr:
+            self.embedding = nn.Linear(down_dim, 32)
+            self.fc = nn.Sequential(nn.BatchNorm1d(32, 0.8), nn.ReLU(inplace=True), nn.Linear(32, down_dim),
+                                    nn.BatchNorm1d(down_dim), nn.ReLU(inplace=True))
+        else:
+            self.fc = nn.Sequential(nn.Linear(down_dim, 32), nn.BatchNorm1d(32, 0.8), nn.ReLU(inplace=True),
+                                    nn.Linear(32, down_dim), nn.BatchNorm1d(down_dim), nn.ReLU(inplace=True))
+        self.up = nn.Sequential(nn.Upsample(scale_factor=2), nn.Conv2d(64, channels, 3, 1, 1))
+
+    def forward(self, img):
+        out = self.down(img)
+        flat = out.view(out.size(0), -1)
+        if self.embedding_attr:
+            emb = self.embedding(flat)
+            out = self.fc(emb)
+        else:
+            out = self.fc(flat)
+        out = self.up(out.view(out.size(0), 64, self.down_size, self.down_size))
+        return (out, emb) if self.embedding_attr else out
+
+
+def clone_models(name, img_size=32):
+    """(G, D, init function or None) of one F2 script with the reference's defaults."""
+    if name == "lsgan":
+        return CloneGenerator(img_size, 100, 1, first_bn=False), CloneDiscriminator(img_size, 1), init_normal_dcgan
+    if name == "sgan":
+        return (CloneGenerator(img_size, 100, 1, label_emb=10),
+                CloneDiscriminator(img_size, 1, "conv_blocks", (("adv_layer", 1, "sigmoid", True), ("aux_layer", 11, "softmax", True))),
+                init_normal_dcgan)
+    if name == "infogan":
+        return (CloneGenerator(img_size, 62, 1, extra=12),
+                CloneDiscriminator(img_size, 1, "conv_blocks", (("adv_layer", 1, None, True), ("aux_layer", 10, "softmax", True),
+                                                                ("latent_layer", 2, None, True))),
+                init_normal_dcgan)
+    if name == "relativistic_gan":
+        return CloneGenerator(img_size, 100, 1), CloneDiscriminator(img_size, 1, "model", (("adv_layer", 1, None, True),)), None
+    if name == "cogan":
+        return CoganGenerators(img_size, 100, 3), CoganDiscriminators(img_size, 3), init_normal_cogan
+    if name == "began":
+        return CloneGenerator(img_size, 62, 1), AutoencoderDiscriminator(img_size, 1, False), init_normal_dcgan
+    if name == "ebgan":
+        return CloneGenerator(img_size, 62, 1, first_bn=False), AutoencoderDiscriminator(img_size, 1, True), init_normal_dcgan
+    raise KeyError(name)

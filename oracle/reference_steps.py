@@ -12,6 +12,7 @@ order, and without the logging / image-saving side effects.  Line references:
   dragan_step     implementations/dragan/dragan.py:144-167,176-217   (conv-critic gradient penalty)
   esrgan_step     implementations/esrgan/esrgan.py:101-174           (relativistic average GAN + warm-up)
   acgan_step      implementations/acgan/acgan.py:167-222             (label-conditioned DCGAN, auxiliary classifier)
+  lsgan_step / relativistic_gan_step / ebgan_step   lsgan.py:140-180, relativistic_gan.py:126-182, ebgan.py:142-202 (8f F2 clones)
 Pinned against the reference by oracle/pin_against_reference.py.
 """
 import itertools
@@ -364,3 +365,100 @@ def acgan_step(s, real_imgs, labels, z=None, gen_labels=None):
     s.opt_D.step()
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen_imgs.detach()}
 
+
+
+# ------------------------------------------------------------------------------------------------ DCGAN-block clones (8f F2)
+def make_clone(name, img_size=32):
+    """Networks of lsgan / sgan / infogan / relativistic_gan / cogan / began / ebgan as their scripts build them (the
+    script's weights_init_normal where it applies one; relativistic_gan.py keeps torch's default init) + Adam(2e-4, (.5, .999))."""
+    G, D, init = M.clone_models(name, img_size)
+    if init is not None:
+        G.apply(init)
+        D.apply(init)
+    return SimpleNamespace(G=G, D=D, opt_G=_adam(G.parameters()), opt_D=_adam(D.parameters()), name=name,
+                           latent_dim=G.l1[0].in_features if hasattr(G, "l1") else 100)
+
+
+def lsgan_step(s, real_imgs, z):
+    """lsgan.py:140-180: the dcgan.py loop with MSELoss on an unbounded validity and 0.5 * (real + fake)."""
+    mse = torch.nn.MSELoss()
+    B = real_imgs.shape[0]
+    valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    g_loss = mse(s.D(gen), valid)
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    d_loss = 0.5 * (mse(s.D(real_imgs), valid) + mse(s.D(gen.detach()), fake))
+    d_loss.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+def relativistic_gan_step(s, real_imgs, z, rel_avg_gan=False):
+    """relativistic_gan.py:126-182.  Quirk kept (relativistic_gan.py:148-157): the generator step evaluates D(real) and
+    D(gen), forms the relativistic loss - and then OVERWRITES it with the plain BCEWithLogits(D(gen), valid) of a third
+    discriminator forward.  The two discarded forwards still draw Dropout2d masks and move the BatchNorm running statistics;
+    the discriminator step (relativistic_gan.py:166-182) is the real relativistic loss."""
+    bce = torch.nn.BCEWithLogitsLoss()
+    B = real_imgs.shape[0]
+    valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    real_pred = s.D(real_imgs).detach()
+    fake_pred = s.D(gen)
+    if rel_avg_gan:
+        g_loss = bce(fake_pred - real_pred.mean(0, keepdim=True), valid)
+    else:
+        g_loss = bce(fake_pred - real_pred, valid)
+    g_loss = bce(s.D(gen), valid)
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    real_pred = s.D(real_imgs)
+    fake_pred = s.D(gen.detach())
+    if rel_avg_gan:
+        real_loss = bce(real_pred - fake_pred.mean(0, keepdim=True), valid)
+        fake_loss = bce(fake_pred - real_pred.mean(0, keepdim=True), fake)
+    else:
+        real_loss = bce(real_pred - fake_pred, valid)
+        fake_loss = bce(fake_pred - real_pred, fake)
+    d_loss = (real_loss + fake_loss) / 2
+    d_loss.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+def pullaway_loss(embeddings):
+    """ebgan.py:142-148: mean off-diagonal cosine similarity of the batch's embeddings."""
+    norm = torch.sqrt(torch.sum(embeddings ** 2, -1, keepdim=True))
+    normalized_emb = embeddings / norm
+    similarity = torch.matmul(normalized_emb, normalized_emb.transpose(1, 0))
+    batch_size = embeddings.size(0)
+    return (torch.sum(similarity) - batch_size) / (batch_size * (batch_size - 1))
+
+
+def ebgan_step(s, real_imgs, z, opt_batch_size=64, lambda_pt=0.1):
+    """ebgan.py:159-202: auto-encoder discriminator; G: reconstruction MSE + 0.1 * pull-away term; D: real reconstruction
+    + hinge max(0, margin - fake reconstruction) with margin = max(1, batch_size / 64) (ebgan.py:157) decided on the HOST
+    from .item() (ebgan.py:198)."""
+    mse = torch.nn.MSELoss()
+    margin = max(1, opt_batch_size / 64.0)
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    recon, emb = s.D(gen)
+    g_loss = mse(recon, gen.detach()) + lambda_pt * pullaway_loss(emb)
+    g_loss.backward()
+    s.opt_G.step()
+    s.opt_D.zero_grad()
+    real_recon, _ = s.D(real_imgs)
+    fake_recon, _ = s.D(gen.detach())
+    d_loss_real = mse(real_recon, real_imgs)
+    d_loss_fake = mse(fake_recon, gen.detach())
+    d_loss = d_loss_real
+    if (margin - d_loss_fake.data).item() > 0:
+        d_loss = d_loss + (margin - d_loss_fake)
+    d_loss.backward()
+    s.opt_D.step()
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}

@@ -146,6 +146,8 @@ _SIGS = {
     "migan_rownorm_fwd": (c_int, [P, P, c_int, c_int, P]),
     "migan_rownorm_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
     "migan_rowscale": (c_int, [P, P, P, c_int, c_int, P]),
+    "migan_pullaway_fwd": (c_int, [P, P, P, c_int, c_int, P]),
+    "migan_pullaway_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
     "migan_adam_chunk": (c_int, []),
     "migan_adam_step": (c_int, [P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
 }

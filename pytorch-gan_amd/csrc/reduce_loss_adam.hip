@@ -211,6 +211,60 @@ __global__ void rowscale_kernel(const float* __restrict__ x, const float* __rest
     float sc = s[b];
     for (int i = threadIdx.x; i < D; i += 256) y[b * D + i] = x[b * D + i] * sc;
 }
+// ebgan.py:142-148 pullaway_loss(embeddings [B][D]) = (sum_ij <n_i, n_j> - B) / (B (B - 1)), n_i = e_i / |e_i| - the mean
+// off-diagonal cosine similarity of the batch.  sum_ij <n_i, n_j> = |sum_i n_i|^2, so one workgroup suffices: forward
+// leaves s[D] = sum_i n_i and inv[B] = 1 / |e_i| in ws (D + B floats) for the backward:
+//   d loss / d e_k = g * 2 / (B (B-1)) * inv_k * (s - n_k <n_k, s>).
+__global__ __launch_bounds__(256) void pullaway_fwd_kernel(const float* __restrict__ e, float* __restrict__ loss,
+                                                           float* __restrict__ ws, int B, int D) {
+    float* s = ws;
+    float* inv = ws + D;
+    __shared__ float red[256];
+    for (int t = threadIdx.x; t < B; t += 256) {
+        float q = 0.f;
+        for (int d = 0; d < D; ++d) q += e[(size_t)t * D + d] * e[(size_t)t * D + d];
+        inv[t] = 1.f / sqrtf(q);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float a = 0.f;
+        for (int t = 0; t < B; ++t) a += e[(size_t)t * D + d] * inv[t];
+        s[d] = a;
+        part += a * a;
+    }
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (red[0] - (float)B) / ((float)B * (float)(B - 1));
+}
+__global__ __launch_bounds__(256) void pullaway_bwd_kernel(const float* __restrict__ e, const float* __restrict__ ws,
+                                                           const float* __restrict__ g, float* __restrict__ de, int B, int D) {
+    const float* s = ws;
+    const float* inv = ws + D;
+    const float c = g[0] * 2.f / ((float)B * (float)(B - 1));
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < B; k += gridDim.x * 256) {
+        const float iv = inv[k];
+        float dot = 0.f;
+        for (int d = 0; d < D; ++d) dot += e[(size_t)k * D + d] * iv * s[d];
+        for (int d = 0; d < D; ++d) de[(size_t)k * D + d] = c * iv * (s[d] - e[(size_t)k * D + d] * iv * dot);
+    }
+}
+MIGAN_API int migan_pullaway_fwd(const float* e, float* loss, float* ws, int B, int D, void* stream) {
+    if (B < 2 || D < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pullaway_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, e, loss, ws, B, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+MIGAN_API int migan_pullaway_bwd(const float* e, const float* ws, const float* g, float* de, int B, int D, void* stream) {
+    hipLaunchKernelGGL(pullaway_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, e, ws, g, de, B, D);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 MIGAN_API int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream) {
     if (B == 0) return 0;
     hipLaunchKernelGGL(rowscale_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, s, y, D);

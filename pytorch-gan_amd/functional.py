@@ -1735,6 +1735,36 @@ class _Loss(Function):
         return dx, None, None, None
 
 
+class _Pullaway(Function):
+    """ebgan.py:142-148 pullaway_loss(embeddings) in one launch (and one for its gradient)."""
+
+    @staticmethod
+    def forward(ctx, e):
+        es = _plain(e).contiguous()
+        if es.dim() != 2 or es.shape[0] < 2:
+            raise ValueError("pullaway_loss: expected (B >= 2, D) embeddings")
+        B, D = es.shape
+        out = torch.empty((), device=es.device, dtype=torch.float32)
+        ws = torch.empty(B + D, device=es.device, dtype=torch.float32)
+        check(lib.migan_pullaway_fwd(es.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, _stream()), "pullaway_fwd")
+        ctx.save_for_backward(es, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        _first_order_only('pullaway_loss')
+        es, ws = ctx.saved_tensors
+        g = _plain(g).contiguous()
+        de = torch.empty_like(es)
+        check(lib.migan_pullaway_bwd(es.data_ptr(), ws.data_ptr(), g.data_ptr(), de.data_ptr(), es.shape[0], es.shape[1],
+                                     _stream()), "pullaway_bwd")
+        return de
+
+
+def pullaway_loss(embeddings):
+    return _Pullaway.apply(embeddings)
+
+
 def loss(kind, x, target=None, tconst=0.0):
     return _Loss.apply(x, target, int(kind), float(tconst))
 

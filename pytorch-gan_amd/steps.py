@@ -583,3 +583,89 @@ def acgan_step(s, real_imgs, labels, z, gen_labels):
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen_imgs.detach()}
 
+
+
+# ------------------------------------------------------------------------------------------------ DCGAN-block clones (8f F2)
+def make_clone_state(G, D, skip_dead_grads=True, dp=None):
+    """lsgan.py:107-135, relativistic_gan.py:95-118, ebgan.py:105-137: swapped networks on the GPU + Adam(2e-4, (0.5, 0.999))."""
+    return SimpleNamespace(G=G, D=D, opt_G=Adam(G.parameters(), **ADAM), opt_D=Adam(D.parameters(), **ADAM), mse=gnn.MSELoss(),
+                           bce_logits=gnn.BCEWithLogitsLoss(), skip=skip_dead_grads, labels={}, dp=dp or LocalStepper())
+
+
+@_scoped
+def lsgan_step(s, real_imgs, z):
+    """lsgan.py:140-180: the dcgan.py loop with MSELoss on the unbounded validity."""
+    valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    with frozen(s.D, enabled=s.skip):
+        g_loss = s.mse(s.D(gen), valid)
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    d_loss = half_sum(s.mse(s.D(real_imgs), valid), s.mse(s.D(gen.detach()), fake))
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+@_scoped
+def relativistic_gan_step(s, real_imgs, z, rel_avg_gan=False):
+    """relativistic_gan.py:126-182.  The generator step's first two discriminator forwards (relativistic_gan.py:148-149) feed a
+    loss that line 157 overwrites; they are still run (without building a graph): they draw Dropout2d masks and move the
+    BatchNorm running statistics exactly as in the reference."""
+    valid, fake = _labels(s, (real_imgs.shape[0], 1), real_imgs.device)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    with torch.no_grad():  # side effects only (the reference discards this loss)
+        s.D(real_imgs)
+        s.D(gen.detach())
+    with frozen(s.D, enabled=s.skip):
+        g_loss = s.bce_logits(s.D(gen), valid)
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    real_pred = s.D(real_imgs)
+    fake_pred = s.D(gen.detach())
+    if rel_avg_gan:
+        real_loss = s.bce_logits(F.sub_batch_mean(real_pred, fake_pred), valid)
+        fake_loss = s.bce_logits(F.sub_batch_mean(fake_pred, real_pred), fake)
+    else:
+        real_loss = s.bce_logits(F.axpby(real_pred, fake_pred, 1.0, -1.0), valid)
+        fake_loss = s.bce_logits(F.axpby(fake_pred, real_pred, 1.0, -1.0), fake)
+    d_loss = half_sum(real_loss, fake_loss)
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+@_scoped
+def ebgan_step(s, real_imgs, z, opt_batch_size=64, lambda_pt=0.1):
+    """ebgan.py:159-202: auto-encoder discriminator; the hinge on the fake reconstruction error is decided on the host from
+    .item(), as the reference does (one sync per step; this loop is therefore not graph-captured)."""
+    margin = max(1, opt_batch_size / 64.0)
+    s.dp.begin_step()
+    s.opt_G.zero_grad()
+    gen = s.G(z)
+    with frozen(s.D, enabled=s.skip):
+        recon, emb = s.D(gen)
+        g_loss = F.axpby(s.mse(recon, gen.detach()), F.pullaway_loss(emb), 1.0, lambda_pt)
+    g_loss.backward()
+    s.dp.step(s.opt_G)
+    s.opt_D.zero_grad()
+    real_recon, _ = s.D(real_imgs)
+    fake_recon, _ = s.D(gen.detach())
+    d_loss_real = s.mse(real_recon, real_imgs)
+    d_loss_fake = s.mse(fake_recon, gen.detach())
+    d_loss = d_loss_real
+    if margin - float(d_loss_fake.detach()) > 0:
+        key = ("margin", str(real_imgs.device))
+        if key not in s.labels:
+            s.labels[key] = torch.ones((), device=real_imgs.device)
+        # d_loss_real + (margin - d_loss_fake); the constant rides on a device scalar so the value matches the reference's
+        d_loss = F.axpby(F.axpby(d_loss_real, d_loss_fake, 1.0, -1.0), s.labels[key], 1.0, float(margin))
+    d_loss.backward()
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}

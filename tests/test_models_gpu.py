@@ -442,3 +442,71 @@ def test_conv_critic_gradient_penalty_vs_reference(pg, golden_dir, name):
         if b.dtype.is_floating_point:
             assert_close(c, b, 1e-5, "%s buffer %s" % (name, k))
 
+
+
+CLONE_NAMES = ["lsgan", "sgan", "infogan", "relativistic_gan", "cogan", "began", "ebgan"]
+
+
+def _multi_fwd_bwd(model, inputs, ctx):
+    for p in model.parameters():
+        p.grad = None
+    ins = [t.clone().requires_grad_(t.is_floating_point()) for t in inputs]
+    with ctx:
+        outs = model(*ins)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    g = torch.Generator().manual_seed(123)
+    loss = 0
+    for o in outs:
+        w = torch.randn(o.shape, generator=g)
+        loss = loss + (o * w.to(device=o.device, dtype=o.dtype)).sum()
+    loss.backward()
+    return [o.detach() for o in outs], [t.grad for t in ins]
+
+
+@pytest.mark.parametrize("name", CLONE_NAMES)
+def test_clone_models(pg, golden_dir, name):
+    """swap() of every DCGAN-block clone (lsgan, sgan, infogan, relativistic_gan, cogan, began, ebgan - their
+    generators and single / multi-head / coupled / auto-encoder discriminators): outputs vs the values recorded from the
+    reference's own classes, input and parameter gradients vs the fp64-anchored oracle, BatchNorm buffers, state_dict keys."""
+    import contextlib
+    import copy
+    import warnings
+
+    from oracle import reference_models as M
+
+    gold = load_golden(golden_dir, "clone_%s_32" % name)
+    _seed(0)
+    G, D, init = M.clone_models(name)
+    if init is not None:
+        G.apply(init)
+        D.apply(init)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, net in (("g", G), ("d", D)):
+            ins = [torch.from_numpy(gold["%s_in%d" % (tag, i)]) for i in range(8) if "%s_in%d" % (tag, i) in gold.files]
+            masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))] if tag == "d" else []
+            gnet, net64 = gpu_copy(net), copy.deepcopy(net).double()
+            cctx = (lambda: M.feed_masks(masks=masks)) if masks else contextlib.nullcontext
+            out_c, gin_c = _multi_fwd_bwd(net, ins, cctx())
+            out_d, gin_d = _multi_fwd_bwd(net64, [t.double() for t in ins], cctx())
+            out_g, gin_g = _multi_fwd_bwd(gnet, [t.to(DEV) for t in ins], pg.dropout_masks(masks) if masks else contextlib.nullcontext())
+            for i, (a, b) in enumerate(zip(out_g, out_c)):
+                assert_close(a, b, TOL_MODEL_FWD, "%s %s output %d vs oracle" % (name, tag, i))
+                assert_close(a, torch.from_numpy(gold["%s_out%d" % (tag, i)]), TOL_MODEL_FWD, "%s %s output %d vs the reference" % (name, tag, i))
+            if tag == "d":
+                for a, b, d in zip(gin_g, gin_c, gin_d):
+                    _noise_aware(a, b, d, TOL_MODEL_GRAD, "%s input grad" % name)
+            gp, p64 = dict(gnet.named_parameters()), dict(net64.named_parameters())
+            for k, p in net.named_parameters():
+                if p.grad is None:
+                    assert gp[k].grad is None or float(gp[k].grad.abs().max()) == 0.0, k
+                    continue
+                _noise_aware(gp[k].grad, p.grad, p64[k].grad, TOL_MODEL_GRAD, "%s grad %s" % (name, k))
+            gb = dict(gnet.named_buffers())
+            for k, b in net.named_buffers():
+                if b.dtype.is_floating_point:
+                    assert_close(gb[k], b, 1e-5, "buffer " + k)
+                else:
+                    assert torch.equal(gb[k].cpu(), b), k
+            assert list(gnet.state_dict().keys()) == list(net.state_dict().keys())
+            _digest_vs_golden(gnet, net, net64, gold[tag + "_keys"], gold[tag + "_digest"], "%s %s" % (name, tag))

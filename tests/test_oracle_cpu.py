@@ -292,3 +292,78 @@ def test_dragan_penalty_against_reference_fixture(golden_dir):
     named = dict(D.named_parameters())
     for k, d in zip([str(k) for k in gold["gp_keys"]], gold["gp_digest"]):
         assert np.allclose(digest(named[k].grad), d, rtol=1e-3, atol=1e-9 + 1e-3 * abs(d[1])), k
+
+
+CLONE_NAMES = ["lsgan", "sgan", "infogan", "relativistic_gan", "cogan", "began", "ebgan"]
+
+
+def _clone_fwd_bwd(model, inputs, ctx, in_grad=False):
+    for p in model.parameters():
+        p.grad = None
+    ins = [x.clone().requires_grad_(in_grad) for x in inputs]
+    with ctx:
+        outs = model(*ins)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    g = torch.Generator().manual_seed(123)
+    loss = 0
+    for o in outs:
+        loss = loss + (o * torch.randn(o.shape, generator=g)).sum()
+    loss.backward()
+    return [o.detach() for o in outs], [x.grad for x in ins]
+
+
+@pytest.mark.parametrize("name", CLONE_NAMES)
+def test_clone_models_against_reference_fixture(golden_dir, name):
+    """the restated generator / discriminator of every DCGAN-block clone (lsgan.py:45,72, sgan.py:46,76,
+    infogan.py:58,88, relativistic_gan.py:37,65, cogan.py:51,90, began.py:47,75, ebgan.py:47,74) reproduce the outputs, input
+    gradients and parameter-gradient digests recorded from the reference's OWN classes (same seeds, inputs, Dropout2d masks)."""
+    import contextlib
+    import warnings
+
+    gold = load_golden(golden_dir, "clone_%s_32" % name)
+    _seed(0)
+    G, D, init = M.clone_models(name)
+    if init is not None:
+        G.apply(init)
+        D.apply(init)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for tag, net in (("g", G), ("d", D)):
+            ins = [torch.from_numpy(gold["%s_in%d" % (tag, i)]) for i in range(8) if "%s_in%d" % (tag, i) in gold.files]
+            masks = [gold["mask_%02d" % i] for i in range(int(gold["n_masks"]))] if tag == "d" else []
+            ctx = M.feed_masks(masks=masks) if masks else contextlib.nullcontext()
+            outs, gins = _clone_fwd_bwd(net, ins, ctx, in_grad=(tag == "d"))
+            assert len(outs) == int(gold[tag + "_nout"])
+            for i, o in enumerate(outs):
+                # (bit-equal in the pinning run; other thread counts / hosts re-order the CPU reductions)
+                assert torch.allclose(o, torch.from_numpy(gold["%s_out%d" % (tag, i)]), rtol=1e-5, atol=1e-6), (name, tag, i)
+            if tag == "d":
+                for i, gi in enumerate(gins):
+                    ref_g = torch.from_numpy(gold["d_in_grad%d" % i])
+                    assert float((gi - ref_g).norm()) <= 1e-4 * float(ref_g.norm()) + 1e-9, (name, "input grad", i)
+            grads = dict(net.named_parameters())
+            # a conv bias in front of a BatchNorm has an exactly-zero true gradient: its recorded digest is rounding noise
+            # (1e-7 against 1e+1 for the weights), so the absolute floor scales with the largest digest of the network
+            scale = np.abs(gold[tag + "_digest"]).max(axis=0)
+            for k, gd in zip([str(k) for k in gold[tag + "_keys"]], gold[tag + "_digest"]):
+                mine = digest(grads[k].grad)
+                assert abs(mine[1] - gd[1]) <= 1e-4 * abs(gd[1]) + 1e-6 * scale[1], (name, k)
+                assert abs(mine[2] - gd[2]) <= 1e-4 * abs(gd[2]) + 1e-9 * scale[2], (name, k)
+
+
+@pytest.mark.parametrize("name,kw", [("relativistic_gan", {}), ("ebgan", {}), ("lsgan", {}),
+                                     ("relativistic_gan_avg", {"rel_avg_gan": True})])
+def test_clone_loops_against_reference_fixture(golden_dir, name, kw):
+    """relativistic_gan.py:126-182 (incl. its overwritten generator loss and the --rel_avg_gan branch), ebgan.py:142-202 and
+    lsgan.py:140-180 restated: the traces recorded with the reference's own classes inside the loop are reproduced."""
+    gold = load_golden(golden_dir, "clone_%s_32_loop" % name)
+    base = name.replace("_avg", "")
+    _seed(0)
+    s = S.make_clone(base)
+    step = getattr(S, base + "_step")
+    n = int(gold["masks_per_step"])
+    for t in range(len(gold["trace"])):
+        masks = [gold["mask_%d_%02d" % (t, i)] for i in range(n)]
+        with M.feed_masks(masks=masks):
+            o = step(s, torch.from_numpy(gold["imgs"][t]), torch.from_numpy(gold["zs"][t]), **kw)
+        assert abs(float(o["g_loss"]) - gold["trace"][t][0]) <= 1e-6 and abs(float(o["d_loss"]) - gold["trace"][t][1]) <= 1e-6, t

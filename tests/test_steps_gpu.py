@@ -377,6 +377,63 @@ def test_acgan_steps(golden_dir):
     _params_close(s_gpu.D, s_cpu.D, 3, "acgan D")
 
 
+@pytest.mark.parametrize("name,kw", [("relativistic_gan", {}), ("relativistic_gan_avg", {"rel_avg_gan": True}), ("ebgan", {}),
+                                     ("lsgan", {})])
+def test_clone_loops(golden_dir, name, kw):
+    """SURVEY.md 8f F2 loops: relativistic_gan.py:126-182 (its discarded relativistic generator loss - two side-effect-only
+    discriminator forwards - and the mean-subtracted BCE-with-logits of the discriminator step, both branches), ebgan.py:142-202
+    (pullaway_loss kernel, host-decided hinge) and lsgan.py:140-180: the iterations of the fixture against the losses recorded
+    with the reference's own classes, against the oracle, and the updated weights."""
+    import warnings
+
+    import pytorch_gan_amd as pg
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+    from util import load_golden
+
+    gold = load_golden(golden_dir, "clone_%s_32_loop" % name)
+    base = name.replace("_avg", "")
+    _seed(0)
+    s_cpu = S.make_clone(base)
+    s_gpu = steps.make_clone_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=False)
+    step_c, step_g = getattr(S, base + "_step"), getattr(steps, base + "_step")
+    n, nt = int(gold["masks_per_step"]), len(gold["trace"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(nt):
+            masks = [gold["mask_%d_%02d" % (t, i)] for i in range(n)]
+            imgs, z = torch.from_numpy(gold["imgs"][t]), torch.from_numpy(gold["zs"][t])
+            with M.feed_masks(masks=masks):
+                o_c = step_c(s_cpu, imgs, z, **kw)
+            with pg.dropout_masks(masks):
+                o_g = step_g(s_gpu, imgs.to(DEV), z.to(DEV), **kw)
+            for j, k in enumerate(("g_loss", "d_loss")):
+                _loss_close(o_g[k], gold["trace"][t][j], "%s %s step %d vs the reference trace" % (name, k, t), 2e-4)
+                _loss_close(o_g[k], o_c[k], "%s %s step %d vs the oracle" % (name, k, t), 2e-4)
+            if t == 0:
+                assert rel_fro(o_g["gen_imgs"], o_c["gen_imgs"]) < 2e-5
+    _params_close(s_gpu.G, s_cpu.G, nt, name + " G")
+    _params_close(s_gpu.D, s_cpu.D, nt, name + " D")
+
+
+def test_pullaway_loss_matches_reference_formula():
+    """ebgan.py:142-148 on the device (one launch forward, one backward) against the reference's chain of torch ops."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_steps as S
+
+    torch.manual_seed(3)
+    e = torch.randn(64, 32)
+    ec = e.clone().requires_grad_(True)
+    lc = S.pullaway_loss(ec)
+    (lc * 1.7).backward()
+    eg = e.to(DEV).requires_grad_(True)
+    lg = pg.functional.pullaway_loss(eg)
+    (lg * 1.7).backward()
+    assert abs(float(lg) - float(lc)) <= 1e-6 * max(1.0, abs(float(lc)))
+    assert rel_fro(eg.grad, ec.grad) < 1e-5
+
+
 def test_bench_config_one_step_matches_oracle():
     """BASELINE.json configs[1] at FULL size (DCGAN 64x64, batch 128): one step against the oracle, plus
     size-independent properties: valid/fake labels are exact 1/0, generator output is bounded by tanh."""
