@@ -51,18 +51,25 @@ def _host_conv_gflops():
     return 4.83 / best
 
 
+_REDUCED = []   # (test, batch run, BASELINE batch): a test that ran reduced reports itself as SKIPPED with the reason, never as passed
+
+
 def _oracle_batch(full_batch, gflop_per_img, budget_s=180.0):
     """The BASELINE batch when the oracle step fits the time budget on this host, else the largest batch that does (>= 1).
     gpurun boxes differ by 10x in host speed (the CycleGAN oracle step: 100 s on one box, 750 s on another); a reduced batch
-    keeps the image size, depth and every kernel shape class of the configuration and is reported as a warning."""
-    import warnings
-
+    keeps the image size, depth and every kernel shape class of the configuration.  A reduced run still checks parity, but
+    the test then ends in _report_batch() -> pytest.skip with the batch in the message, so the report never shows a
+    full-size pass that did not happen."""
     est = gflop_per_img * full_batch / max(_host_conv_gflops() * 0.6, 1e-3)   # whole-step efficiency ~0.6 of the conv rate
     if est <= budget_s:
         return full_batch
-    b = max(1, int(full_batch * budget_s / est))
-    warnings.warn("host too slow for the full-batch oracle step (estimated %.0f s): running batch %d instead of %d" % (est, b, full_batch))
-    return b
+    return max(1, int(full_batch * budget_s / est))
+
+
+def _report_batch(ran, full, what):
+    if ran != full:
+        pytest.skip("%s: host too slow for the batch-%d oracle step - parity HELD at batch %d (same image size, depth and kernel "
+                    "shape classes); not counted as a full-size pass" % (what, full, ran))
 
 
 def _loss_close(a, b, what, tol=2e-4):
@@ -86,11 +93,16 @@ def _net_grad_close(gmod, cmod, tol, what):
 
 
 def _weights_close(gmod, cmod, nsteps, what):
+    """Weight tensors: RMS and mean distance of the two runs well below the n*lr an Adam step moves (a wrong update is ~n*lr
+    away); bias vectors (exactly-zero true gradient in front of a norm layer -> +-lr noise steps in both runs): n*lr ceiling."""
     for (k, p), (_, q) in zip(cmod.named_parameters(), gmod.named_parameters()):
         d = (q.detach().cpu() - p.detach()).abs()
-        assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())
-        if p.dim() > 1:  # bias in front of a norm layer: exactly-zero true gradient -> Adam amplifies rounding noise
+        if p.dim() > 1:
+            rms = float((d * d).mean().sqrt())
+            assert rms <= 0.10 * nsteps * LR, "%s %s: rms |dw| %.3e" % (what, k, rms)
             assert d.mean().item() <= 0.05 * nsteps * LR, "%s %s: mean |dw| %.3e" % (what, k, d.mean().item())
+        else:
+            assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())
 
 
 def test_cyclegan_256_bs8_step():
@@ -121,6 +133,7 @@ def test_cyclegan_256_bs8_step():
     # replay buffers: one sample per image pushed into each, identical index logic
     assert len(s_gpu.buf_A) == len(s_cpu.buf_A.data) == bs
     assert rel_fro(torch.cat(s_gpu.buf_A.samples()), torch.cat(s_cpu.buf_A.data)) < 2e-5
+    _report_batch(bs, 8, "cyclegan 256x256")
 
 
 def test_srgan_96_384_bs16_step():
@@ -149,6 +162,7 @@ def test_srgan_96_384_bs16_step():
             assert rel_fro(c, b) < 1e-4, k
         else:
             assert int(b) == int(c), k
+    _report_batch(bs, 16, "srgan 96->384")
 
 
 def test_wgan_gp_bs64_six_iterations():

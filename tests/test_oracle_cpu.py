@@ -366,4 +366,8 @@ def test_clone_loops_against_reference_fixture(golden_dir, name, kw):
         masks = [gold["mask_%d_%02d" % (t, i)] for i in range(n)]
         with M.feed_masks(masks=masks):
             o = step(s, torch.from_numpy(gold["imgs"][t]), torch.from_numpy(gold["zs"][t]), **kw)
-        assert abs(float(o["g_loss"]) - gold["trace"][t][0]) <= 1e-6 and abs(float(o["d_loss"]) - gold["trace"][t][1]) <= 1e-6, t
+        # step 0 is a pure forward of pinned weights; later steps carry the Adam trajectory of a CPU run with another thread
+        # count (Adam's first steps are sign-like: measured 1e-5 on ebgan's d_loss at step 1)
+        tol = 1e-6 if t == 0 else 1e-4
+        for j, k in enumerate(("g_loss", "d_loss")):
+            assert abs(float(o[k]) - gold["trace"][t][j]) <= tol * max(1.0, abs(gold["trace"][t][j])), (t, k)
