@@ -42,12 +42,13 @@ UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapse
 PROFILE_ROUND = "r02"
 
 
-def dcgan_flops_per_image():
+def dcgan_flops_per_image(ch=None):
     """Algorithmic FLOPs/img of one training step (step = 3*G_fwd + 8*D_fwd)."""
+    ch = CH if ch is None else ch
     s = IMG // 4
     g = 2 * LATENT * 128 * s * s + 2 * (2 * s) ** 2 * 128 * 128 * 9 + 2 * (4 * s) ** 2 * 64 * 128 * 9 \
-        + 2 * (4 * s) ** 2 * CH * 64 * 9
-    d, h, cin = 0, IMG, CH
+        + 2 * (4 * s) ** 2 * ch * 64 * 9
+    d, h, cin = 0, IMG, ch
     for cout in (16, 32, 64, 128):
         h //= 2
         d += 2 * h * h * cout * cin * 9
@@ -86,12 +87,13 @@ def esrgan_flops_per_image(hr=256, blocks=23):
 
 # Per-image algorithmic GFLOP of one training step and the share of it inside Upsample+Conv3x3 layers
 # (fwd+dgrad+wgrad; CycleGAN: u128 + u64 = 154.62 GFLOP per G forward at bs 8, 18 G-forward equivalents per step).
-GFLOP_PER_IMG = {"dcgan": dcgan_flops_per_image() / 1e9, "cyclegan": 2097.99, "srgan": 541.43, "pix2pix": 65.52,
+GFLOP_PER_IMG = {"dcgan": dcgan_flops_per_image() / 1e9, "dcgan_ch3": dcgan_flops_per_image(3) / 1e9, "cyclegan": 2097.99, "srgan": 541.43, "pix2pix": 65.52,
                  "wgan_gp": 0.0219, "esrgan": esrgan_flops_per_image() / 1e9}
-UPCONV_GFLOP_PER_IMG = {"dcgan": dcgan_upconv_flops_per_image() / 1e9, "cyclegan": 18 * 154.62 / 8, "srgan": 0.0,
+UPCONV_GFLOP_PER_IMG = {"dcgan": dcgan_upconv_flops_per_image() / 1e9, "dcgan_ch3": dcgan_upconv_flops_per_image() / 1e9, "cyclegan": 18 * 154.62 / 8, "srgan": 0.0,
                         "pix2pix": 0.0, "wgan_gp": 0.0, "esrgan": 0.0}
 WORKLOAD_NAME = {
     "dcgan": "implementations/dcgan 64x64 bs=128 per GPU fp32 (dcgan.py:143-183 full step)",
+    "dcgan_ch3": "implementations/dcgan 64x64 bs=128 per GPU fp32 with --channels 3 (SURVEY.md 8d: \"also report ch 3\")",
     "cyclegan": "implementations/cyclegan 256x256 bs=8 per GPU fp32, ResNet-9 G + PatchGAN D (cyclegan.py:159-239 full step)",
     "srgan": "implementations/srgan 96->384 bs=16 per GPU fp32 (srgan.py:97-145 full step)",
     "wgan_gp": "implementations/wgan_gp 32x32 bs=64 per GPU fp32, one critic iteration incl. gradient penalty; generator "
@@ -114,13 +116,14 @@ class Workload:
         self.graphed, self.capture_error, self.nets = graphed, capture_error, nets
 
 
-def build_dcgan(dp, rank, dev, args, nsteps):
+def build_dcgan(dp, rank, dev, args, nsteps, ch=None):
     from pytorch_gan_amd import graph as gmod
     from pytorch_gan_amd import models, steps
 
+    ch = CH if ch is None else ch   # dcgan.py:28 --channels (default 1; 3 is reported under extra.dcgan_ch3)
     torch.manual_seed(0)
-    G = models.DcganGenerator(IMG, LATENT, CH)
-    D = models.DcganDiscriminator(IMG, CH)
+    G = models.DcganGenerator(IMG, LATENT, ch)
+    D = models.DcganDiscriminator(IMG, ch)
     G.apply(models.init_normal_dcgan)   # dcgan.py:115-116
     D.apply(models.init_normal_dcgan)
     init = (copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict()))
@@ -130,7 +133,7 @@ def build_dcgan(dp, rank, dev, args, nsteps):
     state = steps.make_gan_state(G, D, LATENT, skip_dead_grads=True, dp=dp)
     batch = args.batch or BATCH
     rng = np.random.RandomState(1234 + rank)
-    real = torch.from_numpy(rng.uniform(-1, 1, (batch, CH, IMG, IMG)).astype(np.float32)).to(dev)
+    real = torch.from_numpy(rng.uniform(-1, 1, (batch, ch, IMG, IMG)).astype(np.float32)).to(dev)
     nz = min(nsteps, 64) + 8
     zs = torch.from_numpy(rng.normal(0, 1, (nz, batch, LATENT)).astype(np.float32)).to(dev)
     z_static = zs[0].clone()
@@ -141,9 +144,13 @@ def build_dcgan(dp, rank, dev, args, nsteps):
         z_static.copy_(zs[i % nz])
         return runner.run()
 
-    w = Workload("dcgan", batch, run, state, init, runner.graphed, runner.capture_error, (G, D))
+    w = Workload("dcgan" if ch == CH else "dcgan_ch%d" % ch, batch, run, state, init, runner.graphed, runner.capture_error, (G, D))
     w.eager = lambda: steps.dcgan_step(state, real, z_static)
     return w
+
+
+def build_dcgan_ch3(dp, rank, dev, args, nsteps):
+    return build_dcgan(dp, rank, dev, args, nsteps, ch=3)
 
 
 def build_cyclegan(dp, rank, dev, args, nsteps):
@@ -275,7 +282,7 @@ def build_pix2pix(dp, rank, dev, args, nsteps):
     return w
 
 
-BUILDERS = {"dcgan": build_dcgan, "cyclegan": build_cyclegan, "srgan": build_srgan, "wgan_gp": build_wgan_gp,
+BUILDERS = {"dcgan": build_dcgan, "dcgan_ch3": build_dcgan_ch3, "cyclegan": build_cyclegan, "srgan": build_srgan, "wgan_gp": build_wgan_gp,
             "pix2pix": build_pix2pix, "esrgan": build_esrgan}
 
 
@@ -421,7 +428,23 @@ class ConvProfiler:
         self._wrap("migan_conv2d_dgrad_reflect1", reflect1)
         self._wrap("migan_conv2d_fwd", fwd)
         self._wrap("migan_conv2d_dropout_fwd", lambda a: fwd(a[:3] + a[4:]))
+        self._wrap("migan_conv2d_fwd_ws", lambda a: fwd(a[:3] + a[4:]))   # (x, w, bias, mask, y, N, ...): geometry one slot later
         self._wrap("migan_conv2d_dgrad", dgrad)
+        self._wrap("migan_conv2d_dgrad_ws", dgrad)
+
+        # HBM-bound kernels (bytes = 4 * (elements read + written) of the layer's activation): the normalisation
+        # layers.  stats = one read; apply = read + write; backward = statistics pass (x, dy) + apply pass (x, dy -> dx)
+        def norm(kind, off, passes):
+            def describe(a):
+                G, P, C = a[off:off + 3]
+                return ("norm_%s[%dx%dx%d]" % (kind, G, P, C), 4.0 * G * P * C * passes, -1.0)
+            return describe
+
+        self._wrap("migan_norm_stats", norm("stats", 8, 1))
+        self._wrap("migan_norm_apply", norm("apply", 7, 2))
+        self._wrap("migan_norm_apply_prelu", norm("apply", 8, 2))
+        self._wrap("migan_norm_bwd", norm("bwd", 9, 5))
+        self._wrap("migan_norm_bwd_prelu", norm("bwd", 11, 5))
         self._wrap("migan_conv2d_wgrad", wgrad)
         self._wrap("migan_upconv3x3_fwd", up_fwd)
         self._wrap("migan_upconv3x3_dgrad", up_dgrad)
@@ -435,8 +458,15 @@ class ConvProfiler:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
+        self.hbm = {}
         for (sym, dense, execd), e0, e1 in self.records:
             ms = e0.elapsed_time(e1)
+            if execd < 0:  # HBM-bound group: `dense` holds the algorithmic bytes
+                d = self.hbm.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+                d["launches"] += 1
+                d["ms"] += ms
+                d["bytes"] += dense
+                continue
             d = agg.setdefault(sym, {"launches": 0, "ms": 0.0, "dense": 0.0, "exec": 0.0})
             d["launches"] += 1
             d["ms"] += ms
@@ -461,7 +491,7 @@ def pmc_table():
 def roofline(w, rank, nprof):
     """Eager runs of the timed step with HIP events (on the launch stream) around every conv-family launch; every rank
     runs the steps (collectives), rank 0 records."""
-    agg = {}
+    agg, hbm = {}, {}
     with (ConvProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
         for i in range(nprof):
             w.state.dp.begin_step()
@@ -470,6 +500,7 @@ def roofline(w, rank, nprof):
         torch.cuda.synchronize()
         if rank == 0:
             agg = prof.summary()
+            hbm = prof.hbm
     if not agg:
         return None
     dom = max(agg, key=lambda k: agg[k]["ms"])
@@ -496,6 +527,23 @@ def roofline(w, rank, nprof):
                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:24]},
         "conv_ms_per_step": round(sum(v["ms"] for v in agg.values()) / nprof, 4),
     }
+    if hbm:
+        # the HBM side of the roofline (BASELINE metric: "HBM GB/s ... vs the chip's roofline"): the normalisation call that takes
+        # the most time; algorithmic bytes = 4 * (elements read + written) / time of the call's launches
+        hk = max(hbm, key=lambda k: hbm[k]["ms"])
+        h = hbm[hk]
+        gbs = h["bytes"] / (h["ms"] * 1e-3) / 1e9
+        out["hbm"] = {
+            "bound": "hbm", "kernel": hk, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+            "frac_of_achievable_6290": round(gbs / 6290.0, 4), "traffic": None,
+            "avg_call_ms": round(h["ms"] / h["launches"], 4), "calls_per_step": h["launches"] // nprof,
+            "algorithmic_mb_per_call": round(h["bytes"] / h["launches"] / 1e6, 2),
+            "note": "one call = the launches of that C entry point (stats: partial + finalize; bwd: partial + finalize + apply)",
+            "norm_calls": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "gb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                               "calls_per_step": v["launches"] // nprof}
+                           for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])[:16]},
+            "norm_ms_per_step": round(sum(v["ms"] for v in hbm.values()) / nprof, 4),
+        }
     return out
 
 
@@ -628,6 +676,8 @@ def main():
                 raise          # ranks must stay in lock step (the eager profiling steps contain collectives)
             rf = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         if rf:
+            if isinstance(rf, dict) and "hbm" in rf:
+                result["roofline_hbm"] = rf.pop("hbm")
             result["roofline"] = rf
     if world > 1:
         result["config"]["replicas_identical"] = replicas_identical(w, world, dev)
@@ -637,10 +687,10 @@ def main():
         del w, out
         torch.cuda.empty_cache()
         extra = {}
-        for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10)):
+        for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
             try:
                 ow = BUILDERS[other](dp, rank, dev, argparse.Namespace(batch=0, no_graph=False), k + wu)
-                ob, oo = timed_blocks(ow, 1, dev, k, wu, 1.0, max_blocks=10)
+                ob, oo = timed_blocks(ow, 1, dev, k, wu, 2.0, max_blocks=20)
                 e = summarise(other, ow.batch, 1, k, ob)
                 e.update(workload=WORKLOAD_NAME[other], steps=k, warmup=wu, hipgraph=ow.graphed,
                          peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),

@@ -48,7 +48,13 @@ def build(force=False, verbose=True):
         return OUT
     if not os.path.exists(HIPCC):
         if os.path.exists(OUT):
-            # No compiler on this box (e.g. a GPU runner without ROCm dev tools): use the shipped binary.
+            # No compiler on this box (e.g. a GPU runner without ROCm dev tools): use the shipped binary - but say so when
+            # the sources it was built from cannot be shown to be these (MIGAN_STRICT_BUILD=1 turns that into an error)
+            msg = "libmigan.so is used as shipped: no hipcc at %s and %s" % (
+                HIPCC, "no build stamp travels with it" if not os.path.exists(STAMP) else "its build stamp differs from the sources")
+            if os.environ.get("MIGAN_STRICT_BUILD") == "1":
+                raise RuntimeError(msg)
+            sys.stderr.write("warning: " + msg + "\n")
             return OUT
         raise RuntimeError("hipcc not found at %s and no prebuilt libmigan.so present" % HIPCC)
     with open(os.path.join(HERE, ".libmigan.lock"), "w") as lock:

@@ -12,7 +12,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ w, const long lon
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / D), d = (int)(e - (size_t)i * D);
         long long v = idx[i];
-        v = v < 0 ? 0 : (v >= V ? V - 1 : v);  // torch raises on out-of-range indices; the host mirror checks labels
+        v = v < 0 ? 0 : (v >= V ? V - 1 : v);  // memory safety only (torch device-asserts; a host check would cost a sync per call): forward and backward clamp alike
         y[e] = w[(size_t)v * D + d];
     }
 }
@@ -140,7 +140,9 @@ __global__ void ce_bwd_kernel(const float* __restrict__ x, const long long* __re
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / C), c = (int)(e - (size_t)i * C);
         const float p = expf(x[e] - lse[i]);
-        dx[e] = gs * (p - (t[i] == c ? 1.f : 0.f));
+        long long tt = t[i];
+        tt = tt < 0 ? 0 : (tt >= C ? C - 1 : tt);  // the same clamp as the forward: loss and gradient stay consistent
+        dx[e] = gs * (p - (tt == c ? 1.f : 0.f));
     }
 }
 // ws: 2*B floats (row losses, row logsumexp); lse = ws + B is what migan_cross_entropy_bwd takes

@@ -155,9 +155,15 @@ def to_float(images, crop=None, corners=None, flip=None, mean=None, std=None, ch
     dev = images.device
     cptr = fptr = mptr = sptr = None
     if corners is not None:
-        corners = torch.as_tensor(corners, dtype=torch.int32).to(dev).contiguous()
-        if tuple(corners.shape) != (N, 2):
+        host = torch.as_tensor(corners, dtype=torch.int32)
+        if tuple(host.shape) != (N, 2):
             raise ValueError("corners must be [N, 2]")
+        if not host.is_cuda:  # host data (what ImagePipeline.draw and callers pass): the window must lie inside the image,
+            # the kernel does not clamp (a device tensor is the caller's responsibility: checking it would cost a sync)
+            if int(host[:, 0].min()) < 0 or int(host[:, 0].max()) > H - h or int(host[:, 1].min()) < 0 \
+                    or int(host[:, 1].max()) > W - w:
+                raise ValueError("corners: crop window (%d, %d) leaves the %d x %d image" % (h, w, H, W))
+        corners = host.to(dev).contiguous()
         cptr = corners.data_ptr()
     if flip is not None:
         flip = torch.as_tensor(flip).to(torch.uint8).to(dev).contiguous()

@@ -491,7 +491,7 @@ class CrossEntropyLoss(tnn.Module):
 
     def __init__(self, weight=None, ignore_index=-100, reduction="mean", label_smoothing=0.0):
         super().__init__()
-        if weight is not None or reduction != "mean" or label_smoothing != 0.0:
+        if weight is not None or reduction != "mean" or label_smoothing != 0.0 or ignore_index != -100:
             raise ValueError("CrossEntropyLoss: only the default configuration is on the reference path")
 
     def forward(self, x, target):
@@ -618,8 +618,8 @@ def swap(module):
                 if m.reduction != "mean":
                     raise ValueError("swap: loss reduction %r is not supported" % m.reduction)
                 if getattr(m, "weight", None) is not None or getattr(m, "pos_weight", None) is not None \
-                        or getattr(m, "label_smoothing", 0.0) != 0.0:
-                    raise ValueError("swap: loss weights / label smoothing are not on the reference path")
+                        or getattr(m, "label_smoothing", 0.0) != 0.0 or getattr(m, "ignore_index", -100) != -100:
+                    raise ValueError("swap: loss weights / label smoothing / ignore_index are not on the reference path")
             m.__class__ = _SWAP[cls]
         elif cls in _OURS:
             continue

@@ -312,7 +312,12 @@ class ReplayBuffer:
         x = F.canon(batch.data)
         B = x.shape[0]
         D = x[0].numel()
-        if self.pool is None or self.pool.shape[1:] != x.shape[1:]:
+        if self.pool is not None and self.pool.shape[1:] != x.shape[1:]:
+            raise ValueError("ReplayBuffer: sample shape changed from %s to %s (the history cannot be mixed; use a new buffer)"
+                             % (tuple(self.pool.shape[1:]), tuple(x.shape[1:])))
+        if D % 4 != 0:
+            raise ValueError("ReplayBuffer: C*H*W = %d must be a multiple of 4 on the device path (16-byte row copies)" % D)
+        if self.pool is None:
             self.pool = torch.empty((self.max_size, *x.shape[1:]), device=x.device, dtype=torch.float32,
                                     memory_format=torch.channels_last if x.dim() == 4 else torch.contiguous_format)
             self.count = 0
@@ -333,15 +338,18 @@ class ReplayBuffer:
                 out_src.append(-1 - k)
         out = torch.empty_like(x)
         st = torch.cuda.current_stream().cuda_stream
-        sel = torch.tensor(out_src, dtype=torch.int32).to(x.device)
-        F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), out.data_ptr(), sel.data_ptr(), None, B, D, st),
+        # both index tables in ONE pinned staging buffer and one asynchronous copy (no pageable-memory sync on the step's path)
+        slots = sorted(slot_src)
+        n = len(slots)
+        table = out_src + [-1 - slot_src[j] for j in slots] + slots
+        host = torch.tensor(table, dtype=torch.int32).pin_memory()
+        dev = host.to(x.device, non_blocking=True)
+        self._staging = (host, dev)  # keeps the pinned source alive until the next call (the copy is stream-ordered)
+        F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), out.data_ptr(), dev.data_ptr(), None, B, D, st),
                 "select_rows")
-        if slot_src:
-            slots = sorted(slot_src)
-            upd = torch.tensor([-1 - slot_src[j] for j in slots] + slots, dtype=torch.int32).to(x.device)
-            n = len(slots)
-            F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), self.pool.data_ptr(), upd.data_ptr(),
-                                            upd.data_ptr() + 4 * n, n, D, st), "select_rows")
+        if n:
+            F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), self.pool.data_ptr(), dev.data_ptr() + 4 * B,
+                                            dev.data_ptr() + 4 * (B + n), n, D, st), "select_rows")
         return out
 
     def _push_and_pop_host(self, batch):

@@ -43,6 +43,19 @@ def _params_close(gmod, cmod, nsteps, what):
             assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())
 
 
+def _params_close_vs_f64(gmod, cmod, fmod, nsteps, what, ratio=4.0):
+    """Weights after a LONG trajectory: two fp32 runs of an Adam loop drift apart on their own (sign-like first updates), so
+    the HIP weights are held to the fp32 oracle's own distance from the fp64 run: per weight tensor
+    rms(hip - f64) <= ratio * rms(cpu32 - f64) + 0.02 * n * lr."""
+    for (k, p), (_, q), (_, d) in zip(cmod.named_parameters(), gmod.named_parameters(), fmod.named_parameters()):
+        if p.dim() <= 1:
+            continue
+        ref = d.detach().float()
+        eg = float(((q.detach().cpu() - ref) ** 2).mean().sqrt())
+        ec = float(((p.detach() - ref) ** 2).mean().sqrt())
+        assert eg <= ratio * ec + 0.02 * nsteps * LR, "%s %s: rms |hip - f64| %.3e vs rms |cpu32 - f64| %.3e" % (what, k, eg, ec)
+
+
 def _trajectory_close(rows, keys, what, ratio=4.0, floor=1e-4):
     """rows[t] = (hip, cpu32, f64) dicts of one loop run three ways from the same weights, inputs and host draws.  Step 0 (no
     update yet) is compared strictly.  Over the whole trajectory the HIP run must stay as close to the fp64 evaluation as
@@ -279,8 +292,8 @@ def test_wgan_gp_trajectory_20_iterations_bs64():
         rows.append((o_g, o_c, o_d))
     _trajectory_close(rows, ("d_loss", "gp"), "wgan_gp bs 64")
     _trajectory_close([r for r in rows if "g_loss" in r[0]], ("g_loss",), "wgan_gp bs 64")
-    _params_close(s_gpu.D, s_cpu.D, 20, "critic")
-    _params_close(s_gpu.G, s_cpu.G, 4, "generator")
+    _params_close_vs_f64(s_gpu.D, s_cpu.D, s_f64.D, 20, "critic")
+    _params_close_vs_f64(s_gpu.G, s_cpu.G, s_f64.G, 4, "generator")
 
 
 def test_srgan_trajectory_20_steps():
@@ -311,7 +324,8 @@ def test_srgan_trajectory_20_steps():
         o_g = steps.srgan_step(s_gpu, lr.to(DEV), hr.to(DEV))
         rows.append((o_g, o_c, o_d))
     _trajectory_close(rows, ("loss_G", "loss_D", "loss_content", "loss_GAN"), "srgan")
-    _params_close(s_gpu.G, s_cpu.G, 20, "srgan G")
+    _params_close_vs_f64(s_gpu.G, s_cpu.G, s_f64.G, 20, "srgan G")
+    _params_close_vs_f64(s_gpu.D, s_cpu.D, s_f64.D, 20, "srgan D")
 
 
 def test_cyclegan_trajectory_10_steps():
@@ -544,7 +558,7 @@ def test_pullaway_loss_matches_reference_formula():
     eg = e.to(DEV).requires_grad_(True)
     lg = pg.functional.pullaway_loss(eg)
     (lg * 1.7).backward()
-    assert abs(float(lg) - float(lc)) <= 1e-6 * max(1.0, abs(float(lc)))
+    assert abs(float(lg.detach()) - float(lc.detach())) <= 1e-6 * max(1.0, abs(float(lc.detach())))
     assert rel_fro(eg.grad, ec.grad) < 1e-5
 
 
