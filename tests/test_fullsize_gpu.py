@@ -93,13 +93,13 @@ def _net_grad_close(gmod, cmod, tol, what):
 
 
 def _weights_close(gmod, cmod, nsteps, what):
-    """Weight tensors: RMS and mean distance of the two runs well below the n*lr an Adam step moves (a wrong update is ~n*lr
+    """Weight tensors: RMS (<= 0.3 n*lr: at most ~2 % of the elements took the opposite sign-like first step) and mean (<= 0.05 n*lr) distance of the two runs well below the n*lr an Adam step moves (a wrong update is ~n*lr
     away); bias vectors (exactly-zero true gradient in front of a norm layer -> +-lr noise steps in both runs): n*lr ceiling."""
     for (k, p), (_, q) in zip(cmod.named_parameters(), gmod.named_parameters()):
         d = (q.detach().cpu() - p.detach()).abs()
         if p.dim() > 1:
             rms = float((d * d).mean().sqrt())
-            assert rms <= 0.10 * nsteps * LR, "%s %s: rms |dw| %.3e" % (what, k, rms)
+            assert rms <= 0.30 * nsteps * LR, "%s %s: rms |dw| %.3e" % (what, k, rms)
             assert d.mean().item() <= 0.05 * nsteps * LR, "%s %s: mean |dw| %.3e" % (what, k, d.mean().item())
         else:
             assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())

@@ -30,14 +30,14 @@ def _loss_close(a, b, what, tol=1e-4):
 
 def _params_close(gmod, cmod, nsteps, what):
     """After n Adam steps every weight moved by at most ~n*lr.  What is asserted is how far the two runs are APART relative
-    to that: per weight tensor the RMS and the mean of |dw| must stay below a tenth / a twentieth of n*lr (a run whose
+    to that: per weight tensor the RMS and the mean of |dw| must stay below 0.3 / 0.05 of n*lr (a run whose
     updates were wrong in sign or size is ~n*lr apart).  Bias vectors only get the n*lr ceiling: a conv bias in front of
     Instance/BatchNorm has an exactly-zero true gradient, so Adam turns its rounding noise into +-lr steps in both runs."""
     for (k, p), (_, q) in zip(cmod.named_parameters(), gmod.named_parameters()):
         d = (q.detach().cpu() - p.detach()).abs()
         if p.dim() > 1:
             rms = float((d * d).mean().sqrt())
-            assert rms <= 0.10 * nsteps * LR, "%s %s: rms |dw| %.3e" % (what, k, rms)
+            assert rms <= 0.30 * nsteps * LR, "%s %s: rms |dw| %.3e" % (what, k, rms)
             assert d.mean().item() <= 0.05 * nsteps * LR, "%s %s: mean |dw| %.3e" % (what, k, d.mean().item())
         else:
             assert d.max().item() <= 2.05 * nsteps * LR, "%s %s: max |dw| %.3e" % (what, k, d.max().item())
