@@ -338,13 +338,12 @@ class ReplayBuffer:
                 out_src.append(-1 - k)
         out = torch.empty_like(x)
         st = torch.cuda.current_stream().cuda_stream
-        # both index tables in ONE pinned staging buffer and one asynchronous copy (no pageable-memory sync on the step's path)
+        # both index tables in ONE host-to-device copy (a pinned staging buffer + non_blocking copy was tried and hung the
+        # two-ranks-on-one-GPU gloo run - pinned allocations synchronise the device under the collective's worker thread)
         slots = sorted(slot_src)
         n = len(slots)
         table = out_src + [-1 - slot_src[j] for j in slots] + slots
-        host = torch.tensor(table, dtype=torch.int32).pin_memory()
-        dev = host.to(x.device, non_blocking=True)
-        self._staging = (host, dev)  # keeps the pinned source alive until the next call (the copy is stream-ordered)
+        dev = torch.tensor(table, dtype=torch.int32).to(x.device)
         F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), out.data_ptr(), dev.data_ptr(), None, B, D, st),
                 "select_rows")
         if n:
