@@ -338,8 +338,8 @@ class ReplayBuffer:
                 out_src.append(-1 - k)
         out = torch.empty_like(x)
         st = torch.cuda.current_stream().cuda_stream
-        # both index tables in ONE host-to-device copy (a pinned staging buffer + non_blocking copy was tried and hung the
-        # two-ranks-on-one-GPU gloo run - pinned allocations synchronise the device under the collective's worker thread)
+        # both index tables in ONE host-to-device copy.  (A pinned staging buffer + non_blocking copy was tried: the
+        # two-ranks-on-one-GPU gloo test hung with it in the tree; the cause was not isolated, so the pageable copy stays.)
         slots = sorted(slot_src)
         n = len(slots)
         table = out_src + [-1 - slot_src[j] for j in slots] + slots
