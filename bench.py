@@ -39,7 +39,8 @@ import torch  # noqa: E402
 IMG, BATCH, LATENT, CH = 64, 128, 100, 1
 PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
 UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapsed Upsample(2)+Conv3x3 kernels
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"  # profiles/r03_pmc_kernels.json does not exist (no PMC pass this round): roofline.traffic stays null
+WATCHDOG_S = 200  # seconds the optional sections of the default run may take after the timed region
 
 
 def dcgan_flops_per_image(ch=None):
@@ -668,6 +669,21 @@ def main():
     }
     if w.capture_error:
         result["config"]["hipgraph_error"] = w.capture_error[:200]
+    # The headline numbers are final here.  What follows (per-kernel accounting, the other BASELINE configs, the CPU baseline)
+    # is optional detail: if it does not finish in time the watchdog prints the line with whatever is attached so far and
+    # exits, so a stall in an optional section can never cost the run its result.
+    watchdog = None
+    if rank == 0 and world == 1:
+        import threading
+
+        def _fire():
+            result["watchdog"] = "optional sections (roofline / extra / cpu_baseline) did not finish within %d s" % WATCHDOG_S
+            print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(WATCHDOG_S, _fire)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_roofline:
         try:
             rf = roofline(w, rank, 5 if name in ("dcgan", "wgan_gp", "pix2pix") else 2)
@@ -705,6 +721,8 @@ def main():
             result["cpu_baseline"] = _safe_cpu_baseline(init)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -42,8 +42,10 @@ def _run_ranks(mode, out, world, extra_env=None):
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(_port()), WORKER, mode, out]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    from util import run_ranks
+
+    rc, _, stderr = run_ranks(cmd, ROOT, env, 600)
+    assert rc == 0, "ranks %s\n%s" % ("timed out (group killed)" if rc is None else "failed", stderr[-3000:])
     return torch.load(out)
 
 

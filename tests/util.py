@@ -55,3 +55,37 @@ def load_golden(golden_dir, name):
 def digest(t):
     t = t.detach().double().cpu().flatten()
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def run_ranks(cmd, cwd, env, timeout):
+    """Run a multi-process launch (torch.distributed.run or bench.py --gpus N) in its OWN process group and return
+    (returncode | None on timeout, stdout, stderr).  On timeout the whole group is killed: ranks orphaned by killing only the
+    launcher would keep the GPU busy under every later test (and under the smoke / bench runs that follow the suite)."""
+    import os
+    import signal
+    import subprocess
+
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        victims = []
+        try:  # every descendant, whatever session the launcher put its workers in
+            import psutil
+
+            victims = psutil.Process(p.pid).children(recursive=True)
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        for v in victims:
+            try:
+                v.kill()
+            except Exception:  # noqa: BLE001
+                pass
+        out, err = p.communicate()
+        return None, out, err
