@@ -637,6 +637,11 @@ def test_bench_cyclegan_strong_scaling_two_ranks_on_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MIGAN_DP_BACKEND="gloo", MIGAN_DP_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # Two PROCESSES time-share one GPU here (never the case in production: one process per GPU).  With the LDS-DMA conv
+    # kernels of round 3 this 50+ step launch did not finish (see the xfail below); the untested working hypothesis is the
+    # preemption of waves with LDS-DMA in flight when the hardware scheduler time-slices the two processes' queues, so this
+    # test - whose subject is the data-parallel control flow, not the kernels - runs the register-staged kernels of round 2.
+    env.update(MIGAN_DMA="0", MIGAN_DMA_WGRAD="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cyclegan",
            "--global-batch", "2", "--steps", "2", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-roofline"]
