@@ -26,6 +26,17 @@ _ADAM_T = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n"
 _BLK_T = np.dtype([("tensor", "<i4"), ("chunk", "<i4")])
 
 
+def bucket_layout(sizes):
+    """(offsets, total) of the flat bucket: one 64-element (256 B) aligned slot per tensor, so every tensor starts on a fresh
+    cache line and the padding between slots is part of what the data-parallel all-reduce moves (tests/test_dp_cpu.py drives
+    dp.DataParallel over exactly this layout on the CPU)."""
+    offsets, off = [], 0
+    for n in sizes:
+        offsets.append(off)
+        off += (int(n) + 63) // 64 * 64
+    return offsets, off
+
+
 def _to_device_bytes(arr, device):
     return torch.from_numpy(np.frombuffer(arr.tobytes(), dtype=np.uint8).copy()).to(device)
 
@@ -47,11 +58,7 @@ class Adam:
         self.param_groups = [{"params": self.params, "lr": float(lr), "betas": tuple(betas), "eps": float(eps)}]
         self.device = dev
         sizes = [p.numel() for p in self.params]
-        # 64-element (256 B) aligned slots so every tensor starts on a fresh cache line
-        self.offsets, off = [], 0
-        for n in sizes:
-            self.offsets.append(off)
-            off += (n + 63) // 64 * 64
+        self.offsets, off = bucket_layout(sizes)
         self.total = off
         self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)

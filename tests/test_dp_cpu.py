@@ -1,8 +1,9 @@
 """Data-parallel logic on the CPU (gloo, world_size 2): sharding + ONE summed all-reduce of the flat gradient
 bucket per optimiser + 1/world scaling in the update reproduces the single-process full-batch step
-(SURVEY.md §8e).  The HIP optimiser needs a GPU, so a flat-bucket stand-in with the same interface
-(`flat_grad`, `step(grad_scale)`) drives `pytorch_gan_amd.dp.DataParallel` here; the real optimiser's bucket
-layout is covered by the GPU tests."""
+(SURVEY.md §8e).  The HIP optimiser's update kernel needs a GPU, so a CPU optimiser with the SAME bucket
+(`pytorch_gan_amd.optim.bucket_layout`: 256-byte aligned slots, padding included in the all-reduce), the same interface
+(`flat_grad`, `step(grad_scale)`) and torch.optim.Adam's arithmetic drives `pytorch_gan_amd.dp.DataParallel` here and is
+compared with stock `torch.optim.Adam` on the whole batch."""
 import os
 import socket
 import sys
@@ -15,26 +16,36 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class FlatSGD:
-    """Same contract as optim.Adam: grads are views of one flat buffer; step() applies grad_scale."""
+class FlatAdam:
+    """optim.Adam's contract on the CPU: every p.grad is a view into ONE flat buffer laid out by optim.bucket_layout, step()
+    applies grad_scale (the 1/world of the data-parallel mean) and torch.optim.Adam's update (`_single_tensor_adam`)."""
 
-    def __init__(self, params, lr=0.1):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        from pytorch_gan_amd.optim import bucket_layout
+
         self.params = list(params)
-        self.lr = lr
-        n = sum(p.numel() for p in self.params)
-        self.flat_grad = torch.zeros(n)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.lr, self.betas, self.eps, self.t = lr, betas, eps, 0
+        self.offsets, total = bucket_layout([p.numel() for p in self.params])
+        assert total % 64 == 0 and total >= sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(total)
+        self.exp_avg, self.exp_avg_sq = torch.zeros(total), torch.zeros(total)
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
     def zero_grad(self):
         self.flat_grad.zero_()
 
     def step(self, grad_scale=1.0):
+        self.t += 1
+        b1, b2 = self.betas
         with torch.no_grad():
-            for p in self.params:
-                p.add_(p.grad, alpha=-self.lr * grad_scale)
+            g = self.flat_grad * grad_scale
+            self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+            upd = (self.exp_avg / bc1) / ((self.exp_avg_sq.sqrt() / bc2 ** 0.5) + self.eps)
+            for p, o in zip(self.params, self.offsets):
+                p.add_(upd[o:o + p.numel()].view_as(p), alpha=-self.lr)
 
 
 def _free_port():
@@ -63,7 +74,7 @@ def _worker(rank, world, port, out):
             for p in list(D.parameters()) + list(G.parameters()):
                 p.add_(1.0)
     dp.broadcast_parameters(D, G)
-    opt_D, opt_G = FlatSGD(D.parameters()), FlatSGD(G.parameters())
+    opt_D, opt_G = FlatAdam(D.parameters()), FlatAdam(G.parameters())
     g = torch.Generator().manual_seed(5)
     xb = torch.rand(8, 1, 8, 8, generator=g)       # global batches, identical on every rank (host RNG is shared)
     yb = torch.rand(4, 3, 32, 32, generator=g)
@@ -114,7 +125,8 @@ def test_two_rank_step_equals_full_batch(tmp_path):
     torch.manual_seed(0)
     D = M.MlpCritic((1, 8, 8))
     G = M.CycleDiscriminator((3, 32, 32))
-    opt_D, opt_G = FlatSGD(D.parameters()), FlatSGD(G.parameters())
+    opt_D = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))   # the single-process reference optimiser
+    opt_G = torch.optim.Adam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
     g = torch.Generator().manual_seed(5)
     xb = torch.rand(8, 1, 8, 8, generator=g)
     yb = torch.rand(4, 3, 32, 32, generator=g)
@@ -125,9 +137,18 @@ def test_two_rank_step_equals_full_batch(tmp_path):
     torch.nn.functional.mse_loss(G(yb), torch.ones(4, 1, 2, 2)).backward()
     opt_G.step()
     want = {k: v for k, v in list(D.state_dict().items()) + [("G." + k, v) for k, v in G.state_dict().items()]}
+    gmax = {k: float(p.grad.abs().max()) for k, p in list(D.named_parameters()) + [("G." + k, p) for k, p in G.named_parameters()]}
     assert got.keys() == want.keys()
+    strict = 0
     for k in want:
-        assert torch.allclose(got[k], want[k], rtol=1e-5, atol=1e-6), k
+        if gmax.get(k, 1.0) < 1e-6:
+            # a conv bias in front of InstanceNorm: the true gradient is exactly zero, what is left is rounding noise, and
+            # Adam's first step turns its SIGN into a full +-lr step - the sharded and the full-batch run may differ by 2 lr
+            assert float((got[k] - want[k]).abs().max()) <= 2.05 * 2e-4, k
+        else:
+            assert torch.allclose(got[k], want[k], rtol=1e-5, atol=2e-6), k
+            strict += 1
+    assert strict >= len(want) - 4
 
 
 def test_shard_rejects_ragged_batch():
