@@ -702,7 +702,9 @@ def main():
         init = w.init
         del w, out
         torch.cuda.empty_cache()
-        extra = {}
+        if not args.no_cpu_baseline:   # before the extras: a watchdog line (a stall in an extra) still carries it
+            result["cpu_baseline"] = _safe_cpu_baseline(init)
+        extra = result["extra"] = {}   # attached first: a watchdog line carries the configs finished so far
         for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
             try:
                 ow = BUILDERS[other](dp, rank, dev, argparse.Namespace(batch=0, no_graph=False), k + wu)
@@ -716,9 +718,6 @@ def main():
             except Exception as ex:  # the headline line must survive a failure here
                 extra[other] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
             torch.cuda.empty_cache()
-        result["extra"] = extra
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = _safe_cpu_baseline(init)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
     if watchdog is not None:
