@@ -271,3 +271,44 @@ def test_dropout_mask_plan(monkeypatch):
     assert calls == [(4, 32)]                             # different first request: no batch
     calls.clear()
     assert nn._next_mask((4, 16), 0.25, "cpu") is not None and calls == [(4, 16)]   # outside a step: never batched
+
+
+def test_splitk_rule_and_workspace_size():
+    """Host-side rules of the split-K conv entry points (no launch): the workspace is 1024 tickets + 1024 64x64 fp32 slabs; a
+    launch is a candidate only with 16-byte channel vectors, >= 32 source channels, more than 4 output channels and at most
+    128 64x64 tiles (pix2pix/models.py:62-71 inner levels yes, a CycleGAN residual conv no)."""
+    from pytorch_gan_amd._lib import lib
+
+    assert lib.migan_conv_splitk_workspace() == 1024 * 4 + 1024 * 64 * 64 * 4
+    assert lib.migan_conv_splitk_applies(1, 512, 512, 1) == 1          # 512->512 on one output pixel
+    assert lib.migan_conv_splitk_applies(64, 512, 512, 1) == 1
+    assert lib.migan_conv_splitk_applies(256, 256, 512, 4) == 1        # stride-2 dgrad, 4 parity classes of 256 pixels
+    assert lib.migan_conv_splitk_applies(32768, 256, 256, 1) == 0      # R256 at batch 8: 2048 tiles
+    assert lib.migan_conv_splitk_applies(64, 512, 16, 1) == 0          # Ci < 32: register-staged kernels
+    assert lib.migan_conv_splitk_applies(64, 3, 512, 1) == 0           # thin-N output: VALU kernels
+    assert lib.migan_conv_splitk_applies(0, 512, 512, 1) == 0
+
+
+def test_bucket_layout_and_run_ranks_helper():
+    """optim.bucket_layout: 256-byte aligned slots in parameter order; tests/util.run_ranks: a launcher whose grandchild
+    outlives the time limit is killed with all its descendants (what keeps a hung multi-rank test from leaving ranks on the GPU)."""
+    import subprocess
+    import time
+
+    from pytorch_gan_amd.optim import bucket_layout
+    from util import run_ranks
+
+    offs, total = bucket_layout([1, 64, 65, 128, 3])
+    assert offs == [0, 64, 128, 256, 384] and total == 448
+    assert bucket_layout([]) == ([], 0)
+    marker = "sleep_marker_%d" % os.getpid()
+    code = ("import subprocess, sys, time; subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(300)  # %s']); "
+            "time.sleep(300)" % marker)
+    t0 = time.time()
+    rc, _, _ = run_ranks([sys.executable, "-c", code], ROOT, dict(os.environ), 2)
+    assert rc is None and time.time() - t0 < 30
+    time.sleep(0.2)
+    left = subprocess.run("ps -eo args | grep '%s' | grep -v grep | wc -l" % marker, shell=True, capture_output=True, text=True)
+    assert int(left.stdout.strip()) == 0
+    rc, out, _ = run_ranks([sys.executable, "-c", "print('ok')"], ROOT, dict(os.environ), 30)
+    assert rc == 0 and out.strip() == "ok"
