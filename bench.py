@@ -628,6 +628,12 @@ def main():
 
     from pytorch_gan_amd import dp as dpmod
 
+    if os.environ.get("MIGAN_HANG_DUMP_S"):
+        # diagnosis aid: after S seconds every rank prints the Python stack of each of its threads to stderr and carries on
+        # (a launch that is still alive then is stuck or far too slow - the stacks say where)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["MIGAN_HANG_DUMP_S"]), repeat=False, file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dp = dpmod.init_from_env()
