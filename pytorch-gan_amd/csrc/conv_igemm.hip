@@ -1143,6 +1143,88 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
     return 0;
 }
 
+// Thin-N convolution with FEW output pixels (PatchGAN heads: cyclegan/models.py:118 and pix2pix/models.py:130
+// Conv2d(512,1,4,padding=1) -> 16x16 per image, srgan/models.py:100 -> 24x24): thin_conv_kernel gives such a launch
+// N * tiles workgroups (1 at the pix2pix batch, 8 at CycleGAN's) that each walk taps*Ci = 8192 products per lane
+// serially - 295 us for 4 MFLOP (profiles/r03_pix2pix_kernel_stats.txt).  Here ONE WAVE owns one output pixel: the
+// lanes split the channels (coalesced 1 KB rows of the NHWC source, straight from L2 - the whole input is < 1 MB per
+// image), every load of a tap is independent, and the 64 partial sums are combined by a fixed butterfly (deterministic).
+// STAGED in round 3 without GPU time left to measure it: off unless MIGAN_THIN_WAVE=1 (tools/gpu_tasks.sh thin_wave).
+template <int CO>
+__global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, const float* __restrict__ A,
+                                                             const float* __restrict__ Bw, const float* __restrict__ bias,
+                                                             float* __restrict__ C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cls = blockIdx.z;
+    const int Ho = g.Ho[cls], Wo = g.Wo[cls], hw = Ho * Wo;
+    const int p = blockIdx.x * 4 + wave;          // wave-uniform
+    if (p >= g.N * hw) return;
+    const int n = p / hw, rem = p - n * hw;
+    const int oi = rem / Wo, oj = rem - oi * Wo;
+    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
+    const float* Ab = A + (size_t)n * g.Hi * g.Wi * g.Ci;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int t = 0; t < ntap; ++t) {
+        int ihs, iws;
+        bool ok = map_bf(oi * g.istride + g.dh[tapbeg + t], g.HiL, g.Hi, g.gather, ihs);
+        ok &= map_bf(oj * g.istride + g.dw[tapbeg + t], g.WiL, g.Wi, g.gather, iws);
+        if (!ok) continue;                         // zero padding (wave-uniform)
+        const float* xr = Ab + ((size_t)ihs * g.Wi + iws) * g.Ci;
+        const float* wr = Bw + g.wofs[tapbeg + t];
+        for (int c = lane * 4; c < g.Ci; c += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+            for (int k = 0; k < CO; ++k) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (size_t)k * g.ldw + c);
+                acc[k] = fmaf(xv[0], wv[0], acc[k]);
+                acc[k] = fmaf(xv[1], wv[1], acc[k]);
+                acc[k] = fmaf(xv[2], wv[2], acc[k]);
+                acc[k] = fmaf(xv[3], wv[3], acc[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CO; ++k)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+    if (lane != 0) return;
+    const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+#pragma unroll
+    for (int k = 0; k < CO; ++k) {
+        float v = acc[k];
+        if (bias) v += bias[k];
+        float o = act_apply(v, g.act, g.slope);
+        if (g.oscale) o *= g.oscale[(size_t)n * g.Co + k];
+        C[opix * g.Co + k] = o;
+    }
+}
+
+// few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel (opt-in)
+static bool thin_wave_ok(const ConvGeom& g, int max_tiles) {
+    static const int on = getenv("MIGAN_THIN_WAVE") ? atoi(getenv("MIGAN_THIN_WAVE")) : 0;
+    return on != 0 && g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
+}
+
+static int launch_thin_conv_wave(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
+                                 hipStream_t st) {
+    long maxM = 0;
+    for (int c = 0; c < g.ncls; ++c) {
+        const long m = (long)g.N * g.Ho[c] * g.Wo[c];
+        maxM = m > maxM ? m : maxM;
+    }
+    dim3 grid((unsigned)cdiv(maxM, 4L), 1, g.ncls);
+    switch (g.Co) {
+        case 1: hipLaunchKernelGGL((thin_conv_wave_kernel<1>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        case 2: hipLaunchKernelGGL((thin_conv_wave_kernel<2>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        case 3: hipLaunchKernelGGL((thin_conv_wave_kernel<3>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        default: hipLaunchKernelGGL((thin_conv_wave_kernel<4>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+    }
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small-K direct kernel (taps * Ci <= 16, Co % 4 == 0): first-layer convs of 1-channel images (dcgan.py:82
 // Conv2d(1,16,3,2,1)), the dgrad of an image-output conv INTO its Co-channel input (dcgan.py:62) and the dgrad of
@@ -1466,8 +1548,10 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
         ThinConv tc = {};
         size_t lds = 0;
         int max_tiles = 0;
-        if (g.N <= 65535 && thin_conv_plan(g, tc, lds, max_tiles))
+        if (g.N <= 65535 && thin_conv_plan(g, tc, lds, max_tiles)) {
+            if (thin_wave_ok(g, max_tiles)) return launch_thin_conv_wave(g, A, Bw, bias, C, st);
             return launch_thin_conv(g, tc, lds, max_tiles, A, Bw, bias, C, st);
+        }
     }
     int ktaps = 0;
     for (int c = 0; c < g.ncls; ++c) ktaps = g.ntap[c] > ktaps ? g.ntap[c] : ktaps;
@@ -2409,11 +2493,56 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         *o = accum ? *o + s : s;
     }
 }
+// Transposing form of the reduction for LARGE weights with few splits (pix2pix/models.py:23,39: 512x512x4x4 = 4.2 M and
+// 1024x512x4x4 = 8.4 M elements at 1..64 pixels -> 1 split): wgrad_reduce_kernel<1> reads the [Co][T][Ci] slabs coalesced
+// but scatters every result 4 B at a stride of T floats into the OIHW gradient (44 / 73 us for 16 / 32 MB,
+// profiles/r03_pix2pix_kernel_stats.txt).  Here a workgroup owns (co, 64 input channels): it sums the slabs in the same
+// split order (bit-identical results), transposes the 64 x T tile through LDS and writes ONE contiguous run of 64*T floats.
+// STAGED in round 3 without GPU time left to measure it: off unless MIGAN_WGRAD_REDUCE_TR=1 (tools/gpu_tasks.sh staged).
+#define RTR_CI 64
+__global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                              int splits, int Co, int T, int Ci, int accum, int ci_tiles,
+                                                              const BiasRed br) {
+    extern __shared__ float rtr_tile[];   // [RTR_CI][T + 1]
+    if ((int)blockIdx.x < br.nbias) {  // block-uniform
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
+        return;
+    }
+    const int b = blockIdx.x - br.nbias;
+    const int co = b / ci_tiles, ci0 = (b - co * ci_tiles) * RTR_CI;
+    const int ncl = Ci - ci0 < RTR_CI ? Ci - ci0 : RTR_CI;
+    const size_t total = (size_t)Co * T * Ci;
+    const float* src = part + (size_t)co * T * Ci + ci0;
+    for (int e = threadIdx.x; e < T * RTR_CI; e += 256) {
+        const int tt = e / RTR_CI, cl = e - tt * RTR_CI;
+        float s = 0.f;
+        if (cl < ncl)
+            for (int k = 0; k < splits; ++k) s += src[(size_t)k * total + (size_t)tt * Ci + cl];
+        rtr_tile[cl * (T + 1) + tt] = s;
+    }
+    __syncthreads();
+    float* o = dw + ((size_t)co * Ci + ci0) * T;
+    for (int e = threadIdx.x; e < ncl * T; e += 256) {
+        const int cl = e / T, tt = e - cl * T;
+        const float s = rtr_tile[cl * (T + 1) + tt];
+        o[e] = accum ? o[e] + s : s;
+    }
+}
+
 static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, int accum,
                                hipStream_t st, BiasRed br = BiasRed{}) {
     long total = (long)Co * T * Ci;
     const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
     br.nbias = extra;
+    static const int tr_env = getenv("MIGAN_WGRAD_REDUCE_TR") ? atoi(getenv("MIGAN_WGRAD_REDUCE_TR")) : 0;
+    if (tr_env != 0 && total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
+        const int ci_tiles = cdiv(Ci, RTR_CI);
+        br.main_blocks = Co * ci_tiles;
+        hipLaunchKernelGGL(wgrad_reduce_tr_kernel, dim3(br.main_blocks + extra), dim3(256), (size_t)RTR_CI * (T + 1) * 4, st,
+                           ws, dw, splits, Co, T, Ci, accum, ci_tiles, br);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (splits >= 64 && total < (1 << 16)) {
         br.main_blocks = cdiv(total, 16);
         hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,

@@ -615,10 +615,47 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
         dst[i] = src[i0 * st[p0] + i1 * st[p1] + i2 * st[p2] + i3 * st[p3]];
     }
 }
+// The two weight packs of a convolution, OIHW -> OHWI (perm 0,2,3,1) and OIHW -> IHWO (perm 1,2,3,0), as LDS-tiled
+// transposes.  With R = kh*kw both are  dst[y][r][x] = src[y*sy + x*sx + r]  (OHWI: y = o, x = i, sy = I*R, sx = R;
+// IHWO: y = i, x = o, sy = R, sx = I*R): permute4_kernel reads them 4 B at a stride of R floats (27 us for a 4.2 M-element
+// pix2pix weight, 22 such launches per step, profiles/r03_pix2pix_kernel_stats.txt).  A workgroup owns (y, 64 x): it reads
+// the 64 runs of R contiguous floats (one contiguous 64*R block for OHWI), transposes through a padded LDS tile and writes
+// R runs of 64 contiguous floats.  STAGED in round 3 without GPU time left to measure it: off unless MIGAN_PACK_TR=1.
+#define PTR_X 64
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int X,
+                                                             int R, long long sy, long long sx, int x_tiles) {
+    extern __shared__ float ptr_tile[];   // [PTR_X][R + 1]
+    const int y = blockIdx.x / x_tiles, x0 = (blockIdx.x - y * x_tiles) * PTR_X;
+    const int nx = X - x0 < PTR_X ? X - x0 : PTR_X;
+    const float* s = src + (size_t)y * sy + (size_t)x0 * sx;
+    for (int e = threadIdx.x; e < nx * R; e += 256) {
+        const int xl = e / R, r = e - xl * R;
+        ptr_tile[xl * (R + 1) + r] = s[(size_t)xl * sx + r];
+    }
+    __syncthreads();
+    float* d = dst + (size_t)y * R * X + x0;
+    for (int e = threadIdx.x; e < R * PTR_X; e += 256) {
+        const int r = e / PTR_X, xl = e - r * PTR_X;
+        if (xl < nx) d[(size_t)r * X + xl] = ptr_tile[xl * (R + 1) + r];
+    }
+}
+
 MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2,
                               int p3, void* stream) {
     size_t total = (size_t)d0 * d1 * d2 * d3;
     if (total == 0) return 0;
+    static const int tr_env = getenv("MIGAN_PACK_TR") ? atoi(getenv("MIGAN_PACK_TR")) : 0;
+    const int R = d2 * d3;
+    const bool ohwi = p0 == 0 && p1 == 2 && p2 == 3 && p3 == 1, ihwo = p0 == 1 && p1 == 2 && p2 == 3 && p3 == 0;
+    if (tr_env != 0 && (ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {
+        const int X = ohwi ? d1 : d0, Y = ohwi ? d0 : d1;
+        const long long sy = ohwi ? (long long)d1 * R : R, sx = ohwi ? R : (long long)d1 * R;
+        const int x_tiles = (X + PTR_X - 1) / PTR_X;
+        hipLaunchKernelGGL(pack_transpose_kernel, dim3((unsigned)Y * x_tiles), dim3(256), (size_t)PTR_X * (R + 1) * 4,
+                           (hipStream_t)stream, src, dst, X, R, sy, sx, x_tiles);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1,
                        d2, d3, p0, p1, p2, p3, total);
     HIP_LAUNCH_CHECK();
