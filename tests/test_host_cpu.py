@@ -312,3 +312,26 @@ def test_bucket_layout_and_run_ranks_helper():
     assert int(left.stdout.strip()) == 0
     rc, out, _ = run_ranks([sys.executable, "-c", "print('ok')"], ROOT, dict(os.environ), 30)
     assert rc == 0 and out.strip() == "ok"
+
+
+def test_rocpd_stats_counts_steps_from_the_trace(tmp_path):
+    """tools/rocpd_stats.py --per-step: the per-step header comes from the optimiser launches in the trace (warm-up steps
+    are traced too), not from the --steps the bench was asked for."""
+    import sqlite3
+    import subprocess
+    import sys
+
+    db = str(tmp_path / "t_results.db")
+    c = sqlite3.connect(db)
+    c.execute("create table kernels(name text, start int, end int, grid_x int, grid_y int, grid_z int)")
+    for _ in range(12):   # 12 steps in the trace: 3 optimiser launches + 10 conv launches each
+        c.executemany("insert into kernels values(?,?,?,?,?,?)", [("adam_kernel(AdamTensor const*)", 0, 1000, 1, 1, 1)] * 3)
+        c.executemany("insert into kernels values(?,?,?,?,?,?)", [("conv", 0, 5000, 2, 1, 1)] * 10)
+    c.commit()
+    c.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rocpd_stats.py"), db, "5", "5", "--by-grid", "--per-step",
+                        "adam_kernel=3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    head = r.stdout.splitlines()[0]
+    assert "13.0 launches per step" in head and "12 steps in the trace" in head, head

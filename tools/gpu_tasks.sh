@@ -141,7 +141,9 @@ task_prof() {
     (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$w -o $w -- python $R/bench.py --workload $w --steps $k --warmup 2 \
        --min-seconds 0 --no-graph --no-roofline --no-cpu-baseline --no-extra > $R/$O/prof_$w.log 2>&1)
     db=$(ls $O/prof_$w/*/${w}_results.db $O/prof_$w/${w}_results.db 2>/dev/null | head -1)
-    python tools/rocpd_stats.py $db 150 $((k+2)) --by-grid > $O/${w}_kernel_stats.txt 2>&1
+    # steps counted from the trace (optimiser launches per step), not from --steps: warm-up steps are traced too
+    a=2; [ $w = cyclegan ] && a=3; [ $w = wgan_gp ] && a=1.2
+    python tools/rocpd_stats.py $db 150 --by-grid --per-step adam_kernel=$a > $O/${w}_kernel_stats.txt 2>&1
     head -3 $O/${w}_kernel_stats.txt
   done
 }
