@@ -114,11 +114,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
         }
     }
     unsigned b_off[IB];
+    int b_kc[IB];
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
         const int X = wave * IB + j;
         const int n = n0 + X * RPI + lrow;
         const int kc = ((lane % CPR) ^ (((X * RPI + lrow) >> SH) & (CPR - 1))) * 4;
+        b_kc[j] = kc;
         b_off[j] = n < g.Co ? (unsigned)(n * g.ldw + kc) * 4u : DMA_SENT;
     }
     unsigned a_off[TAPS_IN][IA];  // byte offset of this lane's chunk of row i at channel 0 of the slot's tap (or DMA_SENT)
@@ -153,9 +155,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                                                      0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < IB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16,
-                                                     (int)((NS > 2 && !live) ? DMA_SENT : b_off[j]), (int)soB, 0, 0);
+        for (int j = 0; j < IB; ++j) {
+            unsigned vo = b_off[j];
+            // channel tail: the A chunk is zero there, but the SGPR offset is outside the descriptor's range check, so the weight
+            // chunk would be fetched from the next tap - and, for the last row of the last tap, from BEHIND the weight tensor,
+            // where a stale NaN times that zero would poison the tile (found by the host execution model, tests/hipemu)
+            if (KTAIL) vo = (f_c0 + b_kc[j] < Ci) ? vo : DMA_SENT;
+            if (NS > 2) vo = live ? vo : DMA_SENT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void_t*)(base + A_FL + (wave * IB + j) * 256), 16, (int)vo, (int)soB,
+                                                     0, 0);
+        }
     };
 
     // ---- fragment read addresses: row = w * T * 32 + i * 32 + l31, chunk (2q + h) ^ f(l31)

@@ -1149,7 +1149,9 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
 // serially - 295 us for 4 MFLOP (profiles/r03_pix2pix_kernel_stats.txt).  Here ONE WAVE owns one output pixel: the
 // lanes split the channels (coalesced 1 KB rows of the NHWC source, straight from L2 - the whole input is < 1 MB per
 // image), every load of a tap is independent, and the 64 partial sums are combined by a fixed butterfly (deterministic).
-// STAGED in round 3 without GPU time left to measure it: off unless MIGAN_THIN_WAVE=1 (tools/gpu_tasks.sh thin_wave).
+// Written after round 3's GPU budget was spent: verified on the host execution model (tests/hipemu: the conv cases and the
+// pix2pix / CycleGAN / SRGAN step parity tests run through it), not yet timed on hardware.  MIGAN_THIN_WAVE=0 disables it
+// (tools/gpu_tasks.sh staged is the A/B).
 template <int CO>
 __global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, const float* __restrict__ A,
                                                              const float* __restrict__ Bw, const float* __restrict__ bias,
@@ -1201,9 +1203,9 @@ __global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, c
     }
 }
 
-// few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel (opt-in)
+// few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel
 static bool thin_wave_ok(const ConvGeom& g, int max_tiles) {
-    static const int on = getenv("MIGAN_THIN_WAVE") ? atoi(getenv("MIGAN_THIN_WAVE")) : 0;
+    static const int on = getenv("MIGAN_THIN_WAVE") ? atoi(getenv("MIGAN_THIN_WAVE")) : 1;  // 0 = A/B against thin_conv_kernel
     return on != 0 && g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
 }
 
@@ -2498,7 +2500,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // but scatters every result 4 B at a stride of T floats into the OIHW gradient (44 / 73 us for 16 / 32 MB,
 // profiles/r03_pix2pix_kernel_stats.txt).  Here a workgroup owns (co, 64 input channels): it sums the slabs in the same
 // split order (bit-identical results), transposes the 64 x T tile through LDS and writes ONE contiguous run of 64*T floats.
-// STAGED in round 3 without GPU time left to measure it: off unless MIGAN_WGRAD_REDUCE_TR=1 (tools/gpu_tasks.sh staged).
+// Written after round 3's GPU budget was spent: verified on the host execution model (tests/hipemu), not yet timed on
+// hardware.  MIGAN_WGRAD_REDUCE_TR=0 disables it (tools/gpu_tasks.sh staged is the A/B).
 #define RTR_CI 64
 __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int splits, int Co, int T, int Ci, int accum, int ci_tiles,
@@ -2534,7 +2537,7 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     long total = (long)Co * T * Ci;
     const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
     br.nbias = extra;
-    static const int tr_env = getenv("MIGAN_WGRAD_REDUCE_TR") ? atoi(getenv("MIGAN_WGRAD_REDUCE_TR")) : 0;
+    static const int tr_env = getenv("MIGAN_WGRAD_REDUCE_TR") ? atoi(getenv("MIGAN_WGRAD_REDUCE_TR")) : 1;  // 0 = A/B
     if (tr_env != 0 && total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
         const int ci_tiles = cdiv(Ci, RTR_CI);
         br.main_blocks = Co * ci_tiles;

@@ -620,7 +620,8 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
 // IHWO: y = i, x = o, sy = R, sx = I*R): permute4_kernel reads them 4 B at a stride of R floats (27 us for a 4.2 M-element
 // pix2pix weight, 22 such launches per step, profiles/r03_pix2pix_kernel_stats.txt).  A workgroup owns (y, 64 x): it reads
 // the 64 runs of R contiguous floats (one contiguous 64*R block for OHWI), transposes through a padded LDS tile and writes
-// R runs of 64 contiguous floats.  STAGED in round 3 without GPU time left to measure it: off unless MIGAN_PACK_TR=1.
+// R runs of 64 contiguous floats.  Written after round 3's GPU budget was spent: verified on the host execution model
+// (tests/hipemu), not yet timed on hardware; MIGAN_PACK_TR=0 disables it.
 #define PTR_X 64
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int X,
                                                              int R, long long sy, long long sx, int x_tiles) {
@@ -644,7 +645,7 @@ MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int 
                               int p3, void* stream) {
     size_t total = (size_t)d0 * d1 * d2 * d3;
     if (total == 0) return 0;
-    static const int tr_env = getenv("MIGAN_PACK_TR") ? atoi(getenv("MIGAN_PACK_TR")) : 0;
+    static const int tr_env = getenv("MIGAN_PACK_TR") ? atoi(getenv("MIGAN_PACK_TR")) : 1;  // 0 = A/B against permute4_kernel
     const int R = d2 * d3;
     const bool ohwi = p0 == 0 && p1 == 2 && p2 == 3 && p3 == 1, ihwo = p0 == 1 && p1 == 2 && p2 == 3 && p3 == 0;
     if (tr_env != 0 && (ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {

@@ -82,8 +82,13 @@ def _plain(t):
         return t.as_subclass(torch.Tensor)
 
 
+def on_device(t):
+    """THE definition of "this tensor lives on the HIP device": every device check of the host mirror asks here."""
+    return t.is_cuda
+
+
 def _check_dev(t):
-    if not t.is_cuda:
+    if not on_device(t):
         raise RuntimeError("pytorch_gan_amd: tensor is on %s; the HIP path has no CPU fallback" % t.device)
     if t.dtype != torch.float32:
         raise TypeError("pytorch_gan_amd: fp32 only (got %s)" % t.dtype)
@@ -276,7 +281,7 @@ class _PackPlan:
         live = []
         for ref, kind, perm in prev.values():
             p = ref()
-            if p is not None and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
+            if p is not None and on_device(p) and p.dtype == torch.float32 and p.is_contiguous():
                 live.append((p, kind, perm))
         if not live:
             return
@@ -1781,7 +1786,7 @@ class _Embedding(Function):
     def forward(ctx, idx, weight):
         w = _plain(weight)
         _check_dev(w)
-        if idx.dtype != torch.int64 or not idx.is_cuda:
+        if idx.dtype != torch.int64 or not on_device(idx):
             raise TypeError("embedding: indices must be an int64 tensor on the GPU (the reference passes LongTensor labels)")
         flat = idx.reshape(-1).contiguous()
         V, D = w.shape
@@ -1845,7 +1850,7 @@ class _CrossEntropy(Function):
         xs = canon(x)
         if xs.dim() != 2 or target.dim() != 1 or target.shape[0] != xs.shape[0]:
             raise ValueError("cross_entropy: expected (B, C) scores and (B,) class indices")
-        if target.dtype != torch.int64 or not target.is_cuda:
+        if target.dtype != torch.int64 or not on_device(target):
             raise TypeError("cross_entropy: targets must be an int64 tensor on the GPU")
         t = target.contiguous()
         B, C = xs.shape

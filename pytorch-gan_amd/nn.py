@@ -58,7 +58,7 @@ class GanTensor(torch.Tensor):
 
 
 def _is_act4(t):
-    return isinstance(t, torch.Tensor) and t.dim() == 4 and t.is_cuda and t.dtype == torch.float32
+    return isinstance(t, torch.Tensor) and t.dim() == 4 and F.on_device(t) and t.dtype == torch.float32
 
 
 def _h_view(func):
@@ -84,7 +84,7 @@ def _h_mul(args, kwargs):
     if len(args) != 2 or kwargs:
         return NotImplemented
     a, b = args
-    ok = lambda t: isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32  # noqa: E731
+    ok = lambda t: isinstance(t, torch.Tensor) and F.on_device(t) and t.dtype == torch.float32  # noqa: E731
     if ok(a) and ok(b) and a.shape == b.shape:
         return _wrap(F.mul(a, b))
     if ok(b) and isinstance(a, (int, float)):

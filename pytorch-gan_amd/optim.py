@@ -16,6 +16,7 @@ import weakref
 import numpy as np
 import torch
 
+from . import functional as F
 from ._lib import check, lib
 
 # Weight epochs (functional.set_weight_cache): process-wide unique, never re-used stamps, so a cached pack made under one
@@ -49,7 +50,7 @@ class Adam:
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
         dev = self.params[0].device
-        if dev.type != "cuda":
+        if not F.on_device(self.params[0]):
             raise RuntimeError("pytorch_gan_amd.optim.Adam needs parameters on the GPU (call .cuda() first, as the "
                                "reference does before building its optimisers)")
         for p in self.params:

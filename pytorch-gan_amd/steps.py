@@ -304,7 +304,7 @@ class ReplayBuffer:
         return self.count if self.pool is not None else len(self.data)
 
     def push_and_pop(self, batch):
-        if not batch.is_cuda:
+        if not F.on_device(batch):
             return self._push_and_pop_host(batch)
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ReplayBuffer draws from the host RNG: it cannot be captured into a hipGraph (run "

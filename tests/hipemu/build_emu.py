@@ -1,0 +1,138 @@
+"""TEST INFRASTRUCTURE: build tests/hipemu/_build/libmigan_emu.so - the kernel sources of pytorch-gan_amd/csrc compiled as
+plain C++ for the host against the execution-model header in tests/hipemu/include (see its first lines for what the model
+covers).  Only tests load the result.
+
+The sources are compiled unchanged except for two textual substitutions no header can express (applied to a copy under
+_build/, with #line directives so diagnostics point at the original):
+  * `extern __shared__ [attr] T name[];`  ->  `T* name = (T*)hipemu::dyn_lds();`   (dynamic LDS of the launch)
+  * `asm volatile(...)` statements: one that contains `s_barrier` becomes `__syncthreads();`, the others (s_waitcnt, register
+    pinning) are dropped - the model has no asynchronous loads to wait for.
+
+    python tests/hipemu/build_emu.py [--force] [source.hip ...]
+"""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "pytorch-gan_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+OUT = os.path.join(BUILD, "libmigan_emu.so")
+CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=fast", "-fvisibility=hidden", "-pthread", "-w",
+         "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DHIPEMU=1"]
+
+
+def sources():
+    sys.path.insert(0, CSRC)
+    try:
+        import build as product_build
+        return list(product_build.SOURCES), list(product_build.HEADERS)
+    finally:
+        sys.path.pop(0)
+
+
+def _drop_asm(text):
+    out, i = [], 0
+    pat = re.compile(r"\basm\s+volatile\s*\(")
+    while True:
+        m = pat.search(text, i)
+        if not m:
+            out.append(text[i:])
+            break
+        out.append(text[i:m.start()])
+        depth, j = 1, m.end()
+        while depth:
+            c = text[j]
+            if c == '"':  # string literal: skip to its end
+                j += 1
+                while text[j] != '"':
+                    j += 2 if text[j] == "\\" else 1
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            j += 1
+        body = text[m.end():j - 1]
+        while text[j] in " \t":
+            j += 1
+        assert text[j] == ";", "asm statement without ';' near: " + text[m.start():j + 20]
+        j += 1
+        keep_lines = "\n" * body.count("\n")  # keep the line numbering
+        out.append(("__syncthreads();" if "s_barrier" in body else "") + keep_lines)
+        i = j
+    return "".join(out)
+
+
+_EXT_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w:]*)\s+(\w+)\s*\[\s*\]\s*;")
+
+
+def transform(text, origin):
+    text = _drop_asm(text)
+    text = _EXT_SHARED.sub(lambda m: "%s* %s = reinterpret_cast<%s*>(hipemu::dyn_lds());" % (m.group(1), m.group(2), m.group(1)), text)
+    assert "extern __shared__" not in text, "unhandled dynamic LDS declaration in " + origin
+    return '#line 1 "%s"\n' % origin + text
+
+
+def _digest(srcs, hdrs):
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in srcs + hdrs] + [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.abspath(__file__)]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, only=None, verbose=False):
+    """Returns the path of the emulation library (built when the sources, the model or this script changed).  `only`: list of
+    source names - a partial library under its own name (quick iterations on one kernel file)."""
+    srcs, hdrs = sources()
+    out = OUT
+    if only:
+        srcs = [s for s in srcs if s in only]
+        out = os.path.join(BUILD, "libmigan_emu_%s.so" % "_".join(s.split(".")[0] for s in srcs))
+    if not os.path.exists(CXX):
+        raise RuntimeError("no host clang++ at %s (HIPEMU_CXX overrides)" % CXX)
+    os.makedirs(BUILD, exist_ok=True)
+    dig = _digest(srcs, hdrs)
+    stamp = out + ".stamp"
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return out
+    procs, objs = [], []
+    for s in srcs + ["hipemu.cpp"]:
+        if s == "hipemu.cpp":
+            src = os.path.join(HERE, s)
+        else:
+            src = os.path.join(BUILD, s.replace(".hip", ".emu.cpp"))
+            with open(os.path.join(CSRC, s)) as fh:
+                text = transform(fh.read(), os.path.join(CSRC, s))
+            with open(src, "w") as fh:
+                fh.write(text)
+        obj = os.path.join(BUILD, os.path.basename(src) + ".o")
+        cmd = [CXX] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    failed = None
+    for s, p in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0 and failed is None:
+            sys.stderr.write(o.decode()[-6000:])
+            failed = s
+    if failed:
+        raise RuntimeError("host compile of %s failed" % failed)
+    tmp = out + ".%d" % os.getpid()
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-o", tmp] + objs)
+    os.replace(tmp, out)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return out
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    print(build(force="--force" in sys.argv, only=args or None, verbose=True))

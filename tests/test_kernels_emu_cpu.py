@@ -1,0 +1,234 @@
+"""Kernel LOGIC without a GPU: the unchanged HIP sources of pytorch-gan_amd/csrc compiled for the host against the execution
+model in tests/hipemu (one fiber per HIP thread, 64-lane waves, __syncthreads, wave shuffles, the fp32 MFMA fragment layouts
+as exact fmaf chains, LDS-DMA with the buffer descriptor's range check, split-K tickets) and driven
+
+  * through the C ABI of include/migan.h against torch's CPU ops, and
+  * through the product's own Python host mirror (autograd Functions, modules, fused Adam, the training-step bodies of
+    steps.py) - by running the BODIES OF THE GPU PARITY TESTS of test_steps_gpu.py on CPU tensors against the oracle.
+
+This is a checker, never a product path: the product has no CPU mode, the patching lives in tests/hipemu/host.py.  What the
+model cannot see (timing, missing waits on asynchronous loads, memory ordering) stays with the `-m gpu` tests; what it does
+see it sees strictly - e.g. an LDS-DMA lane that passes the descriptor's range check and still leaves the tensor fails the
+launch here (the hardware would silently read the neighbouring allocation)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import hipemu
+
+pytestmark = pytest.mark.skipif(not hipemu.available(), reason="no host clang++ / not x86-64: the execution model cannot be built")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    lib = hipemu.load()
+    lib.hipemu_reset_counts()
+    return lib
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _gather_ref(x, pads, gather):
+    t, l, b, r = pads
+    if gather == 2:
+        x = TF.interpolate(x, scale_factor=2, mode="nearest")
+    if gather == 1:
+        return TF.pad(x, (l, r, t, b), mode="reflect")
+    return TF.pad(x, (l, r, t, b))
+
+
+def _conv_case(emu, case, sk):
+    """forward / input gradient / weight gradient of one geometry through migan_conv2d_{fwd_ws,dgrad_ws,wgrad} -> rel. errors"""
+    N, Ci, H, W, Co, k, stride, pads, gather, act, bias = case
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Ci, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(Co, generator=g) if bias else None
+    y_lin = TF.conv2d(_gather_ref(x, pads, gather), w, b, stride)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu, 3: torch.tanh}[act](y_lin)
+    Ho, Wo = y_ref.shape[2:]
+    out = {}
+    xn = x.detach().permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(N, Ho, Wo, Co)
+    w_ohwi, w_ihwo = w.detach().permute(0, 2, 3, 1).contiguous(), w.detach().permute(1, 2, 3, 0).contiguous()
+    rc = emu.migan_conv2d_fwd_ws(_ptr(xn), _ptr(w_ohwi), _ptr(b), None, _ptr(y), N, H, W, Ci,
+                                 Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, act, 0.2, _ptr(sk), sk.numel() * 4, None)
+    assert rc == 0, (case, "fwd", emu.hipemu_last_message())
+    out["fwd"] = _rel(y.permute(0, 3, 1, 2), y_ref.detach())
+    if gather == 0:
+        gy = torch.randn(y_lin.shape, generator=g)
+        y_lin.backward(gy)
+        gyn = gy.permute(0, 2, 3, 1).contiguous()
+        if pads[0] == pads[2] and pads[1] == pads[3]:
+            dx = torch.empty(N, H, W, Ci)
+            rc = emu.migan_conv2d_dgrad_ws(_ptr(gyn), _ptr(w_ihwo), None, _ptr(dx), N, H, W, Ci,
+                                           Ho, Wo, Co, k, k, stride, pads[0], pads[1], 0, 0.0, _ptr(sk), sk.numel() * 4, None)
+            assert rc == 0, (case, "dgrad", emu.hipemu_last_message())
+            out["dgrad"] = _rel(dx.permute(0, 3, 1, 2), x.grad)
+        wsb = emu.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
+        ws = torch.empty(max(wsb // 4, 1))
+        dw = torch.empty(Co, Ci, k, k)
+        rc = emu.migan_conv2d_wgrad(_ptr(xn), _ptr(gyn), _ptr(dw), _ptr(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0],
+                                    pads[1], gather, 0, None, 0, None, 0, None)
+        assert rc == 0, (case, "wgrad", emu.hipemu_last_message())
+        out["wgrad"] = _rel(dw, w.grad)
+    return out
+
+
+def _gpu_conv_cases():
+    from test_ops_gpu import CONV_CASES
+
+    return [c for c in CONV_CASES if c[0] * c[2] * c[3] <= 100000]   # all but the 401k-pixel case
+
+
+def test_every_gpu_conv_case_on_the_execution_model(emu):
+    """The CONV_CASES of test_ops_gpu.py (the GPU suite's list: every kernel family of conv_igemm.hip / conv_dma.hip - LDS-DMA
+    tiles, tap-inner up-conv, K-tails, split-K with tickets, thin-N, small-K, gemv, parity-class dgrads, DMA / incremental /
+    thin wgrads) against torch on the host, same tolerances as on the GPU."""
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    emu.hipemu_reset_counts()
+    for case in _gpu_conv_cases():
+        for what, err in _conv_case(emu, case, sk).items():
+            assert err <= (1e-5 if what == "wgrad" else 3e-6), (case, what, err)
+        assert int(sk[:1024].view(torch.int32).abs().sum()) == 0, ("split-K tickets not back at zero", case)
+    # the list really went through the kernels it is meant for
+    for sym in ("igemm_dma_kernel", "wgrad_dma_kernel", "thin_conv_kernel", "thin_conv_wave_kernel", "smallk", "wgrad_reduce"):
+        assert emu.hipemu_launch_count(sym.encode()) > 0, sym
+
+
+KTAIL_CASES = [
+    (2, 40, 10, 10, 72, 3, 1, (1, 1, 1, 1), 0, 1, True),     # Ci = 40: one full K-tile + a tail of 8 channels
+    (2, 100, 6, 6, 36, 3, 1, (1, 1, 1, 1), 0, 0, False),     # Ci = 100
+    (3, 72, 8, 8, 96, 3, 1, (1, 1, 1, 1), 0, 0, True),       # split-K with a K-tail
+    (3, 32, 9, 7, 48, 3, 1, (1, 1, 1, 1), 0, 2, True),       # dgrad GEMM K = Co = 48
+    (1, 36, 5, 5, 33, 1, 1, (0, 0, 0, 0), 0, 0, True),       # 1x1, one tap: the tail chunk of the LAST weight row
+]
+
+
+@pytest.mark.parametrize("case", KTAIL_CASES)
+def test_lds_dma_channel_tail_stays_inside_the_tensors(emu, case):
+    """Regression (found by this model): in the K-tail variant of igemm_dma_kernel the weight chunk behind Ci was fetched with
+    its row offset in range and the channel offset in the SGPR operand, which the descriptor's range check does not cover -
+    the last row of the last tap read behind the weight tensor (times a zero A chunk: harmless unless the bytes there are a
+    NaN).  The model fails such a launch; results must match as well."""
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    for what, err in _conv_case(emu, case, sk).items():
+        assert err <= 1e-5, (case, what, err)
+
+
+def test_splitk_tickets_and_determinism(emu):
+    """pix2pix/models.py:66 geometry (4 output pixels, K = 8192): slices add in slice order whoever arrives last - with the
+    model's workgroups on 1, 3 and 8 OS threads (different arrival orders) the result is bit-identical."""
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 4, 4, 512, generator=g)
+    w = torch.randn(512, 4, 4, 512, generator=g) * 0.05
+    outs = []
+    for threads in (1, 3, 8):
+        emu.hipemu_set_threads(threads)
+        y = torch.empty(1, 2, 2, 512)
+        rc = emu.migan_conv2d_fwd_ws(_ptr(x), _ptr(w), None, None, _ptr(y), 1, 4, 4, 512, 2, 2, 512, 4, 4, 2, 1, 1, 0, 0, 0.0,
+                                     _ptr(sk), sk.numel() * 4, None)
+        assert rc == 0
+        outs.append(y)
+    emu.hipemu_set_threads(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert int(sk[:1024].view(torch.int32).abs().sum()) == 0
+    ref = TF.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 2, 1)
+    assert _rel(outs[0].permute(0, 3, 1, 2), ref) <= 3e-6
+
+
+@pytest.mark.parametrize("shape,perm", [((96, 80, 4, 4), (0, 2, 3, 1)), ((96, 80, 4, 4), (1, 2, 3, 0)), ((130, 70, 3, 3), (1, 2, 3, 0)),
+                                        ((64, 100, 7, 7), (0, 2, 3, 1)), ((70, 40, 4, 4), (0, 2, 3, 1)), ((5, 6, 7, 8), (3, 1, 0, 2))])
+def test_weight_packs(emu, shape, perm):
+    """OHWI / IHWO packs: pack_transpose_kernel (>= 64 k elements) and the generic permute4_kernel are exact copies."""
+    w = torch.randn(*shape)
+    out = torch.empty(w.numel())
+    emu.hipemu_reset_counts()
+    assert emu.migan_permute4d(_ptr(w), _ptr(out), *shape, *perm, None) == 0
+    assert torch.equal(out, w.permute(*perm).contiguous().view(-1))
+    tiled = w.numel() >= (1 << 16) and perm in ((0, 2, 3, 1), (1, 2, 3, 0))
+    assert emu.hipemu_launch_count(b"pack_transpose_kernel") == (1 if tiled else 0)
+
+
+def _run_gpu_test_body(module_name, test_name, *args):
+    """Run the body of a `-m gpu` parity test on CPU tensors: its device is "cpu", its kernels are the execution model."""
+    import importlib
+
+    import hipemu.host
+    import util
+
+    T = importlib.import_module(module_name)
+    saved = (T.DEV, T.gpu_copy)
+    T.DEV = "cpu"
+    T.gpu_copy = lambda m, device="cpu": util.gpu_copy(m, "cpu")
+    try:
+        with hipemu.host.emulated_device() as lib:
+            lib.hipemu_reset_counts()
+            getattr(T, test_name)(*args)
+            assert lib.hipemu_launch_count(b"_kernel") > 0, "no kernel ran"
+            return lib
+    finally:
+        T.DEV, T.gpu_copy = saved
+
+
+STEP_BODIES = [
+    ("test_dcgan_steps", (True,)),            # dcgan.py:143-183, 3 steps: paired D pass, chained BatchNorm statistics, dropout masks
+    ("test_wgan_gp_steps", (False,)),         # wgan_gp.py:119-193, 6 critic iterations: double backward through the skinny GEMMs
+    ("test_dragan_steps", ()),                # dragan.py:176-217: conv-critic gradient penalty
+    ("test_srgan_step", ()),                  # srgan.py:97-145: PixelShuffle epilogue, VGG features, Toeplitz 9x9
+    ("test_pix2pix_step", ()),                # pix2pix.py:123-172 at 256x256: split-K, ConvTranspose, PatchGAN head, 4-8 M-element weights
+]
+
+
+@pytest.mark.parametrize("name,args", STEP_BODIES, ids=[n for n, _ in STEP_BODIES])
+def test_step_parity_bodies_on_the_execution_model(name, args):
+    """The training-step parity tests of test_steps_gpu.py, unchanged, against the oracle: losses of every step, weights after
+    Adam, BatchNorm buffers - computed by the HIP kernels' source running on the host."""
+    lib = _run_gpu_test_body("test_steps_gpu", name, *args)
+    if name == "test_pix2pix_step":   # the kernels this workload is there for
+        for sym in (b"thin_conv_wave_kernel", b"wgrad_reduce_tr_kernel", b"pack_transpose_kernel", b"true>"):
+            assert lib.hipemu_launch_count(sym) > 0, sym
+
+
+@pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="4 minutes on 8 cores: MIGAN_EMU_SLOW=1")
+def test_cyclegan_steps_on_the_execution_model():
+    _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
+
+
+def test_a_deadlock_is_reported_not_hung(emu, tmp_path):
+    """The model's own safety net: a kernel whose threads do not all reach a barrier ends the launch with an error."""
+    src = tmp_path / "dead.cpp"
+    src.write_text('''
+#include <hip/hip_runtime.h>
+__global__ void dead_kernel(int* out) {
+    if (threadIdx.x < 32) __syncthreads();      // half the workgroup waits for a barrier the other half never reaches ...
+    else while (out[0] == 0) __builtin_amdgcn_s_sleep(1);   // ... because it spins on a flag nobody sets
+    out[1] = 1;
+}
+extern "C" __attribute__((visibility("default"))) int run_dead(int* out) {
+    hipLaunchKernelGGL(dead_kernel, dim3(1), dim3(64), 0, 0, out);
+    return hipGetLastError();
+}
+''')
+    import ctypes
+    import subprocess
+
+    from hipemu import build_emu
+
+    so = str(tmp_path / "dead.so")
+    subprocess.check_call([build_emu.CXX] + build_emu.FLAGS + ["-shared", str(src), os.path.join(os.path.dirname(build_emu.__file__), "hipemu.cpp"), "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.hipemu_last_message.restype = ctypes.c_char_p
+    out = torch.zeros(2, dtype=torch.int32)
+    assert lib.run_dead(ctypes.c_void_p(out.data_ptr())) != 0
+    assert b"deadlock" in lib.hipemu_last_message()

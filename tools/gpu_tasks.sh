@@ -226,25 +226,22 @@ task_suite() {
 }
 
 t=${1:-}; shift || true
-# kernels STAGED at the end of round 3 with no GPU time left (all off by default): parity of the conv / model / step suites
-# with the three flags on, then the pix2pix step A/B (where all three act) and CycleGAN (PatchGAN head only)
-#   MIGAN_THIN_WAVE=1        one-wave-per-pixel thin conv for PatchGAN heads (conv_igemm.hip thin_conv_wave_kernel)
-#   MIGAN_WGRAD_REDUCE_TR=1  transposing wgrad slab reduction for >= 1 M-element weights (wgrad_reduce_tr_kernel)
-#   MIGAN_PACK_TR=1          LDS-tiled OHWI / IHWO weight packs (eltwise.hip pack_transpose_kernel)
+# kernels written at the end of round 3 with no GPU time left (verified on the host execution model only; ON by default):
+# parity with each one switched off and on, then the pix2pix step A/B (where all three act) and CycleGAN (PatchGAN head)
+#   MIGAN_THIN_WAVE        one-wave-per-pixel thin conv for PatchGAN heads (conv_igemm.hip thin_conv_wave_kernel)
+#   MIGAN_WGRAD_REDUCE_TR  transposing wgrad slab reduction for >= 1 M-element weights (wgrad_reduce_tr_kernel)
+#   MIGAN_PACK_TR          LDS-tiled OHWI / IHWO weight packs (eltwise.hip pack_transpose_kernel)
 task_staged() {
   mkdir -p gpurun_out/staged
-  for flag in MIGAN_THIN_WAVE MIGAN_WGRAD_REDUCE_TR MIGAN_PACK_TR; do
-    echo "== parity with $flag=1" >> gpurun_out/staged/pytest.txt
-    env $flag=1 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -q -x \
-      -k "conv or pix2pix or cyclegan or srgan or patch" >> gpurun_out/staged/pytest.txt 2>&1
-    echo "pytest rc=$?" >> gpurun_out/staged/pytest.txt
-  done
-  env MIGAN_THIN_WAVE=1 MIGAN_WGRAD_REDUCE_TR=1 MIGAN_PACK_TR=1 timeout 900 python -m pytest tests/test_steps_gpu.py -q -x \
-    -k "pix2pix or cyclegan_step or srgan_step" >> gpurun_out/staged/pytest.txt 2>&1
+  timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -q -x \
+    -k "conv or pix2pix or cyclegan or srgan or patch" > gpurun_out/staged/pytest.txt 2>&1
+  echo "pytest rc=$?" >> gpurun_out/staged/pytest.txt
+  timeout 900 python -m pytest tests/test_steps_gpu.py -q -x -k "pix2pix or cyclegan_step or srgan_step" >> gpurun_out/staged/pytest.txt 2>&1
   echo "steps pytest rc=$?" >> gpurun_out/staged/pytest.txt
   grep -E "passed|failed|rc=" gpurun_out/staged/pytest.txt
+  OFF="MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0"
   for w in pix2pix cyclegan; do
-    for f in "" "MIGAN_THIN_WAVE=1" "MIGAN_WGRAD_REDUCE_TR=1" "MIGAN_PACK_TR=1" "MIGAN_THIN_WAVE=1 MIGAN_WGRAD_REDUCE_TR=1 MIGAN_PACK_TR=1"; do
+    for f in "$OFF" "MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0" "MIGAN_X=1"; do
       echo "== $w [$f]" >> gpurun_out/staged/bench.txt
       env $f timeout 300 python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-roofline \
         2>>gpurun_out/staged/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'])" >> gpurun_out/staged/bench.txt
