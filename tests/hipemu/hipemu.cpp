@@ -303,6 +303,16 @@ extern "C" __attribute__((visibility("default"))) long hipemu_launch_count(const
         if (kv.first.find(substr) != std::string::npos) n += kv.second;
     return n;
 }
+extern "C" __attribute__((visibility("default"))) void hipemu_print_counts() {
+    std::lock_guard<std::mutex> lk(hipemu::g_count_mu);
+    long total = 0;
+    for (auto& kv : hipemu::g_counts) {
+        printf("%6ld  %s\n", kv.second, kv.first.c_str());
+        total += kv.second;
+    }
+    printf("%6ld  launches\n", total);
+    fflush(stdout);
+}
 extern "C" __attribute__((visibility("default"))) void hipemu_reset_counts() {
     std::lock_guard<std::mutex> lk(hipemu::g_count_mu);
     hipemu::g_counts.clear();
