@@ -81,6 +81,22 @@ int migan_skinny_tn_ok(int M, int N, int K);
 int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
                     int db_accumulate, void* stream);
 
+/* K7 (csrc/critic_fused.hip): one WGAN-GP critic iteration of the MLP critic in ONE persistent launch - replaces, for
+ * wgan_gp.py:68-83 (Discriminator), :119-138 (compute_gradient_penalty, incl. autograd.grad(create_graph=True)) and :160-176
+ * (real_validity, fake_validity, d_loss, d_loss.backward()), the ~75 launches of the op-by-op path: D(real), D(fake), the
+ * gradient penalty of the interpolates alpha*real + (1-alpha)*fake, d_loss = -mean D(real) + mean D(fake) + lambda*gp, and the
+ * gradient of d_loss w.r.t. w1 [H1][Din], b1, w2 [H2][H1], b2, w3 [H2], b3 ADDED into gw1..gb3 (the optimiser's zeroed bucket).
+ * real, fake [B][Din]; alpha [B]; out[4] = d_loss, gp, mean D(real), mean D(fake).  B <= 64; Din, H1, H2 % 128 == 0.
+ * ws: migan_critic_fused_workspace() bytes of scratch; sync: 4 unsigned ints zeroed ONCE by the caller (the kernel re-arms
+ * them); grid: workgroups of the persistent launch, all of which must be resident at once (0 = 128).  The grid barrier spins
+ * a bounded number of times: sync[2] != 0 afterwards means it gave up (results invalid, sync must be re-zeroed), never a hang. */
+int migan_critic_fused_ok(int B, int Din, int H1, int H2);
+size_t migan_critic_fused_workspace(int B, int Din, int H1, int H2);
+int migan_critic_fused(const float* real, const float* fake, const float* alpha, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3, float* gw1, float* gb1, float* gw2,
+                       float* gb2, float* gw3, float* gb3, float* out, float* ws, size_t ws_bytes, unsigned* sync, int B,
+                       int Din, int H1, int H2, float slope, float lambda, int grid, void* stream);
+
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];
  * w_ihwo [Ci][R][S][Co]; dx [N][Hi][Wi][Ci] = act(sum + bias) (bias/act used by the ConvTranspose role).

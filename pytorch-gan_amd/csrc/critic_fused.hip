@@ -1,0 +1,524 @@
+// K7: one WGAN-GP critic iteration of the MLP critic (wgan_gp.py:68-83, 119-138, 160-176) in ONE persistent launch:
+//     real_v = D(real), fake_v = D(fake), gp = compute_gradient_penalty(D, real, fake), d_loss = -mean(real_v) + mean(fake_v) + 10 gp,
+//     d_loss.backward()                                  ->  d_loss, gp and the gradient of every critic parameter.
+// D = Linear(Din,H1) LeakyReLU Linear(H1,H2) LeakyReLU Linear(H2,1) at B <= 64 rows: 1.4 GFLOP, weights 2.6 MB (L2-resident) -
+// the launch-per-op path spends 0.41 ms in ~75 launches of 3-6 us on it.  Here the whole thing is a sequence of seven dependent
+// PHASES separated by grid-wide barriers; a phase is a set of 16x16 (NT / NN) or 16x64 (TN) output tiles on
+// v_mfma_f32_16x16x4_f32, operands straight from L2 (the loops of skinny_mm.hip), K cut over the 8 waves of a workgroup.
+//
+// With x^ = a x_r + (1-a) x_f,  a1 = X W1^T + b1, h1 = lrelu(a1), m1 = lrelu'(a1), a2 = h1 W2^T + b2, h2, m2, o = h2 w3^T + b3:
+//   gp path     u2 = m2 (.) w3,  v1 = u2 W2,  u1 = m1 (.) v1,  g = u1 W1,  n_i = |g_i|,  gp = mean (n_i - 1)^2            (rows of x^)
+//   its grads   c_i = 2 lambda (n_i - 1) / (B n_i) g_i,  du1 = c W1^T,  dv1 = m1 (.) du1,  du2 = dv1 W2^T  (lrelu'' = 0)
+//   plain part  do = -1/B (real rows), +1/B (fake rows):  da2 = do w3 (.) m2,  dh1 = da2 W2,  da1 = dh1 (.) m1
+//   dW1 = [u1; da1_r; da1_f]^T [c; x_r; x_f]      dW2 = [u2; da2_r; da2_f]^T [dv1; h1_r; h1_f]      (one K = 3B GEMM each)
+//   dw3 = sum_{r,f} do h2 + sum_{x^} m2 (.) du2,  db1 = colsum [da1_r; da1_f],  db2 = colsum [da2_r; da2_f],  db3 = sum do = 0
+// x^ is never materialised: a1 is affine in X and the interpolation weights sum to one, so a1(x^) = a a1(x_r) + (1-a) a1(x_f)
+// (one third of the largest GEMM less; the rounding differs from interpolate-then-multiply by ~1 ulp of a1).
+// Phases: 1 a1 (real, fake -> three row blocks)  2 a2 (+ S2 = [u2; da2], row dots for o)  3 [v1; dh1] = S2 W2 (-> S1 = [u1; da1])
+//         4 g = u1 W1 (+ row sums of squares)  5 dv1 = m1 (.) coef (g W1^T) (+ gp, coef)  6 e = m2 (.) (dv1 W2^T)
+//         7 dW1, dW2 (TN, K = 3B rows), db1, db2, dw3, db3, losses.
+// Grid barrier: release fence, agent-scope ticket, bounded spin, acquire fence (the protocol of the split-K reduction in
+// conv_dma.hip).  The spin is BOUNDED: a workgroup that does not see its peers arrive within 65 536 polls (~0.1 s) raises the error flag
+// and every workgroup leaves - a launch that cannot be co-resident (it needs gridDim <= resident slots) ends with an error
+// code in sync[2], never with a hung GPU.
+#include "common.h"
+
+#define CF_WAVES 8
+#define CF_THREADS (64 * CF_WAVES)
+#define CF_SPIN_LIMIT (1u << 16)
+
+struct CriticFused {
+    int B, RB, Din, H1, H2;  // rows, rows rounded up to 16, layer widths (all % 128 == 0)
+    float slope, lambda;
+    const float *real, *fake, *alpha;
+    const float *W1, *b1, *W2, *b2, *w3, *b3;
+    float *gW1, *gb1, *gW2, *gb2, *gw3, *gb3;  // gradients: ADDED into (the optimiser's zeroed bucket)
+    float* out;       // d_loss, gp, mean D(real), mean D(fake)
+    float* ws;        // see cf_layout
+    unsigned* sync;   // [0] barrier arrivals, [1] exits, [2] error flag (sticky: host clears)
+};
+
+// workspace carve-up (floats); row blocks are [x^ | real | fake], RB rows each
+struct CfLayout {
+    size_t h1, h2, s2, s1, g, dv1, e, opart, gsq, coef, total;
+};
+static __host__ __device__ inline CfLayout cf_layout(int RB, int Din, int H1, int H2) {
+    CfLayout L;
+    size_t o = 0;
+    L.h1 = o; o += (size_t)3 * RB * H1;
+    L.h2 = o; o += (size_t)3 * RB * H2;
+    L.s2 = o; o += (size_t)3 * RB * H2;
+    L.s1 = o; o += (size_t)3 * RB * H1;
+    L.g = o; o += (size_t)RB * Din;
+    L.dv1 = o; o += (size_t)RB * H1;
+    L.e = o; o += (size_t)RB * H2;
+    L.opart = o; o += (size_t)3 * RB * (H2 / 16);
+    L.gsq = o; o += (size_t)RB * (Din / 32);
+    L.coef = o; o += 64;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ f32x4 cf_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float cf_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float cf_mask(float h, float s) { return h > 0.f ? 1.f : s; }  // lrelu'(a) from lrelu(a): same sign
+
+// one wave's K-slice of a 16x16 tile, C += A[16][klen] W[16][klen]^T; ap / wp point at this lane's row (+ 4 * (lane >> 4))
+__device__ __forceinline__ f32x4 cf_nt_partial(const float* __restrict__ ap, const float* __restrict__ wp, int klen) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int k0 = 0;
+    for (; k0 + 64 <= klen; k0 += 64) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 * u);
+            b[u] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u += 2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = cf_mfma(a[u][s], b[u][s], acc0);
+                acc1 = cf_mfma(a[u + 1][s], b[u + 1][s], acc1);
+            }
+    }
+    for (; k0 < klen; k0 += 16) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + k0), b0 = *reinterpret_cast<const f32x4*>(wp + k0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc0 = cf_mfma(a0[s], b0[s], acc0);
+    }
+    return acc0 + acc1;
+}
+// two row sets against the same weight rows (phase 1: real and fake)
+__device__ __forceinline__ void cf_nt_partial2(const float* __restrict__ ap0, const float* __restrict__ ap1,
+                                               const float* __restrict__ wp, int klen, f32x4& acc0, f32x4& acc1) {
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k0 = 0;
+    for (; k0 + 64 <= klen; k0 += 64) {
+        f32x4 a[4], c[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap0 + k0 + 16 * u);
+            c[u] = *reinterpret_cast<const f32x4*>(ap1 + k0 + 16 * u);
+            b[u] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = cf_mfma(a[u][s], b[u][s], acc0);
+                acc1 = cf_mfma(c[u][s], b[u][s], acc1);
+            }
+    }
+    for (; k0 < klen; k0 += 16) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + k0), c0 = *reinterpret_cast<const f32x4*>(ap1 + k0);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(wp + k0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc0 = cf_mfma(a0[s], b0[s], acc0);
+            acc1 = cf_mfma(c0[s], b0[s], acc1);
+        }
+    }
+}
+// C[16][32] += A[16][rlen] W[rlen][Nc]: tile e of the wave holds columns col0 + 2 * (lane & 15) + e.  ap: lane's row + 4*(lane>>4);
+// wp: W + (4 * (lane >> 4)) * Nc + col0 + 2 * (lane & 15)  (both at the start of this wave's slice)
+__device__ __forceinline__ void cf_nn_partial(const float* __restrict__ ap, const float* __restrict__ wp, int Nc, int rlen,
+                                              f32x4& acc0, f32x4& acc1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int n0 = 0;
+    for (; n0 + 32 <= rlen; n0 += 32) {
+        f32x4 a[2];
+        f32x2 b[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + n0 + 16 * u);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[u][s] = *reinterpret_cast<const f32x2*>(wp + (size_t)(n0 + 16 * u + s) * Nc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = cf_mfma(a[u][s], b[u][s][0], acc0);
+                acc1 = cf_mfma(a[u][s], b[u][s][1], acc1);
+            }
+    }
+    for (; n0 < rlen; n0 += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + n0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x2 b = *reinterpret_cast<const f32x2*>(wp + (size_t)(n0 + s) * Nc);
+            acc0 = cf_mfma(a[s], b[0], acc0);
+            acc1 = cf_mfma(a[s], b[1], acc1);
+        }
+    }
+}
+
+// sum over the 16 lanes that share lane >> 4 (the 16 columns of one output row)
+__device__ __forceinline__ float cf_rowsum16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float cf_wavesum(float v) {
+    v = cf_rowsum16(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// grid-wide barrier; `target` is this workgroup's running arrival target.  Returns false once the error flag is up.
+__device__ __forceinline__ bool cf_grid_barrier(unsigned* sync, unsigned& target, int* give_up) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += gridDim.x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int bad = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > CF_SPIN_LIMIT) {
+                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *give_up = bad;
+    }
+    __syncthreads();
+    return *give_up == 0;
+}
+
+__global__ __launch_bounds__(CF_THREADS) void critic_fused_kernel(const CriticFused p) {
+    __shared__ f32x4 part[2][(CF_WAVES - 1) * 64];
+    __shared__ float coef_s[16];
+    __shared__ int give_up;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int rr = lane & 15, kq = lane >> 4;
+    const int B = p.B, RB = p.RB, Din = p.Din, H1 = p.H1, H2 = p.H2;
+    const int RG = RB / 16;  // row groups per row block
+    const CfLayout L = cf_layout(RB, Din, H1, H2);
+    float* const h1b = p.ws + L.h1;
+    float* const h2b = p.ws + L.h2;
+    float* const s2b = p.ws + L.s2;
+    float* const s1b = p.ws + L.s1;
+    float* const gb = p.ws + L.g;
+    float* const dv1b = p.ws + L.dv1;
+    float* const eb = p.ws + L.e;
+    float* const opart = p.ws + L.opart;
+    float* const gsq = p.ws + L.gsq;
+    float* const coefb = p.ws + L.coef;
+    const float slope = p.slope, invB = 1.f / (float)B;
+    unsigned target = 0;
+    if (threadIdx.x == 0) give_up = 0;
+
+    // ---- phase 1: a1 of the real and fake rows, K = Din; three row blocks of h1 out
+    for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
+        const int g = t / (H1 / 16), c = t - g * (H1 / 16);
+        const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
+        const int arow = r0 + rr < B ? r0 + rr : B - 1;
+        f32x4 ar, af;
+        cf_nt_partial2(p.real + (size_t)arow * Din + ks * klen + kq * 4, p.fake + (size_t)arow * Din + ks * klen + kq * 4,
+                       p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen, ar, af);
+        if (ks > 0) {
+            part[0][(ks - 1) * 64 + lane] = ar;
+            part[1][(ks - 1) * 64 + lane] = af;
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) {
+                ar += part[0][(q - 1) * 64 + lane];
+                af += part[1][(q - 1) * 64 + lane];
+            }
+            const int col = col0 + rr;
+            const float bv = p.b1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = r0 + kq * 4 + r;
+                const bool ok = i < B;
+                const float al = p.alpha[ok ? i : 0];
+                const float vr = ar[r] + bv, vf = af[r] + bv;
+                const float vx = al * vr + (1.f - al) * vf;
+                h1b[(size_t)(0 * RB + i) * H1 + col] = ok ? cf_lrelu(vx, slope) : 0.f;
+                h1b[(size_t)(1 * RB + i) * H1 + col] = ok ? cf_lrelu(vr, slope) : 0.f;
+                h1b[(size_t)(2 * RB + i) * H1 + col] = ok ? cf_lrelu(vf, slope) : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 2: a2 for the 3 row blocks, K = H1; h2, S2 = [u2; da2_r; da2_f], per-tile row dots h2 . w3
+    for (int t = blockIdx.x; t < 3 * RG * (H2 / 16); t += gridDim.x) {
+        const int g = t / (H2 / 16), c = t - g * (H2 / 16);
+        const int blk = g / RG, r0 = g * 16 /* row in the stacked buffer */, col0 = c * 16, klen = H1 / CF_WAVES;
+        f32x4 acc = cf_nt_partial(h1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
+        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+            const int col = col0 + rr;
+            const float bv = p.b2[col], w3 = p.w3[col];
+            const float dout = blk == 0 ? 1.f : (blk == 1 ? -invB : invB);  // block 0: u2 = m2 (.) w3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + kq * 4 + r, i = row - blk * RB;
+                const bool ok = i < B;
+                const float h = ok ? cf_lrelu(acc[r] + bv, slope) : 0.f;
+                h2b[(size_t)row * H2 + col] = h;
+                s2b[(size_t)row * H2 + col] = ok ? dout * w3 * cf_mask(h, slope) : 0.f;
+                const float dot = cf_rowsum16(h * w3);
+                if (rr == 0) opart[(size_t)row * (H2 / 16) + c] = dot;
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 3: T = S2 W2 (NN, K = H2), S1 = m1 (.) T  (u1 for the x^ rows, da1 for real / fake)
+    for (int t = blockIdx.x; t < 3 * RG * (H1 / 32); t += gridDim.x) {
+        const int g = t / (H1 / 32), c = t - g * (H1 / 32);
+        const int r0 = g * 16, col0 = c * 32, rlen = H2 / CF_WAVES;
+        f32x4 a0, a1;
+        cf_nn_partial(s2b + (size_t)(r0 + rr) * H2 + ks * rlen + kq * 4, p.W2 + (size_t)(ks * rlen + kq * 4) * H1 + col0 + 2 * rr, H1, rlen, a0, a1);
+        if (ks > 0) {
+            part[0][(ks - 1) * 64 + lane] = a0;
+            part[1][(ks - 1) * 64 + lane] = a1;
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) {
+                a0 += part[0][(q - 1) * 64 + lane];
+                a1 += part[1][(q - 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(r0 + kq * 4 + r) * H1 + col0 + 2 * rr;
+                s1b[o] = cf_mask(h1b[o], slope) * a0[r];
+                s1b[o + 1] = cf_mask(h1b[o + 1], slope) * a1[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 4: g = u1 W1 (NN, K = H1) for the x^ rows, per-tile row sums of squares
+    for (int t = blockIdx.x; t < RG * (Din / 32); t += gridDim.x) {
+        const int g = t / (Din / 32), c = t - g * (Din / 32);
+        const int r0 = g * 16, col0 = c * 32, rlen = H1 / CF_WAVES;
+        f32x4 a0, a1;
+        cf_nn_partial(s1b + (size_t)(r0 + rr) * H1 + ks * rlen + kq * 4, p.W1 + (size_t)(ks * rlen + kq * 4) * Din + col0 + 2 * rr, Din, rlen, a0, a1);
+        if (ks > 0) {
+            part[0][(ks - 1) * 64 + lane] = a0;
+            part[1][(ks - 1) * 64 + lane] = a1;
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) {
+                a0 += part[0][(q - 1) * 64 + lane];
+                a1 += part[1][(q - 1) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + kq * 4 + r;
+                const size_t o = (size_t)row * Din + col0 + 2 * rr;
+                gb[o] = a0[r];
+                gb[o + 1] = a1[r];
+                const float sq = cf_rowsum16(a0[r] * a0[r] + a1[r] * a1[r]);
+                if (rr == 0) gsq[(size_t)row * (Din / 32) + c] = sq;
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 5: gradient norms -> coef, gp; du1 = coef (g W1^T) (NT, K = Din); dv1 = m1(x^) (.) du1
+    if (blockIdx.x == 0 && ks == 0) {  // the whole batch once: coef for phase 7, the penalty value
+        float n2 = 0.f;
+        if (lane < B)
+            for (int c = 0; c < Din / 32; ++c) n2 += gsq[(size_t)lane * (Din / 32) + c];
+        const float n = sqrtf(n2);
+        coefb[lane] = lane < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+        const float pen = cf_wavesum(lane < B ? (n - 1.f) * (n - 1.f) : 0.f);
+        if (lane == 0) p.out[1] = pen * invB;
+    }
+    for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
+        const int g = t / (H1 / 16), c = t - g * (H1 / 16);
+        const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
+        f32x4 acc = cf_nt_partial(gb + (size_t)(r0 + rr) * Din + ks * klen + kq * 4, p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen);
+        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+        if (threadIdx.x < 16) {  // this tile's 16 rows
+            const int i = r0 + threadIdx.x;
+            float n2 = 0.f;
+            for (int cc = 0; cc < Din / 32; ++cc) n2 += gsq[(size_t)i * (Din / 32) + cc];
+            const float n = sqrtf(n2);
+            coef_s[threadIdx.x] = i < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + kq * 4 + r;
+                const size_t o = (size_t)row * H1 + col0 + rr;
+                dv1b[o] = cf_mask(h1b[o], slope) * coef_s[kq * 4 + r] * acc[r];   // h1b block 0 = the x^ rows
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 6: du2 = dv1 W2^T (NT, K = H1); e = m2(x^) (.) du2
+    for (int t = blockIdx.x; t < RG * (H2 / 16); t += gridDim.x) {
+        const int g = t / (H2 / 16), c = t - g * (H2 / 16);
+        const int r0 = g * 16, col0 = c * 16, klen = H1 / CF_WAVES;
+        f32x4 acc = cf_nt_partial(dv1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
+        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(r0 + kq * 4 + r) * H2 + col0 + rr;
+                eb[o] = cf_mask(h2b[o], slope) * acc[r];
+            }
+        }
+        __syncthreads();
+    }
+    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 7: weight / bias gradients and the losses.  Wave tiles: dW1 (H1/16 x Din/64), dW2 (H2/16 x H1/64), one misc tile
+    {
+        const int nt1 = (H1 / 16) * (Din / 64), nt2 = (H2 / 16) * (H1 / 64);
+        for (int wt = blockIdx.x * CF_WAVES + ks; wt < nt1 + nt2 + 1; wt += gridDim.x * CF_WAVES) {
+            if (wt < nt1 + nt2) {
+                const bool first = wt < nt1;
+                const int w = first ? wt : wt - nt1;
+                const int N = first ? H1 : H2, K = first ? Din : H1;
+                const int ktiles = K / 64;
+                const int nt = w / ktiles, kt = w - nt * ktiles;
+                const int n0 = nt * 16, k0 = kt * 64;
+                const float* S = first ? s1b : s2b;            // A operand [3 RB][N]
+                float* dW = first ? p.gW1 : p.gW2;
+                float* db = first ? p.gb1 : p.gb2;
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float colsum = 0.f;
+                for (int blk = 0; blk < 3; ++blk) {
+                    // right operand rows of this block: x^ -> coef (.) g | dv1;  real / fake -> the inputs | h1
+                    const float* Rb = first ? (blk == 0 ? gb : (blk == 1 ? p.real : p.fake)) : (blk == 0 ? dv1b : h1b + (size_t)blk * RB * H1);
+                    for (int m0 = 0; m0 < RB; m0 += 16) {
+                        float a[4];
+                        f32x4 b[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const int m = m0 + 4 * s + kq;
+                            const int mc = m < B ? m : B - 1;
+                            const float av = S[(size_t)(blk * RB + mc) * N + n0 + rr];
+                            f32x4 bv = *reinterpret_cast<const f32x4*>(Rb + (size_t)mc * K + k0 + 4 * rr);
+                            if (first && blk == 0) bv *= coefb[mc];
+                            a[s] = m < B ? av : 0.f;
+                            b[s] = bv;
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            if (blk > 0) colsum += a[s];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] = cf_mfma(a[s], b[s][e], acc[e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* o = dW + (size_t)(n0 + kq * 4 + r) * K + k0 + 4 * rr;
+                    f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                    v += *reinterpret_cast<const f32x4*>(o);
+                    *reinterpret_cast<f32x4*>(o) = v;
+                }
+                if (kt == 0) {  // wave-uniform: bias gradient = column sums of the real / fake rows of S
+                    colsum += __shfl_xor(colsum, 16);
+                    colsum += __shfl_xor(colsum, 32);
+                    if (kq == 0) db[n0 + rr] += colsum;
+                }
+            } else {
+                // misc tile (one wave): dw3, db3, the loss values
+                for (int j = lane; j < H2; j += 64) {
+                    float s = 0.f;
+                    for (int i = 0; i < B; ++i)
+                        s += invB * (h2b[(size_t)(2 * RB + i) * H2 + j] - h2b[(size_t)(RB + i) * H2 + j]) + eb[(size_t)i * H2 + j];
+                    p.gw3[j] += s;
+                }
+                float sr = 0.f, sf = 0.f;
+                if (lane < B)
+                    for (int c = 0; c < H2 / 16; ++c) {
+                        sr += opart[(size_t)(RB + lane) * (H2 / 16) + c];
+                        sf += opart[(size_t)(2 * RB + lane) * (H2 / 16) + c];
+                    }
+                sr = cf_wavesum(sr);
+                sf = cf_wavesum(sf);
+                if (lane == 0) {
+                    const float b3 = p.b3[0];
+                    const float mr = sr * invB + b3, mf = sf * invB + b3;
+                    p.out[2] = mr;
+                    p.out[3] = mf;
+                    p.out[0] = -mr + mf + p.lambda * p.out[1];
+                    p.gb3[0] += 0.f;  // sum of do = -1 + 1: the reference's gradient of b3 is exactly zero as well
+                }
+            }
+        }
+    }
+    // ---- leave: the last workgroup out re-arms the barrier for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+MIGAN_API int migan_critic_fused_ok(int B, int Din, int H1, int H2) {
+    return B >= 1 && B <= 64 && Din % 128 == 0 && H1 % 128 == 0 && H2 % 128 == 0 && Din >= 128 && H1 >= 128 && H2 >= 128;
+}
+// bytes of `ws` (float scratch, any contents) - `sync` is 4 unsigned ints, zeroed ONCE by the caller
+MIGAN_API size_t migan_critic_fused_workspace(int B, int Din, int H1, int H2) {
+    if (!migan_critic_fused_ok(B, Din, H1, H2)) return 0;
+    return cf_layout((B + 15) / 16 * 16, Din, H1, H2).total * sizeof(float);
+}
+// One critic iteration's forward + backward (see the file header).  Gradients are ADDED into gw1..gb3.  out[4] = d_loss, gp,
+// mean D(real), mean D(fake).  grid = workgroups of the persistent launch (all must be resident at once: <= 256; 0 = default).
+// sync[2] != 0 after the launch: the grid barrier timed out (results invalid).
+MIGAN_API int migan_critic_fused(const float* real, const float* fake, const float* alpha, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, const float* w3, const float* b3, float* gw1, float* gb1,
+                                 float* gw2, float* gb2, float* gw3, float* gb3, float* out, float* ws, size_t ws_bytes,
+                                 unsigned* sync, int B, int Din, int H1, int H2, float slope, float lambda, int grid, void* stream) {
+    if (!migan_critic_fused_ok(B, Din, H1, H2) || ws_bytes < migan_critic_fused_workspace(B, Din, H1, H2)) return (int)hipErrorInvalidValue;
+    CriticFused p;
+    p.B = B; p.RB = (B + 15) / 16 * 16; p.Din = Din; p.H1 = H1; p.H2 = H2;
+    p.slope = slope; p.lambda = lambda;
+    p.real = real; p.fake = fake; p.alpha = alpha;
+    p.W1 = w1; p.b1 = b1; p.W2 = w2; p.b2 = b2; p.w3 = w3; p.b3 = b3;
+    p.gW1 = gw1; p.gb1 = gb1; p.gW2 = gw2; p.gb2 = gb2; p.gw3 = gw3; p.gb3 = gb3;
+    p.out = out; p.ws = ws; p.sync = sync;
+    static const int grid_env = getenv("MIGAN_K7_GRID") ? atoi(getenv("MIGAN_K7_GRID")) : 0;
+    int g = grid > 0 ? grid : (grid_env > 0 ? grid_env : 128);
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(critic_fused_kernel, dim3(g), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -161,6 +161,97 @@ def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
                            dp=dp or LocalStepper())
 
 
+# K7: the critic half of the iteration (D(real), D(fake), gradient penalty with its double backward, d_loss.backward()) as ONE
+# persistent launch, csrc/critic_fused.hip.  MIGAN_K7=0 keeps the op-by-op path (autograd over the skinny GEMM Functions).
+# The persistent kernel synchronises its workgroups through a grid-wide barrier, so it is taken into service per critic only
+# after ONE iteration in which both paths ran and agreed (`verify`): the first critic iteration of a state is always op-by-op.
+_K7 = os.environ.get("MIGAN_K7", "1") == "1"
+
+
+class _CriticFusedPlan:
+    """The critic of wgan_gp.py:68-83 - Sequential(Linear, LeakyReLU, Linear, LeakyReLU, Linear(., 1)) behind a flatten - as the
+    operands of migan_critic_fused; `ok = False` when the model, the batch or the optimiser layout is anything else."""
+
+    def __init__(self, s, real):
+        from ._lib import lib
+
+        self.ok = self.verified = False
+        seq = getattr(s.D, "model", None)
+        mods = list(seq) if isinstance(seq, torch.nn.Sequential) else []
+        if len(mods) != 5 or not all(isinstance(mods[k], torch.nn.Linear) for k in (0, 2, 4)) \
+                or not all(isinstance(mods[k], torch.nn.LeakyReLU) for k in (1, 3)):
+            return
+        l1, a1, l2, a2, l3 = mods
+        if a1.negative_slope != a2.negative_slope or l3.out_features != 1 or any(l.bias is None for l in (l1, l2, l3)) \
+                or l2.in_features != l1.out_features or l3.in_features != l2.out_features:
+            return
+        B = real.shape[0]
+        if real[0].numel() != l1.in_features or not lib.migan_critic_fused_ok(B, l1.in_features, l1.out_features, l2.out_features):
+            return
+        self.B, self.dims, self.slope = B, (l1.in_features, l1.out_features, l2.out_features), float(a1.negative_slope)
+        self.params = [l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias]
+        if set(map(id, self.params)) != set(map(id, s.opt_D.params)):
+            return
+        dev = real.device
+        self.lambda_gp = float(s.lambda_gp)
+        self.ws_bytes = lib.migan_critic_fused_workspace(B, *self.dims)
+        self.ws = torch.empty(self.ws_bytes // 4, device=dev, dtype=torch.float32)
+        self.sync = torch.zeros(4, device=dev, dtype=torch.int32)
+        self.out = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.ok = True
+
+    def usable(self, real, fake):
+        return self.ok and real.shape[0] == self.B and real.is_contiguous() and fake.is_contiguous() \
+            and real.dtype == fake.dtype == torch.float32
+
+    def run(self, real, fake, alpha, grads):
+        """One launch: the gradient of d_loss is ADDED into `grads` (six contiguous tensors); -> (d_loss, gp)."""
+        from ._lib import check, lib
+
+        a = alpha.reshape(self.B).contiguous()
+        w = [p.detach() for p in self.params]
+        check(lib.migan_critic_fused(real.data_ptr(), fake.data_ptr(), a.data_ptr(), *[t.data_ptr() for t in w],
+                                     *[g.data_ptr() for g in grads], self.out.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                     self.sync.data_ptr(), self.B, *self.dims, self.slope, self.lambda_gp, 0,
+                                     torch.cuda.current_stream().cuda_stream), "critic_fused")
+        o = self.out.clone()   # the kernel's output slot is overwritten by the next iteration; callers keep their losses
+        return o[0], o[1]
+
+    def verify(self, real, fake, alpha, d_loss, gp):
+        """After an op-by-op iteration whose gradients are in the bucket: the fused launch into scratch gradients must give the
+        same losses and gradients (and its grid barrier must not have timed out).  One host sync, once per critic."""
+        import warnings
+
+        scratch = [torch.zeros_like(p) for p in self.params]
+        fd, fg = self.run(real, fake, alpha, scratch)
+        torch.cuda.synchronize()
+        why = None
+        if int(self.sync[2]) != 0:
+            why = "its grid barrier timed out (the launch was not co-resident)"
+            self.sync.zero_()
+        else:
+            for name, got, want in (("d_loss", fd, d_loss), ("gp", fg, gp)):
+                if not abs(float(got) - float(want.detach())) <= 1e-4 * max(1.0, abs(float(want.detach()))):
+                    why = "%s %.7g vs %.7g op by op" % (name, float(got), float(want.detach()))
+            for p, g in zip(self.params, scratch):
+                ref = p.grad.detach()
+                err = float((g - ref).norm()) / max(float(ref.norm()), 1e-12)
+                if float(ref.norm()) > 0 and not err <= 1e-3:
+                    why = why or "gradient of a %s tensor off by %.2e" % (tuple(p.shape), err)
+        if why is None:
+            self.verified = True
+        else:
+            self.ok = False
+            warnings.warn("pytorch_gan_amd: the fused critic kernel is NOT used for this critic: " + why)
+
+
+def _critic_plan(s, real, fake):
+    plan = getattr(s, "_k7_plan", None)
+    if plan is None or (plan.ok and plan.B != real.shape[0]):
+        plan = s._k7_plan = _CriticFusedPlan(s, real)
+    return plan if plan.usable(real, fake) else None
+
+
 @_scoped
 def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0."""
@@ -171,12 +262,21 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
             fake_imgs = s.G(z)
     else:
         fake_imgs = s.G(z)
-    real_v = s.D(real_imgs)
-    fake_v = s.D(fake_imgs)
-    gp = compute_gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
-    # d_loss = -mean(real) + mean(fake) + lambda_gp * gp
-    d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
-    d_loss.backward()
+    plan = _critic_plan(s, real_imgs, fake_imgs) if (_K7 and s.skip) else None
+    if plan is not None and alpha is None:  # the host draw of wgan_gp.py:122, where the reference makes it
+        alpha = _dev(np.random.random((real_imgs.shape[0], 1, 1, 1)), real_imgs.device)
+    grads = [p.grad for p in plan.params] if plan is not None else []
+    if plan is not None and plan.verified and all(g is not None and g.is_contiguous() for g in grads):
+        d_loss, gp = plan.run(real_imgs, fake_imgs, alpha, grads)
+    else:
+        real_v = s.D(real_imgs)
+        fake_v = s.D(fake_imgs)
+        gp = compute_gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
+        # d_loss = -mean(real) + mean(fake) + lambda_gp * gp
+        d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
+        d_loss.backward()
+        if plan is not None and not plan.verified and not torch.cuda.is_current_stream_capturing():
+            plan.verify(real_imgs, fake_imgs, alpha, d_loss, gp)
     s.dp.step(s.opt_D)
     s.opt_G.zero_grad()
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}

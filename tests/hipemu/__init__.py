@@ -8,6 +8,9 @@ Only tests import this package; the product (pytorch-gan_amd/) never does, and h
 import ctypes
 import os
 
+# persistent kernels run one OS thread per workgroup in the model: keep their grids small (read once by the library)
+os.environ.setdefault("MIGAN_K7_GRID", "8")
+
 _LIB = None
 
 
@@ -35,6 +38,8 @@ def load(only=None):
     lib.hipemu_set_coresident.argtypes = [ctypes.c_int]
     lib.hipemu_set_threads.argtypes = [ctypes.c_int]
     lib.hipemu_launch_count.argtypes = [ctypes.c_char_p]
+    lib.hipemu_add_coresident_kernel.argtypes = [ctypes.c_char_p]
+    lib.hipemu_add_coresident_kernel(b"critic_fused_kernel")   # grid-wide barriers: all workgroups alive at once
     lib.hipemu_launch_count.restype = ctypes.c_long
     if only is None:
         _LIB = lib

@@ -77,6 +77,7 @@ static std::string g_msg;
 static std::atomic<int> g_coresident{0};
 static std::atomic<int> g_threads{0};
 static std::atomic<bool> g_abort{false};
+static std::atomic<bool> g_cores_now{false};  // the launch in flight runs one OS thread per workgroup
 
 void note_error(const char* what) {
     std::lock_guard<std::mutex> lk(g_msg_mu);
@@ -215,7 +216,7 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
             // no barrier released, no collective completed, no thread finished: a deadlock unless the workgroup waits for
             // another workgroup (co-resident mode) - there, give it wall-clock time before giving up
             const double idle_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_idle).count();
-            if (!g_coresident.load() || idle_s > 20.0 || g_abort.load()) {
+            if (!g_cores_now.load() || idle_s > 20.0 || g_abort.load()) {
                 char msg[256];
                 snprintf(msg, sizeof msg, "hipemu: deadlock in workgroup (%u,%u,%u): %d live threads, %d at the barrier", bid.x,
                          bid.y, bid.z, w.live, w.bar_arrived);
@@ -231,13 +232,14 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
                 }
                 return;  // fibers stuck outside a synchronisation point are abandoned
             }
-            if (g_coresident.load()) std::this_thread::yield();
+            if (g_cores_now.load()) std::this_thread::yield();
         }
     }
     cur = nullptr;
 }
 
 static std::mutex g_count_mu;
+static std::vector<std::string> g_cores_kernels;  // kernels with grid-wide waits: every workgroup on its own OS thread
 static std::vector<std::pair<std::string, long>> g_counts;  // launches per kernel expression (tests assert which kernels ran)
 
 int launch_impl(const char* kernel, U3 grid, U3 block, size_t lds, const std::function<void()>& body) {
@@ -262,7 +264,14 @@ int launch_impl(const char* kernel, U3 grid, U3 block, size_t lds, const std::fu
     int nthreads = g_threads.load();
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
     if (nthreads <= 0) nthreads = 4;
-    if (g_coresident.load()) {
+    bool cores = g_coresident.load() != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_count_mu);
+        for (auto& k : g_cores_kernels)
+            if (strstr(kernel, k.c_str())) cores = true;
+    }
+    g_cores_now.store(cores);
+    if (cores) {
         if (nb > 512) {
             note_error("hipemu: co-resident launch of more than 512 workgroups");
             return hipErrorInvalidValue;
@@ -316,6 +325,10 @@ extern "C" __attribute__((visibility("default"))) void hipemu_print_counts() {
 extern "C" __attribute__((visibility("default"))) void hipemu_reset_counts() {
     std::lock_guard<std::mutex> lk(hipemu::g_count_mu);
     hipemu::g_counts.clear();
+}
+extern "C" __attribute__((visibility("default"))) void hipemu_add_coresident_kernel(const char* substr) {
+    std::lock_guard<std::mutex> lk(hipemu::g_count_mu);
+    hipemu::g_cores_kernels.emplace_back(substr);
 }
 extern "C" __attribute__((visibility("default"))) void hipemu_set_coresident(int on) { hipemu::g_coresident.store(on); }
 extern "C" __attribute__((visibility("default"))) void hipemu_set_threads(int n) { hipemu::g_threads.store(n); }

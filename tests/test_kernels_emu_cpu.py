@@ -160,6 +160,61 @@ def test_weight_packs(emu, shape, perm):
     assert emu.hipemu_launch_count(b"pack_transpose_kernel") == (1 if tiled else 0)
 
 
+def _critic_reference(real, fake, alpha, params, lam, slope):
+    """wgan_gp.py:68-83,119-138,160-176 with torch autograd (double backward through autograd.grad(create_graph=True))."""
+    ps = [t.clone().requires_grad_(True) for t in params]
+
+    def D(x):
+        h = TF.leaky_relu(x @ ps[0].t() + ps[1], slope)
+        h = TF.leaky_relu(h @ ps[2].t() + ps[3], slope)
+        return h @ ps[4].t() + ps[5]
+
+    rv, fv = D(real), D(fake)
+    xh = (alpha * real + (1 - alpha) * fake).requires_grad_(True)
+    dv = D(xh)
+    g = torch.autograd.grad(dv, xh, torch.ones_like(dv), create_graph=True, retain_graph=True)[0]
+    gp = ((g.norm(2, dim=1) - 1) ** 2).mean()
+    d_loss = -rv.mean() + fv.mean() + lam * gp
+    d_loss.backward()
+    return [float(d_loss), float(gp), float(rv.mean()), float(fv.mean())], [p.grad for p in ps]
+
+
+@pytest.mark.parametrize("B,dims,grid", [(64, (1024, 512, 256), 8), (8, (1024, 512, 256), 3), (33, (256, 128, 128), 1), (1, (128, 256, 128), 5)])
+def test_persistent_critic_kernel_against_autograd(emu, B, dims, grid):
+    """K7 (csrc/critic_fused.hip) through the C ABI: seven phases, six grid-wide barriers, workgroups on their own OS threads;
+    losses and all six parameter gradients against torch's double backward; launched three times (the barrier re-arms itself,
+    gradients accumulate)."""
+    Din, H1, H2 = dims
+    g = torch.Generator().manual_seed(B)
+    real = torch.rand(B, Din, generator=g) * 2 - 1
+    fake = torch.tanh(torch.randn(B, Din, generator=g))
+    alpha = torch.rand(B, 1, generator=g)
+
+    def lin(o, i):
+        k = 1 / i ** 0.5
+        return (torch.rand(o, i, generator=g) * 2 - 1) * k, (torch.rand(o, generator=g) * 2 - 1) * k
+
+    params = [*lin(H1, Din), *lin(H2, H1), *lin(1, H2)]
+    want, gref = _critic_reference(real, fake, alpha, params, 10.0, 0.2)
+    grads = [torch.zeros_like(t) for t in params]
+    out = torch.zeros(4)
+    wsb = emu.migan_critic_fused_workspace(B, Din, H1, H2)
+    ws = torch.full((wsb // 4,), float("nan"))
+    sync = torch.zeros(4, dtype=torch.int32)
+    for rep in range(3):
+        rc = emu.migan_critic_fused(_ptr(real), _ptr(fake), _ptr(alpha), *[_ptr(t) for t in params], *[_ptr(t) for t in grads],
+                                    _ptr(out), _ptr(ws), wsb, _ptr(sync), B, Din, H1, H2, 0.2, 10.0, grid, None)
+        assert rc == 0, emu.hipemu_last_message()
+        assert sync.tolist() == [0, 0, 0, 0]
+        for a, b in zip(out.tolist(), want):
+            assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (out.tolist(), want)
+        for got, ref in zip(grads, gref):
+            if float(ref.norm()) > 0:
+                assert _rel(got, ref * (rep + 1)) <= 3e-6
+            else:
+                assert float(got.abs().max()) == 0.0     # b3: -1 + 1
+
+
 def _run_gpu_test_body(module_name, test_name, *args):
     """Run the body of a `-m gpu` parity test on CPU tensors: its device is "cpu", its kernels are the execution model."""
     import importlib
@@ -184,17 +239,20 @@ def _run_gpu_test_body(module_name, test_name, *args):
 STEP_BODIES = [
     ("test_dcgan_steps", (True,)),            # dcgan.py:143-183, 3 steps: paired D pass, chained BatchNorm statistics, dropout masks
     ("test_wgan_gp_steps", (False,)),         # wgan_gp.py:119-193, 6 critic iterations: double backward through the skinny GEMMs
+    ("test_wgan_gp_steps", (True,)),          # ... and with the persistent critic kernel (K7) verified and in service
     ("test_dragan_steps", ()),                # dragan.py:176-217: conv-critic gradient penalty
     ("test_srgan_step", ()),                  # srgan.py:97-145: PixelShuffle epilogue, VGG features, Toeplitz 9x9
     ("test_pix2pix_step", ()),                # pix2pix.py:123-172 at 256x256: split-K, ConvTranspose, PatchGAN head, 4-8 M-element weights
 ]
 
 
-@pytest.mark.parametrize("name,args", STEP_BODIES, ids=[n for n, _ in STEP_BODIES])
+@pytest.mark.parametrize("name,args", STEP_BODIES, ids=["%s%s" % (n, list(a) if a else "") for n, a in STEP_BODIES])
 def test_step_parity_bodies_on_the_execution_model(name, args):
     """The training-step parity tests of test_steps_gpu.py, unchanged, against the oracle: losses of every step, weights after
     Adam, BatchNorm buffers - computed by the HIP kernels' source running on the host."""
     lib = _run_gpu_test_body("test_steps_gpu", name, *args)
+    if name == "test_wgan_gp_steps":  # first iteration op by op + the verification launch, then five fused iterations
+        assert lib.hipemu_launch_count(b"critic_fused_kernel") == (6 if args[0] else 0)
     if name == "test_pix2pix_step":   # the kernels this workload is there for
         for sym in (b"thin_conv_wave_kernel", b"wgrad_reduce_tr_kernel", b"pack_transpose_kernel", b"true>"):
             assert lib.hipemu_launch_count(sym) > 0, sym

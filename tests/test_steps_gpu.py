@@ -166,6 +166,36 @@ def test_wgan_gp_steps(skip_dead):
     assert nb == nc
 
 
+def test_persistent_critic_kernel_in_service():
+    """K7 (csrc/critic_fused.hip): at the BASELINE batch the critic half of the iteration is ONE persistent
+    launch.  The first iteration of a state runs op by op and verifies the fused kernel against it (losses, six gradients, no
+    barrier time-out); from the second on the kernel is in service.  Both kinds of iteration against the oracle, and the two
+    HIP paths (MIGAN_K7 on / off semantics: a second state that never leaves the op-by-op path) against each other."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_wgan_gp(32)
+    s_k7 = steps.make_wgan_gp_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=True)
+    s_op = steps.make_wgan_gp_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=False)   # never fused
+    _seed(4)
+    for i in range(4):
+        real = torch.rand(64, 1, 32, 32) * 2 - 1
+        z = torch.tensor(np.random.normal(0, 1, (64, 100)), dtype=torch.float32)
+        alpha = torch.tensor(np.random.random((64, 1, 1, 1)), dtype=torch.float32)
+        o_c = S.wgan_gp_step(s_cpu, real, i, z, alpha)
+        o_k = steps.wgan_gp_step(s_k7, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+        o_o = steps.wgan_gp_step(s_op, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+        for k in ("d_loss", "gp"):
+            _loss_close(o_k[k], o_c[k], "%s iter %d (fused from iter 1)" % (k, i))
+            _loss_close(o_k[k], o_o[k], "%s iter %d fused vs op by op" % (k, i), 2e-5)
+        plan = s_k7._k7_plan
+        assert plan.ok and plan.verified, "the persistent critic kernel was not taken into service"
+    _params_close(s_k7.D, s_cpu.D, 4, "critic (K7)")
+    for p, q in zip(s_k7.D.parameters(), s_op.D.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2.05 * 4 * LR
+
+
 def test_wgan_gp_steps_vs_reference_trace(golden_dir):
     """Six critic iterations (one generator update) of wgan_gp.py:146-193 on the HIP path against the trace and the final
     critic weights recorded from the REAL reference modules (tests/golden/wgan_gp_32_loop.npz)."""
