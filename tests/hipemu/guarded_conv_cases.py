@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE: the conv cases of the GPU suite on the host execution model with EVERY operand (inputs, packed weights,
+bias, outputs, workspaces) placed against an inaccessible page: a kernel that reads or writes past the end of a tensor - which a
+GPU run never notices, the neighbouring allocation is mapped - dies with SIGSEGV here.  Run as a subprocess by
+tests/test_kernels_emu_cpu.py::test_no_conv_kernel_leaves_its_tensors (prints the case before running it)."""
+import ctypes, mmap, sys, re
+import os
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import numpy as np, torch
+import hipemu
+emu = hipemu.load()
+libc = ctypes.CDLL(None)
+libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+PAGE = 4096
+keep = []
+def guarded(t):
+    """copy of tensor t whose last byte is (up to 15 B before) the last byte in front of a PROT_NONE page, and whose first byte sits right after one (when size % 4096 == 0 this is exact)"""
+    nbytes = t.numel() * t.element_size()
+    body = (nbytes + PAGE - 1) // PAGE * PAGE
+    m = mmap.mmap(-1, body + 2 * PAGE)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    assert libc.mprotect(base, PAGE, 0) == 0 and libc.mprotect(base + PAGE + body, PAGE, 0) == 0
+    start = base + PAGE + body - (nbytes + 15) // 16 * 16
+    arr = np.ctypeslib.as_array((ctypes.c_float * t.numel()).from_address(start)) if t.dtype == torch.float32 else None
+    g = torch.from_numpy(arr).view(t.shape)
+    g.copy_(t)
+    keep.append(m)
+    return g
+import test_kernels_emu_cpu as K
+def _conv_case_guarded(case):
+    N, Ci, H, W, Co, k, stride, pads, gather, act, bias = case
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Ci, H, W, generator=g); w = torch.randn(Co, Ci, k, k, generator=g) * 0.2
+    b = torch.randn(Co, generator=g) if bias else None
+    y_ref = TF.conv2d(K._gather_ref(x, pads, gather), w, b, stride)
+    Ho, Wo = y_ref.shape[2:]
+    P = K._ptr
+    sk = guarded(torch.zeros(emu.migan_conv_splitk_workspace() // 4))
+    xn = guarded(x.permute(0, 2, 3, 1).contiguous()); wo = guarded(w.permute(0, 2, 3, 1).contiguous()); wi = guarded(w.permute(1, 2, 3, 0).contiguous())
+    bg = guarded(b) if bias else None
+    y = guarded(torch.empty(N, Ho, Wo, Co))
+    rc = emu.migan_conv2d_fwd_ws(P(xn), P(wo), P(bg), None, P(y), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, act, 0.2, P(sk), sk.numel() * 4, None)
+    assert rc == 0
+    if gather == 0:
+        gy = guarded(torch.randn(N, Ho, Wo, Co, generator=g))
+        if pads[0] == pads[2] and pads[1] == pads[3]:
+            dx = guarded(torch.empty(N, H, W, Ci))
+            assert emu.migan_conv2d_dgrad_ws(P(gy), P(wi), None, P(dx), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], 0, 0.0, P(sk), sk.numel() * 4, None) == 0
+        wsb = emu.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
+        ws = guarded(torch.empty(max(wsb // 4, 4))); dw = guarded(torch.empty(Co, Ci, k, k))
+        assert emu.migan_conv2d_wgrad(P(xn), P(gy), P(dw), P(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, 0, None, 0, None, 0, None) == 0
+cases = K._gpu_conv_cases() + K.KTAIL_CASES
+i0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for i, c in enumerate(cases):
+    if i < i0: continue
+    print(i, c, flush=True)
+    _conv_case_guarded(c)
+    keep.clear()
+print("ALL OK")

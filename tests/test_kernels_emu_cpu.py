@@ -125,6 +125,16 @@ def test_lds_dma_channel_tail_stays_inside_the_tensors(emu, case):
         assert err <= 1e-5, (case, what, err)
 
 
+def test_no_conv_kernel_leaves_its_tensors(emu):
+    """Every operand of every conv case ends at an inaccessible page (tests/hipemu/guarded_conv_cases.py): an over-read or
+    over-write past a tensor is a SIGSEGV of the child, with the case it was running as the last line of its output."""
+    import subprocess
+
+    script = os.path.join(os.path.dirname(os.path.abspath(hipemu.__file__)), "guarded_conv_cases.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_splitk_tickets_and_determinism(emu):
     """pix2pix/models.py:66 geometry (4 output pixels, K = 8192): slices add in slice order whoever arrives last - with the
     model's workgroups on 1, 3 and 8 OS threads (different arrival orders) the result is bit-identical."""
