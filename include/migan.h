@@ -97,6 +97,17 @@ int migan_critic_fused(const float* real, const float* fake, const float* alpha,
                        float* gb2, float* gw3, float* gb3, float* out, float* ws, size_t ws_bytes, unsigned* sync, int B,
                        int Din, int H1, int H2, float slope, float lambda, int grid, void* stream);
 
+/* Forward of an MLP generator at <= 64 rows in ONE persistent launch (csrc/mlp_fused.hip): replaces, for the no_grad
+ * `fake_imgs = generator(z)` of wgan_gp.py:163 (Generator wgan_gp.py:42-65; gan.py:38-61), 5 x Linear + 3 x BatchNorm1d(out, 0.8)
+ * (training mode: batch statistics, running statistics and num_batches_tracked updated) + LeakyReLU / Tanh = 14 launches.
+ * Host arrays: dims[4*l] = {K, N, has_bn, act code}, fpar[3*l] = {slope, eps, momentum}, ptrs[7*l] = DEVICE pointers {W [N][K], b,
+ * gamma, beta, running_mean, running_var, num_batches_tracked (int64)}, NULL where absent.  B <= 64, K % 4 == 0, N % 16 == 0,
+ * <= 8 layers.  ws / sync / grid as for migan_critic_fused (sync[2] != 0: the grid barrier gave up, never a hang). */
+int migan_mlp_fused_ok(int B, int nlayers, const int* dims);
+size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims);
+int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar, void* const* ptrs,
+                        float* ws, size_t ws_bytes, unsigned* sync, int grid, void* stream);
+
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];
  * w_ihwo [Ci][R][S][Co]; dx [N][Hi][Wi][Ci] = act(sum + bias) (bias/act used by the ConvTranspose role).

@@ -245,6 +245,122 @@ class _CriticFusedPlan:
             warnings.warn("pytorch_gan_amd: the fused critic kernel is NOT used for this critic: " + why)
 
 
+class _GeneratorFusedPlan:
+    """The MLP generator of wgan_gp.py:42-65 - Sequential of Linear [-> BatchNorm1d] [-> LeakyReLU | Tanh] groups behind a view to
+    img_shape - as the operands of migan_mlp_fused_fwd (one persistent launch for the no_grad forward of a critic iteration)."""
+
+    def __init__(self, G, z):
+        import ctypes
+
+        from ._lib import lib
+
+        self.ok = self.verified = False
+        seq, shape = getattr(G, "model", None), getattr(G, "img_shape", None)
+        if not isinstance(seq, torch.nn.Sequential) or shape is None or z.dim() != 2:
+            return
+        mods, groups, i = list(seq), [], 0
+        while i < len(mods):
+            if not isinstance(mods[i], torch.nn.Linear):
+                return
+            lin, bn, act, slope = mods[i], None, F.ACT_NONE, 0.0
+            i += 1
+            if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm1d):
+                bn = mods[i]
+                i += 1
+                if bn.momentum is None or not bn.track_running_stats:   # cumulative averaging / no buffers: not on the reference path
+                    return
+            if i < len(mods) and isinstance(mods[i], torch.nn.LeakyReLU):
+                act, slope = F.ACT_LRELU, float(mods[i].negative_slope)
+                i += 1
+            elif i < len(mods) and isinstance(mods[i], torch.nn.Tanh):
+                act = F.ACT_TANH
+                i += 1
+            groups.append((lin, bn, act, slope))
+        B, n = z.shape[0], len(groups)
+        if not groups or groups[0][0].in_features != z.shape[1] or int(np.prod(shape)) != groups[-1][0].out_features:
+            return
+        self.dims = (ctypes.c_int * (4 * n))(*[v for (l, bn, a, _) in groups for v in (l.in_features, l.out_features, int(bn is not None), a)])
+        self.fpar = (ctypes.c_float * (3 * n))(*[v for (_, bn, _, sl) in groups for v in (sl, bn.eps if bn else 0.0, bn.momentum if bn else 0.0)])
+        if not lib.migan_mlp_fused_ok(B, n, self.dims):
+            return
+        self.B, self.n, self.groups, self.shape, self.G = B, n, groups, tuple(shape), G
+        self.ws_bytes = lib.migan_mlp_fused_workspace(B, n, self.dims)
+        self.ws = torch.empty(self.ws_bytes // 4, device=z.device, dtype=torch.float32)
+        self.sync = torch.zeros(4, device=z.device, dtype=torch.int32)
+        self.ok = True
+
+    def tensors(self, buffers=None):
+        """Device tensors in the order of the C entry's pointer table; `buffers` replaces the BatchNorm buffers (verification)."""
+        out, k = [], 0
+        for lin, bn, _, _ in self.groups:
+            out += [lin.weight, lin.bias]
+            if bn is None:
+                out += [None] * 5
+            else:
+                bufs = buffers[k:k + 3] if buffers is not None else [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+                k += 3
+                out += [bn.weight, bn.bias] + list(bufs)
+        return out
+
+    def usable(self, z):
+        return self.ok and self.G.training and z.shape[0] == self.B and z.is_contiguous() and z.dtype == torch.float32
+
+    def run(self, z, buffers=None):
+        import ctypes
+
+        from ._lib import check, lib
+
+        ts = self.tensors(buffers)
+        ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32)
+        check(lib.migan_mlp_fused_fwd(z.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.ws.data_ptr(),
+                                      self.ws_bytes, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+        return y.view(self.B, *self.shape)
+
+    def verify(self, z):
+        """First use: the op-by-op forward (its result and side effects are the ones kept) against the fused launch on COPIES of
+        the BatchNorm buffers taken before it.  One host sync, once per generator."""
+        import warnings
+
+        bns = [bn for _, bn, _, _ in self.groups if bn is not None]
+        copies = [b.clone() for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+        want = self.G(z)
+        got = self.run(z, copies)
+        torch.cuda.synchronize()
+        why = None
+        if int(self.sync[2]) != 0:
+            why = "its grid barrier timed out (the launch was not co-resident)"
+            self.sync.zero_()
+        elif not float((got - want).norm()) <= 1e-4 * max(float(want.norm()), 1e-12):
+            why = "output off by %.2e" % (float((got - want).norm()) / max(float(want.norm()), 1e-12))
+        else:
+            mine = [b for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+            for a, b in zip(copies, mine):
+                if not torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6):
+                    why = "BatchNorm1d buffers differ"
+        if why is None:
+            self.verified = True
+        else:
+            self.ok = False
+            warnings.warn("pytorch_gan_amd: the fused generator forward is NOT used for this generator: " + why)
+        return want
+
+
+def _generator_nograd(s, z):
+    """fake_imgs = generator(z) without a graph (wgan_gp.py:163 when its gradients are dead): one persistent launch when the
+    generator is the MLP of wgan_gp.py:42-65 (verified once against the op-by-op forward), else the modules."""
+    if _K7:
+        plan = getattr(s, "_k7_gen_plan", None)
+        if plan is None or (plan.ok and plan.B != z.shape[0]):
+            plan = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
+        if plan.usable(z):
+            if plan.verified:
+                return plan.run(z)
+            if not torch.cuda.is_current_stream_capturing():
+                return plan.verify(z)
+    return s.G(z)
+
+
 def _critic_plan(s, real, fake):
     plan = getattr(s, "_k7_plan", None)
     if plan is None or (plan.ok and plan.B != real.shape[0]):
@@ -259,7 +375,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     s.opt_D.zero_grad()
     if s.skip:
         with torch.no_grad():  # G grads from d_loss are discarded at wgan_gp.py:176
-            fake_imgs = s.G(z)
+            fake_imgs = _generator_nograd(s, z)
     else:
         fake_imgs = s.G(z)
     plan = _critic_plan(s, real_imgs, fake_imgs) if (_K7 and s.skip) else None

@@ -225,6 +225,62 @@ def test_persistent_critic_kernel_against_autograd(emu, B, dims, grid):
                 assert float(got.abs().max()) == 0.0     # b3: -1 + 1
 
 
+@pytest.mark.parametrize("B,img_shape,grid", [(64, (1, 32, 32), 8), (8, (1, 32, 32), 3), (33, (1, 28, 28), 1), (2, (3, 16, 16), 5)])
+def test_persistent_generator_forward_against_torch(emu, B, img_shape, grid):
+    """csrc/mlp_fused.hip through the C ABI against the oracle's MlpGenerator in training mode: output, BatchNorm1d running
+    statistics (momentum, unbiased variance) and num_batches_tracked; K = 100 (a K tail), N = 784 (49 column tiles)."""
+    import copy
+    import ctypes
+
+    from oracle import reference_models as M
+
+    torch.manual_seed(B)
+    G = M.MlpGenerator(img_shape)
+    G.train()
+    for m in G.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    G2 = copy.deepcopy(G)
+    z = torch.randn(B, 100)
+    with torch.no_grad():
+        want = G(z).view(B, -1)
+    mods, groups, i = list(G2.model), [], 0
+    while i < len(mods):
+        lin, bn, act, slope = mods[i], None, 0, 0.0
+        i += 1
+        if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm1d):
+            bn = mods[i]
+            i += 1
+        if i < len(mods) and isinstance(mods[i], torch.nn.LeakyReLU):
+            act, slope = 1, mods[i].negative_slope
+            i += 1
+        elif i < len(mods) and isinstance(mods[i], torch.nn.Tanh):
+            act = 3
+            i += 1
+        groups.append((lin, bn, act, slope))
+    n = len(groups)
+    dims = (ctypes.c_int * (4 * n))(*[v for (l, bn, a, s) in groups for v in (l.in_features, l.out_features, int(bn is not None), a)])
+    fpar = (ctypes.c_float * (3 * n))(*[v for (l, bn, a, s) in groups for v in (s, bn.eps if bn else 0.0, bn.momentum if bn else 0.0)])
+    plist = []
+    for l, bn, a, s in groups:
+        plist += [_ptr(l.weight), _ptr(l.bias)]
+        plist += [_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)] if bn else [None] * 5
+    ptrs = (ctypes.c_void_p * len(plist))(*plist)
+    assert emu.migan_mlp_fused_ok(B, n, dims)
+    wsb = emu.migan_mlp_fused_workspace(B, n, dims)
+    ws = torch.full((wsb // 4,), float("nan"))
+    sync = torch.zeros(4, dtype=torch.int32)
+    y = torch.empty(B, groups[-1][0].out_features)
+    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
+    assert sync.tolist() == [0, 0, 0, 0]
+    assert _rel(y, want) <= 3e-6
+    for a, b in zip(G2.buffers(), G.buffers()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
+
+
 def _run_gpu_test_body(module_name, test_name, *args):
     """Run the body of a `-m gpu` parity test on CPU tensors: its device is "cpu", its kernels are the execution model."""
     import importlib
@@ -263,6 +319,7 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
     lib = _run_gpu_test_body("test_steps_gpu", name, *args)
     if name == "test_wgan_gp_steps":  # first iteration op by op + the verification launch, then five fused iterations
         assert lib.hipemu_launch_count(b"critic_fused_kernel") == (6 if args[0] else 0)
+        assert lib.hipemu_launch_count(b"mlp_fused_fwd_kernel") == (6 if args[0] else 0)
     if name == "test_pix2pix_step":   # the kernels this workload is there for
         for sym in (b"thin_conv_wave_kernel", b"wgrad_reduce_tr_kernel", b"pack_transpose_kernel", b"true>"):
             assert lib.hipemu_launch_count(sym) > 0, sym

@@ -191,6 +191,7 @@ def test_persistent_critic_kernel_in_service():
             _loss_close(o_k[k], o_o[k], "%s iter %d fused vs op by op" % (k, i), 2e-5)
         plan = s_k7._k7_plan
         assert plan.ok and plan.verified, "the persistent critic kernel was not taken into service"
+        assert s_k7._k7_gen_plan.ok and s_k7._k7_gen_plan.verified, "the persistent generator forward was not taken into service"
     _params_close(s_k7.D, s_cpu.D, 4, "critic (K7)")
     for p, q in zip(s_k7.D.parameters(), s_op.D.parameters()):
         assert float((p.detach() - q.detach()).abs().max()) <= 2.05 * 4 * LR
