@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: the conv cases of the GPU suite on the host execution model with EVERY operand (inputs, packed weights,
 bias, outputs, workspaces) placed against an inaccessible page: a kernel that reads or writes past the end of a tensor - which a
-GPU run never notices, the neighbouring allocation is mapped - dies with SIGSEGV here.  Run as a subprocess by
+GPU run never notices, the neighbouring allocation is mapped - dies with SIGSEGV here.  Outputs and workspaces start as NaN: an element a kernel
+forgets to write, or a workspace slab it reads before writing, shows up as a NaN in the result.  Run as a subprocess by
 tests/test_kernels_emu_cpu.py::test_no_conv_kernel_leaves_its_tensors (prints the case before running it)."""
 import ctypes, mmap, sys, re
 import os
@@ -39,17 +40,20 @@ def _conv_case_guarded(case):
     sk = guarded(torch.zeros(emu.migan_conv_splitk_workspace() // 4))
     xn = guarded(x.permute(0, 2, 3, 1).contiguous()); wo = guarded(w.permute(0, 2, 3, 1).contiguous()); wi = guarded(w.permute(1, 2, 3, 0).contiguous())
     bg = guarded(b) if bias else None
-    y = guarded(torch.empty(N, Ho, Wo, Co))
+    y = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
     rc = emu.migan_conv2d_fwd_ws(P(xn), P(wo), P(bg), None, P(y), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, act, 0.2, P(sk), sk.numel() * 4, None)
     assert rc == 0
+    assert not torch.isnan(y).any(), 'fwd NaN'
     if gather == 0:
         gy = guarded(torch.randn(N, Ho, Wo, Co, generator=g))
         if pads[0] == pads[2] and pads[1] == pads[3]:
-            dx = guarded(torch.empty(N, H, W, Ci))
+            dx = guarded(torch.full((N, H, W, Ci), float("nan")))
             assert emu.migan_conv2d_dgrad_ws(P(gy), P(wi), None, P(dx), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], 0, 0.0, P(sk), sk.numel() * 4, None) == 0
+            assert not torch.isnan(dx).any(), 'dgrad NaN'
         wsb = emu.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
-        ws = guarded(torch.empty(max(wsb // 4, 4))); dw = guarded(torch.empty(Co, Ci, k, k))
+        ws = guarded(torch.full((max(wsb // 4, 4),), float("nan"))); dw = guarded(torch.full((Co, Ci, k, k), float("nan")))
         assert emu.migan_conv2d_wgrad(P(xn), P(gy), P(dw), P(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, 0, None, 0, None, 0, None) == 0
+        assert not torch.isnan(dw).any(), 'wgrad NaN'
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
 i0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for i, c in enumerate(cases):
