@@ -91,6 +91,11 @@ void yield() {
     hipemu_switch(&f->sp, w->sched_sp);
 }
 
+void sleep_hint() {
+    yield();
+    if (g_cores_now.load(std::memory_order_relaxed)) std::this_thread::yield();
+}
+
 static void fiber_finish() {
     Worker* w = wk;
     Fiber* f = w->running;

@@ -31,6 +31,7 @@ struct Ctx {  // per HIP thread
 extern thread_local Ctx* cur;
 void syncthreads();
 void yield();
+void sleep_hint();   // s_sleep: let the other fibers run - and, in a co-resident launch, the other workgroups' OS threads
 void* dyn_lds();
 // wave rendezvous: publish `words` 32-bit words, wait for every live lane of the wave, return the wave's slot array
 // ([64][8] words) of this exchange; valid until this lane's next exchange.
@@ -194,7 +195,7 @@ static inline void hipemu_buffer_load_lds(hipemu::BufRsrc r, LdsPtr lds, int siz
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_sleep(x) hipemu::yield()
+#define __builtin_amdgcn_s_sleep(x) hipemu::sleep_hint()
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
