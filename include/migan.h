@@ -102,11 +102,20 @@ int migan_critic_fused(const float* real, const float* fake, const float* alpha,
  * (training mode: batch statistics, running statistics and num_batches_tracked updated) + LeakyReLU / Tanh = 14 launches.
  * Host arrays: dims[4*l] = {K, N, has_bn, act code}, fpar[3*l] = {slope, eps, momentum}, ptrs[7*l] = DEVICE pointers {W [N][K], b,
  * gamma, beta, running_mean, running_var, num_batches_tracked (int64)}, NULL where absent.  B <= 64, K % 4 == 0, N % 16 == 0,
- * <= 8 layers.  ws / sync / grid as for migan_critic_fused (sync[2] != 0: the grid barrier gave up, never a hang). */
+ * <= 8 layers.  save = 0: ws holds two ping-pong activation buffers.  ws / sync / grid as for migan_critic_fused (sync[2] != 0: the grid barrier gave up, never a hang). */
 int migan_mlp_fused_ok(int B, int nlayers, const int* dims);
-size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims);
+size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims, int save);
 int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar, void* const* ptrs,
-                        float* ws, size_t ws_bytes, unsigned* sync, int grid, void* stream);
+                        float* ws, size_t ws_bytes, int save, unsigned* sync, int grid, void* stream);
+/* ... and its backward in one persistent launch (the generator iteration wgan_gp.py:179-193: both `generator(z)` and the frozen
+ * `discriminator(fake_imgs)` are such MLPs): forward with save = 1 (ws then holds every layer's output, and the normalised values
+ * and 1/std of the BatchNorm layers), then dy [B][N_last] -> parameter gradients ADDED into gptrs[4*l] = {dW [N][K], db [N], dgamma,
+ * dbeta} (device pointers in a host array; NULL = not wanted) and, when dx != NULL, the input gradient dx [B][K_0] (K_0 % 32 == 0).
+ * N % 32 == 0 for every layer but the last (a critic's single output column is fine). */
+size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* dims);
+int migan_mlp_fused_bwd(const float* x, const float* y, const float* dy, const float* save, float* dx, int B, int nlayers,
+                        const int* dims, const float* fpar, void* const* ptrs, void* const* gptrs, float* ws, size_t ws_bytes,
+                        unsigned* sync, int grid, void* stream);
 
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];

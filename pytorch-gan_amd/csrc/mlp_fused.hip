@@ -24,10 +24,30 @@ struct MlpFused {
     int B, RB, nlayers, maxN;
     const float* x;
     float* y;
-    float* ws;        // two [RB][maxN] activation buffers
+    float* ws;        // two [RB][maxN] activation buffers (forward without a graph), or the save buffer (see MlpSave)
+    int saving;       // 1: every layer's output (and normalised pre-affine value + invstd of the BatchNorm layers) is kept for mlp_fused_bwd
     unsigned* sync;   // [0] arrivals, [1] exits, [2] error flag
     MlpLayer L[MF_MAX_LAYERS];
 };
+// Save buffer of a forward that will be differentiated: for layer l < last h_l [RB][N_l]; for BatchNorm layers xhat_l [RB][N_l]
+// and invstd_l [N_l] (the last layer's output is y itself).  Offsets in floats.
+struct MlpSave {
+    size_t h[MF_MAX_LAYERS], xhat[MF_MAX_LAYERS], invstd[MF_MAX_LAYERS], total;
+};
+static __host__ __device__ inline MlpSave mf_save_layout(int RB, int nlayers, const MlpLayer* L) {
+    MlpSave S;
+    size_t o = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        const size_t n = (size_t)RB * L[l].N;
+        S.h[l] = o;
+        if (l + 1 < nlayers) o += n;
+        S.xhat[l] = o;
+        S.invstd[l] = o + (L[l].bn ? n : 0);
+        if (L[l].bn) o += n + (size_t)(L[l].N + 15) / 16 * 16;
+    }
+    S.total = o;
+    return S;
+}
 
 __device__ __forceinline__ f32x4 mf_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -99,18 +119,21 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     const bool rows_live = rg < RG;
     float* const buf0 = p.ws;
     float* const buf1 = p.ws + (size_t)RB * p.maxN;
+    const MlpSave S = mf_save_layout(RB, p.nlayers, p.L);
     unsigned target = 0;
     if (threadIdx.x == 0) give_up = 0;
 
     for (int l = 0; l < p.nlayers; ++l) {
         const MlpLayer& Ly = p.L[l];
         const int K = Ly.K, N = Ly.N;
-        const float* in = l == 0 ? p.x : ((l - 1) & 1 ? buf1 : buf0);
-        float* out = l == p.nlayers - 1 ? p.y : (l & 1 ? buf1 : buf0);
+        const float* in = l == 0 ? p.x : (p.saving ? p.ws + S.h[l - 1] : ((l - 1) & 1 ? buf1 : buf0));
+        float* out = l == p.nlayers - 1 ? p.y : (p.saving ? p.ws + S.h[l] : (l & 1 ? buf1 : buf0));
         const int klen = ((K + KSL - 1) / KSL + 15) / 16 * 16;
         const int kbeg = ks * klen < K ? ks * klen : K, kend = (ks + 1) * klen < K ? (ks + 1) * klen : K;
-        for (int t = blockIdx.x; t < N / 16; t += gridDim.x) {
-            const int col0 = t * 16, col = col0 + rr;
+        for (int t = blockIdx.x; t < (N + 15) / 16; t += gridDim.x) {
+            const int col0 = t * 16, colr = col0 + rr;
+            const bool cok = colr < N;             // only the last layer may have N % 16 != 0 (a critic's single output)
+            const int col = cok ? colr : N - 1;
             const int arow = rg * 16 + rr < B ? rg * 16 + rr : B - 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (rows_live && kbeg < kend) acc = mf_nt_partial(in + (size_t)arow * K, Ly.W + (size_t)col * K, kbeg, kend, kq);
@@ -163,13 +186,15 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
                 }
             }
             if (ks == 0) {
-                float scale = 1.f, shift = 0.f;
+                float scale = 1.f, shift = 0.f, istd = 1.f;
                 if (Ly.bn) {
                     const float invstd = 1.f / sqrtf(var + Ly.eps);
+                    istd = invstd;
                     const float gm = Ly.gamma ? Ly.gamma[col] : 1.f, bt = Ly.beta ? Ly.beta[col] : 0.f;
                     scale = invstd * gm;
                     shift = bt;
-                    if (rg == 0 && kq == 0 && Ly.rmean) {  // nn.BatchNorm1d, training: momentum update, unbiased variance
+                    if (p.saving && rg == 0 && kq == 0 && cok) p.ws[S.invstd[l] + col] = invstd;
+                    if (rg == 0 && kq == 0 && cok && Ly.rmean) {  // nn.BatchNorm1d, training: momentum update, unbiased variance
                         const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
                         Ly.rmean[col] = (1.f - Ly.momentum) * Ly.rmean[col] + Ly.momentum * mean;
                         Ly.rvar[col] = (1.f - Ly.momentum) * Ly.rvar[col] + Ly.momentum * unb;
@@ -180,8 +205,9 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
                     for (int r = 0; r < 4; ++r) {
                         const int row = rg * 16 + kq * 4 + r;
                         const float pre = Ly.bn ? d[r] * scale + shift : v[r];
+                        if (p.saving && Ly.bn && cok) p.ws[S.xhat[l] + (size_t)row * N + col] = ok[r] ? d[r] * istd : 0.f;
                         if (l == p.nlayers - 1) {
-                            if (ok[r]) out[(size_t)row * N + col] = act_apply(pre, Ly.act, Ly.slope);
+                            if (ok[r] && cok) out[(size_t)row * N + col] = act_apply(pre, Ly.act, Ly.slope);
                         } else {
                             out[(size_t)row * N + col] = ok[r] ? act_apply(pre, Ly.act, Ly.slope) : 0.f;
                         }
@@ -203,50 +229,411 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward of the same MLP in ONE persistent launch (the generator iteration of wgan_gp.py:179-193: g_loss = -mean(D(G(z))),
+// g_loss.backward()): given dy = d(loss)/d(output) and the forward's save buffer,
+//   top        dz_L = dy (.) act'(y);   dpre_L = BatchNorm-backward(dz_L)                       (column-local: a workgroup owns all rows)
+//   l = L..2   dh_{l-1} = dpre_l W_l  (NN, K = N_l);  dz = dh (.) act'(h_{l-1});  dpre_{l-1} = BN-backward(dz)  (+ dgamma, dbeta)
+//   [l = 1     dx = dpre_1 W_1                                                                     when the input gradient is wanted]
+//   last       dW_l = dpre_l^T h_{l-1}  (TN, K = rows),  db_l = column sums of dpre_l              for every layer that wants them
+// BatchNorm1d backward (training mode): dpre = gamma invstd (dz - mean_rows dz - xhat mean_rows (dz xhat)).  Parameter
+// gradients are ADDED into the caller's buffers.  dpre_l is kept for the last phase with a row stride of N_l rounded up to 16
+// (zero padded), so a one-column top layer (the critic's output) is an ordinary K = 16 slice of zeros and one live column.
+struct MlpBwd {
+    int B, RB, nlayers;
+    const float *x, *y, *dy, *save;
+    float *ws, *dx;
+    unsigned* sync;
+    MlpLayer L[MF_MAX_LAYERS];
+    float *gW[MF_MAX_LAYERS], *gb[MF_MAX_LAYERS], *ggamma[MF_MAX_LAYERS], *gbeta[MF_MAX_LAYERS];
+};
+static __host__ __device__ inline size_t mf_dpre_off(int RB, int nlayers, const MlpLayer* L, int l) {
+    size_t o = 0;
+    for (int q = 0; q < l && q < nlayers; ++q) o += (size_t)RB * ((L[q].N + 15) / 16 * 16);
+    return o;
+}
+
+// C[16][32] += A[16][k range] W[k][Nc] (NN): A rows have stride lda (zero padded to 16), W rows beyond R are not read
+__device__ __forceinline__ void mf_nn_partial(const float* __restrict__ ap, int R, const float* __restrict__ W, int Nc, int col,
+                                              int kbeg, int kend, int kq, f32x4& acc0, f32x4& acc1) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + 4 * kq + s;
+            const f32x2 b = *reinterpret_cast<const f32x2*>(W + (size_t)(k < R ? k : R - 1) * Nc + col);
+            acc0 = mf_mfma(a[s], b[0], acc0);
+            acc1 = mf_mfma(a[s], b[1], acc1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd p) {
+    __shared__ f32x4 part[2][(MF_WAVES - 1) * 64];
+    __shared__ float red[2][4][32];
+    __shared__ int give_up;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane & 15, kq = lane >> 4;
+    const int B = p.B, RB = p.RB, NL = p.nlayers;
+    const int RG = RB / 16;
+    const int RGW = RG >= 3 ? 4 : RG;
+    const int KSL = MF_WAVES / RGW;
+    const int rg = wave % RGW, ks = wave / RGW;
+    const bool rows_live = rg < RG;
+    const float invB = 1.f / (float)B;
+    const MlpSave S = mf_save_layout(RB, NL, p.L);
+    unsigned target = 0;
+    if (threadIdx.x == 0) give_up = 0;
+
+    // ---- top: dpre of the last layer from dy (16 columns x all rows per workgroup; only the ks == 0 waves work)
+    {
+        const int l = NL - 1;
+        const MlpLayer& Ly = p.L[l];
+        const int N = Ly.N, ld = (N + 15) / 16 * 16;
+        float* dpre = p.ws + mf_dpre_off(RB, NL, p.L, l);
+        for (int t = blockIdx.x; t < ld / 16; t += gridDim.x) {
+            const int colr = t * 16 + rr;
+            const bool cok = colr < N;
+            const int col = cok ? colr : N - 1;
+            float dz[4], xh[4];
+            bool ok[4];
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rg * 16 + kq * 4 + r;
+                    ok[r] = rows_live && row < B && cok;
+                    const int rc = row < B ? row : B - 1;
+                    const float yv = p.y[(size_t)rc * N + col];
+                    dz[r] = ok[r] ? p.dy[(size_t)rc * N + col] * act_grad_from_out(yv, Ly.act, Ly.slope) : 0.f;
+                    xh[r] = (Ly.bn && ok[r]) ? p.save[S.xhat[l] + (size_t)row * N + col] : 0.f;
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+            if (Ly.bn) {
+                if (ks == 0) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a += dz[r];
+                        b += dz[r] * xh[r];
+                    }
+                    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                    b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+                    if (kq == 0) {
+                        red[0][rg][rr] = a;
+                        red[1][rg][rr] = b;
+                    }
+                }
+                __syncthreads();
+                if (ks == 0)
+                    for (int q = 0; q < RGW; ++q) {
+                        s1 += red[0][q][rr];
+                        s2 += red[1][q][rr];
+                    }
+            }
+            if (ks == 0 && rows_live) {
+                float g = 1.f;
+                if (Ly.bn) {
+                    g = (Ly.gamma ? Ly.gamma[col] : 1.f) * p.save[S.invstd[l] + col];
+                    if (rg == 0 && kq == 0 && cok) {
+                        if (p.gbeta[l]) p.gbeta[l][col] += s1;
+                        if (p.ggamma[l]) p.ggamma[l][col] += s2;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rg * 16 + kq * 4 + r;
+                    const float v = Ly.bn ? g * (dz[r] - s1 * invB - xh[r] * s2 * invB) : dz[r];
+                    dpre[(size_t)row * ld + colr] = ok[r] ? v : 0.f;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!mf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- l = L-1 .. 1: dpre_{l-1} from dpre_l;  l = 0: dx (when wanted)
+    for (int l = NL - 1; l >= 0; --l) {
+        if (l == 0 && !p.dx) break;
+        const MlpLayer& Ly = p.L[l];
+        const int R = Ly.N, ldR = (R + 15) / 16 * 16, Nc = Ly.K;   // T[rows][Nc] = dpre_l[rows][R] W_l[R][Nc]
+        const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
+        const int klen = ((ldR + KSL - 1) / KSL + 15) / 16 * 16;
+        const int kbeg = ks * klen < ldR ? ks * klen : ldR, kend = (ks + 1) * klen < ldR ? (ks + 1) * klen : ldR;
+        const int lo = l > 0 ? l - 1 : 0;                               // the layer whose output this gradient belongs to
+        float* dprev = l > 0 ? p.ws + mf_dpre_off(RB, NL, p.L, l - 1) : nullptr;
+        for (int t = blockIdx.x; t < Nc / 32; t += gridDim.x) {
+            const int col = t * 32 + 2 * rr;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            if (rows_live && kbeg < kend) mf_nn_partial(dprel + (size_t)(rg * 16 + rr) * ldR, R, Ly.W, Nc, col, kbeg, kend, kq, a0, a1);
+            if (ks > 0) {
+                part[0][((ks - 1) * RGW + rg) * 64 + lane] = a0;
+                part[1][((ks - 1) * RGW + rg) * 64 + lane] = a1;
+            }
+            __syncthreads();
+            float dz[2][4], xh[2][4];
+            bool ok[4];
+            if (ks == 0) {
+                for (int q = 1; q < KSL; ++q) {
+                    a0 += part[0][((q - 1) * RGW + rg) * 64 + lane];
+                    a1 += part[1][((q - 1) * RGW + rg) * 64 + lane];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rg * 16 + kq * 4 + r;
+                    ok[r] = rows_live && row < B;
+                    if (l == 0) {
+                        dz[0][r] = a0[r];
+                        dz[1][r] = a1[r];
+                    } else {
+                        const float* h = p.save + S.h[l - 1] + (size_t)row * Nc + col;
+                        dz[0][r] = ok[r] ? a0[r] * act_grad_from_out(h[0], p.L[lo].act, p.L[lo].slope) : 0.f;
+                        dz[1][r] = ok[r] ? a1[r] * act_grad_from_out(h[1], p.L[lo].act, p.L[lo].slope) : 0.f;
+                        if (p.L[lo].bn) {
+                            const float* xp = p.save + S.xhat[l - 1] + (size_t)row * Nc + col;
+                            xh[0][r] = ok[r] ? xp[0] : 0.f;
+                            xh[1][r] = ok[r] ? xp[1] : 0.f;
+                        }
+                    }
+                }
+            }
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+            const bool bn = l > 0 && p.L[lo].bn;   // layer-uniform
+            if (bn) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float a = 0.f, b = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            a += dz[e][r];
+                            b += dz[e][r] * xh[e][r];
+                        }
+                        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+                        if (kq == 0) {
+                            red[0][rg][2 * rr + e] = a;
+                            red[1][rg][2 * rr + e] = b;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (ks == 0)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        for (int q = 0; q < RGW; ++q) {
+                            s1[e] += red[0][q][2 * rr + e];
+                            s2[e] += red[1][q][2 * rr + e];
+                        }
+            }
+            if (ks == 0 && rows_live) {
+                float g[2] = {1.f, 1.f};
+                if (bn) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[S.invstd[l - 1] + col + e];
+                        if (rg == 0 && kq == 0) {
+                            if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] += s1[e];
+                            if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] += s2[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rg * 16 + kq * 4 + r;
+                    if (l == 0) {
+                        if (ok[r]) {
+                            p.dx[(size_t)row * Nc + col] = dz[0][r];
+                            p.dx[(size_t)row * Nc + col + 1] = dz[1][r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float v = bn ? g[e] * (dz[e][r] - s1[e] * invB - xh[e][r] * s2[e] * invB) : dz[e][r];
+                            dprev[(size_t)row * Nc + col + e] = ok[r] ? v : 0.f;   // interior widths are multiples of 32: stride == width
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const bool more = l > 1 || (l == 1 && p.dx != nullptr);
+        bool any_grad = false;
+        for (int q = 0; q < NL; ++q) any_grad = any_grad || p.gW[q] != nullptr || p.gb[q] != nullptr;
+        if ((more || any_grad) && !mf_grid_barrier(p.sync, target, &give_up)) return;
+    }
+
+    // ---- last: weight / bias gradients, one 16 (n) x 64 (k) tile per wave
+    {
+        int base = 0;
+        for (int l = 0; l < NL; ++l) {
+            const MlpLayer& Ly = p.L[l];
+            if (!p.gW[l] && !p.gb[l]) continue;
+            const int N = Ly.N, K = Ly.K, ld = (N + 15) / 16 * 16;
+            const int ktiles = (K + 63) / 64, ntl = (ld / 16) * ktiles;
+            const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
+            const float* hin = l == 0 ? p.x : p.save + S.h[l - 1];      // [B or RB][K]
+            // rotate the starting wave from layer to layer so the short lists of the small layers do not all land on wave 0
+            const int gstride = gridDim.x * MF_WAVES;
+            const int gw = (blockIdx.x * MF_WAVES + wave + gstride - base % gstride) % gstride;
+            for (int wt = gw; wt < ntl; wt += gstride) {
+                const int nt = wt / ktiles, kt = wt - nt * ktiles;
+                const int n0 = nt * 16, k0 = kt * 64;
+                const int kc = k0 + 4 * rr;
+                const bool kok = kc < K;                      // K % 4 == 0: the lane's four columns are all in or all out
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float colsum = 0.f;
+                for (int m0 = 0; m0 < RB; m0 += 16) {
+                    float a[4];
+                    f32x4 b[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int m = m0 + 4 * s + kq;
+                        const int mc = m < B ? m : B - 1;
+                        a[s] = m < B ? dprel[(size_t)m * ld + n0 + rr] : 0.f;
+                        b[s] = kok ? *reinterpret_cast<const f32x4*>(hin + (size_t)mc * K + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        colsum += a[s];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = mf_mfma(a[s], b[s][e], acc[e]);
+                    }
+                }
+                if (p.gW[l] && kok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + kq * 4 + r;
+                        if (n < N) {
+                            float* o = p.gW[l] + (size_t)n * K + kc;
+                            f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                            v += *reinterpret_cast<const f32x4*>(o);
+                            *reinterpret_cast<f32x4*>(o) = v;
+                        }
+                    }
+                }
+                if (kt == 0 && p.gb[l]) {  // wave-uniform
+                    colsum += __shfl_xor(colsum, 16);
+                    colsum += __shfl_xor(colsum, 32);
+                    if (kq == 0 && n0 + rr < N) p.gb[l][n0 + rr] += colsum;
+                }
+            }
+            base += ntl;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static bool mf_fill_layers(MlpLayer* L, int nlayers, const int* dims, const float* fpar, void* const* ptrs) {
+    for (int l = 0; l < nlayers; ++l) {
+        MlpLayer& Y = L[l];
+        Y.K = dims[4 * l]; Y.N = dims[4 * l + 1]; Y.bn = dims[4 * l + 2]; Y.act = dims[4 * l + 3];
+        Y.slope = fpar[3 * l]; Y.eps = fpar[3 * l + 1]; Y.momentum = fpar[3 * l + 2];
+        Y.W = (const float*)ptrs[7 * l]; Y.b = (const float*)ptrs[7 * l + 1];
+        Y.gamma = (const float*)ptrs[7 * l + 2]; Y.beta = (const float*)ptrs[7 * l + 3];
+        Y.rmean = (float*)ptrs[7 * l + 4]; Y.rvar = (float*)ptrs[7 * l + 5]; Y.nbt = (long long*)ptrs[7 * l + 6];
+        if (!Y.W || (Y.rmean == nullptr) != (Y.rvar == nullptr)) return false;
+    }
+    return true;
+}
+static int mf_grid(int grid, int tiles) {
+    static const int grid_env = getenv("MIGAN_K7_GRID") ? atoi(getenv("MIGAN_K7_GRID")) : 0;
+    int g = grid > 0 ? grid : (grid_env > 0 ? grid_env : tiles);
+    if (g > tiles) g = tiles;
+    if (g > 128) g = 128;
+    return g < 1 ? 1 : g;
+}
+
 // dims: K, N, has_bn, act per layer;  fpar: slope, eps, momentum per layer;  ptrs: W, b, gamma, beta, running_mean, running_var,
-// num_batches_tracked per layer (device pointers in a HOST array; NULL where absent).  Returns 1 when the kernel takes the shape.
+// num_batches_tracked per layer (device pointers in a HOST array; NULL where absent).  Returns 1 when the kernels take the shape:
+// B <= 64, <= 8 layers, K % 4 == 0; N % 32 == 0 for every layer but the last (whose N is free: a critic's single output).
 MIGAN_API int migan_mlp_fused_ok(int B, int nlayers, const int* dims) {
     if (B < 1 || B > 64 || nlayers < 1 || nlayers > MF_MAX_LAYERS) return 0;
     for (int l = 0; l < nlayers; ++l) {
         const int K = dims[4 * l], N = dims[4 * l + 1];
-        if (K < 4 || K % 4 != 0 || N < 16 || N % 16 != 0) return 0;
+        if (K < 4 || K % 4 != 0 || N < 1) return 0;
+        if (l + 1 < nlayers && N % 32 != 0) return 0;
         if (l > 0 && K != dims[4 * (l - 1) + 1]) return 0;
         if (dims[4 * l + 2] && B < 2) return 0;   // BatchNorm1d in training mode needs more than one row
     }
     return 1;
 }
-MIGAN_API size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims) {
+static void mf_dims_to_layers(MlpLayer* L, int nlayers, const int* dims) {
+    for (int l = 0; l < nlayers; ++l) {
+        L[l].K = dims[4 * l]; L[l].N = dims[4 * l + 1]; L[l].bn = dims[4 * l + 2];
+    }
+}
+// bytes of the forward's `ws`: save == 0 two ping-pong activation buffers; save != 0 the save buffer migan_mlp_fused_bwd reads
+MIGAN_API size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims, int save) {
     if (!migan_mlp_fused_ok(B, nlayers, dims)) return 0;
+    const int RB = (B + 15) / 16 * 16;
+    if (save) {
+        MlpLayer L[MF_MAX_LAYERS];
+        mf_dims_to_layers(L, nlayers, dims);
+        return (mf_save_layout(RB, nlayers, L).total + 16) * sizeof(float);
+    }
     int maxN = 0;
     for (int l = 0; l < nlayers; ++l) maxN = dims[4 * l + 1] > maxN ? dims[4 * l + 1] : maxN;
-    return (size_t)2 * ((B + 15) / 16 * 16) * maxN * sizeof(float);
+    return (size_t)2 * RB * maxN * sizeof(float);
+}
+MIGAN_API size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* dims) {
+    if (!migan_mlp_fused_ok(B, nlayers, dims)) return 0;
+    MlpLayer L[MF_MAX_LAYERS];
+    mf_dims_to_layers(L, nlayers, dims);
+    return (mf_dpre_off((B + 15) / 16 * 16, nlayers, L, nlayers) + 16) * sizeof(float);
 }
 // y[B][N_last] = MLP(x[B][K_0]), BatchNorm1d layers in training mode (batch statistics; running statistics and counters updated).
-// ws: migan_mlp_fused_workspace() bytes; sync: 4 unsigned ints zeroed once (sync[2] != 0 afterwards: the grid barrier gave up).
+// ws: migan_mlp_fused_workspace(.., save) bytes; sync: 4 unsigned ints zeroed once (sync[2] != 0 afterwards: the grid barrier gave up).
 MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar,
-                                  void* const* ptrs, float* ws, size_t ws_bytes, unsigned* sync, int grid, void* stream) {
-    if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_workspace(B, nlayers, dims)) return (int)hipErrorInvalidValue;
+                                  void* const* ptrs, float* ws, size_t ws_bytes, int save, unsigned* sync, int grid, void* stream) {
+    if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_workspace(B, nlayers, dims, save)) return (int)hipErrorInvalidValue;
     MlpFused p;
-    p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers; p.maxN = 0;
+    p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers; p.maxN = 0; p.saving = save != 0;
     p.x = x; p.y = y; p.ws = ws; p.sync = sync;
+    if (!mf_fill_layers(p.L, nlayers, dims, fpar, ptrs)) return (int)hipErrorInvalidValue;
     int tiles = 0;
     for (int l = 0; l < nlayers; ++l) {
-        MlpLayer& L = p.L[l];
-        L.K = dims[4 * l]; L.N = dims[4 * l + 1]; L.bn = dims[4 * l + 2]; L.act = dims[4 * l + 3];
-        L.slope = fpar[3 * l]; L.eps = fpar[3 * l + 1]; L.momentum = fpar[3 * l + 2];
-        L.W = (const float*)ptrs[7 * l]; L.b = (const float*)ptrs[7 * l + 1];
-        L.gamma = (const float*)ptrs[7 * l + 2]; L.beta = (const float*)ptrs[7 * l + 3];
-        L.rmean = (float*)ptrs[7 * l + 4]; L.rvar = (float*)ptrs[7 * l + 5]; L.nbt = (long long*)ptrs[7 * l + 6];
-        if (!L.W || (L.rmean == nullptr) != (L.rvar == nullptr)) return (int)hipErrorInvalidValue;
-        p.maxN = L.N > p.maxN ? L.N : p.maxN;
-        tiles = L.N / 16 > tiles ? L.N / 16 : tiles;
+        p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
+        tiles = (p.L[l].N + 15) / 16 > tiles ? (p.L[l].N + 15) / 16 : tiles;
     }
-    int g = grid > 0 ? grid : tiles;
-    static const int grid_env = getenv("MIGAN_K7_GRID") ? atoi(getenv("MIGAN_K7_GRID")) : 0;
-    if (grid <= 0 && grid_env > 0) g = grid_env;
-    if (g > tiles) g = tiles;
-    if (g > 128) g = 128;
-    hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(g), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+// Backward of migan_mlp_fused_fwd(.., save = 1): dy [B][N_last] -> parameter gradients ADDED into gptrs[4*l] = {dW [N][K], db [N],
+// dgamma, dbeta} (device pointers in a host array, NULL = not wanted) and, when dx != NULL, dx [B][K_0] (needs K_0 % 32 == 0).
+// save: the forward's ws; y: the forward's output; ws: migan_mlp_fused_bwd_workspace() bytes.
+MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* dy, const float* save, float* dx, int B, int nlayers,
+                                  const int* dims, const float* fpar, void* const* ptrs, void* const* gptrs, float* ws,
+                                  size_t ws_bytes, unsigned* sync, int grid, void* stream) {
+    if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_bwd_workspace(B, nlayers, dims)) return (int)hipErrorInvalidValue;
+    if (dx && dims[0] % 32 != 0) return (int)hipErrorInvalidValue;
+    MlpBwd p;
+    p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers;
+    p.x = x; p.y = y; p.dy = dy; p.save = save; p.ws = ws; p.dx = dx; p.sync = sync;
+    if (!mf_fill_layers(p.L, nlayers, dims, fpar, ptrs)) return (int)hipErrorInvalidValue;
+    int tiles = 1;
+    for (int l = 0; l < MF_MAX_LAYERS; ++l) {
+        p.gW[l] = p.gb[l] = p.ggamma[l] = p.gbeta[l] = nullptr;
+        if (l < nlayers) {
+            p.gW[l] = (float*)gptrs[4 * l]; p.gb[l] = (float*)gptrs[4 * l + 1];
+            p.ggamma[l] = (float*)gptrs[4 * l + 2]; p.gbeta[l] = (float*)gptrs[4 * l + 3];
+            tiles = p.L[l].K / 32 > tiles ? p.L[l].K / 32 : tiles;
+        }
+    }
+    hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -249,13 +249,13 @@ class _GeneratorFusedPlan:
     """The MLP generator of wgan_gp.py:42-65 - Sequential of Linear [-> BatchNorm1d] [-> LeakyReLU | Tanh] groups behind a view to
     img_shape - as the operands of migan_mlp_fused_fwd (one persistent launch for the no_grad forward of a critic iteration)."""
 
-    def __init__(self, G, z):
+    def __init__(self, G, z, out_shape=None):
         import ctypes
 
         from ._lib import lib
 
-        self.ok = self.verified = False
-        seq, shape = getattr(G, "model", None), getattr(G, "img_shape", None)
+        self.ok = self.verified = self.step_verified = False
+        seq, shape = getattr(G, "model", None), (out_shape if out_shape is not None else getattr(G, "img_shape", None))
         if not isinstance(seq, torch.nn.Sequential) or shape is None or z.dim() != 2:
             return
         mods, groups, i = list(seq), [], 0
@@ -284,10 +284,61 @@ class _GeneratorFusedPlan:
         if not lib.migan_mlp_fused_ok(B, n, self.dims):
             return
         self.B, self.n, self.groups, self.shape, self.G = B, n, groups, tuple(shape), G
-        self.ws_bytes = lib.migan_mlp_fused_workspace(B, n, self.dims)
+        self.ws_bytes = lib.migan_mlp_fused_workspace(B, n, self.dims, 0)
         self.ws = torch.empty(self.ws_bytes // 4, device=z.device, dtype=torch.float32)
         self.sync = torch.zeros(4, device=z.device, dtype=torch.int32)
+        self.save = self.bws = None   # buffers of the differentiated form, made on first use
         self.ok = True
+
+    def _train_buffers(self, dev):
+        from ._lib import lib
+
+        if self.save is None:
+            self.save_bytes = lib.migan_mlp_fused_workspace(self.B, self.n, self.dims, 1)
+            self.save = torch.empty(self.save_bytes // 4, device=dev, dtype=torch.float32)
+            self.bws_bytes = lib.migan_mlp_fused_bwd_workspace(self.B, self.n, self.dims)
+            self.bws = torch.empty(self.bws_bytes // 4, device=dev, dtype=torch.float32)
+
+    def forward_saved(self, x, buffers=None):
+        """Forward that keeps what backward() needs (one launch); BatchNorm side effects as in run()."""
+        import ctypes
+
+        from ._lib import check, lib
+
+        self._train_buffers(x.device)
+        ts = self.tensors(buffers)
+        ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        y = torch.empty(self.B, self.groups[-1][0].out_features, device=x.device, dtype=torch.float32)
+        check(lib.migan_mlp_fused_fwd(x.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.save.data_ptr(),
+                                      self.save_bytes, 1, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+        return y
+
+    def backward(self, x, y, dy, grads=None, want_dx=False):
+        """One launch: parameter gradients ADDED into `grads` (per group [dW, db, dgamma, dbeta], None = not wanted) and / or
+        the input gradient (returned) of the forward_saved() call that produced y."""
+        import ctypes
+
+        from ._lib import check, lib
+
+        ts = self.tensors()
+        ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+        flat = [g for grp in (grads or [[None] * 4] * self.n) for g in grp]
+        gptrs = (ctypes.c_void_p * len(flat))(*[None if g is None else g.data_ptr() for g in flat])
+        dx = torch.empty_like(x) if want_dx else None
+        check(lib.migan_mlp_fused_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), self.save.data_ptr(), None if dx is None else dx.data_ptr(),
+                                      self.B, self.n, self.dims, self.fpar, ptrs, gptrs, self.bws.data_ptr(), self.bws_bytes,
+                                      self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_bwd")
+        return dx
+
+    def param_grads(self):
+        """The parameters' .grad tensors in the order backward() wants them, or None if one is missing / not contiguous."""
+        out = []
+        for lin, bn, _, _ in self.groups:
+            grp = [lin.weight.grad, lin.bias.grad] + ([bn.weight.grad, bn.bias.grad] if bn is not None else [None, None])
+            if any(g is None or not g.is_contiguous() for g in grp[:2 if bn is None else 4]):
+                return None
+            out.append(grp)
+        return out
 
     def tensors(self, buffers=None):
         """Device tensors in the order of the C entry's pointer table; `buffers` replaces the BatchNorm buffers (verification)."""
@@ -314,7 +365,7 @@ class _GeneratorFusedPlan:
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(z.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.ws.data_ptr(),
-                                      self.ws_bytes, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+                                      self.ws_bytes, 0, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y.view(self.B, *self.shape)
 
     def verify(self, z):
@@ -361,6 +412,88 @@ def _generator_nograd(s, z):
     return s.G(z)
 
 
+def _generator_iteration_plans(s, z):
+    """(generator plan, critic-as-MLP plan) for the fused generator iteration, or None"""
+    gp = getattr(s, "_k7_gen_plan", None)
+    if gp is None or not gp.usable(z) or not gp.verified:
+        return None
+    dpn = getattr(s, "_k7_dmlp_plan", None)
+    nin = gp.groups[-1][0].out_features
+    if dpn is None or (dpn.ok and dpn.B != z.shape[0]):
+        probe = torch.empty(z.shape[0], nin, device=z.device, dtype=torch.float32)
+        dpn = s._k7_dmlp_plan = _GeneratorFusedPlan(s.D, probe, out_shape=(1,))
+        if dpn.ok and (dpn.groups[-1][0].out_features != 1 or any(bn is not None for _, bn, _, _ in dpn.groups) or nin % 32 != 0):
+            dpn.ok = False
+    return (gp, dpn) if dpn.ok else None
+
+
+def _fused_generator_pass(gp, dpn, z, buffers, grads):
+    """generator(z) -> frozen critic -> g_loss = -mean(validity) -> gradients of the generator's parameters ADDED into `grads`:
+    four persistent launches (two forwards that keep their activations, two backwards) + the mean."""
+    B = gp.B
+    fake = gp.forward_saved(z, buffers)
+    val = dpn.forward_saved(fake)
+    g_loss = F.axpby(F.mean(val), None, -1.0, 0.0)
+    if getattr(dpn, "_dval", None) is None:
+        dpn._dval = torch.full((B, 1), -1.0 / B, device=z.device, dtype=torch.float32)
+    dfake = dpn.backward(fake, val, dpn._dval, None, want_dx=True)
+    gp.backward(z, fake, dfake, grads, want_dx=False)
+    return g_loss
+
+
+def _generator_iteration_fused(s, z):
+    """wgan_gp.py:179-193 (fake_imgs = generator(z); g_loss = -mean(discriminator(fake_imgs)); g_loss.backward()) when both
+    networks are the MLPs of wgan_gp.py:42-83 and the fused pass has been verified for this state; else None."""
+    plans = _generator_iteration_plans(s, z)
+    if plans is None or not plans[0].step_verified:
+        return None
+    grads = plans[0].param_grads()
+    if grads is None:
+        return None
+    return _fused_generator_pass(plans[0], plans[1], z, None, grads)
+
+
+def _verify_generator_iteration(s, z, g_loss):
+    """After an op-by-op generator iteration (its gradients are in the generator's bucket, its BatchNorm updates applied): the
+    fused pass on scratch gradients and on copies of the BatchNorm buffers must agree.  One host sync, once per state."""
+    import warnings
+
+    if not (_K7 and s.skip) or torch.cuda.is_current_stream_capturing():
+        return
+    plans = _generator_iteration_plans(s, z)
+    if plans is None or plans[0].step_verified or getattr(plans[0], "step_failed", False):
+        return
+    gp, dpn = plans
+    if gp.param_grads() is None:
+        return
+    bns = [bn for _, bn, _, _ in gp.groups if bn is not None]
+    copies = [b.clone() for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
+    scratch = [[torch.zeros_like(g) if g is not None else None for g in grp] for grp in gp.param_grads()]
+    got = _fused_generator_pass(gp, dpn, z, copies, scratch)
+    torch.cuda.synchronize()
+    why = None
+    if int(gp.sync[2]) != 0 or int(dpn.sync[2]) != 0:
+        why = "a grid barrier timed out (a launch was not co-resident)"
+        gp.sync.zero_()
+        dpn.sync.zero_()
+    elif not abs(float(got) - float(g_loss.detach())) <= 1e-4 * max(1.0, abs(float(g_loss.detach()))):
+        why = "g_loss %.7g vs %.7g op by op" % (float(got), float(g_loss.detach()))
+    else:
+        for grp_s, grp in zip(scratch, gp.param_grads()):
+            for a, b in zip(grp_s, grp):
+                if a is None:
+                    continue
+                nb = float(b.norm())
+                # a Linear bias in front of BatchNorm1d has an exactly-zero true gradient: both paths hold rounding noise there
+                if nb > 1e-6 * max(1.0, float(b.numel()) ** 0.5) and not float((a - b).norm()) <= 1e-3 * nb:
+                    why = why or "gradient of a %s tensor off by %.2e" % (tuple(b.shape), float((a - b).norm()) / nb)
+    if why is None:
+        gp.step_verified = True
+    else:
+        gp.step_failed = True
+        warnings.warn("pytorch_gan_amd: the fused generator iteration is NOT used for this state: " + why)
+
+
 def _critic_plan(s, real, fake):
     plan = getattr(s, "_k7_plan", None)
     if plan is None or (plan.ok and plan.B != real.shape[0]):
@@ -398,10 +531,13 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
     if i % s.n_critic == 0:
         s.dp.wait(s.opt_D)  # the generator step reads the critic that was just updated (wgan_gp.py:186)
-        fake_imgs = s.G(z)
-        with frozen(s.D, enabled=s.skip):
-            g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
-        g_loss.backward()
+        g_loss = _generator_iteration_fused(s, z) if (_K7 and s.skip) else None
+        if g_loss is None:
+            fake_imgs = s.G(z)
+            with frozen(s.D, enabled=s.skip):
+                g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
+            g_loss.backward()
+            _verify_generator_iteration(s, z, g_loss)
         s.dp.step(s.opt_G)
         out["g_loss"] = g_loss.detach()
     return out

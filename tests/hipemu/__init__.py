@@ -41,6 +41,7 @@ def load(only=None):
     lib.hipemu_add_coresident_kernel.argtypes = [ctypes.c_char_p]
     lib.hipemu_add_coresident_kernel(b"critic_fused_kernel")   # grid-wide barriers: all workgroups alive at once
     lib.hipemu_add_coresident_kernel(b"mlp_fused_fwd_kernel")
+    lib.hipemu_add_coresident_kernel(b"mlp_fused_bwd_kernel")
     lib.hipemu_launch_count.restype = ctypes.c_long
     if only is None:
         _LIB = lib

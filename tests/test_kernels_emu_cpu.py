@@ -270,15 +270,92 @@ def test_persistent_generator_forward_against_torch(emu, B, img_shape, grid):
         plist += [_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)] if bn else [None] * 5
     ptrs = (ctypes.c_void_p * len(plist))(*plist)
     assert emu.migan_mlp_fused_ok(B, n, dims)
-    wsb = emu.migan_mlp_fused_workspace(B, n, dims)
+    wsb = emu.migan_mlp_fused_workspace(B, n, dims, 0)
     ws = torch.full((wsb // 4,), float("nan"))
     sync = torch.zeros(4, dtype=torch.int32)
     y = torch.empty(B, groups[-1][0].out_features)
-    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
+    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, 0, _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
     assert sync.tolist() == [0, 0, 0, 0]
     assert _rel(y, want) <= 3e-6
     for a, b in zip(G2.buffers(), G.buffers()):
         assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
+
+
+def _mlp_groups(seq):
+    mods, groups, i = list(seq), [], 0
+    while i < len(mods):
+        lin, bn, act, slope = mods[i], None, 0, 0.0
+        i += 1
+        if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm1d):
+            bn = mods[i]
+            i += 1
+        if i < len(mods) and isinstance(mods[i], torch.nn.LeakyReLU):
+            act, slope = 1, mods[i].negative_slope
+            i += 1
+        elif i < len(mods) and isinstance(mods[i], torch.nn.Tanh):
+            act = 3
+            i += 1
+        groups.append((lin, bn, act, slope))
+    return groups
+
+
+@pytest.mark.parametrize("which,B,grid", [("generator", 64, 8), ("generator", 8, 3), ("critic", 64, 5), ("critic", 33, 1)])
+def test_persistent_mlp_backward_against_autograd(emu, which, B, grid):
+    """csrc/mlp_fused.hip, the pair a generator iteration is made of: forward that keeps its activations + backward in one launch
+    each.  generator: Linear / BatchNorm1d (training) / LeakyReLU / Tanh of wgan_gp.py:42-65, all parameter gradients incl.
+    dgamma / dbeta;  critic: wgan_gp.py:68-83 with its single output column, parameter gradients and the input gradient."""
+    import copy
+    import ctypes
+
+    from oracle import reference_models as M
+
+    torch.manual_seed(B)
+    if which == "generator":
+        model, x, dy, want_dx = M.MlpGenerator((1, 32, 32)).model, torch.randn(B, 100), torch.randn(B, 1024) * 0.1, False
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.uniform_(-0.2, 0.2)
+    else:
+        model, x, dy, want_dx = M.MlpCritic((1, 32, 32)).model, torch.randn(B, 1024), torch.randn(B, 1), True
+    model.train()
+    ref = copy.deepcopy(model)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy)
+    groups = _mlp_groups(model)
+    n = len(groups)
+    dims = (ctypes.c_int * (4 * n))(*[v for (l, bn, a, s) in groups for v in (l.in_features, l.out_features, int(bn is not None), a)])
+    fpar = (ctypes.c_float * (3 * n))(*[v for (l, bn, a, s) in groups for v in (s, bn.eps if bn else 0.0, bn.momentum if bn else 0.0)])
+    plist, glist, gts = [], [], []
+    for l, bn, a, s in groups:
+        plist += [_ptr(l.weight), _ptr(l.bias)]
+        plist += [_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)] if bn else [None] * 5
+        g = [torch.zeros_like(l.weight), torch.zeros_like(l.bias)] + ([torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)] if bn else [None, None])
+        gts.append(g)
+        glist += [_ptr(q) for q in g]
+    ptrs, gptrs = (ctypes.c_void_p * len(plist))(*plist), (ctypes.c_void_p * len(glist))(*glist)
+    wsb = emu.migan_mlp_fused_workspace(B, n, dims, 1)
+    save = torch.full((wsb // 4,), float("nan"))
+    bwb = emu.migan_mlp_fused_bwd_workspace(B, n, dims)
+    bws = torch.full((bwb // 4,), float("nan"))
+    sync = torch.zeros(4, dtype=torch.int32)
+    y = torch.empty(B, groups[-1][0].out_features)
+    dx = torch.full_like(x, float("nan")) if want_dx else None
+    assert emu.migan_mlp_fused_fwd(_ptr(x), _ptr(y), B, n, dims, fpar, ptrs, _ptr(save), wsb, 1, _ptr(sync), grid, None) == 0
+    assert emu.migan_mlp_fused_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(save), _ptr(dx), B, n, dims, fpar, ptrs, gptrs, _ptr(bws), bwb,
+                                   _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
+    assert sync.tolist() == [0, 0, 0, 0]
+    assert _rel(y, yr.detach()) <= 3e-6
+    if want_dx:
+        assert _rel(dx, xr.grad) <= 5e-6
+    for (l, bn, _, _), g in zip(_mlp_groups(ref), gts):
+        assert _rel(g[0], l.weight.grad) <= 5e-6
+        if bn is None:
+            assert _rel(g[1], l.bias.grad) <= 5e-6
+        else:   # a bias in front of BatchNorm has a zero true gradient: rounding noise on both sides
+            assert float((g[1] - l.bias.grad).abs().max()) <= 1e-5
+            assert _rel(g[2], bn.weight.grad) <= 5e-6 and _rel(g[3], bn.bias.grad) <= 5e-6
 
 
 def _run_gpu_test_body(module_name, test_name, *args):
@@ -319,7 +396,9 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
     lib = _run_gpu_test_body("test_steps_gpu", name, *args)
     if name == "test_wgan_gp_steps":  # first iteration op by op + the verification launch, then five fused iterations
         assert lib.hipemu_launch_count(b"critic_fused_kernel") == (6 if args[0] else 0)
-        assert lib.hipemu_launch_count(b"mlp_fused_fwd_kernel") == (6 if args[0] else 0)
+        # 6 no_grad forwards + iteration 0's verification of the fused generator iteration (2) + iteration 5 fused (2)
+        assert lib.hipemu_launch_count(b"mlp_fused_fwd_kernel") == (10 if args[0] else 0)
+        assert lib.hipemu_launch_count(b"mlp_fused_bwd_kernel") == (4 if args[0] else 0)
     if name == "test_pix2pix_step":   # the kernels this workload is there for
         for sym in (b"thin_conv_wave_kernel", b"wgrad_reduce_tr_kernel", b"pack_transpose_kernel", b"true>"):
             assert lib.hipemu_launch_count(sym) > 0, sym
