@@ -1436,6 +1436,143 @@ static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Mid-K direct kernel (16 < taps * Ci <= 128 with a source of fewer than 8 channels): the first convs of the image nets -
+// pix2pix/models.py:23 Conv2d(3,64,4,2,1) and :115 Conv2d(6,64,4,2,1), cyclegan/models.py:106 Conv2d(3,64,4,2,1),
+// srgan/models.py:85 Conv2d(3,64,3,1,1).  Their source has 3 / 6 channels, so the vectorised NHWC loaders do not apply and the
+// generic scalar-gather MFMA kernel ran them: at pix2pix's batch of one (16 384 output pixels) that is 128 workgroups walking a
+// gather of 48-96 scalar loads per row - 75 us for 0.1-0.2 GFLOP, four times per step (profiles/r03_pix2pix_kernel_stats.txt).
+// Here, as in smallk_tile_kernel: a workgroup owns 64 consecutive output pixels, the K gathered values of each pixel are fetched
+// ONCE (cooperatively, branch-free, into LDS), the K x Co weights sit in LDS for the life of the workgroup, a thread produces a
+// channel quad for two pixels at a time (8 FMAs per three LDS reads) and the tile's output is one contiguous run of 64 * Co
+// floats.  Written after round 3's GPU budget was spent: verified on the host execution model, not yet timed; MIGAN_MIDK=0 = off.
+// ------------------------------------------------------------------------------------------------
+#define MIDK_PB 64
+__global__ __launch_bounds__(256) void midk_tile_kernel(const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw,
+                                                        const float* __restrict__ bias, float* __restrict__ C, int K, unsigned mgK,
+                                                        int shK) {
+    extern __shared__ float midk_lds[];
+    const int KS = K | 1;                          // odd row stride of the gathered tile: the pixel lanes of a wave hit different banks
+    float* a_s = midk_lds;                         // [MIDK_PB][KS]
+    float* w_s = a_s + MIDK_PB * KS;               // [K][Co]
+    int* s_dh = reinterpret_cast<int*>(w_s + K * g.Co);
+    int* s_dw = s_dh + K;
+    int* s_c = s_dw + K;
+    const int tid = threadIdx.x;
+    const int Ho = g.Ho[0], Wo = g.Wo[0];
+    const int M = g.N * Ho * Wo;
+    const int Co = g.Co, cq_n = Co >> 2;
+    const int rows = 256 / cq_n;                   // pixel lanes per workgroup
+    const int cq = tid % cq_n, pl = tid / cq_n;
+    const int co = cq * 4;
+    for (int k = tid; k < K; k += 256) {
+        const int t = k / g.Ci;
+        s_dh[k] = g.dh[g.tapbeg[0] + t];
+        s_dw[k] = g.dw[g.tapbeg[0] + t];
+        s_c[k] = k - t * g.Ci;
+    }
+    for (int e = tid; e < K * Co; e += 256) {       // w_s[k][co] = weight of output channel co at (tap, channel) k
+        const int k = e / Co, c = e - k * Co;
+        const int t = k / g.Ci;
+        w_s[e] = Bw[(size_t)c * g.ldw + g.wofs[g.tapbeg[0] + t] + (k - t * g.Ci)];
+    }
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
+    const bool linear_out = g.ostep == 1;
+    const int ntiles = (M + MIDK_PB - 1) / MIDK_PB;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * MIDK_PB;
+        __syncthreads();
+        for (int base = 0; base < MIDK_PB * K; base += 1024) {   // gather: 4 independent branch-free loads per thread in flight
+            float v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const bool live = idx < MIDK_PB * K;
+                const int ic = live ? idx : MIDK_PB * K - 1;
+                const int p = fastdiv(ic, mgK, shK), k = ic - p * K;
+                int m = m0 + p;
+                const bool in = m < M;
+                m = in ? m : M - 1;
+                const int n = fastdiv(m, g.mg_hw[0], g.sh_hw[0]);
+                const int rem = m - n * Ho * Wo;
+                const int oi = fastdiv(rem, g.mg_w[0], g.sh_w[0]), oj = rem - oi * Wo;
+                int ihs, iws;
+                bool ok = map_bf(oi * g.istride + s_dh[k], g.HiL, g.Hi, g.gather, ihs);
+                ok &= map_bf(oj * g.istride + s_dw[k], g.WiL, g.Wi, g.gather, iws);
+                const float t = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + s_c[k]];
+                v[u] = (ok && in) ? t : 0.f;
+                dst[u] = live ? p * KS + k : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) a_s[dst[u]] = v[u];
+        }
+        __syncthreads();
+        for (int p = pl * 2; p < MIDK_PB; p += rows * 2) {
+            if (m0 + p >= M) break;
+            f32x4 acc0 = b4, acc1 = b4;
+            const float* a0 = a_s + p * KS;
+            const float* a1 = a0 + KS;
+#pragma unroll 4
+            for (int k = 0; k < K; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w_s + k * Co + co);
+                const float x0 = a0[k], x1 = a1[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0[e] = fmaf(x0, w[e], acc0[e]);
+                    acc1[e] = fmaf(x1, w[e], acc1[e]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + p + q;
+                if (m >= M) break;
+                const f32x4 acc = q == 0 ? acc0 : acc1;
+                size_t opix = (size_t)m;
+                int n = 0;
+                if (!linear_out || g.oscale) {
+                    n = fastdiv(m, g.mg_hw[0], g.sh_hw[0]);
+                    const int rem = m - n * Ho * Wo;
+                    const int oi = fastdiv(rem, g.mg_w[0], g.sh_w[0]), oj = rem - oi * Wo;
+                    if (!linear_out)
+                        opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
+                if (g.oscale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * Co + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+                }
+                *reinterpret_cast<f32x4*>(C + opix * Co + co) = o;
+            }
+        }
+    }
+}
+static size_t midk_lds_bytes(int K, int Co) { return ((size_t)MIDK_PB * (K | 1) + (size_t)K * Co + 3 * K) * 4; }
+static bool midk_ok(const ConvGeom& g) {
+    static const int on = getenv("MIGAN_MIDK") ? atoi(getenv("MIGAN_MIDK")) : 1;
+    const int K = g.ntap[0] * g.Ci;
+    const int cq_n = g.Co / 4;
+    return on != 0 && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 && K <= 128 &&
+           midk_lds_bytes(K, g.Co) <= 64 * 1024;
+}
+static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
+    if (maxM == 0) return 0;
+    const int K = g.ntap[0] * g.Ci;
+    unsigned mgK;
+    int shK;
+    fastdiv_magic((unsigned)K, mgK, shK);
+    long tiles = cdiv(maxM, (long)MIDK_PB);
+    if (tiles > 4096) tiles = 4096;
+    hipLaunchKernelGGL(midk_tile_kernel, dim3((unsigned)tiles), dim3(256), midk_lds_bytes(K, g.Co), st, g, A, Bw, bias, C, K, mgK, shK);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Long-K GEMV (1 tap at offset 0, i.e. Linear / 1x1 conv; Co <= 4; few output pixels): the validity heads
 // Linear(128*ds^2, 1) (dcgan.py:92, wgan_gp.py:88).  A 128x32 MFMA tile would leave ONE workgroup walking the
 // whole K serially; here one wave owns one output row and its 64 lanes stride K with 16 B loads.
@@ -1546,6 +1683,7 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
     if (var != 100 && !g.accum && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
     if (var != 100 && !g.accum && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
+    if (var == 0 && !g.accum && !fast && midk_ok(g)) return launch_midk(g, maxM, A, Bw, bias, C, st);
     if (g.Co <= 4 && var != 100 && !g.accum && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
         ThinConv tc = {};
         size_t lds = 0;

@@ -101,7 +101,7 @@ def test_every_gpu_conv_case_on_the_execution_model(emu):
             assert err <= (1e-5 if what == "wgrad" else 3e-6), (case, what, err)
         assert int(sk[:1024].view(torch.int32).abs().sum()) == 0, ("split-K tickets not back at zero", case)
     # the list really went through the kernels it is meant for
-    for sym in ("igemm_dma_kernel", "wgrad_dma_kernel", "thin_conv_kernel", "thin_conv_wave_kernel", "smallk", "wgrad_reduce"):
+    for sym in ("igemm_dma_kernel", "wgrad_dma_kernel", "thin_conv_kernel", "thin_conv_wave_kernel", "smallk", "midk_tile_kernel", "wgrad_reduce"):
         assert emu.hipemu_launch_count(sym.encode()) > 0, sym
 
 

@@ -68,6 +68,10 @@ CONV_CASES = [
     (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 1, False),     # M = 64
     (3, 72, 8, 8, 96, 3, 1, (1, 1, 1, 1), 0, 0, True),          # split-K with a K-tail (Ci % 32 != 0), ragged N, M = 192
     (8, 64, 8, 8, 128, 3, 2, (1, 1, 1, 1), 0, 1, True),         # dcgan.py:78 last D block shape (M = 128, K = 576)
+    # first convs of the image nets (3 / 6 source channels, 16 < taps * Ci <= 128): the mid-K direct kernel
+    (1, 6, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 1, False),        # pix2pix/models.py:115 Conv2d(6, 64, 4, 2, 1), K = 96
+    (2, 3, 24, 24, 64, 3, 1, (1, 1, 1, 1), 0, 1, True),         # srgan/models.py:85 Conv2d(3, 64, 3, 1, 1), K = 27
+    (3, 3, 9, 7, 16, 3, 1, (1, 1, 1, 1), 1, 2, True),           # ragged M (189 pixels), reflection pad, Co = 16
 ]
 
 
