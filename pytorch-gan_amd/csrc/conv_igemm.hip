@@ -1300,11 +1300,12 @@ __global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, cons
 // gathered source values are computed ONCE (cooperatively, staged in LDS) instead of once per channel quad, each
 // thread keeps its 4xK weights in registers and produces its quad for 256/(Co/4)-strided pixels of the tile; the
 // tile's output is one contiguous run of 64*Co floats.
-template <int K>
+// PB = output pixels per tile: 128, or 16 when 128-pixel tiles would leave most of the chip idle (the dgrad of a PatchGAN head
+// into its 512 channels, cyclegan/models.py:118 / pix2pix/models.py:130: 289 pixels = 3 tiles = 3 workgroups, 54 us)
+template <int K, int PB>
 __global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, const SmallK sk,
                                                           const float* __restrict__ A, const float* __restrict__ Bw,
                                                           const float* __restrict__ bias, float* __restrict__ C) {
-    constexpr int PB = 128;                       // output pixels per tile
     constexpr int IT = (PB * K + 255) / 256;      // gathered values per thread per tile
     __shared__ float a_s[PB * K];
     __shared__ int s_dh[K], s_dw[K], s_c[K];
@@ -1404,7 +1405,11 @@ static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, cons
     if (256 % cq_n == 0) {
         long tiles = cdiv(maxM, 128L);
         if (tiles > 8192) tiles = 8192;
-        hipLaunchKernelGGL((smallk_tile_kernel<K>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+        static const int small_env = getenv("MIGAN_SMALLK_PB16") ? atoi(getenv("MIGAN_SMALLK_PB16")) : 1;  // 0 = A/B
+        if (tiles < 128 && small_env != 0)
+            hipLaunchKernelGGL((smallk_tile_kernel<K, 16>), dim3((unsigned)cdiv(maxM, 16L)), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+        else
+            hipLaunchKernelGGL((smallk_tile_kernel<K, 128>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
     } else
         hipLaunchKernelGGL((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
 }
