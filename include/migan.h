@@ -221,6 +221,14 @@ int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float
                           int W, int Ci, int Co, int accumulate, float* db, int db_accumulate, const float* db_slabs,
                           int db_nslab, void* stream);
 
+/* Small instance-normalised tensors (pix2pix/models.py:25,41 inner U-Net levels and PatchGAN at batch 1, cyclegan/models.py:29
+ * at one image per GPU): nn.InstanceNorm2d forward - statistics, normalisation, fused activation, residual add - in ONE launch
+ * instead of three; mean / invstd [G][C] are written for the backward (migan_norm_bwd takes the same one-launch route for these
+ * shapes).  migan_norm_small_ok: C % 16 == 0, 2 <= P <= 1024, G * C / 16 >= 8, G * P * C <= 2^20. */
+int migan_norm_small_ok(int G, int P, int C);
+int migan_norm_fwd_small(const float* x, float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                         const float* res, int G, int P, int C, int act, float slope, float eps, void* stream);
+
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:
  * wgan_gp.py:49, gan.py:45;  nn.InstanceNorm2d(C): cyclegan/models.py:29,33,51,62,77,108

@@ -489,6 +489,181 @@ static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3&
     grid = dim3(gx, cdiv(P, chunk), G);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small instance-style tensors (no running statistics; P <= 1024 pixels per group): statistics AND normalisation in ONE launch.
+// The inner levels of the pix2pix U-Net (pix2pix/models.py:25,41: InstanceNorm2d on 512 x 2x2 .. 256 x 32x32 at batch 1), its
+// PatchGAN and CycleGAN at one image per GPU are tensors of 2 K - 256 K elements: the three launches of the streaming path
+// (statistics, finalize, apply; three more in backward) are ~5 us of latency each for microseconds of work - 138 of the 337
+// launches of a pix2pix step.  Here a workgroup owns 16 channels of one group and ALL its pixels (64 pixel lanes x 4 channel
+// quads): pass 1 sums around the group's first pixel (the shifted-data form of the streaming kernels), the 64 lanes are combined
+// in a fixed order in double, pass 2 re-reads the (L2-resident) pixels and writes.  No cross-workgroup reduction exists.
+// Written after round 3's GPU budget was spent: verified on the host execution model, not yet timed; MIGAN_NORM_SMALL=0 = off.
+// ---------------------------------------------------------------------------------------------
+#define NS_CH 16
+__global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ res, int P, int C, int act, float slope,
+                                                             float eps) {
+    __shared__ float red[2][256 * 4];
+    __shared__ float st[2][NS_CH];
+    const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
+    const int g = blockIdx.z, c = blockIdx.x * NS_CH + tx * 4;
+    const float* xb = x + (size_t)g * P * C + c;
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(xb);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    for (int p = ty; p < P; p += 64) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C) - shift;
+        s0 += d;
+        s1 += d * d;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        red[0][tid * 4 + v] = s0[v];
+        red[1][tid * 4 + v] = s1[v];
+    }
+    __syncthreads();
+    if (tid < NS_CH) {  // thread = channel tid of the slab: quad tid >> 2, element tid & 3
+        const int q = tid >> 2, v = tid & 3;
+        double sd = 0.0, sq = 0.0;
+        for (int l = 0; l < 64; ++l) {
+            sd += (double)red[0][(l * 4 + q) * 4 + v];
+            sq += (double)red[1][(l * 4 + q) * 4 + v];
+        }
+        const double K = (double)xb[tid - tx * 4];   // the group's first pixel, channel blockIdx.x * 16 + tid
+        const double md = sd / P;
+        double M2 = sq - sd * md;
+        if (M2 < 0.0) M2 = 0.0;
+        const float m = (float)(K + md), is = (float)(1.0 / sqrt(M2 / P + (double)eps));
+        st[0][tid] = m;
+        st[1][tid] = is;
+        mean[(size_t)g * C + blockIdx.x * NS_CH + tid] = m;
+        invstd[(size_t)g * C + blockIdx.x * NS_CH + tid] = is;
+    }
+    __syncthreads();
+    float sc[4], sh[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        sc[v] = st[1][tx * 4 + v] * (gamma ? gamma[c + v] : 1.f);
+        sh[v] = (beta ? beta[c + v] : 0.f) - st[0][tx * 4 + v] * sc[v];
+    }
+    float* yb = y + (size_t)g * P * C + c;
+    const float* rb = res ? res + (size_t)g * P * C + c : nullptr;
+    for (int p = ty; p < P; p += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (rb) r = *reinterpret_cast<const f32x4*>(rb + (size_t)p * C);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act, slope) + r[k];
+        *reinterpret_cast<f32x4*>(yb + (size_t)p * C) = o;
+    }
+}
+// backward: dx = gamma*invstd*(dyz - s0/P - xhat*s1/P), (s0, s1) = sums over the group's pixels of (dyz, dyz*xhat), dyz = dy*act'(z);
+// csum (optional): the column-sum slabs of dx the preceding conv's bias gradient is reduced from - row (g, 0) holds the group's
+// sums, rows (g, 1 .. rows_per_g - 1) are zeroed (the consumer adds all migan_norm_colsum_slabs() rows)
+__global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ dx, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int P, int C, int act, float slope,
+                                                             float* __restrict__ csum, int rows_per_g) {
+    __shared__ float red[2][256 * 4];
+    __shared__ float st[2][NS_CH];
+    const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
+    const int g = blockIdx.z, c = blockIdx.x * NS_CH + tx * 4;
+    const size_t base = (size_t)g * P * C + c;
+    float mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        mu[v] = mean[(size_t)g * C + c + v];
+        is[v] = invstd[(size_t)g * C + c + v];
+        ga[v] = gamma ? gamma[c + v] : 1.f;
+        be[v] = beta ? beta[c + v] : 0.f;
+    }
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    for (int p = ty; p < P; p += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            float d = dv[k];
+            if (act != ACT_NONE) {
+                const float z = xh * ga[k] + be[k];
+                if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
+                else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
+            }
+            s0[k] += d;
+            s1[k] += d * xh;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        red[0][tid * 4 + v] = s0[v];
+        red[1][tid * 4 + v] = s1[v];
+    }
+    __syncthreads();
+    if (tid < NS_CH) {
+        const int q = tid >> 2, v = tid & 3;
+        double a = 0.0, b = 0.0;
+        for (int l = 0; l < 64; ++l) {
+            a += (double)red[0][(l * 4 + q) * 4 + v];
+            b += (double)red[1][(l * 4 + q) * 4 + v];
+        }
+        st[0][tid] = (float)a / (float)P;
+        st[1][tid] = (float)b / (float)P;
+    }
+    __syncthreads();
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    for (int p = ty; p < P; p += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            float d = dv[k];
+            if (act != ACT_NONE) {
+                const float z = xh * ga[k] + be[k];
+                if (act == ACT_LRELU) d *= (z > 0.f ? 1.f : slope);
+                else if (act == ACT_RELU) d = z > 0.f ? d : 0.f;
+            }
+            o[k] = ga[k] * is[k] * (d - st[0][tx * 4 + k] - xh * st[1][tx * 4 + k]);
+        }
+        cs += o;
+        *reinterpret_cast<f32x4*>(dx + base + (size_t)p * C) = o;
+    }
+    if (csum) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[0][tid * 4 + v] = cs[v];
+        __syncthreads();
+        if (tid < NS_CH) {
+            const int q = tid >> 2, v = tid & 3;
+            float a = 0.f;
+            for (int l = 0; l < 64; ++l) a += red[0][(l * 4 + q) * 4 + v];
+            const int ch = blockIdx.x * NS_CH + tid;
+            csum[((size_t)g * rows_per_g) * C + ch] = a;
+            for (int r = 1; r < rows_per_g; ++r) csum[((size_t)g * rows_per_g + r) * C + ch] = 0.f;
+        }
+    }
+}
+static bool norm_small_ok(int G, int P, int C) {
+    static const int on = getenv("MIGAN_NORM_SMALL") ? atoi(getenv("MIGAN_NORM_SMALL")) : 1;
+    return on != 0 && C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
+}
+// 1: migan_norm_fwd_small takes the shape (instance-style statistics: no running statistics, no cross-replica exchange)
+MIGAN_API int migan_norm_small_ok(int G, int P, int C) { return norm_small_ok(G, P, C) ? 1 : 0; }
+// Statistics + normalisation (+ affine, activation, residual) in one launch; mean / invstd [G][C] are written for the backward.
+MIGAN_API int migan_norm_fwd_small(const float* x, float* y, float* mean, float* invstd, const float* gamma, const float* beta,
+                                   const float* res, int G, int P, int C, int act, float slope, float eps, void* stream) {
+    if (!norm_small_ok(G, P, C)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(norm_small_fwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma,
+                       beta, res, P, C, act, slope, eps);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
 static int norm_stats_impl(const float* x, float* mean, float* invstd, float* var_out, float* running_mean,
                            float* running_var, long long* num_batches_tracked, float momentum, float eps, int G, int P,
                            int C, float* ws, size_t ws_bytes, hipStream_t st) {
@@ -678,6 +853,14 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
                              int G, int P, int C, int act, float slope, float* ws, size_t ws_bytes,
                              int accumulate, float* csum, void* stream) {
     if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
+    if (!dgamma && !dbeta && norm_small_ok(G, P, C) && (act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) {
+        // small instance-style tensor: both halves in one launch (see norm_small_fwd_kernel)
+        const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
+        hipLaunchKernelGGL(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+                           gamma, beta, P, C, act, slope, csum, rows_per_g);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(G, P, C, VW, CTX, chunk, nchunks, gx);
     float* sums = ws + (size_t)G * nchunks * C * 3;

@@ -1243,6 +1243,18 @@ class _Norm(Function):
             nb = lib.migan_norm_workspace(G, P, C)
             ws = _ws(nb, xs)
             side = _stats_side(x, instance, G, P, C) if (sync is None and ctx.bn_groups == 1) else None
+            if (instance and side is None and sync is None and pw is None and not shuffle and running_mean is None
+                    and lib.migan_norm_small_ok(G, P, C)):
+                # small instance-normalised tensor (inner U-Net levels, PatchGAN at batch 1): statistics, normalisation,
+                # activation and residual in ONE launch (csrc/norm.hip norm_small_fwd_kernel)
+                rs = canon(res) if res is not None else None
+                y = torch.empty_like(xs)
+                check(lib.migan_norm_fwd_small(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                               _ptr(beta), _ptr(rs), G, P, C, act, slope, eps, st), "norm_fwd_small")
+                ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
+                ctx.sync = sync
+                ctx.save_for_backward(xs, gamma, beta, mean, invstd, x)
+                return y
             if side is not None:  # per-tile (mean, M2, count) left by the conv epilogue: no pass over the tensor
                 check(lib.migan_norm_stats_from_conv(side[0].data_ptr(), side[1], mean.data_ptr(), invstd.data_ptr(),
                                                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, G, C,

@@ -43,6 +43,7 @@ def load(only=None):
     lib.hipemu_add_coresident_kernel(b"mlp_fused_fwd_kernel")
     lib.hipemu_add_coresident_kernel(b"mlp_fused_bwd_kernel")
     lib.hipemu_launch_count.restype = ctypes.c_long
+    lib.hipemu_count_grids.argtypes = [ctypes.c_int]
     if only is None:
         _LIB = lib
     return lib

@@ -244,6 +244,7 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
 }
 
 static std::mutex g_count_mu;
+static std::atomic<int> g_count_grids{0};   // launch counters keyed by (kernel, workgroups, threads): the under-filled-launch inventory
 static std::vector<std::string> g_cores_kernels;  // kernels with grid-wide waits: every workgroup on its own OS thread
 static std::vector<std::pair<std::string, long>> g_counts;  // launches per kernel expression (tests assert which kernels ran)
 
@@ -251,13 +252,15 @@ int launch_impl(const char* kernel, U3 grid, U3 block, size_t lds, const std::fu
     {
         std::lock_guard<std::mutex> lk(g_count_mu);
         bool found = false;
+        std::string key_s(kernel);
+        if (g_count_grids.load()) key_s += " wg=" + std::to_string((size_t)grid.x * grid.y * grid.z) + " x" + std::to_string(block.x * block.y * block.z);
         for (auto& kv : g_counts)
-            if (kv.first == kernel) {
+            if (kv.first == key_s) {
                 kv.second++;
                 found = true;
                 break;
             }
-        if (!found) g_counts.emplace_back(kernel, 1);
+        if (!found) g_counts.emplace_back(key_s, 1);
     }
     const size_t nb = (size_t)grid.x * grid.y * grid.z;
     const size_t nt = (size_t)block.x * block.y * block.z;
@@ -327,6 +330,7 @@ extern "C" __attribute__((visibility("default"))) void hipemu_print_counts() {
     printf("%6ld  launches\n", total);
     fflush(stdout);
 }
+extern "C" __attribute__((visibility("default"))) void hipemu_count_grids(int on) { hipemu::g_count_grids.store(on); }
 extern "C" __attribute__((visibility("default"))) void hipemu_reset_counts() {
     std::lock_guard<std::mutex> lk(hipemu::g_count_mu);
     hipemu::g_counts.clear();

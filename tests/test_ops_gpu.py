@@ -799,7 +799,8 @@ def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", [(1, 128 * 16 * 16, 128, 1, True), (8, 64 * 64, 256, 2, False), (4, 33 * 7, 12, 0, False),
-                                 (2, 50, 3, 0, False), (3, 129, 1, 0, False)])
+                                 (2, 50, 3, 0, False), (3, 129, 1, 0, False),
+                                 (4, 16 * 16, 256, 1, False), (1, 4, 512, 2, False)])   # the one-launch small-tensor route
 def test_norm_bwd_column_sum_slabs(pg, cfg):
     """migan_norm_bwd's per-block column sums of dx (the bias gradient of the conv in front of the norm layer is reduced
     from them inside that conv's wgrad launch) equal the column sums of the dx it wrote, for BatchNorm (G=1) and
