@@ -106,6 +106,9 @@ def _weights_close(gmod, cmod, nsteps, what):
 
 
 def test_cyclegan_256_bs8_step():
+    from util import suite_budget
+
+    suite_budget(250, "test_cyclegan_256_bs8_step")
     from oracle import reference_steps as S
     from pytorch_gan_amd import steps
 
@@ -137,6 +140,9 @@ def test_cyclegan_256_bs8_step():
 
 
 def test_srgan_96_384_bs16_step():
+    from util import suite_budget
+
+    suite_budget(150, "test_srgan_96_384_bs16_step")
     from oracle import reference_steps as S
     from pytorch_gan_amd import steps
 
