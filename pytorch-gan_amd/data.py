@@ -109,7 +109,9 @@ def _stream():
 
 
 def _check_u8(images):
-    if not (isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4
+    from .functional import on_device
+
+    if not (isinstance(images, torch.Tensor) and on_device(images) and images.dtype == torch.uint8 and images.dim() == 4
             and images.is_contiguous()):
         raise TypeError("expected a contiguous uint8 CUDA tensor [N, H, W, C] (decoded bitmaps, as np.asarray(PIL image) lays them out)")
     if not 1 <= images.shape[3] <= 4:
