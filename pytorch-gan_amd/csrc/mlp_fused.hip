@@ -32,20 +32,27 @@ struct MlpFused {
 // Save buffer of a forward that will be differentiated: for layer l < last h_l [RB][N_l]; for BatchNorm layers xhat_l [RB][N_l]
 // and invstd_l [N_l] (the last layer's output is y itself).  Offsets in floats.
 struct MlpSave {
-    size_t h[MF_MAX_LAYERS], xhat[MF_MAX_LAYERS], invstd[MF_MAX_LAYERS], total;
+    size_t h, xhat, invstd;   // offsets of layer l's pieces
 };
-static __host__ __device__ inline MlpSave mf_save_layout(int RB, int nlayers, const MlpLayer* L) {
+// offsets of layer l (l == nlayers: .h = total size).  A loop over <= 8 layers instead of a table: a table indexed with a run-time
+// layer number would live in scratch memory inside the kernels.
+static __host__ __device__ inline MlpSave mf_save_at(int RB, int nlayers, const MlpLayer* L, int l) {
     MlpSave S;
     size_t o = 0;
-    for (int l = 0; l < nlayers; ++l) {
-        const size_t n = (size_t)RB * L[l].N;
-        S.h[l] = o;
-        if (l + 1 < nlayers) o += n;
-        S.xhat[l] = o;
-        S.invstd[l] = o + (L[l].bn ? n : 0);
-        if (L[l].bn) o += n + (size_t)(L[l].N + 15) / 16 * 16;
+    S.h = S.xhat = S.invstd = 0;
+    for (int q = 0; q < nlayers; ++q) {
+        const size_t n = (size_t)RB * L[q].N;
+        const size_t h = o;
+        if (q + 1 < nlayers) o += n;
+        const size_t xh = o, is = o + (L[q].bn ? n : 0);
+        if (L[q].bn) o += n + (size_t)(L[q].N + 15) / 16 * 16;
+        if (q == l) {
+            S.h = h;
+            S.xhat = xh;
+            S.invstd = is;
+        }
     }
-    S.total = o;
+    if (l >= nlayers) S.h = o;
     return S;
 }
 
@@ -119,15 +126,15 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     const bool rows_live = rg < RG;
     float* const buf0 = p.ws;
     float* const buf1 = p.ws + (size_t)RB * p.maxN;
-    const MlpSave S = mf_save_layout(RB, p.nlayers, p.L);
     unsigned target = 0;
     if (threadIdx.x == 0) give_up = 0;
 
     for (int l = 0; l < p.nlayers; ++l) {
         const MlpLayer& Ly = p.L[l];
         const int K = Ly.K, N = Ly.N;
-        const float* in = l == 0 ? p.x : (p.saving ? p.ws + S.h[l - 1] : ((l - 1) & 1 ? buf1 : buf0));
-        float* out = l == p.nlayers - 1 ? p.y : (p.saving ? p.ws + S.h[l] : (l & 1 ? buf1 : buf0));
+        const MlpSave S = mf_save_at(RB, p.nlayers, p.L, l), Sp = mf_save_at(RB, p.nlayers, p.L, l > 0 ? l - 1 : 0);
+        const float* in = l == 0 ? p.x : (p.saving ? p.ws + Sp.h : ((l - 1) & 1 ? buf1 : buf0));
+        float* out = l == p.nlayers - 1 ? p.y : (p.saving ? p.ws + S.h : (l & 1 ? buf1 : buf0));
         const int klen = ((K + KSL - 1) / KSL + 15) / 16 * 16;
         const int kbeg = ks * klen < K ? ks * klen : K, kend = (ks + 1) * klen < K ? (ks + 1) * klen : K;
         for (int t = blockIdx.x; t < (N + 15) / 16; t += gridDim.x) {
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
                     const float gm = Ly.gamma ? Ly.gamma[col] : 1.f, bt = Ly.beta ? Ly.beta[col] : 0.f;
                     scale = invstd * gm;
                     shift = bt;
-                    if (p.saving && rg == 0 && kq == 0 && cok) p.ws[S.invstd[l] + col] = invstd;
+                    if (p.saving && rg == 0 && kq == 0 && cok) p.ws[S.invstd + col] = invstd;
                     if (rg == 0 && kq == 0 && cok && Ly.rmean) {  // nn.BatchNorm1d, training: momentum update, unbiased variance
                         const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
                         Ly.rmean[col] = (1.f - Ly.momentum) * Ly.rmean[col] + Ly.momentum * mean;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
                     for (int r = 0; r < 4; ++r) {
                         const int row = rg * 16 + kq * 4 + r;
                         const float pre = Ly.bn ? d[r] * scale + shift : v[r];
-                        if (p.saving && Ly.bn && cok) p.ws[S.xhat[l] + (size_t)row * N + col] = ok[r] ? d[r] * istd : 0.f;
+                        if (p.saving && Ly.bn && cok) p.ws[S.xhat + (size_t)row * N + col] = ok[r] ? d[r] * istd : 0.f;
                         if (l == p.nlayers - 1) {
                             if (ok[r] && cok) out[(size_t)row * N + col] = act_apply(pre, Ly.act, Ly.slope);
                         } else {
@@ -284,7 +291,6 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
     const int rg = wave % RGW, ks = wave / RGW;
     const bool rows_live = rg < RG;
     const float invB = 1.f / (float)B;
-    const MlpSave S = mf_save_layout(RB, NL, p.L);
     unsigned target = 0;
     if (threadIdx.x == 0) give_up = 0;
 
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         const MlpLayer& Ly = p.L[l];
         const int N = Ly.N, ld = (N + 15) / 16 * 16;
         float* dpre = p.ws + mf_dpre_off(RB, NL, p.L, l);
+        const MlpSave S = mf_save_at(RB, NL, p.L, l);
         for (int t = blockIdx.x; t < ld / 16; t += gridDim.x) {
             const int colr = t * 16 + rr;
             const bool cok = colr < N;
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                     const int rc = row < B ? row : B - 1;
                     const float yv = p.y[(size_t)rc * N + col];
                     dz[r] = ok[r] ? p.dy[(size_t)rc * N + col] * act_grad_from_out(yv, Ly.act, Ly.slope) : 0.f;
-                    xh[r] = (Ly.bn && ok[r]) ? p.save[S.xhat[l] + (size_t)row * N + col] : 0.f;
+                    xh[r] = (Ly.bn && ok[r]) ? p.save[S.xhat + (size_t)row * N + col] : 0.f;
                 }
             }
             float s1 = 0.f, s2 = 0.f;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             if (ks == 0 && rows_live) {
                 float g = 1.f;
                 if (Ly.bn) {
-                    g = (Ly.gamma ? Ly.gamma[col] : 1.f) * p.save[S.invstd[l] + col];
+                    g = (Ly.gamma ? Ly.gamma[col] : 1.f) * p.save[S.invstd + col];
                     if (rg == 0 && kq == 0 && cok) {
                         if (p.gbeta[l]) p.gbeta[l][col] += s1;
                         if (p.ggamma[l]) p.ggamma[l][col] += s2;
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         const int klen = ((ldR + KSL - 1) / KSL + 15) / 16 * 16;
         const int kbeg = ks * klen < ldR ? ks * klen : ldR, kend = (ks + 1) * klen < ldR ? (ks + 1) * klen : ldR;
         const int lo = l > 0 ? l - 1 : 0;                               // the layer whose output this gradient belongs to
+        const MlpSave So = mf_save_at(RB, NL, p.L, lo);
         float* dprev = l > 0 ? p.ws + mf_dpre_off(RB, NL, p.L, l - 1) : nullptr;
         for (int t = blockIdx.x; t < Nc / 32; t += gridDim.x) {
             const int col = t * 32 + 2 * rr;
@@ -389,11 +397,11 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                         dz[0][r] = a0[r];
                         dz[1][r] = a1[r];
                     } else {
-                        const float* h = p.save + S.h[l - 1] + (size_t)row * Nc + col;
+                        const float* h = p.save + So.h + (size_t)row * Nc + col;
                         dz[0][r] = ok[r] ? a0[r] * act_grad_from_out(h[0], p.L[lo].act, p.L[lo].slope) : 0.f;
                         dz[1][r] = ok[r] ? a1[r] * act_grad_from_out(h[1], p.L[lo].act, p.L[lo].slope) : 0.f;
                         if (p.L[lo].bn) {
-                            const float* xp = p.save + S.xhat[l - 1] + (size_t)row * Nc + col;
+                            const float* xp = p.save + So.xhat + (size_t)row * Nc + col;
                             xh[0][r] = ok[r] ? xp[0] : 0.f;
                             xh[1][r] = ok[r] ? xp[1] : 0.f;
                         }
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                 if (bn) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[S.invstd[l - 1] + col + e];
+                        g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[So.invstd + col + e];
                         if (rg == 0 && kq == 0) {
                             if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] += s1[e];
                             if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] += s2[e];
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             const int N = Ly.N, K = Ly.K, ld = (N + 15) / 16 * 16;
             const int ktiles = (K + 63) / 64, ntl = (ld / 16) * ktiles;
             const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
-            const float* hin = l == 0 ? p.x : p.save + S.h[l - 1];      // [B or RB][K]
+            const float* hin = l == 0 ? p.x : p.save + mf_save_at(RB, NL, p.L, l - 1).h;      // [B or RB][K]
             // rotate the starting wave from layer to layer so the short lists of the small layers do not all land on wave 0
             const int gstride = gridDim.x * MF_WAVES;
             const int gw = (blockIdx.x * MF_WAVES + wave + gstride - base % gstride) % gstride;
@@ -582,7 +590,7 @@ MIGAN_API size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims, 
     if (save) {
         MlpLayer L[MF_MAX_LAYERS];
         mf_dims_to_layers(L, nlayers, dims);
-        return (mf_save_layout(RB, nlayers, L).total + 16) * sizeof(float);
+        return (mf_save_at(RB, nlayers, L, nlayers).h + 16) * sizeof(float);
     }
     int maxN = 0;
     for (int l = 0; l < nlayers; ++l) maxN = dims[4 * l + 1] > maxN ? dims[4 * l + 1] : maxN;
