@@ -5,8 +5,9 @@ covers).  Only tests load the result.
 The sources are compiled unchanged except for two textual substitutions no header can express (applied to a copy under
 _build/, with #line directives so diagnostics point at the original):
   * `extern __shared__ [attr] T name[];`  ->  `T* name = (T*)hipemu::dyn_lds();`   (dynamic LDS of the launch)
-  * `asm volatile(...)` statements: one that contains `s_barrier` becomes `__syncthreads();`, the others (s_waitcnt, register
-    pinning) are dropped - the model has no asynchronous loads to wait for.
+  * `asm volatile(...)` statements: `s_waitcnt vmcnt(N)` becomes `hipemu::waitcnt_vm(N)` (the model's LDS-DMA queue lands data only
+    when it is waited for), `s_barrier` becomes `hipemu::barrier_raw()` (a barrier WITHOUT the wait the compiler puts in front of
+    __syncthreads()), everything else (lgkmcnt, register pinning) is dropped.
 
     python tests/hipemu/build_emu.py [--force] [source.hip ...]
 """
@@ -62,7 +63,22 @@ def _drop_asm(text):
         assert text[j] == ";", "asm statement without ';' near: " + text[m.start():j + 20]
         j += 1
         keep_lines = "\n" * body.count("\n")  # keep the line numbering
-        out.append(("__syncthreads();" if "s_barrier" in body else "") + keep_lines)
+        rep = ""
+        m_cnt = re.search(r"vmcnt\((%0|\d+)\)", body)
+        if m_cnt:   # s_waitcnt vmcnt(N): the LDS-DMA queue of the model honours it
+            if m_cnt.group(1) == "%0":
+                m_op = re.search(r'"n"\s*\(', body)
+                assert m_op, "vmcnt(%0) without an \"n\" operand: " + body
+                k, depth = m_op.end(), 1
+                while depth:
+                    depth += {"(": 1, ")": -1}.get(body[k], 0)
+                    k += 1
+                rep += "hipemu::waitcnt_vm(%s);" % body[m_op.end():k - 1]
+            else:
+                rep += "hipemu::waitcnt_vm(%s);" % m_cnt.group(1)
+        if "s_barrier" in body:
+            rep += "hipemu::barrier_raw();"
+        out.append(rep + keep_lines)
         i = j
     return "".join(out)
 

@@ -109,10 +109,29 @@ static void fiber_finish() {
 
 static void fiber_entry() {
     (*wk->body)();
+    waitcnt_vm(0);
     fiber_finish();
 }
 
+void waitcnt_vm(int n) {
+    Ctx* c = cur;
+    while (c->dma_n > n) {
+        const DmaOp& op = c->dma[c->dma_head];
+        if (op.src)
+            memcpy(op.dst, op.src, op.size);
+        else
+            memset(op.dst, 0, op.size);
+        c->dma_head = (c->dma_head + 1) & 63;
+        c->dma_n--;
+    }
+}
+
 void syncthreads() {
+    waitcnt_vm(0);   // what the compiler emits in front of s_barrier when an LDS-DMA may be outstanding
+    barrier_raw();
+}
+
+void barrier_raw() {
     Worker* w = wk;
     const unsigned gen = w->bar_gen;
     w->bar_arrived++;
@@ -189,6 +208,7 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
         f.ctx.lane = (int)(t & 63);
         f.ctx.wave = (int)(t >> 6);
         f.ctx.phase = 0;
+        f.ctx.dma_head = f.ctx.dma_n = 0;
         f.done = false;
         w.waves[f.ctx.wave].live++;
         // initial frame: six callee-saved registers, the entry point as return address, one pad slot (ABI alignment)

@@ -8,8 +8,8 @@
 // Model: one fiber per HIP thread, the fibers of a workgroup scheduled round-robin on one OS thread and switched only at
 // synchronisation points (__syncthreads, wave collectives, s_sleep); workgroups are distributed over a few OS threads (all
 // of them at once in "co-resident" mode, for kernels with grid-wide waits).  Waves are 64 consecutive threads.  What is NOT
-// modelled: timing, asynchrony of LDS-DMA / global loads (every load completes at once, so a missing s_waitcnt is not
-// caught - a write into an LDS buffer that is still being read IS), divergent wave collectives, memory-ordering bugs.
+// modelled: timing, asynchrony of ordinary global loads (LDS-DMA is asynchronous: see Ctx::dma), divergent wave collectives,
+// memory-ordering bugs.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -23,13 +23,25 @@ namespace hipemu {
 struct U3 {
     unsigned x, y, z;
 };
+struct DmaOp {  // one lane's share of an LDS-DMA instruction that has been issued and not yet waited for
+    char* dst;
+    const char* src;   // nullptr: zeros (out of the descriptor's range)
+    int size;
+};
 struct Ctx {  // per HIP thread
     U3 tid, bid, bdim, gdim;
     int lane, wave, linear;
     int phase;  // double-buffer index of the wave exchange slots
+    // LDS-DMA is asynchronous: data lands only when the issuing wave waits for it (s_waitcnt vmcnt(N): all but the N youngest
+    // loads; __syncthreads(): all of them - the compiler puts vmcnt(0) in front of a barrier when an LDS-DMA may be in flight).
+    // A kernel that reads a stage before waiting for it sees the stage's OLD contents here, as it could on the hardware.
+    DmaOp dma[64];
+    int dma_head, dma_n;
 };
 extern thread_local Ctx* cur;
 void syncthreads();
+void barrier_raw();          // s_barrier without the wait for outstanding LDS-DMA
+void waitcnt_vm(int n);      // s_waitcnt vmcnt(n) for the LDS-DMA queue of this lane
 void yield();
 void sleep_hint();   // s_sleep: let the other fibers run - and, in a co-resident launch, the other workgroups' OS threads
 void* dyn_lds();
@@ -173,19 +185,20 @@ template <class LdsPtr>
 static inline void hipemu_buffer_load_lds(hipemu::BufRsrc r, LdsPtr lds, int size, int voffset, int soffset, int imm, int aux) {
     (void)aux;
     const uintptr_t basev = (uintptr_t)lds;  // M0 on the hardware: wave-uniform by construction in these kernels (not checked)
-    char* dst = (char*)basev + (size_t)hipemu::cur->lane * size;
+    hipemu::Ctx* c = hipemu::cur;
+    char* dst = (char*)basev + (size_t)c->lane * size;
     const uint64_t off = (uint64_t)(uint32_t)voffset + (uint64_t)(uint32_t)imm;
+    const char* src = nullptr;
     if (off + (uint64_t)size <= (uint64_t)r.bytes) {
         // the SGPR offset is outside the hardware's range check: a lane that passes it and still leaves the tensor is a bug
-        if (off + (uint32_t)soffset + (uint64_t)size > (uint64_t)r.bytes) {
+        if (off + (uint32_t)soffset + (uint64_t)size > (uint64_t)r.bytes)
             hipemu::note_error("LDS-DMA: voffset in range but voffset + soffset reads past the tensor");
-            memset(dst, 0, size);
-        } else {
-            memcpy(dst, r.base + off + (uint32_t)soffset, size);
-        }
-    } else {
-        memset(dst, 0, size);
+        else
+            src = r.base + off + (uint32_t)soffset;
     }
+    if (c->dma_n == 64) hipemu::waitcnt_vm(63);   // queue depth of the model; the hardware's counter saturates as well
+    c->dma[(c->dma_head + c->dma_n) & 63] = hipemu::DmaOp{dst, src, size};
+    c->dma_n++;
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, size, vo, so, imm, aux) \
     hipemu_buffer_load_lds((r), (lds), (size), (vo), (so), (imm), (aux))

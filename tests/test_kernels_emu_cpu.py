@@ -424,6 +424,47 @@ def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
 
 
+def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):
+    """LDS-DMA is asynchronous in the model: data lands when the issuing wave waits for it (`s_waitcnt vmcnt(N)` / the wait the
+    compiler puts in front of __syncthreads()).  Mutation check of that property: the four-stage split-K pipeline of
+    igemm_dma_kernel with its counted wait loosened by one K-tile reads a stage that has not landed - the model must show it
+    (the unmutated kernel is exact in test_splitk_tickets_and_determinism)."""
+    import ctypes
+    import shutil
+
+    from hipemu import build_emu
+
+    src = build_emu.CSRC
+    tmp = str(tmp_path / "csrc")
+    os.makedirs(tmp)
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h", ".py")):
+            shutil.copy(os.path.join(src, f), tmp)
+    text = open(os.path.join(tmp, "conv_dma.hip")).read()
+    old = '::"n"((NS - 2) * IPT)'
+    assert text.count(old) == 1
+    open(os.path.join(tmp, "conv_dma.hip"), "w").write(text.replace(old, '::"n"((NS - 1) * IPT)'))
+    saved = (build_emu.CSRC, build_emu.BUILD, list(build_emu.FLAGS))
+    try:
+        build_emu.CSRC, build_emu.BUILD = tmp, str(tmp_path / "_build")
+        build_emu.FLAGS = [tmp if a == src else a for a in build_emu.FLAGS]
+        lib = ctypes.CDLL(build_emu.build(only=["conv_igemm.hip", "conv_dma.hip"]))
+    finally:
+        build_emu.CSRC, build_emu.BUILD, build_emu.FLAGS = saved
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.migan_conv2d_fwd_ws.argtypes = [P] * 5 + [I] * 14 + [ctypes.c_float, P, ctypes.c_size_t, P]
+    lib.migan_conv_splitk_workspace.restype = ctypes.c_size_t
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 4, 4, 512, generator=g)
+    w = torch.randn(512, 4, 4, 512, generator=g) * 0.05
+    sk = torch.zeros(lib.migan_conv_splitk_workspace() // 4)
+    y = torch.empty(1, 2, 2, 512)
+    assert lib.migan_conv2d_fwd_ws(_ptr(x), _ptr(w), None, None, _ptr(y), 1, 4, 4, 512, 2, 2, 512, 4, 4, 2, 1, 1, 0, 0, 0.0, _ptr(sk),
+                                   sk.numel() * 4, None) == 0
+    ref = TF.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 2, 1)
+    assert _rel(y.permute(0, 3, 1, 2), ref) > 1e-2, "the model did not notice a stage read before it was waited for"
+
+
 def test_a_deadlock_is_reported_not_hung(emu, tmp_path):
     """The model's own safety net: a kernel whose threads do not all reach a barrier ends the launch with an error."""
     src = tmp_path / "dead.cpp"
