@@ -984,8 +984,11 @@ class _MMNN(Function):
             out = torch.empty((M, Nn), device=ac.device, dtype=torch.float32)
             check(lib.migan_skinny_nn(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), M, R, Nn, _stream()), "skinny_nn")
             return out
-        bt = torch.empty((Nn, R), device=bc.device, dtype=torch.float32)
-        check(lib.migan_transpose_batched(bc.data_ptr(), bt.data_ptr(), 1, R, Nn, _stream()), "transpose")
+        if R == 1 or Nn == 1:
+            bt = bc.reshape(Nn, R)   # the transpose of a row / column vector is the same memory (Linear(K, 1): dcgan.py:92)
+        else:
+            bt = torch.empty((Nn, R), device=bc.device, dtype=torch.float32)
+            check(lib.migan_transpose_batched(bc.data_ptr(), bt.data_ptr(), 1, R, Nn, _stream()), "transpose")
         return _mm_nt_raw(ac, bt, None)
 
     @staticmethod
