@@ -8,8 +8,6 @@ Only tests import this package; the product (pytorch-gan_amd/) never does, and h
 import ctypes
 import os
 
-# persistent kernels run one OS thread per workgroup in the model: keep their grids small (read once by the library)
-os.environ.setdefault("MIGAN_K7_GRID", "8")
 
 _LIB = None
 
@@ -22,6 +20,10 @@ def load(only=None):
         return _LIB
     from . import build_emu
 
+    # persistent kernels run one OS thread per workgroup in the model: keep their grids small.  Set HERE (the emulation library
+    # reads it once, at its first persistent launch) and not at import: pytest imports this package while COLLECTING on the GPU
+    # box too, where the real library must keep its default grid.
+    os.environ.setdefault("MIGAN_K7_GRID", "8")
     path = build_emu.build(only=only)
     lib = ctypes.CDLL(path)
     from pytorch_gan_amd import _lib as product
