@@ -31,7 +31,7 @@ class _Event:
         return True
 
     def elapsed_time(self, other):
-        return 0.0
+        return 1.0   # ms: time is not modelled; a positive constant keeps rate computations of callers finite
 
 
 class _Stream:
@@ -87,6 +87,8 @@ def emulated_device():
     patch(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     patch(torch.cuda, "is_current_stream_capturing", lambda: False)
     patch(torch.cuda, "synchronize", lambda device=None: None)
+    patch(torch.nn.Module, "cuda", lambda self, device=None: self)   # `.cuda()` of callers (bench.py builders): stay where we are
+    patch(torch.Tensor, "cuda", lambda self, *a, **k: self)
     try:
         yield emu
     finally:

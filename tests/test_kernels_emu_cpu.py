@@ -424,6 +424,33 @@ def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
 
 
+def test_bench_builders_and_roofline_accounting_run(emu):
+    """bench.py's own code around the step - the DCGAN and WGAN-GP builders, the per-launch accounting of `roofline` (the
+    wrappers index the C entries' argument lists) - on the execution model at a small batch: a Python error there would only
+    show as a bench line without its `roofline` object on the GPU box."""
+    import types
+
+    import bench
+    import hipemu.host
+    from pytorch_gan_amd.dp import LocalStepper
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.samefile(os.path.dirname(bench.__file__), root)
+    args = types.SimpleNamespace(batch=4, no_graph=True, global_batch=0, sync_bn=False)
+    with hipemu.host.emulated_device():
+        w = bench.BUILDERS["dcgan"](LocalStepper(), 0, torch.device("cpu"), args, 3)
+        out = w.run(0)
+        assert all(torch.isfinite(out[k]) for k in ("g_loss", "d_loss"))
+        r = bench.roofline(w, 0, 1)
+        assert r["kernel"] in r["conv_kernels"] and r["launches_per_step"] >= 1
+        assert any(k.startswith("upconv_wgrad") for k in r["conv_kernels"]) and r["hbm"]["kernel"].startswith("norm_")
+        args.batch = 0
+        g = bench.BUILDERS["wgan_gp"](LocalStepper(), 0, torch.device("cpu"), args, 3)
+        for i in range(2, 7):
+            out = g.run(i)
+        assert g.state._k7_plan.verified and g.state._k7_gen_plan.verified and g.state._k7_gen_plan.step_verified
+
+
 def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):
     """LDS-DMA is asynchronous in the model: data lands when the issuing wave waits for it (`s_waitcnt vmcnt(N)` / the wait the
     compiler puts in front of __syncthreads()).  Mutation check of that property: the four-stage split-K pipeline of
