@@ -424,6 +424,21 @@ def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
 
 
+def test_smoke_body_on_the_execution_model(emu, capsys):
+    """__graft_entry__.smoke() - the driver's first call on the GPU box - with its kernels on the execution model."""
+    import __graft_entry__ as entry
+    import hipemu.host
+
+    with hipemu.host.emulated_device():
+        saved = torch.cuda.is_available
+        torch.cuda.is_available = lambda: True
+        try:
+            entry.smoke()
+        finally:
+            torch.cuda.is_available = saved
+    assert "smoke ok" in capsys.readouterr().out
+
+
 def test_bench_builders_and_roofline_accounting_run(emu):
     """bench.py's own code around the step - the DCGAN and WGAN-GP builders, the per-launch accounting of `roofline` (the
     wrappers index the C entries' argument lists) - on the execution model at a small batch: a Python error there would only
