@@ -109,4 +109,11 @@ def syncbn(out):
 
 
 if __name__ == "__main__":
-    {"nccl1": nccl1, "syncbn": syncbn}[sys.argv[1]](sys.argv[2])
+    if os.environ.get("MIGAN_TEST_EMU") == "1":
+        # the same worker on the host execution model of the kernels (tests/hipemu): CPU tensors, gloo, no GPU
+        import hipemu.host
+
+        with hipemu.host.emulated_device():
+            {"syncbn": syncbn}[sys.argv[1]](sys.argv[2])
+    else:
+        {"nccl1": nccl1, "syncbn": syncbn}[sys.argv[1]](sys.argv[2])

@@ -381,7 +381,7 @@ def _run_gpu_test_body(module_name, test_name, *args):
 
     _load_or_skip()
     T = importlib.import_module(module_name)
-    saved = (T.DEV, T.gpu_copy)
+    saved = (getattr(T, "DEV", None), getattr(T, "gpu_copy", None))
     T.DEV = "cpu"
     T.gpu_copy = lambda m, device="cpu": util.gpu_copy(m, "cpu")
     try:
@@ -417,6 +417,16 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
     if name == "test_pix2pix_step":   # the kernels this workload is there for
         for sym in (b"thin_conv_wave_kernel", b"wgrad_reduce_tr_kernel", b"pack_transpose_kernel", b"true>"):
             assert lib.hipemu_launch_count(sym) > 0, sym
+
+
+def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monkeypatch):
+    """SURVEY.md 8e with real kernels and no GPU: the body of test_dp_gpu.py::test_cross_replica_batchnorm_equals_full_batch -
+    two torch.distributed.run ranks (gloo) each run half of a DCGAN batch with enable_sync_batchnorm() (local moments ->
+    all_gather -> Chan combination; backward sums all-reduced), their kernels on the execution model, against the
+    single-process full-batch step: losses, averaged gradients, BatchNorm running statistics."""
+    monkeypatch.setenv("MIGAN_TEST_EMU", "1")
+    monkeypatch.setenv("MIGAN_TEST_DEVICE", "cpu")
+    _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="4 minutes on 8 cores: MIGAN_EMU_SLOW=1")

@@ -38,8 +38,12 @@ def assert_close(a, b, tol, what=""):
     return r
 
 
-def gpu_copy(model, device="cuda:0"):
+def gpu_copy(model, device=None):
+    import os
+
     import pytorch_gan_amd as pg
+
+    device = device or os.environ.get("MIGAN_TEST_DEVICE", "cuda:0")   # "cpu": worker processes of the execution-model tests
 
     m = copy.deepcopy(model)
     pg.swap(m)
