@@ -198,8 +198,20 @@ _CACHE_SCOPE = None          # token of the training-step invocation in progress
 _SCOPE_IDS = __import__("itertools").count(1)
 
 
+_SCOPE_OWNER = None          # what the scope in progress belongs to (a step state): the per-step plans are kept per owner
+
+
+def _owner_plans(shared):
+    """The dict that holds the per-step plans of the scope in progress: on the owner object itself (they die with it - an
+    arena of packed weights per plan), or `shared` (per class, per device) for scopes without an owner."""
+    o = _SCOPE_OWNER
+    if o is not None and hasattr(o, "__dict__"):
+        return o.__dict__.setdefault("_migan_plans", {})
+    return shared
+
+
 @__import__("contextlib").contextmanager
-def weight_cache_scope():
+def weight_cache_scope(owner=None):
     """Inside this scope the packed (OHWI / IHWO / phase-collapsed) copies of a weight are re-used between calls
     until its optimiser steps: a discriminator applied three times per DCGAN step is packed once (and once for dgrad).
 
@@ -208,14 +220,18 @@ def weight_cache_scope():
     no stamp can see — `weights_init_normal` writing `m.weight.data` (dcgan.py:36-42), `load_state_dict`, an optimiser
     update replayed from a hipGraph — can not be served a stale pack; a capture and the eager steps around it never
     share entries either (the captured step is one scope, every eager step another)."""
-    global _CACHE_SCOPE
-    prev = _CACHE_SCOPE
+    global _CACHE_SCOPE, _SCOPE_OWNER
+    prev, prev_owner = _CACHE_SCOPE, _SCOPE_OWNER
     if prev is None:
         _CACHE_SCOPE = next(_SCOPE_IDS)
+        # `owner` (the step state object): the pack / dropout-mask plans learn the request sequence of ONE step body.
+        # Two bodies that alternate on a device (two models, a train and an eval step) each keep their own plan instead of
+        # overwriting a shared one every step (tables rebuilt, arenas re-allocated, plans dropped during capture).
+        _SCOPE_OWNER = owner
     try:
         yield
     finally:
-        _CACHE_SCOPE = prev
+        _CACHE_SCOPE, _SCOPE_OWNER = prev, prev_owner
 
 
 def _packed(param, w, kind, make):
@@ -259,10 +275,10 @@ class _PackPlan:
 
     @classmethod
     def get(cls, device):
-        key = str(device)
-        if key not in cls.plans:
-            cls.plans[key] = cls()
-        return cls.plans[key]
+        plans, key = _owner_plans(cls.plans), ("pack", str(device))
+        if key not in plans:
+            plans[key] = cls()
+        return plans[key]
 
     def note(self, param, w, kind, perm):
         scope = _CACHE_SCOPE

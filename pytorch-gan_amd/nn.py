@@ -374,10 +374,10 @@ class _MaskPlan:
 
     @classmethod
     def get(cls, device):
-        key = str(device)
-        if key not in cls.plans:
-            cls.plans[key] = cls()
-        return cls.plans[key]
+        plans, key = F._owner_plans(cls.plans), ("mask", str(device))   # one plan per step state (weight_cache_scope(owner))
+        if key not in plans:
+            plans[key] = cls()
+        return plans[key]
 
     def next(self, shape, p, device):
         scope = F._CACHE_SCOPE

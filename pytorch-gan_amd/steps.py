@@ -51,7 +51,8 @@ def _scoped(fn):
 
     @functools.wraps(fn)
     def wrapper(*a, **kw):
-        with F.weight_cache_scope():
+        # the plans that batch a step's weight packs / dropout masks into one launch belong to the step STATE (first argument)
+        with F.weight_cache_scope(owner=a[0] if a else None):
             return fn(*a, **kw)
 
     return wrapper

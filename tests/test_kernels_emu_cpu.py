@@ -434,6 +434,45 @@ def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
 
 
+def test_step_plans_belong_to_the_step_state(emu):
+    """the plans that batch a step's weight packs / dropout masks into one launch used to be one per DEVICE, so two
+    step bodies alternating on a device overwrote each other's plan every step (tables rebuilt, arena re-allocated, per-weight
+    pack launches again).  They now live on the step state: two DCGAN states stepping alternately each settle into one
+    multi-tensor pack launch and one batched mask draw per step, and the plans die with their state."""
+    import gc
+    import weakref
+
+    import hipemu.host
+    import util
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    torch.manual_seed(0)
+    with hipemu.host.emulated_device() as lib:
+        states = []
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            base = S.make_dcgan(32)
+            states.append(steps.make_gan_state(util.gpu_copy(base.G, "cpu"), util.gpu_copy(base.D, "cpu")))
+        imgs, z = torch.rand(4, 1, 32, 32) * 2 - 1, torch.randn(4, 100)
+        per_step = []
+        for rnd in range(4):
+            for s in states:
+                lib.hipemu_reset_counts()
+                steps.dcgan_step(s, imgs, z)
+                per_step.append((lib.hipemu_launch_count(b"multi_permute4_kernel"),
+                                 lib.hipemu_launch_count(b"permute4_kernel") - lib.hipemu_launch_count(b"multi_permute4_kernel")
+                                 + lib.hipemu_launch_count(b"pack_transpose_kernel"), lib.hipemu_launch_count(b"rand_mask_kernel")))
+        # from each state's second step on: ONE multi-tensor pack launch, no per-weight pack launches, ONE mask draw
+        assert per_step[2:] == [(1, 0, 1)] * 6, per_step
+        plan = states[0].__dict__["_migan_plans"][("pack", "cpu")]
+        ref = weakref.ref(plan)
+        del plan, s
+        states.clear()
+        gc.collect()
+        assert ref() is None, "a step state's plans outlived it"
+
+
 def test_smoke_body_on_the_execution_model(emu, capsys):
     """__graft_entry__.smoke() - the driver's first call on the GPU box - with its kernels on the execution model."""
     import __graft_entry__ as entry
