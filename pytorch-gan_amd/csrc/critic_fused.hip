@@ -25,7 +25,9 @@
 
 #define CF_WAVES 8
 #define CF_THREADS (64 * CF_WAVES)
+#ifndef CF_SPIN_LIMIT   // (the host execution model of tests/hipemu builds with a larger bound: its workgroups are OS threads on a shared machine)
 #define CF_SPIN_LIMIT (1u << 16)
+#endif
 
 struct CriticFused {
     int B, RB, Din, H1, H2;  // rows, rows rounded up to 16, layer widths (all % 128 == 0)

@@ -11,7 +11,9 @@
 #define MF_WAVES 8
 #define MF_THREADS (64 * MF_WAVES)
 #define MF_MAX_LAYERS 8
+#ifndef MF_SPIN_LIMIT   // (the host execution model of tests/hipemu builds with a larger bound: its workgroups are OS threads on a shared machine)
 #define MF_SPIN_LIMIT (1u << 16)
+#endif
 
 struct MlpLayer {
     const float *W, *b, *gamma, *beta;

@@ -24,7 +24,9 @@ BUILD = os.path.join(HERE, "_build")
 OUT = os.path.join(BUILD, "libmigan_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=fast", "-fvisibility=hidden", "-pthread", "-w",
-         "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DHIPEMU=1"]
+         "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DHIPEMU=1",
+         # grid-barrier spin bounds of the persistent kernels: workgroups are OS threads here, possibly on a loaded machine
+         "-DCF_SPIN_LIMIT=(1u<<26)", "-DMF_SPIN_LIMIT=(1u<<26)"]
 
 
 def sources():

@@ -241,7 +241,7 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
             // no barrier released, no collective completed, no thread finished: a deadlock unless the workgroup waits for
             // another workgroup (co-resident mode) - there, give it wall-clock time before giving up
             const double idle_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_idle).count();
-            if (!g_cores_now.load() || idle_s > 20.0 || g_abort.load()) {
+            if (!g_cores_now.load() || idle_s > 120.0 || g_abort.load()) {
                 char msg[256];
                 snprintf(msg, sizeof msg, "hipemu: deadlock in workgroup (%u,%u,%u): %d live threads, %d at the barrier", bid.x,
                          bid.y, bid.z, w.live, w.bar_arrived);
