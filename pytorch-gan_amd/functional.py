@@ -1702,7 +1702,10 @@ class _MulMask(Function):
     @staticmethod
     def forward(ctx, x, mask):
         xs = canon(x)
-        mask = _plain(mask).contiguous()
+        mask = _plain(mask)
+        nhwc = mask.dim() == 4 and xs.dim() == 4 and mask.shape == xs.shape and mask.is_contiguous(memory_format=CL)
+        if not nhwc:   # (a mask that already has the activations' NHWC layout is used in place: no copy, no transpose)
+            mask = mask.contiguous()
         y = torch.empty_like(xs)
         ctx.per_plane = xs.dim() == 4 and mask.dim() == 2
         if ctx.per_plane:
@@ -1713,7 +1716,7 @@ class _MulMask(Function):
         else:
             if mask.numel() != xs.numel():
                 raise ValueError("dropout mask must match the input")
-            if xs.dim() == 4:
+            if xs.dim() == 4 and not nhwc:
                 mask = to_nhwc(mask.view(xs.shape)) if mask.shape == xs.shape else mask
             check(lib.migan_mul(xs.data_ptr(), mask.data_ptr(), y.data_ptr(), xs.numel(), _stream()), "mul")
         ctx.save_for_backward(mask)

@@ -426,9 +426,14 @@ def _next_mask(shape, p, device):
             raise ValueError("injected dropout mask has shape %s, expected %s" % (tuple(m.shape), tuple(shape)))
         return m
     m = _MaskPlan.get(device).next(shape, float(p), device)
-    if m is not None:
-        return m
-    return F.rand_mask(shape, p, _DropoutRNG.seed, _DropoutRNG.counter(device), device)
+    if m is None:
+        m = F.rand_mask(shape, p, _DropoutRNG.seed, _DropoutRNG.counter(device), device)
+    if len(shape) == 4:
+        # a DRAWN mask is i.i.d.: read the same numbers as NHWC, the layout of the activations it multiplies - as a contiguous
+        # NCHW tensor every nn.Dropout call paid a transpose launch for it (8 per pix2pix step; injected masks keep their layout)
+        N, C, H, W = shape
+        m = m.view(N, H, W, C).permute(0, 3, 1, 2)
+    return m
 
 
 class Dropout2d(tnn.Dropout2d):
