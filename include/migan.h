@@ -227,7 +227,13 @@ int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_oihw, float
  * shapes).  migan_norm_small_ok: C % 16 == 0, 2 <= P <= 1024, G * C / 16 >= 8, G * P * C <= 2^20. */
 int migan_norm_small_ok(int G, int P, int C);
 int migan_norm_fwd_small(const float* x, float* y, float* mean, float* invstd, const float* gamma, const float* beta,
-                         const float* res, int G, int P, int C, int act, float slope, float eps, void* stream);
+                         const float* res, const float* mask, int G, int P, int C, int act, float slope, float eps, void* stream);
+/* mask (may be NULL): the nn.Dropout behind the activation of pix2pix/models.py:25-28,41-45 (InstanceNorm2d -> LeakyReLU / ReLU ->
+ * Dropout(0.5)) as a [G][P][C] multiplier applied in the same launch; migan_norm_bwd_small is the matching backward
+ * (dz = dy * mask * act'(z); csum as for migan_norm_bwd, may be NULL). */
+int migan_norm_bwd_small(const float* x, const float* dy, const float* mask, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float* dx, int G, int P, int C, int act, float slope, float* csum,
+                         void* stream);
 
 /* ---- BatchNorm2d/1d (train) and InstanceNorm2d (csrc/norm.hip) ---------------------------------------
  * nn.BatchNorm2d(C[,eps]): dcgan.py:53,56,60,80  srgan/models.py:23,26,47,55,87,90;  nn.BatchNorm1d:

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
                                                              float* __restrict__ mean, float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ res, int P, int C, int act, float slope,
-                                                             float eps) {
+                                                             float eps, const float* __restrict__ mask) {
+    // mask (optional, same [G][P][C] layout): the nn.Dropout behind the activation (pix2pix/models.py:27,44) - y = act(..) * mask
     __shared__ float red[2][256 * 4];
     __shared__ float st[2][NS_CH];
     const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
@@ -549,13 +550,15 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
     }
     float* yb = y + (size_t)g * P * C + c;
     const float* rb = res ? res + (size_t)g * P * C + c : nullptr;
+    const float* mb = mask ? mask + (size_t)g * P * C + c : nullptr;
     for (int p = ty; p < P; p += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C);
-        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        f32x4 r = {0.f, 0.f, 0.f, 0.f}, mk = {1.f, 1.f, 1.f, 1.f};
         if (rb) r = *reinterpret_cast<const f32x4*>(rb + (size_t)p * C);
+        if (mb) mk = *reinterpret_cast<const f32x4*>(mb + (size_t)p * C);
         f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act, slope) + r[k];
+        for (int k = 0; k < 4; ++k) o[k] = act_apply(fmaf(v[k], sc[k], sh[k]), act, slope) * mk[k] + r[k];
         *reinterpret_cast<f32x4*>(yb + (size_t)p * C) = o;
     }
 }
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
                                                              float* __restrict__ dx, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int P, int C, int act, float slope,
-                                                             float* __restrict__ csum, int rows_per_g) {
+                                                             float* __restrict__ csum, int rows_per_g, const float* __restrict__ mask) {
     __shared__ float red[2][256 * 4];
     __shared__ float st[2][NS_CH];
     const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
@@ -583,7 +586,8 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     for (int p = ty; p < P; p += 64) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+        if (mask) dv *= *reinterpret_cast<const f32x4*>(mask + base + (size_t)p * C);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float xh = (xv[k] - mu[k]) * is[k];
@@ -617,7 +621,8 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     for (int p = ty; p < P; p += 64) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
+        if (mask) dv *= *reinterpret_cast<const f32x4*>(mask + base + (size_t)p * C);
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -656,13 +661,18 @@ static bool norm_small_ok(int G, int P, int C) {
 MIGAN_API int migan_norm_small_ok(int G, int P, int C) { return norm_small_ok(G, P, C) ? 1 : 0; }
 // Statistics + normalisation (+ affine, activation, residual) in one launch; mean / invstd [G][C] are written for the backward.
 MIGAN_API int migan_norm_fwd_small(const float* x, float* y, float* mean, float* invstd, const float* gamma, const float* beta,
-                                   const float* res, int G, int P, int C, int act, float slope, float eps, void* stream) {
+                                   const float* res, const float* mask, int G, int P, int C, int act, float slope, float eps,
+                                   void* stream) {
     if (!norm_small_ok(G, P, C)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(norm_small_fwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma,
-                       beta, res, P, C, act, slope, eps);
+                       beta, res, P, C, act, slope, eps, mask);
     HIP_LAUNCH_CHECK();
     return 0;
 }
+// Backward of migan_norm_fwd_small with a dropout mask (dz = dy * mask * act'(z)); csum as for migan_norm_bwd (may be NULL)
+MIGAN_API int migan_norm_bwd_small(const float* x, const float* dy, const float* mask, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, float* dx, int G, int P, int C, int act, float slope,
+                                   float* csum, void* stream);
 
 static int norm_stats_impl(const float* x, float* mean, float* invstd, float* var_out, float* running_mean,
                            float* running_var, long long* num_batches_tracked, float momentum, float eps, int G, int P,
@@ -857,7 +867,7 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
         // small instance-style tensor: both halves in one launch (see norm_small_fwd_kernel)
         const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
         hipLaunchKernelGGL(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
-                           gamma, beta, P, C, act, slope, csum, rows_per_g);
+                           gamma, beta, P, C, act, slope, csum, rows_per_g, (const float*)nullptr);
         HIP_LAUNCH_CHECK();
         return 0;
     }
@@ -868,6 +878,17 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
                                  accumulate, stream);
     if (rc) return rc;
     return migan_norm_bwd_apply(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act, slope, P, csum, stream);
+}
+
+MIGAN_API int migan_norm_bwd_small(const float* x, const float* dy, const float* mask, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, float* dx, int G, int P, int C, int act, float slope,
+                                   float* csum, void* stream) {
+    if (!norm_small_ok(G, P, C) || !(act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) return (int)hipErrorInvalidValue;
+    const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
+    hipLaunchKernelGGL(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+                       gamma, beta, P, C, act, slope, csum, rows_per_g, mask);
+    HIP_LAUNCH_CHECK();
+    return 0;
 }
 
 // Backward of y = PReLU(norm(x)*gamma+beta): as migan_norm_bwd with the slope read from the device, plus the slope's own

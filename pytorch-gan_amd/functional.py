@@ -1218,7 +1218,10 @@ class _Norm(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, use_batch_stats, momentum, eps, instance, act,
-                slope, nbt=None, prelu=None, shuffle=0):
+                slope, nbt=None, prelu=None, shuffle=0, mask=None):
+        # mask: the nn.Dropout behind the activation (pix2pix/models.py:25-28,41-45) as an NHWC multiplier of the output's shape,
+        # applied inside the launch - only the one-launch small-tensor route takes it (nn.Sequential checks norm_small_takes())
+        ctx.mask = None
         # prelu: the weight of an nn.PReLU() (one shared slope) behind the norm layer (srgan/models.py:23-24,55-57): applied in
         # the norm's apply launch, differentiated inside the norm's backward launches (csrc/norm.hip)
         # shuffle = 2: nn.PixelShuffle(2) between the two (srgan/models.py:55-57): the output is written - and its gradient
@@ -1268,12 +1271,20 @@ class _Norm(Function):
                 # activation and residual in ONE launch (csrc/norm.hip norm_small_fwd_kernel)
                 rs = canon(res) if res is not None else None
                 y = torch.empty_like(xs)
+                mk = None
+                if mask is not None:
+                    mk = canon(mask)
+                    if mk.shape != xs.shape:
+                        raise ValueError("norm: dropout mask of shape %s for an output of shape %s" % (tuple(mk.shape), tuple(xs.shape)))
+                    ctx.mask = mk
                 check(lib.migan_norm_fwd_small(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                               _ptr(beta), _ptr(rs), G, P, C, act, slope, eps, st), "norm_fwd_small")
+                                               _ptr(beta), _ptr(rs), _ptr(mk), G, P, C, act, slope, eps, st), "norm_fwd_small")
                 ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
                 ctx.sync = sync
                 ctx.save_for_backward(xs, gamma, beta, mean, invstd, x)
                 return y
+            if mask is not None:
+                raise ValueError("norm: a fused dropout mask needs the small-tensor route (norm_small_takes())")
             if side is not None:  # per-tile (mean, M2, count) left by the conv epilogue: no pass over the tensor
                 check(lib.migan_norm_stats_from_conv(side[0].data_ptr(), side[1], mean.data_ptr(), invstd.data_ptr(),
                                                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, G, C,
@@ -1293,6 +1304,8 @@ class _Norm(Function):
                                                    _ptr(running_mean), _ptr(running_var), _ptr(nbt), momentum, eps, C,
                                                    st), "norm_sync_finalize")
         else:
+            if mask is not None:
+                raise ValueError("norm: a fused dropout mask needs batch statistics")
             mean = _plain(running_mean)
             invstd = torch.empty_like(mean)  # eval mode: invstd = 1/sqrt(running_var + eps)
             check(lib.migan_rsqrt_eps(_plain(running_var).data_ptr(), invstd.data_ptr(), C, eps, st), "rsqrt_eps")
@@ -1325,6 +1338,23 @@ class _Norm(Function):
         G, P, C, act, slope, batch_stats, affine, has_res = ctx.cfg
         if not batch_stats:
             raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference path")
+        if ctx.mask is not None:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("double backward through a normalisation with a fused Dropout is not on the reference path")
+            dy = canon(dy)
+            dx = torch.empty_like(xs)
+            slabs, nslab = None, 0
+            if _COLSUM_FUSE and not ctx.x_nchw:
+                nslab = lib.migan_norm_colsum_slabs(G, P, C)
+                slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
+            check(lib.migan_norm_bwd_small(xs.data_ptr(), dy.data_ptr(), ctx.mask.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                           _ptr(gamma), _ptr(beta), dx.data_ptr(), G, P, C, act, slope, _ptr(slabs), _stream()),
+                  "norm_bwd_small")
+            if ctx.x_nchw:
+                dx = to_nchw(dx)
+            elif slabs is not None:
+                _attach_colsum(dx, slabs, nslab, C)
+            return (dx,) + (None,) * 15
         if torch.is_grad_enabled():
             if ctx.bn_groups > 1:
                 raise NotImplementedError("double backward through batch_groups() BatchNorm is not on the reference path")
@@ -1387,7 +1417,7 @@ class _Norm(Function):
             dx = to_nchw(dx)
         elif slabs is not None:
             _attach_colsum(dx, slabs, nslab, C)
-        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, dprelu, None
+        return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, dprelu, None, None
 
 
 class _NormBwdFn(Function):
@@ -1464,7 +1494,7 @@ def _norm_backward_differentiable(ctx, dy, xs, gamma, beta, mean, invstd, x_in):
             check(lib.migan_norm_bwd_sums(xs.data_ptr(), gd.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                           _ptr(beta), sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), G, P, C, ACT_NONE,
                                           0.0, ws.data_ptr(), nb, 0, _stream()), "norm_bwd_sums")
-    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None, None
+    return dx, dgamma, dbeta, (dy if has_res else None), None, None, None, None, None, None, None, None, None, None, None, None
 
 
 _BN_GROUPS = 1
@@ -1483,13 +1513,21 @@ def batch_groups(k):
         _BN_GROUPS = prev
 
 
+def norm_small_takes(x, instance):
+    """True when norm(x, instance=...) takes the one-launch small-tensor route - the only one that applies a dropout `mask`."""
+    if not instance or x.dim() != 4 or (_SYNC_BN is not None and _SYNC_BN.world > 1):
+        return False
+    N, C, H, W = x.shape
+    return bool(lib.migan_norm_small_ok(N, H * W, C)) and _stats_side(x, True, N, H * W, C) is None
+
+
 def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None, use_batch_stats=True, momentum=0.1,
-         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0):
+         eps=1e-5, instance=False, act=ACT_NONE, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0, mask=None):
     """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself; `prelu`: weight of
     an nn.PReLU() (single slope) applied behind the normalisation inside the same launches; `shuffle` = 2: nn.PixelShuffle(2)
     as the store index map of the same launches (output (N, C/4, 2H, 2W))."""
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
-                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu, int(shuffle))
+                       float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu, int(shuffle), mask)
 
 
 # ---------------------------------------------------------------------------------------------- index remaps

@@ -229,14 +229,14 @@ class BatchNorm1d(_BatchNormMixin, tnn.BatchNorm1d):
 
 
 class InstanceNorm2d(tnn.InstanceNorm2d):
-    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None):
+    def fused_forward(self, x, act=F.ACT_NONE, slope=0.0, res=None, mask=None):
         if self.affine or self.track_running_stats:
             raise ValueError("InstanceNorm2d: affine/track_running_stats are not on the reference path")
         if x.dim() != 4:
             raise ValueError("InstanceNorm2d: expected 4D input")
         if x.shape[2] * x.shape[3] == 1 and self.training:
             raise ValueError("Expected more than 1 spatial element when training, got input size %s" % (x.shape,))
-        return _wrap(F.norm(x, None, None, res, None, None, True, 0.1, self.eps, True, act, slope))
+        return _wrap(F.norm(x, None, None, res, None, None, True, 0.1, self.eps, True, act, slope, mask=mask))
 
     def forward(self, x):
         return self.fused_forward(x)
@@ -414,6 +414,7 @@ def _numel(shape):
 
 
 _BATCH_MASKS = __import__("os").environ.get("MIGAN_BATCH_MASKS", "1") == "1"  # A/B knob
+_DROPOUT_FUSE = __import__("os").environ.get("MIGAN_DROPOUT_FUSE", "1") == "1"   # nn.Dropout inside the small InstanceNorm launch
 
 
 def _next_mask(shape, p, device):
@@ -588,6 +589,12 @@ class Sequential(tnn.Sequential):
                         continue
                 if res is not None and k == n and act == F.ACT_NONE and x.dim() == 4 and res.shape == x.shape:
                     x, res = m.fused_forward(x, act, slope, res), None   # y = norm(x) + res in the apply kernel
+                elif _DROPOUT_FUSE and type(m) is InstanceNorm2d and k < n and type(mods[k]) is Dropout and mods[k].training \
+                        and 0.0 < mods[k].p < 1.0 and x.dim() == 4 and F.norm_small_takes(x, True):
+                    # InstanceNorm2d [LeakyReLU | ReLU] Dropout (pix2pix/models.py:25-28,41-45): the mask multiplies inside the
+                    # one-launch normalisation of the small inner U-Net levels, forward and backward
+                    x = m.fused_forward(x, act, slope, None, _next_mask(tuple(x.shape), mods[k].p, x.device))
+                    k += 1
                 else:
                     x = m.fused_forward(x, act, slope)
                 i = k

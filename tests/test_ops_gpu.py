@@ -387,6 +387,27 @@ def test_instancenorm(pg, cfg):
         assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "in dx")
 
 
+@pytest.mark.parametrize("cfg", [(1, 512, 2, 2, 2), (1, 512, 8, 8, 1), (2, 256, 16, 16, 2)])
+def test_instancenorm_with_fused_dropout(pg, cfg):
+    """InstanceNorm2d -> LeakyReLU | ReLU -> Dropout(0.5) of pix2pix/models.py:25-28,41-45 on the small inner U-Net levels: the mask
+    multiplies inside the one-launch normalisation (forward and backward) - against torch with the same mask."""
+    N, C, H, W, act = cfg
+    F = pg.functional
+    x = (_leaf(N, C, H, W, seed=1) * 2 + 0.3).requires_grad_(True)
+    mask = (torch.rand(N, C, H, W, generator=torch.Generator().manual_seed(5)) > 0.5).float() * 2.0
+    z_ref = TF.instance_norm(x, eps=1e-5)
+    y_ref = {1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](z_ref) * mask
+    gy = _leaf(N, C, H, W, seed=2)
+    y_ref.backward(gy)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    assert F.norm_small_takes(xg, True)
+    y = F.norm(xg, None, None, None, None, None, True, 0.1, 1e-5, True, act, 0.2, mask=mask.to(DEV))
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "in+dropout fwd")
+    keep = (z_ref.detach().abs() > 1e-5).float()
+    assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "in+dropout dx")
+
+
 def test_norm_residual(pg):
     F = pg.functional
     x, r = _leaf(2, 64, 8, 8, seed=1).requires_grad_(True), _leaf(2, 64, 8, 8, seed=2).requires_grad_(True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch inventory of one training step on the HOST execution model of the kernels (tests/hipemu - no GPU needed): which
 kernels a `bench.py` workload launches per step, how often, and with how many workgroups.  This is where the launch counts in
-DESIGN.md come from (pix2pix 337 -> 273, wgan_gp ~4 per iteration, dcgan 129 at batch 4).  Counts are exact; times are not
+DESIGN.md come from (pix2pix 337 -> 249, wgan_gp ~4 per iteration, dcgan 129 at batch 4).  Counts are exact; times are not
 modelled.
 
     python tools/emu_inventory.py pix2pix            # full BASELINE shape where the model can afford it (pix2pix: ~40 s per step)

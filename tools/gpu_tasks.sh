@@ -240,7 +240,7 @@ task_staged() {
   timeout 900 python -m pytest tests/test_steps_gpu.py -q -x -k "pix2pix or cyclegan_step or srgan_step" >> gpurun_out/staged/pytest.txt 2>&1
   echo "steps pytest rc=$?" >> gpurun_out/staged/pytest.txt
   grep -E "passed|failed|rc=" gpurun_out/staged/pytest.txt
-  OFF="MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0 MIGAN_MIDK=0 MIGAN_NORM_SMALL=0 MIGAN_SMALLK_PB16=0"
+  OFF="MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0 MIGAN_MIDK=0 MIGAN_NORM_SMALL=0 MIGAN_SMALLK_PB16=0 MIGAN_DROPOUT_FUSE=0"
   for k7 in 0 1; do
     echo "== wgan_gp [MIGAN_K7=$k7]" >> gpurun_out/staged/bench.txt
     env MIGAN_K7=$k7 timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline \
