@@ -143,7 +143,7 @@ def test_sequential_fusion_plan(monkeypatch):
         return torch.zeros(x.shape[0], w.shape[0], 2 * x.shape[2], 2 * x.shape[3])
 
     def norm(x, gamma=None, beta=None, res=None, rm=None, rv=None, use_batch_stats=True, momentum=0.1, eps=1e-5,
-             instance=False, act=0, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0):
+             instance=False, act=0, slope=0.0, num_batches_tracked=None, prelu=None, shuffle=0, mask=None):
         calls.append(("norm", bool(instance), act, float(eps), num_batches_tracked is not None) + (("prelu",) if prelu is not None else ())
                      + (("shuffle", shuffle) if shuffle else ()))
         if shuffle:
