@@ -65,6 +65,22 @@ def _sync_bn(s):
     return getattr(s.dp, "sync_bn", None) is not None
 
 
+_ONES = {}
+
+
+def _backward(loss):
+    """loss.backward() with the root gradient from a cached ones scalar: autograd otherwise makes it with ones_like - one more fill
+    launch (and graph node) per backward call, two to three per training step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ONES.get(key)
+    if one is None:
+        if torch.cuda.is_current_stream_capturing():   # memory made during a capture belongs to the graph's pool: do not keep it
+            loss.backward()
+            return
+        one = _ONES[key] = torch.ones(loss.shape, device=loss.device, dtype=loss.dtype)
+    loss.backward(one)
+
+
 def half_sum(a, b):
     """(a + b) / 2 as the reference writes it (bit-identical: scaling by 0.5 is exact)."""
     return F.axpby(a, b, 0.5, 0.5)
@@ -94,7 +110,7 @@ def dcgan_step(s, real_imgs, z):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce(s.D(gen), valid)
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     if _PAIR_D and real_imgs.shape == gen.shape and not _sync_bn(s):
@@ -115,7 +131,7 @@ def dcgan_step(s, real_imgs, z):
         real_loss = s.bce(s.D(real_imgs), valid)
         fake_loss = s.bce(s.D(gen.detach()), fake)
         d_loss = half_sum(real_loss, fake_loss)
-    d_loss.backward()
+    _backward(d_loss)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
 
@@ -524,7 +540,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
         gp = compute_gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
         # d_loss = -mean(real) + mean(fake) + lambda_gp * gp
         d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
-        d_loss.backward()
+        _backward(d_loss)
         if plan is not None and not plan.verified and not torch.cuda.is_current_stream_capturing():
             plan.verify(real_imgs, fake_imgs, alpha, d_loss, gp)
     s.dp.step(s.opt_D)
@@ -537,7 +553,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
             fake_imgs = s.G(z)
             with frozen(s.D, enabled=s.skip):
                 g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
-            g_loss.backward()
+            _backward(g_loss)
             _verify_generator_iteration(s, z, g_loss)
         s.dp.step(s.opt_G)
         out["g_loss"] = g_loss.detach()
@@ -580,7 +596,7 @@ def dragan_step(s, real_imgs, z, alpha=None, noise=None):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce(s.D(gen), valid)
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     with torch.no_grad() if s.skip else contextlib.nullcontext():  # d_loss is never back-propagated (dragan.py:211-217)
@@ -588,7 +604,7 @@ def dragan_step(s, real_imgs, z, alpha=None, noise=None):
         fake_loss = s.bce(s.D(gen.detach()), fake)
         d_loss = half_sum(real_loss, fake_loss)
     gp = compute_gradient_penalty_dragan(s.D, real_imgs.data, alpha, noise, getattr(s, "lambda_gp", 10.0))
-    gp.backward()
+    _backward(gp)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gp": gp.detach(), "gen_imgs": gen.detach()}
 
@@ -765,21 +781,21 @@ def cyclegan_step(s, real_A, real_B):
     loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
     loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
     loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
-    loss_G.backward()
+    _backward(loss_G)
     s.dp.step(s.opt_G)
 
     s.opt_D_A.zero_grad()
     loss_real = s.mse(s.D_A(real_A), valid)
     fake_A_ = s.buf_A.push_and_pop(fake_A)
     loss_D_A = half_sum(loss_real, s.mse(s.D_A(fake_A_.detach()), fake))
-    loss_D_A.backward()
+    _backward(loss_D_A)
     s.dp.step(s.opt_D_A)
 
     s.opt_D_B.zero_grad()
     loss_real = s.mse(s.D_B(real_B), valid)
     fake_B_ = s.buf_B.push_and_pop(fake_B)
     loss_D_B = half_sum(loss_real, s.mse(s.D_B(fake_B_.detach()), fake))
-    loss_D_B.backward()
+    _backward(loss_D_B)
     s.dp.step(s.opt_D_B)
     return {"loss_G": loss_G.detach(), "loss_D": half_sum(loss_D_A, loss_D_B).detach(), "loss_GAN": loss_GAN.detach(),
             "loss_cycle": loss_cycle.detach(), "loss_identity": loss_id.detach()}
@@ -804,13 +820,13 @@ def pix2pix_step(s, real_A, real_B):
         loss_GAN = s.mse(s.D(fake_B, real_A), valid)
     loss_pixel = s.l1(fake_B, real_B)
     loss_G = F.axpby(loss_GAN, loss_pixel, 1.0, s.lambda_pixel)
-    loss_G.backward()
+    _backward(loss_G)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     loss_real = s.mse(s.D(real_B, real_A), valid)
     loss_fake = s.mse(s.D(fake_B.detach(), real_A), fake)
     loss_D = half_sum(loss_real, loss_fake)
-    loss_D.backward()
+    _backward(loss_D)
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_pixel": loss_pixel.detach(),
             "loss_GAN": loss_GAN.detach()}
@@ -841,13 +857,13 @@ def srgan_step(s, imgs_lr, imgs_hr):
             real_features = s.V(imgs_hr)
     loss_content = s.l1(gen_features, real_features.detach())
     loss_G = F.axpby(loss_content, loss_GAN, 1.0, 1e-3)
-    loss_G.backward()
+    _backward(loss_G)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     loss_real = s.mse(s.D(imgs_hr), valid)
     loss_fake = s.mse(s.D(gen_hr.detach()), fake)
     loss_D = half_sum(loss_real, loss_fake)
-    loss_D.backward()
+    _backward(loss_D)
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach()}
@@ -875,7 +891,7 @@ def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
     gen_hr = s.G(imgs_lr)
     loss_pixel = s.l1_pixel(gen_hr, imgs_hr)
     if batches_done < s.warmup_batches:
-        loss_pixel.backward()
+        _backward(loss_pixel)
         s.dp.step(s.opt_G)
         return {"loss_pixel": loss_pixel.detach()}
     with frozen(s.D, s.V, enabled=s.skip):
@@ -890,7 +906,7 @@ def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
         loss_GAN = s.bce_logits(F.sub_batch_mean(pred_fake, pred_real), valid)
         loss_content = s.l1_content(s.V(gen_hr), real_features)
     loss_G = F.axpby(F.axpby(loss_content, loss_GAN, 1.0, s.lambda_adv), loss_pixel, 1.0, s.lambda_pixel)
-    loss_G.backward()
+    _backward(loss_G)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     pred_real = s.D(imgs_hr)
@@ -898,7 +914,7 @@ def esrgan_step(s, imgs_lr, imgs_hr, batches_done):
     loss_real = s.bce_logits(F.sub_batch_mean(pred_real, pred_fake), valid)
     loss_fake = s.bce_logits(F.sub_batch_mean(pred_fake, pred_real), fake)
     loss_D = half_sum(loss_real, loss_fake)
-    loss_D.backward()
+    _backward(loss_D)
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach(), "loss_pixel": loss_pixel.detach()}
@@ -931,7 +947,7 @@ def acgan_step(s, real_imgs, labels, z, gen_labels):
     with frozen(s.D, enabled=s.skip):
         validity, pred_label = s.D(gen_imgs)
         g_loss = half_sum(s.bce(validity, valid), s.ce(pred_label, gen_labels))
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     real_pred, real_aux = s.D(real_imgs)
@@ -939,7 +955,7 @@ def acgan_step(s, real_imgs, labels, z, gen_labels):
     fake_pred, fake_aux = s.D(gen_imgs.detach())
     d_fake_loss = half_sum(s.bce(fake_pred, fake), s.ce(fake_aux, gen_labels))
     d_loss = half_sum(d_real_loss, d_fake_loss)
-    d_loss.backward()
+    _backward(d_loss)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen_imgs.detach()}
 
@@ -961,11 +977,11 @@ def lsgan_step(s, real_imgs, z):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.mse(s.D(gen), valid)
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     d_loss = half_sum(s.mse(s.D(real_imgs), valid), s.mse(s.D(gen.detach()), fake))
-    d_loss.backward()
+    _backward(d_loss)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
 
@@ -984,7 +1000,7 @@ def relativistic_gan_step(s, real_imgs, z, rel_avg_gan=False):
         s.D(gen.detach())
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce_logits(s.D(gen), valid)
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     real_pred = s.D(real_imgs)
@@ -996,7 +1012,7 @@ def relativistic_gan_step(s, real_imgs, z, rel_avg_gan=False):
         real_loss = s.bce_logits(F.axpby(real_pred, fake_pred, 1.0, -1.0), valid)
         fake_loss = s.bce_logits(F.axpby(fake_pred, real_pred, 1.0, -1.0), fake)
     d_loss = half_sum(real_loss, fake_loss)
-    d_loss.backward()
+    _backward(d_loss)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
 
@@ -1012,7 +1028,7 @@ def ebgan_step(s, real_imgs, z, opt_batch_size=64, lambda_pt=0.1):
     with frozen(s.D, enabled=s.skip):
         recon, emb = s.D(gen)
         g_loss = F.axpby(s.mse(recon, gen.detach()), F.pullaway_loss(emb), 1.0, lambda_pt)
-    g_loss.backward()
+    _backward(g_loss)
     s.dp.step(s.opt_G)
     s.opt_D.zero_grad()
     real_recon, _ = s.D(real_imgs)
@@ -1026,6 +1042,6 @@ def ebgan_step(s, real_imgs, z, opt_batch_size=64, lambda_pt=0.1):
             s.labels[key] = torch.ones((), device=real_imgs.device)
         # d_loss_real + (margin - d_loss_fake); the constant rides on a device scalar so the value matches the reference's
         d_loss = F.axpby(F.axpby(d_loss_real, d_loss_fake, 1.0, -1.0), s.labels[key], 1.0, float(margin))
-    d_loss.backward()
+    _backward(d_loss)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
