@@ -583,6 +583,51 @@ def _safe_cpu_baseline(init):
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
+def _staged_report():
+    try:
+        from pytorch_gan_amd import selfcheck
+
+        return selfcheck.report()
+    except Exception as ex:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:120])}
+
+
+def run_extra(other, k, wu, timeout_s=150.0):
+    """One of the other BASELINE configs, briefly, in ITS OWN PROCESS (`bench.py --workload other`, headline section only):
+    whatever happens to it - a device fault aborts a process - the headline line of this run is already final and is printed."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", other, "--steps", str(k), "--warmup", str(wu),
+           "--max-blocks", "20", "--no-roofline", "--no-cpu-baseline", "--no-extra"]
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    except OSError as ex:
+        return {"error": "could not start: %s" % ex}
+    try:
+        so, se = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, 9)   # its own session: exactly the process group started here
+        except OSError:
+            pass
+        p.communicate()
+        return {"error": "no result within %d s" % timeout_s}
+    line = next((ln for ln in reversed(so.splitlines()) if ln.startswith("{")), None)
+    if p.returncode != 0 or line is None:
+        tail = (se or "").strip().splitlines()[-1:]
+        return {"error": "exit status %d: %s" % (p.returncode, tail[0][:160] if tail else "")}
+    r = json.loads(line)
+    t = r.get("timing", {})
+    return {"images_per_s": r["value"], "ms_per_step": r["ms_per_step"], "ms_per_step_min": t.get("ms_per_step_min"),
+            "ms_per_step_max": t.get("ms_per_step_max"), "blocks": t.get("blocks"), "timed_seconds": t.get("timed_seconds"),
+            "step_executed_frac": r.get("step_executed_frac"), "step_dense_frac": r.get("step_dense_frac"),
+            "workload": r["config"]["workload"], "steps": k, "warmup": wu, "hipgraph": r["config"].get("hipgraph"),
+            "peak_mem_gb": r.get("peak_mem_gb"), "losses": r.get("losses"),
+            **({"staged_kernels_off": [n for n, v in r["staged_kernels"].items() if str(v).startswith("disabled")]}
+               if any(str(v).startswith("disabled") for v in r.get("staged_kernels", {}).values()) else {})}
+
+
+
 def replicas_identical(w, world, dev):
     """Same initial weights + summed gradients -> same updates on every rank."""
     chk = torch.stack([torch.cat([p.detach().double().flatten() for p in m.parameters()]).abs().sum()
@@ -604,6 +649,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: total batch, sharded over the ranks (must be divisible by --gpus)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much is timed")
+    ap.add_argument("--max-blocks", type=int, default=200, help="upper bound on the number of timed K-step blocks")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -653,7 +699,7 @@ def main():
 
     name = args.workload
     w = BUILDERS[name](dp, rank, dev, args, args.warmup + args.steps)
-    blocks, out = timed_blocks(w, world, dev, args.steps, args.warmup, args.min_seconds)
+    blocks, out = timed_blocks(w, world, dev, args.steps, args.warmup, args.min_seconds, max_blocks=args.max_blocks)
     losses = {k: float(v) for k, v in out.items() if "loss" in k}
     if not all(np.isfinite(v) for v in losses.values()):
         raise SystemExit("non-finite loss in the timed region: %s" % losses)
@@ -672,6 +718,10 @@ def main():
                    "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in blocks[:64]]},
         "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
         "losses": losses,
+        "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        # outcome of the hardware self-check of the kernels written without GPU time (pytorch_gan_amd/selfcheck.py):
+        # "ok" = in service, "disabled: ..." = the kernel it replaces ran instead
+        "staged_kernels": _staged_report(),
     }
     if w.capture_error:
         result["config"]["hipgraph_error"] = w.capture_error[:200]
@@ -712,18 +762,7 @@ def main():
             result["cpu_baseline"] = _safe_cpu_baseline(init)
         extra = result["extra"] = {}   # attached first: a watchdog line carries the configs finished so far
         for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
-            try:
-                ow = BUILDERS[other](dp, rank, dev, argparse.Namespace(batch=0, no_graph=False), k + wu)
-                ob, oo = timed_blocks(ow, 1, dev, k, wu, 2.0, max_blocks=20)
-                e = summarise(other, ow.batch, 1, k, ob)
-                e.update(workload=WORKLOAD_NAME[other], steps=k, warmup=wu, hipgraph=ow.graphed,
-                         peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                         losses={kk: float(v) for kk, v in oo.items() if "loss" in kk})
-                extra[other] = e
-                del ow, oo
-            except Exception as ex:  # the headline line must survive a failure here
-                extra[other] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
-            torch.cuda.empty_cache()
+            extra[other] = run_extra(other, k, wu)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
     if watchdog is not None:

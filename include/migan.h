@@ -26,6 +26,13 @@ extern "C" {
 
 const char* migan_version(void);
 const char* migan_error_string(int code);
+/* Staged-kernel switchboard.  Kernels that entered the tree without hardware time carry one bit each (1 thin_conv_wave - PatchGAN
+ * heads, cyclegan/models.py:118 pix2pix/models.py:127; 2 wgrad_reduce_tr; 4 midk_tile - first convs of the image nets,
+ * pix2pix/models.py:23,115; 8 norm_small - nn.InstanceNorm2d at <= 1024 pixels, pix2pix/models.py:25,42; 16 smallk_tile<K,16>;
+ * 32 pack_transpose).  A bit starts from its MIGAN_* environment variable (unset = on).  Clears, then sets, the named bits and
+ * returns the word; migan_staged(0, 0) reads it.  The host mirror's hardware self-check (pytorch_gan_amd/selfcheck.py) clears the
+ * bit of a kernel that disagrees with the kernel it replaces.  No reference counterpart: torch selects its ATen kernels internally. */
+unsigned migan_staged(unsigned clear_bits, unsigned set_bits);
 
 /* ---- Convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip) ----------
  * nn.Conv2d forward: dcgan.py:55,59,62,78  cyclegan/models.py:28,32,50,60,75,82,106,118

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
+#include <atomic>
 
 #define MIGAN_API extern "C" __attribute__((visibility("default")))
 
@@ -61,6 +63,31 @@ static inline void fastdiv_magic(unsigned d, unsigned& m, int& s) {
 __device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
     return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
 }
+
+// Kernels that entered the tree without hardware time ("staged"): one bit each.  A bit starts from its MIGAN_*
+// variable (unset = 1 = on) and can be cleared at run time through migan_staged() - the host's hardware self-check
+// (pytorch_gan_amd/selfcheck.py) takes a staged kernel out of service when it disagrees with the kernel it replaces.
+enum {
+    STG_THIN_WAVE = 1, STG_WGRAD_REDUCE_TR = 2, STG_MIDK = 4, STG_NORM_SMALL = 8, STG_SMALLK_PB16 = 16, STG_PACK_TR = 32,
+    STG_ALL = 63
+};
+inline unsigned staged_from_env() {
+    static const struct { const char* var; unsigned bit; } tab[] = {
+        {"MIGAN_THIN_WAVE", STG_THIN_WAVE}, {"MIGAN_WGRAD_REDUCE_TR", STG_WGRAD_REDUCE_TR}, {"MIGAN_MIDK", STG_MIDK},
+        {"MIGAN_NORM_SMALL", STG_NORM_SMALL}, {"MIGAN_SMALLK_PB16", STG_SMALLK_PB16}, {"MIGAN_PACK_TR", STG_PACK_TR}};
+    unsigned bits = 0;
+    for (const auto& t : tab) {
+        const char* v = getenv(t.var);
+        if (v == nullptr || atoi(v) != 0) bits |= t.bit;
+    }
+    return bits;
+}
+// one word per library: an inline function's static local is shared by the translation units of the shared object
+inline std::atomic<unsigned>& staged_word() {
+    static std::atomic<unsigned> w{staged_from_env()};
+    return w;
+}
+static inline bool staged_on(unsigned bit) { return (staged_word().load(std::memory_order_relaxed) & bit) != 0; }
 
 #define HIP_LAUNCH_CHECK()                         \
     do {                                           \

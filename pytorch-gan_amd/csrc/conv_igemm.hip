@@ -1205,8 +1205,8 @@ __global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, c
 
 // few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel
 static bool thin_wave_ok(const ConvGeom& g, int max_tiles) {
-    static const int on = getenv("MIGAN_THIN_WAVE") ? atoi(getenv("MIGAN_THIN_WAVE")) : 1;  // 0 = A/B against thin_conv_kernel
-    return on != 0 && g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
+    const bool on = staged_on(STG_THIN_WAVE);  // MIGAN_THIN_WAVE=0 = A/B against thin_conv_kernel
+    return on && g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
 }
 
 static int launch_thin_conv_wave(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
@@ -1405,8 +1405,7 @@ static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, cons
     if (256 % cq_n == 0) {
         long tiles = cdiv(maxM, 128L);
         if (tiles > 8192) tiles = 8192;
-        static const int small_env = getenv("MIGAN_SMALLK_PB16") ? atoi(getenv("MIGAN_SMALLK_PB16")) : 1;  // 0 = A/B
-        if (tiles < 128 && small_env != 0)
+        if (tiles < 128 && staged_on(STG_SMALLK_PB16))  // MIGAN_SMALLK_PB16=0 = A/B
             hipLaunchKernelGGL((smallk_tile_kernel<K, 16>), dim3((unsigned)cdiv(maxM, 16L)), dim3(256), 0, st, g, sk, A, Bw, bias, C);
         else
             hipLaunchKernelGGL((smallk_tile_kernel<K, 128>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
@@ -1558,10 +1557,10 @@ __global__ __launch_bounds__(256) void midk_tile_kernel(const ConvGeom g, const 
 }
 static size_t midk_lds_bytes(int K, int Co) { return ((size_t)MIDK_PB * (K | 1) + (size_t)K * Co + 3 * K) * 4; }
 static bool midk_ok(const ConvGeom& g) {
-    static const int on = getenv("MIGAN_MIDK") ? atoi(getenv("MIGAN_MIDK")) : 1;
+    const bool on = staged_on(STG_MIDK);  // MIGAN_MIDK=0 = off
     const int K = g.ntap[0] * g.Ci;
     const int cq_n = g.Co / 4;
-    return on != 0 && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 && K <= 128 &&
+    return on && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 && K <= 128 &&
            midk_lds_bytes(K, g.Co) <= 64 * 1024;
 }
 static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
@@ -2680,8 +2679,7 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     long total = (long)Co * T * Ci;
     const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
     br.nbias = extra;
-    static const int tr_env = getenv("MIGAN_WGRAD_REDUCE_TR") ? atoi(getenv("MIGAN_WGRAD_REDUCE_TR")) : 1;  // 0 = A/B
-    if (tr_env != 0 && total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
+    if (staged_on(STG_WGRAD_REDUCE_TR) && total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
         const int ci_tiles = cdiv(Ci, RTR_CI);
         br.main_blocks = Co * ci_tiles;
         hipLaunchKernelGGL(wgrad_reduce_tr_kernel, dim3(br.main_blocks + extra), dim3(256), (size_t)RTR_CI * (T + 1) * 4, st,

@@ -645,10 +645,10 @@ MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int 
                               int p3, void* stream) {
     size_t total = (size_t)d0 * d1 * d2 * d3;
     if (total == 0) return 0;
-    static const int tr_env = getenv("MIGAN_PACK_TR") ? atoi(getenv("MIGAN_PACK_TR")) : 1;  // 0 = A/B against permute4_kernel
+    const bool tr_env = staged_on(STG_PACK_TR);  // MIGAN_PACK_TR=0 = A/B against permute4_kernel
     const int R = d2 * d3;
     const bool ohwi = p0 == 0 && p1 == 2 && p2 == 3 && p3 == 1, ihwo = p0 == 1 && p1 == 2 && p2 == 3 && p3 == 0;
-    if (tr_env != 0 && (ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {
+    if (tr_env && (ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {
         const int X = ohwi ? d1 : d0, Y = ohwi ? d0 : d1;
         const long long sy = ohwi ? (long long)d1 * R : R, sx = ohwi ? R : (long long)d1 * R;
         const int x_tiles = (X + PTR_X - 1) / PTR_X;

@@ -654,8 +654,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
     }
 }
 static bool norm_small_ok(int G, int P, int C) {
-    static const int on = getenv("MIGAN_NORM_SMALL") ? atoi(getenv("MIGAN_NORM_SMALL")) : 1;
-    return on != 0 && C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
+    return staged_on(STG_NORM_SMALL) && C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
 }
 // 1: migan_norm_fwd_small takes the shape (instance-style statistics: no running statistics, no cross-replica exchange)
 MIGAN_API int migan_norm_small_ok(int G, int P, int C) { return norm_small_ok(G, P, C) ? 1 : 0; }

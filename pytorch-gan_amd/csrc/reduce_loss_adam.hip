@@ -351,4 +351,16 @@ MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, flo
 }
 
 MIGAN_API const char* migan_version() { return "migan 0.1 gfx950"; }
+
+// ---- staged-kernel switchboard (common.h) -----------------------------------------------------------------------------
+// Clear, then set, bits of the staged-kernel word (STG_* of common.h: 1 thin_conv_wave, 2 wgrad_reduce_tr, 4 midk_tile, 8 norm_small,
+// 16 smallk_tile<K,16>, 32 pack_transpose); returns the word afterwards.  migan_staged(0, 0) reads it.  Host-side state only: call it
+// between launches, not while another thread is queueing them.
+MIGAN_API unsigned migan_staged(unsigned clear_bits, unsigned set_bits) {
+    std::atomic<unsigned>& w = staged_word();
+    unsigned cur = w.load(), next;
+    do next = (cur & ~clear_bits) | (set_bits & STG_ALL);
+    while (!w.compare_exchange_weak(cur, next));
+    return next;
+}
 MIGAN_API const char* migan_error_string(int code) { return hipGetErrorString((hipError_t)code); }

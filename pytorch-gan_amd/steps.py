@@ -22,6 +22,7 @@ import torch
 
 from . import functional as F
 from . import nn as gnn
+from . import selfcheck as _selfcheck
 from .dp import LocalStepper
 from .optim import Adam
 
@@ -182,7 +183,13 @@ def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
 # persistent launch, csrc/critic_fused.hip.  MIGAN_K7=0 keeps the op-by-op path (autograd over the skinny GEMM Functions).
 # The persistent kernel synchronises its workgroups through a grid-wide barrier, so it is taken into service per critic only
 # after ONE iteration in which both paths ran and agreed (`verify`): the first critic iteration of a state is always op-by-op.
-_K7 = os.environ.get("MIGAN_K7", "1") == "1"
+_K7 = os.environ.get("MIGAN_K7", "1") == "1"   # selfcheck.ensure() clears it when the probe process says so
+
+
+def _k7():
+    """The persistent kernels may be used: switched on, and the hardware self-check has returned its verdict (until then -
+    a capture before any eager step, say - nothing that has not run on this GPU model is launched)."""
+    return _K7 and not _selfcheck.PENDING
 
 
 class _CriticFusedPlan:
@@ -417,7 +424,7 @@ class _GeneratorFusedPlan:
 def _generator_nograd(s, z):
     """fake_imgs = generator(z) without a graph (wgan_gp.py:163 when its gradients are dead): one persistent launch when the
     generator is the MLP of wgan_gp.py:42-65 (verified once against the op-by-op forward), else the modules."""
-    if _K7:
+    if _k7():
         plan = getattr(s, "_k7_gen_plan", None)
         if plan is None or (plan.ok and plan.B != z.shape[0]):
             plan = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
@@ -475,7 +482,7 @@ def _verify_generator_iteration(s, z, g_loss):
     fused pass on scratch gradients and on copies of the BatchNorm buffers must agree.  One host sync, once per state."""
     import warnings
 
-    if not (_K7 and s.skip) or torch.cuda.is_current_stream_capturing():
+    if not (_k7() and s.skip) or torch.cuda.is_current_stream_capturing():
         return
     plans = _generator_iteration_plans(s, z)
     if plans is None or plans[0].step_verified or getattr(plans[0], "step_failed", False):
@@ -528,7 +535,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
             fake_imgs = _generator_nograd(s, z)
     else:
         fake_imgs = s.G(z)
-    plan = _critic_plan(s, real_imgs, fake_imgs) if (_K7 and s.skip) else None
+    plan = _critic_plan(s, real_imgs, fake_imgs) if (_k7() and s.skip) else None
     if plan is not None and alpha is None:  # the host draw of wgan_gp.py:122, where the reference makes it
         alpha = _dev(np.random.random((real_imgs.shape[0], 1, 1, 1)), real_imgs.device)
     grads = [p.grad for p in plan.params] if plan is not None else []
@@ -548,7 +555,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
     if i % s.n_critic == 0:
         s.dp.wait(s.opt_D)  # the generator step reads the critic that was just updated (wgan_gp.py:186)
-        g_loss = _generator_iteration_fused(s, z) if (_K7 and s.skip) else None
+        g_loss = _generator_iteration_fused(s, z) if (_k7() and s.skip) else None
         if g_loss is None:
             fake_imgs = s.G(z)
             with frozen(s.D, enabled=s.skip):

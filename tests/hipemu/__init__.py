@@ -45,6 +45,10 @@ def load(only=None):
     lib.hipemu_add_coresident_kernel(b"mlp_fused_fwd_kernel")
     lib.hipemu_add_coresident_kernel(b"mlp_fused_bwd_kernel")
     lib.hipemu_launch_count.restype = ctypes.c_long
+    lib.hipemu_set_wave_schedule.argtypes = [ctypes.c_int, ctypes.c_uint]
+    # HIPEMU_SCHED = fwd | rev | rand[:seed]: the order in which a workgroup's waves run between synchronisation points
+    sched = os.environ.get("HIPEMU_SCHED", "fwd").split(":")
+    lib.hipemu_set_wave_schedule({"fwd": 0, "rev": 1, "rand": 2}[sched[0]], int(sched[1]) if len(sched) > 1 else 1)
     lib.hipemu_count_grids.argtypes = [ctypes.c_int]
     if only is None:
         _LIB = lib

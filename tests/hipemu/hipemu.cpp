@@ -4,6 +4,7 @@
 // workgroup's static LDS).  hipemu_set_coresident(1): one OS thread per workgroup, all alive at once (grid-wide waits).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -78,6 +79,12 @@ static std::atomic<int> g_coresident{0};
 static std::atomic<int> g_threads{0};
 static std::atomic<bool> g_abort{false};
 static std::atomic<bool> g_cores_now{false};  // the launch in flight runs one OS thread per workgroup
+// Wave schedule of a workgroup's scheduler pass: 0 = waves in index order, 1 = reversed, 2 = a fresh pseudo-random permutation in
+// every pass (seeded).  Lanes of a wave always run in lane order.  Two waves that touch the same LDS / global word between the same
+// pair of barriers (a missing __syncthreads: the one thing a switch-at-sync-points model cannot see in ONE order) compute different
+// results under different orders; tests/test_kernels_emu_cpu.py::test_results_do_not_depend_on_the_wave_schedule compares them bit for bit.
+static std::atomic<int> g_sched_mode{0};
+static std::atomic<unsigned> g_sched_seed{1};
 
 void note_error(const char* what) {
     std::lock_guard<std::mutex> lk(g_msg_mu);
@@ -225,14 +232,26 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
     unsigned long last_progress = w.progress;
     long idle_passes = 0;
     auto t_idle = std::chrono::steady_clock::now();
+    const int sched = g_sched_mode.load(std::memory_order_relaxed);
+    std::vector<size_t> order(nw);
+    for (size_t i = 0; i < nw; ++i) order[i] = sched == 1 ? nw - 1 - i : i;
+    uint64_t rng = 0x9E3779B97F4A7C15ull * (g_sched_seed.load() + 1) + 0xD1B54A32D192ED03ull * (bid.x + 131u * bid.y + 17161u * bid.z + 1);
     while (w.live > 0) {
-        for (size_t t = 0; t < nt; ++t) {
-            Fiber& f = w.fibers[t];
-            if (f.done) continue;
-            w.running = &f;
-            cur = &f.ctx;
-            hipemu_switch(&w.sched_sp, f.sp);
-        }
+        if (sched == 2)
+            for (size_t i = nw; i > 1; --i) {  // Fisher-Yates with xorshift64*
+                rng ^= rng >> 12;
+                rng ^= rng << 25;
+                rng ^= rng >> 27;
+                std::swap(order[i - 1], order[(size_t)((rng * 0x2545F4914F6CDD1Dull) >> 33) % i]);
+            }
+        for (size_t oi = 0; oi < nw; ++oi)
+            for (size_t t = order[oi] * 64, te = std::min(nt, t + 64); t < te; ++t) {
+                Fiber& f = w.fibers[t];
+                if (f.done) continue;
+                w.running = &f;
+                cur = &f.ctx;
+                hipemu_switch(&w.sched_sp, f.sp);
+            }
         if (w.progress != last_progress) {
             last_progress = w.progress;
             idle_passes = 0;
@@ -360,6 +379,10 @@ extern "C" __attribute__((visibility("default"))) void hipemu_add_coresident_ker
     hipemu::g_cores_kernels.emplace_back(substr);
 }
 extern "C" __attribute__((visibility("default"))) void hipemu_set_coresident(int on) { hipemu::g_coresident.store(on); }
+extern "C" __attribute__((visibility("default"))) void hipemu_set_wave_schedule(int mode, unsigned seed) {
+    hipemu::g_sched_mode.store(mode);
+    hipemu::g_sched_seed.store(seed);
+}
 extern "C" __attribute__((visibility("default"))) void hipemu_set_threads(int n) { hipemu::g_threads.store(n); }
 extern "C" __attribute__((visibility("default"))) const char* hipemu_last_message() {
     std::lock_guard<std::mutex> lk(hipemu::g_msg_mu);

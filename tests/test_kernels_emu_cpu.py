@@ -473,6 +473,95 @@ def test_step_plans_belong_to_the_step_state(emu):
         assert ref() is None, "a step state's plans outlived it"
 
 
+def test_selfcheck_cases_select_the_staged_kernels(emu):
+    """pytorch_gan_amd/selfcheck.py (the hardware self-check of the kernels written without GPU time): run on the execution
+    model, its cases must really launch every staged kernel AND the kernel each one replaces, agree, and leave all bits set."""
+    import hipemu.host
+    from pytorch_gan_amd import selfcheck
+
+    with hipemu.host.emulated_device() as lib:
+        lib.migan_staged(0, 63)
+        lib.hipemu_reset_counts()
+        assert selfcheck.run_in_process("cpu") == 63
+        rep = selfcheck.report()
+        assert {k: rep[k] for k in selfcheck.BITS} == {k: "ok" for k in selfcheck.BITS}, rep
+        assert lib.migan_staged(0, 0) == 63
+        for sym in (b"thin_conv_wave_kernel", b"thin_conv_kernel", b"smallk_tile_kernel<K, 16>", b"smallk_tile_kernel<K, 128>",
+                    b"midk_tile_kernel", b"wgrad_reduce_tr_kernel", b"wgrad_reduce_kernel", b"pack_transpose_kernel",
+                    b"permute4_kernel", b"norm_small_fwd_kernel", b"norm_small_bwd_kernel", b"norm_partial_kernel"):
+            assert lib.hipemu_launch_count(sym) > 0, sym
+        worst = max(v for d in selfcheck.detail().values() for v in d.values())
+        assert worst < 1e-5, selfcheck.detail()   # staged and replaced kernels differ by summation order only
+
+
+@pytest.mark.parametrize("broken,bit", [("migan_norm_fwd_small", "norm_small"), ("migan_permute4d", "pack_transpose")])
+def test_selfcheck_takes_a_disagreeing_kernel_out_of_service(emu, broken, bit):
+    """A staged kernel that computes something else on the hardware than the kernel it replaces (simulated: the C entry's
+    output is perturbed whenever the staged bit is set) loses its bit, is named in the report, and the others stay."""
+    import hipemu.host
+    from pytorch_gan_amd import functional, selfcheck
+
+    with hipemu.host.emulated_device() as lib:
+        lib.migan_staged(0, 63)
+        real = getattr(lib, broken)
+
+        class Proxy:
+            def __getattr__(self, name):
+                return getattr(lib, name)
+
+            def __init__(self):
+                def wrong(*a):
+                    rc = real(*a)
+                    if lib.migan_staged(0, 0) & selfcheck.BITS[bit]:
+                        n = 64   # corrupt the first floats of the output (argument 1 of both entries)
+                        buf = (__import__("ctypes").c_float * n).from_address(a[1])
+                        for i in range(n):
+                            buf[i] += 1.0
+                    return rc
+
+                self.__dict__[broken] = wrong
+
+        saved = functional.lib
+        functional.lib = Proxy()
+        events = []
+        try:
+            keep = selfcheck.run_in_process("cpu", log=lambda ev, name, **kw: events.append((ev, name, kw.get("ok"))))
+        finally:
+            functional.lib = saved
+        rep = selfcheck.report()
+        assert keep == 63 & ~selfcheck.BITS[bit]
+        assert rep[bit].startswith("disabled: differs from the kernel it replaces"), rep
+        assert all(rep[k] == "ok" for k in selfcheck.BITS if k != bit), rep
+        assert ("end", bit, False) in events and ("begin", "combined", None) in events and ("end", "combined", True) in events
+        assert lib.migan_staged(0, 0) == 63 & ~selfcheck.BITS[bit]
+        lib.migan_staged(0, 63)
+
+
+def test_selfcheck_probe_stages_on_the_execution_model(emu):
+    """What the probe process does once it has a device - per-kernel comparisons, then (MIGAN_EMU_SLOW=1: 3 min) the pix2pix
+    step with and without the staged kernels, then twelve WGAN-GP iterations on the persistent kernels - and the log it leaves:
+    fed to probe() it must give the full verdict, all three persistent guards verified."""
+    import hipemu.host
+    from pytorch_gan_amd import selfcheck
+
+    slow = os.environ.get("MIGAN_EMU_SLOW") == "1"
+    stages = ["bits"] + (["workload"] if slow else []) + ["persistent"]
+    with hipemu.host.emulated_device() as lib:
+        lib.migan_staged(0, 63)
+        records = [{"event": "begin", "name": "device"}, {"event": "end", "name": "device", "ok": True}]
+        keep = selfcheck._probe_stages(torch.device("cpu"), 63, 0, stages,
+                                       lambda ev, name, **kw: records.append(dict(kw, event=ev, name=name)), lambda: None)
+        records.append({"event": "end", "name": "probe", "ok": True})
+        assert keep == 63 and lib.migan_staged(0, 0) == 63
+
+    def spawn(index, start, known_ok, asked, timeout):
+        return ([r for r in records if r["name"] != "workload"] + [{"event": "begin", "name": "workload"},
+                {"event": "end", "name": "workload", "ok": True}] if not slow else records), "exit 0"
+
+    v = selfcheck.probe(0, 63, True, spawn=spawn)
+    assert v["bits"] == 63 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
+
+
 def test_smoke_body_on_the_execution_model(emu, capsys):
     """__graft_entry__.smoke() - the driver's first call on the GPU box - with its kernels on the execution model."""
     import __graft_entry__ as entry

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close, rel_fro
+from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close, in_service, rel_fro
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -400,6 +400,9 @@ def test_instancenorm_with_fused_dropout(pg, cfg):
     gy = _leaf(N, C, H, W, seed=2)
     y_ref.backward(gy)
     xg = x.detach().to(DEV).requires_grad_(True)
+    why = in_service("norm_small")
+    if why is not None:
+        pytest.xfail("the one-launch normalisation is not in service on this device - " + why)
     assert F.norm_small_takes(xg, True)
     y = F.norm(xg, None, None, None, None, None, True, 0.1, 1e-5, True, act, 0.2, mask=mask.to(DEV))
     y.backward(gy.to(DEV))

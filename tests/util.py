@@ -50,6 +50,18 @@ def gpu_copy(model, device=None):
     return m.to(device)
 
 
+def in_service(kernel):
+    """None when `kernel` (a key of pytorch_gan_amd.selfcheck.report()) is in service on this device, else why not.  Obtains
+    the hardware self-check's verdict if this process has not yet.  Tests that are ABOUT a staged kernel xfail with this text
+    when the hardware took it out of service (the kernel it replaces ran and the parity assertions still hold)."""
+    from pytorch_gan_amd import selfcheck
+
+    if selfcheck.PENDING and torch.cuda.is_available():
+        selfcheck.ensure()
+    txt = selfcheck.report().get(kernel, "unknown kernel")
+    return None if txt.startswith("ok") or (txt == "not run" and not selfcheck.PENDING) else "%s: %s" % (kernel, txt)
+
+
 def load_golden(golden_dir, name):
     import os
 
