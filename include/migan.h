@@ -29,7 +29,7 @@ const char* migan_error_string(int code);
 /* Staged-kernel switchboard.  Kernels that entered the tree without hardware time carry one bit each (1 thin_conv_wave - PatchGAN
  * heads, cyclegan/models.py:118 pix2pix/models.py:127; 2 wgrad_reduce_tr; 4 midk_tile - first convs of the image nets,
  * pix2pix/models.py:23,115; 8 norm_small - nn.InstanceNorm2d at <= 1024 pixels, pix2pix/models.py:25,42; 16 smallk_tile<K,16>;
- * 32 pack_transpose).  A bit starts from its MIGAN_* environment variable (unset = on).  Clears, then sets, the named bits and
+ * 32 pack_transpose; 64 the few-pixel conv path of csrc/fewpix.hip).  A bit starts from its MIGAN_* environment variable (unset = on).  Clears, then sets, the named bits and
  * returns the word; migan_staged(0, 0) reads it.  The host mirror's hardware self-check (pytorch_gan_amd/selfcheck.py) clears the
  * bit of a kernel that disagrees with the kernel it replaces.  No reference counterpart: torch selects its ATen kernels internally. */
 unsigned migan_staged(unsigned clear_bits, unsigned set_bits);
@@ -87,6 +87,21 @@ int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int 
 int migan_skinny_tn_ok(int M, int N, int K);
 int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, int accumulate,
                     int db_accumulate, void* stream);
+
+/* Few-pixel convolutions (csrc/fewpix.hip): nn.Conv2d / nn.ConvTranspose2d with <= 64 pixel rows and >= 1 M weights - the inner
+ * U-Net levels of pix2pix/models.py:62-71 at the reference's batch 1 (512->512 and 1024->512, 4x4 stride 2, at 8x8 ... 1x1).
+ * torch runs them as ATen convolution / convolution_backward; here every product is one of the skinny GEMMs above on the weight in
+ * its STORED layout (Conv2d [Co][Ci*R*S], ConvTranspose2d [Ci][Co*R*S]) around these two index kernels - no weight packs, no
+ * split-K slabs, no reduction launches.  migan_fewpix_ok: rows = N*Ho*Wo (Conv2d) or N*Hin*Win (ConvTranspose2d), n / k = the
+ * weight's leading dimension / the product of its trailing ones; 0 unless bit 64 of migan_staged() is set.
+ * migan_im2col_small: col[N*Ho*Wo][C*R*S] (column (c, r, s)) of x[N][H][W][C] (NHWC) for taps at h = ho*stride - pt + r.
+ * migan_col2im_small: the adjoint, out[N][H][W][J] = act(bias + sum of ycol[(n,ho,wo)][(j,r,s)] over the taps that land on
+ * (h, w)) in a fixed order; bias may be NULL. */
+int migan_fewpix_ok(int rows, int n, int k);
+int migan_im2col_small(const float* x, float* col, int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pt,
+                       int pl, void* stream);
+int migan_col2im_small(const float* ycol, const float* bias, float* out, int N, int H, int W, int J, int Ho, int Wo, int R, int S,
+                       int stride, int pt, int pl, int act, float slope, void* stream);
 
 /* K7 (csrc/critic_fused.hip): one WGAN-GP critic iteration of the MLP critic in ONE persistent launch - replaces, for
  * wgan_gp.py:68-83 (Discriminator), :119-138 (compute_gradient_penalty, incl. autograd.grad(create_graph=True)) and :160-176

@@ -69,12 +69,13 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
 // (pytorch_gan_amd/selfcheck.py) takes a staged kernel out of service when it disagrees with the kernel it replaces.
 enum {
     STG_THIN_WAVE = 1, STG_WGRAD_REDUCE_TR = 2, STG_MIDK = 4, STG_NORM_SMALL = 8, STG_SMALLK_PB16 = 16, STG_PACK_TR = 32,
-    STG_ALL = 63
+    STG_FEWPIX = 64, STG_ALL = 127
 };
 inline unsigned staged_from_env() {
     static const struct { const char* var; unsigned bit; } tab[] = {
         {"MIGAN_THIN_WAVE", STG_THIN_WAVE}, {"MIGAN_WGRAD_REDUCE_TR", STG_WGRAD_REDUCE_TR}, {"MIGAN_MIDK", STG_MIDK},
-        {"MIGAN_NORM_SMALL", STG_NORM_SMALL}, {"MIGAN_SMALLK_PB16", STG_SMALLK_PB16}, {"MIGAN_PACK_TR", STG_PACK_TR}};
+        {"MIGAN_NORM_SMALL", STG_NORM_SMALL}, {"MIGAN_SMALLK_PB16", STG_SMALLK_PB16}, {"MIGAN_PACK_TR", STG_PACK_TR},
+        {"MIGAN_FEWPIX", STG_FEWPIX}};
     unsigned bits = 0;
     for (const auto& t : tab) {
         const char* v = getenv(t.var);

@@ -1,0 +1,106 @@
+// Convolutions with a handful of pixels and megabytes of weights: the inner levels of the pix2pix U-Net at batch 1
+// (pix2pix/models.py:62-71: Conv2d / ConvTranspose2d 512->512 and 1024->512, 4x4 stride 2, at 8x8 ... 1x1 pixels - 16.8 and
+// 33.5 MB of weights per layer against 1-64 pixels).  They are weight STREAMS, not GEMM tiles: the tiled kernels spend them on
+// OHWI / IHWO packs of the weight (read + write 2 x 16.8 MB per layer and step), a split-K forward, a split-K input gradient, 17-34 MB
+// of weight-gradient slabs and their reduction.  Here every product is one of the <= 64-row skinny GEMMs of skinny_mm.hip on the
+// weight IN ITS STORED torch LAYOUT (no pack, no slab, no reduction launch), around two small index kernels:
+//
+//   Conv2d forward          col = im2col(x)            [M_out][Ci*T]   y  = act(col W^T + b)        skinny_nt, W as [Co][Ci*T]
+//   Conv2d input gradient   ycol = dy W                [M_out][Ci*T]   dx = col2im(ycol)            skinny_nn
+//   Conv2d weight gradient  dW (+)= dy^T col           [Co][Ci*T]                                   skinny_tn (col kept from the forward)
+//   ConvTranspose2d forward ycol = x W                 [M_in][Co*T]    y  = act(col2im(ycol) + b)   skinny_nn, W as [Ci][Co*T]
+//   ConvTranspose2d dgrad   dycol = im2col(dy)         [M_in][Co*T]    dx = dycol W^T               skinny_nt
+//   ConvTranspose2d wgrad   dW (+)= x^T dycol          [Ci][Co*T]                                   skinny_tn
+//
+// (T = R*S taps; column order (channel, tap) = the weight's own trailing dimensions.)  The col matrices are at most
+// 64 x 16384 floats (4 MB, L2 / MALL resident); the weights are read once per product at streaming rates.
+// Written without hardware time: behind bit 64 of migan_staged() (STG_FEWPIX), verified on the host execution model and, on the
+// device, by pytorch_gan_amd/selfcheck.py against the tiled kernels it replaces.
+#include "common.h"
+
+// col[m][c*T + t] = x[n][ho*stride - pt + r][wo*stride - pl + s][c]  (0 outside the image); m = (n*Ho + ho)*Wo + wo, t = r*S + s.
+// One thread per element of col, consecutive threads = consecutive columns: the stores are contiguous, the loads hit a <= 64-pixel
+// (cache-resident) source.
+__global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ x, float* __restrict__ col, int H, int W, int C,
+                                                           int Ho, int Wo, int R, int S, int stride, int pt, int pl, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int T = R * S, K = C * T;
+    const int m = (int)(idx / K), k = (int)(idx - (long)m * K);
+    const int c = k / T, t = k - c * T;
+    const int r = t / S, s = t - r * S;
+    const int wo = m % Wo, q = m / Wo;
+    const int ho = q % Ho, n = q / Ho;
+    const int h = ho * stride - pt + r, w = wo * stride - pl + s;
+    float v = 0.f;
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[(((long)n * H + h) * W + w) * C + c];
+    col[idx] = v;
+}
+
+// out[n][h][w][j] = act(bias[j] + sum over taps t = (r, s) and pixels (ho, wo) with ho*stride - pt + r == h, wo*stride - pl + s == w
+//                                 of ycol[(n*Ho + ho)*Wo + wo][j*T + t]),   taps in increasing order (deterministic).
+// One thread per output element, consecutive threads = consecutive channels j.
+__global__ __launch_bounds__(256) void col2im_small_kernel(const float* __restrict__ ycol, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int H, int W, int J, int Ho, int Wo, int R, int S,
+                                                           int stride, int pt, int pl, int act, float slope, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int T = R * S;
+    const int j = (int)(idx % J);
+    const long p = idx / J;
+    const int w = (int)(p % W);
+    const long q = p / W;
+    const int h = (int)(q % H), n = (int)(q / H);
+    float acc = bias ? bias[j] : 0.f;
+    for (int r = 0; r < R; ++r) {
+        const int hn = h + pt - r;
+        if (hn < 0 || hn % stride != 0) continue;
+        const int ho = hn / stride;
+        if (ho >= Ho) continue;
+        for (int s = 0; s < S; ++s) {
+            const int wn = w + pl - s;
+            if (wn < 0 || wn % stride != 0) continue;
+            const int wo = wn / stride;
+            if (wo >= Wo) continue;
+            acc += ycol[(((long)n * Ho + ho) * Wo + wo) * ((long)J * T) + (long)j * T + r * S + s];
+        }
+    }
+    out[idx] = act_apply(acc, act, slope);
+}
+
+// 1 when a conv whose GEMM has `rows` pixel rows (Conv2d: N*Ho*Wo output pixels; ConvTranspose2d: N*Hin*Win input pixels),
+// `n` = the weight's leading dimension (Conv2d: Co; ConvTranspose2d: Ci) and `k` = the product of its trailing ones takes this
+// path: the staged bit is set, the three skinny GEMM forms take the shape, and the weight is large enough to be a stream.
+MIGAN_API int migan_fewpix_ok(int rows, int n, int k) {
+    return staged_on(STG_FEWPIX) && rows >= 1 && rows <= 64 && n % 16 == 0 && n >= 16 && k % 64 == 0 && k >= 1024 &&
+                   (long)n * k >= (1L << 20)
+               ? 1
+               : 0;
+}
+
+// im2col of an NHWC image batch x[N][H][W][C] for a conv R x S / stride / pads (pt, pl) with Ho x Wo output pixels:
+// col[N*Ho*Wo][C*R*S], column (c, r, s).  Conv2d forward operand (pix2pix/models.py:23) and the dy operand of ConvTranspose2d's
+// gradients (pix2pix/models.py:39: there (H, W) is the transposed conv's OUTPUT and (Ho, Wo) its input).
+MIGAN_API int migan_im2col_small(const float* x, float* col, int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride,
+                                 int pt, int pl, void* stream) {
+    if (N < 1 || H < 1 || W < 1 || C < 1 || Ho < 1 || Wo < 1 || R < 1 || S < 1 || stride < 1) return (int)hipErrorInvalidValue;
+    const long total = (long)N * Ho * Wo * C * R * S;
+    if (total >= (1L << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(im2col_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, x, col, H, W, C, Ho,
+                       Wo, R, S, stride, pt, pl, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// The adjoint: out[N][H][W][J] = act(bias + col2im(ycol[N*Ho*Wo][J*R*S])).  Conv2d input gradient (bias NULL, act 0) and
+// ConvTranspose2d forward (its output is the (H, W) side).
+MIGAN_API int migan_col2im_small(const float* ycol, const float* bias, float* out, int N, int H, int W, int J, int Ho, int Wo, int R,
+                                 int S, int stride, int pt, int pl, int act, float slope, void* stream) {
+    if (N < 1 || H < 1 || W < 1 || J < 1 || Ho < 1 || Wo < 1 || R < 1 || S < 1 || stride < 1) return (int)hipErrorInvalidValue;
+    const long total = (long)N * H * W * J;
+    if (total >= (1L << 31) || (long)N * Ho * Wo * J * R * S >= (1L << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(col2im_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, ycol, bias, out, H,
+                       W, J, Ho, Wo, R, S, stride, pt, pl, act, slope, total);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

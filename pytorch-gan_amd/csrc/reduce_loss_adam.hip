@@ -354,7 +354,7 @@ MIGAN_API const char* migan_version() { return "migan 0.1 gfx950"; }
 
 // ---- staged-kernel switchboard (common.h) -----------------------------------------------------------------------------
 // Clear, then set, bits of the staged-kernel word (STG_* of common.h: 1 thin_conv_wave, 2 wgrad_reduce_tr, 4 midk_tile, 8 norm_small,
-// 16 smallk_tile<K,16>, 32 pack_transpose); returns the word afterwards.  migan_staged(0, 0) reads it.  Host-side state only: call it
+// 16 smallk_tile<K,16>, 32 pack_transpose, 64 fewpix conv path); returns the word afterwards.  migan_staged(0, 0) reads it.  Host-side state only: call it
 // between launches, not while another thread is queueing them.
 MIGAN_API unsigned migan_staged(unsigned clear_bits, unsigned set_bits) {
     std::atomic<unsigned>& w = staged_word();

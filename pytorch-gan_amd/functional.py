@@ -510,6 +510,22 @@ class _Conv2d(Function):
         Ho, Wo = _conv_out(HL, pt, pb, R, stride), _conv_out(WL, pl, pr, S, stride)
         if Ho <= 0 or Wo <= 0:
             raise ValueError("conv2d: empty output")
+        ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
+        ctx.has_bias = b is not None
+        ctx.params = (w_in, b_in)
+        ctx.toep = ctx.few = False
+        if (gather == GATHER_ZERO and mask is None and stats_buf is None and w.is_contiguous()
+                and lib.migan_fewpix_ok(N * Ho * Wo, Co, Ci * R * S) == 1):
+            # a handful of output pixels against megabytes of weights (inner U-Net levels, pix2pix/models.py:62-67 at batch 1):
+            # im2col (<= 64 rows) + the skinny GEMM on the weight as stored - no OHWI pack, no split-K (csrc/fewpix.hip)
+            M, K, st = N * Ho * Wo, Ci * R * S, _stream()
+            col = torch.empty((M, K), device=xs.device, dtype=torch.float32)
+            check(lib.migan_im2col_small(xs.data_ptr(), col.data_ptr(), N, H, W, Ci, Ho, Wo, R, S, stride, pt, pl, st), "im2col_small")
+            y = _empty_nhwc((N, Co, Ho, Wo), xs)
+            check(lib.migan_skinny_nt(col.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), M, Co, K, act, slope, st), "fewpix_conv_fwd")
+            ctx.few = True
+            ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, col)
+            return y
         wp = _packed_perm(w_in, w, "ohwi", (0, 2, 3, 1))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
         if mask is not None:
@@ -533,21 +549,42 @@ class _Conv2d(Function):
             check(lib.migan_conv2d_fwd_ws(xs.data_ptr(), wp.data_ptr(), _ptr(b), _ptr(mask), y.data_ptr(), N, H, W, Ci, Ho,
                                           Wo, Co, R, S, stride, pt, pl, gather, act, slope, skp, skb, _stream()),
                   "conv2d_fwd" if mask is None else "conv2d_dropout_fwd")
-        ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
-        ctx.has_bias = b is not None
-        ctx.params = (w_in, b_in)
         ctx.toep = toep
-        ctx.save_for_backward(xs, w, y if (act != ACT_NONE or mask is not None) else None, mask)
+        ctx.save_for_backward(xs, w, y if (act != ACT_NONE or mask is not None) else None, mask, None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xs, w, y, mask = ctx.saved_tensors
+        xs, w, y, mask, col = ctx.saved_tensors
         N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
         if torch.is_grad_enabled():
             return _Conv2d._backward_differentiable(ctx, dy, xs, w, y, mask)
         dy = to_nhwc(dy)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.few:   # few-pixel path (csrc/fewpix.hip): both gradients from skinny GEMMs on the stored weight / the kept im2col
+            if act != ACT_NONE:
+                dy = _act_bwd_raw(dy, y, act, slope)
+            M, K, st = N * Ho * Wo, Ci * R * S, _stream()
+            dx = dw = db = None
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.params[0])
+                dwt = torch.empty_like(w) if slot is None else slot
+                dbp, dba = None, 0
+                if want_db:
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                    dbp, want_db = dbt.data_ptr(), False
+                check(lib.migan_skinny_tn(dy.data_ptr(), col.data_ptr(), dwt.data_ptr(), dbp, M, Co, K, 0 if slot is None else 1,
+                                          dba, st), "fewpix_conv_wgrad")
+                dw = dwt if slot is None else None
+            if want_db:
+                db = _colsum(dy, M, Co, _grad_slot(ctx.params[1]))
+            if ctx.needs_input_grad[0]:
+                ycol = torch.empty((M, K), device=xs.device, dtype=torch.float32)
+                check(lib.migan_skinny_nn(dy.data_ptr(), w.data_ptr(), ycol.data_ptr(), M, Co, K, st), "fewpix_conv_dgrad")
+                dx = _empty_nhwc((N, Ci, H, W), xs)
+                check(lib.migan_col2im_small(ycol.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, R, S, stride, pt, pl, 0, 0.0,
+                                             st), "col2im_small")
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
         # (this conv's activation backward, or the norm layer behind the conv) and reduced inside the wgrad launch
         side = None
@@ -919,14 +956,27 @@ class _ConvTranspose2d(Function):
             raise ValueError("conv_transpose2d: weight expects %d input channels, got %d" % (Cinw, Cin))
         Hout = (Hin - 1) * stride - 2 * pad + R
         Wout = (Win - 1) * stride - 2 * pad + S
+        ctx.geom = (N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope)
+        ctx.has_bias = b is not None
+        ctx.few = False
+        if w.is_contiguous() and lib.migan_fewpix_ok(N * Hin * Win, Cin, Cout * R * S) == 1:
+            # a handful of INPUT pixels against megabytes of weights (pix2pix/models.py:68-71 at batch 1): ycol = x W on the weight
+            # as stored ([Cin][Cout*R*S]), then the col2im sum with bias and activation (csrc/fewpix.hip) - no IHWO pack, no split-K
+            M, K, st = N * Hin * Win, Cout * R * S, _stream()
+            ycol = torch.empty((M, K), device=xs.device, dtype=torch.float32)
+            check(lib.migan_skinny_nn(xs.data_ptr(), w.data_ptr(), ycol.data_ptr(), M, Cin, K, st), "fewpix_convT_fwd")
+            y = _empty_nhwc((N, Cout, Hout, Wout), xs)
+            check(lib.migan_col2im_small(ycol.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin, Win, R, S, stride, pad, pad,
+                                         act, slope, st), "col2im_small")
+            ctx.few = True
+            ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
+            return y
         # [Cout][R][S][Cin] == w_ihwo of the transposed-role conv
         wp = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
         y = _empty_nhwc((N, Cout, Hout, Wout), xs)
         skp, skb = _splitk_ws(xs, N * -(-Hout // stride) * -(-Wout // stride), Cout, Cin, stride * stride)
         check(lib.migan_conv2d_dgrad_ws(xs.data_ptr(), wp.data_ptr(), _ptr(b), y.data_ptr(), N, Hout, Wout, Cout, Hin,
                                         Win, Cin, R, S, stride, pad, pad, act, slope, skp, skb, _stream()), "convT_fwd")
-        ctx.geom = (N, Cin, Hin, Win, Cout, Hout, Wout, R, S, stride, pad, act, slope)
-        ctx.has_bias = b is not None
         ctx.save_for_backward(xs, w, y if act != ACT_NONE else None)
         return y
 
@@ -939,6 +989,24 @@ class _ConvTranspose2d(Function):
         if act != ACT_NONE:
             dy = _act_bwd_raw(dy, y, act, slope)
         dx = dw = db = None
+        if ctx.few:   # few-pixel path: dycol = im2col(dy) once, then dx = dycol W^T and dW (+)= x^T dycol on the stored weight
+            M, K, st = N * Hin * Win, Cout * R * S, _stream()
+            dycol = torch.empty((M, K), device=xs.device, dtype=torch.float32)
+            check(lib.migan_im2col_small(dy.data_ptr(), dycol.data_ptr(), N, Hout, Wout, Cout, Hin, Win, R, S, stride, pad, pad, st),
+                  "im2col_small")
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.params[0])
+                dwt = torch.empty_like(w) if slot is None else slot
+                check(lib.migan_skinny_tn(xs.data_ptr(), dycol.data_ptr(), dwt.data_ptr(), None, M, Cin, K, 0 if slot is None else 1,
+                                          0, st), "fewpix_convT_wgrad")
+                dw = dwt if slot is None else None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
+            if ctx.needs_input_grad[0]:
+                dx = _empty_nhwc((N, Cin, Hin, Win), xs)
+                check(lib.migan_skinny_nt(dycol.data_ptr(), w.data_ptr(), None, dx.data_ptr(), M, Cin, K, ACT_NONE, 0.0, st),
+                      "fewpix_convT_dgrad")
+            return dx, dw, db, None, None, None, None
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:
             st = _stream()

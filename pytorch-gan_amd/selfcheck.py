@@ -36,10 +36,12 @@ import torch
 
 from ._lib import lib
 
-BITS = {"thin_conv_wave": 1, "wgrad_reduce_tr": 2, "midk_tile": 4, "norm_small": 8, "smallk_tile16": 16, "pack_transpose": 32}
+BITS = {"thin_conv_wave": 1, "wgrad_reduce_tr": 2, "midk_tile": 4, "norm_small": 8, "smallk_tile16": 16, "pack_transpose": 32,
+        "fewpix_conv": 64}
 ENV = {"thin_conv_wave": "MIGAN_THIN_WAVE", "wgrad_reduce_tr": "MIGAN_WGRAD_REDUCE_TR", "midk_tile": "MIGAN_MIDK",
-       "norm_small": "MIGAN_NORM_SMALL", "smallk_tile16": "MIGAN_SMALLK_PB16", "pack_transpose": "MIGAN_PACK_TR"}
-ALL = 63
+       "norm_small": "MIGAN_NORM_SMALL", "smallk_tile16": "MIGAN_SMALLK_PB16", "pack_transpose": "MIGAN_PACK_TR",
+       "fewpix_conv": "MIGAN_FEWPIX"}
+ALL = 127
 
 PENDING = os.environ.get("MIGAN_SELFCHECK", "1") != "0"   # read by functional.conv2d / norm / weight_cache_scope
 # Until the verdict is in, no staged kernel is selectable at all (a hipGraph captured before any eager call would otherwise
@@ -80,6 +82,12 @@ _CONV = [
     ("first_conv_3ch", (2, 3, 24, 24, 64, 3, 1, (1, 1, 1, 1), 0, 0, True), 1e-4),    # midk_tile, K = 27
     ("unet_inner", (1, 512, 4, 4, 512, 4, 2, (1, 1, 1, 1), 0, 0, True), 1e-4),       # wgrad_reduce_tr (4 M weights), pack_transpose
     ("unet_mid", (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4),      # pack_transpose (512 k), wgrad slabs
+    ("fewpix_16px", (1, 128, 8, 8, 512, 4, 2, (1, 1, 1, 1), 0, 1, True), 1e-4),      # fewpix conv: 16 rows, K = 2048, bias + LeakyReLU
+    ("fewpix_1px", (1, 256, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4),      # fewpix conv: ONE output pixel (d8 of the U-Net)
+]
+_CONVT = [   # N, Cin, H, W, Cout, act, bias: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1) | what the geometry selects
+    ("fewpix_convT_4px", (1, 512, 2, 2, 128, 2, True), 1e-4),                        # fewpix transposed conv: 4 input pixels, ReLU
+    ("fewpix_convT_1px", (1, 512, 1, 1, 256, 0, False), 1e-4),                       # u1 of the U-Net: 1 -> 2x2
 ]
 _NORM = [   # N, C, H, W, act, affine, mask, residual
     ("in_4x4", (1, 512, 4, 4, 0, False, False, False), 1e-4),
@@ -94,6 +102,20 @@ def _run_conv(F, case, gen):
     w = _rand(gen, Co, Ci, k, k, scale=0.1).requires_grad_(True)
     b = _rand(gen, Co).requires_grad_(True) if bias else None
     y = F.conv2d(x, w, b, stride, pads, gather, act, 0.2)
+    gy = _rand(gen, *y.shape)
+    y.backward(gy)
+    out = {"y": y.detach(), "dx": x.grad, "dw": w.grad}
+    if bias:
+        out["db"] = b.grad
+    return {k_: torch.Tensor.contiguous(F._plain(v).detach().clone()) for k_, v in out.items()}
+
+
+def _run_convt(F, case, gen):
+    N, Cin, H, W, Cout, act, bias = case
+    x = _rand(gen, N, Cin, H, W).requires_grad_(True)
+    w = _rand(gen, Cin, Cout, 4, 4, scale=0.1).requires_grad_(True)
+    b = _rand(gen, Cout).requires_grad_(True) if bias else None
+    y = F.conv_transpose2d(x, w, b, 2, 1, act, 0.2)
     gy = _rand(gen, *y.shape)
     y.backward(gy)
     out = {"y": y.detach(), "dx": x.grad, "dw": w.grad}
@@ -125,6 +147,8 @@ def _run_norm(F, case, gen):
 def _all_cases(F):
     for name, case, tol in _CONV:
         yield name, tol, (lambda gen, c=case: _run_conv(F, c, gen))
+    for name, case, tol in _CONVT:
+        yield name, tol, (lambda gen, c=case: _run_convt(F, c, gen))
     for name, case, tol in _NORM:
         yield name, tol, (lambda gen, c=case: _run_norm(F, c, gen))
 

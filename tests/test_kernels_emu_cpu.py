@@ -473,6 +473,26 @@ def test_step_plans_belong_to_the_step_state(emu):
         assert ref() is None, "a step state's plans outlived it"
 
 
+@pytest.mark.parametrize("which,cfg", [("test_fewpix_conv2d", (1, 512, 2, 2, 512, False, 1)), ("test_fewpix_conv2d", (2, 256, 4, 4, 256, True, 1)),
+                                       ("test_fewpix_conv2d", (3, 64, 6, 10, 1024, True, 2)),
+                                       ("test_fewpix_conv_transpose2d", (1, 1024, 2, 2, 512, False, 0)),
+                                       ("test_fewpix_conv_transpose2d", (4, 256, 4, 4, 256, True, 0)),
+                                       ("test_fewpix_conv_transpose2d", (2, 128, 5, 6, 512, False, 0))],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v[:5])))
+def test_fewpix_convs_on_the_execution_model(emu, which, cfg):
+    """csrc/fewpix.hip (Conv2d / ConvTranspose2d with <= 64 pixel rows and >= 1 M weights: the inner U-Net levels of pix2pix at
+    batch 1): the bodies of the GPU parity tests against torch, and what ran - the two index kernels around the skinny GEMMs on the
+    weight as stored: no weight pack, no tiled / split-K kernel, no weight-gradient slab reduction."""
+    import pytorch_gan_amd as pg
+
+    lib = _run_gpu_test_body("test_ops_gpu", which, pg, cfg)
+    assert lib.hipemu_launch_count(b"im2col_small_kernel") == 1 and lib.hipemu_launch_count(b"col2im_small_kernel") == 1
+    assert lib.hipemu_launch_count(b"skinny_nt_kernel") == 1 and lib.hipemu_launch_count(b"skinny_nn_kernel") == 1
+    assert lib.hipemu_launch_count(b"skinny_tn_kernel") == 1
+    for sym in (b"permute4_kernel", b"pack_transpose_kernel", b"igemm_", b"wgrad_", b"smallk_"):
+        assert lib.hipemu_launch_count(sym) == 0, sym
+
+
 def test_selfcheck_cases_select_the_staged_kernels(emu):
     """pytorch_gan_amd/selfcheck.py (the hardware self-check of the kernels written without GPU time): run on the execution
     model, its cases must really launch every staged kernel AND the kernel each one replaces, agree, and leave all bits set."""
@@ -480,15 +500,16 @@ def test_selfcheck_cases_select_the_staged_kernels(emu):
     from pytorch_gan_amd import selfcheck
 
     with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 63)
+        lib.migan_staged(0, 127)
         lib.hipemu_reset_counts()
-        assert selfcheck.run_in_process("cpu") == 63
+        assert selfcheck.run_in_process("cpu") == 127
         rep = selfcheck.report()
         assert {k: rep[k] for k in selfcheck.BITS} == {k: "ok" for k in selfcheck.BITS}, rep
-        assert lib.migan_staged(0, 0) == 63
+        assert lib.migan_staged(0, 0) == 127
         for sym in (b"thin_conv_wave_kernel", b"thin_conv_kernel", b"smallk_tile_kernel<K, 16>", b"smallk_tile_kernel<K, 128>",
                     b"midk_tile_kernel", b"wgrad_reduce_tr_kernel", b"wgrad_reduce_kernel", b"pack_transpose_kernel",
-                    b"permute4_kernel", b"norm_small_fwd_kernel", b"norm_small_bwd_kernel", b"norm_partial_kernel"):
+                    b"permute4_kernel", b"norm_small_fwd_kernel", b"norm_small_bwd_kernel", b"norm_partial_kernel",
+                    b"im2col_small_kernel", b"col2im_small_kernel", b"skinny_nt_kernel", b"skinny_nn_kernel", b"skinny_tn_kernel"):
             assert lib.hipemu_launch_count(sym) > 0, sym
         worst = max(v for d in selfcheck.detail().values() for v in d.values())
         assert worst < 1e-5, selfcheck.detail()   # staged and replaced kernels differ by summation order only
@@ -502,7 +523,7 @@ def test_selfcheck_takes_a_disagreeing_kernel_out_of_service(emu, broken, bit):
     from pytorch_gan_amd import functional, selfcheck
 
     with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 63)
+        lib.migan_staged(0, 127)
         real = getattr(lib, broken)
 
         class Proxy:
@@ -529,12 +550,12 @@ def test_selfcheck_takes_a_disagreeing_kernel_out_of_service(emu, broken, bit):
         finally:
             functional.lib = saved
         rep = selfcheck.report()
-        assert keep == 63 & ~selfcheck.BITS[bit]
+        assert keep == 127 & ~selfcheck.BITS[bit]
         assert rep[bit].startswith("disabled: differs from the kernel it replaces"), rep
         assert all(rep[k] == "ok" for k in selfcheck.BITS if k != bit), rep
         assert ("end", bit, False) in events and ("begin", "combined", None) in events and ("end", "combined", True) in events
-        assert lib.migan_staged(0, 0) == 63 & ~selfcheck.BITS[bit]
-        lib.migan_staged(0, 63)
+        assert lib.migan_staged(0, 0) == 127 & ~selfcheck.BITS[bit]
+        lib.migan_staged(0, 127)
 
 
 def test_selfcheck_probe_stages_on_the_execution_model(emu):
@@ -547,19 +568,19 @@ def test_selfcheck_probe_stages_on_the_execution_model(emu):
     slow = os.environ.get("MIGAN_EMU_SLOW") == "1"
     stages = ["bits"] + (["workload"] if slow else []) + ["persistent"]
     with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 63)
+        lib.migan_staged(0, 127)
         records = [{"event": "begin", "name": "device"}, {"event": "end", "name": "device", "ok": True}]
-        keep = selfcheck._probe_stages(torch.device("cpu"), 63, 0, stages,
+        keep = selfcheck._probe_stages(torch.device("cpu"), 127, 0, stages,
                                        lambda ev, name, **kw: records.append(dict(kw, event=ev, name=name)), lambda: None)
         records.append({"event": "end", "name": "probe", "ok": True})
-        assert keep == 63 and lib.migan_staged(0, 0) == 63
+        assert keep == 127 and lib.migan_staged(0, 0) == 127
 
     def spawn(index, start, known_ok, asked, timeout):
         return ([r for r in records if r["name"] != "workload"] + [{"event": "begin", "name": "workload"},
                 {"event": "end", "name": "workload", "ok": True}] if not slow else records), "exit 0"
 
-    v = selfcheck.probe(0, 63, True, spawn=spawn)
-    assert v["bits"] == 63 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
+    v = selfcheck.probe(0, 127, True, spawn=spawn)
+    assert v["bits"] == 127 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
 
 
 def test_smoke_body_on_the_execution_model(emu, capsys):

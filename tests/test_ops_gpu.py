@@ -258,6 +258,68 @@ def test_conv_transpose2d(pg, shape):
         assert_close(bg.grad, b.grad, TOL_WGRAD, "convT bias")
 
 
+# N, Ci, H, W, Co, bias, act - Conv2d(Ci, Co, 4, 2, 1) with <= 64 output pixels and >= 1 M weights: the inner U-Net levels of
+# pix2pix/models.py:62-67 at batch 1 (d5 ... d8) and scaled-down relatives; the few-pixel path of csrc/fewpix.hip when the hardware
+# self-check left it in service (tests/test_zz_staged_gpu.py says which), the split-K tiled kernels otherwise - parity either way
+FEWPIX_CONV = [(1, 512, 16, 16, 512, False, 0), (1, 512, 8, 8, 512, False, 1), (1, 512, 2, 2, 512, False, 1), (2, 256, 4, 4, 256, True, 1),
+               (1, 128, 8, 8, 512, True, 0), (3, 64, 6, 10, 1024, True, 2)]
+
+
+@pytest.mark.parametrize("cfg", FEWPIX_CONV, ids=["%dx%dx%dx%d-%d" % c[:5] for c in FEWPIX_CONV])
+def test_fewpix_conv2d(pg, cfg):
+    N, Ci, H, W, Co, bias, act = cfg
+    F = pg.functional
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, 4, 4, seed=2, scale=0.05).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True) if bias else None
+    z_ref = TF.conv2d(x, w, b, 2, 1)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](z_ref)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+    y = F.conv2d(xg, wg, bg, 2, (1, 1, 1, 1), F.GATHER_ZERO, act, 0.2)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "fewpix conv fwd")
+    keep = (z_ref.detach().abs() > 1e-5).float()   # pre-activations at the kink may take the other branch
+    if float(keep.min()) == 1.0:
+        assert_close(xg.grad, x.grad, TOL_FWD, "fewpix conv dgrad")
+        assert_close(wg.grad, w.grad, TOL_WGRAD, "fewpix conv wgrad")
+        if bias:
+            assert_close(bg.grad, b.grad, TOL_WGRAD, "fewpix conv bias")
+    else:
+        assert_close(xg.grad, x.grad, 1e-3, "fewpix conv dgrad (kink)")
+        assert_close(wg.grad, w.grad, 1e-3, "fewpix conv wgrad (kink)")
+
+
+# N, Cin, H, W, Cout, bias, act - ConvTranspose2d(Cin, Cout, 4, 2, 1) with <= 64 INPUT pixels: u1 ... u4 of pix2pix/models.py:68-71
+FEWPIX_CONVT = [(1, 1024, 2, 2, 512, False, 0), (1, 1024, 8, 8, 512, False, 0), (1, 512, 8, 8, 256, True, 2), (4, 256, 4, 4, 256, True, 0),
+                (2, 128, 5, 6, 512, False, 0)]
+
+
+@pytest.mark.parametrize("cfg", FEWPIX_CONVT, ids=["%dx%dx%dx%d-%d" % c[:5] for c in FEWPIX_CONVT])
+def test_fewpix_conv_transpose2d(pg, cfg):
+    N, Cin, H, W, Cout, bias, act = cfg
+    F = pg.functional
+    x = _leaf(N, Cin, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Cin, Cout, 4, 4, seed=2, scale=0.05).requires_grad_(True)
+    b = _leaf(Cout, seed=3).requires_grad_(True) if bias else None
+    z_ref = TF.conv_transpose2d(x, w, b, 2, 1)
+    y_ref = torch.relu(z_ref) if act == 2 else z_ref
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    bg = b.detach().to(DEV).requires_grad_(True) if bias else None
+    y = F.conv_transpose2d(xg, wg, bg, 2, 1, act, 0.0)
+    y.backward(gy.to(DEV))
+    assert_close(y, y_ref, TOL_FWD, "fewpix convT fwd")
+    tol_g = (TOL_FWD, TOL_WGRAD) if float((z_ref.detach().abs() > 1e-5).float().min()) == 1.0 or act == 0 else (1e-3, 1e-3)
+    assert_close(xg.grad, x.grad, tol_g[0], "fewpix convT dgrad")
+    assert_close(wg.grad, w.grad, tol_g[1], "fewpix convT wgrad")
+    if bias:
+        assert_close(bg.grad, b.grad, max(TOL_WGRAD, tol_g[1]), "fewpix convT bias")
+
+
 @pytest.mark.parametrize("dims", [(128, 100, 8192), (64, 1024, 512), (64, 256, 1), (7, 33, 5), (128, 2048, 1)])
 def test_linear(pg, dims):
     B, K, Nf = dims
