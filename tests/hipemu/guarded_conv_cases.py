@@ -54,7 +54,54 @@ def _conv_case_guarded(case):
         ws = guarded(torch.full((max(wsb // 4, 4),), float("nan"))); dw = guarded(torch.full((Co, Ci, k, k), float("nan")))
         assert emu.migan_conv2d_wgrad(P(xn), P(gy), P(dw), P(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, 0, None, 0, None, 0, None) == 0
         assert not torch.isnan(dw).any(), 'wgrad NaN'
+def _fewpix_case_guarded(N, Ci, H, W, Co):
+    """csrc/fewpix.hip on a Conv2d(Ci, Co, 4, 2, 1) and the ConvTranspose2d(Co, Ci, 4, 2, 1) that mirrors it: the two index
+    kernels and the three skinny GEMM forms at these (streaming) sizes, every operand against a guard page, outputs NaN-filled,
+    results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(3)
+    P = K._ptr
+    x = torch.randn(N, Ci, H, W, generator=g); w = torch.randn(Co, Ci, 4, 4, generator=g) * 0.05; b = torch.randn(Co, generator=g)
+    y_ref = TF.leaky_relu(TF.conv2d(x, w, b, 2, 1), 0.2)
+    Ho, Wo = y_ref.shape[2:]
+    M, Kk = N * Ho * Wo, Ci * 16
+    assert emu.migan_fewpix_ok(M, Co, Kk) == 1, (M, Co, Kk)
+    xn, wg, bg = guarded(x.permute(0, 2, 3, 1).contiguous()), guarded(w), guarded(b)
+    col = guarded(torch.full((M, Kk), float("nan")))
+    assert emu.migan_im2col_small(P(xn), P(col), N, H, W, Ci, Ho, Wo, 4, 4, 2, 1, 1, None) == 0
+    y = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
+    assert emu.migan_skinny_nt(P(col), P(wg), P(bg), P(y), M, Co, Kk, 1, 0.2, None) == 0
+    assert K._rel(y.permute(0, 3, 1, 2), y_ref) < 3e-6, "fewpix fwd"
+    gy = torch.randn(N, Co, Ho, Wo, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    TF.conv2d(xr, wr, None, 2, 1).backward(gy)
+    gyn = guarded(gy.permute(0, 2, 3, 1).contiguous())
+    ycol = guarded(torch.full((M, Kk), float("nan")))
+    assert emu.migan_skinny_nn(P(gyn), P(wg), P(ycol), M, Co, Kk, None) == 0
+    dx = guarded(torch.full((N, H, W, Ci), float("nan")))
+    assert emu.migan_col2im_small(P(ycol), None, P(dx), N, H, W, Ci, Ho, Wo, 4, 4, 2, 1, 1, 0, 0.0, None) == 0
+    assert K._rel(dx.permute(0, 3, 1, 2), xr.grad) < 3e-6, "fewpix dgrad"
+    dw = guarded(torch.full((Co, Ci, 4, 4), float("nan"))); db = guarded(torch.full((Co,), float("nan")))
+    assert emu.migan_skinny_tn(P(gyn), P(col), P(dw), P(db), M, Co, Kk, 0, 0, None) == 0
+    assert K._rel(dw, wr.grad) < 1e-5 and K._rel(db, gy.sum((0, 2, 3))) < 1e-5, "fewpix wgrad"
+    # the transposed conv that maps y's shape back to x's: weight [Co][Ci][4][4] read as [Cin = Co][Cout*16 = Ci*16]
+    t_ref = TF.conv_transpose2d(gy, w, None, 2, 1)
+    if t_ref.shape[2:] == (H, W):
+        tcol = guarded(torch.full((M, Kk), float("nan")))
+        assert emu.migan_skinny_nn(P(gyn), P(wg), P(tcol), M, Co, Kk, None) == 0
+        t = guarded(torch.full((N, H, W, Ci), float("nan")))
+        assert emu.migan_col2im_small(P(tcol), None, P(t), N, H, W, Ci, Ho, Wo, 4, 4, 2, 1, 1, 2, 0.0, None) == 0
+        assert K._rel(t.permute(0, 3, 1, 2), torch.relu(t_ref)) < 3e-6, "fewpix convT fwd"
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "fewpix":
+    for c in [(1, 256, 2, 2, 512), (1, 64, 16, 16, 1024), (3, 128, 4, 6, 512), (1, 512, 8, 8, 128)]:
+        print("fewpix", c, flush=True)
+        _fewpix_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 i0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 for i, c in enumerate(cases):
     if i < i0: continue

@@ -149,6 +149,16 @@ def test_no_conv_kernel_leaves_its_tensors(emu):
     assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
 
 
+def test_fewpix_kernels_stay_inside_their_tensors(emu):
+    """The same for csrc/fewpix.hip: im2col / col2im and the three skinny GEMM forms at few-pixel-conv sizes, every operand
+    against an inaccessible page, NaN-filled outputs, results against torch."""
+    import subprocess
+
+    script = os.path.join(os.path.dirname(os.path.abspath(hipemu.__file__)), "guarded_conv_cases.py")
+    r = subprocess.run([sys.executable, script, "fewpix"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_splitk_tickets_and_determinism(emu):
     """pix2pix/models.py:66 geometry (4 output pixels, K = 8192): slices add in slice order whoever arrives last - with the
     model's workgroups on 1, 3 and 8 OS threads (different arrival orders) the result is bit-identical."""
