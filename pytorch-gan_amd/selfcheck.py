@@ -73,26 +73,26 @@ def _rand(gen, *shape, scale=1.0):
     return torch.randn(*shape, device=gen.device, generator=gen) * scale
 
 
-# N, Ci, H, W, Co, k, stride, pads, gather, act, bias | what the geometry selects (execution-model launch counts:
-# tests/test_kernels_emu_cpu.py::test_selfcheck_cases_select_the_staged_kernels)
+# N, Ci, H, W, Co, k, stride, pads, gather, act, bias | tolerance | the staged bits whose kernels the geometry selects (a check of
+# one bit runs the cases tagged with it; execution-model launch counts: tests/test_kernels_emu_cpu.py::test_selfcheck_cases_select_the_staged_kernels)
 _CONV = [
-    ("patchgan_head", (2, 512, 6, 6, 1, 4, 1, (2, 2, 1, 1), 0, 0, True), 1e-4),     # fwd thin_conv_wave, dgrad smallk_tile<.,16>
-    ("patchgan_head_b1", (1, 256, 9, 9, 1, 4, 1, (2, 2, 1, 1), 0, 0, True), 1e-4),
-    ("first_conv_6ch", (1, 6, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4),   # midk_tile, K = 96
-    ("first_conv_3ch", (2, 3, 24, 24, 64, 3, 1, (1, 1, 1, 1), 0, 0, True), 1e-4),    # midk_tile, K = 27
-    ("unet_inner", (1, 512, 4, 4, 512, 4, 2, (1, 1, 1, 1), 0, 0, True), 1e-4),       # wgrad_reduce_tr (4 M weights), pack_transpose
-    ("unet_mid", (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4),      # pack_transpose (512 k), wgrad slabs
-    ("fewpix_16px", (1, 128, 8, 8, 512, 4, 2, (1, 1, 1, 1), 0, 1, True), 1e-4),      # fewpix conv: 16 rows, K = 2048, bias + LeakyReLU
-    ("fewpix_1px", (1, 256, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4),      # fewpix conv: ONE output pixel (d8 of the U-Net)
+    ("patchgan_head", (2, 512, 6, 6, 1, 4, 1, (2, 2, 1, 1), 0, 0, True), 1e-4, 1 | 16),     # fwd thin_conv_wave, dgrad smallk_tile<.,16>
+    ("patchgan_head_b1", (1, 256, 9, 9, 1, 4, 1, (2, 2, 1, 1), 0, 0, True), 1e-4, 1 | 16),
+    ("first_conv_6ch", (1, 6, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4, 4),       # midk_tile, K = 96
+    ("first_conv_3ch", (2, 3, 24, 24, 64, 3, 1, (1, 1, 1, 1), 0, 0, True), 1e-4, 4),        # midk_tile, K = 27
+    ("unet_inner", (1, 512, 4, 4, 512, 4, 2, (1, 1, 1, 1), 0, 0, True), 1e-4, 2 | 32 | 64), # wgrad_reduce_tr (4 M weights), pack_transpose; with bit 64 the fewpix path (4 rows)
+    ("unet_mid", (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4, 2 | 32),     # pack_transpose (512 k), wgrad slabs
+    ("fewpix_16px", (1, 128, 8, 8, 512, 4, 2, (1, 1, 1, 1), 0, 1, True), 1e-4, 64),         # fewpix conv: 16 rows, K = 2048, bias + LeakyReLU
+    ("fewpix_1px", (1, 256, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4, 64),         # fewpix conv: ONE output pixel (d8 of the U-Net)
 ]
-_CONVT = [   # N, Cin, H, W, Cout, act, bias: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1) | what the geometry selects
-    ("fewpix_convT_4px", (1, 512, 2, 2, 128, 2, True), 1e-4),                        # fewpix transposed conv: 4 input pixels, ReLU
-    ("fewpix_convT_1px", (1, 512, 1, 1, 256, 0, False), 1e-4),                       # u1 of the U-Net: 1 -> 2x2
+_CONVT = [   # N, Cin, H, W, Cout, act, bias: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1)
+    ("fewpix_convT_4px", (1, 512, 2, 2, 128, 2, True), 1e-4, 64),                           # fewpix transposed conv: 4 input pixels, ReLU
+    ("fewpix_convT_1px", (1, 512, 1, 1, 256, 0, False), 1e-4, 64),                          # u1 of the U-Net: 1 -> 2x2
 ]
 _NORM = [   # N, C, H, W, act, affine, mask, residual
-    ("in_4x4", (1, 512, 4, 4, 0, False, False, False), 1e-4),
-    ("in_16x16_lrelu_mask", (2, 64, 16, 16, 1, False, True, False), 2e-2),   # an activation kink may flip one element
-    ("in_32x32_affine_res", (1, 32, 32, 32, 0, True, False, True), 1e-4),
+    ("in_4x4", (1, 512, 4, 4, 0, False, False, False), 1e-4, 8),
+    ("in_16x16_lrelu_mask", (2, 64, 16, 16, 1, False, True, False), 2e-2, 8),   # an activation kink may flip one element
+    ("in_32x32_affine_res", (1, 32, 32, 32, 0, True, False, True), 1e-4, 8),
 ]
 
 
@@ -144,19 +144,23 @@ def _run_norm(F, case, gen):
     return {k_: F._plain(v).detach().clone() for k_, v in out.items()}
 
 
-def _all_cases(F):
-    for name, case, tol in _CONV:
-        yield name, tol, (lambda gen, c=case: _run_conv(F, c, gen))
-    for name, case, tol in _CONVT:
-        yield name, tol, (lambda gen, c=case: _run_convt(F, c, gen))
-    for name, case, tol in _NORM:
-        yield name, tol, (lambda gen, c=case: _run_norm(F, c, gen))
+def _all_cases(F, word=ALL):
+    """(name, tolerance, runner) of the cases that exercise a kernel of `word`"""
+    for name, case, tol, tags in _CONV:
+        if tags & word:
+            yield name, tol, (lambda gen, c=case: _run_conv(F, c, gen))
+    for name, case, tol, tags in _CONVT:
+        if tags & word:
+            yield name, tol, (lambda gen, c=case: _run_convt(F, c, gen))
+    for name, case, tol, tags in _NORM:
+        if tags & word:
+            yield name, tol, (lambda gen, c=case: _run_norm(F, c, gen))
 
 
 def _compare(F, device, bits_on, seed=1234):
     """Every case with `bits_on` set and with all staged bits cleared -> {case: (tol, {tensor: rel (device scalar)})}."""
     res = {}
-    for name, tol, fn in _all_cases(F):
+    for name, tol, fn in _all_cases(F, bits_on):
         outs = []
         for word in (bits_on, 0):
             lib.migan_staged(ALL, word)

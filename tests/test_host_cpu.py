@@ -335,3 +335,41 @@ def test_rocpd_stats_counts_steps_from_the_trace(tmp_path):
     assert r.returncode == 0, r.stderr
     head = r.stdout.splitlines()[0]
     assert "13.0 launches per step" in head and "12 steps in the trace" in head, head
+
+
+def _stub_bench(tmp_path, body):
+    """A stand-in for bench.py as run_extra() starts it (python <file> --workload ...): `body` is what the child does."""
+    p = tmp_path / "stub_bench.py"
+    p.write_text("import json, os, sys, time\nargs = sys.argv[1:]\n" + body)
+    return str(p)
+
+
+def test_bench_extra_configs_run_in_child_processes(tmp_path, monkeypatch):
+    """bench.run_extra(): the other BASELINE configs are measured by child processes, so that a device fault in one of them (the
+    process is aborted) cannot take the already-final headline line down: a good child's line is folded into `extra`, a child
+    that is killed by a signal, exits non-zero, prints nothing or hangs becomes an `error` entry."""
+    import bench
+
+    good = {"metric": "training images/sec", "value": 321.5, "ms_per_step": 3.11, "step_executed_frac": 0.4, "step_dense_frac": 0.5,
+            "timing": {"blocks": 7, "timed_seconds": 2.1, "ms_per_step_min": 3.0, "ms_per_step_max": 3.3},
+            "config": {"workload": "pix2pix 256x256 bs 1", "hipgraph": True}, "losses": {"loss_G": 1.5}, "peak_mem_gb": 1.25,
+            "staged_kernels": {"midk_tile": "ok", "norm_small": "disabled: differs"}}
+    stub = _stub_bench(tmp_path, "assert args[:2] == ['--workload', 'pix2pix'] and '--no-extra' in args and '--no-roofline' in args\n"
+                                 "print('some warning line')\nprint(json.dumps(%r))\n" % good)
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: stub if p == bench.__file__ else os.path.normpath(os.path.join(os.getcwd(), p)))
+    e = bench.run_extra("pix2pix", 50, 5)
+    assert e["images_per_s"] == 321.5 and e["ms_per_step"] == 3.11 and e["blocks"] == 7 and e["hipgraph"] is True
+    assert e["workload"] == "pix2pix 256x256 bs 1" and e["steps"] == 50 and e["warmup"] == 5 and e["peak_mem_gb"] == 1.25
+    assert e["staged_kernels_off"] == ["norm_small"] and e["losses"] == {"loss_G": 1.5}
+
+    for body, what in (("os.kill(os.getpid(), 6)\n", "exit status -6"), ("sys.stderr.write('boom\\n'); sys.exit(3)\n", "exit status 3: boom"),
+                       ("print('no json here')\n", "exit status 0")):
+        stub = _stub_bench(tmp_path, body)
+        monkeypatch.setattr(bench.os.path, "abspath", lambda p, s=stub: s if p == bench.__file__ else p)
+        e = bench.run_extra("srgan", 4, 1)
+        assert list(e) == ["error"] and what in e["error"], e
+    stub = _stub_bench(tmp_path, "time.sleep(60)\n")
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p, s=stub: s if p == bench.__file__ else p)
+    t0 = __import__("time").time()
+    e = bench.run_extra("cyclegan", 4, 1, timeout_s=2.0)
+    assert "no result within 2 s" in e["error"] and __import__("time").time() - t0 < 20
