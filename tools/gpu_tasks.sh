@@ -234,13 +234,24 @@ t=${1:-}; shift || true
 #   MIGAN_MIDK             direct conv for the 3 / 6-channel first layers (conv_igemm.hip midk_tile_kernel)
 task_staged() {
   mkdir -p gpurun_out/staged
+  # first: what does the hardware self-check say, and how long does the probe take (cold, then from the cached verdict)
+  for i in 1 2; do
+    ( time timeout 300 python -c "
+import torch, pytorch_gan_amd
+from pytorch_gan_amd import selfcheck
+selfcheck.ensure()
+print(selfcheck.report()); print('cached' if (selfcheck.VERDICT or {}).get('cached') else 'probed'); print(selfcheck.detail())" ) > gpurun_out/staged/selfcheck_$i.txt 2>&1
+  done
+  cat gpurun_out/staged/selfcheck_1.txt
+  MIGAN_SELFCHECK=inproc timeout 300 python -m pytest tests/test_zz_staged_gpu.py -q -rxs > gpurun_out/staged/selfcheck_inproc.txt 2>&1
+  tail -5 gpurun_out/staged/selfcheck_inproc.txt
   timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_models_gpu.py -q -x \
     -k "conv or pix2pix or cyclegan or srgan or patch" > gpurun_out/staged/pytest.txt 2>&1
   echo "pytest rc=$?" >> gpurun_out/staged/pytest.txt
   timeout 900 python -m pytest tests/test_steps_gpu.py -q -x -k "pix2pix or cyclegan_step or srgan_step" >> gpurun_out/staged/pytest.txt 2>&1
   echo "steps pytest rc=$?" >> gpurun_out/staged/pytest.txt
   grep -E "passed|failed|rc=" gpurun_out/staged/pytest.txt
-  OFF="MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0 MIGAN_MIDK=0 MIGAN_NORM_SMALL=0 MIGAN_SMALLK_PB16=0 MIGAN_DROPOUT_FUSE=0"
+  OFF="MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0 MIGAN_MIDK=0 MIGAN_NORM_SMALL=0 MIGAN_SMALLK_PB16=0 MIGAN_DROPOUT_FUSE=0 MIGAN_FEWPIX=0"
   for k7 in 0 1; do
     echo "== wgan_gp [MIGAN_K7=$k7]" >> gpurun_out/staged/bench.txt
     env MIGAN_K7=$k7 timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline \
@@ -249,7 +260,7 @@ task_staged() {
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan or critic" >> gpurun_out/staged/pytest.txt 2>&1
   echo "wgan pytest rc=$?" >> gpurun_out/staged/pytest.txt
   for w in pix2pix cyclegan; do
-    for f in "$OFF" "MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0" "MIGAN_MIDK=0" "MIGAN_NORM_SMALL=0" "MIGAN_SMALLK_PB16=0" "MIGAN_X=1"; do
+    for f in "$OFF" "MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_PACK_TR=0" "MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0" "MIGAN_MIDK=0" "MIGAN_NORM_SMALL=0" "MIGAN_SMALLK_PB16=0" "MIGAN_FEWPIX=0" "MIGAN_X=1"; do
       echo "== $w [$f]" >> gpurun_out/staged/bench.txt
       env $f timeout 300 python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-roofline \
         2>>gpurun_out/staged/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'])" >> gpurun_out/staged/bench.txt
@@ -270,5 +281,5 @@ case "$t" in
   pmc_gap) task_pmc_gap "$@" ;;
   staged) task_staged "$@" ;;
   suite) task_suite "$@" ;;
-  *) echo "usage: gpu_tasks.sh {parity|tile_sweep|wgrad_ab|wgrad_sweep|splitk|prof|pair_d|new_tests|pmc_gap|suite} [args]"; exit 2 ;;
+  *) echo "usage: gpu_tasks.sh {parity|tile_sweep|wgrad_ab|wgrad_sweep|splitk|prof|pair_d|new_tests|pmc_gap|staged|suite} [args]"; exit 2 ;;
 esac
