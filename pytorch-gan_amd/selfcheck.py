@@ -435,7 +435,7 @@ def probe(index, start, want_persistent, spawn=_spawn_probe, timeout=None, max_s
     rep["persistent"] = "not run" if want_persistent else "off (MIGAN_K7=0)"
     todo, ok_bits = start, 0
     need_workload, need_persistent = True, bool(want_persistent)
-    spawns = 0
+    spawns, reached = 0, True
     while spawns < max_spawns and (todo or (need_workload and ok_bits) or need_persistent):
         spawns += 1
         stages = (["bits"] if todo else []) + (["workload"] if need_workload else []) + (["persistent"] if need_persistent else [])
@@ -451,6 +451,7 @@ def probe(index, start, want_persistent, spawn=_spawn_probe, timeout=None, max_s
             if need_persistent:
                 rep["persistent"] = "disabled: the probe process did not reach the device (%s)" % how
             todo, need_persistent = 0, False
+            reached = reached and spawns > 1
             break
         for k, bit in BITS.items():
             if todo & bit and k in done:
@@ -510,7 +511,9 @@ def probe(index, start, want_persistent, spawn=_spawn_probe, timeout=None, max_s
         ok_bits = 0
     if need_persistent:
         rep["persistent"] = "disabled: not verified (the probe was stopped after an earlier check ended or hung it)"
-    return {"bits": ok_bits, "report": rep, "persistent": rep["persistent"].startswith("ok")}
+    # "definitive": every probe process got as far as the device - a verdict worth keeping for this machine (a probe that could
+    # not even start, or found no GPU, says nothing about the kernels and is asked again by the next process)
+    return {"bits": ok_bits, "report": rep, "persistent": rep["persistent"].startswith("ok"), "definitive": reached}
 
 
 # ------------------------------------------------------------------------------------------------ verdict cache
@@ -546,10 +549,11 @@ def _cached_verdict(index, start, want_persistent, make):
             except (OSError, ValueError):
                 pass
             v = make()
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "w") as fh:
-                json.dump(v, fh)
-            os.replace(tmp, path)
+            if v.get("definitive", True):
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "w") as fh:
+                    json.dump(v, fh)
+                os.replace(tmp, path)
             return v
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

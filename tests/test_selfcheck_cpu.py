@@ -65,7 +65,7 @@ def _full_run(fail=(), die_in=None, workload=True, persistent=True, flags=None):
 def test_clean_probe_gives_every_kernel():
     spawn = _script(_full_run())
     v = selfcheck.probe(0, ALL, True, spawn=spawn)
-    assert v["bits"] == ALL and v["persistent"] is True
+    assert v["bits"] == ALL and v["persistent"] is True and v["definitive"] is True
     assert v["report"] == dict({k: "ok" for k in NAMES}, persistent="ok")
     assert len(spawn.calls) == 1 and spawn.calls[0]["stages"] == ["bits", "workload", "persistent"]
 
@@ -116,7 +116,7 @@ def test_probe_that_never_reaches_the_device_leaves_everything_off():
     v = selfcheck.probe(0, ALL, True, spawn=spawn)
     assert v["bits"] == 0 and v["persistent"] is False
     assert all("did not reach the device" in t for t in v["report"].values())
-    assert len(spawn.calls) == 1
+    assert len(spawn.calls) == 1 and v["definitive"] is False   # ... and is not worth caching
 
 
 def test_env_switched_off_bits_are_not_probed():
@@ -173,6 +173,12 @@ def test_verdict_cache_probes_once(tmp_path, monkeypatch):
     a = selfcheck._cached_verdict(0, ALL, True, make)
     b = selfcheck._cached_verdict(0, ALL, True, make)
     assert made == [1] and a["bits"] == b["bits"] == 5 and b.get("cached") is True and "cached" not in a
+    (tmp_path / "verdict.json").unlink()
+    d = selfcheck._cached_verdict(0, ALL, True, lambda: {"bits": 0, "report": {}, "persistent": False, "definitive": False})
+    assert d["bits"] == 0 and not (tmp_path / "verdict.json").exists()     # "the probe never saw a GPU" is not kept
+    made.clear()
+    made.append(1)
+    selfcheck._cached_verdict(0, ALL, True, lambda: {"bits": 5, "report": {"x": "ok"}, "persistent": True})
     (tmp_path / "verdict.json").write_text("{ torn")
     c = selfcheck._cached_verdict(0, ALL, True, make)
     assert made == [1, 1] and c["bits"] == 5
