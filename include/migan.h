@@ -98,6 +98,12 @@ int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M
  * migan_col2im_small: the adjoint, out[N][H][W][J] = act(bias + sum of ycol[(n,ho,wo)][(j,r,s)] over the taps that land on
  * (h, w)) in a fixed order; bias may be NULL. */
 int migan_fewpix_ok(int rows, int n, int k);
+/* The NT product of that path with K also split over workgroups (a 16.8-33.5 MB weight against <= 64 rows wants 256+ workgroups,
+ * not N/16): out[M][N] = act(a[M][K] w[N][K]^T + bias), partial tiles in ws (migan_fewpix_nt_workspace bytes; 0 = no split, the
+ * call is migan_skinny_nt), added in a fixed order by a second launch.  Conv2d forward / ConvTranspose2d input gradient. */
+size_t migan_fewpix_nt_workspace(int M, int N, int K);
+int migan_fewpix_nt(const float* a, const float* w, const float* bias, float* out, float* ws, size_t ws_bytes, int M, int N, int K,
+                    int act, float slope, void* stream);
 int migan_im2col_small(const float* x, float* col, int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pt,
                        int pl, void* stream);
 int migan_col2im_small(const float* ycol, const float* bias, float* out, int N, int H, int W, int J, int Ho, int Wo, int R, int S,

@@ -85,6 +85,8 @@ _SIGS = {
     "migan_skinny_tn_ok": (c_int, [c_int] * 3),
     "migan_skinny_tn": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "migan_fewpix_ok": (c_int, [c_int] * 3),
+    "migan_fewpix_nt_workspace": (c_size_t, [c_int] * 3),
+    "migan_fewpix_nt": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_float, P]),
     "migan_im2col_small": (c_int, [P, P] + [c_int] * 11 + [P]),
     "migan_col2im_small": (c_int, [P, P, P] + [c_int] * 12 + [c_float, P]),
     "migan_act_bwd_nc": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, P]),

@@ -18,6 +18,10 @@
 // device, by pytorch_gan_amd/selfcheck.py against the tiled kernels it replaces.
 #include "common.h"
 
+extern "C" int migan_skinny_nt_ok(int M, int N, int K);
+extern "C" int migan_skinny_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int act, float slope,
+                               void* stream);
+
 // col[m][c*T + t] = x[n][ho*stride - pt + r][wo*stride - pl + s][c]  (0 outside the image); m = (n*Ho + ho)*Wo + wo, t = r*S + s.
 // One thread per element of col, consecutive threads = consecutive columns: the stores are contiguous, the loads hit a <= 64-pixel
 // (cache-resident) source.
@@ -66,6 +70,108 @@ __global__ __launch_bounds__(256) void col2im_small_kernel(const float* __restri
         }
     }
     out[idx] = act_apply(acc, act, slope);
+}
+
+// ---- the NT product at streaming rate ------------------------------------------------------------------------------------------
+// skinny_nt_kernel (skinny_mm.hip) gives one workgroup a 16-column tile and ALL of K: N / 16 = 32-64 workgroups for these layers,
+// each walking 8-16 dependent load rounds - fine for the 2.6 MB L2-resident critic it was written for, a sixth of the chip's memory
+// parallelism for a 16.8-33.5 MB weight stream.  Here the same wave-level loop (16-byte loads of both operands straight into
+// v_mfma_f32_16x16x4_f32, k order permuted identically for both) also splits K over blockIdx.z: N/16 x row groups x Z workgroups
+// (256-512), one or two load rounds per wave, raw partial tiles into part[Z][M][N], and a second small launch adds the Z partials
+// in z order (deterministic) with bias and activation.
+__device__ __forceinline__ f32x4 fp_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// part[z][m][n] = sum over k in [z*Kc, (z+1)*Kc) of A[m][k] W[n][k];  M <= 64, N % 16 == 0, Kc % (16 * KS) == 0
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void fewpix_nt_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                             float* __restrict__ part, int M, int N, int K, int Kc) {
+    __shared__ f32x4 red[KS > 1 ? (KS - 1) * 64 : 1];
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int rr = lane & 15, kq = lane >> 4;
+    const int r0 = blockIdx.y * 16, col0 = blockIdx.x * 16, z = blockIdx.z;
+    const int Kslice = Kc / KS;
+    const int arow = r0 + rr < M ? r0 + rr : M - 1;
+    const size_t kbase = (size_t)z * Kc + (size_t)ks * Kslice + kq * 4;
+    const float* ap = A + (size_t)arow * K + kbase;
+    const float* wp = W + (size_t)(col0 + rr) * K + kbase;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int k0 = 0;
+    for (; k0 + 128 <= Kslice; k0 += 128) {  // 16 independent 16-byte loads in flight per lane, then 32 MFMAs
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 * u);
+            b[u] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = fp_mfma16(a[u][t], b[u][t], acc0);
+                acc1 = fp_mfma16(a[u + 1][t], b[u + 1][t], acc1);
+            }
+    }
+    for (; k0 < Kslice; k0 += 16) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + k0), b0 = *reinterpret_cast<const f32x4*>(wp + k0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0 = fp_mfma16(a0[t], b0[t], acc0);
+    }
+    f32x4 acc = acc0 + acc1;
+    if (KS > 1) {
+        if (ks > 0) red[(ks - 1) * 64 + lane] = acc;
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; ++q) acc += red[(q - 1) * 64 + lane];
+    }
+    const int col = col0 + rr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r0 + kq * 4 + r;
+        if (row < M) part[((size_t)z * M + row) * N + col] = acc[r];
+    }
+}
+
+// out[m][n] = act(bias[n] + part[0][m][n] + part[1][m][n] + ... ) - the partials in z order
+__global__ __launch_bounds__(256) void fewpix_nt_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int MN, int N, int Z, int act, float slope) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float v = part[i];
+    for (int z = 1; z < Z; ++z) v += part[(size_t)z * MN + i];
+    if (bias) v += bias[i % N];
+    out[i] = act_apply(v, act, slope);
+}
+
+// K-split of the NT product: the largest Z in {16, 8, 4, 2} that leaves every wave whole 128-deep load rounds (8 waves x 128 =
+// 1024 of K per workgroup and round) and keeps the launch at or under 512 workgroups; 1 = no split (skinny_nt_kernel's own launch)
+static int fewpix_nt_split(int M, int N, int K) {
+    const long tiles = (long)(N / 16) * ((M + 15) / 16);
+    for (int Z = 16; Z >= 2; Z >>= 1)
+        if (K % (Z * 1024) == 0 && tiles * Z <= 512) return Z;
+    return 1;
+}
+// bytes of the partial-tile workspace migan_fewpix_nt needs (0: no split)
+MIGAN_API size_t migan_fewpix_nt_workspace(int M, int N, int K) {
+    const int Z = fewpix_nt_split(M, N, K);
+    return Z > 1 ? (size_t)Z * M * N * sizeof(float) : 0;
+}
+// out[M][N] = act(a[M][K] w[N][K]^T + bias): the forward of a few-pixel Conv2d (a = its im2col) and the input gradient of a
+// few-pixel ConvTranspose2d (pix2pix/models.py:23,39), K split over workgroups; ws from migan_fewpix_nt_workspace (may be NULL when 0).
+MIGAN_API int migan_fewpix_nt(const float* a, const float* w, const float* bias, float* out, float* ws, size_t ws_bytes, int M, int N,
+                              int K, int act, float slope, void* stream) {
+    if (migan_skinny_nt_ok(M, N, K) != 1) return (int)hipErrorInvalidValue;
+    const int Z = fewpix_nt_split(M, N, K);
+    if (Z == 1) return migan_skinny_nt(a, w, bias, out, M, N, K, act, slope, stream);
+    if (ws == nullptr || ws_bytes < (size_t)Z * M * N * sizeof(float)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int Kc = K / Z;
+    hipLaunchKernelGGL(fewpix_nt_kernel<8>, dim3(N / 16, (M + 15) / 16, Z), dim3(512), 0, st, a, w, ws, M, N, K, Kc);
+    HIP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fewpix_nt_reduce_kernel, dim3(cdiv((long)M * N, 256L)), dim3(256), 0, st, ws, bias, out, M * N, N, Z, act, slope);
+    HIP_LAUNCH_CHECK();
+    return 0;
 }
 
 // 1 when a conv whose GEMM has `rows` pixel rows (Conv2d: N*Ho*Wo output pixels; ConvTranspose2d: N*Hin*Win input pixels),

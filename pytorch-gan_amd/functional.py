@@ -489,6 +489,13 @@ class _ConvDgradFn(Function):
         return g_dy, g_w, None
 
 
+def _fewpix_nt(a, w, b, out, M, N, K, act, slope, st, what):
+    """out[M][N] = act(a[M][K] w[N][K]^T + b) of the few-pixel conv path: K split over workgroups (csrc/fewpix.hip)"""
+    nb = lib.migan_fewpix_nt_workspace(M, N, K)
+    ws = _ws(nb, a) if nb else None
+    check(lib.migan_fewpix_nt(a.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), _ptr(ws), nb, M, N, K, act, slope, st), what)
+
+
 class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
@@ -522,7 +529,7 @@ class _Conv2d(Function):
             col = torch.empty((M, K), device=xs.device, dtype=torch.float32)
             check(lib.migan_im2col_small(xs.data_ptr(), col.data_ptr(), N, H, W, Ci, Ho, Wo, R, S, stride, pt, pl, st), "im2col_small")
             y = _empty_nhwc((N, Co, Ho, Wo), xs)
-            check(lib.migan_skinny_nt(col.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), M, Co, K, act, slope, st), "fewpix_conv_fwd")
+            _fewpix_nt(col, w, b, y, M, Co, K, act, slope, st, "fewpix_conv_fwd")
             ctx.few = True
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, col)
             return y
@@ -1004,8 +1011,7 @@ class _ConvTranspose2d(Function):
                 db = _colsum(dy, N * Hout * Wout, Cout, _grad_slot(ctx.params[1]))
             if ctx.needs_input_grad[0]:
                 dx = _empty_nhwc((N, Cin, Hin, Win), xs)
-                check(lib.migan_skinny_nt(dycol.data_ptr(), w.data_ptr(), None, dx.data_ptr(), M, Cin, K, ACT_NONE, 0.0, st),
-                      "fewpix_convT_dgrad")
+                _fewpix_nt(dycol, w, None, dx, M, Cin, K, ACT_NONE, 0.0, st, "fewpix_convT_dgrad")
             return dx, dw, db, None, None, None, None
         fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
         with fork:

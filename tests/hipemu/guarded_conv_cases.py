@@ -72,6 +72,11 @@ def _fewpix_case_guarded(N, Ci, H, W, Co):
     y = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
     assert emu.migan_skinny_nt(P(col), P(wg), P(bg), P(y), M, Co, Kk, 1, 0.2, None) == 0
     assert K._rel(y.permute(0, 3, 1, 2), y_ref) < 3e-6, "fewpix fwd"
+    nb = emu.migan_fewpix_nt_workspace(M, Co, Kk)   # the same product with K split over workgroups: partial tiles NaN-filled
+    ws = guarded(torch.full((max(nb // 4, 4),), float("nan")))
+    y2 = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
+    assert emu.migan_fewpix_nt(P(col), P(wg), P(bg), P(y2), P(ws), nb, M, Co, Kk, 1, 0.2, None) == 0
+    assert K._rel(y2.permute(0, 3, 1, 2), y_ref) < 3e-6, "fewpix fwd (K split %d B)" % nb
     gy = torch.randn(N, Co, Ho, Wo, generator=g)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     TF.conv2d(xr, wr, None, 2, 1).backward(gy)
@@ -96,7 +101,7 @@ def _fewpix_case_guarded(N, Ci, H, W, Co):
 
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
 if len(sys.argv) > 1 and sys.argv[1] == "fewpix":
-    for c in [(1, 256, 2, 2, 512), (1, 64, 16, 16, 1024), (3, 128, 4, 6, 512), (1, 512, 8, 8, 128)]:
+    for c in [(1, 256, 2, 2, 512), (1, 64, 16, 16, 1024), (3, 128, 4, 6, 512), (1, 512, 8, 8, 128), (2, 1024, 2, 2, 256)]:
         print("fewpix", c, flush=True)
         _fewpix_case_guarded(*c)
         keep.clear()

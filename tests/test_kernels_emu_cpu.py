@@ -497,8 +497,11 @@ def test_fewpix_convs_on_the_execution_model(emu, which, cfg):
 
     lib = _run_gpu_test_body("test_ops_gpu", which, pg, cfg)
     assert lib.hipemu_launch_count(b"im2col_small_kernel") == 1 and lib.hipemu_launch_count(b"col2im_small_kernel") == 1
-    assert lib.hipemu_launch_count(b"skinny_nt_kernel") == 1 and lib.hipemu_launch_count(b"skinny_nn_kernel") == 1
-    assert lib.hipemu_launch_count(b"skinny_tn_kernel") == 1
+    # the NT product: K split over workgroups (+ the ordered sum of the partial tiles) where the shape allows, else the plain launch
+    split = lib.hipemu_launch_count(b"fewpix_nt_kernel")
+    assert split == lib.hipemu_launch_count(b"fewpix_nt_reduce_kernel") and split + lib.hipemu_launch_count(b"skinny_nt_kernel") == 1
+    assert split == (1 if (cfg[1] if which == "test_fewpix_conv2d" else cfg[4]) * 16 % 2048 == 0 else 0)
+    assert lib.hipemu_launch_count(b"skinny_nn_kernel") == 1 and lib.hipemu_launch_count(b"skinny_tn_kernel") == 1
     for sym in (b"permute4_kernel", b"pack_transpose_kernel", b"igemm_", b"wgrad_", b"smallk_"):
         assert lib.hipemu_launch_count(sym) == 0, sym
 
@@ -519,7 +522,8 @@ def test_selfcheck_cases_select_the_staged_kernels(emu):
         for sym in (b"thin_conv_wave_kernel", b"thin_conv_kernel", b"smallk_tile_kernel<K, 16>", b"smallk_tile_kernel<K, 128>",
                     b"midk_tile_kernel", b"wgrad_reduce_tr_kernel", b"wgrad_reduce_kernel", b"pack_transpose_kernel",
                     b"permute4_kernel", b"norm_small_fwd_kernel", b"norm_small_bwd_kernel", b"norm_partial_kernel",
-                    b"im2col_small_kernel", b"col2im_small_kernel", b"skinny_nt_kernel", b"skinny_nn_kernel", b"skinny_tn_kernel"):
+                    b"im2col_small_kernel", b"col2im_small_kernel", b"fewpix_nt_kernel", b"fewpix_nt_reduce_kernel",
+                    b"skinny_nn_kernel", b"skinny_tn_kernel"):
             assert lib.hipemu_launch_count(sym) > 0, sym
         worst = max(v for d in selfcheck.detail().values() for v in d.values())
         assert worst < 1e-5, selfcheck.detail()   # staged and replaced kernels differ by summation order only
