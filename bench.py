@@ -583,6 +583,22 @@ def _safe_cpu_baseline(init):
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
+def persistent_kernel_state(state):
+    """Which persistent WGAN-GP kernels (csrc/critic_fused.hip, mlp_fused.hip) the state took into service, and whether any of
+    their grid barriers gave up (sync[2] of a plan: set by the kernel, cleared only by the host) - None for other workloads."""
+    plans = {"critic": getattr(state, "_k7_plan", None), "generator_forward": getattr(state, "_k7_gen_plan", None),
+             "critic_as_mlp": getattr(state, "_k7_dmlp_plan", None)}
+    if all(p is None for p in plans.values()):
+        return None
+    out = {k: bool(getattr(p, "verified", False) or getattr(p, "step_verified", False)) if p is not None else False
+           for k, p in plans.items()}
+    gp = plans["generator_forward"]
+    out["generator_iteration"] = bool(getattr(gp, "step_verified", False)) if gp is not None else False
+    out["barrier_timeouts"] = sum(1 for p in plans.values()
+                                  if p is not None and getattr(p, "sync", None) is not None and int(p.sync[2]) != 0)
+    return out
+
+
 def _staged_report():
     try:
         from pytorch_gan_amd import selfcheck
@@ -703,6 +719,10 @@ def main():
     losses = {k: float(v) for k, v in out.items() if "loss" in k}
     if not all(np.isfinite(v) for v in losses.values()):
         raise SystemExit("non-finite loss in the timed region: %s" % losses)
+    pk = persistent_kernel_state(w.state)
+    if pk and pk.get("barrier_timeouts"):
+        # a grid barrier of a persistent WGAN-GP kernel gave up inside the timed region: those iterations computed nothing valid
+        raise SystemExit("persistent kernels: grid barrier timed out in the timed region (%s); rerun with MIGAN_K7=0" % pk)
     summ = summarise(name, w.batch, world, args.steps, blocks)
     result = {
         "metric": "training images/sec", "value": round(summ["images_per_s"], 2), "unit": "images/s", "n_gpus": world,
@@ -725,6 +745,8 @@ def main():
     }
     if w.capture_error:
         result["config"]["hipgraph_error"] = w.capture_error[:200]
+    if pk:
+        result["config"]["persistent_kernels"] = pk
     # The headline numbers are final here.  What follows (per-kernel accounting, the other BASELINE configs, the CPU baseline)
     # is optional detail: if it does not finish in time the watchdog prints the line with whatever is attached so far and
     # exits, so a stall in an optional section can never cost the run its result.

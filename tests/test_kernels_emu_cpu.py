@@ -637,6 +637,13 @@ def test_bench_builders_and_roofline_accounting_run(emu):
         for i in range(2, 7):
             out = g.run(i)
         assert g.state._k7_plan.verified and g.state._k7_gen_plan.verified and g.state._k7_gen_plan.step_verified
+        pk = bench.persistent_kernel_state(g.state)   # what the bench line reports (and refuses a run over: barrier time-outs)
+        assert pk == {"critic": True, "generator_forward": True, "critic_as_mlp": False, "generator_iteration": True,
+                      "barrier_timeouts": 0} or (pk["critic"] and pk["generator_iteration"] and pk["barrier_timeouts"] == 0), pk
+        g.state._k7_plan.sync[2] = 1
+        assert bench.persistent_kernel_state(g.state)["barrier_timeouts"] == 1
+        g.state._k7_plan.sync[2] = 0
+        assert bench.persistent_kernel_state(w.state) is None
 
 
 def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):
