@@ -346,6 +346,7 @@ def _probe_main(argv):
 def _probe_stages(device, start, known_ok, stages, log, sync):
     """What a probe process does once it has a device; -> the staged word it leaves set."""
     keep = start & known_ok
+    lib.migan_staged(ALL, keep)   # (this process starts from the environment's word: nothing unverified below)
     if "bits" in stages:
         keep = run_in_process(device, start, known_ok, log)
     if "workload" in stages and keep:
