@@ -30,6 +30,8 @@ static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, int) { *e = std::chrono::steady_clock::now(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(*b - *a).count(); return 0; }
+extern "C" void hipemu_add_coresident_kernel(const char* substr);   // kernels with grid-wide barriers: one OS thread per workgroup
+extern "C" const char* hipemu_last_message();
 #endif
 
 #include <algorithm>
@@ -264,8 +266,204 @@ static void fewpix_case(const char* name, int N, int Ci, int H, int W, int Co) {
     report(name, "wgrad", rel(dw1.host(), dw0.host()), 1e-4, t_new, t_old, wmb);
 }
 
+// ---- one-launch InstanceNorm for small tensors against a host fp64 evaluation of nn.InstanceNorm2d -> LeakyReLU -> Dropout mask ----
+static void norm_small_case(const char* name, int G, int P, int C, int act, bool use_mask) {
+    migan_staged(B_ALL, B_NORM);
+    if (migan_norm_small_ok(G, P, C) != 1) {
+        printf("%-34s not a small-norm shape\n", name);
+        return;
+    }
+    const size_t n = (size_t)G * P * C;
+    Buf x(n), dy(n), mask(n), y(n, 0, false), mean((size_t)G * C, 0, false), invstd((size_t)G * C, 0, false), dx(n, 0, false);
+    std::vector<float> hx = x.host(), hdy = dy.host(), hm = mask.host();
+    for (auto& v : hm) v = v > 0.f ? 2.f : 0.f;   // Dropout(0.5) scaled by 1/(1-p)
+    CK(hipMemcpy(mask.d, hm.data(), n * 4, hipMemcpyHostToDevice));
+    const float slope = 0.2f, eps = 1e-5f;
+    float t_f = time_us([&] {
+        RC(migan_norm_fwd_small(x.d, y.d, mean.d, invstd.d, nullptr, nullptr, nullptr, use_mask ? mask.d : nullptr, G, P, C, act, slope, eps, nullptr));
+    });
+    float t_b = time_us([&] {
+        RC(migan_norm_bwd_small(x.d, dy.d, use_mask ? mask.d : nullptr, mean.d, invstd.d, nullptr, nullptr, dx.d, G, P, C, act, slope, nullptr, nullptr));
+    });
+    std::vector<float> ry(n), rdx(n);
+    for (int g = 0; g < G; ++g)
+        for (int c = 0; c < C; ++c) {
+            double m = 0, v = 0;
+            for (int p = 0; p < P; ++p) m += hx[((size_t)g * P + p) * C + c];
+            m /= P;
+            for (int p = 0; p < P; ++p) { double d = hx[((size_t)g * P + p) * C + c] - m; v += d * d; }
+            const double is = 1.0 / std::sqrt(v / P + eps);
+            double s0 = 0, s1 = 0;
+            std::vector<double> dz(P), xh(P);
+            for (int p = 0; p < P; ++p) {
+                const size_t i = ((size_t)g * P + p) * C + c;
+                xh[p] = (hx[i] - m) * is;
+                const double a = act == 1 ? (xh[p] > 0 ? xh[p] : xh[p] * slope) : act == 2 ? (xh[p] > 0 ? xh[p] : 0.0) : xh[p];
+                const double da = act == 1 ? (xh[p] > 0 ? 1.0 : slope) : act == 2 ? (xh[p] > 0 ? 1.0 : 0.0) : 1.0;
+                const double mk = use_mask ? hm[i] : 1.0;
+                ry[i] = (float)(a * mk);
+                dz[p] = hdy[i] * mk * da;
+                s0 += dz[p];
+                s1 += dz[p] * xh[p];
+            }
+            for (int p = 0; p < P; ++p) rdx[((size_t)g * P + p) * C + c] = (float)(is * (dz[p] - s0 / P - xh[p] * s1 / P));
+        }
+    report(name, "norm_small fwd", rel(y.host(), ry), 2e-6, t_f, 0.f);
+    report(name, "norm_small bwd", rel(dx.host(), rdx), 2e-5, t_b, 0.f);
+}
+
+// ---- persistent WGAN-GP kernels: does the grid barrier hold on this device, what does a launch cost, is the result independent of the grid ----
+static void critic_case(int B, int Din, int H1, int H2) {
+    if (migan_critic_fused_ok(B, Din, H1, H2) != 1) { printf("critic_fused: shape not taken\n"); return; }
+    Buf real((size_t)B * Din), fake((size_t)B * Din), alpha(B), w1((size_t)H1 * Din, 0.03f), b1(H1, 0.1f), w2((size_t)H2 * H1, 0.05f), b2(H2, 0.1f),
+        w3(H2, 0.1f), b3(1, 0.1f);
+    std::vector<float> ha = alpha.host();
+    for (auto& v : ha) v = 0.5f * (v + 1.f);
+    CK(hipMemcpy(alpha.d, ha.data(), B * 4, hipMemcpyHostToDevice));
+    const size_t wsb = migan_critic_fused_workspace(B, Din, H1, H2);
+    Buf ws(wsb / 4, 0, false);
+    unsigned* sync;
+    CK(hipMalloc((float**)&sync, 16));
+    // host fp64: mean D(real), mean D(fake) (out[2], out[3])
+    auto hr = real.host(), hf = fake.host(), hw1 = w1.host(), hb1 = b1.host(), hw2 = w2.host(), hb2 = b2.host(), hw3 = w3.host(), hb3 = b3.host();
+    auto dmean = [&](const std::vector<float>& xin) {
+        double tot = 0;
+        std::vector<double> h1(H1), h2(H2);
+        for (int r = 0; r < B; ++r) {
+            for (int j = 0; j < H1; ++j) {
+                double a = hb1[j];
+                for (int k = 0; k < Din; ++k) a += (double)xin[(size_t)r * Din + k] * hw1[(size_t)j * Din + k];
+                h1[j] = a > 0 ? a : 0.2 * a;
+            }
+            for (int j = 0; j < H2; ++j) {
+                double a = hb2[j];
+                for (int k = 0; k < H1; ++k) a += h1[k] * hw2[(size_t)j * H1 + k];
+                h2[j] = a > 0 ? a : 0.2 * a;
+            }
+            double o = hb3[0];
+            for (int k = 0; k < H2; ++k) o += h2[k] * hw3[k];
+            tot += o;
+        }
+        return tot / B;
+    };
+    const double mr = dmean(hr), mf = dmean(hf);
+    std::vector<float> first_g;
+    float first_out[4] = {0, 0, 0, 0};
+    for (int grid : {0, 32, 64, 256}) {
+        CK(hipMemset(sync, 0, 16));
+        Buf gw1((size_t)H1 * Din, 0.f), gb1(H1, 0.f), gw2((size_t)H2 * H1, 0.f), gb2(H2, 0.f), gw3(H2, 0.f), gb3(1, 0.f), out(4, 0.f);
+        auto run = [&] {
+            RC(migan_critic_fused(real.d, fake.d, alpha.d, w1.d, b1.d, w2.d, b2.d, w3.d, b3.d, gw1.d, gb1.d, gw2.d, gb2.d, gw3.d, gb3.d, out.d, ws.d,
+                                  wsb, sync, B, Din, H1, H2, 0.2f, 10.f, grid, nullptr));
+        };
+        run();
+        CK(hipDeviceSynchronize());
+        unsigned hs[4];
+        CK(hipMemcpy(hs, sync, 16, hipMemcpyDeviceToHost));
+        std::vector<float> ho = out.host(), g1 = gw1.host();   // after ONE launch (the gradients are accumulated)
+        const float us = hs[2] == 0 ? time_us(run) : 0.f;
+        CK(hipMemcpy(hs, sync, 16, hipMemcpyDeviceToHost));
+        const bool fin = std::isfinite(ho[0]) && std::isfinite(ho[1]);
+        const double e = std::max(std::fabs(ho[2] - mr), std::fabs(ho[3] - mf)) / std::max(1.0, std::fabs(mr));
+        double rg = 0;
+        if (first_g.empty()) { first_g = g1; for (int i = 0; i < 4; ++i) first_out[i] = ho[i]; }
+        else rg = std::max(rel(g1, first_g), (double)std::fabs(ho[0] - first_out[0]) / std::max(1.f, std::fabs(first_out[0])));
+        const bool ok = hs[2] == 0 && fin && e <= 1e-4 && rg <= 1e-5;
+        if (!ok) ++failures;
+        printf("critic_fused B%d %d-%d-%d grid %-3d  barrier %s  d_loss %.6g gp %.6g  |mean D - fp64| %.1e  vs first grid %.1e  %s  %8.1f us\n", B, Din,
+               H1, H2, grid, hs[2] == 0 ? "held" : "TIMED OUT", ho[0], ho[1], e, rg, ok ? "ok" : "FAIL", us);
+        fflush(stdout);
+    }
+    (void)hipFree(sync);
+}
+
+static void mlp_case(int B) {
+    const int L = 5;
+    const int K[L] = {100, 128, 256, 512, 1024}, Nn[L] = {128, 256, 512, 1024, 1024}, bn[L] = {0, 1, 1, 1, 0}, actc[L] = {1, 1, 1, 1, 3};
+    int dims[4 * L];
+    float fpar[3 * L];
+    for (int l = 0; l < L; ++l) {
+        dims[4 * l] = K[l]; dims[4 * l + 1] = Nn[l]; dims[4 * l + 2] = bn[l]; dims[4 * l + 3] = actc[l];
+        fpar[3 * l] = 0.2f; fpar[3 * l + 1] = 0.8f; fpar[3 * l + 2] = 0.1f;
+    }
+    if (migan_mlp_fused_ok(B, L, dims) != 1) { printf("mlp_fused: shape not taken\n"); return; }
+    std::vector<Buf*> keep;
+    void* ptrs[7 * L];
+    std::vector<std::vector<float>> hW(L), hb(L), hg(L), hbe(L);
+    long long* nbt;
+    CK(hipMalloc((float**)&nbt, 8 * L));
+    CK(hipMemset(nbt, 0, 8 * L));
+    for (int l = 0; l < L; ++l) {
+        Buf* W = new Buf((size_t)Nn[l] * K[l], 1.0f / std::sqrt((float)K[l]));
+        Buf* b = new Buf(Nn[l], 0.1f);
+        keep.push_back(W); keep.push_back(b);
+        hW[l] = W->host(); hb[l] = b->host();
+        ptrs[7 * l] = W->d; ptrs[7 * l + 1] = b->d;
+        for (int q = 2; q < 7; ++q) ptrs[7 * l + q] = nullptr;
+        if (bn[l]) {
+            Buf* g = new Buf(Nn[l], 0.2f); Buf* be = new Buf(Nn[l], 0.1f); Buf* rm = new Buf(Nn[l], 0.f); Buf* rv = new Buf(Nn[l], 0.f);
+            keep.insert(keep.end(), {g, be, rm, rv});
+            hg[l] = g->host(); hbe[l] = be->host();
+            for (auto& v : hg[l]) v += 1.f;
+            CK(hipMemcpy(g->d, hg[l].data(), Nn[l] * 4, hipMemcpyHostToDevice));
+            ptrs[7 * l + 2] = g->d; ptrs[7 * l + 3] = be->d; ptrs[7 * l + 4] = rm->d; ptrs[7 * l + 5] = rv->d; ptrs[7 * l + 6] = nbt + l;
+        }
+    }
+    Buf x((size_t)B * K[0]);
+    // host fp64 forward: Linear -> BatchNorm1d(train, eps 0.8) -> LeakyReLU(0.2) | Tanh
+    std::vector<double> a(x.n);
+    { auto hx = x.host(); for (size_t i = 0; i < hx.size(); ++i) a[i] = hx[i]; }
+    for (int l = 0; l < L; ++l) {
+        std::vector<double> o((size_t)B * Nn[l]);
+        for (int r = 0; r < B; ++r)
+            for (int j = 0; j < Nn[l]; ++j) {
+                double s_ = hb[l][j];
+                for (int k = 0; k < K[l]; ++k) s_ += a[(size_t)r * K[l] + k] * hW[l][(size_t)j * K[l] + k];
+                o[(size_t)r * Nn[l] + j] = s_;
+            }
+        if (bn[l])
+            for (int j = 0; j < Nn[l]; ++j) {
+                double m = 0, v = 0;
+                for (int r = 0; r < B; ++r) m += o[(size_t)r * Nn[l] + j];
+                m /= B;
+                for (int r = 0; r < B; ++r) { double d = o[(size_t)r * Nn[l] + j] - m; v += d * d; }
+                const double is = 1.0 / std::sqrt(v / B + 0.8);
+                for (int r = 0; r < B; ++r) o[(size_t)r * Nn[l] + j] = (o[(size_t)r * Nn[l] + j] - m) * is * hg[l][j] + hbe[l][j];
+            }
+        for (auto& v : o) v = actc[l] == 1 ? (v > 0 ? v : 0.2 * v) : std::tanh(v);
+        a.swap(o);
+    }
+    std::vector<float> ref(a.begin(), a.end());
+    const size_t wsb = migan_mlp_fused_workspace(B, L, dims, 0);
+    Buf ws(wsb / 4, 0, false);
+    unsigned* sync;
+    CK(hipMalloc((float**)&sync, 16));
+    for (int grid : {0, 32, 128}) {
+        CK(hipMemset(sync, 0, 16));
+        Buf y((size_t)B * Nn[L - 1], 0, false);
+        auto run = [&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, sync, grid, nullptr)); };
+        run();
+        CK(hipDeviceSynchronize());
+        unsigned hs[4];
+        CK(hipMemcpy(hs, sync, 16, hipMemcpyDeviceToHost));
+        const double r = rel(y.host(), ref);
+        const float us = hs[2] == 0 ? time_us(run) : 0.f;
+        const bool ok = hs[2] == 0 && r <= 1e-5;
+        if (!ok) ++failures;
+        printf("mlp_fused_fwd B%d 100-128-256-512-1024-1024 grid %-3d  barrier %s  rel vs fp64 %.2e  %s  %8.1f us\n", B, grid,
+               hs[2] == 0 ? "held" : "TIMED OUT", r, ok ? "ok" : "FAIL", us);
+        fflush(stdout);
+    }
+    (void)hipFree(sync);
+    (void)hipFree(nbt);
+    for (Buf* b : keep) delete b;
+}
+
 int main(int argc, char** argv) {
     int dev = 0;
+#ifdef ABI_CHECK_HOST
+    for (const char* k : {"critic_fused_kernel", "mlp_fused_fwd_kernel", "mlp_fused_bwd_kernel"}) hipemu_add_coresident_kernel(k);
+#endif
     CK(hipSetDevice(dev));
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, dev));
@@ -298,6 +496,14 @@ int main(int argc, char** argv) {
         fewpix_case("fewpix 512->512 @16x16 (d5)", 1, 512, 16, 16, 512);
         fewpix_case("fewpix 1024->512 @8x8", 1, 1024, 8, 8, 512);
     }
+    if (want("norm")) {
+        norm_small_case("IN 512ch 2x2 lrelu+mask", 1, 4, 512, 1, true);
+        norm_small_case("IN 512ch 8x8 relu+mask", 1, 64, 512, 2, true);
+        norm_small_case("IN 256ch 32x32 lrelu", 1, 1024, 256, 1, false);
+        norm_small_case("IN 64ch 16x16 b8", 8, 256, 64, 0, false);
+    }
+    if (want("critic")) critic_case(64, 1024, 512, 256);
+    if (want("mlp")) mlp_case(64);
     migan_staged(B_ALL, 0);
     printf(failures ? "FAILED: %d comparison(s) out of bound\n" : "ALL OK\n", failures);
     return failures ? 1 : 0;
