@@ -1560,8 +1560,11 @@ static bool midk_ok(const ConvGeom& g) {
     const bool on = staged_on(STG_MIDK);  // MIGAN_MIDK=0 = off
     const int K = g.ntap[0] * g.Ci;
     const int cq_n = g.Co / 4;
-    return on && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 && K <= 128 &&
-           midk_lds_bytes(K, g.Co) <= 64 * 1024;
+    // measured (profiles/r03_abi_check.txt): 6 -> 64 4x4 s2 at batch 1 26.8 -> 22.5 us, 3 -> 64 3x3 at 2.4 M pixels 362 -> 316 us, but
+    // 3 -> 64 4x4 s2 at 131 k pixels (CycleGAN's discriminators at batch 8) 37.2 -> 45.3 us: that shape stays on the MFMA kernel
+    const bool loses = g.ntap[0] == 16 && g.Ci == 3 && (long)g.N * g.HoF * g.WoF >= 65536;
+    return on && !loses && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 &&
+           K <= 128 && midk_lds_bytes(K, g.Co) <= 64 * 1024;
 }
 static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
     if (maxM == 0) return 0;
