@@ -2,7 +2,7 @@
 // each staged kernel against the kernel it replaces (the same entry point with its migan_staged() bit cleared), results
 // compared on the host, both timed with hipEvents (min of 10 launches).  It links libmigan.so and the HIP runtime only, so a GPU
 // call costs seconds instead of the minute or two a first `import torch` takes on a fresh box:
-//     make -C tools abi_check && ./tools/abi_check.bin            (or: python tools/build_abi_check.py)
+//     tools/build_abi_check.sh && ./tools/abi_check.bin [thin|midk|reduce|pack|fewpix|norm|critic|mlp]      (host: tools/build_abi_check.sh host)
 // Exit status 0 = every comparison within its bound.  Test tooling, not a product path.
 #ifndef ABI_CHECK_HOST
 #include <hip/hip_runtime.h>

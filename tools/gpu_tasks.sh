@@ -234,7 +234,10 @@ t=${1:-}; shift || true
 #   MIGAN_MIDK             direct conv for the 3 / 6-channel first layers (conv_igemm.hip midk_tile_kernel)
 task_staged() {
   mkdir -p gpurun_out/staged
-  # first: what does the hardware self-check say, and how long does the probe take (cold, then from the cached verdict)
+  # torch-free: every staged kernel against the kernel it replaces / host fp64, with launch times (seconds)
+  [ -x tools/abi_check.bin ] || tools/build_abi_check.sh
+  timeout 120 ./tools/abi_check.bin > gpurun_out/staged/abi_check.txt 2>&1; echo "abi_check rc=$?"; tail -3 gpurun_out/staged/abi_check.txt
+  # then: what does the hardware self-check say, and how long does the probe take (cold, then from the cached verdict)
   for i in 1 2; do
     ( time timeout 300 python -c "
 import torch, pytorch_gan_amd
