@@ -597,6 +597,21 @@ def test_selfcheck_probe_stages_on_the_execution_model(emu):
     assert v["bits"] == 127 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
 
 
+def test_abi_check_harness_on_the_execution_model(emu, tmp_path):
+    """tools/abi_check.cpp - the torch-free program that compares every staged kernel with the kernel it replaces on the hardware
+    (profiles/r03_abi_check.txt) - built against the execution model instead of the HIP runtime: its arguments, geometries and host
+    references must hold here too (the quick sections; MIGAN_EMU_SLOW=1: all but the 2.4 M-pixel one)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "build_abi_check.sh"), "host"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
+    sections = ["thin", "pack", "norm", "mlp"] + (["reduce", "fewpix", "critic"] if os.environ.get("MIGAN_EMU_SLOW") == "1" else [])
+    for sec in sections:
+        r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900, env=dict(os.environ, MIGAN_K7_GRID="8"))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK") and "FAIL" not in r.stdout, (sec, r.stdout[-1500:], r.stderr[-400:])
+
+
 def test_smoke_body_on_the_execution_model(emu, capsys):
     """__graft_entry__.smoke() - the driver's first call on the GPU box - with its kernels on the execution model."""
     import __graft_entry__ as entry
