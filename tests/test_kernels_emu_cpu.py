@@ -439,6 +439,15 @@ def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monk
     _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
+@pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="3.5 minutes on 8 cores: MIGAN_EMU_SLOW=1")
+def test_pix2pix_trajectory_on_the_execution_model():
+    """test_steps_gpu.py::test_pix2pix_trajectory_5_steps (five pix2pix iterations at 256x256 three ways: HIP kernels, oracle fp32, oracle
+    fp64) with the kernels on the execution model - whose arithmetic is the hardware's: tools/abi_check prints the same differences
+    here and on the MI355X (profiles/r03_abi_check.txt)."""
+    lib = _run_gpu_test_body("test_steps_gpu", "test_pix2pix_trajectory_5_steps")
+    assert lib.hipemu_launch_count(b"fewpix_nt_kernel") == 40 and lib.hipemu_launch_count(b"norm_small_fwd_kernel") == 80
+
+
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="4 minutes on 8 cores: MIGAN_EMU_SLOW=1")
 def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")

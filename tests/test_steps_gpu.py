@@ -489,6 +489,49 @@ def test_pix2pix_step():
     _params_close(s_gpu.D, s_cpu.D, 1, "pix2pix D")
 
 
+def test_pix2pix_trajectory_5_steps():
+    """Five iterations of pix2pix.py:123-172 at the reference's 256x256, batch 1 (the U-Net's 1x1 bottleneck needs the full size),
+    three ways from the same weights, inputs and dropout masks: HIP path, the oracle in fp32, the oracle in fp64.  InstanceNorm over
+    2x2 ... 1x1 maps and Adam's sign-like first updates separate any two fp32 evaluations of this loop after the first step, so - as for
+    CycleGAN - step 0 is strict and the trajectory is compared statistically: rms |hip - f64| within 4x the fp32 oracle's own."""
+    from util import suite_budget
+
+    suite_budget(150, "test_pix2pix_trajectory_5_steps")
+    import pytorch_gan_amd as pg
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_pix2pix(256)
+    s_gpu = steps.make_pix2pix_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), 256)
+    _seed(0)
+    s_f64 = S.make_pix2pix(256)
+    s_f64.G.double()
+    s_f64.D.double()
+    s_f64.opt_G, s_f64.opt_D = S._adam(s_f64.G.parameters()), S._adam(s_f64.D.parameters())
+    _seed(5)
+    rows = []
+    for t in range(5):
+        a = torch.rand(1, 3, 256, 256) * 2 - 1
+        b = torch.rand(1, 3, 256, 256) * 2 - 1
+        rec = []
+        with M.feed_masks(record=rec):
+            o_c = S.pix2pix_step(s_cpu, a, b)
+        masks = [m.numpy() for m in rec]
+        f32 = S._f32
+        S._f32 = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+        try:
+            with M.feed_masks(masks=masks):
+                o_d = S.pix2pix_step(s_f64, a.double(), b.double())
+        finally:
+            S._f32 = f32
+        with pg.dropout_masks(masks):
+            o_g = steps.pix2pix_step(s_gpu, a.to(DEV), b.to(DEV))
+        rows.append((o_g, o_c, o_d))
+    _trajectory_close(rows, ("loss_G", "loss_D", "loss_pixel", "loss_GAN"), "pix2pix 256x256", floor=1e-3)
+
+
 def test_srgan_step():
     from oracle import reference_steps as S
     from pytorch_gan_amd import steps
