@@ -84,6 +84,7 @@ _CONV = [
     ("unet_mid", (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4, 2 | 32),     # pack_transpose (512 k), wgrad slabs
     ("fewpix_16px", (1, 128, 8, 8, 512, 4, 2, (1, 1, 1, 1), 0, 1, True), 1e-4, 64),         # fewpix conv: 16 rows, K = 2048, bias + LeakyReLU
     ("fewpix_1px", (1, 256, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 0, False), 1e-4, 64),         # fewpix conv: ONE output pixel (d8 of the U-Net)
+    ("fewpix_3x3_s1", (2, 256, 2, 2, 512, 3, 1, (1, 1, 1, 1), 0, 2, True), 1e-4, 64),       # fewpix conv: 3x3 stride 1 (VGG19 tail on small crops)
 ]
 _CONVT = [   # N, Cin, H, W, Cout, act, bias: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1)
     ("fewpix_convT_4px", (1, 512, 2, 2, 128, 2, True), 1e-4, 64),                           # fewpix transposed conv: 4 input pixels, ReLU

@@ -439,6 +439,14 @@ def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monk
     _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
+@pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="70 s on 8 cores: MIGAN_EMU_SLOW=1")
+def test_esrgan_full_depth_on_the_execution_model():
+    """test_steps_gpu.py::test_esrgan_full_depth_steps (23 RRDB generator, warm-up + relativistic iteration) on the execution model;
+    the VGG19 tail on 2x2 maps runs as few-pixel 3x3 stride-1 convs (csrc/fewpix.hip)."""
+    lib = _run_gpu_test_body("test_steps_gpu", "test_esrgan_full_depth_steps")
+    assert lib.hipemu_launch_count(b"im2col_small_kernel") > 0
+
+
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="3.5 minutes on 8 cores: MIGAN_EMU_SLOW=1")
 def test_pix2pix_trajectory_on_the_execution_model():
     """test_steps_gpu.py::test_pix2pix_trajectory_5_steps (five pix2pix iterations at 256x256 three ways: HIP kernels, oracle fp32, oracle

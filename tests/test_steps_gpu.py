@@ -580,6 +580,31 @@ def test_esrgan_steps():
     assert rel_fro(sr, want) < 1e-5
 
 
+def test_esrgan_full_depth_steps():
+    """esrgan.py:101-174 with the generator at its REAL depth (23 RRDB = 345 dense-block convs + the two PixelShuffle stages,
+    esrgan/models.py:18-83; the other ESRGAN tests use 2 blocks) on 8x8 -> 32x32 crops, batch 2: one pixel-loss warm-up iteration and
+    one relativistic GAN iteration against the oracle - losses, then every generator weight after two Adam steps."""
+    from util import suite_budget
+
+    suite_budget(60, "test_esrgan_full_depth_steps")
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_esrgan((32, 32), n_res=23)
+    s_cpu.warmup_batches = 1
+    s_gpu = steps.make_esrgan_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), gpu_copy(s_cpu.V), warmup_batches=1)
+    _seed(11)
+    for t in range(2):
+        lr, hr = torch.randn(2, 3, 8, 8), torch.randn(2, 3, 32, 32)
+        o_c = S.esrgan_step(s_cpu, lr, hr, t)
+        o_g = steps.esrgan_step(s_gpu, lr.to(DEV), hr.to(DEV), t)
+        assert o_c.keys() == o_g.keys()
+        for k in o_c:
+            _loss_close(o_g[k], o_c[k], "%s step %d (23 RRDB)" % (k, t), 2e-4)
+    _params_close(s_gpu.G, s_cpu.G, 2, "esrgan G, 23 RRDB")
+
+
 def test_acgan_steps(golden_dir):
     """SURVEY.md 8f F2 (acgan.py:167-222): Embedding * noise generator, two-headed discriminator (Sigmoid validity, Softmax
     classes fed to CrossEntropyLoss as the reference does), three iterations from the fixture's inputs and Dropout2d masks
