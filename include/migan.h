@@ -117,7 +117,10 @@ int migan_col2im_small(const float* ycol, const float* bias, float* out, int N, 
  * real, fake [B][Din]; alpha [B]; out[4] = d_loss, gp, mean D(real), mean D(fake).  B <= 64; Din, H1, H2 % 128 == 0.
  * ws: migan_critic_fused_workspace() bytes of scratch; sync: 4 unsigned ints zeroed ONCE by the caller (the kernel re-arms
  * them); grid: workgroups of the persistent launch, all of which must be resident at once (0 = 128).  The grid barrier spins
- * a bounded number of times: sync[2] != 0 afterwards means it gave up (results invalid, sync must be re-zeroed), never a hang. */
+ * a bounded number of times: sync[2] != 0 afterwards means it gave up (results invalid, sync must be re-zeroed), never a hang.
+ * Launch form: by default the kernel is launched once per phase (seven ordinary dependent launches, no grid barrier - measured
+ * faster on the MI355X than the barriers' L2 write-back / invalidate); MIGAN_K7_PERSIST=1 = the single persistent launch.  The same
+ * holds for migan_mlp_fused_fwd / _bwd (one launch per layer / per backward phase). */
 int migan_critic_fused_ok(int B, int Din, int H1, int H2);
 size_t migan_critic_fused_workspace(int B, int Din, int H1, int H2);
 int migan_critic_fused(const float* real, const float* fake, const float* alpha, const float* w1, const float* b1,

@@ -38,6 +38,8 @@ struct CriticFused {
     float* out;       // d_loss, gp, mean D(real), mean D(fake)
     float* ws;        // see cf_layout
     unsigned* sync;   // [0] barrier arrivals, [1] exits, [2] error flag (sticky: host clears)
+    int ph_lo, ph_hi; // this launch runs phases ph_lo..ph_hi (1..7): all seven = the persistent form with grid barriers between them;
+                      // one phase per launch = seven ordinary dependent launches, no barrier, no residency requirement
 };
 
 // workspace carve-up (floats); row blocks are [x^ | real | fake], RB rows each
@@ -222,270 +224,284 @@ __global__ __launch_bounds__(CF_THREADS) void critic_fused_kernel(const CriticFu
     if (threadIdx.x == 0) give_up = 0;
 
     // ---- phase 1: a1 of the real and fake rows, K = Din; three row blocks of h1 out
-    for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
-        const int g = t / (H1 / 16), c = t - g * (H1 / 16);
-        const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
-        const int arow = r0 + rr < B ? r0 + rr : B - 1;
-        f32x4 ar, af;
-        cf_nt_partial2(p.real + (size_t)arow * Din + ks * klen + kq * 4, p.fake + (size_t)arow * Din + ks * klen + kq * 4,
-                       p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen, ar, af);
-        if (ks > 0) {
-            part[0][(ks - 1) * 64 + lane] = ar;
-            part[1][(ks - 1) * 64 + lane] = af;
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) {
-                ar += part[0][(q - 1) * 64 + lane];
-                af += part[1][(q - 1) * 64 + lane];
+    if (p.ph_lo <= 1 && 1 <= p.ph_hi) {
+        for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
+            const int g = t / (H1 / 16), c = t - g * (H1 / 16);
+            const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
+            const int arow = r0 + rr < B ? r0 + rr : B - 1;
+            f32x4 ar, af;
+            cf_nt_partial2(p.real + (size_t)arow * Din + ks * klen + kq * 4, p.fake + (size_t)arow * Din + ks * klen + kq * 4,
+                           p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen, ar, af);
+            if (ks > 0) {
+                part[0][(ks - 1) * 64 + lane] = ar;
+                part[1][(ks - 1) * 64 + lane] = af;
             }
-            const int col = col0 + rr;
-            const float bv = p.b1[col];
+            __syncthreads();
+            if (ks == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = r0 + kq * 4 + r;
-                const bool ok = i < B;
-                const float al = p.alpha[ok ? i : 0];
-                const float vr = ar[r] + bv, vf = af[r] + bv;
-                const float vx = al * vr + (1.f - al) * vf;
-                h1b[(size_t)(0 * RB + i) * H1 + col] = ok ? cf_lrelu(vx, slope) : 0.f;
-                h1b[(size_t)(1 * RB + i) * H1 + col] = ok ? cf_lrelu(vr, slope) : 0.f;
-                h1b[(size_t)(2 * RB + i) * H1 + col] = ok ? cf_lrelu(vf, slope) : 0.f;
+                for (int q = 1; q < CF_WAVES; ++q) {
+                    ar += part[0][(q - 1) * 64 + lane];
+                    af += part[1][(q - 1) * 64 + lane];
+                }
+                const int col = col0 + rr;
+                const float bv = p.b1[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = r0 + kq * 4 + r;
+                    const bool ok = i < B;
+                    const float al = p.alpha[ok ? i : 0];
+                    const float vr = ar[r] + bv, vf = af[r] + bv;
+                    const float vx = al * vr + (1.f - al) * vf;
+                    h1b[(size_t)(0 * RB + i) * H1 + col] = ok ? cf_lrelu(vx, slope) : 0.f;
+                    h1b[(size_t)(1 * RB + i) * H1 + col] = ok ? cf_lrelu(vr, slope) : 0.f;
+                    h1b[(size_t)(2 * RB + i) * H1 + col] = ok ? cf_lrelu(vf, slope) : 0.f;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+    if (p.ph_lo <= 1 && 2 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
 
     // ---- phase 2: a2 for the 3 row blocks, K = H1; h2, S2 = [u2; da2_r; da2_f], per-tile row dots h2 . w3
-    for (int t = blockIdx.x; t < 3 * RG * (H2 / 16); t += gridDim.x) {
-        const int g = t / (H2 / 16), c = t - g * (H2 / 16);
-        const int blk = g / RG, r0 = g * 16 /* row in the stacked buffer */, col0 = c * 16, klen = H1 / CF_WAVES;
-        f32x4 acc = cf_nt_partial(h1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
-        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
-        __syncthreads();
-        if (ks == 0) {
+    if (p.ph_lo <= 2 && 2 <= p.ph_hi) {
+        for (int t = blockIdx.x; t < 3 * RG * (H2 / 16); t += gridDim.x) {
+            const int g = t / (H2 / 16), c = t - g * (H2 / 16);
+            const int blk = g / RG, r0 = g * 16 /* row in the stacked buffer */, col0 = c * 16, klen = H1 / CF_WAVES;
+            f32x4 acc = cf_nt_partial(h1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
+            if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+            __syncthreads();
+            if (ks == 0) {
 #pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
-            const int col = col0 + rr;
-            const float bv = p.b2[col], w3 = p.w3[col];
-            const float dout = blk == 0 ? 1.f : (blk == 1 ? -invB : invB);  // block 0: u2 = m2 (.) w3
+                for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+                const int col = col0 + rr;
+                const float bv = p.b2[col], w3 = p.w3[col];
+                const float dout = blk == 0 ? 1.f : (blk == 1 ? -invB : invB);  // block 0: u2 = m2 (.) w3
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + kq * 4 + r, i = row - blk * RB;
-                const bool ok = i < B;
-                const float h = ok ? cf_lrelu(acc[r] + bv, slope) : 0.f;
-                h2b[(size_t)row * H2 + col] = h;
-                s2b[(size_t)row * H2 + col] = ok ? dout * w3 * cf_mask(h, slope) : 0.f;
-                const float dot = cf_rowsum16(h * w3);
-                if (rr == 0) opart[(size_t)row * (H2 / 16) + c] = dot;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + kq * 4 + r, i = row - blk * RB;
+                    const bool ok = i < B;
+                    const float h = ok ? cf_lrelu(acc[r] + bv, slope) : 0.f;
+                    h2b[(size_t)row * H2 + col] = h;
+                    s2b[(size_t)row * H2 + col] = ok ? dout * w3 * cf_mask(h, slope) : 0.f;
+                    const float dot = cf_rowsum16(h * w3);
+                    if (rr == 0) opart[(size_t)row * (H2 / 16) + c] = dot;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
+    if (p.ph_lo <= 2 && 3 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
 
     // ---- phase 3: T = S2 W2 (NN, K = H2), S1 = m1 (.) T  (u1 for the x^ rows, da1 for real / fake)
-    for (int t = blockIdx.x; t < 3 * RG * (H1 / 32); t += gridDim.x) {
-        const int g = t / (H1 / 32), c = t - g * (H1 / 32);
-        const int r0 = g * 16, col0 = c * 32, rlen = H2 / CF_WAVES;
-        f32x4 a0, a1;
-        cf_nn_partial(s2b + (size_t)(r0 + rr) * H2 + ks * rlen + kq * 4, p.W2 + (size_t)(ks * rlen + kq * 4) * H1 + col0 + 2 * rr, H1, rlen, a0, a1);
-        if (ks > 0) {
-            part[0][(ks - 1) * 64 + lane] = a0;
-            part[1][(ks - 1) * 64 + lane] = a1;
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) {
-                a0 += part[0][(q - 1) * 64 + lane];
-                a1 += part[1][(q - 1) * 64 + lane];
+    if (p.ph_lo <= 3 && 3 <= p.ph_hi) {
+        for (int t = blockIdx.x; t < 3 * RG * (H1 / 32); t += gridDim.x) {
+            const int g = t / (H1 / 32), c = t - g * (H1 / 32);
+            const int r0 = g * 16, col0 = c * 32, rlen = H2 / CF_WAVES;
+            f32x4 a0, a1;
+            cf_nn_partial(s2b + (size_t)(r0 + rr) * H2 + ks * rlen + kq * 4, p.W2 + (size_t)(ks * rlen + kq * 4) * H1 + col0 + 2 * rr, H1, rlen, a0, a1);
+            if (ks > 0) {
+                part[0][(ks - 1) * 64 + lane] = a0;
+                part[1][(ks - 1) * 64 + lane] = a1;
             }
+            __syncthreads();
+            if (ks == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const size_t o = (size_t)(r0 + kq * 4 + r) * H1 + col0 + 2 * rr;
-                s1b[o] = cf_mask(h1b[o], slope) * a0[r];
-                s1b[o + 1] = cf_mask(h1b[o + 1], slope) * a1[r];
-            }
-        }
-        __syncthreads();
-    }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
-
-    // ---- phase 4: g = u1 W1 (NN, K = H1) for the x^ rows, per-tile row sums of squares
-    for (int t = blockIdx.x; t < RG * (Din / 32); t += gridDim.x) {
-        const int g = t / (Din / 32), c = t - g * (Din / 32);
-        const int r0 = g * 16, col0 = c * 32, rlen = H1 / CF_WAVES;
-        f32x4 a0, a1;
-        cf_nn_partial(s1b + (size_t)(r0 + rr) * H1 + ks * rlen + kq * 4, p.W1 + (size_t)(ks * rlen + kq * 4) * Din + col0 + 2 * rr, Din, rlen, a0, a1);
-        if (ks > 0) {
-            part[0][(ks - 1) * 64 + lane] = a0;
-            part[1][(ks - 1) * 64 + lane] = a1;
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) {
-                a0 += part[0][(q - 1) * 64 + lane];
-                a1 += part[1][(q - 1) * 64 + lane];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + kq * 4 + r;
-                const size_t o = (size_t)row * Din + col0 + 2 * rr;
-                gb[o] = a0[r];
-                gb[o + 1] = a1[r];
-                const float sq = cf_rowsum16(a0[r] * a0[r] + a1[r] * a1[r]);
-                if (rr == 0) gsq[(size_t)row * (Din / 32) + c] = sq;
-            }
-        }
-        __syncthreads();
-    }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
-
-    // ---- phase 5: gradient norms -> coef, gp; du1 = coef (g W1^T) (NT, K = Din); dv1 = m1(x^) (.) du1
-    if (blockIdx.x == 0 && ks == 0) {  // the whole batch once: coef for phase 7, the penalty value
-        float n2 = 0.f;
-        if (lane < B)
-            for (int c = 0; c < Din / 32; ++c) n2 += gsq[(size_t)lane * (Din / 32) + c];
-        const float n = sqrtf(n2);
-        coefb[lane] = lane < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
-        const float pen = cf_wavesum(lane < B ? (n - 1.f) * (n - 1.f) : 0.f);
-        if (lane == 0) p.out[1] = pen * invB;
-    }
-    for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
-        const int g = t / (H1 / 16), c = t - g * (H1 / 16);
-        const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
-        f32x4 acc = cf_nt_partial(gb + (size_t)(r0 + rr) * Din + ks * klen + kq * 4, p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen);
-        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
-        if (threadIdx.x < 16) {  // this tile's 16 rows
-            const int i = r0 + threadIdx.x;
-            float n2 = 0.f;
-            for (int cc = 0; cc < Din / 32; ++cc) n2 += gsq[(size_t)i * (Din / 32) + cc];
-            const float n = sqrtf(n2);
-            coef_s[threadIdx.x] = i < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + kq * 4 + r;
-                const size_t o = (size_t)row * H1 + col0 + rr;
-                dv1b[o] = cf_mask(h1b[o], slope) * coef_s[kq * 4 + r] * acc[r];   // h1b block 0 = the x^ rows
-            }
-        }
-        __syncthreads();
-    }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
-
-    // ---- phase 6: du2 = dv1 W2^T (NT, K = H1); e = m2(x^) (.) du2
-    for (int t = blockIdx.x; t < RG * (H2 / 16); t += gridDim.x) {
-        const int g = t / (H2 / 16), c = t - g * (H2 / 16);
-        const int r0 = g * 16, col0 = c * 16, klen = H1 / CF_WAVES;
-        f32x4 acc = cf_nt_partial(dv1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
-        if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const size_t o = (size_t)(r0 + kq * 4 + r) * H2 + col0 + rr;
-                eb[o] = cf_mask(h2b[o], slope) * acc[r];
-            }
-        }
-        __syncthreads();
-    }
-    if (!cf_grid_barrier(p.sync, target, &give_up)) return;
-
-    // ---- phase 7: weight / bias gradients and the losses.  Wave tiles: dW1 (H1/16 x Din/64), dW2 (H2/16 x H1/64), one misc tile
-    {
-        const int nt1 = (H1 / 16) * (Din / 64), nt2 = (H2 / 16) * (H1 / 64);
-        for (int wt = blockIdx.x * CF_WAVES + ks; wt < nt1 + nt2 + 1; wt += gridDim.x * CF_WAVES) {
-            if (wt < nt1 + nt2) {
-                const bool first = wt < nt1;
-                const int w = first ? wt : wt - nt1;
-                const int N = first ? H1 : H2, K = first ? Din : H1;
-                const int ktiles = K / 64;
-                const int nt = w / ktiles, kt = w - nt * ktiles;
-                const int n0 = nt * 16, k0 = kt * 64;
-                const float* S = first ? s1b : s2b;            // A operand [3 RB][N]
-                float* dW = first ? p.gW1 : p.gW2;
-                float* db = first ? p.gb1 : p.gb2;
-                f32x4 acc[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-                float colsum = 0.f;
-                for (int blk = 0; blk < 3; ++blk) {
-                    // right operand rows of this block: x^ -> coef (.) g | dv1;  real / fake -> the inputs | h1
-                    const float* Rb = first ? (blk == 0 ? gb : (blk == 1 ? p.real : p.fake)) : (blk == 0 ? dv1b : h1b + (size_t)blk * RB * H1);
-                    for (int m0 = 0; m0 < RB; m0 += 16) {
-                        float a[4];
-                        f32x4 b[4];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const int m = m0 + 4 * s + kq;
-                            const int mc = m < B ? m : B - 1;
-                            const float av = S[(size_t)(blk * RB + mc) * N + n0 + rr];
-                            f32x4 bv = *reinterpret_cast<const f32x4*>(Rb + (size_t)mc * K + k0 + 4 * rr);
-                            if (first && blk == 0) bv *= coefb[mc];
-                            a[s] = m < B ? av : 0.f;
-                            b[s] = bv;
-                        }
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            if (blk > 0) colsum += a[s];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[e] = cf_mfma(a[s], b[s][e], acc[e]);
-                        }
-                    }
+                for (int q = 1; q < CF_WAVES; ++q) {
+                    a0 += part[0][(q - 1) * 64 + lane];
+                    a1 += part[1][(q - 1) * 64 + lane];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* o = dW + (size_t)(n0 + kq * 4 + r) * K + k0 + 4 * rr;
-                    f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                    v += *reinterpret_cast<const f32x4*>(o);
-                    *reinterpret_cast<f32x4*>(o) = v;
+                    const size_t o = (size_t)(r0 + kq * 4 + r) * H1 + col0 + 2 * rr;
+                    s1b[o] = cf_mask(h1b[o], slope) * a0[r];
+                    s1b[o + 1] = cf_mask(h1b[o + 1], slope) * a1[r];
                 }
-                if (kt == 0) {  // wave-uniform: bias gradient = column sums of the real / fake rows of S
-                    colsum += __shfl_xor(colsum, 16);
-                    colsum += __shfl_xor(colsum, 32);
-                    if (kq == 0) db[n0 + rr] += colsum;
+            }
+            __syncthreads();
+        }
+    }
+    if (p.ph_lo <= 3 && 4 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 4: g = u1 W1 (NN, K = H1) for the x^ rows, per-tile row sums of squares
+    if (p.ph_lo <= 4 && 4 <= p.ph_hi) {
+        for (int t = blockIdx.x; t < RG * (Din / 32); t += gridDim.x) {
+            const int g = t / (Din / 32), c = t - g * (Din / 32);
+            const int r0 = g * 16, col0 = c * 32, rlen = H1 / CF_WAVES;
+            f32x4 a0, a1;
+            cf_nn_partial(s1b + (size_t)(r0 + rr) * H1 + ks * rlen + kq * 4, p.W1 + (size_t)(ks * rlen + kq * 4) * Din + col0 + 2 * rr, Din, rlen, a0, a1);
+            if (ks > 0) {
+                part[0][(ks - 1) * 64 + lane] = a0;
+                part[1][(ks - 1) * 64 + lane] = a1;
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int q = 1; q < CF_WAVES; ++q) {
+                    a0 += part[0][(q - 1) * 64 + lane];
+                    a1 += part[1][(q - 1) * 64 + lane];
                 }
-            } else {
-                // misc tile (one wave): dw3, db3, the loss values
-                for (int j = lane; j < H2; j += 64) {
-                    float s = 0.f;
-                    for (int i = 0; i < B; ++i)
-                        s += invB * (h2b[(size_t)(2 * RB + i) * H2 + j] - h2b[(size_t)(RB + i) * H2 + j]) + eb[(size_t)i * H2 + j];
-                    p.gw3[j] += s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + kq * 4 + r;
+                    const size_t o = (size_t)row * Din + col0 + 2 * rr;
+                    gb[o] = a0[r];
+                    gb[o + 1] = a1[r];
+                    const float sq = cf_rowsum16(a0[r] * a0[r] + a1[r] * a1[r]);
+                    if (rr == 0) gsq[(size_t)row * (Din / 32) + c] = sq;
                 }
-                float sr = 0.f, sf = 0.f;
-                if (lane < B)
-                    for (int c = 0; c < H2 / 16; ++c) {
-                        sr += opart[(size_t)(RB + lane) * (H2 / 16) + c];
-                        sf += opart[(size_t)(2 * RB + lane) * (H2 / 16) + c];
+            }
+            __syncthreads();
+        }
+    }
+    if (p.ph_lo <= 4 && 5 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 5: gradient norms -> coef, gp; du1 = coef (g W1^T) (NT, K = Din); dv1 = m1(x^) (.) du1
+    if (p.ph_lo <= 5 && 5 <= p.ph_hi) {
+        if (blockIdx.x == 0 && ks == 0) {  // the whole batch once: coef for phase 7, the penalty value
+            float n2 = 0.f;
+            if (lane < B)
+                for (int c = 0; c < Din / 32; ++c) n2 += gsq[(size_t)lane * (Din / 32) + c];
+            const float n = sqrtf(n2);
+            coefb[lane] = lane < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+            const float pen = cf_wavesum(lane < B ? (n - 1.f) * (n - 1.f) : 0.f);
+            if (lane == 0) p.out[1] = pen * invB;
+        }
+        for (int t = blockIdx.x; t < RG * (H1 / 16); t += gridDim.x) {
+            const int g = t / (H1 / 16), c = t - g * (H1 / 16);
+            const int r0 = g * 16, col0 = c * 16, klen = Din / CF_WAVES;
+            f32x4 acc = cf_nt_partial(gb + (size_t)(r0 + rr) * Din + ks * klen + kq * 4, p.W1 + (size_t)(col0 + rr) * Din + ks * klen + kq * 4, klen);
+            if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+            if (threadIdx.x < 16) {  // this tile's 16 rows
+                const int i = r0 + threadIdx.x;
+                float n2 = 0.f;
+                for (int cc = 0; cc < Din / 32; ++cc) n2 += gsq[(size_t)i * (Din / 32) + cc];
+                const float n = sqrtf(n2);
+                coef_s[threadIdx.x] = i < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = r0 + kq * 4 + r;
+                    const size_t o = (size_t)row * H1 + col0 + rr;
+                    dv1b[o] = cf_mask(h1b[o], slope) * coef_s[kq * 4 + r] * acc[r];   // h1b block 0 = the x^ rows
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.ph_lo <= 5 && 6 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 6: du2 = dv1 W2^T (NT, K = H1); e = m2(x^) (.) du2
+    if (p.ph_lo <= 6 && 6 <= p.ph_hi) {
+        for (int t = blockIdx.x; t < RG * (H2 / 16); t += gridDim.x) {
+            const int g = t / (H2 / 16), c = t - g * (H2 / 16);
+            const int r0 = g * 16, col0 = c * 16, klen = H1 / CF_WAVES;
+            f32x4 acc = cf_nt_partial(dv1b + (size_t)(r0 + rr) * H1 + ks * klen + kq * 4, p.W2 + (size_t)(col0 + rr) * H1 + ks * klen + kq * 4, klen);
+            if (ks > 0) part[0][(ks - 1) * 64 + lane] = acc;
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int q = 1; q < CF_WAVES; ++q) acc += part[0][(q - 1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(r0 + kq * 4 + r) * H2 + col0 + rr;
+                    eb[o] = cf_mask(h2b[o], slope) * acc[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.ph_lo <= 6 && 7 <= p.ph_hi && !cf_grid_barrier(p.sync, target, &give_up)) return;
+
+    // ---- phase 7: weight / bias gradients and the losses.  Wave tiles: dW1 (H1/16 x Din/64), dW2 (H2/16 x H1/64), one misc tile
+    if (p.ph_lo <= 7 && 7 <= p.ph_hi) {
+        {
+            const int nt1 = (H1 / 16) * (Din / 64), nt2 = (H2 / 16) * (H1 / 64);
+            for (int wt = blockIdx.x * CF_WAVES + ks; wt < nt1 + nt2 + 1; wt += gridDim.x * CF_WAVES) {
+                if (wt < nt1 + nt2) {
+                    const bool first = wt < nt1;
+                    const int w = first ? wt : wt - nt1;
+                    const int N = first ? H1 : H2, K = first ? Din : H1;
+                    const int ktiles = K / 64;
+                    const int nt = w / ktiles, kt = w - nt * ktiles;
+                    const int n0 = nt * 16, k0 = kt * 64;
+                    const float* S = first ? s1b : s2b;            // A operand [3 RB][N]
+                    float* dW = first ? p.gW1 : p.gW2;
+                    float* db = first ? p.gb1 : p.gb2;
+                    f32x4 acc[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float colsum = 0.f;
+                    for (int blk = 0; blk < 3; ++blk) {
+                        // right operand rows of this block: x^ -> coef (.) g | dv1;  real / fake -> the inputs | h1
+                        const float* Rb = first ? (blk == 0 ? gb : (blk == 1 ? p.real : p.fake)) : (blk == 0 ? dv1b : h1b + (size_t)blk * RB * H1);
+                        for (int m0 = 0; m0 < RB; m0 += 16) {
+                            float a[4];
+                            f32x4 b[4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const int m = m0 + 4 * s + kq;
+                                const int mc = m < B ? m : B - 1;
+                                const float av = S[(size_t)(blk * RB + mc) * N + n0 + rr];
+                                f32x4 bv = *reinterpret_cast<const f32x4*>(Rb + (size_t)mc * K + k0 + 4 * rr);
+                                if (first && blk == 0) bv *= coefb[mc];
+                                a[s] = m < B ? av : 0.f;
+                                b[s] = bv;
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                if (blk > 0) colsum += a[s];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[e] = cf_mfma(a[s], b[s][e], acc[e]);
+                            }
+                        }
                     }
-                sr = cf_wavesum(sr);
-                sf = cf_wavesum(sf);
-                if (lane == 0) {
-                    const float b3 = p.b3[0];
-                    const float mr = sr * invB + b3, mf = sf * invB + b3;
-                    p.out[2] = mr;
-                    p.out[3] = mf;
-                    p.out[0] = -mr + mf + p.lambda * p.out[1];
-                    p.gb3[0] += 0.f;  // sum of do = -1 + 1: the reference's gradient of b3 is exactly zero as well
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* o = dW + (size_t)(n0 + kq * 4 + r) * K + k0 + 4 * rr;
+                        f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                        v += *reinterpret_cast<const f32x4*>(o);
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    }
+                    if (kt == 0) {  // wave-uniform: bias gradient = column sums of the real / fake rows of S
+                        colsum += __shfl_xor(colsum, 16);
+                        colsum += __shfl_xor(colsum, 32);
+                        if (kq == 0) db[n0 + rr] += colsum;
+                    }
+                } else {
+                    // misc tile (one wave): dw3, db3, the loss values
+                    for (int j = lane; j < H2; j += 64) {
+                        float s = 0.f;
+                        for (int i = 0; i < B; ++i)
+                            s += invB * (h2b[(size_t)(2 * RB + i) * H2 + j] - h2b[(size_t)(RB + i) * H2 + j]) + eb[(size_t)i * H2 + j];
+                        p.gw3[j] += s;
+                    }
+                    float sr = 0.f, sf = 0.f;
+                    if (lane < B)
+                        for (int c = 0; c < H2 / 16; ++c) {
+                            sr += opart[(size_t)(RB + lane) * (H2 / 16) + c];
+                            sf += opart[(size_t)(2 * RB + lane) * (H2 / 16) + c];
+                        }
+                    sr = cf_wavesum(sr);
+                    sf = cf_wavesum(sf);
+                    if (lane == 0) {
+                        const float b3 = p.b3[0];
+                        const float mr = sr * invB + b3, mf = sf * invB + b3;
+                        p.out[2] = mr;
+                        p.out[3] = mf;
+                        p.out[0] = -mr + mf + p.lambda * p.out[1];
+                        p.gb3[0] += 0.f;  // sum of do = -1 + 1: the reference's gradient of b3 is exactly zero as well
+                    }
                 }
             }
         }
     }
-    // ---- leave: the last workgroup out re-arms the barrier for the next launch
+    // ---- leave: the last workgroup out re-arms the barrier for the next launch (single-phase launches never touched it)
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && p.ph_hi > p.ph_lo) {
         const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) {
             __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -520,7 +536,23 @@ MIGAN_API int migan_critic_fused(const float* real, const float* fake, const flo
     static const int grid_env = getenv("MIGAN_K7_GRID") ? atoi(getenv("MIGAN_K7_GRID")) : 0;
     int g = grid > 0 ? grid : (grid_env > 0 ? grid_env : 128);
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(critic_fused_kernel, dim3(g), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
-    HIP_LAUNCH_CHECK();
+    // Measured on the MI355X (profiles/r03_abi_check.txt): the ONE persistent launch takes 152 us at 128 workgroups - ~20 us per phase,
+    // because every grid barrier's agent-scope release / acquire writes back and invalidates the L2 (buffer_wbl2 / buffer_inv sc1) and the
+    // phase behind it re-fetches its weights - while a small dependent launch costs ~5-6 us on this device.  So the default is the same
+    // kernel once per phase: seven ordinary launches, no grid barrier, no residency requirement, nothing to time out.
+    // MIGAN_K7_PERSIST=1 = the single persistent launch.
+    static const int persist = getenv("MIGAN_K7_PERSIST") ? atoi(getenv("MIGAN_K7_PERSIST")) : 0;
+    if (persist) {
+        p.ph_lo = 1;
+        p.ph_hi = 7;
+        hipLaunchKernelGGL(critic_fused_kernel, dim3(g), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
+    for (int ph = 1; ph <= 7; ++ph) {
+        p.ph_lo = p.ph_hi = ph;
+        hipLaunchKernelGGL(critic_fused_kernel, dim3(g), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+    }
     return 0;
 }

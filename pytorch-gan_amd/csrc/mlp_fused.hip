@@ -29,6 +29,8 @@ struct MlpFused {
     float* ws;        // two [RB][maxN] activation buffers (forward without a graph), or the save buffer (see MlpSave)
     int saving;       // 1: every layer's output (and normalised pre-affine value + invstd of the BatchNorm layers) is kept for mlp_fused_bwd
     unsigned* sync;   // [0] arrivals, [1] exits, [2] error flag
+    int l_lo, l_hi;   // this launch runs layers l_lo .. l_hi - 1: all = the persistent form (grid barrier between layers); one layer per
+                      // launch = ordinary dependent launches (measured faster on the MI355X, see migan_mlp_fused_fwd)
     MlpLayer L[MF_MAX_LAYERS];
 };
 // Save buffer of a forward that will be differentiated: for layer l < last h_l [RB][N_l]; for BatchNorm layers xhat_l [RB][N_l]
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     unsigned target = 0;
     if (threadIdx.x == 0) give_up = 0;
 
-    for (int l = 0; l < p.nlayers; ++l) {
+    for (int l = p.l_lo; l < p.l_hi; ++l) {
         const MlpLayer& Ly = p.L[l];
         const int K = Ly.K, N = Ly.N;
         const MlpSave S = mf_save_at(RB, p.nlayers, p.L, l), Sp = mf_save_at(RB, p.nlayers, p.L, l > 0 ? l - 1 : 0);
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
             __syncthreads();
         }
         if (Ly.bn && Ly.nbt && blockIdx.x == 0 && threadIdx.x == 0) *Ly.nbt += 1;
-        if (l + 1 < p.nlayers && !mf_grid_barrier(p.sync, target, &give_up)) return;
+        if (l + 1 < p.l_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && p.l_hi - p.l_lo > 1) {   // (a one-layer launch never touched the barrier)
         const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) {
             __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -255,6 +257,7 @@ struct MlpBwd {
     unsigned* sync;
     MlpLayer L[MF_MAX_LAYERS];
     float *gW[MF_MAX_LAYERS], *gb[MF_MAX_LAYERS], *ggamma[MF_MAX_LAYERS], *gbeta[MF_MAX_LAYERS];
+    int ph_lo, ph_hi;   // phases of this launch: 0 = top, j = 1 .. NL the layer l = NL - j of the chain, NL + 1 = weight / bias gradients
 };
 static __host__ __device__ inline size_t mf_dpre_off(int RB, int nlayers, const MlpLayer* L, int l) {
     size_t o = 0;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
     if (threadIdx.x == 0) give_up = 0;
 
     // ---- top: dpre of the last layer from dy (16 columns x all rows per workgroup; only the ks == 0 waves work)
-    {
+    if (p.ph_lo <= 0 && 0 <= p.ph_hi) {
         const int l = NL - 1;
         const MlpLayer& Ly = p.L[l];
         const int N = Ly.N, ld = (N + 15) / 16 * 16;
@@ -362,11 +365,13 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             __syncthreads();
         }
     }
-    if (!mf_grid_barrier(p.sync, target, &give_up)) return;
+    if (p.ph_lo <= 0 && 1 <= p.ph_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
 
     // ---- l = L-1 .. 1: dpre_{l-1} from dpre_l;  l = 0: dx (when wanted)
     for (int l = NL - 1; l >= 0; --l) {
         if (l == 0 && !p.dx) break;
+        const int ph = NL - l;
+        if (ph < p.ph_lo || ph > p.ph_hi) continue;
         const MlpLayer& Ly = p.L[l];
         const int R = Ly.N, ldR = (R + 15) / 16 * 16, Nc = Ly.K;   // T[rows][Nc] = dpre_l[rows][R] W_l[R][Nc]
         const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
@@ -473,11 +478,12 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         const bool more = l > 1 || (l == 1 && p.dx != nullptr);
         bool any_grad = false;
         for (int q = 0; q < NL; ++q) any_grad = any_grad || p.gW[q] != nullptr || p.gb[q] != nullptr;
-        if ((more || any_grad) && !mf_grid_barrier(p.sync, target, &give_up)) return;
+        // (the phase behind this one - the next layer of the chain, or the gradients - runs in this launch too: barrier)
+        if ((more || any_grad) && (more ? ph + 1 : NL + 1) <= p.ph_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
     }
 
     // ---- last: weight / bias gradients, one 16 (n) x 64 (k) tile per wave
-    {
+    if (p.ph_lo <= NL + 1 && NL + 1 <= p.ph_hi) {
         int base = 0;
         for (int l = 0; l < NL; ++l) {
             const MlpLayer& Ly = p.L[l];
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && p.ph_hi > p.ph_lo) {
         const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1) {
             __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -546,6 +552,10 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
     }
 }
 
+static bool mf_persist() {
+    static const int v = getenv("MIGAN_K7_PERSIST") ? atoi(getenv("MIGAN_K7_PERSIST")) : 0;
+    return v != 0;
+}
 static bool mf_fill_layers(MlpLayer* L, int nlayers, const int* dims, const float* fpar, void* const* ptrs) {
     for (int l = 0; l < nlayers; ++l) {
         MlpLayer& Y = L[l];
@@ -618,8 +628,23 @@ MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, 
         p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
         tiles = (p.L[l].N + 15) / 16 > tiles ? (p.L[l].N + 15) / 16 : tiles;
     }
-    hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
-    HIP_LAUNCH_CHECK();
+    // Measured on the MI355X (profiles/r03_abi_check.txt): the ONE persistent launch of the 5-layer generator takes 63 us - a grid
+    // barrier's agent-scope release / acquire writes back and invalidates the L2, so every layer re-fetches its weights (~12-20 us per
+    // layer) - while a small dependent launch costs ~5-6 us.  Default: the same kernel once per layer, no barrier, no residency
+    // requirement.  MIGAN_K7_PERSIST=1 = the single persistent launch.
+    if (mf_persist()) {
+        p.l_lo = 0;
+        p.l_hi = nlayers;
+        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
+    for (int l = 0; l < nlayers; ++l) {
+        p.l_lo = l;
+        p.l_hi = l + 1;
+        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+    }
     return 0;
 }
 // Backward of migan_mlp_fused_fwd(.., save = 1): dy [B][N_last] -> parameter gradients ADDED into gptrs[4*l] = {dW [N][K], db [N],
@@ -643,7 +668,22 @@ MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* d
             tiles = p.L[l].K / 32 > tiles ? p.L[l].K / 32 : tiles;
         }
     }
-    hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
-    HIP_LAUNCH_CHECK();
+    bool any_grad = false;
+    for (int l = 0; l < nlayers; ++l) any_grad = any_grad || p.gW[l] != nullptr || p.gb[l] != nullptr;
+    if (mf_persist()) {
+        p.ph_lo = 0;
+        p.ph_hi = nlayers + 1;
+        hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
+    // one launch per phase (see migan_mlp_fused_fwd): top, the chain l = NL-1 .. 1 (.. 0 when dx is wanted), the gradients
+    for (int ph = 0; ph <= nlayers + 1; ++ph) {
+        if (ph == nlayers && !dx) continue;          // l = 0 computes only dx
+        if (ph == nlayers + 1 && !any_grad) continue;
+        p.ph_lo = p.ph_hi = ph;
+        hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        HIP_LAUNCH_CHECK();
+    }
     return 0;
 }
