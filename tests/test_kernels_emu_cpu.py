@@ -119,6 +119,55 @@ def test_every_gpu_conv_case_on_the_execution_model(emu):
         assert emu.hipemu_launch_count(sym.encode()) > 0, sym
 
 
+def test_results_do_not_depend_on_the_wave_schedule(emu):
+    """A model that switches fibers only at synchronisation points runs the waves of a workgroup in ONE order between two
+    barriers: a missing __syncthreads (two waves touching the same LDS / global word with no barrier between them) is invisible in
+    that order - and changes the result in another.  Every conv case (all kernel families), the staged kernels' self-check cases
+    (small-tensor InstanceNorm, few-pixel conv path, PatchGAN heads, packs) and the fused critic kernel: waves in index order, in
+    reverse order and in a seeded random order per scheduler pass must give bit-identical results."""
+    import hipemu.host
+    from pytorch_gan_amd import selfcheck
+
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    cases = _gpu_conv_cases() + KTAIL_CASES
+
+    def conv_pass():
+        return [sorted(_conv_case(emu, c, sk).items()) for c in cases]
+
+    def mirror_pass():
+        from pytorch_gan_amd import functional as F
+
+        out = {}
+        with hipemu.host.emulated_device() as lib:
+            lib.migan_staged(0, 127)
+            saved = selfcheck._quiet_scope(F)
+            try:
+                with torch.enable_grad():
+                    for name, _tol, fn in selfcheck._all_cases(F, selfcheck.ALL):
+                        gen = torch.Generator(device="cpu")
+                        gen.manual_seed(99)
+                        out[name] = {k: v.clone() for k, v in fn(gen).items()}
+            finally:
+                selfcheck._restore_scope(F, saved)
+        return out
+
+    try:
+        emu.hipemu_set_wave_schedule(0, 1)
+        conv_ref, mirror_ref = conv_pass(), mirror_pass()
+        for mode, seed in ((1, 1), (2, 7)):
+            emu.hipemu_set_wave_schedule(mode, seed)
+            got = conv_pass()
+            for c, a, b in zip(cases, conv_ref, got):
+                assert a == b, ("wave schedule changes a conv result", mode, c, a, b)
+            if mode == 1:
+                m = mirror_pass()
+                for name, tensors in mirror_ref.items():
+                    for k, v in tensors.items():
+                        assert torch.equal(v, m[name][k]), ("wave schedule changes a result", name, k)
+    finally:
+        emu.hipemu_set_wave_schedule(0, 1)
+
+
 KTAIL_CASES = [
     (2, 40, 10, 10, 72, 3, 1, (1, 1, 1, 1), 0, 1, True),     # Ci = 40: one full K-tile + a tail of 8 channels
     (2, 100, 6, 6, 36, 3, 1, (1, 1, 1, 1), 0, 0, False),     # Ci = 100
