@@ -549,9 +549,10 @@ MIGAN_API int migan_critic_fused(const float* real, const float* fake, const flo
         HIP_LAUNCH_CHECK();
         return 0;
     }
+    const int gs = (grid > 0 || grid_env > 0) ? g : 256;   // no residency requirement here: a workgroup per tile of the widest phase (192)
     for (int ph = 1; ph <= 7; ++ph) {
         p.ph_lo = p.ph_hi = ph;
-        hipLaunchKernelGGL(critic_fused_kernel, dim3(g), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(critic_fused_kernel, dim3(gs), dim3(CF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;
