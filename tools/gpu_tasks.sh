@@ -237,6 +237,9 @@ task_staged() {
   # torch-free: every staged kernel against the kernel it replaces / host fp64, with launch times (seconds)
   [ -x tools/abi_check.bin ] || tools/build_abi_check.sh
   timeout 120 ./tools/abi_check.bin > gpurun_out/staged/abi_check.txt 2>&1; echo "abi_check rc=$?"; tail -3 gpurun_out/staged/abi_check.txt
+  # the fused WGAN-GP kernels as ONE persistent launch (152 / 63 us in round 3) against the default one-launch-per-phase form above
+  for s in critic mlp; do MIGAN_K7_PERSIST=1 timeout 60 ./tools/abi_check.bin $s >> gpurun_out/staged/abi_check_persist.txt 2>&1; done
+  grep -E "critic_fused|mlp_fused" gpurun_out/staged/abi_check.txt gpurun_out/staged/abi_check_persist.txt
   # then: what does the hardware self-check say, and how long does the probe take (cold, then from the cached verdict)
   for i in 1 2; do
     ( time timeout 300 python -c "
