@@ -598,7 +598,8 @@ def test_selfcheck_cases_select_the_staged_kernels(emu):
         assert worst < 1e-5, selfcheck.detail()   # staged and replaced kernels differ by summation order only
 
 
-@pytest.mark.parametrize("broken,bit", [("migan_norm_fwd_small", "norm_small"), ("migan_permute4d", "pack_transpose")])
+@pytest.mark.parametrize("broken,bit", [("migan_norm_fwd_small", "norm_small")] + (
+    [("migan_permute4d", "pack_transpose")] if os.environ.get("MIGAN_EMU_SLOW") == "1" else []))
 def test_selfcheck_takes_a_disagreeing_kernel_out_of_service(emu, broken, bit):
     """A staged kernel that computes something else on the hardware than the kernel it replaces (simulated: the C entry's
     output is perturbed whenever the staged bit is set) loses its bit, is named in the report, and the others stay."""
@@ -649,11 +650,14 @@ def test_selfcheck_probe_stages_on_the_execution_model(emu):
     from pytorch_gan_amd import selfcheck
 
     slow = os.environ.get("MIGAN_EMU_SLOW") == "1"
-    stages = ["bits"] + (["workload"] if slow else []) + ["persistent"]
+    # quick mode: the per-kernel comparisons have their own test (test_selfcheck_cases_select_the_staged_kernels) - here they count as
+    # done by an earlier probe process (known_ok), so the glue, the restart bookkeeping and the WGAN-GP pass are what runs
+    stages = (["bits", "workload"] if slow else ["bits"]) + ["persistent"]
+    known = 0 if slow else 127
     with hipemu.host.emulated_device() as lib:
         lib.migan_staged(0, 127)
         records = [{"event": "begin", "name": "device"}, {"event": "end", "name": "device", "ok": True}]
-        keep = selfcheck._probe_stages(torch.device("cpu"), 127, 0, stages,
+        keep = selfcheck._probe_stages(torch.device("cpu"), 127, known, stages,
                                        lambda ev, name, **kw: records.append(dict(kw, event=ev, name=name)), lambda: None)
         records.append({"event": "end", "name": "probe", "ok": True})
         assert keep == 127 and lib.migan_staged(0, 0) == 127
@@ -662,6 +666,8 @@ def test_selfcheck_probe_stages_on_the_execution_model(emu):
         return ([r for r in records if r["name"] != "workload"] + [{"event": "begin", "name": "workload"},
                 {"event": "end", "name": "workload", "ok": True}] if not slow else records), "exit 0"
 
+    if not slow:   # what the earlier probe process would have logged for the comparisons
+        records[2:2] = [{"event": e, "name": k, **({"ok": True} if e == "end" else {})} for k in selfcheck.BITS for e in ("begin", "end")]
     v = selfcheck.probe(0, 127, True, spawn=spawn)
     assert v["bits"] == 127 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
 
