@@ -1,0 +1,106 @@
+#!/bin/bash
+# Round-4 gpurun calls:  gpurun --timeout T -- "bash tools/gpu_r04.sh <task> [args]"
+# Tasks write under gpurun_out/<dir>/ (scratch); what DESIGN.md quotes is copied into profiles/r04_*.
+set -u
+cd ${GRAFT_REPO_ROOT:-.}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+timeout 120 python tools/gpu_sanity.py || { echo "bad box, giving up"; exit 3; }
+
+# two gloo ranks on ONE GPU, cyclegan --global-batch 2 (tests/test_steps_gpu.py::test_bench_cyclegan_strong_scaling_two_ranks_on_one_gpu):
+#   two_rank <tag> <limit_s> <dump_s> [ENV=VAL ...]   -> gpurun_out/hang/<tag>.{out,err,rc}
+two_rank() { python tools/two_rank.py "$@"; }
+
+task_hang() {
+  rm -f /tmp/migan_selfcheck_*
+  # A: no self-check, default kernels
+  two_rank A_noselfcheck 100 50 MIGAN_SELFCHECK=0
+  rcA=$?
+  # B: self-check on, cold verdict cache (what a run of this test ALONE sees)
+  rm -f /tmp/migan_selfcheck_*
+  two_rank B_selfcheck_cold 200 120
+  # C: self-check on, cached verdict (what the test sees inside the suite)
+  two_rank C_selfcheck_cached 100 50
+  if [ $rcA -ne 0 ]; then
+    two_rank D_noselfcheck_regstage 100 50 MIGAN_SELFCHECK=0 MIGAN_DMA=0 MIGAN_DMA_WGRAD=0
+    two_rank E_noselfcheck_nostaged 100 50 MIGAN_SELFCHECK=0 MIGAN_THIN_WAVE=0 MIGAN_WGRAD_REDUCE_TR=0 MIGAN_PACK_TR=0 MIGAN_MIDK=0 MIGAN_NORM_SMALL=0 MIGAN_SMALLK_PB16=0 MIGAN_DROPOUT_FUSE=0 MIGAN_FEWPIX=0
+  fi
+  cat gpurun_out/hang/*.rc
+  for f in gpurun_out/hang/*.err; do echo "== $f"; grep -v "^/opt\|Warning\|warn" $f | tail -60; done
+}
+
+# rocprofv3 --kernel-trace --stats of bench steps:  prof <outdir> <workload>[:graph] ...
+task_prof() {
+  local O=gpurun_out/${1:-r4prof}; shift
+  mkdir -p $O
+  for spec in "$@"; do
+    w=${spec%%:*}; mode=eager; flag=--no-graph; [ "$spec" != "$w" ] && { mode=graph; flag=; }
+    k=3; [ $w = dcgan ] && k=20; [ $w = pix2pix ] && k=20; [ $w = wgan_gp ] && k=50
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_${w}_$mode -o $w -- python $R/bench.py --workload $w --steps $k --warmup 2 \
+       --min-seconds 0 $flag --no-roofline --no-cpu-baseline --no-extra > $R/$O/prof_${w}_$mode.log 2>&1)
+    db=$(ls $O/prof_${w}_$mode/*/${w}_results.db $O/prof_${w}_$mode/${w}_results.db 2>/dev/null | head -1)
+    a=2; [ $w = cyclegan ] && a=3; [ $w = wgan_gp ] && a=1.2
+    python tools/rocpd_stats.py $db 150 --by-grid --per-step adam_kernel=$a > $O/${w}_${mode}_kernel_stats.txt 2>&1
+    head -4 $O/${w}_${mode}_kernel_stats.txt
+    rm -rf $O/prof_${w}_$mode   # the database is large; the table is what is kept
+  done
+}
+
+# PMC passes (separate, --kernel-trace only) over the eager step of a workload and over the microbench of the same layers
+#   pmc <workload> <microbench-shapes> <match> <dirs>
+task_pmc() {
+  local w=$1 shapes=$2 match=$3 dirs=$4
+  local O=gpurun_out/r4pmc_$w
+  mkdir -p $O
+  local k=6; [ $w = cyclegan ] && k=2; [ $w = srgan ] && k=2
+  BENCH="python $R/bench.py --workload $w --steps $k --warmup 2 --min-seconds 0 --no-graph --no-roofline --no-cpu-baseline --no-extra"
+  MICRO="python $R/tools/conv_microbench.py --shapes $shapes --match $match --dirs $dirs --iters 6"
+  pass() {  # name, target cmd, counters...
+    local name=$1; shift
+    local cmd=$1; shift
+    mkdir -p $R/$O/$name
+    (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/$O/$name -o p -- $cmd > $R/$O/$name.log 2>&1)
+  }
+  for tgt in bench micro; do
+    cmd="$BENCH"; [ $tgt = micro ] && cmd="$MICRO"
+    pass ${tgt}_sq "$cmd" GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA
+    pass ${tgt}_l2 "$cmd" TCC_HIT_sum TCC_MISS_sum
+    pass ${tgt}_fetch "$cmd" FETCH_SIZE
+    pass ${tgt}_write "$cmd" WRITE_SIZE
+  done
+  for tgt in bench micro; do
+    python tools/pmc_summary.py $O/${tgt}_sq $O/${tgt}_l2 $O/${tgt}_fetch $O/${tgt}_write > $O/${tgt}_summary.txt 2>&1
+  done
+  # keep the per-kernel summaries; drop the raw CSVs beyond what the 64 MiB merge limit allows
+  find $O -name "*.csv" -size +8M -delete
+  head -40 $O/bench_summary.txt
+}
+
+# the default bench line (what the driver runs)
+task_bench() {
+  local O=gpurun_out/r4bench; mkdir -p $O
+  timeout 600 python bench.py "$@" > $O/bench_default.json 2> $O/bench_default.err
+  echo "bench rc=$?"; cut -c1-1500 $O/bench_default.json
+}
+
+task_suite() {
+  local O=gpurun_out/r4suite; mkdir -p $O
+  timeout 1300 python -m pytest tests -m gpu -q --timeout=700 --durations=25 -rxs > $O/pytest_gpu.txt 2>&1
+  echo "pytest rc=$?" >> $O/pytest_gpu.txt
+  grep -v "^  \|^$" $O/pytest_gpu.txt | tail -60
+}
+
+t=${1:-}; shift || true
+case "$t" in
+  hang) task_hang "$@" ;;
+  prof) task_prof "$@" ;;
+  pmc) task_pmc "$@" ;;
+  bench) task_bench "$@" ;;
+  suite) task_suite "$@" ;;
+  first)   # call 1 of the round: hang diagnosis, then kernel traces of HEAD for all five workloads, then the DCGAN PMC passes
+    task_hang
+    task_prof r4prof dcgan cyclegan srgan pix2pix wgan_gp wgan_gp:graph
+    task_pmc dcgan dcgan G.conv ufwd,udgrad,uwgrad
+    task_bench ;;
+  *) echo "usage: gpu_r04.sh {hang|prof|pmc|bench|suite|first} [args]"; exit 2 ;;
+esac
