@@ -39,8 +39,7 @@ import torch  # noqa: E402
 IMG, BATCH, LATENT, CH = 64, 128, 100, 1
 PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
 UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapsed Upsample(2)+Conv3x3 kernels
-PROFILE_ROUND = "r03"  # profiles/r03_pmc_kernels.json does not exist (no PMC pass this round): roofline.traffic stays null
-WATCHDOG_S = 200  # seconds the optional sections of the default run may take after the timed region
+PROFILE_ROUND = "r04"  # profiles/r04_pmc_kernels.json: the rocprofv3 --pmc passes over `bench.py --pmc-log` (tools/gpu_r04.sh pmc)
 
 
 def dcgan_flops_per_image(ch=None):
@@ -180,9 +179,13 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
         return out
 
     # replay buffers warm (>= 50 entries) before timing, so the picks and clones of the timed steps are
-    # those of a run in steady state
-    while len(state.buf_A) < state.buf_A.max_size:
-        run(0)
+    # those of a run in steady state.  The histories are filled with generator outputs under no_grad - no training step, no
+    # collective: at --global-batch 2 the former 50 warm-up STEPS each moved 113 MB of gradients through gloo (the two-rank
+    # single-GPU test mode: 2-3 s per step), which is what made that launch take > 150 s in round 3.
+    with torch.no_grad():
+        while len(state.buf_A) < state.buf_A.max_size:
+            state.buf_A.push_and_pop(state.G_BA(b))
+            state.buf_B.push_and_pop(state.G_AB(a))
     w = Workload("cyclegan", batch, run, state, None, False, None, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)
     return w
@@ -342,22 +345,32 @@ class ConvProfiler:
     """Times every conv-family launch with HIP events on the launch stream and attributes it to the kernel the library
     picks (migan_igemm_tile_code), with its dense (reference) and executed FLOPs."""
 
-    def __init__(self):
+    def __init__(self, segments=None):
         from pytorch_gan_amd._lib import lib
 
         self.lib, self.records, self.orig = lib, [], {}
+        # --pmc-log: [group, first, last) ordinals of the library's launches (migan_debug_launch_count, counted from process start)
+        # that each wrapped call issued - a rocprofv3 --pmc pass over the same deterministic command lists the same launches in the
+        # same order, so tools/pmc_step.py attributes its counter rows to the roofline groups without marker kernels
+        self.segments = segments
 
     def _wrap(self, name, describe):
         fn = getattr(self.lib, name)
         self.orig[name] = fn
 
+        count = self.lib.migan_debug_launch_count
+
         def wrapper(*a):
             st = torch.cuda.current_stream()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            i0 = count(None)
             e0.record(st)
             rc = fn(*a)
             e1.record(st)
-            self.records.append((describe(a), e0, e1))
+            d = describe(a)
+            self.records.append((d, e0, e1))
+            if self.segments is not None:
+                self.segments.append({"group": d[0], "first": i0, "last": count(None), "dense": d[1], "executed": d[2]})
             return rc
 
         setattr(self.lib, name, wrapper)
@@ -489,11 +502,11 @@ def pmc_table():
         return {}, None
 
 
-def roofline(w, rank, nprof):
+def roofline(w, rank, nprof, segments=None):
     """Eager runs of the timed step with HIP events (on the launch stream) around every conv-family launch; every rank
     runs the steps (collectives), rank 0 records."""
     agg, hbm = {}, {}
-    with (ConvProfiler() if rank == 0 else contextlib.nullcontext()) as prof:
+    with (ConvProfiler(segments) if rank == 0 else contextlib.nullcontext()) as prof:
         for i in range(nprof):
             w.state.dp.begin_step()
             w.eager()
@@ -583,65 +596,27 @@ def _safe_cpu_baseline(init):
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
-def persistent_kernel_state(state):
-    """Which persistent WGAN-GP kernels (csrc/critic_fused.hip, mlp_fused.hip) the state took into service, and whether any of
-    their grid barriers gave up (sync[2] of a plan: set by the kernel, cleared only by the host) - None for other workloads."""
-    plans = {"critic": getattr(state, "_k7_plan", None), "generator_forward": getattr(state, "_k7_gen_plan", None),
-             "critic_as_mlp": getattr(state, "_k7_dmlp_plan", None)}
-    if all(p is None for p in plans.values()):
-        return None
-    out = {k: bool(getattr(p, "verified", False) or getattr(p, "step_verified", False)) if p is not None else False
-           for k, p in plans.items()}
-    gp = plans["generator_forward"]
-    out["generator_iteration"] = bool(getattr(gp, "step_verified", False)) if gp is not None else False
-    out["barrier_timeouts"] = sum(1 for p in plans.values()
-                                  if p is not None and getattr(p, "sync", None) is not None and int(p.sync[2]) != 0)
-    return out
-
-
-def _staged_report():
+def run_extra(other, k, wu, dp, rank, dev, args):
+    """One of the other BASELINE configs, briefly (headline section only), after the headline workload has been released."""
+    w = None
     try:
-        from pytorch_gan_amd import selfcheck
-
-        return selfcheck.report()
-    except Exception as ex:  # noqa: BLE001
-        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:120])}
-
-
-def run_extra(other, k, wu, timeout_s=150.0):
-    """One of the other BASELINE configs, briefly, in ITS OWN PROCESS (`bench.py --workload other`, headline section only):
-    whatever happens to it - a device fault aborts a process - the headline line of this run is already final and is printed."""
-    import subprocess
-
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", other, "--steps", str(k), "--warmup", str(wu),
-           "--max-blocks", "20", "--no-roofline", "--no-cpu-baseline", "--no-extra"]
-    try:
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    except OSError as ex:
-        return {"error": "could not start: %s" % ex}
-    try:
-        so, se = p.communicate(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        try:
-            os.killpg(p.pid, 9)   # its own session: exactly the process group started here
-        except OSError:
-            pass
-        p.communicate()
-        return {"error": "no result within %d s" % timeout_s}
-    line = next((ln for ln in reversed(so.splitlines()) if ln.startswith("{")), None)
-    if p.returncode != 0 or line is None:
-        tail = (se or "").strip().splitlines()[-1:]
-        return {"error": "exit status %d: %s" % (p.returncode, tail[0][:160] if tail else "")}
-    r = json.loads(line)
-    t = r.get("timing", {})
-    return {"images_per_s": r["value"], "ms_per_step": r["ms_per_step"], "ms_per_step_min": t.get("ms_per_step_min"),
-            "ms_per_step_max": t.get("ms_per_step_max"), "blocks": t.get("blocks"), "timed_seconds": t.get("timed_seconds"),
-            "step_executed_frac": r.get("step_executed_frac"), "step_dense_frac": r.get("step_dense_frac"),
-            "workload": r["config"]["workload"], "steps": k, "warmup": wu, "hipgraph": r["config"].get("hipgraph"),
-            "peak_mem_gb": r.get("peak_mem_gb"), "losses": r.get("losses"),
-            **({"staged_kernels_off": [n for n, v in r["staged_kernels"].items() if str(v).startswith("disabled")]}
-               if any(str(v).startswith("disabled") for v in r.get("staged_kernels", {}).values()) else {})}
-
+        ns = argparse.Namespace(**vars(args))
+        ns.batch = 0
+        w = BUILDERS[other](dp, rank, dev, ns, wu + k)
+        torch.cuda.reset_peak_memory_stats()
+        blocks, out = timed_blocks(w, 1, dev, k, wu, 2.0, max_blocks=20)
+        summ = summarise(other, w.batch, 1, k, blocks)
+        return {"images_per_s": summ["images_per_s"], "ms_per_step": summ["ms_per_step"], "ms_per_step_min": summ["ms_per_step_min"],
+                "ms_per_step_max": summ["ms_per_step_max"], "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
+                "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
+                "workload": WORKLOAD_NAME[other], "steps": k, "warmup": wu, "hipgraph": w.graphed,
+                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                "losses": {kk: float(v) for kk, v in out.items() if "loss" in kk}}
+    except Exception as ex:  # noqa: BLE001 - the headline line must survive a failure of an extra
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    finally:
+        del w
+        torch.cuda.empty_cache()
 
 
 def replicas_identical(w, world, dev):
@@ -667,6 +642,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much is timed")
     ap.add_argument("--max-blocks", type=int, default=200, help="upper bound on the number of timed K-step blocks")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of hipGraph replay")
+    ap.add_argument("--pmc-log", default="", help="target mode of the rocprofv3 --pmc passes: run --steps eager steps of the workload "
+                    "with the per-launch accounting of `roofline`, write which library launches (by ordinal) belong to which "
+                    "roofline group to this file (tools/pmc_step.py joins it with the pass's counter CSV) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the brief runs of the other BASELINE configs (N=1)")
@@ -714,15 +692,26 @@ def main():
         dp.enable_sync_batchnorm()
 
     name = args.workload
+    if args.pmc_log:
+        args.no_graph = True
     w = BUILDERS[name](dp, rank, dev, args, args.warmup + args.steps)
+    if args.pmc_log:
+        from pytorch_gan_amd._lib import lib
+
+        for i in range(args.warmup):
+            w.run(i)
+        segs = []
+        rf = roofline(w, rank, args.steps, segs)
+        torch.cuda.synchronize()
+        with open(args.pmc_log, "w") as fh:
+            json.dump({"workload": name, "steps": args.steps, "total_launches": lib.migan_debug_launch_count(None), "segments": segs,
+                       "conv_kernels": rf.get("conv_kernels"), "norm_calls": (rf.get("hbm") or {}).get("norm_calls")}, fh)
+        print(json.dumps({"pmc_log": args.pmc_log, "segments": len(segs), "total_launches": lib.migan_debug_launch_count(None)}))
+        return
     blocks, out = timed_blocks(w, world, dev, args.steps, args.warmup, args.min_seconds, max_blocks=args.max_blocks)
     losses = {k: float(v) for k, v in out.items() if "loss" in k}
     if not all(np.isfinite(v) for v in losses.values()):
         raise SystemExit("non-finite loss in the timed region: %s" % losses)
-    pk = persistent_kernel_state(w.state)
-    if pk and pk.get("barrier_timeouts"):
-        # a grid barrier of a persistent WGAN-GP kernel gave up inside the timed region: those iterations computed nothing valid
-        raise SystemExit("persistent kernels: grid barrier timed out in the timed region (%s); rerun with MIGAN_K7=0" % pk)
     summ = summarise(name, w.batch, world, args.steps, blocks)
     result = {
         "metric": "training images/sec", "value": round(summ["images_per_s"], 2), "unit": "images/s", "n_gpus": world,
@@ -739,29 +728,9 @@ def main():
         "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
         "losses": losses,
         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-        # outcome of the hardware self-check of the kernels written without GPU time (pytorch_gan_amd/selfcheck.py):
-        # "ok" = in service, "disabled: ..." = the kernel it replaces ran instead
-        "staged_kernels": _staged_report(),
     }
     if w.capture_error:
         result["config"]["hipgraph_error"] = w.capture_error[:200]
-    if pk:
-        result["config"]["persistent_kernels"] = pk
-    # The headline numbers are final here.  What follows (per-kernel accounting, the other BASELINE configs, the CPU baseline)
-    # is optional detail: if it does not finish in time the watchdog prints the line with whatever is attached so far and
-    # exits, so a stall in an optional section can never cost the run its result.
-    watchdog = None
-    if rank == 0 and world == 1:
-        import threading
-
-        def _fire():
-            result["watchdog"] = "optional sections (roofline / extra / cpu_baseline) did not finish within %d s" % WATCHDOG_S
-            print(json.dumps(result), flush=True)
-            os._exit(0)
-
-        watchdog = threading.Timer(WATCHDOG_S, _fire)
-        watchdog.daemon = True
-        watchdog.start()
     if not args.no_roofline:
         try:
             rf = roofline(w, rank, 5 if name in ("dcgan", "wgan_gp", "pix2pix") else 2)
@@ -780,15 +749,13 @@ def main():
         init = w.init
         del w, out
         torch.cuda.empty_cache()
-        if not args.no_cpu_baseline:   # before the extras: a watchdog line (a stall in an extra) still carries it
+        if not args.no_cpu_baseline:
             result["cpu_baseline"] = _safe_cpu_baseline(init)
-        extra = result["extra"] = {}   # attached first: a watchdog line carries the configs finished so far
+        extra = result["extra"] = {}
         for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
-            extra[other] = run_extra(other, k, wu)
+            extra[other] = run_extra(other, k, wu, dp, rank, dev, args)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
-    if watchdog is not None:
-        watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

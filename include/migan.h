@@ -26,13 +26,11 @@ extern "C" {
 
 const char* migan_version(void);
 const char* migan_error_string(int code);
-/* Staged-kernel switchboard.  Kernels that entered the tree without hardware time carry one bit each (1 thin_conv_wave - PatchGAN
- * heads, cyclegan/models.py:118 pix2pix/models.py:127; 2 wgrad_reduce_tr; 4 midk_tile - first convs of the image nets,
- * pix2pix/models.py:23,115; 8 norm_small - nn.InstanceNorm2d at <= 1024 pixels, pix2pix/models.py:25,42; 16 smallk_tile<K,16>;
- * 32 pack_transpose; 64 the few-pixel conv path of csrc/fewpix.hip).  A bit starts from its MIGAN_* environment variable (unset = on).  Clears, then sets, the named bits and
- * returns the word; migan_staged(0, 0) reads it.  The host mirror's hardware self-check (pytorch_gan_amd/selfcheck.py) clears the
- * bit of a kernel that disagrees with the kernel it replaces.  No reference counterpart: torch selects its ATen kernels internally. */
-unsigned migan_staged(unsigned clear_bits, unsigned set_bits);
+/* Debug launch counters: launches issued by this library since the last reset, summed over the launch sites whose kernel
+ * expression contains `substr` (NULL or "" = all).  The parity tests assert with it WHICH kernel family served a geometry
+ * (torch's counterpart is the profiler's kernel list; the reference itself never looks).  Host-side bookkeeping only. */
+long migan_debug_launch_count(const char* substr);
+void migan_debug_launch_reset(void);
 
 /* ---- Convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip) ----------
  * nn.Conv2d forward: dcgan.py:55,59,62,78  cyclegan/models.py:28,32,50,60,75,82,106,118
@@ -93,7 +91,7 @@ int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M
  * torch runs them as ATen convolution / convolution_backward; here every product is one of the skinny GEMMs above on the weight in
  * its STORED layout (Conv2d [Co][Ci*R*S], ConvTranspose2d [Ci][Co*R*S]) around these two index kernels - no weight packs, no
  * split-K slabs, no reduction launches.  migan_fewpix_ok: rows = N*Ho*Wo (Conv2d) or N*Hin*Win (ConvTranspose2d), n / k = the
- * weight's leading dimension / the product of its trailing ones; 0 unless bit 64 of migan_staged() is set.
+ * weight's leading dimension / the product of its trailing ones.
  * migan_im2col_small: col[N*Ho*Wo][C*R*S] (column (c, r, s)) of x[N][H][W][C] (NHWC) for taps at h = ho*stride - pt + r.
  * migan_col2im_small: the adjoint, out[N][H][W][J] = act(bias + sum of ycol[(n,ho,wo)][(j,r,s)] over the taps that land on
  * (h, w)) in a fixed order; bias may be NULL. */

@@ -53,7 +53,8 @@ P = c_void_p
 _SIGS = {
     "migan_version": (c_char_p, []),
     "migan_error_string": (c_char_p, [c_int]),
-    "migan_staged": (ctypes.c_uint, [ctypes.c_uint, ctypes.c_uint]),
+    "migan_debug_launch_count": (ctypes.c_long, [c_char_p]),
+    "migan_debug_launch_reset": (None, []),
     "migan_conv2d_fwd": (c_int, [P, P, P, P] + [c_int] * 14 + [c_float, P]),
     "migan_conv2d_dropout_fwd": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P]),
     "migan_conv2d_stats_chunks": (c_int, [c_int] * 14),

@@ -32,7 +32,7 @@ MIGAN_API int migan_embedding_fwd(const float* w, const long long* idx, float* y
     if ((size_t)n * D == 0) return 0;
     int blocks = cdiv((long)n * D, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, idx, y, n, D, V);
+    MIGAN_LAUNCH(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, idx, y, n, D, V);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -41,7 +41,7 @@ MIGAN_API int migan_embedding_bwd(const float* dy, const long long* idx, float* 
     if ((size_t)V * D == 0) return 0;
     int blocks = cdiv((long)V * D, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, dw, n, D, V,
+    MIGAN_LAUNCH(embedding_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, idx, dw, n, D, V,
                        accumulate);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 }
 MIGAN_API int migan_softmax_fwd(const float* x, float* y, int B, int C, void* stream) {
     if ((size_t)B * C == 0) return 0;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, y, B, C);
+    MIGAN_LAUNCH(softmax_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, y, B, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, void* stream) {
     if ((size_t)B * C == 0) return 0;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, B, C);
+    MIGAN_LAUNCH(softmax_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, B, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -150,9 +150,9 @@ MIGAN_API int migan_cross_entropy_fwd(const float* x, const long long* target, f
                                       void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (B <= 0 || C <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, target, ws, ws + B, B, C);
+    MIGAN_LAUNCH(ce_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, target, ws, ws + B, B, C);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, ws, out, B);
+    MIGAN_LAUNCH(ce_mean_kernel, dim3(1), dim3(256), 0, st, ws, out, B);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -161,7 +161,7 @@ MIGAN_API int migan_cross_entropy_bwd(const float* x, const long long* target, c
     if ((size_t)B * C == 0) return 0;
     int blocks = cdiv((long)B * C, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, target, lse, g, dx, B, C);
+    MIGAN_LAUNCH(ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, target, lse, g, dx, B, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }

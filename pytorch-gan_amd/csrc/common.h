@@ -64,31 +64,34 @@ __device__ __forceinline__ int fastdiv(int n, unsigned m, int s) {
     return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s);
 }
 
-// Kernels that entered the tree without hardware time ("staged"): one bit each.  A bit starts from its MIGAN_*
-// variable (unset = 1 = on) and can be cleared at run time through migan_staged() - the host's hardware self-check
-// (pytorch_gan_amd/selfcheck.py) takes a staged kernel out of service when it disagrees with the kernel it replaces.
-enum {
-    STG_THIN_WAVE = 1, STG_WGRAD_REDUCE_TR = 2, STG_MIDK = 4, STG_NORM_SMALL = 8, STG_SMALLK_PB16 = 16, STG_PACK_TR = 32,
-    STG_FEWPIX = 64, STG_ALL = 127
+// Debug launch counters: every kernel launch of the library goes through MIGAN_LAUNCH, which counts it per launch SITE (a static
+// record per site, linked into one list; a relaxed increment per launch).  migan_debug_launch_count(substr) sums the sites whose
+// kernel expression contains substr - the parity tests use it to assert WHICH kernel family served a geometry on the hardware
+// (the host execution model of tests/hipemu keeps the same count by kernel expression).
+namespace migan_dbg {
+struct Site {
+    const char* name;
+    std::atomic<long> n{0};
+    Site* next = nullptr;
+    explicit Site(const char* nm);
 };
-inline unsigned staged_from_env() {
-    static const struct { const char* var; unsigned bit; } tab[] = {
-        {"MIGAN_THIN_WAVE", STG_THIN_WAVE}, {"MIGAN_WGRAD_REDUCE_TR", STG_WGRAD_REDUCE_TR}, {"MIGAN_MIDK", STG_MIDK},
-        {"MIGAN_NORM_SMALL", STG_NORM_SMALL}, {"MIGAN_SMALLK_PB16", STG_SMALLK_PB16}, {"MIGAN_PACK_TR", STG_PACK_TR},
-        {"MIGAN_FEWPIX", STG_FEWPIX}};
-    unsigned bits = 0;
-    for (const auto& t : tab) {
-        const char* v = getenv(t.var);
-        if (v == nullptr || atoi(v) != 0) bits |= t.bit;
-    }
-    return bits;
+// one list per library: an inline function's static local is shared by the translation units of the shared object
+inline std::atomic<Site*>& sites() {
+    static std::atomic<Site*> head{nullptr};
+    return head;
 }
-// one word per library: an inline function's static local is shared by the translation units of the shared object
-inline std::atomic<unsigned>& staged_word() {
-    static std::atomic<unsigned> w{staged_from_env()};
-    return w;
+inline Site::Site(const char* nm) : name(nm) {
+    Site* h = sites().load(std::memory_order_acquire);
+    do next = h;
+    while (!sites().compare_exchange_weak(h, this, std::memory_order_release, std::memory_order_acquire));
 }
-static inline bool staged_on(unsigned bit) { return (staged_word().load(std::memory_order_relaxed) & bit) != 0; }
+}  // namespace migan_dbg
+#define MIGAN_LAUNCH(kern, ...)                                   \
+    do {                                                          \
+        static migan_dbg::Site site__(#kern);                     \
+        site__.n.fetch_add(1, std::memory_order_relaxed);         \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                    \
+    } while (0)
 
 #define HIP_LAUNCH_CHECK()                         \
     do {                                           \

@@ -354,7 +354,7 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     tapin = tapin && tapin_env != 0;
     const bool ktail = g.Ci % BK != 0;
 #define DMA_LAUNCH(TI_, KT_)                                                                                         \
-    hipLaunchKernelGGL((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
+    MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
                        a_bytes, b_bytes)
     if (tapin) {
         if (ktail) DMA_LAUNCH(4, true); else DMA_LAUNCH(4, false);
@@ -438,7 +438,7 @@ static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, 
     }
     dim3 grid((unsigned)tm, (unsigned)tn, (unsigned)(g.ncls * S));
 #define DMA_SMALL(KT_, SK_)                                                                                             \
-    hipLaunchKernelGGL((igemm_dma_kernel<64, 64, 2, 2, 32, 1, KT_, 2, 4, SK_>), grid, dim3(256), 0, st, g, A, Bw, bias, \
+    MIGAN_LAUNCH((igemm_dma_kernel<64, 64, 2, 2, 32, 1, KT_, 2, 4, SK_>), grid, dim3(256), 0, st, g, A, Bw, bias, \
                        C, ab, bb, S, ws)
     if (S < 2) return -2;  // not worth cutting: the ordinary tiles
     if (ktail) DMA_SMALL(true, true); else DMA_SMALL(false, true);
@@ -717,11 +717,11 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
     dim3 grid(cdiv(gg.tiles_m * gg.tiles_n * gg.splits, 8) * 8, dys ? 4 : 1);
 #define WGD(BM_, BN_, BK_, OCC_)                                                                                             \
     do {                                                                                                                 \
-        if (dys) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+        if (dys) MIGAN_LAUNCH((wgrad_dma_kernel<BM_, BN_, BK_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
                                     (unsigned)xb, (unsigned)db);                                                         \
-        else if (refl) hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, false, true, OCC_>), grid, dim3(256), 0, st, gg, x,   \
+        else if (refl) MIGAN_LAUNCH((wgrad_dma_kernel<BM_, BN_, BK_, false, true, OCC_>), grid, dim3(256), 0, st, gg, x,   \
                                           dy, ws, (unsigned)xb, (unsigned)db);                                           \
-        else hipLaunchKernelGGL((wgrad_dma_kernel<BM_, BN_, BK_, false, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
+        else MIGAN_LAUNCH((wgrad_dma_kernel<BM_, BN_, BK_, false, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
                                 (unsigned)xb, (unsigned)db);                                                             \
     } while (0)
     // 128x128: BK = 16 (32 KB of LDS, 4-5 workgroups per CU); the narrower tiles: BK = 32 (3 / 5 per CU) - measured

@@ -869,7 +869,7 @@ static int launch_db(const ConvGeom& g, const float* A, const float* Bw, const f
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    hipLaunchKernelGGL((igemm_db_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    MIGAN_LAUNCH((igemm_db_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -914,12 +914,12 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     do {                                                                                                                    \
         if constexpr (BM * BN == 8192 && !(KT_ && TI_)) {                                                                   \
             if (occ5) {                                                                                                     \
-                hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_, 5>), grid, dim3(256), 0, st, g, A, Bw,  \
+                MIGAN_LAUNCH((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_, 5>), grid, dim3(256), 0, st, g, A, Bw,  \
                                    bias, C);                                                                                \
                 break;                                                                                                      \
             }                                                                                                               \
         }                                                                                                                   \
-        hipLaunchKernelGGL((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_>), grid, dim3(256), 0, st, g, A, Bw, bias, C);   \
+        MIGAN_LAUNCH((igemm_pipe_kernel<BM, BN, WM, WN, KT_, TI_, ST_>), grid, dim3(256), 0, st, g, A, Bw, bias, C);   \
     } while (0)
     if constexpr (BM * BN < 16384) {
         if (tapin) {
@@ -946,7 +946,7 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, FAST, VAR>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    MIGAN_LAUNCH((igemm_kernel<BM, BN, WM, WN, FAST, VAR>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1134,10 +1134,10 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
                             const float* Bw, const float* bias, float* C, hipStream_t st) {
     dim3 grid(max_tiles, g.N, g.ncls);
     switch (g.Co) {
-        case 1: hipLaunchKernelGGL((thin_conv_kernel<1>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        case 2: hipLaunchKernelGGL((thin_conv_kernel<2>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        case 3: hipLaunchKernelGGL((thin_conv_kernel<3>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        default: hipLaunchKernelGGL((thin_conv_kernel<4>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        case 1: MIGAN_LAUNCH((thin_conv_kernel<1>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        case 2: MIGAN_LAUNCH((thin_conv_kernel<2>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        case 3: MIGAN_LAUNCH((thin_conv_kernel<3>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
+        default: MIGAN_LAUNCH((thin_conv_kernel<4>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
     }
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1149,9 +1149,7 @@ static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, i
 // serially - 295 us for 4 MFLOP (profiles/r03_pix2pix_kernel_stats.txt).  Here ONE WAVE owns one output pixel: the
 // lanes split the channels (coalesced 1 KB rows of the NHWC source, straight from L2 - the whole input is < 1 MB per
 // image), every load of a tap is independent, and the 64 partial sums are combined by a fixed butterfly (deterministic).
-// Written after round 3's GPU budget was spent: verified on the host execution model (tests/hipemu: the conv cases and the
-// pix2pix / CycleGAN / SRGAN step parity tests run through it), not yet timed on hardware.  MIGAN_THIN_WAVE=0 disables it
-// (tools/gpu_tasks.sh staged is the A/B).
+// Measured (profiles/r03_abi_check.txt): PatchGAN head 512 -> 1 forward 168 -> 12.4 us.
 template <int CO>
 __global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, const float* __restrict__ A,
                                                              const float* __restrict__ Bw, const float* __restrict__ bias,
@@ -1205,8 +1203,7 @@ __global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, c
 
 // few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel
 static bool thin_wave_ok(const ConvGeom& g, int max_tiles) {
-    const bool on = staged_on(STG_THIN_WAVE);  // MIGAN_THIN_WAVE=0 = A/B against thin_conv_kernel
-    return on && g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
+    return g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
 }
 
 static int launch_thin_conv_wave(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
@@ -1218,10 +1215,10 @@ static int launch_thin_conv_wave(const ConvGeom& g, const float* A, const float*
     }
     dim3 grid((unsigned)cdiv(maxM, 4L), 1, g.ncls);
     switch (g.Co) {
-        case 1: hipLaunchKernelGGL((thin_conv_wave_kernel<1>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        case 2: hipLaunchKernelGGL((thin_conv_wave_kernel<2>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        case 3: hipLaunchKernelGGL((thin_conv_wave_kernel<3>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        default: hipLaunchKernelGGL((thin_conv_wave_kernel<4>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        case 1: MIGAN_LAUNCH((thin_conv_wave_kernel<1>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        case 2: MIGAN_LAUNCH((thin_conv_wave_kernel<2>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        case 3: MIGAN_LAUNCH((thin_conv_wave_kernel<3>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
+        default: MIGAN_LAUNCH((thin_conv_wave_kernel<4>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
     }
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1405,12 +1402,12 @@ static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, cons
     if (256 % cq_n == 0) {
         long tiles = cdiv(maxM, 128L);
         if (tiles > 8192) tiles = 8192;
-        if (tiles < 128 && staged_on(STG_SMALLK_PB16))  // MIGAN_SMALLK_PB16=0 = A/B
-            hipLaunchKernelGGL((smallk_tile_kernel<K, 16>), dim3((unsigned)cdiv(maxM, 16L)), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+        if (tiles < 128)
+            MIGAN_LAUNCH((smallk_tile_kernel<K, 16>), dim3((unsigned)cdiv(maxM, 16L)), dim3(256), 0, st, g, sk, A, Bw, bias, C);
         else
-            hipLaunchKernelGGL((smallk_tile_kernel<K, 128>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+            MIGAN_LAUNCH((smallk_tile_kernel<K, 128>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
     } else
-        hipLaunchKernelGGL((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
+        MIGAN_LAUNCH((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
 }
 
 static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C,
@@ -1448,7 +1445,7 @@ static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const flo
 // Here, as in smallk_tile_kernel: a workgroup owns 64 consecutive output pixels, the K gathered values of each pixel are fetched
 // ONCE (cooperatively, branch-free, into LDS), the K x Co weights sit in LDS for the life of the workgroup, a thread produces a
 // channel quad for two pixels at a time (8 FMAs per three LDS reads) and the tile's output is one contiguous run of 64 * Co
-// floats.  Written after round 3's GPU budget was spent: verified on the host execution model, not yet timed; MIGAN_MIDK=0 = off.
+// floats.  Measured in profiles/r03_abi_check.txt (see midk_ok for the one shape that stays on the MFMA kernel).
 // ------------------------------------------------------------------------------------------------
 #define MIDK_PB 64
 __global__ __launch_bounds__(256) void midk_tile_kernel(const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw,
@@ -1557,13 +1554,12 @@ __global__ __launch_bounds__(256) void midk_tile_kernel(const ConvGeom g, const 
 }
 static size_t midk_lds_bytes(int K, int Co) { return ((size_t)MIDK_PB * (K | 1) + (size_t)K * Co + 3 * K) * 4; }
 static bool midk_ok(const ConvGeom& g) {
-    const bool on = staged_on(STG_MIDK);  // MIGAN_MIDK=0 = off
     const int K = g.ntap[0] * g.Ci;
     const int cq_n = g.Co / 4;
     // measured (profiles/r03_abi_check.txt): 6 -> 64 4x4 s2 at batch 1 26.8 -> 22.5 us, 3 -> 64 3x3 at 2.4 M pixels 362 -> 316 us, but
     // 3 -> 64 4x4 s2 at 131 k pixels (CycleGAN's discriminators at batch 8) 37.2 -> 45.3 us: that shape stays on the MFMA kernel
     const bool loses = g.ntap[0] == 16 && g.Ci == 3 && (long)g.N * g.HoF * g.WoF >= 65536;
-    return on && !loses && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 &&
+    return !loses && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 &&
            K <= 128 && midk_lds_bytes(K, g.Co) <= 64 * 1024;
 }
 static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
@@ -1574,7 +1570,7 @@ static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float
     fastdiv_magic((unsigned)K, mgK, shK);
     long tiles = cdiv(maxM, (long)MIDK_PB);
     if (tiles > 4096) tiles = 4096;
-    hipLaunchKernelGGL(midk_tile_kernel, dim3((unsigned)tiles), dim3(256), midk_lds_bytes(K, g.Co), st, g, A, Bw, bias, C, K, mgK, shK);
+    MIGAN_LAUNCH(midk_tile_kernel, dim3((unsigned)tiles), dim3(256), midk_lds_bytes(K, g.Co), st, g, A, Bw, bias, C, K, mgK, shK);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1624,7 +1620,7 @@ static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* B
     dim3 grid((unsigned)cdiv(M, 4L));
 #define GEMV_CASE(CO_)                                                                                          \
     case CO_:                                                                                                   \
-        hipLaunchKernelGGL(gemv_rows_kernel<CO_>, grid, dim3(256), 0, st, A, Bw, bias, C, (int)M, g.Ci, g.ldw,  \
+        MIGAN_LAUNCH(gemv_rows_kernel<CO_>, grid, dim3(256), 0, st, A, Bw, bias, C, (int)M, g.Ci, g.ldw,  \
                            g.act, g.slope);                                                                     \
         break;
     switch (g.Co) {
@@ -2645,8 +2641,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // but scatters every result 4 B at a stride of T floats into the OIHW gradient (44 / 73 us for 16 / 32 MB,
 // profiles/r03_pix2pix_kernel_stats.txt).  Here a workgroup owns (co, 64 input channels): it sums the slabs in the same
 // split order (bit-identical results), transposes the 64 x T tile through LDS and writes ONE contiguous run of 64*T floats.
-// Written after round 3's GPU budget was spent: verified on the host execution model (tests/hipemu), not yet timed on
-// hardware.  MIGAN_WGRAD_REDUCE_TR=0 disables it (tools/gpu_tasks.sh staged is the A/B).
+// Measured (profiles/r03_abi_check.txt): wgrad + reduce of a 4 M / 8 M-element weight 37-40 -> 25-26 us.
 #define RTR_CI 64
 __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int splits, int Co, int T, int Ci, int accum, int ci_tiles,
@@ -2682,25 +2677,25 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     long total = (long)Co * T * Ci;
     const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
     br.nbias = extra;
-    if (staged_on(STG_WGRAD_REDUCE_TR) && total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
+    if (total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
         const int ci_tiles = cdiv(Ci, RTR_CI);
         br.main_blocks = Co * ci_tiles;
-        hipLaunchKernelGGL(wgrad_reduce_tr_kernel, dim3(br.main_blocks + extra), dim3(256), (size_t)RTR_CI * (T + 1) * 4, st,
+        MIGAN_LAUNCH(wgrad_reduce_tr_kernel, dim3(br.main_blocks + extra), dim3(256), (size_t)RTR_CI * (T + 1) * 4, st,
                            ws, dw, splits, Co, T, Ci, accum, ci_tiles, br);
         HIP_LAUNCH_CHECK();
         return 0;
     }
     if (splits >= 64 && total < (1 << 16)) {
         br.main_blocks = cdiv(total, 16);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+        MIGAN_LAUNCH((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
                            T, Ci, accum, br);
     } else if (splits >= 16 && total < (1 << 20)) {
         br.main_blocks = cdiv(total, 64);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<4>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+        MIGAN_LAUNCH((wgrad_reduce_kernel<4>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
                            T, Ci, accum, br);
     } else {
         br.main_blocks = cdiv(total, 256);
-        hipLaunchKernelGGL((wgrad_reduce_kernel<1>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
+        MIGAN_LAUNCH((wgrad_reduce_kernel<1>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
                            T, Ci, accum, br);
     }
     HIP_LAUNCH_CHECK();
@@ -2836,7 +2831,7 @@ MIGAN_API int migan_upconv3x3_pack(const float* w_oihw, float* wf, float* wd, in
     size_t total = (size_t)Co * 16 * Ci;
     int blocks = cdiv((long)total, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(upconv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, wd, Co, Ci);
+    MIGAN_LAUNCH(upconv_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wf, wd, Co, Ci);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -2971,8 +2966,8 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8, 4);                                                           \
-        if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
-        else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+        if (inc) MIGAN_LAUNCH((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+        else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
     const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
     const int rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, true, x, dy, ws, st) : -2;  // LDS-DMA main loop (conv_dma.hip)
@@ -2989,7 +2984,7 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64), 0};
     if (db && db_slabs) { br.bpart = db_slabs; br.nslab = db_nslab; }
     br.nbias = br.bpart ? cdiv(Co, BIAS_CB) : 0;
-    hipLaunchKernelGGL(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws,
+    MIGAN_LAUNCH(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws,
                        dw_oihw, g.splits, Co, Ci, accumulate, br);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -3084,15 +3079,15 @@ template <int KS>
 static void launch_thin(int Co, dim3 grid, size_t lds, hipStream_t st, const ThinGeom& tg, const float* x,
                         const float* dy, float* ws) {
     switch (Co) {
-        case 1: hipLaunchKernelGGL((thin_wgrad_kernel<1, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-        case 2: hipLaunchKernelGGL((thin_wgrad_kernel<2, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+        case 1: MIGAN_LAUNCH((thin_wgrad_kernel<1, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
+        case 2: MIGAN_LAUNCH((thin_wgrad_kernel<2, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
         case 3:
             if constexpr (KS * KS * 3 <= THIN_MAX_ACC)
-                hipLaunchKernelGGL((thin_wgrad_kernel<3, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
+                MIGAN_LAUNCH((thin_wgrad_kernel<3, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
             break;
         default:
             if constexpr (KS * KS * 4 <= THIN_MAX_ACC)
-                hipLaunchKernelGGL((thin_wgrad_kernel<4, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
+                MIGAN_LAUNCH((thin_wgrad_kernel<4, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
             break;
     }
 }
@@ -3382,7 +3377,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         fastdiv_magic((unsigned)(R * S * Ci), sg.mg_k, sg.sh_k);
         if ((size_t)nblk * Co * R * S * Ci * sizeof(float) <= ws_bytes && Mpix > 0) {
             const size_t lds = (size_t)128 * (Co + R * S * Ci) * sizeof(float);
-            hipLaunchKernelGGL(small_wgrad_kernel, dim3(nblk), dim3(256), lds, st, sg, x, dy, ws);
+            MIGAN_LAUNCH(small_wgrad_kernel, dim3(nblk), dim3(256), lds, st, sg, x, dy, ws);
             HIP_LAUNCH_CHECK();
             return launch_wgrad_reduce(ws, dw_oihw, nblk, Co, R * S, Ci, accumulate, st, ext);
         }
@@ -3396,10 +3391,10 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             (size_t)tw.nblocks * Co * R * S * Ci * sizeof(float) <= ws_bytes) {
             dim3 grid(tw.nblocks);
             switch (Co) {
-                case 1: hipLaunchKernelGGL((thin_wgrad_tile_kernel<1>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
-                case 2: hipLaunchKernelGGL((thin_wgrad_tile_kernel<2>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
-                case 3: hipLaunchKernelGGL((thin_wgrad_tile_kernel<3>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
-                default: hipLaunchKernelGGL((thin_wgrad_tile_kernel<4>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                case 1: MIGAN_LAUNCH((thin_wgrad_tile_kernel<1>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                case 2: MIGAN_LAUNCH((thin_wgrad_tile_kernel<2>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                case 3: MIGAN_LAUNCH((thin_wgrad_tile_kernel<3>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
+                default: MIGAN_LAUNCH((thin_wgrad_tile_kernel<4>), grid, dim3(256), lds, st, cg, tc, tw, x, dy, ws); break;
             }
             HIP_LAUNCH_CHECK();
             return launch_wgrad_reduce(ws, dw_oihw, tw.nblocks, Co, R * S, Ci, accumulate, st, ext);
@@ -3435,9 +3430,9 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);                                                              \
         if (inc && refl)                                                                                           \
-            hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
-        else if (inc) hipLaunchKernelGGL((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
-        else hipLaunchKernelGGL((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
+            MIGAN_LAUNCH((wgrad_inc_kernel<BM_, BN_, false, true>), grid_, dim3(256), 0, st, g, x, dy, ws);  \
+        else if (inc) MIGAN_LAUNCH((wgrad_inc_kernel<BM_, BN_, false>), grid_, dim3(256), 0, st, g, x, dy, ws); \
+        else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
         const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
         const int rc_dma = (inc && wvar == 0) ? launch_wgrad_dma(g, bm, bn_sel, false, x, dy, ws, st) : -2;
@@ -3448,9 +3443,9 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
             if (wvar == 1 || wvar == 2 || wvar == 3) {
                 g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
                 dim3 grid(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);
-                if (wvar == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
-                else if (wvar == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
-                else hipLaunchKernelGGL((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
+                if (wvar == 1) MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
+                else if (wvar == 2) MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
+                else MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
             } else
 #endif
             {
@@ -3469,17 +3464,17 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
 #ifdef MIGAN_ABLATION
-        if (vec) hipLaunchKernelGGL((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
+        if (vec) MIGAN_LAUNCH((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
         else
 #endif
-        hipLaunchKernelGGL((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        MIGAN_LAUNCH((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     } else {
         dim3 grid(cdiv(Co, 64), cdiv(Ncol, 64), g.splits);
 #ifdef MIGAN_ABLATION
-        if (vec) hipLaunchKernelGGL((wgrad_kernel<64, 64, true>), grid, dim3(256), 0, st, g, x, dy, ws);
+        if (vec) MIGAN_LAUNCH((wgrad_kernel<64, 64, true>), grid, dim3(256), 0, st, g, x, dy, ws);
         else
 #endif
-        hipLaunchKernelGGL((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        MIGAN_LAUNCH((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
     return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st, ext);

@@ -85,7 +85,7 @@ MIGAN_API int migan_act_bwd_nc(const float* dy, const float* y, const float* mas
     size_t total = (size_t)N * HW * C;
     if (total == 0) return 0;
     if (C % 4 != 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(act_bwd_nc_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx,
+    MIGAN_LAUNCH(act_bwd_nc_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, y, mask, dx,
                        HW, C, total / 4, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -105,7 +105,7 @@ __global__ void act_bwd2_kernel(const float* __restrict__ g, const float* __rest
 MIGAN_API int migan_act_bwd2(const float* g, const float* gg, const float* y, float* out, size_t n, int act,
                              void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(act_bwd2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, gg, y, out, n, act);
+    MIGAN_LAUNCH(act_bwd2_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, gg, y, out, n, act);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -127,7 +127,7 @@ __global__ void dragan_interp_kernel(const float* __restrict__ x, const float* _
 MIGAN_API int migan_dragan_interp(const float* x, const float* alpha, const float* noise, const float* var_biased,
                                   float* out, size_t n, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(dragan_interp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, noise,
+    MIGAN_LAUNCH(dragan_interp_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, alpha, noise,
                        var_biased, out, n);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -148,7 +148,7 @@ __global__ void batch_mean_axpy_kernel(const float* __restrict__ a, const float*
 MIGAN_API int migan_batch_mean_axpy(const float* a, const float* b, float* y, int N, size_t P, float alpha, float beta,
                                     void* stream) {
     if (N <= 0 || P == 0) return 0;
-    hipLaunchKernelGGL(batch_mean_axpy_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, N, P,
+    MIGAN_LAUNCH(batch_mean_axpy_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, N, P,
                        alpha, beta);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -156,7 +156,7 @@ MIGAN_API int migan_batch_mean_axpy(const float* a, const float* b, float* y, in
 
 MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,
+    MIGAN_LAUNCH(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,
                        slope);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -164,7 +164,7 @@ MIGAN_API int migan_act_fwd(const float* x, float* y, size_t n, int act, float s
 MIGAN_API int migan_act_bwd(const float* dy, const float* y, float* dx, size_t n, int act, float slope,
                             void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n,
+    MIGAN_LAUNCH(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n,
                        act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -217,7 +217,7 @@ MIGAN_API size_t migan_reduce_workspace() { return REDUCE_BLOCKS * sizeof(float)
 
 MIGAN_API int migan_prelu_fwd(const float* x, const float* a, float* y, size_t n, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(prelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, n);
+    MIGAN_LAUNCH(prelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, n);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -226,9 +226,9 @@ MIGAN_API int migan_prelu_bwd(const float* x, const float* dy, const float* a, f
     hipStream_t st = (hipStream_t)stream;
     int blocks = grid_for(n);
     if (blocks > REDUCE_BLOCKS) blocks = REDUCE_BLOCKS;
-    hipLaunchKernelGGL(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, dy, a, dx, ws, n);
+    MIGAN_LAUNCH(prelu_bwd_kernel, dim3(blocks), dim3(256), 0, st, x, dy, a, dx, ws, n);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, blocks, da, 1.f);
+    MIGAN_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, st, ws, blocks, da, 1.f);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -270,21 +270,21 @@ __global__ void mul_nc_kernel(const float* __restrict__ x, const float* __restri
 MIGAN_API int migan_axpby(const float* a, float alpha, const float* b, float beta, float* y, size_t n,
                           void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, alpha, b,
+    MIGAN_LAUNCH(axpby_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, alpha, b,
                        beta, y, n);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_mul(const float* a, const float* b, float* y, size_t n, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    MIGAN_LAUNCH(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_mul_nc(const float* x, const float* m, float* y, int N, int HW, int C, void* stream) {
     size_t total = (size_t)N * HW * C;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(mul_nc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, m, y, HW, C,
+    MIGAN_LAUNCH(mul_nc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, m, y, HW, C,
                        total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -348,7 +348,7 @@ MIGAN_API int migan_rand_mask(float* mask, size_t n, float p, unsigned long long
                               unsigned long long* counter, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(rand_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, mask, n, p, seed, counter);
+    MIGAN_LAUNCH(rand_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, mask, n, p, seed, counter);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -410,7 +410,7 @@ MIGAN_API int migan_gather2d_fwd(const float* x, float* y, int N, int Hi, int Wi
                                  int pad_t, int pad_l, int mode, void* stream) {
     size_t total = (size_t)N * Ho * Wo * C;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(gather2d_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi,
+    MIGAN_LAUNCH(gather2d_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi,
                        C, Ho, Wo, pad_t, pad_l, mode, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -419,7 +419,7 @@ MIGAN_API int migan_gather2d_bwd(const float* dy, float* dx, int N, int Hi, int 
                                  int pad_t, int pad_l, int mode, void* stream) {
     size_t total = (size_t)N * Hi * Wi * C;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(gather2d_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, Hi,
+    MIGAN_LAUNCH(gather2d_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, Hi,
                        Wi, C, Ho, Wo, pad_t, pad_l, mode, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -446,10 +446,10 @@ MIGAN_API int migan_pixel_shuffle(const float* src, float* dst, int N, int H, in
     size_t total = (size_t)N * H * W * C * r * r;
     if (total == 0) return 0;
     if (forward)
-        hipLaunchKernelGGL((pixel_shuffle_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        MIGAN_LAUNCH((pixel_shuffle_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            src, dst, H, W, C, r, total);
     else
-        hipLaunchKernelGGL((pixel_shuffle_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        MIGAN_LAUNCH((pixel_shuffle_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            src, dst, H, W, C, r, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -496,7 +496,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
 MIGAN_API int migan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
     size_t total = (size_t)N * (H / 2) * (W / 2) * C;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C,
+    MIGAN_LAUNCH(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C,
                        total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -505,7 +505,7 @@ MIGAN_API int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int
                                  void* stream) {
     size_t total = (size_t)N * (H / 2) * (W / 2) * C;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H,
+    MIGAN_LAUNCH(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H,
                        W, C, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -532,10 +532,10 @@ MIGAN_API int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca,
     size_t total = P * (size_t)(Ca + Cb);
     if (total == 0) return 0;
     if (forward)
-        hipLaunchKernelGGL((cat_c_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+        MIGAN_LAUNCH((cat_c_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
                            Ca, Cb, total);
     else
-        hipLaunchKernelGGL((cat_c_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
+        MIGAN_LAUNCH((cat_c_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, y,
                            Ca, Cb, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -565,7 +565,7 @@ MIGAN_API int migan_transpose_batched(const float* src, float* dst, int B, int R
     // grid.y is limited to 65535 blocks: R up to 2M rows
     dim3 grid(cdiv(Cc, 32), cdiv(R, 32), B);
     if (grid.y > 65535 || grid.z > 65535) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc);
+    MIGAN_LAUNCH(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, R, Cc);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -594,7 +594,7 @@ MIGAN_API int migan_select_rows(const float* a, const float* b, float* dst, cons
     if (D % 4 != 0 || n > 65535) return (int)hipErrorInvalidValue;
     size_t bx = (D / 4 + 255) / 256;
     if (bx > 512) bx = 512;
-    hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream, a, b, dst, sel, dst_row, D);
+    MIGAN_LAUNCH(select_rows_kernel, dim3((unsigned)bx, n), dim3(256), 0, (hipStream_t)stream, a, b, dst, sel, dst_row, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -620,8 +620,8 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
 // IHWO: y = i, x = o, sy = R, sx = I*R): permute4_kernel reads them 4 B at a stride of R floats (27 us for a 4.2 M-element
 // pix2pix weight, 22 such launches per step, profiles/r03_pix2pix_kernel_stats.txt).  A workgroup owns (y, 64 x): it reads
 // the 64 runs of R contiguous floats (one contiguous 64*R block for OHWI), transposes through a padded LDS tile and writes
-// R runs of 64 contiguous floats.  Written after round 3's GPU budget was spent: verified on the host execution model
-// (tests/hipemu), not yet timed on hardware; MIGAN_PACK_TR=0 disables it.
+// R runs of 64 contiguous floats.  Measured (profiles/r03_abi_check.txt): 4 M / 8 M-element
+// packs 17.6-41.5 -> 11.3 / 17.4 us (3.0 / 3.9 TB/s).
 #define PTR_X 64
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int X,
                                                              int R, long long sy, long long sx, int x_tiles) {
@@ -645,19 +645,18 @@ MIGAN_API int migan_permute4d(const float* src, float* dst, int d0, int d1, int 
                               int p3, void* stream) {
     size_t total = (size_t)d0 * d1 * d2 * d3;
     if (total == 0) return 0;
-    const bool tr_env = staged_on(STG_PACK_TR);  // MIGAN_PACK_TR=0 = A/B against permute4_kernel
     const int R = d2 * d3;
     const bool ohwi = p0 == 0 && p1 == 2 && p2 == 3 && p3 == 1, ihwo = p0 == 1 && p1 == 2 && p2 == 3 && p3 == 0;
-    if (tr_env && (ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {
+    if ((ohwi || ihwo) && R > 1 && R <= 96 && total >= (1u << 16) && total < (1ull << 31)) {
         const int X = ohwi ? d1 : d0, Y = ohwi ? d0 : d1;
         const long long sy = ohwi ? (long long)d1 * R : R, sx = ohwi ? R : (long long)d1 * R;
         const int x_tiles = (X + PTR_X - 1) / PTR_X;
-        hipLaunchKernelGGL(pack_transpose_kernel, dim3((unsigned)Y * x_tiles), dim3(256), (size_t)PTR_X * (R + 1) * 4,
+        MIGAN_LAUNCH(pack_transpose_kernel, dim3((unsigned)Y * x_tiles), dim3(256), (size_t)PTR_X * (R + 1) * 4,
                            (hipStream_t)stream, src, dst, X, R, sy, sx, x_tiles);
         HIP_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1,
+    MIGAN_LAUNCH(permute4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1,
                        d2, d3, p0, p1, p2, p3, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -702,7 +701,7 @@ __global__ __launch_bounds__(256) void multi_permute4_kernel(const PackEntry* __
 // ceil(n / 1024) blocks per entry
 MIGAN_API int migan_multi_permute4d(const void* entries, const void* blocks, int nblocks, void* stream) {
     if (nblocks <= 0) return 0;
-    hipLaunchKernelGGL(multi_permute4_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)entries,
+    MIGAN_LAUNCH(multi_permute4_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const PackEntry*)entries,
                        (const PackBlock*)blocks);
     HIP_LAUNCH_CHECK();
     return 0;

@@ -14,8 +14,8 @@
 //
 // (T = R*S taps; column order (channel, tap) = the weight's own trailing dimensions.)  The col matrices are at most
 // 64 x 16384 floats (4 MB, L2 / MALL resident); the weights are read once per product at streaming rates.
-// Written without hardware time: behind bit 64 of migan_staged() (STG_FEWPIX), verified on the host execution model and, on the
-// device, by pytorch_gan_amd/selfcheck.py against the tiled kernels it replaces.
+// Measured (profiles/r03_abi_check.txt): per 16.8 MB layer forward 46.6 -> 13.8 us, input gradient 50.5 -> 9.8 us, weight gradient
+// 39.8 -> 12.7 us against the pack + split-K kernels that served these shapes before.
 #include "common.h"
 
 extern "C" int migan_skinny_nt_ok(int M, int N, int K);
@@ -167,18 +167,18 @@ MIGAN_API int migan_fewpix_nt(const float* a, const float* w, const float* bias,
     if (ws == nullptr || ws_bytes < (size_t)Z * M * N * sizeof(float)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const int Kc = K / Z;
-    hipLaunchKernelGGL(fewpix_nt_kernel<8>, dim3(N / 16, (M + 15) / 16, Z), dim3(512), 0, st, a, w, ws, M, N, K, Kc);
+    MIGAN_LAUNCH(fewpix_nt_kernel<8>, dim3(N / 16, (M + 15) / 16, Z), dim3(512), 0, st, a, w, ws, M, N, K, Kc);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fewpix_nt_reduce_kernel, dim3(cdiv((long)M * N, 256L)), dim3(256), 0, st, ws, bias, out, M * N, N, Z, act, slope);
+    MIGAN_LAUNCH(fewpix_nt_reduce_kernel, dim3(cdiv((long)M * N, 256L)), dim3(256), 0, st, ws, bias, out, M * N, N, Z, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 
 // 1 when a conv whose GEMM has `rows` pixel rows (Conv2d: N*Ho*Wo output pixels; ConvTranspose2d: N*Hin*Win input pixels),
 // `n` = the weight's leading dimension (Conv2d: Co; ConvTranspose2d: Ci) and `k` = the product of its trailing ones takes this
-// path: the staged bit is set, the three skinny GEMM forms take the shape, and the weight is large enough to be a stream.
+// path: the three skinny GEMM forms take the shape and the weight is large enough to be a stream.
 MIGAN_API int migan_fewpix_ok(int rows, int n, int k) {
-    return staged_on(STG_FEWPIX) && rows >= 1 && rows <= 64 && n % 16 == 0 && n >= 16 && k % 64 == 0 && k >= 1024 &&
+    return rows >= 1 && rows <= 64 && n % 16 == 0 && n >= 16 && k % 64 == 0 && k >= 1024 &&
                    (long)n * k >= (1L << 20)
                ? 1
                : 0;
@@ -192,7 +192,7 @@ MIGAN_API int migan_im2col_small(const float* x, float* col, int N, int H, int W
     if (N < 1 || H < 1 || W < 1 || C < 1 || Ho < 1 || Wo < 1 || R < 1 || S < 1 || stride < 1) return (int)hipErrorInvalidValue;
     const long total = (long)N * Ho * Wo * C * R * S;
     if (total >= (1L << 31)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(im2col_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, x, col, H, W, C, Ho,
+    MIGAN_LAUNCH(im2col_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, x, col, H, W, C, Ho,
                        Wo, R, S, stride, pt, pl, total);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -205,7 +205,7 @@ MIGAN_API int migan_col2im_small(const float* ycol, const float* bias, float* ou
     if (N < 1 || H < 1 || W < 1 || J < 1 || Ho < 1 || Wo < 1 || R < 1 || S < 1 || stride < 1) return (int)hipErrorInvalidValue;
     const long total = (long)N * H * W * J;
     if (total >= (1L << 31) || (long)N * Ho * Wo * J * R * S >= (1L << 31)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(col2im_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, ycol, bias, out, H,
+    MIGAN_LAUNCH(col2im_small_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream, ycol, bias, out, H,
                        W, J, Ho, Wo, R, S, stride, pt, pl, act, slope, total);
     HIP_LAUNCH_CHECK();
     return 0;

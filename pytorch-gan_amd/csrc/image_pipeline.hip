@@ -72,14 +72,14 @@ MIGAN_API int migan_resample_u8(const unsigned char* src, unsigned char* dst, co
         const size_t rows = (size_t)N * Hi, total = rows * out;
         const dim3 grid((unsigned)((total + 255) / 256));
         switch (C) {
-            case 1: hipLaunchKernelGGL(resample_h_kernel<1>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
-            case 2: hipLaunchKernelGGL(resample_h_kernel<2>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
-            case 3: hipLaunchKernelGGL(resample_h_kernel<3>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
-            default: hipLaunchKernelGGL(resample_h_kernel<4>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
+            case 1: MIGAN_LAUNCH(resample_h_kernel<1>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
+            case 2: MIGAN_LAUNCH(resample_h_kernel<2>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
+            case 3: MIGAN_LAUNCH(resample_h_kernel<3>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
+            default: MIGAN_LAUNCH(resample_h_kernel<4>, grid, dim3(256), 0, st, src, dst, kk, bounds, ksize, rows, Wi, out); break;
         }
     } else {
         const size_t rowbytes = (size_t)Wi * C, total = (size_t)N * out * rowbytes;
-        hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kk, bounds, ksize, N,
+        MIGAN_LAUNCH(resample_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kk, bounds, ksize, N,
                            Hi, out, rowbytes);
     }
     HIP_LAUNCH_CHECK();
@@ -123,7 +123,7 @@ MIGAN_API int migan_u8_to_f32(const unsigned char* src, float* dst, const int* c
     if (N < 1 || C < 1 || h < 1 || w < 1 || h > Hi || w > Wi || ((mean == nullptr) != (stdv == nullptr)))
         return (int)hipErrorInvalidValue;
     const size_t total = (size_t)N * h * w * C;
-    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, crop_yx,
+    MIGAN_LAUNCH(u8_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, crop_yx,
                        flip, mean, stdv, N, Hi, Wi, C, h, w, nchw);
     HIP_LAUNCH_CHECK();
     return 0;

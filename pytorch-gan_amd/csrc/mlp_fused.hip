@@ -635,14 +635,17 @@ MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, 
     if (mf_persist()) {
         p.l_lo = 0;
         p.l_hi = nlayers;
-        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
         return 0;
     }
+    const int only = grid >= 1000 ? grid - 1000 : -1;   // grid = 1000 + l: layer l alone (timing harness, tools/abi_check.cpp)
+    if (only >= 0) grid = 0;
     for (int l = 0; l < nlayers; ++l) {
+        if (only >= 0 && l != only) continue;
         p.l_lo = l;
         p.l_hi = l + 1;
-        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;
@@ -673,7 +676,7 @@ MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* d
     if (mf_persist()) {
         p.ph_lo = 0;
         p.ph_hi = nlayers + 1;
-        hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
         return 0;
     }
@@ -682,7 +685,7 @@ MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* d
         if (ph == nlayers && !dx) continue;          // l = 0 computes only dx
         if (ph == nlayers + 1 && !any_grad) continue;
         p.ph_lo = p.ph_hi = ph;
-        hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;

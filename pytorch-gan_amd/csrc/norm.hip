@@ -497,7 +497,7 @@ static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3&
 // launches of a pix2pix step.  Here a workgroup owns 16 channels of one group and ALL its pixels (64 pixel lanes x 4 channel
 // quads): pass 1 sums around the group's first pixel (the shifted-data form of the streaming kernels), the 64 lanes are combined
 // in a fixed order in double, pass 2 re-reads the (L2-resident) pixels and writes.  No cross-workgroup reduction exists.
-// Written after round 3's GPU budget was spent: verified on the host execution model, not yet timed; MIGAN_NORM_SMALL=0 = off.
+// Measured (profiles/r03_abi_check.txt): 6.3-18.6 us per launch, 4e-8 / 5e-8 from a host fp64 evaluation.
 // ---------------------------------------------------------------------------------------------
 #define NS_CH 16
 __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
     }
 }
 static bool norm_small_ok(int G, int P, int C) {
-    return staged_on(STG_NORM_SMALL) && C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
+    return C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
 }
 // 1: migan_norm_fwd_small takes the shape (instance-style statistics: no running statistics, no cross-replica exchange)
 MIGAN_API int migan_norm_small_ok(int G, int P, int C) { return norm_small_ok(G, P, C) ? 1 : 0; }
@@ -663,7 +663,7 @@ MIGAN_API int migan_norm_fwd_small(const float* x, float* y, float* mean, float*
                                    const float* res, const float* mask, int G, int P, int C, int act, float slope, float eps,
                                    void* stream) {
     if (!norm_small_ok(G, P, C)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_small_fwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma,
+    MIGAN_LAUNCH(norm_small_fwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma,
                        beta, res, P, C, act, slope, eps, mask);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -681,14 +681,14 @@ static int norm_stats_impl(const float* x, float* mean, float* invstd, float* va
     if (ws_bytes < migan_norm_workspace(G, P, C)) return (int)hipErrorInvalidValue;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
-        hipLaunchKernelGGL((norm_partial_kernel<4, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
+        MIGAN_LAUNCH((norm_partial_kernel<4, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr, PShuf{});
     else
-        hipLaunchKernelGGL((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
+        MIGAN_LAUNCH((norm_partial_kernel<1, false>), grid, dim3(256), 0, st, x, nullptr, nullptr,
                            nullptr, nullptr, nullptr, ws, P, C, CTX, chunk, nchunks, 0, 0.f, nullptr, PShuf{});
     HIP_LAUNCH_CHECK();
     const int chain = (G > 1 && running_mean != nullptr) ? 1 : 0;  // BatchNorm over G sub-batches (InstanceNorm has no running stats)
-    hipLaunchKernelGGL(norm_finalize_fwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, mean,
+    MIGAN_LAUNCH(norm_finalize_fwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, mean,
                        invstd, var_out, running_mean, running_var, num_batches_tracked, G, P, C, nchunks, chunk, eps,
                        momentum, chain);
     HIP_LAUNCH_CHECK();
@@ -742,7 +742,7 @@ MIGAN_API int migan_norm_sync_finalize(const float* gathered, int world, long lo
                                        float* running_mean, float* running_var, long long* num_batches_tracked,
                                        float momentum, float eps, int C, void* stream) {
     if (world < 1 || C < 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_sync_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
+    MIGAN_LAUNCH(norm_sync_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gathered, world,
                        (double)P_local, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, C);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -758,10 +758,10 @@ static int norm_apply_impl(const float* x, float* y, const float* mean, const fl
     apply_plan(G, P, C, VW, CTX, chunk, grid);
     if (ps.on && (VW != 4 || G != 1 || res)) return (int)hipErrorInvalidValue;
     if (VW == 4)
-        hipLaunchKernelGGL((norm_apply_kernel<4>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
+        MIGAN_LAUNCH((norm_apply_kernel<4>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
                            CTX, chunk, act, slope, slope_ptr, ps);
     else
-        hipLaunchKernelGGL((norm_apply_kernel<1>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
+        MIGAN_LAUNCH((norm_apply_kernel<1>), grid, dim3(256), 0, st, x, y, mean, invstd, gamma, beta, res, P, C,
                            CTX, chunk, act, slope, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -806,14 +806,14 @@ static int norm_bwd_sums_impl(const float* x, const float* dy, const float* mean
     if (ps.on && (VW != 4 || G != 1)) return (int)hipErrorInvalidValue;
     dim3 grid(gx, nchunks, G);
     if (VW == 4)
-        hipLaunchKernelGGL((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
+        MIGAN_LAUNCH((norm_partial_kernel<4, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
                            beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr, ps);
     else
-        hipLaunchKernelGGL((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
+        MIGAN_LAUNCH((norm_partial_kernel<1, true>), grid, dim3(256), 0, st, x, dy, mean, invstd, gamma,
                            beta, ws, P, C, CTX, chunk, nchunks, act, slope, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     const int chain = (G > 1 && (dgamma != nullptr || dbeta != nullptr)) ? 1 : 0;  // BatchNorm over G sub-batches
-    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, sums,
+    MIGAN_LAUNCH(norm_finalize_bwd_kernel, dim3(cdiv((long)(chain ? 1 : G) * C * 64, 256)), dim3(256), 0, st, ws, sums,
                        dgamma, dbeta, G, C, nchunks, accumulate, dslope_gc, chain);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -841,10 +841,10 @@ static int norm_bwd_apply_impl(const float* x, const float* dy, float* dx, const
     if (ps.on && (VW != 4 || G != 1)) return (int)hipErrorInvalidValue;
     const float invP = (float)(1.0 / (double)(P_total > 0 ? P_total : P));
     if (VW == 4)
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<4>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+        MIGAN_LAUNCH((norm_bwd_apply_kernel<4>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
                            sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr, ps);
     else
-        hipLaunchKernelGGL((norm_bwd_apply_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
+        MIGAN_LAUNCH((norm_bwd_apply_kernel<1>), grid, dim3(256), 0, st, x, dy, dx, mean, invstd, gamma, beta,
                            sums, P, C, CTX, chunk, act, slope, invP, csum, slope_ptr, ps);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -865,7 +865,7 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
     if (!dgamma && !dbeta && norm_small_ok(G, P, C) && (act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) {
         // small instance-style tensor: both halves in one launch (see norm_small_fwd_kernel)
         const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
-        hipLaunchKernelGGL(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+        MIGAN_LAUNCH(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
                            gamma, beta, P, C, act, slope, csum, rows_per_g, (const float*)nullptr);
         HIP_LAUNCH_CHECK();
         return 0;
@@ -884,7 +884,7 @@ MIGAN_API int migan_norm_bwd_small(const float* x, const float* dy, const float*
                                    float* csum, void* stream) {
     if (!norm_small_ok(G, P, C) || !(act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) return (int)hipErrorInvalidValue;
     const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
-    hipLaunchKernelGGL(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+    MIGAN_LAUNCH(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
                        gamma, beta, P, C, act, slope, csum, rows_per_g, mask);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -915,7 +915,7 @@ MIGAN_API int migan_norm_bwd_prelu(const float* x, const float* dy, const float*
                                 (dprelu && prelu_weight) ? dsl : nullptr, st, ps);
     if (rc) return rc;
     if (dprelu && prelu_weight) {
-        hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(256), 0, st, dsl, G * C, dprelu, dprelu_accumulate);
+        MIGAN_LAUNCH(sum_small_kernel, dim3(1), dim3(256), 0, st, dsl, G * C, dprelu, dprelu_accumulate);
         HIP_LAUNCH_CHECK();
     }
     return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act_, 0.f, P, csum, prelu_weight, st, ps);
@@ -932,10 +932,10 @@ MIGAN_API int migan_act_bwd_colsum(const float* dy, const float* y, const float*
     dim3 grid;
     apply_plan(G, P, C, VW, CTX, chunk, grid);
     if (VW == 4)
-        hipLaunchKernelGGL((act_bwd_colsum_kernel<4>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
+        MIGAN_LAUNCH((act_bwd_colsum_kernel<4>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
                            act, slope);
     else
-        hipLaunchKernelGGL((act_bwd_colsum_kernel<1>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
+        MIGAN_LAUNCH((act_bwd_colsum_kernel<1>), grid, dim3(256), 0, st, dy, y, mask_gc, dx, csum, P, C, CTX, chunk,
                            act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -948,7 +948,7 @@ __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float* __restric
 }
 MIGAN_API int migan_rsqrt_eps(const float* var, float* invstd, int C, float eps, void* stream) {
     if (C <= 0) return 0;
-    hipLaunchKernelGGL(rsqrt_eps_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, var, invstd, C, eps);
+    MIGAN_LAUNCH(rsqrt_eps_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, var, invstd, C, eps);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1131,11 +1131,11 @@ MIGAN_API int migan_norm_bwd2(const float* x, const float* d, const float* u, co
     float* sums = ws + (size_t)G * nchunks * C * 5;
     dim3 grid(gxb, nchunks, G);
     if (VW == 4)
-        hipLaunchKernelGGL((norm_bwd2_partial_kernel<4>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
+        MIGAN_LAUNCH((norm_bwd2_partial_kernel<4>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
     else
-        hipLaunchKernelGGL((norm_bwd2_partial_kernel<1>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
+        MIGAN_LAUNCH((norm_bwd2_partial_kernel<1>), grid, dim3(256), 0, st, x, d, u, mean, invstd, ws, P, C, CTX, chunk, nchunks);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd2_finalize_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums, invstd,
+    MIGAN_LAUNCH(norm_bwd2_finalize_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, st, ws, sums, invstd,
                        nullptr, G, C, nchunks, 0);
     HIP_LAUNCH_CHECK();
     int VW2, CTX2, chunk2;
@@ -1144,10 +1144,10 @@ MIGAN_API int migan_norm_bwd2(const float* x, const float* d, const float* u, co
     float* dgm = (G == 1) ? dgamma : nullptr;
     const float invP = (float)(1.0 / (double)P);
     if (VW == 4)
-        hipLaunchKernelGGL((norm_bwd2_apply_kernel<4>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
+        MIGAN_LAUNCH((norm_bwd2_apply_kernel<4>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
                            dgm, dgamma_accumulate, P, C, CTX2, chunk2, invP);
     else
-        hipLaunchKernelGGL((norm_bwd2_apply_kernel<1>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
+        MIGAN_LAUNCH((norm_bwd2_apply_kernel<1>), grid2, dim3(256), 0, st, x, d, u, gd, gx, mean, invstd, gamma, sums,
                            dgm, dgamma_accumulate, P, C, CTX2, chunk2, invP);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -1202,7 +1202,7 @@ MIGAN_API int migan_norm_stats_from_conv(const float* part, int nchunks, float* 
                                          float* running_var, long long* num_batches_tracked, float momentum, float eps,
                                          int G, int C, void* stream) {
     if (G < 1 || C < 1 || nchunks < 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(norm_finalize_chan_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, (hipStream_t)stream, part,
+    MIGAN_LAUNCH(norm_finalize_chan_kernel, dim3(cdiv((long)G * C * 64, 256)), dim3(256), 0, (hipStream_t)stream, part,
                        mean, invstd, running_mean, running_var, num_batches_tracked, G, C, nchunks, eps, momentum);
     HIP_LAUNCH_CHECK();
     return 0;

@@ -5,6 +5,7 @@
 //   gradients.norm(2, dim=1) and ((.-1)**2).mean() (wgan_gp.py:136-137),
 //   torch.optim.Adam single-tensor arithmetic (dcgan.py:134-135).
 #include "common.h"
+#include <string.h>
 
 #define REDUCE_BLOCKS 1024
 static int grid_for(size_t nvec, int cap = 4096) {
@@ -85,9 +86,9 @@ MIGAN_API int migan_colsum(const float* x, float* out, size_t P, int C, float* w
     size_t chunk; int nchunks;
     colsum_plan(P, C, chunk, nchunks);
     if (ws_bytes < (size_t)nchunks * C * sizeof(float)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, x, ws, P, C, chunk);
+    MIGAN_LAUNCH(colsum_partial_kernel, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, x, ws, P, C, chunk);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, ws, out, C, nchunks,
+    MIGAN_LAUNCH(colsum_final_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, ws, out, C, nchunks,
                        accumulate);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -153,21 +154,21 @@ MIGAN_API int migan_loss_fwd(int kind, const float* x, const float* t, float tco
     hipStream_t st = (hipStream_t)stream;
     if (n == 0 || ws_bytes < REDUCE_BLOCKS * sizeof(float)) return (int)hipErrorInvalidValue;
     if (n <= 16384) {
-        hipLaunchKernelGGL(loss_small_kernel, dim3(1), dim3(256), 0, st, kind, x, t, tconst, out, (int)n);
+        MIGAN_LAUNCH(loss_small_kernel, dim3(1), dim3(256), 0, st, kind, x, t, tconst, out, (int)n);
         HIP_LAUNCH_CHECK();
         return 0;
     }
     int blocks = grid_for(n, REDUCE_BLOCKS);
-    hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, x, t, tconst, ws, n);
+    MIGAN_LAUNCH(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, kind, x, t, tconst, ws, n);
     HIP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out, 1.0 / (double)n);
+    MIGAN_LAUNCH(final_sum_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out, 1.0 / (double)n);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_loss_bwd(int kind, const float* x, const float* t, float tconst, const float* g, float* dx,
                              size_t n, void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, t, tconst, g,
+    MIGAN_LAUNCH(loss_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, kind, x, t, tconst, g,
                        (float)(1.0 / (double)n), dx, n);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -193,14 +194,14 @@ __global__ void rownorm_bwd_kernel(const float* __restrict__ x, const float* __r
 }
 MIGAN_API int migan_rownorm_fwd(const float* x, float* out, int B, int D, void* stream) {
     if (B == 0) return 0;
-    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, D);
+    MIGAN_LAUNCH(rownorm_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, out, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_rownorm_bwd(const float* x, const float* nrm, const float* dn, float* dx, int B, int D,
                                 void* stream) {
     if (B == 0) return 0;
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, nrm, dn, dx, D);
+    MIGAN_LAUNCH(rownorm_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, nrm, dn, dx, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -255,19 +256,19 @@ __global__ __launch_bounds__(256) void pullaway_bwd_kernel(const float* __restri
 }
 MIGAN_API int migan_pullaway_fwd(const float* e, float* loss, float* ws, int B, int D, void* stream) {
     if (B < 2 || D < 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(pullaway_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, e, loss, ws, B, D);
+    MIGAN_LAUNCH(pullaway_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, e, loss, ws, B, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 MIGAN_API int migan_pullaway_bwd(const float* e, const float* ws, const float* g, float* de, int B, int D, void* stream) {
-    hipLaunchKernelGGL(pullaway_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, e, ws, g, de, B, D);
+    MIGAN_LAUNCH(pullaway_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, e, ws, g, de, B, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
 
 MIGAN_API int migan_rowscale(const float* x, const float* s, float* y, int B, int D, void* stream) {
     if (B == 0) return 0;
-    hipLaunchKernelGGL(rowscale_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, s, y, D);
+    MIGAN_LAUNCH(rowscale_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, s, y, D);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -339,12 +340,12 @@ MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, flo
                               void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (nblocks > 0 && ticket) {
-        hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, (const AdamTensor*)tab,
+        MIGAN_LAUNCH(adam_kernel, dim3(nblocks), dim3(256), 0, st, (const AdamTensor*)tab,
                            (const AdamBlock*)blk, step, ticket, lr_dev, lr, b1, b2, eps, grad_scale);
         HIP_LAUNCH_CHECK();
     } else {
         if (nblocks > 0) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+        MIGAN_LAUNCH(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
         HIP_LAUNCH_CHECK();
     }
     return 0;
@@ -352,15 +353,16 @@ MIGAN_API int migan_adam_step(const void* tab, const void* blk, int nblocks, flo
 
 MIGAN_API const char* migan_version() { return "migan 0.1 gfx950"; }
 
-// ---- staged-kernel switchboard (common.h) -----------------------------------------------------------------------------
-// Clear, then set, bits of the staged-kernel word (STG_* of common.h: 1 thin_conv_wave, 2 wgrad_reduce_tr, 4 midk_tile, 8 norm_small,
-// 16 smallk_tile<K,16>, 32 pack_transpose, 64 fewpix conv path); returns the word afterwards.  migan_staged(0, 0) reads it.  Host-side state only: call it
-// between launches, not while another thread is queueing them.
-MIGAN_API unsigned migan_staged(unsigned clear_bits, unsigned set_bits) {
-    std::atomic<unsigned>& w = staged_word();
-    unsigned cur = w.load(), next;
-    do next = (cur & ~clear_bits) | (set_bits & STG_ALL);
-    while (!w.compare_exchange_weak(cur, next));
-    return next;
+// ---- debug launch counters (common.h) -----------------------------------------------------------------------------------
+// Launches issued by this library since the last reset, summed over the launch sites whose kernel expression contains `substr`
+// (NULL or "" = all sites).  Host-side bookkeeping only (one relaxed increment per launch).
+MIGAN_API long migan_debug_launch_count(const char* substr) {
+    long total = 0;
+    for (migan_dbg::Site* s = migan_dbg::sites().load(std::memory_order_acquire); s; s = s->next)
+        if (substr == nullptr || substr[0] == 0 || strstr(s->name, substr)) total += s->n.load(std::memory_order_relaxed);
+    return total;
+}
+MIGAN_API void migan_debug_launch_reset() {
+    for (migan_dbg::Site* s = migan_dbg::sites().load(std::memory_order_acquire); s; s = s->next) s->n.store(0, std::memory_order_relaxed);
 }
 MIGAN_API const char* migan_error_string(int code) { return hipGetErrorString((hipError_t)code); }

@@ -219,7 +219,7 @@ MIGAN_API int migan_skinny_tn(const float* dy, const float* x, float* dw, float*
                               int db_accumulate, void* stream) {
     if (!migan_skinny_tn_ok(M, N, K)) return (int)hipErrorInvalidValue;
     const int wave_tiles = (N / 16) * (K / 64);
-    hipLaunchKernelGGL(skinny_tn_kernel, dim3((wave_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, M, N,
+    MIGAN_LAUNCH(skinny_tn_kernel, dim3((wave_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, M, N,
                        K, accumulate, db_accumulate);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -236,13 +236,13 @@ MIGAN_API int migan_skinny_nt(const float* a, const float* w, const float* bias,
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(N / 16, (M + 15) / 16);
     if (K % 128 == 0 && K >= 1024)
-        hipLaunchKernelGGL(skinny_nt_kernel<8>, grid, dim3(512), 0, st, a, w, bias, c, M, N, K, act, slope);
+        MIGAN_LAUNCH(skinny_nt_kernel<8>, grid, dim3(512), 0, st, a, w, bias, c, M, N, K, act, slope);
     else if (K % 64 == 0 && K >= 256)
-        hipLaunchKernelGGL(skinny_nt_kernel<4>, grid, dim3(256), 0, st, a, w, bias, c, M, N, K, act, slope);
+        MIGAN_LAUNCH(skinny_nt_kernel<4>, grid, dim3(256), 0, st, a, w, bias, c, M, N, K, act, slope);
     else if (K % 32 == 0 && K >= 64)
-        hipLaunchKernelGGL(skinny_nt_kernel<2>, grid, dim3(128), 0, st, a, w, bias, c, M, N, K, act, slope);
+        MIGAN_LAUNCH(skinny_nt_kernel<2>, grid, dim3(128), 0, st, a, w, bias, c, M, N, K, act, slope);
     else
-        hipLaunchKernelGGL(skinny_nt_kernel<1>, grid, dim3(64), 0, st, a, w, bias, c, M, N, K, act, slope);
+        MIGAN_LAUNCH(skinny_nt_kernel<1>, grid, dim3(64), 0, st, a, w, bias, c, M, N, K, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -252,13 +252,13 @@ MIGAN_API int migan_skinny_nn(const float* a, const float* w, float* c, int M, i
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(Nc / 32, (M + 15) / 16);
     if (R % 128 == 0 && R >= 512)
-        hipLaunchKernelGGL(skinny_nn_kernel<8>, grid, dim3(512), 0, st, a, w, c, M, R, Nc);
+        MIGAN_LAUNCH(skinny_nn_kernel<8>, grid, dim3(512), 0, st, a, w, c, M, R, Nc);
     else if (R % 64 == 0 && R >= 256)
-        hipLaunchKernelGGL(skinny_nn_kernel<4>, grid, dim3(256), 0, st, a, w, c, M, R, Nc);
+        MIGAN_LAUNCH(skinny_nn_kernel<4>, grid, dim3(256), 0, st, a, w, c, M, R, Nc);
     else if (R % 32 == 0 && R >= 64)
-        hipLaunchKernelGGL(skinny_nn_kernel<2>, grid, dim3(128), 0, st, a, w, c, M, R, Nc);
+        MIGAN_LAUNCH(skinny_nn_kernel<2>, grid, dim3(128), 0, st, a, w, c, M, R, Nc);
     else
-        hipLaunchKernelGGL(skinny_nn_kernel<1>, grid, dim3(64), 0, st, a, w, c, M, R, Nc);
+        MIGAN_LAUNCH(skinny_nn_kernel<1>, grid, dim3(64), 0, st, a, w, c, M, R, Nc);
     HIP_LAUNCH_CHECK();
     return 0;
 }

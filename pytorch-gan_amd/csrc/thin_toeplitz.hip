@@ -65,7 +65,7 @@ __global__ void toep_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 MIGAN_API int migan_thin_toeplitz_pack(const float* w_oihw, float* wt, float* wd, int Co, int Ci, int R, int S, void* stream) {
     const int Cop = toep_cols(Co, S), n = Cop * R * Ci;
-    hipLaunchKernelGGL(toep_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, wt, wd, Co, Ci, R, S,
+    MIGAN_LAUNCH(toep_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, wt, wd, Co, Ci, R, S,
                        Cop);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -112,7 +112,7 @@ MIGAN_API int migan_thin_toeplitz_fwd(const float* x, const float* wt, const flo
     if (int rc = migan_conv2d_fwd(x, wt, nullptr, ws, N, Hi, Wi, Ci, Ho, Wi, Cop, R, 1, 1, pad_t, 0, gather, ACT_NONE, 0.f, stream))
         return rc;
     const size_t lds = (size_t)(TOEP_TW + S - 1) * (Cop + 1) * sizeof(float);
-    hipLaunchKernelGGL(toep_sum_kernel, dim3((Wo + TOEP_TW - 1) / TOEP_TW, Ho, N), dim3(256), lds, (hipStream_t)stream, ws, bias,
+    MIGAN_LAUNCH(toep_sum_kernel, dim3((Wo + TOEP_TW - 1) / TOEP_TW, Ho, N), dim3(256), lds, (hipStream_t)stream, ws, bias,
                        y, Ho, Wo, Co, Wi, Cop, S, pad_l, gather, act, slope);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void toep_expand_kernel(const float* __restric
 MIGAN_API int migan_thin_toeplitz_expand(const float* dy, float* q, int N, int Ho, int Wo, int Co, int Wi, int S, int pad_l,
                                          int gather, void* stream) {
     if (N < 1 || N > 65535 || Ho < 1 || Ho > 65535 || Co < 1 || Co > 4 || S * Co > 32) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(toep_expand_kernel, dim3((Wi + TOEP_TW - 1) / TOEP_TW, Ho, N), dim3(256), 0, (hipStream_t)stream, dy, q, Ho,
+    MIGAN_LAUNCH(toep_expand_kernel, dim3((Wi + TOEP_TW - 1) / TOEP_TW, Ho, N), dim3(256), 0, (hipStream_t)stream, dy, q, Ho,
                        Wo, Co, Wi, toep_cols(Co, S), S, pad_l, gather);
     HIP_LAUNCH_CHECK();
     return 0;
@@ -181,7 +181,7 @@ MIGAN_API int migan_thin_toeplitz_wgrad(const float* x, const float* q, float* d
                                     1, pad_t, 0, gather, 0, nullptr, 0, nullptr, 0, stream))
         return rc;
     const int n = Co * Ci * R * S;
-    hipLaunchKernelGGL(toep_fold_dw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwt, dw_oihw, Co, Ci, R, S,
+    MIGAN_LAUNCH(toep_fold_dw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwt, dw_oihw, Co, Ci, R, S,
                        accumulate);
     HIP_LAUNCH_CHECK();
     return 0;

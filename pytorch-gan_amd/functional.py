@@ -13,7 +13,6 @@ import contextlib
 import torch
 from torch.autograd import Function
 
-from . import selfcheck as _selfcheck
 from ._lib import check, lib
 
 CL = torch.channels_last
@@ -222,8 +221,6 @@ def weight_cache_scope(owner=None):
     update replayed from a hipGraph — can not be served a stale pack; a capture and the eager steps around it never
     share entries either (the captured step is one scope, every eager step another)."""
     global _CACHE_SCOPE, _SCOPE_OWNER
-    if _selfcheck.PENDING:
-        _selfcheck.ensure()
     prev, prev_owner = _CACHE_SCOPE, _SCOPE_OWNER
     if prev is None:
         _CACHE_SCOPE = next(_SCOPE_IDS)
@@ -821,8 +818,6 @@ def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=AC
     """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue.
     `stats` ("batch" | "instance"): the conv epilogue also leaves per-tile statistics of its output for the BatchNorm /
     InstanceNorm layer that follows (picked up by `norm()`; ignored where the geometry does not support it)."""
-    if _selfcheck.PENDING:
-        _selfcheck.ensure(x.device)
     stride, pads = int(stride), tuple(int(p) for p in pads)
     if stats is not None and _CONV_STATS and x.dim() == 4:
         inst = 1 if stats == "instance" else 0
@@ -1605,8 +1600,6 @@ def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None
     """`num_batches_tracked` (int64 scalar on the device) is incremented by the statistics kernel itself; `prelu`: weight of
     an nn.PReLU() (single slope) applied behind the normalisation inside the same launches; `shuffle` = 2: nn.PixelShuffle(2)
     as the store index map of the same launches (output (N, C/4, 2H, 2W))."""
-    if _selfcheck.PENDING:
-        _selfcheck.ensure(x.device)
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
                        float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu, int(shuffle), mask)
 

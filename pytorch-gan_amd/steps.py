@@ -22,7 +22,6 @@ import torch
 
 from . import functional as F
 from . import nn as gnn
-from . import selfcheck as _selfcheck
 from .dp import LocalStepper
 from .optim import Adam
 
@@ -179,17 +178,14 @@ def make_wgan_gp_state(G, D, latent_dim=100, skip_dead_grads=True, dp=None):
                            dp=dp or LocalStepper())
 
 
-# K7: the critic half of the iteration (D(real), D(fake), gradient penalty with its double backward, d_loss.backward()) as ONE
-# persistent launch, csrc/critic_fused.hip.  MIGAN_K7=0 keeps the op-by-op path (autograd over the skinny GEMM Functions).
-# The persistent kernel synchronises its workgroups through a grid-wide barrier, so it is taken into service per critic only
-# after ONE iteration in which both paths ran and agreed (`verify`): the first critic iteration of a state is always op-by-op.
-_K7 = os.environ.get("MIGAN_K7", "1") == "1"   # selfcheck.ensure() clears it when the probe process says so
+# K7: the critic half of the iteration (D(real), D(fake), gradient penalty with its double backward, d_loss.backward()) on the
+# fused kernels of csrc/critic_fused.hip, the generator's no_grad forward and the generator iteration on csrc/mlp_fused.hip.
+# MIGAN_K7=0 keeps the op-by-op path (autograd over the skinny GEMM Functions): the A/B of bench.py and the parity tests.
+_K7 = os.environ.get("MIGAN_K7", "1") == "1"
 
 
 def _k7():
-    """The persistent kernels may be used: switched on, and the hardware self-check has returned its verdict (until then -
-    a capture before any eager step, say - nothing that has not run on this GPU model is launched)."""
-    return _K7 and not _selfcheck.PENDING
+    return _K7
 
 
 class _CriticFusedPlan:
@@ -199,7 +195,7 @@ class _CriticFusedPlan:
     def __init__(self, s, real):
         from ._lib import lib
 
-        self.ok = self.verified = False
+        self.ok = False
         seq = getattr(s.D, "model", None)
         mods = list(seq) if isinstance(seq, torch.nn.Sequential) else []
         if len(mods) != 5 or not all(isinstance(mods[k], torch.nn.Linear) for k in (0, 2, 4)) \
@@ -241,33 +237,6 @@ class _CriticFusedPlan:
         o = self.out.clone()   # the kernel's output slot is overwritten by the next iteration; callers keep their losses
         return o[0], o[1]
 
-    def verify(self, real, fake, alpha, d_loss, gp):
-        """After an op-by-op iteration whose gradients are in the bucket: the fused launch into scratch gradients must give the
-        same losses and gradients (and its grid barrier must not have timed out).  One host sync, once per critic."""
-        import warnings
-
-        scratch = [torch.zeros_like(p) for p in self.params]
-        fd, fg = self.run(real, fake, alpha, scratch)
-        torch.cuda.synchronize()
-        why = None
-        if int(self.sync[2]) != 0:
-            why = "its grid barrier timed out (the launch was not co-resident)"
-            self.sync.zero_()
-        else:
-            for name, got, want in (("d_loss", fd, d_loss), ("gp", fg, gp)):
-                if not abs(float(got) - float(want.detach())) <= 1e-4 * max(1.0, abs(float(want.detach()))):
-                    why = "%s %.7g vs %.7g op by op" % (name, float(got), float(want.detach()))
-            for p, g in zip(self.params, scratch):
-                ref = p.grad.detach()
-                err = float((g - ref).norm()) / max(float(ref.norm()), 1e-12)
-                if float(ref.norm()) > 0 and not err <= 1e-3:
-                    why = why or "gradient of a %s tensor off by %.2e" % (tuple(p.shape), err)
-        if why is None:
-            self.verified = True
-        else:
-            self.ok = False
-            warnings.warn("pytorch_gan_amd: the fused critic kernel is NOT used for this critic: " + why)
-
 
 class _GeneratorFusedPlan:
     """The MLP generator of wgan_gp.py:42-65 - Sequential of Linear [-> BatchNorm1d] [-> LeakyReLU | Tanh] groups behind a view to
@@ -278,7 +247,7 @@ class _GeneratorFusedPlan:
 
         from ._lib import lib
 
-        self.ok = self.verified = self.step_verified = False
+        self.ok = False
         seq, shape = getattr(G, "model", None), (out_shape if out_shape is not None else getattr(G, "img_shape", None))
         if not isinstance(seq, torch.nn.Sequential) or shape is None or z.dim() != 2:
             return
@@ -392,54 +361,25 @@ class _GeneratorFusedPlan:
                                       self.ws_bytes, 0, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y.view(self.B, *self.shape)
 
-    def verify(self, z):
-        """First use: the op-by-op forward (its result and side effects are the ones kept) against the fused launch on COPIES of
-        the BatchNorm buffers taken before it.  One host sync, once per generator."""
-        import warnings
-
-        bns = [bn for _, bn, _, _ in self.groups if bn is not None]
-        copies = [b.clone() for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
-        want = self.G(z)
-        got = self.run(z, copies)
-        torch.cuda.synchronize()
-        why = None
-        if int(self.sync[2]) != 0:
-            why = "its grid barrier timed out (the launch was not co-resident)"
-            self.sync.zero_()
-        elif not float((got - want).norm()) <= 1e-4 * max(float(want.norm()), 1e-12):
-            why = "output off by %.2e" % (float((got - want).norm()) / max(float(want.norm()), 1e-12))
-        else:
-            mine = [b for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
-            for a, b in zip(copies, mine):
-                if not torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6):
-                    why = "BatchNorm1d buffers differ"
-        if why is None:
-            self.verified = True
-        else:
-            self.ok = False
-            warnings.warn("pytorch_gan_amd: the fused generator forward is NOT used for this generator: " + why)
-        return want
-
 
 def _generator_nograd(s, z):
-    """fake_imgs = generator(z) without a graph (wgan_gp.py:163 when its gradients are dead): one persistent launch when the
-    generator is the MLP of wgan_gp.py:42-65 (verified once against the op-by-op forward), else the modules."""
+    """fake_imgs = generator(z) without a graph (wgan_gp.py:163 when its gradients are dead): the fused forward when the
+    generator is the MLP of wgan_gp.py:42-65, else the modules."""
     if _k7():
         plan = getattr(s, "_k7_gen_plan", None)
         if plan is None or (plan.ok and plan.B != z.shape[0]):
             plan = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
         if plan.usable(z):
-            if plan.verified:
-                return plan.run(z)
-            if not torch.cuda.is_current_stream_capturing():
-                return plan.verify(z)
+            return plan.run(z)
     return s.G(z)
 
 
 def _generator_iteration_plans(s, z):
     """(generator plan, critic-as-MLP plan) for the fused generator iteration, or None"""
     gp = getattr(s, "_k7_gen_plan", None)
-    if gp is None or not gp.usable(z) or not gp.verified:
+    if gp is None or (gp.ok and gp.B != z.shape[0]):
+        gp = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
+    if not gp.usable(z):
         return None
     dpn = getattr(s, "_k7_dmlp_plan", None)
     nin = gp.groups[-1][0].out_features
@@ -467,55 +407,14 @@ def _fused_generator_pass(gp, dpn, z, buffers, grads):
 
 def _generator_iteration_fused(s, z):
     """wgan_gp.py:179-193 (fake_imgs = generator(z); g_loss = -mean(discriminator(fake_imgs)); g_loss.backward()) when both
-    networks are the MLPs of wgan_gp.py:42-83 and the fused pass has been verified for this state; else None."""
+    networks are the MLPs of wgan_gp.py:42-83; else None."""
     plans = _generator_iteration_plans(s, z)
-    if plans is None or not plans[0].step_verified:
+    if plans is None:
         return None
     grads = plans[0].param_grads()
     if grads is None:
         return None
     return _fused_generator_pass(plans[0], plans[1], z, None, grads)
-
-
-def _verify_generator_iteration(s, z, g_loss):
-    """After an op-by-op generator iteration (its gradients are in the generator's bucket, its BatchNorm updates applied): the
-    fused pass on scratch gradients and on copies of the BatchNorm buffers must agree.  One host sync, once per state."""
-    import warnings
-
-    if not (_k7() and s.skip) or torch.cuda.is_current_stream_capturing():
-        return
-    plans = _generator_iteration_plans(s, z)
-    if plans is None or plans[0].step_verified or getattr(plans[0], "step_failed", False):
-        return
-    gp, dpn = plans
-    if gp.param_grads() is None:
-        return
-    bns = [bn for _, bn, _, _ in gp.groups if bn is not None]
-    copies = [b.clone() for bn in bns for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked)]
-    scratch = [[torch.zeros_like(g) if g is not None else None for g in grp] for grp in gp.param_grads()]
-    got = _fused_generator_pass(gp, dpn, z, copies, scratch)
-    torch.cuda.synchronize()
-    why = None
-    if int(gp.sync[2]) != 0 or int(dpn.sync[2]) != 0:
-        why = "a grid barrier timed out (a launch was not co-resident)"
-        gp.sync.zero_()
-        dpn.sync.zero_()
-    elif not abs(float(got) - float(g_loss.detach())) <= 1e-4 * max(1.0, abs(float(g_loss.detach()))):
-        why = "g_loss %.7g vs %.7g op by op" % (float(got), float(g_loss.detach()))
-    else:
-        for grp_s, grp in zip(scratch, gp.param_grads()):
-            for a, b in zip(grp_s, grp):
-                if a is None:
-                    continue
-                nb = float(b.norm())
-                # a Linear bias in front of BatchNorm1d has an exactly-zero true gradient: both paths hold rounding noise there
-                if nb > 1e-6 * max(1.0, float(b.numel()) ** 0.5) and not float((a - b).norm()) <= 1e-3 * nb:
-                    why = why or "gradient of a %s tensor off by %.2e" % (tuple(b.shape), float((a - b).norm()) / nb)
-    if why is None:
-        gp.step_verified = True
-    else:
-        gp.step_failed = True
-        warnings.warn("pytorch_gan_amd: the fused generator iteration is NOT used for this state: " + why)
 
 
 def _critic_plan(s, real, fake):
@@ -539,7 +438,7 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     if plan is not None and alpha is None:  # the host draw of wgan_gp.py:122, where the reference makes it
         alpha = _dev(np.random.random((real_imgs.shape[0], 1, 1, 1)), real_imgs.device)
     grads = [p.grad for p in plan.params] if plan is not None else []
-    if plan is not None and plan.verified and all(g is not None and g.is_contiguous() for g in grads):
+    if plan is not None and all(g is not None and g.is_contiguous() for g in grads):
         d_loss, gp = plan.run(real_imgs, fake_imgs, alpha, grads)
     else:
         real_v = s.D(real_imgs)
@@ -548,8 +447,6 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
         # d_loss = -mean(real) + mean(fake) + lambda_gp * gp
         d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
         _backward(d_loss)
-        if plan is not None and not plan.verified and not torch.cuda.is_current_stream_capturing():
-            plan.verify(real_imgs, fake_imgs, alpha, d_loss, gp)
     s.dp.step(s.opt_D)
     s.opt_G.zero_grad()
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
@@ -561,7 +458,6 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
             with frozen(s.D, enabled=s.skip):
                 g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
             _backward(g_loss)
-            _verify_generator_iteration(s, z, g_loss)
         s.dp.step(s.opt_G)
         out["g_loss"] = g_loss.detach()
     return out

@@ -67,7 +67,7 @@ _MAIN = _Stream()
 def emulated_device():
     import hipemu
     import pytorch_gan_amd as pg
-    from pytorch_gan_amd import _lib, functional, selfcheck
+    from pytorch_gan_amd import _lib, functional
 
     emu = hipemu.load()
     saved = []
@@ -81,7 +81,6 @@ def emulated_device():
         if getattr(mod, "__name__", "").startswith("pytorch_gan_amd") and getattr(mod, "lib", None) is real:
             patch(mod, "lib", emu)
     patch(functional, "on_device", lambda t: True)
-    patch(selfcheck, "PENDING", False)   # the hardware self-check has its own test on the model (test_selfcheck_*)
     patch(torch.cuda, "current_stream", lambda device=None: _MAIN)
     patch(torch.cuda, "Stream", _Stream)
     patch(torch.cuda, "Event", _Event)

@@ -99,18 +99,20 @@ def test_bench_flop_accounting_and_pmc_table():
     assert s["ms_per_step"] == 4.0 and s["ms_per_step_min"] == 3.5 and s["blocks"] == 3
     assert abs(s["images_per_s"] - 32000.0) < 1e-6
     assert abs(s["step_executed_frac"] - 32000 * 1.3007e9 / 157.3e12) < 2e-4
-    # round 3 took no PMC pass on its new kernels (open): no table for the current round -> roofline.traffic = null
-    tab, src = bench.pmc_table()
-    assert bench.PROFILE_ROUND == "r03" and tab == {} and src is None
-    # the committed table of round 2 (tools/pmc_kernels.py from the rocprofv3 --pmc passes of tools/round_measure.sh) describes
-    # the register-staged kernels; its arithmetic is still checked
+    # the current round's table (tools/pmc_step.py over the rocprofv3 --pmc passes of `bench.py --pmc-log`: counters of the kernels IN the
+    # training step); the committed table of round 2 (tools/pmc_kernels.py, stand-alone microbench passes, register-staged kernels)
+    # is kept as history - the arithmetic of both is checked
+    assert bench.PROFILE_ROUND == "r04"
+    tab4, src4 = bench.pmc_table()
+    if src4 is not None:
+        assert src4 == "profiles/r04_pmc_kernels.json" and any(k.startswith("upconv_wgrad[") for k in tab4)
     bench.PROFILE_ROUND = "r02"
     try:
         tab, src = bench.pmc_table()
     finally:
-        bench.PROFILE_ROUND = "r03"
+        bench.PROFILE_ROUND = "r04"
     assert src == "profiles/r02_pmc_kernels.json" and "upconv_fwd[128x 128->64 @64]" in tab and "_calibration" in tab
-    for name, ent in tab.items():
+    for name, ent in list(tab.items()) + [kv for kv in tab4.items() if "hbm_bytes_per_launch" in kv[1]]:
         if name.startswith("_"):
             continue
         assert ent["hbm_bytes_per_launch"] > 0 and ent["symbol"]
@@ -337,39 +339,54 @@ def test_rocpd_stats_counts_steps_from_the_trace(tmp_path):
     assert "13.0 launches per step" in head and "12 steps in the trace" in head, head
 
 
-def _stub_bench(tmp_path, body):
-    """A stand-in for bench.py as run_extra() starts it (python <file> --workload ...): `body` is what the child does."""
-    p = tmp_path / "stub_bench.py"
-    p.write_text("import json, os, sys, time\nargs = sys.argv[1:]\n" + body)
-    return str(p)
+def test_pmc_step_joins_counter_rows_to_roofline_groups_by_launch_ordinal(tmp_path):
+    """tools/pmc_step.py: bench.py --pmc-log names, per call of a roofline group, the ordinals of the library launches it issued; the
+    pass's dispatch list filtered to library kernels (ATen / runtime kernels interleave freely) is the same sequence.  Synthetic pass:
+    two calls of one group (main kernel + reduce), one norm call, ATen kernels in between; a pass with a missing dispatch is refused."""
+    import csv
+    import json
+    import shutil
+    import subprocess
 
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake_root = tmp_path / "repo"
+    (fake_root / "tools").mkdir(parents=True)
+    (fake_root / "profiles").mkdir()
+    shutil.copy(os.path.join(root, "tools", "pmc_step.py"), fake_root / "tools" / "pmc_step.py")
+    seq = [("void at::native::fill<float>(x)", 1 << 20), ("pack_kernel(float*)", 256), ("void wgrad_dma_kernel<64, 128>(WgradGeom)", 49152),
+           ("void at::native::add(x)", 256), ("upconv_wgrad_reduce_kernel(float const*)", 1024), ("void norm_apply_kernel<4>(float*)", 4096),
+           ("void wgrad_dma_kernel<64, 128>(WgradGeom)", 49152), ("upconv_wgrad_reduce_kernel(float const*)", 1024)]
+    log = {"workload": "dcgan", "steps": 2, "total_launches": 6, "segments": [
+        {"group": "upconv_wgrad[2x 4->4 @8]", "first": 1, "last": 3, "dense": 9e9, "executed": 4e9},
+        {"group": "norm_apply[1x64x4]", "first": 3, "last": 4, "dense": 64e6, "executed": -1.0},
+        {"group": "upconv_wgrad[2x 4->4 @8]", "first": 4, "last": 6, "dense": 9e9, "executed": 4e9}]}
 
-def test_bench_extra_configs_run_in_child_processes(tmp_path, monkeypatch):
-    """bench.run_extra(): the other BASELINE configs are measured by child processes, so that a device fault in one of them (the
-    process is aborted) cannot take the already-final headline line down: a good child's line is folded into `extra`, a child
-    that is killed by a signal, exits non-zero, prints nothing or hangs becomes an `error` entry."""
-    import bench
+    def make_pass(name, counters, drop=None):
+        d = fake_root / name
+        (d / "sub").mkdir(parents=True)
+        json.dump(log, open(d / "segments.json", "w"))
+        with open(d / "sub" / "p_counter_collection.csv", "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+            for i, (nm, grid) in enumerate(seq):
+                if i == drop:
+                    continue
+                for cn, val in counters(nm).items():
+                    wr.writerow([i + 1, nm, grid, cn, val, 1000 * i, 1000 * i + (300 if "wgrad_dma" in nm else 20)])
+        return str(d)
 
-    good = {"metric": "training images/sec", "value": 321.5, "ms_per_step": 3.11, "step_executed_frac": 0.4, "step_dense_frac": 0.5,
-            "timing": {"blocks": 7, "timed_seconds": 2.1, "ms_per_step_min": 3.0, "ms_per_step_max": 3.3},
-            "config": {"workload": "pix2pix 256x256 bs 1", "hipgraph": True}, "losses": {"loss_G": 1.5}, "peak_mem_gb": 1.25,
-            "staged_kernels": {"midk_tile": "ok", "norm_small": "disabled: differs"}}
-    stub = _stub_bench(tmp_path, "assert args[:2] == ['--workload', 'pix2pix'] and '--no-extra' in args and '--no-roofline' in args\n"
-                                 "print('some warning line')\nprint(json.dumps(%r))\n" % good)
-    monkeypatch.setattr(bench.os.path, "abspath", lambda p: stub if p == bench.__file__ else os.path.normpath(os.path.join(os.getcwd(), p)))
-    e = bench.run_extra("pix2pix", 50, 5)
-    assert e["images_per_s"] == 321.5 and e["ms_per_step"] == 3.11 and e["blocks"] == 7 and e["hipgraph"] is True
-    assert e["workload"] == "pix2pix 256x256 bs 1" and e["steps"] == 50 and e["warmup"] == 5 and e["peak_mem_gb"] == 1.25
-    assert e["staged_kernels_off"] == ["norm_small"] and e["losses"] == {"loss_G": 1.5}
-
-    for body, what in (("os.kill(os.getpid(), 6)\n", "exit status -6"), ("sys.stderr.write('boom\\n'); sys.exit(3)\n", "exit status 3: boom"),
-                       ("print('no json here')\n", "exit status 0")):
-        stub = _stub_bench(tmp_path, body)
-        monkeypatch.setattr(bench.os.path, "abspath", lambda p, s=stub: s if p == bench.__file__ else p)
-        e = bench.run_extra("srgan", 4, 1)
-        assert list(e) == ["error"] and what in e["error"], e
-    stub = _stub_bench(tmp_path, "time.sleep(60)\n")
-    monkeypatch.setattr(bench.os.path, "abspath", lambda p, s=stub: s if p == bench.__file__ else p)
-    t0 = __import__("time").time()
-    e = bench.run_extra("cyclegan", 4, 1, timeout_s=2.0)
-    assert "no result within 2 s" in e["error"] and __import__("time").time() - t0 < 20
+    sq = make_pass("sq", lambda nm: {"GRBM_GUI_ACTIVE": 1000.0, "SQ_VALU_MFMA_BUSY_CYCLES": 64000.0 if "wgrad_dma" in nm else 0.0})
+    fe = make_pass("fetch", lambda nm: {"FETCH_SIZE": 100.0 if "wgrad_dma" in nm else (31.25 if "norm" in nm else 4.0)})
+    wr_ = make_pass("write", lambda nm: {"WRITE_SIZE": 50.0 if "wgrad_dma" in nm else (62.5 if "norm" in nm else 2.0)})
+    bad = make_pass("bad", lambda nm: {"FETCH_SIZE": 1.0}, drop=4)
+    r = subprocess.run([sys.executable, str(fake_root / "tools" / "pmc_step.py"), "r99", sq, fe, wr_, bad], capture_output=True, text=True)
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "bad" in r.stdout, r.stdout + r.stderr
+    tab = json.load(open(fake_root / "profiles" / "r99_pmc_kernels.json"))
+    g = tab["upconv_wgrad[2x 4->4 @8]"]
+    assert g["symbol"].startswith("wgrad_dma_kernel<64, 128>") and g["kernels_per_launch"] == {"wgrad_dma_kernel<64, 128>": 1.0, "upconv_wgrad_reduce_kernel": 1.0}
+    assert g["hbm_bytes_per_launch"] == int((2 * (100.0 + 4.0) + (50.0 + 2.0)) * 1024)      # main kernel + reduce, per call
+    assert abs(g["mfma_busy_frac"] - 64000.0 / (128 * 2000.0)) < 1e-4                        # GUI_ACTIVE of both kernels of the call
+    assert g["launch_us_under_pmc"] == 0.3 and g["executed_gflop_per_launch"] == 4.0
+    n = tab["norm_apply[1x64x4]"]
+    assert n["algorithmic_mb_per_call"] == 64.0 and n["hbm_bytes_per_launch"] == int((2 * 31.25 + 62.5) * 1024)
+    assert [os.path.basename(p_) for p_ in tab["_source"]["passes"]] == ["fetch", "sq", "write"]

@@ -122,11 +122,11 @@ def test_every_gpu_conv_case_on_the_execution_model(emu):
 def test_results_do_not_depend_on_the_wave_schedule(emu):
     """A model that switches fibers only at synchronisation points runs the waves of a workgroup in ONE order between two
     barriers: a missing __syncthreads (two waves touching the same LDS / global word with no barrier between them) is invisible in
-    that order - and changes the result in another.  Every conv case (all kernel families), the staged kernels' self-check cases
-    (small-tensor InstanceNorm, few-pixel conv path, PatchGAN heads, packs) and the fused critic kernel: waves in index order, in
+    that order - and changes the result in another.  Every conv case (all kernel families), the specialised-kernel cases of
+    tests/kernel_cases.py (small-tensor InstanceNorm, few-pixel conv path, PatchGAN heads, packs) and the fused critic kernel: waves in index order, in
     reverse order and in a seeded random order per scheduler pass must give bit-identical results."""
     import hipemu.host
-    from pytorch_gan_amd import selfcheck
+    import kernel_cases
 
     sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
     cases = _gpu_conv_cases() + KTAIL_CASES
@@ -138,17 +138,16 @@ def test_results_do_not_depend_on_the_wave_schedule(emu):
         from pytorch_gan_amd import functional as F
 
         out = {}
-        with hipemu.host.emulated_device() as lib:
-            lib.migan_staged(0, 127)
-            saved = selfcheck._quiet_scope(F)
+        with hipemu.host.emulated_device():
+            saved = kernel_cases.quiet_scope(F)
             try:
                 with torch.enable_grad():
-                    for name, _tol, fn in selfcheck._all_cases(F, selfcheck.ALL):
+                    for name, _syms, inputs, run, _ref in kernel_cases.all_cases():
                         gen = torch.Generator(device="cpu")
                         gen.manual_seed(99)
-                        out[name] = {k: v.clone() for k, v in fn(gen).items()}
+                        out[name] = {k: v.clone() for k, v in run(F, inputs(gen)).items()}
             finally:
-                selfcheck._restore_scope(F, saved)
+                kernel_cases.restore_scope(F, saved)
         return out
 
     try:
@@ -456,7 +455,7 @@ def _run_gpu_test_body(module_name, test_name, *args):
 STEP_BODIES = [
     ("test_dcgan_steps", (True,)),            # dcgan.py:143-183, 3 steps: paired D pass, chained BatchNorm statistics, dropout masks
     ("test_wgan_gp_steps", (False,)),         # wgan_gp.py:119-193, 6 critic iterations: double backward through the skinny GEMMs
-    ("test_wgan_gp_steps", (True,)),          # ... and with the persistent critic kernel (K7) verified and in service
+    ("test_wgan_gp_steps", (True,)),          # ... and on the fused WGAN-GP kernels (K7)
     ("test_dragan_steps", ()),                # dragan.py:176-217: conv-critic gradient penalty
     ("test_srgan_step", ()),                  # srgan.py:97-145: PixelShuffle epilogue, VGG features, Toeplitz 9x9
     ("test_pix2pix_step", ()),                # pix2pix.py:123-172 at 256x256: split-K, ConvTranspose, PatchGAN head, 4-8 M-element weights
@@ -468,12 +467,12 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
     """The training-step parity tests of test_steps_gpu.py, unchanged, against the oracle: losses of every step, weights after
     Adam, BatchNorm buffers - computed by the HIP kernels' source running on the host."""
     lib = _run_gpu_test_body("test_steps_gpu", name, *args)
-    if name == "test_wgan_gp_steps":  # first iteration op by op + the verification launch, then five fused iterations
+    if name == "test_wgan_gp_steps":  # six fused iterations
         # (each call of the critic kernel = seven one-phase launches: the measured-faster form, csrc/critic_fused.hip)
         assert lib.hipemu_launch_count(b"critic_fused_kernel") == (6 * 7 if args[0] else 0)
-        # 6 no_grad forwards + iteration 0's verification of the fused generator iteration (2) + iteration 5 fused (2)
+        # 6 no_grad forwards + the fused generator iterations 0 and 5 (2 saving forwards each)
         # one launch per layer: generator 5, critic-as-MLP 3 -> 6 * 5 + 2 * (5 + 3); backward: critic (top + 3 chain phases, dx) 4 +
-        # generator (top + 4 chain phases + gradients) 6, twice (verification, then in service)
+        # generator (top + 4 chain phases + gradients) 6, twice
         assert lib.hipemu_launch_count(b"mlp_fused_fwd_kernel") == (46 if args[0] else 0)
         assert lib.hipemu_launch_count(b"mlp_fused_bwd_kernel") == (20 if args[0] else 0)
     if name == "test_pix2pix_step":   # the kernels this workload is there for
@@ -575,113 +574,25 @@ def test_fewpix_convs_on_the_execution_model(emu, which, cfg):
         assert lib.hipemu_launch_count(sym) == 0, sym
 
 
-def test_selfcheck_cases_select_the_staged_kernels(emu):
-    """pytorch_gan_amd/selfcheck.py (the hardware self-check of the kernels written without GPU time): run on the execution
-    model, its cases must really launch every staged kernel AND the kernel each one replaces, agree, and leave all bits set."""
-    import hipemu.host
-    from pytorch_gan_amd import selfcheck
+@pytest.mark.parametrize("case", list(__import__("kernel_cases").all_cases()), ids=[c[0] for c in __import__("kernel_cases").all_cases()])
+def test_geometry_selects_kernel_on_the_execution_model(emu, case):
+    """tests/kernel_cases.py on the execution model: the body of test_ops_gpu.py::test_geometry_selects_kernel - every shape is served
+    by the specialised kernel written for it (the library's own launch counters, the ones the GPU test reads) and agrees with torch."""
+    import pytorch_gan_amd as pg
 
-    with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 127)
-        lib.hipemu_reset_counts()
-        assert selfcheck.run_in_process("cpu") == 127
-        rep = selfcheck.report()
-        assert {k: rep[k] for k in selfcheck.BITS} == {k: "ok" for k in selfcheck.BITS}, rep
-        assert lib.migan_staged(0, 0) == 127
-        for sym in (b"thin_conv_wave_kernel", b"thin_conv_kernel", b"smallk_tile_kernel<K, 16>", b"smallk_tile_kernel<K, 128>",
-                    b"midk_tile_kernel", b"wgrad_reduce_tr_kernel", b"wgrad_reduce_kernel", b"pack_transpose_kernel",
-                    b"permute4_kernel", b"norm_small_fwd_kernel", b"norm_small_bwd_kernel", b"norm_partial_kernel",
-                    b"im2col_small_kernel", b"col2im_small_kernel", b"fewpix_nt_kernel", b"fewpix_nt_reduce_kernel",
-                    b"skinny_nn_kernel", b"skinny_tn_kernel"):
-            assert lib.hipemu_launch_count(sym) > 0, sym
-        worst = max(v for d in selfcheck.detail().values() for v in d.values())
-        assert worst < 1e-5, selfcheck.detail()   # staged and replaced kernels differ by summation order only
-
-
-@pytest.mark.parametrize("broken,bit", [("migan_norm_fwd_small", "norm_small")] + (
-    [("migan_permute4d", "pack_transpose")] if os.environ.get("MIGAN_EMU_SLOW") == "1" else []))
-def test_selfcheck_takes_a_disagreeing_kernel_out_of_service(emu, broken, bit):
-    """A staged kernel that computes something else on the hardware than the kernel it replaces (simulated: the C entry's
-    output is perturbed whenever the staged bit is set) loses its bit, is named in the report, and the others stay."""
-    import hipemu.host
-    from pytorch_gan_amd import functional, selfcheck
-
-    with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 127)
-        real = getattr(lib, broken)
-
-        class Proxy:
-            def __getattr__(self, name):
-                return getattr(lib, name)
-
-            def __init__(self):
-                def wrong(*a):
-                    rc = real(*a)
-                    if lib.migan_staged(0, 0) & selfcheck.BITS[bit]:
-                        n = 64   # corrupt the first floats of the output (argument 1 of both entries)
-                        buf = (__import__("ctypes").c_float * n).from_address(a[1])
-                        for i in range(n):
-                            buf[i] += 1.0
-                    return rc
-
-                self.__dict__[broken] = wrong
-
-        saved = functional.lib
-        functional.lib = Proxy()
-        events = []
-        try:
-            keep = selfcheck.run_in_process("cpu", log=lambda ev, name, **kw: events.append((ev, name, kw.get("ok"))))
-        finally:
-            functional.lib = saved
-        rep = selfcheck.report()
-        assert keep == 127 & ~selfcheck.BITS[bit]
-        assert rep[bit].startswith("disabled: differs from the kernel it replaces"), rep
-        assert all(rep[k] == "ok" for k in selfcheck.BITS if k != bit), rep
-        assert ("end", bit, False) in events and ("begin", "combined", None) in events and ("end", "combined", True) in events
-        assert lib.migan_staged(0, 0) == 127 & ~selfcheck.BITS[bit]
-        lib.migan_staged(0, 127)
-
-
-def test_selfcheck_probe_stages_on_the_execution_model(emu):
-    """What the probe process does once it has a device - per-kernel comparisons, then (MIGAN_EMU_SLOW=1: 3 min) the pix2pix
-    step with and without the staged kernels, then twelve WGAN-GP iterations on the persistent kernels - and the log it leaves:
-    fed to probe() it must give the full verdict, all three persistent guards verified."""
-    import hipemu.host
-    from pytorch_gan_amd import selfcheck
-
-    slow = os.environ.get("MIGAN_EMU_SLOW") == "1"
-    # quick mode: the per-kernel comparisons have their own test (test_selfcheck_cases_select_the_staged_kernels) - here they count as
-    # done by an earlier probe process (known_ok), so the glue, the restart bookkeeping and the WGAN-GP pass are what runs
-    stages = (["bits", "workload"] if slow else ["bits"]) + ["persistent"]
-    known = 0 if slow else 127
-    with hipemu.host.emulated_device() as lib:
-        lib.migan_staged(0, 127)
-        records = [{"event": "begin", "name": "device"}, {"event": "end", "name": "device", "ok": True}]
-        keep = selfcheck._probe_stages(torch.device("cpu"), 127, known, stages,
-                                       lambda ev, name, **kw: records.append(dict(kw, event=ev, name=name)), lambda: None)
-        records.append({"event": "end", "name": "probe", "ok": True})
-        assert keep == 127 and lib.migan_staged(0, 0) == 127
-
-    def spawn(index, start, known_ok, asked, timeout):
-        return ([r for r in records if r["name"] != "workload"] + [{"event": "begin", "name": "workload"},
-                {"event": "end", "name": "workload", "ok": True}] if not slow else records), "exit 0"
-
-    if not slow:   # what the earlier probe process would have logged for the comparisons
-        records[2:2] = [{"event": e, "name": k, **({"ok": True} if e == "end" else {})} for k in selfcheck.BITS for e in ("begin", "end")]
-    v = selfcheck.probe(0, 127, True, spawn=spawn)
-    assert v["bits"] == 127 and v["report"] == dict({k: "ok" for k in selfcheck.BITS}, persistent="ok"), v
+    _run_gpu_test_body("test_ops_gpu", "test_geometry_selects_kernel", pg, case)
 
 
 def test_abi_check_harness_on_the_execution_model(emu, tmp_path):
-    """tools/abi_check.cpp - the torch-free program that compares every staged kernel with the kernel it replaces on the hardware
-    (profiles/r03_abi_check.txt) - built against the execution model instead of the HIP runtime: its arguments, geometries and host
-    references must hold here too (the quick sections; MIGAN_EMU_SLOW=1: all but the 2.4 M-pixel one)."""
+    """tools/abi_check.cpp - the torch-free program that checks and times the latency-regime kernels on the hardware - built against
+    the execution model instead of the HIP runtime: its arguments, geometries and host references must hold here too (the quick
+    sections; MIGAN_EMU_SLOW=1: the fused critic as well)."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["bash", os.path.join(root, "tools", "build_abi_check.sh"), "host"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
-    sections = ["thin", "pack", "norm", "mlp"] + (["reduce", "fewpix", "critic"] if os.environ.get("MIGAN_EMU_SLOW") == "1" else [])
+    sections = ["norm", "mlp"] + (["critic"] if os.environ.get("MIGAN_EMU_SLOW") == "1" else [])
     for sec in sections:
         r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900, env=dict(os.environ, MIGAN_K7_GRID="8"))
         assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK") and "FAIL" not in r.stdout, (sec, r.stdout[-1500:], r.stderr[-400:])
@@ -726,14 +637,7 @@ def test_bench_builders_and_roofline_accounting_run(emu):
         g = bench.BUILDERS["wgan_gp"](LocalStepper(), 0, torch.device("cpu"), args, 3)
         for i in range(2, 7):
             out = g.run(i)
-        assert g.state._k7_plan.verified and g.state._k7_gen_plan.verified and g.state._k7_gen_plan.step_verified
-        pk = bench.persistent_kernel_state(g.state)   # what the bench line reports (and refuses a run over: barrier time-outs)
-        assert pk == {"critic": True, "generator_forward": True, "critic_as_mlp": False, "generator_iteration": True,
-                      "barrier_timeouts": 0} or (pk["critic"] and pk["generator_iteration"] and pk["barrier_timeouts"] == 0), pk
-        g.state._k7_plan.sync[2] = 1
-        assert bench.persistent_kernel_state(g.state)["barrier_timeouts"] == 1
-        g.state._k7_plan.sync[2] = 0
-        assert bench.persistent_kernel_state(w.state) is None
+        assert g.state._k7_plan.ok and g.state._k7_gen_plan.ok
 
 
 def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):

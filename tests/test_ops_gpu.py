@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, assert_close, in_service, rel_fro
+from util import TOL_BIAS, TOL_FWD, TOL_WGRAD, Launches, assert_close, rel_fro
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -99,6 +99,38 @@ def test_conv2d_fwd_bwd(pg, case):
     assert_close(wg.grad, w.grad, TOL_WGRAD, "conv wgrad")
     if bias:
         assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
+
+
+def _kernel_cases():
+    import kernel_cases
+
+    return list(kernel_cases.all_cases())
+
+
+@pytest.mark.parametrize("case", _kernel_cases(), ids=[c[0] for c in _kernel_cases()])
+def test_geometry_selects_kernel(pg, case):
+    """Dispatch inside the library is by geometry alone: each shape of tests/kernel_cases.py must be served by the specialised
+    kernel written for it (launch counters of the C ABI) AND agree with torch on the host."""
+    import kernel_cases
+
+    name, syms, inputs, run, ref = case
+    F = pg.functional
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(1234)
+    tensors = inputs(gen)
+    want = ref(tensors)
+    saved = kernel_cases.quiet_scope(F)
+    try:
+        with torch.enable_grad(), Launches() as n:
+            got = run(F, tuple(None if t is None else t.to(DEV) for t in tensors))
+            for sym in syms:
+                assert n(sym) > 0, "%s: no launch of %s" % (name, sym)
+    finally:
+        kernel_cases.restore_scope(F, saved)
+    kink = float((want["_pre"].abs() > 1e-5).float().min()) == 0.0   # an activation input within rounding of 0 may take the other branch
+    for k, v in got.items():
+        tol = {"y": TOL_FWD, "dx": 5e-5 if name.startswith("in_") else TOL_FWD, "db": TOL_BIAS}.get(k, TOL_WGRAD)
+        assert_close(v, want[k], 1e-3 if (kink and k != "y") else tol, "%s %s" % (name, k))
 
 
 def test_splitk_conv_is_deterministic(pg):
@@ -259,8 +291,7 @@ def test_conv_transpose2d(pg, shape):
 
 
 # N, Ci, H, W, Co, bias, act - Conv2d(Ci, Co, 4, 2, 1) with <= 64 output pixels and >= 1 M weights: the inner U-Net levels of
-# pix2pix/models.py:62-67 at batch 1 (d5 ... d8) and scaled-down relatives; the few-pixel path of csrc/fewpix.hip when the hardware
-# self-check left it in service (tests/test_zz_staged_gpu.py says which), the split-K tiled kernels otherwise - parity either way
+# pix2pix/models.py:62-67 at batch 1 (d5 ... d8) and scaled-down relatives: the few-pixel path of csrc/fewpix.hip (asserted)
 FEWPIX_CONV = [(1, 512, 16, 16, 512, False, 0), (1, 512, 8, 8, 512, False, 1), (1, 512, 2, 2, 512, False, 1), (2, 256, 4, 4, 256, True, 1),
                (1, 128, 8, 8, 512, True, 0), (3, 64, 6, 10, 1024, True, 2)]
 
@@ -278,8 +309,13 @@ def test_fewpix_conv2d(pg, cfg):
     y_ref.backward(gy)
     xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     bg = b.detach().to(DEV).requires_grad_(True) if bias else None
-    y = F.conv2d(xg, wg, bg, 2, (1, 1, 1, 1), F.GATHER_ZERO, act, 0.2)
-    y.backward(gy.to(DEV))
+    with Launches() as n:
+        y = F.conv2d(xg, wg, bg, 2, (1, 1, 1, 1), F.GATHER_ZERO, act, 0.2)
+        y.backward(gy.to(DEV))
+        # forward im2col + NT product, input gradient NN + col2im, weight gradient TN straight into the bucket: no tiled kernel, no pack
+        assert n("im2col_small_kernel") == 1 and n("col2im_small_kernel") == 1 and n("skinny_nn_kernel") == 1 and n("skinny_tn_kernel") == 1
+        assert n("fewpix_nt_kernel") + n("skinny_nt_kernel") == 1
+        assert n("igemm") == 0 and n("wgrad") == 0 and n("permute4") == 0 and n("pack_transpose") == 0
     assert_close(y, y_ref, TOL_FWD, "fewpix conv fwd")
     keep = (z_ref.detach().abs() > 1e-5).float()   # pre-activations at the kink may take the other branch
     if float(keep.min()) == 1.0:
@@ -310,8 +346,11 @@ def test_fewpix_conv_transpose2d(pg, cfg):
     y_ref.backward(gy)
     xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     bg = b.detach().to(DEV).requires_grad_(True) if bias else None
-    y = F.conv_transpose2d(xg, wg, bg, 2, 1, act, 0.0)
-    y.backward(gy.to(DEV))
+    with Launches() as n:
+        y = F.conv_transpose2d(xg, wg, bg, 2, 1, act, 0.0)
+        y.backward(gy.to(DEV))
+        assert n("im2col_small_kernel") == 1 and n("col2im_small_kernel") == 1 and n("skinny_tn_kernel") == 1
+        assert n("igemm") == 0 and n("wgrad") == 0 and n("permute4") == 0 and n("pack_transpose") == 0
     assert_close(y, y_ref, TOL_FWD, "fewpix convT fwd")
     tol_g = (TOL_FWD, TOL_WGRAD) if float((z_ref.detach().abs() > 1e-5).float().min()) == 1.0 or act == 0 else (1e-3, 1e-3)
     assert_close(xg.grad, x.grad, tol_g[0], "fewpix convT dgrad")
@@ -462,12 +501,11 @@ def test_instancenorm_with_fused_dropout(pg, cfg):
     gy = _leaf(N, C, H, W, seed=2)
     y_ref.backward(gy)
     xg = x.detach().to(DEV).requires_grad_(True)
-    why = in_service("norm_small")
-    if why is not None:
-        pytest.xfail("the one-launch normalisation is not in service on this device - " + why)
     assert F.norm_small_takes(xg, True)
-    y = F.norm(xg, None, None, None, None, None, True, 0.1, 1e-5, True, act, 0.2, mask=mask.to(DEV))
-    y.backward(gy.to(DEV))
+    with Launches() as n:
+        y = F.norm(xg, None, None, None, None, None, True, 0.1, 1e-5, True, act, 0.2, mask=mask.to(DEV))
+        y.backward(gy.to(DEV))
+        assert n("norm_small_fwd_kernel") == 1 and n("norm_small_bwd_kernel") == 1 and n("norm_") == 2   # nothing else of norm.hip
     assert_close(y, y_ref, TOL_FWD, "in+dropout fwd")
     keep = (z_ref.detach().abs() > 1e-5).float()
     assert_close(xg.grad.cpu() * keep, x.grad * keep, 5e-5, "in+dropout dx")

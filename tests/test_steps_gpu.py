@@ -166,46 +166,41 @@ def test_wgan_gp_steps(skip_dead):
     assert nb == nc
 
 
-def test_persistent_critic_kernel_in_service():
-    """K7 (csrc/critic_fused.hip): at the BASELINE batch the critic half of the iteration is ONE persistent
-    launch.  The first iteration of a state runs op by op and verifies the fused kernel against it (losses, six gradients, no
-    barrier time-out); from the second on the kernel is in service.  Likewise the generator's no_grad forward (one launch) and
-    the generator iteration (wgan_gp.py:179-193: two saving forwards + two backwards, csrc/mlp_fused.hip).  Every kind of
-    iteration against the oracle, and the two HIP paths (a second state that never leaves the op-by-op path) against each other."""
+def test_fused_wgan_gp_kernels_serve_the_baseline_batch():
+    """K7 (csrc/critic_fused.hip + csrc/mlp_fused.hip): at the BASELINE batch the critic half of the iteration
+    (D(real), D(fake), the gradient penalty with its double backward, d_loss.backward()), the generator's no_grad forward and the
+    generator iteration (wgan_gp.py:179-193) run on the fused kernels from the FIRST iteration on (launch counters of the C ABI:
+    no op-by-op GEMM is launched).  Every kind of iteration against the oracle, and the two HIP paths (a second state that never
+    leaves the op-by-op path) against each other."""
     from oracle import reference_steps as S
     from pytorch_gan_amd import steps
+    from util import Launches
 
     _seed(0)
     s_cpu = S.make_wgan_gp(32)
     s_k7 = steps.make_wgan_gp_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=True)
     s_op = steps.make_wgan_gp_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=False)   # never fused
-    from util import in_service
-
-    out_of_service = in_service("persistent")   # the hardware self-check's verdict (pytorch_gan_amd/selfcheck.py)
-    not_taken = []
     _seed(4)
     for i in range(6):
         real = torch.rand(64, 1, 32, 32) * 2 - 1
         z = torch.tensor(np.random.normal(0, 1, (64, 100)), dtype=torch.float32)
         alpha = torch.tensor(np.random.random((64, 1, 1, 1)), dtype=torch.float32)
         o_c = S.wgan_gp_step(s_cpu, real, i, z, alpha)
-        o_k = steps.wgan_gp_step(s_k7, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
-        o_o = steps.wgan_gp_step(s_op, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+        with Launches() as n:
+            o_k = steps.wgan_gp_step(s_k7, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+            assert n("critic_fused") > 0 and n("mlp_fused_fwd") > 0, "iteration %d did not run on the fused kernels" % i
+            assert n("skinny") == 0 and n("igemm") == 0 and n("wgrad") == 0, "iteration %d launched op-by-op GEMMs" % i
+            if "g_loss" in o_c:
+                assert n("mlp_fused_bwd") > 0
+        with Launches() as n:
+            o_o = steps.wgan_gp_step(s_op, real.to(DEV), i, z.to(DEV), alpha.to(DEV))
+            assert n("critic_fused") == 0 and n("mlp_fused") == 0 and n("skinny") > 0
         for k in ("d_loss", "gp"):
-            _loss_close(o_k[k], o_c[k], "%s iter %d (fused from iter 1)" % (k, i))
+            _loss_close(o_k[k], o_c[k], "%s iter %d (fused)" % (k, i))
             _loss_close(o_k[k], o_o[k], "%s iter %d fused vs op by op" % (k, i), 2e-5)
-        # a guard that does not take its kernel into service on THIS hardware (barrier not co-resident, a difference) leaves the
-        # op-by-op path running: the parity assertions of this test still hold for it; the test then reports an expected failure
-        plan, gplan = getattr(s_k7, "_k7_plan", None), getattr(s_k7, "_k7_gen_plan", None)
-        if not (plan is not None and plan.ok and plan.verified):
-            not_taken.append("iter %d: the persistent critic kernel was not taken into service" % i)
-        if not (gplan is not None and gplan.ok and gplan.verified):
-            not_taken.append("iter %d: the persistent generator forward was not taken into service" % i)
-        if "g_loss" in o_c:   # iteration 0: op by op + verification of the fused generator iteration; iteration 5: fused
+        if "g_loss" in o_c:
             _loss_close(o_k["g_loss"], o_c["g_loss"], "g_loss iter %d" % i)
             _loss_close(o_k["g_loss"], o_o["g_loss"], "g_loss iter %d fused vs op by op" % i, 2e-5)
-            if not (gplan is not None and gplan.step_verified):
-                not_taken.append("iter %d: the fused generator iteration was not taken into service" % i)
     _params_close(s_k7.D, s_cpu.D, 6, "critic (K7)")
     _params_close(s_k7.G, s_cpu.G, 2, "generator (fused iteration)")
     for p, q in zip(s_k7.D.parameters(), s_op.D.parameters()):
@@ -215,9 +210,6 @@ def test_persistent_critic_kernel_in_service():
             assert int(b) == int(c) == 8, k
         else:   # the two runs' weights are up to ~n*lr apart after Adam's sign-like first steps: statistics follow loosely
             assert torch.allclose(c.detach().cpu().double(), b.double(), rtol=2e-2, atol=2e-3), (k, float((c.detach().cpu() - b).abs().max()))
-    if out_of_service is not None or not_taken:
-        pytest.xfail("parity holds on the op-by-op HIP path; the persistent kernels are not in service on this device - %s"
-                     % (out_of_service or "; ".join(not_taken[:3])))
 
 
 def test_wgan_gp_steps_vs_reference_trace(golden_dir):
@@ -774,25 +766,17 @@ def test_bench_cyclegan_strong_scaling_two_ranks_on_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MIGAN_DP_BACKEND="gloo", MIGAN_DP_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    # Two PROCESSES time-share one GPU here (never the case in production: one process per GPU).  With the LDS-DMA conv
-    # kernels of round 3 this 50+ step launch did not finish (see the xfail below); the untested working hypothesis is the
-    # preemption of waves with LDS-DMA in flight when the hardware scheduler time-slices the two processes' queues, so this
-    # test - whose subject is the data-parallel control flow, not the kernels - runs the register-staged kernels of round 2.
-    env.update(MIGAN_DMA="0", MIGAN_DMA_WGRAD="0", MIGAN_HANG_DUMP_S="120")   # stacks of both ranks before the limit hits
+    env.update(MIGAN_HANG_DUMP_S="120")   # stacks of both ranks should the launch ever stall again
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cyclegan",
            "--global-batch", "2", "--steps", "2", "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-roofline"]
     from util import run_ranks
 
+    # three steps; gloo stages the 91 + 2 x 11 MB buckets through the host (2-3 s per step in this single-GPU test mode).  Round 3's
+    # "hang" was 50 such steps: bench.py warmed its image histories with whole training steps
     rc, stdout, stderr = run_ranks(cmd, root, env, 150)
-    if rc is None:
-        # OPEN ISSUE (round 3): this launch passed in round 2 (< 100 s) and did not finish in two round-3 runs (700 s, 140 s);
-        # the GPU budget of the round ran out before the cause could be isolated (the same two-rank path with the DCGAN
-        # step - test_bench_two_ranks_on_one_gpu - passes, and every single-process CycleGAN test passes).  The ranks are
-        # killed as a group so nothing lingers on the GPU; reported as an expected failure, not as a pass.
-        where = [ln for ln in stderr.splitlines() if ln.startswith(("Thread ", "Current thread", "  File "))][-24:]
-        pytest.xfail("cyclegan --global-batch 2 with two gloo ranks on one GPU did not finish in 150 s (DESIGN.md, open issues); "
-                     "rank stacks at 120 s:\n" + "\n".join(where))
+    where = [ln for ln in stderr.splitlines() if ln.startswith(("Thread ", "Current thread", "  File "))][-24:]
+    assert rc is not None, "cyclegan --global-batch 2 with two gloo ranks did not finish in 150 s; rank stacks:\n" + "\n".join(where)
     assert rc == 0, stderr[-2000:]
     res = json.loads([ln for ln in stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 and res["scaling"] == "strong"

@@ -90,8 +90,54 @@ task_suite() {
   grep -v "^  \|^$" $O/pytest_gpu.txt | tail -60
 }
 
+# PMC passes over the training step itself: bench.py --pmc-log (launch ordinals per roofline group) joined by tools/pmc_step.py
+#   pmcstep <workload> <steps> <pass>...      pass = sq | l2 | fetch | write
+task_pmcstep() {
+  local w=$1 k=$2; shift 2
+  local O=gpurun_out/r4pmcstep_$w
+  mkdir -p $O
+  for name in "$@"; do
+    case $name in
+      sq) ctr="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" ;;
+      l2) ctr="TCC_HIT_sum TCC_MISS_sum" ;;
+      fetch) ctr="FETCH_SIZE" ;;
+      write) ctr="WRITE_SIZE" ;;
+    esac
+    mkdir -p $R/$O/$name
+    (cd /tmp && timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/$O/$name -o p -- \
+       python $R/bench.py --workload $w --steps $k --warmup 1 --pmc-log $R/$O/$name/segments.json > $R/$O/$name.log 2>&1)
+    tail -1 $O/$name.log | cut -c1-200
+  done
+  python tools/pmc_step.py r04 $(for n in "$@"; do echo $O/$n; done) > $O/summary.txt 2>&1
+  head -30 $O/summary.txt | cut -c1-200
+  find $O -name "*.csv" -size +6M -delete
+  cp profiles/r04_pmc_kernels.json gpurun_out/r04_pmc_kernels.json
+}
+
+task_second() {
+  local O=gpurun_out/r4b; mkdir -p $O
+  timeout 120 ./tools/abi_check.bin floor > $O/abi_check.txt 2>&1
+  for s in critic mlp norm; do timeout 120 ./tools/abi_check.bin $s >> $O/abi_check.txt 2>&1; done
+  grep -v "^migan" $O/abi_check.txt | cut -c1-220
+  # item 1: the two-rank CycleGAN launch with the collective-free buffer warm-up, as the suite runs it
+  timeout 300 python -m pytest tests/test_steps_gpu.py -q -x -k "two_ranks_on_one_gpu" --durations=5 > $O/pytest_two_rank.txt 2>&1
+  tail -8 $O/pytest_two_rank.txt
+  port=$((20000 + RANDOM % 20000))
+  MIGAN_DP_BACKEND=gloo timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port \
+     tools/gloo_bucket_probe.py > $O/gloo_probe.txt 2>&1
+  grep "gloo all_reduce" $O/gloo_probe.txt
+  # which kernel ran (launch counters) + parity of the cases that used to sit behind run-time switches
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -x -k "geometry_selects or fewpix or fused_dropout or fused_wgan or wgan_gp_steps" > $O/pytest_counters.txt 2>&1
+  tail -4 $O/pytest_counters.txt
+  task_pmcstep dcgan 3 sq l2 fetch write
+  task_pmcstep cyclegan 1 sq fetch write
+  task_pmcstep srgan 1 sq fetch write
+}
+
 t=${1:-}; shift || true
 case "$t" in
+  second) task_second "$@" ;;
+  pmcstep) task_pmcstep "$@" ;;
   hang) task_hang "$@" ;;
   prof) task_prof "$@" ;;
   pmc) task_pmc "$@" ;;
