@@ -362,7 +362,7 @@ __global__ __launch_bounds__(CF_THREADS) void critic_fused_kernel(const CriticFu
             if (lane < B)
                 for (int c = 0; c < Din / 32; ++c) n2 += gsq[(size_t)lane * (Din / 32) + c];
             const float n = sqrtf(n2);
-            coefb[lane] = lane < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+            coefb[lane] = (lane < B && n > 0.f) ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;   // torch's norm() backward: zero subgradient at 0
             const float pen = cf_wavesum(lane < B ? (n - 1.f) * (n - 1.f) : 0.f);
             if (lane == 0) p.out[1] = pen * invB;
         }
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(CF_THREADS) void critic_fused_kernel(const CriticFu
                 float n2 = 0.f;
                 for (int cc = 0; cc < Din / 32; ++cc) n2 += gsq[(size_t)i * (Din / 32) + cc];
                 const float n = sqrtf(n2);
-                coef_s[threadIdx.x] = i < B ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
+                coef_s[threadIdx.x] = (i < B && n > 0.f) ? 2.f * p.lambda * (n - 1.f) * invB / n : 0.f;
             }
             __syncthreads();
             if (ks == 0) {

@@ -161,6 +161,12 @@ def _splitk_ws(ref, max_m, Co, Ci_src, ncls=1):
     key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
     ws = _SK_WS.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # The tickets must be zero AT REST: a buffer created inside a capture would be zeroed by a captured memset node only
+            # (never eagerly) and would live in that graph's private pool while staying cached here under the stream key - a later
+            # graph or eager launch on the stream would then run on unzeroed tickets and silently skip its output tile.
+            # No cached buffer for this stream yet => this launch takes the un-split kernel (same result, by geometry rule).
+            return None, 0
         ws = torch.zeros(lib.migan_conv_splitk_workspace() // 4, device=ref.device, dtype=torch.float32)
         _SK_WS[key] = ws
     return ws.data_ptr(), ws.numel() * 4
