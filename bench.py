@@ -255,9 +255,10 @@ def build_wgan_gp(dp, rank, dev, args, nsteps):
     zs = torch.from_numpy(rng.normal(0, 1, (64, batch, 100)).astype(np.float32)).to(dev)
     alphas = torch.from_numpy(rng.random_sample((64, batch, 1, 1, 1)).astype(np.float32)).to(dev)
     runner = steps.WganGpRunner(state, batch, (1, 32, 32), use_graph=not args.no_graph).prepare(real, zs[0], alphas[0])
+    za = torch.cat([zs.reshape(64, -1), alphas.reshape(64, -1)], 1).contiguous()   # the draws of an iteration, packed: one staging copy
 
     def run(i):
-        return runner.run(i, None, zs[i % 64], alphas[i % 64])
+        return runner.run(i, None, None, None, packed=za[i % 64])
 
     w = Workload("wgan_gp", batch, run, state, None, runner.graphed, runner.capture_error, (G, D))
     w.eager = lambda: steps.wgan_gp_step(state, real, 1, zs[0], alphas[0])

@@ -107,44 +107,41 @@ int migan_im2col_small(const float* x, float* col, int N, int H, int W, int C, i
 int migan_col2im_small(const float* ycol, const float* bias, float* out, int N, int H, int W, int J, int Ho, int Wo, int R, int S,
                        int stride, int pt, int pl, int act, float slope, void* stream);
 
-/* K7 (csrc/critic_fused.hip): one WGAN-GP critic iteration of the MLP critic in ONE persistent launch - replaces, for
+/* K7 (csrc/critic_fused.hip): one WGAN-GP critic iteration of the MLP critic as six dependent launches - replaces, for
  * wgan_gp.py:68-83 (Discriminator), :119-138 (compute_gradient_penalty, incl. autograd.grad(create_graph=True)) and :160-176
  * (real_validity, fake_validity, d_loss, d_loss.backward()), the ~75 launches of the op-by-op path: D(real), D(fake), the
  * gradient penalty of the interpolates alpha*real + (1-alpha)*fake, d_loss = -mean D(real) + mean D(fake) + lambda*gp, and the
- * gradient of d_loss w.r.t. w1 [H1][Din], b1, w2 [H2][H1], b2, w3 [H2], b3 ADDED into gw1..gb3 (the optimiser's zeroed bucket).
- * real, fake [B][Din]; alpha [B]; out[4] = d_loss, gp, mean D(real), mean D(fake).  B <= 64; Din, H1, H2 % 128 == 0.
- * ws: migan_critic_fused_workspace() bytes of scratch; sync: 4 unsigned ints zeroed ONCE by the caller (the kernel re-arms
- * them); grid: workgroups of the persistent launch, all of which must be resident at once (0 = 128).  The grid barrier spins
- * a bounded number of times: sync[2] != 0 afterwards means it gave up (results invalid, sync must be re-zeroed), never a hang.
- * Launch form: by default the kernel is launched once per phase (seven ordinary dependent launches, no grid barrier - measured
- * faster on the MI355X than the barriers' L2 write-back / invalidate); MIGAN_K7_PERSIST=1 = the single persistent launch.  The same
- * holds for migan_mlp_fused_fwd / _bwd (one launch per layer / per backward phase). */
+ * gradient of d_loss w.r.t. w1 [H1][Din], b1, w2 [H2][H1], b2, w3 [H2], b3 written into gw1..gb3 (accumulate != 0: added, as
+ * optimizer.zero_grad() + backward() would leave them).  real, fake [B][Din]; alpha [B]; out[4] = d_loss, gp, mean D(real),
+ * mean D(fake).  B <= 64; Din, H1, H2 % 128 == 0.  ws: migan_critic_fused_workspace() bytes of scratch.  phase: 0 = all six
+ * launches; 1..6 = that launch alone (timing harness). */
 int migan_critic_fused_ok(int B, int Din, int H1, int H2);
 size_t migan_critic_fused_workspace(int B, int Din, int H1, int H2);
 int migan_critic_fused(const float* real, const float* fake, const float* alpha, const float* w1, const float* b1,
                        const float* w2, const float* b2, const float* w3, const float* b3, float* gw1, float* gb1, float* gw2,
-                       float* gb2, float* gw3, float* gb3, float* out, float* ws, size_t ws_bytes, unsigned* sync, int B,
-                       int Din, int H1, int H2, float slope, float lambda, int grid, void* stream);
+                       float* gb2, float* gw3, float* gb3, float* out, float* ws, size_t ws_bytes, int B, int Din, int H1,
+                       int H2, float slope, float lambda, int accumulate, int phase, void* stream);
 
-/* Forward of an MLP generator at <= 64 rows in ONE persistent launch (csrc/mlp_fused.hip): replaces, for the no_grad
+/* Forward of an MLP generator at <= 64 rows, one launch per layer (csrc/mlp_fused.hip): replaces, for the no_grad
  * `fake_imgs = generator(z)` of wgan_gp.py:163 (Generator wgan_gp.py:42-65; gan.py:38-61), 5 x Linear + 3 x BatchNorm1d(out, 0.8)
  * (training mode: batch statistics, running statistics and num_batches_tracked updated) + LeakyReLU / Tanh = 14 launches.
  * Host arrays: dims[4*l] = {K, N, has_bn, act code}, fpar[3*l] = {slope, eps, momentum}, ptrs[7*l] = DEVICE pointers {W [N][K], b,
  * gamma, beta, running_mean, running_var, num_batches_tracked (int64)}, NULL where absent.  B <= 64, K % 4 == 0, N % 16 == 0,
- * <= 8 layers.  save = 0: ws holds two ping-pong activation buffers.  ws / sync / grid as for migan_critic_fused (sync[2] != 0: the grid barrier gave up, never a hang). */
+ * <= 8 layers.  save = 0: ws holds two ping-pong activation buffers.  only: 0 = every layer; 1 + l = layer l alone (timing harness). */
 int migan_mlp_fused_ok(int B, int nlayers, const int* dims);
 size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims, int save);
 int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar, void* const* ptrs,
-                        float* ws, size_t ws_bytes, int save, unsigned* sync, int grid, void* stream);
-/* ... and its backward in one persistent launch (the generator iteration wgan_gp.py:179-193: both `generator(z)` and the frozen
+                        float* ws, size_t ws_bytes, int save, int only, void* stream);
+/* ... and its backward, one launch per phase (the generator iteration wgan_gp.py:179-193: both `generator(z)` and the frozen
  * `discriminator(fake_imgs)` are such MLPs): forward with save = 1 (ws then holds every layer's output, and the normalised values
- * and 1/std of the BatchNorm layers), then dy [B][N_last] -> parameter gradients ADDED into gptrs[4*l] = {dW [N][K], db [N], dgamma,
- * dbeta} (device pointers in a host array; NULL = not wanted) and, when dx != NULL, the input gradient dx [B][K_0] (K_0 % 32 == 0).
- * N % 32 == 0 for every layer but the last (a critic's single output column is fine). */
+ * and 1/std of the BatchNorm layers), then dy [B][N_last] -> parameter gradients written into (accumulate != 0: added to)
+ * gptrs[4*l] = {dW [N][K], db [N], dgamma, dbeta} (device pointers in a host array; NULL = not wanted) and, when dx != NULL, the
+ * input gradient dx [B][K_0] (K_0 % 32 == 0).  N % 32 == 0 for every layer but the last (a critic's single output column is fine).
+ * only: 0 = every phase; 1 + ph = phase ph alone (timing harness). */
 size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* dims);
 int migan_mlp_fused_bwd(const float* x, const float* y, const float* dy, const float* save, float* dx, int B, int nlayers,
                         const int* dims, const float* fpar, void* const* ptrs, void* const* gptrs, float* ws, size_t ws_bytes,
-                        unsigned* sync, int grid, void* stream);
+                        int accumulate, int only, void* stream);
 
 /* Conv2d input gradient (aten::convolution_backward, grad_input) == nn.ConvTranspose2d forward
  * (pix2pix/models.py:39, k=4 s=2 p=1).  Geometry arguments describe the FORWARD conv; dy [N][Ho][Wo][Co];

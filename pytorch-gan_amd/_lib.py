@@ -157,12 +157,12 @@ _SIGS = {
     "migan_pullaway_bwd": (c_int, [P, P, P, P, c_int, c_int, P]),
     "migan_critic_fused_ok": (c_int, [c_int] * 4),
     "migan_critic_fused_workspace": (c_size_t, [c_int] * 4),
-    "migan_critic_fused": (c_int, [P] * 17 + [c_size_t, P] + [c_int] * 4 + [c_float, c_float, c_int, P]),
+    "migan_critic_fused": (c_int, [P] * 17 + [c_size_t] + [c_int] * 4 + [c_float, c_float, c_int, c_int, P]),
     "migan_mlp_fused_ok": (c_int, [c_int, c_int, P]),
     "migan_mlp_fused_workspace": (c_size_t, [c_int, c_int, P, c_int]),
     "migan_mlp_fused_bwd_workspace": (c_size_t, [c_int, c_int, P]),
-    "migan_mlp_fused_fwd": (c_int, [P, P, c_int, c_int, P, P, P, P, c_size_t, c_int, P, c_int, P]),
-    "migan_mlp_fused_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P, c_int, P]),
+    "migan_mlp_fused_fwd": (c_int, [P, P, c_int, c_int, P, P, P, P, c_size_t, c_int, c_int, P]),
+    "migan_mlp_fused_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, c_int, c_int, P]),
     "migan_norm_small_ok": (c_int, [c_int, c_int, c_int]),
     "migan_norm_fwd_small": (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, P]),
     "migan_norm_bwd_small": (c_int, [P] * 8 + [c_int] * 4 + [c_float, P, P]),

@@ -2617,8 +2617,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
     const size_t src = (size_t)(blockIdx.x - br.nbias) * OUTS + lo;
     float s = 0.f;
-    if (src < total)
-        for (int k = grp; k < splits; k += GROUPS) s += part[(size_t)k * total + src];
+    if (src < total) {
+        // eight slabs per round of loads (same summation order as one at a time: bit-identical), so a 48-split reduction is 2-6 dependent
+        // rounds instead of 12-48
+        int k = grp;
+        for (; k + 7 * GROUPS < splits; k += 8 * GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u * GROUPS) * total + src];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; k += GROUPS) s += part[(size_t)k * total + src];
+    }
     if (GROUPS > 1) {
         red[threadIdx.x] = s;
         __syncthreads();
@@ -2923,7 +2934,15 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
         for (int ab = 0; ab < 4; ++ab) {
             const int tap = up_idx(ab >> 1, r) * 2 + up_idx(ab & 1, q);
             const float* src = part + (size_t)ab * splits * slab + ((size_t)co * 4 + tap) * Ci + ci;
-            for (int k = grp; k < splits; k += GROUPS) acc += src[(size_t)k * slab];
+            int k = grp;   // eight slabs per round of loads, summed in the same order as one at a time
+            for (; k + 7 * GROUPS < splits; k += 8 * GROUPS) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u * GROUPS) * slab];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; k < splits; k += GROUPS) acc += src[(size_t)k * slab];
         }
     }
     red[threadIdx.x] = acc;

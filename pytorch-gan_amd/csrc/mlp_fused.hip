@@ -1,19 +1,19 @@
-// Forward of an MLP generator - Linear [-> BatchNorm1d (training mode)] [-> LeakyReLU | Tanh | ...] per layer - at <= 64 rows in ONE
-// persistent launch: wgan_gp.py:42-65 / gan.py:38-61 (100 -> 128 -> 256 -> 512 -> 1024 -> prod(img_shape), BatchNorm1d(out, 0.8)
+// Forward of an MLP generator - Linear [-> BatchNorm1d (training mode)] [-> LeakyReLU | Tanh | ...] per layer - at <= 64 rows, one
+// launch per layer: wgan_gp.py:42-65 / gan.py:38-61 (100 -> 128 -> 256 -> 512 -> 1024 -> prod(img_shape), BatchNorm1d(out, 0.8)
 // on layers 2-4, LeakyReLU(0.2), Tanh), which the critic iterations of wgan_gp.py:163 run under no_grad: 5 Linear + 3 x (statistics,
-// finalize, apply) = 14 launches of 3-6 us op by op.  One phase per layer, a grid-wide barrier between layers (the bounded-spin
-// barrier of critic_fused.hip).  A workgroup owns 16 output columns and ALL rows, so the batch statistics of a BatchNorm1d column
-// never leave the workgroup: its 8 waves are (row group) x (K slice), the K slices are combined through LDS in a fixed order, the
-// column mean and the two-pass variance over the <= 64 rows are taken across the row-group waves through LDS, and the running
-// statistics (momentum, unbiased variance) and num_batches_tracked are updated as nn.BatchNorm1d does in training mode.
+// finalize, apply) = 14 launches of 3-6 us op by op.  A workgroup owns 16 output columns and ALL rows, so the batch statistics of a
+// BatchNorm1d column never leave the workgroup: its 16 waves are (row group) x (K slice), every wave fetches its K slice in batches of
+// 128 k values (one round trip to the L2 / Infinity Cache per batch; round 3's kernel took one round per 64 with half the slices: eight
+// dependent rounds for K = 1024, 19.6 us for that layer - profiles/r04_abi_check_and_two_rank.txt), the K slices are combined through LDS
+// in a fixed order, the column mean and the two-pass variance over the <= 64 rows are taken across the row-group waves through LDS, and
+// the running statistics (momentum, unbiased variance) and num_batches_tracked are updated as nn.BatchNorm1d does in training mode.
+// (A single persistent launch with grid-wide barriers between the layers was measured slower - 63 us against 61 us for five launches in
+// round 3, each barrier writes back and invalidates the L2 - and is gone.)
 #include "common.h"
 
-#define MF_WAVES 8
+#define MF_WAVES 16
 #define MF_THREADS (64 * MF_WAVES)
 #define MF_MAX_LAYERS 8
-#ifndef MF_SPIN_LIMIT   // (the host execution model of tests/hipemu builds with a larger bound: its workgroups are OS threads on a shared machine)
-#define MF_SPIN_LIMIT (1u << 16)
-#endif
 
 struct MlpLayer {
     const float *W, *b, *gamma, *beta;
@@ -28,9 +28,7 @@ struct MlpFused {
     float* y;
     float* ws;        // two [RB][maxN] activation buffers (forward without a graph), or the save buffer (see MlpSave)
     int saving;       // 1: every layer's output (and normalised pre-affine value + invstd of the BatchNorm layers) is kept for mlp_fused_bwd
-    unsigned* sync;   // [0] arrivals, [1] exits, [2] error flag
-    int l_lo, l_hi;   // this launch runs layers l_lo .. l_hi - 1: all = the persistent form (grid barrier between layers); one layer per
-                      // launch = ordinary dependent launches (measured faster on the MI355X, see migan_mlp_fused_fwd)
+    int layer;        // the layer this launch computes
     MlpLayer L[MF_MAX_LAYERS];
 };
 // Save buffer of a forward that will be differentiated: for layer l < last h_l [RB][N_l]; for BatchNorm layers xhat_l [RB][N_l]
@@ -62,78 +60,55 @@ static __host__ __device__ inline MlpSave mf_save_at(int RB, int nlayers, const 
 
 __device__ __forceinline__ f32x4 mf_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// K slice [kbeg, kend) of a 16x16 NT tile; ap / wp point at this lane's row at k = 0; K % 4 == 0, so a lane's float4 is inside or outside
+// K slice [kbeg, kend) of a 16x16 NT tile; ap / wp point at this lane's row at k = 0; K % 4 == 0, so a lane's float4 is inside or
+// outside the slice.  NB x 16 k values per batch: all loads of a batch are issued before its first MFMA.
+template <int NB>
+__device__ __forceinline__ void mf_nt_batch(const float* __restrict__ ap, const float* __restrict__ wp, int k0, int kbeg, int kend, int kq,
+                                            f32x4& acc0, f32x4& acc1) {
+    f32x4 a[NB], b[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int k = k0 + 16 * u + 4 * kq;
+        const bool in = k < kend;
+        const int kc = in ? k : kbeg;  // any valid address
+        a[u] = *reinterpret_cast<const f32x4*>(ap + kc);
+        b[u] = *reinterpret_cast<const f32x4*>(wp + kc);
+        if (!in) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);   // every load of the batch is issued before its first MFMA (one round trip, not NB)
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (u & 1) acc1 = mf_mfma(a[u][s], b[u][s], acc1);
+            else acc0 = mf_mfma(a[u][s], b[u][s], acc0);
+        }
+}
 __device__ __forceinline__ f32x4 mf_nt_partial(const float* __restrict__ ap, const float* __restrict__ wp, int kbeg, int kend, int kq) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int k0 = kbeg;
-    for (; k0 + 64 <= kend; k0 += 64) {
-        f32x4 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 * u + 4 * kq);
-            b[u] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 * u + 4 * kq);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u += 2)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc0 = mf_mfma(a[u][s], b[u][s], acc0);
-                acc1 = mf_mfma(a[u + 1][s], b[u + 1][s], acc1);
-            }
-    }
-    for (; k0 < kend; k0 += 16) {
-        const int k = k0 + 4 * kq;
-        const bool in = k < kend;
-        const int kc = in ? k : kbeg;  // any valid address
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + kc), b0 = *reinterpret_cast<const f32x4*>(wp + kc);
-        if (!in) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc0 = mf_mfma(a0[s], b0[s], acc0);
-    }
+    for (; k0 + 64 < kend; k0 += 128) mf_nt_batch<8>(ap, wp, k0, kbeg, kend, kq, acc0, acc1);   // > 64 left: a batch of 128
+    if (k0 + 32 < kend) mf_nt_batch<4>(ap, wp, k0, kbeg, kend, kq, acc0, acc1);
+    else if (k0 + 16 < kend) mf_nt_batch<2>(ap, wp, k0, kbeg, kend, kq, acc0, acc1);
+    else if (k0 < kend) mf_nt_batch<1>(ap, wp, k0, kbeg, kend, kq, acc0, acc1);
     return acc0 + acc1;
-}
-
-__device__ __forceinline__ bool mf_grid_barrier(unsigned* sync, unsigned& target, int* give_up) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        target += gridDim.x;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        int bad = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > MF_SPIN_LIMIT) {
-                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bad = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *give_up = bad;
-    }
-    __syncthreads();
-    return *give_up == 0;
 }
 
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFused p) {
     __shared__ f32x4 part[(MF_WAVES - 1) * 64];   // partial tiles of the waves with ks > 0: [(ks - 1) * RGW + rg][lane]
     __shared__ float red[4][16];
-    __shared__ int give_up;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, kq = lane >> 4;
     const int B = p.B, RB = p.RB;
     const int RG = RB / 16;
-    const int RGW = RG >= 3 ? 4 : RG;             // row-group waves (1, 2 or 4); the rest of the 8 waves are K slices
+    const int RGW = RG >= 3 ? 4 : RG;             // row-group waves (1, 2 or 4); the rest of the 16 waves are K slices
     const int KSL = MF_WAVES / RGW;
     const int rg = wave % RGW, ks = wave / RGW;
     const bool rows_live = rg < RG;
     float* const buf0 = p.ws;
     float* const buf1 = p.ws + (size_t)RB * p.maxN;
-    unsigned target = 0;
-    if (threadIdx.x == 0) give_up = 0;
-
-    for (int l = p.l_lo; l < p.l_hi; ++l) {
+    {
+        const int l = p.layer;
         const MlpLayer& Ly = p.L[l];
         const int K = Ly.K, N = Ly.N;
         const MlpSave S = mf_save_at(RB, p.nlayers, p.L, l), Sp = mf_save_at(RB, p.nlayers, p.L, l > 0 ? l - 1 : 0);
@@ -228,36 +203,27 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
             __syncthreads();
         }
         if (Ly.bn && Ly.nbt && blockIdx.x == 0 && threadIdx.x == 0) *Ly.nbt += 1;
-        if (l + 1 < p.l_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && p.l_hi - p.l_lo > 1) {   // (a one-layer launch never touched the barrier)
-        const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Backward of the same MLP in ONE persistent launch (the generator iteration of wgan_gp.py:179-193: g_loss = -mean(D(G(z))),
+// Backward of the same MLP, one launch per phase (the generator iteration of wgan_gp.py:179-193: g_loss = -mean(D(G(z))),
 // g_loss.backward()): given dy = d(loss)/d(output) and the forward's save buffer,
 //   top        dz_L = dy (.) act'(y);   dpre_L = BatchNorm-backward(dz_L)                       (column-local: a workgroup owns all rows)
 //   l = L..2   dh_{l-1} = dpre_l W_l  (NN, K = N_l);  dz = dh (.) act'(h_{l-1});  dpre_{l-1} = BN-backward(dz)  (+ dgamma, dbeta)
 //   [l = 1     dx = dpre_1 W_1                                                                     when the input gradient is wanted]
 //   last       dW_l = dpre_l^T h_{l-1}  (TN, K = rows),  db_l = column sums of dpre_l              for every layer that wants them
 // BatchNorm1d backward (training mode): dpre = gamma invstd (dz - mean_rows dz - xhat mean_rows (dz xhat)).  Parameter
-// gradients are ADDED into the caller's buffers.  dpre_l is kept for the last phase with a row stride of N_l rounded up to 16
+// gradients are written into the caller's buffers (accum: added).  dpre_l is kept for the last phase with a row stride of N_l rounded up to 16
 // (zero padded), so a one-column top layer (the critic's output) is an ordinary K = 16 slice of zeros and one live column.
 struct MlpBwd {
     int B, RB, nlayers;
     const float *x, *y, *dy, *save;
     float *ws, *dx;
-    unsigned* sync;
+    int accum;          // 1: parameter gradients are added into gW / gb / ggamma / gbeta, 0: written
     MlpLayer L[MF_MAX_LAYERS];
     float *gW[MF_MAX_LAYERS], *gb[MF_MAX_LAYERS], *ggamma[MF_MAX_LAYERS], *gbeta[MF_MAX_LAYERS];
-    int ph_lo, ph_hi;   // phases of this launch: 0 = top, j = 1 .. NL the layer l = NL - j of the chain, NL + 1 = weight / bias gradients
+    int ph_lo, ph_hi;   // phase of this launch (ph_lo == ph_hi): 0 = top, j = 1 .. NL the layer l = NL - j of the chain, NL + 1 = weight / bias gradients
 };
 static __host__ __device__ inline size_t mf_dpre_off(int RB, int nlayers, const MlpLayer* L, int l) {
     size_t o = 0;
@@ -265,28 +231,47 @@ static __host__ __device__ inline size_t mf_dpre_off(int RB, int nlayers, const 
     return o;
 }
 
-// C[16][32] += A[16][k range] W[k][Nc] (NN): A rows have stride lda (zero padded to 16), W rows beyond R are not read
-__device__ __forceinline__ void mf_nn_partial(const float* __restrict__ ap, int R, const float* __restrict__ W, int Nc, int col,
-                                              int kbeg, int kend, int kq, f32x4& acc0, f32x4& acc1) {
+// C[16][32] += A[16][k range] W[k][Nc] (NN): A rows have stride lda (zero padded to 16), W rows beyond R are not read.  NB x 16 k values
+// per batch, all loads of a batch before its first MFMA.
+template <int NB>
+__device__ __forceinline__ void mf_nn_batch(const float* __restrict__ ap, int R, const float* __restrict__ W, int Nc, int col, int k0,
+                                            int kend, int kq, f32x4& acc0, f32x4& acc1) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + k0 + 4 * kq);
+    f32x4 a[NB];
+    f32x2 b[NB][4];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int kk = k0 + 16 * u + 4 * kq;                 // the slice ends on a multiple of 16: whole chunks are in or out
+        const bool in = k0 + 16 * u < kend;
+        a[u] = in ? *reinterpret_cast<const f32x4*>(ap + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = k0 + 4 * kq + s;
-            const f32x2 b = *reinterpret_cast<const f32x2*>(W + (size_t)(k < R ? k : R - 1) * Nc + col);
-            acc0 = mf_mfma(a[s], b[0], acc0);
-            acc1 = mf_mfma(a[s], b[1], acc1);
+            const int k = in ? kk + s : 0;
+            b[u][s] = *reinterpret_cast<const f32x2*>(W + (size_t)(k < R ? k : R - 1) * Nc + col);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);   // every load of the batch is issued before its first MFMA (one round trip, not NB)
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc0 = mf_mfma(a[u][s], b[u][s][0], acc0);
+            acc1 = mf_mfma(a[u][s], b[u][s][1], acc1);
+        }
+}
+__device__ __forceinline__ void mf_nn_partial(const float* __restrict__ ap, int R, const float* __restrict__ W, int Nc, int col,
+                                              int kbeg, int kend, int kq, f32x4& acc0, f32x4& acc1) {
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k0 = kbeg;
+    for (; k0 + 32 < kend; k0 += 64) mf_nn_batch<4>(ap, R, W, Nc, col, k0, kend, kq, acc0, acc1);   // > 32 left: a batch of 64
+    if (k0 + 16 < kend) mf_nn_batch<2>(ap, R, W, Nc, col, k0, kend, kq, acc0, acc1);
+    else if (k0 < kend) mf_nn_batch<1>(ap, R, W, Nc, col, k0, kend, kq, acc0, acc1);
 }
 
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd p) {
     __shared__ f32x4 part[2][(MF_WAVES - 1) * 64];
     __shared__ float red[2][4][32];
-    __shared__ int give_up;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, kq = lane >> 4;
     const int B = p.B, RB = p.RB, NL = p.nlayers;
@@ -296,8 +281,6 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
     const int rg = wave % RGW, ks = wave / RGW;
     const bool rows_live = rg < RG;
     const float invB = 1.f / (float)B;
-    unsigned target = 0;
-    if (threadIdx.x == 0) give_up = 0;
 
     // ---- top: dpre of the last layer from dy (16 columns x all rows per workgroup; only the ks == 0 waves work)
     if (p.ph_lo <= 0 && 0 <= p.ph_hi) {
@@ -351,8 +334,8 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                 if (Ly.bn) {
                     g = (Ly.gamma ? Ly.gamma[col] : 1.f) * p.save[S.invstd + col];
                     if (rg == 0 && kq == 0 && cok) {
-                        if (p.gbeta[l]) p.gbeta[l][col] += s1;
-                        if (p.ggamma[l]) p.ggamma[l][col] += s2;
+                        if (p.gbeta[l]) p.gbeta[l][col] = p.accum ? p.gbeta[l][col] + s1 : s1;
+                        if (p.ggamma[l]) p.ggamma[l][col] = p.accum ? p.ggamma[l][col] + s2 : s2;
                     }
                 }
 #pragma unroll
@@ -365,7 +348,6 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             __syncthreads();
         }
     }
-    if (p.ph_lo <= 0 && 1 <= p.ph_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
 
     // ---- l = L-1 .. 1: dpre_{l-1} from dpre_l;  l = 0: dx (when wanted)
     for (int l = NL - 1; l >= 0; --l) {
@@ -451,8 +433,8 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                     for (int e = 0; e < 2; ++e) {
                         g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[So.invstd + col + e];
                         if (rg == 0 && kq == 0) {
-                            if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] += s1[e];
-                            if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] += s2[e];
+                            if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] = p.accum ? p.gbeta[l - 1][col + e] + s1[e] : s1[e];
+                            if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] = p.accum ? p.ggamma[l - 1][col + e] + s2[e] : s2[e];
                         }
                     }
                 }
@@ -475,11 +457,6 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             }
             __syncthreads();
         }
-        const bool more = l > 1 || (l == 1 && p.dx != nullptr);
-        bool any_grad = false;
-        for (int q = 0; q < NL; ++q) any_grad = any_grad || p.gW[q] != nullptr || p.gb[q] != nullptr;
-        // (the phase behind this one - the next layer of the chain, or the gradients - runs in this launch too: barrier)
-        if ((more || any_grad) && (more ? ph + 1 : NL + 1) <= p.ph_hi && !mf_grid_barrier(p.sync, target, &give_up)) return;
     }
 
     // ---- last: weight / bias gradients, one 16 (n) x 64 (k) tile per wave
@@ -504,22 +481,28 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
                 float colsum = 0.f;
-                for (int m0 = 0; m0 < RB; m0 += 16) {
-                    float a[4];
-                    f32x4 b[4];
+                for (int c0 = 0; c0 * 16 < RB; c0 += 2) {   // two 16-row chunks per batch of loads (<= 2 rounds; 128 registers per lane at 16 waves)
+                    float a[2][4];
+                    f32x4 b[2][4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int m = m0 + 4 * s + kq;
-                        const int mc = m < B ? m : B - 1;
-                        a[s] = m < B ? dprel[(size_t)m * ld + n0 + rr] : 0.f;
-                        b[s] = kok ? *reinterpret_cast<const f32x4*>(hin + (size_t)mc * K + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        colsum += a[s];
+                        for (int s = 0; s < 4; ++s) {
+                            const int m = (c0 + c) * 16 + 4 * s + kq;
+                            const int mc = m < B ? m : B - 1;
+                            const bool live = (c0 + c) * 16 < RB;
+                            a[c][s] = (live && m < B) ? dprel[(size_t)mc * ld + n0 + rr] : 0.f;
+                            b[c][s] = (live && kok) ? *reinterpret_cast<const f32x4*>(hin + (size_t)mc * K + kc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[e] = mf_mfma(a[s], b[s][e], acc[e]);
-                    }
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            colsum += a[c][s];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[e] = mf_mfma(a[c][s], b[c][s][e], acc[e]);
+                        }
                 }
                 if (p.gW[l] && kok) {
 #pragma unroll
@@ -528,7 +511,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                         if (n < N) {
                             float* o = p.gW[l] + (size_t)n * K + kc;
                             f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                            v += *reinterpret_cast<const f32x4*>(o);
+                            if (p.accum) v += *reinterpret_cast<const f32x4*>(o);
                             *reinterpret_cast<f32x4*>(o) = v;
                         }
                     }
@@ -536,26 +519,14 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
                 if (kt == 0 && p.gb[l]) {  // wave-uniform
                     colsum += __shfl_xor(colsum, 16);
                     colsum += __shfl_xor(colsum, 32);
-                    if (kq == 0 && n0 + rr < N) p.gb[l][n0 + rr] += colsum;
+                    if (kq == 0 && n0 + rr < N) p.gb[l][n0 + rr] = p.accum ? p.gb[l][n0 + rr] + colsum : colsum;
                 }
             }
             base += ntl;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && p.ph_hi > p.ph_lo) {
-        const unsigned t = __hip_atomic_fetch_add(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
-static bool mf_persist() {
-    static const int v = getenv("MIGAN_K7_PERSIST") ? atoi(getenv("MIGAN_K7_PERSIST")) : 0;
-    return v != 0;
-}
 static bool mf_fill_layers(MlpLayer* L, int nlayers, const int* dims, const float* fpar, void* const* ptrs) {
     for (int l = 0; l < nlayers; ++l) {
         MlpLayer& Y = L[l];
@@ -568,14 +539,6 @@ static bool mf_fill_layers(MlpLayer* L, int nlayers, const int* dims, const floa
     }
     return true;
 }
-static int mf_grid(int grid, int tiles) {
-    static const int grid_env = getenv("MIGAN_K7_GRID") ? atoi(getenv("MIGAN_K7_GRID")) : 0;
-    int g = grid > 0 ? grid : (grid_env > 0 ? grid_env : tiles);
-    if (g > tiles) g = tiles;
-    if (g > 128) g = 128;
-    return g < 1 ? 1 : g;
-}
-
 // dims: K, N, has_bn, act per layer;  fpar: slope, eps, momentum per layer;  ptrs: W, b, gamma, beta, running_mean, running_var,
 // num_batches_tracked per layer (device pointers in a HOST array; NULL where absent).  Returns 1 when the kernels take the shape:
 // B <= 64, <= 8 layers, K % 4 == 0; N % 32 == 0 for every layer but the last (whose N is free: a critic's single output).
@@ -614,78 +577,63 @@ MIGAN_API size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* di
     mf_dims_to_layers(L, nlayers, dims);
     return (mf_dpre_off((B + 15) / 16 * 16, nlayers, L, nlayers) + 16) * sizeof(float);
 }
-// y[B][N_last] = MLP(x[B][K_0]), BatchNorm1d layers in training mode (batch statistics; running statistics and counters updated).
-// ws: migan_mlp_fused_workspace(.., save) bytes; sync: 4 unsigned ints zeroed once (sync[2] != 0 afterwards: the grid barrier gave up).
+// y[B][N_last] = MLP(x[B][K_0]), BatchNorm1d layers in training mode (batch statistics; running statistics and counters updated): one
+// launch per layer on `stream`.  ws: migan_mlp_fused_workspace(.., save) bytes.  only: 0 = every layer; 1 + l = layer l alone on whatever
+// the workspace holds (timing harness, tools/abi_check.cpp).
 MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar,
-                                  void* const* ptrs, float* ws, size_t ws_bytes, int save, unsigned* sync, int grid, void* stream) {
+                                  void* const* ptrs, float* ws, size_t ws_bytes, int save, int only, void* stream) {
     if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_workspace(B, nlayers, dims, save)) return (int)hipErrorInvalidValue;
+    if (only < 0 || only > nlayers) return (int)hipErrorInvalidValue;
     MlpFused p;
     p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers; p.maxN = 0; p.saving = save != 0;
-    p.x = x; p.y = y; p.ws = ws; p.sync = sync;
+    p.x = x; p.y = y; p.ws = ws;
     if (!mf_fill_layers(p.L, nlayers, dims, fpar, ptrs)) return (int)hipErrorInvalidValue;
-    int tiles = 0;
+    for (int l = 0; l < nlayers; ++l) p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
     for (int l = 0; l < nlayers; ++l) {
-        p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
-        tiles = (p.L[l].N + 15) / 16 > tiles ? (p.L[l].N + 15) / 16 : tiles;
-    }
-    // Measured on the MI355X (profiles/r03_abi_check.txt): the ONE persistent launch of the 5-layer generator takes 63 us - a grid
-    // barrier's agent-scope release / acquire writes back and invalidates the L2, so every layer re-fetches its weights (~12-20 us per
-    // layer) - while a small dependent launch costs ~5-6 us.  Default: the same kernel once per layer, no barrier, no residency
-    // requirement.  MIGAN_K7_PERSIST=1 = the single persistent launch.
-    if (mf_persist()) {
-        p.l_lo = 0;
-        p.l_hi = nlayers;
-        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
-        HIP_LAUNCH_CHECK();
-        return 0;
-    }
-    const int only = grid >= 1000 ? grid - 1000 : -1;   // grid = 1000 + l: layer l alone (timing harness, tools/abi_check.cpp)
-    if (only >= 0) grid = 0;
-    for (int l = 0; l < nlayers; ++l) {
-        if (only >= 0 && l != only) continue;
-        p.l_lo = l;
-        p.l_hi = l + 1;
-        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        if (only && l != only - 1) continue;
+        p.layer = l;
+        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3((p.L[l].N + 15) / 16), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;
 }
-// Backward of migan_mlp_fused_fwd(.., save = 1): dy [B][N_last] -> parameter gradients ADDED into gptrs[4*l] = {dW [N][K], db [N],
-// dgamma, dbeta} (device pointers in a host array, NULL = not wanted) and, when dx != NULL, dx [B][K_0] (needs K_0 % 32 == 0).
-// save: the forward's ws; y: the forward's output; ws: migan_mlp_fused_bwd_workspace() bytes.
+// Backward of migan_mlp_fused_fwd(.., save = 1): dy [B][N_last] -> parameter gradients written into (accumulate != 0: added to)
+// gptrs[4*l] = {dW [N][K], db [N], dgamma, dbeta} (device pointers in a host array, NULL = not wanted) and, when dx != NULL, dx [B][K_0]
+// (needs K_0 % 32 == 0).  save: the forward's ws; y: the forward's output; ws: migan_mlp_fused_bwd_workspace() bytes.  One launch per
+// phase: top, the chain l = NL-1 .. 1 (.. 0 when dx is wanted), the gradients.  only: 0 = every phase; 1 + ph = phase ph alone.
 MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* dy, const float* save, float* dx, int B, int nlayers,
                                   const int* dims, const float* fpar, void* const* ptrs, void* const* gptrs, float* ws,
-                                  size_t ws_bytes, unsigned* sync, int grid, void* stream) {
+                                  size_t ws_bytes, int accumulate, int only, void* stream) {
     if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_bwd_workspace(B, nlayers, dims)) return (int)hipErrorInvalidValue;
     if (dx && dims[0] % 32 != 0) return (int)hipErrorInvalidValue;
+    if (only < 0 || only > nlayers + 2) return (int)hipErrorInvalidValue;
     MlpBwd p;
-    p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers;
-    p.x = x; p.y = y; p.dy = dy; p.save = save; p.ws = ws; p.dx = dx; p.sync = sync;
+    p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers; p.accum = accumulate != 0;
+    p.x = x; p.y = y; p.dy = dy; p.save = save; p.ws = ws; p.dx = dx;
     if (!mf_fill_layers(p.L, nlayers, dims, fpar, ptrs)) return (int)hipErrorInvalidValue;
-    int tiles = 1;
+    int wave_tiles = 0;   // 16 x 64 wave tiles of the gradient phase
+    bool any_grad = false;
     for (int l = 0; l < MF_MAX_LAYERS; ++l) {
         p.gW[l] = p.gb[l] = p.ggamma[l] = p.gbeta[l] = nullptr;
         if (l < nlayers) {
             p.gW[l] = (float*)gptrs[4 * l]; p.gb[l] = (float*)gptrs[4 * l + 1];
             p.ggamma[l] = (float*)gptrs[4 * l + 2]; p.gbeta[l] = (float*)gptrs[4 * l + 3];
-            tiles = p.L[l].K / 32 > tiles ? p.L[l].K / 32 : tiles;
+            if (p.gW[l] || p.gb[l]) {
+                any_grad = true;
+                wave_tiles += (p.L[l].N + 15) / 16 * ((p.L[l].K + 63) / 64);
+            }
         }
     }
-    bool any_grad = false;
-    for (int l = 0; l < nlayers; ++l) any_grad = any_grad || p.gW[l] != nullptr || p.gb[l] != nullptr;
-    if (mf_persist()) {
-        p.ph_lo = 0;
-        p.ph_hi = nlayers + 1;
-        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
-        HIP_LAUNCH_CHECK();
-        return 0;
-    }
-    // one launch per phase (see migan_mlp_fused_fwd): top, the chain l = NL-1 .. 1 (.. 0 when dx is wanted), the gradients
     for (int ph = 0; ph <= nlayers + 1; ++ph) {
         if (ph == nlayers && !dx) continue;          // l = 0 computes only dx
         if (ph == nlayers + 1 && !any_grad) continue;
+        if (only && ph != only - 1) continue;
         p.ph_lo = p.ph_hi = ph;
-        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(mf_grid(grid, tiles)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        int grid;
+        if (ph == 0) grid = (p.L[nlayers - 1].N + 15) / 16;
+        else if (ph <= nlayers) grid = p.L[nlayers - ph].K / 32;
+        else grid = (wave_tiles + MF_WAVES - 1) / MF_WAVES;   // one wave tile per wave
+        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(grid < 1 ? 1 : grid), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;

@@ -114,6 +114,15 @@ class Adam:
             if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
+    def attach_grads(self):
+        """zero_grad() without the fill: every `p.grad` is (again) its view of the bucket.  For callers whose backward WRITES every
+        gradient of this optimiser (the fused WGAN-GP kernels, steps.wgan_gp_step) - zeroing first would be a dead store."""
+        self.wait_pending()
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
+
     def step(self, grad_scale=1.0):
         for p, o, ptr in zip(self.params, self.offsets, self._ptrs):
             if p.data_ptr() != ptr:

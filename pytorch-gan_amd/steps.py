@@ -216,8 +216,6 @@ class _CriticFusedPlan:
         self.lambda_gp = float(s.lambda_gp)
         self.ws_bytes = lib.migan_critic_fused_workspace(B, *self.dims)
         self.ws = torch.empty(self.ws_bytes // 4, device=dev, dtype=torch.float32)
-        self.sync = torch.zeros(4, device=dev, dtype=torch.int32)
-        self.out = torch.zeros(4, device=dev, dtype=torch.float32)
         self.ok = True
 
     def usable(self, real, fake):
@@ -225,16 +223,16 @@ class _CriticFusedPlan:
             and real.dtype == fake.dtype == torch.float32
 
     def run(self, real, fake, alpha, grads):
-        """One launch: the gradient of d_loss is ADDED into `grads` (six contiguous tensors); -> (d_loss, gp)."""
+        """Six launches: the gradient of d_loss is WRITTEN into `grads` (six contiguous tensors); -> (d_loss, gp)."""
         from ._lib import check, lib
 
         a = alpha.reshape(self.B).contiguous()
         w = [p.detach() for p in self.params]
+        o = torch.empty(4, device=real.device, dtype=torch.float32)   # a fresh slot per call: callers keep their losses
         check(lib.migan_critic_fused(real.data_ptr(), fake.data_ptr(), a.data_ptr(), *[t.data_ptr() for t in w],
-                                     *[g.data_ptr() for g in grads], self.out.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
-                                     self.sync.data_ptr(), self.B, *self.dims, self.slope, self.lambda_gp, 0,
+                                     *[g.data_ptr() for g in grads], o.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                     self.B, *self.dims, self.slope, self.lambda_gp, 0, 0,
                                      torch.cuda.current_stream().cuda_stream), "critic_fused")
-        o = self.out.clone()   # the kernel's output slot is overwritten by the next iteration; callers keep their losses
         return o[0], o[1]
 
 
@@ -279,7 +277,6 @@ class _GeneratorFusedPlan:
         self.B, self.n, self.groups, self.shape, self.G = B, n, groups, tuple(shape), G
         self.ws_bytes = lib.migan_mlp_fused_workspace(B, n, self.dims, 0)
         self.ws = torch.empty(self.ws_bytes // 4, device=z.device, dtype=torch.float32)
-        self.sync = torch.zeros(4, device=z.device, dtype=torch.int32)
         self.save = self.bws = None   # buffers of the differentiated form, made on first use
         self.ok = True
 
@@ -303,12 +300,12 @@ class _GeneratorFusedPlan:
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         y = torch.empty(self.B, self.groups[-1][0].out_features, device=x.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(x.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.save.data_ptr(),
-                                      self.save_bytes, 1, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+                                      self.save_bytes, 1, 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y
 
-    def backward(self, x, y, dy, grads=None, want_dx=False):
-        """One launch: parameter gradients ADDED into `grads` (per group [dW, db, dgamma, dbeta], None = not wanted) and / or
-        the input gradient (returned) of the forward_saved() call that produced y."""
+    def backward(self, x, y, dy, grads=None, want_dx=False, accumulate=False):
+        """One launch per phase: parameter gradients written into (accumulate: added to) `grads` (per group [dW, db, dgamma, dbeta],
+        None = not wanted) and / or the input gradient (returned) of the forward_saved() call that produced y."""
         import ctypes
 
         from ._lib import check, lib
@@ -320,7 +317,7 @@ class _GeneratorFusedPlan:
         dx = torch.empty_like(x) if want_dx else None
         check(lib.migan_mlp_fused_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), self.save.data_ptr(), None if dx is None else dx.data_ptr(),
                                       self.B, self.n, self.dims, self.fpar, ptrs, gptrs, self.bws.data_ptr(), self.bws_bytes,
-                                      self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_bwd")
+                                      int(bool(accumulate)), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_bwd")
         return dx
 
     def param_grads(self):
@@ -358,7 +355,7 @@ class _GeneratorFusedPlan:
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(z.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.ws.data_ptr(),
-                                      self.ws_bytes, 0, self.sync.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+                                      self.ws_bytes, 0, 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y.view(self.B, *self.shape)
 
 
@@ -388,12 +385,18 @@ def _generator_iteration_plans(s, z):
         dpn = s._k7_dmlp_plan = _GeneratorFusedPlan(s.D, probe, out_shape=(1,))
         if dpn.ok and (dpn.groups[-1][0].out_features != 1 or any(bn is not None for _, bn, _, _ in dpn.groups) or nin % 32 != 0):
             dpn.ok = False
-    return (gp, dpn) if dpn.ok else None
+    if not dpn.ok:
+        return None
+    if not hasattr(gp, "_covers_opt"):   # the fused backward WRITES gradients: it must own every parameter of the generator's optimiser
+        mine = {id(t) for lin, bn, _, _ in gp.groups for t in ((lin.weight, lin.bias) + ((bn.weight, bn.bias) if bn is not None else ()))
+                if t is not None}
+        gp._covers_opt = mine == {id(q) for q in s.opt_G.params}
+    return (gp, dpn) if gp._covers_opt else None
 
 
 def _fused_generator_pass(gp, dpn, z, buffers, grads):
-    """generator(z) -> frozen critic -> g_loss = -mean(validity) -> gradients of the generator's parameters ADDED into `grads`:
-    four persistent launches (two forwards that keep their activations, two backwards) + the mean."""
+    """generator(z) -> frozen critic -> g_loss = -mean(validity) -> gradients of the generator's parameters WRITTEN into `grads`:
+    two forwards that keep their activations, two backwards (one launch per layer / phase) + the mean."""
     B = gp.B
     fake = gp.forward_saved(z, buffers)
     val = dpn.forward_saved(fake)
@@ -428,7 +431,6 @@ def _critic_plan(s, real, fake):
 def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0."""
     s.dp.begin_step()
-    s.opt_D.zero_grad()
     if s.skip:
         with torch.no_grad():  # G grads from d_loss are discarded at wgan_gp.py:176
             fake_imgs = _generator_nograd(s, z)
@@ -437,10 +439,16 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
     plan = _critic_plan(s, real_imgs, fake_imgs) if (_k7() and s.skip) else None
     if plan is not None and alpha is None:  # the host draw of wgan_gp.py:122, where the reference makes it
         alpha = _dev(np.random.random((real_imgs.shape[0], 1, 1, 1)), real_imgs.device)
+    if plan is not None:
+        s.opt_D.attach_grads()   # optimizer_D.zero_grad() of wgan_gp.py:157 without the fill: the fused kernels WRITE every gradient
+    else:
+        s.opt_D.zero_grad()
     grads = [p.grad for p in plan.params] if plan is not None else []
     if plan is not None and all(g is not None and g.is_contiguous() for g in grads):
         d_loss, gp = plan.run(real_imgs, fake_imgs, alpha, grads)
     else:
+        if plan is not None:
+            s.opt_D.zero_grad()
         real_v = s.D(real_imgs)
         fake_v = s.D(fake_imgs)
         gp = compute_gradient_penalty(s.D, real_imgs.data, fake_imgs.data, alpha)
@@ -448,12 +456,18 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None):
         d_loss = F.axpby(F.axpby(F.mean(fake_v), F.mean(real_v), 1.0, -1.0), gp, 1.0, s.lambda_gp)
         _backward(d_loss)
     s.dp.step(s.opt_D)
-    s.opt_G.zero_grad()
     out = {"d_loss": d_loss.detach(), "gp": gp.detach()}
+    gen_fused = _k7() and s.skip and _generator_iteration_plans(s, z) is not None
+    if gen_fused:
+        s.opt_G.attach_grads()   # optimizer_G.zero_grad() of wgan_gp.py:178: the fused generator backward writes every gradient
+    else:
+        s.opt_G.zero_grad()
     if i % s.n_critic == 0:
         s.dp.wait(s.opt_D)  # the generator step reads the critic that was just updated (wgan_gp.py:186)
-        g_loss = _generator_iteration_fused(s, z) if (_k7() and s.skip) else None
+        g_loss = _generator_iteration_fused(s, z) if gen_fused else None
         if g_loss is None:
+            if gen_fused:
+                s.opt_G.zero_grad()
             fake_imgs = s.G(z)
             with frozen(s.D, enabled=s.skip):
                 g_loss = F.axpby(F.mean(s.D(fake_imgs)), None, -1.0, 0.0)
@@ -525,8 +539,10 @@ class WganGpRunner:
         dev = next(s.G.parameters()).device
         self.s = s
         self.real = torch.zeros(batch, *img_shape, device=dev)
-        self.z = torch.zeros(batch, s.latent_dim, device=dev)
-        self.alpha = torch.zeros(batch, 1, 1, 1, device=dev)
+        # z and alpha share ONE staging buffer, so a caller that keeps its draws packed [z | alpha] feeds an iteration with one copy
+        self.inp = torch.zeros(batch * s.latent_dim + batch, device=dev)
+        self.z = self.inp[:batch * s.latent_dim].view(batch, s.latent_dim)
+        self.alpha = self.inp[batch * s.latent_dim:].view(batch, 1, 1, 1)
         self.runners = {
             True: StepRunner(lambda: wgan_gp_step(s, self.real, 0, self.z, self.alpha), s.dp, use_graph, warmup),
             False: StepRunner(lambda: wgan_gp_step(s, self.real, 1, self.z, self.alpha), s.dp, use_graph, warmup),
@@ -546,15 +562,19 @@ class WganGpRunner:
     def capture_error(self):
         return next((r.capture_error for r in self.runners.values() if r.capture_error), None)
 
-    def _load(self, real, z, alpha):
+    def _load(self, real, z, alpha, packed=None):
         if real is not None:
             self.real.copy_(real)
-        self.z.copy_(z)
-        self.alpha.copy_(alpha.reshape(self.alpha.shape))
+        if packed is not None:
+            self.inp.copy_(packed.reshape(self.inp.shape))
+        else:
+            self.z.copy_(z)
+            self.alpha.copy_(alpha.reshape(self.alpha.shape))
 
-    def run(self, i, real, z, alpha):
-        """Iteration i on (real, z, alpha); pass real=None to keep the batch already in the static buffer."""
-        self._load(real, z, alpha)
+    def run(self, i, real, z, alpha, packed=None):
+        """Iteration i on (real, z, alpha); pass real=None to keep the batch already in the static buffer; `packed` = the flat
+        [z | alpha] of this iteration (batch * latent + batch floats) instead of z and alpha."""
+        self._load(real, z, alpha, packed)
         return self.runners[i % self.s.n_critic == 0].run()
 
 

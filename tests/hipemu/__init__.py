@@ -23,7 +23,6 @@ def load(only=None):
     # persistent kernels run one OS thread per workgroup in the model: keep their grids small.  Set HERE (the emulation library
     # reads it once, at its first persistent launch) and not at import: pytest imports this package while COLLECTING on the GPU
     # box too, where the real library must keep its default grid.
-    os.environ.setdefault("MIGAN_K7_GRID", "8")
     path = build_emu.build(only=only)
     lib = ctypes.CDLL(path)
     from pytorch_gan_amd import _lib as product
@@ -41,9 +40,6 @@ def load(only=None):
     lib.hipemu_set_threads.argtypes = [ctypes.c_int]
     lib.hipemu_launch_count.argtypes = [ctypes.c_char_p]
     lib.hipemu_add_coresident_kernel.argtypes = [ctypes.c_char_p]
-    lib.hipemu_add_coresident_kernel(b"critic_fused_kernel")   # grid-wide barriers: all workgroups alive at once
-    lib.hipemu_add_coresident_kernel(b"mlp_fused_fwd_kernel")
-    lib.hipemu_add_coresident_kernel(b"mlp_fused_bwd_kernel")
     lib.hipemu_launch_count.restype = ctypes.c_long
     lib.hipemu_set_wave_schedule.argtypes = [ctypes.c_int, ctypes.c_uint]
     # HIPEMU_SCHED = fwd | rev | rand[:seed]: the order in which a workgroup's waves run between synchronisation points

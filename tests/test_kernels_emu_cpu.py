@@ -261,11 +261,10 @@ def _critic_reference(real, fake, alpha, params, lam, slope):
     return [float(d_loss), float(gp), float(rv.mean()), float(fv.mean())], [p.grad for p in ps]
 
 
-@pytest.mark.parametrize("B,dims,grid", [(64, (1024, 512, 256), 8), (8, (1024, 512, 256), 3), (33, (256, 128, 128), 1), (1, (128, 256, 128), 5)])
-def test_persistent_critic_kernel_against_autograd(emu, B, dims, grid):
-    """K7 (csrc/critic_fused.hip) through the C ABI: seven phases, six grid-wide barriers, workgroups on their own OS threads;
-    losses and all six parameter gradients against torch's double backward; launched three times (the barrier re-arms itself,
-    gradients accumulate)."""
+@pytest.mark.parametrize("B,dims", [(64, (1024, 512, 256)), (8, (1024, 512, 256)), (33, (256, 128, 128)), (1, (128, 256, 128)), (17, (384, 128, 256))])
+def test_fused_critic_kernels_against_autograd(emu, B, dims):
+    """K7 (csrc/critic_fused.hip) through the C ABI: six launches; losses and all six parameter gradients against torch's double
+    backward; gradients written (first call, into NaN-filled buffers) and accumulated (two more calls)."""
     Din, H1, H2 = dims
     g = torch.Generator().manual_seed(B)
     real = torch.rand(B, Din, generator=g) * 2 - 1
@@ -278,16 +277,14 @@ def test_persistent_critic_kernel_against_autograd(emu, B, dims, grid):
 
     params = [*lin(H1, Din), *lin(H2, H1), *lin(1, H2)]
     want, gref = _critic_reference(real, fake, alpha, params, 10.0, 0.2)
-    grads = [torch.zeros_like(t) for t in params]
+    grads = [torch.full_like(t, float("nan")) for t in params]   # the first call WRITES every gradient
     out = torch.zeros(4)
     wsb = emu.migan_critic_fused_workspace(B, Din, H1, H2)
     ws = torch.full((wsb // 4,), float("nan"))
-    sync = torch.zeros(4, dtype=torch.int32)
     for rep in range(3):
         rc = emu.migan_critic_fused(_ptr(real), _ptr(fake), _ptr(alpha), *[_ptr(t) for t in params], *[_ptr(t) for t in grads],
-                                    _ptr(out), _ptr(ws), wsb, _ptr(sync), B, Din, H1, H2, 0.2, 10.0, grid, None)
+                                    _ptr(out), _ptr(ws), wsb, B, Din, H1, H2, 0.2, 10.0, int(rep > 0), 0, None)
         assert rc == 0, emu.hipemu_last_message()
-        assert sync.tolist() == [0, 0, 0, 0]
         for a, b in zip(out.tolist(), want):
             assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (out.tolist(), want)
         for got, ref in zip(grads, gref):
@@ -297,8 +294,8 @@ def test_persistent_critic_kernel_against_autograd(emu, B, dims, grid):
                 assert float(got.abs().max()) == 0.0     # b3: -1 + 1
 
 
-@pytest.mark.parametrize("B,img_shape,grid", [(64, (1, 32, 32), 8), (8, (1, 32, 32), 3), (33, (1, 28, 28), 1), (2, (3, 16, 16), 5)])
-def test_persistent_generator_forward_against_torch(emu, B, img_shape, grid):
+@pytest.mark.parametrize("B,img_shape", [(64, (1, 32, 32)), (8, (1, 32, 32)), (33, (1, 28, 28)), (2, (3, 16, 16))])
+def test_fused_generator_forward_against_torch(emu, B, img_shape):
     """csrc/mlp_fused.hip through the C ABI against the oracle's MlpGenerator in training mode: output, BatchNorm1d running
     statistics (momentum, unbiased variance) and num_batches_tracked; K = 100 (a K tail), N = 784 (49 column tiles)."""
     import copy
@@ -344,10 +341,8 @@ def test_persistent_generator_forward_against_torch(emu, B, img_shape, grid):
     assert emu.migan_mlp_fused_ok(B, n, dims)
     wsb = emu.migan_mlp_fused_workspace(B, n, dims, 0)
     ws = torch.full((wsb // 4,), float("nan"))
-    sync = torch.zeros(4, dtype=torch.int32)
     y = torch.empty(B, groups[-1][0].out_features)
-    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, 0, _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
-    assert sync.tolist() == [0, 0, 0, 0]
+    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, 0, 0, None) == 0, emu.hipemu_last_message()
     assert _rel(y, want) <= 3e-6
     for a, b in zip(G2.buffers(), G.buffers()):
         assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
@@ -371,10 +366,10 @@ def _mlp_groups(seq):
     return groups
 
 
-@pytest.mark.parametrize("which,B,grid", [("generator", 64, 8), ("generator", 8, 3), ("critic", 64, 5), ("critic", 33, 1)])
-def test_persistent_mlp_backward_against_autograd(emu, which, B, grid):
-    """csrc/mlp_fused.hip, the pair a generator iteration is made of: forward that keeps its activations + backward in one launch
-    each.  generator: Linear / BatchNorm1d (training) / LeakyReLU / Tanh of wgan_gp.py:42-65, all parameter gradients incl.
+@pytest.mark.parametrize("which,B", [("generator", 64), ("generator", 8), ("critic", 64), ("critic", 33)])
+def test_fused_mlp_backward_against_autograd(emu, which, B):
+    """csrc/mlp_fused.hip, the pair a generator iteration is made of: forward that keeps its activations + backward (one launch per
+    layer / phase), gradients written into NaN-filled buffers.  generator: Linear / BatchNorm1d (training) / LeakyReLU / Tanh of wgan_gp.py:42-65, all parameter gradients incl.
     dgamma / dbeta;  critic: wgan_gp.py:68-83 with its single output column, parameter gradients and the input gradient."""
     import copy
     import ctypes
@@ -403,7 +398,8 @@ def test_persistent_mlp_backward_against_autograd(emu, which, B, grid):
     for l, bn, a, s in groups:
         plist += [_ptr(l.weight), _ptr(l.bias)]
         plist += [_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)] if bn else [None] * 5
-        g = [torch.zeros_like(l.weight), torch.zeros_like(l.bias)] + ([torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)] if bn else [None, None])
+        g = [torch.full_like(l.weight, float("nan")), torch.full_like(l.bias, float("nan"))] + \
+            ([torch.full_like(bn.weight, float("nan")), torch.full_like(bn.bias, float("nan"))] if bn else [None, None])
         gts.append(g)
         glist += [_ptr(q) for q in g]
     ptrs, gptrs = (ctypes.c_void_p * len(plist))(*plist), (ctypes.c_void_p * len(glist))(*glist)
@@ -411,13 +407,11 @@ def test_persistent_mlp_backward_against_autograd(emu, which, B, grid):
     save = torch.full((wsb // 4,), float("nan"))
     bwb = emu.migan_mlp_fused_bwd_workspace(B, n, dims)
     bws = torch.full((bwb // 4,), float("nan"))
-    sync = torch.zeros(4, dtype=torch.int32)
     y = torch.empty(B, groups[-1][0].out_features)
     dx = torch.full_like(x, float("nan")) if want_dx else None
-    assert emu.migan_mlp_fused_fwd(_ptr(x), _ptr(y), B, n, dims, fpar, ptrs, _ptr(save), wsb, 1, _ptr(sync), grid, None) == 0
+    assert emu.migan_mlp_fused_fwd(_ptr(x), _ptr(y), B, n, dims, fpar, ptrs, _ptr(save), wsb, 1, 0, None) == 0
     assert emu.migan_mlp_fused_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(save), _ptr(dx), B, n, dims, fpar, ptrs, gptrs, _ptr(bws), bwb,
-                                   _ptr(sync), grid, None) == 0, emu.hipemu_last_message()
-    assert sync.tolist() == [0, 0, 0, 0]
+                                   0, 0, None) == 0, emu.hipemu_last_message()
     assert _rel(y, yr.detach()) <= 3e-6
     if want_dx:
         assert _rel(dx, xr.grad) <= 5e-6
@@ -456,6 +450,7 @@ STEP_BODIES = [
     ("test_dcgan_steps", (True,)),            # dcgan.py:143-183, 3 steps: paired D pass, chained BatchNorm statistics, dropout masks
     ("test_wgan_gp_steps", (False,)),         # wgan_gp.py:119-193, 6 critic iterations: double backward through the skinny GEMMs
     ("test_wgan_gp_steps", (True,)),          # ... and on the fused WGAN-GP kernels (K7)
+    ("test_fused_wgan_gp_kernels_serve_the_baseline_batch", ()),   # batch 64: launch counters + fused vs op-by-op vs oracle
     ("test_dragan_steps", ()),                # dragan.py:176-217: conv-critic gradient penalty
     ("test_srgan_step", ()),                  # srgan.py:97-145: PixelShuffle epilogue, VGG features, Toeplitz 9x9
     ("test_pix2pix_step", ()),                # pix2pix.py:123-172 at 256x256: split-K, ConvTranspose, PatchGAN head, 4-8 M-element weights
@@ -468,8 +463,8 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
     Adam, BatchNorm buffers - computed by the HIP kernels' source running on the host."""
     lib = _run_gpu_test_body("test_steps_gpu", name, *args)
     if name == "test_wgan_gp_steps":  # six fused iterations
-        # (each call of the critic kernel = seven one-phase launches: the measured-faster form, csrc/critic_fused.hip)
-        assert lib.hipemu_launch_count(b"critic_fused_kernel") == (6 * 7 if args[0] else 0)
+        # (each critic iteration = six launches, csrc/critic_fused.hip)
+        assert lib.hipemu_launch_count(b"critic_fused_p") == (6 * 6 if args[0] else 0)
         # 6 no_grad forwards + the fused generator iterations 0 and 5 (2 saving forwards each)
         # one launch per layer: generator 5, critic-as-MLP 3 -> 6 * 5 + 2 * (5 + 3); backward: critic (top + 3 chain phases, dx) 4 +
         # generator (top + 4 chain phases + gradients) 6, twice
@@ -594,7 +589,7 @@ def test_abi_check_harness_on_the_execution_model(emu, tmp_path):
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
     sections = ["norm", "mlp"] + (["critic"] if os.environ.get("MIGAN_EMU_SLOW") == "1" else [])
     for sec in sections:
-        r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900, env=dict(os.environ, MIGAN_K7_GRID="8"))
+        r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK") and "FAIL" not in r.stdout, (sec, r.stdout[-1500:], r.stderr[-400:])
 
 
