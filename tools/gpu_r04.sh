@@ -134,8 +134,31 @@ task_second() {
   task_pmcstep srgan 1 sq fetch write
 }
 
+task_third() {
+  local O=gpurun_out/r4c; mkdir -p $O
+  for s in floor critic mlp; do timeout 120 ./tools/abi_check.bin $s >> $O/abi_check.txt 2>&1; done
+  grep -v "^migan" $O/abi_check.txt | cut -c1-220
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_ops_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan or adam or splitk or upconv or bias_grad or critic" --durations=5 > $O/pytest.txt 2>&1
+  tail -5 $O/pytest.txt
+  for k7 in 1 0; do
+    echo "== wgan_gp MIGAN_K7=$k7" >> $O/bench.txt
+    MIGAN_K7=$k7 timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline 2>>$O/bench.err | cut -c1-400 >> $O/bench.txt
+  done
+  cat $O/bench.txt
+  task_prof r4c wgan_gp:graph
+  timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+  echo "bench rc=$?"; python - <<'PY'
+import json
+r=json.loads(open('gpurun_out/r4c/bench_default.json').read().strip().splitlines()[-1])
+print({k:r[k] for k in ('value','ms_per_step')})
+rf=r['roofline']; print({k:rf.get(k) for k in ('kernel','frac','traffic','mfma_busy_frac','symbol','avg_launch_ms')})
+for k,v in r['extra'].items(): print(k, {a:v.get(a) for a in ('images_per_s','ms_per_step','error')})
+PY
+}
+
 t=${1:-}; shift || true
 case "$t" in
+  third) task_third "$@" ;;
   second) task_second "$@" ;;
   pmcstep) task_pmcstep "$@" ;;
   hang) task_hang "$@" ;;
