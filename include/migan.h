@@ -127,11 +127,13 @@ int migan_critic_fused(const float* real, const float* fake, const float* alpha,
  * (training mode: batch statistics, running statistics and num_batches_tracked updated) + LeakyReLU / Tanh = 14 launches.
  * Host arrays: dims[4*l] = {K, N, has_bn, act code}, fpar[3*l] = {slope, eps, momentum}, ptrs[7*l] = DEVICE pointers {W [N][K], b,
  * gamma, beta, running_mean, running_var, num_batches_tracked (int64)}, NULL where absent.  B <= 64, K % 4 == 0, N % 16 == 0,
- * <= 8 layers.  save = 0: ws holds two ping-pong activation buffers.  only: 0 = every layer; 1 + l = layer l alone (timing harness). */
+ * <= 8 layers.  save = 0: ws holds two ping-pong activation buffers.  tickets: 1024 unsigned ints zeroed ONCE by the caller (left zero
+ * by every launch; the row-group workgroups of a BatchNorm1d column tile meet there).  only: 0 = every layer; 1 + l = layer l alone
+ * (timing harness). */
 int migan_mlp_fused_ok(int B, int nlayers, const int* dims);
 size_t migan_mlp_fused_workspace(int B, int nlayers, const int* dims, int save);
 int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar, void* const* ptrs,
-                        float* ws, size_t ws_bytes, int save, int only, void* stream);
+                        float* ws, size_t ws_bytes, int save, unsigned* tickets, int only, void* stream);
 /* ... and its backward, one launch per phase (the generator iteration wgan_gp.py:179-193: both `generator(z)` and the frozen
  * `discriminator(fake_imgs)` are such MLPs): forward with save = 1 (ws then holds every layer's output, and the normalised values
  * and 1/std of the BatchNorm layers), then dy [B][N_last] -> parameter gradients written into (accumulate != 0: added to)

@@ -161,7 +161,7 @@ _SIGS = {
     "migan_mlp_fused_ok": (c_int, [c_int, c_int, P]),
     "migan_mlp_fused_workspace": (c_size_t, [c_int, c_int, P, c_int]),
     "migan_mlp_fused_bwd_workspace": (c_size_t, [c_int, c_int, P]),
-    "migan_mlp_fused_fwd": (c_int, [P, P, c_int, c_int, P, P, P, P, c_size_t, c_int, c_int, P]),
+    "migan_mlp_fused_fwd": (c_int, [P, P, c_int, c_int, P, P, P, P, c_size_t, c_int, P, c_int, P]),
     "migan_mlp_fused_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, c_int, c_int, P]),
     "migan_norm_small_ok": (c_int, [c_int, c_int, c_int]),
     "migan_norm_fwd_small": (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, P]),

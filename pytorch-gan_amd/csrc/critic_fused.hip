@@ -85,8 +85,7 @@ __device__ __forceinline__ void cf_nt_batch(const float* __restrict__ ap, const 
 __device__ __forceinline__ f32x4 cf_nt_partial(const float* __restrict__ ap, const float* __restrict__ wp, int klen) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int k0 = 0;
-    for (; k0 + 256 <= klen; k0 += 256) cf_nt_batch<16>(ap + k0, wp + k0, acc0, acc1);
-    if (k0 + 128 <= klen) { cf_nt_batch<8>(ap + k0, wp + k0, acc0, acc1); k0 += 128; }
+    for (; k0 + 128 <= klen; k0 += 128) cf_nt_batch<8>(ap + k0, wp + k0, acc0, acc1);   // 128 k values per round of loads (64 registers)
     if (k0 + 64 <= klen) { cf_nt_batch<4>(ap + k0, wp + k0, acc0, acc1); k0 += 64; }
     if (k0 + 32 <= klen) { cf_nt_batch<2>(ap + k0, wp + k0, acc0, acc1); k0 += 32; }
     if (k0 + 16 <= klen) cf_nt_batch<1>(ap + k0, wp + k0, acc0, acc1);
@@ -348,7 +347,7 @@ __device__ __forceinline__ void cf_dw_tiles(const CriticFused& p, const bool fir
     float a[3][4];
     f32x4 b[3][4];
     bool plain[3], pen[3];
-    int mrow[3][4];
+    int m0s[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = sl * cps + j;
@@ -357,15 +356,16 @@ __device__ __forceinline__ void cf_dw_tiles(const CriticFused& p, const bool fir
         const int blk = qc / RG, m0 = (qc - blk * RG) * 16;
         plain[j] = blk > 0;
         pen[j] = first && blk == 0;
+        m0s[j] = m0;
         const float* Rb = first ? (blk == 0 ? gb : (blk == 1 ? p.real : p.fake)) : (blk == 0 ? dv1b : h1b + (size_t)blk * RB * H1);
+        const float* Sq = S + (size_t)(blk * RB + m0 + kq) * N + n0 + rr;   // the workspace holds RB rows per block: no clamp
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m = m0 + 4 * s + kq;
-            const int mc = m < B ? m : B - 1;
-            const float av = S[(size_t)(blk * RB + mc) * N + n0 + rr];
+            const int mc = m < B ? m : B - 1;                                 // the inputs hold B rows only
+            const float av = Sq[(size_t)(4 * s) * N];
             a[j][s] = (live && m < B) ? av : 0.f;
             b[j][s] = *reinterpret_cast<const f32x4*>(Rb + (size_t)mc * K + k0 + 4 * rr);
-            mrow[j][s] = mc;
         }
     }
     __builtin_amdgcn_sched_barrier(0);   // the tile's loads and the coefficient loads are in flight together
@@ -379,7 +379,10 @@ __device__ __forceinline__ void cf_dw_tiles(const CriticFused& p, const bool fir
         for (int j = 0; j < 3; ++j)
             if (pen[j])   // c = coef (.) g
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[j][s] *= coef_rows[mrow[j][s]];
+                for (int s = 0; s < 4; ++s) {
+                    const int m = m0s[j] + 4 * s + kq;
+                    b[j][s] *= coef_rows[m < B ? m : B - 1];
+                }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -418,6 +421,7 @@ __device__ __forceinline__ void cf_dw_tiles(const CriticFused& p, const bool fir
 }
 
 // ---- launch 5: workgroups [0, RG * H1/16): du1 = coef (g W1^T) (NT, K = Din), dv1 = m1(x^) (.) du1;  the rest: dW1, db1
+// (two workgroups per CU: 384 workgroups in one round - at 150 registers the second 128 waited for the first 256, 12 us)
 __global__ __launch_bounds__(CF_THREADS) void critic_fused_p5_kernel(const CriticFused p) {
     __shared__ f32x4 part[2][3][4][64];   // role 1 uses the first 7 * 64 entries
     __shared__ float cred[2][3][16];

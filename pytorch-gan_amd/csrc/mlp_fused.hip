@@ -14,6 +14,7 @@
 #define MF_WAVES 16
 #define MF_THREADS (64 * MF_WAVES)
 #define MF_MAX_LAYERS 8
+#define MF_TICKETS 1024   // column tiles of a BatchNorm1d layer (N <= 16384); the caller's `tickets` holds this many zeroed words
 
 struct MlpLayer {
     const float *W, *b, *gamma, *beta;
@@ -29,6 +30,7 @@ struct MlpFused {
     float* ws;        // two [RB][maxN] activation buffers (forward without a graph), or the save buffer (see MlpSave)
     int saving;       // 1: every layer's output (and normalised pre-affine value + invstd of the BatchNorm layers) is kept for mlp_fused_bwd
     int layer;        // the layer this launch computes
+    unsigned* tickets;  // one per column tile, zero at rest (BatchNorm1d layers: the last row-group workgroup normalises the column block)
     MlpLayer L[MF_MAX_LAYERS];
 };
 // Save buffer of a forward that will be differentiated: for layer l < last h_l [RB][N_l]; for BatchNorm layers xhat_l [RB][N_l]
@@ -94,116 +96,147 @@ __device__ __forceinline__ f32x4 mf_nt_partial(const float* __restrict__ ap, con
     return acc0 + acc1;
 }
 
+// One workgroup = one 16 x 16 output tile (column tile x row group), K cut over the 16 waves: (N / 16) * (rows / 16) small workgroups per
+// layer instead of N / 16 fat ones - a workgroup that pulls 320 KB through one CU's L1 ran at 20-40 GB/s (20 us for the 1024 -> 1024
+// layer, profiles/r04_abi_check_and_two_rank.txt), the same bytes spread over four times the CUs do not.  A BatchNorm1d layer still needs
+// whole columns: every row-group workgroup leaves its tile (Linear output + bias) in the layer's output buffer, releases it and takes a
+// ticket of its column tile; the last of the rows / 16 arrivers (acquire) re-reads the column block - one row group per wave, the lane
+// layout of the MFMA tile - and runs the SAME two-pass statistics, running-statistics update, affine and activation as before
+// (bit-identical results, whoever arrives last).  The tickets are back at zero when the launch ends.
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFused p) {
-    __shared__ f32x4 part[(MF_WAVES - 1) * 64];   // partial tiles of the waves with ks > 0: [(ks - 1) * RGW + rg][lane]
+    __shared__ f32x4 part[(MF_WAVES - 1) * 64];   // partial tiles of the K-slice waves 1 .. 15
     __shared__ float red[4][16];
+    __shared__ unsigned last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, kq = lane >> 4;
     const int B = p.B, RB = p.RB;
     const int RG = RB / 16;
-    const int RGW = RG >= 3 ? 4 : RG;             // row-group waves (1, 2 or 4); the rest of the 16 waves are K slices
-    const int KSL = MF_WAVES / RGW;
-    const int rg = wave % RGW, ks = wave / RGW;
-    const bool rows_live = rg < RG;
     float* const buf0 = p.ws;
     float* const buf1 = p.ws + (size_t)RB * p.maxN;
+    const int l = p.layer;
+    const MlpLayer& Ly = p.L[l];
+    const int K = Ly.K, N = Ly.N;
+    const MlpSave S = mf_save_at(RB, p.nlayers, p.L, l), Sp = mf_save_at(RB, p.nlayers, p.L, l > 0 ? l - 1 : 0);
+    const float* in = l == 0 ? p.x : (p.saving ? p.ws + Sp.h : ((l - 1) & 1 ? buf1 : buf0));
+    float* out = l == p.nlayers - 1 ? p.y : (p.saving ? p.ws + S.h : (l & 1 ? buf1 : buf0));
+    const int t = blockIdx.x / RG, rg0 = blockIdx.x - t * RG;   // column tile, row group
+    const int col0 = t * 16, colr = col0 + rr;
+    const bool cok = colr < N;             // only the last layer may have N % 16 != 0 (a critic's single output)
+    const int col = cok ? colr : N - 1;
+    const bool last_layer = l == p.nlayers - 1;
     {
-        const int l = p.layer;
-        const MlpLayer& Ly = p.L[l];
-        const int K = Ly.K, N = Ly.N;
-        const MlpSave S = mf_save_at(RB, p.nlayers, p.L, l), Sp = mf_save_at(RB, p.nlayers, p.L, l > 0 ? l - 1 : 0);
-        const float* in = l == 0 ? p.x : (p.saving ? p.ws + Sp.h : ((l - 1) & 1 ? buf1 : buf0));
-        float* out = l == p.nlayers - 1 ? p.y : (p.saving ? p.ws + S.h : (l & 1 ? buf1 : buf0));
-        const int klen = ((K + KSL - 1) / KSL + 15) / 16 * 16;
-        const int kbeg = ks * klen < K ? ks * klen : K, kend = (ks + 1) * klen < K ? (ks + 1) * klen : K;
-        for (int t = blockIdx.x; t < (N + 15) / 16; t += gridDim.x) {
-            const int col0 = t * 16, colr = col0 + rr;
-            const bool cok = colr < N;             // only the last layer may have N % 16 != 0 (a critic's single output)
-            const int col = cok ? colr : N - 1;
-            const int arow = rg * 16 + rr < B ? rg * 16 + rr : B - 1;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (rows_live && kbeg < kend) acc = mf_nt_partial(in + (size_t)arow * K, Ly.W + (size_t)col * K, kbeg, kend, kq);
-            if (ks > 0) part[((ks - 1) * RGW + rg) * 64 + lane] = acc;
-            __syncthreads();
-            float v[4], d[4];
-            bool ok[4];
-            if (ks == 0) {
-                for (int q = 1; q < KSL; ++q) acc += part[((q - 1) * RGW + rg) * 64 + lane];
-                const float bv = Ly.b ? Ly.b[col] : 0.f;
+        const int klen = ((K + MF_WAVES - 1) / MF_WAVES + 15) / 16 * 16;
+        const int kbeg = wave * klen < K ? wave * klen : K, kend = (wave + 1) * klen < K ? (wave + 1) * klen : K;
+        const int arow = rg0 * 16 + rr < B ? rg0 * 16 + rr : B - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (kbeg < kend) acc = mf_nt_partial(in + (size_t)arow * K, Ly.W + (size_t)col * K, kbeg, kend, kq);
+        if (wave > 0) part[(wave - 1) * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ok[r] = rows_live && rg * 16 + kq * 4 + r < B;
-                    v[r] = acc[r] + bv;
-                }
-            }
-            float mean = 0.f, var = 0.f;
-            if (Ly.bn) {  // layer-uniform: every thread takes the same barriers
-                if (ks == 0) {
-                    float s = 0.f;
+            for (int q = 1; q < MF_WAVES; ++q) acc += part[(q - 1) * 64 + lane];
+            const float bv = Ly.b ? Ly.b[col] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s += ok[r] ? v[r] : 0.f;
-                    s += __shfl_xor(s, 16);
-                    s += __shfl_xor(s, 32);
-                    if (kq == 0) red[rg][rr] = s;
-                }
-                __syncthreads();
-                if (ks == 0) {
-                    float s = 0.f;
-                    for (int q = 0; q < RGW; ++q) s += red[q][rr];
-                    mean = s / (float)B;
-                }
-                __syncthreads();
-                if (ks == 0) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        d[r] = v[r] - mean;
-                        s += ok[r] ? d[r] * d[r] : 0.f;
-                    }
-                    s += __shfl_xor(s, 16);
-                    s += __shfl_xor(s, 32);
-                    if (kq == 0) red[rg][rr] = s;
-                }
-                __syncthreads();
-                if (ks == 0) {
-                    float s = 0.f;
-                    for (int q = 0; q < RGW; ++q) s += red[q][rr];
-                    var = s / (float)B;
-                }
-            }
-            if (ks == 0) {
-                float scale = 1.f, shift = 0.f, istd = 1.f;
+            for (int r = 0; r < 4; ++r) {
+                const int row = rg0 * 16 + kq * 4 + r;
+                const bool ok = row < B;
+                const float v = acc[r] + bv;
                 if (Ly.bn) {
-                    const float invstd = 1.f / sqrtf(var + Ly.eps);
-                    istd = invstd;
-                    const float gm = Ly.gamma ? Ly.gamma[col] : 1.f, bt = Ly.beta ? Ly.beta[col] : 0.f;
-                    scale = invstd * gm;
-                    shift = bt;
-                    if (p.saving && rg == 0 && kq == 0 && cok) p.ws[S.invstd + col] = invstd;
-                    if (rg == 0 && kq == 0 && cok && Ly.rmean) {  // nn.BatchNorm1d, training: momentum update, unbiased variance
-                        const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
-                        Ly.rmean[col] = (1.f - Ly.momentum) * Ly.rmean[col] + Ly.momentum * mean;
-                        Ly.rvar[col] = (1.f - Ly.momentum) * Ly.rvar[col] + Ly.momentum * unb;
-                    }
-                }
-                if (rows_live) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rg * 16 + kq * 4 + r;
-                        const float pre = Ly.bn ? d[r] * scale + shift : v[r];
-                        if (p.saving && Ly.bn && cok) p.ws[S.xhat + (size_t)row * N + col] = ok[r] ? d[r] * istd : 0.f;
-                        if (l == p.nlayers - 1) {
-                            if (ok[r] && cok) out[(size_t)row * N + col] = act_apply(pre, Ly.act, Ly.slope);
-                        } else {
-                            out[(size_t)row * N + col] = ok[r] ? act_apply(pre, Ly.act, Ly.slope) : 0.f;
-                        }
-                    }
+                    if (cok) out[(size_t)row * N + col] = ok ? v : 0.f;   // the tile's Linear output: normalised by the column's last arriver
+                } else if (last_layer) {
+                    if (ok && cok) out[(size_t)row * N + col] = act_apply(v, Ly.act, Ly.slope);
+                } else {
+                    out[(size_t)row * N + col] = ok ? act_apply(v, Ly.act, Ly.slope) : 0.f;
                 }
             }
-            __syncthreads();
         }
-        if (Ly.bn && Ly.nbt && blockIdx.x == 0 && threadIdx.x == 0) *Ly.nbt += 1;
     }
+    if (!Ly.bn) return;   // (layer-uniform)
+    // ---- BatchNorm1d: the last row-group workgroup of this column tile to arrive normalises the whole column block
+    if (wave == 0) {
+        unsigned tk = 0;
+        if (RG > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) tk = __hip_atomic_fetch_add(p.tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            tk = 0;
+        }
+        if (lane == 0) last_s = (RG <= 1 || tk == (unsigned)(RG - 1)) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_s == 0u) return;
+    if (RG > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) __hip_atomic_store(p.tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again
+    }
+    const int RGW = RG >= 3 ? 4 : RG;      // waves 0 .. RGW-1: one row group each (the lane layout of the MFMA tile)
+    const int rg = wave;
+    const bool act_wave = wave < RGW, rows_live = rg < RG;
+    float v[4], d[4];
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = rg * 16 + kq * 4 + r;
+        ok[r] = act_wave && rows_live && row < B;
+        v[r] = (act_wave && rows_live && cok) ? out[(size_t)row * N + col] : 0.f;
+    }
+    float mean = 0.f, var = 0.f;
+    if (act_wave) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += ok[r] ? v[r] : 0.f;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (kq == 0) red[rg][rr] = s;
+    }
+    __syncthreads();
+    if (act_wave) {
+        float s = 0.f;
+        for (int q = 0; q < RGW; ++q) s += red[q][rr];
+        mean = s / (float)B;
+    }
+    __syncthreads();
+    if (act_wave) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d[r] = v[r] - mean;
+            s += ok[r] ? d[r] * d[r] : 0.f;
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (kq == 0) red[rg][rr] = s;
+    }
+    __syncthreads();
+    if (!act_wave) return;
+    {
+        float s = 0.f;
+        for (int q = 0; q < RGW; ++q) s += red[q][rr];
+        var = s / (float)B;
+    }
+    const float invstd = 1.f / sqrtf(var + Ly.eps);
+    const float gm = Ly.gamma ? Ly.gamma[col] : 1.f, bt = Ly.beta ? Ly.beta[col] : 0.f;
+    const float scale = invstd * gm, shift = bt;
+    if (p.saving && rg == 0 && kq == 0 && cok) p.ws[S.invstd + col] = invstd;
+    if (rg == 0 && kq == 0 && cok && Ly.rmean) {  // nn.BatchNorm1d, training: momentum update, unbiased variance
+        const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
+        Ly.rmean[col] = (1.f - Ly.momentum) * Ly.rmean[col] + Ly.momentum * mean;
+        Ly.rvar[col] = (1.f - Ly.momentum) * Ly.rvar[col] + Ly.momentum * unb;
+    }
+    if (rows_live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rg * 16 + kq * 4 + r;
+            const float pre = d[r] * scale + shift;
+            if (p.saving && cok) p.ws[S.xhat + (size_t)row * N + col] = ok[r] ? d[r] * invstd : 0.f;
+            if (last_layer) {
+                if (ok[r] && cok) out[(size_t)row * N + col] = act_apply(pre, Ly.act, Ly.slope);
+            } else if (cok) {
+                out[(size_t)row * N + col] = ok[r] ? act_apply(pre, Ly.act, Ly.slope) : 0.f;
+            }
+        }
+    }
+    if (Ly.nbt && t == 0 && threadIdx.x == 0) *Ly.nbt += 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -578,21 +611,25 @@ MIGAN_API size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* di
     return (mf_dpre_off((B + 15) / 16 * 16, nlayers, L, nlayers) + 16) * sizeof(float);
 }
 // y[B][N_last] = MLP(x[B][K_0]), BatchNorm1d layers in training mode (batch statistics; running statistics and counters updated): one
-// launch per layer on `stream`.  ws: migan_mlp_fused_workspace(.., save) bytes.  only: 0 = every layer; 1 + l = layer l alone on whatever
+// launch per layer on `stream`.  ws: migan_mlp_fused_workspace(.., save) bytes.  tickets: 1024 unsigned ints, zeroed ONCE by the caller (the
+// kernels leave them zero; needed when a layer has BatchNorm1d).  only: 0 = every layer; 1 + l = layer l alone on whatever
 // the workspace holds (timing harness, tools/abi_check.cpp).
 MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, const int* dims, const float* fpar,
-                                  void* const* ptrs, float* ws, size_t ws_bytes, int save, int only, void* stream) {
+                                  void* const* ptrs, float* ws, size_t ws_bytes, int save, unsigned* tickets, int only, void* stream) {
     if (!migan_mlp_fused_ok(B, nlayers, dims) || ws_bytes < migan_mlp_fused_workspace(B, nlayers, dims, save)) return (int)hipErrorInvalidValue;
     if (only < 0 || only > nlayers) return (int)hipErrorInvalidValue;
     MlpFused p;
     p.B = B; p.RB = (B + 15) / 16 * 16; p.nlayers = nlayers; p.maxN = 0; p.saving = save != 0;
-    p.x = x; p.y = y; p.ws = ws;
+    p.x = x; p.y = y; p.ws = ws; p.tickets = tickets;
     if (!mf_fill_layers(p.L, nlayers, dims, fpar, ptrs)) return (int)hipErrorInvalidValue;
-    for (int l = 0; l < nlayers; ++l) p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
+    for (int l = 0; l < nlayers; ++l) {
+        p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
+        if (p.L[l].bn && (tickets == nullptr || (p.L[l].N + 15) / 16 > MF_TICKETS)) return (int)hipErrorInvalidValue;
+    }
     for (int l = 0; l < nlayers; ++l) {
         if (only && l != only - 1) continue;
         p.layer = l;
-        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3((p.L[l].N + 15) / 16), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3((p.L[l].N + 15) / 16 * (p.RB / 16)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;

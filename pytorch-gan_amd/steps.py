@@ -277,6 +277,7 @@ class _GeneratorFusedPlan:
         self.B, self.n, self.groups, self.shape, self.G = B, n, groups, tuple(shape), G
         self.ws_bytes = lib.migan_mlp_fused_workspace(B, n, self.dims, 0)
         self.ws = torch.empty(self.ws_bytes // 4, device=z.device, dtype=torch.float32)
+        self.tickets = torch.zeros(1024, device=z.device, dtype=torch.int32)   # zero at rest: the BatchNorm1d column tiles' arrival counters
         self.save = self.bws = None   # buffers of the differentiated form, made on first use
         self.ok = True
 
@@ -300,7 +301,7 @@ class _GeneratorFusedPlan:
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         y = torch.empty(self.B, self.groups[-1][0].out_features, device=x.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(x.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.save.data_ptr(),
-                                      self.save_bytes, 1, 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+                                      self.save_bytes, 1, self.tickets.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y
 
     def backward(self, x, y, dy, grads=None, want_dx=False, accumulate=False):
@@ -355,7 +356,7 @@ class _GeneratorFusedPlan:
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
         y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(z.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.ws.data_ptr(),
-                                      self.ws_bytes, 0, 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
+                                      self.ws_bytes, 0, self.tickets.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y.view(self.B, *self.shape)
 
 

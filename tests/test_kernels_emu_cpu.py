@@ -342,7 +342,9 @@ def test_fused_generator_forward_against_torch(emu, B, img_shape):
     wsb = emu.migan_mlp_fused_workspace(B, n, dims, 0)
     ws = torch.full((wsb // 4,), float("nan"))
     y = torch.empty(B, groups[-1][0].out_features)
-    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, 0, 0, None) == 0, emu.hipemu_last_message()
+    tickets = torch.zeros(1024, dtype=torch.int32)
+    assert emu.migan_mlp_fused_fwd(_ptr(z), _ptr(y), B, n, dims, fpar, ptrs, _ptr(ws), wsb, 0, _ptr(tickets), 0, None) == 0, emu.hipemu_last_message()
+    assert int(tickets.abs().sum()) == 0, "the column tickets must be back at zero"
     assert _rel(y, want) <= 3e-6
     for a, b in zip(G2.buffers(), G.buffers()):
         assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-6)
@@ -409,7 +411,9 @@ def test_fused_mlp_backward_against_autograd(emu, which, B):
     bws = torch.full((bwb // 4,), float("nan"))
     y = torch.empty(B, groups[-1][0].out_features)
     dx = torch.full_like(x, float("nan")) if want_dx else None
-    assert emu.migan_mlp_fused_fwd(_ptr(x), _ptr(y), B, n, dims, fpar, ptrs, _ptr(save), wsb, 1, 0, None) == 0
+    tickets = torch.zeros(1024, dtype=torch.int32)
+    assert emu.migan_mlp_fused_fwd(_ptr(x), _ptr(y), B, n, dims, fpar, ptrs, _ptr(save), wsb, 1, _ptr(tickets), 0, None) == 0
+    assert int(tickets.abs().sum()) == 0
     assert emu.migan_mlp_fused_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(save), _ptr(dx), B, n, dims, fpar, ptrs, gptrs, _ptr(bws), bwb,
                                    0, 0, None) == 0, emu.hipemu_last_message()
     assert _rel(y, yr.detach()) <= 3e-6

@@ -134,12 +134,16 @@ def test_geometry_selects_kernel(pg, case):
 
 
 def test_splitk_conv_is_deterministic(pg):
-    """The in-kernel split-K reduction adds the slabs in slice order whoever arrives last: two runs are bit-identical, and
-    the tickets are back at zero afterwards (pix2pix/models.py:66 geometry: 4 output pixels, K = 8192)."""
+    """The in-kernel split-K reduction adds the slabs in slice order whoever arrives last: runs are bit-identical, and the
+    tickets are back at zero afterwards (pix2pix/models.py:63 geometry: 64 output pixels, K = 2048, 512 k weights - below the few-pixel
+    path's 1 M-weight threshold, so the split-K tile kernel serves it: asserted with the launch counters)."""
     F = pg.functional
-    x = _leaf(1, 512, 4, 4, seed=11).to(DEV)
-    w = _leaf(512, 512, 4, 4, seed=12, scale=0.05).to(DEV)
-    outs = [F.conv2d(x, w, None, 2, (1, 1, 1, 1), 0, 0, 0.0).clone() for _ in range(4)]
+    x = _leaf(1, 128, 16, 16, seed=11).to(DEV)
+    w = _leaf(256, 128, 4, 4, seed=12, scale=0.05).to(DEV)
+    F._SK_WS.clear()
+    with Launches() as n:
+        outs = [F.conv2d(x, w, None, 2, (1, 1, 1, 1), 0, 0, 0.0).clone() for _ in range(4)]
+        assert n("4, true>") == 4 and n("im2col_small") == 0, "the split-K kernel (NS = 4, SPLITK) must serve this shape"
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])

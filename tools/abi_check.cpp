@@ -311,9 +311,12 @@ static void mlp_case(int B) {
     std::vector<float> ref(a.begin(), a.end());
     const size_t wsb = migan_mlp_fused_workspace(B, L, dims, 0);
     Buf ws(wsb / 4, 0, false);
+    unsigned* tickets;
+    CK(hipMalloc((float**)&tickets, 4096));
+    CK(hipMemset(tickets, 0, 4096));
     {
         Buf y((size_t)B * Nn[L - 1], 0, false);
-        auto run = [&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, 0, nullptr)); };
+        auto run = [&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, tickets, 0, nullptr)); };
         run();
         CK(hipDeviceSynchronize());
         const double r = rel(y.host(), ref);
@@ -326,16 +329,17 @@ static void mlp_case(int B) {
     {
         Buf y((size_t)B * Nn[L - 1], 0, false);
         printf("mlp_fused_fwd, 20 calls back to back: %.1f us per call (%d launches)\n",
-               train_us([&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, 0, nullptr)); }), L);
+               train_us([&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, tickets, 0, nullptr)); }), L);
         printf("mlp_fused_fwd per layer:");
         for (int l = 0; l < L; ++l) {
-            const float us = train_us([&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, 1 + l, nullptr)); });
+            const float us = train_us([&] { RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, ws.d, wsb, 0, tickets, 1 + l, nullptr)); });
             printf("  l%d (%d->%d) %.1f us", l, K[l], Nn[l], us);
         }
         printf("\n");
         fflush(stdout);
     }
     (void)hipFree(nbt);
+    (void)hipFree(tickets);
     for (Buf* b : keep) delete b;
 }
 

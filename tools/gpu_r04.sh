@@ -156,8 +156,28 @@ for k,v in r['extra'].items(): print(k, {a:v.get(a) for a in ('images_per_s','ms
 PY
 }
 
+task_fourth() {
+  local O=gpurun_out/r4d; mkdir -p $O
+  for s in critic mlp; do timeout 120 ./tools/abi_check.bin $s >> $O/abi_check.txt 2>&1; done
+  grep -v "^migan" $O/abi_check.txt | cut -c1-220
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_ops_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan or adam or splitk or critic" --durations=5 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  echo "== wgan_gp" >> $O/bench.txt
+  timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline 2>>$O/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'])" >> $O/bench.txt
+  task_prof r4d wgan_gp:graph
+  for w in dcgan cyclegan srgan; do
+    k=4; [ $w = dcgan ] && k=50
+    for ns in 2 3 2 3; do
+      echo "== $w MIGAN_DMA_NS=$ns" >> $O/bench.txt
+      MIGAN_DMA_NS=$ns timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$O/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $O/bench.txt
+    done
+  done
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
+  fourth) task_fourth "$@" ;;
   third) task_third "$@" ;;
   second) task_second "$@" ;;
   pmcstep) task_pmcstep "$@" ;;
