@@ -353,20 +353,8 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     static const int tapin_env = getenv("MIGAN_DMA_TAPIN") ? atoi(getenv("MIGAN_DMA_TAPIN")) : 1;
     tapin = tapin && tapin_env != 0;
     const bool ktail = g.Ci % BK != 0;
-    // A/B knob MIGAN_DMA_NS=3: three LDS stages with counted waits (two K-tiles in flight) for the tap-outer BK = 16 tiles.  In a
-    // training step the operands of a conv come from HBM, not from an Infinity Cache warmed by the previous repetition of the same
-    // layer (stand-alone timing): the PMC passes show the wait-for-memory share of these kernels rising from 11 to 15-18 % in-step
-    // (profiles/r04_pmc_kernels.json) - a deeper prefetch trades one workgroup of occupancy against that.
-    static const int ns_env = getenv("MIGAN_DMA_NS") ? atoi(getenv("MIGAN_DMA_NS")) : 2;
-    if constexpr (BK == 16) {
-        if (ns_env == 3 && !tapin) {
-            constexpr int OCC3 = OCC >= 8 ? 6 : (OCC >= 5 ? 4 : 3);
-            if (ktail) MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, 1, true, OCC3, 3>), grid, dim3(256), 0, st, g, A, Bw, bias, C, a_bytes, b_bytes);
-            else MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, 1, false, OCC3, 3>), grid, dim3(256), 0, st, g, A, Bw, bias, C, a_bytes, b_bytes);
-            HIP_LAUNCH_CHECK();
-            return 0;
-        }
-    }
+    // (Three LDS stages with counted waits - two K-tiles in flight, one workgroup of occupancy less - were measured on whole steps for
+    // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
 #define DMA_LAUNCH(TI_, KT_)                                                                                         \
     MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
                        a_bytes, b_bytes)

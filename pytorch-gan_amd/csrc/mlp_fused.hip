@@ -99,8 +99,8 @@ __device__ __forceinline__ f32x4 mf_nt_partial(const float* __restrict__ ap, con
 // One workgroup = one 16 x 16 output tile (column tile x row group), K cut over the 16 waves: (N / 16) * (rows / 16) small workgroups per
 // layer instead of N / 16 fat ones - a workgroup that pulls 320 KB through one CU's L1 ran at 20-40 GB/s (20 us for the 1024 -> 1024
 // layer, profiles/r04_abi_check_and_two_rank.txt), the same bytes spread over four times the CUs do not.  A BatchNorm1d layer still needs
-// whole columns: every row-group workgroup leaves its tile (Linear output + bias) in the layer's output buffer, releases it and takes a
-// ticket of its column tile; the last of the rows / 16 arrivers (acquire) re-reads the column block - one row group per wave, the lane
+// whole columns: every row-group workgroup leaves its tile (Linear output + bias) in the layer's output buffer (write-through stores) and
+// takes a ticket of its column tile; the last of the rows / 16 arrivers re-reads the column block (sc1 loads) - one row group per wave, the lane
 // layout of the MFMA tile - and runs the SAME two-pass statistics, running-statistics update, affine and activation as before
 // (bit-identical results, whoever arrives last).  The tickets are back at zero when the launch ends.
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFused p) {
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
                 const bool ok = row < B;
                 const float v = acc[r] + bv;
                 if (Ly.bn) {
-                    if (cok) out[(size_t)row * N + col] = ok ? v : 0.f;   // the tile's Linear output: normalised by the column's last arriver
+                    // the tile's Linear output, normalised by the column's last arriver: written THROUGH to the device-coherent level
+                    // (sc1), no cache-wide release - see the hand-off below
+                    if (cok) __hip_atomic_store(out + (size_t)row * N + col, ok ? v : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else if (last_layer) {
                     if (ok && cok) out[(size_t)row * N + col] = act_apply(v, Ly.act, Ly.slope);
                 } else {
@@ -153,22 +155,21 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     }
     if (!Ly.bn) return;   // (layer-uniform)
     // ---- BatchNorm1d: the last row-group workgroup of this column tile to arrive normalises the whole column block
+    // Hand-off without agent-scope fences (a release / acquire pair is buffer_wbl2 / buffer_inv of the whole L2: with one per workgroup
+    // the 512 -> 1024 layer took 39.7 us instead of 15, profiles/r04_abi_check_and_two_rank.txt): the tile was stored write-through
+    // (sc1), this wave waits until its stores are acknowledged (vmcnt(0)), then takes the ticket; the last arriver reads the column
+    // block with sc1 loads, which do not hit a stale L2 line (MI355X_MICROARCH.md, "handoff-flag" / "publish-large").
     if (wave == 0) {
         unsigned tk = 0;
         if (RG > 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) tk = __hip_atomic_fetch_add(p.tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            tk = 0;
         }
         if (lane == 0) last_s = (RG <= 1 || tk == (unsigned)(RG - 1)) ? 1u : 0u;
     }
     __syncthreads();
     if (last_s == 0u) return;
-    if (RG > 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (threadIdx.x == 0) __hip_atomic_store(p.tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again
-    }
+    if (RG > 1 && threadIdx.x == 0) __hip_atomic_store(p.tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again
     const int RGW = RG >= 3 ? 4 : RG;      // waves 0 .. RGW-1: one row group each (the lane layout of the MFMA tile)
     const int rg = wave;
     const bool act_wave = wave < RGW, rows_live = rg < RG;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     for (int r = 0; r < 4; ++r) {
         const int row = rg * 16 + kq * 4 + r;
         ok[r] = act_wave && rows_live && row < B;
-        v[r] = (act_wave && rows_live && cok) ? out[(size_t)row * N + col] : 0.f;
+        v[r] = (act_wave && rows_live && cok) ? __hip_atomic_load(out + (size_t)row * N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     }
     float mean = 0.f, var = 0.f;
     if (act_wave) {

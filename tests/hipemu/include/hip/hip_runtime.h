@@ -214,8 +214,20 @@ static inline void hipemu_buffer_load_lds(hipemu::BufRsrc r, LdsPtr lds, int siz
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
-#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
-#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+// (generic forms: the kernels also hand float tiles over with relaxed agent-scope - sc1 - stores and loads)
+template <class T>
+static inline T hipemu_atomic_load(const T* p) {
+    T v;
+    __atomic_load(p, &v, __ATOMIC_SEQ_CST);
+    return v;
+}
+template <class T, class V>
+static inline void hipemu_atomic_store(T* p, V v) {
+    T t = (T)v;
+    __atomic_store(p, &t, __ATOMIC_SEQ_CST);
+}
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load((p))
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store((p), (v))
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

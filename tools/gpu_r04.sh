@@ -175,8 +175,21 @@ task_fourth() {
   cat $O/bench.txt
 }
 
+task_fifth() {
+  local O=gpurun_out/r4e; mkdir -p $O
+  for s in critic mlp; do timeout 120 ./tools/abi_check.bin $s >> $O/abi_check.txt 2>&1; done
+  grep -v "^migan" $O/abi_check.txt | cut -c1-220
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan or critic" --durations=5 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  echo "== wgan_gp" >> $O/bench.txt
+  timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline 2>>$O/bench.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'])" >> $O/bench.txt
+  cat $O/bench.txt
+  task_prof r4e wgan_gp:graph
+}
+
 t=${1:-}; shift || true
 case "$t" in
+  fifth) task_fifth "$@" ;;
   fourth) task_fourth "$@" ;;
   third) task_third "$@" ;;
   second) task_second "$@" ;;
