@@ -162,6 +162,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
     if (wave == 0) {
         unsigned tk = 0;
         if (RG > 1) {
+            __builtin_amdgcn_wave_barrier();   // every lane's stores are issued before the wave waits for them (no code on the hardware)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) tk = __hip_atomic_fetch_add(p.tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -306,6 +307,7 @@ __device__ __forceinline__ void mf_nn_partial(const float* __restrict__ ap, int 
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd p) {
     __shared__ f32x4 part[2][(MF_WAVES - 1) * 64];
     __shared__ float red[2][4][32];
+    __shared__ unsigned last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rr = lane & 15, kq = lane >> 4;
     const int B = p.B, RB = p.RB, NL = p.nlayers;
@@ -318,6 +320,10 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
 
     // ---- top: dpre of the last layer from dy (16 columns x all rows per workgroup; only the ks == 0 waves work)
     if (p.ph_lo <= 0 && 0 <= p.ph_hi) {
+        if (blockIdx.x == 0) {   // the chain phases' column-tile tickets (behind the dpre buffers): zero before the first of them runs
+            unsigned* tickets = reinterpret_cast<unsigned*>(p.ws + mf_dpre_off(RB, NL, p.L, NL) + 16);
+            for (int i = threadIdx.x; i < MF_TICKETS; i += MF_THREADS) tickets[i] = 0u;
+        }
         const int l = NL - 1;
         const MlpLayer& Ly = p.L[l];
         const int N = Ly.N, ld = (N + 15) / 16 * 16;
@@ -383,7 +389,12 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         }
     }
 
-    // ---- l = L-1 .. 1: dpre_{l-1} from dpre_l;  l = 0: dx (when wanted)
+    // ---- l = L-1 .. 1: dpre_{l-1} from dpre_l;  l = 0: dx (when wanted).  One workgroup = (32-column tile) x (16-row group), the K
+    // dimension (R = N_l <= 1024: one batch of <= 64 k values per wave, ONE round trip) cut over the 16 waves - Nc / 32 * rows / 16
+    // workgroups instead of Nc / 32 fat ones that walked K in four dependent rounds (21 us for the 1024 -> 1024 layer on 32 CUs,
+    // profiles/r04_wgan_gp_graph_kernel_stats.txt).  Where the layer below has a BatchNorm1d its backward needs the column sums over ALL
+    // rows: the forward kernel's hand-off - every row-group workgroup leaves dz (write-through), takes the column tile's ticket, the last
+    // arriver re-reads the column block (sc1 loads) and runs the same sums in the same order whoever it is.
     for (int l = NL - 1; l >= 0; --l) {
         if (l == 0 && !p.dx) break;
         const int ph = NL - l;
@@ -391,105 +402,127 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
         const MlpLayer& Ly = p.L[l];
         const int R = Ly.N, ldR = (R + 15) / 16 * 16, Nc = Ly.K;   // T[rows][Nc] = dpre_l[rows][R] W_l[R][Nc]
         const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
-        const int klen = ((ldR + KSL - 1) / KSL + 15) / 16 * 16;
-        const int kbeg = ks * klen < ldR ? ks * klen : ldR, kend = (ks + 1) * klen < ldR ? (ks + 1) * klen : ldR;
+        const int klen = ((ldR + MF_WAVES - 1) / MF_WAVES + 15) / 16 * 16;
+        const int kbeg = wave * klen < ldR ? wave * klen : ldR, kend = (wave + 1) * klen < ldR ? (wave + 1) * klen : ldR;
         const int lo = l > 0 ? l - 1 : 0;                               // the layer whose output this gradient belongs to
         const MlpSave So = mf_save_at(RB, NL, p.L, lo);
         float* dprev = l > 0 ? p.ws + mf_dpre_off(RB, NL, p.L, l - 1) : nullptr;
-        for (int t = blockIdx.x; t < Nc / 32; t += gridDim.x) {
-            const int col = t * 32 + 2 * rr;
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-            if (rows_live && kbeg < kend) mf_nn_partial(dprel + (size_t)(rg * 16 + rr) * ldR, R, Ly.W, Nc, col, kbeg, kend, kq, a0, a1);
-            if (ks > 0) {
-                part[0][((ks - 1) * RGW + rg) * 64 + lane] = a0;
-                part[1][((ks - 1) * RGW + rg) * 64 + lane] = a1;
+        const int t = blockIdx.x / RG, rg0 = blockIdx.x - t * RG;       // column tile, row group
+        if (t >= Nc / 32) continue;
+        const int col = t * 32 + 2 * rr;
+        const bool bn = l > 0 && p.L[lo].bn;   // layer-uniform
+        unsigned* tickets = reinterpret_cast<unsigned*>(p.ws + mf_dpre_off(RB, NL, p.L, NL) + 16);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (kbeg < kend) mf_nn_partial(dprel + (size_t)(rg0 * 16 + rr) * ldR, R, Ly.W, Nc, col, kbeg, kend, kq, a0, a1);
+        if (wave > 0) {
+            part[0][(wave - 1) * 64 + lane] = a0;
+            part[1][(wave - 1) * 64 + lane] = a1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int q = 1; q < MF_WAVES; ++q) {
+                a0 += part[0][(q - 1) * 64 + lane];
+                a1 += part[1][(q - 1) * 64 + lane];
             }
-            __syncthreads();
-            float dz[2][4], xh[2][4];
-            bool ok[4];
-            if (ks == 0) {
-                for (int q = 1; q < KSL; ++q) {
-                    a0 += part[0][((q - 1) * RGW + rg) * 64 + lane];
-                    a1 += part[1][((q - 1) * RGW + rg) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rg0 * 16 + kq * 4 + r;
+                const bool okr = row < B;
+                if (l == 0) {
+                    if (okr) {
+                        p.dx[(size_t)row * Nc + col] = a0[r];
+                        p.dx[(size_t)row * Nc + col + 1] = a1[r];
+                    }
+                } else {
+                    const float* h = p.save + So.h + (size_t)row * Nc + col;
+                    const float z0 = okr ? a0[r] * act_grad_from_out(h[0], p.L[lo].act, p.L[lo].slope) : 0.f;
+                    const float z1 = okr ? a1[r] * act_grad_from_out(h[1], p.L[lo].act, p.L[lo].slope) : 0.f;
+                    float* o = dprev + (size_t)row * Nc + col;   // interior widths are multiples of 32: stride == width
+                    if (bn && RG > 1) {   // dz, finished by the column tile's last arriver: written THROUGH (sc1), see mlp_fused_fwd_kernel
+                        __hip_atomic_store(o, z0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(o + 1, z1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        o[0] = z0;
+                        o[1] = z1;
+                    }
                 }
+            }
+        }
+        if (!bn) continue;
+        // ---- BatchNorm1d backward of layer lo over the whole column block, by the last row-group workgroup to arrive
+        if (wave == 0) {
+            unsigned tk = 0;
+            if (RG > 1) {
+                __builtin_amdgcn_wave_barrier();   // every lane's stores are issued before the wave waits for them (no code on the hardware)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) tk = __hip_atomic_fetch_add(tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) last_s = (RG <= 1 || tk == (unsigned)(RG - 1)) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last_s == 0u) continue;
+        if (RG > 1 && threadIdx.x == 0) __hip_atomic_store(tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again
+        const int trg = wave;
+        const bool act_wave = wave < RGW, live = act_wave && trg < RG;
+        float dz[2][4], xh[2][4];
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = trg * 16 + kq * 4 + r;
+            ok[r] = live && row < B;
+            const float* o = dprev + (size_t)(live ? row : 0) * Nc + col;
+            const float* xp = p.save + So.xhat + (size_t)(live ? row : 0) * Nc + col;
+            if (RG > 1) {
+                dz[0][r] = live ? __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                dz[1][r] = live ? __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            } else {
+                dz[0][r] = live ? o[0] : 0.f;
+                dz[1][r] = live ? o[1] : 0.f;
+            }
+            xh[0][r] = ok[r] ? xp[0] : 0.f;
+            xh[1][r] = ok[r] ? xp[1] : 0.f;
+        }
+        if (act_wave) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float a = 0.f, b = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rg * 16 + kq * 4 + r;
-                    ok[r] = rows_live && row < B;
-                    if (l == 0) {
-                        dz[0][r] = a0[r];
-                        dz[1][r] = a1[r];
-                    } else {
-                        const float* h = p.save + So.h + (size_t)row * Nc + col;
-                        dz[0][r] = ok[r] ? a0[r] * act_grad_from_out(h[0], p.L[lo].act, p.L[lo].slope) : 0.f;
-                        dz[1][r] = ok[r] ? a1[r] * act_grad_from_out(h[1], p.L[lo].act, p.L[lo].slope) : 0.f;
-                        if (p.L[lo].bn) {
-                            const float* xp = p.save + So.xhat + (size_t)row * Nc + col;
-                            xh[0][r] = ok[r] ? xp[0] : 0.f;
-                            xh[1][r] = ok[r] ? xp[1] : 0.f;
-                        }
-                    }
+                    a += dz[e][r];
+                    b += dz[e][r] * xh[e][r];
+                }
+                a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+                if (kq == 0) {
+                    red[0][trg][2 * rr + e] = a;
+                    red[1][trg][2 * rr + e] = b;
                 }
             }
-            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-            const bool bn = l > 0 && p.L[lo].bn;   // layer-uniform
-            if (bn) {
-                if (ks == 0) {
+        }
+        __syncthreads();
+        if (live) {
+            float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, g[2];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        float a = 0.f, b = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            a += dz[e][r];
-                            b += dz[e][r] * xh[e][r];
-                        }
-                        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-                        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-                        if (kq == 0) {
-                            red[0][rg][2 * rr + e] = a;
-                            red[1][rg][2 * rr + e] = b;
-                        }
-                    }
+            for (int e = 0; e < 2; ++e) {
+                for (int q = 0; q < RGW; ++q) {
+                    s1[e] += red[0][q][2 * rr + e];
+                    s2[e] += red[1][q][2 * rr + e];
                 }
-                __syncthreads();
-                if (ks == 0)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        for (int q = 0; q < RGW; ++q) {
-                            s1[e] += red[0][q][2 * rr + e];
-                            s2[e] += red[1][q][2 * rr + e];
-                        }
-            }
-            if (ks == 0 && rows_live) {
-                float g[2] = {1.f, 1.f};
-                if (bn) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[So.invstd + col + e];
-                        if (rg == 0 && kq == 0) {
-                            if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] = p.accum ? p.gbeta[l - 1][col + e] + s1[e] : s1[e];
-                            if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] = p.accum ? p.ggamma[l - 1][col + e] + s2[e] : s2[e];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rg * 16 + kq * 4 + r;
-                    if (l == 0) {
-                        if (ok[r]) {
-                            p.dx[(size_t)row * Nc + col] = dz[0][r];
-                            p.dx[(size_t)row * Nc + col + 1] = dz[1][r];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const float v = bn ? g[e] * (dz[e][r] - s1[e] * invB - xh[e][r] * s2[e] * invB) : dz[e][r];
-                            dprev[(size_t)row * Nc + col + e] = ok[r] ? v : 0.f;   // interior widths are multiples of 32: stride == width
-                        }
-                    }
+                g[e] = (p.L[lo].gamma ? p.L[lo].gamma[col + e] : 1.f) * p.save[So.invstd + col + e];
+                if (trg == 0 && kq == 0) {
+                    if (p.gbeta[l - 1]) p.gbeta[l - 1][col + e] = p.accum ? p.gbeta[l - 1][col + e] + s1[e] : s1[e];
+                    if (p.ggamma[l - 1]) p.ggamma[l - 1][col + e] = p.accum ? p.ggamma[l - 1][col + e] + s2[e] : s2[e];
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = trg * 16 + kq * 4 + r;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = g[e] * (dz[e][r] - s1[e] * invB - xh[e][r] * s2[e] * invB);
+                    dprev[(size_t)row * Nc + col + e] = ok[r] ? v : 0.f;
+                }
+            }
         }
     }
 
@@ -504,8 +537,9 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_bwd_kernel(const MlpBwd 
             const float* dprel = p.ws + mf_dpre_off(RB, NL, p.L, l);
             const float* hin = l == 0 ? p.x : p.save + mf_save_at(RB, NL, p.L, l - 1).h;      // [B or RB][K]
             // rotate the starting wave from layer to layer so the short lists of the small layers do not all land on wave 0
-            const int gstride = gridDim.x * MF_WAVES;
-            const int gw = (blockIdx.x * MF_WAVES + wave + gstride - base % gstride) % gstride;
+            const int nw = (int)blockDim.x >> 6;   // this phase is launched with 4-wave workgroups: one wave tile per wave on every CU
+            const int gstride = gridDim.x * nw;
+            const int gw = (blockIdx.x * nw + wave + gstride - base % gstride) % gstride;
             for (int wt = gw; wt < ntl; wt += gstride) {
                 const int nt = wt / ktiles, kt = wt - nt * ktiles;
                 const int n0 = nt * 16, k0 = kt * 64;
@@ -609,7 +643,7 @@ MIGAN_API size_t migan_mlp_fused_bwd_workspace(int B, int nlayers, const int* di
     if (!migan_mlp_fused_ok(B, nlayers, dims)) return 0;
     MlpLayer L[MF_MAX_LAYERS];
     mf_dims_to_layers(L, nlayers, dims);
-    return (mf_dpre_off((B + 15) / 16 * 16, nlayers, L, nlayers) + 16) * sizeof(float);
+    return (mf_dpre_off((B + 15) / 16 * 16, nlayers, L, nlayers) + 16 + MF_TICKETS) * sizeof(float);   // dpre buffers | pad | tickets
 }
 // y[B][N_last] = MLP(x[B][K_0]), BatchNorm1d layers in training mode (batch statistics; running statistics and counters updated): one
 // launch per layer on `stream`.  ws: migan_mlp_fused_workspace(.., save) bytes.  tickets: 1024 unsigned ints, zeroed ONCE by the caller (the
@@ -669,9 +703,9 @@ MIGAN_API int migan_mlp_fused_bwd(const float* x, const float* y, const float* d
         p.ph_lo = p.ph_hi = ph;
         int grid;
         if (ph == 0) grid = (p.L[nlayers - 1].N + 15) / 16;
-        else if (ph <= nlayers) grid = p.L[nlayers - ph].K / 32;
-        else grid = (wave_tiles + MF_WAVES - 1) / MF_WAVES;   // one wave tile per wave
-        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(grid < 1 ? 1 : grid), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
+        else if (ph <= nlayers) grid = p.L[nlayers - ph].K / 32 * (p.RB / 16);
+        else grid = (wave_tiles + 3) / 4;   // one wave tile per wave, four waves per workgroup (1712 tiles for the generator: every CU takes part)
+        MIGAN_LAUNCH(mlp_fused_bwd_kernel, dim3(grid < 1 ? 1 : grid), dim3(ph == nlayers + 1 ? 256 : MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();
     }
     return 0;

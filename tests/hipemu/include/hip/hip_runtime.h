@@ -206,6 +206,9 @@ static inline void hipemu_buffer_load_lds(hipemu::BufRsrc r, LdsPtr lds, int siz
 // ---- scalar helpers, scheduling hints, atomics ------------------------------------------------------------------------
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// a wave executes in lockstep: what one lane does behind this point comes after what EVERY lane did in front of it (the fibers of the
+// model run one lane at a time between synchronisation points, so the point has to exist here; on the hardware it emits no code)
+#define __builtin_amdgcn_wave_barrier() ((void)__shfl(0, 0))
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) hipemu::sleep_hint()

@@ -338,6 +338,39 @@ static void mlp_case(int B) {
         printf("\n");
         fflush(stdout);
     }
+    {   // the generator iteration's pair: forward that keeps its activations + backward (top, chain l = 4 .. 1, gradients), timed per phase
+        const size_t sb = migan_mlp_fused_workspace(B, L, dims, 1), bb = migan_mlp_fused_bwd_workspace(B, L, dims);
+        Buf save(sb / 4, 0, false), bws(bb / 4, 0, false), y((size_t)B * Nn[L - 1], 0, false), dy((size_t)B * Nn[L - 1], 0.01f);
+        void* gptrs[4 * L];
+        std::vector<Buf*> gk;
+        for (int l = 0; l < L; ++l) {
+            Buf* gW = new Buf((size_t)Nn[l] * K[l], 0, false); Buf* gb = new Buf(Nn[l], 0, false);
+            gk.push_back(gW); gk.push_back(gb);
+            gptrs[4 * l] = gW->d; gptrs[4 * l + 1] = gb->d; gptrs[4 * l + 2] = gptrs[4 * l + 3] = nullptr;
+            if (bn[l]) {
+                Buf* gg = new Buf(Nn[l], 0, false); Buf* gbe = new Buf(Nn[l], 0, false);
+                gk.push_back(gg); gk.push_back(gbe);
+                gptrs[4 * l + 2] = gg->d; gptrs[4 * l + 3] = gbe->d;
+            }
+        }
+        RC(migan_mlp_fused_fwd(x.d, y.d, B, L, dims, fpar, ptrs, save.d, sb, 1, tickets, 0, nullptr));
+        auto bwd = [&](int only) {
+            RC(migan_mlp_fused_bwd(x.d, y.d, dy.d, save.d, nullptr, B, L, dims, fpar, ptrs, gptrs, bws.d, bb, 0, only, nullptr));
+        };
+        bwd(0);
+        CK(hipDeviceSynchronize());
+        bool fin = true;
+        double asum = 0;
+        for (Buf* g : gk) for (float v : g->host()) { fin = fin && std::isfinite(v); asum += std::fabs(v); }
+        if (!fin || asum == 0) ++failures;
+        printf("mlp_fused_bwd B%d  gradients finite %s (sum |g| %.4g)  20 calls back to back: %.1f us per call\n", B, fin ? "ok" : "FAIL", asum,
+               train_us([&] { bwd(0); }));
+        printf("mlp_fused_bwd per phase:  top %.1f us", train_us([&] { bwd(1); }));
+        for (int ph = 1; ph < L; ++ph) printf("  chain l%d (%d<-%d) %.1f us", L - ph, K[L - ph], Nn[L - ph], train_us([&] { bwd(1 + ph); }));
+        printf("  gradients %.1f us\n", train_us([&] { bwd(L + 2); }));
+        fflush(stdout);
+        for (Buf* g : gk) delete g;
+    }
     (void)hipFree(nbt);
     (void)hipFree(tickets);
     for (Buf* b : keep) delete b;
