@@ -168,6 +168,14 @@ int migan_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, 
 int migan_conv2d_dgrad_ws(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
                           int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
                           float slope, float* ws, size_t ws_bytes, void* stream);
+/* Input gradient of a conv whose INPUT is the output of a fused conv+ReLU (or of the MaxPool2d behind one): the frozen
+ * vgg19.features[:18] of srgan/models.py:8-15 as srgan.py:112-113 differentiates it (loss_content.backward through conv, ReLU,
+ * conv ...).  dx[i] = relu_out[i] > 0 ? dgrad(dy)[i] : 0 in the epilogue of the input-gradient launch, so the ReLU backward of the
+ * producing layer costs no pass over the tensor (ATen: threshold_backward).  relu_out = the conv's saved input [N][Hi][Wi][Ci].
+ * Returns hipErrorNotSupported (801) for geometries the LDS-DMA kernels do not serve: run migan_conv2d_dgrad_ws + migan_act_bwd. */
+int migan_conv2d_dgrad_relu_ws(const float* dy, const float* w_ihwo, float* dx, const float* relu_out, int N, int Hi, int Wi,
+                               int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, float* ws,
+                               size_t ws_bytes, void* stream);
 
 /* Which tile configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
  * Co columns and a source with Ci_src channels: fast*1000000 + BM*1000 + BN ("fast" = vectorised NHWC loader,
@@ -374,6 +382,8 @@ int migan_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C
 /* MaxPool2d(2,2) inside vgg19.features[:18] (srgan/models.py:11-12). */
 int migan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* ... with the backward of the ReLU in front of the pool (vgg19.features[3:5], [8:10]) applied to dx: x is that ReLU's output. */
+int migan_maxpool2_relu_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* torch.cat((a,b),1) pix2pix/models.py:50,132 (forward=1) and its backward split (forward=0). */
 int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca, int Cb, int forward, void* stream);
 /* dst[dst_row ? dst_row[k] : k][:] = sel[k] >= 0 ? a[sel[k]][:] : b[-1 - sel[k]][:], rows of D floats (D % 4 == 0);

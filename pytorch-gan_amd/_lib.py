@@ -96,6 +96,7 @@ _SIGS = {
     "migan_conv_splitk_applies": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_fwd_ws": (c_int, [P, P, P, P, P] + [c_int] * 14 + [c_float, P, c_size_t, P]),
     "migan_conv2d_dgrad_ws": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, P, c_size_t, P]),
+    "migan_conv2d_dgrad_relu_ws": (c_int, [P, P, P, P] + [c_int] * 12 + [P, c_size_t, P]),
     "migan_igemm_tile_code": (c_int, [ctypes.c_longlong, c_int, c_int, c_int]),
     "migan_conv2d_wgrad_workspace": (c_size_t, [c_int] * 7),
     "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P, c_int, P]),
@@ -136,6 +137,7 @@ _SIGS = {
     "migan_pixel_shuffle": (c_int, [P, P] + [c_int] * 6 + [P]),
     "migan_maxpool2_fwd": (c_int, [P, P] + [c_int] * 4 + [P]),
     "migan_maxpool2_bwd": (c_int, [P, P, P] + [c_int] * 4 + [P]),
+    "migan_maxpool2_relu_bwd": (c_int, [P, P, P] + [c_int] * 4 + [P]),
     "migan_cat_channels": (c_int, [P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "migan_select_rows": (c_int, [P, P, P, P, P, c_int, c_size_t, P]),
     "migan_transpose_batched": (c_int, [P, P, c_int, c_int, c_int, P]),

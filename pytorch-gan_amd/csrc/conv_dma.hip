@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                     if (bias) v += bias[col];
                     float o = act_apply(v, g.act, g.slope);
                     if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
+                    if (g.omask) o = g.omask[opix * g.Co + col] > 0.f ? o : 0.f;
                     if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
                 }

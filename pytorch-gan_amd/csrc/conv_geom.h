@@ -26,6 +26,10 @@ struct ConvGeom {
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)
+    // optional ReLU-backward mask, same shape as the output: out = omask > 0 ? out : 0.  The input gradient of a conv whose INPUT is the
+    // output of a fused conv+ReLU (the frozen VGG19 of srgan.py:61,112-113: conv, ReLU, conv ...) leaves through the ReLU's derivative
+    // here, so the producing layer's backward has no separate act' pass.  LDS-DMA kernels only (launch_igemm refuses otherwise).
+    const float* omask;
     // optional per-tile output statistics for the normalisation layer behind the conv (BatchNorm / InstanceNorm):
     // stats[((group * stats_chunks + chunk) * Co + col) * 3 + {0,1,2}] = (mean, M2, count) of this tile's rows of column col,
     // combined by migan_norm_stats_from_conv (Chan) - the norm layer's own statistics pass over the tensor disappears.

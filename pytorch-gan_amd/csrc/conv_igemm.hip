@@ -1684,6 +1684,12 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     }
     static const int var_env = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
     const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
+    if (g.omask) {  // the ReLU-mask epilogue exists in the LDS-DMA kernels only: take it or tell the caller to run the two-launch form
+        for (int t = 0; t < MAX_TAPS; ++t) g.dhw[t] = ((int)g.dh[t] << 16) | ((int)g.dw[t] & 0xffff);
+        if (!fast || g.accum || g.stats) return (int)hipErrorNotSupported;
+        const int rc = launch_igemm_dma(g, A, Bw, bias, C, sk_ws, sk_bytes, st);
+        return rc == -2 ? (int)hipErrorNotSupported : rc;
+    }
     if (var != 100 && !g.accum && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
     if (var != 100 && !g.accum && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
     if (var == 0 && !g.accum && !fast && midk_ok(g)) return launch_midk(g, maxM, A, Bw, bias, C, st);
@@ -1847,7 +1853,7 @@ MIGAN_API int migan_conv2d_dropout_fwd(const float* x, const float* w_ohwi, cons
 // ------------------------------------------------------------------------------------------------
 static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
                              int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
-                             float slope, void* stream, float* sk_ws, size_t sk_bytes);
+                             float slope, void* stream, float* sk_ws, size_t sk_bytes, const float* omask = nullptr);
 MIGAN_API int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, float* dx,
                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
                                  int stride, int pad_t, int pad_l, int act, float slope, void* stream) {
@@ -1862,11 +1868,23 @@ MIGAN_API int migan_conv2d_dgrad_ws(const float* dy, const float* w_ihwo, const 
     return conv2d_dgrad_impl(dy, w_ihwo, bias, dx, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, act, slope, stream,
                              ws, ws_bytes);
 }
+// dx = conv-dgrad(dy) masked by the derivative of the ReLU that produced this conv's input: dx[i] = relu_out[i] > 0 ? dx[i] : 0 in the
+// epilogue of the input-gradient launch (relu_out: the conv's saved input [N][Hi][Wi][Ci], the output of a fused conv+ReLU or of a
+// MaxPool2d behind one) - the ReLU backward of vgg19.features[:18] (srgan/models.py:8-15) costs no pass of its own.  Returns
+// hipErrorNotSupported when the geometry is not served by the LDS-DMA kernels (caller: migan_conv2d_dgrad_ws + migan_act_bwd).
+MIGAN_API int migan_conv2d_dgrad_relu_ws(const float* dy, const float* w_ihwo, float* dx, const float* relu_out, int N, int Hi,
+                                         int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
+                                         float* ws, size_t ws_bytes, void* stream) {
+    if (!relu_out) return (int)hipErrorInvalidValue;
+    return conv2d_dgrad_impl(dy, w_ihwo, nullptr, dx, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, 0, 0.f, stream, ws,
+                             ws_bytes, relu_out);
+}
 static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* bias, float* dx, int N, int Hi, int Wi,
                              int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act,
-                             float slope, void* stream, float* sk_ws, size_t sk_bytes) {
+                             float slope, void* stream, float* sk_ws, size_t sk_bytes, const float* omask) {
     if (R * S > MAX_TAPS || stride < 1 || stride > 2) return (int)hipErrorInvalidValue;
     ConvGeom g = {};
+    g.omask = omask;
     // roles: source = dy (Ho,Wo,Co), output = dx (Hi,Wi,Ci)
     g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co; g.HiL = Ho; g.WiL = Wo;
     g.Co = Ci; g.HoF = Hi; g.WoF = Wi;

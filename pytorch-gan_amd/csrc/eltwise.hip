@@ -472,9 +472,10 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restri
         y[i] = m;
     }
 }
-// dx: first maximal element of each window (scan order h, w) receives dy (torch tie rule)
+// dx: first maximal element of each window (scan order h, w) receives dy (torch tie rule).  relu != 0: x is the output of a ReLU
+// whose backward rides here - the maximum of a window is > 0 or the whole window is 0, where ReLU' is 0
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                    float* __restrict__ dx, int H, int W, int C, size_t total) {
+                                    float* __restrict__ dx, int H, int W, int C, size_t total, int relu) {
     const int Ho = H / 2, Wo = W / 2;
     GRID_STRIDE(i, total) {
         size_t q, n;
@@ -490,6 +491,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
             if (v > m) { m = v; arg = k; }
         }
         float d = dy[i];
+        if (relu && !(m > 0.f)) d = 0.f;
         for (int k = 0; k < 4; ++k) dx[o[k]] = (k == arg) ? d : 0.f;
     }
 }
@@ -506,7 +508,17 @@ MIGAN_API int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int
     size_t total = (size_t)N * (H / 2) * (W / 2) * C;
     if (total == 0) return 0;
     MIGAN_LAUNCH(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H,
-                       W, C, total);
+                       W, C, total, 0);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+// MaxPool2d(2) backward fused with the backward of the ReLU that produced x (vgg19.features[3:5], [8:10]: ReLU, MaxPool2d)
+MIGAN_API int migan_maxpool2_relu_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                                      void* stream) {
+    size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    if (total == 0) return 0;
+    MIGAN_LAUNCH(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H,
+                       W, C, total, 1);
     HIP_LAUNCH_CHECK();
     return 0;
 }

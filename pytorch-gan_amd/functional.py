@@ -503,7 +503,15 @@ class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pads, gather, act, slope, mask=None, stats_buf=None, stats_chunks=0, stats_inst=0):
+    def forward(ctx, x, w, b, stride, pads, gather, act, slope, mask=None, stats_buf=None, stats_chunks=0, stats_inst=0,
+                relu_in=False, handed=False):
+        # relu_in: x is the output of a fused conv+ReLU whose backward THIS conv applies to its input gradient (in the epilogue of
+        # the dgrad launch where the kernel has one); handed: this conv's own ReLU backward is applied by its consumer (a conv with
+        # relu_in, or F.maxpool2(relu_in=True)) - the pair is set up by nn.Sequential for conv, ReLU, conv | MaxPool2d chains
+        # (vgg19.features[:18], srgan/models.py:8-15: eight ReLU-backward passes of 90-360 us per SRGAN step)
+        if handed and (act != ACT_RELU or mask is not None):
+            raise ValueError("conv2d: only a fused ReLU can be handed to the consumer")
+        ctx.relu_in, ctx.handed = bool(relu_in), bool(handed)
         xs = to_nhwc(x)
         w_in, b_in = w, b
         w = _plain(w)
@@ -565,11 +573,23 @@ class _Conv2d(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        xs = ctx.saved_tensors[0]
+        ctx.dx_masked = False
+        out = _Conv2d._bwd(ctx, dy)
+        dx = out[0]
+        if ctx.relu_in and dx is not None and not ctx.dx_masked:   # a path without the mask epilogue: the ReLU backward as its own pass
+            dx = _ActBwd.apply(dx, xs, ACT_RELU, 0.0) if torch.is_grad_enabled() else _act_bwd_raw(to_nhwc(dx), xs, ACT_RELU, 0.0)
+        return (dx,) + tuple(out[1:3]) + (None,) * 11
+
+    @staticmethod
+    def _bwd(ctx, dy):
         xs, w, y, mask, col = ctx.saved_tensors
         N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
         if torch.is_grad_enabled():
             return _Conv2d._backward_differentiable(ctx, dy, xs, w, y, mask)
         dy = to_nhwc(dy)
+        if ctx.handed:   # dy arrives through this conv's ReLU already (the consumer's epilogue)
+            act = ACT_NONE
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.few:   # few-pixel path (csrc/fewpix.hip): both gradients from skinny GEMMs on the stored weight / the kept im2col
             if act != ACT_NONE:
@@ -687,8 +707,16 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
         return dx, join
     if gather == GATHER_ZERO:
         skp, skb = _splitk_ws(dy, N * -(-H // stride) * -(-W // stride), Ci, Co, stride * stride)
-        check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
-                                        Co, R, S, stride, pt, pl, 0, 0.0, skp, skb, st), "conv2d_dgrad")
+        rc = 801
+        if ctx.relu_in:   # dx leaves through the derivative of the ReLU that produced xs, in the launch's epilogue
+            rc = lib.migan_conv2d_dgrad_relu_ws(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), xs.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R,
+                                                S, stride, pt, pl, skp, skb, st)
+            if rc != 801:   # hipErrorNotSupported: a geometry the LDS-DMA kernels do not take
+                check(rc, "conv2d_dgrad_relu")
+                ctx.dx_masked = True
+        if rc == 801:
+            check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo,
+                                            Co, R, S, stride, pt, pl, 0, 0.0, skp, skb, st), "conv2d_dgrad")
     elif _reflect1_applies(ctx.geom):
         # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
         check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
@@ -769,7 +797,7 @@ def _conv2d_backward_differentiable(ctx, dy, xs, w, y, mask):
     if gather != GATHER_ZERO:
         raise NotImplementedError("double backward through a reflection-padded / upsampled conv is not on the reference path")
     g = dy
-    if act != ACT_NONE:
+    if act != ACT_NONE and not ctx.handed:
         # dx = dy * act'(y): y is the (masked) layer output; where the Dropout2d mask is 0 the product with the mask below
         # is 0 whatever act' evaluates to
         g = _ActBwd.apply(g, y, act, slope)
@@ -820,7 +848,7 @@ def _stats_side(x, inst, G, P, C):
 
 
 def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=ACT_NONE, slope=0.0, dropout_mask=None,
-           stats=None):
+           stats=None, relu_in=False, handed=False):
     """`dropout_mask` (N, Co), already scaled by 1/(1-p): fuses a following nn.Dropout2d into the conv epilogue.
     `stats` ("batch" | "instance"): the conv epilogue also leaves per-tile statistics of its output for the BatchNorm /
     InstanceNorm layer that follows (picked up by `norm()`; ignored where the geometry does not support it)."""
@@ -836,9 +864,11 @@ def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=GATHER_ZERO, act=AC
         if chunks > 0:
             G = N if inst else 1
             buf = torch.empty(G * chunks * Co * 3, device=x.device, dtype=torch.float32)
-            y = _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask, buf, chunks, inst)
+            y = _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask, buf, chunks, inst,
+                              bool(relu_in), bool(handed))
             return _attach_stats(y, buf, chunks, inst, G, (Ho * Wo) if inst else N * Ho * Wo, Co)
-    return _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask)
+    return _Conv2d.apply(x, w, b, stride, pads, int(gather), int(act), float(slope), dropout_mask, None, 0, 0, bool(relu_in),
+                         bool(handed))
 
 
 class _UpConv3x3(Function):
@@ -1672,7 +1702,8 @@ def pixel_shuffle(x, r):
 
 class _MaxPool2(Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, relu_in=False):
+        ctx.relu_in = bool(relu_in)   # x is the output of a conv+ReLU that handed its ReLU backward to this pool (see _Conv2d.forward)
         xs = to_nhwc(x)
         N, C, H, W = xs.shape
         if H % 2 or W % 2:
@@ -1689,12 +1720,13 @@ class _MaxPool2(Function):
         N, C, H, W = xs.shape
         dy = to_nhwc(dy)
         dx = torch.empty_like(xs)
-        check(lib.migan_maxpool2_bwd(xs.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, C, _stream()), "maxpool2_bwd")
-        return dx
+        fn = lib.migan_maxpool2_relu_bwd if ctx.relu_in else lib.migan_maxpool2_bwd
+        check(fn(xs.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, C, _stream()), "maxpool2_bwd")
+        return dx, None
 
 
-def maxpool2(x):
-    return _MaxPool2.apply(x)
+def maxpool2(x, relu_in=False):
+    return _MaxPool2.apply(x, bool(relu_in))
 
 
 class _CatC(Function):

@@ -22,6 +22,7 @@ import torch.nn as tnn
 from . import functional as F
 
 _FUSE = True
+_RELU_HANDOFF = True   # conv, ReLU, conv | MaxPool2d: the consumer applies the ReLU backward (tests flip it for the A/B comparison)
 
 
 _PRELU_FUSE = __import__("os").environ.get("MIGAN_NO_PRELU_FUSE", "0") != "1"  # A/B knob: 1 = PReLU as its own launches
@@ -160,7 +161,7 @@ class Conv2d(tnn.Conv2d):
         return s[0], _pair(self.padding)
 
     def fused_forward(self, x, pre_pads=(0, 0, 0, 0), gather=F.GATHER_ZERO, act=F.ACT_NONE, slope=0.0, dropout=None,
-                      stats=None):
+                      stats=None, relu_in=False, handed=False):
         """`dropout`: a following training-mode Dropout2d module whose mask multiply rides in the conv epilogue.
         `stats` ("batch" / "instance"): a normalisation layer consumes this output next - its statistics are taken in the
         conv epilogue (only where everything in between is fused into this launch)."""
@@ -171,13 +172,15 @@ class Conv2d(tnn.Conv2d):
         if (gather == F.GATHER_UP2 and stride == 1 and pads == (1, 1, 1, 1)
                 and tuple(self.weight.shape[2:]) == (3, 3)):
             # phase-collapsed Upsample+Conv3x3
+            if relu_in or handed:
+                raise ValueError("the ReLU hand-off (Sequential) never reaches an Upsample+Conv pair")
             y = _wrap(F.upconv3x3(x, self.weight, self.bias, act, slope, stats if dropout is None else None))
             return dropout(y) if dropout is not None else y
         if dropout is not None and self.out_channels % 4 == 0:
             mask = _next_mask((x.shape[0], self.out_channels), dropout.p, x.device)
-            return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, mask, stats))
+            return _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, mask, stats, relu_in, handed))
         y = _wrap(F.conv2d(x, self.weight, self.bias, stride, pads, gather, act, slope, None,
-                           stats if dropout is None else None))
+                           stats if dropout is None else None, relu_in, handed))
         return dropout(y) if dropout is not None else y
 
     def forward(self, x):
@@ -303,11 +306,11 @@ class PixelShuffle(tnn.PixelShuffle):
 
 
 class MaxPool2d(tnn.MaxPool2d):
-    def forward(self, x):
+    def forward(self, x, relu_in=False):
         if (_pair(self.kernel_size) != (2, 2) or _pair(self.stride) != (2, 2) or _pair(self.padding) != (0, 0)
                 or _pair(self.dilation) != (1, 1) or self.ceil_mode or self.return_indices):
             raise ValueError("MaxPool2d: only kernel 2 / stride 2 (VGG19) is on the reference path")
-        return _wrap(F.maxpool2(x))
+        return _wrap(F.maxpool2(x, relu_in))
 
 
 # ---- dropout: device Philox stream for training runs, injected host masks for parity tests ---------
@@ -533,8 +536,15 @@ class Sequential(tnn.Sequential):
                 x = m(x)
             return x if res is None else x + res
         i, n = 0, len(mods)
+        # conv, ReLU, conv | MaxPool2d (vgg19.features[:18], srgan/models.py:8-15): the ReLU backward of the first conv is applied by
+        # its consumer - in the epilogue of the second conv's input-gradient launch, or inside the pool's backward - instead of a
+        # pass of its own.  relu_hand: x is the output of a conv+ReLU that skips its own ReLU backward; the next module MUST take it.
+        relu_hand = False
         while i < n:
             m = mods[i]
+            if relu_hand and type(m) is MaxPool2d:
+                x, relu_hand, i = m(x, relu_in=True), False, i + 1
+                continue
             # -- [Upsample] [ZeroPad2d | ReflectionPad2d] Conv2d [act] ------------------------------------
             j, gather, pre = i, F.GATHER_ZERO, (0, 0, 0, 0)
             if isinstance(mods[j], Upsample) and j + 1 < n:
@@ -556,9 +566,15 @@ class Sequential(tnn.Sequential):
                     stats = "instance"
                 elif k < n and type(mods[k]) is BatchNorm2d and (mods[k].training or not mods[k].track_running_stats):
                     stats = "batch"
-                x = mods[j].fused_forward(x, pre, gather, act, slope, drop, stats)
+                rin, relu_hand = relu_hand, False
+                if (_RELU_HANDOFF and act == F.ACT_RELU and drop is None and stats is None and k < n and x.dim() == 4
+                        and type(mods[k]) in (Conv2d, MaxPool2d)):
+                    relu_hand = True    # mods[k] is next in this loop: a Conv2d reached with no pad / upsample module in front, or the pool
+                x = mods[j].fused_forward(x, pre, gather, act, slope, drop, stats, rin, relu_hand)
                 i = k
                 continue
+            if relu_hand:
+                raise RuntimeError("Sequential: a handed-off ReLU backward was not taken")
             # -- Linear [LeakyReLU | ReLU | Tanh | Sigmoid] ------------------------------------------------
             if type(m) is Linear and i + 1 < n and _act_of(mods[i + 1]) is not None and type(mods[i + 1]) in _OURS \
                     and x.dim() == 2:

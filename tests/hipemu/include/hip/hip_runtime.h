@@ -65,7 +65,7 @@ struct dim3 {
 typedef struct ihipStream_t* hipStream_t;
 typedef struct ihipGraph_t* hipGraph_t;
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719, hipErrorNotSupported = 801 };
 static inline hipError_t hipGetLastError() { return hipemu::last_error(); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 

@@ -707,3 +707,13 @@ extern "C" __attribute__((visibility("default"))) int run_dead(int* out) {
     out = torch.zeros(2, dtype=torch.int32)
     assert lib.run_dead(ctypes.c_void_p(out.data_ptr())) != 0
     assert b"deadlock" in lib.hipemu_last_message()
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 8, 32, 64), (1, 6, 8, 32, 40)], ids=["32-64ch", "k-tail-40ch"])
+def test_relu_handoff_on_the_execution_model(emu, shape):
+    """conv, ReLU, conv | MaxPool2d chains (vgg19.features[:18]): the ReLU backward inside the consumer's input-gradient epilogue
+    (igemm_dma_kernel's `omask`) / the pool's backward - body of test_ops_gpu.py::test_relu_backward_handed_to_the_consumer."""
+    import pytorch_gan_amd as pg
+
+    lib = _run_gpu_test_body("test_ops_gpu", "test_relu_backward_handed_to_the_consumer", pg, shape)
+    assert lib.hipemu_launch_count(b"igemm_dma_kernel") > 0

@@ -648,6 +648,52 @@ def test_sequential_bn_shuffle_prelu_equals_unfused(pg):
         assert_close(ga, gb, 5e-5, "gradient of " + k)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 32, 40)], ids=["64-128ch", "k-tail-40ch"])
+def test_relu_backward_handed_to_the_consumer(pg, shape):
+    """vgg19.features[:18] (srgan/models.py:8-15): conv ReLU conv ReLU MaxPool conv ReLU.  nn.Sequential hands the ReLU backward of a
+    conv to its consumer - the epilogue of the next conv's input-gradient launch (migan_conv2d_dgrad_relu_ws) or the pool's backward
+    (migan_maxpool2_relu_bwd).  Same input / weight gradients as torch on the host, bit-identical to the un-handed form, and no
+    act_bwd_kernel launch for the handed layers."""
+    import copy
+
+    import torch.nn as tnn
+
+    from pytorch_gan_amd import nn as gnn
+
+    N, H, W, C1, C2 = shape
+    torch.manual_seed(3)
+    ref = tnn.Sequential(tnn.Conv2d(C1, C1, 3, 1, 1), tnn.ReLU(inplace=True), tnn.Conv2d(C1, C2, 3, 1, 1), tnn.ReLU(inplace=True),
+                         tnn.MaxPool2d(2, 2), tnn.Conv2d(C2, C2, 3, 1, 1), tnn.ReLU(inplace=True))
+    x = torch.randn(N, C1, H, W)
+    dy = torch.randn(N, C2, H // 2, W // 2)
+    xr = x.clone().requires_grad_(True)
+    ref(xr).backward(dy)
+    outs = {}
+    for hand in (True, False):
+        m = pg.swap(copy.deepcopy(ref)).to(DEV)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        old = gnn._RELU_HANDOFF
+        gnn._RELU_HANDOFF = hand
+        try:
+            with Launches() as n:
+                y = m(xg)
+                y.backward(dy.to(DEV))
+                counts = (n("act_bwd"), n("maxpool2_bwd_kernel"))   # act_bwd_kernel | act_bwd_colsum_kernel (trainable convs with a bias)
+        finally:
+            gnn._RELU_HANDOFF = old
+        outs[hand] = (y.detach().cpu().clone(), xg.grad.cpu().clone(), [p.grad.cpu().clone() for p in m.parameters()])
+        # three ReLUs: handed -> only the last one (consumed by the loss) runs its own backward pass
+        assert counts == ((1, 1) if hand else (3, 1)), counts
+    # against torch on the host: a pre-activation within rounding of 0 may take the other side of the ReLU (one element in ~1e5)
+    assert_close(outs[True][1], xr.grad, 5e-3, "dx vs torch")
+    for g, p in zip(outs[True][2], ref.parameters()):
+        assert_close(g, p.grad, 5e-3, "parameter gradient vs torch")
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    for a, b in zip(outs[True][2], outs[False][2]):   # bias gradients: column sums from another kernel (no act_bwd_colsum pass to ride in)
+        assert torch.equal(a, b) if a.dim() == 4 else rel_fro(a, b) <= TOL_BIAS
+
+
+
 @pytest.mark.parametrize("cfg", [((3, 3, 3, 3), 1), ((1, 1, 1, 1), 1), ((1, 1, 0, 0), 0), ((0, 0, 0, 0), 2), ((2, 2, 1, 1), 2)])
 def test_gather2d(pg, cfg):
     pads, mode = cfg
