@@ -1890,10 +1890,24 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* 
     g.Co = Ci; g.HoF = Hi; g.WoF = Wi;
     g.ostep = stride; g.istride = 1; g.gather = GATHER_ZERO; g.ldw = R * S * Co;
     g.ncls = stride * stride; g.act = act; g.slope = slope;
+    // Class order = launch order (blockIdx.z): the parity classes of a 3x3 / stride-2 conv have 1, 2, 2 and 4 taps; the longest goes
+    // FIRST, so the short classes fill the tail of the launch instead of the 4-tap class starting last (longest-processing-time-first)
+    int order[4] = {0, 1, 2, 3}, ntaps[4] = {0, 0, 0, 0};
+    for (int q = 0; q < stride * stride; ++q) {
+        const int ph = q / stride, pw = q % stride;
+        int nh = 0, nw = 0;
+        for (int r = 0; r < R; ++r) nh += (ph + pad_t - r) % stride == 0;
+        for (int s = 0; s < S; ++s) nw += (pw + pad_l - s) % stride == 0;
+        ntaps[q] = nh * nw;
+    }
+    for (int a = 1; a < stride * stride; ++a)   // stable insertion sort, descending
+        for (int b = a; b > 0 && ntaps[order[b]] > ntaps[order[b - 1]]; --b) {
+            const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+        }
     int tp = 0;
-    for (int ph = 0; ph < stride; ++ph)
-        for (int pw = 0; pw < stride; ++pw) {
-            int c = ph * stride + pw;
+    for (int c = 0; c < stride * stride; ++c) {
+        {
+            const int ph = order[c] / stride, pw = order[c] % stride;
             g.oh0[c] = ph; g.ow0[c] = pw;
             g.Ho[c] = Hi > ph ? (Hi - ph + stride - 1) / stride : 0;
             g.Wo[c] = Wi > pw ? (Wi - pw + stride - 1) / stride : 0;
@@ -1912,6 +1926,7 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* 
             }
             g.ntap[c] = tp - g.tapbeg[c];
         }
+    }
     return launch_igemm(g, dy, w_ihwo, bias, dx, (hipStream_t)stream, sk_ws, sk_bytes);
 }
 

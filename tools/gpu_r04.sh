@@ -187,8 +187,30 @@ task_fifth() {
   task_prof r4e wgan_gp:graph
 }
 
+# bench one workload:  bl <outfile> <workload> <steps> [ENV=VAL ...]  -> "img/s ms/step min-block"
+bl() {
+  local out=$1 w=$2 k=$3; shift 3
+  echo "== $w $*" >> $out
+  env "$@" timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$out.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $out
+}
+
+task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), longest-class-first strided dgrad
+  local O=gpurun_out/r4f; mkdir -p $O
+  timeout 120 ./tools/abi_check.bin mlp > $O/abi_check.txt 2>&1
+  grep -v "^migan" $O/abi_check.txt | cut -c1-260
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_ops_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan or relu_backward or srgan or maxpool or conv2d_strided or test_conv2d" --durations=5 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  bl $O/bench.txt wgan_gp 200
+  bl $O/bench.txt srgan 4
+  bl $O/bench.txt cyclegan 4
+  bl $O/bench.txt dcgan 50
+  cat $O/bench.txt
+  task_prof r4f wgan_gp:graph srgan
+}
+
 t=${1:-}; shift || true
 case "$t" in
+  sixth) task_sixth "$@" ;;
   fifth) task_fifth "$@" ;;
   fourth) task_fourth "$@" ;;
   third) task_third "$@" ;;
