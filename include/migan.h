@@ -201,7 +201,7 @@ int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* w
  *     (migan_norm_bwd / migan_norm_bwd_apply / migan_act_bwd_colsum, csum argument); any wgrad path accepts them.
  *   db_slabs == NULL: the column-tile-0 workgroups of the MFMA wgrad sum their dy tiles (already in LDS as the A
  *     operand) - only where migan_conv2d_wgrad_fuses_bias() returns 1; measured no faster than migan_colsum on MI355X
- *     (those workgroups become the tail of the launch), so the host mirror uses it only with MIGAN_FUSE_BIAS=1. */
+ *     (those workgroups become the tail of the launch), so the host mirror leaves it off (functional._FUSE_BIAS). */
 int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int gather);
 /* Input gradient of nn.ReflectionPad2d(1) -> nn.Conv2d(Ci, Co, 3) (cyclegan/models.py:26-35) straight into
  * dx [N][H][W][Ci] from dy [N][H][W][Co], w_ihwo [Ci][3][3][Co]: the ordinary pad-1 dgrad plus a second small launch

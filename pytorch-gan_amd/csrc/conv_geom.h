@@ -79,6 +79,6 @@ struct WgradGeom {
     // already in LDS) into bpart[cls*splits + split][Co]; the reduction launch adds the slabs.  NULL: not requested.
     // Measured on MI355X: no faster than the separate column-sum launches (the column-0 blocks become the critical
     // path of a one-wave launch; spreading the rows over all column tiles costs every block more than it saves), so
-    // the host mirror leaves it off by default (MIGAN_FUSE_BIAS=1 enables it).
+    // the host mirror leaves it off (functional._FUSE_BIAS).
     float* bpart;
 };

@@ -28,7 +28,7 @@ def _stream():
 # 0 off (default), 1 always, n > 1: only for gradients of at least n elements.  Measured (profiles/r02_ab.txt): with the
 # round-1 split-K plan the wave tails of a layer's wgrad and dgrad launches filled each other (+2.5 % on the CycleGAN step);
 # with the balanced plan the tails are gone (+0.3 %), and the captured DCGAN step is 4 % slower with the two branches.
-_OVERLAP_WGRAD = int(__import__("os").environ.get("MIGAN_WGRAD_OVERLAP", "0"))
+_OVERLAP_WGRAD = 0   # wgrad on a side stream beside dgrad: measured +0.3 % CycleGAN, -4 % DCGAN (profiles/r02_ab.txt); tests flip it
 _SIDE_STREAMS = {}
 
 
@@ -182,7 +182,7 @@ def _ws(nbytes, ref):
 _DIRECT_GRAD = True
 _WEIGHT_CACHE = True   # only effective inside weight_cache_scope()
 # bias gradient inside the wgrad launches (include/migan.h): measured no faster than the column-sum launches -> opt-in
-_FUSE_BIAS = __import__("os").environ.get("MIGAN_FUSE_BIAS", "0") == "1"
+_FUSE_BIAS = False
 
 
 def _bias_out(param, C, ref):
@@ -257,11 +257,11 @@ def _packed(param, w, kind, make):
     return t
 
 
-_BATCH_PACKS = __import__("os").environ.get("MIGAN_BATCH_PACKS", "1") == "1"  # A/B knob: 0 = one permute launch per pack
+_BATCH_PACKS = True   # False = one permute launch per pack
 # only weights up to this many elements go through the plan: the plan saves launch latency, and a large pack written at the
 # start of the step has left the MALL by the time its conv runs (pix2pix, 54 M parameters: 8.65 -> 9.50 ms with every
 # weight planned, profiles/r02_ab.txt)
-_BATCH_PACKS_MAX = int(__import__("os").environ.get("MIGAN_BATCH_PACKS_MAX", str(1 << 20)))
+_BATCH_PACKS_MAX = 1 << 20
 
 
 class _PackPlan:
@@ -378,7 +378,7 @@ def _colsum(x2d_ptr_tensor, P, C, slot=None):
     return out if slot is None else None
 
 
-_COLSUM_FUSE = __import__("os").environ.get("MIGAN_COLSUM_FUSE", "1") == "1"  # A/B knob
+_COLSUM_FUSE = True
 
 
 def _attach_colsum(t, slabs, nslab, C):
@@ -671,7 +671,7 @@ class _Conv2d(Function):
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-_RING_OVERLAP = __import__("os").environ.get("MIGAN_RING_OVERLAP", "1") == "1"  # A/B knob
+_RING_OVERLAP = True
 
 
 def _reflect1_applies(geom):
@@ -784,7 +784,7 @@ def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
     return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-_REFLECT1 = __import__("os").environ.get("MIGAN_REFLECT1", "1") == "1"  # A/B knob: 0 = padded extent + fold pass
+_REFLECT1 = True   # False = padded extent + fold pass
 
 
 def _conv2d_backward_differentiable(ctx, dy, xs, w, y, mask):
@@ -827,8 +827,8 @@ _Conv2d._backward_differentiable = staticmethod(_conv2d_backward_differentiable)
 # Statistics of the following norm layer from the conv epilogue: implemented, parity-tested, and measured SLOWER than the
 # norm layer's own statistics pass (profiles/r02_ab.txt: DCGAN step 3.93 -> 4.12 ms, CycleGAN 173.3 -> 174.5 ms; the
 # two-pass per-tile reduction in the epilogue of every conv workgroup costs more than one streaming pass at 5 TB/s saves),
-# so it is opt-in: MIGAN_CONV_STATS=1.
-_CONV_STATS = __import__("os").environ.get("MIGAN_CONV_STATS", "0") == "1"
+# so it is off (functional._CONV_STATS; the parity tests of the epilogue flip it).
+_CONV_STATS = False
 
 
 def _attach_stats(y, buf, chunks, inst, G, P, C):
@@ -1091,7 +1091,7 @@ def _mm_nt_raw(a, b, bias, act=ACT_NONE, slope=0.0):
     return out
 
 
-_SKINNY = __import__("os").environ.get("MIGAN_SKINNY", "1") == "1"  # A/B knob
+_SKINNY = True
 
 
 class _MMNN(Function):

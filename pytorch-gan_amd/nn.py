@@ -25,8 +25,8 @@ _FUSE = True
 _RELU_HANDOFF = True   # conv, ReLU, conv | MaxPool2d: the consumer applies the ReLU backward (tests flip it for the A/B comparison)
 
 
-_PRELU_FUSE = __import__("os").environ.get("MIGAN_NO_PRELU_FUSE", "0") != "1"  # A/B knob: 1 = PReLU as its own launches
-_SHUFFLE_FUSE = __import__("os").environ.get("MIGAN_NO_SHUFFLE_FUSE", "0") != "1"  # A/B knob: 1 = PixelShuffle as its own launches
+_PRELU_FUSE = True     # False = PReLU as its own launches
+_SHUFFLE_FUSE = True   # False = PixelShuffle as its own launches
 
 
 def set_fusion(enabled):
@@ -416,8 +416,8 @@ def _numel(shape):
     return n
 
 
-_BATCH_MASKS = __import__("os").environ.get("MIGAN_BATCH_MASKS", "1") == "1"  # A/B knob
-_DROPOUT_FUSE = __import__("os").environ.get("MIGAN_DROPOUT_FUSE", "1") == "1"   # nn.Dropout inside the small InstanceNorm launch
+_BATCH_MASKS = True
+_DROPOUT_FUSE = True   # nn.Dropout inside the small InstanceNorm launch
 
 
 def _next_mask(shape, p, device):

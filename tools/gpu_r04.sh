@@ -194,6 +194,16 @@ bl() {
   env "$@" timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$out.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $out
 }
 
+# whole-step A/B on ONE box against the tree of the round's start (ab_base/ = git archive c76fc2b + its built library; git-ignored,
+# travels with the snapshot):  ab <outfile> <workload> <steps> [reps]   -> alternating base / head lines
+ab() {
+  local out=$1 w=$2 k=$3 reps=${4:-2}
+  for r in $(seq $reps); do
+    (cd ab_base && echo "== base $w" >> $R/$out && timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$R/$out.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $R/$out)
+    bl $out $w $k
+  done
+}
+
 task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), longest-class-first strided dgrad
   local O=gpurun_out/r4f; mkdir -p $O
   timeout 120 ./tools/abi_check.bin mlp > $O/abi_check.txt 2>&1
