@@ -30,6 +30,7 @@ struct MlpFused {
     float* ws;        // two [RB][maxN] activation buffers (forward without a graph), or the save buffer (see MlpSave)
     int saving;       // 1: every layer's output (and normalised pre-affine value + invstd of the BatchNorm layers) is kept for mlp_fused_bwd
     int layer;        // the layer this launch computes
+    int fuse0;        // 1: the launch of layer 1 computes layer 0 on the fly (see mlp_fused_fwd_kernel) and layer 0 has no launch
     unsigned* tickets;  // one per column tile, zero at rest (BatchNorm1d layers: the last row-group workgroup normalises the column block)
     MlpLayer L[MF_MAX_LAYERS];
 };
@@ -129,7 +130,31 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_fwd_kernel(const MlpFuse
         const int kbeg = wave * klen < K ? wave * klen : K, kend = (wave + 1) * klen < K ? (wave + 1) * klen : K;
         const int arow = rg0 * 16 + rr < B ? rg0 * 16 + rr : B - 1;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (kbeg < kend) acc = mf_nt_partial(in + (size_t)arow * K, Ly.W + (size_t)col * K, kbeg, kend, kq);
+        if (p.fuse0 && l == 1) {
+            // Layer 0 (Linear + activation, no BatchNorm, <= 128 inputs, <= 256 outputs: 100 -> 128 of wgan_gp.py:55) inside the launch of
+            // layer 1: K = N_0 <= 256 gives every K-slice wave exactly 16 k values = 16 layer-0 columns, whose 16 x 16 tile the wave
+            // computes itself with the operands SWAPPED - C' = W_0 tile . X^T leaves lane (rr, kq) with h_0[row rr][column kbeg + 4 kq + r],
+            // which is the A fragment of the product with W_1 (no LDS, no store / reload of h_0).  W_1's fragment is fetched in the same
+            // round of loads as X and W_0, so the fused launch costs what layer 1 alone did and layer 0's launch (5.8 us) is gone.
+            if (kbeg < kend) {
+                const MlpLayer& L0 = p.L[0];
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(Ly.W + (size_t)col * K + kbeg + 4 * kq);
+                const f32x4 bv = L0.b ? *reinterpret_cast<const f32x4*>(L0.b + kbeg + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 h = mf_nt_partial(L0.W + (size_t)(kbeg + rr) * L0.K, p.x + (size_t)arow * L0.K, 0, L0.K, kq);
+                f32x4 a;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[r] = act_apply(h[r] + bv[r], L0.act, L0.slope);
+                    acc = mf_mfma(a[r], wv[r], acc);
+                }
+                if (p.saving && t == 0) {   // the backward reads h_0: the column-tile-0 workgroup of each row group keeps it
+                    const int row = rg0 * 16 + rr;
+                    *reinterpret_cast<f32x4*>(p.ws + Sp.h + (size_t)row * K + kbeg + 4 * kq) = row < B ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else if (kbeg < kend) {
+            acc = mf_nt_partial(in + (size_t)arow * K, Ly.W + (size_t)col * K, kbeg, kend, kq);
+        }
         if (wave > 0) part[(wave - 1) * 64 + lane] = acc;
         __syncthreads();
         if (wave == 0) {
@@ -661,8 +686,11 @@ MIGAN_API int migan_mlp_fused_fwd(const float* x, float* y, int B, int nlayers, 
         p.maxN = p.L[l].N > p.maxN ? p.L[l].N : p.maxN;
         if (p.L[l].bn && (tickets == nullptr || (p.L[l].N + 15) / 16 > MF_TICKETS)) return (int)hipErrorInvalidValue;
     }
+    // layer 0 inside the launch of layer 1 (see the kernel): Linear + activation without BatchNorm, <= 128 inputs, 16 .. 256 outputs
+    p.fuse0 = (nlayers >= 2 && !p.L[0].bn && p.L[0].N % 16 == 0 && p.L[0].N <= 256 && p.L[0].K <= 128 && p.L[1].K == p.L[0].N) ? 1 : 0;
     for (int l = 0; l < nlayers; ++l) {
         if (only && l != only - 1) continue;
+        if (!only && l == 0 && p.fuse0) continue;
         p.layer = l;
         MIGAN_LAUNCH(mlp_fused_fwd_kernel, dim3((p.L[l].N + 15) / 16 * (p.RB / 16)), dim3(MF_THREADS), 0, (hipStream_t)stream, p);
         HIP_LAUNCH_CHECK();

@@ -63,6 +63,9 @@ SHAPES = {
         ("vgg 64->64 @384", 16, 64, 384, 384, 64, 3, 1, 1, 0),
         ("vgg 256->256 @96", 16, 256, 96, 96, 256, 3, 1, 1, 0),
         ("D 512->512 s2 @48", 16, 512, 48, 48, 512, 3, 2, 1, 0),
+        ("D 64->64 s2 @384", 16, 64, 384, 384, 64, 3, 2, 1, 0),
+        ("D 128->128 s2 @192", 16, 128, 192, 192, 128, 3, 2, 1, 0),
+        ("D 256->256 s2 @96", 16, 256, 96, 96, 256, 3, 2, 1, 0),
     ],
 }
 

@@ -204,6 +204,30 @@ ab() {
   done
 }
 
+task_seventh() {   # MLP layer 0 inside layer 1's launch; tiles-per-workgroup sweep on the SRGAN trunk; longest-class-first dgrad vs the round-start tree
+  local O=gpurun_out/r4g; mkdir -p $O
+  timeout 120 ./tools/abi_check.bin mlp > $O/abi_check.txt 2>&1
+  grep -v "^migan" $O/abi_check.txt | cut -c1-260
+  timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  bl $O/bench.txt wgan_gp 200
+  for tpw in 0 3 2 0 3; do
+    echo "== res 64->64 @96 MIGAN_DMA_TPW=$tpw" >> $O/micro.txt
+    MIGAN_DMA_TPW=$tpw timeout 200 python tools/conv_microbench.py --shapes srgan --match "res 64" --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep "res 64" >> $O/micro.txt
+  done
+  echo "== strided dgrad, round-start tree (classes in parity order)" >> $O/micro.txt
+  (cd ab_base && timeout 200 python tools/conv_microbench.py --shapes srgan --match " s2" --only dgrad --iters 10 --repeat 3 2>&1 | grep " s2" >> $R/$O/micro.txt)
+  (cd ab_base && timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "d128\|d256" --only dgrad --iters 10 --repeat 3 2>&1 | grep " s2" >> $R/$O/micro.txt)
+  echo "== strided dgrad, HEAD (longest class first)" >> $O/micro.txt
+  timeout 200 python tools/conv_microbench.py --shapes srgan --match " s2" --only dgrad --iters 10 --repeat 3 2>&1 | grep " s2" >> $O/micro.txt
+  timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "d128\|d256" --only dgrad --iters 10 --repeat 3 2>&1 | grep " s2" >> $O/micro.txt
+  cat $O/micro.txt
+  ab $O/bench.txt dcgan 50 2
+  ab $O/bench.txt srgan 4 1
+  ab $O/bench.txt cyclegan 4 1
+  cat $O/bench.txt
+}
+
 task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), longest-class-first strided dgrad
   local O=gpurun_out/r4f; mkdir -p $O
   timeout 120 ./tools/abi_check.bin mlp > $O/abi_check.txt 2>&1
@@ -220,6 +244,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  seventh) task_seventh "$@" ;;
   sixth) task_sixth "$@" ;;
   fifth) task_fifth "$@" ;;
   fourth) task_fourth "$@" ;;
