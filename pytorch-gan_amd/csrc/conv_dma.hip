@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                                                              const float* __restrict__ Bw,
                                                              const float* __restrict__ bias, float* __restrict__ C,
                                                              unsigned a_bytes, unsigned b_bytes, int splits = 1,
-                                                             float* __restrict__ sk_ws = nullptr, int tpw = 1) {
+                                                             float* __restrict__ sk_ws = nullptr) {
     constexpr int CPR = BK / 4;                 // 16-B chunks per row
     constexpr int RPI = 64 / CPR;               // rows per DMA instruction (1 KiB)
     constexpr int SH = CPR == 8 ? 1 : 2;        // swizzle: f(row) = (row >> SH) & (CPR - 1)
@@ -64,11 +64,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     __shared__ __attribute__((aligned(16))) float smem[NS * ST_FL];
 
     const int tid = threadIdx.x;
-    // tpw > 1 (never with SPLITK): the workgroup works through tpw consecutive M-tiles.  A launch whose tile count is a small multiple of
-    // the CU count just above the resident slots (SRGAN's 64 -> 64 trunk at 96x96: 2304 64x64 tiles = 9 per CU on 8 slots) otherwise ends in
-    // a round of lone, latency-bound tiles; 768 workgroups x 3 tiles are all resident from the start and every CU gets the same work.
-    for (int it = 0; it < tpw; ++it) {
-    const int cls = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, bx = (int)blockIdx.x * tpw + it, by = blockIdx.y;
+    const int cls = SPLITK ? (int)blockIdx.z / splits : (int)blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
     const int slice = SPLITK ? (int)blockIdx.z - cls * splits : 0;
     const int Ho = g.Ho[cls], Wo = g.Wo[cls];
     const int M = g.N * Ho * Wo;
@@ -344,7 +340,6 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             }
         }
     }
-    }   // tile loop (the last K-tile ended in a barrier: both LDS stages are free for the next tile's prologue)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,15 +349,9 @@ template <int BM, int BN, int WM, int WN, int BK, int OCC>
 static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, unsigned a_bytes,
                           unsigned b_bytes, long maxM, hipStream_t st) {
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    // tiles per workgroup (see the kernel): only where every workgroup gets the same whole number of tiles and the grid still gives every
-    // CU >= 2 workgroups; MIGAN_DMA_TPW forces a count (A/B knob)
-    int tpw = 1;
-    {
-        static const int tpw_env = getenv("MIGAN_DMA_TPW") ? atoi(getenv("MIGAN_DMA_TPW")) : 0;
-        const long T = (long)grid.x * grid.y * grid.z;
-        if (tpw_env > 1 && grid.x % tpw_env == 0 && T <= 16L * 256) tpw = tpw_env;
-        if (tpw > 1) grid.x /= tpw;
-    }
+    // (Several consecutive M-tiles per workgroup - 768 resident workgroups x 3 tiles for the 2304 64x64 tiles of SRGAN's 64 -> 64 trunk
+    // at 96x96 instead of 9 tiles per CU on 8 slots - were measured and rejected: 122 vs 114 us forward, 116 vs 110 us input gradient,
+    // profiles/r04_ab.txt; the loop also cost every variant 8-14 registers.)
     bool tapin = true;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     static const int tapin_env = getenv("MIGAN_DMA_TAPIN") ? atoi(getenv("MIGAN_DMA_TAPIN")) : 1;
@@ -372,7 +361,7 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
 #define DMA_LAUNCH(TI_, KT_)                                                                                         \
     MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
-                       a_bytes, b_bytes, 1, (float*)nullptr, tpw)
+                       a_bytes, b_bytes)
     if (tapin) {
         if (ktail) DMA_LAUNCH(4, true); else DMA_LAUNCH(4, false);
     } else {
