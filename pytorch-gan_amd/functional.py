@@ -251,10 +251,36 @@ def _packed(param, w, kind, make):
     cache = param.__dict__.setdefault("_migan_pack", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == stamp:
+        if _TWO_STREAMS and len(hit) > 2 and hit[2] is not None:   # made on the other stream of a forked step body: wait for it
+            cur = torch.cuda.current_stream(w.device)
+            if hit[2][0] != cur.cuda_stream:
+                cur.wait_event(hit[2][1])
         return hit[1]
     t = make()
-    cache[kind] = (stamp, t)
+    made = None
+    if _TWO_STREAMS and on_device(w):
+        cur = torch.cuda.current_stream(w.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        made = (cur.cuda_stream, ev)
+    cache[kind] = (stamp, t, made)
     return t
+
+
+# > 0 while a step body runs two halves on two streams (steps.dcgan_step: the discriminator update underneath the generator's
+# backward): a weight pack made inside that region carries the event of its launch, and a hit from the other stream waits for it.
+# Packs made before the fork (the step's multi-tensor plan launch, the forwards in front of the fork) need no event.
+_TWO_STREAMS = 0
+
+
+@__import__("contextlib").contextmanager
+def two_streams():
+    global _TWO_STREAMS
+    _TWO_STREAMS += 1
+    try:
+        yield
+    finally:
+        _TWO_STREAMS -= 1
 
 
 _BATCH_PACKS = True   # False = one permute launch per pack

@@ -68,17 +68,25 @@ def _sync_bn(s):
 _ONES = {}
 
 
-def _backward(loss):
-    """loss.backward() with the root gradient from a cached ones scalar: autograd otherwise makes it with ones_like - one more fill
-    launch (and graph node) per backward call, two to three per training step."""
+def _root_grad(loss):
+    """The cached ones tensor `_backward` seeds loss.backward() with, or None while a capture is in progress and none is cached yet."""
     key = (loss.device, loss.dtype, tuple(loss.shape))
     one = _ONES.get(key)
     if one is None:
-        if torch.cuda.is_current_stream_capturing():   # memory made during a capture belongs to the graph's pool: do not keep it
-            loss.backward()
-            return
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():   # memory made during a capture belongs to the graph's pool: do not keep it
+            return None
         one = _ONES[key] = torch.ones(loss.shape, device=loss.device, dtype=loss.dtype)
-    loss.backward(one)
+    return one
+
+
+def _backward(loss):
+    """loss.backward() with the root gradient from a cached ones scalar: autograd otherwise makes it with ones_like - one more fill
+    launch (and graph node) per backward call, two to three per training step."""
+    one = _root_grad(loss)
+    if one is None:
+        loss.backward()
+    else:
+        loss.backward(one)
 
 
 def half_sum(a, b):
@@ -101,6 +109,25 @@ def _labels(s, shape, device):
     return s.labels[key]
 
 
+# The discriminator update of dcgan.py:170-183 needs from the generator update only `gen_imgs.detach()` (made by the forward) and the
+# discriminator as the generator's loss left it (its weights untouched - it is frozen there - and its BatchNorm running statistics after
+# the D(gen) forward): nothing of the generator's BACKWARD.  With one process per GPU and no collective in the step, its forward and
+# backward - ~65 launches of 5-30 us on 2 x 128 images of at most 32 x 32, which cannot fill the chip - run on a second HIP stream
+# UNDERNEATH the generator's backward (six MFMA launches of 150-330 us and the large BatchNorm passes); optimizer_D.step() follows the
+# join, so nothing reads a weight that is being updated.  Same kernels in the same order per stream: results are bit-identical to the
+# sequential order (tests flip `_OVERLAP_D`).  Inside a captured step the fork / join are edges of the one hipGraph.
+_OVERLAP_D = True
+_D_STREAMS = {}
+
+
+def _d_stream(device):
+    main = torch.cuda.current_stream(device)
+    key = (device.index, main.cuda_stream)
+    if key not in _D_STREAMS:
+        _D_STREAMS[key] = torch.cuda.Stream(device)
+    return main, _D_STREAMS[key]
+
+
 @_scoped
 def dcgan_step(s, real_imgs, z):
     """dcgan.py:143-183 (and gan.py:121-161)."""
@@ -110,8 +137,28 @@ def dcgan_step(s, real_imgs, z):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce(s.D(gen), valid)
+    overlap = (_OVERLAP_D and s.skip and isinstance(s.dp, LocalStepper) and real_imgs.is_cuda and not _sync_bn(s))
+    if overlap:
+        main, side = _d_stream(real_imgs.device)
+        _root_grad(g_loss)       # both backward calls are seeded from this tensor: it exists before the fork
+        side.wait_stream(main)   # fork: everything up to the generator's loss
+        with F.two_streams():
+            with torch.cuda.stream(side):
+                d_loss = _dcgan_d_half(s, real_imgs, gen, valid, fake)
+            _backward(g_loss)
+        s.dp.step(s.opt_G)
+        main.wait_stream(side)   # join
+        s.dp.step(s.opt_D)
+        return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
     _backward(g_loss)
     s.dp.step(s.opt_G)
+    d_loss = _dcgan_d_half(s, real_imgs, gen, valid, fake)
+    s.dp.step(s.opt_D)
+    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+
+
+def _dcgan_d_half(s, real_imgs, gen, valid, fake):
+    """dcgan.py:170-181: optimizer_D.zero_grad() ... d_loss.backward() (the optimiser step is the caller's)."""
     s.opt_D.zero_grad()
     if _PAIR_D and real_imgs.shape == gen.shape and not _sync_bn(s):
         # D(real) and D(fake) of dcgan.py:176-177 as ONE pass over cat(real, fake): per-half BatchNorm statistics (and
@@ -132,8 +179,7 @@ def dcgan_step(s, real_imgs, z):
         fake_loss = s.bce(s.D(gen.detach()), fake)
         d_loss = half_sum(real_loss, fake_loss)
     _backward(d_loss)
-    s.dp.step(s.opt_D)
-    return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
+    return d_loss
 
 
 gan_step = dcgan_step

@@ -138,6 +138,49 @@ def test_dcgan_graph_replay_equals_eager():
         assert torch.allclose(p, q, rtol=0, atol=2 * LR)
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+def test_dcgan_discriminator_half_on_a_second_stream_is_bit_identical(use_graph):
+    """steps.dcgan_step runs the discriminator update (dcgan.py:170-181) on a second HIP stream underneath the generator's backward
+    and steps its optimiser after the join.  Same kernels in the same order per stream: losses, weights, BatchNorm buffers and Adam
+    state after five steps are bit-identical to the sequential order (steps._OVERLAP_D = False), eagerly and as one captured hipGraph
+    with the fork and join inside it.  Injected dropout masks are off (p = 0) so both runs draw nothing."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import graph, steps
+    from pytorch_gan_amd.dp import LocalStepper
+
+    _seed(0)
+    base = S.make_dcgan(32)
+    for m in base.D.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    _seed(5)
+    imgs = (torch.rand(16, 1, 32, 32) * 2 - 1).to(DEV)
+    zs = torch.randn(6, 16, 100).to(DEV)
+    res = {}
+    old = steps._OVERLAP_D
+    try:
+        for overlap in (True, False):
+            steps._OVERLAP_D = overlap
+            st = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D))
+            z_static = zs[0].clone()
+            runner = graph.StepRunner(lambda: steps.dcgan_step(st, imgs, z_static), LocalStepper(), use_graph=use_graph, warmup=2).prepare()
+            assert runner.graphed == use_graph, runner.capture_error
+            losses = []
+            for i in range(1, 6):
+                z_static.copy_(zs[i])
+                o = runner.run()
+                losses.append((o["g_loss"].clone(), o["d_loss"].clone()))
+            torch.cuda.synchronize()
+            res[overlap] = (losses, [p.detach().clone() for p in list(st.G.parameters()) + list(st.D.parameters())],
+                            [b.detach().clone() for b in list(st.G.buffers()) + list(st.D.buffers())])
+    finally:
+        steps._OVERLAP_D = old
+    for (ga, da), (gb, db) in zip(res[True][0], res[False][0]):
+        assert torch.equal(ga, gb) and torch.equal(da, db)
+    for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("skip_dead", [False, True])
 def test_wgan_gp_steps(skip_dead):
     from oracle import reference_steps as S

@@ -204,6 +204,16 @@ ab() {
   done
 }
 
+task_eighth() {   # dcgan: discriminator half on a second stream underneath the generator's backward
+  local O=gpurun_out/r4h; mkdir -p $O
+  timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "dcgan or acgan or clone" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  ab $O/bench.txt dcgan 50 2
+  bl $O/bench.txt dcgan 50 MIGAN_PAIR_D=0
+  bl $O/bench.txt dcgan_ch3 50
+  cat $O/bench.txt
+}
+
 task_seventh() {   # MLP layer 0 inside layer 1's launch; tiles-per-workgroup sweep on the SRGAN trunk; longest-class-first dgrad vs the round-start tree
   local O=gpurun_out/r4g; mkdir -p $O
   timeout 120 ./tools/abi_check.bin mlp > $O/abi_check.txt 2>&1
@@ -244,6 +254,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  eighth) task_eighth "$@" ;;
   seventh) task_seventh "$@" ;;
   sixth) task_sixth "$@" ;;
   fifth) task_fifth "$@" ;;
