@@ -128,6 +128,28 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
+def _two_streams_ok(s, ref):
+    # skip_dead_grads: otherwise the generator's backward also writes (dead) discriminator gradients, which the other stream zeroes;
+    # cross-replica BatchNorm puts collectives inside forward / backward: one stream
+    return _OVERLAP_D and s.skip and ref.is_cuda and not _sync_bn(s)
+
+
+def _fork_join(g_loss, d_half):
+    """g_loss.backward() on the current stream with d_half() - forward + backward of the discriminator update(s) - on the second stream
+    underneath it; returns d_half()'s value after the join.  The optimiser steps are the caller's, AFTER the join: with data
+    parallelism they close a hipGraph segment (graph.StepRunner cuts the captured step at every dp.step()), which must not happen
+    while a stream is forked, and no weight is updated while the other stream may still read it."""
+    main, side = _d_stream(g_loss.device)
+    _root_grad(g_loss)       # both backward calls are seeded from this tensor: it exists before the fork
+    side.wait_stream(main)   # fork: everything up to the generator's loss
+    with F.two_streams():
+        with torch.cuda.stream(side):
+            out = d_half()
+        _backward(g_loss)
+    main.wait_stream(side)   # join
+    return out
+
+
 @_scoped
 def dcgan_step(s, real_imgs, z):
     """dcgan.py:143-183 (and gan.py:121-161)."""
@@ -137,22 +159,13 @@ def dcgan_step(s, real_imgs, z):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce(s.D(gen), valid)
-    overlap = (_OVERLAP_D and s.skip and isinstance(s.dp, LocalStepper) and real_imgs.is_cuda and not _sync_bn(s))
-    if overlap:
-        main, side = _d_stream(real_imgs.device)
-        _root_grad(g_loss)       # both backward calls are seeded from this tensor: it exists before the fork
-        side.wait_stream(main)   # fork: everything up to the generator's loss
-        with F.two_streams():
-            with torch.cuda.stream(side):
-                d_loss = _dcgan_d_half(s, real_imgs, gen, valid, fake)
-            _backward(g_loss)
+    if _two_streams_ok(s, real_imgs):
+        d_loss = _fork_join(g_loss, lambda: _dcgan_d_half(s, real_imgs, gen, valid, fake))
         s.dp.step(s.opt_G)
-        main.wait_stream(side)   # join
-        s.dp.step(s.opt_D)
-        return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
-    _backward(g_loss)
-    s.dp.step(s.opt_G)
-    d_loss = _dcgan_d_half(s, real_imgs, gen, valid, fake)
+    else:
+        _backward(g_loss)
+        s.dp.step(s.opt_G)
+        d_loss = _dcgan_d_half(s, real_imgs, gen, valid, fake)
     s.dp.step(s.opt_D)
     return {"g_loss": g_loss.detach(), "d_loss": d_loss.detach(), "gen_imgs": gen.detach()}
 
@@ -751,22 +764,30 @@ def cyclegan_step(s, real_A, real_B):
     loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
     loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
     loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
-    _backward(loss_G)
-    s.dp.step(s.opt_G)
 
-    s.opt_D_A.zero_grad()
-    loss_real = s.mse(s.D_A(real_A), valid)
-    fake_A_ = s.buf_A.push_and_pop(fake_A)
-    loss_D_A = half_sum(loss_real, s.mse(s.D_A(fake_A_.detach()), fake))
-    _backward(loss_D_A)
-    s.dp.step(s.opt_D_A)
+    def d_half(opt, D, real, buf, fake_img):   # cyclegan.py:203-233 up to loss_D_X.backward()
+        opt.zero_grad()
+        loss_real = s.mse(D(real), valid)
+        fake_ = buf.push_and_pop(fake_img)
+        loss_D = half_sum(loss_real, s.mse(D(fake_.detach()), fake))
+        _backward(loss_D)
+        return loss_D
 
-    s.opt_D_B.zero_grad()
-    loss_real = s.mse(s.D_B(real_B), valid)
-    fake_B_ = s.buf_B.push_and_pop(fake_B)
-    loss_D_B = half_sum(loss_real, s.mse(s.D_B(fake_B_.detach()), fake))
-    _backward(loss_D_B)
-    s.dp.step(s.opt_D_B)
+    if _two_streams_ok(s, real_A):
+        # both discriminator updates underneath the generators' backward (see dcgan_step): they need fake_A / fake_B of the forward
+        # only, and the step is ~1900 eager launches whose dependent-launch gaps the second stream's kernels fill
+        loss_D_A, loss_D_B = _fork_join(loss_G, lambda: (d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A),
+                                                         d_half(s.opt_D_B, s.D_B, real_B, s.buf_B, fake_B)))
+        s.dp.step(s.opt_G)
+        s.dp.step(s.opt_D_A)
+        s.dp.step(s.opt_D_B)
+    else:
+        _backward(loss_G)
+        s.dp.step(s.opt_G)
+        loss_D_A = d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A)
+        s.dp.step(s.opt_D_A)
+        loss_D_B = d_half(s.opt_D_B, s.D_B, real_B, s.buf_B, fake_B)
+        s.dp.step(s.opt_D_B)
     return {"loss_G": loss_G.detach(), "loss_D": half_sum(loss_D_A, loss_D_B).detach(), "loss_GAN": loss_GAN.detach(),
             "loss_cycle": loss_cycle.detach(), "loss_identity": loss_id.detach()}
 
@@ -790,13 +811,22 @@ def pix2pix_step(s, real_A, real_B):
         loss_GAN = s.mse(s.D(fake_B, real_A), valid)
     loss_pixel = s.l1(fake_B, real_B)
     loss_G = F.axpby(loss_GAN, loss_pixel, 1.0, s.lambda_pixel)
-    _backward(loss_G)
-    s.dp.step(s.opt_G)
-    s.opt_D.zero_grad()
-    loss_real = s.mse(s.D(real_B, real_A), valid)
-    loss_fake = s.mse(s.D(fake_B.detach(), real_A), fake)
-    loss_D = half_sum(loss_real, loss_fake)
-    _backward(loss_D)
+
+    def d_half():   # pix2pix.py:151-165 up to loss_D.backward()
+        s.opt_D.zero_grad()
+        loss_real = s.mse(s.D(real_B, real_A), valid)
+        loss_fake = s.mse(s.D(fake_B.detach(), real_A), fake)
+        loss_D = half_sum(loss_real, loss_fake)
+        _backward(loss_D)
+        return loss_D
+
+    if _two_streams_ok(s, real_A):   # the discriminator update underneath the generator's backward (see dcgan_step)
+        loss_D = _fork_join(loss_G, d_half)
+        s.dp.step(s.opt_G)
+    else:
+        _backward(loss_G)
+        s.dp.step(s.opt_G)
+        loss_D = d_half()
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_pixel": loss_pixel.detach(),
             "loss_GAN": loss_GAN.detach()}
@@ -827,13 +857,22 @@ def srgan_step(s, imgs_lr, imgs_hr):
             real_features = s.V(imgs_hr)
     loss_content = s.l1(gen_features, real_features.detach())
     loss_G = F.axpby(loss_content, loss_GAN, 1.0, 1e-3)
-    _backward(loss_G)
-    s.dp.step(s.opt_G)
-    s.opt_D.zero_grad()
-    loss_real = s.mse(s.D(imgs_hr), valid)
-    loss_fake = s.mse(s.D(gen_hr.detach()), fake)
-    loss_D = half_sum(loss_real, loss_fake)
-    _backward(loss_D)
+
+    def d_half():   # srgan.py:129-141 up to loss_D.backward()
+        s.opt_D.zero_grad()
+        loss_real = s.mse(s.D(imgs_hr), valid)
+        loss_fake = s.mse(s.D(gen_hr.detach()), fake)
+        loss_D = half_sum(loss_real, loss_fake)
+        _backward(loss_D)
+        return loss_D
+
+    if _two_streams_ok(s, imgs_lr):   # the discriminator update underneath the generator's backward (see dcgan_step)
+        loss_D = _fork_join(loss_G, d_half)
+        s.dp.step(s.opt_G)
+    else:
+        _backward(loss_G)
+        s.dp.step(s.opt_G)
+        loss_D = d_half()
     s.dp.step(s.opt_D)
     return {"loss_G": loss_G.detach(), "loss_D": loss_D.detach(), "loss_content": loss_content.detach(),
             "loss_GAN": loss_GAN.detach()}

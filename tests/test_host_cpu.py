@@ -135,8 +135,10 @@ def test_sequential_fusion_plan(monkeypatch):
         hl, wl = (2 * h, 2 * w) if gather == F.GATHER_UP2 else (h, w)
         return (hl + pads[0] + pads[2] - k) // stride + 1, (wl + pads[1] + pads[3] - k) // stride + 1
 
-    def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=0, act=0, slope=0.0, dropout_mask=None, stats=None):
-        calls.append(("conv2d", tuple(pads), gather, act, dropout_mask is not None) + ((stats,) if stats else ()))
+    def conv2d(x, w, b=None, stride=1, pads=(0, 0, 0, 0), gather=0, act=0, slope=0.0, dropout_mask=None, stats=None, relu_in=False,
+               handed=False):
+        calls.append(("conv2d", tuple(pads), gather, act, dropout_mask is not None) + ((stats,) if stats else ())
+                     + (("relu_in",) if relu_in else ()) + (("handed",) if handed else ()))
         ho, wo = out_hw(x.shape[2], x.shape[3], w.shape[2], stride, pads, gather)
         return torch.zeros(x.shape[0], w.shape[0], ho, wo)
 
@@ -189,6 +191,18 @@ def test_sequential_fusion_plan(monkeypatch):
     assert tuple(y.shape) == (1, 8, 6, 6)
     assert calls == [("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False, "instance"), ("norm", True, F.ACT_RELU, 1e-5, False),
                      ("conv2d", (1, 1, 1, 1), F.GATHER_REFLECT, F.ACT_NONE, False, "instance"), ("norm", True, F.ACT_NONE, 1e-5, False)]
+
+    # vgg19.features[:10] (srgan/models.py:8-15): conv ReLU conv ReLU MaxPool conv ReLU conv ReLU MaxPool - the ReLU backward of a conv is
+    # handed to its consumer (the next conv's input-gradient epilogue, or the pool's backward); the chain's last ReLU has none
+    calls.clear()
+    monkeypatch.setattr(F, "maxpool2", lambda x, relu_in=False: (calls.append(("maxpool2",) + (("relu_in",) if relu_in else ())),
+                                                                 torch.zeros(x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2))[1])
+    blk = nn.Sequential(nn.Conv2d(3, 8, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(8, 8, 3, 1, 1), nn.ReLU(inplace=True), nn.MaxPool2d(2, 2),
+                        nn.Conv2d(8, 16, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(16, 16, 3, 1, 1), nn.ReLU(inplace=True))
+    y = blk(torch.zeros(1, 3, 8, 8))
+    assert tuple(y.shape) == (1, 16, 4, 4)
+    c = ("conv2d", (1, 1, 1, 1), F.GATHER_ZERO, F.ACT_RELU, False)
+    assert calls == [c + ("handed",), c + ("relu_in", "handed"), ("maxpool2", "relu_in"), c + ("handed",), c + ("relu_in",)]
 
     # PatchGAN tail (cyclegan/models.py:117-118): ZeroPad2d((1,0,1,0)) -> Conv2d(C, 1, 4, padding=1): pads fold into the conv
     calls.clear()

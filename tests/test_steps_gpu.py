@@ -181,6 +181,41 @@ def test_dcgan_discriminator_half_on_a_second_stream_is_bit_identical(use_graph)
         assert torch.equal(a, b)
 
 
+def test_cyclegan_discriminator_halves_on_a_second_stream_are_bit_identical():
+    """cyclegan.py:159-239 with both discriminator updates (and their replay-buffer draws) on the second stream underneath the
+    generators' backward: four steps at 64x64 with replay buffers of 3 - losses and every weight bit-identical to the sequential order."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    shape, n_res = (3, 64, 64), 2
+    _seed(0)
+    base = S.make_cyclegan(shape, n_res)
+    _seed(9)
+    As = (torch.rand(4, 2, *shape) * 2 - 1).to(DEV)
+    Bs = (torch.rand(4, 2, *shape) * 2 - 1).to(DEV)
+    res = {}
+    old = steps._OVERLAP_D
+    try:
+        for overlap in (True, False):
+            steps._OVERLAP_D = overlap
+            st = steps.make_cyclegan_state(gpu_copy(base.G_AB), gpu_copy(base.G_BA), gpu_copy(base.D_A), gpu_copy(base.D_B))
+            st.buf_A.max_size = st.buf_B.max_size = 3
+            outs = []
+            for t in range(4):
+                random.seed(40 + t)
+                o = steps.cyclegan_step(st, As[t], Bs[t])
+                outs.append({k: v.clone() for k, v in o.items()})
+            torch.cuda.synchronize()
+            res[overlap] = (outs, [p.detach().clone() for m in (st.G_AB, st.G_BA, st.D_A, st.D_B) for p in m.parameters()])
+    finally:
+        steps._OVERLAP_D = old
+    for a, b in zip(res[True][0], res[False][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("skip_dead", [False, True])
 def test_wgan_gp_steps(skip_dead):
     from oracle import reference_steps as S

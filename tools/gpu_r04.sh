@@ -204,6 +204,17 @@ ab() {
   done
 }
 
+task_ninth() {   # the discriminator halves of srgan / cyclegan / pix2pix on the second stream; data-parallel path of the dcgan overlap
+  local O=gpurun_out/r4i; mkdir -p $O
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_dp_gpu.py -q -x -k "second_stream or cyclegan_steps or srgan_step or pix2pix_step or two_ranks or dcgan_graph or world1" --durations=5 > $O/pytest.txt 2>&1
+  tail -5 $O/pytest.txt
+  ab $O/bench.txt cyclegan 4 2
+  ab $O/bench.txt srgan 4 2
+  ab $O/bench.txt pix2pix 50 1
+  ab $O/bench.txt dcgan 50 1
+  cat $O/bench.txt
+}
+
 task_eighth() {   # dcgan: discriminator half on a second stream underneath the generator's backward
   local O=gpurun_out/r4h; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "dcgan or acgan or clone" --durations=3 > $O/pytest.txt 2>&1
@@ -254,6 +265,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  ninth) task_ninth "$@" ;;
   eighth) task_eighth "$@" ;;
   seventh) task_seventh "$@" ;;
   sixth) task_sixth "$@" ;;
