@@ -354,8 +354,6 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     // profiles/r04_ab.txt; the loop also cost every variant 8-14 registers.)
     bool tapin = true;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
-    static const int tapin_env = getenv("MIGAN_DMA_TAPIN") ? atoi(getenv("MIGAN_DMA_TAPIN")) : 1;
-    tapin = tapin && tapin_env != 0;
     const bool ktail = g.Ci % BK != 0;
     // (Three LDS stages with counted waits - two K-tiles in flight, one workgroup of occupancy less - were measured on whole steps for
     // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
@@ -428,7 +426,7 @@ static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, 
     int minKT = 1 << 30;
     for (int c = 0; c < g.ncls; ++c)
         if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * tpt < minKT) minKT = g.ntap[c] * tpt;
-    static const int sk_env = getenv("MIGAN_DMA_SPLITK") ? atoi(getenv("MIGAN_DMA_SPLITK")) : 1;  // 0: off, >1: forced
+    constexpr int sk_env = 1;
     int S = 1;
     if (ws && sk_env != 0 && T <= DMA_SK_TICKETS && ws_bytes >= igemm_dma_splitk_ws_bytes()) {
         // a slice costs ~0.5 us per K-tile (one 64x64x32 MFMA tile per wave), the last arriver ~0.16 us per 16 KB slab it
@@ -731,10 +729,9 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
                                 (unsigned)xb, (unsigned)db);                                                             \
     } while (0)
     // 128x128: BK = 16 (32 KB of LDS, 4-5 workgroups per CU); the narrower tiles: BK = 32 (3 / 5 per CU) - measured
-    // per layer in profiles/r03_wgrad_dma.txt (differences <= 3 %); MIGAN_DMA_WGRAD_BK=16|32 forces one (A/B knob).
+    // per layer in profiles/r03_wgrad_dma.txt (differences <= 3 %).
     // wgrad_occ() in conv_igemm.hip (the split planner's slot count) follows this choice.
-    static const int bk_env = getenv("MIGAN_DMA_WGRAD_BK") ? atoi(getenv("MIGAN_DMA_WGRAD_BK")) : 0;
-    const int bk = bk_env ? bk_env : (bm == 128 ? 16 : 32);
+    const int bk = bm == 128 ? 16 : 32;
     if (bk == 32) {
         if (bm == 128 && bn == 128) WGD(128, 128, 32, 2);
         else if (bm == 64 && bn == 128) WGD(64, 128, 32, 3);

@@ -884,8 +884,9 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g_in.Co, BN), g_in.ncls);
-    static const int prio_env = getenv("MIGAN_MFMA_PRIO") ? atoi(getenv("MIGAN_MFMA_PRIO")) : 0;
-    static const int xcd_env = getenv("MIGAN_IGEMM_XCD") ? atoi(getenv("MIGAN_IGEMM_XCD")) : 0;  // opt-in: measured no gain (profiles/r02_ab.txt)
+    // s_setprio around the MFMA stream and the XCD-contiguous tile order: both measured without gain (profiles/r02_ab.txt) and off;
+    // the kernel-side code stays behind these two constants
+    constexpr int prio_env = 0, xcd_env = 0;
     ConvGeom gs;
     if (prio_env != 0 && xcd_env == 0) {
         gs = g_in;
@@ -903,13 +904,11 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     const ConvGeom& g = (xcd_env != 0 || prio_env != 0) ? gs : g_in;
     // tap-inner K order: small tiles, every class exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad) and at
     // least 2 K-tiles per tap
-    static const int tapin_env = getenv("MIGAN_IGEMM_TAPIN") ? atoi(getenv("MIGAN_IGEMM_TAPIN")) : 1;
-    bool tapin = tapin_env != 0 && BM * BN < 16384 && g.Ci >= 64;
+    bool tapin = BM * BN < 16384 && g.Ci >= 64;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     const bool ktail = g.Ci % 32 != 0, stats = g.stats != nullptr;
     // 128x64: 5 workgroups per CU (see OCC above) except the K-tail + tap-inner variant, which would spill
-    static const int occ5_env = getenv("MIGAN_IGEMM_OCC5") ? atoi(getenv("MIGAN_IGEMM_OCC5")) : 1;  // A/B knob
-    const bool occ5 = BM * BN == 8192 && occ5_env != 0 && !(ktail && tapin);
+    const bool occ5 = BM * BN == 8192 && !(ktail && tapin);
 #define PIPE_LAUNCH(KT_, TI_, ST_)                                                                                          \
     do {                                                                                                                    \
         if constexpr (BM * BN == 8192 && !(KT_ && TI_)) {                                                                   \
@@ -957,8 +956,6 @@ static inline bool igemm_fast_ci(int Ci) { return Ci % 4 == 0 && Ci >= 8; }
 // Tile selection (pure function of the GEMM shape; also exported for the bench's per-kernel accounting).
 // code = fast*1000000 + BM*1000 + BN
 static int igemm_select(long maxM, int Co, bool fast, int ncls, long K = 0) {
-    static const int tile_env = getenv("MIGAN_IGEMM_TILE") ? atoi(getenv("MIGAN_IGEMM_TILE")) : 0;  // A/B knob, e.g. 128128
-    if (fast && tile_env && Co > 32) return 1000000 + tile_env;
     if (fast) {
         // candidates from the most MFMA-efficient tile down; take the first one that fills the chip
         // (>= 896 workgroups ~ 256 CUs x 4 resident), else the one with the most workgroups
@@ -1682,7 +1679,7 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
         long m = (long)g.N * g.Ho[c] * g.Wo[c];
         if (m > maxM) maxM = m;
     }
-    static const int var_env = getenv("MIGAN_IGEMM_VAR") ? atoi(getenv("MIGAN_IGEMM_VAR")) : 0;  // tuning knob
+    constexpr int var_env = 0;  // (the A/B variants behind it are compiled with -DMIGAN_ABLATION only)
     const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
     if (g.omask) {  // the ReLU-mask epilogue exists in the LDS-DMA kernels only: take it or tell the caller to run the two-launch form
         for (int t = 0; t < MAX_TAPS; ++t) g.dhw[t] = ((int)g.dh[t] << 16) | ((int)g.dw[t] & 0xffff);
@@ -2747,7 +2744,7 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
 }
 
 static int wgrad_var() {
-    static const int v = getenv("MIGAN_WGRAD_VAR") ? atoi(getenv("MIGAN_WGRAD_VAR")) : 0;  // tuning knob (A/B runs)
+    constexpr int v = 0;
     return v;
 }
 // tile shape: 128x128 when both GEMM dims exceed 64; 64x128 for 32 < Co <= 64 with a wide column side (2 MFMAs per 3
@@ -2757,16 +2754,8 @@ static int wgrad_bn(int Co, int Ncol) {
     return (Co > 32 && Ncol >= 128 && wgrad_var() != 64) ? 128 : 64;
 }
 // Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
-// LDS-DMA kernels (conv_dma.hip): 4 (128x128, BK = 16) / 3 / 5 (BK = 32), LDS bound; MIGAN_WGRAD_OCCS=a,b,c overrides (sweeps).
-static int wgrad_occ(int bm, int bn) {
-    static int occs[3] = {0, 0, 0};
-    if (occs[0] == 0) {
-        int a = 4, b = 3, c = 5;
-        if (const char* e = getenv("MIGAN_WGRAD_OCCS")) sscanf(e, "%d,%d,%d", &a, &b, &c);
-        occs[2] = c; occs[1] = b; occs[0] = a;
-    }
-    return bm * bn >= 16384 ? occs[0] : (bm * bn >= 8192 ? occs[1] : occs[2]);
-}
+// LDS-DMA kernels (conv_dma.hip): 4 (128x128, BK = 16) / 3 / 5 (BK = 32), LDS bound.
+static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 4 : (bm * bn >= 8192 ? 3 : 5); }
 
 // Split-K factor.  The launch is tiles * splits equal workgroups on 256 CUs x occ resident slots.  Measured on MI355X
 // (profiles/r02_wgrad_split_sweep.txt): what decides the time is how EVENLY the workgroups fall on the CUs - R256 wgrad
@@ -2796,7 +2785,7 @@ static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int oc
 }
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
     // 3 (default) = the balance model above; 1 = round-1 rule: about 1024 workgroups, split count a multiple of 8
-    static const int plan_env = getenv("MIGAN_WGRAD_PLAN") ? atoi(getenv("MIGAN_WGRAD_PLAN")) : 3;
+    constexpr int plan_env = 3;
     static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
     long Mpix = (long)N * Ho * Wo;
     // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
@@ -3416,7 +3405,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st, ext);
     }
-    static const int small_on = getenv("MIGAN_SMALL_WGRAD") ? atoi(getenv("MIGAN_SMALL_WGRAD")) : 1;  // A/B knob
+    constexpr int small_on = 1;
     if (small_on && Co * R * S * Ci <= 256 && Co <= 64 && R * S * Ci <= 64 && !(Co % 4 == 0 && Ci % 4 == 0)) {
         SmallWgrad sg = {N, Hi, Wi, Ci, gather == GATHER_UP2 ? 2 * Hi : Hi, gather == GATHER_UP2 ? 2 * Wi : Wi,
                          Ho, Wo, Co, S, R * S, stride, pad_t, pad_l, gather, 0, 0, 0, 0, 0, 0, 0};
