@@ -506,16 +506,24 @@ def pmc_table():
 def roofline(w, rank, nprof, segments=None):
     """Eager runs of the timed step with HIP events (on the launch stream) around every conv-family launch; every rank
     runs the steps (collectives), rank 0 records."""
+    from pytorch_gan_amd import steps as _steps
+
     agg, hbm = {}, {}
-    with (ConvProfiler(segments) if rank == 0 else contextlib.nullcontext()) as prof:
-        for i in range(nprof):
-            w.state.dp.begin_step()
-            w.eager()
-            w.state.dp.end_step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            agg = prof.summary()
-            hbm = prof.hbm
+    # per-launch times are a property of a kernel alone on the chip: the step bodies' second stream (the discriminator update underneath the
+    # generator's backward, steps._fork_join) is off while the launches are timed - the events sit on ONE launch stream
+    overlap, _steps._OVERLAP_D = _steps._OVERLAP_D, False
+    try:
+        with (ConvProfiler(segments) if rank == 0 else contextlib.nullcontext()) as prof:
+            for i in range(nprof):
+                w.state.dp.begin_step()
+                w.eager()
+                w.state.dp.end_step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                agg = prof.summary()
+                hbm = prof.hbm
+    finally:
+        _steps._OVERLAP_D = overlap
     if not agg:
         return None
     dom = max(agg, key=lambda k: agg[k]["ms"])
@@ -646,6 +654,8 @@ def main():
     ap.add_argument("--pmc-log", default="", help="target mode of the rocprofv3 --pmc passes: run --steps eager steps of the workload "
                     "with the per-launch accounting of `roofline`, write which library launches (by ordinal) belong to which "
                     "roofline group to this file (tools/pmc_step.py joins it with the pass's counter CSV) and exit")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: the discriminator update after the generator's backward on one stream "
+                                                             "(reference order) instead of underneath it on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the brief runs of the other BASELINE configs (N=1)")
@@ -693,6 +703,10 @@ def main():
         dp.enable_sync_batchnorm()
 
     name = args.workload
+    if args.no_overlap:
+        from pytorch_gan_amd import steps as _steps
+
+        _steps._OVERLAP_D = False
     if args.pmc_log:
         args.no_graph = True
     w = BUILDERS[name](dp, rank, dev, args, args.warmup + args.steps)
@@ -721,7 +735,9 @@ def main():
         "config": {"workload": WORKLOAD_NAME[name], "global_batch": world * w.batch, "parallelism": "dp%d" % world,
                    "hipgraph": w.graphed, "gflop_per_image": round(GFLOP_PER_IMG[name], 4),
                    "executed_gflop_per_image": round(executed_gflop_per_image(name), 4),
-                   "sync_batchnorm": bool(args.sync_bn and world > 1)},
+                   "sync_batchnorm": bool(args.sync_bn and world > 1),
+                   "streams": "discriminator update on a second HIP stream underneath the generator's backward" if not args.no_overlap
+                   and not (args.sync_bn and world > 1) and name not in ("wgan_gp", "esrgan") else "one"},
         "timing": {"rule": "median over blocks of exactly --steps steps, each bracketed by barrier+synchronize, MAX over ranks",
                    "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
                    "ms_per_step_min": summ["ms_per_step_min"], "ms_per_step_max": summ["ms_per_step_max"],
