@@ -107,25 +107,8 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < VW; ++v) shift[v] = (!BWD && cok) ? xb[c + v] : 0.f;
     if (cok) {
-        for (int p = p0 + ty; p < p1; p += TY) {
-            float xv[VW], dv[VW];
-            if (VW == 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
-                xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
-                if (BWD) {
-                    if (ps.on) {
-                        const size_t q = pshuf_base(ps, p, c >> 2);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) dv[k] = dy[q + pshuf_off(ps, k)];
-                    } else {
-                        f32x4 d = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + c);
-                        dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2]; dv[3] = d[3];
-                    }
-                }
-            } else {
-                xv[0] = xb[(size_t)p * C + c];
-                if (BWD) dv[0] = dyb[(size_t)p * C + c];
-            }
+        // one pixel's contribution, in pixel order (the sums of a thread are sequential whatever the batching of the loads below)
+        auto accum = [&](const float (&xv)[VW], const float (&dv)[VW]) {
 #pragma unroll
             for (int v = 0; v < VW; ++v) {
                 if (BWD) {
@@ -143,6 +126,40 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                     s1[v] += d * d;
                 }
             }
+        };
+        auto load = [&](int p, float (&xv)[VW], float (&dv)[VW]) {
+            if (VW == 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + c);
+                xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3];
+                if (BWD) {
+                    if (ps.on) {
+                        const size_t q = pshuf_base(ps, p, c >> 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dv[k] = dy[q + pshuf_off(ps, k)];
+                    } else {
+                        f32x4 d = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + c);
+                        dv[0] = d[0]; dv[1] = d[1]; dv[2] = d[2]; dv[3] = d[3];
+                    }
+                }
+            } else {
+                xv[0] = xb[(size_t)p * C + c];
+                if (BWD) dv[0] = dyb[(size_t)p * C + c];
+            }
+        };
+        // four pixels' loads in flight per thread (a thread walks 9-512 pixels: one load at a time left the pass latency-bound at
+        // 2.2 TB/s on the 38-75 MB tensors of SRGAN's trunk against 4-5 TB/s for the apply pass, profiles/r04_srgan_kernel_stats.txt)
+        int p = p0 + ty;
+        for (; p + 3 * TY < p1; p += 4 * TY) {
+            float xv[4][VW], dv[4][VW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(p + u * TY, xv[u], dv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(xv[u], dv[u]);
+        }
+        for (; p < p1; p += TY) {
+            float xv[VW], dv[VW];
+            load(p, xv, dv);
+            accum(xv, dv);
         }
     }
 #pragma unroll
