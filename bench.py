@@ -510,8 +510,12 @@ def roofline(w, rank, nprof, segments=None):
 
     agg, hbm = {}, {}
     # per-launch times are a property of a kernel alone on the chip: the step bodies' second stream (the discriminator update underneath the
-    # generator's backward, steps._fork_join) is off while the launches are timed - the events sit on ONE launch stream
+    # generator's backward, steps._fork_join) and the weight-gradient stream (functional._Fork) are off while the launches are timed -
+    # the events sit on ONE launch stream
+    from pytorch_gan_amd import functional as _F
+
     overlap, _steps._OVERLAP_D = _steps._OVERLAP_D, False
+    wstream, _F._WGRAD_STREAM = _F._WGRAD_STREAM, False
     try:
         with (ConvProfiler(segments) if rank == 0 else contextlib.nullcontext()) as prof:
             for i in range(nprof):
@@ -523,7 +527,7 @@ def roofline(w, rank, nprof, segments=None):
                 agg = prof.summary()
                 hbm = prof.hbm
     finally:
-        _steps._OVERLAP_D = overlap
+        _steps._OVERLAP_D, _F._WGRAD_STREAM = overlap, wstream
     if not agg:
         return None
     dom = max(agg, key=lambda k: agg[k]["ms"])
@@ -654,8 +658,8 @@ def main():
     ap.add_argument("--pmc-log", default="", help="target mode of the rocprofv3 --pmc passes: run --steps eager steps of the workload "
                     "with the per-launch accounting of `roofline`, write which library launches (by ordinal) belong to which "
                     "roofline group to this file (tools/pmc_step.py joins it with the pass's counter CSV) and exit")
-    ap.add_argument("--no-overlap", action="store_true", help="A/B: the discriminator update after the generator's backward on one stream "
-                                                             "(reference order) instead of underneath it on a second stream")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: one stream - the discriminator update after the generator's backward "
+                                                             "(reference order) and every weight gradient in line with its layer's backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the brief runs of the other BASELINE configs (N=1)")
@@ -704,9 +708,11 @@ def main():
 
     name = args.workload
     if args.no_overlap:
+        from pytorch_gan_amd import functional as _F
         from pytorch_gan_amd import steps as _steps
 
         _steps._OVERLAP_D = False
+        _F._WGRAD_STREAM = False
     if args.pmc_log:
         args.no_graph = True
     w = BUILDERS[name](dp, rank, dev, args, args.warmup + args.steps)

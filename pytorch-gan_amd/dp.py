@@ -69,6 +69,9 @@ class DataParallel:
 
     def step(self, opt):
         """All-reduce opt.flat_grad (SUM) and apply the update with grads scaled by 1/world."""
+        from . import functional as F
+
+        F.join_wgrad_streams()   # before the segment is cut / the bucket is read: no weight-gradient stream is left forked
         if self._segmenter is not None:
             # hipGraph recording: close the current compute segment; the exchange + update replay eagerly.  The update
             # itself does not run while recording, but the recorded segments after it must not re-use weight packs made

@@ -41,12 +41,38 @@ def set_wgrad_overlap(enabled):
     _OVERLAP_WGRAD = int(enabled)
 
 
-class _Fork:
-    """fork(): side stream waits for the current one and becomes current;  join(): current waits for the side."""
+# Weight-gradient launches on their own stream, joined only where the optimiser needs them (steps / dp call join_wgrad_streams()
+# before every optimiser step): a weight gradient feeds nothing but Adam, so the backward chain on the main stream - the HBM-bound
+# normalisation passes and the next layer's input gradient - does not wait for it, and a streaming norm kernel runs beside an MFMA-bound
+# weight gradient instead of after it.  All weight gradients of one main stream go to ONE side stream in launch order, so the
+# accumulation order into a shared parameter's gradient (a generator applied three times in cyclegan.py:170-190) is unchanged and the
+# results are bit-identical.  Only where the gradient goes straight into the optimiser's bucket (functional._grad_slot): a gradient
+# returned to autograd is joined at once.  Tests and bench.py --no-overlap flip it.
+_WGRAD_STREAM = True
+_PENDING_WGRAD = {}
 
-    def __init__(self, device, enabled, numel=0):
-        self.on = (bool(enabled) and _OVERLAP_WGRAD != 0 and not torch.is_grad_enabled()
-                   and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
+
+def join_wgrad_streams():
+    """The current stream waits for every weight-gradient stream with launches in flight (before an optimiser step, a gradient
+    all-reduce, or the end of a captured hipGraph segment)."""
+    if not _PENDING_WGRAD:
+        return
+    for dev_index, side in list(_PENDING_WGRAD.values()):
+        torch.cuda.current_stream(dev_index).wait_stream(side)
+    _PENDING_WGRAD.clear()
+
+
+class _Fork:
+    """fork(): side stream waits for the current one and becomes current;  join(): current waits for the side - at once, or (deferred:
+    the weight-gradient stream above) at the next join_wgrad_streams()."""
+
+    def __init__(self, device, both, numel=0, wgrad=False):
+        first_order = not torch.is_grad_enabled()
+        # only inside a step body (weight_cache_scope): its optimiser steps and its end join the stream - a bare loss.backward() of user
+        # code reads .grad right away
+        self.defer = bool(wgrad) and _WGRAD_STREAM and first_order and device.type == "cuda" and _CACHE_SCOPE is not None
+        self.on = self.defer or (bool(both) and _OVERLAP_WGRAD != 0 and first_order
+                                 and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
         if self.on:
             self.main = torch.cuda.current_stream(device)
             key = (device.index, self.main.cuda_stream)
@@ -54,6 +80,7 @@ class _Fork:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device)
             self.side = _SIDE_STREAMS[key]
             self.ctx = None
+            self.key = key
 
     def __enter__(self):
         if self.on:
@@ -67,11 +94,20 @@ class _Fork:
             self.ctx.__exit__(*exc)
         return False
 
-    def join(self):
-        # Every side-stream use starts by waiting for the main stream and ends with the main stream waiting for it, so
+    def join(self, returned=(), reads=()):
+        """`returned`: what the side launches produced for autograd (all None = everything went into gradient slots);
+        `reads`: main-stream tensors the side launches read (kept from being recycled under them when the join is deferred)."""
+        if not self.on:
+            return
+        if self.defer and all(t is None for t in returned):
+            for t in reads:
+                if t is not None:
+                    t.record_stream(self.side)
+            _PENDING_WGRAD[self.key] = (self.key[0], self.side)
+            return
+        # Every immediate side-stream use starts by waiting for the main stream and ends with the main stream waiting for it, so
         # buffers from either stream's allocator pool are never recycled under a kernel that still reads them.
-        if self.on:
-            self.main.wait_stream(self.side)
+        self.main.wait_stream(self.side)
 
 
 def _plain(t):
@@ -660,7 +696,7 @@ class _Conv2d(Function):
         dx = dw = db = None
         if ctx.toep:
             return _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db)
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
         # ReflectionPad2d(1)+Conv3x3 with both gradients wanted: the input gradient's main launch goes FIRST, its ring
         # correction (a latency-bound launch of tiny workgroups, 64 us on CycleGAN's R256) runs on the side stream underneath
         # the weight-gradient launch that follows on this stream
@@ -693,7 +729,7 @@ class _Conv2d(Function):
             ring()   # this stream waits for the ring correction before dx leaves the Function
         elif ctx.needs_input_grad[0]:
             dx = _conv2d_dgrad_raw(ctx, dy, xs, w)
-        fork.join()
+        fork.join((dw, db), (dy, xs, side[0] if side is not None else None))
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
@@ -943,7 +979,7 @@ class _UpConv3x3(Function):
         elif fuse_db:
             side = _colsum_side(dy, Co)
         dx = dw = db = None
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
         with fork:
             st = _stream()
             if ctx.needs_input_grad[1]:
@@ -976,7 +1012,7 @@ class _UpConv3x3(Function):
             dx = _empty_nhwc((N, Ci, H, W), xs)
             check(lib.migan_upconv3x3_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, _stream()),
                   "upconv_dgrad")
-        fork.join()
+        fork.join((dw, db), (dy, xs, side[0] if side is not None else None))
         return dx, dw, db, None, None, None, None, None
 
 
@@ -1070,7 +1106,7 @@ class _ConvTranspose2d(Function):
                 dx = _empty_nhwc((N, Cin, Hin, Win), xs)
                 _fewpix_nt(dycol, w, None, dx, M, Cin, K, ACT_NONE, 0.0, st, "fewpix_convT_dgrad")
             return dx, dw, db, None, None, None, None
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel())
+        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
         with fork:
             st = _stream()
             if ctx.needs_input_grad[1]:
@@ -1093,7 +1129,7 @@ class _ConvTranspose2d(Function):
             skp, skb = _splitk_ws(dy, N * Hin * Win, Cin, Cout)
             check(lib.migan_conv2d_fwd_ws(dy.data_ptr(), wo.data_ptr(), None, None, dx.data_ptr(), N, Hout, Wout, Cout, Hin,
                                           Win, Cin, R, S, stride, pad, pad, GATHER_ZERO, 0, 0.0, skp, skb, st), "convT_dgrad")
-        fork.join()
+        fork.join((dw, db), (dy, xs))
         return dx, dw, db, None, None, None, None
 
 
@@ -1187,7 +1223,7 @@ class _MMNT(Function):
         if ctx.act != ACT_NONE:  # fused activation epilogue (Linear -> LeakyReLU / Tanh / Sigmoid): differentiable act'
             g = _ActBwd.apply(g, y, ctx.act, ctx.slope)
         da = db = dbias = None
-        fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel())
+        fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel(), ctx.needs_input_grad[1])
         gc, ac = canon(g), canon(a)  # on the main stream: both branches read them
         with fork:
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -1208,7 +1244,7 @@ class _MMNT(Function):
                 dbias = _colsum(gc, gc.shape[0], gc.shape[1], _grad_slot(ctx.bias_param))
         if ctx.needs_input_grad[0]:
             da = mm_nn(g, b)
-        fork.join()
+        fork.join((db, dbias), (gc, ac))
         return da, db, dbias, None, None
 
 

@@ -124,6 +124,7 @@ class Adam:
                 p.grad = self.flat_grad[o:o + p.numel()].view_as(p)
 
     def step(self, grad_scale=1.0):
+        F.join_wgrad_streams()   # weight gradients still in flight on their own stream (functional._Fork) land before they are read
         for p, o, ptr in zip(self.params, self.offsets, self._ptrs):
             if p.data_ptr() != ptr:
                 raise RuntimeError("parameter storage moved after the optimiser was built")

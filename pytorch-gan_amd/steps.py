@@ -53,7 +53,10 @@ def _scoped(fn):
     def wrapper(*a, **kw):
         # the plans that batch a step's weight packs / dropout masks into one launch belong to the step STATE (first argument)
         with F.weight_cache_scope(owner=a[0] if a else None):
-            return fn(*a, **kw)
+            try:
+                return fn(*a, **kw)
+            finally:
+                F.join_wgrad_streams()   # no weight-gradient launch outlives the step body that issued it (normally joined by dp.step())
 
     return wrapper
 

@@ -204,6 +204,21 @@ ab() {
   done
 }
 
+task_eleventh() {   # weight gradients on their own stream (deferred join), batched norm statistics loads
+  local O=gpurun_out/r4k; mkdir -p $O
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_dp_gpu.py tests/test_ops_gpu.py -q -x -k "second_stream or dcgan or cyclegan_steps or srgan_step or pix2pix_step or two_ranks or world1 or norm or wgan_gp_steps or bias_grad" --durations=5 > $O/pytest.txt 2>&1
+  tail -5 $O/pytest.txt
+  for w in dcgan srgan cyclegan; do
+    k=4; [ $w = dcgan ] && k=50
+    bl $O/bench.txt $w $k
+    echo "== $w --no-overlap" >> $O/bench.txt
+    timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline --no-overlap 2>>$O/bench.txt.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $O/bench.txt
+    bl $O/bench.txt $w $k
+  done
+  ab $O/bench.txt pix2pix 50 1
+  cat $O/bench.txt
+}
+
 task_ninth() {   # the discriminator halves of srgan / cyclegan / pix2pix on the second stream; data-parallel path of the dcgan overlap
   local O=gpurun_out/r4i; mkdir -p $O
   timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_dp_gpu.py -q -x -k "second_stream or cyclegan_steps or srgan_step or pix2pix_step or two_ranks or dcgan_graph or world1" --durations=5 > $O/pytest.txt 2>&1
@@ -265,6 +280,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  eleventh) task_eleventh "$@" ;;
   ninth) task_ninth "$@" ;;
   eighth) task_eighth "$@" ;;
   seventh) task_seventh "$@" ;;
