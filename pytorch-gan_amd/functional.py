@@ -49,6 +49,10 @@ def set_wgrad_overlap(enabled):
 # results are bit-identical.  Only where the gradient goes straight into the optimiser's bucket (functional._grad_slot): a gradient
 # returned to autograd is joined at once.  Tests and bench.py --no-overlap flip it.
 _WGRAD_STREAM = True
+# ... for gradients of at least this many elements (dy): the launch must be long enough (an MFMA-bound weight gradient of >= ~100 us) to
+# be worth two more edges in the stream / hipGraph.  Measured with every weight gradient forked (profiles/r04_ab.txt, call 11): CycleGAN
+# 149.6 -> 144.9 ms, but the captured DCGAN step 2.53 -> 2.72 ms and pix2pix 3.32 -> 3.62 ms (dozens of forks around 5-20 us launches)
+_WGRAD_STREAM_MIN = 6 << 20
 _PENDING_WGRAD = {}
 
 
@@ -70,7 +74,8 @@ class _Fork:
         first_order = not torch.is_grad_enabled()
         # only inside a step body (weight_cache_scope): its optimiser steps and its end join the stream - a bare loss.backward() of user
         # code reads .grad right away
-        self.defer = bool(wgrad) and _WGRAD_STREAM and first_order and device.type == "cuda" and _CACHE_SCOPE is not None
+        self.defer = (bool(wgrad) and _WGRAD_STREAM and numel >= _WGRAD_STREAM_MIN and first_order and device.type == "cuda"
+                      and _CACHE_SCOPE is not None)
         self.on = self.defer or (bool(both) and _OVERLAP_WGRAD != 0 and first_order
                                  and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
         if self.on:

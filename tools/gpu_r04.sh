@@ -204,6 +204,19 @@ ab() {
   done
 }
 
+task_twelfth() {   # weight-gradient stream only for gradients of >= 6 M elements
+  local O=gpurun_out/r4l; mkdir -p $O
+  timeout 600 python -m pytest tests/test_steps_gpu.py -q -x -k "second_stream" > $O/pytest.txt 2>&1
+  tail -2 $O/pytest.txt
+  for w in dcgan srgan cyclegan pix2pix; do
+    k=4; [ $w = dcgan ] && k=50; [ $w = pix2pix ] && k=50
+    echo "== $w --no-overlap" >> $O/bench.txt
+    timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline --no-overlap 2>>$O/bench.txt.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $O/bench.txt
+    bl $O/bench.txt $w $k
+  done
+  cat $O/bench.txt
+}
+
 task_eleventh() {   # weight gradients on their own stream (deferred join), batched norm statistics loads
   local O=gpurun_out/r4k; mkdir -p $O
   timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_dp_gpu.py tests/test_ops_gpu.py -q -x -k "second_stream or dcgan or cyclegan_steps or srgan_step or pix2pix_step or two_ranks or world1 or norm or wgan_gp_steps or bias_grad" --durations=5 > $O/pytest.txt 2>&1
@@ -280,6 +293,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  twelfth) task_twelfth "$@" ;;
   eleventh) task_eleventh "$@" ;;
   ninth) task_ninth "$@" ;;
   eighth) task_eighth "$@" ;;
