@@ -623,6 +623,41 @@ def test_srgan_step():
     _params_close(s_gpu.G, s_cpu.G, 2, "srgan G")
 
 
+def test_srgan_three_streams_are_bit_identical():
+    """srgan.py:97-145 with the frozen VGG passes on a third stream (features of the real images beside the generator's forward, features
+    of gen_hr beside the discriminator's pass; their backward passes side by side), the discriminator update on the second stream and the
+    large weight gradients on theirs: three steps, every loss and weight bit-identical to the one-stream order."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import functional as F
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    base = S.make_srgan((32, 32), n_res=3)
+    _seed(8)
+    lrs, hrs = torch.randn(3, 4, 3, 8, 8).to(DEV), torch.randn(3, 4, 3, 32, 32).to(DEV)
+    res = {}
+    old = (steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN)
+    try:
+        for overlap in (True, False):
+            steps._OVERLAP_D = F._WGRAD_STREAM = overlap
+            F._WGRAD_STREAM_MIN = 1 << 12   # at this size no gradient reaches the production threshold: fork the larger ones anyway
+            st = steps.make_srgan_state(gpu_copy(base.G), gpu_copy(base.D), gpu_copy(base.V))
+            outs = []
+            for t in range(3):
+                o = steps.srgan_step(st, lrs[t], hrs[t])
+                outs.append({k: v.clone() for k, v in o.items()})
+            torch.cuda.synchronize()
+            res[overlap] = (outs, [p.detach().clone() for m in (st.G, st.D) for p in m.parameters()],
+                            [b.detach().clone() for m in (st.G, st.D) for b in m.buffers()])
+    finally:
+        steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN = old
+    for a, b in zip(res[True][0], res[False][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert torch.equal(a, b)
+
+
 def test_esrgan_steps():
     """esrgan.py:101-174: one pixel-loss warm-up iteration, then two relativistic average GAN iterations
     (BCEWithLogits on D(x) - mean_batch D(other), VGG19[:35] content loss, Adam betas (0.9, 0.999)) against the oracle."""

@@ -204,6 +204,19 @@ ab() {
   done
 }
 
+task_thirteenth() {   # srgan: the frozen VGG passes on a third stream
+  local O=gpurun_out/r4m; mkdir -p $O
+  timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "srgan or second_stream" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for r in 1 2; do
+    echo "== srgan --no-overlap" >> $O/bench.txt
+    timeout 300 python bench.py --workload srgan --steps 4 --warmup 2 --no-cpu-baseline --no-extra --no-roofline --no-overlap 2>>$O/bench.txt.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $O/bench.txt
+    bl $O/bench.txt srgan 4
+  done
+  ab $O/bench.txt srgan 4 1
+  cat $O/bench.txt
+}
+
 task_twelfth() {   # weight-gradient stream only for gradients of >= 6 M elements
   local O=gpurun_out/r4l; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py -q -x -k "second_stream" > $O/pytest.txt 2>&1
@@ -293,6 +306,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  thirteenth) task_thirteenth "$@" ;;
   twelfth) task_twelfth "$@" ;;
   eleventh) task_eleventh "$@" ;;
   ninth) task_ninth "$@" ;;
