@@ -131,19 +131,6 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
-_V_STREAMS = {}
-
-
-def _v_stream(device):
-    """(current stream, the third stream of srgan_step) - not the discriminator half's stream: the VGG backward sits on the generator
-    backward's critical path and must not queue behind the discriminator update."""
-    main = torch.cuda.current_stream(device)
-    key = (device.index, main.cuda_stream)
-    if key not in _V_STREAMS:
-        _V_STREAMS[key] = torch.cuda.Stream(device)
-    return main, _V_STREAMS[key]
-
-
 def _two_streams_ok(s, ref):
     # skip_dead_grads: otherwise the generator's backward also writes (dead) discriminator gradients, which the other stream zeroes;
     # cross-replica BatchNorm puts collectives inside forward / backward: one stream
@@ -862,34 +849,18 @@ def srgan_step(s, imgs_lr, imgs_hr):
     valid, fake = _labels(s, (imgs_lr.size(0), *s.D.output_shape), imgs_lr.device)
     s.dp.begin_step()
     s.opt_G.zero_grad()
-    if _two_streams_ok(s, imgs_lr):
-        # The frozen VGG19 passes (srgan.py:112-114) on a third stream: features of the real images under no_grad beside the generator's
-        # forward (they need nothing from it), features of gen_hr beside the discriminator's pass over gen_hr.  Autograd runs each
-        # backward node on its forward's stream, so the VGG backward and the backward through the frozen discriminator also run side by
-        # side before they meet at gen_hr.  No parameter gradient is produced on the third stream (VGG and D are frozen here), so
-        # nothing accumulates from two streams; MFMA-bound VGG convs beside the generator's HBM-bound BatchNorm passes.
-        main, vs = _v_stream(imgs_lr.device)
-        vs.wait_stream(main)
-        with torch.cuda.stream(vs), torch.no_grad():
-            real_features = s.V(imgs_hr)
-        gen_hr = s.G(imgs_lr)
-        with frozen(s.D, s.V, enabled=True):
-            vs.wait_stream(main)   # gen_hr
-            with torch.cuda.stream(vs):
-                loss_content = s.l1(s.V(gen_hr), real_features)
-            loss_GAN = s.mse(s.D(gen_hr), valid)
-        main.wait_stream(vs)
-    else:
-        gen_hr = s.G(imgs_lr)
-        with frozen(s.D, s.V, enabled=s.skip):
-            loss_GAN = s.mse(s.D(gen_hr), valid)
-            gen_features = s.V(gen_hr)
-            if s.skip:
-                with torch.no_grad():
-                    real_features = s.V(imgs_hr)
-            else:
+    gen_hr = s.G(imgs_lr)
+    with frozen(s.D, s.V, enabled=s.skip):
+        loss_GAN = s.mse(s.D(gen_hr), valid)
+        gen_features = s.V(gen_hr)
+        if s.skip:
+            with torch.no_grad():
                 real_features = s.V(imgs_hr)
-        loss_content = s.l1(gen_features, real_features.detach())
+        else:
+            real_features = s.V(imgs_hr)
+    loss_content = s.l1(gen_features, real_features.detach())
+    # (The frozen VGG19 passes on a third stream - real features beside the generator's forward, gen features and their backward beside
+    # the discriminator's pass over gen_hr - were measured: 83.97 vs 83.15-83.41 ms without, profiles/r04_ab.txt call 13; removed.)
     loss_G = F.axpby(loss_content, loss_GAN, 1.0, 1e-3)
 
     def d_half():   # srgan.py:129-141 up to loss_D.backward()

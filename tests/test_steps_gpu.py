@@ -623,10 +623,9 @@ def test_srgan_step():
     _params_close(s_gpu.G, s_cpu.G, 2, "srgan G")
 
 
-def test_srgan_three_streams_are_bit_identical():
-    """srgan.py:97-145 with the frozen VGG passes on a third stream (features of the real images beside the generator's forward, features
-    of gen_hr beside the discriminator's pass; their backward passes side by side), the discriminator update on the second stream and the
-    large weight gradients on theirs: three steps, every loss and weight bit-identical to the one-stream order."""
+def test_srgan_second_streams_are_bit_identical():
+    """srgan.py:97-145 with the discriminator update on the second stream and the weight gradients on theirs (threshold lowered so that
+    they fork at this size): three steps, every loss, weight and BatchNorm buffer bit-identical to the one-stream order."""
     from oracle import reference_steps as S
     from pytorch_gan_amd import functional as F
     from pytorch_gan_amd import steps
