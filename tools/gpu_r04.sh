@@ -34,7 +34,8 @@ task_prof() {
   local O=gpurun_out/${1:-r4prof}; shift
   mkdir -p $O
   for spec in "$@"; do
-    w=${spec%%:*}; mode=eager; flag=--no-graph; [ "$spec" != "$w" ] && { mode=graph; flag=; }
+    # eager traces: one stream (--no-overlap), so a kernel's duration is its own; graph traces: the step as it is timed
+    w=${spec%%:*}; mode=eager; flag="--no-graph --no-overlap"; [ "$spec" != "$w" ] && { mode=graph; flag=; }
     k=3; [ $w = dcgan ] && k=20; [ $w = pix2pix ] && k=20; [ $w = wgan_gp ] && k=50
     (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_${w}_$mode -o $w -- python $R/bench.py --workload $w --steps $k --warmup 2 \
        --min-seconds 0 $flag --no-roofline --no-cpu-baseline --no-extra > $R/$O/prof_${w}_$mode.log 2>&1)
@@ -204,6 +205,15 @@ ab() {
   done
 }
 
+task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
+  task_bench
+  cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
+  task_prof r4final dcgan dcgan:graph cyclegan srgan wgan_gp:graph pix2pix:graph
+  task_pmcstep dcgan 3 sq l2 fetch write
+  task_pmcstep cyclegan 1 sq fetch write
+  task_pmcstep srgan 1 sq fetch write
+}
+
 task_thirteenth() {   # srgan: the frozen VGG passes on a third stream
   local O=gpurun_out/r4m; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "srgan or second_stream" --durations=3 > $O/pytest.txt 2>&1
@@ -306,6 +316,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  final) task_final "$@" ;;
   thirteenth) task_thirteenth "$@" ;;
   twelfth) task_twelfth "$@" ;;
   eleventh) task_eleventh "$@" ;;
