@@ -145,11 +145,13 @@ def _fork_join(g_loss, d_half):
     main, side = _d_stream(g_loss.device)
     _root_grad(g_loss)       # both backward calls are seeded from this tensor: it exists before the fork
     side.wait_stream(main)   # fork: everything up to the generator's loss
-    with F.two_streams():
-        with torch.cuda.stream(side):
-            out = d_half()
-        _backward(g_loss)
-    main.wait_stream(side)   # join
+    try:
+        with F.two_streams():
+            with torch.cuda.stream(side):
+                out = d_half()
+            _backward(g_loss)
+    finally:
+        main.wait_stream(side)   # join - also when a half raised: no stream stays forked (a capture in progress could not end)
     return out
 
 
