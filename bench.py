@@ -254,10 +254,8 @@ def build_wgan_gp(dp, rank, dev, args, nsteps):
     real = torch.from_numpy(rng.uniform(-1, 1, (batch, 1, 32, 32)).astype(np.float32)).to(dev)
     zs = torch.from_numpy(rng.normal(0, 1, (64, batch, 100)).astype(np.float32)).to(dev)
     alphas = torch.from_numpy(rng.random_sample((64, batch, 1, 1, 1)).astype(np.float32)).to(dev)
-    runner = steps.WganGpRunner(state, batch, (1, 32, 32), use_graph=not args.no_graph,
-                                pipeline=not args.no_overlap).prepare(real, zs[0], alphas[0], zs[1])
-    # the draws of an iteration, packed [z_i | alpha_i | z_(i+1)]: one staging copy (z_(i+1) feeds the generator-forward prefetch)
-    za = torch.cat([zs.reshape(64, -1), alphas.reshape(64, -1), torch.roll(zs, -1, 0).reshape(64, -1)], 1).contiguous()
+    runner = steps.WganGpRunner(state, batch, (1, 32, 32), use_graph=not args.no_graph).prepare(real, zs[0], alphas[0])
+    za = torch.cat([zs.reshape(64, -1), alphas.reshape(64, -1)], 1).contiguous()   # the draws of an iteration, packed: one staging copy
 
     def run(i):
         return runner.run(i, None, None, None, packed=za[i % 64])

@@ -411,42 +411,29 @@ class _GeneratorFusedPlan:
     def usable(self, z):
         return self.ok and self.G.training and z.shape[0] == self.B and z.is_contiguous() and z.dtype == torch.float32
 
-    def run(self, z, buffers=None, out=None):
+    def run(self, z, buffers=None):
         import ctypes
 
         from ._lib import check, lib
 
         ts = self.tensors(buffers)
         ptrs = (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
-        y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32) if out is None \
-            else out.view(self.B, self.groups[-1][0].out_features)
+        y = torch.empty(self.B, self.groups[-1][0].out_features, device=z.device, dtype=torch.float32)
         check(lib.migan_mlp_fused_fwd(z.data_ptr(), y.data_ptr(), self.B, self.n, self.dims, self.fpar, ptrs, self.ws.data_ptr(),
                                       self.ws_bytes, 0, self.tickets.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "mlp_fused_fwd")
         return y.view(self.B, *self.shape)
 
 
-def _generator_nograd(s, z, out=None):
+def _generator_nograd(s, z):
     """fake_imgs = generator(z) without a graph (wgan_gp.py:163 when its gradients are dead): the fused forward when the
-    generator is the MLP of wgan_gp.py:42-65, else the modules.  out: a contiguous buffer the images are written into."""
+    generator is the MLP of wgan_gp.py:42-65, else the modules."""
     if _k7():
         plan = getattr(s, "_k7_gen_plan", None)
         if plan is None or (plan.ok and plan.B != z.shape[0]):
             plan = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
         if plan.usable(z):
-            return plan.run(z, out=out)
-    y = s.G(z)
-    if out is not None:
-        out.copy_(y)
-        return out
-    return y
-
-
-def _prefetch_pipe(s, like):
-    """State of the generator-forward prefetch of wgan_gp_step: `buf` = the images of the NEXT iteration's z when `valid`."""
-    pipe = s.__dict__.get("_k7_pipe")
-    if pipe is None or pipe.buf.shape != like.shape or pipe.buf.device != like.device:
-        pipe = s._k7_pipe = SimpleNamespace(buf=torch.empty_like(like, memory_format=torch.contiguous_format), valid=False)
-    return pipe
+            return plan.run(z)
+    return s.G(z)
 
 
 def _generator_iteration_plans(s, z):
@@ -506,37 +493,15 @@ def _critic_plan(s, real, fake):
 
 
 @_scoped
-def wgan_gp_step(s, real_imgs, i, z, alpha=None, z_next=None):
-    """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0.
-
-    z_next (the NEXT iteration's latent draw, optional): `fake_imgs = generator(z)` of wgan_gp.py:163 depends on z and on the generator,
-    which changes only in the iterations that update it - so in every other iteration the next iteration's no_grad forward runs on a
-    second stream underneath this iteration's critic launches (both are chains of latency-bound launches at 64 rows that leave the chip
-    idle), and the next call finds its images ready.  Same launches in the same per-network order: the BatchNorm1d running statistics
-    see the same sequence of forwards and every result is bit-identical to calling without z_next."""
+def wgan_gp_step(s, real_imgs, i, z, alpha=None):
+    """wgan_gp.py:146-193: critic iteration i, generator update when i % n_critic == 0."""
     s.dp.begin_step()
-    pipe = s.__dict__.get("_k7_pipe")
-    have = bool(s.skip and pipe is not None and pipe.valid and pipe.buf.shape == (z.shape[0], *pipe.buf.shape[1:]))
     if s.skip:
         with torch.no_grad():  # G grads from d_loss are discarded at wgan_gp.py:176
-            if have:
-                fake_imgs, pipe.valid = pipe.buf, False   # made during the previous call
-            else:
-                fake_imgs = _generator_nograd(s, z)
+            fake_imgs = _generator_nograd(s, z)
     else:
         fake_imgs = s.G(z)
     plan = _critic_plan(s, real_imgs, fake_imgs) if (_k7() and s.skip) else None
-    side = None
-    if (z_next is not None and plan is not None and i % s.n_critic != 0 and real_imgs.is_cuda and _OVERLAP_D
-            and isinstance(s.dp, LocalStepper)):
-        pipe = _prefetch_pipe(s, fake_imgs)
-        if have:
-            fake_imgs = fake_imgs.clone()   # the prefetch below overwrites the buffer these images live in
-        main, side = _d_stream(real_imgs.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad():
-            _generator_nograd(s, z_next, out=pipe.buf)
-        pipe.valid = True
     if plan is not None and alpha is None:  # the host draw of wgan_gp.py:122, where the reference makes it
         alpha = _dev(np.random.random((real_imgs.shape[0], 1, 1, 1)), real_imgs.device)
     if plan is not None:
@@ -574,8 +539,6 @@ def wgan_gp_step(s, real_imgs, i, z, alpha=None, z_next=None):
             _backward(g_loss)
         s.dp.step(s.opt_G)
         out["g_loss"] = g_loss.detach()
-    if side is not None:
-        torch.cuda.current_stream(real_imgs.device).wait_stream(side)   # join (a captured step ends with no stream forked)
     return out
 
 
@@ -629,93 +592,55 @@ def dragan_step(s, real_imgs, z, alpha=None, noise=None):
 
 
 class WganGpRunner:
-    """`wgan_gp_step` replayed as hipGraphs.  The loop body has several shapes - critic only / critic + generator update when
-    `i % n_critic == 0` (wgan_gp.py:179), each with or without the next iteration's generator forward prefetched underneath the critic
-    launches and with or without this iteration's images already made (see wgan_gp_step) - and a capture freezes host control flow, so
-    every shape is captured once over static input buffers and `run(i, ...)` replays the one iteration i needs.  `prepare()` executes
-    `warmup` real iterations per shape (they update the networks like any other iteration).  pipeline=False: the two shapes of the
-    plain loop."""
+    """`wgan_gp_step` replayed as hipGraphs.  The loop body has two shapes — critic only, and critic + generator when
+    `i % n_critic == 0` (wgan_gp.py:179) — and a capture freezes host control flow, so both shapes are captured once
+    over static input buffers and `run(i, ...)` replays the one iteration i needs.  The step is ~100 dependent small
+    launches (Linear / LeakyReLU / double-backward chain at batch 64): replay removes the host launch cost.
+    `prepare()` executes `2 * warmup` real iterations (they update the networks like any other iteration)."""
 
-    def __init__(self, s, batch, img_shape, use_graph=True, warmup=2, pipeline=True):
+    def __init__(self, s, batch, img_shape, use_graph=True, warmup=2):
+        from .graph import StepRunner
+
         dev = next(s.G.parameters()).device
-        self.s, self.use_graph, self.warmup = s, use_graph, warmup
-        self.pipeline = bool(pipeline) and dev.type == "cuda"
+        self.s = s
         self.real = torch.zeros(batch, *img_shape, device=dev)
-        # z, alpha and the next iteration's z share ONE staging buffer: a caller that keeps its draws packed [z | alpha | z_next]
-        # feeds an iteration with one copy
-        nz = batch * s.latent_dim
-        self.inp = torch.zeros(2 * nz + batch, device=dev)
-        self.z = self.inp[:nz].view(batch, s.latent_dim)
-        self.alpha = self.inp[nz:nz + batch].view(batch, 1, 1, 1)
-        self.z_next = self.inp[nz + batch:].view(batch, s.latent_dim)
-        self.has = False          # the prefetch buffer holds this iteration's images (state of the replayed sequence)
-        self.runners = {}
+        # z and alpha share ONE staging buffer, so a caller that keeps its draws packed [z | alpha] feeds an iteration with one copy
+        self.inp = torch.zeros(batch * s.latent_dim + batch, device=dev)
+        self.z = self.inp[:batch * s.latent_dim].view(batch, s.latent_dim)
+        self.alpha = self.inp[batch * s.latent_dim:].view(batch, 1, 1, 1)
+        self.runners = {
+            True: StepRunner(lambda: wgan_gp_step(s, self.real, 0, self.z, self.alpha), s.dp, use_graph, warmup),
+            False: StepRunner(lambda: wgan_gp_step(s, self.real, 1, self.z, self.alpha), s.dp, use_graph, warmup),
+        }
 
-    def _shape(self, i):
-        gen = i % self.s.n_critic == 0
-        do = self.pipeline and not gen
-        return (self.has and self.pipeline, do, gen)
-
-    def _runner(self, key):
-        r = self.runners.get(key)
-        if r is None:
-            from .graph import StepRunner
-
-            has, do, gen = key
-
-            def fn():
-                if self.pipeline:
-                    _prefetch_pipe(self.s, self.real).valid = has   # the shape's entry state, for the warm-up runs and the capture alike
-                return wgan_gp_step(self.s, self.real, 0 if gen else 1, self.z, self.alpha, z_next=self.z_next if do else None)
-
-            r = self.runners[key] = StepRunner(fn, self.s.dp, self.use_graph, self.warmup).prepare()
-        return r
-
-    def prepare(self, real, z, alpha, z_next=None):
-        self._load(real, z, alpha, z_next=z if z_next is None else z_next)
-        if self.pipeline:
-            _prefetch_pipe(self.s, self.real)
-            # in the order a run meets them: iteration 0 (generator update, nothing prefetched), 1 (prefetches), 2 (consumes and
-            # prefetches), 5 (consumes, generator update) - every shape's warm-up finds a real generator output in the buffer
-            for key in ((False, False, True), (False, True, False), (True, True, False), (True, False, True)):
-                self._runner(key)
-            self.has = False
-        else:
-            for key in ((False, False, True), (False, False, False)):
-                self._runner(key)
+    def prepare(self, real, z, alpha):
+        self._load(real, z, alpha)
+        for r in self.runners.values():
+            r.prepare()
         return self
 
     @property
     def graphed(self):
-        return bool(self.runners) and all(r.graphed for r in self.runners.values())
+        return all(r.graphed for r in self.runners.values())
 
     @property
     def capture_error(self):
         return next((r.capture_error for r in self.runners.values() if r.capture_error), None)
 
-    def _load(self, real, z, alpha, packed=None, z_next=None):
+    def _load(self, real, z, alpha, packed=None):
         if real is not None:
             self.real.copy_(real)
         if packed is not None:
-            flat = packed.reshape(-1)
-            self.inp[:flat.numel()].copy_(flat)   # [z | alpha] or [z | alpha | z_next]
+            self.inp.copy_(packed.reshape(self.inp.shape))
         else:
             self.z.copy_(z)
             self.alpha.copy_(alpha.reshape(self.alpha.shape))
-            if z_next is not None:
-                self.z_next.copy_(z_next)
 
-    def run(self, i, real, z, alpha, packed=None, z_next=None):
+    def run(self, i, real, z, alpha, packed=None):
         """Iteration i on (real, z, alpha); pass real=None to keep the batch already in the static buffer; `packed` = the flat
-        [z | alpha | z_next] of this iteration instead of the separate tensors.  z_next = the z of iteration i + 1 (what the
-        prefetch runs on; with pipeline=True it must be given - directly or in `packed` - and the next call's z must equal it)."""
-        self._load(real, z, alpha, packed, z_next)
-        key = self._shape(i)
-        out = self._runner(key).run()
-        self.has = key[1]
-        if self.pipeline:
-            _prefetch_pipe(self.s, self.real).valid = self.has   # eager fall-back runs keep the same state as the replayed sequence
-        return out
+        [z | alpha] of this iteration (batch * latent + batch floats) instead of z and alpha."""
+        self._load(real, z, alpha, packed)
+        return self.runners[i % self.s.n_critic == 0].run()
 
 
 # ------------------------------------------------------------------------------------------------ cyclegan

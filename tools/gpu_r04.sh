@@ -205,19 +205,6 @@ ab() {
   done
 }
 
-task_fourteenth() {   # wgan_gp: the next iteration's generator forward prefetched underneath the critic launches
-  local O=gpurun_out/r4n; mkdir -p $O
-  timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "wgan" --durations=3 > $O/pytest.txt 2>&1
-  tail -4 $O/pytest.txt
-  for r in 1 2; do
-    echo "== wgan_gp --no-overlap" >> $O/bench.txt
-    timeout 300 python bench.py --workload wgan_gp --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-roofline --no-overlap 2>>$O/bench.txt.err | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'])" >> $O/bench.txt
-    bl $O/bench.txt wgan_gp 200
-  done
-  cat $O/bench.txt; tail -3 $O/bench.txt.err
-  task_prof r4n wgan_gp:graph
-}
-
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -329,7 +316,6 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
-  fourteenth) task_fourteenth "$@" ;;
   final) task_final "$@" ;;
   thirteenth) task_thirteenth "$@" ;;
   twelfth) task_twelfth "$@" ;;
