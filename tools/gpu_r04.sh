@@ -205,6 +205,17 @@ ab() {
   done
 }
 
+task_fifteenth() {   # priority of the discriminator half's stream
+  local O=gpurun_out/r4o; mkdir -p $O
+  for w in dcgan pix2pix srgan cyclegan; do
+    k=4; [ $w = dcgan ] && k=50; [ $w = pix2pix ] && k=50
+    for pr in 0 -1 0 -1; do
+      bl $O/bench.txt $w $k MIGAN_D_PRIORITY=$pr
+    done
+  done
+  cat $O/bench.txt
+}
+
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -316,6 +327,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  fifteenth) task_fifteenth "$@" ;;
   final) task_final "$@" ;;
   thirteenth) task_thirteenth "$@" ;;
   twelfth) task_twelfth "$@" ;;
