@@ -120,7 +120,6 @@ def _labels(s, shape, device):
 # join, so nothing reads a weight that is being updated.  Same kernels in the same order per stream: results are bit-identical to the
 # sequential order (tests flip `_OVERLAP_D`).  Inside a captured step the fork / join are edges of the one hipGraph.
 _OVERLAP_D = True
-_D_PRIORITY = int(os.environ.get("MIGAN_D_PRIORITY", "-1"))   # temporary A/B knob (gpu_r04.sh fifteenth)
 _D_STREAMS = {}
 
 
@@ -128,9 +127,9 @@ def _d_stream(device):
     main = torch.cuda.current_stream(device)
     key = (device.index, main.cuda_stream)
     if key not in _D_STREAMS:
-        # high priority: the second stream carries chains of SHORT dependent launches; at equal priority every one of them queues behind
-        # the thousands of workgroups of the MFMA launch on the other stream (_D_PRIORITY = 0: the A/B)
-        _D_STREAMS[key] = torch.cuda.Stream(device, priority=_D_PRIORITY)
+        # (default priority: a high-priority second stream was measured - the captured DCGAN step 2.91 -> 4.33 ms, SRGAN +0.5 %,
+        # CycleGAN -0.5 %, profiles/r04_ab.txt call 16)
+        _D_STREAMS[key] = torch.cuda.Stream(device)
     return main, _D_STREAMS[key]
 
 
