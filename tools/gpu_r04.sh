@@ -216,6 +216,19 @@ task_fifteenth() {   # priority of the discriminator half's stream
   cat $O/bench.txt
 }
 
+task_timeline() {   # kernel timeline of the captured DCGAN step (which stream is the critical path)
+  local O=gpurun_out/r4p; mkdir -p $O
+  for mode in overlap nooverlap; do
+    flag=; [ $mode = nooverlap ] && flag=--no-overlap
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $R/$O/tl_$mode -o dcgan -- python $R/bench.py --workload dcgan --steps 20 --warmup 2 --min-seconds 0 \
+       --no-roofline --no-cpu-baseline --no-extra $flag > $R/$O/tl_$mode.log 2>&1)
+    db=$(ls $O/tl_$mode/*/dcgan_results.db $O/tl_$mode/dcgan_results.db 2>/dev/null | head -1)
+    python tools/rocpd_timeline.py $db 420 > $O/timeline_$mode.csv 2>&1
+    rm -rf $O/tl_$mode
+    head -3 $O/timeline_$mode.csv | cut -c1-200
+  done
+}
+
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -327,6 +340,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  timeline) task_timeline "$@" ;;
   fifteenth) task_fifteenth "$@" ;;
   final) task_final "$@" ;;
   thirteenth) task_thirteenth "$@" ;;
