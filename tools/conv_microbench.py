@@ -24,6 +24,8 @@ SHAPES = {
         ("D.conv2 16->32 s2", 128, 16, 32, 32, 32, 3, 2, 1, 0),
         ("D.conv3 32->64 s2", 128, 32, 16, 16, 64, 3, 2, 1, 0),
         ("D.conv4 64->128 s2", 128, 64, 8, 8, 128, 3, 2, 1, 0),
+        ("D2.conv3 32->64 s2 b256", 256, 32, 16, 16, 64, 3, 2, 1, 0),
+        ("D2.conv4 64->128 s2 b256", 256, 64, 8, 8, 128, 3, 2, 1, 0),
     ],
     "cyclegan": [
         ("c7s1-64 3->64 reflect", 8, 3, 256, 256, 64, 7, 1, 3, 1),

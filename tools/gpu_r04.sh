@@ -229,6 +229,21 @@ task_timeline() {   # kernel timeline of the captured DCGAN step (which stream i
   done
 }
 
+task_sixteenth() {   # split-K reach for the under-filled DCGAN discriminator convs
+  local O=gpurun_out/r4q; mkdir -p $O
+  for cfg in "0 0" "256 8" "512 8" "256 4" "0 0" "256 8"; do
+    set -- $cfg
+    echo "== MIGAN_DMA_SK_T=$1 MIGAN_DMA_SK_KT=$2" >> $O/micro.txt
+    MIGAN_DMA_SK_T=$1 MIGAN_DMA_SK_KT=$2 timeout 200 python tools/conv_microbench.py --shapes dcgan --match "D" --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep "conv3\|conv4" >> $O/micro.txt
+  done
+  cat $O/micro.txt
+  for cfg in "0 0" "256 8" "0 0" "256 8"; do
+    set -- $cfg
+    bl $O/bench.txt dcgan 50 MIGAN_DMA_SK_T=$1 MIGAN_DMA_SK_KT=$2
+  done
+  cat $O/bench.txt
+}
+
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -340,6 +355,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  sixteenth) task_sixteenth "$@" ;;
   timeline) task_timeline "$@" ;;
   fifteenth) task_fifteenth "$@" ;;
   final) task_final "$@" ;;
