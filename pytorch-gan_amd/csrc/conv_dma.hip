@@ -476,9 +476,9 @@ int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const f
         int minKT = 1 << 30;
         for (int c = 0; c < g.ncls; ++c)
             if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * ((g.Ci + 31) / 32) < minKT) minKT = g.ntap[c] * ((g.Ci + 31) / 32);
-        static const int sk_t = getenv("MIGAN_DMA_SK_T") ? atoi(getenv("MIGAN_DMA_SK_T")) : 0;      // sweep knobs (gpu_r04.sh sixteenth)
-        static const int sk_kt = getenv("MIGAN_DMA_SK_KT") ? atoi(getenv("MIGAN_DMA_SK_KT")) : 0;
-        if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64) || (sk_t > 0 && T64 <= sk_t && minKT >= sk_kt)) {
+        // (a wider reach - up to 256 / 512 tiles, from 4 / 8 K-tiles - was measured on the DCGAN discriminator convs at batch 128 / 256:
+        // 13.6 -> 18.2 us, 14.7 -> 23.7 us, 19.4 -> 21.7 us, the step 2.906 -> 2.931 ms; profiles/r04_ab.txt call 18)
+        if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64)) {
             const int rc = launch_dma_small(g, A, Bw, bias, C, ab, bb, maxM, ws, ws_bytes, st);
             if (rc != -2) return rc;
         }
