@@ -159,10 +159,11 @@ def test_dcgan_discriminator_half_on_a_second_stream_is_bit_identical(use_graph)
     from pytorch_gan_amd import functional as F
 
     res = {}
-    old = (steps._OVERLAP_D, F._WGRAD_STREAM)
+    old = (steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN)
     try:
         for overlap in (True, False):   # True: second stream for the discriminator half AND the weight-gradient streams (functional._Fork)
             steps._OVERLAP_D = F._WGRAD_STREAM = overlap
+            F._WGRAD_STREAM_MIN = 1 << 12   # no gradient of this 32x32 model reaches the production threshold: fork the larger ones anyway
             st = steps.make_gan_state(gpu_copy(base.G), gpu_copy(base.D))
             z_static = zs[0].clone()
             runner = graph.StepRunner(lambda: steps.dcgan_step(st, imgs, z_static), LocalStepper(), use_graph=use_graph, warmup=2).prepare()
@@ -176,7 +177,7 @@ def test_dcgan_discriminator_half_on_a_second_stream_is_bit_identical(use_graph)
             res[overlap] = (losses, [p.detach().clone() for p in list(st.G.parameters()) + list(st.D.parameters())],
                             [b.detach().clone() for b in list(st.G.buffers()) + list(st.D.buffers())])
     finally:
-        steps._OVERLAP_D, F._WGRAD_STREAM = old
+        steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN = old
     for (ga, da), (gb, db) in zip(res[True][0], res[False][0]):
         assert torch.equal(ga, gb) and torch.equal(da, db)
     for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
@@ -198,10 +199,11 @@ def test_cyclegan_discriminator_halves_on_a_second_stream_are_bit_identical():
     from pytorch_gan_amd import functional as F
 
     res = {}
-    old = (steps._OVERLAP_D, F._WGRAD_STREAM)
+    old = (steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN)
     try:
         for overlap in (True, False):   # both kinds of second stream on / off
             steps._OVERLAP_D = F._WGRAD_STREAM = overlap
+            F._WGRAD_STREAM_MIN = 1 << 12   # at 64x64 no gradient reaches the production threshold: fork the larger ones anyway
             st = steps.make_cyclegan_state(gpu_copy(base.G_AB), gpu_copy(base.G_BA), gpu_copy(base.D_A), gpu_copy(base.D_B))
             st.buf_A.max_size = st.buf_B.max_size = 3
             outs = []
@@ -212,7 +214,7 @@ def test_cyclegan_discriminator_halves_on_a_second_stream_are_bit_identical():
             torch.cuda.synchronize()
             res[overlap] = (outs, [p.detach().clone() for m in (st.G_AB, st.G_BA, st.D_A, st.D_B) for p in m.parameters()])
     finally:
-        steps._OVERLAP_D, F._WGRAD_STREAM = old
+        steps._OVERLAP_D, F._WGRAD_STREAM, F._WGRAD_STREAM_MIN = old
     for a, b in zip(res[True][0], res[False][0]):
         for k in a:
             assert torch.equal(a[k], b[k]), k
