@@ -53,7 +53,23 @@ _WGRAD_STREAM = True
 # be worth two more edges in the stream / hipGraph.  Measured with every weight gradient forked (profiles/r04_ab.txt, call 11): CycleGAN
 # 149.6 -> 144.9 ms, but the captured DCGAN step 2.53 -> 2.72 ms and pix2pix 3.32 -> 3.62 ms (dozens of forks around 5-20 us launches)
 _WGRAD_STREAM_MIN = 6 << 20
+# > 0 (one_wgrad_stream()): EVERY parameter-gradient launch of the region goes to ONE stream per device, whatever its size and whichever
+# stream its backward node runs on.  A step body that runs two forward chains on two streams (cyclegan_step: the A -> B -> A and the
+# B -> A -> B half of cyclegan.py:170-190 use the same two generators) has its backward on two streams as well - autograd runs a node on
+# its forward's stream - and both halves add into the same parameters' gradients: on one stream, in the autograd engine's (fixed) node order,
+# those additions stay serial and in the order of the one-stream step.
+_WGRAD_ONE_STREAM = 0
 _PENDING_WGRAD = {}
+
+
+@__import__("contextlib").contextmanager
+def one_wgrad_stream():
+    global _WGRAD_ONE_STREAM
+    _WGRAD_ONE_STREAM += 1
+    try:
+        yield
+    finally:
+        _WGRAD_ONE_STREAM -= 1
 
 
 def join_wgrad_streams():
@@ -74,13 +90,14 @@ class _Fork:
         first_order = not torch.is_grad_enabled()
         # only inside a step body (weight_cache_scope): its optimiser steps and its end join the stream - a bare loss.backward() of user
         # code reads .grad right away
-        self.defer = (bool(wgrad) and _WGRAD_STREAM and numel >= _WGRAD_STREAM_MIN and first_order and device.type == "cuda"
-                      and _CACHE_SCOPE is not None)
+        force = _WGRAD_ONE_STREAM > 0
+        self.defer = (bool(wgrad) and first_order and device.type == "cuda" and _CACHE_SCOPE is not None
+                      and (force or (_WGRAD_STREAM and numel >= _WGRAD_STREAM_MIN)))
         self.on = self.defer or (bool(both) and _OVERLAP_WGRAD != 0 and first_order
                                  and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
         if self.on:
             self.main = torch.cuda.current_stream(device)
-            key = (device.index, self.main.cuda_stream)
+            key = (device.index, "all") if (force and self.defer) else (device.index, self.main.cuda_stream)
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device)
             self.side = _SIDE_STREAMS[key]
@@ -104,6 +121,9 @@ class _Fork:
         `reads`: main-stream tensors the side launches read (kept from being recycled under them when the join is deferred)."""
         if not self.on:
             return
+        if self.defer and _WGRAD_ONE_STREAM > 0 and not all(t is None for t in returned):
+            raise RuntimeError("one_wgrad_stream(): a parameter gradient without a gradient slot would be accumulated by autograd on its "
+                               "own stream (the step body must own every parameter through an optimiser's bucket)")
         if self.defer and all(t is None for t in returned):
             for t in reads:
                 if t is not None:
@@ -825,17 +845,20 @@ def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
     nq = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, S)
     q = _ws(nq, xs)
     check(lib.migan_thin_toeplitz_expand(dy.data_ptr(), q.data_ptr(), N, Ho, Wo, Co, W, S, pl, gather, st), "thin_toeplitz_expand")
-    if ctx.needs_input_grad[1]:
-        slot = _grad_slot(ctx.params[0])
-        dw = torch.empty_like(w) if slot is None else slot
-        nb = lib.migan_thin_toeplitz_wgrad_workspace(N, Ho, W, Ci, Co, R, S)
-        ws = _ws(nb, xs)
-        check(lib.migan_thin_toeplitz_wgrad(xs.data_ptr(), q.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci, Ho, Co, R,
-                                            S, pt, gather, 0 if slot is None else 1, st), "thin_toeplitz_wgrad")
-        if slot is not None:
-            dw = None
-    if want_db:
-        db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
+    fork = _Fork(xs.device, False, dy.numel(), ctx.needs_input_grad[1] or want_db)
+    with fork:
+        if ctx.needs_input_grad[1]:
+            slot = _grad_slot(ctx.params[0])
+            dw = torch.empty_like(w) if slot is None else slot
+            nb = lib.migan_thin_toeplitz_wgrad_workspace(N, Ho, W, Ci, Co, R, S)
+            ws = _ws(nb, xs)
+            check(lib.migan_thin_toeplitz_wgrad(xs.data_ptr(), q.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci, Ho, Co, R,
+                                                S, pt, gather, 0 if slot is None else 1, _stream()), "thin_toeplitz_wgrad")
+            if slot is not None:
+                dw = None
+        if want_db:
+            db = _colsum(dy, N * Ho * Wo, Co, _grad_slot(ctx.params[1]))
+    fork.join((dw, db), (dy, xs, q))
     if ctx.needs_input_grad[0] and gather != GATHER_ZERO:
         # reflection padding: the expansion's input gradient needs a row-padded intermediate + fold and measured slower
         # than the direct kernel (c7s1-3: 294 vs 208 us, profiles/r02_conv_microbench.txt)

@@ -133,6 +133,32 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
+_CHAINS = os.environ.get("MIGAN_CHAINS", "1") == "1"      # (env: temporary A/B knob) cyclegan_step: the two halves of the generators' forward (and backward) on two streams; tests / bench --no-overlap flip it
+_C_STREAMS = {}
+
+
+def _c_stream(device):
+    """(current stream, the stream of cyclegan_step's second forward chain) - not the discriminator halves' stream: the chain's
+    backward nodes run on it during the generators' backward, beside the discriminator updates."""
+    main = torch.cuda.current_stream(device)
+    key = (device.index, main.cuda_stream)
+    if key not in _C_STREAMS:
+        _C_STREAMS[key] = torch.cuda.Stream(device)
+    return main, _C_STREAMS[key]
+
+
+def _conv_params_only(s):
+    """True when every parameter of the CycleGAN generators belongs to a conv layer (cyclegan/models.py:22-88: InstanceNorm2d without
+    affine parameters): their gradients all come from weight-gradient launches, which one_wgrad_stream() serialises.  A norm layer with
+    affine parameters would add its gradients on the backward node's own stream."""
+    ok = s.__dict__.get("_chains_ok")
+    if ok is None:
+        ok = all(isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) or not list(m.parameters(recurse=False))
+                 for g in (s.G_AB, s.G_BA) for m in g.modules())
+        s._chains_ok = ok
+    return ok
+
+
 def _two_streams_ok(s, ref):
     # skip_dead_grads: otherwise the generator's backward also writes (dead) discriminator gradients, which the other stream zeroes;
     # cross-replica BatchNorm puts collectives inside forward / backward: one stream
@@ -762,14 +788,48 @@ def cyclegan_step(s, real_A, real_B):
     s.G_BA.train()
     s.dp.begin_step()
     s.opt_G.zero_grad()
-    loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
-    with frozen(s.D_A, s.D_B, enabled=s.skip):
-        fake_B = s.G_AB(real_A)
-        loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
-        fake_A = s.G_BA(real_B)
-        loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
-    loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
-    loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
+    chains = _CHAINS and _two_streams_ok(s, real_A) and _conv_params_only(s)
+    if chains:
+        # The generators' step is two independent halves (cyclegan.py:170-190): real_A -> G_AB -> fake_B -> {D_B, G_BA -> recov_A} with
+        # the identity pass G_BA(real_A), and the mirror image from real_B.  They share nothing but the (read-only) weights until the
+        # losses are added, so the second half's forward runs on a second stream beside the first: one half's InstanceNorm passes (HBM)
+        # and its MFMA launches' stalls are filled by the other half's launches.  Autograd runs each backward node on its forward's
+        # stream, so the backward is two-stream as well; every parameter-gradient launch of both halves goes to ONE stream
+        # (functional.one_wgrad_stream) in the engine's node order, so the additions into the shared parameters' gradients are serial
+        # and in the order of the one-stream step: bit-identical results.
+        main, side = _c_stream(real_A.device)
+        wcm = F.one_wgrad_stream()
+        wcm.__enter__()
+        try:
+            side.wait_stream(main)
+            with F.two_streams(), frozen(s.D_A, s.D_B, enabled=True):
+                with torch.cuda.stream(side):
+                    id_B = s.l1(s.G_AB(real_B), real_B)
+                    fake_A = s.G_BA(real_B)
+                    loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+                    cyc_B = s.l1(s.G_AB(fake_A), real_B)
+                id_A = s.l1(s.G_BA(real_A), real_A)
+                fake_B = s.G_AB(real_A)
+                loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+                cyc_A = s.l1(s.G_BA(fake_B), real_A)
+            main.wait_stream(side)
+        except BaseException:
+            wcm.__exit__(None, None, None)
+            main.wait_stream(side)
+            raise
+        loss_id = half_sum(id_A, id_B)
+        loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
+        loss_cycle = half_sum(cyc_A, cyc_B)
+    else:
+        wcm = None
+        loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
+        with frozen(s.D_A, s.D_B, enabled=s.skip):
+            fake_B = s.G_AB(real_A)
+            loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+            fake_A = s.G_BA(real_B)
+            loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+        loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
+        loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
     loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
 
     def d_half(opt, D, real, buf, fake_img):   # cyclegan.py:203-233 up to loss_D_X.backward()
@@ -783,8 +843,14 @@ def cyclegan_step(s, real_A, real_B):
     if _two_streams_ok(s, real_A):
         # both discriminator updates underneath the generators' backward (see dcgan_step): they need fake_A / fake_B of the forward
         # only, and the step is ~1900 eager launches whose dependent-launch gaps the second stream's kernels fill
-        loss_D_A, loss_D_B = _fork_join(loss_G, lambda: (d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A),
-                                                         d_half(s.opt_D_B, s.D_B, real_B, s.buf_B, fake_B)))
+        try:
+            loss_D_A, loss_D_B = _fork_join(loss_G, lambda: (d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A),
+                                                             d_half(s.opt_D_B, s.D_B, real_B, s.buf_B, fake_B)))
+        finally:
+            if wcm is not None:
+                wcm.__exit__(None, None, None)
+                # the backward nodes of the second forward chain ran on its stream: the optimiser steps wait for them
+                torch.cuda.current_stream(real_A.device).wait_stream(_c_stream(real_A.device)[1])
         s.dp.step(s.opt_G)
         s.dp.step(s.opt_D_A)
         s.dp.step(s.opt_D_B)

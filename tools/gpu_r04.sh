@@ -244,6 +244,17 @@ task_sixteenth() {   # split-K reach for the under-filled DCGAN discriminator co
   cat $O/bench.txt
 }
 
+task_seventeenth() {   # cyclegan: the two halves of the generators' forward / backward on two streams
+  local O=gpurun_out/r4r; mkdir -p $O
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py tests/test_models_gpu.py -q -x -k "cyclegan or second_stream" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  for r in 1 2; do
+    bl $O/bench.txt cyclegan 4 MIGAN_CHAINS=0
+    bl $O/bench.txt cyclegan 4 MIGAN_CHAINS=1
+  done
+  cat $O/bench.txt
+}
+
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -355,6 +366,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  seventeenth) task_seventeenth "$@" ;;
   sixteenth) task_sixteenth "$@" ;;
   timeline) task_timeline "$@" ;;
   fifteenth) task_fifteenth "$@" ;;
