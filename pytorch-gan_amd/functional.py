@@ -428,6 +428,19 @@ class _PackPlan:
             p.__dict__.setdefault("_migan_pack", {})[kind] = (stamp, view)
 
 
+def prefill_packs(device):
+    """Run the step's multi-tensor pack launch NOW on the current stream (normally it rides on the first pack request of the step
+    body): a body that forks streams before its first conv calls this in front of the fork, so that no stream uses a planned pack
+    another stream is still writing."""
+    plan = _PackPlan.get(device)
+    scope = _CACHE_SCOPE
+    if scope is None or not (_BATCH_PACKS and _WEIGHT_CACHE) or scope == plan.scope:
+        return
+    prev, plan.scope, plan.seq = plan.seq, scope, {}
+    if prev:
+        plan._prefill(prev, device)
+
+
 def _packed_perm(param, w, kind, perm):
     """Cached `w.permute(perm).contiguous()` (weight pack), produced by the step's one multi-tensor launch when planned."""
     _PackPlan.get(w.device).note(param, w, kind, perm)

@@ -801,6 +801,7 @@ def cyclegan_step(s, real_A, real_B):
         wcm = F.one_wgrad_stream()
         wcm.__enter__()
         try:
+            F.prefill_packs(real_A.device)   # the step's planned weight packs exist before either half asks for one
             side.wait_stream(main)
             with F.two_streams(), frozen(s.D_A, s.D_B, enabled=True):
                 with torch.cuda.stream(side):
