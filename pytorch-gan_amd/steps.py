@@ -804,15 +804,19 @@ def cyclegan_step(s, real_A, real_B):
             F.prefill_packs(real_A.device)   # the step's planned weight packs exist before either half asks for one
             side.wait_stream(main)
             with F.two_streams(), frozen(s.D_A, s.D_B, enabled=True):
+                # host order = the one-stream body's order of calls: autograd numbers its nodes as they are made and walks them backward
+                # by that number, so the parameter-gradient launches reach their one stream in the same order as without the second stream
+                id_A = s.l1(s.G_BA(real_A), real_A)
                 with torch.cuda.stream(side):
                     id_B = s.l1(s.G_AB(real_B), real_B)
-                    fake_A = s.G_BA(real_B)
-                    loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
-                    cyc_B = s.l1(s.G_AB(fake_A), real_B)
-                id_A = s.l1(s.G_BA(real_A), real_A)
                 fake_B = s.G_AB(real_A)
                 loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+                with torch.cuda.stream(side):
+                    fake_A = s.G_BA(real_B)
+                    loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
                 cyc_A = s.l1(s.G_BA(fake_B), real_A)
+                with torch.cuda.stream(side):
+                    cyc_B = s.l1(s.G_AB(fake_A), real_B)
             main.wait_stream(side)
         except BaseException:
             wcm.__exit__(None, None, None)
