@@ -133,7 +133,7 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
-_CHAINS = os.environ.get("MIGAN_CHAINS", "1") == "1"      # (env: temporary A/B knob) cyclegan_step: the two halves of the generators' forward (and backward) on two streams; tests / bench --no-overlap flip it
+_CHAINS = True      # cyclegan_step: the two halves of the generators' forward (and backward) on two streams; tests / bench --no-overlap flip it
 _C_STREAMS = {}
 
 

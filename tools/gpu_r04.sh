@@ -255,6 +255,14 @@ task_seventeenth() {   # cyclegan: the two halves of the generators' forward / b
   cat $O/bench.txt
 }
 
+task_closing() {   # the round's closing call: parity of what changed after the full suite of call 19, then the default bench line
+  local O=gpurun_out/r4s; mkdir -p $O
+  timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "second_stream or srgan or pix2pix_step or dcgan_steps or two_ranks" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  task_bench
+  cp gpurun_out/r4bench/bench_default.json $O/bench_closing.json
+}
+
 task_final() {   # the round's last measurement pass on the final tree: default bench line, kernel traces, PMC passes over the steps
   task_bench
   cp gpurun_out/r4bench/bench_default.json gpurun_out/r4bench/bench_final.json
@@ -366,6 +374,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 
 t=${1:-}; shift || true
 case "$t" in
+  closing) task_closing "$@" ;;
   seventeenth) task_seventeenth "$@" ;;
   sixteenth) task_sixteenth "$@" ;;
   timeline) task_timeline "$@" ;;
