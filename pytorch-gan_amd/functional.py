@@ -849,9 +849,6 @@ def _toep_pack(w):
     return buf
 
 
-_TOEP_FORK = __import__("os").environ.get("MIGAN_TOEP_FORK", "1") == "1"   # temporary A/B knob (closing call)
-
-
 def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
     """First-order backward of a conv that ran through the width-Toeplitz expansion: dy (already through the activation
     backward) is expanded once into q, which both the weight and the input gradient GEMMs consume."""
@@ -861,7 +858,7 @@ def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
     nq = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, S)
     q = _ws(nq, xs)
     check(lib.migan_thin_toeplitz_expand(dy.data_ptr(), q.data_ptr(), N, Ho, Wo, Co, W, S, pl, gather, st), "thin_toeplitz_expand")
-    fork = _Fork(xs.device, False, dy.numel() if _TOEP_FORK else 0, ctx.needs_input_grad[1] or want_db)
+    fork = _Fork(xs.device, False, dy.numel(), ctx.needs_input_grad[1] or want_db)
     with fork:
         if ctx.needs_input_grad[1]:
             slot = _grad_slot(ctx.params[0])
