@@ -52,7 +52,7 @@ _WGRAD_STREAM = True
 # ... for gradients of at least this many elements (dy): the launch must be long enough (an MFMA-bound weight gradient of >= ~100 us) to
 # be worth two more edges in the stream / hipGraph.  Measured with every weight gradient forked (profiles/r04_ab.txt, call 11): CycleGAN
 # 149.6 -> 144.9 ms, but the captured DCGAN step 2.53 -> 2.72 ms and pix2pix 3.32 -> 3.62 ms (dozens of forks around 5-20 us launches)
-_WGRAD_STREAM_MIN = int(__import__("os").environ.get("MIGAN_WGRAD_MIN", str(6 << 20)))   # (env: temporary A/B knob)
+_WGRAD_STREAM_MIN = 6 << 20   # (1 M and 256 k measured on SRGAN: 82.7-82.8 vs 82.5-82.7 ms, profiles/r04_ab.txt call 28)
 # > 0 (one_wgrad_stream()): EVERY parameter-gradient launch of the region goes to ONE stream per device, whatever its size and whichever
 # stream its backward node runs on.  A step body that runs two forward chains on two streams (cyclegan_step: the A -> B -> A and the
 # B -> A -> B half of cyclegan.py:170-190 use the same two generators) has its backward on two streams as well - autograd runs a node on
