@@ -133,6 +133,7 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
+_VREAL_SIDE = os.environ.get("MIGAN_VREAL_SIDE", "1") == "1"   # (env: temporary A/B knob) srgan_step: VGG features of the real images beside the generator's forward
 _CHAINS = True      # cyclegan_step: the two halves of the generators' forward (and backward) on two streams; tests / bench --no-overlap flip it
 _C_STREAMS = {}
 
@@ -924,11 +925,21 @@ def srgan_step(s, imgs_lr, imgs_hr):
     valid, fake = _labels(s, (imgs_lr.size(0), *s.D.output_shape), imgs_lr.device)
     s.dp.begin_step()
     s.opt_G.zero_grad()
+    vside = _VREAL_SIDE and _two_streams_ok(s, imgs_lr)
+    if vside:
+        # feature_extractor(imgs_hr) of srgan.py:114 needs nothing from the generator and nobody differentiates it: it runs on the
+        # second stream beside the generator's forward (whose 33 trunk convs are single-round launches with a latency-bound tail)
+        main, side = _d_stream(imgs_lr.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            real_features = s.V(imgs_hr)
     gen_hr = s.G(imgs_lr)
     with frozen(s.D, s.V, enabled=s.skip):
         loss_GAN = s.mse(s.D(gen_hr), valid)
         gen_features = s.V(gen_hr)
-        if s.skip:
+        if vside:
+            main.wait_stream(side)
+        elif s.skip:
             with torch.no_grad():
                 real_features = s.V(imgs_hr)
         else:
