@@ -133,7 +133,7 @@ def _d_stream(device):
     return main, _D_STREAMS[key]
 
 
-_VREAL_SIDE = os.environ.get("MIGAN_VREAL_SIDE", "1") == "1"   # (env: temporary A/B knob) srgan_step: VGG features of the real images beside the generator's forward
+_VREAL_SIDE = True   # srgan_step: VGG features of the real images beside the generator's forward (83.10 -> 82.77 ms, profiles/r04_ab.txt call 29)
 _CHAINS = True      # cyclegan_step: the two halves of the generators' forward (and backward) on two streams; tests / bench --no-overlap flip it
 _C_STREAMS = {}
 
