@@ -1031,14 +1031,16 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const 
 
     for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
         __syncthreads();
-        // stage the window: flattened over (window pixel, channel quad), 4 independent branch-free loads per thread
-        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load)
+        // stage the window: flattened over (window pixel, channel quad), THIN_LD independent branch-free loads per thread
+        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load; 8 instead of 4: the
+        // 10 x 34 x 32-channel window of dcgan.py:62 is two rounds instead of three)
+        constexpr int THIN_LD = 8;
         const int total = tc.SH * tc.SW * Q;
-        for (int base = 0; base < total; base += 1024) {
-            f32x4 v[4];
-            int off[4];
+        for (int base = 0; base < total; base += 256 * THIN_LD) {
+            f32x4 v[THIN_LD];
+            int off[THIN_LD];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < THIN_LD; ++u) {
                 const int e = base + u * 256 + tid;
                 const bool in = e < total;
                 const int ec = in ? e : total - 1;
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const 
                 off[u] = in ? pidx * LDC + q * 4 : -1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < THIN_LD; ++u)
                 if (off[u] >= 0) *reinterpret_cast<f32x4*>(win + off[u]) = v[u];
         }
         __syncthreads();
