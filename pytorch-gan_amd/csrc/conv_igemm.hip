@@ -1032,9 +1032,9 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const 
     for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
         __syncthreads();
         // stage the window: flattened over (window pixel, channel quad), THIN_LD independent branch-free loads per thread
-        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load; 8 instead of 4: the
-        // 10 x 34 x 32-channel window of dcgan.py:62 is two rounds instead of three)
-        constexpr int THIN_LD = 8;
+        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load; 8 in flight were
+        // measured slower than 4 - 66.6 vs 62.5 us on the 10 x 34 x 32-channel window of dcgan.py:62, profiles/r04_ab.txt call 30)
+        constexpr int THIN_LD = 4;
         const int total = tc.SH * tc.SW * Q;
         for (int base = 0; base < total; base += 256 * THIN_LD) {
             f32x4 v[THIN_LD];
