@@ -4,6 +4,7 @@ import json
 import os
 import sys
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -404,3 +405,84 @@ def test_pmc_step_joins_counter_rows_to_roofline_groups_by_launch_ordinal(tmp_pa
     n = tab["norm_apply[1x64x4]"]
     assert n["algorithmic_mb_per_call"] == 64.0 and n["hbm_bytes_per_launch"] == int((2 * 31.25 + 62.5) * 1024)
     assert [os.path.basename(p_) for p_ in tab["_source"]["passes"]] == ["fetch", "sq", "write"]
+
+
+def test_weight_gradient_stream_protocol(monkeypatch):
+    """functional._Fork in its deferred form (weight-gradient launches of a step body on their own stream): which launches fork, what is
+    joined when - with recording stand-ins for the HIP streams (no GPU: the stream objects only have to remember who waited for whom)."""
+    import pytorch_gan_amd.functional as F
+
+    log = []
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name, self.cuda_stream = name, hash(name) & 0xffff
+
+        def wait_stream(self, other):
+            log.append((self.name, "waits", other.name))
+
+        def __enter__(self):
+            log.append((self.name, "enter"))
+
+        def __exit__(self, *a):
+            log.append((self.name, "exit"))
+
+    main = FakeStream("main")
+    made = []
+
+    def new_stream(device=None):
+        made.append(FakeStream("side%d" % len(made)))
+        return made[-1]
+
+    class FakeTensor:
+        def __init__(self):
+            self.recorded = []
+
+        def record_stream(self, st):
+            self.recorded.append(st.name)
+
+    dev = torch.device("cuda", 0)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda d=None: main)
+    monkeypatch.setattr(torch.cuda, "Stream", new_stream)
+    monkeypatch.setattr(torch.cuda, "stream", lambda st: st)
+    monkeypatch.setattr(F, "_SIDE_STREAMS", {})
+    monkeypatch.setattr(F, "_PENDING_WGRAD", {})
+    big, small = F._WGRAD_STREAM_MIN, F._WGRAD_STREAM_MIN - 1
+    with torch.no_grad():
+        # outside a step body (no weight_cache_scope): never deferred - a bare loss.backward() reads .grad right away
+        assert not F._Fork(dev, True, big, True).on
+        with F.weight_cache_scope():
+            f = F._Fork(dev, True, small, True)
+            assert not f.on                                   # below the threshold: in line with its layer's backward
+            f = F._Fork(dev, False, big, True)
+            assert f.on and f.defer
+            dy, xs = FakeTensor(), FakeTensor()
+            with f:
+                pass
+            f.join((None, None), (dy, xs, None))              # everything went into gradient slots: join deferred
+            assert log == [("side0", "waits", "main"), ("side0", "enter"), ("side0", "exit")]
+            assert dy.recorded == xs.recorded == ["side0"] and len(F._PENDING_WGRAD) == 1
+            g = F._Fork(dev, False, big, True)
+            with g:
+                pass
+            g.join((object(), None), (dy,))                   # a gradient returned to autograd: joined at once
+            assert log[-1] == ("main", "waits", "side0")
+            F.join_wgrad_streams()
+            assert log[-1] == ("main", "waits", "side0") and not F._PENDING_WGRAD
+            n = len(log)
+            F.join_wgrad_streams()                            # nothing pending: no wait
+            assert len(log) == n
+            # one_wgrad_stream(): every size, ONE stream per device whatever the forking stream, and a returned gradient is an error
+            with F.one_wgrad_stream():
+                h = F._Fork(dev, False, 16, True)
+                assert h.on and h.defer and h.key == (0, "all")
+                with h:
+                    pass
+                with pytest.raises(RuntimeError):
+                    h.join((object(),), ())
+                h.join((None,), ())
+            assert (0, "all") in F._PENDING_WGRAD
+            F.join_wgrad_streams()
+    # second-order backward (grad mode on): never forked
+    with F.weight_cache_scope():
+        assert not F._Fork(dev, True, big, True).on
