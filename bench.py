@@ -775,7 +775,7 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = _safe_cpu_baseline(init)
         extra = result["extra"] = {}
-        for other, k, wu in (("cyclegan", 4, 1), ("srgan", 4, 1), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
+        for other, k, wu in (("cyclegan", 4, 3), ("srgan", 4, 3), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
             extra[other] = run_extra(other, k, wu, dp, rank, dev, args)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
