@@ -51,7 +51,7 @@ class DataParallel:
         self.cuda = torch.cuda.is_available() and dist.get_backend(group) in ("nccl", "gloo")
         self.side = torch.cuda.Stream() if (self.cuda and overlap) else None
         self.segment = True     # graph.StepRunner cuts the captured step at every step(): the collective replays eagerly
-        self.graph_ok = True    # False while cross-replica BatchNorm is on (collectives inside forward/backward)
+        self.graph_ok = True    # graph.StepRunner may record the step (cross-replica BatchNorm cuts segments at its collectives)
         self.sync_bn = None
         self._pending = []      # optimisers with an update in flight on the side stream (event in opt.pending)
         self._segmenter = None  # set by graph.StepRunner while it records the step
@@ -126,19 +126,19 @@ class DataParallel:
         """BatchNorm statistics (forward) and batch sums (backward) over the GLOBAL batch: with equal shards the N-rank
         step then computes what the single-process reference computes on the whole batch for the BatchNorm models
         (dcgan.py:53-60, srgan/models.py:23-26,47,87-90, wgan_gp.py:49), instead of per-rank statistics.  Costs one
-        all_gather of 2*C floats per BatchNorm forward and one all_reduce of 2*C floats per backward; these run inside
-        forward/backward, so the step can no longer be captured into hipGraphs (graph.StepRunner runs it eagerly)."""
+        all_gather of 2*C floats per BatchNorm forward and one all_reduce of 2*C floats per backward.  These run inside
+        forward/backward: a recorded step (graph.StepRunner) is cut into one more hipGraph segment at each of them, the
+        collective replaying eagerly in between on buffers that belong to the recording (DCGAN: 24 + the 2 optimiser cuts)."""
         from . import functional as F
 
         self.sync_bn = _SyncBN(self)
-        self.graph_ok = False
         F.set_sync_batchnorm(self.sync_bn)
         return self.sync_bn
 
     def disable_sync_batchnorm(self):
         from . import functional as F
 
-        self.sync_bn, self.graph_ok = None, True
+        self.sync_bn = None
         F.set_sync_batchnorm(None)
 
     # -- helpers -----------------------------------------------------------------------------------
@@ -158,27 +158,51 @@ class DataParallel:
 
 
 class _SyncBN:
-    """The two collectives of cross-replica BatchNorm, on the current stream (functional._Norm calls them)."""
+    """The two collectives of cross-replica BatchNorm, on the current stream (functional._Norm calls them).
+
+    While graph.StepRunner records the step (dp._segmenter set) a collective cannot go into the capture: the open hipGraph segment is
+    closed, the collective is queued as an eager item between segments, and the next segment opens.  Its operands are tensors of the
+    recording (allocated from the graph pool, kept alive by the queued closure), so every replay runs it on the addresses the
+    neighbouring segments write and read.  The cut happens on the thread that records - graph.StepRunner turns the autograd worker
+    threads off for the recording, so backward nodes run on it too."""
 
     def __init__(self, dp):
         self.dp, self.world = dp, dp.world
+        self.cuts = 0   # collectives queued as eager items by the last recording
+
+    def _run(self, fn):
+        seg = self.dp._segmenter
+        if seg is None:
+            fn()
+            return
+        from . import functional as F
+
+        F.join_wgrad_streams()   # a segment ends with every stream it forked joined
+        seg.cut(fn)
+        self.cuts += 1
 
     def all_gather(self, t):
         """[K] per rank -> [world * K], rank-major."""
         k = t.numel()
+        src = t.contiguous()
+        out = torch.empty(self.world * k, device=t.device, dtype=t.dtype)
         if dist.get_backend(self.dp.group) == "nccl":
-            out = torch.empty(self.world * k, device=t.device, dtype=t.dtype)
-            dist.all_gather_into_tensor(out, t.contiguous(), group=self.dp.group)
+            self._run(lambda: dist.all_gather_into_tensor(out, src, group=self.dp.group))
             return out
         # gloo (CPU tests, 2-ranks-on-one-GPU test mode): a summed all-reduce of a buffer in which every rank filled only
         # its own slot is the same gather, on the collective every backend implements for every device
-        out = torch.zeros(self.world * k, device=t.device, dtype=t.dtype)
-        out[self.dp.rank * k:(self.dp.rank + 1) * k] = t.reshape(-1)
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.dp.group)
+        flat, lo = src.reshape(-1), self.dp.rank * k
+
+        def gather():
+            out.zero_()
+            out[lo:lo + k] = flat
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.dp.group)
+
+        self._run(gather)
         return out
 
     def all_reduce_sum(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.group)
+        self._run(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.dp.group))
         return t
 
 

@@ -7,7 +7,9 @@ so the step is recorded once with torch.cuda.CUDAGraph (hipGraph on ROCm) and re
 
 world_size == 1: one graph for the whole step (forward, backward, Adam of G and D).
 world_size  > 1: the step is cut at every `dp.step(opt)`; the compute segments are graphs, and the RCCL
-all-reduce + fused Adam run eagerly between them on the side stream (no collective inside a capture).
+all-reduce + fused Adam run eagerly between them on the side stream (no collective inside a capture).  With
+cross-replica BatchNorm on (dp.enable_sync_batchnorm) the step is also cut at each of its collectives - inside forward
+and backward; the recording runs autograd on the recording thread for that (a capture ends on the thread that began it).
 
 What a capture freezes, and how the step bodies deal with it:
   * scalar kernel arguments — the learning rate is therefore read from a device scalar (optim.Adam.lr_t) that
@@ -18,6 +20,8 @@ What a capture freezes, and how the step bodies deal with it:
     large enough not to be host-bound);
   * packed-weight cache entries never cross a capture boundary (functional.weight_cache_scope).
 """
+import contextlib
+
 import torch
 
 from .optim import sync_all_lr
@@ -86,7 +90,7 @@ class StepRunner:
         if not self.use_graph:
             return self
         if not getattr(self.dp, "graph_ok", True):
-            self.capture_error = "not captured: cross-replica BatchNorm runs collectives inside forward/backward"
+            self.capture_error = "not captured: the data-parallel wrapper does not allow it (graph_ok)"
             return self
         try:
             self._capture(side)
@@ -103,10 +107,17 @@ class StepRunner:
         multi = getattr(self.dp, "segment", getattr(self.dp, "world", 1) > 1)  # DataParallel: collectives between segments
         if multi:
             self.dp._segmenter = seg
+        sync_bn = getattr(self.dp, "sync_bn", None)
+        if sync_bn is not None:
+            sync_bn.cuts = 0
+        # cross-replica BatchNorm cuts segments from inside backward nodes: those must run on this thread, not on autograd's device
+        # worker (hipStreamEndCapture belongs to the thread of hipStreamBeginCapture under the thread_local mode)
+        threads = torch.autograd.set_multithreading_enabled(False) if sync_bn is not None else contextlib.nullcontext()
         try:
-            seg.begin()
-            self.out = self.fn()
-            seg.end()
+            with threads:
+                seg.begin()
+                self.out = self.fn()
+                seg.end()
         except BaseException as e:
             seg.abort(e)
             raise

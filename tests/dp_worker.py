@@ -2,6 +2,9 @@
 
     python tests/dp_worker.py nccl1 <out.json>     world_size 1, backend nccl (= RCCL): side-stream all-reduce + graph segments
     python tests/dp_worker.py syncbn <out.pt>      N ranks (gloo, all on cuda:0): cross-replica BatchNorm DCGAN step
+                                                   MIGAN_TEST_STEPS=k: k steps;  MIGAN_TEST_GRAPH=1: step 1 eager, the rest replays of
+                                                   the recorded step (hipGraph segments cut at every BatchNorm collective);
+                                                   MIGAN_TEST_GRAPH=cuts: the recording protocol without a capture (CPU)
 """
 import json
 import os
@@ -91,7 +94,46 @@ def syncbn(out):
     _seed(9)
     imgs = (torch.rand(16, 1, 32, 32) * 2 - 1).cuda()
     z = torch.randn(16, 100).cuda()
-    o = steps.dcgan_step(s, dp.shard(imgs), dp.shard(z))
+    nsteps, mode = int(os.environ.get("MIGAN_TEST_STEPS", "1")), os.environ.get("MIGAN_TEST_GRAPH", "0")
+    xs, zs = dp.shard(imgs).clone(), dp.shard(z).clone()
+    info = {}
+    if mode == "1":
+        from pytorch_gan_amd import graph
+
+        runner = graph.StepRunner(lambda: steps.dcgan_step(s, xs, zs), dp, use_graph=True, warmup=1).prepare()
+        for _ in range(nsteps - 1):
+            o = runner.run()
+        kinds = [k for k, _ in runner._segments or []]
+        info = {"graphed": runner.graphed, "capture_error": runner.capture_error, "graphs": kinds.count("graph"),
+                "eager": kinds.count("eager"), "cuts": dp.sync_bn.cuts if sync else 0}
+    elif mode == "cuts":
+        # what a recording does to the step, minus the capture: every BatchNorm collective and every dp.step() goes through
+        # _Segmenter.cut() on the thread that runs the step (autograd worker threads off, as graph.StepRunner._capture sets it)
+        import threading
+
+        class Cuts:
+            def __init__(self):
+                self.items, self.threads = [], set()
+
+            def cut(self, fn):
+                self.threads.add(threading.get_ident())
+                self.items.append(fn)
+                fn()
+
+        for _ in range(nsteps):
+            seg = dp._segmenter = Cuts()
+            if sync:
+                dp.sync_bn.cuts = 0
+            with torch.autograd.set_multithreading_enabled(False):
+                o = steps.dcgan_step(s, xs, zs)
+            dp._segmenter = None
+            dp.end_step()
+        info = {"items": len(seg.items), "cuts": dp.sync_bn.cuts if sync else 0,
+                "own_thread": seg.threads == {threading.get_ident()}}
+    else:
+        for _ in range(nsteps):
+            dp.begin_step()
+            o = steps.dcgan_step(s, xs, zs)
     dp.end_step()
     torch.cuda.synchronize()
     # the logged loss of a rank is the mean over its shard: average over ranks = the full-batch mean
@@ -99,7 +141,7 @@ def syncbn(out):
     dist.all_reduce(losses)
     losses /= dp.world
     if dp.rank == 0:
-        torch.save({"losses": losses.cpu(),
+        torch.save({"losses": losses.cpu(), "info": info,
                     "G": {k: v.detach().cpu() for k, v in s.G.state_dict().items()},
                     "D": {k: v.detach().cpu() for k, v in s.D.state_dict().items()},
                     "gG": s.opt_G.flat_grad.cpu() / dp.world, "gD": s.opt_D.flat_grad.cpu() / dp.world}, out)

@@ -81,7 +81,7 @@ def _worker(rank, world, port, out):
     # cross-replica BatchNorm protocol (host side): gather of the per-rank moments + Chan combination == moments of the
     # whole batch; all-reduced backward sums == sums over the whole batch
     sync = dp.enable_sync_batchnorm()
-    assert dp.graph_ok is False
+    assert dp.graph_ok is True and dp.sync_bn is sync   # recorded steps are cut at the BatchNorm collectives (graph.StepRunner)
     feat = torch.rand(8, 6, generator=torch.Generator().manual_seed(11)) * 3 + 5
     mine = dp.shard(feat)
     mom = torch.cat([mine.mean(0), mine.var(0, unbiased=False)])
@@ -92,7 +92,7 @@ def _worker(rank, world, port, out):
     sums = sync.all_reduce_sum(mine.sum(0).clone())
     assert torch.allclose(sums, feat.sum(0), atol=1e-5)
     dp.disable_sync_batchnorm()
-    assert dp.graph_ok is True
+    assert dp.sync_bn is None
     dp.begin_step()
     opt_D.zero_grad()
     (-torch.mean(D(dp.shard(xb)))).backward()      # every loss on the path is a batch mean

@@ -49,6 +49,30 @@ def _run_ranks(mode, out, world, extra_env=None):
     return torch.load(out)
 
 
+def test_cross_replica_batchnorm_step_replays_as_graph_segments(tmp_path):
+    """with enable_sync_batchnorm() the recorded DCGAN step is cut at each of the 24 BatchNorm collectives (3 + 3
+    layers x generator pass, discriminator passes on real and generated images, and the backward of each) and at the two optimiser
+    exchanges; the collectives replay eagerly between the hipGraph segments on buffers of the recording.  Three steps (one eager
+    warm-up + two replays) on two ranks leave bit-identical parameters, gradients and running statistics to three eager steps.
+    On the execution model (no capture there) the same worker checks the recording protocol: every cut on the recording thread."""
+    mode = "cuts" if os.environ.get("MIGAN_TEST_EMU") == "1" else "1"
+    want = _run_ranks("syncbn", str(tmp_path / "eager.pt"), 2, {"MIGAN_TEST_STEPS": "3"})
+    got = _run_ranks("syncbn", str(tmp_path / "graph.pt"), 2, {"MIGAN_TEST_STEPS": "3", "MIGAN_TEST_GRAPH": mode})
+    info = got["info"]
+    assert info["cuts"] == 24, info
+    if mode == "1":
+        assert info["graphed"], info
+        assert info["eager"] == 24 + 2 and info["graphs"] == info["eager"] + 1, info
+    else:
+        assert info["items"] == 24 + 2 and info["own_thread"], info
+    assert torch.equal(got["losses"], want["losses"])
+    for name in ("gG", "gD"):
+        assert torch.equal(got[name], want[name]), name
+    for net in ("G", "D"):
+        for k, v in want[net].items():
+            assert torch.equal(got[net][k], v), (net, k)
+
+
 def test_cross_replica_batchnorm_equals_full_batch(tmp_path):
     """2 ranks x 8 samples with enable_sync_batchnorm() == 1 process x 16 samples: losses, gradients (after the 1/world
     averaging) and BatchNorm running statistics; with per-rank statistics (the default) they differ measurably."""

@@ -489,6 +489,18 @@ def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monk
     _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
+def test_cross_replica_batchnorm_recording_protocol_on_the_execution_model(tmp_path, monkeypatch):
+    """test_dp_gpu.py::test_cross_replica_batchnorm_step_replays_as_graph_segments without a GPU: two gloo ranks run three DCGAN steps
+    with a recording segmenter installed - 24 BatchNorm collectives + 2 optimiser exchanges go through _Segmenter.cut() on the thread
+    that runs the step (backward nodes included), on operands that outlive the step; results equal three plain steps bit for bit."""
+    monkeypatch.setenv("MIGAN_TEST_EMU", "1")
+    monkeypatch.setenv("MIGAN_TEST_DEVICE", "cpu")
+    _load_or_skip()
+    import test_dp_gpu
+
+    test_dp_gpu.test_cross_replica_batchnorm_step_replays_as_graph_segments(tmp_path)   # every kernel runs in the rank processes
+
+
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="70 s on 8 cores: MIGAN_EMU_SLOW=1")
 def test_esrgan_full_depth_on_the_execution_model():
     """test_steps_gpu.py::test_esrgan_full_depth_steps (23 RRDB generator, warm-up + relativistic iteration) on the execution model;

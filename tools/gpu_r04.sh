@@ -255,6 +255,12 @@ task_seventeenth() {   # cyclegan: the two halves of the generators' forward / b
   cat $O/bench.txt
 }
 
+task_syncbn() {   # call 32: the recorded step under cross-replica BatchNorm (segments cut at the collectives), two ranks on the one GPU
+  local O=gpurun_out/r4t; mkdir -p $O
+  timeout 240 python -m pytest tests/test_dp_gpu.py -q -x -k "cross_replica" --durations=3 > $O/pytest.txt 2>&1
+  tail -25 $O/pytest.txt
+}
+
 task_closing() {   # the round's closing call: parity of what changed after the full suite of call 19, then the default bench line
   local O=gpurun_out/r4s; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "second_stream or srgan or pix2pix_step or dcgan_steps or two_ranks" --durations=3 > $O/pytest.txt 2>&1
@@ -375,6 +381,7 @@ task_sixth() {   # MLP backward on row-group workgroups, ReLU hand-off (SRGAN), 
 t=${1:-}; shift || true
 case "$t" in
   closing) task_closing "$@" ;;
+  syncbn) task_syncbn "$@" ;;
   seventeenth) task_seventeenth "$@" ;;
   sixteenth) task_sixteenth "$@" ;;
   timeline) task_timeline "$@" ;;
