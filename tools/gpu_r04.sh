@@ -261,6 +261,17 @@ task_syncbn() {   # call 32: the recorded step under cross-replica BatchNorm (se
   tail -25 $O/pytest.txt
 }
 
+task_syncbn_bench() {   # call 33: two ranks on the one GPU (gloo, host-staged collectives): DCGAN --sync-bn, segments vs eager launches
+  local O=gpurun_out/r4t; mkdir -p $O
+  export MIGAN_DP_BACKEND=gloo MIGAN_DP_SINGLE_DEVICE=1
+  for v in graph nograph; do
+    local f=""; [ $v = nograph ] && f="--no-graph"
+    timeout 110 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 \
+      --sync-bn --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --no-extra $f > $O/syncbn_$v.json 2> $O/syncbn_$v.err
+    tail -c 1500 $O/syncbn_$v.json; tail -3 $O/syncbn_$v.err
+  done
+}
+
 task_closing() {   # the round's closing call: parity of what changed after the full suite of call 19, then the default bench line
   local O=gpurun_out/r4s; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "second_stream or srgan or pix2pix_step or dcgan_steps or two_ranks" --durations=3 > $O/pytest.txt 2>&1
@@ -382,6 +393,7 @@ t=${1:-}; shift || true
 case "$t" in
   closing) task_closing "$@" ;;
   syncbn) task_syncbn "$@" ;;
+  syncbn_bench) task_syncbn_bench "$@" ;;
   seventeenth) task_seventeenth "$@" ;;
   sixteenth) task_sixteenth "$@" ;;
   timeline) task_timeline "$@" ;;
