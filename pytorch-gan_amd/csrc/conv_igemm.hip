@@ -2618,13 +2618,50 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_ker
 // stride over the slabs (the streaming backward kernels leave one slab per block: thousands), butterfly-add in double -
 // a fixed order, and the same shape as the stand-alone column-sum finalize it replaces (a serial loop over 4096 slabs
 // made these blocks the 100 us tail of the reduction launch).
+// s + p[k * stride] for k = k0, k0 + step, ... < n, in that order, with up to EIGHT loads in flight per round: inside a round the slab
+// index is clamped instead of branched on, so its loads issue back to back, and a slab past the end is read again but not added - the
+// sums are bit-identical to one load at a time.  The round width follows the slabs that are left (8 / 4 / 2 / 1), so a 1- or 2-split
+// reduction of a large weight issues no redundant loads.  (The first form of this batching ran only while eight whole strides were
+// left: with 4 split lanes and 16-28 splits - most layers - every load was its own dependent round trip; upconv 128->64 @64^2,
+// 48 splits x 4 classes: 131 us.)
+template <int U>
+__device__ __forceinline__ float slab_round(const float* __restrict__ p, size_t stride, int k, int step, int n, float s) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int kk = k + u * step;
+        v[u] = p[(size_t)(kk < n ? kk : n - 1) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (k + u * step < n) s += v[u];
+    return s;
+}
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t stride, int k0, int step, int n, float s) {
+    int k = k0;
+    for (; k + 4 * step < n; k += 8 * step) s = slab_round<8>(p, stride, k, step, n, s);   // five or more slabs left
+    if (k + 2 * step < n) s = slab_round<4>(p, stride, k, step, n, s);
+    else if (k + step < n) s = slab_round<2>(p, stride, k, step, n, s);
+    else if (k < n) s = slab_round<1>(p, stride, k, step, n, s);
+    return s;
+}
 #define BIAS_CB 4  // channels (waves) per block
 __device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bpart, float* __restrict__ db, int nslab,
                                                  int Co, int accum, int blk) {
     const int co = blk * BIAS_CB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (co >= Co) return;  // wave-uniform
     double s = 0.0;
-    for (int k = lane; k < nslab; k += 64) s += (double)bpart[(size_t)k * Co + co];
+    for (int k = lane; k < nslab; k += 8 * 64) {   // eight slabs per round of loads (clamped index, guarded add: same order, same sums)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + u * 64;
+            v[u] = bpart[(size_t)(kk < nslab ? kk : nslab - 1) * Co + co];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k + u * 64 < nslab) s += (double)v[u];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) db[co] = accum ? db[co] + (float)s : (float)s;
@@ -2649,19 +2686,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
     const size_t src = (size_t)(blockIdx.x - br.nbias) * OUTS + lo;
     float s = 0.f;
-    if (src < total) {
-        // eight slabs per round of loads (same summation order as one at a time: bit-identical), so a 48-split reduction is 2-6 dependent
-        // rounds instead of 12-48
-        int k = grp;
-        for (; k + 7 * GROUPS < splits; k += 8 * GROUPS) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u * GROUPS) * total + src];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; k < splits; k += GROUPS) s += part[(size_t)k * total + src];
-    }
+    if (src < total) s = slab_sum(part + src, total, grp, GROUPS, splits, 0.f);
     if (GROUPS > 1) {
         red[threadIdx.x] = s;
         __syncthreads();
@@ -2702,8 +2727,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __res
     for (int e = threadIdx.x; e < T * RTR_CI; e += 256) {
         const int tt = e / RTR_CI, cl = e - tt * RTR_CI;
         float s = 0.f;
-        if (cl < ncl)
-            for (int k = 0; k < splits; ++k) s += src[(size_t)k * total + (size_t)tt * Ci + cl];
+        if (cl < ncl) s = slab_sum(src + (size_t)tt * Ci + cl, total, 0, 1, splits, 0.f);
         rtr_tile[cl * (T + 1) + tt] = s;
     }
     __syncthreads();
@@ -2931,6 +2955,23 @@ MIGAN_API int migan_upconv3x3_dgrad(const float* dy, const float* wd, float* dx,
     return launch_igemm(g, dy, wd, nullptr, dx, (hipStream_t)stream);
 }
 
+template <int U>
+__device__ __forceinline__ void upconv_slab_round(const float* const (&src)[4], size_t slab, int k, int step, int n, float (&a)[4]) {
+    float v[4][U];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + u * step;
+            v[ab][u] = src[ab][(size_t)(kk < n ? kk : n - 1) * slab];
+        }
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u * step < n) a[ab] += v[ab][u];
+}
+
 // part[cls][split][co][tap*Ci+ci] (tap = ih*2+iw) -> dw[co][ci][r][s] = sum_{a,b} sum_split part[a,b][.][co][tap(a,r),(b,s)][ci]
 // 4 split-lanes per output (fixed-order LDS combine -> deterministic); reads coalesced along ci.
 __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* __restrict__ part,
@@ -2954,20 +2995,22 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
         rs = (int)(r_ % 9);
         co = (int)(r_ / 9);
         const int r = rs / 3, q = rs - r * 3;
+        // one round = up to eight slabs of each of the four classes: 32 loads in flight per thread (clamped index, guarded add, as
+        // slab_round; the width follows the slabs that are left), so 48 splits are two dependent rounds; one accumulator per class,
+        // combined in class order
+        const float* src[4];
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {
             const int tap = up_idx(ab >> 1, r) * 2 + up_idx(ab & 1, q);
-            const float* src = part + (size_t)ab * splits * slab + ((size_t)co * 4 + tap) * Ci + ci;
-            int k = grp;   // eight slabs per round of loads, summed in the same order as one at a time
-            for (; k + 7 * GROUPS < splits; k += 8 * GROUPS) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u * GROUPS) * slab];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
-            }
-            for (; k < splits; k += GROUPS) acc += src[(size_t)k * slab];
+            src[ab] = part + (size_t)ab * splits * slab + ((size_t)co * 4 + tap) * Ci + ci;
         }
+        int k = grp;
+        for (; k + 4 * GROUPS < splits; k += 8 * GROUPS) upconv_slab_round<8>(src, slab, k, GROUPS, splits, a);
+        if (k + 2 * GROUPS < splits) upconv_slab_round<4>(src, slab, k, GROUPS, splits, a);
+        else if (k + GROUPS < splits) upconv_slab_round<2>(src, slab, k, GROUPS, splits, a);
+        else if (k < splits) upconv_slab_round<1>(src, slab, k, GROUPS, splits, a);
+        acc = ((a[0] + a[1]) + a[2]) + a[3];
     }
     red[threadIdx.x] = acc;
     __syncthreads();

@@ -60,7 +60,17 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     const int c = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;  // one wave per channel
     if (c >= C) return;
     double s = 0.0;
-    for (int k = lane; k < nchunks; k += 64) s += (double)part[(size_t)k * C + c];
+    for (int k = lane; k < nchunks; k += 8 * 64) {   // eight chunks per round of loads (clamped index, guarded add: same order, same sum)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + u * 64;
+            v[u] = part[(size_t)(kk < nchunks ? kk : nchunks - 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k + u * 64 < nchunks) s += (double)v[u];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) out[c] = accum ? out[c] + (float)s : (float)s;

@@ -119,6 +119,46 @@ def test_every_gpu_conv_case_on_the_execution_model(emu):
         assert emu.hipemu_launch_count(sym.encode()) > 0, sym
 
 
+def test_split_count_sweep_of_the_weight_gradient_reductions(emu):
+    """The slab reductions behind the split-K weight gradients load up to eight slabs per round with the round width following the
+    slabs that are left (csrc/conv_igemm.hip slab_sum / upconv_slab_round: 8 / 4 / 2 / 1, clamped index, guarded add).  Sweep the split
+    count over every width and remainder - 1 ... 12 on one split lane, 17 / 20 / 33 on four, 70 on sixteen; the phase-collapsed
+    up-conv form over 1 ... 20 - and compare with torch."""
+    seen, seen_up = set(), set()
+    Co = Ci = 16
+    for N in (1, 2, 3, 4, 5, 6, 7, 9, 12, 17, 20, 33, 70):
+        g = torch.Generator().manual_seed(N)
+        x = torch.randn(N, Ci, 16, 16, generator=g)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.2).requires_grad_(True)
+        y = TF.conv2d(x, w, None, 1, 1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xn, gyn = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
+        wsb = emu.migan_conv2d_wgrad_workspace(N, 16, 16, Co, 3, 3, Ci)
+        ws, dw = torch.empty(wsb // 4), torch.empty(Co, Ci, 3, 3)
+        rc = emu.migan_conv2d_wgrad(_ptr(xn), _ptr(gyn), _ptr(dw), _ptr(ws), wsb, N, 16, 16, Ci, 16, 16, Co, 3, 3, 1, 1, 1, 0, 0, None,
+                                    0, None, 0, None)
+        assert rc == 0, (N, emu.hipemu_last_message())
+        assert _rel(dw, w.grad) <= 2e-6, (N, _rel(dw, w.grad))
+        seen.add(wsb // (Co * Ci * 9 * 4))
+    assert seen >= {1, 2, 3, 4, 5, 6, 7, 9, 12, 17, 20, 33, 70}, seen
+    for N in (1, 2, 3, 5, 6, 9, 13, 19, 40, 80):
+        g = torch.Generator().manual_seed(100 + N)
+        x = torch.randn(N, Ci, 8, 8, generator=g)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.2).requires_grad_(True)
+        y = TF.conv2d(TF.interpolate(x, scale_factor=2, mode="nearest"), w, None, 1, 1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xn, gyn = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
+        wsb = emu.migan_upconv3x3_wgrad_workspace(N, 8, 8, Co, Ci)
+        ws, dw = torch.empty(wsb // 4), torch.empty(Co, Ci, 3, 3)
+        rc = emu.migan_upconv3x3_wgrad(_ptr(xn), _ptr(gyn), _ptr(dw), _ptr(ws), wsb, N, 8, 8, Ci, Co, 0, None, 0, None, 0, None)
+        assert rc == 0, (N, emu.hipemu_last_message())
+        assert _rel(dw, w.grad) <= 2e-6, (N, _rel(dw, w.grad))
+        seen_up.add(wsb // (4 * Co * (4 * Ci + 1) * 4))   # 4 classes x splits x (Co x 4 Ci partials + Co bias slab)
+    assert len(seen_up) >= 6 and max(seen_up) >= 17, seen_up   # 17+: a whole round of eight on every split lane
+
+
 def test_results_do_not_depend_on_the_wave_schedule(emu):
     """A model that switches fibers only at synchronisation points runs the waves of a workgroup in ONE order between two
     barriers: a missing __syncthreads (two waves touching the same LDS / global word with no barrier between them) is invisible in

@@ -272,6 +272,19 @@ task_syncbn_bench() {   # call 33: two ranks on the one GPU (gloo, host-staged c
   done
 }
 
+task_reduce_ab() {   # call 34: slab / chunk reductions with all of a round's loads in flight (ab_base/ = the tree one commit earlier)
+  local O=gpurun_out/r4u; mkdir -p $O
+  timeout 130 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -x -k "upconv or conv2d_fwd_bwd or batchnorm or instancenorm or norm_bwd_column or colsum or bias_grad or norm_double or epilogue_statistics or conv_transpose2d or dcgan_steps or splitk or direct_grad" > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for tree in ab_base .; do
+    echo "== tree $tree" >> $O/micro.txt
+    (cd $tree && timeout 60 python tools/conv_microbench.py --shapes dcgan --match "G.conv" --dirs uwgrad --iters 20 --repeat 3 2>&1 | grep "G.conv") >> $O/micro.txt
+  done
+  cat $O/micro.txt
+  ab $O/bench.txt dcgan 50 2
+  cat $O/bench.txt
+}
+
 task_closing() {   # the round's closing call: parity of what changed after the full suite of call 19, then the default bench line
   local O=gpurun_out/r4s; mkdir -p $O
   timeout 600 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -x -k "second_stream or srgan or pix2pix_step or dcgan_steps or two_ranks" --durations=3 > $O/pytest.txt 2>&1
@@ -393,6 +406,7 @@ t=${1:-}; shift || true
 case "$t" in
   closing) task_closing "$@" ;;
   syncbn) task_syncbn "$@" ;;
+  reduce_ab) task_reduce_ab "$@" ;;
   syncbn_bench) task_syncbn_bench "$@" ;;
   seventeenth) task_seventeenth "$@" ;;
   sixteenth) task_sixteenth "$@" ;;
