@@ -438,6 +438,10 @@ class _GeneratorFusedPlan:
         return out
 
     def usable(self, z):
+        # the fused kernels take BatchNorm1d statistics over the rows they are given: with cross-replica BatchNorm on
+        # (dp.enable_sync_batchnorm, world > 1) a generator with BatchNorm layers goes through the modules, whose norm calls gather
+        if F._SYNC_BN is not None and F._SYNC_BN.world > 1 and self.ok and any(bn is not None for _, bn, _, _ in self.groups):
+            return False
         return self.ok and self.G.training and z.shape[0] == self.B and z.is_contiguous() and z.dtype == torch.float32
 
     def run(self, z, buffers=None):

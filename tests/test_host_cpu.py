@@ -486,3 +486,32 @@ def test_weight_gradient_stream_protocol(monkeypatch):
     # second-order backward (grad mode on): never forked
     with F.weight_cache_scope():
         assert not F._Fork(dev, True, big, True).on
+
+
+def test_fused_generator_plan_steps_aside_for_cross_replica_batchnorm(monkeypatch):
+    """The fused WGAN-GP generator kernels (csrc/mlp_fused.hip) take BatchNorm1d statistics over the rows of ONE rank.  With
+    dp.enable_sync_batchnorm() at world size > 1 the generator of wgan_gp.py:42-65 (Linear, BatchNorm1d(eps 0.8), LeakyReLU groups) must go
+    through the modules, whose norm calls gather the moments - the plan reports itself unusable; a generator without BatchNorm and
+    world size 1 keep the fused path."""
+    import types
+
+    import pytorch_gan_amd.functional as F
+    from pytorch_gan_amd import steps
+
+    def gen(bn):
+        layers = [torch.nn.Linear(100, 128), torch.nn.LeakyReLU(0.2), torch.nn.Linear(128, 256)]
+        if bn:
+            layers.append(torch.nn.BatchNorm1d(256, 0.8))
+        layers += [torch.nn.LeakyReLU(0.2), torch.nn.Linear(256, 1024), torch.nn.Tanh()]
+        g = torch.nn.Module()
+        g.model, g.img_shape = torch.nn.Sequential(*layers), (1, 32, 32)
+        return g.train()
+
+    z = torch.randn(64, 100)
+    with_bn, without = steps._GeneratorFusedPlan(gen(True), z), steps._GeneratorFusedPlan(gen(False), z)
+    assert with_bn.ok and without.ok
+    assert with_bn.usable(z) and without.usable(z)
+    monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=2))
+    assert not with_bn.usable(z) and without.usable(z)
+    monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=1))
+    assert with_bn.usable(z)
