@@ -1462,6 +1462,9 @@ class _Norm(Function):
             raise ValueError("norm: expected 2-D or 4-D input")
         st = _stream()
         sync = _SYNC_BN if (use_batch_stats and not instance and _SYNC_BN is not None and _SYNC_BN.world > 1) else None
+        if sync is not None and (pw is not None or shuffle):
+            # the fused backward (norm_bwd_prelu) takes the two batch sums over this rank's rows only; nn.Sequential does not fuse in this mode
+            raise NotImplementedError("cross-replica BatchNorm with a fused PReLU / PixelShuffle: use the separate layers")
         # batch_groups(k): this BatchNorm call stands for k calls on k consecutive sub-batches (statistics, running-statistics
         # updates and num_batches_tracked per sub-batch, in order) - [G = k][P / k][C] in the kernels' group view
         ctx.bn_groups = 1

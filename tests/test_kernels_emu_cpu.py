@@ -529,6 +529,29 @@ def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monk
     _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
+def test_cross_replica_batchnorm_refuses_the_fused_prelu_form(emu, monkeypatch):
+    """The fused BatchNorm2d + PReLU [+ PixelShuffle] launches (srgan/models.py:23-24,55-57) take their backward batch sums over one
+    rank's rows: with cross-replica BatchNorm on, nn.Sequential keeps the layers apart and a direct functional call raises instead of
+    computing per-rank sums silently; with world size 1 the fused form runs."""
+    import types
+
+    import hipemu.host
+    from pytorch_gan_amd import functional as F
+
+    x = torch.randn(2, 8, 4, 4).contiguous(memory_format=torch.channels_last)
+    gamma, beta, pw = torch.ones(8), torch.zeros(8), torch.full((1,), 0.25)
+    with hipemu.host.emulated_device():
+        monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=2))
+        with pytest.raises(NotImplementedError):
+            F.norm(x, gamma, beta, prelu=pw)
+        with pytest.raises(NotImplementedError):
+            F.norm(x, gamma, beta, prelu=pw, shuffle=2)
+        monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=1))
+        y = F.norm(x, gamma, beta, prelu=pw)
+        ref = TF.prelu(TF.batch_norm(x, None, None, gamma, beta, True), pw)
+        assert _rel(y, ref) <= 1e-5
+
+
 def test_cross_replica_batchnorm_recording_protocol_on_the_execution_model(tmp_path, monkeypatch):
     """test_dp_gpu.py::test_cross_replica_batchnorm_step_replays_as_graph_segments without a GPU: two gloo ranks run three DCGAN steps
     with a recording segmenter installed - 24 BatchNorm collectives + 2 optimiser exchanges go through _Segmenter.cut() on the thread
