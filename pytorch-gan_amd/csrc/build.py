@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "libmigan.so")
 STAMP = os.path.join(HERE, ".libmigan.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-gpu-rdc"]
-# e.g. MIGAN_CFLAGS=-DMIGAN_ABLATION also compiles the A/B kernel variants selected by MIGAN_IGEMM_VAR / MIGAN_WGRAD_VAR
+# extra compiler flags for experiments (e.g. MIGAN_CFLAGS=-save-temps); part of the build digest
 FLAGS += os.environ.get("MIGAN_CFLAGS", "").split()
 
 

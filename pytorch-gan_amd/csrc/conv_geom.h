@@ -14,7 +14,7 @@ struct ConvGeom {
     int ostep, istride;  // output sub-grid step (parity classes), source step per output index
     int gather, ldw, ncls;
     int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
-    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe; opt-in, MIGAN_IGEMM_XCD=1): swz != 0 -> 1-D grid of
+    // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe behind the constant xcd_env, measured without gain in profiles/r02_ab.txt): swz != 0 -> 1-D grid of
     // 8 * per * ntn * ncls workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's
     // CONTIGUOUS eighth of the image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of
     // adjacent rows, the N-tiles, the 4 phase classes of an up-conv - runs back to back on ONE XCD and finds it in that
@@ -22,7 +22,7 @@ struct ConvGeom {
     // parity-class dgrads lose 40 % (classes with 4/2/2/1 taps interleaved on one XCD), whole steps lose 2-3 % - the L2
     // misses of these kernels are served by the MALL and are not what limits them.  Default off.
     int swz, mtiles, ntn, per;
-    int prio;            // MIGAN_MFMA_PRIO=1 (A/B knob): s_setprio 1 while a wave is in its MFMA stream, 0 around the LDS fill
+    int prio;            // launch_pipe's constant prio_env (measured without gain): s_setprio 1 while a wave is in its MFMA stream, 0 around the LDS fill
     int act;
     float slope;
     const float* oscale;  // optional [N][Co] multiplier applied after the activation (fused nn.Dropout2d mask)

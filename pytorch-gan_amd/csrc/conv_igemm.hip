@@ -26,8 +26,12 @@
 #include "conv_geom.h"
 
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, int VAR = 0>
-__global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
+// The generic kernel: any channel count (scalar 4-byte gathers, one k per thread), every tap map.  It serves what the vector kernels do not
+// take - source channels not a multiple of 4 (the 1- and 3-channel first layers that the small-K / thin kernels leave) - and is the
+// arithmetic the other main loops were derived from; its register-staged vector variant and the round-1 ablation switches are gone
+// (profiles/r01_igemm_ablation.txt records what they measured).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 1) void igemm_kernel(const ConvGeom g, const float* __restrict__ A,
                                                     const float* __restrict__ Bw,
                                                     const float* __restrict__ bias,
                                                     float* __restrict__ C) {
@@ -62,22 +66,20 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
         s_dh[i] = g.dh[tapbeg + i];
         s_dw[i] = g.dw[tapbeg + i];
     }
-    if (!FAST) {
-        for (int r = tid; r < BM; r += 256) {
-            int m = m0 + r;
-            int base = -1, ih = 0, iw = 0;
-            if (m < M) {
-                int n = m / (Ho * Wo);
-                int rem = m - n * Ho * Wo;
-                int oi = rem / Wo, oj = rem - oi * Wo;
-                base = n * Hi * Wi;
-                ih = oi * g.istride;
-                iw = oj * g.istride;
-            }
-            r_base[r] = base;
-            r_ih[r] = ih;
-            r_iw[r] = iw;
+    for (int r = tid; r < BM; r += 256) {
+        int m = m0 + r;
+        int base = -1, ih = 0, iw = 0;
+        if (m < M) {
+            int n = m / (Ho * Wo);
+            int rem = m - n * Ho * Wo;
+            int oi = rem / Wo, oj = rem - oi * Wo;
+            base = n * Hi * Wi;
+            ih = oi * g.istride;
+            iw = oj * g.istride;
         }
+        r_base[r] = base;
+        r_ih[r] = ih;
+        r_iw[r] = iw;
     }
     __syncthreads();
 
@@ -93,168 +95,67 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int KT;
-    if (FAST) KT = ntap * (Ci >> 5);
-    else KT = (ntap * Ci + BK - 1) / BK;
+    const int KT = (ntap * Ci + BK - 1) / BK;
 
-    // ---------------- staging state ----------------
-    constexpr int NA = FAST ? BM / 32 : BM / 8;
-    constexpr int NB = FAST ? BN / 32 : BN / 8;
-    f32x4 ra4[FAST ? NA : 1], rb4[FAST ? NB : 1];
-    float ra1[FAST ? 1 : NA], rb1[FAST ? 1 : NB];
-    // FAST: thread owns k-quad kq of rows (tid>>3)+32j.   GENERIC: thread owns k = tid&31 of rows (tid>>5)+8j.
-    const int kq = tid & 7, frow = tid >> 3;
+    // ---------------- staging state: thread owns k = tid & 31 of rows (tid >> 5) + 8 j ----------------
+    constexpr int NA = BM / 8;
+    constexpr int NB = BN / 8;
+    float ra1[NA], rb1[NB];
     const int gk = tid & 31, grow = tid >> 5;
-    int a_base[FAST ? NA : 1], a_ih[FAST ? NA : 1], a_iw[FAST ? NA : 1];
-    unsigned avalid = 0;
-    if (FAST) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            int m = m0 + frow + 32 * j;
-            a_base[j] = 0; a_ih[j] = 0; a_iw[j] = 0;
-            if (m < M) {
-                int n = m / (Ho * Wo);
-                int rem = m - n * Ho * Wo;
-                int oi = rem / Wo, oj = rem - oi * Wo;
-                a_base[j] = n * Hi * Wi;
-                a_ih[j] = oi * g.istride;
-                a_iw[j] = oj * g.istride;
-                avalid |= 1u << j;
-            }
-        }
-    }
-    const int tpt = Ci >> 5;  // FAST: K-tiles per tap
 
     auto load_tile = [&](int kt) {
-        if (FAST) {
-            int t = kt / tpt;
-            int c0 = (kt - t * tpt) << 5;
-            int dh = s_dh[t], dw = s_dw[t], wo = s_wofs[t];
+        int k = kt * BK + gk;
+        bool kval = k < ntap * Ci;
+        int t = kval ? k / Ci : 0;
+        int c = k - t * Ci;
+        int dh = s_dh[t], dw = s_dw[t], wo = s_wofs[t];
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                int ihs, iws;
-                if (((avalid >> j) & 1u) && map_coord(a_ih[j] + dh, g.HiL, g.gather, ihs) &&
-                    map_coord(a_iw[j] + dw, g.WiL, g.gather, iws)) {
-                    const float* p = A + (size_t)(a_base[j] + ihs * Wi + iws) * Ci + c0 + kq * 4;
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                ra4[j] = v;
+        for (int j = 0; j < NA; ++j) {
+            int r = grow + 8 * j;
+            float v = 0.f;
+            int base = r_base[r];
+            int ihs, iws;
+            if (kval && base >= 0 && map_coord(r_ih[r] + dh, g.HiL, g.gather, ihs) &&
+                map_coord(r_iw[r] + dw, g.WiL, g.gather, iws)) {
+                v = A[(size_t)(base + ihs * Wi + iws) * Ci + c];
             }
+            ra1[j] = v;
+        }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                int n = n0 + frow + 32 * j;
-                if (n < g.Co) {
-                    const float* p = Bw + (size_t)n * g.ldw + wo + c0 + kq * 4;
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                rb4[j] = v;
-            }
-        } else {
-            int k = kt * BK + gk;
-            bool kval = k < ntap * Ci;
-            int t = kval ? k / Ci : 0;
-            int c = k - t * Ci;
-            int dh = s_dh[t], dw = s_dw[t], wo = s_wofs[t];
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int r = grow + 8 * j;
-                float v = 0.f;
-                int base = r_base[r];
-                int ihs, iws;
-                if (kval && base >= 0 && map_coord(r_ih[r] + dh, g.HiL, g.gather, ihs) &&
-                    map_coord(r_iw[r] + dw, g.WiL, g.gather, iws)) {
-                    v = A[(size_t)(base + ihs * Wi + iws) * Ci + c];
-                }
-                ra1[j] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int n = n0 + grow + 8 * j;
-                float v = 0.f;
-                if (kval && n < g.Co) v = Bw[(size_t)n * g.ldw + wo + c];
-                rb1[j] = v;
-            }
+        for (int j = 0; j < NB; ++j) {
+            int n = n0 + grow + 8 * j;
+            float v = 0.f;
+            if (kval && n < g.Co) v = Bw[(size_t)n * g.ldw + wo + c];
+            rb1[j] = v;
         }
     };
     auto store_tile = [&]() {
-        if (FAST) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j)
+        for (int j = 0; j < NA; ++j) As[(grow + 8 * j) * LDK + gk] = ra1[j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[(frow + 32 * j) * LDK + kq * 4 + e] = ra4[j][e];
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[(frow + 32 * j) * LDK + kq * 4 + e] = rb4[j][e];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) As[(grow + 8 * j) * LDK + gk] = ra1[j];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) Bs[(grow + 8 * j) * LDK + gk] = rb1[j];
-        }
+        for (int j = 0; j < NB; ++j) Bs[(grow + 8 * j) * LDK + gk] = rb1[j];
     };
 
-    if constexpr ((VAR & 12) != 0) {
-        // experiment: de-phase the co-resident workgroups of a CU so their MFMA phases do not run in lockstep
-        int j = (VAR & 4) ? ((blockIdx.x >> 8) & 3) : ((blockIdx.x >> 3) & 3);
-        for (int d = 0; d < j; ++d) __builtin_amdgcn_s_sleep(64);
-    }
     if (KT > 0) load_tile(0);
     for (int kt = 0; kt < KT; ++kt) {
-        if ((VAR & 32) == 0 || kt == 0) {  // ablation bit 32: keep only the first LDS fill
-            __syncthreads();
-            store_tile();
-            __syncthreads();
-        }
-        if ((VAR & 16) == 0) {  // ablation bit 16: no global loads in the loop
-            if (kt + 1 < KT) load_tile(kt + 1);
-        }
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < KT) load_tile(kt + 1);
         const float* ap = As + (wm * (TM * 32) + l31) * LDK + h;
         const float* bp = Bs + (wn * (TN * 32) + l31) * LDK + h;
-        if constexpr ((VAR & 2) != 0) {
-            // fragment double-buffering: the LDS reads of k-pair kp+1 are issued before the MFMAs of k-pair kp
-            float a[2][TM], b[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32 * LDK];
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[TM], b[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32 * LDK];
+            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
 #pragma unroll
-            for (int kp = 0; kp < BK / 2; ++kp) {
-                const int cur = kp & 1, nxt = cur ^ 1;
-                if (kp + 1 < BK / 2) {
+            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[nxt][i] = ap[(kp + 1) * 2 + i * 32 * LDK];
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[nxt][j] = bp[(kp + 1) * 2 + j * 32 * LDK];
-                }
-                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kp = 0; kp < BK / 2; ++kp) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
-                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                if constexpr ((VAR & 1) != 0) __builtin_amdgcn_s_setprio(0);
-            }
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -293,7 +194,7 @@ __global__ __launch_bounds__(256, (FAST && BM * BN >= 16384 ? 4 : 1)) void igemm
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pipelined fast path (source channels % 32 == 0).  Same tiles and LDS image as igemm_kernel<.., true>, but
+// Pipelined fast path (source channels % 4 == 0; % 32 != 0 takes the K-tail variant).  Same tiles and LDS image as igemm_kernel, but
 //  * the gather is BRANCH-FREE (coordinates clamped into the tensor, loads unconditional, padding taps and
 //    tail rows zeroed by a per-tile mask when the tile is written to LDS), so the whole K-step is one basic
 //    block, and
@@ -632,248 +533,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? 4 : (OCC ? OCC : 1))) void
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Double-buffered fast path.  tools/mfma_loop_probe.hip (profiles/r01_mfma_loop_probe.txt) shows that ONE wave
-// per SIMD already drives the fp32 matrix pipe at 94-98 % when its stream is dense in MFMAs, while FOUR
-// MFMA-issuing waves per SIMD arbitrate at only ~77 %.  So this kernel runs 2 workgroups per CU and removes
-// the serial sections from the K-loop instead of hiding them behind occupancy:
-//   * two LDS buffers; while tile kt is multiplied out of buf[cur], the register-staged tile kt+1 is written
-//     into buf[cur^1] during k-pairs 0..NL-1 and the global loads of tile kt+2 are issued during k-pairs
-//     NL..2NL-1 (one slot per k-pair, inside the MFMA stream), and there is ONE barrier per K-tile;
-//   * loads are branch-free (see igemm_pipe_kernel).
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void igemm_db_kernel(const ConvGeom g, const float* __restrict__ A,
-                                                          const float* __restrict__ Bw,
-                                                          const float* __restrict__ bias, float* __restrict__ C) {
-    constexpr int BK = 32, LDK = BK + 1;
-    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    constexpr int NA = BM / 32, NB = BN / 32, NL = NA + NB;
-    static_assert(WAVES_M * WAVES_N == 4 && 2 * NL <= BK / 2, "tile shape");
-    constexpr int SM_A = BM * LDK, SM_B = BN * LDK, SM_T = SM_A + SM_B;
-    __shared__ __attribute__((aligned(16))) int smem_i[2 * SM_T + 3 * MAX_TAPS];
-    float* S0 = reinterpret_cast<float*>(smem_i);
-    int* s_wofs = smem_i + 2 * SM_T;
-    int* s_dh = s_wofs + MAX_TAPS;
-    int* s_dw = s_dh + MAX_TAPS;
-
-    const int tid = threadIdx.x;
-    const int cls = blockIdx.z;
-    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
-    const int M = g.N * Ho * Wo;
-    const int m0 = blockIdx.x * BM;
-    if (m0 >= M) return;
-    const int n0 = blockIdx.y * BN;
-    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
-    const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
-    for (int i = tid; i < ntap; i += 256) {
-        s_wofs[i] = g.wofs[tapbeg + i];
-        s_dh[i] = g.dh[tapbeg + i];
-        s_dw[i] = g.dw[tapbeg + i];
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int kq = tid & 7, frow = tid >> 3;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int tpt = Ci >> 5;
-    const int KT = ntap * tpt;
-    int a_base[NA], a_pos[NA];
-    unsigned rowok = 0;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        int m = m0 + frow + 32 * j;
-        a_base[j] = 0;
-        a_pos[j] = 0;
-        if (m < M) {
-            int n = m / (Ho * Wo);
-            int rem = m - n * Ho * Wo;
-            int oi = rem / Wo, oj = rem - oi * Wo;
-            a_base[j] = n * Hi * Wi;
-            a_pos[j] = ((oi * g.istride) << 16) | (oj * g.istride);
-            rowok |= 1u << j;
-        }
-    }
-    int b_off[NB];
-    unsigned colok = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        int n = n0 + frow + 32 * j;
-        if (n < g.Co) colok |= 1u << j;
-        n = n < g.Co ? n : g.Co - 1;
-        b_off[j] = n * g.ldw + kq * 4;
-    }
-    f32x4 ra[NA], rb[NB];
-    unsigned okA = 0;
-    int f_dh = 0, f_dw = 0, f_wo = 0, f_c0 = 0;
-    auto tile_params = [&](int kt) {
-        int t = kt / tpt;
-        f_c0 = (kt - t * tpt) << 5;
-        f_dh = s_dh[t];
-        f_dw = s_dw[t];
-        f_wo = s_wofs[t];
-    };
-#define DB_ISSUE(idx)                                                                                  \
-    do {                                                                                               \
-        if ((idx) < NA) {                                                                              \
-            constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
-            int ihs, iws;                                                                              \
-            bool ok = (rowok >> jj) & 1u;                                                              \
-            ok &= map_bf((a_pos[jj] >> 16) + f_dh, g.HiL, Hi, mode, ihs);                              \
-            ok &= map_bf((a_pos[jj] & 0xffff) + f_dw, g.WiL, Wi, mode, iws);                           \
-            ra[jj] = *reinterpret_cast<const f32x4*>(A + (size_t)(a_base[jj] + ihs * Wi + iws) * Ci +  \
-                                                     f_c0 + kq * 4);                                   \
-            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                       \
-        } else {                                                                                       \
-            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
-            rb[jj] = *reinterpret_cast<const f32x4*>(Bw + (size_t)(b_off[jj] + f_wo + f_c0));         \
-        }                                                                                              \
-    } while (0)
-#define DB_WRITE(idx, dst)                                                                             \
-    do {                                                                                               \
-        if ((idx) < NA) {                                                                              \
-            constexpr int jj = (idx) < NA ? (idx) : 0;                                                 \
-            const bool ok = (okA >> jj) & 1u;                                                          \
-            float* d_ = (dst) + (frow + 32 * jj) * LDK + kq * 4;                                       \
-            d_[0] = ok ? ra[jj][0] : 0.f; d_[1] = ok ? ra[jj][1] : 0.f;                                \
-            d_[2] = ok ? ra[jj][2] : 0.f; d_[3] = ok ? ra[jj][3] : 0.f;                                \
-        } else {                                                                                       \
-            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                      \
-            const bool ok = (colok >> jj) & 1u;                                                        \
-            float* d_ = (dst) + SM_A + (frow + 32 * jj) * LDK + kq * 4;                                \
-            d_[0] = ok ? rb[jj][0] : 0.f; d_[1] = ok ? rb[jj][1] : 0.f;                                \
-            d_[2] = ok ? rb[jj][2] : 0.f; d_[3] = ok ? rb[jj][3] : 0.f;                                \
-        }                                                                                              \
-    } while (0)
-#define DB_FOR_SLOTS(OP)                                                       \
-    do {                                                                       \
-        if (0 < NL) OP(0); if (1 < NL) OP(1); if (2 < NL) OP(2); if (3 < NL) OP(3); \
-        if (4 < NL) OP(4); if (5 < NL) OP(5); if (6 < NL) OP(6); if (7 < NL) OP(7); \
-    } while (0)
-
-    // prologue: tile 0 -> buf 0, tile 1 staged in registers
-    if (KT > 0) {
-        tile_params(0);
-#define OP_I(i) DB_ISSUE(i)
-        DB_FOR_SLOTS(OP_I);
-#define OP_W0(i) DB_WRITE(i, S0)
-        DB_FOR_SLOTS(OP_W0);
-        tile_params(KT > 1 ? 1 : 0);
-        DB_FOR_SLOTS(OP_I);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        float* cur = S0 + (kt & 1) * SM_T;
-        float* nxt = S0 + ((kt & 1) ^ 1) * SM_T;
-        const float* ap = cur + (wm * (TM * 32) + l31) * LDK + h;
-        const float* bp = cur + SM_A + (wn * (TN * 32) + l31) * LDK + h;
-        tile_params(kt + 2 < KT ? kt + 2 : KT - 1);  // tail iterations refetch the last tile (harmless, branch-free)
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            if (kp < NL) {
-                // staged tile kt+1 -> the other LDS buffer (its previous readers passed the barrier of tile kt-1)
-                switch (kp) {
-                    case 0: DB_WRITE(0, nxt); break;
-                    case 1: DB_WRITE(1, nxt); break;
-                    case 2: DB_WRITE(2, nxt); break;
-                    case 3: DB_WRITE(3, nxt); break;
-                    case 4: DB_WRITE(4, nxt); break;
-                    case 5: DB_WRITE(5, nxt); break;
-                    case 6: DB_WRITE(6, nxt); break;
-                    default: DB_WRITE(7, nxt); break;
-                }
-            } else if (kp < 2 * NL) {
-                asm volatile("" : "+v"(f_dh), "+v"(f_dw));
-                switch (kp - NL) {
-                    case 0: DB_ISSUE(0); break;
-                    case 1: DB_ISSUE(1); break;
-                    case 2: DB_ISSUE(2); break;
-                    case 3: DB_ISSUE(3); break;
-                    case 4: DB_ISSUE(4); break;
-                    case 5: DB_ISSUE(5); break;
-                    case 6: DB_ISSUE(6); break;
-                    default: DB_ISSUE(7); break;
-                }
-            }
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 + i * 32 * LDK];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 + j * 32 * LDK];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    }
-#undef DB_ISSUE
-#undef DB_WRITE
-#undef DB_FOR_SLOTS
-#undef OP_I
-#undef OP_W0
-
-    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            int m = m0 + row;
-            if (m >= M) continue;
-            size_t opix;
-            if (linear_out) {
-                opix = (size_t)m;
-            } else {
-                int n = m / (Ho * Wo);
-                int rem = m - n * Ho * Wo;
-                int oi = rem / Wo, oj = rem - oi * Wo;
-                opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (col < g.Co) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[col];
-                    float o = act_apply(v, g.act, g.slope);
-                    if (g.oscale) o *= g.oscale[(size_t)(m / (Ho * Wo)) * g.Co + col];
-                    if (g.accum) o += C[opix * g.Co + col];
-                    C[opix * g.Co + col] = o;
-                }
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_db(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
-                     hipStream_t st) {
-    int maxM = 0;
-    for (int c = 0; c < g.ncls; ++c) {
-        int m = g.N * g.Ho[c] * g.Wo[c];
-        if (m > maxM) maxM = m;
-    }
-    if (maxM == 0) return 0;
-    dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    MIGAN_LAUNCH((igemm_db_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
 template <int BM, int BN, int WM, int WN>
 static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C,
                        hipStream_t st) {
@@ -935,7 +594,7 @@ static int launch_pipe(const ConvGeom& g_in, const float* A, const float* Bw, co
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST, int VAR = 0>
+template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
                       hipStream_t st) {
     int maxM = 0;
@@ -945,7 +604,7 @@ static int launch_cfg(const ConvGeom& g, const float* A, const float* Bw, const 
     }
     if (maxM == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.Co, BN), g.ncls);
-    MIGAN_LAUNCH((igemm_kernel<BM, BN, WM, WN, FAST, VAR>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
+    MIGAN_LAUNCH((igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, st, g, A, Bw, bias, C);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1681,18 +1340,16 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
         long m = (long)g.N * g.Ho[c] * g.Wo[c];
         if (m > maxM) maxM = m;
     }
-    constexpr int var_env = 0;  // (the A/B variants behind it are compiled with -DMIGAN_ABLATION only)
-    const int var = (g.Ci % 32 == 0) ? var_env : 0;  // the A/B variants only exist for whole K-tiles
     if (g.omask) {  // the ReLU-mask epilogue exists in the LDS-DMA kernels only: take it or tell the caller to run the two-launch form
         for (int t = 0; t < MAX_TAPS; ++t) g.dhw[t] = ((int)g.dh[t] << 16) | ((int)g.dw[t] & 0xffff);
         if (!fast || g.accum || g.stats) return (int)hipErrorNotSupported;
         const int rc = launch_igemm_dma(g, A, Bw, bias, C, sk_ws, sk_bytes, st);
         return rc == -2 ? (int)hipErrorNotSupported : rc;
     }
-    if (var != 100 && !g.accum && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
-    if (var != 100 && !g.accum && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
-    if (var == 0 && !g.accum && !fast && midk_ok(g)) return launch_midk(g, maxM, A, Bw, bias, C, st);
-    if (g.Co <= 4 && var != 100 && !g.accum && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
+    if (!g.accum && smallk_ok(g)) return launch_smallk(g, maxM, A, Bw, bias, C, st);
+    if (!g.accum && gemv_ok(g, maxM)) return launch_gemv(g, maxM, A, Bw, bias, C, st);
+    if (!g.accum && !fast && midk_ok(g)) return launch_midk(g, maxM, A, Bw, bias, C, st);
+    if (g.Co <= 4 && !g.accum && maxM >= 64L * g.N) {  // one pixel per lane: needs >= a wave of pixels per image
         ThinConv tc = {};
         size_t lds = 0;
         int max_tiles = 0;
@@ -1707,49 +1364,22 @@ static int launch_igemm(const ConvGeom& g_in, const float* A, const float* Bw, c
     for (int t = 0; t < MAX_TAPS; ++t) g.dhw[t] = ((int)g.dh[t] << 16) | ((int)g.dw[t] & 0xffff);
     // LDS-DMA main loop (conv_dma.hip) for the shapes it takes; MIGAN_DMA=0 keeps the register-staged kernels (A/B knob)
     static const int dma_env = getenv("MIGAN_DMA") ? atoi(getenv("MIGAN_DMA")) : 1;
-    if (fast && dma_env != 0 && var == 0) {
+    if (fast && dma_env != 0) {
         const int rc = launch_igemm_dma(g, A, Bw, bias, C, sk_ws, sk_bytes, st);
         if (rc != -2) return rc;
     }
     switch (tile_code) {
         case 1128128:
-#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
-            if (var == 1) return launch_cfg<128, 128, 2, 2, true, 1>(g, A, Bw, bias, C, st);
-            if (var == 2) return launch_cfg<128, 128, 2, 2, true, 2>(g, A, Bw, bias, C, st);
-            if (var == 3) return launch_cfg<128, 128, 2, 2, true, 3>(g, A, Bw, bias, C, st);
-            if (var == 4) return launch_cfg<128, 128, 2, 2, true, 4>(g, A, Bw, bias, C, st);
-            if (var == 8) return launch_cfg<128, 128, 2, 2, true, 8>(g, A, Bw, bias, C, st);
-            if (var == 16) return launch_cfg<128, 128, 2, 2, true, 16>(g, A, Bw, bias, C, st);
-            if (var == 32) return launch_cfg<128, 128, 2, 2, true, 32>(g, A, Bw, bias, C, st);
-            if (var == 48) return launch_cfg<128, 128, 2, 2, true, 48>(g, A, Bw, bias, C, st);
-            if (var == 100) return launch_cfg<128, 128, 2, 2, true>(g, A, Bw, bias, C, st);
-            if (var == 300) return launch_db<128, 128, 2, 2>(g, A, Bw, bias, C, st);
-#endif
             return launch_pipe<128, 128, 2, 2>(g, A, Bw, bias, C, st);
         case 1128064:
-#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
-            if (var == 1) return launch_cfg<128, 64, 2, 2, true, 1>(g, A, Bw, bias, C, st);
-            if (var == 2) return launch_cfg<128, 64, 2, 2, true, 2>(g, A, Bw, bias, C, st);
-            if (var == 3) return launch_cfg<128, 64, 2, 2, true, 3>(g, A, Bw, bias, C, st);
-            if (var == 100) return launch_cfg<128, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-            if (var == 300) return launch_db<128, 64, 2, 2>(g, A, Bw, bias, C, st);
-#endif
             return launch_pipe<128, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1064064:
-#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
-            if (var == 100) return launch_cfg<64, 64, 2, 2, true>(g, A, Bw, bias, C, st);
-            if (var == 300) return launch_db<64, 64, 2, 2>(g, A, Bw, bias, C, st);
-#endif
             return launch_pipe<64, 64, 2, 2>(g, A, Bw, bias, C, st);
         case 1128032:
-#ifdef MIGAN_ABLATION  // A/B variants of profiles/r01_igemm_ablation.txt (build with -DMIGAN_ABLATION)
-            if (var == 100) return launch_cfg<128, 32, 4, 1, true>(g, A, Bw, bias, C, st);
-            if (var == 300) return launch_db<128, 32, 4, 1>(g, A, Bw, bias, C, st);
-#endif
             return launch_pipe<128, 32, 4, 1>(g, A, Bw, bias, C, st);
-        case 128128: return launch_cfg<128, 128, 2, 2, false>(g, A, Bw, bias, C, st);
-        case 128064: return launch_cfg<128, 64, 2, 2, false>(g, A, Bw, bias, C, st);
-        default: return launch_cfg<128, 32, 4, 1, false>(g, A, Bw, bias, C, st);
+        case 128128: return launch_cfg<128, 128, 2, 2>(g, A, Bw, bias, C, st);
+        case 128064: return launch_cfg<128, 64, 2, 2>(g, A, Bw, bias, C, st);
+        default: return launch_cfg<128, 32, 4, 1>(g, A, Bw, bias, C, st);
     }
 }
 
@@ -2004,7 +1634,7 @@ static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, 
 // ------------------------------------------------------------------------------------------------
 
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const float* __restrict__ X,
                                                     const float* __restrict__ DY,
                                                     float* __restrict__ part) {
@@ -2041,20 +1671,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // VEC: thread owns float4 column-quad q of pixel rows (tid / QA) + j*(256/QA).
-    constexpr int QA = BM / 4, QB = BN / 4;
-    constexpr int NA = VEC ? (BK * QA) / 256 : (BK * BM) / 256;
-    constexpr int NB = VEC ? (BK * QB) / 256 : (BK * BN) / 256;
-    f32x4 ra4[VEC ? NA : 1], rb4[VEC ? NB : 1];
-    float ra1[VEC ? 1 : NA], rb1[VEC ? 1 : NB];
+    // thread owns column tid % BM (tid % BN) of pixel rows tid / BM + j * (256 / BM)
+    constexpr int NA = (BK * BM) / 256;
+    constexpr int NB = (BK * BN) / 256;
+    float ra1[NA], rb1[NB];
 
     // column decode for B (fixed per thread)
     int b_dh = 0, b_dw = 0, b_ci = 0;
     bool b_colok = false;
-    const int qa = VEC ? tid % QA : tid % BM;
-    const int qb = VEC ? tid % QB : tid % BN;
+    const int qa = tid % BM;
+    const int qb = tid % BN;
     {
-        int col = nc0 + (VEC ? qb * 4 : qb);
+        int col = nc0 + qb;
         if (col < Ncol) {
             int t = col / g.Ci;
             b_ci = col - t * g.Ci;
@@ -2064,7 +1692,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
             b_colok = true;
         }
     }
-    const bool a_colok = (co0 + (VEC ? qa * 4 : qa)) < g.Co;
+    const bool a_colok = (co0 + qa) < g.Co;
 
     auto calc_rowinfo = [&](int kt) {
         if (tid < BK) {
@@ -2085,67 +1713,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
     };
     auto load_tile = [&](int kt) {
         const int pt0 = p_begin + kt * BK;
-        if (VEC) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int pl = tid / QA + j * (256 / QA);
-                int p = pt0 + pl;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_colok && p < p_end)
-                    v = *reinterpret_cast<const f32x4*>(DY + (size_t)p * g.Co + co0 + qa * 4);
-                ra4[j] = v;
-            }
+        for (int j = 0; j < NA; ++j) {
+            int pl = tid / BM + j * (256 / BM);
+            int p = pt0 + pl;
+            float v = 0.f;
+            if (a_colok && p < p_end) v = DY[(size_t)p * g.Co + co0 + qa];
+            ra1[j] = v;
+        }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int pl = tid / QB + j * (256 / QB);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                int base = r_base[pl];
-                int ihs, iws;
-                if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
-                    map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
-                    v = *reinterpret_cast<const f32x4*>(X + (size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci);
-                rb4[j] = v;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int pl = tid / BM + j * (256 / BM);
-                int p = pt0 + pl;
-                float v = 0.f;
-                if (a_colok && p < p_end) v = DY[(size_t)p * g.Co + co0 + qa];
-                ra1[j] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int pl = tid / BN + j * (256 / BN);
-                float v = 0.f;
-                int base = r_base[pl];
-                int ihs, iws;
-                if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
-                    map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
-                    v = X[(size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci];
-                rb1[j] = v;
-            }
+        for (int j = 0; j < NB; ++j) {
+            int pl = tid / BN + j * (256 / BN);
+            float v = 0.f;
+            int base = r_base[pl];
+            int ihs, iws;
+            if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
+                map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
+                v = X[(size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci];
+            rb1[j] = v;
         }
     };
     auto store_tile = [&]() {
-        if (VEC) {
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int pl = tid / QA + j * (256 / QA);
-                *reinterpret_cast<f32x4*>(As + pl * LDA + qa * 4) = ra4[j];
-            }
+        for (int j = 0; j < NA; ++j) As[(tid / BM + j * (256 / BM)) * LDA + qa] = ra1[j];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int pl = tid / QB + j * (256 / QB);
-                *reinterpret_cast<f32x4*>(Bs + pl * LDB + qb * 4) = rb4[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NA; ++j) As[(tid / BM + j * (256 / BM)) * LDA + qa] = ra1[j];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) Bs[(tid / BN + j * (256 / BN)) * LDB + qb] = rb1[j];
-        }
+        for (int j = 0; j < NB; ++j) Bs[(tid / BN + j * (256 / BN)) * LDB + qb] = rb1[j];
     };
 
     if (KT > 0) {
@@ -2196,7 +1788,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const flo
 // dependency), the gather is branch-free and the loads of K-tile kt+1 are issued one per k-pair inside the MFMA
 // stream of tile kt (see igemm_pipe_kernel).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int ABL = 0, bool DYS = false, int OCC = 4>
+template <int BM, int BN, bool DYS = false, int OCC = 4>
 __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_kernel(
     const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
     constexpr int BK = 32;
@@ -2321,7 +1913,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
     const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
     float bsum = 0.f;
     for (int kt = 0; kt < KT; ++kt) {
-        if ((ABL & 2) == 0 || kt == 0) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NA; ++j)
@@ -2330,7 +1921,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
         for (int j = 0; j < NB; ++j)
             *reinterpret_cast<f32x4*>(Bs + (plB + j * (256 / QB)) * LDB + qb * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
         __syncthreads();
-        }
         if (bias_blk && tid < BM) {  // column sums of the (masked) dy tile: conflict-free, consecutive lanes = consecutive co
             float s_ = 0.f;
 #pragma unroll
@@ -2340,7 +1930,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_
         f_pt0 = p_begin + (kt + 1 < KT ? kt + 1 : kt) * BK;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
-            if ((ABL & 1) == 0 && (kp & 1) == 0 && (kp >> 1) < NL) {
+            if ((kp & 1) == 0 && (kp >> 1) < NL) {
                 asm volatile("" : "+s"(f_pt0));
                 switch (kp >> 1) {
                     case 0: WGRAD_ISSUE(0); break;
@@ -2769,15 +2359,11 @@ static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, i
     return 0;
 }
 
-static int wgrad_var() {
-    constexpr int v = 0;
-    return v;
-}
 // tile shape: 128x128 when both GEMM dims exceed 64; 64x128 for 32 < Co <= 64 with a wide column side (2 MFMAs per 3
 // LDS fragment reads instead of 1 per 2); else 64x64.  BNsel is returned through BMsel's companion wgrad_bn().
 static int wgrad_bn(int Co, int Ncol) {
     if (Co > 64 && Ncol > 64) return 128;
-    return (Co > 32 && Ncol >= 128 && wgrad_var() != 64) ? 128 : 64;
+    return (Co > 32 && Ncol >= 128) ? 128 : 64;
 }
 // Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
 // LDS-DMA kernels (conv_dma.hip): 4 (128x128, BK = 16) / 3 / 5 (BK = 32), LDS bound.
@@ -2810,8 +2396,7 @@ static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int oc
     return t + (double)s_ * out_bytes / 3.0e12 + (s_ > 1 ? 4e-6 : 0.0);
 }
 static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
-    // 3 (default) = the balance model above; 1 = round-1 rule: about 1024 workgroups, split count a multiple of 8
-    constexpr int plan_env = 3;
+    // the split count comes from the balance model above (round 1's rule - about 1024 workgroups - is gone)
     static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
     long Mpix = (long)N * Ho * Wo;
     // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
@@ -2827,15 +2412,6 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
         long want = splits_env > maxs ? maxs : splits_env;
         pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
         splits = cdiv(Mpix, pps);
-        return;
-    }
-    if (plan_env == 1) {
-        long want = cdiv(1024, tiles);
-        if (want > maxs) want = maxs;
-        if (want < 1) want = 1;
-        pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
-        splits = cdiv(Mpix, pps);
-        if (splits > 4) splits = cdiv(splits, 8) * 8;  // round-1 launch order: whole splits per XCD, padded with empty ones
         return;
     }
     const int occ = wgrad_occ(BMsel, bn);
@@ -3047,13 +2623,13 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
     float* bpart = ws + (size_t)4 * g.splits * Co * Ncol;
     g.bpart = (db && !db_slabs) ? bpart : nullptr;  // in-kernel column sums only when no external slabs are given
-    const bool inc = wgrad_var() != 200 && (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31);
+    const bool inc = (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31);
 #define UPW_LAUNCH(BM_, BN_)                                                                                       \
     do {                                                                                                           \
         g.tiles_m = cdiv(Co, BM_); g.tiles_n = cdiv(Ncol, BN_);                                                    \
         dim3 grid_(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8, 4);                                                           \
         if (inc) MIGAN_LAUNCH((wgrad_inc_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
-        else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_, 0, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
+        else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
     const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
     const int rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, true, x, dy, ws, st) : -2;  // LDS-DMA main loop (conv_dma.hip)
@@ -3426,7 +3002,7 @@ MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int
 // (the MFMA path with 16-byte channel vectors); 0: the caller runs migan_colsum for it.
 MIGAN_API int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int gather) {
     if (thin_wgrad_ok(Co, R, S, Ci, stride, gather) || Co <= 4) return 0;
-    return (Ci % 4 == 0 && Co % 4 == 0 && wgrad_var() != 100) ? 1 : 0;
+    return (Ci % 4 == 0 && Co % 4 == 0) ? 1 : 0;
 }
 
 MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes,
@@ -3450,8 +3026,7 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         HIP_LAUNCH_CHECK();
         return launch_wgrad_reduce(ws, dw_oihw, tg.nchunks, Co, R * S, Ci, accumulate, st, ext);
     }
-    constexpr int small_on = 1;
-    if (small_on && Co * R * S * Ci <= 256 && Co <= 64 && R * S * Ci <= 64 && !(Co % 4 == 0 && Ci % 4 == 0)) {
+    if (Co * R * S * Ci <= 256 && Co <= 64 && R * S * Ci <= 64 && !(Co % 4 == 0 && Ci % 4 == 0)) {
         SmallWgrad sg = {N, Hi, Wi, Ci, gather == GATHER_UP2 ? 2 * Hi : Hi, gather == GATHER_UP2 ? 2 * Wi : Wi,
                          Ho, Wo, Co, S, R * S, stride, pad_t, pad_l, gather, 0, 0, 0, 0, 0, 0, 0};
         const long Mpix = (long)N * Ho * Wo;
@@ -3499,16 +3074,10 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     g.bpart = (db && !db_slabs) ? ws + (size_t)g.splits * Co * Ncol : nullptr;
     fastdiv_magic((unsigned)(Ho * Wo), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)Wo, g.mg_w, g.sh_w);
-    const int wvar = wgrad_var();  // 100 = old kernel (only in -DMIGAN_ABLATION builds)
-#ifdef MIGAN_ABLATION
-    if (vec && wvar != 100) {
-#else
     if (vec) {
-#endif
-
         // incremental-addressing kernel for the zero-padding and reflection gathers; the decode-per-load kernel keeps
-        // the (rarely used, dense) upsample gather (and MIGAN_WGRAD_VAR=200 forces it for A/B runs)
-        const bool inc = gather != GATHER_UP2 && wvar != 200 && wvar != 1 && wvar != 2 && wvar != 3 &&
+        // the (rarely used, dense) upsample gather
+        const bool inc = gather != GATHER_UP2 &&
                          (size_t)N * Hi * Wi * Ci < (1ull << 31) && (size_t)N * Ho * Wo * Co < (1ull << 31);
         const bool refl = gather == GATHER_REFLECT;
 #define WG_LAUNCH(BM_, BN_)                                                                                        \
@@ -3521,22 +3090,11 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
         else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_>), grid_, dim3(256), 0, st, g, x, dy, ws);             \
     } while (0)
         const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
-        const int rc_dma = (inc && wvar == 0) ? launch_wgrad_dma(g, bm, bn_sel, false, x, dy, ws, st) : -2;
+        const int rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, false, x, dy, ws, st) : -2;
         if (rc_dma != -2) {
             if (rc_dma != 0) return rc_dma;
         } else if (bm == 128) {
-#ifdef MIGAN_ABLATION
-            if (wvar == 1 || wvar == 2 || wvar == 3) {
-                g.tiles_m = cdiv(Co, 128); g.tiles_n = cdiv(Ncol, 128);
-                dim3 grid(cdiv(g.tiles_m * g.tiles_n * g.splits, 8) * 8);
-                if (wvar == 1) MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 1>), grid, dim3(256), 0, st, g, x, dy, ws);
-                else if (wvar == 2) MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 2>), grid, dim3(256), 0, st, g, x, dy, ws);
-                else MIGAN_LAUNCH((wgrad_pipe_kernel<128, 128, 3>), grid, dim3(256), 0, st, g, x, dy, ws);
-            } else
-#endif
-            {
-                WG_LAUNCH(128, 128);
-            }
+            WG_LAUNCH(128, 128);
         } else if (wgrad_bn(Co, Ncol) == 128) {
             WG_LAUNCH(64, 128);
         } else {
@@ -3549,18 +3107,10 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
     }
     if (bm == 128) {
         dim3 grid(cdiv(Co, 128), cdiv(Ncol, 128), g.splits);
-#ifdef MIGAN_ABLATION
-        if (vec) MIGAN_LAUNCH((wgrad_kernel<128, 128, true>), grid, dim3(256), 0, st, g, x, dy, ws);
-        else
-#endif
-        MIGAN_LAUNCH((wgrad_kernel<128, 128, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        MIGAN_LAUNCH((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, g, x, dy, ws);
     } else {
         dim3 grid(cdiv(Co, 64), cdiv(Ncol, 64), g.splits);
-#ifdef MIGAN_ABLATION
-        if (vec) MIGAN_LAUNCH((wgrad_kernel<64, 64, true>), grid, dim3(256), 0, st, g, x, dy, ws);
-        else
-#endif
-        MIGAN_LAUNCH((wgrad_kernel<64, 64, false>), grid, dim3(256), 0, st, g, x, dy, ws);
+        MIGAN_LAUNCH((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, g, x, dy, ws);
     }
     HIP_LAUNCH_CHECK();
     return launch_wgrad_reduce(ws, dw_oihw, g.splits, Co, R * S, Ci, accumulate, st, ext);

@@ -119,6 +119,19 @@ def test_every_gpu_conv_case_on_the_execution_model(emu):
         assert emu.hipemu_launch_count(sym.encode()) > 0, sym
 
 
+def test_generic_kernels_serve_channel_counts_that_are_no_multiple_of_four(emu):
+    """igemm_kernel / wgrad_kernel (csrc/conv_igemm.hip: scalar gathers, any channel count) are what runs when the source channels are
+    not a multiple of 4 and the small-K / thin kernels do not take the shape: forward, input gradient (its GEMM's channels are Co) and
+    weight gradient against torch, with the launch counters saying which kernel served."""
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    for case in [(2, 6, 12, 12, 40, 3, 1, (1, 1, 1, 1), 0, 1, True), (3, 10, 9, 9, 72, 3, 2, (1, 1, 1, 1), 0, 0, True),
+                 (2, 7, 10, 10, 130, 5, 1, (2, 2, 2, 2), 0, 2, False)]:
+        emu.hipemu_reset_counts()
+        for what, err in _conv_case(emu, case, sk).items():
+            assert err <= (1e-5 if what == "wgrad" else 3e-6), (case, what, err)
+        assert emu.hipemu_launch_count(b"igemm_kernel<") >= 1 and emu.hipemu_launch_count(b"wgrad_kernel<") == 1, case
+
+
 def test_split_count_sweep_of_the_weight_gradient_reductions(emu):
     """The slab reductions behind the split-K weight gradients load up to eight slabs per round with the round width following the
     slabs that are left (csrc/conv_igemm.hip slab_sum / upconv_slab_round: 8 / 4 / 2 / 1, clamped index, guarded add).  Sweep the split
