@@ -25,20 +25,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# 0 off (default), 1 always, n > 1: only for gradients of at least n elements.  Measured (profiles/r02_ab.txt): with the
-# round-1 split-K plan the wave tails of a layer's wgrad and dgrad launches filled each other (+2.5 % on the CycleGAN step);
-# with the balanced plan the tails are gone (+0.3 %), and the captured DCGAN step is 4 % slower with the two branches.
-_OVERLAP_WGRAD = 0   # wgrad on a side stream beside dgrad: measured +0.3 % CycleGAN, -4 % DCGAN (profiles/r02_ab.txt); tests flip it
 _SIDE_STREAMS = {}
-
-
-def set_wgrad_overlap(enabled):
-    """Run the weight-gradient chain of a conv backward (wgrad, split-K reduction, bias column sums) on a side
-    stream concurrently with its dgrad (they only share the read-only dy); the two streams join before backward
-    returns.  Captured into a hipGraph this becomes two parallel branches.  `enabled`: False/0 off, True/1 always,
-    n > 1 only for gradients of at least n elements."""
-    global _OVERLAP_WGRAD
-    _OVERLAP_WGRAD = int(enabled)
 
 
 # Weight-gradient launches on their own stream, joined only where the optimiser needs them (steps / dp call join_wgrad_streams()
@@ -83,18 +70,18 @@ def join_wgrad_streams():
 
 
 class _Fork:
-    """fork(): side stream waits for the current one and becomes current;  join(): current waits for the side - at once, or (deferred:
-    the weight-gradient stream above) at the next join_wgrad_streams()."""
+    """fork(): the weight-gradient stream waits for the current one and becomes current;  join(): deferred to the next
+    join_wgrad_streams() when everything the side launches produced went into gradient slots, else the current stream waits at once."""
 
-    def __init__(self, device, both, numel=0, wgrad=False):
+    def __init__(self, device, numel=0, wgrad=False):
         first_order = not torch.is_grad_enabled()
         # only inside a step body (weight_cache_scope): its optimiser steps and its end join the stream - a bare loss.backward() of user
-        # code reads .grad right away
+        # code reads .grad right away.  (Round 2's other form - the weight gradient beside its own layer's input gradient, joined before
+        # backward returns - measured +0.3 % CycleGAN / -4 % DCGAN, profiles/r02_ab.txt, and is gone.)
         force = _WGRAD_ONE_STREAM > 0
         self.defer = (bool(wgrad) and first_order and device.type == "cuda" and _CACHE_SCOPE is not None
                       and (force or (_WGRAD_STREAM and numel >= _WGRAD_STREAM_MIN)))
-        self.on = self.defer or (bool(both) and _OVERLAP_WGRAD != 0 and first_order
-                                 and (_OVERLAP_WGRAD == 1 or numel >= _OVERLAP_WGRAD))
+        self.on = self.defer
         if self.on:
             self.main = torch.cuda.current_stream(device)
             key = (device.index, "all") if (force and self.defer) else (device.index, self.main.cuda_stream)
@@ -734,7 +721,7 @@ class _Conv2d(Function):
         dx = dw = db = None
         if ctx.toep:
             return _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db)
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
+        fork = _Fork(xs.device, dy.numel(), ctx.needs_input_grad[1])
         # ReflectionPad2d(1)+Conv3x3 with both gradients wanted: the input gradient's main launch goes FIRST, its ring
         # correction (a latency-bound launch of tiny workgroups, 64 us on CycleGAN's R256) runs on the side stream underneath
         # the weight-gradient launch that follows on this stream
@@ -858,7 +845,7 @@ def _conv2d_backward_toeplitz(ctx, dy, xs, w, want_db):
     nq = lib.migan_thin_toeplitz_workspace(N, Ho, W, Co, S)
     q = _ws(nq, xs)
     check(lib.migan_thin_toeplitz_expand(dy.data_ptr(), q.data_ptr(), N, Ho, Wo, Co, W, S, pl, gather, st), "thin_toeplitz_expand")
-    fork = _Fork(xs.device, False, dy.numel(), ctx.needs_input_grad[1] or want_db)
+    fork = _Fork(xs.device, dy.numel(), ctx.needs_input_grad[1] or want_db)
     with fork:
         if ctx.needs_input_grad[1]:
             slot = _grad_slot(ctx.params[0])
@@ -1020,7 +1007,7 @@ class _UpConv3x3(Function):
         elif fuse_db:
             side = _colsum_side(dy, Co)
         dx = dw = db = None
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
+        fork = _Fork(xs.device, dy.numel(), ctx.needs_input_grad[1])
         with fork:
             st = _stream()
             if ctx.needs_input_grad[1]:
@@ -1147,7 +1134,7 @@ class _ConvTranspose2d(Function):
                 dx = _empty_nhwc((N, Cin, Hin, Win), xs)
                 _fewpix_nt(dycol, w, None, dx, M, Cin, K, ACT_NONE, 0.0, st, "fewpix_convT_dgrad")
             return dx, dw, db, None, None, None, None
-        fork = _Fork(xs.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], dy.numel(), ctx.needs_input_grad[1])
+        fork = _Fork(xs.device, dy.numel(), ctx.needs_input_grad[1])
         with fork:
             st = _stream()
             if ctx.needs_input_grad[1]:
@@ -1264,7 +1251,7 @@ class _MMNT(Function):
         if ctx.act != ACT_NONE:  # fused activation epilogue (Linear -> LeakyReLU / Tanh / Sigmoid): differentiable act'
             g = _ActBwd.apply(g, y, ctx.act, ctx.slope)
         da = db = dbias = None
-        fork = _Fork(g.device, ctx.needs_input_grad[0] and ctx.needs_input_grad[1], g.numel(), ctx.needs_input_grad[1])
+        fork = _Fork(g.device, g.numel(), ctx.needs_input_grad[1])
         gc, ac = canon(g), canon(a)  # on the main stream: both branches read them
         with fork:
             want_db = ctx.has_bias and ctx.needs_input_grad[2]

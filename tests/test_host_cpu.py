@@ -450,11 +450,11 @@ def test_weight_gradient_stream_protocol(monkeypatch):
     big, small = F._WGRAD_STREAM_MIN, F._WGRAD_STREAM_MIN - 1
     with torch.no_grad():
         # outside a step body (no weight_cache_scope): never deferred - a bare loss.backward() reads .grad right away
-        assert not F._Fork(dev, True, big, True).on
+        assert not F._Fork(dev, big, True).on
         with F.weight_cache_scope():
-            f = F._Fork(dev, True, small, True)
+            f = F._Fork(dev, small, True)
             assert not f.on                                   # below the threshold: in line with its layer's backward
-            f = F._Fork(dev, False, big, True)
+            f = F._Fork(dev, big, True)
             assert f.on and f.defer
             dy, xs = FakeTensor(), FakeTensor()
             with f:
@@ -462,7 +462,7 @@ def test_weight_gradient_stream_protocol(monkeypatch):
             f.join((None, None), (dy, xs, None))              # everything went into gradient slots: join deferred
             assert log == [("side0", "waits", "main"), ("side0", "enter"), ("side0", "exit")]
             assert dy.recorded == xs.recorded == ["side0"] and len(F._PENDING_WGRAD) == 1
-            g = F._Fork(dev, False, big, True)
+            g = F._Fork(dev, big, True)
             with g:
                 pass
             g.join((object(), None), (dy,))                   # a gradient returned to autograd: joined at once
@@ -474,7 +474,7 @@ def test_weight_gradient_stream_protocol(monkeypatch):
             assert len(log) == n
             # one_wgrad_stream(): every size, ONE stream per device whatever the forking stream, and a returned gradient is an error
             with F.one_wgrad_stream():
-                h = F._Fork(dev, False, 16, True)
+                h = F._Fork(dev, 16, True)
                 assert h.on and h.defer and h.key == (0, "all")
                 with h:
                     pass
@@ -485,7 +485,7 @@ def test_weight_gradient_stream_protocol(monkeypatch):
             F.join_wgrad_streams()
     # second-order backward (grad mode on): never forked
     with F.weight_cache_scope():
-        assert not F._Fork(dev, True, big, True).on
+        assert not F._Fork(dev, big, True).on
 
 
 def test_fused_generator_plan_steps_aside_for_cross_replica_batchnorm(monkeypatch):
