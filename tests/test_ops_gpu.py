@@ -922,7 +922,7 @@ def test_conv_lrelu_dropout2d_fused(pg, cfg):
 
 
 def test_bias_grad_fused_into_wgrad(pg):
-    """Opt-in path (MIGAN_FUSE_BIAS=1): the bias gradient comes out of the wgrad launches (db argument of
+    """Opt-in path (functional._FUSE_BIAS): the bias gradient comes out of the wgrad launches (db argument of
     migan_conv2d_wgrad / migan_upconv3x3_wgrad) instead of migan_colsum; same values, with and without .grad slots."""
     F, nn = pg.functional, pg.nn
     torch.manual_seed(0)
