@@ -331,7 +331,8 @@ class _CriticFusedPlan:
 
 class _GeneratorFusedPlan:
     """The MLP generator of wgan_gp.py:42-65 - Sequential of Linear [-> BatchNorm1d] [-> LeakyReLU | Tanh] groups behind a view to
-    img_shape - as the operands of migan_mlp_fused_fwd (one persistent launch for the no_grad forward of a critic iteration)."""
+    img_shape - as the operands of migan_mlp_fused_fwd (four launches for the no_grad forward of a critic iteration: one per layer, the
+    first layer inside the launch of the second)."""
 
     def __init__(self, G, z, out_shape=None):
         import ctypes
