@@ -385,7 +385,7 @@ class _GeneratorFusedPlan:
             self.bws = torch.empty(self.bws_bytes // 4, device=dev, dtype=torch.float32)
 
     def forward_saved(self, x, buffers=None):
-        """Forward that keeps what backward() needs (one launch); BatchNorm side effects as in run()."""
+        """Forward that keeps what backward() needs (one launch per layer); BatchNorm side effects as in run()."""
         import ctypes
 
         from ._lib import check, lib
