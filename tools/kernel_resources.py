@@ -16,7 +16,7 @@ def main():
     blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
     seen = set()
     for b in blocks:
-        name = b.split("\n")[0].strip()
+        name = b.split("\n")[0].strip().split(" ")[0]   # the remark line ends in " [-Rpass-analysis=...]"
         if name in seen:
             continue
         seen.add(name)
@@ -30,8 +30,8 @@ def main():
         lds = g(r"LDS Size \[bytes/block\]")
         occ = g(r"Occupancy \[waves/SIMD\]")
         wg = min(occ, (160 * 1024) // lds if lds > 0 else 99)
-        print("%-64s VGPR %3d AGPR %3d SGPR %3d waves/SIMD %d LDS %6d -> WG/CU %2d scratch %d" % (
-            dn[:64], g("VGPRs"), g("AGPRs"), g("SGPRs"), occ, lds, wg, g(r"ScratchSize \[bytes/lane\]")))
+        print("%-96s VGPR %3d AGPR %3d SGPR %3d waves/SIMD %d LDS %6d -> WG/CU %2d scratch %d" % (
+            dn[:96], g("VGPRs"), g("AGPRs"), g("SGPRs"), occ, lds, wg, g(r"ScratchSize \[bytes/lane\]")))
 
 
 if __name__ == "__main__":
