@@ -99,7 +99,97 @@ def _fewpix_case_guarded(N, Ci, H, W, Co):
         assert K._rel(t.permute(0, 3, 1, 2), torch.relu(t_ref)) < 3e-6, "fewpix convT fwd"
 
 
+def _upconv_case_guarded(N, Ci, H, W, Co):
+    """Upsample(2) + Conv2d(Ci, Co, 3, 1, 1) phase-collapsed (dcgan.py:54-59): pack, forward, input gradient, weight gradient with
+    its four-class slab reduction (upconv_wgrad_reduce_kernel: clamped slab indices, the bias slabs behind the partials) - every
+    operand against a guard page, outputs and the workspace NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(5)
+    P = K._ptr
+    x = torch.randn(N, Ci, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(Co, generator=g)
+    y_ref = TF.conv2d(TF.interpolate(x, scale_factor=2, mode="nearest"), w, b, 1, 1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xn, wg, bg = guarded(x.detach().permute(0, 2, 3, 1).contiguous()), guarded(w.detach().clone()), guarded(b)
+    wf, wd = guarded(torch.full((Co * 16 * Ci,), float("nan"))), guarded(torch.full((Co * 16 * Ci,), float("nan")))
+    assert emu.migan_upconv3x3_pack(P(wg), P(wf), P(wd), Co, Ci, None) == 0
+    y = guarded(torch.full((N, 2 * H, 2 * W, Co), float("nan")))
+    assert emu.migan_upconv3x3_fwd(P(xn), P(wf), P(bg), P(y), N, H, W, Ci, Co, 0, 0.0, None) == 0
+    assert K._rel(y.permute(0, 3, 1, 2), y_ref.detach()) < 3e-6, "upconv fwd"
+    gyn = guarded(gy.permute(0, 2, 3, 1).contiguous())
+    dx = guarded(torch.full((N, H, W, Ci), float("nan")))
+    assert emu.migan_upconv3x3_dgrad(P(gyn), P(wd), P(dx), N, H, W, Ci, Co, None) == 0
+    assert K._rel(dx.permute(0, 3, 1, 2), x.grad) < 3e-6, "upconv dgrad"
+    nb = emu.migan_upconv3x3_wgrad_workspace(N, H, W, Co, Ci)
+    ws = guarded(torch.full((max(nb // 4, 4),), float("nan")))
+    dw, db = guarded(torch.full((Co, Ci, 3, 3), float("nan"))), guarded(torch.full((Co,), float("nan")))
+    assert emu.migan_upconv3x3_wgrad(P(xn), P(gyn), P(dw), P(ws), nb, N, H, W, Ci, Co, 0, P(db), 0, None, 0, None) == 0
+    assert K._rel(dw, w.grad) < 1e-5 and K._rel(db, gy.sum((0, 2, 3))) < 1e-5, "upconv wgrad (%d B of slabs)" % nb
+
+
+def _norm_case_guarded(G, N, HW, C, act):
+    """BatchNorm (G = 1) / InstanceNorm (G = N) statistics, apply, backward and the column-sum reduction: the chunked partial passes
+    and their one-wave-per-channel finalize kernels (four records per round of loads, clamped record index) - every operand against a
+    guard page, outputs and workspaces NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(7)
+    P = K._ptr
+    Pp = N * HW // G   # pixels per group
+    x = (torch.randn(N, HW, C, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).requires_grad_(True), torch.randn(C, generator=g).requires_grad_(True)
+    xg = x.view(G, Pp, C)
+    mean_ref, var_ref = xg.mean(1), xg.var(1, unbiased=False)
+    yl = ((xg - mean_ref[:, None]) / torch.sqrt(var_ref[:, None] + 1e-5) * gamma + beta)
+    y_ref = TF.leaky_relu(yl, 0.2) if act == 1 else yl
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xs = guarded(x.detach().clone())
+    gm, bt = guarded(gamma.detach().clone()), guarded(beta.detach().clone())
+    mean, invstd = guarded(torch.full((G * C,), float("nan"))), guarded(torch.full((G * C,), float("nan")))
+    nb = emu.migan_norm_workspace(G, Pp, C)
+    ws = guarded(torch.full((max(nb // 4, 4),), float("nan")))
+    assert emu.migan_norm_stats(P(xs), P(mean), P(invstd), None, None, None, 0.1, 1e-5, G, Pp, C, P(ws), nb, None) == 0
+    assert K._rel(mean.view(G, C), mean_ref.detach()) < 1e-5 and K._rel(invstd.view(G, C), 1 / torch.sqrt(var_ref.detach() + 1e-5)) < 1e-5, "stats"
+    y = guarded(torch.full((N, HW, C), float("nan")))
+    assert emu.migan_norm_apply(P(xs), P(y), P(mean), P(invstd), P(gm), P(bt), None, G, Pp, C, act, 0.2, None) == 0
+    assert K._rel(y.view(G, Pp, C), y_ref.detach()) < 3e-6, "apply"
+    gyn = guarded(gy.reshape(N, HW, C).contiguous())
+    dx = guarded(torch.full((N, HW, C), float("nan")))
+    dg, dbt = (guarded(torch.full((C,), float("nan"))), guarded(torch.full((C,), float("nan")))) if G == 1 else (None, None)
+    ws.fill_(float("nan"))
+    assert emu.migan_norm_bwd(P(xs), P(gyn), P(mean), P(invstd), P(gm), P(bt), P(dx), P(dg), P(dbt), G, Pp, C, act, 0.2, P(ws), nb, 0,
+                              None, None) == 0
+    assert K._rel(dx, x.grad) < 2e-5, "bwd dx %g" % K._rel(dx, x.grad)
+    if G == 1:
+        assert K._rel(dg, gamma.grad) < 2e-5 and K._rel(dbt, beta.grad) < 2e-5, "bwd dgamma / dbeta"
+    cb = emu.migan_colsum_workspace(N * HW, C)
+    cws = guarded(torch.full((max(cb // 4, 4),), float("nan")))
+    cs = guarded(torch.full((C,), float("nan")))
+    assert emu.migan_colsum(P(gyn), P(cs), N * HW, C, P(cws), cb, 0, None) == 0
+    assert K._rel(cs, gy.reshape(-1, C).sum(0)) < 1e-5, "colsum"
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "upconv":
+    # split counts 1 ... 20 (N x 8 x 8 source pixels): every round width and remainder of the four-class reduction
+    for c in [(1, 16, 8, 8, 16), (3, 16, 8, 8, 16), (5, 16, 8, 8, 32), (9, 32, 8, 8, 16), (19, 16, 8, 8, 16), (40, 16, 8, 8, 16), (80, 16, 8, 8, 16),
+              (2, 128, 6, 6, 64)]:
+        print("upconv", c, flush=True)
+        _upconv_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "norm":
+    # chunk counts from 1 to > 256 per (group, channel): every remainder of the four-records-per-round finalize loops
+    for c in [(1, 2, 6, 8, 0), (1, 4, 64, 16, 1), (1, 8, 1000, 64, 1), (1, 16, 4096, 128, 0), (1, 3, 5000, 12, 1), (4, 4, 300, 32, 1),
+              (2, 2, 4096, 64, 0), (1, 5, 777, 3, 0)]:
+        print("norm", c, flush=True)
+        _norm_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "fewpix":
     for c in [(1, 256, 2, 2, 512), (1, 64, 16, 16, 1024), (3, 128, 4, 6, 512), (1, 512, 8, 8, 128), (2, 1024, 2, 2, 256)]:
         print("fewpix", c, flush=True)

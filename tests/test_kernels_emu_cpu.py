@@ -260,6 +260,19 @@ def test_fewpix_kernels_stay_inside_their_tensors(emu):
     assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
 
 
+@pytest.mark.parametrize("family", ["upconv", "norm"])
+def test_upconv_and_norm_kernels_stay_inside_their_tensors(emu, family):
+    """The same for the phase-collapsed up-conv (pack, forward, input gradient, weight gradient + its four-class slab reduction over
+    1 ... 20 splits) and for the norm / column-sum passes (chunked partial kernels + one-wave-per-channel finalize kernels over 1 ... > 256
+    chunks): the reductions load several slabs / records per round through a CLAMPED index - an index one past the range would read the
+    guard page here and nothing a GPU run notices."""
+    import subprocess
+
+    script = os.path.join(os.path.dirname(os.path.abspath(hipemu.__file__)), "guarded_conv_cases.py")
+    r = subprocess.run([sys.executable, script, family], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_splitk_tickets_and_determinism(emu):
     """pix2pix/models.py:66 geometry (4 output pixels, K = 8192): slices add in slice order whoever arrives last - with the
     model's workgroups on 1, 3 and 8 OS threads (different arrival orders) the result is bit-identical."""
