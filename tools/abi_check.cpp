@@ -19,8 +19,20 @@ enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 typedef std::chrono::steady_clock::time_point* hipEvent_t;
 struct hipDeviceProp_t { char name[64]; int multiProcessorCount; };
 static inline const char* hipGetErrorString(hipError_t) { return "host"; }
-static inline hipError_t hipMalloc(float** p, size_t n) { *p = (float*)malloc(n); return 0; }
-static inline hipError_t hipFree(void* p) { free(p); return 0; }
+// Every "device" buffer ends (to 16 bytes) at an inaccessible page, starts behind one and is filled with NaN: a kernel that reads or writes
+// past one of its operands - which a GPU run never notices, the neighbouring allocation is mapped - dies with SIGSEGV here, and a
+// workspace word read before it was written poisons the compared result.  (Buffers are not unmapped: the program is short-lived.)
+#include <sys/mman.h>
+static inline hipError_t hipMalloc(float** p, size_t n) {
+    const size_t page = 4096, body = (n + page - 1) / page * page;
+    char* m = (char*)mmap(nullptr, body + 2 * page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == (char*)MAP_FAILED || mprotect(m, page, PROT_NONE) != 0 || mprotect(m + page + body, page, PROT_NONE) != 0) return 1;
+    char* start = m + page + body - (n + 15) / 16 * 16;
+    for (size_t i = 0; i + 4 <= n; i += 4) { const unsigned nan = 0x7fc00000u; memcpy(start + i, &nan, 4); }
+    *p = (float*)start;
+    return 0;
+}
+static inline hipError_t hipFree(void*) { return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
