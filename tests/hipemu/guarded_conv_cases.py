@@ -171,7 +171,56 @@ def _norm_case_guarded(G, N, HW, C, act):
     assert K._rel(cs, gy.reshape(-1, C).sum(0)) < 1e-5, "colsum"
 
 
+def _toeplitz_case_guarded(N, Ci, H, W, Co, k, gather):
+    """Image-output conv (cyclegan/models.py:75 ReflectionPad2d(3) + Conv2d(64, 3, 7); srgan/models.py:62 Conv2d(64, 3, 9, 1, 4)) on the
+    width-Toeplitz path of csrc/thin_toeplitz.hip: pack, forward (R x 1 GEMM into P + diagonal sum), expansion of dy into Q, weight and
+    input gradients from Q - every operand and the P / Q / slab buffers against a guard page, NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(9)
+    P = K._ptr
+    pad = k // 2
+    assert emu.migan_thin_toeplitz_ok(Co, k, k, Ci, 1, gather) == 1, (Co, k, Ci, gather)
+    x = torch.randn(N, Ci, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(Co, generator=g)
+    y_ref = torch.tanh(TF.conv2d(K._gather_ref(x, (pad,) * 4, gather), w, b, 1))
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_lin = TF.conv2d(K._gather_ref(x, (pad,) * 4, gather), w, b, 1)
+    y_lin.backward(gy)
+    Ho, Wo = y_ref.shape[2:]
+    cop = emu.migan_thin_toeplitz_cols(Co, k)
+    xn, wg, bg = guarded(x.detach().permute(0, 2, 3, 1).contiguous()), guarded(w.detach().clone()), guarded(b)
+    wt, wd = guarded(torch.full((cop * k * Ci,), float("nan"))), guarded(torch.full((cop * k * Ci,), float("nan")))
+    assert emu.migan_thin_toeplitz_pack(P(wg), P(wt), P(wd), Co, Ci, k, k, None) == 0
+    nbp = emu.migan_thin_toeplitz_workspace(N, Ho, W, Co, k)
+    pq = guarded(torch.full((nbp // 4,), float("nan")))
+    y = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
+    assert emu.migan_thin_toeplitz_fwd(P(xn), P(wt), P(bg), P(y), P(pq), nbp, N, H, W, Ci, Ho, Wo, Co, k, k, pad, pad, gather, 3, 0.0,
+                                       None) == 0
+    assert K._rel(y.permute(0, 3, 1, 2), y_ref.detach()) < 3e-6, "toeplitz fwd"
+    gyn = guarded(gy.permute(0, 2, 3, 1).contiguous())
+    pq.fill_(float("nan"))
+    assert emu.migan_thin_toeplitz_expand(P(gyn), P(pq), N, Ho, Wo, Co, W, k, pad, gather, None) == 0
+    nbw = emu.migan_thin_toeplitz_wgrad_workspace(N, Ho, W, Ci, Co, k, k)
+    wsw = guarded(torch.full((max(nbw // 4, 4),), float("nan")))
+    dw = guarded(torch.full((Co, Ci, k, k), float("nan")))
+    assert emu.migan_thin_toeplitz_wgrad(P(xn), P(pq), P(dw), P(wsw), nbw, N, H, W, Ci, Ho, Co, k, k, pad, gather, 0, None) == 0
+    assert K._rel(dw, w.grad) < 1e-5, "toeplitz wgrad %g" % K._rel(dw, w.grad)
+    nbd = emu.migan_thin_toeplitz_dgrad_workspace(N, H, W, Ci, Ho, k, gather)
+    wsd = guarded(torch.full((max(nbd // 4, 4),), float("nan")))
+    dx = guarded(torch.full((N, H, W, Ci), float("nan")))
+    assert emu.migan_thin_toeplitz_dgrad(P(pq), P(wd), P(dx), P(wsd), nbd, N, H, W, Ci, Ho, Co, k, k, pad, gather, None) == 0
+    assert K._rel(dx.permute(0, 3, 1, 2), x.grad) < 3e-6, "toeplitz dgrad %g" % K._rel(dx.permute(0, 3, 1, 2), x.grad)
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "toeplitz":
+    for c in [(1, 64, 20, 24, 3, 7, 1), (2, 64, 16, 16, 3, 9, 0), (1, 16, 13, 17, 3, 7, 0), (1, 32, 24, 40, 2, 9, 1), (3, 64, 11, 9, 4, 7, 1)]:
+        print("toeplitz", c, flush=True)
+        _toeplitz_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "upconv":
     # split counts 1 ... 20 (N x 8 x 8 source pixels): every round width and remainder of the four-class reduction
     for c in [(1, 16, 8, 8, 16), (3, 16, 8, 8, 16), (5, 16, 8, 8, 32), (9, 32, 8, 8, 16), (19, 16, 8, 8, 16), (40, 16, 8, 8, 16), (80, 16, 8, 8, 16),
