@@ -213,7 +213,87 @@ def _toeplitz_case_guarded(N, Ci, H, W, Co, k, gather):
     assert K._rel(dx.permute(0, 3, 1, 2), x.grad) < 3e-6, "toeplitz dgrad %g" % K._rel(dx.permute(0, 3, 1, 2), x.grad)
 
 
+def _eltwise_case_guarded(N, H, W, C):
+    """The elementwise / index kernels of csrc/eltwise.hip on shapes whose element counts are NOT multiples of a vector width: activation
+    forward / backward, axpby, MaxPool2d(2) forward / backward / backward-through-ReLU, gather (zero pad, reflection pad, upsample), channel
+    concat / split, batched transpose, PixelShuffle - every operand against a guard page, outputs NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(13)
+    P = K._ptr
+    x = torch.randn(N, H, W, C, generator=g)
+    xs, n = guarded(x.clone()), x.numel()
+    y = guarded(torch.full((N, H, W, C), float("nan")))
+    for act, ref in ((1, lambda t: TF.leaky_relu(t, 0.2)), (2, torch.relu), (3, torch.tanh), (4, torch.sigmoid)):
+        y.fill_(float("nan"))
+        assert emu.migan_act_fwd(P(xs), P(y), n, act, 0.2, None) == 0
+        assert K._rel(y, ref(x)) < 2e-6, ("act_fwd", act)
+        dy, dx = guarded(torch.randn(N, H, W, C, generator=g)), guarded(torch.full((N, H, W, C), float("nan")))
+        assert emu.migan_act_bwd(P(dy), P(y), P(dx), n, act, 0.2, None) == 0
+        xr = x.clone().requires_grad_(True)
+        ref(xr).backward(dy.clone())
+        assert K._rel(dx, xr.grad) < 2e-5, ("act_bwd", act)
+    b2, out = guarded(torch.randn(N, H, W, C, generator=g)), guarded(torch.full((N, H, W, C), float("nan")))
+    assert emu.migan_axpby(P(xs), 0.5, P(b2), -2.0, P(out), n, None) == 0
+    assert K._rel(out, 0.5 * x - 2.0 * b2) < 1e-6, "axpby"
+    if H % 2 == 0 and W % 2 == 0:
+        xc = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        pr = TF.max_pool2d(xc, 2)
+        gp = torch.randn(pr.shape, generator=g)
+        pr.backward(gp)
+        py = guarded(torch.full((N, H // 2, W // 2, C), float("nan")))
+        assert emu.migan_maxpool2_fwd(P(xs), P(py), N, H, W, C, None) == 0
+        assert torch.equal(py.permute(0, 3, 1, 2), pr.detach()), "maxpool fwd"
+        gpn, pdx = guarded(gp.permute(0, 2, 3, 1).contiguous()), guarded(torch.full((N, H, W, C), float("nan")))
+        assert emu.migan_maxpool2_bwd(P(xs), P(gpn), P(pdx), N, H, W, C, None) == 0
+        assert K._rel(pdx.permute(0, 3, 1, 2), xc.grad) < 1e-6, "maxpool bwd"
+        xq = x.permute(0, 3, 1, 2).clone().requires_grad_(True)   # the pool behind a ReLU whose backward it applies (srgan/models.py:8-15)
+        rq = torch.relu(xq)
+        TF.max_pool2d(rq, 2).backward(gp)
+        rx = guarded(torch.relu(x).clone())
+        pdx.fill_(float("nan"))
+        assert emu.migan_maxpool2_relu_bwd(P(rx), P(gpn), P(pdx), N, H, W, C, None) == 0
+        assert K._rel(pdx.permute(0, 3, 1, 2), xq.grad) < 1e-6, "maxpool relu bwd"
+    for mode, (pt, pl, Ho, Wo), ref in ((0, (1, 2, H + 2, W + 4), lambda t: TF.pad(t, (2, 2, 1, 1))),
+                                        (1, (2, 1, H + 4, W + 2), lambda t: TF.pad(t, (1, 1, 2, 2), mode="reflect")),
+                                        (2, (0, 0, 2 * H, 2 * W), lambda t: TF.interpolate(t, scale_factor=2, mode="nearest"))):
+        gyv = guarded(torch.full((N, Ho, Wo, C), float("nan")))
+        assert emu.migan_gather2d_fwd(P(xs), P(gyv), N, H, W, C, Ho, Wo, pt, pl, mode, None) == 0
+        xc = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        r = ref(xc)
+        assert torch.equal(gyv.permute(0, 3, 1, 2), r.detach()), ("gather fwd", mode)
+        gg = torch.randn(r.shape, generator=g)
+        r.backward(gg)
+        ggn, gdx = guarded(gg.permute(0, 2, 3, 1).contiguous()), guarded(torch.full((N, H, W, C), float("nan")))
+        assert emu.migan_gather2d_bwd(P(ggn), P(gdx), N, H, W, C, Ho, Wo, pt, pl, mode, None) == 0
+        assert K._rel(gdx.permute(0, 3, 1, 2), xc.grad) < 1e-6, ("gather bwd", mode)
+    Cb = C + 3
+    bb = guarded(torch.randn(N, H, W, Cb, generator=g))
+    cy = guarded(torch.full((N, H, W, C + Cb), float("nan")))
+    assert emu.migan_cat_channels(P(xs), P(bb), P(cy), N * H * W, C, Cb, 1, None) == 0
+    assert torch.equal(cy, torch.cat([x, bb], 3)), "cat"
+    da, db = guarded(torch.full((N, H, W, C), float("nan"))), guarded(torch.full((N, H, W, Cb), float("nan")))
+    assert emu.migan_cat_channels(P(da), P(db), P(cy), N * H * W, C, Cb, 0, None) == 0
+    assert torch.equal(da, x) and torch.equal(db, bb), "split"
+    ty = guarded(torch.full((N, C, H * W), float("nan")))
+    assert emu.migan_transpose_batched(P(xs), P(ty), N, H * W, C, None) == 0
+    assert torch.equal(ty, x.view(N, H * W, C).transpose(1, 2)), "transpose"
+    if C % 4 == 0:
+        sy = guarded(torch.full((N, 2 * H, 2 * W, C // 4), float("nan")))
+        assert emu.migan_pixel_shuffle(P(xs), P(sy), N, H, W, C // 4, 2, 1, None) == 0   # C = channels of the shuffled tensor
+        assert torch.equal(sy.permute(0, 3, 1, 2), TF.pixel_shuffle(x.permute(0, 3, 1, 2), 2)), "pixel shuffle"
+        ux = guarded(torch.full((N, H, W, C), float("nan")))
+        assert emu.migan_pixel_shuffle(P(sy), P(ux), N, H, W, C // 4, 2, 0, None) == 0
+        assert torch.equal(ux, x), "pixel unshuffle"
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "eltwise":
+    for c in [(1, 3, 5, 1), (2, 6, 10, 3), (1, 8, 8, 4), (3, 7, 9, 5), (2, 12, 4, 8), (1, 16, 18, 66), (1, 30, 30, 64)]:
+        print("eltwise", c, flush=True)
+        _eltwise_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "toeplitz":
     for c in [(1, 64, 20, 24, 3, 7, 1), (2, 64, 16, 16, 3, 9, 0), (1, 16, 13, 17, 3, 7, 0), (1, 32, 24, 40, 2, 9, 1), (3, 64, 11, 9, 4, 7, 1)]:
         print("toeplitz", c, flush=True)
