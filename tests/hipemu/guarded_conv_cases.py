@@ -50,6 +50,14 @@ def _conv_case_guarded(case):
             dx = guarded(torch.full((N, H, W, Ci), float("nan")))
             assert emu.migan_conv2d_dgrad_ws(P(gy), P(wi), None, P(dx), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], 0, 0.0, P(sk), sk.numel() * 4, None) == 0
             assert not torch.isnan(dx).any(), 'dgrad NaN'
+            # the same input gradient through the ReLU that produced this conv's input (mask = that ReLU's output, in the launch's epilogue);
+            # 801 = this geometry has no kernel with the epilogue (the host applies the mask as its own pass)
+            ro = guarded(torch.relu(torch.randn(N, H, W, Ci, generator=g)))
+            dxr = guarded(torch.full((N, H, W, Ci), float("nan")))
+            rc = emu.migan_conv2d_dgrad_relu_ws(P(gy), P(wi), P(dxr), P(ro), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], P(sk), sk.numel() * 4, None)
+            assert rc in (0, 801), rc
+            if rc == 0:
+                assert torch.equal(dxr, torch.where(ro > 0, dx, torch.zeros(()))), 'dgrad with the ReLU mask epilogue'
         wsb = emu.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
         ws = guarded(torch.full((max(wsb // 4, 4),), float("nan"))); dw = guarded(torch.full((Co, Ci, k, k), float("nan")))
         assert emu.migan_conv2d_wgrad(P(xn), P(gy), P(dw), P(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, 0, None, 0, None, 0, None) == 0
