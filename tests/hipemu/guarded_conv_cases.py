@@ -294,7 +294,60 @@ def _eltwise_case_guarded(N, H, W, C):
         assert torch.equal(ux, x), "pixel unshuffle"
 
 
+def _loss_case_guarded(n, B, D):
+    """The mean-reduced losses of csrc/reduce_loss_adam.hip (BCE, MSE, L1, mean, BCE-with-logits; tensor and constant targets) with their
+    gradients on n elements, and the per-row norm / row scaling of the gradient penalty on a B x D matrix - every operand and the reduction
+    workspace against a guard page, NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(17)
+    P = K._ptr
+    nb = emu.migan_reduce_workspace()
+    ws = guarded(torch.full((max(nb // 4, 4),), float("nan")))
+    prob, tgt = torch.rand(n, generator=g) * 0.98 + 0.01, torch.rand(n, generator=g)
+    raw = torch.randn(n, generator=g)
+    refs = {0: lambda x, t: TF.binary_cross_entropy(x, t), 1: lambda x, t: TF.mse_loss(x, t), 2: lambda x, t: TF.l1_loss(x, t),
+            3: lambda x, t: x.mean(), 4: lambda x, t: TF.binary_cross_entropy_with_logits(x, t)}
+    for kind in (0, 1, 2, 3, 4):
+        for const in (False, True):
+            if kind == 3 and const:
+                continue
+            xin = (prob if kind == 0 else raw).clone().requires_grad_(True)
+            t = torch.full((n,), 1.0) if const else tgt
+            ref = refs[kind](xin, t)
+            ref.backward()
+            xs = guarded(xin.detach().clone())
+            tg = None if (const or kind == 3) else guarded(t.clone())
+            out = guarded(torch.full((4,), float("nan")))
+            ws.fill_(float("nan"))
+            assert emu.migan_loss_fwd(kind, P(xs), P(tg), 1.0, P(out), n, P(ws), nb, None) == 0
+            rv = float(ref.detach())
+            assert abs(float(out[0]) - rv) <= 2e-6 * max(1.0, abs(rv)), ("loss", kind, const, float(out[0]), rv)
+            one, dx = guarded(torch.ones(4)), guarded(torch.full((n,), float("nan")))
+            assert emu.migan_loss_bwd(kind, P(xs), P(tg), 1.0, P(one), P(dx), n, None) == 0
+            assert K._rel(dx, xin.grad) < 2e-5, ("loss bwd", kind, const)
+    x = torch.randn(B, D, generator=g, requires_grad=True)
+    nr = x.norm(2, dim=1)
+    gn = torch.randn(B, generator=g)
+    nr.backward(gn)
+    xs, out = guarded(x.detach().clone()), guarded(torch.full((B,), float("nan")))
+    assert emu.migan_rownorm_fwd(P(xs), P(out), B, D, None) == 0
+    assert K._rel(out, nr.detach()) < 2e-6, "rownorm"
+    gng, dx = guarded(gn.clone()), guarded(torch.full((B, D), float("nan")))
+    assert emu.migan_rownorm_bwd(P(xs), P(out), P(gng), P(dx), B, D, None) == 0
+    assert K._rel(dx, x.grad) < 2e-5, "rownorm bwd"
+    sc, y = guarded(torch.rand(B, generator=g)), guarded(torch.full((B, D), float("nan")))
+    assert emu.migan_rowscale(P(xs), P(sc), P(y), B, D, None) == 0
+    assert torch.equal(y, x.detach() * sc[:, None]), "rowscale"
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "loss":
+    for c in [(1, 1, 1), (7, 3, 5), (64, 64, 1024), (1000, 5, 333), (128 * 25, 64, 3072), (65537, 9, 1027)]:
+        print("loss", c, flush=True)
+        _loss_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "eltwise":
     for c in [(1, 3, 5, 1), (2, 6, 10, 3), (1, 8, 8, 4), (3, 7, 9, 5), (2, 12, 4, 8), (1, 16, 18, 66), (1, 30, 30, 64)]:
         print("eltwise", c, flush=True)
