@@ -340,7 +340,48 @@ def _loss_case_guarded(n, B, D):
     assert torch.equal(y, x.detach() * sc[:, None]), "rowscale"
 
 
+def _adam_case_guarded(sizes):
+    """migan_adam_step (one launch for all tensors of an optimiser; 16-byte accesses on whole 4096-element chunks, scalar tails) on
+    parameters of the given sizes, each its OWN guarded allocation, with the gradient / moment buckets in optim.bucket_layout - two steps
+    against torch.optim.Adam; the step counter advances by itself and the ticket returns to zero."""
+    from pytorch_gan_amd import optim
+    g = torch.Generator().manual_seed(19)
+    P = K._ptr
+    offs, total = optim.bucket_layout(sizes)
+    ps = [guarded(torch.randn(n, generator=g)) for n in sizes]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    topt = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    grad, m, v = guarded(torch.zeros(total)), guarded(torch.zeros(total)), guarded(torch.zeros(total))
+    step, ticket, lr = guarded(torch.zeros(4)), guarded(torch.zeros(4)), guarded(torch.full((4,), 2e-4))
+    chunk = emu.migan_adam_chunk()
+    tab = np.zeros(len(sizes), dtype=optim._ADAM_T)
+    blks = []
+    for i, (p, o, n) in enumerate(zip(ps, offs, sizes)):
+        tab[i] = (p.data_ptr(), grad.data_ptr() + 4 * o, m.data_ptr() + 4 * o, v.data_ptr() + 4 * o, n)
+        blks += [(i, c) for c in range((n + chunk - 1) // chunk)]
+    blk = np.array(blks, dtype=optim._BLK_T)
+    tabg = guarded(torch.from_numpy(np.frombuffer(tab.tobytes(), dtype=np.float32).copy()))
+    blkg = guarded(torch.from_numpy(np.frombuffer(blk.tobytes(), dtype=np.float32).copy()))
+    for it in range(2):
+        for r, o, n in zip(ref, offs, sizes):
+            gr = torch.randn(n, generator=g)
+            r.grad = gr.clone()
+            grad[o:o + n] = gr
+        topt.step()
+        assert emu.migan_adam_step(P(tabg), P(blkg), len(blks), P(step), P(ticket), P(lr), 2e-4, 0.5, 0.999, 1e-8, 1.0, None) == 0
+        assert float(step[0]) == it + 1 and int(ticket.view(torch.int32)[0]) == 0, (float(step[0]), ticket)
+        for p, r in zip(ps, ref):
+            assert K._rel(p, r.detach()) < 1e-6, ("adam", it, p.numel(), K._rel(p, r.detach()))
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "adam":
+    for c in [[1], [3, 64, 1], [4096], [4097, 5], [8192 + 4, 100, 4096 * 3], [128 * 100, 1, 64 * 3 * 9, 3]]:
+        print("adam", c, flush=True)
+        _adam_case_guarded(c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "loss":
     for c in [(1, 1, 1), (7, 3, 5), (64, 64, 1024), (1000, 5, 333), (128 * 25, 64, 3072), (65537, 9, 1027)]:
         print("loss", c, flush=True)
