@@ -172,6 +172,36 @@ def _norm_case_guarded(G, N, HW, C, act):
     assert K._rel(dx, x.grad) < 2e-5, "bwd dx %g" % K._rel(dx, x.grad)
     if G == 1:
         assert K._rel(dg, gamma.grad) < 2e-5 and K._rel(dbt, beta.grad) < 2e-5, "bwd dgamma / dbeta"
+    if G == 1 and N % 2 == 0:
+        # cross-replica form (dp.enable_sync_batchnorm): two equal shards' moments, gathered and Chan-combined, = the statistics of the
+        # whole batch; backward sums of the shards added (the all-reduce) feed the shard-wise apply pass
+        Ph = Pp // 2
+        allm = guarded(torch.full((2, 2, C), float("nan")))
+        for r in range(2):
+            sh = guarded(x.detach().view(2, Ph, C)[r].clone())
+            mom = guarded(torch.full((2 * C,), float("nan")))
+            ws.fill_(float("nan"))
+            assert emu.migan_norm_moments(P(sh), P(mom), mom.data_ptr() + 4 * C, 1, Ph, C, P(ws), nb, None) == 0
+            allm[r] = mom.view(2, C)
+        m2, i2 = guarded(torch.full((C,), float("nan"))), guarded(torch.full((C,), float("nan")))
+        assert emu.migan_norm_sync_finalize(P(allm), 2, Ph, P(m2), P(i2), None, None, None, 0.1, 1e-5, C, None) == 0
+        assert K._rel(m2, mean) < 1e-5 and K._rel(i2, invstd) < 1e-5, "sync statistics"
+        sums = torch.zeros(2 * C)
+        parts = []
+        for r in range(2):
+            sh, gsh = guarded(x.detach().view(2, Ph, C)[r].clone()), guarded(gy.reshape(2, Ph, C)[r].clone())
+            s_r = guarded(torch.full((2 * C,), float("nan")))
+            ws.fill_(float("nan"))
+            assert emu.migan_norm_bwd_sums(P(sh), P(gsh), P(mean), P(invstd), P(gm), P(bt), P(s_r), None, None, 1, Ph, C, act, 0.2, P(ws),
+                                           nb, 0, None) == 0
+            sums += s_r
+            parts.append((sh, gsh))
+        sg = guarded(sums.clone())
+        for r, (sh, gsh) in enumerate(parts):
+            dxr = guarded(torch.full((Ph, C), float("nan")))
+            assert emu.migan_norm_bwd_apply(P(sh), P(gsh), P(dxr), P(mean), P(invstd), P(gm), P(bt), P(sg), 1, Ph, C, act, 0.2, Pp, None,
+                                            None) == 0
+            assert K._rel(dxr, x.grad.view(2, Ph, C)[r]) < 2e-5, ("sync bwd", r, K._rel(dxr, x.grad.view(2, Ph, C)[r]))
     cb = emu.migan_colsum_workspace(N * HW, C)
     cws = guarded(torch.full((max(cb // 4, 4),), float("nan")))
     cs = guarded(torch.full((C,), float("nan")))
