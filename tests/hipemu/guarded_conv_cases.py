@@ -404,7 +404,42 @@ def _adam_case_guarded(sizes):
             assert K._rel(p, r.detach()) < 1e-6, ("adam", it, p.numel(), K._rel(p, r.detach()))
 
 
+def _skinny_case_guarded(M, N, Kk):
+    """The <= 64-row GEMMs of csrc/skinny_mm.hip behind nn.Linear at small batch (wgan_gp.py:46-78): forward NT with bias + LeakyReLU,
+    input gradient NN, weight / bias gradient TN - row counts that are no multiple of the 16-row MFMA tile included (the kernels clamp
+    the row index) - every operand against a guard page, outputs NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(23)
+    P = K._ptr
+    x = torch.randn(M, Kk, generator=g, requires_grad=True)
+    w = (torch.randn(N, Kk, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(N, generator=g, requires_grad=True)
+    y_lin = TF.linear(x, w, b)
+    gy = torch.randn(M, N, generator=g)
+    y_lin.backward(gy)
+    xg, wg, bg, gyg = guarded(x.detach().clone()), guarded(w.detach().clone()), guarded(b.detach().clone()), guarded(gy.clone())
+    if emu.migan_skinny_nt_ok(M, N, Kk):
+        y = guarded(torch.full((M, N), float("nan")))
+        assert emu.migan_skinny_nt(P(xg), P(wg), P(bg), P(y), M, N, Kk, 1, 0.2, None) == 0
+        assert K._rel(y, TF.leaky_relu(y_lin.detach(), 0.2)) < 3e-6, "skinny nt"
+    if emu.migan_skinny_nn_ok(M, N, Kk):
+        dx = guarded(torch.full((M, Kk), float("nan")))
+        assert emu.migan_skinny_nn(P(gyg), P(wg), P(dx), M, N, Kk, None) == 0
+        assert K._rel(dx, x.grad) < 3e-6, "skinny nn"
+    if emu.migan_skinny_tn_ok(M, N, Kk):
+        dw, db = guarded(torch.full((N, Kk), float("nan"))), guarded(torch.full((N,), float("nan")))
+        assert emu.migan_skinny_tn(P(gyg), P(xg), P(dw), P(db), M, N, Kk, 0, 0, None) == 0
+        assert K._rel(dw, w.grad) < 1e-5 and K._rel(db, b.grad) < 1e-5, "skinny tn"
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "skinny":
+    for c in [(1, 16, 64), (7, 32, 128), (64, 512, 1024), (33, 256, 512), (64, 16, 256), (5, 1024, 1024), (64, 1024, 128), (17, 48, 192)]:
+        print("skinny", c, flush=True)
+        _skinny_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "adam":
     for c in [[1], [3, 64, 1], [4096], [4097, 5], [8192 + 4, 100, 4096 * 3], [128 * 100, 1, 64 * 3 * 9, 3]]:
         print("adam", c, flush=True)
