@@ -432,7 +432,51 @@ def _skinny_case_guarded(M, N, Kk):
         assert K._rel(dw, w.grad) < 1e-5 and K._rel(db, b.grad) < 1e-5, "skinny tn"
 
 
+def _norm_prelu_case_guarded(N, H, W, C, shuffle):
+    """BatchNorm2d [PixelShuffle(2)] PReLU of srgan/models.py:23-24,55-57 inside the norm launches (apply with the single PReLU slope and
+    the shuffle as the store index map; backward with the slope's gradient): every operand against a guard page, outputs and workspaces
+    NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(29)
+    P = K._ptr
+    Pp = N * H * W
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).requires_grad_(True), torch.randn(C, generator=g).requires_grad_(True)
+    pw = torch.full((1,), 0.25, requires_grad=True)
+    yb = TF.batch_norm(x, None, None, gamma, beta, True, 0.1, 0.8)
+    y_ref = TF.prelu(TF.pixel_shuffle(yb, 2) if shuffle else yb, pw)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xs = guarded(x.detach().permute(0, 2, 3, 1).contiguous())
+    gm, bt, pg = guarded(gamma.detach().clone()), guarded(beta.detach().clone()), guarded(pw.detach().clone())
+    mean, invstd = guarded(torch.full((C,), float("nan"))), guarded(torch.full((C,), float("nan")))
+    nb = emu.migan_norm_workspace(1, Pp, C)
+    ws = guarded(torch.full((max(nb // 4, 4),), float("nan")))
+    assert emu.migan_norm_stats(P(xs), P(mean), P(invstd), None, None, None, 0.1, 0.8, 1, Pp, C, P(ws), nb, None) == 0
+    sh, sw = (H, W) if shuffle else (0, 0)
+    y = guarded(torch.full(tuple(y_ref.permute(0, 2, 3, 1).shape), float("nan")))
+    assert emu.migan_norm_apply_prelu(P(xs), P(y), P(mean), P(invstd), P(gm), P(bt), None, P(pg), 1, Pp, C, sh, sw, None) == 0
+    assert K._rel(y.permute(0, 3, 1, 2), y_ref.detach()) < 3e-6, ("apply_prelu", K._rel(y.permute(0, 3, 1, 2), y_ref.detach()))
+    nbp = emu.migan_norm_workspace_prelu(1, Pp, C)
+    wsp = guarded(torch.full((max(nbp // 4, 4),), float("nan")))
+    gyn = guarded(gy.permute(0, 2, 3, 1).contiguous())
+    dx = guarded(torch.full((N, H, W, C), float("nan")))
+    dg, dbt, dp = guarded(torch.full((C,), float("nan"))), guarded(torch.full((C,), float("nan"))), guarded(torch.full((4,), float("nan")))
+    assert emu.migan_norm_bwd_prelu(P(xs), P(gyn), P(mean), P(invstd), P(gm), P(bt), P(pg), P(dx), P(dg), P(dbt), P(dp), 1, Pp, C, P(wsp),
+                                    nbp, 0, 0, None, sh, sw, None) == 0
+    assert K._rel(dx.permute(0, 3, 1, 2), x.grad) < 2e-5, ("bwd_prelu dx", K._rel(dx.permute(0, 3, 1, 2), x.grad))
+    assert K._rel(dg, gamma.grad) < 2e-5 and K._rel(dbt, beta.grad) < 2e-5, "bwd_prelu dgamma / dbeta"
+    assert abs(float(dp[0]) - float(pw.grad)) <= 2e-5 * max(1.0, abs(float(pw.grad))), ("dprelu", float(dp[0]), float(pw.grad))
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "norm_prelu":
+    for c in [(2, 6, 6, 64, False), (1, 5, 7, 12, False), (2, 4, 4, 256, True), (1, 3, 5, 8, True), (4, 24, 24, 64, False), (2, 12, 12, 256, True)]:
+        print("norm_prelu", c, flush=True)
+        _norm_prelu_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "skinny":
     for c in [(1, 16, 64), (7, 32, 128), (64, 512, 1024), (33, 256, 512), (64, 16, 256), (5, 1024, 1024), (64, 1024, 128), (17, 48, 192)]:
         print("skinny", c, flush=True)
