@@ -469,7 +469,73 @@ def _norm_prelu_case_guarded(N, H, W, C, shuffle):
     assert abs(float(dp[0]) - float(pw.grad)) <= 2e-5 * max(1.0, abs(float(pw.grad))), ("dprelu", float(dp[0]), float(pw.grad))
 
 
+def _guarded_i64(t):
+    buf = guarded(torch.zeros(2 * t.numel()))
+    out = buf.view(torch.int64)
+    out.copy_(t.reshape(-1))
+    return out
+
+
+def _classify_case_guarded(B, C, D):
+    """csrc/classify.hip behind the DCGAN-block clones (acgan / cgan / infogan ...): softmax and cross entropy over B x C logits with their
+    gradients, the label embedding (V = C rows of D floats) with its scatter-add gradient; plus a weight pack (migan_permute4d) and a
+    dropout-mask draw - every operand against a guard page, outputs NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(31)
+    P = K._ptr
+    x = torch.randn(B, C, generator=g, requires_grad=True)
+    t = torch.randint(0, C, (B,), generator=g)
+    sm = TF.softmax(x, 1)
+    gs = torch.randn(B, C, generator=g)
+    sm.backward(gs)
+    xs, y = guarded(x.detach().clone()), guarded(torch.full((B, C), float("nan")))
+    assert emu.migan_softmax_fwd(P(xs), P(y), B, C, None) == 0
+    assert K._rel(y, sm.detach()) < 2e-6, "softmax"
+    gsg, dx = guarded(gs.clone()), guarded(torch.full((B, C), float("nan")))
+    assert emu.migan_softmax_bwd(P(y), P(gsg), P(dx), B, C, None) == 0
+    assert K._rel(dx, x.grad) < 2e-5, "softmax bwd"
+    x2 = x.detach().clone().requires_grad_(True)
+    ce = TF.cross_entropy(x2, t)
+    ce.backward()
+    tg = _guarded_i64(t)
+    out, ws = guarded(torch.full((4,), float("nan"))), guarded(torch.full((2 * B,), float("nan")))
+    assert emu.migan_cross_entropy_fwd(P(xs), tg.data_ptr(), P(out), P(ws), B, C, None) == 0
+    assert abs(float(out[0]) - float(ce.detach())) <= 2e-6 * max(1.0, abs(float(ce.detach()))), "cross entropy"
+    one, dce = guarded(torch.ones(4)), guarded(torch.full((B, C), float("nan")))
+    assert emu.migan_cross_entropy_bwd(P(xs), tg.data_ptr(), ws.data_ptr() + 4 * B, P(one), P(dce), B, C, None) == 0
+    assert K._rel(dce, x2.grad) < 2e-5, "cross entropy bwd"
+    w = torch.randn(C, D, generator=g, requires_grad=True)
+    e = TF.embedding(t, w)
+    ge = torch.randn(B, D, generator=g)
+    e.backward(ge)
+    wg, ey = guarded(w.detach().clone()), guarded(torch.full((B, D), float("nan")))
+    assert emu.migan_embedding_fwd(P(wg), tg.data_ptr(), P(ey), B, D, C, None) == 0
+    assert torch.equal(ey, e.detach()), "embedding"
+    geg, dw = guarded(ge.clone()), guarded(torch.full((C, D), float("nan")))
+    assert emu.migan_embedding_bwd(P(geg), tg.data_ptr(), P(dw), B, D, C, 0, None) == 0
+    assert K._rel(dw, w.grad) < 1e-5, "embedding bwd"
+    d = (C, D, 3, 3)
+    src = torch.randn(*d, generator=g)
+    sg = guarded(src.clone())
+    for perm in ((0, 2, 3, 1), (1, 2, 3, 0)):
+        dst = guarded(torch.full(tuple(d[q] for q in perm), float("nan")))
+        assert emu.migan_permute4d(P(sg), P(dst), d[0], d[1], d[2], d[3], perm[0], perm[1], perm[2], perm[3], None) == 0
+        assert torch.equal(dst, src.permute(*perm).contiguous()), ("permute4d", perm)
+    n = B * C + 3
+    mk = guarded(torch.full((n,), float("nan")))
+    assert emu.migan_rand_mask(P(mk), n, 0.25, 1234, None, None) == 0
+    vals = set(mk.unique().tolist())
+    assert vals <= {0.0, 1.0 / 0.75} or all(abs(v) < 1e-6 or abs(v - 1 / 0.75) < 1e-6 for v in vals), vals
+
+
 cases = K._gpu_conv_cases() + K.KTAIL_CASES
+if len(sys.argv) > 1 and sys.argv[1] == "classify":
+    for c in [(1, 2, 3), (7, 10, 100), (64, 10, 62), (33, 101, 17), (128, 1000, 5)]:
+        print("classify", c, flush=True)
+        _classify_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "norm_prelu":
     for c in [(2, 6, 6, 64, False), (1, 5, 7, 12, False), (2, 4, 4, 256, True), (1, 3, 5, 8, True), (4, 24, 24, 64, False), (2, 12, 12, 256, True)]:
         print("norm_prelu", c, flush=True)
