@@ -88,8 +88,32 @@ def _drop_asm(text):
 _EXT_SHARED = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w:]*)\s+(\w+)\s*\[\s*\]\s*;")
 
 
+_STATIC_SHARED = re.compile(r"^([ \t]*)__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?[A-Za-z_][\w:]*\s+([^;]+);", re.M)
+
+
+def _poison_static_lds(text):
+    """`__shared__ T a[N], b[M];` -> the same + `hipemu::poison_lds(&a, sizeof(a), &seen_a); ...` on the same line (see hipemu.cpp)."""
+    def rep(m):
+        decl, names = m.group(0), []
+        depth, cur = 0, ""
+        for ch in m.group(2) + ",":
+            if ch == "," and depth == 0:
+                nm = re.match(r"\s*(\w+)", cur)
+                assert nm, "unparsed __shared__ declarator: " + decl
+                names.append(nm.group(1))
+                cur = ""
+                continue
+            depth += {"[": 1, "(": 1, "<": 0, "]": -1, ")": -1}.get(ch, 0)
+            cur += ch
+        calls = "".join(" { static thread_local unsigned long seen_%s = 0; hipemu::poison_lds(&%s, sizeof(%s), &seen_%s); }" % (n, n, n, n)
+                        for n in names)
+        return decl + calls
+    return _STATIC_SHARED.sub(rep, text)
+
+
 def transform(text, origin):
     text = _drop_asm(text)
+    text = _poison_static_lds(text)
     text = _EXT_SHARED.sub(lambda m: "%s* %s = reinterpret_cast<%s*>(hipemu::dyn_lds());" % (m.group(1), m.group(2), m.group(1)), text)
     assert "extern __shared__" not in text, "unhandled dynamic LDS declaration in " + origin
     return '#line 1 "%s"\n' % origin + text

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <cstring>
 #include <vector>
 #include <sys/mman.h>
 
@@ -53,6 +54,7 @@ struct Wave {
     alignas(16) uint32_t slots[2][64 * 8];
 };
 struct Worker {  // per OS thread
+    unsigned long wg_serial = 0;   // workgroups this OS thread has run (poison_lds: static LDS is poisoned once per workgroup)
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
     char* stacks = nullptr;
@@ -183,6 +185,17 @@ const uint32_t* wave_exchange(const uint32_t* mine, int words) {
 
 void* dyn_lds() { return wk->dyn.data(); }
 
+// LDS comes up with whatever the previous workgroup left in it; the model's `static thread_local` arrays would come up ZERO on first use and a
+// kernel that reads a word it never wrote (a K-tail lane, a padding row) would pass here and multiply garbage on the hardware.  With
+// HIPEMU_POISON_LDS=1 (default on) every static LDS array is filled with 0xFF bytes - float / double NaN, int -1 - by the first thread of each
+// workgroup that reaches its declaration (build_emu.py appends the call to the declaration), the dynamic LDS by run_block.
+static const bool poison_on = !(getenv("HIPEMU_POISON_LDS") && atoi(getenv("HIPEMU_POISON_LDS")) == 0);
+void poison_lds(void* p, size_t n, unsigned long* seen) {
+    if (!poison_on || *seen == wk->wg_serial) return;
+    *seen = wk->wg_serial;
+    memset(p, 0xFF, n);
+}
+
 static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
     const size_t nt = (size_t)block.x * block.y * block.z;
     if (w.nstacks < nt) {
@@ -197,6 +210,8 @@ static void run_block(Worker& w, U3 grid, U3 block, U3 bid, size_t lds) {
         w.nstacks = nt;
     }
     if (w.dyn.size() < lds + 64) w.dyn.resize(lds + 64);
+    w.wg_serial += 1;
+    if (poison_on && lds) memset(w.dyn.data(), 0xFF, lds);
     w.fibers.assign(nt, Fiber{});
     const size_t nw = (nt + 63) / 64;
     w.waves.resize(nw);

@@ -45,6 +45,7 @@ void waitcnt_vm(int n);      // s_waitcnt vmcnt(n) for the LDS-DMA queue of this
 void yield();
 void sleep_hint();   // s_sleep: let the other fibers run - and, in a co-resident launch, the other workgroups' OS threads
 void* dyn_lds();
+void poison_lds(void* p, size_t n, unsigned long* seen);
 // wave rendezvous: publish `words` 32-bit words, wait for every live lane of the wave, return the wave's slot array
 // ([64][8] words) of this exchange; valid until this lane's next exchange.
 const uint32_t* wave_exchange(const uint32_t* mine, int words);

@@ -784,7 +784,8 @@ def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):
     assert lib.migan_conv2d_fwd_ws(_ptr(x), _ptr(w), None, None, _ptr(y), 1, 4, 4, 512, 2, 2, 512, 4, 4, 2, 1, 1, 0, 0, 0.0, _ptr(sk),
                                    sk.numel() * 4, None) == 0
     ref = TF.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), None, 2, 1)
-    assert _rel(y.permute(0, 3, 1, 2), ref) > 1e-2, "the model did not notice a stage read before it was waited for"
+    err = _rel(y.permute(0, 3, 1, 2), ref)   # NaN since the model poisons LDS (the stage that has not landed holds 0xFF bytes), else large
+    assert not (err <= 1e-2), "the model did not notice a stage read before it was waited for"
 
 
 def test_a_deadlock_is_reported_not_hung(emu, tmp_path):
