@@ -57,7 +57,8 @@ def _conv_case_guarded(case):
             rc = emu.migan_conv2d_dgrad_relu_ws(P(gy), P(wi), P(dxr), P(ro), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], P(sk), sk.numel() * 4, None)
             assert rc in (0, 801), rc
             if rc == 0:
-                assert torch.equal(dxr, torch.where(ro > 0, dx, torch.zeros(()))), 'dgrad with the ReLU mask epilogue'
+                want = torch.where(ro > 0, dx, torch.zeros(()))   # (bit-equal when both launches are the LDS-DMA kernel; MIGAN_DMA=0 runs the
+                assert torch.equal(dxr == 0, want == 0) and K._rel(dxr, want) < 3e-6, 'dgrad with the ReLU mask epilogue'   # plain launch on the other family)
         wsb = emu.migan_conv2d_wgrad_workspace(N, Ho, Wo, Co, k, k, Ci)
         ws = guarded(torch.full((max(wsb // 4, 4),), float("nan"))); dw = guarded(torch.full((Co, Ci, k, k), float("nan")))
         assert emu.migan_conv2d_wgrad(P(xn), P(gy), P(dw), P(ws), wsb, N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, 0, None, 0, None, 0, None) == 0

@@ -250,6 +250,17 @@ def test_no_conv_kernel_leaves_its_tensors(emu):
     assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
 
 
+def test_register_staged_conv_kernels_stay_inside_their_tensors(emu):
+    """The same with MIGAN_DMA=0 MIGAN_DMA_WGRAD=0: every geometry on the register-staged family (igemm_pipe_kernel, wgrad_inc_kernel,
+    wgrad_pipe_kernel) - the shipped alternative of the LDS-DMA kernels and what serves the geometries those decline."""
+    import subprocess
+
+    script = os.path.join(os.path.dirname(os.path.abspath(hipemu.__file__)), "guarded_conv_cases.py")
+    env = dict(os.environ, MIGAN_DMA="0", MIGAN_DMA_WGRAD="0")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_fewpix_kernels_stay_inside_their_tensors(emu):
     """The same for csrc/fewpix.hip: im2col / col2im and the three skinny GEMM forms at few-pixel-conv sizes, every operand
     against an inaccessible page, NaN-filled outputs, results against torch."""
