@@ -709,10 +709,22 @@ def test_abi_check_harness_on_the_execution_model(emu, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run(["bash", os.path.join(root, "tools", "build_abi_check.sh"), "host"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
+    import re
+
     sections = ["norm", "mlp", "critic"]
+    digests = {}
     for sec in sections:
         r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK") and "FAIL" not in r.stdout, (sec, r.stdout[-1500:], r.stderr[-400:])
+        digests[sec] = re.findall(r"digest ([0-9a-f]{16})", r.stdout)
+    assert len(digests["mlp"]) == 2 and len(digests["critic"]) == 1, digests
+    # the ticketed BatchNorm1d hand-offs and the K-slice reductions of the fused kernels: waves in reverse order, workgroups on 3 OS
+    # threads (other arrival orders at the tickets) - bit-identical outputs, losses and gradients
+    env = dict(os.environ, HIPEMU_SCHED="rev", HIPEMU_THREADS="3")
+    for sec in ("mlp", "critic"):
+        r = subprocess.run(["/tmp/abi_check_host", sec], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (sec, r.stdout[-1500:], r.stderr[-400:])
+        assert re.findall(r"digest ([0-9a-f]{16})", r.stdout) == digests[sec], (sec, "results depend on the wave schedule / arrival order")
 
 
 def test_smoke_body_on_the_execution_model(emu, capsys):

@@ -44,6 +44,8 @@ static inline hipError_t hipEventRecord(hipEvent_t e, int) { *e = std::chrono::s
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(*b - *a).count(); return 0; }
 extern "C" void hipemu_add_coresident_kernel(const char* substr);   // kernels with grid-wide barriers: one OS thread per workgroup
+extern "C" void hipemu_set_wave_schedule(int mode, unsigned seed);  // order of a workgroup's waves between synchronisation points
+extern "C" void hipemu_set_threads(int n);                          // OS threads the workgroups of a launch are spread over
 extern "C" const char* hipemu_last_message();
 #endif
 
@@ -154,6 +156,11 @@ static float train_us(const std::function<void()>& f, int n = 20) {
     return best;
 }
 static int failures = 0;
+// FNV-1a over the bit patterns: equal digests = bit-identical results (the execution-model runs compare them across wave schedules)
+static unsigned long long digest(const std::vector<float>& v, unsigned long long h = 1469598103934665603ull) {
+    for (float f : v) { unsigned u; memcpy(&u, &f, 4); for (int b = 0; b < 4; ++b) { h ^= (u >> (8 * b)) & 0xff; h *= 1099511628211ull; } }
+    return h;
+}
 static void report(const char* what, const char* kernel, double r, double tol, float us_new, float us_old, double mbytes = 0) {
     const bool ok = r <= tol;
     if (!ok) ++failures;
@@ -254,6 +261,9 @@ static void critic_case(int B, int Din, int H1, int H2) {
         const double e = std::max(std::fabs(ho[2] - mr), std::fabs(ho[3] - mf)) / std::max(1.0, std::fabs(mr));
         const bool ok = fin && e <= 1e-4;
         if (!ok) ++failures;
+        unsigned long long dg = digest(ho);
+        for (Buf* gbuf : {&gw1, &gb1, &gw2, &gb2, &gw3, &gb3}) dg = digest(gbuf->host(), dg);
+        printf("critic_fused gradients + losses digest %016llx\n", dg);
         printf("critic_fused B%d %d-%d-%d  d_loss %.6g gp %.6g  |mean D - fp64| %.1e  %s  single call between events %8.1f us\n", B, Din, H1, H2, ho[0],
                ho[1], e, ok ? "ok" : "FAIL", time_us([&] { run(0); }));
         printf("critic_fused, 20 calls back to back: %.1f us per call (6 launches)\n", train_us([&] { run(0); }));
@@ -334,8 +344,8 @@ static void mlp_case(int B) {
         const double r = rel(y.host(), ref);
         const bool ok = r <= 1e-5;
         if (!ok) ++failures;
-        printf("mlp_fused_fwd B%d 100-128-256-512-1024-1024  rel vs fp64 %.2e  %s  single call between events %8.1f us\n", B, r, ok ? "ok" : "FAIL",
-               time_us(run));
+        printf("mlp_fused_fwd B%d 100-128-256-512-1024-1024  rel vs fp64 %.2e  %s  digest %016llx  single call between events %8.1f us\n", B, r,
+               ok ? "ok" : "FAIL", digest(y.host()), time_us(run));
         fflush(stdout);
     }
     {
@@ -373,10 +383,11 @@ static void mlp_case(int B) {
         CK(hipDeviceSynchronize());
         bool fin = true;
         double asum = 0;
-        for (Buf* g : gk) for (float v : g->host()) { fin = fin && std::isfinite(v); asum += std::fabs(v); }
+        unsigned long long dg = 1469598103934665603ull;
+        for (Buf* g : gk) { const auto hv = g->host(); dg = digest(hv, dg); for (float v : hv) { fin = fin && std::isfinite(v); asum += std::fabs(v); } }
         if (!fin || asum == 0) ++failures;
-        printf("mlp_fused_bwd B%d  gradients finite %s (sum |g| %.4g)  20 calls back to back: %.1f us per call\n", B, fin ? "ok" : "FAIL", asum,
-               train_us([&] { bwd(0); }));
+        printf("mlp_fused_bwd B%d  gradients finite %s (sum |g| %.4g)  digest %016llx  20 calls back to back: %.1f us per call\n", B,
+               fin ? "ok" : "FAIL", asum, dg, train_us([&] { bwd(0); }));
         printf("mlp_fused_bwd per phase:  top %.1f us", train_us([&] { bwd(1); }));
         for (int ph = 1; ph < L; ++ph) printf("  chain l%d (%d<-%d) %.1f us", L - ph, K[L - ph], Nn[L - ph], train_us([&] { bwd(1 + ph); }));
         printf("  gradients %.1f us\n", train_us([&] { bwd(L + 2); }));
@@ -391,6 +402,15 @@ static void mlp_case(int B) {
 int main(int argc, char** argv) {
     int dev = 0;
 #ifdef ABI_CHECK_HOST
+    // HIPEMU_SCHED=fwd|rev|rand[:seed], HIPEMU_THREADS=n: the ticketed hand-offs and K-slice reductions must give the same numbers in
+    // every wave order and workgroup arrival order (tests/test_kernels_emu_cpu.py runs the sections under several)
+    if (const char* e = getenv("HIPEMU_SCHED")) {
+        const std::string v = e;
+        const size_t c = v.find(':');
+        const std::string m = v.substr(0, c);
+        hipemu_set_wave_schedule(m == "rev" ? 1 : m == "rand" ? 2 : 0, c == std::string::npos ? 1u : (unsigned)atoi(v.c_str() + c + 1));
+    }
+    if (const char* e = getenv("HIPEMU_THREADS")) hipemu_set_threads(atoi(e));
 #endif
     CK(hipSetDevice(dev));
     hipDeviceProp_t p;
