@@ -53,6 +53,7 @@ extern "C" const char* hipemu_last_message();
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
