@@ -710,7 +710,11 @@ def test_abi_check_harness_on_the_execution_model(emu, tmp_path):
     r = subprocess.run(["bash", os.path.join(root, "tools", "build_abi_check.sh"), "host"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-800:]
     import re
+    import shutil
 
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):   # the program's HIP form must keep compiling too (no GPU needed)
+        r = subprocess.run(["bash", os.path.join(root, "tools", "build_abi_check.sh")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "built tools/abi_check.bin" in r.stdout, r.stdout[-400:] + r.stderr[-1200:]
     sections = ["norm", "mlp", "critic"]
     digests = {}
     for sec in sections:
