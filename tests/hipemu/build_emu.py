@@ -26,7 +26,10 @@ CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=fast", "-fvisibility=hidden", "-pthread", "-w",
          "-I", os.path.join(HERE, "include"), "-I", CSRC, "-DHIPEMU=1",
          # grid-barrier spin bounds of the persistent kernels: workgroups are OS threads here, possibly on a loaded machine
-         "-DCF_SPIN_LIMIT=(1u<<26)", "-DMF_SPIN_LIMIT=(1u<<26)"]
+         "-DCF_SPIN_LIMIT=(1u<<26)", "-DMF_SPIN_LIMIT=(1u<<26)",
+         # the kernel sources do not include the public header: here every extern "C" definition is compiled AGAINST its prototype in
+         # include/migan.h ("conflicting types" when the two drift) - the header is what INTEGRATION.md tells a maintainer to bind
+         "-include", os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "migan.h")]
 
 
 def sources():

@@ -153,3 +153,49 @@ def test_thin_toeplitz_applicability():
     assert lib.migan_thin_toeplitz_ok(8, 7, 7, 64, 1, 0) == 0
     assert lib.migan_thin_toeplitz_cols(3, 9) == 28 and lib.migan_thin_toeplitz_cols(3, 7) == 24
     assert lib.migan_thin_toeplitz_workspace(16, 384, 384, 3, 9) == 16 * 384 * 384 * 28 * 4
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/migan.h against the argtypes / restype table the host mirror calls through (pytorch_gan_amd/_lib.py):
+    same parameter count, and per parameter the same class - pointer, int, float, size_t, (unsigned) long long.  A drift here is silent
+    on the GPU: ctypes passes what the table says, the kernel launcher reads what the prototype says."""
+    import ctypes
+
+    from pytorch_gan_amd import _lib
+
+    src = open(os.path.join(ROOT, "include", "migan.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"([A-Za-z_][\w \*]*?)\b(migan_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src)
+    assert len(protos) >= 100, len(protos)
+
+    def cls(decl):
+        d = decl.strip()
+        if "*" in d:
+            return "ptr"
+        d = re.sub(r"\b\w+$", "", d).strip() if len(d.split()) > 1 else d   # drop the parameter name
+        d = d.replace("const", "").strip()
+        return {"int": "int", "float": "float", "size_t": "size_t", "long long": "longlong", "unsigned long long": "ulonglong",
+                "long": "long", "unsigned": "uint", "unsigned int": "uint", "void": "void"}[d]
+
+    def ccls(t):
+        if t is None:
+            return "void"
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_size_t: "size_t", ctypes.c_longlong: "longlong",
+                ctypes.c_ulonglong: "ulonglong", ctypes.c_long: "long", ctypes.c_uint: "uint"}[t]
+
+    # on this ABI size_t and unsigned long long are the same register class, as are long and long long: equal for the call
+    same = {"size_t": "u64", "ulonglong": "u64", "long": "i64", "longlong": "i64"}
+    checked = 0
+    for ret, name, params in protos:
+        fn = getattr(_lib.lib, name)
+        want = [] if params.strip() in ("", "void") else [cls(p) for p in params.split(",")]
+        got = [ccls(t) for t in (fn.argtypes or [])]
+        assert len(want) == len(got), (name, len(want), len(got))
+        for i, (a, b) in enumerate(zip(want, got)):
+            assert same.get(a, a) == same.get(b, b), (name, i, a, b)
+        r_want, r_got = cls(ret + " x") if "*" not in ret else "ptr", ccls(fn.restype)
+        assert same.get(r_want, r_want) == same.get(r_got, r_got), (name, "return", r_want, r_got)
+        checked += 1
+    assert checked == len(_lib.EXPORTS), (checked, len(_lib.EXPORTS))
