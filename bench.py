@@ -132,10 +132,13 @@ def build_dcgan(dp, rank, dev, args, nsteps, ch=None):
         dp.broadcast_parameters(G, D)
     state = steps.make_gan_state(G, D, LATENT, skip_dead_grads=True, dp=dp)
     batch = args.batch or BATCH
-    rng = np.random.RandomState(1234 + rank)
-    real = torch.from_numpy(rng.uniform(-1, 1, (batch, ch, IMG, IMG)).astype(np.float32)).to(dev)
+    # SURVEY.md 8e "Partitioning": ONE globally seeded draw of the global batch (and of every step's z), sliced by rank - an N-rank
+    # run consumes the random numbers the single-process run of the global batch consumes
+    rng = np.random.RandomState(1234)
+    lo, hi = rank * batch, (rank + 1) * batch
+    real = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, ch, IMG, IMG)).astype(np.float32)[lo:hi]).to(dev)
     nz = min(nsteps, 64) + 8
-    zs = torch.from_numpy(rng.normal(0, 1, (nz, batch, LATENT)).astype(np.float32)).to(dev)
+    zs = torch.from_numpy(rng.normal(0, 1, (nz, dp.world * batch, LATENT)).astype(np.float32)[:, lo:hi].copy()).to(dev)
     z_static = zs[0].clone()
     runner = gmod.StepRunner(lambda: steps.dcgan_step(state, real, z_static), dp, use_graph=not args.no_graph)
     runner.prepare()
@@ -168,16 +171,10 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
         dp.broadcast_parameters(*nets)
     state = steps.make_cyclegan_state(*nets, dp=dp)
     batch = args.batch or 8
-    rng = np.random.RandomState(4321 + rank)
-    a = torch.from_numpy(rng.uniform(-1, 1, (batch, *shape)).astype(np.float32)).to(dev)
-    b = torch.from_numpy(rng.uniform(-1, 1, (batch, *shape)).astype(np.float32)).to(dev)
-
-    def run(i):   # eager: the replay buffer draws from the host RNG between the generator and discriminator phases
-        dp.begin_step()
-        out = steps.cyclegan_step(state, a, b)
-        dp.end_step()
-        return out
-
+    rng = np.random.RandomState(4321)   # one global draw, sliced by rank
+    lo, hi = rank * batch, (rank + 1) * batch
+    a = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, *shape)).astype(np.float32)[lo:hi]).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, *shape)).astype(np.float32)[lo:hi]).to(dev)
     # replay buffers warm (>= 50 entries) before timing, so the picks and clones of the timed steps are
     # those of a run in steady state.  The histories are filled with generator outputs under no_grad - no training step, no
     # collective: at --global-batch 2 the former 50 warm-up STEPS each moved 113 MB of gradients through gloo (the two-rank
@@ -186,7 +183,10 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
         while len(state.buf_A) < state.buf_A.max_size:
             state.buf_A.push_and_pop(state.G_BA(b))
             state.buf_B.push_and_pop(state.G_AB(a))
-    w = Workload("cyclegan", batch, run, state, None, False, None, tuple(nets))
+    # the recorded step: the replay buffers' host draws (python `random`, the reference's order) happen in front of every replay
+    # into static device tables (steps.CycleGanRunner); --no-graph launches the same step eagerly
+    runner = steps.CycleGanRunner(state, a, b, use_graph=not args.no_graph, warmup=1).prepare()
+    w = Workload("cyclegan", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)
     return w
 
@@ -201,9 +201,10 @@ def build_srgan(dp, rank, dev, args, nsteps):
         dp.broadcast_parameters(G, D, V)
     state = steps.make_srgan_state(G, D, V, dp=dp)
     batch = args.batch or 16
-    g = torch.Generator().manual_seed(99 + rank)
-    lr = torch.randn(batch, 3, 96, 96, generator=g).to(dev)
-    hr = torch.randn(batch, 3, 384, 384, generator=g).to(dev)
+    g = torch.Generator().manual_seed(99)   # one global draw, sliced by rank
+    lo, hi = rank * batch, (rank + 1) * batch
+    lr = torch.randn(dp.world * batch, 3, 96, 96, generator=g)[lo:hi].to(dev)
+    hr = torch.randn(dp.world * batch, 3, 384, 384, generator=g)[lo:hi].to(dev)
 
     def run(i):
         dp.begin_step()
@@ -226,9 +227,10 @@ def build_esrgan(dp, rank, dev, args, nsteps):
         dp.broadcast_parameters(G, D, V)
     state = steps.make_esrgan_state(G, D, V, dp=dp, warmup_batches=0)  # timed steps are the full relativistic step
     batch = args.batch or 4
-    g = torch.Generator().manual_seed(99 + rank)
-    lr = torch.randn(batch, 3, 64, 64, generator=g).to(dev)
-    hr = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
+    g = torch.Generator().manual_seed(99)
+    lo, hi = rank * batch, (rank + 1) * batch
+    lr = torch.randn(dp.world * batch, 3, 64, 64, generator=g)[lo:hi].to(dev)
+    hr = torch.randn(dp.world * batch, 3, 256, 256, generator=g)[lo:hi].to(dev)
 
     def run(i):
         dp.begin_step()
@@ -250,10 +252,11 @@ def build_wgan_gp(dp, rank, dev, args, nsteps):
         dp.broadcast_parameters(G, D)
     state = steps.make_wgan_gp_state(G, D, dp=dp)
     batch = args.batch or 64
-    rng = np.random.RandomState(777 + rank)
-    real = torch.from_numpy(rng.uniform(-1, 1, (batch, 1, 32, 32)).astype(np.float32)).to(dev)
-    zs = torch.from_numpy(rng.normal(0, 1, (64, batch, 100)).astype(np.float32)).to(dev)
-    alphas = torch.from_numpy(rng.random_sample((64, batch, 1, 1, 1)).astype(np.float32)).to(dev)
+    rng = np.random.RandomState(777)
+    lo, hi = rank * batch, (rank + 1) * batch
+    real = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, 1, 32, 32)).astype(np.float32)[lo:hi]).to(dev)
+    zs = torch.from_numpy(rng.normal(0, 1, (64, dp.world * batch, 100)).astype(np.float32)[:, lo:hi].copy()).to(dev)
+    alphas = torch.from_numpy(rng.random_sample((64, dp.world * batch, 1, 1, 1)).astype(np.float32)[:, lo:hi].copy()).to(dev)
     runner = steps.WganGpRunner(state, batch, (1, 32, 32), use_graph=not args.no_graph).prepare(real, zs[0], alphas[0])
     za = torch.cat([zs.reshape(64, -1), alphas.reshape(64, -1)], 1).contiguous()   # the draws of an iteration, packed: one staging copy
 
@@ -278,9 +281,10 @@ def build_pix2pix(dp, rank, dev, args, nsteps):
         dp.broadcast_parameters(G, D)
     state = steps.make_pix2pix_state(G, D, 256, dp=dp)
     batch = args.batch or 1
-    rng = np.random.RandomState(555 + rank)
-    a = torch.from_numpy(rng.uniform(-1, 1, (batch, 3, 256, 256)).astype(np.float32)).to(dev)
-    b = torch.from_numpy(rng.uniform(-1, 1, (batch, 3, 256, 256)).astype(np.float32)).to(dev)
+    rng = np.random.RandomState(555)
+    lo, hi = rank * batch, (rank + 1) * batch
+    a = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, 3, 256, 256)).astype(np.float32)[lo:hi]).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, (dp.world * batch, 3, 256, 256)).astype(np.float32)[lo:hi]).to(dev)
     runner = gmod.StepRunner(lambda: steps.pix2pix_step(state, a, b), dp, use_graph=not args.no_graph).prepare()
     w = Workload("pix2pix", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, (G, D))
     w.eager = lambda: steps.pix2pix_step(state, a, b)
@@ -602,6 +606,62 @@ def cpu_baseline(init, seconds_budget=25.0):
                       % (n, BATCH, IMG, IMG, el, threads)}
 
 
+def cpu_baseline_extra(name, seconds_budget=12.0):
+    """The oracle's step of one of the other BASELINE configs on this box's host cores, on a BOUNDED sample: a reduced batch where a
+    full-batch step alone would take minutes (stated in `sample`); images/s scales with the batch on a CPU, so the figure is
+    comparable per image.  A reported baseline, not a target."""
+    import random as _random
+
+    from oracle import reference_steps as S
+
+    torch.manual_seed(1)
+    np.random.seed(1)
+    _random.seed(1)
+    threads = torch.get_num_threads()
+    if name == "cyclegan":
+        bs, s = 1, S.make_cyclegan((3, 256, 256), 9)
+        a, b = torch.rand(bs, 3, 256, 256) * 2 - 1, torch.rand(bs, 3, 256, 256) * 2 - 1
+        step, what, warm = (lambda: S.cyclegan_step(s, a, b)), "cyclegan 256x256, 9 blocks, batch 1 of the config's 8", 0
+    elif name == "srgan":
+        bs, s = 2, S.make_srgan((384, 384), 16)
+        lr, hr = torch.randn(bs, 3, 96, 96), torch.randn(bs, 3, 384, 384)
+        step, what, warm = (lambda: S.srgan_step(s, lr, hr)), "srgan 96->384 incl. VGG19[:18], batch 2 of the config's 16", 0
+    elif name == "pix2pix":
+        bs, s = 1, S.make_pix2pix(256)
+        a, b = torch.rand(bs, 3, 256, 256) * 2 - 1, torch.rand(bs, 3, 256, 256) * 2 - 1
+        step, what, warm = (lambda: S.pix2pix_step(s, a, b)), "pix2pix 256x256 batch 1 (the config's)", 1
+    elif name == "wgan_gp":
+        bs, s = 64, S.make_wgan_gp(32)
+        real = torch.rand(bs, 1, 32, 32) * 2 - 1
+        it = [0]
+
+        def step():
+            it[0] += 1
+            return S.wgan_gp_step(s, real, it[0])
+
+        what, warm = "wgan_gp 32x32 batch 64 critic iterations (generator update every 5th)", 5
+    else:
+        return None
+    for _ in range(warm):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 200:
+            break
+    return {"value": round(bs * n / el, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d oracle step(s) of %s after %d warm-up, %.1f s, torch CPU fp32, %d threads" % (n, what, warm, el, threads)}
+
+
+def _safe_cpu_baseline_extra(name):
+    try:
+        return cpu_baseline_extra(name)
+    except Exception as ex:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+
+
 def _safe_cpu_baseline(init):
     try:
         return cpu_baseline(init)
@@ -609,22 +669,45 @@ def _safe_cpu_baseline(init):
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
-def run_extra(other, k, wu, dp, rank, dev, args):
-    """One of the other BASELINE configs, briefly (headline section only), after the headline workload has been released."""
+def run_extra(other, k, wu, dp, rank, dev, args, batch=0, eager_too=False):
+    """One of the other BASELINE configs, briefly (headline section only), after the headline workload has been released.
+    `batch`: per-GPU batch other than the config's (cyclegan at 1 image per GPU = the shard of the 8-GPU configuration);
+    `eager_too`: also time the same step launched one kernel at a time, and count its launches."""
     w = None
     try:
         ns = argparse.Namespace(**vars(args))
-        ns.batch = 0
+        ns.batch = batch
         w = BUILDERS[other](dp, rank, dev, ns, wu + k)
         torch.cuda.reset_peak_memory_stats()
         blocks, out = timed_blocks(w, 1, dev, k, wu, 2.0, max_blocks=20)
         summ = summarise(other, w.batch, 1, k, blocks)
-        return {"images_per_s": summ["images_per_s"], "ms_per_step": summ["ms_per_step"], "ms_per_step_min": summ["ms_per_step_min"],
-                "ms_per_step_max": summ["ms_per_step_max"], "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
-                "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
-                "workload": WORKLOAD_NAME[other], "steps": k, "warmup": wu, "hipgraph": w.graphed,
-                "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                "losses": {kk: float(v) for kk, v in out.items() if "loss" in kk}}
+        res = {"images_per_s": summ["images_per_s"], "ms_per_step": summ["ms_per_step"], "ms_per_step_min": summ["ms_per_step_min"],
+               "ms_per_step_max": summ["ms_per_step_max"], "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
+               "step_executed_frac": summ["step_executed_frac"], "step_dense_frac": summ["step_dense_frac"],
+               "workload": WORKLOAD_NAME[other] if not batch else "%s - at batch %d per GPU" % (WORKLOAD_NAME[other], batch),
+               "steps": k, "warmup": wu, "hipgraph": w.graphed,
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+               "losses": {kk: float(v) for kk, v in out.items() if "loss" in kk}}
+        if w.capture_error:
+            res["hipgraph_error"] = w.capture_error[:200]
+        if eager_too:
+            from pytorch_gan_amd._lib import lib
+
+            def eager_step(i):
+                dp.begin_step()
+                o = w.eager()
+                dp.end_step()
+                return o
+
+            eager_step(0)
+            torch.cuda.synchronize()
+            n0 = lib.migan_debug_launch_count(None)
+            eager_step(1)
+            res["library_launches_per_step"] = int(lib.migan_debug_launch_count(None) - n0)
+            we = Workload(other, w.batch, eager_step, w.state)
+            eb, _ = timed_blocks(we, 1, dev, k, 1, 1.0, max_blocks=10)
+            res["eager_ms_per_step"] = round(1e3 * float(np.median(eb)) / k, 4)
+        return res
     except Exception as ex:  # noqa: BLE001 - the headline line must survive a failure of an extra
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     finally:
@@ -663,6 +746,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the brief runs of the other BASELINE configs (N=1)")
+    ap.add_argument("--dp-order", default="", choices=["", "sequential", "fork"],
+                    help="N>1: 'sequential' (default) = the reference's order, the generator bucket's all-reduce + Adam run on the side "
+                         "stream UNDER the discriminator phase; 'fork' = the single-GPU body (discriminator update underneath the "
+                         "generator's backward, exchanges behind the join) - A/B on the 8-GPU node")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: BatchNorm statistics over the global batch (the reference's single-process semantics)")
     args = ap.parse_args()
@@ -707,6 +794,10 @@ def main():
         dp.enable_sync_batchnorm()
 
     name = args.workload
+    if args.dp_order:
+        from pytorch_gan_amd import steps as _steps
+
+        _steps.set_dp_order(args.dp_order)
     if args.no_overlap:
         from pytorch_gan_amd import functional as _F
         from pytorch_gan_amd import steps as _steps
@@ -730,6 +821,14 @@ def main():
         print(json.dumps({"pmc_log": args.pmc_log, "segments": len(segs), "total_launches": lib.migan_debug_launch_count(None)}))
         return
     blocks, out = timed_blocks(w, world, dev, args.steps, args.warmup, args.min_seconds, max_blocks=args.max_blocks)
+    exchange = None
+    if world > 1 and hasattr(dp, "start_timing"):
+        # what the exchange costs and how much of it the overlap hides: HIP events around every bucket all-reduce (side stream) and
+        # around every wait of the main stream for an update in flight, over one more block of --steps steps (not the timed ones)
+        dp.start_timing()
+        for i in range(args.steps):
+            w.run(i)
+        exchange = dp.timing_report(args.steps)
     losses = {k: float(v) for k, v in out.items() if "loss" in k}
     if not all(np.isfinite(v) for v in losses.values()):
         raise SystemExit("non-finite loss in the timed region: %s" % losses)
@@ -742,8 +841,10 @@ def main():
                    "hipgraph": w.graphed, "gflop_per_image": round(GFLOP_PER_IMG[name], 4),
                    "executed_gflop_per_image": round(executed_gflop_per_image(name), 4),
                    "sync_batchnorm": bool(args.sync_bn and world > 1),
-                   "streams": "discriminator update on a second HIP stream underneath the generator's backward" if not args.no_overlap
-                   and not (args.sync_bn and world > 1) and name not in ("wgan_gp", "esrgan") else "one"},
+                   "streams": ("one" if args.no_overlap or (args.sync_bn and world > 1) or name in ("wgan_gp", "esrgan") else
+                               "discriminator update on a second HIP stream underneath the generator's backward"
+                               if world == 1 or args.dp_order == "fork" or os.environ.get("MIGAN_DP_ORDER") == "fork" else
+                               "reference order: generator exchange + Adam on the data-parallel side stream under the discriminator phase")},
         "timing": {"rule": "median over blocks of exactly --steps steps, each bracketed by barrier+synchronize, MAX over ranks",
                    "blocks": summ["blocks"], "timed_seconds": summ["timed_seconds"],
                    "ms_per_step_min": summ["ms_per_step_min"], "ms_per_step_max": summ["ms_per_step_max"],
@@ -766,7 +867,17 @@ def main():
                 result["roofline_hbm"] = rf.pop("hbm")
             result["roofline"] = rf
     if world > 1:
+        from pytorch_gan_amd import steps as _steps
+
         result["config"]["replicas_identical"] = replicas_identical(w, world, dev)
+        result["config"]["rccl_ranks"] = world
+        result["config"]["backend"] = torch.distributed.get_backend()
+        result["config"]["dp_order"] = _steps._DP_ORDER
+        result["config"]["bucket_bytes"] = {k: int(getattr(w.state, k).flat_grad.numel() * 4) for k in sorted(vars(w.state))
+                                            if k.startswith("opt_") and hasattr(getattr(w.state, k), "flat_grad")}
+        result["config"]["batch_slicing"] = "one globally seeded draw of the global batch, sliced by rank"
+        if exchange:
+            result["exchange"] = exchange
     if rank == 0 and world == 1 and name == "dcgan" and not args.no_extra:
         # the other GPU configs of BASELINE.json, briefly (north_star names CycleGAN 256x256 bs 8 as the second target)
         init = w.init
@@ -777,6 +888,11 @@ def main():
         extra = result["extra"] = {}
         for other, k, wu in (("cyclegan", 4, 3), ("srgan", 4, 3), ("wgan_gp", 100, 10), ("dcgan_ch3", 50, 5), ("pix2pix", 50, 5)):
             extra[other] = run_extra(other, k, wu, dp, rank, dev, args)
+            if not args.no_cpu_baseline and other != "dcgan_ch3" and "error" not in extra[other]:
+                extra[other]["cpu_baseline"] = _safe_cpu_baseline_extra(other)
+        # config 4's per-GPU shard at N = 8: one image per GPU (= the reference's default batch, cyclegan.py:28) - the recorded step
+        # beside the same step launched kernel by kernel
+        extra["cyclegan_bs1"] = run_extra("cyclegan", 10, 3, dp, rank, dev, args, batch=1, eager_too=True)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
     if rank == 0:

@@ -387,7 +387,8 @@ int migan_maxpool2_relu_bwd(const float* x, const float* dy, float* dx, int N, i
 /* torch.cat((a,b),1) pix2pix/models.py:50,132 (forward=1) and its backward split (forward=0). */
 int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca, int Cb, int forward, void* stream);
 /* dst[dst_row ? dst_row[k] : k][:] = sel[k] >= 0 ? a[sel[k]][:] : b[-1 - sel[k]][:], rows of D floats (D % 4 == 0);
- * sel / dst_row: device int32 [n].  The device-resident image history of cyclegan/utils.py:13-33 (ReplayBuffer):
+ * sel / dst_row: device int32 [n]; a row with dst_row[k] < 0 is skipped (padding of a fixed-length table: a recorded hipGraph
+ * launches n = batch rows every step).  The device-resident image history of cyclegan/utils.py:13-33 (ReplayBuffer):
  * one launch assembles the returned batch from old pool entries and new samples, one writes the new samples into the
  * pool. */
 int migan_select_rows(const float* a, const float* b, float* dst, const int* sel, const int* dst_row, int n, size_t D,

@@ -591,14 +591,16 @@ __global__ void select_rows_kernel(const float* __restrict__ a, const float* __r
     const int k = blockIdx.y;
     const int sidx = sel[k];
     const float* src = sidx >= 0 ? a + (size_t)sidx * D : b + (size_t)(-1 - sidx) * D;
-    float* out = dst + (size_t)(dst_row ? dst_row[k] : k) * D;
+    const int drow = dst_row ? dst_row[k] : k;
+    if (drow < 0) return;  // padding entry of a fixed-length table (a recorded hipGraph launches n = batch rows every step)
+    float* out = dst + (size_t)drow * D;
     const size_t n4 = D / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
         reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(src)[i];
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < D; i += (size_t)gridDim.x * blockDim.x)
         out[i] = src[i];
 }
-// n rows; sel / dst_row are device int32 arrays (dst_row NULL: dst row k).  Rows must be 16-byte aligned (D % 4 == 0 or
+// n rows; sel / dst_row are device int32 arrays (dst_row NULL: dst row k; dst_row[k] < 0: row k is skipped).  Rows must be 16-byte aligned (D % 4 == 0 or
 // the scalar tail path handles the remainder only when the row starts are aligned, i.e. D % 4 == 0 for row > 0).
 MIGAN_API int migan_select_rows(const float* a, const float* b, float* dst, const int* sel, const int* dst_row, int n,
                                 size_t D, void* stream) {

@@ -55,6 +55,7 @@ class DataParallel:
         self.sync_bn = None
         self._pending = []      # optimisers with an update in flight on the side stream (event in opt.pending)
         self._segmenter = None  # set by graph.StepRunner while it records the step
+        self.timing = None      # start_timing(): event pairs around every exchange (side stream) and every wait of the main stream
 
     # -- per-step protocol -------------------------------------------------------------------------
     # Ordering rule: `step(opt)` returns while the all-reduce + Adam of `opt` may still run on the side stream.  The
@@ -93,7 +94,13 @@ class DataParallel:
         ready.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
             dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.timing is not None:
+                e1.record(self.side)
+                self.timing["exchange"].append((e0, e1, opt.flat_grad.numel() * 4))
             opt.step(grad_scale=scale)
             done = torch.cuda.Event()
             done.record(self.side)
@@ -108,7 +115,37 @@ class DataParallel:
             return
         self._wait_now(opt)
 
+    def start_timing(self):
+        """From now on: HIP-event pairs around every bucket all-reduce (on the side stream) and around every wait of the main stream
+        for an update in flight.  timing_report() turns them into milliseconds (it synchronises)."""
+        self.timing = {"exchange": [], "wait": []}
+
+    def timing_report(self, steps):
+        """Per step: bytes and time of the bucket all-reduces, and the EXPOSED time - how long the main stream sat in front of an
+        update still in flight (the part of exchange + Adam that the overlap did not hide)."""
+        t, self.timing = self.timing, None
+        if t is None:
+            return None
+        torch.cuda.synchronize()
+        ex = [(a.elapsed_time(b), nb) for a, b, nb in t["exchange"]]
+        wt = [a.elapsed_time(b) for a, b in t["wait"]]
+        n = max(1, steps)
+        return {"all_reduces_per_step": round(len(ex) / n, 2), "bucket_bytes_per_step": int(sum(nb for _, nb in ex) / n),
+                "all_reduce_ms_per_step": round(sum(ms for ms, _ in ex) / n, 4),
+                "exposed_wait_ms_per_step": round(sum(wt) / n, 4), "steps": steps}
+
     def _wait_now(self, opt):
+        if self.timing is not None and self.side is not None and (self._pending if opt is None else opt in self._pending):
+            main = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
+            self._wait_now_untimed(opt)
+            e1.record(main)
+            self.timing["wait"].append((e0, e1))
+            return
+        self._wait_now_untimed(opt)
+
+    def _wait_now_untimed(self, opt):
         if opt is None:
             for o in self._pending:
                 o.wait_pending()

@@ -47,6 +47,7 @@ _WGRAD_STREAM_MIN = 6 << 20   # (1 M and 256 k measured on SRGAN: 82.7-82.8 vs 8
 # those additions stay serial and in the order of the one-stream step.
 _WGRAD_ONE_STREAM = 0
 _PENDING_WGRAD = {}
+_PENDING_READS = []   # tensors read by deferred weight-gradient launches of a recording in progress (see _Fork.join)
 
 
 @__import__("contextlib").contextmanager
@@ -67,6 +68,7 @@ def join_wgrad_streams():
     for dev_index, side in list(_PENDING_WGRAD.values()):
         torch.cuda.current_stream(dev_index).wait_stream(side)
     _PENDING_WGRAD.clear()
+    _PENDING_READS.clear()
 
 
 class _Fork:
@@ -87,6 +89,7 @@ class _Fork:
             key = (device.index, "all") if (force and self.defer) else (device.index, self.main.cuda_stream)
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+                ensure_splitk_ws(device, _SIDE_STREAMS[key])
             self.side = _SIDE_STREAMS[key]
             self.ctx = None
             self.key = key
@@ -112,9 +115,16 @@ class _Fork:
             raise RuntimeError("one_wgrad_stream(): a parameter gradient without a gradient slot would be accumulated by autograd on its "
                                "own stream (the step body must own every parameter through an optimiser's bucket)")
         if self.defer and all(t is None for t in returned):
-            for t in reads:
-                if t is not None:
-                    t.record_stream(self.side)
+            if torch.cuda.is_current_stream_capturing():
+                # inside a recording the allocator frees a block with a recorded stream use only when the capture ends: every activation
+                # and gradient a forked weight gradient reads would stay pinned for the whole recorded step.  Holding the tensors by
+                # reference until the join has the same effect on correctness (not recycled under the side launch) and releases them at
+                # the join.
+                _PENDING_READS.extend(t for t in reads if t is not None)
+            else:
+                for t in reads:
+                    if t is not None:
+                        t.record_stream(self.side)
             _PENDING_WGRAD[self.key] = (self.key[0], self.side)
             return
         # Every immediate side-stream use starts by waiting for the main stream and ends with the main stream waiting for it, so
@@ -213,11 +223,29 @@ def _splitk_ws(ref, max_m, Co, Ci_src, ncls=1):
             # The tickets must be zero AT REST: a buffer created inside a capture would be zeroed by a captured memset node only
             # (never eagerly) and would live in that graph's private pool while staying cached here under the stream key - a later
             # graph or eager launch on the stream would then run on unzeroed tickets and silently skip its output tile.
-            # No cached buffer for this stream yet => this launch takes the un-split kernel (same result, by geometry rule).
+            # No cached buffer for this stream yet => this launch takes the un-split kernel: the same result up to summation order
+            # (the recorded and the eager launch of this geometry then differ in the last bits).  Counted: the step bodies create the
+            # workspace of every stream they fork when they create the stream (ensure_splitk_ws), so this should not happen -
+            # tests assert SPLITK_CAPTURE_FALLBACKS stays 0.
+            global SPLITK_CAPTURE_FALLBACKS
+            SPLITK_CAPTURE_FALLBACKS += 1
             return None, 0
         ws = torch.zeros(lib.migan_conv_splitk_workspace() // 4, device=ref.device, dtype=torch.float32)
         _SK_WS[key] = ws
     return ws.data_ptr(), ws.numel() * 4
+
+
+SPLITK_CAPTURE_FALLBACKS = 0
+
+
+def ensure_splitk_ws(device, stream):
+    """Create the (zeroed) split-K workspace of `stream` now, outside any capture: called where a step body creates a side stream,
+    so a stream first used inside a recording already has one."""
+    if not _SPLITK or device.type != "cuda":
+        return
+    key = (device.index, stream.cuda_stream)
+    if key not in _SK_WS and not torch.cuda.is_current_stream_capturing():
+        _SK_WS[key] = torch.zeros(lib.migan_conv_splitk_workspace() // 4, device=device, dtype=torch.float32)
 
 
 _SPLITK = __import__("os").environ.get("MIGAN_SPLITK", "1") == "1"  # A/B knob

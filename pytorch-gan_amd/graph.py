@@ -15,9 +15,8 @@ What a capture freezes, and how the step bodies deal with it:
   * scalar kernel arguments — the learning rate is therefore read from a device scalar (optim.Adam.lr_t) that
     `run()` refreshes from `param_groups` before every replay, so LambdaLR schedules keep working;
   * host control flow and host RNG — `steps.wgan_gp_step` has two shapes (critic only / critic + generator):
-    use `steps.WganGpRunner`, which captures both; `steps.ReplayBuffer` draws from python `random` and keeps
-    references to samples, so it refuses to run under capture (the CycleGAN step replays eagerly; its launches are
-    large enough not to be host-bound);
+    use `steps.WganGpRunner`, which captures both; `steps.ReplayBuffer` draws from python `random`: `steps.CycleGanRunner`
+    draws in front of every replay into static device tables the recorded launches read (same draws, same order);
   * packed-weight cache entries never cross a capture boundary (functional.weight_cache_scope).
 """
 import contextlib
@@ -65,8 +64,9 @@ class _Segmenter:
 class StepRunner:
     """Runs `fn()` (one full training step on static device buffers) eagerly or as captured graph(s)."""
 
-    def __init__(self, fn, dp, use_graph=True, warmup=3):
+    def __init__(self, fn, dp, use_graph=True, warmup=3, before_capture=None):
         self.fn, self.dp, self.use_graph, self.warmup = fn, dp, use_graph, warmup
+        self.before_capture = before_capture   # called once after the warm-up steps, before the recording (static buffers a capture needs)
         self.graphed = False
         self.out = None
         self._segments = None
@@ -93,6 +93,8 @@ class StepRunner:
             self.capture_error = "not captured: the data-parallel wrapper does not allow it (graph_ok)"
             return self
         try:
+            if self.before_capture is not None:
+                self.before_capture()
             self._capture(side)
             self.graphed = True
         except Exception as e:  # capture is an optimisation: fall back to eager launches, but say so

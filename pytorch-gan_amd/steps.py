@@ -130,6 +130,7 @@ def _d_stream(device):
         # (default priority: a high-priority second stream was measured - the captured DCGAN step 2.91 -> 4.33 ms, SRGAN +0.5 %,
         # CycleGAN -0.5 %, profiles/r04_ab.txt call 16)
         _D_STREAMS[key] = torch.cuda.Stream(device)
+        F.ensure_splitk_ws(device, _D_STREAMS[key])
     return main, _D_STREAMS[key]
 
 
@@ -145,6 +146,7 @@ def _c_stream(device):
     key = (device.index, main.cuda_stream)
     if key not in _C_STREAMS:
         _C_STREAMS[key] = torch.cuda.Stream(device)
+        F.ensure_splitk_ws(device, _C_STREAMS[key])
     return main, _C_STREAMS[key]
 
 
@@ -164,6 +166,28 @@ def _two_streams_ok(s, ref):
     # skip_dead_grads: otherwise the generator's backward also writes (dead) discriminator gradients, which the other stream zeroes;
     # cross-replica BatchNorm puts collectives inside forward / backward: one stream
     return _OVERLAP_D and s.skip and ref.is_cuda and not _sync_bn(s)
+
+
+# Where the discriminator update runs when there is more than one rank (SURVEY.md 8e "Overlap").
+#   "sequential" (default for world > 1): the reference's order - generator backward, dp.step(opt_G), discriminator update,
+#       dp.step(opt_D).  The generator bucket's all-reduce + Adam leave for the data-parallel side stream right after the generator's
+#       backward and run UNDER the discriminator phase (which reads gen.detach() only: dcgan.py:179, cyclegan.py:216,233, srgan.py:139).
+#   "fork": the single-GPU body - the discriminator update on a second stream underneath the generator's backward, every dp.step()
+#       behind the join.  Faster compute (the D phase is hidden), but the generator bucket's exchange is then exposed at the end of the step.
+# Which one wins at N = 8 depends on exchange time vs the D phase's length and needs the 8-GPU node to decide: bench.py --dp-order.
+# world == 1 always takes the fork (there is no exchange to hide).
+_DP_ORDER = os.environ.get("MIGAN_DP_ORDER", "sequential")
+
+
+def set_dp_order(order):
+    global _DP_ORDER
+    if order not in ("sequential", "fork"):
+        raise ValueError("dp order: 'sequential' or 'fork'")
+    _DP_ORDER = order
+
+
+def _d_under_g_ok(s, ref):
+    return _two_streams_ok(s, ref) and (getattr(s.dp, "world", 1) == 1 or _DP_ORDER == "fork")
 
 
 def _fork_join(g_loss, d_half):
@@ -193,7 +217,7 @@ def dcgan_step(s, real_imgs, z):
     gen = s.G(z)
     with frozen(s.D, enabled=s.skip):
         g_loss = s.bce(s.D(gen), valid)
-    if _two_streams_ok(s, real_imgs):
+    if _d_under_g_ok(s, real_imgs):
         d_loss = _fork_join(g_loss, lambda: _dcgan_d_half(s, real_imgs, gen, valid, fake))
         s.dp.step(s.opt_G)
     else:
@@ -464,28 +488,47 @@ def _generator_nograd(s, z):
     if _k7():
         plan = getattr(s, "_k7_gen_plan", None)
         if plan is None or (plan.ok and plan.B != z.shape[0]):
+            if _capturing(z):   # see _capturing: no plan is built inside a recording
+                return s.G(z)
             plan = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
         if plan.usable(z):
             return plan.run(z)
     return s.G(z)
 
 
+def _capturing(t):
+    """A fused-kernel plan owns buffers that must be zero AT REST (ticket counters) and that every later step - eager or another
+    recorded graph - reuses: built inside a capture they would live in that graph's private pool and be zeroed by a captured memset
+    only.  While a recording is in progress no plan is built; the step takes the module path, whose result is the same."""
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 def _generator_iteration_plans(s, z):
     """(generator plan, critic-as-MLP plan) for the fused generator iteration, or None"""
     gp = getattr(s, "_k7_gen_plan", None)
     if gp is None or (gp.ok and gp.B != z.shape[0]):
+        if _capturing(z):
+            return None
         gp = s._k7_gen_plan = _GeneratorFusedPlan(s.G, z)
     if not gp.usable(z):
         return None
     dpn = getattr(s, "_k7_dmlp_plan", None)
     nin = gp.groups[-1][0].out_features
     if dpn is None or (dpn.ok and dpn.B != z.shape[0]):
+        if _capturing(z):
+            return None
         probe = torch.empty(z.shape[0], nin, device=z.device, dtype=torch.float32)
         dpn = s._k7_dmlp_plan = _GeneratorFusedPlan(s.D, probe, out_shape=(1,))
         if dpn.ok and (dpn.groups[-1][0].out_features != 1 or any(bn is not None for _, bn, _, _ in dpn.groups) or nin % 32 != 0):
             dpn.ok = False
     if not dpn.ok:
         return None
+    if gp.save is None or dpn.save is None or getattr(dpn, "_dval", None) is None:   # buffers of the differentiated form: made outside a capture
+        if _capturing(z):
+            return None
+        gp._train_buffers(z.device)
+        dpn._train_buffers(z.device)
+        dpn._dval = torch.full((gp.B, 1), -1.0 / gp.B, device=z.device, dtype=torch.float32)
     if not hasattr(gp, "_covers_opt"):   # the fused backward WRITES gradients: it must own every parameter of the generator's optimiser
         mine = {id(t) for lin, bn, _, _ in gp.groups for t in ((lin.weight, lin.bias) + ((bn.weight, bn.bias) if bn is not None else ()))
                 if t is not None}
@@ -522,6 +565,8 @@ def _generator_iteration_fused(s, z):
 def _critic_plan(s, real, fake):
     plan = getattr(s, "_k7_plan", None)
     if plan is None or (plan.ok and plan.B != real.shape[0]):
+        if _capturing(real):
+            return None
         plan = s._k7_plan = _CriticFusedPlan(s, real)
     return plan if plan.usable(real, fake) else None
 
@@ -683,38 +728,25 @@ class ReplayBuffer:
     draws are the reference's, bit for bit; the samples live in one pool tensor [max_size][C][H][W] on the GPU and a call
     is two kernel launches - one gathers the returned batch from old pool entries and new samples, one writes the new
     samples into the pool - instead of per-sample clones and a torch.cat.  CPU tensors (the oracle comparison of the index
-    logic) take the reference's list path."""
+    logic) take the reference's list path.  The draws need nothing from the device, so a step recorded into a hipGraph keeps
+    them on the host: plan(B) draws before each replay and refreshes a static device table the recorded launches read."""
 
     def __init__(self, max_size=50):
         if max_size <= 0:
             raise AssertionError("Empty buffer or trying to create a black hole. Be careful.")
         self.max_size, self.data = max_size, []
         self.pool, self.count = None, 0
+        self.table, self._planned = None, None   # static pick table of the recorded step (plan()); batch size plan() drew for
 
     def __len__(self):
         return self.count if self.pool is not None else len(self.data)
 
-    def push_and_pop(self, batch):
-        if not F.on_device(batch):
-            return self._push_and_pop_host(batch)
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("ReplayBuffer draws from the host RNG: it cannot be captured into a hipGraph (run "
-                               "cyclegan_step eagerly)")
-        x = F.canon(batch.data)
-        B = x.shape[0]
-        D = x[0].numel()
-        if self.pool is not None and self.pool.shape[1:] != x.shape[1:]:
-            raise ValueError("ReplayBuffer: sample shape changed from %s to %s (the history cannot be mixed; use a new buffer)"
-                             % (tuple(self.pool.shape[1:]), tuple(x.shape[1:])))
-        if D % 4 != 0:
-            raise ValueError("ReplayBuffer: C*H*W = %d must be a multiple of 4 on the device path (16-byte row copies)" % D)
-        if self.pool is None:
-            self.pool = torch.empty((self.max_size, *x.shape[1:]), device=x.device, dtype=torch.float32,
-                                    memory_format=torch.channels_last if x.dim() == 4 else torch.contiguous_format)
-            self.count = 0
-        # the reference loop, on indices: where each returned element comes from, and what each pool slot holds afterwards
-        out_src = []                      # per returned element: pool slot j >= 0 (its CURRENT content) or new sample -1-k
-        slot_src = {}                     # pool slot -> new sample k written to it in this call (last write wins)
+    def _draw(self, B):
+        """The reference loop (cyclegan/utils.py:17-32) on indices, for a batch of B new samples: -> (out_src, slot_src) where
+        out_src[k] is the pool slot j >= 0 whose CURRENT content is returned as element k, or -1-k' for new sample k', and
+        slot_src maps every pool slot written by this call to the new sample it holds afterwards (last write wins).  Consumes
+        python `random` exactly as the reference does and advances the fill count."""
+        out_src, slot_src = [], {}
         for k in range(B):
             if self.count < self.max_size:
                 slot_src[self.count] = k
@@ -727,8 +759,62 @@ class ReplayBuffer:
                 slot_src[j] = k
             else:
                 out_src.append(-1 - k)
+        return out_src, slot_src
+
+    def reserve(self, B):
+        """Allocate the static pick table for B-sample batches (no draw): what a recording of the step needs to exist."""
+        if self.pool is None:
+            raise RuntimeError("ReplayBuffer.reserve(): no device pool yet (run one eager push_and_pop first)")
+        if self.table is None or self.table.numel() != 3 * B:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ReplayBuffer: the static table must exist before a capture")
+            self.table = torch.full((3 * B,), -1, dtype=torch.int32, device=self.pool.device)
+
+    def plan(self, B):
+        """Draw the picks of the NEXT push_and_pop of a B-sample batch now and put them into the buffer's static device table
+        ([returned-batch sources | pool-update sources | pool-update slots, -1 = no update], 3*B int32).  A recorded hipGraph
+        (CycleGanRunner) launches the two row-selection kernels over this table every replay: the host RNG draws - the
+        reference's, in the reference's order - happen here, before the replay, and only the table's contents change."""
+        self.reserve(B)
+        out_src, slot_src = self._draw(B)
+        slots = sorted(slot_src)
+        pad = B - len(slots)
+        table = out_src + [-1 - slot_src[j] for j in slots] + [-1] * pad + slots + [-1] * pad
+        self.table.copy_(torch.tensor(table, dtype=torch.int32))
+        self._planned = B
+
+    def push_and_pop(self, batch):
+        if not F.on_device(batch):
+            return self._push_and_pop_host(batch)
+        x = F.canon(batch.data)
+        B = x.shape[0]
+        D = x[0].numel()
+        if self.pool is not None and self.pool.shape[1:] != x.shape[1:]:
+            raise ValueError("ReplayBuffer: sample shape changed from %s to %s (the history cannot be mixed; use a new buffer)"
+                             % (tuple(self.pool.shape[1:]), tuple(x.shape[1:])))
+        if D % 4 != 0:
+            raise ValueError("ReplayBuffer: C*H*W = %d must be a multiple of 4 on the device path (16-byte row copies)" % D)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.pool is None:
+            if capturing:
+                raise RuntimeError("ReplayBuffer: the device pool must exist before the step is recorded into a hipGraph (run an "
+                                   "eager step first - CycleGanRunner.prepare() does)")
+            self.pool = torch.empty((self.max_size, *x.shape[1:]), device=x.device, dtype=torch.float32,
+                                    memory_format=torch.channels_last if x.dim() == 4 else torch.contiguous_format)
+            self.count = 0
         out = torch.empty_like(x)
         st = torch.cuda.current_stream().cuda_stream
+        if capturing or self._planned is not None:
+            # the picks were drawn by plan() (or will be, before every replay): both launches run over the static table, B rows each
+            if self.table is None or self.table.numel() != 3 * B or (not capturing and self._planned != B):
+                raise RuntimeError("ReplayBuffer: push_and_pop(%d samples) under a capture / after plan() needs plan(%d) first" % (B, B))
+            self._planned = None
+            t = self.table.data_ptr()
+            F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), out.data_ptr(), t, None, B, D, st), "select_rows")
+            F.check(F.lib.migan_select_rows(self.pool.data_ptr(), x.data_ptr(), self.pool.data_ptr(), t + 4 * B, t + 8 * B, B, D, st),
+                    "select_rows")
+            return out
+        out_src, slot_src = self._draw(B)
         # both index tables in ONE host-to-device copy.  (A pinned staging buffer + non_blocking copy was tried: the
         # two-ranks-on-one-GPU gloo test hung with it in the tree; the cause was not isolated, so the pageable copy stays.)
         slots = sorted(slot_src)
@@ -789,59 +875,14 @@ def make_cyclegan_state(G_AB, G_BA, D_A, D_B, skip_dead_grads=True, dp=None):
 def cyclegan_step(s, real_A, real_B):
     """cyclegan.py:159-239."""
     B = real_A.size(0)
-    valid, fake = _labels(s, (B, *s.D_A.output_shape), real_A.device)
+    dev = real_A.device
+    valid, fake = _labels(s, (B, *s.D_A.output_shape), dev)
     s.G_AB.train()
     s.G_BA.train()
     s.dp.begin_step()
     s.opt_G.zero_grad()
     chains = _CHAINS and _two_streams_ok(s, real_A) and _conv_params_only(s)
-    if chains:
-        # The generators' step is two independent halves (cyclegan.py:170-190): real_A -> G_AB -> fake_B -> {D_B, G_BA -> recov_A} with
-        # the identity pass G_BA(real_A), and the mirror image from real_B.  They share nothing but the (read-only) weights until the
-        # losses are added, so the second half's forward runs on a second stream beside the first: one half's InstanceNorm passes (HBM)
-        # and its MFMA launches' stalls are filled by the other half's launches.  Autograd runs each backward node on its forward's
-        # stream, so the backward is two-stream as well; every parameter-gradient launch of both halves goes to ONE stream
-        # (functional.one_wgrad_stream) in the engine's node order, so the additions into the shared parameters' gradients are serial
-        # and in the order of the one-stream step: bit-identical results.
-        main, side = _c_stream(real_A.device)
-        wcm = F.one_wgrad_stream()
-        wcm.__enter__()
-        try:
-            F.prefill_packs(real_A.device)   # the step's planned weight packs exist before either half asks for one
-            side.wait_stream(main)
-            with F.two_streams(), frozen(s.D_A, s.D_B, enabled=True):
-                # host order = the one-stream body's order of calls: autograd numbers its nodes as they are made and walks them backward
-                # by that number, so the parameter-gradient launches reach their one stream in the same order as without the second stream
-                id_A = s.l1(s.G_BA(real_A), real_A)
-                with torch.cuda.stream(side):
-                    id_B = s.l1(s.G_AB(real_B), real_B)
-                fake_B = s.G_AB(real_A)
-                loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
-                with torch.cuda.stream(side):
-                    fake_A = s.G_BA(real_B)
-                    loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
-                cyc_A = s.l1(s.G_BA(fake_B), real_A)
-                with torch.cuda.stream(side):
-                    cyc_B = s.l1(s.G_AB(fake_A), real_B)
-            main.wait_stream(side)
-        except BaseException:
-            wcm.__exit__(None, None, None)
-            main.wait_stream(side)
-            raise
-        loss_id = half_sum(id_A, id_B)
-        loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
-        loss_cycle = half_sum(cyc_A, cyc_B)
-    else:
-        wcm = None
-        loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
-        with frozen(s.D_A, s.D_B, enabled=s.skip):
-            fake_B = s.G_AB(real_A)
-            loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
-            fake_A = s.G_BA(real_B)
-            loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
-        loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
-        loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
-    loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
+    under = _d_under_g_ok(s, real_A)
 
     def d_half(opt, D, real, buf, fake_img):   # cyclegan.py:203-233 up to loss_D_X.backward()
         opt.zero_grad()
@@ -851,22 +892,66 @@ def cyclegan_step(s, real_A, real_B):
         _backward(loss_D)
         return loss_D
 
-    if _two_streams_ok(s, real_A):
-        # both discriminator updates underneath the generators' backward (see dcgan_step): they need fake_A / fake_B of the forward
-        # only, and the step is ~1900 eager launches whose dependent-launch gaps the second stream's kernels fill
-        try:
+    with contextlib.ExitStack() as region:   # everything that forks a stream; left with every stream joined, also on an exception
+        if chains:
+            # The generators' step is two independent halves (cyclegan.py:170-190): real_A -> G_AB -> fake_B -> {D_B, G_BA -> recov_A} with
+            # the identity pass G_BA(real_A), and the mirror image from real_B.  They share nothing but the (read-only) weights until the
+            # losses are added, so the second half's forward runs on a second stream beside the first: one half's InstanceNorm passes (HBM)
+            # and its MFMA launches' stalls are filled by the other half's launches.  Autograd runs each backward node on its forward's
+            # stream, so the backward is two-stream as well; every parameter-gradient launch of both halves goes to ONE stream
+            # (functional.one_wgrad_stream) in the engine's node order, so the additions into the shared parameters' gradients are serial
+            # and in the order of the one-stream step: bit-identical results.
+            main, side = _c_stream(dev)
+            region.enter_context(F.one_wgrad_stream())   # until the generators' backward is over
+            # the backward nodes of the second chain run on its stream: whoever leaves the region (the optimiser steps) waits for them
+            region.callback(lambda: torch.cuda.current_stream(dev).wait_stream(side))
+            F.prefill_packs(dev)   # the step's planned weight packs exist before either half asks for one
+            side.wait_stream(main)
+            try:
+                with F.two_streams(), frozen(s.D_A, s.D_B, enabled=True):
+                    # host order = the one-stream body's order of calls: autograd numbers its nodes as they are made and walks them
+                    # backward by that number, so the parameter-gradient launches reach their one stream in the same order as without
+                    # the second stream
+                    id_A = s.l1(s.G_BA(real_A), real_A)
+                    with torch.cuda.stream(side):
+                        id_B = s.l1(s.G_AB(real_B), real_B)
+                    fake_B = s.G_AB(real_A)
+                    loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+                    with torch.cuda.stream(side):
+                        fake_A = s.G_BA(real_B)
+                        loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+                    cyc_A = s.l1(s.G_BA(fake_B), real_A)
+                    with torch.cuda.stream(side):
+                        cyc_B = s.l1(s.G_AB(fake_A), real_B)
+            finally:
+                main.wait_stream(side)
+            loss_id = half_sum(id_A, id_B)
+            loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
+            loss_cycle = half_sum(cyc_A, cyc_B)
+        else:
+            loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
+            with frozen(s.D_A, s.D_B, enabled=s.skip):
+                fake_B = s.G_AB(real_A)
+                loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
+                fake_A = s.G_BA(real_B)
+                loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
+            loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
+            loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
+        loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
+        if under:
+            # both discriminator updates underneath the generators' backward (see dcgan_step): they need fake_A / fake_B of the forward
+            # only, and the step is ~1900 launches whose dependent-launch gaps the second stream's kernels fill
             loss_D_A, loss_D_B = _fork_join(loss_G, lambda: (d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A),
                                                              d_half(s.opt_D_B, s.D_B, real_B, s.buf_B, fake_B)))
-        finally:
-            if wcm is not None:
-                wcm.__exit__(None, None, None)
-                # the backward nodes of the second forward chain ran on its stream: the optimiser steps wait for them
-                torch.cuda.current_stream(real_A.device).wait_stream(_c_stream(real_A.device)[1])
+        else:
+            _backward(loss_G)
+    if under:
         s.dp.step(s.opt_G)
         s.dp.step(s.opt_D_A)
         s.dp.step(s.opt_D_B)
     else:
-        _backward(loss_G)
+        # the reference's order (and the data-parallel default, see set_dp_order): the generators' gradient exchange + Adam leave for the
+        # data-parallel side stream here and run underneath the two discriminator updates
         s.dp.step(s.opt_G)
         loss_D_A = d_half(s.opt_D_A, s.D_A, real_A, s.buf_A, fake_A)
         s.dp.step(s.opt_D_A)
@@ -874,6 +959,46 @@ def cyclegan_step(s, real_A, real_B):
         s.dp.step(s.opt_D_B)
     return {"loss_G": loss_G.detach(), "loss_D": half_sum(loss_D_A, loss_D_B).detach(), "loss_GAN": loss_GAN.detach(),
             "loss_cycle": loss_cycle.detach(), "loss_identity": loss_id.detach()}
+
+
+class CycleGanRunner:
+    """`cyclegan_step` on static device batches, replayed as hipGraph(s).  What kept the step out of a capture was the replay
+    buffers' host RNG (cyclegan/utils.py:21-30, called between the generator and discriminator phases, cyclegan.py:216,233); the draws
+    need nothing from the device, so they move IN FRONT of the replay: `run()` draws buffer A's picks, then buffer B's - the order
+    of the reference's calls - into each buffer's static index table (ReplayBuffer.plan) and replays the recorded launches, which
+    read the tables.  Same random numbers, same picks, same arithmetic as the eager step (tests compare them bit for bit).  At one
+    image per GPU - the reference's default batch (cyclegan.py:28) and the per-GPU shard of the 8-GPU configuration - the step is
+    ~2000 launches of 5-60 us: host-bound when launched one by one.  `prepare()` runs `warmup` real steps."""
+
+    def __init__(self, s, real_A, real_B, use_graph=True, warmup=2):
+        from .graph import StepRunner
+
+        self.s = s
+        self.a, self.b = real_A.clone(), real_B.clone()
+        self.runner = StepRunner(lambda: cyclegan_step(s, self.a, self.b), s.dp, use_graph, max(1, warmup), before_capture=self._reserve)
+
+    def _reserve(self):
+        B = self.a.shape[0]
+        self.s.buf_A.reserve(B)
+        self.s.buf_B.reserve(B)
+
+    def prepare(self):
+        self.runner.prepare()
+        return self
+
+    graphed = property(lambda self: self.runner.graphed)
+    capture_error = property(lambda self: self.runner.capture_error)
+
+    def run(self, real_A=None, real_B=None):
+        if real_A is not None:
+            self.a.copy_(real_A)
+        if real_B is not None:
+            self.b.copy_(real_B)
+        if self.runner.graphed:
+            B = self.a.shape[0]
+            self.s.buf_A.plan(B)   # cyclegan.py:216 fake_A_buffer.push_and_pop(fake_A) draws first ...
+            self.s.buf_B.plan(B)   # ... cyclegan.py:233 fake_B_buffer.push_and_pop(fake_B) second
+        return self.runner.run()
 
 
 # ------------------------------------------------------------------------------------------------ pix2pix
@@ -904,7 +1029,7 @@ def pix2pix_step(s, real_A, real_B):
         _backward(loss_D)
         return loss_D
 
-    if _two_streams_ok(s, real_A):   # the discriminator update underneath the generator's backward (see dcgan_step)
+    if _d_under_g_ok(s, real_A):   # the discriminator update underneath the generator's backward (see dcgan_step)
         loss_D = _fork_join(loss_G, d_half)
         s.dp.step(s.opt_G)
     else:
@@ -935,16 +1060,26 @@ def srgan_step(s, imgs_lr, imgs_hr):
         # feature_extractor(imgs_hr) of srgan.py:114 needs nothing from the generator and nobody differentiates it: it runs on the
         # second stream beside the generator's forward (whose 33 trunk convs are single-round launches with a latency-bound tail)
         main, side = _d_stream(imgs_lr.device)
+        # the step's planned weight packs (G's, D's and V's) are written by ONE launch that rides on the first pack request: it runs
+        # here, on the main stream, before the fork - otherwise the side stream's first VGG conv would issue it and the generator's
+        # convs on the main stream would read their arena views with no dependency on that launch
+        F.prefill_packs(imgs_lr.device)
         side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad():
-            real_features = s.V(imgs_hr)
-    gen_hr = s.G(imgs_lr)
-    with frozen(s.D, s.V, enabled=s.skip):
-        loss_GAN = s.mse(s.D(gen_hr), valid)
-        gen_features = s.V(gen_hr)
+    try:
+        # two_streams(): a pack made inside the forked region carries the event of its launch, a hit from the other stream waits for it
+        with F.two_streams() if vside else contextlib.nullcontext():
+            if vside:
+                with torch.cuda.stream(side), torch.no_grad():
+                    real_features = s.V(imgs_hr)
+            gen_hr = s.G(imgs_lr)
+            with frozen(s.D, s.V, enabled=s.skip):
+                loss_GAN = s.mse(s.D(gen_hr), valid)
+                gen_features = s.V(gen_hr)
+    finally:
         if vside:
-            main.wait_stream(side)
-        elif s.skip:
+            main.wait_stream(side)   # join - also when a forward raised: no stream stays forked
+    if not vside:
+        if s.skip:
             with torch.no_grad():
                 real_features = s.V(imgs_hr)
         else:
@@ -962,7 +1097,7 @@ def srgan_step(s, imgs_lr, imgs_hr):
         _backward(loss_D)
         return loss_D
 
-    if _two_streams_ok(s, imgs_lr):   # the discriminator update underneath the generator's backward (see dcgan_step)
+    if _d_under_g_ok(s, imgs_lr):   # the discriminator update underneath the generator's backward (see dcgan_step)
         loss_D = _fork_join(loss_G, d_half)
         s.dp.step(s.opt_G)
     else:

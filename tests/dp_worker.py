@@ -5,6 +5,8 @@
                                                    MIGAN_TEST_STEPS=k: k steps;  MIGAN_TEST_GRAPH=1: step 1 eager, the rest replays of
                                                    the recorded step (hipGraph segments cut at every BatchNorm collective);
                                                    MIGAN_TEST_GRAPH=cuts: the recording protocol without a capture (CPU)
+    python tests/dp_worker.py order <out.pt>       N ranks (gloo, all on cuda:0): CycleGAN steps, one image pair per rank, under
+                                                   MIGAN_TEST_ORDER=sequential|fork (steps.set_dp_order)
 """
 import json
 import os
@@ -150,12 +152,58 @@ def syncbn(out):
     del pg
 
 
+def order(out):
+    """Every rank runs ONE image pair of a two-pair CycleGAN batch (InstanceNorm: shards exactly) for MIGAN_TEST_STEPS steps under
+    steps.set_dp_order(MIGAN_TEST_ORDER); rank 0 stores the rank-averaged losses of the last step, all four networks' weights and the
+    three buckets' gradients (divided by world) of the last step."""
+    import random
+
+    import pytorch_gan_amd as pg
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import dp as dpmod
+    from pytorch_gan_amd import steps
+    from util import gpu_copy
+
+    dp = dpmod.init_from_env()
+    steps.set_dp_order(os.environ.get("MIGAN_TEST_ORDER", "sequential"))
+    _seed(0)
+    side = int(os.environ.get("MIGAN_TEST_SIDE", "64"))
+    shape = (3, side, side)
+    base = S.make_cyclegan(shape, 1)
+    s = steps.make_cyclegan_state(gpu_copy(base.G_AB), gpu_copy(base.G_BA), gpu_copy(base.D_A), gpu_copy(base.D_B), dp=dp)
+    _seed(9)
+    A = (torch.rand(2, *shape) * 2 - 1).cuda()
+    B = (torch.rand(2, *shape) * 2 - 1).cuda()
+    a, b = dp.shard(A).clone(), dp.shard(B).clone()
+    nsteps = int(os.environ.get("MIGAN_TEST_STEPS", "1"))
+    keys = ("loss_G", "loss_D", "loss_GAN", "loss_cycle", "loss_identity")
+    first = None
+    for t in range(nsteps):
+        random.seed(5 + t)
+        dp.begin_step()
+        o = steps.cyclegan_step(s, a, b)
+        dp.end_step()
+        torch.cuda.synchronize()
+        losses = torch.stack([o[k] for k in keys]).clone()
+        dist.all_reduce(losses)
+        losses /= dp.world
+        if t == 0:   # the buckets hold the summed gradients of this step until the next zero_grad()
+            first = {"losses": losses.cpu(), "grads": {n: getattr(s, n).flat_grad.cpu() / dp.world for n in ("opt_G", "opt_D_A", "opt_D_B")}}
+    if dp.rank == 0:
+        torch.save({"losses": losses.cpu(), "first": first,
+                    "nets": {n: {k: v.detach().cpu() for k, v in getattr(s, n).state_dict().items()} for n in ("G_AB", "G_BA", "D_A", "D_B")},
+                    "grads": {n: getattr(s, n).flat_grad.cpu() / dp.world for n in ("opt_G", "opt_D_A", "opt_D_B")}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+    del pg
+
+
 if __name__ == "__main__":
     if os.environ.get("MIGAN_TEST_EMU") == "1":
         # the same worker on the host execution model of the kernels (tests/hipemu): CPU tensors, gloo, no GPU
         import hipemu.host
 
         with hipemu.host.emulated_device():
-            {"syncbn": syncbn}[sys.argv[1]](sys.argv[2])
+            {"syncbn": syncbn, "order": order}[sys.argv[1]](sys.argv[2])
     else:
-        {"nccl1": nccl1, "syncbn": syncbn}[sys.argv[1]](sys.argv[2])
+        {"nccl1": nccl1, "syncbn": syncbn, "order": order}[sys.argv[1]](sys.argv[2])

@@ -109,3 +109,44 @@ def test_cross_replica_batchnorm_equals_full_batch(tmp_path):
     # per-rank statistics are a different computation: the running variance of the first generator BatchNorm differs
     k = "conv_blocks.0.running_var"
     assert not torch.allclose(local["G"][k], s.G.state_dict()[k].cpu(), rtol=1e-4, atol=1e-6)
+
+
+def test_both_step_orders_of_the_data_parallel_step_equal_the_full_batch(tmp_path):
+    """SURVEY.md 8e "Overlap": with more than one rank the step bodies run in the reference's order by default ('sequential': the generator
+    bucket's exchange + Adam leave for the side stream right after the generator's backward, under the discriminator phase) or as the
+    single-GPU body ('fork': discriminator update underneath the generator's backward, exchanges behind the join) - steps.set_dp_order /
+    bench.py --dp-order.  Two ranks x one CycleGAN image pair (InstanceNorm shards exactly): both orders leave bit-identical weights after
+    two steps, and the first step's losses and averaged gradients equal the single-process step on the two-pair batch."""
+    import random
+
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    emu = os.environ.get("MIGAN_TEST_EMU") == "1"
+    # 64x64 on the GPU; 32x32 on the execution model (time): there the PatchGAN's last InstanceNorm sees 2x2 = 4 values - ill-conditioned,
+    # it amplifies the rounding differences between one image per launch and two - hence the wider bound on the generators' gradient
+    side, tol = (32, 1e-2) if emu else (64, 6e-4)
+    env = {"MIGAN_TEST_STEPS": "2", "MIGAN_TEST_SIDE": str(side)}
+    got = {o: _run_ranks("order", str(tmp_path / (o + ".pt")), 2, dict(env, MIGAN_TEST_ORDER=o)) for o in ("sequential", "fork")}
+    assert torch.equal(got["sequential"]["losses"], got["fork"]["losses"])
+    for n, sd in got["sequential"]["nets"].items():
+        for k, v in sd.items():
+            assert torch.equal(got["fork"]["nets"][n][k], v), (n, k)
+    one = got["sequential"]["first"]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    shape = (3, side, side)
+    base = S.make_cyclegan(shape, 1)
+    s = steps.make_cyclegan_state(gpu_copy(base.G_AB), gpu_copy(base.G_BA), gpu_copy(base.D_A), gpu_copy(base.D_B))
+    torch.manual_seed(9)
+    np.random.seed(9)
+    A = (torch.rand(2, *shape) * 2 - 1).cuda()
+    B = (torch.rand(2, *shape) * 2 - 1).cuda()
+    random.seed(5)
+    o = steps.cyclegan_step(s, A, B)
+    torch.cuda.synchronize()
+    want = torch.stack([o[k] for k in ("loss_G", "loss_D", "loss_GAN", "loss_cycle", "loss_identity")]).cpu()
+    assert torch.allclose(one["losses"], want, rtol=2e-5, atol=1e-6), (one["losses"], want)
+    for name in ("opt_G", "opt_D_A", "opt_D_B"):
+        a, b = one["grads"][name].double(), getattr(s, name).flat_grad.cpu().double()
+        assert float((a - b).norm() / b.norm()) < tol, name

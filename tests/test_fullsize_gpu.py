@@ -139,6 +139,38 @@ def test_cyclegan_256_bs8_step():
     _report_batch(bs, 8, "cyclegan 256x256")
 
 
+def test_cyclegan_256_bs1_step():
+    """Row N2: the per-GPU shard of config 4 at N = 8 - cyclegan.py:159-239 at 256x256 with ONE image (the reference's default
+    --batch_size, cyclegan.py:28): M = 4096 GEMMs in the residual trunk pick other tiles / split counts than batch 8.  Losses,
+    gradients of all four networks and the weights after Adam against the oracle's step on the same image pair."""
+    from util import suite_budget
+
+    suite_budget(60, "test_cyclegan_256_bs1_step")
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    shape = (3, 256, 256)
+    _seed(0)
+    s_cpu = S.make_cyclegan(shape, 9)
+    s_gpu = steps.make_cyclegan_state(gpu_copy(s_cpu.G_AB), gpu_copy(s_cpu.G_BA), gpu_copy(s_cpu.D_A),
+                                      gpu_copy(s_cpu.D_B), skip_dead_grads=True)
+    _seed(13)
+    A = torch.rand(1, *shape) * 2 - 1
+    B = torch.rand(1, *shape) * 2 - 1
+    random.seed(5)
+    o_g = steps.cyclegan_step(s_gpu, A.to(DEV), B.to(DEV))
+    torch.cuda.synchronize()
+    random.seed(5)
+    o_c = S.cyclegan_step(s_cpu, A, B)
+    for k in ("loss_G", "loss_D", "loss_GAN", "loss_cycle", "loss_identity"):
+        _loss_close(o_g[k], o_c[k], k)
+    for name in ("G_AB", "G_BA", "D_A", "D_B"):
+        _net_grad_close(getattr(s_gpu, name), getattr(s_cpu, name), 5e-3, "cyclegan bs1 " + name)
+        _weights_close(getattr(s_gpu, name), getattr(s_cpu, name), 1, "cyclegan bs1 " + name)
+    assert len(s_gpu.buf_A) == len(s_cpu.buf_A.data) == 1
+    assert rel_fro(torch.cat(s_gpu.buf_A.samples()), torch.cat(s_cpu.buf_A.data)) < 2e-5
+
+
 def test_srgan_96_384_bs16_step():
     from util import suite_budget
 

@@ -605,6 +605,15 @@ def test_cross_replica_batchnorm_recording_protocol_on_the_execution_model(tmp_p
     test_dp_gpu.test_cross_replica_batchnorm_step_replays_as_graph_segments(tmp_path)   # every kernel runs in the rank processes
 
 
+def test_data_parallel_step_orders_on_the_execution_model(tmp_path, monkeypatch):
+    """test_dp_gpu.py::test_both_step_orders_of_the_data_parallel_step_equal_the_full_batch without a GPU: two gloo ranks, CycleGAN
+    at 32x32, 'sequential' and 'fork' order of the discriminator updates relative to the generator bucket's exchange - bit-identical
+    to each other, and the first step equal to the single-process step on the whole batch."""
+    monkeypatch.setenv("MIGAN_TEST_EMU", "1")
+    monkeypatch.setenv("MIGAN_TEST_DEVICE", "cpu")
+    _run_gpu_test_body("test_dp_gpu", "test_both_step_orders_of_the_data_parallel_step_equal_the_full_batch", tmp_path)
+
+
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="70 s on 8 cores: MIGAN_EMU_SLOW=1")
 def test_esrgan_full_depth_on_the_execution_model():
     """test_steps_gpu.py::test_esrgan_full_depth_steps (23 RRDB generator, warm-up + relativistic iteration) on the execution model;
@@ -625,6 +634,43 @@ def test_pix2pix_trajectory_on_the_execution_model():
 @pytest.mark.skipif(os.environ.get("MIGAN_EMU_SLOW") != "1", reason="4 minutes on 8 cores: MIGAN_EMU_SLOW=1")
 def test_cyclegan_steps_on_the_execution_model():
     _run_gpu_test_body("test_steps_gpu", "test_cyclegan_steps")
+
+
+def test_replay_buffer_planned_picks_equal_the_eager_picks(emu):
+    """cyclegan/utils.py:13-33 for a recorded step: ReplayBuffer.plan(B) draws the picks of the next call in front of it into the
+    buffer's static table (fixed length 3*B, -1 = no pool update: select_rows skips the row), push_and_pop then launches over the
+    table - the path a hipGraph replay takes.  Same `random` seed => the same returned batches and the same history as the eager
+    call and as the reference's list logic, through fill-up, picks, and a slot replaced twice in one call."""
+    import random
+
+    import hipemu.host
+    from oracle import reference_models as M
+    from pytorch_gan_amd import steps
+
+    torch.manual_seed(3)
+    batches = [torch.randn(3, 2, 4, 4) for _ in range(12)]
+    with hipemu.host.emulated_device():
+        out = {}
+        for mode in ("eager", "planned"):
+            buf = steps.ReplayBuffer(4)
+            random.seed(11)
+            got = []
+            for i, b in enumerate(batches):
+                if mode == "planned" and i > 0:   # the pool exists after the first (eager) call, as after CycleGanRunner's warm-up
+                    buf.plan(3)
+                    assert buf._planned == 3
+                got.append(buf.push_and_pop(b.clone()).clone())
+                assert buf._planned is None
+            out[mode] = (got, torch.cat(buf.samples()).clone())
+        with pytest.raises(RuntimeError):
+            buf.plan(3)
+            buf.push_and_pop(batches[0][:2].clone())   # planned for 3 samples, called with 2
+    ref = M.ReplayBuffer(4)
+    random.seed(11)
+    want = [ref.push_and_pop(b.clone()) for b in batches]
+    for a, b, c in zip(out["eager"][0], out["planned"][0], want):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(out["eager"][1], out["planned"][1]) and torch.equal(out["eager"][1], torch.cat(ref.data))
 
 
 def test_step_plans_belong_to_the_step_state(emu):

@@ -222,6 +222,51 @@ def test_cyclegan_discriminator_halves_on_a_second_stream_are_bit_identical():
         assert torch.equal(a, b)
 
 
+def test_cyclegan_recorded_step_equals_eager_steps():
+    """Row N2 / cyclegan.py:159-239 as a hipGraph: steps.CycleGanRunner draws the replay buffers' picks (python `random`, buffer A then
+    buffer B - the reference's call order, cyclegan.py:216,233) in front of every replay into static device tables; six steps at 64x64
+    with replay buffers of 3 (picks start at the second step) - losses, every weight and both image histories bit-identical to the same
+    steps launched eagerly, and no launch of the recording fell back to the un-split kernel for lack of a per-stream workspace."""
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import functional as F
+    from pytorch_gan_amd import steps
+
+    shape, n_res = (3, 64, 64), 2
+    _seed(0)
+    base = S.make_cyclegan(shape, n_res)
+    _seed(9)
+    As = (torch.rand(6, 2, *shape) * 2 - 1).to(DEV)
+    Bs = (torch.rand(6, 2, *shape) * 2 - 1).to(DEV)
+    fallbacks = F.SPLITK_CAPTURE_FALLBACKS
+    res = {}
+    for graph in (False, True):
+        st = steps.make_cyclegan_state(gpu_copy(base.G_AB), gpu_copy(base.G_BA), gpu_copy(base.D_A), gpu_copy(base.D_B))
+        st.buf_A.max_size = st.buf_B.max_size = 3
+        outs = []
+        random.seed(40)
+        if graph:
+            runner = steps.CycleGanRunner(st, As[0], Bs[0], use_graph=True, warmup=1).prepare()   # = eager step 0
+            assert runner.graphed, runner.capture_error
+            first = runner.runner.out
+        else:
+            first = steps.cyclegan_step(st, As[0], Bs[0])
+        outs.append({k: v.clone() for k, v in first.items()})
+        for t in range(1, 6):
+            random.seed(40 + t)
+            o = runner.run(As[t], Bs[t]) if graph else steps.cyclegan_step(st, As[t], Bs[t])
+            outs.append({k: v.clone() for k, v in o.items()})
+        torch.cuda.synchronize()
+        res[graph] = (outs, [p.detach().clone() for m in (st.G_AB, st.G_BA, st.D_A, st.D_B) for p in m.parameters()],
+                      torch.cat(st.buf_A.samples() + st.buf_B.samples()).clone())
+    assert F.SPLITK_CAPTURE_FALLBACKS == fallbacks
+    for t, (a, b) in enumerate(zip(res[True][0], res[False][0])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (t, k, float(a[k]), float(b[k]))
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][2], res[False][2])
+
+
 @pytest.mark.parametrize("skip_dead", [False, True])
 def test_wgan_gp_steps(skip_dead):
     from oracle import reference_steps as S
