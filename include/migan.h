@@ -214,6 +214,14 @@ int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx,
  * mostly tiny workgroups that a caller may overlap with independent work on another stream. */
 int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                      void* stream);
+/* migan_conv2d_dgrad_reflect1 with a split-K workspace (migan_conv_splitk_workspace() bytes, zero at rest, one per stream; NULL:
+ * none) for both launches: at one image per GPU (cyclegan.py:28) the pad-1 launch is one 64x64 tile per CU and the ring launch a
+ * chain of 56 dependent K-tiles - both are cut along K where migan_conv_splitk_applies() says so. */
+int migan_conv2d_dgrad_reflect1_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                                   float* ws, size_t ws_bytes, void* stream);
+/* ... and its ring launch alone with a workspace (the workspace of the stream it is launched on). */
+int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                                        float* ws, size_t ws_bytes, void* stream);
 
 /* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
  * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz

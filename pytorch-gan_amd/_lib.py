@@ -102,6 +102,8 @@ _SIGS = {
     "migan_conv2d_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 14 + [P, c_int, P, c_int, P]),
     "migan_conv2d_dgrad_reflect1": (c_int, [P, P, P] + [c_int] * 5 + [P]),
     "migan_conv2d_dgrad_reflect1_ring": (c_int, [P, P, P] + [c_int] * 5 + [P]),
+    "migan_conv2d_dgrad_reflect1_ws": (c_int, [P, P, P] + [c_int] * 5 + [P, c_size_t, P]),
+    "migan_conv2d_dgrad_reflect1_ring_ws": (c_int, [P, P, P] + [c_int] * 5 + [P, c_size_t, P]),
     "migan_conv2d_wgrad_fuses_bias": (c_int, [c_int] * 6),
     "migan_upconv3x3_pack": (c_int, [P, P, P, c_int, c_int, P]),
     "migan_upconv3x3_fwd": (c_int, [P, P, P, P] + [c_int] * 6 + [c_float, P]),

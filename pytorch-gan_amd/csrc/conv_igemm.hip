@@ -1451,7 +1451,7 @@ MIGAN_API size_t migan_conv_splitk_workspace(void) { return igemm_dma_splitk_ws_
 // mirror allocates its per-stream workspace only then)
 MIGAN_API int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls) {
     if (Ci_src % 4 != 0 || Ci_src < 32 || Co <= 4 || maxM <= 0) return 0;
-    return (long)cdiv((long)maxM, 64) * cdiv(Co, 64) * ncls <= 128 ? 1 : 0;
+    return (long)cdiv((long)maxM, 64) * cdiv(Co, 64) * ncls <= 256 ? 1 : 0;
 }
 // migan_conv2d_fwd / migan_conv2d_dropout_fwd (mask_nc may be NULL) with a split-K workspace: under-filled GEMMs - a few
 // pixels against megabytes of weights (pix2pix/models.py:62-71), PatchGAN heads, the DCGAN discriminator - are cut along K
@@ -1572,13 +1572,24 @@ static int conv2d_dgrad_impl(const float* dy, const float* w_ihwo, const float* 
 // Returns hipErrorInvalidValue for geometries outside this case (caller uses migan_conv2d_dgrad + migan_gather2d_bwd).
 // ------------------------------------------------------------------------------------------------
 static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
-                               void* stream);
+                               void* stream, float* sk_ws = nullptr, size_t sk_bytes = 0);
 MIGAN_API int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci,
                                           int Co, void* stream) {
     if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
     int rc = migan_conv2d_dgrad(dy, w_ihwo, nullptr, dx, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.f, stream);
     if (rc) return rc;
     return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream);
+}
+// ... with a split-K workspace (migan_conv_splitk_workspace(), zero at rest, one per stream) for both launches: at one image per GPU
+// (cyclegan.py:28, the per-GPU shard of the 8-GPU configuration) the pad-1 launch is 256 64x64 tiles of 72 K-tiles each - one
+// workgroup per CU, alone with its latencies - and the ring launch 64 tiles whose corner classes walk 56 dependent K-tiles
+// (78 us for 1 % of the work, profiles/r05_cyclegan_bs1_kernel_stats.txt); cut along K both fill the chip.  ws == NULL: as above.
+MIGAN_API int migan_conv2d_dgrad_reflect1_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
+                                             float* ws, size_t ws_bytes, void* stream) {
+    if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
+    int rc = migan_conv2d_dgrad_ws(dy, w_ihwo, nullptr, dx, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.f, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream, ws, ws_bytes);
 }
 // The second launch of migan_conv2d_dgrad_reflect1 alone: ADDS the mirrored-ring terms onto a dx that already holds the
 // pad-1 input gradient (migan_conv2d_dgrad(..., 3, 3, 1, 1, 1, ...)).  It is 512 mostly tiny workgroups whose critical path is
@@ -1589,8 +1600,13 @@ MIGAN_API int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_i
     if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
     return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream);
 }
+MIGAN_API int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci,
+                                                  int Co, float* ws, size_t ws_bytes, void* stream) {
+    if (H < 4 || W < 4 || !igemm_fast_ci(Co) || Ci <= 4) return (int)hipErrorInvalidValue;
+    return dgrad_reflect1_ring(dy, w_ihwo, dx, N, H, W, Ci, Co, stream, ws, ws_bytes);
+}
 static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
-                               void* stream) {
+                               void* stream, float* sk_ws, size_t sk_bytes) {
     ConvGeom g = {};
     g.N = N; g.Hi = H; g.Wi = W; g.Ci = Co; g.HiL = H; g.WiL = W;  // source = dy (same extent as dx for 3x3 / pad 1)
     g.Co = Ci; g.HoF = H; g.WoF = W; g.ostep = 1; g.istride = 1; g.gather = GATHER_ZERO; g.ldw = 9 * Co;
@@ -1624,7 +1640,7 @@ static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, 
             ++c;
         }
     g.ncls = c;  // 16
-    return launch_igemm(g, dy, w_ihwo, nullptr, dx, (hipStream_t)stream);
+    return launch_igemm(g, dy, w_ihwo, nullptr, dx, (hipStream_t)stream, sk_ws, sk_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------

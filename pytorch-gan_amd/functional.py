@@ -47,6 +47,7 @@ _WGRAD_STREAM_MIN = 6 << 20   # (1 M and 256 k measured on SRGAN: 82.7-82.8 vs 8
 # those additions stay serial and in the order of the one-stream step.
 _WGRAD_ONE_STREAM = 0
 _PENDING_WGRAD = {}
+_CAPTURE_REFS = __import__("os").environ.get("MIGAN_CAPTURE_REFS", "1") == "1"   # A/B knob (round 5)
 _PENDING_READS = []   # tensors read by deferred weight-gradient launches of a recording in progress (see _Fork.join)
 
 
@@ -115,7 +116,7 @@ class _Fork:
             raise RuntimeError("one_wgrad_stream(): a parameter gradient without a gradient slot would be accumulated by autograd on its "
                                "own stream (the step body must own every parameter through an optimiser's bucket)")
         if self.defer and all(t is None for t in returned):
-            if torch.cuda.is_current_stream_capturing():
+            if _CAPTURE_REFS and torch.cuda.is_current_stream_capturing():
                 # inside a recording the allocator frees a block with a recorded stream use only when the capture ends: every activation
                 # and gradient a forked weight gradient reads would stay pinned for the whole recorded step.  Holding the tensors by
                 # reference until the join has the same effect on correctness (not recycled under the side launch) and releases them at
@@ -330,6 +331,20 @@ def _packed(param, w, kind, make):
         if _TWO_STREAMS and len(hit) > 2 and hit[2] is not None:   # made on the other stream of a forked step body: wait for it
             cur = torch.cuda.current_stream(w.device)
             if hit[2][0] != cur.cuda_stream:
+                if torch.cuda.is_current_stream_capturing():
+                    # Inside a recording two forked streams must never wait for EACH OTHER's events: hipStreamWaitEvent makes the waiting
+                    # stream a "parallel capture stream" of the event's stream every time, two side streams that each hit a pack the other
+                    # made end up in each other's lists, and hip::Stream::EndCapture() walks those lists recursively without marking
+                    # visited streams - unbounded recursion, SIGSEGV in hipStreamEndCapture (ROCm 7.0 runtime; rocgdb backtrace in
+                    # profiles/r05_capture_crash.txt: the CycleGAN step with the second forward chain AND the discriminator halves forked,
+                    # the PatchGAN 256 -> 512 weight - too large for the step's pack plan - packed on one and hit on the other).
+                    # While recording, a stream that did not make the pack makes its own copy instead (same bits, one more launch).
+                    own = cache.get((kind, cur.cuda_stream))
+                    if own is not None and own[0] == stamp:
+                        return own[1]
+                    t = make()
+                    cache[(kind, cur.cuda_stream)] = (stamp, t, None)
+                    return t
                 cur.wait_event(hit[2][1])
         return hit[1]
     t = make()
@@ -804,16 +819,20 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
     wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
     dx = _empty_nhwc((N, Ci, H, W), xs)
     if ring_on_side:
-        check(lib.migan_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.0,
-                                     st), "conv2d_dgrad")
+        skp, skb = _splitk_ws(dy, N * H * W, Ci, Co)
+        check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.0,
+                                        skp, skb, st), "conv2d_dgrad")
         main = torch.cuda.current_stream(xs.device)
         key = (xs.device.index, main.cuda_stream)
         if key not in _SIDE_STREAMS:
             _SIDE_STREAMS[key] = torch.cuda.Stream(xs.device)
+            ensure_splitk_ws(xs.device, _SIDE_STREAMS[key])
         side = _SIDE_STREAMS[key]
         side.wait_stream(main)
-        check(lib.migan_conv2d_dgrad_reflect1_ring(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, side.cuda_stream),
-              "conv2d_dgrad_reflect1_ring")
+        with torch.cuda.stream(side):   # the ring's split-K workspace is the side stream's own
+            skp, skb = _splitk_ws(dy, N * H * W, Ci, Co)
+        check(lib.migan_conv2d_dgrad_reflect1_ring_ws(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, skp, skb,
+                                                      side.cuda_stream), "conv2d_dgrad_reflect1_ring")
         # the closure keeps dy / wt alive until the join: they were allocated on `main`, and a tensor dropped before the
         # side-stream launch has run would be handed to the next main-stream allocation (the wgrad workspace) under it
         def join(_keep=(dy, wt, dx)):
@@ -834,7 +853,8 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
                                             Co, R, S, stride, pt, pl, 0, 0.0, skp, skb, st), "conv2d_dgrad")
     elif _reflect1_applies(ctx.geom):
         # ReflectionPad2d(1) + Conv3x3 (cyclegan/models.py:26-35): no padded intermediate, no fold pass
-        check(lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, st),
+        skp, skb = _splitk_ws(dy, N * H * W, Ci, Co)
+        check(lib.migan_conv2d_dgrad_reflect1_ws(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), N, H, W, Ci, Co, skp, skb, st),
               "conv2d_dgrad_reflect1")
     else:
         if gather == GATHER_REFLECT:

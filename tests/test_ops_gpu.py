@@ -949,11 +949,17 @@ def test_bias_grad_fused_into_wgrad(pg):
 
 
 # ------------------------------------------------------------------------------------------------ round-2 kernels
-@pytest.mark.parametrize("case", [(2, 8, 5, 4, 16), (1, 256, 12, 12, 256), (2, 64, 20, 18, 32), (3, 32, 4, 7, 40)])
+@pytest.mark.parametrize("case", [(2, 8, 5, 4, 16), (1, 256, 12, 12, 256), (2, 64, 20, 18, 32), (3, 32, 4, 7, 40), (1, 256, 64, 64, 256)])
 def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
     """ReflectionPad2d(1)+Conv3x3 input gradient: the direct form (pad-1 dgrad + added ring terms, no padded
-    intermediate; cyclegan/models.py:26-35) against torch CPU and against the padded-extent + fold path it replaces."""
+    intermediate; cyclegan/models.py:26-35) against torch CPU and against the padded-extent + fold path it replaces.
+    The 256-channel cases run both launches cut along K (migan_conv2d_dgrad_reflect1_ws): 1 x 256 x 64 x 64 is the residual trunk at one
+    image per GPU - 256 tiles of 72 K-tiles for the pad-1 launch, 64 tiles whose corner classes are 56 K-tiles deep for the ring."""
+    from util import Launches
+
     N, Ci, H, W, Co = case
+    if DEV == "cpu" and H * W > 1024:
+        pytest.skip("the trunk-sized case is for the hardware (minutes on the execution model)")
     F = pg.functional
     x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
     w = _leaf(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True)
@@ -966,7 +972,10 @@ def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
         xg = x.detach().to(DEV).requires_grad_(True)
         wg = w.detach().to(DEV).requires_grad_(True)
         y = F.conv2d(xg, wg, None, 1, (1, 1, 1, 1), F.GATHER_REFLECT)
-        y.backward(gy.to(DEV))
+        with Launches() as n:
+            y.backward(gy.to(DEV))
+            if direct and Ci == 256:   # pad-1 launch and ring launch, both through the ticketed split-K instantiation
+                assert n("2, 4, true>") >= 2, "reflect dgrad of %s was not cut along K" % (case,)
         assert_close(xg.grad, x.grad, TOL_FWD, "reflect dgrad direct=%s" % direct)
         outs.append(xg.grad.clone())
     assert_close(outs[0], outs[1], 2e-6, "direct vs padded+fold")

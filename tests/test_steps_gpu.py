@@ -245,12 +245,10 @@ def test_cyclegan_recorded_step_equals_eager_steps():
         outs = []
         random.seed(40)
         if graph:
-            runner = steps.CycleGanRunner(st, As[0], Bs[0], use_graph=True, warmup=1).prepare()   # = eager step 0
+            runner = steps.CycleGanRunner(st, As[0], Bs[0], use_graph=True, warmup=1).prepare()   # = eager step 0, then the recording
             assert runner.graphed, runner.capture_error
-            first = runner.runner.out
         else:
-            first = steps.cyclegan_step(st, As[0], Bs[0])
-        outs.append({k: v.clone() for k, v in first.items()})
+            steps.cyclegan_step(st, As[0], Bs[0])
         for t in range(1, 6):
             random.seed(40 + t)
             o = runner.run(As[t], Bs[t]) if graph else steps.cyclegan_step(st, As[t], Bs[t])

@@ -1,0 +1,176 @@
+#!/bin/bash
+# Round-5 gpurun calls:  gpurun --timeout T -- "bash tools/gpu_r05.sh <task> [args]"
+# Tasks write under gpurun_out/<dir>/ (scratch); what DESIGN.md quotes is copied into profiles/r05_*.
+# ab_base/ = `git archive c6c64d7` (the round-start tree) + its built library: git-ignored, travels with the snapshot.
+set -u
+cd ${GRAFT_REPO_ROOT:-.}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+timeout 120 python tools/gpu_sanity.py || { echo "bad box, giving up"; exit 3; }
+
+line() { python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['timing']['ms_per_step_min'], 'graph' if r['config'].get('hipgraph') else 'eager', r['config'].get('hipgraph_error',''))"; }
+
+# bench one workload:  bl <outfile> <workload> <steps> [ENV=VAL ... | --flag ...]  -> "img/s ms/step min-block"
+bl() {
+  local out=$1 w=$2 k=$3; shift 3
+  local envs=() flags=()
+  for a in "$@"; do case $a in --*|[0-9]*) flags+=("$a") ;; *) envs+=("$a") ;; esac; done
+  echo "== $w $*" >> $out
+  env "${envs[@]}" timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline "${flags[@]}" 2>>$out.err | line >> $out
+}
+
+# whole-step A/B on ONE box against the round-start tree:  ab <outfile> <workload> <steps> [reps]
+ab() {
+  local out=$1 w=$2 k=$3 reps=${4:-2}
+  for r in $(seq $reps); do
+    (cd ab_base && echo "== base $w" >> $R/$out && timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$R/$out.err | line >> $R/$out)
+    bl $out $w $k
+  done
+}
+
+# rocprofv3 --kernel-trace --stats of bench steps:  prof <outdir> <workload>[:graph][@batch] ...
+task_prof() {
+  local O=gpurun_out/${1:-r5prof}; shift
+  mkdir -p $O
+  for spec in "$@"; do
+    local b=; case $spec in *@*) b=${spec##*@}; spec=${spec%@*} ;; esac
+    w=${spec%%:*}; mode=eager; flag="--no-graph --no-overlap"; [ "$spec" != "$w" ] && { mode=graph; flag=; }
+    k=3; [ $w = dcgan ] && k=20; [ $w = pix2pix ] && k=20; [ $w = wgan_gp ] && k=50
+    tag=$w; [ -n "$b" ] && { flag="$flag --batch $b"; tag=${w}_bs$b; k=10; }
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_${tag}_$mode -o $w -- python $R/bench.py --workload $w --steps $k --warmup 2 \
+       --min-seconds 0 $flag --no-roofline --no-cpu-baseline --no-extra > $R/$O/prof_${tag}_$mode.log 2>&1)
+    db=$(ls $O/prof_${tag}_$mode/*/${w}_results.db $O/prof_${tag}_$mode/${w}_results.db 2>/dev/null | head -1)
+    a=2; [ $w = cyclegan ] && a=3; [ $w = wgan_gp ] && a=1.2
+    python tools/rocpd_stats.py $db 150 --by-grid --per-step adam_kernel=$a > $O/${tag}_${mode}_kernel_stats.txt 2>&1
+    head -4 $O/${tag}_${mode}_kernel_stats.txt
+    rm -rf $O/prof_${tag}_$mode
+  done
+}
+
+task_pmcstep() {
+  local w=$1 k=$2; shift 2
+  local O=gpurun_out/r5pmcstep_$w
+  mkdir -p $O
+  for name in "$@"; do
+    case $name in
+      sq) ctr="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" ;;
+      l2) ctr="TCC_HIT_sum TCC_MISS_sum" ;;
+      fetch) ctr="FETCH_SIZE" ;;
+      write) ctr="WRITE_SIZE" ;;
+    esac
+    mkdir -p $R/$O/$name
+    (cd /tmp && timeout 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $R/$O/$name -o p -- \
+       python $R/bench.py --workload $w --steps $k --warmup 1 --pmc-log $R/$O/$name/segments.json > $R/$O/$name.log 2>&1)
+    tail -1 $O/$name.log | cut -c1-200
+  done
+  python tools/pmc_step.py r05 $(for n in "$@"; do echo $O/$n; done) > $O/summary.txt 2>&1
+  head -30 $O/summary.txt | cut -c1-200
+  find $O -name "*.csv" -size +6M -delete
+  cp profiles/r05_pmc_kernels.json gpurun_out/r05_pmc_kernels.json 2>/dev/null
+}
+
+task_bench() {
+  local O=gpurun_out/r5bench; mkdir -p $O
+  timeout 900 python bench.py "$@" > $O/bench_default.json 2> $O/bench_default.err
+  echo "bench rc=$?"; python - <<'PY'
+import json
+r=json.loads(open('gpurun_out/r5bench/bench_default.json').read().strip().splitlines()[-1])
+print({k:r[k] for k in ('value','ms_per_step')})
+rf=r.get('roofline',{}); print({k:rf.get(k) for k in ('kernel','frac','traffic','mfma_busy_frac','symbol','avg_launch_ms')})
+print('cpu', r.get('cpu_baseline'))
+for k,v in r.get('extra',{}).items(): print(k, {a:v.get(a) for a in ('images_per_s','ms_per_step','hipgraph','eager_ms_per_step','library_launches_per_step','error','hipgraph_error')}, (v.get('cpu_baseline') or {}).get('value'))
+PY
+  tail -5 $O/bench_default.err
+}
+
+task_suite() {
+  local O=gpurun_out/r5suite; mkdir -p $O
+  timeout 1500 python -m pytest tests -m gpu -q --timeout=700 --durations=25 -rxs > $O/pytest_gpu.txt 2>&1
+  echo "pytest rc=$?" >> $O/pytest_gpu.txt
+  grep -v "^  \|^$" $O/pytest_gpu.txt | tail -60
+}
+
+task_first() {   # call 1: what the CPU cannot check - the recorded CycleGAN step, one image per GPU, both dp orders, the SRGAN fork fix
+  local O=gpurun_out/r5a; mkdir -p $O
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py tests/test_dp_gpu.py -q -x \
+     -k "cyclegan_recorded or cyclegan_256_bs1 or both_step_orders or two_ranks or second_stream or srgan_step or cyclegan_steps or world1" --durations=8 > $O/pytest.txt 2>&1
+  tail -15 $O/pytest.txt
+  bl $O/bench.txt cyclegan 10 --batch 1
+  bl $O/bench.txt cyclegan 10 --batch 1 --no-graph
+  bl $O/bench.txt cyclegan 4
+  bl $O/bench.txt cyclegan 4 --no-graph
+  ab $O/bench.txt srgan 4 1
+  cat $O/bench.txt
+  tail -5 $O/bench.txt.err 2>/dev/null
+}
+
+task_probe() {   # call 2: which fork of the CycleGAN step body the capture does not survive (segfault in hipStreamEndCapture, call 1)
+  local O=gpurun_out/r5b; mkdir -p $O
+  for cfg in "0 0 0" "0 1 0" "1 0 0" "0 0 1" "1 1 0" "1 1 1"; do
+    timeout 120 python tools/capture_probe.py $cfg >> $O/probe.txt 2>&1
+    echo "  rc=$?" >> $O/probe.txt
+  done
+  PROBE_WGRAD_MIN=4096 timeout 120 python tools/capture_probe.py 0 0 1 >> $O/probe.txt 2>&1; echo "  rc=$? (wgrad min 4096)" >> $O/probe.txt
+  PROBE_WGRAD_MIN=4096 timeout 120 python tools/capture_probe.py 1 1 1 >> $O/probe.txt 2>&1; echo "  rc=$? (wgrad min 4096)" >> $O/probe.txt
+  timeout 200 python tools/capture_probe.py 1 1 1 256 9 1 >> $O/probe.txt 2>&1; echo "  rc=$? (256, 9 blocks, bs 1)" >> $O/probe.txt
+  timeout 200 python tools/capture_probe.py 0 0 0 256 9 1 >> $O/probe.txt 2>&1; echo "  rc=$? (256, 9 blocks, bs 1)" >> $O/probe.txt
+  grep -v "amdgpu.ids\|^  File\|Extension modules" $O/probe.txt | cut -c1-220
+}
+
+task_probe2() {   # call 3: the crash needs 256x256 / 9 blocks / batch 1 with the forks on - which fork, which kernel family; native backtrace
+  local O=gpurun_out/r5c; mkdir -p $O
+  pr() { local tag=$1; shift; env "$@" > /dev/null 2>&1; }
+  run() { local note=$1; shift; timeout 200 "$@" >> $O/probe.txt 2>&1; echo "  rc=$? ($note)" >> $O/probe.txt; }
+  run "256/9/1" python tools/capture_probe.py 1 0 0 256 9 1
+  run "256/9/1" python tools/capture_probe.py 0 1 0 256 9 1
+  run "256/9/1" python tools/capture_probe.py 0 0 1 256 9 1
+  run "256/9/1" python tools/capture_probe.py 1 1 0 256 9 1
+  run "256/2/1" python tools/capture_probe.py 1 1 1 256 2 1
+  run "128/9/1" python tools/capture_probe.py 1 1 1 128 9 1
+  run "256/9/1 no toeplitz" env MIGAN_TOEPLITZ=0 python tools/capture_probe.py 1 1 1 256 9 1
+  run "256/9/1 no split-K" env MIGAN_SPLITK=0 python tools/capture_probe.py 1 1 1 256 9 1
+  run "256/9/1 record_stream instead of held references" env MIGAN_CAPTURE_REFS=0 python tools/capture_probe.py 1 1 1 256 9 1
+  grep -v "amdgpu.ids\|^  File\|Extension modules" $O/probe.txt | cut -c1-220
+  timeout 300 /opt/rocm/bin/rocgdb -batch -ex run -ex bt -ex "info threads" --args python tools/capture_probe.py 1 1 1 256 9 1 > $O/gdb.txt 2>&1
+  grep -n "SIGSEGV" -A 40 $O/gdb.txt | cut -c1-200 | head -80
+}
+
+task_fourth() {   # call 4: the capture with per-stream pack copies; then call 1's list
+  local O=gpurun_out/r5d; mkdir -p $O
+  timeout 200 python tools/capture_probe.py 1 1 1 256 9 1 > $O/probe.txt 2>&1; echo "  rc=$?" >> $O/probe.txt
+  timeout 200 python tools/capture_probe.py 1 1 1 256 9 8 >> $O/probe.txt 2>&1; echo "  rc=$?" >> $O/probe.txt
+  grep -v "amdgpu.ids\|^  File\|Extension modules" $O/probe.txt | cut -c1-220
+  task_first
+}
+
+task_fifth() {   # call 5: the tests of call 1 again (test fixed), kernel traces of the one-image CycleGAN step, eager and recorded
+  local O=gpurun_out/r5e; mkdir -p $O
+  timeout 900 python -m pytest tests/test_steps_gpu.py tests/test_fullsize_gpu.py tests/test_dp_gpu.py -q \
+     -k "cyclegan_recorded or cyclegan_256_bs1 or both_step_orders or two_ranks or second_stream or srgan_step or cyclegan_steps or world1" --durations=8 > $O/pytest.txt 2>&1
+  tail -15 $O/pytest.txt
+  task_prof r5e cyclegan@1 cyclegan:graph@1
+}
+
+task_sixth() {   # call 6: split-K reach (256 tiles x >= 64 K-tiles) and the reflect-1 ring with a workspace: parity, one image per GPU, batch 8 A/B
+  local O=gpurun_out/r5f; mkdir -p $O
+  timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q \
+     -k "reflect or splitk or cyclegan_recorded or cyclegan_256_bs1 or conv2d_fwd_bwd or geometry_selects" --durations=5 > $O/pytest.txt 2>&1
+  tail -6 $O/pytest.txt
+  bl $O/bench.txt cyclegan 10 --batch 1
+  bl $O/bench.txt cyclegan 10 --batch 1 MIGAN_SPLITK=0
+  bl $O/bench.txt cyclegan 10 --batch 1 --no-graph
+  ab $O/bench.txt cyclegan 4 1
+  bl $O/bench.txt cyclegan 4 --no-graph
+  ab $O/bench.txt pix2pix 50 1
+  cat $O/bench.txt
+}
+
+t=${1:-}; shift || true
+case "$t" in
+  first) task_first "$@" ;;
+  prof) task_prof "$@" ;;
+  pmcstep) task_pmcstep "$@" ;;
+  bench) task_bench "$@" ;;
+  suite) task_suite "$@" ;;
+  *) if declare -F "task_$t" > /dev/null; then "task_$t" "$@"; else echo "usage: gpu_r05.sh <task> [args]"; exit 2; fi ;;
+esac
