@@ -223,6 +223,25 @@ int migan_conv2d_dgrad_reflect1_ws(const float* dy, const float* w_ihwo, float* 
 int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                         float* ws, size_t ws_bytes, void* stream);
 
+/* Image-input convolutions (3 source channels, stride 1, square 3 / 7 / 9 kernel, 32 or 64 output channels, zero or reflection
+ * padding: srgan/models.py:85 Conv2d(3,64,3,1,1), vgg19.features[0] behind srgan/models.py:11, cyclegan/models.py:49-50
+ * ReflectionPad2d(3)+Conv2d(3,64,7), srgan/models.py:38 Conv2d(3,64,9,1,4)) on the MFMA units straight from staged image rows
+ * (csrc/rgb_conv.hip): K = R*S*3 is the GEMM's reduction as it is - no 32-channel tap tiles, no im2col buffer.
+ *   fwd:   x [N][H][W][3], w_hwio [R][S][3][Co] (the OIHW weight permuted (2,3,1,0)), y [N][Ho][Wo][Co] = act(conv + bias)
+ *   wgrad: dw_oihw [Co][3][R][S] and (db != NULL) db [Co] of y = act(conv(x, w) + b) from dy and the layer's OUTPUT y_act:
+ *          the activation backward g = dy * act'(y_act) and the bias column sums are part of the launch (dy, y_act read once;
+ *          y_act == NULL with act = 0: dy is the gradient of the pre-activation).  accumulate_w / accumulate_b != 0: +=.
+ *          ws >= migan_rgb_conv_wgrad_workspace(Co, R, S) bytes; fixed-order reduction (deterministic).
+ * migan_rgb_conv_ok / migan_rgb_conv_wgrad_ok: 1 when the entry takes the geometry (pixels = N*Ho*Wo). */
+int migan_rgb_conv_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels);
+int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ho, int Wo, int Co,
+                       int R, int S, int pad_t, int pad_l, int gather, int act, float slope, void* stream);
+int migan_rgb_conv_wgrad_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels);
+size_t migan_rgb_conv_wgrad_workspace(int Co, int R, int S);
+int migan_rgb_conv_wgrad(const float* x, const float* dy, const float* y_act, float* dw_oihw, float* db, float* ws, size_t ws_bytes,
+                         int N, int H, int W, int Ho, int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather, int act,
+                         float slope, int accumulate_w, int accumulate_b, void* stream);
+
 /* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
  * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz
  * expansion: the kernel column s moves into the GEMM N dimension (Co' = S*Co rounded up to 4 columns, 84 % of a 32-wide

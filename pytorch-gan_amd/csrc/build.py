@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "image_pipeline.hip", "critic_fused.hip", "mlp_fused.hip", "fewpix.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "rgb_conv.hip", "image_pipeline.hip", "critic_fused.hip", "mlp_fused.hip", "fewpix.hip"]
 HEADERS = ["common.h", "conv_geom.h"]
 OUT = os.path.join(HERE, "libmigan.so")
 STAMP = os.path.join(HERE, ".libmigan.stamp")

@@ -478,9 +478,10 @@ int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const f
             if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * ((g.Ci + 31) / 32) < minKT) minKT = g.ntap[c] * ((g.Ci + 31) / 32);
         // (a wider reach - up to 256 / 512 tiles, from 4 / 8 K-tiles - was measured on the DCGAN discriminator convs at batch 128 / 256:
         // 13.6 -> 18.2 us, 14.7 -> 23.7 us, 19.4 -> 21.7 us, the step 2.906 -> 2.931 ms; profiles/r04_ab.txt call 18)
-        // one 64x64 tile per CU with a long reduction (CycleGAN's 256 -> 256 trunk at ONE image, cyclegan.py:28: 256 tiles x 72 K-tiles, 60 us
-        // = half the rate of the batch-8 launch): two slices per tile fill the kernel's 512 slots
-        if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64) || (T64 <= 256 && minKT >= 64)) {
+        // (One 64x64 tile per CU with a long reduction - CycleGAN's 256 -> 256 trunk at ONE image, cyclegan.py:28: 256 tiles x 72 K-tiles -
+        // cut in two slices per tile was measured: 62.7 vs 60.4 us, profiles/r05_call7_cyclegan_bs1_eager_kernel_stats.txt.  A 64x64 tile
+        // fetches 16 KB per 262 kFLOP: at 16 FLOP/B the launch is bound by L2 -> LDS traffic, not by occupancy; removed.)
+        if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64)) {
             const int rc = launch_dma_small(g, A, Bw, bias, C, ab, bb, maxM, ws, ws_bytes, st);
             if (rc != -2) return rc;
         }

@@ -1,0 +1,334 @@
+// Image-input convolutions (3 source channels, stride 1) on the MFMA units without an im2col buffer and without the general
+// kernels' 32-channel K-tiles.
+//
+// Reference call sites: srgan/models.py:85 (discriminator Conv2d(3, 64, 3, 1, 1) + LeakyReLU on 384 x 384 images - three forwards and
+// two weight gradients per step), torchvision vgg19.features[0] behind srgan/models.py:11 (Conv2d(3, 64, 3, padding=1) + ReLU, two
+// forwards per step), cyclegan/models.py:49-50 (ReflectionPad2d(3) + Conv2d(3, 64, 7)), srgan/models.py:38 (Conv2d(3, 64, 9, 1, 4)).
+//
+// With Ci = 3 the reduction of a 3x3 layer is K = 27: the general implicit-GEMM kernels pad every tap to a 32-channel tile (10.7x the
+// work) and the VALU kernels that served these layers ran at 2-15 % of peak while writing or reading a 604 MB activation
+// (profiles/r04_pmc_kernels.json: forward 277 us against a 120 us store floor, weight gradient 508 us, activation backward + bias
+// column sums 351 us in a launch of their own).  In NHWC with 3 channels the S taps of one kernel row are 3*S CONTIGUOUS floats, so
+// the whole patch of a pixel is R runs: the GEMM operand is read straight out of R staged image rows in LDS.
+//
+//   forward   y[p][co] = act(b[co] + sum_k patch[p][k] * w[k][co]),  k = (r*S + s)*3 + c:
+//             M = 32 pixels per wave, N = Co in 32-column blocks, K = 27 -> 14 steps of v_mfma_f32_32x32x2_f32; a workgroup owns
+//             128 pixels of an output row (x TH rows), stages the R source rows once, keeps w [K][Co] in LDS.  Bound by the store.
+//   weight gradient, with the activation backward and the bias gradient inside:
+//             dw[co][k] = sum_p g[p][co] * patch[p][k],  g = dy * act'(y):  M = Co, N = K + 1 columns (column K is the constant 1:
+//             the bias gradient is one more column of the same product), contraction over pixels.  The A operand - 32 output
+//             channels of one pixel per half-wave - is read straight from dy and y in the MFMA's own layout (128 B per half-wave),
+//             the B operand from the staged rows.  Partial [Co][32*NBK] slabs per workgroup, then a fixed-order reduction
+//             (deterministic) that also writes the OIHW layout.  Bound by reading dy and y once.
+#include "common.h"
+
+#define RGB_TW 128   // output pixels of one row per workgroup (4 waves x 32)
+
+__device__ __forceinline__ int rgb_map(int v, int L, int reflect) {   // source coordinate or -1 (zero)
+    if (reflect) {
+        v = v < 0 ? -v : v;
+        return v >= L ? 2 * L - 2 - v : v;
+    }
+    return (unsigned)v < (unsigned)L ? v : -1;
+}
+
+struct RgbGeom {
+    int N, H, W, Ho, Wo, Co;
+    int pad_t, pad_l, reflect, act;
+    float slope;
+    int rows_per_wg;   // output rows a workgroup walks
+};
+
+// stage the R source rows of output row oh, columns [ow0 - pad_l, ow0 - pad_l + TW + S - 1), 3 channels, into xs[R][XW]
+template <int R, int S>
+__device__ __forceinline__ void rgb_stage_rows(const RgbGeom& g, const float* __restrict__ x, float* xs, int n, int oh, int ow0) {
+    constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
+    for (int e = threadIdx.x; e < R * XP * 3; e += 256) {
+        const int r = e / (XP * 3), q = e - r * (XP * 3);
+        const int j = q / 3, c = q - j * 3;
+        const int ih = rgb_map(oh + r - g.pad_t, g.H, g.reflect), iw = rgb_map(ow0 + j - g.pad_l, g.W, g.reflect);
+        float v = 0.f;
+        if (ih >= 0 && iw >= 0) v = x[((size_t)(n * g.H + ih) * g.W + iw) * 3 + c];
+        xs[r * XW + q] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int R, int S, int NB>
+__global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, const float* __restrict__ x, const float* __restrict__ wk,
+                                                           const float* __restrict__ bias, float* __restrict__ y) {
+    constexpr int K = R * S * 3, K2 = (K + 1) & ~1;
+    constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
+    extern __shared__ float rgb_lds[];
+    float* wl = rgb_lds;                 // [K2][NB * 32]
+    float* xs = rgb_lds + K2 * NB * 32;  // [R][XW]
+    const int Co = NB * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ow0 = blockIdx.x * RGB_TW, n = blockIdx.z;
+    const int oh_begin = blockIdx.y * g.rows_per_wg;
+    const int oh_end = oh_begin + g.rows_per_wg < g.Ho ? oh_begin + g.rows_per_wg : g.Ho;
+
+    for (int e = threadIdx.x; e < K2 * Co; e += 256) wl[e] = e < K * Co ? wk[e] : 0.f;   // wk is [K][Co]; row K (odd K) = 0
+    float bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = bias ? bias[nb * 32 + l31] : 0.f;
+    const int a_base = (wave * 32 + l31) * 3;
+
+    for (int oh = oh_begin; oh < oh_end; ++oh) {
+        __syncthreads();   // the previous row's reads of xs are over (and, first time round, wl is complete after the next barrier)
+        rgb_stage_rows<R, S>(g, x, xs, n, oh, ow0);
+        __syncthreads();
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < K2 / 2; ++st) {
+            // k = 2*st + kk; patch element k of pixel p sits at xs[(k / (3S)) * XW + p*3 + k % (3S)]; k >= K multiplies the zero row of wl
+            constexpr int S3 = 3 * S;
+            const int k0 = 2 * st, k1 = 2 * st + 1;
+            const int o0 = (k0 / S3) * XW + k0 % S3;
+            const int o1 = k1 < K ? (k1 / S3) * XW + k1 % S3 : o0;   // (the product with the zero row must not read a NaN: any valid word)
+            const float a = xs[a_base + (kk ? o1 : o0)];
+            const int krow = (2 * st + kk) * Co;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float b = wl[krow + nb * 32 + l31];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nb], 0, 0, 0);
+            }
+        }
+        const size_t rowbase = (size_t)(n * g.Ho + oh) * g.Wo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ow = ow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (ow >= g.Wo) continue;
+            float* o = y + (rowbase + ow) * Co + l31;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) o[nb * 32] = act_apply(acc[nb][r] + bv[nb], g.act, g.slope);
+        }
+    }
+}
+
+// 1 when the image-input kernels take this layer: 3 source channels, stride 1, square 3 / 7 / 9 kernel, 32 or 64 output channels,
+// zero or reflection padding smaller than the image, and enough pixels to be worth a launch of 128-pixel row tiles
+MIGAN_API int migan_rgb_conv_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels) {
+    if (Ci != 3 || stride != 1 || R != S || (R != 3 && R != 7 && R != 9) || (Co != 32 && Co != 64)) return 0;
+    if (gather != GATHER_ZERO && gather != GATHER_REFLECT) return 0;
+    return pixels >= 16384 ? 1 : 0;
+}
+
+static size_t rgb_fwd_lds(int R, int S, int Co) {
+    const int K2 = (R * S * 3 + 1) & ~1;
+    return ((size_t)K2 * Co + (size_t)R * ((RGB_TW + S - 1) * 3 + 1)) * sizeof(float);
+}
+
+// x [N][H][W][3], w_hwio [R][S][3][Co] (= the OIHW weight permuted (2,3,1,0)), bias [Co] or NULL, y [N][Ho][Wo][Co]
+MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ho, int Wo,
+                                 int Co, int R, int S, int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
+    if (!migan_rgb_conv_ok(3, Co, R, S, 1, gather, (long long)N * Ho * Wo) || N < 1 || N > 65535) return (int)hipErrorInvalidValue;
+    if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
+        return (int)hipErrorInvalidValue;
+    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0};
+    // rows per workgroup: the weights are staged once per workgroup - long enough walks to amortise that, enough workgroups for 8 / CU
+    const int xt = (Wo + RGB_TW - 1) / RGB_TW;
+    int th = 8;
+    while (th > 1 && (long)xt * ((Ho + th - 1) / th) * N < 2048) th >>= 1;
+    g.rows_per_wg = th;
+    const dim3 grid(xt, (Ho + th - 1) / th, N);
+    const size_t lds = rgb_fwd_lds(R, S, Co);
+#define RGB_FWD(R_, NB_)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set && lds > 48 * 1024) {                                                                               \
+            hipFuncSetAttribute((const void*)rgb_conv_fwd_kernel<R_, R_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                                \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        MIGAN_LAUNCH((rgb_conv_fwd_kernel<R_, R_, NB_>), grid, dim3(256), lds, (hipStream_t)stream, g, x, w_hwio, bias, y); \
+    } while (0)
+    if (Co == 64) {
+        if (R == 3) RGB_FWD(3, 2); else if (R == 7) RGB_FWD(7, 2); else RGB_FWD(9, 2);
+    } else {
+        if (R == 3) RGB_FWD(3, 1); else if (R == 7) RGB_FWD(7, 1); else RGB_FWD(9, 1);
+    }
+#undef RGB_FWD
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient (+ activation backward, + bias)
+// slab layout: part[wg][co][NBK * 32]; column j < K: dw of patch element j, column K: the bias gradient, beyond: zero
+template <int R, int S, int MB, int NBK>
+__global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(const RgbGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ yact, float* __restrict__ part, int tiles_x,
+                                                             int tiles_total) {
+    constexpr int K = R * S * 3, S3 = 3 * S;
+    constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
+    constexpr int J = NBK * 32;
+    static_assert(K + 1 <= J, "the bias column needs room");
+    extern __shared__ float rgb_lds[];
+    float* xs = rgb_lds;   // [R][XW]; after the walk: the workgroup's slab [MB * 32][J]
+    const int Co = MB * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+
+    f32x16 acc[MB][NBK];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // B operand of column block nbk: patch element j = nbk*32 + l31 of pixel p = wave*32 + 2*step + kk
+    int b_off[NBK];      // LDS word of that element for p = wave*32 + kk (step adds 6), or -1: the constant column / a zero column
+    float b_const[NBK];
+#pragma unroll
+    for (int nbk = 0; nbk < NBK; ++nbk) {
+        const int j = nbk * 32 + l31;
+        b_off[nbk] = j < K ? (j / S3) * XW + j % S3 + (wave * 32 + kk) * 3 : -1;
+        b_const[nbk] = j == K ? 1.f : 0.f;
+    }
+
+    // a workgroup walks the row tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... (tile = 128 pixels of one output row)
+    for (int t = blockIdx.x; t < tiles_total; t += gridDim.x) {
+        const int tx = t % tiles_x, row = t / tiles_x;   // row = n * Ho + oh
+        const int n = row / g.Ho, oh = row - n * g.Ho;
+        const int ow0 = tx * RGB_TW;
+        __syncthreads();
+        rgb_stage_rows<R, S>(g, x, xs, n, oh, ow0);
+        // this wave's 32 pixels: g = dy * act'(y) in the MFMA A layout (lane: channel l31 of block mb, pixel 2*step + kk), all loads first
+        const int pw = ow0 + wave * 32;
+        const size_t gbase = ((size_t)row * g.Wo + pw) * Co + l31;
+        float av[16][MB];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int p = 2 * st + kk;
+            const bool ok = pw + p < g.Wo;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[st][mb] = ok ? dy[gbase + (size_t)p * Co + mb * 32] : 0.f;
+        }
+        if (g.act != ACT_NONE) {
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int p = 2 * st + kk;
+                const bool ok = pw + p < g.Wo;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const float yv = ok ? yact[gbase + (size_t)p * Co + mb * 32] : 0.f;
+                    av[st][mb] *= act_grad_from_out(yv, g.act, g.slope);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            float b[NBK];
+#pragma unroll
+            for (int nbk = 0; nbk < NBK; ++nbk) b[nbk] = b_off[nbk] >= 0 ? xs[b_off[nbk] + 6 * st] : b_const[nbk];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nbk = 0; nbk < NBK; ++nbk)
+                    acc[mb][nbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][mb], b[nbk], acc[mb][nbk], 0, 0, 0);
+        }
+    }
+    // the four waves' partial products, added in wave order through LDS (a fixed order), then the slab
+    float* slab = rgb_lds;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nbk = 0; nbk < NBK; ++nbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        float* o = slab + co * J + nbk * 32 + l31;
+                        *o = w == 0 ? acc[mb][nbk][r] : *o + acc[mb][nbk][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * Co * J;
+    for (int e = threadIdx.x; e < Co * J; e += 256) out[e] = slab[e];
+}
+
+// dw_oihw[co][c][r][s] (+)= sum_wg part[wg][co][(r*S + s)*3 + c];  db[co] (+)= sum_wg part[wg][co][K]  - slabs added in index order
+__global__ __launch_bounds__(256) void rgb_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                               int nslab, int Co, int J, int R, int S, int accum_w, int accum_b) {
+    __shared__ float red[256];
+    const int K = R * S * 3;
+    const int lo = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 outputs x 16 slab groups
+    const int idx = blockIdx.x * 16 + lo;                      // (co, j), j <= K
+    const int co = idx / (K + 1), j = idx - co * (K + 1);
+    float s = 0.f;
+    if (co < Co) {
+        const float* p = part + (size_t)co * J + j;
+        const size_t stride = (size_t)Co * J;
+        const int per = (nslab + 15) / 16;
+        const int b = grp * per, e = b + per < nslab ? b + per : nslab;
+        for (int q = b; q < e; ++q) s += p[(size_t)q * stride];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && co < Co) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) s += red[q * 16 + lo];
+        if (j == K) {
+            if (db) db[co] = accum_b ? db[co] + s : s;
+        } else {
+            const int c = j % 3, t = j / 3, r = t / S, s_ = t - r * S;
+            float* o = dw + (((size_t)co * 3 + c) * R + r) * S + s_;
+            *o = accum_w ? *o + s : s;
+        }
+    }
+}
+
+#define RGB_WGRAD_WGS 512
+MIGAN_API size_t migan_rgb_conv_wgrad_workspace(int Co, int R, int S) {
+    const int J = (R * S * 3 + 1 + 31) / 32 * 32;
+    return (size_t)RGB_WGRAD_WGS * Co * J * sizeof(float);
+}
+// 1 when migan_rgb_conv_wgrad takes the layer (the 9 x 9 kernel's 8 column blocks do not fit a wave's accumulators)
+MIGAN_API int migan_rgb_conv_wgrad_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels) {
+    return migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, pixels) && R <= 7 && (R == 3 || Co == 64);
+}
+// dw_oihw [Co][3][R][S] (accumulate_w: +=) and, when db != NULL, db [Co] (accumulate_b: +=) of
+//   y = act(conv(x, w) + b):  g = dy * act'(y_act)  (y_act = the layer's OUTPUT, NULL with act = ACT_NONE: dy is used as it is),
+//   dw = sum_p g[p] (x) patch[p],  db = sum_p g[p]
+// - the activation backward and the bias column sums happen inside the weight-gradient launch: dy and y are read once, nothing is
+// written but the slabs.  ws >= migan_rgb_conv_wgrad_workspace() bytes.
+MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float* y_act, float* dw_oihw, float* db, float* ws,
+                                   size_t ws_bytes, int N, int H, int W, int Ho, int Wo, int Co, int R, int S, int pad_t, int pad_l,
+                                   int gather, int act, float slope, int accumulate_w, int accumulate_b, void* stream) {
+    if (!migan_rgb_conv_wgrad_ok(3, Co, R, S, 1, gather, (long long)N * Ho * Wo) || ws_bytes < migan_rgb_conv_wgrad_workspace(Co, R, S))
+        return (int)hipErrorInvalidValue;
+    if (act != ACT_NONE && !y_act) return (int)hipErrorInvalidValue;
+    if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
+        return (int)hipErrorInvalidValue;
+    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0};
+    const int tiles_x = (Wo + RGB_TW - 1) / RGB_TW;
+    const long tiles = (long)tiles_x * Ho * N;
+    if (tiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    const int wgs = tiles < RGB_WGRAD_WGS ? (int)tiles : RGB_WGRAD_WGS;
+    const int J = (R * S * 3 + 1 + 31) / 32 * 32;
+    const size_t rows_lds = (size_t)R * ((RGB_TW + S - 1) * 3 + 1) * sizeof(float), slab_lds = (size_t)Co * J * sizeof(float);
+    const size_t lds = rows_lds > slab_lds ? rows_lds : slab_lds;
+#define RGB_WG(R_, MB_, NBK_)                                                                                              \
+    MIGAN_LAUNCH((rgb_conv_wgrad_kernel<R_, R_, MB_, NBK_>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, g, x, dy, y_act, ws, \
+                 tiles_x, (int)tiles)
+    if (R == 3 && Co == 64) RGB_WG(3, 2, 1);
+    else if (R == 3) RGB_WG(3, 1, 1);
+    else RGB_WG(7, 2, 5);
+#undef RGB_WG
+    HIP_LAUNCH_CHECK();
+    const int outs = Co * (R * S * 3 + 1);
+    MIGAN_LAUNCH(rgb_wgrad_reduce_kernel, dim3((outs + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, db, wgs, Co, J, R, S,
+                 accumulate_w, accumulate_b);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

@@ -661,7 +661,7 @@ class _Conv2d(Function):
         ctx.geom = (N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope)
         ctx.has_bias = b is not None
         ctx.params = (w_in, b_in)
-        ctx.toep = ctx.few = False
+        ctx.toep = ctx.few = ctx.rgb = False
         if (gather == GATHER_ZERO and mask is None and stats_buf is None and w.is_contiguous()
                 and lib.migan_fewpix_ok(N * Ho * Wo, Co, Ci * R * S) == 1):
             # a handful of output pixels against megabytes of weights (inner U-Net levels, pix2pix/models.py:62-67 at batch 1):
@@ -673,6 +673,18 @@ class _Conv2d(Function):
             _fewpix_nt(col, w, b, y, M, Co, K, act, slope, st, "fewpix_conv_fwd")
             ctx.few = True
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, col)
+            return y
+        ctx.rgb = False
+        if (_RGB and mask is None and stats_buf is None and w.is_contiguous()
+                and lib.migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
+            # image-input layer (3 source channels: srgan/models.py:85, vgg19.features[0], cyclegan/models.py:50): K = R*S*3 as it is
+            # on the MFMA units, operands straight from staged image rows (csrc/rgb_conv.hip)
+            wk = _packed_perm(w_in, w, "hwio", (2, 3, 1, 0))
+            y = _empty_nhwc((N, Co, Ho, Wo), xs)
+            check(lib.migan_rgb_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ho, Wo, Co, R, S, pt, pl, gather,
+                                         act, slope, _stream()), "rgb_conv_fwd")
+            ctx.rgb = True
+            ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
             return y
         wp = _packed_perm(w_in, w, "ohwi", (0, 2, 3, 1))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
@@ -745,6 +757,27 @@ class _Conv2d(Function):
                 check(lib.migan_col2im_small(ycol.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, R, S, stride, pt, pl, 0, 0.0,
                                              st), "col2im_small")
             return dx, dw, db, None, None, None, None, None, None, None, None, None
+        if (getattr(ctx, "rgb", False) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and lib.migan_rgb_conv_wgrad_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
+            # image-input layer, weights only (the discriminator's first conv in its own update, srgan.py:129-141): the activation
+            # backward, the bias column sums and the weight gradient in ONE launch that reads dy and y once (csrc/rgb_conv.hip) -
+            # they were three passes, one of which wrote a 604 MB gradient only for the next to read it
+            fork = _Fork(xs.device, dy.numel(), True)
+            with fork:
+                slot = _grad_slot(ctx.params[0])
+                dw = torch.empty_like(w) if slot is None else slot
+                dbt, dba, db = (None, 0, None)
+                if want_db:
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                nb = lib.migan_rgb_conv_wgrad_workspace(Co, R, S)
+                ws = _ws(nb, xs)
+                check(lib.migan_rgb_conv_wgrad(xs.data_ptr(), dy.data_ptr(), _ptr(y) if act != ACT_NONE else None, dw.data_ptr(),
+                                               _ptr(dbt), ws.data_ptr(), nb, N, H, W, Ho, Wo, Co, R, S, pt, pl, gather, act, slope,
+                                               0 if slot is None else 1, dba, _stream()), "rgb_conv_wgrad")
+                if slot is not None:
+                    dw = None
+            fork.join((dw, db), (dy, xs, y))
+            return None, dw, db, None, None, None, None, None, None, None, None, None
         # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
         # (this conv's activation backward, or the norm layer behind the conv) and reduced inside the wgrad launch
         side = None
@@ -802,6 +835,7 @@ class _Conv2d(Function):
 
 
 _RING_OVERLAP = True
+_RGB = __import__("os").environ.get("MIGAN_RGB", "1") == "1"   # A/B knob (round 5): 0 = the general kernels for the 3-channel layers
 
 
 def _reflect1_applies(geom):

@@ -69,6 +69,9 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719, hipErrorNotSupported = 801 };
 static inline hipError_t hipGetLastError() { return hipemu::last_error(); }
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+// dynamic LDS beyond 64 KB needs this opt-in on the hardware; the model's dynamic LDS is sized per launch
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 #define __global__
 #define __device__

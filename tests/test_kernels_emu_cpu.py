@@ -673,6 +673,18 @@ def test_replay_buffer_planned_picks_equal_the_eager_picks(emu):
     assert torch.equal(out["eager"][1], out["planned"][1]) and torch.equal(out["eager"][1], torch.cat(ref.data))
 
 
+@pytest.mark.parametrize("idx", [0, 2, 3, 4])
+def test_image_input_conv_kernels_on_the_execution_model(idx):
+    """test_ops_gpu.py::test_rgb_conv_layers (csrc/rgb_conv.hip: forward and the fused activation-backward + bias + weight-gradient
+    launch of the 3-channel layers) on the execution model, LDS poisoned: 3x3 with ragged row tiles, 32 output channels, 7x7 under
+    reflection padding, 9x9 forward."""
+    _load_or_skip()
+    import pytorch_gan_amd as pg
+    import test_ops_gpu
+
+    _run_gpu_test_body("test_ops_gpu", "test_rgb_conv_layers", pg, test_ops_gpu.RGB_CASES[idx])
+
+
 def test_step_plans_belong_to_the_step_state(emu):
     """the plans that batch a step's weight packs / dropout masks into one launch used to be one per DEVICE, so two
     step bodies alternating on a device overwrote each other's plan every step (tables rebuilt, arena re-allocated, per-weight

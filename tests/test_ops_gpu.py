@@ -101,6 +101,62 @@ def test_conv2d_fwd_bwd(pg, case):
         assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
 
 
+RGB_CASES = [
+    # N, H, W, Co, k, pad, gather, act, what
+    (1, 110, 150, 64, 3, 1, 0, 1, "srgan/models.py:85 Conv2d(3,64,3,1,1)+LeakyReLU, ragged row tiles"),
+    (2, 96, 128, 64, 3, 1, 0, 2, "vgg19.features[0:2] Conv2d(3,64,3,padding=1)+ReLU"),
+    (1, 128, 130, 32, 3, 1, 0, 0, "32 output channels, no activation"),
+    (1, 128, 128, 64, 7, 3, 1, 0, "cyclegan/models.py:49-50 ReflectionPad2d(3)+Conv2d(3,64,7)"),
+    (1, 128, 136, 64, 9, 4, 0, 1, "srgan/models.py:38 Conv2d(3,64,9,1,4) (forward on the image-input kernel, gradients on the general ones)"),
+]
+
+
+@pytest.mark.parametrize("case", RGB_CASES, ids=["k%d_co%d_g%d_a%d" % (c[4], c[3], c[6], c[7]) for c in RGB_CASES])
+def test_rgb_conv_layers(pg, case):
+    """The image-input layers (3 source channels) on csrc/rgb_conv.hip against torch on the host: forward; the weights-only backward
+    (the discriminator's first conv in its own update: activation backward + bias column sums + weight gradient in ONE launch, asserted
+    with the launch counters); the backward with an input gradient as well (general path) - same results either way."""
+    N, H, W, Co, k, pad, gather, act, _ = case
+    F = pg.functional
+    pads = (pad,) * 4
+    x = _leaf(N, 3, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, 3, k, k, seed=2, scale=0.2).requires_grad_(True)
+    b = _leaf(Co, seed=3).requires_grad_(True)
+    y_ref = TF.conv2d(_ref_gather(x, pads, gather), w, b, 1)
+    y_ref = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act](y_ref)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    fused_ok = k <= 7
+    for want_dx in (False, True):
+        xg = x.detach().to(DEV).requires_grad_(want_dx)
+        wg = w.detach().to(DEV).requires_grad_(True)
+        bg = b.detach().to(DEV).requires_grad_(True)
+        with Launches() as n:
+            y = F.conv2d(xg, wg, bg, 1, pads, gather, act, 0.2)
+            assert n("rgb_conv_fwd_kernel") == 1, "forward not on the image-input kernel"
+            y.backward(gy.to(DEV))
+            fused = n("rgb_conv_wgrad_kernel")
+            assert fused == (1 if (fused_ok and not want_dx) else 0), (want_dx, fused)
+            if fused:
+                assert n("act_bwd") == 0 and n("colsum") == 0, "the fused launch was not alone"
+        assert_close(y, y_ref, TOL_FWD, "rgb conv fwd")
+        assert_close(wg.grad, w.grad, TOL_WGRAD, "rgb conv wgrad (dx %s)" % want_dx)
+        assert_close(bg.grad, b.grad, TOL_BIAS, "rgb conv bias grad (dx %s)" % want_dx)
+        if want_dx:
+            assert_close(xg.grad, x.grad, TOL_FWD, "rgb conv dgrad")
+    # gradient slots (the optimiser's bucket): the fused launch adds into them
+    if fused_ok:
+        wg = w.detach().to(DEV).requires_grad_(True)
+        bg = b.detach().to(DEV).requires_grad_(True)
+        wg.grad, bg.grad = torch.full_like(wg, 0.25), torch.full_like(bg, -0.5)
+        with torch.no_grad():
+            pass
+        y = F.conv2d(x.detach().to(DEV), wg, bg, 1, pads, gather, act, 0.2)
+        y.backward(gy.to(DEV))
+        assert_close(wg.grad - 0.25, w.grad, TOL_WGRAD, "rgb conv wgrad into a slot")
+        assert_close(bg.grad + 0.5, b.grad, TOL_BIAS, "rgb conv bias grad into a slot")
+
+
 def _kernel_cases():
     import kernel_cases
 

@@ -59,6 +59,8 @@ SHAPES = {
         ("D.c4 256->512 @32", 1, 256, 32, 32, 512, 4, 2, 1, 0),
     ],
     "srgan": [
+        ("D.c1 3->64 @384", 16, 3, 384, 384, 64, 3, 1, 1, 0),
+        ("G.c1 3->64 k9 @96", 16, 3, 96, 96, 64, 9, 1, 4, 0),
         ("res 64->64 @96", 16, 64, 96, 96, 64, 3, 1, 1, 0),
         ("up 64->256 @192", 16, 64, 192, 192, 256, 3, 1, 1, 0),
         ("conv3 9x9 64->3 @384", 16, 64, 384, 384, 3, 9, 1, 4, 0),
@@ -171,6 +173,21 @@ def main():
             calls["tdgrad"] = lambda: lib.migan_thin_toeplitz_dgrad(pq.data_ptr(), wtd.data_ptr() + 4 * cop * k * Ci, dxt.data_ptr(),
                                                                     wsd.data_ptr(), nbd, N, H, W, Ci, Ho, Co, k, k, p, gth, st)
             dirs += ["tfwd", "texpand", "twgrad", "tdgrad"]
+        if lib.migan_rgb_conv_ok(Ci, Co, k, k, s, gth, N * Ho * Wo) == 1:
+            # image-input layer (csrc/rgb_conv.hip): xfwd = forward with LeakyReLU; xwgrad = activation backward + bias + weight gradient
+            # in one launch (what replaces act_bwd_colsum + wgrad); abwd = the activation-backward + column-sum pass it makes unnecessary
+            wk = w.view(Co, Ci, k, k).permute(2, 3, 1, 0).contiguous()
+            bz = torch.zeros(Co, device=dev)
+            calls["xfwd"] = lambda: lib.migan_rgb_conv_fwd(x.data_ptr(), wk.data_ptr(), bz.data_ptr(), y.data_ptr(), N, H, W, Ho, Wo, Co,
+                                                           k, k, p, p, gth, 1, 0.2, st)
+            dirs += ["xfwd"]
+            if lib.migan_rgb_conv_wgrad_ok(Ci, Co, k, k, s, gth, N * Ho * Wo) == 1:
+                nbx = lib.migan_rgb_conv_wgrad_workspace(Co, k, k)
+                wsx = torch.empty(nbx // 4, device=dev)
+                db = torch.empty(Co, device=dev)
+                calls["xwgrad"] = lambda: lib.migan_rgb_conv_wgrad(x.data_ptr(), dy.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                                   wsx.data_ptr(), nbx, N, H, W, Ho, Wo, Co, k, k, p, p, gth, 1, 0.2, 0, 0, st)
+                dirs += ["xwgrad"]
         for d in dirs:
             if exact is not None:
                 if d not in exact:
@@ -181,7 +198,7 @@ def main():
             elif d[0] == "t" and d[1:] in ("fwd", "wgrad", "dgrad"):
                 if d[1:] not in only:
                     continue
-            elif d.lstrip("ur") not in only and not (d == "fold" and "dgrad" in only):
+            elif d.lstrip("urx") not in only and not (d == "fold" and "dgrad" in only):
                 continue
             fn = calls[d]
             if plog:

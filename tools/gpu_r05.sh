@@ -165,6 +165,22 @@ task_sixth() {   # call 6: split-K reach (256 tiles x >= 64 K-tiles) and the ref
   cat $O/bench.txt
 }
 
+task_rgb() {   # call 8: the image-input kernels (csrc/rgb_conv.hip): parity on the hardware, stand-alone times, SRGAN / CycleGAN whole steps
+  local O=gpurun_out/r5h; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -k "rgb_conv or srgan or test_conv2d_fwd_bwd" --durations=5 > $O/pytest.txt 2>&1
+  tail -6 $O/pytest.txt
+  timeout 200 python tools/conv_microbench.py --shapes srgan --match "3->64" --iters 20 --repeat 3 > $O/micro.txt 2>&1
+  timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "c7s1-64" --iters 20 --repeat 3 >> $O/micro.txt 2>&1
+  cat $O/micro.txt
+  for r in 1 2; do
+    bl $O/bench.txt srgan 4 MIGAN_RGB=0
+    bl $O/bench.txt srgan 4
+  done
+  bl $O/bench.txt cyclegan 4 MIGAN_RGB=0 --no-graph
+  bl $O/bench.txt cyclegan 4 --no-graph
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
