@@ -39,19 +39,39 @@ struct RgbGeom {
     int rows_per_wg;   // output rows a workgroup walks
 };
 
-// stage the R source rows of output row oh, columns [ow0 - pad_l, ow0 - pad_l + TW + S - 1), 3 channels, into xs[R][XW]
+// The R source rows of output row oh, columns [ow0 - pad_l, ow0 - pad_l + TW + S - 1), 3 channels -> xs[R][XW].  Two halves: load() puts
+// this thread's elements into registers with EVERY load issued before the first use (a padded element reads word 0 of the tensor and is
+// replaced by zero: no branch, no wait between loads), store() writes them to LDS - callers put the previous tile's arithmetic between
+// the two, so the fetch of tile t+1 runs under the MFMAs and stores of tile t.
 template <int R, int S>
-__device__ __forceinline__ void rgb_stage_rows(const RgbGeom& g, const float* __restrict__ x, float* xs, int n, int oh, int ow0) {
-    constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
-    for (int e = threadIdx.x; e < R * XP * 3; e += 256) {
-        const int r = e / (XP * 3), q = e - r * (XP * 3);
-        const int j = q / 3, c = q - j * 3;
-        const int ih = rgb_map(oh + r - g.pad_t, g.H, g.reflect), iw = rgb_map(ow0 + j - g.pad_l, g.W, g.reflect);
-        float v = 0.f;
-        if (ih >= 0 && iw >= 0) v = x[((size_t)(n * g.H + ih) * g.W + iw) * 3 + c];
-        xs[r * XW + q] = v;
+struct RgbStage {
+    static constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1, NE = R * XP * 3, NL = (NE + 255) / 256;
+    float v[NL];
+    __device__ __forceinline__ void load(const RgbGeom& g, const float* __restrict__ x, int n, int oh, int ow0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int e = (int)threadIdx.x + i * 256;
+            e = e < NE ? e : NE - 1;
+            const int r = e / (XP * 3), q = e - r * (XP * 3);
+            const int j = q / 3, c = q - j * 3;
+            const int ih = rgb_map(oh + r - g.pad_t, g.H, g.reflect), iw = rgb_map(ow0 + j - g.pad_l, g.W, g.reflect);
+            const bool ok = (ih | iw) >= 0;
+            const size_t idx = ok ? ((size_t)(n * g.H + ih) * g.W + iw) * 3 + c : 0;
+            const float t = x[idx];
+            v[i] = ok ? t : 0.f;
+        }
     }
-}
+    __device__ __forceinline__ void store(float* xs) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = (int)threadIdx.x + i * 256;
+            if (e < NE) {
+                const int r = e / (XP * 3), q = e - r * (XP * 3);
+                xs[r * XW + q] = v[i];
+            }
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int R, int S, int NB>
@@ -74,11 +94,17 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bv[nb] = bias ? bias[nb * 32 + l31] : 0.f;
     const int a_base = (wave * 32 + l31) * 3;
+    // none / LeakyReLU / ReLU as one select (negative-side factor 1 / slope / 0); tanh and sigmoid through act_apply
+    const bool simple = g.act <= ACT_RELU;
+    const float ns = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);
 
+    RgbStage<R, S> stage;
+    if (oh_begin < oh_end) stage.load(g, x, n, oh_begin, ow0);
     for (int oh = oh_begin; oh < oh_end; ++oh) {
-        __syncthreads();   // the previous row's reads of xs are over (and, first time round, wl is complete after the next barrier)
-        rgb_stage_rows<R, S>(g, x, xs, n, oh, ow0);
-        __syncthreads();
+        __syncthreads();   // the previous row's reads of xs are over (first time round: nothing)
+        stage.store(xs);
+        __syncthreads();   // xs (and, first time round, wl) complete
+        if (oh + 1 < oh_end) stage.load(g, x, n, oh + 1, ow0);   // in flight under this row's MFMAs and stores
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -106,7 +132,10 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
             if (ow >= g.Wo) continue;
             float* o = y + (rowbase + ow) * Co + l31;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) o[nb * 32] = act_apply(acc[nb][r] + bv[nb], g.act, g.slope);
+            for (int nb = 0; nb < NB; ++nb) {
+                const float v = acc[nb][r] + bv[nb];
+                o[nb * 32] = simple ? (v > 0.f ? v : v * ns) : act_apply(v, g.act, g.slope);
+            }
         }
     }
 }
@@ -160,10 +189,12 @@ MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const floa
 
 // ------------------------------------------------------------------------------------------------ weight gradient (+ activation backward, + bias)
 // slab layout: part[wg][co][NBK * 32]; column j < K: dw of patch element j, column K: the bias gradient, beyond: zero
-template <int R, int S, int MB, int NBK>
+// HAS_ACT: g = dy * (y > 0 ? 1 : ns) with ns = slope (LeakyReLU) or 0 (ReLU) - the only activations an image-input layer of the
+// reference carries (srgan/models.py:85 LeakyReLU(0.2), vgg19.features[1] ReLU); false: dy is the gradient of the pre-activation
+template <int R, int S, int MB, int NBK, bool HAS_ACT>
 __global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(const RgbGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ yact, float* __restrict__ part, int tiles_x,
-                                                             int tiles_total) {
+                                                             int tiles_total, float ns) {
     constexpr int K = R * S * 3, S3 = 3 * S;
     constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
     constexpr int J = NBK * 32;
@@ -193,46 +224,52 @@ __global__ __launch_bounds__(256) void rgb_conv_wgrad_kernel(const RgbGeom g, co
     }
 
     // a workgroup walks the row tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... (tile = 128 pixels of one output row)
-    for (int t = blockIdx.x; t < tiles_total; t += gridDim.x) {
+    RgbStage<R, S> stage;
+    int t = blockIdx.x;
+    if (t < tiles_total) {
+        const int row = t / tiles_x;
+        stage.load(g, x, row / g.Ho, row % g.Ho, (t % tiles_x) * RGB_TW);
+    }
+    for (; t < tiles_total; t += gridDim.x) {
         const int tx = t % tiles_x, row = t / tiles_x;   // row = n * Ho + oh
-        const int n = row / g.Ho, oh = row - n * g.Ho;
         const int ow0 = tx * RGB_TW;
-        __syncthreads();
-        rgb_stage_rows<R, S>(g, x, xs, n, oh, ow0);
-        // this wave's 32 pixels: g = dy * act'(y) in the MFMA A layout (lane: channel l31 of block mb, pixel 2*step + kk), all loads first
+        // this wave's 32 pixels: g = dy * act'(y) in the MFMA A layout (lane: channel l31 of block mb, pixel 2*step + kk).  Every load is
+        // issued before the first use; a pixel beyond the row reads a valid word and is replaced by zero (no branch between loads)
         const int pw = ow0 + wave * 32;
         const size_t gbase = ((size_t)row * g.Wo + pw) * Co + l31;
-        float av[16][MB];
+        float av[16][MB], yv[HAS_ACT ? 16 : 1][MB];
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             const int p = 2 * st + kk;
-            const bool ok = pw + p < g.Wo;
+            const size_t idx = pw + p < g.Wo ? gbase + (size_t)p * Co : (size_t)l31;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[st][mb] = ok ? dy[gbase + (size_t)p * Co + mb * 32] : 0.f;
-        }
-        if (g.act != ACT_NONE) {
-#pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int p = 2 * st + kk;
-                const bool ok = pw + p < g.Wo;
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const float yv = ok ? yact[gbase + (size_t)p * Co + mb * 32] : 0.f;
-                    av[st][mb] *= act_grad_from_out(yv, g.act, g.slope);
-                }
+            for (int mb = 0; mb < MB; ++mb) {
+                av[st][mb] = dy[idx + mb * 32];
+                if (HAS_ACT) yv[st][mb] = yact[idx + mb * 32];
             }
         }
+        __syncthreads();   // the previous tile's reads of xs are over
+        stage.store(xs);
         __syncthreads();
+        const int tn = t + (int)gridDim.x;
+        if (tn < tiles_total) {   // the next tile's image rows: in flight under this tile's MFMAs
+            const int rown = tn / tiles_x;
+            stage.load(g, x, rown / g.Ho, rown % g.Ho, (tn % tiles_x) * RGB_TW);
+        }
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
+            const bool ok = pw + 2 * st + kk < g.Wo;
             float b[NBK];
 #pragma unroll
             for (int nbk = 0; nbk < NBK; ++nbk) b[nbk] = b_off[nbk] >= 0 ? xs[b_off[nbk] + 6 * st] : b_const[nbk];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb) {
+                float a = ok ? av[st][mb] : 0.f;
+                if (HAS_ACT) a *= yv[st][mb] > 0.f ? 1.f : ns;
 #pragma unroll
                 for (int nbk = 0; nbk < NBK; ++nbk)
-                    acc[mb][nbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st][mb], b[nbk], acc[mb][nbk], 0, 0, 0);
+                    acc[mb][nbk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nbk], acc[mb][nbk], 0, 0, 0);
+            }
         }
     }
     // the four waves' partial products, added in wave order through LDS (a fixed order), then the slab
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(256) void rgb_wgrad_reduce_kernel(const float* __re
     }
 }
 
-#define RGB_WGRAD_WGS 512
+#define RGB_WGRAD_WGS 1024
 MIGAN_API size_t migan_rgb_conv_wgrad_workspace(int Co, int R, int S) {
     const int J = (R * S * 3 + 1 + 31) / 32 * 32;
     return (size_t)RGB_WGRAD_WGS * Co * J * sizeof(float);
@@ -307,7 +344,7 @@ MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float*
                                    int gather, int act, float slope, int accumulate_w, int accumulate_b, void* stream) {
     if (!migan_rgb_conv_wgrad_ok(3, Co, R, S, 1, gather, (long long)N * Ho * Wo) || ws_bytes < migan_rgb_conv_wgrad_workspace(Co, R, S))
         return (int)hipErrorInvalidValue;
-    if (act != ACT_NONE && !y_act) return (int)hipErrorInvalidValue;
+    if (act != ACT_NONE && (!y_act || (act != ACT_LRELU && act != ACT_RELU))) return (int)hipErrorInvalidValue;
     if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
         return (int)hipErrorInvalidValue;
     RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0};
@@ -318,9 +355,16 @@ MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float*
     const int J = (R * S * 3 + 1 + 31) / 32 * 32;
     const size_t rows_lds = (size_t)R * ((RGB_TW + S - 1) * 3 + 1) * sizeof(float), slab_lds = (size_t)Co * J * sizeof(float);
     const size_t lds = rows_lds > slab_lds ? rows_lds : slab_lds;
-#define RGB_WG(R_, MB_, NBK_)                                                                                              \
-    MIGAN_LAUNCH((rgb_conv_wgrad_kernel<R_, R_, MB_, NBK_>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, g, x, dy, y_act, ws, \
-                 tiles_x, (int)tiles)
+    const float ns = act == ACT_LRELU ? slope : 0.f;
+#define RGB_WG(R_, MB_, NBK_)                                                                                                     \
+    do {                                                                                                                          \
+        if (act != ACT_NONE)                                                                                                      \
+            MIGAN_LAUNCH((rgb_conv_wgrad_kernel<R_, R_, MB_, NBK_, true>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, g, x, dy, \
+                         y_act, ws, tiles_x, (int)tiles, ns);                                                                     \
+        else                                                                                                                      \
+            MIGAN_LAUNCH((rgb_conv_wgrad_kernel<R_, R_, MB_, NBK_, false>), dim3(wgs), dim3(256), lds, (hipStream_t)stream, g, x,    \
+                         dy, y_act, ws, tiles_x, (int)tiles, ns);                                                                 \
+    } while (0)
     if (R == 3 && Co == 64) RGB_WG(3, 2, 1);
     else if (R == 3) RGB_WG(3, 1, 1);
     else RGB_WG(7, 2, 5);

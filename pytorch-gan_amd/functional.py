@@ -758,6 +758,7 @@ class _Conv2d(Function):
                                              st), "col2im_small")
             return dx, dw, db, None, None, None, None, None, None, None, None, None
         if (getattr(ctx, "rgb", False) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
                 and lib.migan_rgb_conv_wgrad_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
             # image-input layer, weights only (the discriminator's first conv in its own update, srgan.py:129-141): the activation
             # backward, the bias column sums and the weight gradient in ONE launch that reads dy and y once (csrc/rgb_conv.hip) -
