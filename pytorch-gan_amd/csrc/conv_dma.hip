@@ -27,6 +27,22 @@
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// GEMM row m of class cls -> (image, class-local output row, column); see ConvGeom::m2d
+__device__ __forceinline__ void dma_decode_m(const ConvGeom& g, int cls, int m, int Ho, int Wo, int& n, int& oi, int& oj) {
+    n = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);   // 128-pixel blocks do not straddle images (Ho * Wo % 128 == 0)
+    const int rem = m - n * Ho * Wo;
+    if (g.m2d) {
+        const int blk = rem >> 7, i = rem & 127;
+        const int bi = fastdiv(blk << 4, g.mg_w[cls], g.sh_w[cls]);   // blk / (Wo / 16)
+        const int bj = blk - bi * (Wo >> 4);
+        oi = bi * 8 + (i >> 4);
+        oj = bj * 16 + (i & 15);
+    } else {
+        oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]);
+        oj = rem - oi * Wo;
+    }
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p, unsigned bytes) {
     // wave-uniform by construction (kernel arguments): no waterfall loop around the buffer ops
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -105,9 +121,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
         a_base[i] = 0;
         a_pos[i] = 0;
         if (m < M) {
-            const int n = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
-            const int rem = m - n * Ho * Wo;
-            const int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
+            int n, oi, oj;
+            dma_decode_m(g, cls, m, Ho, Wo, n, oi, oj);
             a_base[i] = n * Hi * Wi;
             a_pos[i] = ((oi * g.istride) << 16) | (oj * g.istride);
             rowok |= 1u << i;
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     }
 
     // ---- epilogue (igemm_pipe_kernel's): bias + activation + optional [N][Co] mask, strided class scatter, accumulate
-    const bool linear_out = (g.ostep == 1 && g.ncls == 1);
+    const bool linear_out = (g.ostep == 1 && g.ncls == 1 && !g.m2d);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -320,9 +335,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             if (linear_out && !g.oscale) {
                 opix = (size_t)m;
             } else {
-                n_img = fastdiv(m, g.mg_hw[cls], g.sh_hw[cls]);
-                const int rem = m - n_img * Ho * Wo;
-                const int oi = fastdiv(rem, g.mg_w[cls], g.sh_w[cls]), oj = rem - oi * Wo;
+                int oi, oj;
+                dma_decode_m(g, cls, m, Ho, Wo, n_img, oi, oj);
                 opix = ((size_t)n_img * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
             }
 #pragma unroll
@@ -453,8 +467,26 @@ static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, 
 
 // Returns -2 when this geometry is not taken by the LDS-DMA kernels (the caller falls through to igemm_pipe_kernel),
 // otherwise the launch status.
-int launch_igemm_dma(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, float* ws,
+int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C, float* ws,
                      size_t ws_bytes, hipStream_t st) {
+    ConvGeom g = g_in;
+    {
+        // 8 x 16-pixel M blocks (ConvGeom::m2d) for tall column kernels - the R x 1 GEMM of the width-Toeplitz forward (R = 7 / 9, one
+        // column): MIGAN_M2D=0 off, 1 (default) those, 2 every stride-1 one-class geometry with >= 3 kernel rows (A/B knob, round 5)
+        static const int m2d_env = getenv("MIGAN_M2D") ? atoi(getenv("MIGAN_M2D")) : 1;
+        int rows = 0, cols = 0;   // kernel extent from the tap offsets
+        if (g.ncls == 1 && g.ntap[0] > 0) {
+            int dh0 = 1 << 20, dh1 = -(1 << 20), dw0 = 1 << 20, dw1 = -(1 << 20);
+            for (int t = 0; t < g.ntap[0]; ++t) {
+                dh0 = g.dh[t] < dh0 ? g.dh[t] : dh0; dh1 = g.dh[t] > dh1 ? g.dh[t] : dh1;
+                dw0 = g.dw[t] < dw0 ? g.dw[t] : dw0; dw1 = g.dw[t] > dw1 ? g.dw[t] : dw1;
+            }
+            rows = dh1 - dh0 + 1; cols = dw1 - dw0 + 1;
+        }
+        const bool shape_ok = g.ncls == 1 && g.ostep == 1 && g.istride == 1 && !g.accum && g.gather != GATHER_UP2 && g.Ho[0] % 8 == 0 &&
+                              g.Wo[0] % 16 == 0 && g.oh0[0] == 0 && g.ow0[0] == 0 && (long)g.N * g.Ho[0] * g.Wo[0] >= 1024;
+        g.m2d = shape_ok && ((m2d_env >= 1 && cols == 1 && rows >= 5) || (m2d_env >= 2 && rows >= 3)) ? 1 : 0;
+    }
     if (g.stats || g.swz) return -2;
     if (g.Ci % 4 != 0 || g.Ci < 32 || g.ldw % 4 != 0 || g.Co <= 4) return -2;
     for (int c = 0; c < g.ncls; ++c)

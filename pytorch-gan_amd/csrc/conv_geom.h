@@ -14,6 +14,12 @@ struct ConvGeom {
     int ostep, istride;  // output sub-grid step (parity classes), source step per output index
     int gather, ldw, ncls;
     int accum;           // epilogue adds into the output instead of storing (border-correction launch of the reflection dgrad)
+    // LDS-DMA kernels only, one class, Ho % 8 == 0, Wo % 16 == 0: GEMM row m counts pixels in 128-pixel blocks of 8 rows x 16 columns
+    // (m = block * 128 + local_row * 16 + local_col, blocks row-major over an image) instead of row-major over the image.  A 128-row
+    // M-tile then touches 8 + R - 1 source rows of 16 columns for its R vertical taps instead of R x 128 distinct pixels: the tall
+    // R x 1 GEMM of the width-Toeplitz forward (thin_toeplitz.hip) fetched every image row 9 times (6.0 GB against 0.63 GB of operands,
+    // profiles/r04_pmc_kernels.json), here the re-reads of a tile are 8 of its own 16 rows.  Set by launch_igemm.
+    int m2d;
     // XCD-aware tile order of igemm_pipe_kernel (filled by launch_pipe behind the constant xcd_env, measured without gain in profiles/r02_ab.txt): swz != 0 -> 1-D grid of
     // 8 * per * ntn * ncls workgroups; workgroup L runs on XCD L % 8 and takes M-tile (L % 8) * per + k of that XCD's
     // CONTIGUOUS eighth of the image, with (N-tile, class) fastest: every consumer of one pixel neighbourhood - the 9 taps of

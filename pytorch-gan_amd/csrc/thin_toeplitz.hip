@@ -33,7 +33,10 @@ MIGAN_API int migan_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw
 MIGAN_API int migan_gather2d_bwd(const float* dy, float* dx, int N, int Hi, int Wi, int C, int Ho, int Wo, int pad_t,
                                  int pad_l, int mode, void* stream);
 
-static inline int toep_cols(int Co, int S) { return (S * Co + 3) / 4 * 4; }
+// Row length Co' of wt / P / Q: S*Co (16..32) padded to 32.  (Round 5: it was the next multiple of 4 - 28 for the 9x9, 24 for the 7x7
+// layer.  With 32 the input-gradient GEMM - source channels = Co' - is taken by the LDS-DMA kernels, which want >= 32 source channels and
+// whole 32-channel K-tiles; the forward GEMM's N tile is 32 wide either way.  P / Q grow by 14 % / 33 %.)
+static inline int toep_cols(int Co, int S) { return S * Co <= 32 ? 32 : (S * Co + 3) / 4 * 4; }
 
 // 1 when the expansion applies AND pays: <= 4 output channels, stride 1, 16 <= S*Co <= 32 columns (at least half of a
 // 32-wide MFMA tile: 7x7 and 9x9 kernels with 3 channels; a 3x3 kernel fills 28 % and stays on thin_conv_kernel), a
@@ -42,7 +45,7 @@ MIGAN_API int migan_thin_toeplitz_ok(int Co, int R, int S, int Ci, int stride, i
     return Co >= 1 && Co <= 4 && stride == 1 && S * Co >= 16 && S * Co <= 32 && R >= 1 && R <= 16 && Ci % 4 == 0 && Ci >= 16 &&
            (gather == GATHER_ZERO || gather == GATHER_REFLECT);
 }
-// Co' = S*Co rounded up to a multiple of 4 (row length of wt / P / Q)
+// Co' = 32 (row length of wt / P / Q)
 MIGAN_API int migan_thin_toeplitz_cols(int Co, int S) { return toep_cols(Co, S); }
 // bytes of the P (forward) / Q (backward) buffer
 MIGAN_API size_t migan_thin_toeplitz_workspace(int N, int Ho, int Wi, int Co, int S) {
@@ -155,6 +158,166 @@ MIGAN_API int migan_thin_toeplitz_expand(const float* dy, float* q, int N, int H
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the R x 1 convolution with the image rows kept in LDS (round 5).
+// The general weight-gradient kernel sees dwt[(s,co)][(r,c)] = sum_p Q[p][(s,co)] * x[p + (r - pad_t) rows][c] as a GEMM with M = Co' = 28
+// rows - its 64-row tiles are 56 % padding - and N = R * Ci columns cut into tiles per tap r, each of which fetches "its" source row per
+// K-tile: every image row is fetched R times (profiles/r04_pmc_kernels.json: 1.45 ms, 5.0 GB against 0.87 GB of operands, MFMA busy on
+// twice the necessary work).  Here a workgroup owns a 16-pixel-wide column strip of one image and WALKS DOWN it: the R source rows of the
+// current output row sit in an LDS ring of R + 1 slots, each step fetches ONE new row (4 KB) and one Q row (1.8 KB) while the previous
+// ones are multiplied, and the whole N = R * 64 columns belong to the workgroup (each wave a fixed set of 32-column blocks, so no
+// cross-wave sum).  M = 32 rows: 28 / 32 of the MFMA work is real.  Partial [32][R*64] slabs per workgroup, one fixed-order fold.
+// ------------------------------------------------------------------------------------------------
+#define TWR_PX 16
+struct ToepRingGeom {
+    int N, Hi, Wi, Ho, Co, Cop, S, pad_t, reflect;
+    int rows_per_seg, segs;
+};
+template <int R, int NBW>   // NBW = 32-column blocks per wave; waves = 2 * R / NBW
+__global__ __launch_bounds__(64 * (2 * R / NBW)) void toep_wgrad_ring_kernel(const ToepRingGeom g, const float* __restrict__ x,
+                                                                              const float* __restrict__ q, float* __restrict__ part) {
+    constexpr int CI = 64, NSLOT = R + 1, ROWF = TWR_PX * CI;   // floats per ring slot
+    constexpr int NT = 64 * (2 * R / NBW);
+    __shared__ __attribute__((aligned(16))) float ring[NSLOT * ROWF];
+    __shared__ __attribute__((aligned(16))) float qs[2 * TWR_PX * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int strips = g.Wi / TWR_PX;
+    int wg = blockIdx.x;
+    const int seg = wg % g.segs;
+    wg /= g.segs;
+    const int strip = wg % strips, n = wg / strips;
+    const int u0 = strip * TWR_PX;
+    const int oi0 = seg * g.rows_per_seg;
+    const int oi1 = oi0 + g.rows_per_seg < g.Ho ? oi0 + g.rows_per_seg : g.Ho;
+
+    // loader roles: threads 0..255 one 16-byte chunk of an image row (pixel tid / 16, channels 4 * (tid % 16) ..), the next
+    // 16 * Cop / 4 threads one chunk of a Q row
+    const int q4 = g.Cop >> 2;
+    const bool x_role = tid < 256, q_role = tid >= 256 && tid < 256 + TWR_PX * q4;
+    const int xp = tid >> 4, xc = (tid & 15) * 4;
+    const int qi = tid - 256, qp = q_role ? qi / q4 : 0, qc = q_role ? (qi - qp * q4) * 4 : 0;
+    auto load_x = [&](int v) -> f32x4 {   // virtual (padded) row v of the strip
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        int ih = v;
+        bool ok = x_role;
+        if (g.reflect) {
+            ih = ih < 0 ? -ih : ih;
+            ih = ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih;
+        } else {
+            ok = ok && (unsigned)ih < (unsigned)g.Hi;
+        }
+        if (ok) r4 = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * g.Hi + ih) * g.Wi + u0 + xp) * CI + xc);
+        return r4;
+    };
+    auto load_q = [&](int oi) -> f32x4 {
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        if (q_role && oi < oi1) r4 = *reinterpret_cast<const f32x4*>(q + ((size_t)(n * g.Ho + oi) * g.Wi + u0 + qp) * g.Cop + qc);
+        return r4;
+    };
+    auto slot_of = [&](int v) { return (v + 4 * NSLOT) % NSLOT; };   // v >= -pad_t > -4 * NSLOT
+
+    for (int e = tid; e < 2 * TWR_PX * 32; e += NT) qs[e] = 0.f;   // columns Cop .. 31 stay zero
+    __syncthreads();
+    // the R rows of the first output row, and its Q row
+    if (oi0 < oi1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f32x4 t = load_x(oi0 - g.pad_t + r);
+            if (x_role) *reinterpret_cast<f32x4*>(ring + slot_of(oi0 - g.pad_t + r) * ROWF + xp * CI + xc) = t;
+        }
+        const f32x4 t = load_q(oi0);
+        if (q_role) *reinterpret_cast<f32x4*>(qs + qp * 32 + qc) = t;
+    }
+    __syncthreads();
+
+    f32x16 acc[NBW];
+#pragma unroll
+    for (int b = 0; b < NBW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    int cur = 0;
+    for (int oi = oi0; oi < oi1; ++oi) {
+        // the row the NEXT output row adds, and its Q row: in flight under this row's MFMAs
+        const int vnew = oi - g.pad_t + R;
+        const bool more = oi + 1 < oi1;
+        f32x4 nx = {0.f, 0.f, 0.f, 0.f}, nq = {0.f, 0.f, 0.f, 0.f};
+        if (more) {
+            nx = load_x(vnew);
+            nq = load_q(oi + 1);
+        }
+        const float* qb = qs + cur * (TWR_PX * 32);
+        float a[TWR_PX / 2];
+#pragma unroll
+        for (int st = 0; st < TWR_PX / 2; ++st) a[st] = qb[(2 * st + kk) * 32 + l31];
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+            const int blk = wave * NBW + b;            // (tap r, channel half)
+            const int r = blk >> 1, ch = blk & 1;
+            const float* rb = ring + slot_of(oi - g.pad_t + r) * ROWF + ch * 32 + l31;
+#pragma unroll
+            for (int st = 0; st < TWR_PX / 2; ++st)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], rb[(2 * st + kk) * CI], acc[b], 0, 0, 0);
+        }
+        if (more) {   // the free slot (the row that left the window with the previous output row) and the other Q buffer
+            if (x_role) *reinterpret_cast<f32x4*>(ring + slot_of(vnew) * ROWF + xp * CI + xc) = nx;
+            if (q_role) *reinterpret_cast<f32x4*>(qs + (cur ^ 1) * (TWR_PX * 32) + qp * 32 + qc) = nq;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // slab [32][R * 64]: this wave's column blocks
+    float* out = part + (size_t)blockIdx.x * 32 * (R * CI);
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int blk = wave * NBW + b;
+        const int col = (blk >> 1) * CI + (blk & 1) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            out[(size_t)row * (R * CI) + col] = acc[b][r];
+        }
+    }
+}
+// dw[co][c][r][s] (+)= sum_wg part[wg][s * Co + co][r * 64 + c], slabs added in index order
+__global__ __launch_bounds__(256) void toep_ring_fold_kernel(const float* __restrict__ part, float* __restrict__ dw, int nslab, int Co,
+                                                             int R, int S, int accum) {
+    __shared__ float red[256];
+    const int lo = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int NC = R * 64, total = S * Co * NC;
+    const int e = blockIdx.x * 16 + lo;
+    float s = 0.f;
+    if (e < total) {
+        const size_t stride = (size_t)32 * NC;
+        const int per = (nslab + 15) / 16;
+        const int b = grp * per, en = b + per < nslab ? b + per : nslab;
+        for (int w = b; w < en; ++w) s += part[(size_t)w * stride + e];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0 && e < total) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k * 16 + lo];
+        const int row = e / NC, rem = e - row * NC;
+        const int r = rem >> 6, c = rem & 63;
+        const int s_ = row / Co, co = row - s_ * Co;
+        float* o = dw + (((size_t)co * 64 + c) * R + r) * S + s_;
+        *o = accum ? *o + s : s;
+    }
+}
+static bool toep_ring_ok(int Co, int R, int S, int Ci, int Wi, int Cop) {
+    return Ci == 64 && (R == 7 || R == 9) && R == S && Wi % TWR_PX == 0 && Cop <= 32 && S * Co <= 32;
+}
+static void toep_ring_plan(int N, int Wi, int Ho, int& segs, int& rows) {
+    const int strips = N * (Wi / TWR_PX);
+    segs = (768 + strips - 1) / strips;          // about three workgroups per CU
+    if (segs < 1) segs = 1;
+    if (segs > Ho / 16) segs = Ho / 16 > 0 ? Ho / 16 : 1;   // a walk re-fetches R - 1 rows at its start: at least 16 rows long
+    rows = (Ho + segs - 1) / segs;
+    segs = (Ho + rows - 1) / rows;
+}
+
 // dw[co][c][r][s] (+)= dwt[(s*Co + co)][c][r]
 __global__ void toep_fold_dw_kernel(const float* __restrict__ dwt, float* __restrict__ dw, int Co, int Ci, int R, int S,
                                     int accum) {
@@ -166,7 +329,14 @@ __global__ void toep_fold_dw_kernel(const float* __restrict__ dwt, float* __rest
 }
 MIGAN_API size_t migan_thin_toeplitz_wgrad_workspace(int N, int Ho, int Wi, int Ci, int Co, int R, int S) {
     const int Cop = toep_cols(Co, S);
-    return (size_t)Cop * Ci * R * sizeof(float) + migan_conv2d_wgrad_workspace(N, Ho, Wi, Cop, R, 1, Ci);
+    size_t general = (size_t)Cop * Ci * R * sizeof(float) + migan_conv2d_wgrad_workspace(N, Ho, Wi, Cop, R, 1, Ci);
+    if (toep_ring_ok(Co, R, S, Ci, Wi, Cop)) {
+        int segs, rows;
+        toep_ring_plan(N, Wi, Ho, segs, rows);
+        const size_t ring = (size_t)N * (Wi / TWR_PX) * segs * 32 * R * 64 * sizeof(float);
+        if (ring > general) general = ring;
+    }
+    return general;
 }
 // weight gradient: x [N][Hi][Wi][Ci], q from migan_thin_toeplitz_expand, dw_oihw [Co][Ci][R][S] (accumulate != 0: +=)
 MIGAN_API int migan_thin_toeplitz_wgrad(const float* x, const float* q, float* dw_oihw, float* ws, size_t ws_bytes, int N, int Hi,
@@ -175,6 +345,20 @@ MIGAN_API int migan_thin_toeplitz_wgrad(const float* x, const float* q, float* d
     if (!migan_thin_toeplitz_ok(Co, R, S, Ci, 1, gather) || ws_bytes < migan_thin_toeplitz_wgrad_workspace(N, Ho, Wi, Ci, Co, R, S))
         return (int)hipErrorInvalidValue;
     const int Cop = toep_cols(Co, S);
+    static const int ring_env = getenv("MIGAN_TOEP_RING") ? atoi(getenv("MIGAN_TOEP_RING")) : 1;   // A/B knob (round 5)
+    if (ring_env && toep_ring_ok(Co, R, S, Ci, Wi, Cop)) {
+        ToepRingGeom g = {N, Hi, Wi, Ho, Co, Cop, S, pad_t, gather == GATHER_REFLECT, 0, 0};
+        toep_ring_plan(N, Wi, Ho, g.segs, g.rows_per_seg);
+        const int wgs = N * (Wi / TWR_PX) * g.segs;
+        if (R == 9) MIGAN_LAUNCH((toep_wgrad_ring_kernel<9, 3>), dim3(wgs), dim3(384), 0, (hipStream_t)stream, g, x, q, ws);
+        else MIGAN_LAUNCH((toep_wgrad_ring_kernel<7, 2>), dim3(wgs), dim3(448), 0, (hipStream_t)stream, g, x, q, ws);
+        HIP_LAUNCH_CHECK();
+        const int total = S * Co * R * 64;
+        MIGAN_LAUNCH(toep_ring_fold_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, wgs, Co, R, S,
+                     accumulate);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     float* dwt = ws;
     float* ws2 = ws + (size_t)Cop * Ci * R;
     if (int rc = migan_conv2d_wgrad(x, q, dwt, ws2, ws_bytes - (size_t)Cop * Ci * R * sizeof(float), N, Hi, Wi, Ci, Ho, Wi, Cop, R, 1,

@@ -573,7 +573,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "eltwise":
     print("ALL OK")
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "toeplitz":
-    for c in [(1, 64, 20, 24, 3, 7, 1), (2, 64, 16, 16, 3, 9, 0), (1, 16, 13, 17, 3, 7, 0), (1, 32, 24, 40, 2, 9, 1), (3, 64, 11, 9, 4, 7, 1)]:
+    for c in [(1, 64, 20, 24, 3, 7, 1), (2, 64, 16, 16, 3, 9, 0), (1, 16, 13, 17, 3, 7, 0), (1, 32, 24, 40, 2, 9, 1), (3, 64, 11, 9, 4, 7, 1),
+              (1, 64, 40, 32, 3, 7, 1)]:   # the last: strip-walking weight gradient, two row segments, mirrored virtual rows
         print("toeplitz", c, flush=True)
         _toeplitz_case_guarded(*c)
         keep.clear()

@@ -218,6 +218,9 @@ TOEP_CASES = [
     (1, 16, 10, 67, (4, 5, 5), (2, 1, 2, 3), 0, 1, False),    # Co = 4, asymmetric zero padding
     (1, 16, 9, 12, (3, 7, 7), (3, 2, 3, 1), 1, 0, True),      # reflection, asymmetric, Wo < W
     (2, 24, 11, 13, (3, 3, 7), (1, 3, 1, 3), 1, 2, True),     # R != S, Ci % 32 != 0
+    (2, 64, 24, 32, (3, 9, 9), (4, 4, 4, 4), 0, 3, True),     # 64 channels, W % 16 == 0: the weight gradient walks column strips (LDS ring)
+    (1, 64, 40, 16, (3, 9, 9), (4, 4, 4, 4), 0, 0, False),    # ... one strip cut into two row segments (halo rows re-fetched)
+    (1, 64, 24, 48, (3, 7, 7), (3, 3, 3, 3), 1, 3, True),     # ... 7x7 under reflection padding (virtual rows mirrored); 8 x 16 M blocks
 ]
 
 
@@ -246,7 +249,10 @@ def test_thin_toeplitz_conv(pg, case, monkeypatch):
         bg = b.detach().to(DEV).requires_grad_(True) if bias else None
         y = F.conv2d(xg, wg, bg, 1, pads, gather, act, 0.2)
         assert y.grad_fn.toep is on
-        y.backward(gy.to(DEV))
+        with Launches() as nl:
+            y.backward(gy.to(DEV))
+            if on and Ci == 64 and R == S and R in (7, 9) and W % 16 == 0:
+                assert nl("toep_wgrad_ring_kernel") == 1, "the strip-walking weight gradient did not run"
         assert_close(y, y_ref, TOL_FWD, "toeplitz=%s fwd" % on)
         assert_close(xg.grad, x.grad, TOL_FWD, "toeplitz=%s dgrad" % on)
         assert_close(wg.grad, w.grad, TOL_WGRAD, "toeplitz=%s wgrad" % on)

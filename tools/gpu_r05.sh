@@ -181,6 +181,33 @@ task_rgb() {   # call 8: the image-input kernels (csrc/rgb_conv.hip): parity on 
   cat $O/bench.txt
 }
 
+task_toep() {   # call 10: strip-walking Toeplitz weight gradient, 8 x 16 M blocks, Co' = 32: parity, stand-alone times, whole steps
+  local O=gpurun_out/r5i; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -k "toeplitz or srgan_step or test_conv2d_fwd_bwd or cyclegan_steps" --durations=5 > $O/pytest.txt 2>&1
+  tail -5 $O/pytest.txt
+  for cfg in "MIGAN_M2D=0 MIGAN_TOEP_RING=0" "MIGAN_M2D=1 MIGAN_TOEP_RING=1" "MIGAN_M2D=2 MIGAN_TOEP_RING=1"; do
+    echo "== $cfg" >> $O/micro.txt
+    env $cfg timeout 200 python tools/conv_microbench.py --shapes srgan --match "conv3" --iters 10 --repeat 3 2>&1 | grep "tfwd\|twgrad\|tdgrad\|texpand" >> $O/micro.txt
+    env $cfg timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "c7s1-3" --iters 10 --repeat 3 2>&1 | grep "tfwd\|twgrad\|tdgrad\|texpand" >> $O/micro.txt
+  done
+  for cfg in "MIGAN_M2D=1" "MIGAN_M2D=2"; do
+    echo "== $cfg" >> $O/micro.txt
+    env $cfg timeout 300 python tools/conv_microbench.py --shapes srgan --match "vgg" --only fwd,dgrad --iters 10 --repeat 3 >> $O/micro.txt 2>&1
+    env $cfg timeout 300 python tools/conv_microbench.py --shapes srgan --match "up 64" --only fwd,dgrad --iters 10 --repeat 3 >> $O/micro.txt 2>&1
+    env $cfg timeout 300 python tools/conv_microbench.py --shapes srgan --match "res 64" --only fwd,dgrad --iters 10 --repeat 3 >> $O/micro.txt 2>&1
+  done
+  cat $O/micro.txt
+  bl $O/bench.txt srgan 4 MIGAN_M2D=0 MIGAN_TOEP_RING=0
+  bl $O/bench.txt srgan 4
+  bl $O/bench.txt srgan 4 MIGAN_M2D=2
+  bl $O/bench.txt srgan 4 MIGAN_M2D=0 MIGAN_TOEP_RING=0
+  bl $O/bench.txt srgan 4
+  bl $O/bench.txt srgan 4 MIGAN_M2D=2
+  bl $O/bench.txt cyclegan 4 --no-graph
+  bl $O/bench.txt cyclegan 4 --no-graph MIGAN_M2D=2
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
