@@ -164,24 +164,29 @@ MIGAN_API int migan_thin_toeplitz_expand(const float* dy, float* q, int N, int H
 // rows - its 64-row tiles are 56 % padding - and N = R * Ci columns cut into tiles per tap r, each of which fetches "its" source row per
 // K-tile: every image row is fetched R times (profiles/r04_pmc_kernels.json: 1.45 ms, 5.0 GB against 0.87 GB of operands, MFMA busy on
 // twice the necessary work).  Here a workgroup owns a 16-pixel-wide column strip of one image and WALKS DOWN it: the R source rows of the
-// current output row sit in an LDS ring of R + 1 slots, each step fetches ONE new row (4 KB) and one Q row (1.8 KB) while the previous
-// ones are multiplied, and the whole N = R * 64 columns belong to the workgroup (each wave a fixed set of 32-column blocks, so no
-// cross-wave sum).  M = 32 rows: 28 / 32 of the MFMA work is real.  Partial [32][R*64] slabs per workgroup, one fixed-order fold.
+// current output row sit in an LDS ring of R + 1 slots, each step fetches ONE new row (4 KB) and one Q row (2 KB) while the previous
+// ones are multiplied, and the whole N = R * 64 columns belong to the workgroup.  M = 32 rows: 27 / 32 of the MFMA work is real.
+// Partial [32][R*64] slabs per workgroup and pixel half, one fixed-order fold.
 // ------------------------------------------------------------------------------------------------
 #define TWR_PX 16
 struct ToepRingGeom {
     int N, Hi, Wi, Ho, Co, Cop, S, pad_t, reflect;
     int rows_per_seg, segs;
 };
-template <int R, int NBW>   // NBW = 32-column blocks per wave; waves = 2 * R / NBW
-__global__ __launch_bounds__(64 * (2 * R / NBW)) void toep_wgrad_ring_kernel(const ToepRingGeom g, const float* __restrict__ x,
-                                                                              const float* __restrict__ q, float* __restrict__ part) {
+// Four waves: wave = (g, j); g = which 8 of the K-tile's 16 pixels it contracts, j = which channel half: its R column blocks are
+// (tap r, half j), r = 0 .. R-1.  (A first version gave six / seven waves two or three blocks each over all 16 pixels: 1.16 ms for the
+// 9 x 9 layer - a workgroup of six waves puts two waves on two SIMDs and one on the others, the MFMA work of a CU is 2:2:1:1.)
+// The two pixel halves leave separate slabs; the fold adds them like slabs of different workgroups.
+template <int R>
+__global__ __launch_bounds__(256, 2) void toep_wgrad_ring_kernel(const ToepRingGeom g, const float* __restrict__ x,
+                                                                  const float* __restrict__ q, float* __restrict__ part) {
     constexpr int CI = 64, NSLOT = R + 1, ROWF = TWR_PX * CI;   // floats per ring slot
-    constexpr int NT = 64 * (2 * R / NBW);
+    constexpr int NT = 256, HS = TWR_PX / 4;                     // MFMA steps (2 pixels each) per wave and K-tile
     __shared__ __attribute__((aligned(16))) float ring[NSLOT * ROWF];
     __shared__ __attribute__((aligned(16))) float qs[2 * TWR_PX * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kk = lane >> 5;
+    const int pg = wave >> 1, ch = wave & 1;
     const int strips = g.Wi / TWR_PX;
     int wg = blockIdx.x;
     const int seg = wg % g.segs;
@@ -191,21 +196,21 @@ __global__ __launch_bounds__(64 * (2 * R / NBW)) void toep_wgrad_ring_kernel(con
     const int oi0 = seg * g.rows_per_seg;
     const int oi1 = oi0 + g.rows_per_seg < g.Ho ? oi0 + g.rows_per_seg : g.Ho;
 
-    // loader roles: threads 0..255 one 16-byte chunk of an image row (pixel tid / 16, channels 4 * (tid % 16) ..), the next
-    // 16 * Cop / 4 threads one chunk of a Q row
+    // loader roles: every thread one 16-byte chunk of an image row (pixel tid / 16, channels 4 * (tid % 16) ..), the first
+    // 16 * Cop / 4 threads also one chunk of a Q row
     const int q4 = g.Cop >> 2;
-    const bool x_role = tid < 256, q_role = tid >= 256 && tid < 256 + TWR_PX * q4;
+    const bool q_role = tid < TWR_PX * q4;
     const int xp = tid >> 4, xc = (tid & 15) * 4;
-    const int qi = tid - 256, qp = q_role ? qi / q4 : 0, qc = q_role ? (qi - qp * q4) * 4 : 0;
+    const int qp = q_role ? tid / q4 : 0, qc = q_role ? (tid - qp * q4) * 4 : 0;
     auto load_x = [&](int v) -> f32x4 {   // virtual (padded) row v of the strip
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
         int ih = v;
-        bool ok = x_role;
+        bool ok = true;
         if (g.reflect) {
             ih = ih < 0 ? -ih : ih;
             ih = ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih;
         } else {
-            ok = ok && (unsigned)ih < (unsigned)g.Hi;
+            ok = (unsigned)ih < (unsigned)g.Hi;
         }
         if (ok) r4 = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * g.Hi + ih) * g.Wi + u0 + xp) * CI + xc);
         return r4;
@@ -224,16 +229,16 @@ __global__ __launch_bounds__(64 * (2 * R / NBW)) void toep_wgrad_ring_kernel(con
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const f32x4 t = load_x(oi0 - g.pad_t + r);
-            if (x_role) *reinterpret_cast<f32x4*>(ring + slot_of(oi0 - g.pad_t + r) * ROWF + xp * CI + xc) = t;
+            *reinterpret_cast<f32x4*>(ring + slot_of(oi0 - g.pad_t + r) * ROWF + xp * CI + xc) = t;
         }
         const f32x4 t = load_q(oi0);
         if (q_role) *reinterpret_cast<f32x4*>(qs + qp * 32 + qc) = t;
     }
     __syncthreads();
 
-    f32x16 acc[NBW];
+    f32x16 acc[R];
 #pragma unroll
-    for (int b = 0; b < NBW; ++b)
+    for (int b = 0; b < R; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
@@ -247,32 +252,31 @@ __global__ __launch_bounds__(64 * (2 * R / NBW)) void toep_wgrad_ring_kernel(con
             nx = load_x(vnew);
             nq = load_q(oi + 1);
         }
-        const float* qb = qs + cur * (TWR_PX * 32);
-        float a[TWR_PX / 2];
+        const float* qb = qs + cur * (TWR_PX * 32) + (pg * 2 * HS + kk) * 32 + l31;
+        float a[HS];
 #pragma unroll
-        for (int st = 0; st < TWR_PX / 2; ++st) a[st] = qb[(2 * st + kk) * 32 + l31];
+        for (int st = 0; st < HS; ++st) a[st] = qb[2 * st * 32];
+        int slot = slot_of(oi - g.pad_t);
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) {
-            const int blk = wave * NBW + b;            // (tap r, channel half)
-            const int r = blk >> 1, ch = blk & 1;
-            const float* rb = ring + slot_of(oi - g.pad_t + r) * ROWF + ch * 32 + l31;
+        for (int r = 0; r < R; ++r) {
+            const float* rb = ring + slot * ROWF + (pg * 2 * HS + kk) * CI + ch * 32 + l31;
 #pragma unroll
-            for (int st = 0; st < TWR_PX / 2; ++st)
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], rb[(2 * st + kk) * CI], acc[b], 0, 0, 0);
+            for (int st = 0; st < HS; ++st)
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], rb[2 * st * CI], acc[r], 0, 0, 0);
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
         if (more) {   // the free slot (the row that left the window with the previous output row) and the other Q buffer
-            if (x_role) *reinterpret_cast<f32x4*>(ring + slot_of(vnew) * ROWF + xp * CI + xc) = nx;
+            *reinterpret_cast<f32x4*>(ring + slot_of(vnew) * ROWF + xp * CI + xc) = nx;
             if (q_role) *reinterpret_cast<f32x4*>(qs + (cur ^ 1) * (TWR_PX * 32) + qp * 32 + qc) = nq;
         }
         __syncthreads();
         cur ^= 1;
     }
-    // slab [32][R * 64]: this wave's column blocks
-    float* out = part + (size_t)blockIdx.x * 32 * (R * CI);
+    // slab [32][R * 64] per (workgroup, pixel half): this wave's column blocks
+    float* out = part + ((size_t)blockIdx.x * 2 + pg) * 32 * (R * CI);
 #pragma unroll
-    for (int b = 0; b < NBW; ++b) {
-        const int blk = wave * NBW + b;
-        const int col = (blk >> 1) * CI + (blk & 1) * 32 + l31;
+    for (int b = 0; b < R; ++b) {
+        const int col = b * CI + ch * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
@@ -311,7 +315,7 @@ static bool toep_ring_ok(int Co, int R, int S, int Ci, int Wi, int Cop) {
 }
 static void toep_ring_plan(int N, int Wi, int Ho, int& segs, int& rows) {
     const int strips = N * (Wi / TWR_PX);
-    segs = (768 + strips - 1) / strips;          // about three workgroups per CU
+    segs = (512 + strips - 1) / strips;          // two workgroups per CU (accumulators: R x 16 registers per lane)
     if (segs < 1) segs = 1;
     if (segs > Ho / 16) segs = Ho / 16 > 0 ? Ho / 16 : 1;   // a walk re-fetches R - 1 rows at its start: at least 16 rows long
     rows = (Ho + segs - 1) / segs;
@@ -333,7 +337,7 @@ MIGAN_API size_t migan_thin_toeplitz_wgrad_workspace(int N, int Ho, int Wi, int 
     if (toep_ring_ok(Co, R, S, Ci, Wi, Cop)) {
         int segs, rows;
         toep_ring_plan(N, Wi, Ho, segs, rows);
-        const size_t ring = (size_t)N * (Wi / TWR_PX) * segs * 32 * R * 64 * sizeof(float);
+        const size_t ring = (size_t)N * (Wi / TWR_PX) * segs * 2 * 32 * R * 64 * sizeof(float);
         if (ring > general) general = ring;
     }
     return general;
@@ -350,11 +354,11 @@ MIGAN_API int migan_thin_toeplitz_wgrad(const float* x, const float* q, float* d
         ToepRingGeom g = {N, Hi, Wi, Ho, Co, Cop, S, pad_t, gather == GATHER_REFLECT, 0, 0};
         toep_ring_plan(N, Wi, Ho, g.segs, g.rows_per_seg);
         const int wgs = N * (Wi / TWR_PX) * g.segs;
-        if (R == 9) MIGAN_LAUNCH((toep_wgrad_ring_kernel<9, 3>), dim3(wgs), dim3(384), 0, (hipStream_t)stream, g, x, q, ws);
-        else MIGAN_LAUNCH((toep_wgrad_ring_kernel<7, 2>), dim3(wgs), dim3(448), 0, (hipStream_t)stream, g, x, q, ws);
+        if (R == 9) MIGAN_LAUNCH((toep_wgrad_ring_kernel<9>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, g, x, q, ws);
+        else MIGAN_LAUNCH((toep_wgrad_ring_kernel<7>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, g, x, q, ws);
         HIP_LAUNCH_CHECK();
         const int total = S * Co * R * 64;
-        MIGAN_LAUNCH(toep_ring_fold_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, wgs, Co, R, S,
+        MIGAN_LAUNCH(toep_ring_fold_kernel, dim3((total + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, 2 * wgs, Co, R, S,
                      accumulate);
         HIP_LAUNCH_CHECK();
         return 0;

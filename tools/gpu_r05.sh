@@ -208,6 +208,20 @@ task_toep() {   # call 10: strip-walking Toeplitz weight gradient, 8 x 16 M bloc
   cat $O/bench.txt
 }
 
+task_toep2() {   # call 11: the four-wave strip-walking weight gradient
+  local O=gpurun_out/r5j; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -k "toeplitz or srgan_step" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  for cfg in "MIGAN_TOEP_RING=0" "MIGAN_TOEP_RING=1"; do
+    echo "== $cfg" >> $O/micro.txt
+    env $cfg timeout 200 python tools/conv_microbench.py --shapes srgan --match "conv3" --dirs twgrad --iters 10 --repeat 3 2>&1 | grep "twgrad" >> $O/micro.txt
+    env $cfg timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "c7s1-3" --dirs twgrad --iters 10 --repeat 3 2>&1 | grep "twgrad" >> $O/micro.txt
+  done
+  cat $O/micro.txt
+  ab $O/bench.txt srgan 4 2
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
