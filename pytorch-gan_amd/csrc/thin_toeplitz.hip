@@ -243,14 +243,21 @@ __global__ __launch_bounds__(256, 2) void toep_wgrad_ring_kernel(const ToepRingG
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
     int cur = 0;
+    // fetch distance TWO output rows: the row (and Q row) that output row oi + 2 adds is requested while row oi is multiplied and written
+    // to LDS at the end of row oi + 1 - one row of MFMAs (~1 us) is less than a loaded memory system's latency (with distance one:
+    // 0.96 ms for the 9 x 9 layer, profiles/r05_ab.txt)
+    f32x4 nx = {0.f, 0.f, 0.f, 0.f}, nq = {0.f, 0.f, 0.f, 0.f};
+    if (oi0 + 1 < oi1) {
+        nx = load_x(oi0 - g.pad_t + R);
+        nq = load_q(oi0 + 1);
+    }
     for (int oi = oi0; oi < oi1; ++oi) {
-        // the row the NEXT output row adds, and its Q row: in flight under this row's MFMAs
-        const int vnew = oi - g.pad_t + R;
+        const int vnew = oi - g.pad_t + R;   // the row output row oi + 1 adds: in nx / nq since the previous iteration
         const bool more = oi + 1 < oi1;
-        f32x4 nx = {0.f, 0.f, 0.f, 0.f}, nq = {0.f, 0.f, 0.f, 0.f};
-        if (more) {
-            nx = load_x(vnew);
-            nq = load_q(oi + 1);
+        f32x4 fx = {0.f, 0.f, 0.f, 0.f}, fq = {0.f, 0.f, 0.f, 0.f};
+        if (oi + 2 < oi1) {
+            fx = load_x(vnew + 1);
+            fq = load_q(oi + 2);
         }
         const float* qb = qs + cur * (TWR_PX * 32) + (pg * 2 * HS + kk) * 32 + l31;
         float a[HS];
@@ -269,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void toep_wgrad_ring_kernel(const ToepRingG
             *reinterpret_cast<f32x4*>(ring + slot_of(vnew) * ROWF + xp * CI + xc) = nx;
             if (q_role) *reinterpret_cast<f32x4*>(qs + (cur ^ 1) * (TWR_PX * 32) + qp * 32 + qc) = nq;
         }
+        nx = fx;
+        nq = fq;
         __syncthreads();
         cur ^= 1;
     }

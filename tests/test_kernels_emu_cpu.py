@@ -533,6 +533,7 @@ def _run_gpu_test_body(module_name, test_name, *args):
 
 STEP_BODIES = [
     ("test_dcgan_steps", (True,)),            # dcgan.py:143-183, 3 steps: paired D pass, chained BatchNorm statistics, dropout masks
+    ("test_dcgan_steps_three_channels", ()),  # dcgan.py:28 --channels 3 at 64x64 (bench.py's extra.dcgan_ch3)
     ("test_wgan_gp_steps", (False,)),         # wgan_gp.py:119-193, 6 critic iterations: double backward through the skinny GEMMs
     ("test_wgan_gp_steps", (True,)),          # ... and on the fused WGAN-GP kernels (K7)
     ("test_fused_wgan_gp_kernels_serve_the_baseline_batch", ()),   # batch 64: launch counters + fused vs op-by-op vs oracle

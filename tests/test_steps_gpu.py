@@ -103,6 +103,42 @@ def test_dcgan_steps(skip_dead):
             assert torch.allclose(sd_g[k].cpu(), sd_c[k], rtol=1e-4, atol=1e-5), k
 
 
+def test_dcgan_steps_three_channels():
+    """dcgan.py:28 --channels 3 (the configuration bench.py reports as extra.dcgan_ch3, dcgan.py:62 Conv2d(64, 3, 3) / dcgan.py:84
+    Conv2d(3, 16, 3, 2, 1)) at 64x64: three iterations against the oracle with its dropout masks replayed - losses, weights after
+    Adam, BatchNorm side effects."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_models as M
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import steps
+
+    _seed(0)
+    s_cpu = S.make_dcgan(64, channels=3)
+    s_gpu = steps.make_gan_state(gpu_copy(s_cpu.G), gpu_copy(s_cpu.D), skip_dead_grads=True)
+    _seed(1)
+    for t in range(3):
+        imgs = torch.rand(8, 3, 64, 64) * 2 - 1
+        z = torch.tensor(np.random.normal(0, 1, (8, 100)), dtype=torch.float32)
+        rec = []
+        with M.feed_masks(record=rec):
+            o_c = S.dcgan_step(s_cpu, imgs, z)
+        with pg.dropout_masks([m.numpy() for m in rec]):
+            o_g = steps.dcgan_step(s_gpu, imgs.to(DEV), z.to(DEV))
+        assert tuple(o_g["gen_imgs"].shape) == (8, 3, 64, 64)
+        _loss_close(o_g["g_loss"], o_c["g_loss"], "ch3 g_loss step %d" % t)
+        _loss_close(o_g["d_loss"], o_c["d_loss"], "ch3 d_loss step %d" % t)
+    _params_close(s_gpu.G, s_cpu.G, 3, "G ch3")
+    _params_close(s_gpu.D, s_cpu.D, 3, "D ch3")
+    sd_c, sd_g = s_cpu.D.state_dict(), s_gpu.D.state_dict()
+    for k in sd_c:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_c[k]) == int(sd_g[k]) == 9, k
+        elif "running" in k:
+            # (after three Adam updates of every layer in front of it: the deepest layer's running mean is O(1e-2) and moves by the
+            # weights' rounding-level differences: the 1e-4 / 1e-5 bound of the one-channel 32x32 test is exceeded there while losses and weights agree)
+            assert torch.allclose(sd_g[k].cpu(), sd_c[k], rtol=1e-3, atol=1e-4), k
+
+
 def test_dcgan_graph_replay_equals_eager():
     """The hipGraph-captured step must produce what the eager step produces (same weights, same inputs; dropout
     disabled so both consume no random stream)."""
