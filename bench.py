@@ -39,7 +39,7 @@ import torch  # noqa: E402
 IMG, BATCH, LATENT, CH = 64, 128, 100, 1
 PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
 UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapsed Upsample(2)+Conv3x3 kernels
-PROFILE_ROUND = "r04"  # profiles/r04_pmc_kernels.json: the rocprofv3 --pmc passes over `bench.py --pmc-log` (tools/gpu_r04.sh pmc)
+PROFILE_ROUND = "r05"  # profiles/r05_pmc_kernels.json: the rocprofv3 --pmc passes over `bench.py --pmc-log` (tools/gpu_r05.sh pmcstep)
 
 
 def dcgan_flops_per_image(ch=None):
@@ -499,12 +499,14 @@ def pmc_table():
     (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, separate passes) and MFMA-busy cycles,
     keyed by the roofline group names used here.  The PMC passes cannot run inside bench.py (counter collection
     serialises the launches), so they are taken on `bench.py --no-graph` by tools/round_measure.sh and committed."""
-    path = os.path.join(ROOT, "profiles", "%s_pmc_kernels.json" % PROFILE_ROUND)
-    try:
-        with open(path) as f:
-            return json.load(f), os.path.relpath(path, ROOT)
-    except (OSError, ValueError):
-        return {}, None
+    for rnd in (PROFILE_ROUND, "r04"):   # the newest committed pass; the previous round's until this round's has been taken
+        path = os.path.join(ROOT, "profiles", "%s_pmc_kernels.json" % rnd)
+        try:
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return {}, None
 
 
 def roofline(w, rank, nprof, segments=None):
@@ -564,9 +566,11 @@ def roofline(w, rank, nprof, segments=None):
         hk = max(hbm, key=lambda k: hbm[k]["ms"])
         h = hbm[hk]
         gbs = h["bytes"] / (h["ms"] * 1e-3) / 1e9
+        hent = tab.get(hk, {})   # the same call under the PMC passes (tools/pmc_step.py): counted HBM-side bytes per call
         out["hbm"] = {
             "bound": "hbm", "kernel": hk, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-            "frac_of_achievable_6290": round(gbs / 6290.0, 4), "traffic": None,
+            "frac_of_achievable_6290": round(gbs / 6290.0, 4), "traffic": hent.get("hbm_bytes_per_launch"),
+            "traffic_source": src if hent else None,
             "avg_call_ms": round(h["ms"] / h["launches"], 4), "calls_per_step": h["launches"] // nprof,
             "algorithmic_mb_per_call": round(h["bytes"] / h["launches"] / 1e6, 2),
             "note": "one call = the launches of that C entry point (stats: partial + finalize; bwd: partial + finalize + apply)",
