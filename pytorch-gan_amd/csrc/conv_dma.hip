@@ -553,8 +553,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int T> struct FragT;
 template <> struct FragT<1> { typedef float type; };
 template <> struct FragT<2> { typedef f32x2 type; };
+template <> struct FragT<4> { typedef f32x4 type; };
 __device__ __forceinline__ float frag_get(float v, int) { return v; }
 __device__ __forceinline__ float frag_get(f32x2 v, int e) { return v[e]; }
+__device__ __forceinline__ float frag_get(f32x4 v, int e) { return v[e]; }
 
 template <int BM, int BN, int BK, bool DYS, bool REFL, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, const float* __restrict__ X,
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, 
     constexpr int IA = PPW / RPA, IB = PPW / RPB;  // DMA instructions per wave per K-tile
     static_assert((BK == 32 || BK == 16) && IA >= 1 && IB >= 1, "BK");
     constexpr int A_FL = BK * BM, B_FL = BK * BN, ST_FL = A_FL + B_FL;
-    static_assert(TM >= 1 && TM <= 2 && TN >= 1 && TN <= 2, "tile shape");
+    static_assert(TM >= 1 && TM <= 2 && (TN == 1 || TN == 2 || TN == 4), "tile shape");
     __shared__ __attribute__((aligned(16))) float smem[2 * ST_FL];
 
     const int tid = threadIdx.x;
@@ -726,7 +728,16 @@ __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, 
             if (co >= g.Co) continue;
             const int col = nc0 + wn * (TN * 32) + TN * l31;
             float* o = out + (size_t)co * Ncol + col;
-            if (TN == 2) {
+            if (TN == 4) {
+                if (col + 3 < Ncol) {
+                    f32x4 v = {acc[e][0][r], acc[e][1 % TN][r], acc[e][2 % TN][r], acc[e][3 % TN][r]};
+                    *reinterpret_cast<f32x4*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TN; ++q)
+                        if (col + q < Ncol) o[q] = acc[e][q][r];
+                }
+            } else if (TN == 2) {
                 if (col + 1 < Ncol) {
                     f32x2 v = {acc[e][0][r], acc[e][TN - 1][r]};
                     *reinterpret_cast<f32x2*>(o) = v;
@@ -771,6 +782,7 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
     const int bk = bm == 128 ? 16 : 32;
     if (bk == 32) {
         if (bm == 128 && bn == 128) WGD(128, 128, 32, 2);
+        else if (bm == 64 && bn == 256) WGD(64, 256, 32, 2);
         else if (bm == 64 && bn == 128) WGD(64, 128, 32, 3);
         else if (bm == 64 && bn == 64) WGD(64, 64, 32, 5);
         else return -2;

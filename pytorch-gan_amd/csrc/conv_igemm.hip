@@ -2411,7 +2411,16 @@ static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int oc
     }
     return t + (double)s_ * out_bytes / 3.0e12 + (s_ > 1 ? 4e-6 : 0.0);
 }
-static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1) {
+// Upsample + Conv3x3 weight gradient with <= 64 output channels (dcgan.py:59, cyclegan/models.py:75 - the dominant launch of the DCGAN step):
+// 64 x 256 tiles.  A 64 x 128 tile fetches the strided dy rows once per N-tile - four times for the 512 collapsed columns of a
+// 128-channel source - and gives a wave 32 MFMAs between two barriers; with 256 columns a wave runs 64 (one A fragment feeds four
+// accumulator tiles) and dy is fetched twice.  MIGAN_UPW_BN=128 keeps the narrower tile (A/B knob, round 5).
+static int upw_bn(int N, int H, int W, int Co, int Ci) {   // 256 or 0 (the general rule); the workspace query and the launch both ask here
+    static const int env = getenv("MIGAN_UPW_BN") ? atoi(getenv("MIGAN_UPW_BN")) : 256;
+    const bool fits = (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31) && W % 8 == 0;
+    return (env == 256 && fits && Co <= 64 && Co > 32 && (4 * Ci) % 256 == 0) ? 256 : 0;
+}
+static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1, int bn_force = 0) {
     // the split count comes from the balance model above (round 1's rule - about 1024 workgroups - is gone)
     static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
     long Mpix = (long)N * Ho * Wo;
@@ -2419,7 +2428,7 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
     // the split-K factor fills the chip (measured: G.conv1 up-conv wgrad 209 -> 186 us, PatchGAN 4x4 s2 wgrads -10 %,
     // while Conv2d(64,256) on 590k pixels prefers 128x128)
     BMsel = (Co > 128 && Ncol > 64 && Mpix * ncls > 16384) ? 128 : 64;
-    const int bn = wgrad_bn(Co, Ncol);
+    const int bn = bn_force ? bn_force : wgrad_bn(Co, Ncol);
     long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, bn) * ncls;
     long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
     if (maxs > 512) maxs = 512;
@@ -2430,7 +2439,7 @@ static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int&
         splits = cdiv(Mpix, pps);
         return;
     }
-    const int occ = wgrad_occ(BMsel, bn);
+    const int occ = bn == 256 ? 2 : wgrad_occ(BMsel, bn);
     const double out_bytes = (double)Co * Ncol * ncls * 8.0;
     double best = 1e30;
     long best_s = 1;
@@ -2616,7 +2625,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
 
 MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci) {
     int bm, splits, pps;
-    wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4);
+    wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4, upw_bn(N, H, W, Co, Ci));
     return ((size_t)4 * splits * Co * 4 * Ci + (size_t)4 * splits * Co) * sizeof(float);  // partials + bias slabs
 }
 
@@ -2633,7 +2642,8 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     g.N = N; g.Hi = H; g.Wi = W; g.Ci = Ci; g.HiL = H; g.WiL = W;
     g.Ho = H; g.Wo = W; g.Co = Co; g.R = 2; g.S = 2; g.stride = 1; g.gather = GATHER_ZERO;
     int Ncol = 4 * Ci, bm;
-    wgrad_plan(N, H, W, Co, Ncol, bm, g.splits, g.pix_per_split, 4);
+    const int bn256 = upw_bn(N, H, W, Co, Ci);
+    wgrad_plan(N, H, W, Co, Ncol, bm, g.splits, g.pix_per_split, 4, bn256);
     fastdiv_magic((unsigned)(H * W), g.mg_hw, g.sh_hw);
     fastdiv_magic((unsigned)W, g.mg_w, g.sh_w);
     g.dy_H = 2 * H; g.dy_W = 2 * W; g.dy_step = 2;
@@ -2648,7 +2658,9 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
         else MIGAN_LAUNCH((wgrad_pipe_kernel<BM_, BN_, true>), grid_, dim3(256), 0, st, g, x, dy, ws);    \
     } while (0)
     const int bn_sel = (bm == 128 || wgrad_bn(Co, Ncol) == 128) ? 128 : 64;
-    const int rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, true, x, dy, ws, st) : -2;  // LDS-DMA main loop (conv_dma.hip)
+    int rc_dma = -2;
+    if (bn256 && bm == 64) rc_dma = launch_wgrad_dma(g, 64, 256, true, x, dy, ws, st);   // -2: the geometry does not fit, narrower tile below
+    if (rc_dma == -2) rc_dma = inc ? launch_wgrad_dma(g, bm, bn_sel, true, x, dy, ws, st) : -2;  // LDS-DMA main loop (conv_dma.hip)
     if (rc_dma == -2) {
         if (bm == 128) UPW_LAUNCH(128, 128);
         else if (bn_sel == 128) UPW_LAUNCH(64, 128);

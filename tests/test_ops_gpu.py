@@ -887,7 +887,8 @@ def test_cpu_tensor_raises(pg):
 
 @pytest.mark.parametrize("cfg", [(2, 128, 16, 16, 128, 0, True), (2, 128, 8, 12, 64, 1, True), (1, 256, 6, 5, 128, 2, False),
                                  (2, 32, 7, 9, 20, 0, True), (1, 64, 4, 4, 3, 3, True),
-                                 (8, 128, 48, 48, 64, 0, True)])  # last: 128x64 tiles, tap-inner K order
+                                 (8, 128, 48, 48, 64, 0, True),   # 128x64 tiles, tap-inner K order; weight gradient on 64x256 tiles
+                                 (1, 64, 8, 16, 64, 1, True)])    # ... 64x256 weight-gradient tiles, one N-tile per class
 def test_upconv3x3_phase_collapsed(pg, cfg):
     """Upsample(2) -> Conv3x3(p=1) in the phase-collapsed form (dcgan.py:54-55,58-59; cyclegan/models.py:74-75)
     against the dense reference: forward, dgrad, wgrad (collapsed when Co%4==0 and Ci%4==0, dense fallback else)."""
@@ -903,7 +904,10 @@ def test_upconv3x3_phase_collapsed(pg, cfg):
     xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     bg = b.detach().to(DEV).requires_grad_(True) if bias else None
     y = F.upconv3x3(xg, wg, bg, act, 0.2)
-    y.backward(gy.to(DEV))
+    with Launches() as nl:
+        y.backward(gy.to(DEV))
+        if Co == 64 and Ci % 64 == 0 and W % 8 == 0:   # dcgan.py:59 / cyclegan/models.py:75 shape class: the wide weight-gradient tile
+            assert nl("wgrad_dma_kernel<64, 256") == 1
     assert_close(y, y_ref, TOL_FWD, "upconv fwd")
     assert_close(xg.grad, x.grad, TOL_FWD, "upconv dgrad")
     assert_close(wg.grad, w.grad, TOL_WGRAD, "upconv wgrad")

@@ -222,6 +222,28 @@ task_toep2() {   # call 11: the four-wave strip-walking weight gradient
   cat $O/bench.txt
 }
 
+task_upw() {   # call 12: 64 x 256 weight-gradient tiles of the Upsample+Conv3x3 layers with 64 output channels; ring kernel with fetch distance two
+  local O=gpurun_out/r5k; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -k "upconv or toeplitz or dcgan_steps" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  for bn in 128 256 128 256; do
+    echo "== MIGAN_UPW_BN=$bn" >> $O/micro.txt
+    MIGAN_UPW_BN=$bn timeout 100 python tools/conv_microbench.py --shapes dcgan --match "G.conv2" --dirs uwgrad --iters 20 --repeat 3 2>&1 | grep uwgrad >> $O/micro.txt
+    MIGAN_UPW_BN=$bn timeout 100 python tools/conv_microbench.py --shapes cyclegan --match "u64" --dirs uwgrad --iters 20 --repeat 3 2>&1 | grep uwgrad >> $O/micro.txt
+  done
+  echo "== ring, fetch distance two" >> $O/micro.txt
+  timeout 200 python tools/conv_microbench.py --shapes srgan --match "conv3" --dirs twgrad --iters 10 --repeat 3 2>&1 | grep "twgrad" >> $O/micro.txt
+  timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "c7s1-3" --dirs twgrad --iters 10 --repeat 3 2>&1 | grep "twgrad" >> $O/micro.txt
+  cat $O/micro.txt
+  for r in 1 2; do
+    bl $O/bench.txt dcgan 50 MIGAN_UPW_BN=128
+    bl $O/bench.txt dcgan 50 MIGAN_UPW_BN=256
+  done
+  bl $O/bench.txt cyclegan 4 MIGAN_UPW_BN=128 --no-graph
+  bl $O/bench.txt cyclegan 4 MIGAN_UPW_BN=256 --no-graph
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
