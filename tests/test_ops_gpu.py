@@ -42,6 +42,7 @@ CONV_CASES = [
     (4, 16, 16, 16, 32, 3, 2, (1, 1, 1, 1), 0, 0, True),        # Ci=16 generic
     (2, 64, 16, 16, 128, 3, 2, (1, 1, 1, 1), 0, 0, True),       # cyclegan/models.py:60
     (1, 256, 12, 12, 256, 3, 1, (1, 1, 1, 1), 1, 0, True),      # ResidualBlock: ReflectionPad2d(1)+conv
+    (2, 192, 32, 32, 256, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 32 tiles of 128 x 128, 108 K-tiles: wide tiles cut along K (one image per GPU)
     (1, 3, 20, 20, 64, 7, 1, (3, 3, 3, 3), 1, 0, True),         # c7s1-64 with reflection pad 3 (generic)
     (1, 64, 20, 20, 3, 7, 1, (3, 3, 3, 3), 1, 3, True),         # c7s1-3 + Tanh
     (2, 3, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 1, True),         # PatchGAN first block
@@ -1019,8 +1020,8 @@ def test_bias_grad_fused_into_wgrad(pg):
 def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
     """ReflectionPad2d(1)+Conv3x3 input gradient: the direct form (pad-1 dgrad + added ring terms, no padded
     intermediate; cyclegan/models.py:26-35) against torch CPU and against the padded-extent + fold path it replaces.
-    The 256-channel cases run both launches cut along K (migan_conv2d_dgrad_reflect1_ws): 1 x 256 x 64 x 64 is the residual trunk at one
-    image per GPU - 256 tiles of 72 K-tiles for the pad-1 launch, 64 tiles whose corner classes are 56 K-tiles deep for the ring."""
+    The 256-channel cases go through migan_conv2d_dgrad_reflect1_ws: 1 x 256 x 64 x 64 is the residual trunk at one image per GPU, whose
+    ring launch - 64 tiles, corner classes 56 K-tiles deep - is cut along K."""
     from util import Launches
 
     N, Ci, H, W, Co = case
@@ -1040,8 +1041,11 @@ def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
         y = F.conv2d(xg, wg, None, 1, (1, 1, 1, 1), F.GATHER_REFLECT)
         with Launches() as n:
             y.backward(gy.to(DEV))
-            if direct and Ci == 256:   # pad-1 launch and ring launch, both through the ticketed split-K instantiation
-                assert n("2, 4, true>") >= 2, "reflect dgrad of %s was not cut along K" % (case,)
+            if direct and Ci == 256:
+                # 12 x 12: both launches under-filled -> both through the ticketed 64 x 64 split-K instantiation; 64 x 64: the ring launch
+                assert n("2, 4, true>") >= (2 if H * W <= 1024 else 1), "reflect dgrad of %s was not cut along K" % (case,)
+                if H * W == 4096:   # ... and the pad-1 launch as 128 x 128 tiles in four K slices (launch_dma_wide_sk)
+                    assert n("128, 128, 2, 2, 16, 1, false, 2, 2, true>") == 1
         assert_close(xg.grad, x.grad, TOL_FWD, "reflect dgrad direct=%s" % direct)
         outs.append(xg.grad.clone())
     assert_close(outs[0], outs[1], 2e-6, "direct vs padded+fold")

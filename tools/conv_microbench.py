@@ -32,6 +32,7 @@ SHAPES = {
         ("d128 64->128 s2", 8, 64, 256, 256, 128, 3, 2, 1, 0),
         ("d256 128->256 s2", 8, 128, 128, 128, 256, 3, 2, 1, 0),
         ("R256 reflect 256->256 @64", 8, 256, 64, 64, 256, 3, 1, 1, 1),
+        ("R256 bs1 256->256 @64", 1, 256, 64, 64, 256, 3, 1, 1, 1),
         ("u128 up2 256->128 @128", 8, 256, 64, 64, 128, 3, 1, 1, 2),
         ("u64 up2 128->64 @256", 8, 128, 128, 128, 64, 3, 1, 1, 2),
         ("c7s1-3 64->3 reflect", 8, 64, 256, 256, 3, 7, 1, 3, 1),
@@ -132,8 +133,8 @@ def main():
             # ReflectionPad2d(1)+Conv3x3 input gradient straight into H x W (pad-1 dgrad + added ring terms); "dgrad" above
             # is the padded-extent launch it replaces (which additionally needs the fold pass, timed as "fold")
             dxr = torch.empty(N * H * W * Ci, device=dev)
-            calls["rdgrad"] = lambda: lib.migan_conv2d_dgrad_reflect1(dy.data_ptr(), w.data_ptr(), dxr.data_ptr(), N, H, W,
-                                                                      Ci, Co, st)
+            calls["rdgrad"] = lambda: lib.migan_conv2d_dgrad_reflect1_ws(dy.data_ptr(), w.data_ptr(), dxr.data_ptr(), N, H, W,
+                                                                         Ci, Co, skp, skb, st)
             calls["fold"] = lambda: lib.migan_gather2d_bwd(dx.data_ptr(), dxr.data_ptr(), N, H, W, Ci, Hd, Wd, p, p, 1, st)
             dirs += ["rdgrad", "fold"]
         if gth == 2 and k == 3 and s == 1 and p == 1 and Co % 4 == 0 and Ci % 4 == 0:

@@ -244,6 +244,25 @@ task_upw() {   # call 12: 64 x 256 weight-gradient tiles of the Upsample+Conv3x3
   cat $O/bench.txt
 }
 
+task_bs1() {   # call 14: one image per GPU: 128 x 128 tiles cut along K for the trunk
+  local O=gpurun_out/r5l; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -k "reflect or test_conv2d_fwd_bwd or cyclegan_recorded or cyclegan_256_bs1 or splitk" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  for v in 0 1; do
+    echo "== MIGAN_DMA_WIDE_SK=$v" >> $O/micro.txt
+    MIGAN_DMA_WIDE_SK=$v timeout 100 python tools/conv_microbench.py --shapes cyclegan --match "R256 bs1" --dirs fwd,rdgrad,wgrad --iters 30 --repeat 3 2>&1 | grep "R256" >> $O/micro.txt
+  done
+  cat $O/micro.txt
+  for r in 1 2; do
+    bl $O/bench.txt cyclegan 10 --batch 1 MIGAN_DMA_WIDE_SK=0
+    bl $O/bench.txt cyclegan 10 --batch 1
+  done
+  bl $O/bench.txt cyclegan 10 --batch 1 --no-graph
+  bl $O/bench.txt pix2pix 50 MIGAN_DMA_WIDE_SK=0
+  bl $O/bench.txt pix2pix 50
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
