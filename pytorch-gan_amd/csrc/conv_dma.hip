@@ -465,30 +465,6 @@ static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, 
     return 0;
 }
 
-// One image per GPU (cyclegan.py:28 - the per-GPU shard of the 8-GPU configuration): the residual trunk's GEMM is M = 4096 pixels x
-// N = 256 x K = 2304.  As 256 tiles of 64 x 64 it runs at half the MFMA rate of the batch-8 launch - and not for lack of workgroups
-// (two K slices per tile changed nothing, profiles/r05_ab.txt): a 64 x 64 tile moves 16 KB from L2 into LDS per 262 kFLOP, 16 FLOP / B.
-// The 128 x 128 tile of the large launches moves half of that per FLOP but gives only 64 tiles; cut along K into 4 slices it is 256
-// workgroups again, each with the large tile's operand reuse.  Slabs: 64 KB per (tile, slice) in the same ticket workspace.
-static int launch_dma_wide_sk(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C, unsigned ab, unsigned bb,
-                              long maxM, float* ws, size_t ws_bytes, hipStream_t st) {
-    static const int env = getenv("MIGAN_DMA_WIDE_SK") ? atoi(getenv("MIGAN_DMA_WIDE_SK")) : 1;   // A/B knob (round 5)
-    if (!env || !ws || ws_bytes < igemm_dma_splitk_ws_bytes() || g.Ci % 16 != 0) return -2;
-    const long tm = cdiv(maxM, 128), tn = cdiv(g.Co, 128);
-    const long T = tm * tn * g.ncls;
-    int minKT = 1 << 30;
-    for (int c = 0; c < g.ncls; ++c)
-        if ((long)g.N * g.Ho[c] * g.Wo[c] > 0 && g.ntap[c] * (g.Ci / 16) < minKT) minKT = g.ntap[c] * (g.Ci / 16);
-    if (T < 32 || T > 128 || minKT < 96 || maxM % 128 != 0 || g.Co % 128 != 0) return -2;
-    int S = (int)(256 / T);
-    if (S > 8) S = 8;
-    if (S < 2 || (long)S * T * 4 > DMA_SK_MAX_SLABS) return -2;   // a 128 x 128 slab = four 64 x 64 slabs of the workspace
-    dim3 grid((unsigned)tm, (unsigned)tn, (unsigned)(g.ncls * S));
-    MIGAN_LAUNCH((igemm_dma_kernel<128, 128, 2, 2, 16, 1, false, 2, 2, true>), grid, dim3(256), 0, st, g, A, Bw, bias, C, ab, bb, S, ws);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
 // Returns -2 when this geometry is not taken by the LDS-DMA kernels (the caller falls through to igemm_pipe_kernel),
 // otherwise the launch status.
 int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C, float* ws,
@@ -540,10 +516,11 @@ int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, cons
         if ((T64 <= 64 && minKT >= 16) || (T64 <= 128 && minKT >= 64)) {
             const int rc = launch_dma_small(g, A, Bw, bias, C, ab, bb, maxM, ws, ws_bytes, st);
             if (rc != -2) return rc;
-        } else if (T64 <= 512 && minKT >= 48) {
-            const int rc = launch_dma_wide_sk(g, A, Bw, bias, C, ab, bb, maxM, ws, ws_bytes, st);
-            if (rc != -2) return rc;
         }
+        // (One image per GPU, cyclegan.py:28: the residual trunk's GEMM - M = 4096, N = 256, K = 2304, 256 tiles of 64 x 64, 57 us = half
+        // the MFMA rate of the batch-8 launch - was also measured as 64 tiles of 128 x 128 in four K slices, for the large tile's operand
+        // reuse: 70 us forward, the step 39.2 vs 35.2 ms, profiles/r05_ab.txt call 14.  Neither occupancy nor L2 -> LDS traffic is what
+        // holds this launch back; removed.)
     }
     switch (dma_select(maxM, g.Co, g.ncls)) {
 #define DMA_CASE(BK_, BM_, BN_, WM_, WN_, OCC_) \

@@ -1451,7 +1451,7 @@ MIGAN_API size_t migan_conv_splitk_workspace(void) { return igemm_dma_splitk_ws_
 // mirror allocates its per-stream workspace only then)
 MIGAN_API int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls) {
     if (Ci_src % 4 != 0 || Ci_src < 32 || Co <= 4 || maxM <= 0) return 0;
-    return (long)cdiv((long)maxM, 64) * cdiv(Co, 64) * ncls <= 512 ? 1 : 0;
+    return (long)cdiv((long)maxM, 64) * cdiv(Co, 64) * ncls <= 256 ? 1 : 0;
 }
 // migan_conv2d_fwd / migan_conv2d_dropout_fwd (mask_nc may be NULL) with a split-K workspace: under-filled GEMMs - a few
 // pixels against megabytes of weights (pix2pix/models.py:62-71), PatchGAN heads, the DCGAN discriminator - are cut along K

@@ -42,7 +42,6 @@ CONV_CASES = [
     (4, 16, 16, 16, 32, 3, 2, (1, 1, 1, 1), 0, 0, True),        # Ci=16 generic
     (2, 64, 16, 16, 128, 3, 2, (1, 1, 1, 1), 0, 0, True),       # cyclegan/models.py:60
     (1, 256, 12, 12, 256, 3, 1, (1, 1, 1, 1), 1, 0, True),      # ResidualBlock: ReflectionPad2d(1)+conv
-    (2, 192, 32, 32, 256, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 32 tiles of 128 x 128, 108 K-tiles: wide tiles cut along K (one image per GPU)
     (1, 3, 20, 20, 64, 7, 1, (3, 3, 3, 3), 1, 0, True),         # c7s1-64 with reflection pad 3 (generic)
     (1, 64, 20, 20, 3, 7, 1, (3, 3, 3, 3), 1, 3, True),         # c7s1-3 + Tanh
     (2, 3, 32, 32, 64, 4, 2, (1, 1, 1, 1), 0, 1, True),         # PatchGAN first block
@@ -1044,8 +1043,6 @@ def test_reflect_pad1_dgrad_matches_padded_path(pg, case, monkeypatch):
             if direct and Ci == 256:
                 # 12 x 12: both launches under-filled -> both through the ticketed 64 x 64 split-K instantiation; 64 x 64: the ring launch
                 assert n("2, 4, true>") >= (2 if H * W <= 1024 else 1), "reflect dgrad of %s was not cut along K" % (case,)
-                if H * W == 4096:   # ... and the pad-1 launch as 128 x 128 tiles in four K slices (launch_dma_wide_sk)
-                    assert n("128, 128, 2, 2, 16, 1, false, 2, 2, true>") == 1
         assert_close(xg.grad, x.grad, TOL_FWD, "reflect dgrad direct=%s" % direct)
         outs.append(xg.grad.clone())
     assert_close(outs[0], outs[1], 2e-6, "direct vs padded+fold")
