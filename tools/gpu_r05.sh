@@ -263,6 +263,21 @@ task_bs1() {   # call 14: one image per GPU: 128 x 128 tiles cut along K for the
   cat $O/bench.txt
 }
 
+task_mid() {   # call 15: the default bench line of the tree + kernel traces of the workloads the round worked on
+  task_bench
+  cp gpurun_out/r5bench/bench_default.json gpurun_out/r5bench/bench_call15.json
+  task_prof r5mid srgan cyclegan:graph@1
+}
+
+task_final() {   # closing pass: default bench line, kernel traces of all workloads, PMC passes over the steps
+  task_bench
+  cp gpurun_out/r5bench/bench_default.json gpurun_out/r5bench/bench_final.json
+  task_prof r5final dcgan dcgan:graph cyclegan srgan wgan_gp:graph pix2pix:graph cyclegan:graph@1
+  task_pmcstep dcgan 3 sq l2 fetch write
+  task_pmcstep cyclegan 1 sq fetch write
+  task_pmcstep srgan 1 sq fetch write
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
