@@ -185,7 +185,11 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
             state.buf_B.push_and_pop(state.G_AB(a))
     # the recorded step: the replay buffers' host draws (python `random`, the reference's order) happen in front of every replay
     # into static device tables (steps.CycleGanRunner); --no-graph launches the same step eagerly
-    runner = steps.CycleGanRunner(state, a, b, use_graph=not args.no_graph, warmup=1).prepare()
+    # Recorded where the step is bound by launches (one or two images per GPU: 34.5 ms recorded vs 40.9 ms launched one by one at
+    # batch 1); at batch 8 the ~2000 launches are 30-1000 us each and the recorded step measured SLOWER than the eager one (147.8 vs
+    # 140-146 ms, profiles/r05_ab.txt calls 4, 6, 15): eager there.  --graph-always / --no-graph override.
+    use_graph = (not args.no_graph) and (batch <= 2 or getattr(args, "graph_always", False))
+    runner = steps.CycleGanRunner(state, a, b, use_graph=use_graph, warmup=1).prepare()
     w = Workload("cyclegan", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)
     return w
@@ -742,6 +746,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much is timed")
     ap.add_argument("--max-blocks", type=int, default=200, help="upper bound on the number of timed K-step blocks")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of hipGraph replay")
+    ap.add_argument("--graph-always", action="store_true", help="cyclegan: record the step at every batch size (default: batch <= 2 only)")
     ap.add_argument("--pmc-log", default="", help="target mode of the rocprofv3 --pmc passes: run --steps eager steps of the workload "
                     "with the per-launch accounting of `roofline`, write which library launches (by ordinal) belong to which "
                     "roofline group to this file (tools/pmc_step.py joins it with the pass's counter CSV) and exit")

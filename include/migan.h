@@ -227,20 +227,34 @@ int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, fl
  * padding: srgan/models.py:85 Conv2d(3,64,3,1,1), vgg19.features[0] behind srgan/models.py:11, cyclegan/models.py:49-50
  * ReflectionPad2d(3)+Conv2d(3,64,7), srgan/models.py:38 Conv2d(3,64,9,1,4)) on the MFMA units straight from staged image rows
  * (csrc/rgb_conv.hip): K = R*S*3 is the GEMM's reduction as it is - no 32-channel tap tiles, no im2col buffer.
- *   fwd:   x [N][H][W][3], w_hwio [R][S][3][Co] (the OIHW weight permuted (2,3,1,0)), y [N][Ho][Wo][Co] = act(conv + bias)
+ *   fwd:   x [N][H][W][Ci] (Ci = 3; 1 with a 3x3 kernel), w_hwio [R][S][Ci][Co] (the OIHW weight permuted (2,3,1,0)),
+ *          y [N][Ho][Wo][Co] = act(conv + bias).  flip != 0: taps read in reverse order - with x = dy and w_hwio = a thin-output
+ *          layer's weight [c][Co][R][S] permuted (2,3,0,1) this is that layer's input gradient (dcgan.py:62 backward)
  *   wgrad: dw_oihw [Co][3][R][S] and (db != NULL) db [Co] of y = act(conv(x, w) + b) from dy and the layer's OUTPUT y_act:
  *          the activation backward g = dy * act'(y_act) and the bias column sums are part of the launch (dy, y_act read once;
  *          y_act == NULL with act = 0: dy is the gradient of the pre-activation).  accumulate_w / accumulate_b != 0: +=.
  *          ws >= migan_rgb_conv_wgrad_workspace(Co, R, S) bytes; fixed-order reduction (deterministic).
  * migan_rgb_conv_ok / migan_rgb_conv_wgrad_ok: 1 when the entry takes the geometry (pixels = N*Ho*Wo). */
 int migan_rgb_conv_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels);
-int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ho, int Wo, int Co,
-                       int R, int S, int pad_t, int pad_l, int gather, int act, float slope, void* stream);
+int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ci, int Ho, int Wo,
+                       int Co, int R, int S, int pad_t, int pad_l, int gather, int act, float slope, int flip, void* stream);
 int migan_rgb_conv_wgrad_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels);
 size_t migan_rgb_conv_wgrad_workspace(int Co, int R, int S);
 int migan_rgb_conv_wgrad(const float* x, const float* dy, const float* y_act, float* dw_oihw, float* db, float* ws, size_t ws_bytes,
                          int N, int H, int W, int Ho, int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather, int act,
                          float slope, int accumulate_w, int accumulate_b, void* stream);
+
+/* 3x3 convolutions with 64 source channels and 1..3 OUTPUT channels, stride 1, zero padding 1 (csrc/rgb_conv.hip): dcgan.py:62
+ * Conv2d(64, channels, 3, stride=1, padding=1) + Tanh, and the INPUT gradient of the image-input layers above (srgan/models.py:85,
+ * vgg19.features[0]: dx = conv(dy * act'(y), w flipped and transposed) - the activation backward happens in the operand load).
+ *   pack: wt [64][32] from w_oihw: dgrad == 0: w is [Co][64][3][3] (forward weight); dgrad != 0: w is [64][Co][3][3] (the weight of
+ *         the layer whose input gradient is wanted)
+ *   conv: y [N][H][W][Co] = act(bias + conv3x3(g, wt)), g = x [N][H][W][64] or x * act'(x_act) (in_act = 1 LeakyReLU / 2 ReLU with the
+ *         layer's OUTPUT x_act; in_act = 0: x_act unused) */
+int migan_thinout3_ok(int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather, long long pixels);
+int migan_thinout3_pack(const float* w, float* wt, int Co, int dgrad, void* stream);
+int migan_thinout3_conv(const float* x, const float* x_act, const float* wt, const float* bias, float* y, int N, int H, int W, int Co,
+                        int act, float slope, int in_act, float in_slope, void* stream);
 
 /* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
  * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz

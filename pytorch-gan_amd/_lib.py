@@ -67,10 +67,13 @@ _SIGS = {
     "migan_skinny_nt": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P]),
     "migan_skinny_nn": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "migan_rgb_conv_ok": (c_int, [c_int] * 6 + [ctypes.c_longlong]),
-    "migan_rgb_conv_fwd": (c_int, [P, P, P, P] + [c_int] * 12 + [c_float, P]),
+    "migan_rgb_conv_fwd": (c_int, [P, P, P, P] + [c_int] * 13 + [c_float, c_int, P]),
     "migan_rgb_conv_wgrad_ok": (c_int, [c_int] * 6 + [ctypes.c_longlong]),
     "migan_rgb_conv_wgrad_workspace": (c_size_t, [c_int] * 3),
     "migan_rgb_conv_wgrad": (c_int, [P, P, P, P, P, P, c_size_t] + [c_int] * 12 + [c_float, c_int, c_int, P]),
+    "migan_thinout3_ok": (c_int, [c_int] * 8 + [ctypes.c_longlong]),
+    "migan_thinout3_pack": (c_int, [P, P, c_int, c_int, P]),
+    "migan_thinout3_conv": (c_int, [P, P, P, P, P] + [c_int] * 5 + [c_float, c_int, c_float, P]),
     "migan_thin_toeplitz_ok": (c_int, [c_int] * 6),
     "migan_thin_toeplitz_cols": (c_int, [c_int] * 2),
     "migan_thin_toeplitz_workspace": (c_size_t, [c_int] * 5),

@@ -37,26 +37,27 @@ struct RgbGeom {
     int pad_t, pad_l, reflect, act;
     float slope;
     int rows_per_wg;   // output rows a workgroup walks
+    int flip;          // forward kernel: tap t of the staged weight is read from tap T-1-t of w (the input gradient of a thin-output layer)
 };
 
 // The R source rows of output row oh, columns [ow0 - pad_l, ow0 - pad_l + TW + S - 1), 3 channels -> xs[R][XW].  Two halves: load() puts
 // this thread's elements into registers with EVERY load issued before the first use (a padded element reads word 0 of the tensor and is
 // replaced by zero: no branch, no wait between loads), store() writes them to LDS - callers put the previous tile's arithmetic between
 // the two, so the fetch of tile t+1 runs under the MFMAs and stores of tile t.
-template <int R, int S>
+template <int R, int S, int C = 3>
 struct RgbStage {
-    static constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1, NE = R * XP * 3, NL = (NE + 255) / 256;
+    static constexpr int XP = RGB_TW + S - 1, XW = XP * C + 1, NE = R * XP * C, NL = (NE + 255) / 256;
     float v[NL];
     __device__ __forceinline__ void load(const RgbGeom& g, const float* __restrict__ x, int n, int oh, int ow0) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             int e = (int)threadIdx.x + i * 256;
             e = e < NE ? e : NE - 1;
-            const int r = e / (XP * 3), q = e - r * (XP * 3);
-            const int j = q / 3, c = q - j * 3;
+            const int r = e / (XP * C), q = e - r * (XP * C);
+            const int j = q / C, c = q - j * C;
             const int ih = rgb_map(oh + r - g.pad_t, g.H, g.reflect), iw = rgb_map(ow0 + j - g.pad_l, g.W, g.reflect);
             const bool ok = (ih | iw) >= 0;
-            const size_t idx = ok ? ((size_t)(n * g.H + ih) * g.W + iw) * 3 + c : 0;
+            const size_t idx = ok ? ((size_t)(n * g.H + ih) * g.W + iw) * C + c : 0;
             const float t = x[idx];
             v[i] = ok ? t : 0.f;
         }
@@ -66,7 +67,7 @@ struct RgbStage {
         for (int i = 0; i < NL; ++i) {
             const int e = (int)threadIdx.x + i * 256;
             if (e < NE) {
-                const int r = e / (XP * 3), q = e - r * (XP * 3);
+                const int r = e / (XP * C), q = e - r * (XP * C);
                 xs[r * XW + q] = v[i];
             }
         }
@@ -74,11 +75,11 @@ struct RgbStage {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int R, int S, int NB>
+template <int R, int S, int NB, int C = 3>
 __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, const float* __restrict__ x, const float* __restrict__ wk,
                                                            const float* __restrict__ bias, float* __restrict__ y) {
-    constexpr int K = R * S * 3, K2 = (K + 1) & ~1;
-    constexpr int XP = RGB_TW + S - 1, XW = XP * 3 + 1;
+    constexpr int K = R * S * C, K2 = (K + 1) & ~1;
+    constexpr int XP = RGB_TW + S - 1, XW = XP * C + 1;
     extern __shared__ float rgb_lds[];
     float* wl = rgb_lds;                 // [K2][NB * 32]
     float* xs = rgb_lds + K2 * NB * 32;  // [R][XW]
@@ -89,16 +90,20 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
     const int oh_begin = blockIdx.y * g.rows_per_wg;
     const int oh_end = oh_begin + g.rows_per_wg < g.Ho ? oh_begin + g.rows_per_wg : g.Ho;
 
-    for (int e = threadIdx.x; e < K2 * Co; e += 256) wl[e] = e < K * Co ? wk[e] : 0.f;   // wk is [K][Co]; row K (odd K) = 0
+    for (int e = threadIdx.x; e < K2 * Co; e += 256) {   // wk is [K][Co]; row K (odd K) = 0; flip: tap t <- tap T-1-t
+        const int k = e / Co, col = e - k * Co;
+        const int ks = g.flip ? (R * S - 1 - k / C) * C + k % C : k;
+        wl[e] = k < K ? wk[ks * Co + col] : 0.f;
+    }
     float bv[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bv[nb] = bias ? bias[nb * 32 + l31] : 0.f;
-    const int a_base = (wave * 32 + l31) * 3;
+    const int a_base = (wave * 32 + l31) * C;
     // none / LeakyReLU / ReLU as one select (negative-side factor 1 / slope / 0); tanh and sigmoid through act_apply
     const bool simple = g.act <= ACT_RELU;
     const float ns = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);
 
-    RgbStage<R, S> stage;
+    RgbStage<R, S, C> stage;
     if (oh_begin < oh_end) stage.load(g, x, n, oh_begin, ow0);
     for (int oh = oh_begin; oh < oh_end; ++oh) {
         __syncthreads();   // the previous row's reads of xs are over (first time round: nothing)
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 #pragma unroll
         for (int st = 0; st < K2 / 2; ++st) {
             // k = 2*st + kk; patch element k of pixel p sits at xs[(k / (3S)) * XW + p*3 + k % (3S)]; k >= K multiplies the zero row of wl
-            constexpr int S3 = 3 * S;
+            constexpr int S3 = C * S;
             const int k0 = 2 * st, k1 = 2 * st + 1;
             const int o0 = (k0 / S3) * XW + k0 % S3;
             const int o1 = k1 < K ? (k1 / S3) * XW + k1 % S3 : o0;   // (the product with the zero row must not read a NaN: any valid word)
@@ -143,44 +148,49 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 // 1 when the image-input kernels take this layer: 3 source channels, stride 1, square 3 / 7 / 9 kernel, 32 or 64 output channels,
 // zero or reflection padding smaller than the image, and enough pixels to be worth a launch of 128-pixel row tiles
 MIGAN_API int migan_rgb_conv_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels) {
-    if (Ci != 3 || stride != 1 || R != S || (R != 3 && R != 7 && R != 9) || (Co != 32 && Co != 64)) return 0;
+    if ((Ci != 3 && !(Ci == 1 && R == 3)) || stride != 1 || R != S || (R != 3 && R != 7 && R != 9) || (Co != 32 && Co != 64)) return 0;
     if (gather != GATHER_ZERO && gather != GATHER_REFLECT) return 0;
     return pixels >= 16384 ? 1 : 0;
 }
 
-static size_t rgb_fwd_lds(int R, int S, int Co) {
-    const int K2 = (R * S * 3 + 1) & ~1;
-    return ((size_t)K2 * Co + (size_t)R * ((RGB_TW + S - 1) * 3 + 1)) * sizeof(float);
+static size_t rgb_fwd_lds(int R, int S, int Co, int C) {
+    const int K2 = (R * S * C + 1) & ~1;
+    return ((size_t)K2 * Co + (size_t)R * ((RGB_TW + S - 1) * C + 1)) * sizeof(float);
 }
 
-// x [N][H][W][3], w_hwio [R][S][3][Co] (= the OIHW weight permuted (2,3,1,0)), bias [Co] or NULL, y [N][Ho][Wo][Co]
-MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ho, int Wo,
-                                 int Co, int R, int S, int pad_t, int pad_l, int gather, int act, float slope, void* stream) {
-    if (!migan_rgb_conv_ok(3, Co, R, S, 1, gather, (long long)N * Ho * Wo) || N < 1 || N > 65535) return (int)hipErrorInvalidValue;
+// x [N][H][W][Ci] (Ci = 3; 1 with a 3x3 kernel), w_hwio [R][S][Ci][Co] (= the OIHW weight permuted (2,3,1,0)), bias [Co] or NULL,
+// y [N][Ho][Wo][Co].  flip != 0: the taps are read in reverse order - with x = dy [N][H][W][c] and w_hwio = the weight [c][Co][R][S] of
+// a thin-output layer permuted (2,3,0,1) this is that layer's INPUT gradient (dcgan.py:62: 64 channels back from 1 or 3)
+MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int N, int H, int W, int Ci, int Ho,
+                                 int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather, int act, float slope, int flip,
+                                 void* stream) {
+    if (!migan_rgb_conv_ok(Ci, Co, R, S, 1, gather, (long long)N * Ho * Wo) || N < 1 || N > 65535) return (int)hipErrorInvalidValue;
     if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
         return (int)hipErrorInvalidValue;
-    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0};
+    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0, flip != 0};
     // rows per workgroup: the weights are staged once per workgroup - long enough walks to amortise that, enough workgroups for 8 / CU
     const int xt = (Wo + RGB_TW - 1) / RGB_TW;
     int th = 8;
     while (th > 1 && (long)xt * ((Ho + th - 1) / th) * N < 2048) th >>= 1;
     g.rows_per_wg = th;
     const dim3 grid(xt, (Ho + th - 1) / th, N);
-    const size_t lds = rgb_fwd_lds(R, S, Co);
-#define RGB_FWD(R_, NB_)                                                                                                  \
-    do {                                                                                                                  \
-        static bool attr_set = false;                                                                                     \
-        if (!attr_set && lds > 48 * 1024) {                                                                               \
-            hipFuncSetAttribute((const void*)rgb_conv_fwd_kernel<R_, R_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                                \
-            attr_set = true;                                                                                              \
-        }                                                                                                                 \
-        MIGAN_LAUNCH((rgb_conv_fwd_kernel<R_, R_, NB_>), grid, dim3(256), lds, (hipStream_t)stream, g, x, w_hwio, bias, y); \
+    const size_t lds = rgb_fwd_lds(R, S, Co, Ci);
+#define RGB_FWD(R_, NB_, C_)                                                                                                   \
+    do {                                                                                                                       \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set && lds > 48 * 1024) {                                                                                    \
+            hipFuncSetAttribute((const void*)rgb_conv_fwd_kernel<R_, R_, NB_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                                     \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+        MIGAN_LAUNCH((rgb_conv_fwd_kernel<R_, R_, NB_, C_>), grid, dim3(256), lds, (hipStream_t)stream, g, x, w_hwio, bias, y); \
     } while (0)
-    if (Co == 64) {
-        if (R == 3) RGB_FWD(3, 2); else if (R == 7) RGB_FWD(7, 2); else RGB_FWD(9, 2);
+    if (Ci == 1) {
+        if (Co == 64) RGB_FWD(3, 2, 1); else RGB_FWD(3, 1, 1);
+    } else if (Co == 64) {
+        if (R == 3) RGB_FWD(3, 2, 3); else if (R == 7) RGB_FWD(7, 2, 3); else RGB_FWD(9, 2, 3);
     } else {
-        if (R == 3) RGB_FWD(3, 1); else if (R == 7) RGB_FWD(7, 1); else RGB_FWD(9, 1);
+        if (R == 3) RGB_FWD(3, 1, 3); else if (R == 7) RGB_FWD(7, 1, 3); else RGB_FWD(9, 1, 3);
     }
 #undef RGB_FWD
     HIP_LAUNCH_CHECK();
@@ -332,7 +342,7 @@ MIGAN_API size_t migan_rgb_conv_wgrad_workspace(int Co, int R, int S) {
 }
 // 1 when migan_rgb_conv_wgrad takes the layer (the 9 x 9 kernel's 8 column blocks do not fit a wave's accumulators)
 MIGAN_API int migan_rgb_conv_wgrad_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels) {
-    return migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, pixels) && R <= 7 && (R == 3 || Co == 64);
+    return Ci == 3 && migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, pixels) && R <= 7 && (R == 3 || Co == 64);
 }
 // dw_oihw [Co][3][R][S] (accumulate_w: +=) and, when db != NULL, db [Co] (accumulate_b: +=) of
 //   y = act(conv(x, w) + b):  g = dy * act'(y_act)  (y_act = the layer's OUTPUT, NULL with act = ACT_NONE: dy is used as it is),
@@ -347,7 +357,7 @@ MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float*
     if (act != ACT_NONE && (!y_act || (act != ACT_LRELU && act != ACT_RELU))) return (int)hipErrorInvalidValue;
     if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
         return (int)hipErrorInvalidValue;
-    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0};
+    RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0, 0};
     const int tiles_x = (Wo + RGB_TW - 1) / RGB_TW;
     const long tiles = (long)tiles_x * Ho * N;
     if (tiles > 0x7fffffffL) return (int)hipErrorInvalidValue;
@@ -373,6 +383,145 @@ MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float*
     const int outs = Co * (R * S * 3 + 1);
     MIGAN_LAUNCH(rgb_wgrad_reduce_kernel, dim3((outs + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, db, wgs, Co, J, R, S,
                  accumulate_w, accumulate_b);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ thin-OUTPUT 3x3 (<= 3 output channels)
+// y[p][co] = act(b[co] + sum_{r,s,c} g[p + (r-1, s-1)][c] * w[c][(r,s,co)]),  64 source channels, stride 1, zero padding 1:
+//   * dcgan.py:62 Conv2d(64, channels, 3, stride=1, padding=1) + Tanh (forward: g = x), and
+//   * the INPUT gradient of the image-input layers above (srgan/models.py:85, vgg19.features[0] in the generator's update, srgan.py:121-128:
+//     dx = conv(g, w flipped and transposed), g = dy * act'(y) - the activation backward of that layer happens in the operand load).
+// These are GEMMs with N = 1..3 columns, served so far by one-pixel-per-lane VALU kernels behind an LDS window (66 us for the 134 MB
+// of dcgan.py:62 against a 25 us read; 358 us + a 162 us activation-backward pass for the 604 MB of SRGAN's first-layer gradients).
+// The tap index moves into N: P[q][(r,s,co)] = sum_c g[q][c] w[c][(r,s,co)] is a plain GEMM with K = 64 and 9*Co <= 27 columns - one
+// 32-column MFMA block - whose A operand is read straight from global memory in the MFMA's layout (a lane = one pixel, 32 contiguous
+// channels: the k-permutation k <-> channel kk*32 + step makes a lane's operands one 128-byte run), and y[p] = sum_{r,s} P[p+(r-1,s-1)]
+// [(r,s,co)] is a 9-term gather out of a 3-row LDS ring.  A workgroup of five waves owns a 128-pixel column strip (130 P pixels) and
+// walks down TH rows; the source is read once (+ 2 / TH halo rows), nothing but y is written.
+struct ThinOutGeom {
+    int N, H, W, Co, act, rows_per_wg;
+    float slope, ns;   // ns: negative-side factor of the FUSED activation backward on the operand (slope / 0)
+};
+#define TO3_TW 128
+#define TO3_PW (TO3_TW + 2)
+template <bool HAS_ACT>
+__global__ __launch_bounds__(320) void thinout3_kernel(const ThinOutGeom g, const float* __restrict__ x, const float* __restrict__ xact,
+                                                       const float* __restrict__ wt, const float* __restrict__ bias,
+                                                       float* __restrict__ y) {
+    constexpr int CI = 64, LDP = 28;
+    __shared__ float pring[3 * TO3_PW * LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ow0 = blockIdx.x * TO3_TW, n = blockIdx.z;
+    const int oh0 = blockIdx.y * g.rows_per_wg;
+    const int oh1 = oh0 + g.rows_per_wg < g.H ? oh0 + g.rows_per_wg : g.H;
+    float breg[32];   // B operand: w[channel kk*32 + st][column l31] (columns >= 9*Co are zero in the pack)
+#pragma unroll
+    for (int st = 0; st < 32; ++st) breg[st] = wt[(kk * 32 + st) * 32 + l31];
+
+    // this lane's P pixel: local index pl = wave*32 + l31 (image column ow0 - 1 + pl); needed while pl < TW + 2
+    const int pl = wave * 32 + l31;
+    const int pxi = ow0 - 1 + pl;
+    const bool px_ok = pl < TO3_PW && (unsigned)pxi < (unsigned)g.W;
+    auto load_row = [&](int v, f32x4 (&av)[8], f32x4 (&yv)[8]) {
+        const bool ok = px_ok && (unsigned)v < (unsigned)g.H;
+        const size_t idx = ok ? ((size_t)(n * g.H + v) * g.W + pxi) * CI + kk * 32 : (size_t)0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(x + idx + 4 * j);
+            av[j] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (HAS_ACT) yv[j] = *reinterpret_cast<const f32x4*>(xact + idx + 4 * j);
+        }
+    };
+
+    f32x4 av[8], yv[8], nav[8], nyv[8];
+    load_row(oh0 - 1, av, yv);
+    for (int v = oh0 - 1; v <= oh1; ++v) {   // P rows oh0 - 1 .. oh1; output row v - 1 follows P row v
+        if (v < oh1) load_row(v + 1, nav, nyv);   // in flight under this row's MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (wave * 32 < TO3_PW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = av[j][e];
+                    if (HAS_ACT) a *= yv[j][e] > 0.f ? 1.f : g.ns;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[4 * j + e], acc, 0, 0, 0);
+                }
+            // P row v -> ring slot v mod 3: acc[r] = P[pixel wave*32 + row(r)][column l31]
+            float* slot = pring + ((v + 3) % 3) * (TO3_PW * LDP);
+            if (l31 < LDP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (p < TO3_PW) slot[p * LDP + l31] = acc[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int oh = v - 1;
+        if (oh >= oh0 && oh < oh1) {
+            for (int o = tid; o < TO3_TW * g.Co; o += 320) {   // output (pixel px_o, channel co_o): 128 * Co <= 384 per row
+                const int px_o = o / g.Co, co_o = o - px_o * g.Co;
+                if (ow0 + px_o >= g.W) continue;
+                float s = bias ? bias[co_o] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float* row = pring + ((oh + r - 1 + 3) % 3) * (TO3_PW * LDP);   // P row oh + r - 1 (a zero row outside the image)
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) s += row[(px_o + s_) * LDP + (r * 3 + s_) * g.Co + co_o];
+                }
+                y[((size_t)(n * g.H + oh) * g.W + ow0 + px_o) * g.Co + co_o] = act_apply(s, g.act, g.slope);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            av[j] = nav[j];
+            if (HAS_ACT) yv[j] = nyv[j];
+        }
+    }
+}
+// wt[c][32]: column (r*3 + s)*Co + co.  dgrad == 0: = w_oihw[co][c][r][s] (w is [Co][64][3][3]: the forward weight of the thin-output layer);
+// dgrad != 0: = w_oihw[c][co][2 - r][2 - s] (w is [64][Co][3][3]: the weight of an image-input layer whose input gradient is wanted)
+__global__ void thinout3_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int dgrad) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * 32) return;
+    const int c = idx >> 5, col = idx & 31;
+    float v = 0.f;
+    if (col < 9 * Co) {
+        const int t = col / Co, co = col - t * Co, r = t / 3, s = t - r * 3;
+        v = dgrad ? w[(((size_t)c * Co + co) * 3 + (2 - r)) * 3 + (2 - s)] : w[(((size_t)co * 64 + c) * 3 + r) * 3 + s];
+    }
+    wt[idx] = v;
+}
+MIGAN_API int migan_thinout3_ok(int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather, long long pixels) {
+    return Ci == 64 && Co >= 1 && Co <= 3 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && gather == GATHER_ZERO &&
+           pixels >= 16384;
+}
+MIGAN_API int migan_thinout3_pack(const float* w, float* wt, int Co, int dgrad, void* stream) {
+    if (Co < 1 || Co > 3) return (int)hipErrorInvalidValue;
+    MIGAN_LAUNCH(thinout3_pack_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w, wt, Co, dgrad);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}
+// y [N][H][W][Co] = act(bias + conv3x3(g, wt)), g = x [N][H][W][64], or x * act'(x_act) when in_act is ACT_LRELU / ACT_RELU (x_act:
+// the OUTPUT of the layer whose input gradient this computes); wt from migan_thinout3_pack; bias may be NULL
+MIGAN_API int migan_thinout3_conv(const float* x, const float* x_act, const float* wt, const float* bias, float* y, int N, int H, int W,
+                                  int Co, int act, float slope, int in_act, float in_slope, void* stream) {
+    if (!migan_thinout3_ok(64, Co, 3, 3, 1, 1, 1, GATHER_ZERO, (long long)N * H * W) || N > 65535) return (int)hipErrorInvalidValue;
+    if (in_act != ACT_NONE && (!x_act || (in_act != ACT_LRELU && in_act != ACT_RELU))) return (int)hipErrorInvalidValue;
+    ThinOutGeom g = {N, H, W, Co, act, 0, slope, in_act == ACT_LRELU ? in_slope : 0.f};
+    const int xt = (W + TO3_TW - 1) / TO3_TW;
+    int th = 32;   // two halo rows per walk: long walks, as long as there are >= 3 workgroups per CU
+    while (th > 4 && (long)xt * ((H + th - 1) / th) * N < 768) th >>= 1;
+    g.rows_per_wg = th;
+    const dim3 grid(xt, (H + th - 1) / th, N);
+    if (in_act != ACT_NONE) MIGAN_LAUNCH((thinout3_kernel<true>), grid, dim3(320), 0, (hipStream_t)stream, g, x, x_act, wt, bias, y);
+    else MIGAN_LAUNCH((thinout3_kernel<false>), grid, dim3(320), 0, (hipStream_t)stream, g, x, x_act, wt, bias, y);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -686,6 +686,16 @@ def test_image_input_conv_kernels_on_the_execution_model(idx):
     _run_gpu_test_body("test_ops_gpu", "test_rgb_conv_layers", pg, test_ops_gpu.RGB_CASES[idx])
 
 
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_thin_output_conv_kernel_on_the_execution_model(idx):
+    """test_ops_gpu.py::test_thin_output_3x3_conv (dcgan.py:62 on csrc/rgb_conv.hip's thinout3_kernel) on the execution model."""
+    _load_or_skip()
+    import pytorch_gan_amd as pg
+
+    cases = [(2, 64, 128, 1, 3), (1, 100, 170, 3, 0), (3, 48, 130, 2, 1)]
+    _run_gpu_test_body("test_ops_gpu", "test_thin_output_3x3_conv", pg, cases[idx])
+
+
 def test_step_plans_belong_to_the_step_state(emu):
     """the plans that batch a step's weight packs / dropout masks into one launch used to be one per DEVICE, so two
     step bodies alternating on a device overwrote each other's plan every step (tables rebuilt, arena re-allocated, per-weight

@@ -278,6 +278,26 @@ task_final() {   # closing pass: default bench line, kernel traces of all worklo
   task_pmcstep srgan 1 sq fetch write
 }
 
+task_thin() {   # call 16: thin-output 3x3 on the MFMA units (dcgan.py:62 forward; input gradients of the image-input layers), its input gradient
+  local O=gpurun_out/r5m; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py tests/test_fullsize_gpu.py -q -k "rgb_conv or thin_output or dcgan or srgan_step or srgan_96" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  timeout 200 python tools/conv_microbench.py --shapes dcgan --match "G.conv3" --iters 30 --repeat 3 > $O/micro.txt 2>&1
+  timeout 200 python tools/conv_microbench.py --shapes srgan --match "D.c1" --only dgrad --iters 20 --repeat 3 >> $O/micro.txt 2>&1
+  cat $O/micro.txt
+  for r in 1 2; do
+    bl $O/bench.txt dcgan 50 MIGAN_RGB=0
+    bl $O/bench.txt dcgan 50
+  done
+  ab $O/bench.txt dcgan 50 1
+  bl $O/bench.txt dcgan_ch3 50 MIGAN_RGB=0
+  bl $O/bench.txt dcgan_ch3 50
+  bl $O/bench.txt srgan 4 MIGAN_RGB=0
+  bl $O/bench.txt srgan 4
+  ab $O/bench.txt srgan 4 1
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
