@@ -244,18 +244,6 @@ int migan_rgb_conv_wgrad(const float* x, const float* dy, const float* y_act, fl
                          int N, int H, int W, int Ho, int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather, int act,
                          float slope, int accumulate_w, int accumulate_b, void* stream);
 
-/* 3x3 convolutions with 64 source channels and 1..3 OUTPUT channels, stride 1, zero padding 1 (csrc/rgb_conv.hip): dcgan.py:62
- * Conv2d(64, channels, 3, stride=1, padding=1) + Tanh, and the INPUT gradient of the image-input layers above (srgan/models.py:85,
- * vgg19.features[0]: dx = conv(dy * act'(y), w flipped and transposed) - the activation backward happens in the operand load).
- *   pack: wt [64][32] from w_oihw: dgrad == 0: w is [Co][64][3][3] (forward weight); dgrad != 0: w is [64][Co][3][3] (the weight of
- *         the layer whose input gradient is wanted)
- *   conv: y [N][H][W][Co] = act(bias + conv3x3(g, wt)), g = x [N][H][W][64] or x * act'(x_act) (in_act = 1 LeakyReLU / 2 ReLU with the
- *         layer's OUTPUT x_act; in_act = 0: x_act unused) */
-int migan_thinout3_ok(int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather, long long pixels);
-int migan_thinout3_pack(const float* w, float* wt, int Co, int dgrad, void* stream);
-int migan_thinout3_conv(const float* x, const float* x_act, const float* wt, const float* bias, float* y, int N, int H, int W, int Co,
-                        int act, float slope, int in_act, float in_slope, void* stream);
-
 /* Thin-N convolutions (Co <= 4 output channels, stride 1: cyclegan/models.py:82 ReflectionPad2d(3)+Conv2d(64,3,7),
  * srgan/models.py:62 Conv2d(64,3,9,1,4); needs 16 <= S*Co <= 32, Ci % 4 == 0, Ci >= 16) on the MFMA kernels through a width-Toeplitz
  * expansion: the kernel column s moves into the GEMM N dimension (Co' = S*Co rounded up to 4 columns, 84 % of a 32-wide

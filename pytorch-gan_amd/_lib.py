@@ -71,9 +71,6 @@ _SIGS = {
     "migan_rgb_conv_wgrad_ok": (c_int, [c_int] * 6 + [ctypes.c_longlong]),
     "migan_rgb_conv_wgrad_workspace": (c_size_t, [c_int] * 3),
     "migan_rgb_conv_wgrad": (c_int, [P, P, P, P, P, P, c_size_t] + [c_int] * 12 + [c_float, c_int, c_int, P]),
-    "migan_thinout3_ok": (c_int, [c_int] * 8 + [ctypes.c_longlong]),
-    "migan_thinout3_pack": (c_int, [P, P, c_int, c_int, P]),
-    "migan_thinout3_conv": (c_int, [P, P, P, P, P] + [c_int] * 5 + [c_float, c_int, c_float, P]),
     "migan_thin_toeplitz_ok": (c_int, [c_int] * 6),
     "migan_thin_toeplitz_cols": (c_int, [c_int] * 2),
     "migan_thin_toeplitz_workspace": (c_size_t, [c_int] * 5),

@@ -387,141 +387,8 @@ MIGAN_API int migan_rgb_conv_wgrad(const float* x, const float* dy, const float*
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ thin-OUTPUT 3x3 (<= 3 output channels)
-// y[p][co] = act(b[co] + sum_{r,s,c} g[p + (r-1, s-1)][c] * w[c][(r,s,co)]),  64 source channels, stride 1, zero padding 1:
-//   * dcgan.py:62 Conv2d(64, channels, 3, stride=1, padding=1) + Tanh (forward: g = x), and
-//   * the INPUT gradient of the image-input layers above (srgan/models.py:85, vgg19.features[0] in the generator's update, srgan.py:121-128:
-//     dx = conv(g, w flipped and transposed), g = dy * act'(y) - the activation backward of that layer happens in the operand load).
-// These are GEMMs with N = 1..3 columns, served so far by one-pixel-per-lane VALU kernels behind an LDS window (66 us for the 134 MB
-// of dcgan.py:62 against a 25 us read; 358 us + a 162 us activation-backward pass for the 604 MB of SRGAN's first-layer gradients).
-// The tap index moves into N: P[q][(r,s,co)] = sum_c g[q][c] w[c][(r,s,co)] is a plain GEMM with K = 64 and 9*Co <= 27 columns - one
-// 32-column MFMA block - whose A operand is read straight from global memory in the MFMA's layout (a lane = one pixel, 32 contiguous
-// channels: the k-permutation k <-> channel kk*32 + step makes a lane's operands one 128-byte run), and y[p] = sum_{r,s} P[p+(r-1,s-1)]
-// [(r,s,co)] is a 9-term gather out of a 3-row LDS ring.  A workgroup of five waves owns a 128-pixel column strip (130 P pixels) and
-// walks down TH rows; the source is read once (+ 2 / TH halo rows), nothing but y is written.
-struct ThinOutGeom {
-    int N, H, W, Co, act, rows_per_wg;
-    float slope, ns;   // ns: negative-side factor of the FUSED activation backward on the operand (slope / 0)
-};
-#define TO3_TW 128
-#define TO3_PW (TO3_TW + 2)
-template <bool HAS_ACT>
-__global__ __launch_bounds__(320) void thinout3_kernel(const ThinOutGeom g, const float* __restrict__ x, const float* __restrict__ xact,
-                                                       const float* __restrict__ wt, const float* __restrict__ bias,
-                                                       float* __restrict__ y) {
-    constexpr int CI = 64, LDP = 28;
-    __shared__ float pring[3 * TO3_PW * LDP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, kk = lane >> 5;
-    const int ow0 = blockIdx.x * TO3_TW, n = blockIdx.z;
-    const int oh0 = blockIdx.y * g.rows_per_wg;
-    const int oh1 = oh0 + g.rows_per_wg < g.H ? oh0 + g.rows_per_wg : g.H;
-    float breg[32];   // B operand: w[channel kk*32 + st][column l31] (columns >= 9*Co are zero in the pack)
-#pragma unroll
-    for (int st = 0; st < 32; ++st) breg[st] = wt[(kk * 32 + st) * 32 + l31];
-
-    // this lane's P pixel: local index pl = wave*32 + l31 (image column ow0 - 1 + pl); needed while pl < TW + 2
-    const int pl = wave * 32 + l31;
-    const int pxi = ow0 - 1 + pl;
-    const bool px_ok = pl < TO3_PW && (unsigned)pxi < (unsigned)g.W;
-    auto load_row = [&](int v, f32x4 (&av)[8], f32x4 (&yv)[8]) {
-        const bool ok = px_ok && (unsigned)v < (unsigned)g.H;
-        const size_t idx = ok ? ((size_t)(n * g.H + v) * g.W + pxi) * CI + kk * 32 : (size_t)0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(x + idx + 4 * j);
-            av[j] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (HAS_ACT) yv[j] = *reinterpret_cast<const f32x4*>(xact + idx + 4 * j);
-        }
-    };
-
-    f32x4 av[8], yv[8], nav[8], nyv[8];
-    load_row(oh0 - 1, av, yv);
-    for (int v = oh0 - 1; v <= oh1; ++v) {   // P rows oh0 - 1 .. oh1; output row v - 1 follows P row v
-        if (v < oh1) load_row(v + 1, nav, nyv);   // in flight under this row's MFMAs
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (wave * 32 < TO3_PW) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = av[j][e];
-                    if (HAS_ACT) a *= yv[j][e] > 0.f ? 1.f : g.ns;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[4 * j + e], acc, 0, 0, 0);
-                }
-            // P row v -> ring slot v mod 3: acc[r] = P[pixel wave*32 + row(r)][column l31]
-            float* slot = pring + ((v + 3) % 3) * (TO3_PW * LDP);
-            if (l31 < LDP) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    if (p < TO3_PW) slot[p * LDP + l31] = acc[r];
-                }
-            }
-        }
-        __syncthreads();
-        const int oh = v - 1;
-        if (oh >= oh0 && oh < oh1) {
-            for (int o = tid; o < TO3_TW * g.Co; o += 320) {   // output (pixel px_o, channel co_o): 128 * Co <= 384 per row
-                const int px_o = o / g.Co, co_o = o - px_o * g.Co;
-                if (ow0 + px_o >= g.W) continue;
-                float s = bias ? bias[co_o] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const float* row = pring + ((oh + r - 1 + 3) % 3) * (TO3_PW * LDP);   // P row oh + r - 1 (a zero row outside the image)
-#pragma unroll
-                    for (int s_ = 0; s_ < 3; ++s_) s += row[(px_o + s_) * LDP + (r * 3 + s_) * g.Co + co_o];
-                }
-                y[((size_t)(n * g.H + oh) * g.W + ow0 + px_o) * g.Co + co_o] = act_apply(s, g.act, g.slope);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            av[j] = nav[j];
-            if (HAS_ACT) yv[j] = nyv[j];
-        }
-    }
-}
-// wt[c][32]: column (r*3 + s)*Co + co.  dgrad == 0: = w_oihw[co][c][r][s] (w is [Co][64][3][3]: the forward weight of the thin-output layer);
-// dgrad != 0: = w_oihw[c][co][2 - r][2 - s] (w is [64][Co][3][3]: the weight of an image-input layer whose input gradient is wanted)
-__global__ void thinout3_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int dgrad) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 64 * 32) return;
-    const int c = idx >> 5, col = idx & 31;
-    float v = 0.f;
-    if (col < 9 * Co) {
-        const int t = col / Co, co = col - t * Co, r = t / 3, s = t - r * 3;
-        v = dgrad ? w[(((size_t)c * Co + co) * 3 + (2 - r)) * 3 + (2 - s)] : w[(((size_t)co * 64 + c) * 3 + r) * 3 + s];
-    }
-    wt[idx] = v;
-}
-MIGAN_API int migan_thinout3_ok(int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int gather, long long pixels) {
-    return Ci == 64 && Co >= 1 && Co <= 3 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && gather == GATHER_ZERO &&
-           pixels >= 16384;
-}
-MIGAN_API int migan_thinout3_pack(const float* w, float* wt, int Co, int dgrad, void* stream) {
-    if (Co < 1 || Co > 3) return (int)hipErrorInvalidValue;
-    MIGAN_LAUNCH(thinout3_pack_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w, wt, Co, dgrad);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-// y [N][H][W][Co] = act(bias + conv3x3(g, wt)), g = x [N][H][W][64], or x * act'(x_act) when in_act is ACT_LRELU / ACT_RELU (x_act:
-// the OUTPUT of the layer whose input gradient this computes); wt from migan_thinout3_pack; bias may be NULL
-MIGAN_API int migan_thinout3_conv(const float* x, const float* x_act, const float* wt, const float* bias, float* y, int N, int H, int W,
-                                  int Co, int act, float slope, int in_act, float in_slope, void* stream) {
-    if (!migan_thinout3_ok(64, Co, 3, 3, 1, 1, 1, GATHER_ZERO, (long long)N * H * W) || N > 65535) return (int)hipErrorInvalidValue;
-    if (in_act != ACT_NONE && (!x_act || (in_act != ACT_LRELU && in_act != ACT_RELU))) return (int)hipErrorInvalidValue;
-    ThinOutGeom g = {N, H, W, Co, act, 0, slope, in_act == ACT_LRELU ? in_slope : 0.f};
-    const int xt = (W + TO3_TW - 1) / TO3_TW;
-    int th = 32;   // two halo rows per walk: long walks, as long as there are >= 3 workgroups per CU
-    while (th > 4 && (long)xt * ((H + th - 1) / th) * N < 768) th >>= 1;
-    g.rows_per_wg = th;
-    const dim3 grid(xt, (H + th - 1) / th, N);
-    if (in_act != ACT_NONE) MIGAN_LAUNCH((thinout3_kernel<true>), grid, dim3(320), 0, (hipStream_t)stream, g, x, x_act, wt, bias, y);
-    else MIGAN_LAUNCH((thinout3_kernel<false>), grid, dim3(320), 0, (hipStream_t)stream, g, x, x_act, wt, bias, y);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
+// (Round 5 also built the thin-OUTPUT 3x3 layers - dcgan.py:62 forward, and the input gradients of the image-input layers above - as an
+// MFMA kernel: nine taps as GEMM columns, the A operand read from global memory in the MFMA's own layout (a lane = one pixel's 32
+// contiguous channels), a 9-term gather out of an LDS ring.  Measured and removed: 115.6 us against 62.0 us for the one-pixel-per-lane
+// VALU kernel on dcgan.py:62, 553.9 us against 354 + 162 us on SRGAN's first-layer gradient, the DCGAN step 2.62 vs 2.53 ms
+// (profiles/r05_ab.txt call 16) - 64 lanes reading 16 bytes each from 64 different cache lines per instruction thrash the L1.)

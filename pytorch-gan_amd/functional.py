@@ -686,15 +686,6 @@ class _Conv2d(Function):
             ctx.rgb = True
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
             return y
-        if (_RGB and mask is None and stats_buf is None and w.is_contiguous() and (pt, pl, pb, pr) == (1, 1, 1, 1)
-                and lib.migan_thinout3_ok(Ci, Co, R, S, stride, pt, pl, gather, N * Ho * Wo) == 1):
-            # image-OUTPUT 3x3 layer (dcgan.py:62 Conv2d(64, channels, 3, 1, 1) + Tanh): the nine taps as GEMM columns (csrc/rgb_conv.hip)
-            wt = _packed(w_in, w, "to3f", lambda: _thinout3_pack(w, Co, 0))
-            y = _empty_nhwc((N, Co, Ho, Wo), xs)
-            check(lib.migan_thinout3_conv(xs.data_ptr(), None, wt.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Co, act, slope, ACT_NONE,
-                                          0.0, _stream()), "thinout3_conv")
-            ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
-            return y
         wp = _packed_perm(w_in, w, "ohwi", (0, 2, 3, 1))
         y = _empty_nhwc((N, Co, Ho, Wo), xs)
         if mask is not None:
@@ -766,38 +757,28 @@ class _Conv2d(Function):
                 check(lib.migan_col2im_small(ycol.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, Ho, Wo, R, S, stride, pt, pl, 0, 0.0,
                                              st), "col2im_small")
             return dx, dw, db, None, None, None, None, None, None, None, None, None
-        rgb = getattr(ctx, "rgb", False) and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
-        rgb_w = rgb and ctx.needs_input_grad[1] and lib.migan_rgb_conv_wgrad_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1
-        rgb_x = (rgb and ctx.needs_input_grad[0] and (pt, pl, pb, pr) == (1, 1, 1, 1) and Co == 64
-                 and lib.migan_thinout3_ok(Co, Ci, R, S, stride, pt, pl, gather, N * H * W) == 1)
-        if (rgb_w or not ctx.needs_input_grad[1]) and (rgb_x or not ctx.needs_input_grad[0]) and (rgb_w or rgb_x):
-            # image-input layer (srgan/models.py:85, vgg19.features[0], cyclegan/models.py:50): the activation backward is never a pass
-            # of its own - the weight-gradient launch (with the bias column sums) and the input-gradient launch each apply act'(y) to
-            # dy as they load it (csrc/rgb_conv.hip); they were activation backward (+ column sums) -> 604 MB gradient -> two readers
-            dx = dw = db = None
-            yact = y if act != ACT_NONE else None
-            if rgb_w:
-                fork = _Fork(xs.device, dy.numel(), True)
-                with fork:
-                    slot = _grad_slot(ctx.params[0])
-                    dw = torch.empty_like(w) if slot is None else slot
-                    dbt, dba = None, 0
-                    if want_db:
-                        dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
-                    nb = lib.migan_rgb_conv_wgrad_workspace(Co, R, S)
-                    ws = _ws(nb, xs)
-                    check(lib.migan_rgb_conv_wgrad(xs.data_ptr(), dy.data_ptr(), _ptr(yact), dw.data_ptr(), _ptr(dbt), ws.data_ptr(), nb,
-                                                   N, H, W, Ho, Wo, Co, R, S, pt, pl, gather, act, slope, 0 if slot is None else 1, dba,
-                                                   _stream()), "rgb_conv_wgrad")
-                    if slot is not None:
-                        dw = None
-                fork.join((dw, db), (dy, xs, y))
-            if rgb_x:   # dx = conv3x3(dy * act'(y), w flipped and transposed): 64 -> 3 channels on the MFMA units
-                wt = _packed(ctx.params[0], w, "to3d", lambda: _thinout3_pack(w, Ci, 1))
-                dx = _empty_nhwc((N, Ci, H, W), xs)
-                check(lib.migan_thinout3_conv(dy.data_ptr(), _ptr(yact), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, ACT_NONE, 0.0,
-                                              act, slope, _stream()), "thinout3_conv (dgrad)")
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+        if (getattr(ctx, "rgb", False) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
+                and lib.migan_rgb_conv_wgrad_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
+            # image-input layer, weights only (the discriminator's first conv in its own update, srgan.py:129-141): the activation
+            # backward, the bias column sums and the weight gradient in ONE launch that reads dy and y once (csrc/rgb_conv.hip) -
+            # they were three passes, one of which wrote a 604 MB gradient only for the next to read it
+            fork = _Fork(xs.device, dy.numel(), True)
+            with fork:
+                slot = _grad_slot(ctx.params[0])
+                dw = torch.empty_like(w) if slot is None else slot
+                dbt, dba, db = (None, 0, None)
+                if want_db:
+                    dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
+                nb = lib.migan_rgb_conv_wgrad_workspace(Co, R, S)
+                ws = _ws(nb, xs)
+                check(lib.migan_rgb_conv_wgrad(xs.data_ptr(), dy.data_ptr(), _ptr(y) if act != ACT_NONE else None, dw.data_ptr(),
+                                               _ptr(dbt), ws.data_ptr(), nb, N, H, W, Ho, Wo, Co, R, S, pt, pl, gather, act, slope,
+                                               0 if slot is None else 1, dba, _stream()), "rgb_conv_wgrad")
+                if slot is not None:
+                    dw = None
+            fork.join((dw, db), (dy, xs, y))
+            return None, dw, db, None, None, None, None, None, None, None, None, None
         # bias gradient = column sums of the gradient the wgrad consumes: taken from the kernel that writes that gradient
         # (this conv's activation backward, or the norm layer behind the conv) and reduced inside the wgrad launch
         side = None
@@ -934,13 +915,6 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
 # A/B knob: 0 = the direct VALU kernels (thin_conv_kernel / thin_wgrad_tile_kernel) for the 7x7 / 9x9 image-output convs
 _TOEPLITZ = __import__("os").environ.get("MIGAN_TOEPLITZ", "1") == "1"
 _TOEP_MIN_PIXELS = 65536  # below this the two extra streaming launches outweigh the GEMM's gain
-
-
-def _thinout3_pack(w, co_out, dgrad):
-    """wt [64][32] of migan_thinout3_pack (columns (r, s, co)): forward weight [Co][64][3][3], or, dgrad, an image-input layer's [64][Co][3][3]."""
-    wt = torch.empty(64 * 32, device=w.device, dtype=torch.float32)
-    check(lib.migan_thinout3_pack(w.data_ptr(), wt.data_ptr(), co_out, dgrad, _stream()), "thinout3_pack")
-    return wt
 
 
 def _toep_pack(w):

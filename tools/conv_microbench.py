@@ -189,25 +189,12 @@ def main():
                 calls["xwgrad"] = lambda: lib.migan_rgb_conv_wgrad(x.data_ptr(), dy.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                                                    wsx.data_ptr(), nbx, N, H, W, Ho, Wo, Co, k, k, p, p, gth, 1, 0.2, 0, 0, st)
                 dirs += ["xwgrad"]
-        if lib.migan_rgb_conv_ok(Ci, Co, k, k, s, gth, N * Ho * Wo) == 1 and lib.migan_thinout3_ok(Co, Ci, k, k, s, p, p, gth, N * H * W) == 1:
-            # input gradient of the image-input layer: conv3x3(dy * act'(y), w flipped / transposed) on the thin-output kernel, act' fused
-            wtd = torch.empty(64 * 32, device=dev)
-            check(lib.migan_thinout3_pack(w.data_ptr(), wtd.data_ptr(), Ci, 1, st), "to3 pack")
-            dx3 = torch.empty(N * H * W * Ci, device=dev)
-            calls["xdgrad"] = lambda: lib.migan_thinout3_conv(dy.data_ptr(), y.data_ptr(), wtd.data_ptr(), None, dx3.data_ptr(), N, H, W, Ci,
-                                                              0, 0.0, 1, 0.2, st)
-            dirs += ["xdgrad"]
-        if lib.migan_thinout3_ok(Ci, Co, k, k, s, p, p, gth, N * Ho * Wo) == 1:
-            # thin-OUTPUT layer (dcgan.py:62): ofwd = forward + Tanh on the MFMA kernel; odgrad = its input gradient on the image-input kernel
-            wtf = torch.empty(64 * 32, device=dev)
-            check(lib.migan_thinout3_pack(w.data_ptr(), wtf.data_ptr(), Co, 0, st), "to3 pack")
-            calls["ofwd"] = lambda: lib.migan_thinout3_conv(x.data_ptr(), None, wtf.data_ptr(), None, y.data_ptr(), N, H, W, Co, 3, 0.0, 0, 0.0, st)
-            dirs += ["ofwd"]
-            if lib.migan_rgb_conv_ok(Co, Ci, k, k, s, gth, N * H * W) == 1:
-                wko = w.view(Co, Ci, k, k).permute(2, 3, 0, 1).contiguous()
-                calls["odgrad"] = lambda: lib.migan_rgb_conv_fwd(dy.data_ptr(), wko.data_ptr(), None, dx.data_ptr(), N, H, W, Co, H, W, Ci, k, k,
-                                                                 p, p, 0, 0, 0.0, 1, st)
-                dirs += ["odgrad"]
+        if Co <= 3 and lib.migan_rgb_conv_ok(Co, Ci, k, k, s, gth, N * H * W) == 1 and p == 1 and gth == 0:
+            # thin-OUTPUT layer (dcgan.py:62): odgrad = its input gradient on the image-input forward kernel, taps reversed
+            wko = w.view(Co, Ci, k, k).permute(2, 3, 0, 1).contiguous()
+            calls["odgrad"] = lambda: lib.migan_rgb_conv_fwd(dy.data_ptr(), wko.data_ptr(), None, dx.data_ptr(), N, H, W, Co, H, W, Ci, k, k,
+                                                             p, p, 0, 0, 0.0, 1, st)
+            dirs += ["odgrad"]
         for d in dirs:
             if exact is not None:
                 if d not in exact:
