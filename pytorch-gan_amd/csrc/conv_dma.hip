@@ -471,9 +471,9 @@ int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, cons
                      size_t ws_bytes, hipStream_t st) {
     ConvGeom g = g_in;
     {
-        // 8 x 16-pixel M blocks (ConvGeom::m2d) for tall column kernels - the R x 1 GEMM of the width-Toeplitz forward (R = 7 / 9, one
-        // column): MIGAN_M2D=0 off, 1 (default) those, 2 every stride-1 one-class geometry with >= 3 kernel rows (A/B knob, round 5)
-        static const int m2d_env = getenv("MIGAN_M2D") ? atoi(getenv("MIGAN_M2D")) : 1;
+        // 8 x 16-pixel M blocks (ConvGeom::m2d) for tall column kernels - the R x 1 GEMMs of the width-Toeplitz layers (R = 7 / 9, one
+        // column).  (For every stride-1 3x3 layer it was measured 1-3 % slower, profiles/r05_ab.txt call 10: constant 1.)
+        constexpr int m2d_env = 1;
         int rows = 0, cols = 0;   // kernel extent from the tap offsets
         if (g.ncls == 1 && g.ntap[0] > 0) {
             int dh0 = 1 << 20, dh1 = -(1 << 20), dw0 = 1 << 20, dw1 = -(1 << 20);

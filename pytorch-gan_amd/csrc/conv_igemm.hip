@@ -2414,9 +2414,9 @@ static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int oc
 // Upsample + Conv3x3 weight gradient with <= 64 output channels (dcgan.py:59, cyclegan/models.py:75 - the dominant launch of the DCGAN step):
 // 64 x 256 tiles.  A 64 x 128 tile fetches the strided dy rows once per N-tile - four times for the 512 collapsed columns of a
 // 128-channel source - and gives a wave 32 MFMAs between two barriers; with 256 columns a wave runs 64 (one A fragment feeds four
-// accumulator tiles) and dy is fetched twice.  MIGAN_UPW_BN=128 keeps the narrower tile (A/B knob, round 5).
+// accumulator tiles) and dy is fetched twice.  Measured 299 -> 290 us on both layers (profiles/r05_ab.txt call 12).
 static int upw_bn(int N, int H, int W, int Co, int Ci) {   // 256 or 0 (the general rule); the workspace query and the launch both ask here
-    static const int env = getenv("MIGAN_UPW_BN") ? atoi(getenv("MIGAN_UPW_BN")) : 256;
+    constexpr int env = 256;
     const bool fits = (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31) && W % 8 == 0;
     return (env == 256 && fits && Co <= 64 && Co > 32 && (4 * Ci) % 256 == 0) ? 256 : 0;
 }

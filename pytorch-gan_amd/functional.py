@@ -47,7 +47,6 @@ _WGRAD_STREAM_MIN = 6 << 20   # (1 M and 256 k measured on SRGAN: 82.7-82.8 vs 8
 # those additions stay serial and in the order of the one-stream step.
 _WGRAD_ONE_STREAM = 0
 _PENDING_WGRAD = {}
-_CAPTURE_REFS = __import__("os").environ.get("MIGAN_CAPTURE_REFS", "1") == "1"   # A/B knob (round 5)
 _PENDING_READS = []   # tensors read by deferred weight-gradient launches of a recording in progress (see _Fork.join)
 
 
@@ -116,7 +115,7 @@ class _Fork:
             raise RuntimeError("one_wgrad_stream(): a parameter gradient without a gradient slot would be accumulated by autograd on its "
                                "own stream (the step body must own every parameter through an optimiser's bucket)")
         if self.defer and all(t is None for t in returned):
-            if _CAPTURE_REFS and torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
                 # inside a recording the allocator frees a block with a recorded stream use only when the capture ends: every activation
                 # and gradient a forked weight gradient reads would stay pinned for the whole recorded step.  Holding the tensors by
                 # reference until the join has the same effect on correctness (not recycled under the side launch) and releases them at
