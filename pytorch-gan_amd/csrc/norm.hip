@@ -148,7 +148,16 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
         };
         // four pixels' loads in flight per thread (a thread walks 9-512 pixels: one load at a time left the pass latency-bound at
         // 2.2 TB/s on the 38-75 MB tensors of SRGAN's trunk against 4-5 TB/s for the apply pass, profiles/r04_srgan_kernel_stats.txt)
+        // (round 5: eight where the thread has eight left - the 144-pixel chunks of SRGAN's trunk are 9 pixels per thread: one round + one
+        // instead of three dependent round trips)
         int p = p0 + ty;
+        for (; !BWD && p + 7 * TY < p1; p += 8 * TY) {   // (the backward form would need 179 registers: two waves per SIMD)
+            float xv[8][VW], dv[8][VW];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load(p + u * TY, xv[u], dv[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) accum(xv[u], dv[u]);
+        }
         for (; p + 3 * TY < p1; p += 4 * TY) {
             float xv[4][VW], dv[4][VW];
 #pragma unroll

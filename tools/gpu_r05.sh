@@ -298,6 +298,18 @@ task_thin() {   # call 16: thin-output 3x3 on the MFMA units (dcgan.py:62 forwar
   cat $O/bench.txt
 }
 
+task_ab_all() {   # call 17: the tree against the round-start tree on one box, all workloads; norm statistics pass with eight loads in flight
+  local O=gpurun_out/r5n; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -k "norm or thin_output or rgb_conv or dcgan_steps or srgan_step" --durations=3 > $O/pytest.txt 2>&1
+  tail -4 $O/pytest.txt
+  ab $O/bench.txt dcgan 50 2
+  ab $O/bench.txt srgan 4 2
+  ab $O/bench.txt cyclegan 4 1
+  ab $O/bench.txt pix2pix 50 1
+  ab $O/bench.txt dcgan_ch3 50 1
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
