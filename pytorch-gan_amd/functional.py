@@ -873,14 +873,9 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
             main.wait_stream(side)
 
         return dx, join
-    if (gather == GATHER_ZERO and _RGB and not ctx.relu_in and (R, S, stride) == (3, 3, 1) and (pt, pl, pb, pr) == (1, 1, 1, 1)
-            and w.is_contiguous() and lib.migan_rgb_conv_ok(Co, Ci, R, S, 1, GATHER_ZERO, N * H * W) == 1):
-        # input gradient of a thin-OUTPUT layer (dcgan.py:62 Conv2d(64, channels, 3, 1, 1)): 64 channels back from 1 or 3 - the image-input
-        # forward kernel on dy with the taps reversed (csrc/rgb_conv.hip), bound by writing dx once
-        wk = _packed_perm(ctx.params[0], w, "hwoi", (2, 3, 0, 1))
-        check(lib.migan_rgb_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, Co, H, W, Ci, R, S, 1, 1, GATHER_ZERO,
-                                     ACT_NONE, 0.0, 1, st), "rgb_conv_fwd (dgrad of a thin-output layer)")
-        return dx
+    # (The input gradient of a thin-OUTPUT layer - dcgan.py:62: 64 channels back from 1 or 3 - also runs on the image-input forward kernel
+    # with the taps reversed, migan_rgb_conv_fwd(..., flip = 1): 45.5 vs 54.4 us stand-alone, but the captured DCGAN step measured
+    # 2.530 / 2.531 ms with it against 2.521 / 2.529 without, profiles/r05_ab.txt call 18 - the host mirror stays on the general kernel.)
     if gather == GATHER_ZERO:
         skp, skb = _splitk_ws(dy, N * -(-H // stride) * -(-W // stride), Ci, Co, stride * stride)
         rc = 801

@@ -688,7 +688,7 @@ def test_image_input_conv_kernels_on_the_execution_model(idx):
 
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_thin_output_conv_kernel_on_the_execution_model(idx):
-    """test_ops_gpu.py::test_thin_output_3x3_conv (dcgan.py:62; its input gradient on csrc/rgb_conv.hip's forward kernel, taps reversed)."""
+    """test_ops_gpu.py::test_thin_output_3x3_conv (dcgan.py:62; its input gradient also through migan_rgb_conv_fwd with reversed taps)."""
     _load_or_skip()
     import pytorch_gan_amd as pg
 

@@ -159,8 +159,8 @@ def test_rgb_conv_layers(pg, case):
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 1, 3), (1, 100, 170, 3, 0), (3, 48, 130, 2, 1)], ids=["dcgan_g_conv3", "ch3_ragged", "two_ch"])
 def test_thin_output_3x3_conv(pg, case):
-    """dcgan.py:62 Conv2d(64, channels, 3, stride=1, padding=1) + Tanh against torch; its INPUT gradient - 64 channels back from 1 or 3 -
-    runs on the image-input forward kernel with the taps reversed (csrc/rgb_conv.hip, launch counter)."""
+    """dcgan.py:62 Conv2d(64, channels, 3, stride=1, padding=1) + Tanh against torch; and its INPUT gradient - 64 channels back from 1 or 3 -
+    also through the C ABI's image-input forward kernel with the taps reversed (migan_rgb_conv_fwd, flip = 1)."""
     N, H, W, Co, act = case
     F = pg.functional
     x = _leaf(N, 64, H, W, seed=1).requires_grad_(True)
@@ -172,9 +172,19 @@ def test_thin_output_3x3_conv(pg, case):
     y_ref.backward(gy)
     xg, wg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
     y = F.conv2d(xg, wg, bg, 1, (1, 1, 1, 1), 0, act, 0.2)
-    with Launches() as n:
-        y.backward(gy.to(DEV))
-        assert n("rgb_conv_fwd_kernel") == (1 if Co in (1, 3) else 0), "input gradient of the 1 / 3-channel layer not on the image-input kernel"
+    y.backward(gy.to(DEV))
+    if Co in (1, 3) and act == 0 or Co == 1:
+        # the C ABI's other form of this input gradient: the image-input forward kernel on dy with reversed taps (migan_rgb_conv_fwd, flip = 1)
+        from pytorch_gan_amd._lib import check, lib
+
+        g_pre = gy if act == 0 else gy * (1 - y_ref.detach() ** 2)   # through Tanh for the dcgan.py:62 case
+        dyd = F.to_nhwc(g_pre.to(DEV))
+        wk = w.detach().permute(2, 3, 0, 1).contiguous().to(DEV)
+        dx = torch.empty((N, 64, H, W), device=DEV).contiguous(memory_format=torch.channels_last)
+        assert lib.migan_rgb_conv_ok(Co, 64, 3, 3, 1, 0, N * H * W) == 1
+        check(lib.migan_rgb_conv_fwd(dyd.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, Co, H, W, 64, 3, 3, 1, 1, 0, 0, 0.0, 1,
+                                     torch.cuda.current_stream().cuda_stream), "rgb_conv_fwd flip")
+        assert_close(dx, x.grad, TOL_FWD, "thin-output dgrad on the image-input kernel (taps reversed)")
     assert_close(y, y_ref, TOL_FWD, "thin-output fwd")
     assert_close(xg.grad, x.grad, TOL_FWD, "thin-output dgrad")
     assert_close(wg.grad, w.grad, TOL_WGRAD, "thin-output wgrad")

@@ -310,6 +310,16 @@ task_ab_all() {   # call 17: the tree against the round-start tree on one box, a
   cat $O/bench.txt
 }
 
+task_dcgan_bisect() {   # call 18: which change costs the DCGAN step 2.7 % (call 17)
+  local O=gpurun_out/r5o; mkdir -p $O
+  for r in 1 2; do
+    (cd ab_base && echo "== base dcgan" >> $R/$O/bench.txt && timeout 300 python bench.py --workload dcgan --steps 50 --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$R/$O/bench.txt.err | line >> $R/$O/bench.txt)
+    bl $O/bench.txt dcgan 50 MIGAN_RGB=0
+    bl $O/bench.txt dcgan 50
+  done
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
