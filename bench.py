@@ -445,6 +445,20 @@ class ConvProfiler:
             f = 2.0 * N * H * W * Co * Ci * 9
             return ("dgrad_reflect1" + shape(N, Ci, Co, H, 3, 1), f, f)
 
+        # image-input layers (csrc/rgb_conv.hip): FLOPs of the layer as the reference specifies it
+        def rgb_fwd(a):
+            N, H, W, Ci, Ho, Wo, Co, R, S = a[4:13]
+            f = 2.0 * N * Ho * Wo * Co * Ci * R * S
+            return ("rgb_fwd" + shape(N, Ci, Co, Ho, R, 1), f, f)
+
+        def rgb_wgrad(a):
+            N, H, W, Ho, Wo, Co, R, S = a[7:15]
+            f = 2.0 * N * Ho * Wo * Co * 3 * R * S
+            return ("rgb_wgrad_act_bias" + shape(N, 3, Co, Ho, R, 1), f, f)
+
+        self._wrap("migan_rgb_conv_fwd", rgb_fwd)
+        self._wrap("migan_rgb_conv_wgrad", rgb_wgrad)
+        self._wrap("migan_conv2d_dgrad_reflect1_ws", reflect1)
         self._wrap("migan_thin_toeplitz_fwd", toep("fwd", 6))
         self._wrap("migan_thin_toeplitz_wgrad", toep("wgrad", 5))
         self._wrap("migan_thin_toeplitz_dgrad", toep("dgrad", 5))
