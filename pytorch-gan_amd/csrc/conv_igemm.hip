@@ -648,647 +648,7 @@ MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls
     return igemm_select((long)maxM, Co, igemm_fast_ci(Ci_src), ncls);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Thin-N direct convolution (GEMM N = output channels <= 4, source channels % 4 == 0): image-output convs
-// (dcgan.py:62 64->1, cyclegan/models.py:82 7x7 64->3, srgan/models.py:62 9x9 64->3, PatchGAN heads 512->1,
-// pix2pix/models.py:79 128->3) and dgrads INTO 1/3-channel images.  An MFMA tile would be >= 87 % padding,
-// and the fp32 VALU has the same peak as the fp32 MFMA, so this is a VALU kernel: one output pixel per lane,
-// the source window of an output tile (with halo, already padded / reflected / upsampled) is staged once in LDS
-// per channel chunk with coalesced 16 B loads, each lane walks its window with conflict-free ds_read_b128, and
-// the <= 4 weight rows are wave-uniform (scalar loads).  Same ConvGeom tap lists / parity classes as the igemm.
-// ------------------------------------------------------------------------------------------------
-struct ThinConv {
-    int TH, TW, CC, logQ;        // output tile (TH*TW == 256), channel chunk, log2(CC/4)
-    int SH, SW;                  // staged window extent (logical source coordinates)
-    unsigned mgSW;               // fastdiv magic for / SW
-    int shSW;
-    int dhmin[MAX_CLS], dwmin[MAX_CLS];
-    int tiles_w[MAX_CLS], tiles[MAX_CLS];
-};
-template <int CO>
-__global__ __launch_bounds__(256) void thin_conv_kernel(const ConvGeom g, const ThinConv tc,
-                                                        const float* __restrict__ A, const float* __restrict__ Bw,
-                                                        const float* __restrict__ bias, float* __restrict__ C) {
-    extern __shared__ __attribute__((aligned(16))) float win[];
-    const int tid = threadIdx.x;
-    const int cls = blockIdx.z, n = blockIdx.y;
-    if ((int)blockIdx.x >= tc.tiles[cls]) return;
-    const int Ho = g.Ho[cls], Wo = g.Wo[cls];
-    const int tile_r = blockIdx.x / tc.tiles_w[cls], tile_c = blockIdx.x - tile_r * tc.tiles_w[cls];
-    const int oi0 = tile_r * tc.TH, oj0 = tile_c * tc.TW;
-    const int ti = tid / tc.TW, tj = tid - ti * tc.TW;
-    const int oi = oi0 + ti, oj = oj0 + tj;
-    const bool valid = oi < Ho && oj < Wo;
-    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
-    const int LDC = tc.CC + 4, Q = tc.CC >> 2;
-    const int vh0 = oi0 * g.istride + tc.dhmin[cls], vw0 = oj0 * g.istride + tc.dwmin[cls];
-    const float* Ab = A + (size_t)n * g.Hi * g.Wi * g.Ci;
-    float acc[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    const int px_off = (ti * g.istride - tc.dhmin[cls]) * tc.SW + (tj * g.istride - tc.dwmin[cls]);
-
-    for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
-        __syncthreads();
-        // stage the window: flattened over (window pixel, channel quad), THIN_LD independent branch-free loads per thread
-        // in flight (a row-by-row loop with a branch around each load pays one memory latency per load; 8 in flight were
-        // measured slower than 4 - 66.6 vs 62.5 us on the 10 x 34 x 32-channel window of dcgan.py:62, profiles/r04_ab.txt call 30)
-        constexpr int THIN_LD = 4;
-        const int total = tc.SH * tc.SW * Q;
-        for (int base = 0; base < total; base += 256 * THIN_LD) {
-            f32x4 v[THIN_LD];
-            int off[THIN_LD];
-#pragma unroll
-            for (int u = 0; u < THIN_LD; ++u) {
-                const int e = base + u * 256 + tid;
-                const bool in = e < total;
-                const int ec = in ? e : total - 1;
-                const int q = ec & (Q - 1), pidx = ec >> tc.logQ;
-                const int sr = fastdiv(pidx, tc.mgSW, tc.shSW), sc = pidx - sr * tc.SW;
-                int ihs, iws;
-                bool ok = map_bf(vh0 + sr, g.HiL, g.Hi, g.gather, ihs);
-                ok &= map_bf(vw0 + sc, g.WiL, g.Wi, g.gather, iws);
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(Ab + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + q * 4);
-                v[u] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
-                off[u] = in ? pidx * LDC + q * 4 : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < THIN_LD; ++u)
-                if (off[u] >= 0) *reinterpret_cast<f32x4*>(win + off[u]) = v[u];
-        }
-        __syncthreads();
-        if (valid) {
-            for (int t = 0; t < ntap; ++t) {
-                const int dh = g.dh[tapbeg + t], dw = g.dw[tapbeg + t];
-                const float* xr = win + (size_t)(px_off + dh * tc.SW + dw) * LDC;
-                const float* wr = Bw + g.wofs[tapbeg + t] + c0;
-                for (int c = 0; c < tc.CC; c += 4) {
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
-#pragma unroll
-                    for (int k = 0; k < CO; ++k) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (size_t)k * g.ldw + c);  // wave-uniform
-                        acc[k] = fmaf(xv[0], wv[0], acc[k]);
-                        acc[k] = fmaf(xv[1], wv[1], acc[k]);
-                        acc[k] = fmaf(xv[2], wv[2], acc[k]);
-                        acc[k] = fmaf(xv[3], wv[3], acc[k]);
-                    }
-                }
-            }
-        }
-    }
-    if (!valid) return;
-    const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
-#pragma unroll
-    for (int k = 0; k < CO; ++k) {
-        float v = acc[k];
-        if (bias) v += bias[k];
-        float o = act_apply(v, g.act, g.slope);
-        if (g.oscale) o *= g.oscale[(size_t)n * g.Co + k];
-        C[opix * g.Co + k] = o;
-    }
-}
-
-static bool thin_conv_plan(const ConvGeom& g, ThinConv& tc, size_t& lds_bytes, int& max_tiles) {
-    if (g.Co > 4 || g.Ci % 4 != 0 || g.Ci < 8 || g.ldw % 4 != 0) return false;
-    for (int t = 0; t < MAX_TAPS; ++t)
-        if (g.wofs[t] % 4 != 0) return false;
-    int wmax = 0;
-    for (int c = 0; c < g.ncls; ++c) wmax = g.Wo[c] > wmax ? g.Wo[c] : wmax;
-    tc.TW = wmax > 16 ? 32 : (wmax > 8 ? 16 : 8);
-    tc.TH = 256 / tc.TW;
-    int ehmax = 0, ewmax = 0;
-    max_tiles = 0;
-    for (int c = 0; c < g.ncls; ++c) {
-        int dh0 = 127, dh1 = -128, dw0 = 127, dw1 = -128;
-        for (int t = 0; t < g.ntap[c]; ++t) {
-            int dh = g.dh[g.tapbeg[c] + t], dw = g.dw[g.tapbeg[c] + t];
-            dh0 = dh < dh0 ? dh : dh0; dh1 = dh > dh1 ? dh : dh1;
-            dw0 = dw < dw0 ? dw : dw0; dw1 = dw > dw1 ? dw : dw1;
-        }
-        if (g.ntap[c] == 0) dh0 = dh1 = dw0 = dw1 = 0;
-        tc.dhmin[c] = dh0; tc.dwmin[c] = dw0;
-        ehmax = dh1 - dh0 > ehmax ? dh1 - dh0 : ehmax;
-        ewmax = dw1 - dw0 > ewmax ? dw1 - dw0 : ewmax;
-        tc.tiles_w[c] = cdiv(g.Wo[c], tc.TW);
-        tc.tiles[c] = tc.tiles_w[c] * cdiv(g.Ho[c], tc.TH);
-        max_tiles = tc.tiles[c] > max_tiles ? tc.tiles[c] : max_tiles;
-    }
-    tc.SH = (tc.TH - 1) * g.istride + ehmax + 1;
-    tc.SW = (tc.TW - 1) * g.istride + ewmax + 1;
-    fastdiv_magic((unsigned)tc.SW, tc.mgSW, tc.shSW);
-    // largest power-of-two channel chunk (>= 8 channels) dividing Ci whose window fits in 64 KB of LDS
-    int cc = 8;
-    for (int cand = 16; cand <= 256; cand <<= 1)
-        if (g.Ci % cand == 0 && (size_t)tc.SH * tc.SW * (cand + 4) * 4 <= 64 * 1024) cc = cand;
-    if (g.Ci % cc != 0 || (size_t)tc.SH * tc.SW * (cc + 4) * 4 > 64 * 1024) return false;
-    tc.CC = cc;
-    tc.logQ = 0;
-    while ((1 << tc.logQ) < cc / 4) ++tc.logQ;
-    lds_bytes = (size_t)tc.SH * tc.SW * (cc + 4) * 4;
-    return max_tiles > 0;
-}
-
-static int launch_thin_conv(const ConvGeom& g, const ThinConv& tc, size_t lds, int max_tiles, const float* A,
-                            const float* Bw, const float* bias, float* C, hipStream_t st) {
-    dim3 grid(max_tiles, g.N, g.ncls);
-    switch (g.Co) {
-        case 1: MIGAN_LAUNCH((thin_conv_kernel<1>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        case 2: MIGAN_LAUNCH((thin_conv_kernel<2>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        case 3: MIGAN_LAUNCH((thin_conv_kernel<3>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-        default: MIGAN_LAUNCH((thin_conv_kernel<4>), grid, dim3(256), lds, st, g, tc, A, Bw, bias, C); break;
-    }
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// Thin-N convolution with FEW output pixels (PatchGAN heads: cyclegan/models.py:118 and pix2pix/models.py:130
-// Conv2d(512,1,4,padding=1) -> 16x16 per image, srgan/models.py:100 -> 24x24): thin_conv_kernel gives such a launch
-// N * tiles workgroups (1 at the pix2pix batch, 8 at CycleGAN's) that each walk taps*Ci = 8192 products per lane
-// serially - 295 us for 4 MFLOP (profiles/r03_pix2pix_kernel_stats.txt).  Here ONE WAVE owns one output pixel: the
-// lanes split the channels (coalesced 1 KB rows of the NHWC source, straight from L2 - the whole input is < 1 MB per
-// image), every load of a tap is independent, and the 64 partial sums are combined by a fixed butterfly (deterministic).
-// Measured (profiles/r03_abi_check.txt): PatchGAN head 512 -> 1 forward 168 -> 12.4 us.
-template <int CO>
-__global__ __launch_bounds__(256) void thin_conv_wave_kernel(const ConvGeom g, const float* __restrict__ A,
-                                                             const float* __restrict__ Bw, const float* __restrict__ bias,
-                                                             float* __restrict__ C) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cls = blockIdx.z;
-    const int Ho = g.Ho[cls], Wo = g.Wo[cls], hw = Ho * Wo;
-    const int p = blockIdx.x * 4 + wave;          // wave-uniform
-    if (p >= g.N * hw) return;
-    const int n = p / hw, rem = p - n * hw;
-    const int oi = rem / Wo, oj = rem - oi * Wo;
-    const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
-    const float* Ab = A + (size_t)n * g.Hi * g.Wi * g.Ci;
-    float acc[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    for (int t = 0; t < ntap; ++t) {
-        int ihs, iws;
-        bool ok = map_bf(oi * g.istride + g.dh[tapbeg + t], g.HiL, g.Hi, g.gather, ihs);
-        ok &= map_bf(oj * g.istride + g.dw[tapbeg + t], g.WiL, g.Wi, g.gather, iws);
-        if (!ok) continue;                         // zero padding (wave-uniform)
-        const float* xr = Ab + ((size_t)ihs * g.Wi + iws) * g.Ci;
-        const float* wr = Bw + g.wofs[tapbeg + t];
-        for (int c = lane * 4; c < g.Ci; c += 256) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
-#pragma unroll
-            for (int k = 0; k < CO; ++k) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + (size_t)k * g.ldw + c);
-                acc[k] = fmaf(xv[0], wv[0], acc[k]);
-                acc[k] = fmaf(xv[1], wv[1], acc[k]);
-                acc[k] = fmaf(xv[2], wv[2], acc[k]);
-                acc[k] = fmaf(xv[3], wv[3], acc[k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < CO; ++k)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
-    if (lane != 0) return;
-    const size_t opix = ((size_t)n * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
-#pragma unroll
-    for (int k = 0; k < CO; ++k) {
-        float v = acc[k];
-        if (bias) v += bias[k];
-        float o = act_apply(v, g.act, g.slope);
-        if (g.oscale) o *= g.oscale[(size_t)n * g.Co + k];
-        C[opix * g.Co + k] = o;
-    }
-}
-
-// few workgroups from the tiled kernel and enough channels for a wave to split: the one-wave-per-pixel kernel
-static bool thin_wave_ok(const ConvGeom& g, int max_tiles) {
-    return g.Ci >= 64 && (long)max_tiles * g.N * g.ncls < 128;
-}
-
-static int launch_thin_conv_wave(const ConvGeom& g, const float* A, const float* Bw, const float* bias, float* C,
-                                 hipStream_t st) {
-    long maxM = 0;
-    for (int c = 0; c < g.ncls; ++c) {
-        const long m = (long)g.N * g.Ho[c] * g.Wo[c];
-        maxM = m > maxM ? m : maxM;
-    }
-    dim3 grid((unsigned)cdiv(maxM, 4L), 1, g.ncls);
-    switch (g.Co) {
-        case 1: MIGAN_LAUNCH((thin_conv_wave_kernel<1>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        case 2: MIGAN_LAUNCH((thin_conv_wave_kernel<2>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        case 3: MIGAN_LAUNCH((thin_conv_wave_kernel<3>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-        default: MIGAN_LAUNCH((thin_conv_wave_kernel<4>), grid, dim3(256), 0, st, g, A, Bw, bias, C); break;
-    }
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Small-K direct kernel (taps * Ci <= 16, Co % 4 == 0): first-layer convs of 1-channel images (dcgan.py:82
-// Conv2d(1,16,3,2,1)), the dgrad of an image-output conv INTO its Co-channel input (dcgan.py:62) and the dgrad of
-// Linear(K,1) (an outer product, dcgan.py:92).  With K <= 16 an MFMA K-tile would be >= 50-97 % zero padding and
-// the op is bound by WRITING the output, so: one thread = one pixel x 4 output channels, the <= 16 gathered
-// source values are shared through L1 by the Co/4 threads of the pixel, the store is a coalesced 16 B vector.
-// ------------------------------------------------------------------------------------------------
-struct SmallK {
-    int dh[16], dw[16], c[16], wofs[16];  // flattened k = (tap, channel) -> tap offset, source channel, weight offset
-    unsigned mg_hw, mg_w;                 // fastdiv magics for / (Ho*Wo) and / Wo
-    int sh_hw, sh_w;
-};
-// thread = (pixel, 4 output channels); K and the whole gather are compile-time unrolled and branch-free, so the K
-// source loads of a pixel are in flight together.  FIXED: the thread count is a multiple of Co/4, so a thread keeps
-// its 4xK weights in registers while it strides over pixels.
-template <int K, bool FIXED>
-__global__ __launch_bounds__(256) void smallk_conv_kernel(const ConvGeom g, const SmallK sk,
-                                                          const float* __restrict__ A, const float* __restrict__ Bw,
-                                                          const float* __restrict__ bias, float* __restrict__ C) {
-    const int Ho = g.Ho[0], Wo = g.Wo[0];
-    const int M = g.N * Ho * Wo;
-    const int cq_n = g.Co >> 2;
-    const long total = (long)M * cq_n;
-    const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    float w[K][4];
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_w = [&](int co) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[k][e] = Bw[(size_t)(co + e) * g.ldw + sk.wofs[k]];
-        if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
-    };
-    if (FIXED && i < total) load_w((int)(i % cq_n) * 4);
-    for (; i < total; i += stride) {
-        const int m = (int)(i / cq_n);
-        const int co = (int)(i - (long)m * cq_n) * 4;
-        if (!FIXED) load_w(co);
-        const int n = m / (Ho * Wo);
-        const int rem = m - n * Ho * Wo;
-        const int oi = rem / Wo, oj = rem - oi * Wo;
-        float a[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            int ihs, iws;
-            bool ok = map_bf(oi * g.istride + sk.dh[k], g.HiL, g.Hi, g.gather, ihs);
-            ok &= map_bf(oj * g.istride + sk.dw[k], g.WiL, g.Wi, g.gather, iws);
-            const float v = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + sk.c[k]];
-            a[k] = ok ? v : 0.f;
-        }
-        f32x4 acc = b4;
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(a[k], w[k][e], acc[e]);
-        const size_t opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
-        if (g.oscale) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * g.Co + co);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] *= sc[e];
-        }
-        *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
-    }
-}
-
-// Tiled variant for Co/4 dividing 256 (the common case): a block owns PB = 64 consecutive output pixels.  Their K
-// gathered source values are computed ONCE (cooperatively, staged in LDS) instead of once per channel quad, each
-// thread keeps its 4xK weights in registers and produces its quad for 256/(Co/4)-strided pixels of the tile; the
-// tile's output is one contiguous run of 64*Co floats.
-// PB = output pixels per tile: 128, or 16 when 128-pixel tiles would leave most of the chip idle (the dgrad of a PatchGAN head
-// into its 512 channels, cyclegan/models.py:118 / pix2pix/models.py:130: 289 pixels = 3 tiles = 3 workgroups, 54 us)
-template <int K, int PB>
-__global__ __launch_bounds__(256) void smallk_tile_kernel(const ConvGeom g, const SmallK sk,
-                                                          const float* __restrict__ A, const float* __restrict__ Bw,
-                                                          const float* __restrict__ bias, float* __restrict__ C) {
-    constexpr int IT = (PB * K + 255) / 256;      // gathered values per thread per tile
-    __shared__ float a_s[PB * K];
-    __shared__ int s_dh[K], s_dw[K], s_c[K];
-    if (threadIdx.x < K) {
-        s_dh[threadIdx.x] = sk.dh[threadIdx.x];
-        s_dw[threadIdx.x] = sk.dw[threadIdx.x];
-        s_c[threadIdx.x] = sk.c[threadIdx.x];
-    }
-    const int Ho = g.Ho[0], Wo = g.Wo[0];
-    const int M = g.N * Ho * Wo;
-    const int cq_n = g.Co >> 2;
-    const int rows = 256 / cq_n;  // pixel lanes per block
-    const int tid = threadIdx.x;
-    const int cq = tid % cq_n, pl = tid / cq_n;
-    const int co = cq * 4;
-    float w[K][4];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[k][e] = Bw[(size_t)(co + e) * g.ldw + sk.wofs[k]];
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
-    const bool linear_out = g.ostep == 1;
-    const int ntiles = (M + PB - 1) / PB;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * PB;
-        __syncthreads();
-        {   // gather: IT independent branch-free loads per thread (clamped coordinates, validity folded into the value)
-            float v[IT];
-#pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                const int idx = tid + u * 256;
-                const int ic = idx < PB * K ? idx : PB * K - 1;
-                const int p = ic / K, k = ic - p * K;
-                int m = m0 + p;
-                const bool in = m < M;
-                m = in ? m : M - 1;
-                const int n = fastdiv(m, sk.mg_hw, sk.sh_hw);
-                const int rem = m - n * Ho * Wo;
-                const int oi = fastdiv(rem, sk.mg_w, sk.sh_w), oj = rem - oi * Wo;
-                int ihs, iws;
-                bool ok = map_bf(oi * g.istride + s_dh[k], g.HiL, g.Hi, g.gather, ihs);
-                ok &= map_bf(oj * g.istride + s_dw[k], g.WiL, g.Wi, g.gather, iws);
-                const float t = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + s_c[k]];
-                v[u] = (ok && in) ? t : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < IT; ++u) {
-                const int idx = tid + u * 256;
-                if (idx < PB * K) a_s[idx] = v[u];
-            }
-        }
-        __syncthreads();
-        for (int p = pl; p < PB; p += rows) {
-            const int m = m0 + p;
-            if (m >= M) break;
-            f32x4 acc = b4;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float a = a_s[p * K + k];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(a, w[k][e], acc[e]);
-            }
-            size_t opix = (size_t)m;
-            int n = 0;
-            if (!linear_out || g.oscale) {
-                n = fastdiv(m, sk.mg_hw, sk.sh_hw);
-                const int rem = m - n * Ho * Wo;
-                const int oi = fastdiv(rem, sk.mg_w, sk.sh_w), oj = rem - oi * Wo;
-                if (!linear_out)
-                    opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
-            }
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
-            if (g.oscale) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * g.Co + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] *= sc[e];
-            }
-            *reinterpret_cast<f32x4*>(C + opix * g.Co + co) = o;
-        }
-    }
-}
-
-static bool smallk_ok(const ConvGeom& g) {
-    const int K = g.ntap[0] * g.Ci;
-    return g.ncls == 1 && g.Co % 4 == 0 && K >= 1 && K <= 16;
-}
-
-template <int K>
-static void launch_smallk_k(const ConvGeom& g, const SmallK& sk, long maxM, const float* A, const float* Bw,
-                            const float* bias, float* C, hipStream_t st) {
-    const int cq_n = g.Co >> 2;
-    long blocks = cdiv(maxM * cq_n, 256L);
-    if (blocks > 8192) blocks = 8192;
-    if (256 % cq_n == 0) {
-        long tiles = cdiv(maxM, 128L);
-        if (tiles > 8192) tiles = 8192;
-        if (tiles < 128)
-            MIGAN_LAUNCH((smallk_tile_kernel<K, 16>), dim3((unsigned)cdiv(maxM, 16L)), dim3(256), 0, st, g, sk, A, Bw, bias, C);
-        else
-            MIGAN_LAUNCH((smallk_tile_kernel<K, 128>), dim3((unsigned)tiles), dim3(256), 0, st, g, sk, A, Bw, bias, C);
-    } else
-        MIGAN_LAUNCH((smallk_conv_kernel<K, false>), dim3((unsigned)blocks), dim3(256), 0, st, g, sk, A, Bw, bias, C);
-}
-
-static int launch_smallk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C,
-                         hipStream_t st) {
-    if (maxM == 0) return 0;
-    SmallK sk = {};
-    const int K = g.ntap[0] * g.Ci;
-    for (int t = 0, k = 0; t < g.ntap[0]; ++t)
-        for (int c = 0; c < g.Ci; ++c, ++k) {
-            sk.dh[k] = g.dh[g.tapbeg[0] + t];
-            sk.dw[k] = g.dw[g.tapbeg[0] + t];
-            sk.c[k] = c;
-            sk.wofs[k] = g.wofs[g.tapbeg[0] + t] + c;
-        }
-    fastdiv_magic((unsigned)(g.Ho[0] * g.Wo[0]), sk.mg_hw, sk.sh_hw);
-    fastdiv_magic((unsigned)g.Wo[0], sk.mg_w, sk.sh_w);
-#define SMALLK_CASE(K_) case K_: launch_smallk_k<K_>(g, sk, maxM, A, Bw, bias, C, st); break;
-    switch (K) {
-        SMALLK_CASE(1) SMALLK_CASE(2) SMALLK_CASE(3) SMALLK_CASE(4) SMALLK_CASE(5) SMALLK_CASE(6) SMALLK_CASE(7)
-        SMALLK_CASE(8) SMALLK_CASE(9) SMALLK_CASE(10) SMALLK_CASE(11) SMALLK_CASE(12) SMALLK_CASE(13)
-        SMALLK_CASE(14) SMALLK_CASE(15) SMALLK_CASE(16)
-        default: return (int)hipErrorInvalidValue;
-    }
-#undef SMALLK_CASE
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Mid-K direct kernel (16 < taps * Ci <= 128 with a source of fewer than 8 channels): the first convs of the image nets -
-// pix2pix/models.py:23 Conv2d(3,64,4,2,1) and :115 Conv2d(6,64,4,2,1), cyclegan/models.py:106 Conv2d(3,64,4,2,1),
-// srgan/models.py:85 Conv2d(3,64,3,1,1).  Their source has 3 / 6 channels, so the vectorised NHWC loaders do not apply and the
-// generic scalar-gather MFMA kernel ran them: at pix2pix's batch of one (16 384 output pixels) that is 128 workgroups walking a
-// gather of 48-96 scalar loads per row - 75 us for 0.1-0.2 GFLOP, four times per step (profiles/r03_pix2pix_kernel_stats.txt).
-// Here, as in smallk_tile_kernel: a workgroup owns 64 consecutive output pixels, the K gathered values of each pixel are fetched
-// ONCE (cooperatively, branch-free, into LDS), the K x Co weights sit in LDS for the life of the workgroup, a thread produces a
-// channel quad for two pixels at a time (8 FMAs per three LDS reads) and the tile's output is one contiguous run of 64 * Co
-// floats.  Measured in profiles/r03_abi_check.txt (see midk_ok for the one shape that stays on the MFMA kernel).
-// ------------------------------------------------------------------------------------------------
-#define MIDK_PB 64
-__global__ __launch_bounds__(256) void midk_tile_kernel(const ConvGeom g, const float* __restrict__ A, const float* __restrict__ Bw,
-                                                        const float* __restrict__ bias, float* __restrict__ C, int K, unsigned mgK,
-                                                        int shK) {
-    extern __shared__ float midk_lds[];
-    const int KS = K | 1;                          // odd row stride of the gathered tile: the pixel lanes of a wave hit different banks
-    float* a_s = midk_lds;                         // [MIDK_PB][KS]
-    float* w_s = a_s + MIDK_PB * KS;               // [K][Co]
-    int* s_dh = reinterpret_cast<int*>(w_s + K * g.Co);
-    int* s_dw = s_dh + K;
-    int* s_c = s_dw + K;
-    const int tid = threadIdx.x;
-    const int Ho = g.Ho[0], Wo = g.Wo[0];
-    const int M = g.N * Ho * Wo;
-    const int Co = g.Co, cq_n = Co >> 2;
-    const int rows = 256 / cq_n;                   // pixel lanes per workgroup
-    const int cq = tid % cq_n, pl = tid / cq_n;
-    const int co = cq * 4;
-    for (int k = tid; k < K; k += 256) {
-        const int t = k / g.Ci;
-        s_dh[k] = g.dh[g.tapbeg[0] + t];
-        s_dw[k] = g.dw[g.tapbeg[0] + t];
-        s_c[k] = k - t * g.Ci;
-    }
-    for (int e = tid; e < K * Co; e += 256) {       // w_s[k][co] = weight of output channel co at (tap, channel) k
-        const int k = e / Co, c = e - k * Co;
-        const int t = k / g.Ci;
-        w_s[e] = Bw[(size_t)c * g.ldw + g.wofs[g.tapbeg[0] + t] + (k - t * g.Ci)];
-    }
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + co);
-    const bool linear_out = g.ostep == 1;
-    const int ntiles = (M + MIDK_PB - 1) / MIDK_PB;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * MIDK_PB;
-        __syncthreads();
-        for (int base = 0; base < MIDK_PB * K; base += 1024) {   // gather: 4 independent branch-free loads per thread in flight
-            float v[4];
-            int dst[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + tid;
-                const bool live = idx < MIDK_PB * K;
-                const int ic = live ? idx : MIDK_PB * K - 1;
-                const int p = fastdiv(ic, mgK, shK), k = ic - p * K;
-                int m = m0 + p;
-                const bool in = m < M;
-                m = in ? m : M - 1;
-                const int n = fastdiv(m, g.mg_hw[0], g.sh_hw[0]);
-                const int rem = m - n * Ho * Wo;
-                const int oi = fastdiv(rem, g.mg_w[0], g.sh_w[0]), oj = rem - oi * Wo;
-                int ihs, iws;
-                bool ok = map_bf(oi * g.istride + s_dh[k], g.HiL, g.Hi, g.gather, ihs);
-                ok &= map_bf(oj * g.istride + s_dw[k], g.WiL, g.Wi, g.gather, iws);
-                const float t = A[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + s_c[k]];
-                v[u] = (ok && in) ? t : 0.f;
-                dst[u] = live ? p * KS + k : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) a_s[dst[u]] = v[u];
-        }
-        __syncthreads();
-        for (int p = pl * 2; p < MIDK_PB; p += rows * 2) {
-            if (m0 + p >= M) break;
-            f32x4 acc0 = b4, acc1 = b4;
-            const float* a0 = a_s + p * KS;
-            const float* a1 = a0 + KS;
-#pragma unroll 4
-            for (int k = 0; k < K; ++k) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(w_s + k * Co + co);
-                const float x0 = a0[k], x1 = a1[k];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc0[e] = fmaf(x0, w[e], acc0[e]);
-                    acc1[e] = fmaf(x1, w[e], acc1[e]);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = m0 + p + q;
-                if (m >= M) break;
-                const f32x4 acc = q == 0 ? acc0 : acc1;
-                size_t opix = (size_t)m;
-                int n = 0;
-                if (!linear_out || g.oscale) {
-                    n = fastdiv(m, g.mg_hw[0], g.sh_hw[0]);
-                    const int rem = m - n * Ho * Wo;
-                    const int oi = fastdiv(rem, g.mg_w[0], g.sh_w[0]), oj = rem - oi * Wo;
-                    if (!linear_out)
-                        opix = ((size_t)n * g.HoF + (g.oh0[0] + oi * g.ostep)) * g.WoF + (g.ow0[0] + oj * g.ostep);
-                }
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = act_apply(acc[e], g.act, g.slope);
-                if (g.oscale) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(g.oscale + (size_t)n * Co + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] *= sc[e];
-                }
-                *reinterpret_cast<f32x4*>(C + opix * Co + co) = o;
-            }
-        }
-    }
-}
-static size_t midk_lds_bytes(int K, int Co) { return ((size_t)MIDK_PB * (K | 1) + (size_t)K * Co + 3 * K) * 4; }
-static bool midk_ok(const ConvGeom& g) {
-    const int K = g.ntap[0] * g.Ci;
-    const int cq_n = g.Co / 4;
-    // measured (profiles/r03_abi_check.txt): 6 -> 64 4x4 s2 at batch 1 26.8 -> 22.5 us, 3 -> 64 3x3 at 2.4 M pixels 362 -> 316 us, but
-    // 3 -> 64 4x4 s2 at 131 k pixels (CycleGAN's discriminators at batch 8) 37.2 -> 45.3 us: that shape stays on the MFMA kernel
-    const bool loses = g.ntap[0] == 16 && g.Ci == 3 && (long)g.N * g.HoF * g.WoF >= 65536;
-    return !loses && g.ncls == 1 && !g.stats && g.Ci < 8 && g.Co % 4 == 0 && cq_n >= 2 && cq_n <= 128 && 256 % cq_n == 0 && K > 16 &&
-           K <= 128 && midk_lds_bytes(K, g.Co) <= 64 * 1024;
-}
-static int launch_midk(const ConvGeom& g, long maxM, const float* A, const float* Bw, const float* bias, float* C, hipStream_t st) {
-    if (maxM == 0) return 0;
-    const int K = g.ntap[0] * g.Ci;
-    unsigned mgK;
-    int shK;
-    fastdiv_magic((unsigned)K, mgK, shK);
-    long tiles = cdiv(maxM, (long)MIDK_PB);
-    if (tiles > 4096) tiles = 4096;
-    MIGAN_LAUNCH(midk_tile_kernel, dim3((unsigned)tiles), dim3(256), midk_lds_bytes(K, g.Co), st, g, A, Bw, bias, C, K, mgK, shK);
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Long-K GEMV (1 tap at offset 0, i.e. Linear / 1x1 conv; Co <= 4; few output pixels): the validity heads
-// Linear(128*ds^2, 1) (dcgan.py:92, wgan_gp.py:88).  A 128x32 MFMA tile would leave ONE workgroup walking the
-// whole K serially; here one wave owns one output row and its 64 lanes stride K with 16 B loads.
-// ------------------------------------------------------------------------------------------------
-template <int CO>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ A, const float* __restrict__ Bw,
-                                                        const float* __restrict__ bias, float* __restrict__ C,
-                                                        int M, int K, int ldw, int act, float slope) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const float* a = A + (size_t)m * K;
-    float acc[CO];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(a + k);
-#pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(Bw + (size_t)c * ldw + k);
-            acc[c] += av[0] * wv[0] + av[1] * wv[1] + av[2] * wv[2] + av[3] * wv[3];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CO; ++c) {
-        float v = acc[c];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) C[(size_t)m * CO + c] = act_apply(v + (bias ? bias[c] : 0.f), act, slope);
-    }
-}
-
-static bool gemv_ok(const ConvGeom& g, long maxM) {
-    return g.ncls == 1 && g.ntap[0] == 1 && g.dh[0] == 0 && g.dw[0] == 0 && g.wofs[0] == 0 && g.istride == 1 &&
-           g.ostep == 1 && g.gather == GATHER_ZERO && g.Hi == g.Ho[0] && g.Wi == g.Wo[0] && g.Co <= 4 &&
-           g.Ci % 4 == 0 && g.ldw % 4 == 0 && g.Ci >= 256 && maxM <= 16384 && g.oscale == nullptr;
-}
-
-static int launch_gemv(const ConvGeom& g, long M, const float* A, const float* Bw, const float* bias, float* C,
-                       hipStream_t st) {
-    if (M == 0) return 0;
-    dim3 grid((unsigned)cdiv(M, 4L));
-#define GEMV_CASE(CO_)                                                                                          \
-    case CO_:                                                                                                   \
-        MIGAN_LAUNCH(gemv_rows_kernel<CO_>, grid, dim3(256), 0, st, A, Bw, bias, C, (int)M, g.Ci, g.ldw,  \
-                           g.act, g.slope);                                                                     \
-        break;
-    switch (g.Co) {
-        GEMV_CASE(1) GEMV_CASE(2) GEMV_CASE(3) GEMV_CASE(4)
-        default: return (int)hipErrorInvalidValue;
-    }
-#undef GEMV_CASE
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
+#include "conv_valu_fwd.inc"   // thin-N / small-K / mid-K / GEMV VALU kernels + their launchers
 
 // Number of statistics chunks per group the pipelined kernel will write for this launch (ConvGeom::stats), or 0 when the
 // launch takes another kernel (small-K, GEMV, thin-N, scalar-gather) or - for InstanceNorm groups - a tile would straddle
@@ -2680,342 +2040,7 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Thin weight gradient (Co <= 4, stride 1, zero padding, R*S*Co <= 32): the GEMM has only Co useful
-// rows, so MFMA tiles would be >= 94% padding and the kernel is bound by reading x.  This VALU kernel
-// walks the INPUT pixels once (16 B/lane along channels): dW[co][t][ci] += x[q][ci] * dy[q + pad - t][co];
-// the 9..16 dy taps per pixel are wave-broadcast loads of a tiny tensor.  Partials per pixel chunk go
-// through the same fixed-order reduction as the MFMA path (dcgan.py:62 conv 64->1, PatchGAN heads
-// cyclegan/models.py:118, pix2pix/models.py:127, srgan/models.py:100).
-// ------------------------------------------------------------------------------------------------
-#define THIN_MAX_ACC 32
-#define THIN_CHUNKS 1024
-struct ThinGeom {
-    int N, Hi, Wi, Ci, Ho, Wo, R, S, pad_t, pad_l, chunk, nchunks, CTX;
-};
-template <int CO, int KS>  // KS = square kernel size (compile time: tap offsets fold to constants)
-__global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinGeom g, const float* __restrict__ X,
-                                                         const float* __restrict__ DY, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float red[];
-    const int tid = threadIdx.x;
-    const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
-    constexpr int T = KS * KS, NACC = T * CO;
-    static_assert(NACC <= THIN_MAX_ACC, "too many accumulators");
-    const int c = (blockIdx.y * g.CTX + tx) * 4;
-    const bool cok = c < g.Ci;
-    f32x4 acc[THIN_MAX_ACC];
-#pragma unroll
-    for (int i = 0; i < THIN_MAX_ACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int P = g.N * g.Hi * g.Wi;
-    int q0 = blockIdx.x * g.chunk, q1 = q0 + g.chunk;
-    if (q1 > P) q1 = P;
-    if (cok && q0 + ty < q1) {
-        // (n, ih, iw) of the walking pixel is carried incrementally: no integer division in the loop
-        int q = q0 + ty;
-        int n = q / (g.Hi * g.Wi);
-        int rem = q - n * g.Hi * g.Wi;
-        int ih = rem / g.Wi, iw = rem - ih * g.Wi;
-        for (; q < q1; q += TY, iw += TY) {
-            while (iw >= g.Wi) {
-                iw -= g.Wi;
-                if (++ih >= g.Hi) { ih = 0; ++n; }
-            }
-            f32x4 xv = *reinterpret_cast<const f32x4*>(X + (size_t)q * g.Ci + c);
-            // branch-free taps: clamped coordinates, unconditional (wave-broadcast) loads, validity folded into the
-            // value - all T*CO loads of a pixel are in flight together instead of one latency per tap
-            float dv[NACC];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int r = t / KS, s = t % KS;
-                const int oh = ih + g.pad_t - r, ow = iw + g.pad_l - s;
-                const bool ok = (unsigned)oh < (unsigned)g.Ho && (unsigned)ow < (unsigned)g.Wo;
-                const int ohc = oh < 0 ? 0 : (oh > g.Ho - 1 ? g.Ho - 1 : oh);
-                const int owc = ow < 0 ? 0 : (ow > g.Wo - 1 ? g.Wo - 1 : ow);
-                const float* d = DY + ((long)(n * g.Ho + ohc) * g.Wo + owc) * CO;
-#pragma unroll
-                for (int co = 0; co < CO; ++co) {
-                    const float v = d[co];
-                    dv[t * CO + co] = ok ? v : 0.f;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < NACC; ++a) acc[a] += xv * dv[a];
-        }
-    }
-    // reduce over the TY pixel lanes through LDS, one accumulator slab at a time
-    float* out = part + (size_t)blockIdx.x * CO * T * g.Ci;
-    for (int a = 0; a < NACC; ++a) {
-        f32x4 v = acc[0];
-#pragma unroll
-        for (int i = 1; i < THIN_MAX_ACC; ++i)
-            if (i == a) v = acc[i];
-        __syncthreads();
-        *reinterpret_cast<f32x4*>(red + tid * 4) = v;
-        __syncthreads();
-        if (ty == 0 && cok) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int y = 0; y < TY; ++y) s += *reinterpret_cast<const f32x4*>(red + (y * g.CTX + tx) * 4);
-            int t = a / CO, co = a - t * CO;
-            *reinterpret_cast<f32x4*>(out + ((size_t)co * T + t) * g.Ci + c) = s;
-        }
-    }
-}
-
-static bool thin_wgrad_ok(int Co, int R, int S, int Ci, int stride, int gather) {
-    return Co <= 4 && stride == 1 && gather == GATHER_ZERO && R == S && (S == 1 || S == 3 || S == 4) &&
-           R * S * Co <= THIN_MAX_ACC && Ci % 4 == 0 && Ci >= 16;  // one f32x4 accumulator per (tap, co)
-}
-template <int KS>
-static void launch_thin(int Co, dim3 grid, size_t lds, hipStream_t st, const ThinGeom& tg, const float* x,
-                        const float* dy, float* ws) {
-    switch (Co) {
-        case 1: MIGAN_LAUNCH((thin_wgrad_kernel<1, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-        case 2: MIGAN_LAUNCH((thin_wgrad_kernel<2, KS>), grid, dim3(256), lds, st, tg, x, dy, ws); break;
-        case 3:
-            if constexpr (KS * KS * 3 <= THIN_MAX_ACC)
-                MIGAN_LAUNCH((thin_wgrad_kernel<3, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
-            break;
-        default:
-            if constexpr (KS * KS * 4 <= THIN_MAX_ACC)
-                MIGAN_LAUNCH((thin_wgrad_kernel<4, KS>), grid, dim3(256), lds, st, tg, x, dy, ws);
-            break;
-    }
-}
-static void thin_plan(int N, int Hi, int Wi, int Ci, ThinGeom& g) {
-    int cv = Ci / 4;
-    g.CTX = 1;
-    while (g.CTX < cv && g.CTX < 64) g.CTX <<= 1;
-    long P = (long)N * Hi * Wi;
-    int TY = 256 / g.CTX;
-    long gy = cdiv(cv, g.CTX);
-    long want = cdiv(THIN_CHUNKS, gy);
-    long maxc = cdiv(P, (long)TY * 4);
-    if (want > maxc) want = maxc;
-    if (want < 1) want = 1;
-    g.chunk = (int)cdiv(P, want);
-    g.nchunks = cdiv(P, g.chunk);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Small weight gradient (Co * taps * Ci <= 256 outputs, Co <= 64, taps * Ci <= 64): the first conv of a 1-channel
-// image (dcgan.py:82, Conv2d(1, 16, 3, 2, 1): 144 numbers reduced from 131 072 output pixels), where an MFMA tile
-// would be > 97 % padding and the scalar-gather wgrad_kernel spends 40 us on 10 MB.  A block walks chunks of 128
-// output pixels: their dy rows (contiguous) and their taps*Ci gathered source values (branch-free, 4 loads in flight)
-// are staged in LDS once, then thread o = (co, tap, ci) accumulates sum_p dy[p][co] * x[p][tap, ci] from LDS
-// (wave-broadcast reads).  One partial slab per block for the common fixed-order reduction.
-// ------------------------------------------------------------------------------------------------
-struct SmallWgrad {
-    int N, Hi, Wi, Ci, HiL, WiL, Ho, Wo, Co, S, T, stride, pad_t, pad_l, gather, nchunk;
-    unsigned mg_hw, mg_w, mg_k;  // fastdiv magics: / (Ho*Wo), / Wo, / (T*Ci)
-    int sh_hw, sh_w, sh_k;
-};
-__global__ __launch_bounds__(256) void small_wgrad_kernel(const SmallWgrad g, const float* __restrict__ X,
-                                                          const float* __restrict__ DY, float* __restrict__ part) {
-    constexpr int PB = 128;
-    extern __shared__ __attribute__((aligned(16))) float sw_lds[];
-    const int K = g.T * g.Ci, nout = g.Co * K;
-    float* dys = sw_lds;             // [PB][Co]
-    float* xs = sw_lds + PB * g.Co;  // [PB][K]
-    __shared__ int k_dh[64], k_dw[64], k_ci[64];
-    const int tid = threadIdx.x;
-    if (tid < K) {
-        const int t = tid / g.Ci;
-        k_ci[tid] = tid - t * g.Ci;
-        k_dh[tid] = t / g.S - g.pad_t;
-        k_dw[tid] = t % g.S - g.pad_l;
-    }
-    const bool act = tid < nout;
-    const int oc = act ? tid : 0;
-    const int o_co = fastdiv(oc, g.mg_k, g.sh_k), o_k = oc - o_co * K;
-    const int Mpix = g.N * g.Ho * g.Wo;
-    const long dy_total = (long)Mpix * g.Co;
-    float acc = 0.f;
-    for (int chunk = blockIdx.x; chunk < g.nchunk; chunk += gridDim.x) {
-        const int p0 = chunk * PB;
-        __syncthreads();
-        {   // dy rows of the chunk: one contiguous run of PB*Co floats
-            const long base = (long)p0 * g.Co;
-            for (int i = tid; i < PB * g.Co; i += 256) dys[i] = base + i < dy_total ? DY[base + i] : 0.f;
-        }
-        for (int b = 0; b < PB * K; b += 1024) {  // gathered source values, 4 branch-free loads in flight
-            float v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = b + u * 256 + tid;
-                const int ic = idx < PB * K ? idx : PB * K - 1;
-                const int p = fastdiv(ic, g.mg_k, g.sh_k), k = ic - p * K;
-                int m = p0 + p;
-                const bool in = m < Mpix;
-                m = in ? m : Mpix - 1;
-                const int n = fastdiv(m, g.mg_hw, g.sh_hw);
-                const int rem = m - n * g.Ho * g.Wo;
-                const int oi = fastdiv(rem, g.mg_w, g.sh_w), oj = rem - oi * g.Wo;
-                int ihs, iws;
-                bool ok = map_bf(oi * g.stride + k_dh[k], g.HiL, g.Hi, g.gather, ihs);
-                ok &= map_bf(oj * g.stride + k_dw[k], g.WiL, g.Wi, g.gather, iws);
-                const float t = X[(size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + k_ci[k]];
-                v[u] = (ok && in) ? t : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = b + u * 256 + tid;
-                if (idx < PB * K) xs[idx] = v[u];
-            }
-        }
-        __syncthreads();
-        if (act) {
-#pragma unroll 8
-            for (int p = 0; p < PB; ++p) acc = fmaf(dys[p * g.Co + o_co], xs[p * K + o_k], acc);
-        }
-    }
-    if (act) part[(size_t)blockIdx.x * nout + tid] = acc;  // slab layout [co][t][ci] == thread order
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tiled thin weight gradient (Co <= 4, ANY kernel size / stride / gather): the 7x7 and 9x9 image-output convs
-// (cyclegan/models.py:82, srgan/models.py:62) have 49 / 81 taps x 3 output channels, too many accumulators for
-// thin_wgrad_kernel and a 95 %-padding MFMA tile otherwise.  A persistent workgroup walks output tiles; per tile
-// and channel chunk the source window (with halo; padded / reflected / upsampled at staging, like
-// thin_conv_kernel) and the tile's dy values are staged in LDS; thread (q, tg) owns channel quad q and the taps
-// t = tg, tg+NG, ... and accumulates dW[co][t][4q..4q+3] over the tile's pixels.  One partial slab per
-// workgroup, reduced by the common fixed-order reduction.
-// ------------------------------------------------------------------------------------------------
-#define TWG_MAX_TPT 6   // taps per thread (81 taps / 16 tap groups)
-struct ThinWgradTile {
-    int NG, TPT, nblocks, ntiles_img, ntiles;  // tap groups, taps per thread, persistent blocks, tiles
-};
-template <int CO>
-__global__ __launch_bounds__(256) void thin_wgrad_tile_kernel(const ConvGeom g, const ThinConv tc,
-                                                              const ThinWgradTile tw, const float* __restrict__ X,
-                                                              const float* __restrict__ DY, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float win[];  // window [SH*SW][CC+4] then dy [256][CO]
-    const int tid = threadIdx.x;
-    const int LDC = tc.CC + 4, Q = tc.CC >> 2;
-    float* dys = win + (size_t)tc.SH * tc.SW * LDC;
-    const int q = tid & (Q - 1), tg = tid >> tc.logQ;
-    const int T = g.ntap[0];
-    const int Ho = g.Ho[0], Wo = g.Wo[0];
-    float* out = part + (size_t)blockIdx.x * CO * T * g.Ci;
-    int t_dh[TWG_MAX_TPT], t_dw[TWG_MAX_TPT];
-#pragma unroll
-    for (int k = 0; k < TWG_MAX_TPT; ++k) {
-        int t = tg + k * tw.NG;
-        bool ok = k < tw.TPT && t < T;
-        t_dh[k] = ok ? g.dh[t] - tc.dhmin[0] : -1;  // -1 marks an unused slot
-        t_dw[k] = ok ? g.dw[t] - tc.dwmin[0] : 0;
-    }
-    for (int c0 = 0; c0 < g.Ci; c0 += tc.CC) {
-        f32x4 acc[TWG_MAX_TPT][CO];
-#pragma unroll
-        for (int k = 0; k < TWG_MAX_TPT; ++k)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) acc[k][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int tile = blockIdx.x; tile < tw.ntiles; tile += tw.nblocks) {
-            const int n = tile / tw.ntiles_img, ti_ = tile - n * tw.ntiles_img;
-            const int tile_r = ti_ / tc.tiles_w[0], tile_c = ti_ - tile_r * tc.tiles_w[0];
-            const int oi0 = tile_r * tc.TH, oj0 = tile_c * tc.TW;
-            const int vh0 = oi0 * g.istride + tc.dhmin[0], vw0 = oj0 * g.istride + tc.dwmin[0];
-            const float* Xb = X + (size_t)n * g.Hi * g.Wi * g.Ci;
-            __syncthreads();
-            {   // window staging: 4 independent branch-free loads per thread in flight (see thin_conv_kernel)
-                const int total = tc.SH * tc.SW * Q;
-                for (int base = 0; base < total; base += 1024) {
-                    f32x4 v[4];
-                    int off[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = base + u * 256 + tid;
-                        const bool in = e < total;
-                        const int ec = in ? e : total - 1;
-                        const int qq = ec & (Q - 1), pidx = ec >> tc.logQ;
-                        const int sr = fastdiv(pidx, tc.mgSW, tc.shSW), sc = pidx - sr * tc.SW;
-                        int ihs, iws;
-                        bool ok = map_bf(vh0 + sr, g.HiL, g.Hi, g.gather, ihs);
-                        ok &= map_bf(vw0 + sc, g.WiL, g.Wi, g.gather, iws);
-                        const f32x4 t4 =
-                            *reinterpret_cast<const f32x4*>(Xb + ((size_t)ihs * g.Wi + iws) * g.Ci + c0 + qq * 4);
-                        v[u] = ok ? t4 : f32x4{0.f, 0.f, 0.f, 0.f};
-                        off[u] = in ? pidx * LDC + qq * 4 : -1;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (off[u] >= 0) *reinterpret_cast<f32x4*>(win + off[u]) = v[u];
-                }
-            }
-            {   // dy of the tile: thread <-> pixel, zero outside the image
-                const int pi = tid / tc.TW, pj = tid - pi * tc.TW;
-                const bool v = (oi0 + pi) < Ho && (oj0 + pj) < Wo;
-                const float* d = DY + (((size_t)n * Ho + oi0 + pi) * Wo + oj0 + pj) * CO;
-#pragma unroll
-                for (int c = 0; c < CO; ++c) dys[tid * CO + c] = v ? d[c] : 0.f;
-            }
-            __syncthreads();
-            for (int pi = 0; pi < tc.TH; ++pi) {
-                for (int pj = 0; pj < tc.TW; ++pj) {
-                    float dv[CO];
-#pragma unroll
-                    for (int c = 0; c < CO; ++c) dv[c] = dys[(pi * tc.TW + pj) * CO + c];  // wave-uniform broadcast
-                    const float* xb = win + (size_t)((pi * g.istride) * tc.SW + pj * g.istride) * LDC + q * 4;
-#pragma unroll
-                    for (int k = 0; k < TWG_MAX_TPT; ++k) {
-                        if (t_dh[k] >= 0) {
-                            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)(t_dh[k] * tc.SW + t_dw[k]) * LDC);
-#pragma unroll
-                            for (int c = 0; c < CO; ++c) acc[k][c] += xv * dv[c];
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TWG_MAX_TPT; ++k) {
-            int t = tg + k * tw.NG;
-            if (t_dh[k] >= 0) {
-#pragma unroll
-                for (int c = 0; c < CO; ++c)
-                    *reinterpret_cast<f32x4*>(out + ((size_t)c * T + t) * g.Ci + c0 + q * 4) = acc[k][c];
-            }
-        }
-    }
-}
-
-// plan + launch; returns false when the configuration is not covered (caller falls through to the MFMA path)
-static bool thin_wgrad_tile_plan(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride,
-                                 int pad_t, int pad_l, int gather, ConvGeom& g, ThinConv& tc, ThinWgradTile& tw,
-                                 size_t& lds) {
-    if (Co > 4 || Ci % 4 != 0 || Ci < 16 || R * S > MAX_TAPS || N > 65535) return false;
-    g = ConvGeom{};
-    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci;
-    g.HiL = gather == GATHER_UP2 ? 2 * Hi : Hi;
-    g.WiL = gather == GATHER_UP2 ? 2 * Wi : Wi;
-    g.Co = Co; g.HoF = Ho; g.WoF = Wo; g.ostep = 1; g.istride = stride; g.gather = gather; g.ldw = R * S * Ci;
-    g.ncls = 1; g.Ho[0] = Ho; g.Wo[0] = Wo; g.ntap[0] = R * S;
-    for (int r = 0; r < R; ++r)
-        for (int s2 = 0; s2 < S; ++s2) {
-            g.dh[r * S + s2] = (short)(r - pad_t);
-            g.dw[r * S + s2] = (short)(s2 - pad_l);
-            g.wofs[r * S + s2] = (r * S + s2) * Ci;
-        }
-    size_t l0 = 0;
-    int max_tiles = 0;
-    if (!thin_conv_plan(g, tc, l0, max_tiles)) return false;
-    // the tile kernel also keeps 256*Co dy values in LDS; shrink the channel chunk if needed (64 KB budget)
-    while ((size_t)tc.SH * tc.SW * (tc.CC + 4) * 4 + 256 * 4 * 4 > 64 * 1024 && tc.CC > 8) {
-        tc.CC >>= 1;
-        tc.logQ -= 1;
-    }
-    if (Ci % tc.CC != 0) return false;
-    lds = (size_t)tc.SH * tc.SW * (tc.CC + 4) * 4 + 256 * 4 * 4;
-    if (lds > 64 * 1024) return false;
-    int Q = tc.CC / 4;
-    tw.NG = 256 / Q;
-    tw.TPT = cdiv(R * S, tw.NG);
-    if (tw.TPT > TWG_MAX_TPT) return false;
-    tw.ntiles_img = tc.tiles[0];
-    tw.ntiles = tw.ntiles_img * N;
-    tw.nblocks = tw.ntiles < 512 ? tw.ntiles : 512;
-    return true;
-}
+#include "conv_valu_wgrad.inc"   // thin / small / tiled-thin VALU weight-gradient kernels + their planners
 
 MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci) {
     int bm, splits, pps;

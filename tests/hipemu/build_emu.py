@@ -153,7 +153,10 @@ def build(force=False, only=None, verbose=False):
         else:
             src = os.path.join(BUILD, s.replace(".hip", ".emu.cpp"))
             with open(os.path.join(CSRC, s)) as fh:
-                text = transform(fh.read(), os.path.join(CSRC, s))
+                raw = fh.read()
+            # `#include "x.inc"`: pieces of the same translation unit (kernels with LDS declarations and asm the transform must see)
+            raw = re.sub(r'^#include "(\w+\.inc)"[^\n]*$', lambda m: open(os.path.join(CSRC, m.group(1))).read(), raw, flags=re.M)
+            text = transform(raw, os.path.join(CSRC, s))
             with open(src, "w") as fh:
                 fh.write(text)
         obj = os.path.join(BUILD, os.path.basename(src) + ".o")
