@@ -320,6 +320,25 @@ task_dcgan_bisect() {   # call 18: which change costs the DCGAN step 2.7 % (call
   cat $O/bench.txt
 }
 
+task_stats() {   # call 21: norm statistics from the conv epilogue of the LDS-DMA kernels (MIGAN_CONV_STATS=1) against the statistics pass
+  local O=gpurun_out/r5p; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py -q -k "conv_epilogue_statistics or test_conv2d_fwd_bwd or upconv" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for r in 1 2; do
+    bl $O/bench.txt dcgan 50 MIGAN_CONV_STATS=0
+    bl $O/bench.txt dcgan 50 MIGAN_CONV_STATS=1
+  done
+  for r in 1 2; do
+    bl $O/bench.txt srgan 4 MIGAN_CONV_STATS=0
+    bl $O/bench.txt srgan 4 MIGAN_CONV_STATS=1
+  done
+  bl $O/bench.txt cyclegan 4 MIGAN_CONV_STATS=0
+  bl $O/bench.txt cyclegan 4 MIGAN_CONV_STATS=1
+  bl $O/bench.txt pix2pix 50 MIGAN_CONV_STATS=0
+  bl $O/bench.txt pix2pix 50 MIGAN_CONV_STATS=1
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
