@@ -60,10 +60,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p, unsign
 // and leaves its raw accumulators in a slab of the caller's workspace; the last slice to arrive at the tile's ticket
 // (agent-scope release / acquire, cdna_hip_programming.md Guideline 16) adds the slabs in slice order - a fixed order, so
 // the result is deterministic - and runs the epilogue.  The ticket resets itself; the workspace needs zeroing once.
-// STATS: the epilogue also leaves the per-tile (mean, M2, count) of every output column for the BatchNorm / InstanceNorm layer behind the
-// conv (ConvGeom::stats, combined by migan_norm_stats_from_conv) - that layer's own statistics pass over the tensor disappears.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int TAPS_IN, bool KTAIL, int OCC, int NS = 2, bool SPLITK = false,
-          bool STATS = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int TAPS_IN, bool KTAIL, int OCC, int NS = 2, bool SPLITK = false>
 __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, const float* __restrict__ A,
                                                              const float* __restrict__ Bw,
                                                              const float* __restrict__ bias, float* __restrict__ C,
@@ -80,7 +77,6 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile shape");
     static_assert(NS >= 2 && NS <= 4 && (!SPLITK || TAPS_IN == 1), "pipeline depth / split-K");
-    static_assert(!STATS || (NS == 2 && !SPLITK), "statistics epilogue: plain two-stage kernels only");
     __shared__ __attribute__((aligned(16))) float smem[NS * ST_FL];
 
     const int tid = threadIdx.x;
@@ -89,14 +85,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     const int Ho = g.Ho[cls], Wo = g.Wo[cls];
     const int M = g.N * Ho * Wo;
     const int m0 = bx * BM, n0 = by * BN;
-    if (m0 >= M) {
-        // a class smaller than the largest one: no rows here; BatchNorm statistics still expect an (empty) entry for the chunk
-        if (STATS && !g.stats_inst && tid < BN && n0 + tid < g.Co) {
-            float* sp = g.stats + (((size_t)cls * gridDim.x + bx) * g.Co + n0 + tid) * 3;
-            sp[0] = 0.f; sp[1] = 0.f; sp[2] = 0.f;
-        }
-        return;
-    }
+    if (m0 >= M) return;
     const int ntap = g.ntap[cls], tapbeg = g.tapbeg[cls];
     const int Ci = g.Ci, Hi = g.Hi, Wi = g.Wi, mode = g.gather;
 
@@ -361,60 +350,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                     if (g.omask) o = g.omask[opix * g.Co + col] > 0.f ? o : 0.f;
                     if (g.accum) o += C[opix * g.Co + col];
                     C[opix * g.Co + col] = o;
-                    if (STATS) acc[i][j][r] = o;   // kept for the statistics below
                 }
             }
-        }
-    }
-    if constexpr (STATS) {   // two passes over the tile's values in registers (mean, then M2 around it); cross-wave sums through LDS
-        const int nvalid = M - m0 < BM ? M - m0 : BM;
-        float* red = smem;   // [WAVES_M][BN]: the K loop is done with the stages after the barrier
-        __syncthreads();
-        float mean_c[TN];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float sacc = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < nvalid) {
-                            const float d = pass == 0 ? acc[i][j][r] : acc[i][j][r] - mean_c[j];
-                            sacc += pass == 0 ? d : d * d;
-                        }
-                    }
-                sacc += __shfl_xor(sacc, 32);
-                if (h == 0) red[wm * BN + wn * (TN * 32) + j * 32 + l31] = sacc;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float t = 0.f;
-#pragma unroll
-                for (int q = 0; q < WAVES_M; ++q) t += red[q * BN + wn * (TN * 32) + j * 32 + l31];
-                if (pass == 0) mean_c[j] = t / (float)nvalid;
-                else if (wm == 0 && h == 0) {
-                    const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-                    if (col < g.Co) {
-                        size_t chunk, grp = 0;
-                        if (g.stats_inst) {
-                            const int hw = Ho * Wo;
-                            grp = (size_t)(m0 / hw);
-                            chunk = (size_t)cls * (hw / BM) + (size_t)((m0 - (int)grp * hw) / BM);
-                        } else {
-                            chunk = (size_t)cls * gridDim.x + bx;
-                        }
-                        float* sp = g.stats + ((grp * g.stats_chunks + chunk) * g.Co + col) * 3;
-                        sp[0] = mean_c[j];
-                        sp[1] = t;
-                        sp[2] = (float)nvalid;
-                    }
-                }
-            }
-            __syncthreads();
         }
     }
 }
@@ -434,15 +371,9 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     const bool ktail = g.Ci % BK != 0;
     // (Three LDS stages with counted waits - two K-tiles in flight, one workgroup of occupancy less - were measured on whole steps for
     // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
-#define DMA_LAUNCH(TI_, KT_)                                                                                                       \
-    do {                                                                                                                           \
-        if (g.stats)                                                                                                               \
-            MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC, 2, false, true>), grid, dim3(256), 0, st, g, A, Bw,  \
-                         bias, C, a_bytes, b_bytes);                                                                               \
-        else                                                                                                                       \
-            MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, a_bytes, \
-                         b_bytes);                                                                                                 \
-    } while (0)
+#define DMA_LAUNCH(TI_, KT_)                                                                                         \
+    MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
+                       a_bytes, b_bytes)
     if (tapin) {
         if (ktail) DMA_LAUNCH(4, true); else DMA_LAUNCH(4, false);
     } else {
@@ -534,25 +465,6 @@ static int launch_dma_small(const ConvGeom& g, const float* A, const float* Bw, 
     return 0;
 }
 
-// The M-tile height the LDS-DMA path will use for this geometry WITHOUT a split-K workspace (statistics launches never get one), or
-// 0 when launch_igemm_dma will not take it: the statistics chunk count of a launch is its number of M-tiles (igemm_stats_chunks).
-int igemm_dma_tile_bm(const ConvGeom& g) {
-    static const int dma_env = getenv("MIGAN_DMA") ? atoi(getenv("MIGAN_DMA")) : 1;
-    if (dma_env == 0 || g.swz || g.omask) return 0;
-    if (g.Ci % 4 != 0 || g.Ci < 32 || g.ldw % 4 != 0 || g.Co <= 4) return 0;
-    for (int c = 0; c < g.ncls; ++c)
-        for (int t = 0; t < g.ntap[c]; ++t)
-            if (g.wofs[g.tapbeg[c] + t] % 4 != 0) return 0;
-    if ((size_t)g.N * g.Hi * g.Wi * g.Ci * 4 >= 0x7ffffff0ull || (size_t)g.Co * g.ldw * 4 >= 0x7ffffff0ull) return 0;
-    long maxM = 0;
-    for (int c = 0; c < g.ncls; ++c) {
-        const long m = (long)g.N * g.Ho[c] * g.Wo[c];
-        if (m > maxM) maxM = m;
-    }
-    if (maxM == 0) return 0;
-    return (dma_select(maxM, g.Co, g.ncls) / 1000) % 1000;
-}
-
 // Returns -2 when this geometry is not taken by the LDS-DMA kernels (the caller falls through to igemm_pipe_kernel),
 // otherwise the launch status.
 int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, const float* bias, float* C, float* ws,
@@ -573,10 +485,14 @@ int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, cons
         }
         const bool shape_ok = g.ncls == 1 && g.ostep == 1 && g.istride == 1 && !g.accum && g.gather != GATHER_UP2 && g.Ho[0] % 8 == 0 &&
                               g.Wo[0] % 16 == 0 && g.oh0[0] == 0 && g.ow0[0] == 0 && (long)g.N * g.Ho[0] * g.Wo[0] >= 1024;
-        g.m2d = !g.stats && shape_ok && ((m2d_env >= 1 && cols == 1 && rows >= 5) || (m2d_env >= 2 && rows >= 3)) ? 1 : 0;
+        g.m2d = shape_ok && ((m2d_env >= 1 && cols == 1 && rows >= 5) || (m2d_env >= 2 && rows >= 3)) ? 1 : 0;
     }
-    if (g.swz) return -2;
-    if (g.stats && g.omask) return -2;
+    // (g.stats: the per-tile statistics epilogue for the norm layer behind the conv was ported to this kernel in round 5 and measured
+    // against the norm layer's own statistics pass on whole steps: DCGAN 2.530 / 2.550 -> 2.561 / 2.563 ms, SRGAN 82.3 / 81.9 -> 82.4 / 82.1,
+    // CycleGAN 139.3 -> 140.3, pix2pix 2.99 -> 3.39 ms (profiles/r05_ab.txt call 21) - the two cross-wave reductions at the end of every
+    // tile cost more than one streaming pass saves, as round 2 found on the register-staged kernels.  Removed again; opt-in
+    // statistics stay on igemm_pipe_kernel.)
+    if (g.stats || g.swz) return -2;
     if (g.Ci % 4 != 0 || g.Ci < 32 || g.ldw % 4 != 0 || g.Co <= 4) return -2;
     for (int c = 0; c < g.ncls; ++c)
         for (int t = 0; t < g.ntap[c]; ++t)
@@ -592,7 +508,7 @@ int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, cons
     const unsigned ab = (unsigned)a_bytes, bb = (unsigned)b_bytes;
     // split-K pays when the chip is badly under-filled and K is long (profiles/r03_splitk.txt: pix2pix inner levels
     // 164 -> 31 us, DCGAN D.conv4 19 -> 15 us; at 128+ tiles or < 16 K-tiles the slab traffic and the ticket cost more)
-    if (ws && !g.stats) {
+    if (ws) {
         const long T64 = (long)cdiv(maxM, 64) * cdiv(g.Co, 64) * g.ncls;
         int minKT = 1 << 30;
         for (int c = 0; c < g.ncls; ++c)

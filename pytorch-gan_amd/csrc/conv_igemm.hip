@@ -650,7 +650,6 @@ MIGAN_API int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls
 
 #include "conv_valu_fwd.inc"   // thin-N / small-K / mid-K / GEMV VALU kernels + their launchers
 
-int igemm_dma_tile_bm(const ConvGeom& g);   // conv_dma.hip
 // Number of statistics chunks per group the pipelined kernel will write for this launch (ConvGeom::stats), or 0 when the
 // launch takes another kernel (small-K, GEMV, thin-N, scalar-gather) or - for InstanceNorm groups - a tile would straddle
 // two images.  Mirrors the routing of launch_igemm.
@@ -666,8 +665,7 @@ static int igemm_stats_chunks(const ConvGeom& g, int instance) {
     }
     if (!fast || g.accum || maxM == 0 || g.Co <= 4 || smallk_ok(g) || gemv_ok(g, maxM)) return 0;
     const int code = igemm_select(maxM, g.Co, fast, g.ncls, (long)ktaps * g.Ci);
-    const int bm_dma = igemm_dma_tile_bm(g);   // the LDS-DMA kernels take the launch when this is non-zero: their tile decides
-    const int bm = bm_dma ? bm_dma : (code == 1064064 ? 64 : 128);
+    const int bm = code == 1064064 ? 64 : 128;
     if (!instance) return g.ncls * cdiv(maxM, bm);
     const int hw = g.Ho[0] * g.Wo[0];
     for (int c = 0; c < g.ncls; ++c)

@@ -1003,7 +1003,7 @@ _Conv2d._backward_differentiable = staticmethod(_conv2d_backward_differentiable)
 # norm layer's own statistics pass (profiles/r02_ab.txt: DCGAN step 3.93 -> 4.12 ms, CycleGAN 173.3 -> 174.5 ms; the
 # two-pass per-tile reduction in the epilogue of every conv workgroup costs more than one streaming pass at 5 TB/s saves),
 # so it is off (functional._CONV_STATS; the parity tests of the epilogue flip it).
-_CONV_STATS = __import__("os").environ.get("MIGAN_CONV_STATS", "0") == "1"   # round 5: the LDS-DMA kernels have the epilogue too - A/B knob
+_CONV_STATS = False
 
 
 def _attach_stats(y, buf, chunks, inst, G, P, C):
