@@ -228,7 +228,7 @@ int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, fl
  * ReflectionPad2d(3)+Conv2d(3,64,7), srgan/models.py:38 Conv2d(3,64,9,1,4)) on the MFMA units straight from staged image rows
  * (csrc/rgb_conv.hip): K = R*S*3 is the GEMM's reduction as it is - no 32-channel tap tiles, no im2col buffer.
  *   fwd:   x [N][H][W][Ci] (Ci = 3; 1 with a 3x3 kernel), w_hwio [R][S][Ci][Co] (the OIHW weight permuted (2,3,1,0)),
- *          y [N][Ho][Wo][Co] = act(conv + bias).  flip != 0: taps read in reverse order - with x = dy and w_hwio = a thin-output
+ *          y [N][Ho][Wo][Co] = act(conv + bias), act = none / LeakyReLU / ReLU.  flip != 0: taps read in reverse order - with x = dy and w_hwio = a thin-output
  *          layer's weight [c][Co][R][S] permuted (2,3,0,1) this is that layer's input gradient (dcgan.py:62 backward)
  *   wgrad: dw_oihw [Co][3][R][S] and (db != NULL) db [Co] of y = act(conv(x, w) + b) from dy and the layer's OUTPUT y_act:
  *          the activation backward g = dy * act'(y_act) and the bias column sums are part of the launch (dy, y_act read once;

@@ -24,12 +24,11 @@
 
 #define RGB_TW 128   // output pixels of one row per workgroup (4 waves x 32)
 
-__device__ __forceinline__ int rgb_map(int v, int L, int reflect) {   // source coordinate or -1 (zero)
-    if (reflect) {
-        v = v < 0 ? -v : v;
-        return v >= L ? 2 * L - 2 - v : v;
-    }
-    return (unsigned)v < (unsigned)L ? v : -1;
+__device__ __forceinline__ int rgb_map(int v, int L, int reflect) {   // source coordinate or -1 (zero); both forms computed, one selected
+    int vr = v < 0 ? -v : v;
+    vr = vr >= L ? 2 * L - 2 - vr : vr;
+    const int vz = (unsigned)v < (unsigned)L ? v : -1;
+    return reflect ? vr : vz;
 }
 
 struct RgbGeom {
@@ -99,8 +98,7 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) bv[nb] = bias ? bias[nb * 32 + l31] : 0.f;
     const int a_base = (wave * 32 + l31) * C;
-    // none / LeakyReLU / ReLU as one select (negative-side factor 1 / slope / 0); tanh and sigmoid through act_apply
-    const bool simple = g.act <= ACT_RELU;
+    // none / LeakyReLU / ReLU as one select: negative-side factor 1 / slope / 0
     const float ns = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);
 
     RgbStage<R, S, C> stage;
@@ -110,11 +108,11 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
         stage.store(xs);
         __syncthreads();   // xs (and, first time round, wl) complete
         if (oh + 1 < oh_end) stage.load(g, x, n, oh + 1, ow0);   // in flight under this row's MFMAs and stores
-        f32x16 acc[NB];
+        f32x16 acc[NB];   // starts at the bias: the epilogue needs no loaded value
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[nb][r] = bv[nb];
 #pragma unroll
         for (int st = 0; st < K2 / 2; ++st) {
             // k = 2*st + kk; patch element k of pixel p sits at xs[(k / (3S)) * XW + p*3 + k % (3S)]; k >= K multiplies the zero row of wl
@@ -131,15 +129,30 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
             }
         }
         const size_t rowbase = (size_t)(n * g.Ho + oh) * g.Wo;
+        // none / LeakyReLU / ReLU only (the launcher refuses the others).  Full tiles (Wo % 128 == 0: every layer of the reference) store
+        // unconditionally: ONE basic block of 32 selects and stores.  (With a per-element switch over five activations, and then with a
+        // bounds branch around every store, the compiler put `s_waitcnt vmcnt(0)` in front of each store - every store waited for the one
+        // before it and for the next row's fetch: 215 us for the 604 MB of SRGAN's first layer.)
+        if (g.Wo % RGB_TW == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ow = ow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (ow >= g.Wo) continue;
-            float* o = y + (rowbase + ow) * Co + l31;
+            for (int r = 0; r < 16; ++r) {
+                float* o = y + (rowbase + ow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * Co + l31;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float v = acc[nb][r] + bv[nb];
-                o[nb * 32] = simple ? (v > 0.f ? v : v * ns) : act_apply(v, g.act, g.slope);
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = acc[nb][r];
+                    o[nb * 32] = v > 0.f ? v : v * ns;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ow = ow0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                float* o = y + (rowbase + ow) * Co + l31;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = acc[nb][r];
+                    if (ow < g.Wo) o[nb * 32] = v > 0.f ? v : v * ns;
+                }
             }
         }
     }
@@ -165,6 +178,7 @@ MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const floa
                                  int Wo, int Co, int R, int S, int pad_t, int pad_l, int gather, int act, float slope, int flip,
                                  void* stream) {
     if (!migan_rgb_conv_ok(Ci, Co, R, S, 1, gather, (long long)N * Ho * Wo) || N < 1 || N > 65535) return (int)hipErrorInvalidValue;
+    if (act != ACT_NONE && act != ACT_LRELU && act != ACT_RELU) return (int)hipErrorInvalidValue;   // the activations image-input layers carry
     if (gather == GATHER_REFLECT && (pad_t >= H || pad_l >= W || Ho + R - 1 - pad_t - H >= H || Wo + S - 1 - pad_l - W >= W))
         return (int)hipErrorInvalidValue;
     RgbGeom g = {N, H, W, Ho, Wo, Co, pad_t, pad_l, gather == GATHER_REFLECT, act, slope, 0, flip != 0};

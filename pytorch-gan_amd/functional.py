@@ -674,7 +674,7 @@ class _Conv2d(Function):
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, col)
             return y
         ctx.rgb = False
-        if (_RGB and mask is None and stats_buf is None and w.is_contiguous() and Ci == 3
+        if (_RGB and mask is None and stats_buf is None and w.is_contiguous() and Ci == 3 and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
                 and lib.migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
             # image-input layer (3 source channels: srgan/models.py:85, vgg19.features[0], cyclegan/models.py:50): K = R*S*3 as it is
             # on the MFMA units, operands straight from staged image rows (csrc/rgb_conv.hip)

@@ -339,6 +339,18 @@ task_stats() {   # call 21: norm statistics from the conv epilogue of the LDS-DM
   cat $O/bench.txt
 }
 
+task_rgb3() {   # call 22: image-input forward with a straight-line epilogue (no wait in front of every store)
+  local O=gpurun_out/r5q; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -k "rgb_conv or thin_output or srgan_step" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  timeout 200 python tools/conv_microbench.py --shapes srgan --match "3->64" --dirs fwd,xfwd,xwgrad --iters 20 --repeat 3 > $O/micro.txt 2>&1
+  timeout 200 python tools/conv_microbench.py --shapes cyclegan --match "c7s1-64" --dirs fwd,xfwd,xwgrad --iters 20 --repeat 3 >> $O/micro.txt 2>&1
+  cat $O/micro.txt
+  ab $O/bench.txt srgan 4 2
+  bl $O/bench.txt cyclegan 4 --no-graph
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
