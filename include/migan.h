@@ -223,9 +223,9 @@ int migan_conv2d_dgrad_reflect1_ws(const float* dy, const float* w_ihwo, float* 
 int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                         float* ws, size_t ws_bytes, void* stream);
 
-/* Image-input convolutions (3 source channels, stride 1, square 3 / 7 / 9 kernel, 32 or 64 output channels, zero or reflection
+/* Image-input convolutions (3 source channels, stride 1, square 3 / 7 kernel, 32 or 64 output channels, zero or reflection
  * padding: srgan/models.py:85 Conv2d(3,64,3,1,1), vgg19.features[0] behind srgan/models.py:11, cyclegan/models.py:49-50
- * ReflectionPad2d(3)+Conv2d(3,64,7), srgan/models.py:38 Conv2d(3,64,9,1,4)) on the MFMA units straight from staged image rows
+ * ReflectionPad2d(3)+Conv2d(3,64,7)) on the MFMA units straight from staged image rows
  * (csrc/rgb_conv.hip): K = R*S*3 is the GEMM's reduction as it is - no 32-channel tap tiles, no im2col buffer.
  *   fwd:   x [N][H][W][Ci] (Ci = 3; 1 with a 3x3 kernel), w_hwio [R][S][Ci][Co] (the OIHW weight permuted (2,3,1,0)),
  *          y [N][Ho][Wo][Co] = act(conv + bias), act = none / LeakyReLU / ReLU.  flip != 0: taps read in reverse order - with x = dy and w_hwio = a thin-output

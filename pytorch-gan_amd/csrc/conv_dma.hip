@@ -321,8 +321,33 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += sl[((i * TN + j) * 16 + r) * 256 + tid];
     }
 
-    // ---- epilogue (igemm_pipe_kernel's): bias + activation + optional [N][Co] mask, strided class scatter, accumulate
-    const bool linear_out = (g.ostep == 1 && g.ncls == 1 && !g.m2d);
+    // ---- epilogue: bias + activation + optional [N][Co] mask / ReLU mask / accumulate, strided class scatter.
+    // Round 5 found what this loop cost as it was written (a per-value `if (bias) v += bias[col]`, the geometry read from the argument
+    // table inside the row loop): the compiler put `s_waitcnt vmcnt(0)` in front of every value - each of a lane's 16-64 stores waited for
+    // the store before it - and two to six scalar loads with their own waits into every row.  Now: the bias of a lane's TN columns is
+    // loaded once and USED once right here (the empty asm reads the registers, so the one wait for them sits in this block and no later
+    // join has a load pending), the class geometry lives in scalars, none / LeakyReLU / ReLU are one select.
+    float bcol[TN];
+    bool colok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (TN * 32) + j * 32 + l31;
+        colok[j] = col < g.Co;
+        bcol[j] = (bias && colok[j]) ? bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        asm volatile("" : "+v"(bcol[j]));
+    }
+    const int Co = g.Co, ostep = g.ostep, HoF = g.HoF, WoF = g.WoF, oh0 = g.oh0[cls], ow0 = g.ow0[cls], m2d = g.m2d, accum = g.accum;
+    const unsigned mg_hw = g.mg_hw[cls], mg_w = g.mg_w[cls];
+    const int sh_hw = g.sh_hw[cls], sh_w = g.sh_w[cls], act = g.act;
+    const float slope = g.slope;
+    const float* oscale = g.oscale;
+    const float* omask = g.omask;
+    const bool linear_out = (ostep == 1 && g.ncls == 1 && !m2d) && !oscale;
+    const bool simple = act <= ACT_RELU;
+    const float ns = act == ACT_NONE ? 1.f : (act == ACT_LRELU ? slope : 0.f);   // negative-side factor of the simple activations
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -330,26 +355,33 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int m = m0 + row;
             if (m >= M) continue;
-            size_t opix;
+            size_t opix = (size_t)m;
             int n_img = 0;
-            if (linear_out && !g.oscale) {
-                opix = (size_t)m;
-            } else {
+            if (!linear_out) {
+                n_img = fastdiv(m, mg_hw, sh_hw);
+                const int rem = m - n_img * Ho * Wo;
                 int oi, oj;
-                dma_decode_m(g, cls, m, Ho, Wo, n_img, oi, oj);
-                opix = ((size_t)n_img * g.HoF + (g.oh0[cls] + oi * g.ostep)) * g.WoF + (g.ow0[cls] + oj * g.ostep);
+                if (m2d) {
+                    const int blk = rem >> 7, ii = rem & 127;
+                    const int bi = fastdiv(blk << 4, mg_w, sh_w);
+                    oi = bi * 8 + (ii >> 4);
+                    oj = (blk - bi * (Wo >> 4)) * 16 + (ii & 15);
+                } else {
+                    oi = fastdiv(rem, mg_w, sh_w);
+                    oj = rem - oi * Wo;
+                }
+                opix = ((size_t)n_img * HoF + (oh0 + oi * ostep)) * WoF + (ow0 + oj * ostep);
             }
+            float* crow = C + opix * Co + n0 + wn * (TN * 32) + l31;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (col < g.Co) {
-                    float v = acc[i][j][r];
-                    if (bias) v += bias[col];
-                    float o = act_apply(v, g.act, g.slope);
-                    if (g.oscale) o *= g.oscale[(size_t)n_img * g.Co + col];
-                    if (g.omask) o = g.omask[opix * g.Co + col] > 0.f ? o : 0.f;
-                    if (g.accum) o += C[opix * g.Co + col];
-                    C[opix * g.Co + col] = o;
+                if (colok[j]) {
+                    const float v = acc[i][j][r] + bcol[j];
+                    float o = simple ? (v > 0.f ? v : v * ns) : act_apply(v, act, slope);
+                    if (oscale) o *= oscale[(size_t)n_img * Co + n0 + wn * (TN * 32) + j * 32 + l31];
+                    if (omask) o = omask[opix * Co + n0 + wn * (TN * 32) + j * 32 + l31] > 0.f ? o : 0.f;
+                    if (accum) o += crow[j * 32];
+                    crow[j * 32] = o;
                 }
             }
         }

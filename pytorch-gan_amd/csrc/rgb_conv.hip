@@ -3,7 +3,7 @@
 //
 // Reference call sites: srgan/models.py:85 (discriminator Conv2d(3, 64, 3, 1, 1) + LeakyReLU on 384 x 384 images - three forwards and
 // two weight gradients per step), torchvision vgg19.features[0] behind srgan/models.py:11 (Conv2d(3, 64, 3, padding=1) + ReLU, two
-// forwards per step), cyclegan/models.py:49-50 (ReflectionPad2d(3) + Conv2d(3, 64, 7)), srgan/models.py:38 (Conv2d(3, 64, 9, 1, 4)).
+// forwards per step), cyclegan/models.py:49-50 (ReflectionPad2d(3) + Conv2d(3, 64, 7)).
 //
 // With Ci = 3 the reduction of a 3x3 layer is K = 27: the general implicit-GEMM kernels pad every tap to a 32-channel tile (10.7x the
 // work) and the VALU kernels that served these layers ran at 2-15 % of peak while writing or reading a 604 MB activation
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
     }
 }
 
-// 1 when the image-input kernels take this layer: 3 source channels, stride 1, square 3 / 7 / 9 kernel, 32 or 64 output channels,
+// 1 when the image-input kernels take this layer: 3 source channels, stride 1, square 3 / 7 kernel, 32 or 64 output channels,
 // zero or reflection padding smaller than the image, and enough pixels to be worth a launch of 128-pixel row tiles
 MIGAN_API int migan_rgb_conv_ok(int Ci, int Co, int R, int S, int stride, int gather, long long pixels) {
-    if ((Ci != 3 && !(Ci == 1 && R == 3)) || stride != 1 || R != S || (R != 3 && R != 7 && R != 9) || (Co != 32 && Co != 64)) return 0;
+    // (9 x 9 - srgan/models.py:38 on 96 x 96 images - was measured too: 89-120 us against 94 us for the general kernel; not taken)
+    if ((Ci != 3 && !(Ci == 1 && R == 3)) || stride != 1 || R != S || (R != 3 && R != 7) || (Co != 32 && Co != 64)) return 0;
     if (gather != GATHER_ZERO && gather != GATHER_REFLECT) return 0;
     return pixels >= 16384 ? 1 : 0;
 }
@@ -202,9 +203,9 @@ MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const floa
     if (Ci == 1) {
         if (Co == 64) RGB_FWD(3, 2, 1); else RGB_FWD(3, 1, 1);
     } else if (Co == 64) {
-        if (R == 3) RGB_FWD(3, 2, 3); else if (R == 7) RGB_FWD(7, 2, 3); else RGB_FWD(9, 2, 3);
+        if (R == 3) RGB_FWD(3, 2, 3); else RGB_FWD(7, 2, 3);
     } else {
-        if (R == 3) RGB_FWD(3, 1, 3); else if (R == 7) RGB_FWD(7, 1, 3); else RGB_FWD(9, 1, 3);
+        if (R == 3) RGB_FWD(3, 1, 3); else RGB_FWD(7, 1, 3);
     }
 #undef RGB_FWD
     HIP_LAUNCH_CHECK();

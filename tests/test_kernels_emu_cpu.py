@@ -674,11 +674,11 @@ def test_replay_buffer_planned_picks_equal_the_eager_picks(emu):
     assert torch.equal(out["eager"][1], out["planned"][1]) and torch.equal(out["eager"][1], torch.cat(ref.data))
 
 
-@pytest.mark.parametrize("idx", [0, 2, 3, 4])
+@pytest.mark.parametrize("idx", [0, 2, 3])
 def test_image_input_conv_kernels_on_the_execution_model(idx):
     """test_ops_gpu.py::test_rgb_conv_layers (csrc/rgb_conv.hip: forward and the fused activation-backward + bias + weight-gradient
     launch of the 3-channel layers) on the execution model, LDS poisoned: 3x3 with ragged row tiles, 32 output channels, 7x7 under
-    reflection padding, 9x9 forward."""
+    reflection padding."""
     _load_or_skip()
     import pytorch_gan_amd as pg
     import test_ops_gpu

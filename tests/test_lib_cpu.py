@@ -154,7 +154,7 @@ def test_thin_toeplitz_applicability():
     # Co' = 32 since round 5 (the input-gradient GEMM's source channels: whole 32-channel K-tiles for the LDS-DMA kernels)
     assert lib.migan_thin_toeplitz_cols(3, 9) == 32 and lib.migan_thin_toeplitz_cols(3, 7) == 32
     assert lib.migan_thin_toeplitz_workspace(16, 384, 384, 3, 9) == 16 * 384 * 384 * 32 * 4
-    # image-input layers (csrc/rgb_conv.hip): 3 source channels, stride 1, square 3 / 7 / 9 kernels, 32 / 64 output channels
+    # image-input layers (csrc/rgb_conv.hip): 3 source channels, stride 1, square 3 / 7 kernels, 32 / 64 output channels
     assert lib.migan_rgb_conv_ok(3, 64, 3, 3, 1, 0, 16 * 384 * 384) == 1 and lib.migan_rgb_conv_ok(3, 64, 7, 7, 1, 1, 8 * 256 * 256) == 1
     assert lib.migan_rgb_conv_ok(3, 64, 3, 3, 2, 0, 1 << 20) == 0 and lib.migan_rgb_conv_ok(1, 16, 3, 3, 1, 0, 1 << 20) == 0
     assert lib.migan_rgb_conv_ok(3, 64, 3, 3, 1, 0, 1000) == 0 and lib.migan_rgb_conv_ok(3, 64, 4, 4, 1, 0, 1 << 20) == 0

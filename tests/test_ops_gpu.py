@@ -107,7 +107,6 @@ RGB_CASES = [
     (2, 96, 128, 64, 3, 1, 0, 2, "vgg19.features[0:2] Conv2d(3,64,3,padding=1)+ReLU"),
     (1, 128, 130, 32, 3, 1, 0, 0, "32 output channels, no activation"),
     (1, 128, 128, 64, 7, 3, 1, 0, "cyclegan/models.py:49-50 ReflectionPad2d(3)+Conv2d(3,64,7)"),
-    (1, 128, 136, 64, 9, 4, 0, 1, "srgan/models.py:38 Conv2d(3,64,9,1,4) (forward on the image-input kernel, gradients on the general ones)"),
 ]
 
 

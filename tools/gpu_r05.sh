@@ -351,6 +351,23 @@ task_rgb3() {   # call 22: image-input forward with a straight-line epilogue (no
   cat $O/bench.txt
 }
 
+task_epi() {   # call 23: igemm_dma_kernel epilogue without a wait in front of every store (bias / decode parameters in registers)
+  local O=gpurun_out/r5r; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py -q -k "conv2d_fwd_bwd or upconv or conv_transpose or reflect or splitk or strided" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for tree in ab_base . ab_base .; do
+    echo "== tree $tree" >> $O/micro.txt
+    (cd $tree && for sh in dcgan srgan cyclegan; do timeout 200 python tools/conv_microbench.py --shapes $sh --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep -v "^#" ; done) >> $O/micro.txt 2>&1
+  done
+  cat $O/micro.txt
+  ab $O/bench.txt dcgan 50 2
+  ab $O/bench.txt srgan 4 2
+  ab $O/bench.txt cyclegan 4 1
+  ab $O/bench.txt pix2pix 50 1
+  bl $O/bench.txt cyclegan 10 --batch 1
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
