@@ -420,6 +420,10 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
 // number of tiles a CU has to work through (T / 256, rounded up for the last CU to finish), the padding of the tile grid
 // and how dense a wave's MFMA stream is between two barriers (eff: 64 MFMAs per K-tile and wave for 128x128 / 256x64, 32
 // for 128x64, 16 for 64x64 and 128x32).  MIGAN_DMA_TILE=BBBNNN forces a tile (A/B knob).
+// (192x64 tiles - three 32-row blocks per wave, 48 KB of LDS so that exactly three workgroups fit a CU - for SRGAN's 64 -> 64 trunk at 96x96,
+// batch 16 (srgan/models.py:22-27: 2304 64x64 tiles on 2048 slots, or exactly 3 x 256 of these) were measured: 107.0 vs 109.0 us forward, 100.5
+// vs 102.9 us input gradient stand-alone, the SRGAN step 198.9 / 198.7 vs 199.4 / 199.7 img/s; profiles/r05_ab.txt call 24.  The second round
+// of 256 tiles is not what holds that launch at 0.65 of the MFMA rate; removed.)
 struct DmaCand { int bm, bn; double eff; };
 static const DmaCand kDmaCands[] = {{128, 128, 1.00}, {128, 64, 0.97}, {64, 64, 0.93}, {128, 32, 0.70}};
 static int dma_select(long maxM, int Co, int ncls) {

@@ -368,6 +368,28 @@ task_epi() {   # call 23: igemm_dma_kernel epilogue without a wait in front of e
   cat $O/bench.txt
 }
 
+task_tile192() {   # call 24: 192x64 tiles for launches of <= 3 such tiles per CU (SRGAN trunk), norm statistics pass cut into more blocks
+  local O=gpurun_out/r5s; mkdir -p $O
+  timeout 600 python -m pytest tests/test_ops_gpu.py -q -k "conv2d_fwd_bwd or geometry_selects" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for v in 0 1 0 1; do
+    echo "== MIGAN_DMA_192=$v" >> $O/micro.txt
+    MIGAN_DMA_192=$v timeout 100 python tools/conv_microbench.py --shapes srgan --match "res 64" --dirs fwd,dgrad --iters 30 --repeat 3 2>&1 | grep "res 64" >> $O/micro.txt
+  done
+  cat $O/micro.txt
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=0
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=1
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=1 MIGAN_NORM_BLOCKS=2048
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=1 MIGAN_NORM_BLOCKS=4096
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=0
+  bl $O/bench.txt srgan 4 MIGAN_DMA_192=1
+  bl $O/bench.txt cyclegan 4 MIGAN_NORM_BLOCKS=1024
+  bl $O/bench.txt cyclegan 4 MIGAN_NORM_BLOCKS=2048
+  bl $O/bench.txt dcgan 50 MIGAN_NORM_BLOCKS=1024
+  bl $O/bench.txt dcgan 50 MIGAN_NORM_BLOCKS=2048
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
