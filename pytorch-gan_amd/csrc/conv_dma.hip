@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                        // weights as the row operand: accumulator tile (i, j) holds CHANNEL (r & 3) + 8 * (r >> 2) + 4 * h of block j in
+                        // register r, for PIXEL l31 of block i - four consecutive channels of one pixel per register quad (see the epilogue)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
         }
     };
     if constexpr (NS == 2) {
@@ -322,66 +324,109 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     }
 
     // ---- epilogue: bias + activation + optional [N][Co] mask / ReLU mask / accumulate, strided class scatter.
-    // Round 5 found what this loop cost as it was written (a per-value `if (bias) v += bias[col]`, the geometry read from the argument
-    // table inside the row loop): the compiler put `s_waitcnt vmcnt(0)` in front of every value - each of a lane's 16-64 stores waited for
-    // the store before it - and two to six scalar loads with their own waits into every row.  Now: the bias of a lane's TN columns is
-    // loaded once and USED once right here (the empty asm reads the registers, so the one wait for them sits in this block and no later
-    // join has a load pending), the class geometry lives in scalars, none / LeakyReLU / ReLU are one select.
-    float bcol[TN];
-    bool colok[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (TN * 32) + j * 32 + l31;
-        colok[j] = col < g.Co;
-        bcol[j] = (bias && colok[j]) ? bias[col] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        asm volatile("" : "+v"(bcol[j]));
-    }
+    // A lane owns ONE pixel per 32-row block (the MFMA column l31) and, per 32-channel block, the four channel quads 8k + 4h .. + 3: a
+    // 128x128 tile leaves through 16 `global_store_dwordx4` per lane (lanes l31 and l31 + 32 write 32 adjacent bytes of one pixel) instead of
+    // 64 `global_store_dword`, and the pixel decode runs once per block, not once per row.  Round 5 measured what the row-per-register
+    // form cost: the stores are ISSUE-bound (cdna_hip_programming.md T21) and the vector-memory unit they occupy is the one the LDS-DMA of
+    // the CU's other workgroups goes through - 88 us of a 1292 us launch (64 -> 256 @192, srgan/models.py:53), 96 of 1385 (VGG 64 -> 64 @384),
+    // 7 of 100 (trunk), added to the K loop's time whatever the phase of the workgroups (profiles/r05_ab.txt calls 26, 27).
+    // (Before that, round 5 found `s_waitcnt vmcnt(0)` in front of every store - a per-value `if (bias)` load; the bias quads are now loaded
+    // once and USED once right here, so no later join has a load pending.)
     const int Co = g.Co, ostep = g.ostep, HoF = g.HoF, WoF = g.WoF, oh0 = g.oh0[cls], ow0 = g.ow0[cls], m2d = g.m2d, accum = g.accum;
     const unsigned mg_hw = g.mg_hw[cls], mg_w = g.mg_w[cls];
     const int sh_hw = g.sh_hw[cls], sh_w = g.sh_w[cls], act = g.act;
     const float slope = g.slope;
     const float* oscale = g.oscale;
     const float* omask = g.omask;
+    const bool vec = (Co & 3) == 0;   // channel quads are whole and 16-byte aligned
+    const int cbase = n0 + wn * (TN * 32) + 4 * h;
+    f32x4 bq[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cbase + j * 32 + 8 * k;
+            bq[j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                if (vec && c < Co) bq[j][k] = *reinterpret_cast<const f32x4*>(bias + c);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bq[j][k][e] = c + e < Co ? bias[c + e] : 0.f;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "+v"(bq[j][k]));
+        }
     const bool linear_out = (ostep == 1 && g.ncls == 1 && !m2d) && !oscale;
     const bool simple = act <= ACT_RELU;
     const float ns = act == ACT_NONE ? 1.f : (act == ACT_LRELU ? slope : 0.f);   // negative-side factor of the simple activations
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int m = m0 + row;
-            if (m >= M) continue;
-            size_t opix = (size_t)m;
-            int n_img = 0;
-            if (!linear_out) {
-                n_img = fastdiv(m, mg_hw, sh_hw);
-                const int rem = m - n_img * Ho * Wo;
-                int oi, oj;
-                if (m2d) {
-                    const int blk = rem >> 7, ii = rem & 127;
-                    const int bi = fastdiv(blk << 4, mg_w, sh_w);
-                    oi = bi * 8 + (ii >> 4);
-                    oj = (blk - bi * (Wo >> 4)) * 16 + (ii & 15);
-                } else {
-                    oi = fastdiv(rem, mg_w, sh_w);
-                    oj = rem - oi * Wo;
-                }
-                opix = ((size_t)n_img * HoF + (oh0 + oi * ostep)) * WoF + (ow0 + oj * ostep);
+        const int m = m0 + wm * (TM * 32) + i * 32 + l31;
+        if (m >= M) continue;
+        size_t opix = (size_t)m;
+        int n_img = 0;
+        if (!linear_out) {
+            n_img = fastdiv(m, mg_hw, sh_hw);
+            const int rem = m - n_img * Ho * Wo;
+            int oi, oj;
+            if (m2d) {
+                const int blk = rem >> 7, ii = rem & 127;
+                const int bi = fastdiv(blk << 4, mg_w, sh_w);
+                oi = bi * 8 + (ii >> 4);
+                oj = (blk - bi * (Wo >> 4)) * 16 + (ii & 15);
+            } else {
+                oi = fastdiv(rem, mg_w, sh_w);
+                oj = rem - oi * Wo;
             }
-            float* crow = C + opix * Co + n0 + wn * (TN * 32) + l31;
+            opix = ((size_t)n_img * HoF + (oh0 + oi * ostep)) * WoF + (ow0 + oj * ostep);
+        }
+        float* crow = C + opix * Co;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (colok[j]) {
-                    const float v = acc[i][j][r] + bcol[j];
-                    float o = simple ? (v > 0.f ? v : v * ns) : act_apply(v, act, slope);
-                    if (oscale) o *= oscale[(size_t)n_img * Co + n0 + wn * (TN * 32) + j * 32 + l31];
-                    if (omask) o = omask[opix * Co + n0 + wn * (TN * 32) + j * 32 + l31] > 0.f ? o : 0.f;
-                    if (accum) o += crow[j * 32];
-                    crow[j * 32] = o;
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = cbase + j * 32 + 8 * k;
+                if (c >= Co) continue;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][j][4 * k + e] + bq[j][k][e];
+                    o[e] = simple ? (v > 0.f ? v : v * ns) : act_apply(v, act, slope);
+                }
+                if (vec) {
+                    if (oscale) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(oscale + (size_t)n_img * Co + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] *= sc[e];
+                    }
+                    if (omask) {
+                        const f32x4 mk = *reinterpret_cast<const f32x4*>(omask + opix * Co + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = mk[e] > 0.f ? o[e] : 0.f;
+                    }
+                    if (accum) {
+                        const f32x4 old = *reinterpret_cast<const f32x4*>(crow + c);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += old[e];
+                    }
+                    // (plain store: `nt`, `sc1` and `nt sc1` buffer stores were measured - every launch slower, the strided ones up to 2x;
+                    // profiles/r05_ab.txt call 29)
+                    *reinterpret_cast<f32x4*>(crow + c) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (c + e < Co) {
+                            float oe = o[e];
+                            if (oscale) oe *= oscale[(size_t)n_img * Co + c + e];
+                            if (omask) oe = omask[opix * Co + c + e] > 0.f ? oe : 0.f;
+                            if (accum) oe += crow[c + e];
+                            crow[c + e] = oe;
+                        }
+                    }
                 }
             }
         }
@@ -398,6 +443,9 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     // (Several consecutive M-tiles per workgroup - 768 resident workgroups x 3 tiles for the 2304 64x64 tiles of SRGAN's 64 -> 64 trunk
     // at 96x96 instead of 9 tiles per CU on 8 slots - were measured and rejected: 122 vs 114 us forward, 116 vs 110 us input gradient,
     // profiles/r04_ab.txt; the loop also cost every variant 8-14 registers.)
+    // (Fewer workgroups per CU than the kernel allows - unused dynamic LDS - so that 9 tiles per CU run as 3 + 3 + 3 or 5 + 4 instead of
+    // 8 + 1 / 4 + 4 + 1 with a lone last workgroup: no layer of the three image workloads gains, the trunk loses 3-8 %; profiles/r05_ab.txt
+    // call 25.)
     bool tapin = true;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     const bool ktail = g.Ci % BK != 0;

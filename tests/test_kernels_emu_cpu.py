@@ -856,7 +856,7 @@ def test_a_wait_that_is_one_tile_short_is_noticed(emu, tmp_path):
     tmp = str(tmp_path / "csrc")
     os.makedirs(tmp)
     for f in os.listdir(src):
-        if f.endswith((".hip", ".h", ".py")):
+        if f.endswith((".hip", ".h", ".inc", ".py")):
             shutil.copy(os.path.join(src, f), tmp)
     text = open(os.path.join(tmp, "conv_dma.hip")).read()
     old = '::"n"((NS - 2) * IPT)'

@@ -390,6 +390,84 @@ task_tile192() {   # call 24: 192x64 tiles for launches of <= 3 such tiles per C
   cat $O/bench.txt
 }
 
+task_cap() {   # call 25: workgroups per CU capped below the kernel's occupancy (unused dynamic LDS) so that the last round of a launch is not one lone workgroup per CU
+  local O=gpurun_out/r5t; mkdir -p $O
+  for v in 0 3 5 6 -1; do
+    echo "== MIGAN_DMA_CAP=$v" >> $O/micro.txt
+    MIGAN_DMA_CAP=$v timeout 100 python tools/conv_microbench.py --shapes srgan --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep " us " | grep -v "9x9\|3->64" >> $O/micro.txt
+  done
+  for v in 0 -1; do
+    echo "== MIGAN_DMA_CAP=$v" >> $O/micro2.txt
+    for sh in dcgan cyclegan; do MIGAN_DMA_CAP=$v timeout 100 python tools/conv_microbench.py --shapes $sh --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep " us " >> $O/micro2.txt; done
+  done
+  cat $O/micro.txt $O/micro2.txt
+  for r in 1 2; do
+    bl $O/bench.txt srgan 4 MIGAN_DMA_CAP=0
+    bl $O/bench.txt srgan 4 MIGAN_DMA_CAP=-1
+  done
+  bl $O/bench.txt cyclegan 4 MIGAN_DMA_CAP=0
+  bl $O/bench.txt cyclegan 4 MIGAN_DMA_CAP=-1
+  bl $O/bench.txt dcgan 50 MIGAN_DMA_CAP=0
+  bl $O/bench.txt dcgan 50 MIGAN_DMA_CAP=-1
+  cat $O/bench.txt
+}
+
+task_probe3() {   # call 26 (probe, kernel hack not committed): what a launch of igemm_dma_kernel costs besides its K loop
+  local O=gpurun_out/r5u; mkdir -p $O
+  for v in 0 -1001 -1002 -1003; do
+    echo "== MIGAN_MB_SLOPE=$v (0 normal, -1001 no epilogue, -1002 two K-tiles, -1003 two K-tiles and no epilogue)" >> $O/micro.txt
+    MIGAN_MB_SLOPE=$v timeout 100 python tools/conv_microbench.py --shapes srgan --dirs fwd --iters 20 --repeat 3 2>&1 | grep " us " | grep -v "9x9\|3->64" >> $O/micro.txt
+    MIGAN_MB_SLOPE=$v timeout 100 python tools/conv_microbench.py --shapes cyclegan --dirs fwd --match "R256" --iters 20 --repeat 3 2>&1 | grep " us " >> $O/micro.txt
+  done
+  cat $O/micro.txt
+}
+
+task_probe4() {   # call 27 (probe, kernel hack not committed): half of the first-round workgroups start late - do the rounds of a launch run in lockstep?
+  local O=gpurun_out/r5v; mkdir -p $O
+  for v in 0 -2010 -2020 -2040 -2070 -2100; do
+    echo "== MIGAN_MB_SLOPE=$v (0 normal; -2000 - d: odd half of the first round starts d us late)" >> $O/micro.txt
+    MIGAN_MB_SLOPE=$v timeout 100 python tools/conv_microbench.py --shapes srgan --dirs fwd --iters 20 --repeat 3 2>&1 | grep " us " | grep -v "9x9\|3->64" >> $O/micro.txt
+    MIGAN_MB_SLOPE=$v timeout 100 python tools/conv_microbench.py --shapes cyclegan --dirs fwd --match "R256" --iters 20 --repeat 3 2>&1 | grep " us " >> $O/micro.txt
+  done
+  cat $O/micro.txt
+}
+
+# whole-step A/B on ONE box against the tree of the previous commit (ab_prev/ = git archive HEAD + built library):  abp <outfile> <workload> <steps> [reps]
+abp() {
+  local out=$1 w=$2 k=$3 reps=${4:-2}
+  for r in $(seq $reps); do
+    (cd ab_prev && echo "== prev $w" >> $R/$out && timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline 2>>$R/$out.err | line >> $R/$out)
+    bl $out $w $k
+  done
+}
+
+task_epi2() {   # call 28: igemm_dma_kernel epilogue with channel quads per lane (weights as the MFMA row operand): 16 dwordx4 stores instead of 64 dword stores per lane
+  local O=gpurun_out/r5w; mkdir -p $O
+  timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_steps_gpu.py -q -x -k "conv2d_fwd_bwd or upconv or conv_transpose or reflect or splitk or strided or dropout or relu_backward or toeplitz or geometry_selects or dcgan_step or srgan_step" --durations=3 > $O/pytest.txt 2>&1
+  tail -3 $O/pytest.txt
+  for tree in ab_prev . ab_prev .; do
+    echo "== tree $tree" >> $O/micro.txt
+    (cd $tree && for sh in dcgan srgan cyclegan; do timeout 200 python tools/conv_microbench.py --shapes $sh --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep " us " ; done) >> $O/micro.txt 2>&1
+  done
+  abp $O/bench.txt dcgan 50 2
+  abp $O/bench.txt srgan 4 2
+  abp $O/bench.txt cyclegan 4 1
+  abp $O/bench.txt pix2pix 50 1
+  cat $O/bench.txt
+}
+
+task_probe5() {   # call 29 (probe, not committed): cache policy of the output stores of igemm_dma_kernel (0 global, 1 buffer, 2 nt, 3 sc1, 4 sc1 nt)
+  local O=gpurun_out/r5x; mkdir -p $O
+  for v in 0 1 2 3 4; do
+    echo "== MIGAN_ST_MODE=$v" >> $O/micro.txt
+    MIGAN_ST_MODE=$v timeout 100 python tools/conv_microbench.py --shapes srgan --only fwd,dgrad --iters 20 --repeat 3 2>&1 | grep " us " | grep -v "9x9\|3->64" >> $O/micro.txt
+    MIGAN_ST_MODE=$v timeout 100 python tools/conv_microbench.py --shapes dcgan --dirs ufwd,udgrad --iters 20 --repeat 3 2>&1 | grep " us " >> $O/micro.txt
+  done
+  for v in 0 2 3 4; do bl $O/bench.txt srgan 4 MIGAN_ST_MODE=$v; done
+  for v in 0 3; do bl $O/bench.txt dcgan 50 MIGAN_ST_MODE=$v; done
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
