@@ -468,6 +468,12 @@ task_probe5() {   # call 29 (probe, not committed): cache policy of the output s
   cat $O/bench.txt
 }
 
+task_final2() {   # call 31, closing pass of the final tree with 3.9 GPU-minutes left: kernel traces of the DCGAN and SRGAN steps, then the default bench line (PMC tables stay those of call 20)
+  task_prof r5final2 dcgan dcgan:graph srgan
+  task_bench
+  cp gpurun_out/r5bench/bench_default.json gpurun_out/r5bench/bench_final2.json
+}
+
 t=${1:-}; shift || true
 case "$t" in
   first) task_first "$@" ;;
