@@ -921,3 +921,49 @@ def test_relu_handoff_on_the_execution_model(emu, shape):
 
     lib = _run_gpu_test_body("test_ops_gpu", "test_relu_backward_handed_to_the_consumer", pg, shape)
     assert lib.hipemu_launch_count(b"igemm_dma_kernel") > 0
+
+
+@pytest.mark.parametrize("Co", [40, 38], ids=["quads", "ragged-channels"])
+def test_lds_dma_epilogue_forms_on_the_execution_model(emu, Co):
+    """The epilogue of igemm_dma_kernel (a lane owns channel quads of one pixel): 16-byte stores when Co % 4 == 0, the per-channel form
+    when not, each with the [N][Co] multiplier of the fused Dropout2d (`oscale`), the ReLU mask of the consumer hand-off (`omask`) and the
+    accumulating ring launch of the reflection input gradient (`accum`) - against torch on the host."""
+    g = torch.Generator().manual_seed(5)
+    N, Ci, H, W = 3, 32, 12, 12
+    sk = torch.zeros(emu.migan_conv_splitk_workspace() // 4)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    mask = (torch.rand(N, Co, generator=g) > 0.4).float() * 2.0 if Co % 4 == 0 else None   # (the C ABI takes the multiplier for whole quads only)
+    xn, w_ohwi = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous()
+    emu.hipemu_reset_counts()
+    # forward with bias, LeakyReLU and the per-(image, channel) multiplier
+    y = torch.empty(N, H, W, Co)
+    assert emu.migan_conv2d_fwd_ws(_ptr(xn), _ptr(w_ohwi), _ptr(b), _ptr(mask), _ptr(y), N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 1, 0.2,
+                                   _ptr(sk), sk.numel() * 4, None) == 0, emu.hipemu_last_message()
+    ref = TF.leaky_relu(TF.conv2d(x, w, b, 1, 1), 0.2)
+    if mask is not None:
+        ref = ref * mask[:, :, None, None]
+    assert _rel(y.permute(0, 3, 1, 2), ref) <= 3e-6
+    # input gradient of a conv whose input was a fused conv+ReLU: dx = (dy (*) w^T) where relu_out > 0  (the conv maps Co -> Ci here, so the
+    # GEMM's output channels are Co: the same quad / ragged split)
+    w2 = torch.randn(Ci, Co, 3, 3, generator=g) * 0.2   # Conv2d(Co, Ci): weight [Ci][Co][3][3]
+    dy = torch.randn(N, Ci, H, W, generator=g)
+    relu_out = torch.relu(torch.randn(N, Co, H, W, generator=g))
+    dx = torch.empty(N, H, W, Co)
+    w2_ihwo = w2.permute(1, 2, 3, 0).contiguous()       # [Co][3][3][Ci]
+    assert emu.migan_conv2d_dgrad_relu_ws(_ptr(dy.permute(0, 2, 3, 1).contiguous()), _ptr(w2_ihwo), _ptr(dx),
+                                          _ptr(relu_out.permute(0, 2, 3, 1).contiguous()), N, H, W, Co, H, W, Ci, 3, 3, 1, 1, 1, _ptr(sk),
+                                          sk.numel() * 4, None) == 0, emu.hipemu_last_message()
+    ref = TF.conv_transpose2d(dy, w2, None, 1, 1) * (relu_out > 0)
+    assert _rel(dx.permute(0, 3, 1, 2), ref) <= 3e-6
+    # ReflectionPad2d(1) + Conv3x3 input gradient straight into H x W: interior launch + accumulating ring launch
+    if Co % 4 == 0:
+        xr = torch.randn(N, Co, H, W, generator=g, requires_grad=True)
+        TF.conv2d(TF.pad(xr, (1, 1, 1, 1), mode="reflect"), w2).backward(dy)
+        dxr = torch.empty(N, H, W, Co)
+        assert emu.migan_conv2d_dgrad_reflect1_ws(_ptr(dy.permute(0, 2, 3, 1).contiguous()), _ptr(w2_ihwo), _ptr(dxr), N, H, W, Co, Ci,
+                                                  _ptr(sk), sk.numel() * 4, None) == 0, emu.hipemu_last_message()
+        assert _rel(dxr.permute(0, 3, 1, 2), xr.grad) <= 3e-6
+    assert emu.hipemu_launch_count(b"igemm_dma_kernel") >= 2
+    assert int(sk[:1024].view(torch.int32).abs().sum()) == 0

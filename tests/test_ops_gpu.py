@@ -60,7 +60,8 @@ CONV_CASES = [
     (2, 64, 11, 13, 64, 7, 1, (3, 3, 3, 3), 1, 0, False),       # reflect pad 3, 7x7 (49 taps), 64x128 wgrad tiles
     (5, 32, 6, 6, 160, 4, 2, (1, 1, 1, 1), 0, 0, True),         # 4x4 s2 with Ho*Wo = 9 < 32: several images per K-tile
     (2, 32, 448, 448, 48, 3, 1, (1, 1, 1, 1), 0, 0, True),      # 401k-pixel GEMM (3136 M-tiles), N tail; no act (kink flips)
-    (16, 64, 96, 96, 64, 3, 1, (1, 1, 1, 1), 0, 0, True),       # srgan/models.py:22-27 trunk at the bench batch: 768 tiles of 192 x 64
+    (16, 64, 96, 96, 64, 3, 1, (1, 1, 1, 1), 0, 0, True),       # srgan/models.py:22-27 trunk at the bench batch (2304 tiles of 64 x 64)
+    (2, 32, 12, 12, 38, 3, 1, (1, 1, 1, 1), 0, 1, True),        # Co % 4 != 0 on the LDS-DMA kernels: per-channel form of the quad epilogue
     # under-filled GEMMs (pix2pix/models.py:62-71): M = 1, 4, 16, 64 output pixels against K = 8192 / 4096 / 2048:
     # LDS-DMA kernel with four stages, split-K over up to 64 slices, in-kernel ticket reduction + epilogue
     (1, 512, 2, 2, 512, 4, 2, (1, 1, 1, 1), 0, 1, False),       # M = 1
