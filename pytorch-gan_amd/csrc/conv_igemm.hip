@@ -17,6 +17,15 @@
 // fragments are read with conflict-free ds_read_b32 (lanes 0-31 = 32 consecutive rows at k=2kp,
 // lanes 32-63 the same rows at k=2kp+1).  An fp32 MFMA occupies its SIMD for 64 cycles, so one
 // b32 read per operand per MFMA is far below the LDS issue budget (MI355X_MICROARCH.md §LDS).
+//
+// Layout of this translation unit (the .inc files are included below at the places their code used to stand; tools/isa_diff.py
+// showed the device code of all 135 kernels identical before and after each move):
+//   conv_igemm.hip         generic + register-staged forward / input-gradient kernels, tile selection, the conv2d / dgrad /
+//                          reflect-1 ring / phase-collapsed up-conv entry points and all extern "C" definitions of the family
+//   conv_valu_fwd.inc      thin-N, small-K, mid-K and GEMV VALU kernels of the forward side
+//   conv_wgrad_mfma.inc    MFMA weight-gradient kernels, their fixed-order reductions, the split planner
+//   conv_valu_wgrad.inc    VALU weight-gradient kernels
+// The LDS-DMA kernels that serve every launch with >= 32 source channels are their own file (conv_dma.hip).
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -1003,815 +1012,7 @@ static int dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, 
     return launch_igemm(g, dy, w_ihwo, nullptr, dx, (hipStream_t)stream, sk_ws, sk_bytes);
 }
 
-// ------------------------------------------------------------------------------------------------
-// wgrad: dW[co][t][ci] = sum_p dy[p][co] * gather(x)[p][t][ci];  GEMM M=Co, N=T*Ci, K=pixels.
-// Split-K over pixel ranges into a workspace, then a fixed-order reduction that also re-lays the
-// result out as OIHW (the torch parameter layout), so the run-to-run result is deterministic.
-// ------------------------------------------------------------------------------------------------
-
-
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradGeom g, const float* __restrict__ X,
-                                                    const float* __restrict__ DY,
-                                                    float* __restrict__ part) {
-    constexpr int BK = 32;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;  // 2x2 waves
-    __shared__ __attribute__((aligned(16))) int smem_i[BK * LDA + BK * LDB + 4 * BK];
-    float* As = reinterpret_cast<float*>(smem_i);
-    float* Bs = As + BK * LDA;
-    int* r_base = smem_i + BK * LDA + BK * LDB;  // per K-row (pixel) gather info
-    int* r_ih = r_base + BK;
-    int* r_iw = r_ih + BK;
-
-    const int tid = threadIdx.x;
-    const int T = g.R * g.S;
-    const int Ncol = T * g.Ci;
-    const int Mpix = g.N * g.Ho * g.Wo;
-    const int co0 = blockIdx.x * BM, nc0 = blockIdx.y * BN;
-    const int split = blockIdx.z;
-    const int p_begin = split * g.pix_per_split;
-    int p_end = p_begin + g.pix_per_split;
-    if (p_end > Mpix) p_end = Mpix;
-    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // thread owns column tid % BM (tid % BN) of pixel rows tid / BM + j * (256 / BM)
-    constexpr int NA = (BK * BM) / 256;
-    constexpr int NB = (BK * BN) / 256;
-    float ra1[NA], rb1[NB];
-
-    // column decode for B (fixed per thread)
-    int b_dh = 0, b_dw = 0, b_ci = 0;
-    bool b_colok = false;
-    const int qa = tid % BM;
-    const int qb = tid % BN;
-    {
-        int col = nc0 + qb;
-        if (col < Ncol) {
-            int t = col / g.Ci;
-            b_ci = col - t * g.Ci;
-            int r = t / g.S, s = t - r * g.S;
-            b_dh = r - g.pad_t;
-            b_dw = s - g.pad_l;
-            b_colok = true;
-        }
-    }
-    const bool a_colok = (co0 + qa) < g.Co;
-
-    auto calc_rowinfo = [&](int kt) {
-        if (tid < BK) {
-            int p = p_begin + kt * BK + tid;
-            int base = -1, ih = 0, iw = 0;
-            if (p < p_end) {
-                int n = p / (g.Ho * g.Wo);
-                int rem = p - n * g.Ho * g.Wo;
-                int oi = rem / g.Wo, oj = rem - oi * g.Wo;
-                base = n * g.Hi * g.Wi;
-                ih = oi * g.stride;
-                iw = oj * g.stride;
-            }
-            r_base[tid] = base;
-            r_ih[tid] = ih;
-            r_iw[tid] = iw;
-        }
-    };
-    auto load_tile = [&](int kt) {
-        const int pt0 = p_begin + kt * BK;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            int pl = tid / BM + j * (256 / BM);
-            int p = pt0 + pl;
-            float v = 0.f;
-            if (a_colok && p < p_end) v = DY[(size_t)p * g.Co + co0 + qa];
-            ra1[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int pl = tid / BN + j * (256 / BN);
-            float v = 0.f;
-            int base = r_base[pl];
-            int ihs, iws;
-            if (b_colok && base >= 0 && map_coord(r_ih[pl] + b_dh, g.HiL, g.gather, ihs) &&
-                map_coord(r_iw[pl] + b_dw, g.WiL, g.gather, iws))
-                v = X[(size_t)(base + ihs * g.Wi + iws) * g.Ci + b_ci];
-            rb1[j] = v;
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) As[(tid / BM + j * (256 / BM)) * LDA + qa] = ra1[j];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) Bs[(tid / BN + j * (256 / BN)) * LDB + qb] = rb1[j];
-    };
-
-    if (KT > 0) {
-        calc_rowinfo(0);
-        __syncthreads();
-        load_tile(0);
-    }
-    for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();  // everyone done reading LDS tiles + rowinfo of the previous step
-        store_tile();
-        if (kt + 1 < KT) calc_rowinfo(kt + 1);
-        __syncthreads();
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const float* ap = As + h * LDA + wm * (TM * 32) + l31;
-        const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    float* out = part + (size_t)split * g.Co * Ncol;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co >= g.Co) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
-                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pipelined wgrad (Co % 4 == 0 and Ci % 4 == 0): same tiling and [k][row] LDS image as wgrad_kernel, but the
-// pixel -> (n, oi, oj) decode uses multiply-shift division per thread (no LDS row-info pass, no extra barrier
-// dependency), the gather is branch-free and the loads of K-tile kt+1 are issued one per k-pair inside the MFMA
-// stream of tile kt (see igemm_pipe_kernel).
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool DYS = false, int OCC = 4>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? OCC : 1)) void wgrad_pipe_kernel(
-    const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
-    constexpr int BK = 32;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
-    constexpr int QA = BM / 4, QB = BN / 4;
-    constexpr int NA = (BK * QA) / 256, NB = (BK * QB) / 256, NL = NA + NB;
-    static_assert(NL <= BK / 2, "tile shape");
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
-    float* As = smem;
-    float* Bs = smem + BK * LDA;
-
-    const int tid = threadIdx.x;
-    const int T = g.R * g.S;
-    const int Ncol = T * g.Ci;
-    const int Mpix = g.N * g.Ho * g.Wo;
-    // XCD-aware block order (workgroup b runs on XCD b % 8): the tiles of ONE split run back-to-back on ONE XCD, so
-    // the dy / x pixel range they all re-read is served by that XCD's L2 instead of 8 separate L2s + Infinity Cache.
-    int split, tile;
-    {
-        // workgroup b runs on XCD b % 8: XCD x takes the x-th CONTIGUOUS eighth of the split-major (split, tile) list, so
-        // the tiles of one split - which all re-read that split's dy / x pixel range - run on one XCD (two at a seam)
-        const int tiles = g.tiles_m * g.tiles_n;
-        const int total = tiles * g.splits, per = (total + 7) >> 3;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int lin = xcd * per + k;
-        if (k >= per || lin >= total) return;
-        split = lin / tiles;
-        tile = lin - split * tiles;
-    }
-    const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
-    const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
-    int p_end = p_begin + g.pix_per_split;
-    if (p_end > Mpix) p_end = Mpix;
-    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    // DYS (phase-collapsed up-conv): blockIdx.y = output phase (a, b); it fixes the padding and the dy sub-lattice
-    const int cls = DYS ? (int)blockIdx.y : 0;
-    const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
-    const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int qa = tid % QA, qb = tid % QB;
-    const int plA = tid / QA, plB = tid / QB;
-    // fixed column of the gathered operand
-    int b_dh = 0, b_dw = 0, b_ci = 0;
-    bool b_colok = false;
-    {
-        int col = nc0 + qb * 4;
-        if (col < Ncol) {
-            int t = col / g.Ci;
-            b_ci = col - t * g.Ci;
-            int r = t / g.S, s = t - r * g.S;
-            b_dh = r - pad_t;
-            b_dw = s - pad_l;
-            b_colok = true;
-        }
-    }
-    const bool a_colok = (co0 + qa * 4) < g.Co;
-    const int a_col = a_colok ? co0 + qa * 4 : 0;
-    const int HoWo = g.Ho * g.Wo;
-    f32x4 ra[NA], rb[NB];
-    unsigned okA = 0, okB = 0;
-    int f_pt0 = p_begin;
-
-#define WGRAD_ISSUE(idx)                                                                                  \
-    do {                                                                                                  \
-        if ((idx) < NA) {                                                                                 \
-            constexpr int jj = (idx) < NA ? (idx) : 0;                                                    \
-            int p = f_pt0 + plA + jj * (256 / QA);                                                        \
-            bool ok = a_colok && p < p_end;                                                               \
-            p = p < p_end ? p : p_end - 1;                                                                \
-            if (DYS) {                                                                                    \
-                int n_ = fastdiv(p, g.mg_hw, g.sh_hw);                                                    \
-                int rem_ = p - n_ * HoWo;                                                                 \
-                int oi_ = fastdiv(rem_, g.mg_w, g.sh_w);                                                  \
-                int oj_ = rem_ - oi_ * g.Wo;                                                              \
-                p = (n_ * g.dy_H + dy_oh0 + oi_ * 2) * g.dy_W + dy_ow0 + oj_ * 2;                        \
-            }                                                                                             \
-            ra[jj] = *reinterpret_cast<const f32x4*>(DY + (size_t)p * g.Co + a_col);                      \
-            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                          \
-        } else {                                                                                          \
-            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                         \
-            int p = f_pt0 + plB + jj * (256 / QB);                                                        \
-            bool ok = b_colok && p < p_end;                                                               \
-            p = p < p_end ? p : p_end - 1;                                                                \
-            int n = fastdiv(p, g.mg_hw, g.sh_hw);                                                         \
-            int rem = p - n * HoWo;                                                                       \
-            int oi = fastdiv(rem, g.mg_w, g.sh_w);                                                        \
-            int oj = rem - oi * g.Wo;                                                                     \
-            int ihs, iws;                                                                                 \
-            ok &= map_bf(oi * g.stride + b_dh, g.HiL, g.Hi, g.gather, ihs);                               \
-            ok &= map_bf(oj * g.stride + b_dw, g.WiL, g.Wi, g.gather, iws);                               \
-            rb[jj] = *reinterpret_cast<const f32x4*>(X + (size_t)((n * g.Hi + ihs) * g.Wi + iws) * g.Ci + \
-                                                     b_ci);                                               \
-            okB = ok ? (okB | (1u << jj)) : (okB & ~(1u << jj));                                          \
-        }                                                                                                 \
-    } while (0)
-
-    if (KT > 0) {
-        if (0 < NL) WGRAD_ISSUE(0);
-        if (1 < NL) WGRAD_ISSUE(1);
-        if (2 < NL) WGRAD_ISSUE(2);
-        if (3 < NL) WGRAD_ISSUE(3);
-        if (4 < NL) WGRAD_ISSUE(4);
-        if (5 < NL) WGRAD_ISSUE(5);
-        if (6 < NL) WGRAD_ISSUE(6);
-        if (7 < NL) WGRAD_ISSUE(7);
-    }
-    const float* ap = As + h * LDA + wm * (TM * 32) + l31;
-    const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
-    float bsum = 0.f;
-    for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<f32x4*>(As + (plA + j * (256 / QA)) * LDA + qa * 4) = ((okA >> j) & 1u) ? ra[j] : zero4;
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<f32x4*>(Bs + (plB + j * (256 / QB)) * LDB + qb * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
-        __syncthreads();
-        if (bias_blk && tid < BM) {  // column sums of the (masked) dy tile: conflict-free, consecutive lanes = consecutive co
-            float s_ = 0.f;
-#pragma unroll
-            for (int k = 0; k < BK; ++k) s_ += As[k * LDA + tid];
-            bsum += s_;
-        }
-        f_pt0 = p_begin + (kt + 1 < KT ? kt + 1 : kt) * BK;
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            if ((kp & 1) == 0 && (kp >> 1) < NL) {
-                asm volatile("" : "+s"(f_pt0));
-                switch (kp >> 1) {
-                    case 0: WGRAD_ISSUE(0); break;
-                    case 1: WGRAD_ISSUE(1); break;
-                    case 2: WGRAD_ISSUE(2); break;
-                    case 3: WGRAD_ISSUE(3); break;
-                    case 4: WGRAD_ISSUE(4); break;
-                    case 5: WGRAD_ISSUE(5); break;
-                    case 6: WGRAD_ISSUE(6); break;
-                    default: WGRAD_ISSUE(7); break;
-                }
-            }
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef WGRAD_ISSUE
-    if (bias_blk && tid < BM && co0 + tid < g.Co)
-        g.bpart[((size_t)cls * g.splits + split) * g.Co + co0 + tid] = bsum;
-    float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co >= g.Co) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
-                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// wgrad with INCREMENTAL addressing (zero-padding gather, all tensors < 2^31 elements): wgrad_pipe_kernel spends
-// 190-260 VALU instructions per K-tile per wave on pixel decode (its forward sibling: ~20), because each of its NA+NB
-// loads belongs to a different pixel.  Here a thread owns ONE pixel row of the K-tile (row = tid / 8) and loads that
-// pixel's column quads cq0 + 8*jj of both operands, so
-//   * the pixel -> (n, oi, oj) decode happens once per thread at kernel start; a K-tile step (+32 pixels) is a carry
-//     update of (oi, oj) plus `base += D0 + carry ? D1 : 0 + carry2 ? D2 : 0` on two linear element offsets
-//     (x: ((n*Hi + oi*s)*Wi + oj*s)*Ci,  dy: pixel*Co or its strided phase view);
-//   * a load is `base + constant column offset` and two range compares of the tap-shifted coordinates.
-// LDS image, MFMA loop, split-K layout and epilogue are those of wgrad_pipe_kernel.
-// ------------------------------------------------------------------------------------------------
-// REFL (ReflectionPad2d folded into the gather, cyclegan/models.py:27-35): the mirrored coordinate is not linear in
-// (oi, oj), so only the image base n*Hi*Wi*Ci is carried and the in-image offset is rebuilt per load (~12 VALU).
-template <int BM, int BN, bool DYS, bool REFL = false>
-__global__ __launch_bounds__(256, (BM * BN >= 16384 ? 3 : 1)) void wgrad_inc_kernel(
-    const WgradGeom g, const float* __restrict__ X, const float* __restrict__ DY, float* __restrict__ part) {
-    constexpr int BK = 32;
-    constexpr int LDA = BM + 4, LDB = BN + 4;
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
-    constexpr int NA = BM / 32, NB = BN / 32, NL = NA + NB;
-    static_assert(NL <= BK / 2, "tile shape");
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
-    float* As = smem;
-    float* Bs = smem + BK * LDA;
-
-    const int tid = threadIdx.x;
-    const int T = g.R * g.S;
-    const int Ncol = T * g.Ci;
-    const int HoWo = g.Ho * g.Wo;
-    const int Mpix = g.N * HoWo;
-    int split, tile;  // XCD-aware block order, see wgrad_pipe_kernel
-    {
-        // workgroup b runs on XCD b % 8: XCD x takes the x-th CONTIGUOUS eighth of the split-major (split, tile) list, so
-        // the tiles of one split - which all re-read that split's dy / x pixel range - run on one XCD (two at a seam)
-        const int tiles = g.tiles_m * g.tiles_n;
-        const int total = tiles * g.splits, per = (total + 7) >> 3;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int lin = xcd * per + k;
-        if (k >= per || lin >= total) return;
-        split = lin / tiles;
-        tile = lin - split * tiles;
-    }
-    const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
-    const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
-    int p_end = p_begin + g.pix_per_split;
-    if (p_end > Mpix) p_end = Mpix;
-    const int KT = p_end > p_begin ? (p_end - p_begin + BK - 1) / BK : 0;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int cls = DYS ? (int)blockIdx.y : 0;
-    const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
-    const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- load mapping: pixel row of the K-tile and first column quad of this thread
-    const int row = tid >> 3, cq0 = tid & 7;
-    const int a_c0 = co0 + cq0 * 4;  // dy columns a_c0 + 32*jj
-    unsigned a_colok = 0, b_colok = 0;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) a_colok |= (a_c0 + 32 * j < g.Co) ? (1u << j) : 0u;
-    int b_tap[NB], b_off[NB];  // (dh << 16 | dw & 0xffff), linear element offset of the column's tap + channel
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int col = nc0 + (cq0 + 8 * j) * 4;
-        b_tap[j] = 0;
-        b_off[j] = 0;
-        if (col < Ncol) {
-            const int t = col / g.Ci, ci = col - t * g.Ci;
-            const int r = t / g.S, s_ = t - r * g.S;
-            const int dh = r - pad_t, dw = s_ - pad_l;
-            b_tap[j] = (dh << 16) | (dw & 0xffff);
-            b_off[j] = REFL ? ci : (dh * g.Wi + dw) * g.Ci + ci;
-            b_colok |= 1u << j;
-        }
-    }
-    // ---- pixel state of the FETCH position (starts at the first K-tile)
-    int f_p = p_begin + row;
-    int f_oi, f_oj, f_bx, f_ba;
-    {
-        const int pc = f_p < Mpix ? f_p : (Mpix > 0 ? Mpix - 1 : 0);
-        const int n = fastdiv(pc, g.mg_hw, g.sh_hw);
-        const int rem = pc - n * HoWo;
-        f_oi = fastdiv(rem, g.mg_w, g.sh_w);
-        f_oj = rem - f_oi * g.Wo;
-        f_bx = REFL ? n * g.Hi * g.Wi * g.Ci : ((n * g.Hi + f_oi * g.stride) * g.Wi + f_oj * g.stride) * g.Ci;
-        f_ba = DYS ? ((n * g.dy_H + dy_oh0 + 2 * f_oi) * g.dy_W + dy_ow0 + 2 * f_oj) * g.Co : pc * g.Co;
-    }
-    // +32 pixels = (d_n images, d_oi rows, d_oj columns) + carries   (block-uniform scalars)
-    const int d_n = BK / HoWo, r32 = BK - d_n * HoWo;
-    const int d_oi = r32 / g.Wo, d_oj = r32 - d_oi * g.Wo;
-    const int DX0 = REFL ? d_n * g.Hi * g.Wi * g.Ci
-                         : (d_n * g.Hi * g.Wi + d_oi * g.stride * g.Wi + d_oj * g.stride) * g.Ci;
-    const int DX1 = REFL ? 0 : (g.stride * g.Wi - g.Wo * g.stride) * g.Ci;                  // oj wrapped: oi + 1, oj - Wo
-    const int DX2 = REFL ? g.Hi * g.Wi * g.Ci : (g.Hi * g.Wi - g.Ho * g.stride * g.Wi) * g.Ci;  // oi wrapped: n + 1
-    const int DA0 = DYS ? (d_n * g.dy_H * g.dy_W + d_oi * 2 * g.dy_W + d_oj * 2) * g.Co : BK * g.Co;
-    const int DA1 = DYS ? (2 * g.dy_W - 2 * g.Wo) * g.Co : 0;
-    const int DA2 = DYS ? (g.dy_H * g.dy_W - 2 * g.Ho * g.dy_W) * g.Co : 0;
-
-    f32x4 ra[NA], rb[NB];
-    unsigned okA = 0, okB = 0;
-
-#define WGI_ISSUE(idx)                                                                                     \
-    do {                                                                                                   \
-        const bool pix_ok = f_p < p_end;                                                                   \
-        if ((idx) < NA) {                                                                                  \
-            constexpr int jj = (idx) < NA ? (idx) : 0;                                                     \
-            const bool ok = pix_ok && ((a_colok >> jj) & 1u);                                              \
-            const int off = ok ? f_ba + a_c0 + 32 * jj : 0;                                                \
-            ra[jj] = *reinterpret_cast<const f32x4*>(DY + (size_t)(unsigned)off);                          \
-            okA = ok ? (okA | (1u << jj)) : (okA & ~(1u << jj));                                           \
-        } else {                                                                                           \
-            constexpr int jj = ((idx) >= NA && (idx) - NA < NB) ? (idx) - NA : 0;                          \
-            int ih = f_oi * g.stride + (b_tap[jj] >> 16);                                                  \
-            int iw = f_oj * g.stride + (int)(short)(b_tap[jj] & 0xffff);                                   \
-            bool ok = pix_ok && ((b_colok >> jj) & 1u);                                                    \
-            int off;                                                                                       \
-            if (REFL) {                                                                                    \
-                ih = ih < 0 ? -ih : ih;                                                                    \
-                ih = ih >= g.Hi ? 2 * g.Hi - 2 - ih : ih;                                                  \
-                iw = iw < 0 ? -iw : iw;                                                                    \
-                iw = iw >= g.Wi ? 2 * g.Wi - 2 - iw : iw;                                                  \
-                off = ok ? f_bx + (ih * g.Wi + iw) * g.Ci + b_off[jj] : 0;                                 \
-            } else {                                                                                       \
-                ok = ok && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi;                 \
-                off = ok ? f_bx + b_off[jj] : 0;                                                           \
-            }                                                                                              \
-            rb[jj] = *reinterpret_cast<const f32x4*>(X + (size_t)(unsigned)off);                           \
-            okB = ok ? (okB | (1u << jj)) : (okB & ~(1u << jj));                                           \
-        }                                                                                                  \
-    } while (0)
-
-    if (KT > 0) {
-        if (0 < NL) WGI_ISSUE(0);
-        if (1 < NL) WGI_ISSUE(1);
-        if (2 < NL) WGI_ISSUE(2);
-        if (3 < NL) WGI_ISSUE(3);
-        if (4 < NL) WGI_ISSUE(4);
-        if (5 < NL) WGI_ISSUE(5);
-        if (6 < NL) WGI_ISSUE(6);
-        if (7 < NL) WGI_ISSUE(7);
-    }
-    const float* ap = As + h * LDA + wm * (TM * 32) + l31;
-    const float* bp = Bs + h * LDB + wn * (TN * 32) + l31;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const bool bias_blk = g.bpart != nullptr && nc0 == 0;  // block-uniform
-    float bsum = 0.f;
-    for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<f32x4*>(As + row * LDA + (cq0 + 8 * j) * 4) = ((okA >> j) & 1u) ? ra[j] : zero4;
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            *reinterpret_cast<f32x4*>(Bs + row * LDB + (cq0 + 8 * j) * 4) = ((okB >> j) & 1u) ? rb[j] : zero4;
-        __syncthreads();
-        if (bias_blk && tid < BM) {
-            float s_ = 0.f;
-#pragma unroll
-            for (int k = 0; k < BK; ++k) s_ += As[k * LDA + tid];
-            bsum += s_;
-        }
-        if (kt + 1 < KT) {  // move the fetch position one K-tile on (the last iteration refetches its own tile)
-            f_p += BK;
-            f_oj += d_oj;
-            const bool c1 = f_oj >= g.Wo;
-            f_oj -= c1 ? g.Wo : 0;
-            f_oi += d_oi + (c1 ? 1 : 0);
-            const bool c2 = f_oi >= g.Ho;
-            f_oi -= c2 ? g.Ho : 0;
-            f_bx += DX0 + (c1 ? DX1 : 0) + (c2 ? DX2 : 0);
-            f_ba += DA0 + (c1 ? DA1 : 0) + (c2 ? DA2 : 0);
-        }
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            if ((kp & 1) == 0 && (kp >> 1) < NL) {
-                asm volatile("" : "+v"(f_bx));  // keep this slot's address arithmetic in its slot
-                switch (kp >> 1) {
-                    case 0: WGI_ISSUE(0); break;
-                    case 1: WGI_ISSUE(1); break;
-                    case 2: WGI_ISSUE(2); break;
-                    case 3: WGI_ISSUE(3); break;
-                    case 4: WGI_ISSUE(4); break;
-                    case 5: WGI_ISSUE(5); break;
-                    case 6: WGI_ISSUE(6); break;
-                    default: WGI_ISSUE(7); break;
-                }
-            }
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ap[kp * 2 * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bp[kp * 2 * LDB + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef WGI_ISSUE
-    if (bias_blk && tid < BM && co0 + tid < g.Co)
-        g.bpart[((size_t)cls * g.splits + split) * g.Co + co0 + tid] = bsum;
-    float* out = part + ((size_t)cls * g.splits + split) * g.Co * Ncol;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int co = co0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (co >= g.Co) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = nc0 + wn * (TN * 32) + j * 32 + l31;
-                if (col < Ncol) out[(size_t)co * Ncol + col] = acc[i][j][r];
-            }
-        }
-}
-
-// part[s][co][t*Ci+ci]  ->  dw[co][ci][t]  (OIHW), summed over s in a fixed order (deterministic).
-// Threads walk the SOURCE order so that the splits*total partial reads (the heavy side) are coalesced; only the
-// `total` result writes are scattered by the OHWI->OIHW permutation.  GROUPS split-lanes per output share the
-// split loop (LDS combine in fixed order) when there are many splits and few outputs.
-// bias slabs [nslab][Co] -> db[co]; run by the trailing blocks of the reduce launches.  ONE WAVE per channel: lanes
-// stride over the slabs (the streaming backward kernels leave one slab per block: thousands), butterfly-add in double -
-// a fixed order, and the same shape as the stand-alone column-sum finalize it replaces (a serial loop over 4096 slabs
-// made these blocks the 100 us tail of the reduction launch).
-// s + p[k * stride] for k = k0, k0 + step, ... < n, in that order, with up to EIGHT loads in flight per round: inside a round the slab
-// index is clamped instead of branched on, so its loads issue back to back, and a slab past the end is read again but not added - the
-// sums are bit-identical to one load at a time.  The round width follows the slabs that are left (8 / 4 / 2 / 1), so a 1- or 2-split
-// reduction of a large weight issues no redundant loads.  (The first form of this batching ran only while eight whole strides were
-// left: with 4 split lanes and 16-28 splits - most layers - every load was its own dependent round trip; upconv 128->64 @64^2,
-// 48 splits x 4 classes: 131 us.)
-template <int U>
-__device__ __forceinline__ float slab_round(const float* __restrict__ p, size_t stride, int k, int step, int n, float s) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int kk = k + u * step;
-        v[u] = p[(size_t)(kk < n ? kk : n - 1) * stride];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (k + u * step < n) s += v[u];
-    return s;
-}
-__device__ __forceinline__ float slab_sum(const float* __restrict__ p, size_t stride, int k0, int step, int n, float s) {
-    int k = k0;
-    for (; k + 4 * step < n; k += 8 * step) s = slab_round<8>(p, stride, k, step, n, s);   // five or more slabs left
-    if (k + 2 * step < n) s = slab_round<4>(p, stride, k, step, n, s);
-    else if (k + step < n) s = slab_round<2>(p, stride, k, step, n, s);
-    else if (k < n) s = slab_round<1>(p, stride, k, step, n, s);
-    return s;
-}
-#define BIAS_CB 4  // channels (waves) per block
-__device__ __forceinline__ void bias_slab_reduce(const float* __restrict__ bpart, float* __restrict__ db, int nslab,
-                                                 int Co, int accum, int blk) {
-    const int co = blk * BIAS_CB + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (co >= Co) return;  // wave-uniform
-    double s = 0.0;
-    for (int k = lane; k < nslab; k += 8 * 64) {   // eight slabs per round of loads (clamped index, guarded add: same order, same sums)
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int kk = k + u * 64;
-            v[u] = bpart[(size_t)(kk < nslab ? kk : nslab - 1) * Co + co];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k + u * 64 < nslab) s += (double)v[u];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) db[co] = accum ? db[co] + (float)s : (float)s;
-}
-struct BiasRed {
-    const float* bpart;  // NULL: no bias work
-    float* db;
-    int nslab, accum, main_blocks;
-    int nbias;           // leading blocks of the launch that reduce the bias slabs (they start first, never the tail)
-};
-template <int GROUPS>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int splits, int Co, int T, int Ci, int accum,
-                                                           const BiasRed br) {
-    constexpr int OUTS = 256 / GROUPS;
-    __shared__ float red[256];
-    if ((int)blockIdx.x < br.nbias) {  // block-uniform
-        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
-        return;
-    }
-    const size_t total = (size_t)Co * T * Ci;
-    const int lo = threadIdx.x % OUTS, grp = threadIdx.x / OUTS;
-    const size_t src = (size_t)(blockIdx.x - br.nbias) * OUTS + lo;
-    float s = 0.f;
-    if (src < total) s = slab_sum(part + src, total, grp, GROUPS, splits, 0.f);
-    if (GROUPS > 1) {
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int q = 1; q < GROUPS; ++q) s += red[q * OUTS + lo];
-        }
-    }
-    if (grp == 0 && src < total) {
-        int ci = (int)(src % Ci);
-        size_t r = src / Ci;
-        int t = (int)(r % T);
-        int co = (int)(r / T);
-        float* o = dw + ((size_t)co * Ci + ci) * T + t;
-        *o = accum ? *o + s : s;
-    }
-}
-// Transposing form of the reduction for LARGE weights with few splits (pix2pix/models.py:23,39: 512x512x4x4 = 4.2 M and
-// 1024x512x4x4 = 8.4 M elements at 1..64 pixels -> 1 split): wgrad_reduce_kernel<1> reads the [Co][T][Ci] slabs coalesced
-// but scatters every result 4 B at a stride of T floats into the OIHW gradient (44 / 73 us for 16 / 32 MB,
-// profiles/r03_pix2pix_kernel_stats.txt).  Here a workgroup owns (co, 64 input channels): it sums the slabs in the same
-// split order (bit-identical results), transposes the 64 x T tile through LDS and writes ONE contiguous run of 64*T floats.
-// Measured (profiles/r03_abi_check.txt): wgrad + reduce of a 4 M / 8 M-element weight 37-40 -> 25-26 us.
-#define RTR_CI 64
-__global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                              int splits, int Co, int T, int Ci, int accum, int ci_tiles,
-                                                              const BiasRed br) {
-    extern __shared__ float rtr_tile[];   // [RTR_CI][T + 1]
-    if ((int)blockIdx.x < br.nbias) {  // block-uniform
-        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
-        return;
-    }
-    const int b = blockIdx.x - br.nbias;
-    const int co = b / ci_tiles, ci0 = (b - co * ci_tiles) * RTR_CI;
-    const int ncl = Ci - ci0 < RTR_CI ? Ci - ci0 : RTR_CI;
-    const size_t total = (size_t)Co * T * Ci;
-    const float* src = part + (size_t)co * T * Ci + ci0;
-    for (int e = threadIdx.x; e < T * RTR_CI; e += 256) {
-        const int tt = e / RTR_CI, cl = e - tt * RTR_CI;
-        float s = 0.f;
-        if (cl < ncl) s = slab_sum(src + (size_t)tt * Ci + cl, total, 0, 1, splits, 0.f);
-        rtr_tile[cl * (T + 1) + tt] = s;
-    }
-    __syncthreads();
-    float* o = dw + ((size_t)co * Ci + ci0) * T;
-    for (int e = threadIdx.x; e < ncl * T; e += 256) {
-        const int cl = e / T, tt = e - cl * T;
-        const float s = rtr_tile[cl * (T + 1) + tt];
-        o[e] = accum ? o[e] + s : s;
-    }
-}
-
-static int launch_wgrad_reduce(const float* ws, float* dw, int splits, int Co, int T, int Ci, int accum,
-                               hipStream_t st, BiasRed br = BiasRed{}) {
-    long total = (long)Co * T * Ci;
-    const int extra = br.bpart ? cdiv(Co, BIAS_CB) : 0;
-    br.nbias = extra;
-    if (total >= (1 << 20) && splits < 16 && T > 1 && T <= 96) {
-        const int ci_tiles = cdiv(Ci, RTR_CI);
-        br.main_blocks = Co * ci_tiles;
-        MIGAN_LAUNCH(wgrad_reduce_tr_kernel, dim3(br.main_blocks + extra), dim3(256), (size_t)RTR_CI * (T + 1) * 4, st,
-                           ws, dw, splits, Co, T, Ci, accum, ci_tiles, br);
-        HIP_LAUNCH_CHECK();
-        return 0;
-    }
-    if (splits >= 64 && total < (1 << 16)) {
-        br.main_blocks = cdiv(total, 16);
-        MIGAN_LAUNCH((wgrad_reduce_kernel<16>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
-                           T, Ci, accum, br);
-    } else if (splits >= 16 && total < (1 << 20)) {
-        br.main_blocks = cdiv(total, 64);
-        MIGAN_LAUNCH((wgrad_reduce_kernel<4>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
-                           T, Ci, accum, br);
-    } else {
-        br.main_blocks = cdiv(total, 256);
-        MIGAN_LAUNCH((wgrad_reduce_kernel<1>), dim3(br.main_blocks + extra), dim3(256), 0, st, ws, dw, splits, Co,
-                           T, Ci, accum, br);
-    }
-    HIP_LAUNCH_CHECK();
-    return 0;
-}
-
-// tile shape: 128x128 when both GEMM dims exceed 64; 64x128 for 32 < Co <= 64 with a wide column side (2 MFMAs per 3
-// LDS fragment reads instead of 1 per 2); else 64x64.  BNsel is returned through BMsel's companion wgrad_bn().
-static int wgrad_bn(int Co, int Ncol) {
-    if (Co > 64 && Ncol > 64) return 128;
-    return (Co > 32 && Ncol >= 128) ? 128 : 64;
-}
-// Resident workgroups per CU of the pipelined wgrad kernels (register bound; tools/kernel_resources.py prints them).
-// LDS-DMA kernels (conv_dma.hip): 4 (128x128, BK = 16) / 3 / 5 (BK = 32), LDS bound.
-static int wgrad_occ(int bm, int bn) { return bm * bn >= 16384 ? 4 : (bm * bn >= 8192 ? 3 : 5); }
-
-// Split-K factor.  The launch is tiles * splits equal workgroups on 256 CUs x occ resident slots.  Measured on MI355X
-// (profiles/r02_wgrad_split_sweep.txt): what decides the time is how EVENLY the workgroups fall on the CUs - R256 wgrad
-// (cyclegan/models.py:28; 36 tiles, 3 slots per CU): 21 splits = 756 workgroups = one full wave 374 us, 24 splits = 864
-// (a wave + 1/8) 444 us, 32 splits (the round-1 rule "about 1024 workgroups") 410-455 us, 64 splits = 3 full waves 379 us;
-// Conv2d(64,128,3,2,1) with 10 tiles: 240 workgroups (one per CU) 296 us, 320 (a quarter of the CUs get two) 351 us.
-// So: time model with CU-granular balance, minimised over the split count.
-//   a CU that runs j workgroups side by side advances all of them one K-tile in j * t1 / eff(j)  (eff = share of the
-//   MFMA rate j resident workgroups sustain: 1 -> .45, 2 -> .65, 3 -> .75, >= 4 -> .80);
-//   full waves: floor(W) * (KT + c0) * occ * t1 / eff(occ);  the rest r workgroups: j = ceil(r / 256) on the busiest CU;
-//   + the partial-sum slabs the reduction re-reads: s * outputs * 8 B at 3 TB/s.
-static double wgrad_model(long tiles, long s_, long Mpix, int bm, int bn, int occ, double out_bytes) {
-    static const double eff[5] = {0.45, 0.45, 0.65, 0.75, 0.80};
-    const double t1 = (double)bm * bn * 64.0 / (157.3e12 / 256.0);  // one workgroup K-tile at the MFMA peak of one CU
-    const double c0 = 4.0;                                          // prologue + epilogue in K-tile units
-    const long pp = cdiv(cdiv(Mpix, s_), 32) * 32;
-    const double kt = (double)pp / 32.0 + c0;
-    const long blocks = tiles * s_, slots = 256L * occ;
-    const long full = blocks / slots, rem = blocks - full * slots;
-    const int jo = occ > 4 ? 4 : occ;
-    double t = (double)full * kt * t1 * occ / eff[jo];
-    if (rem > 0) {
-        const long j = cdiv(rem, 256);
-        t += kt * t1 * (double)j / eff[j > 4 ? 4 : j];
-    }
-    return t + (double)s_ * out_bytes / 3.0e12 + (s_ > 1 ? 4e-6 : 0.0);
-}
-// Upsample + Conv3x3 weight gradient with <= 64 output channels (dcgan.py:59, cyclegan/models.py:75 - the dominant launch of the DCGAN step):
-// 64 x 256 tiles.  A 64 x 128 tile fetches the strided dy rows once per N-tile - four times for the 512 collapsed columns of a
-// 128-channel source - and gives a wave 32 MFMAs between two barriers; with 256 columns a wave runs 64 (one A fragment feeds four
-// accumulator tiles) and dy is fetched twice.  Measured 299 -> 290 us on both layers (profiles/r05_ab.txt call 12).
-static int upw_bn(int N, int H, int W, int Co, int Ci) {   // 256 or 0 (the general rule); the workspace query and the launch both ask here
-    constexpr int env = 256;
-    const bool fits = (size_t)N * H * W * Ci < (1ull << 31) && (size_t)N * 4 * H * W * Co < (1ull << 31) && W % 8 == 0;
-    return (env == 256 && fits && Co <= 64 && Co > 32 && (4 * Ci) % 256 == 0) ? 256 : 0;
-}
-static void wgrad_plan(int N, int Ho, int Wo, int Co, int Ncol, int& BMsel, int& splits, int& pps, int ncls = 1, int bn_force = 0) {
-    // the split count comes from the balance model above (round 1's rule - about 1024 workgroups - is gone)
-    static const int splits_env = getenv("MIGAN_WGRAD_SPLITS") ? atoi(getenv("MIGAN_WGRAD_SPLITS")) : 0;  // sweep knob
-    long Mpix = (long)N * Ho * Wo;
-    // 128x128 only for wide-and-long GEMMs: with Co <= 128 or few pixels the 64x128 tile gives twice the tiles, so half
-    // the split-K factor fills the chip (measured: G.conv1 up-conv wgrad 209 -> 186 us, PatchGAN 4x4 s2 wgrads -10 %,
-    // while Conv2d(64,256) on 590k pixels prefers 128x128)
-    BMsel = (Co > 128 && Ncol > 64 && Mpix * ncls > 16384) ? 128 : 64;
-    const int bn = bn_force ? bn_force : wgrad_bn(Co, Ncol);
-    long tiles = (long)cdiv(Co, BMsel) * cdiv(Ncol, bn) * ncls;
-    long maxs = cdiv(Mpix, 256);  // at least 256 pixels per split
-    if (maxs > 512) maxs = 512;
-    if (maxs < 1) maxs = 1;
-    if (splits_env > 0) {
-        long want = splits_env > maxs ? maxs : splits_env;
-        pps = (int)(cdiv(cdiv(Mpix, want), 32) * 32);
-        splits = cdiv(Mpix, pps);
-        return;
-    }
-    const int occ = bn == 256 ? 2 : wgrad_occ(BMsel, bn);
-    const double out_bytes = (double)Co * Ncol * ncls * 8.0;
-    double best = 1e30;
-    long best_s = 1;
-    for (long s_ = 1; s_ <= maxs; ++s_) {
-        const long pp = cdiv(cdiv(Mpix, s_), 32) * 32;
-        if (cdiv(Mpix, pp) != s_) continue;  // the split count this request really produces
-        const double t = wgrad_model(tiles, s_, Mpix, BMsel, bn, occ, out_bytes);
-        if (t < best) { best = t; best_s = s_; }
-    }
-    pps = (int)(cdiv(cdiv(Mpix, best_s), 32) * 32);
-    splits = cdiv(Mpix, pps);
-}
+#include "conv_wgrad_mfma.inc"   // MFMA weight-gradient kernels, their fixed-order reductions and the split planner
 
 // ------------------------------------------------------------------------------------------------
 // Phase-collapsed  nn.Upsample(scale_factor=2) -> nn.Conv2d(C, K, 3, stride=1, padding=1)
