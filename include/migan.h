@@ -26,7 +26,8 @@ extern "C" {
 
 const char* migan_version(void);
 const char* migan_error_string(int code);
-/* Debug launch counters: launches issued by this library since the last reset, summed over the launch sites whose kernel
+/* Debug launch counters (test tooling, no reference counterpart): launches issued by this library since the last reset, summed
+ * over the launch sites whose kernel
  * expression contains `substr` (NULL or "" = all).  The parity tests assert with it WHICH kernel family served a geometry
  * (torch's counterpart is the profiler's kernel list; the reference itself never looks).  Host-side bookkeeping only. */
 long migan_debug_launch_count(const char* substr);
@@ -79,7 +80,8 @@ int migan_skinny_nn_ok(int M, int R, int Nc);
 int migan_skinny_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int act, float slope,
                     void* stream);
 int migan_skinny_nn(const float* a, const float* w, float* c, int M, int R, int Nc, void* stream);
-/* nn.Linear weight + bias gradient at <= 64 rows: dw[N][K] (+)= dy[M][N]^T x[M][K], db[N] (+)= column sums of dy (db may
+/* nn.Linear weight + bias gradient at <= 64 rows (the Linear layers of wgan_gp.py:46-78 under d_loss.backward() /
+ * g_loss.backward(), wgan_gp.py:173,192): dw[N][K] (+)= dy[M][N]^T x[M][K], db[N] (+)= column sums of dy (db may
  * be NULL) in ONE launch straight into the caller's buffers (no split-K slabs, no reduction, no column-sum launches).
  * N % 16 == 0, K % 64 == 0. */
 int migan_skinny_tn_ok(int M, int N, int K);
@@ -96,7 +98,8 @@ int migan_skinny_tn(const float* dy, const float* x, float* dw, float* db, int M
  * migan_col2im_small: the adjoint, out[N][H][W][J] = act(bias + sum of ycol[(n,ho,wo)][(j,r,s)] over the taps that land on
  * (h, w)) in a fixed order; bias may be NULL. */
 int migan_fewpix_ok(int rows, int n, int k);
-/* The NT product of that path with K also split over workgroups (a 16.8-33.5 MB weight against <= 64 rows wants 256+ workgroups,
+/* The NT product of that path (pix2pix/models.py:62-71 at batch 1) with K also split over workgroups (a 16.8-33.5 MB weight against
+ * <= 64 rows wants 256+ workgroups,
  * not N/16): out[M][N] = act(a[M][K] w[N][K]^T + bias), partial tiles in ws (migan_fewpix_nt_workspace bytes; 0 = no split, the
  * call is migan_skinny_nt), added in a fixed order by a second launch.  Conv2d forward / ConvTranspose2d input gradient. */
 size_t migan_fewpix_nt_workspace(int M, int N, int K);
@@ -161,7 +164,7 @@ int migan_conv2d_dgrad(const float* dy, const float* w_ihwo, const float* bias, 
  * (tickets return to zero after every launch), not shared by launches that may overlap (one per stream); NULL = no split.
  * mask_nc: optional [N][Co] multiplier (the fused nn.Dropout2d of migan_conv2d_dropout_fwd) or NULL. */
 size_t migan_conv_splitk_workspace(void);
-int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls);  /* 1: a workspace would be used */
+int migan_conv_splitk_applies(long long maxM, int Co, int Ci_src, int ncls);  /* 1: a workspace would be used (same layers) */
 int migan_conv2d_fwd_ws(const float* x, const float* w_ohwi, const float* bias, const float* mask_nc, float* y, int N,
                         int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l,
                         int gather, int act, float slope, float* ws, size_t ws_bytes, void* stream);
@@ -177,13 +180,16 @@ int migan_conv2d_dgrad_relu_ws(const float* dy, const float* w_ihwo, float* dx, 
                                int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, float* ws,
                                size_t ws_bytes, void* stream);
 
-/* Which tile configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
+/* Introspection, no reference counterpart (the reference cannot say which ATen kernel served a layer): which tile
+ * configuration migan_conv2d_fwd/dgrad will launch for a GEMM of maxM rows (largest parity class),
  * Co columns and a source with Ci_src channels: fast*1000000 + BM*1000 + BN ("fast" = vectorised NHWC loader,
  * Ci_src % 4 == 0 and >= 8); 4000 = the thin-N VALU kernel (Co <= 4).  Pure function; used by bench.py to attribute
  * launches to kernel symbols. */
 int migan_igemm_tile_code(long long maxM, int Co, int Ci_src, int ncls);
 
-/* Conv2d / Linear weight gradient (aten::convolution_backward grad_weight; aten::mm in AddmmBackward).
+/* Conv2d / Linear weight gradient (aten::convolution_backward grad_weight; aten::mm in AddmmBackward): what every
+ * loss.backward() of the path runs per conv / linear layer - dcgan.py:168,182, wgan_gp.py:173,192, cyclegan.py:204,221,238,
+ * pix2pix.py:150,171, srgan.py:128,144.
  * Split-K over pixels + fixed-order reduction (deterministic).  dw_oihw has the torch parameter layout
  * [Co][Ci][R][S].  ws must hold migan_conv2d_wgrad_workspace() bytes.  accumulate != 0: dw += gradient (the
  * final reduction adds into the caller's buffer - what autograd's AccumulateGrad does with a separate
@@ -210,7 +216,8 @@ int migan_conv2d_wgrad_fuses_bias(int Co, int R, int S, int Ci, int stride, int 
  * caller runs migan_conv2d_dgrad on the padded extent + migan_gather2d_bwd. */
 int migan_conv2d_dgrad_reflect1(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                 void* stream);
-/* Its second launch alone (dx must already hold the pad-1 input gradient of migan_conv2d_dgrad): a latency-bound launch of
+/* Its second launch alone (cyclegan/models.py:26-35 under cyclegan.py:204; dx must already hold the pad-1 input gradient of
+ * migan_conv2d_dgrad): a latency-bound launch of
  * mostly tiny workgroups that a caller may overlap with independent work on another stream. */
 int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                      void* stream);
@@ -219,7 +226,7 @@ int migan_conv2d_dgrad_reflect1_ring(const float* dy, const float* w_ihwo, float
  * chain of 56 dependent K-tiles - both are cut along K where migan_conv_splitk_applies() says so. */
 int migan_conv2d_dgrad_reflect1_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                    float* ws, size_t ws_bytes, void* stream);
-/* ... and its ring launch alone with a workspace (the workspace of the stream it is launched on). */
+/* ... and its ring launch alone (cyclegan/models.py:26-35 backward) with a workspace (the workspace of the stream it is launched on). */
 int migan_conv2d_dgrad_reflect1_ring_ws(const float* dy, const float* w_ihwo, float* dx, int N, int H, int W, int Ci, int Co,
                                         float* ws, size_t ws_bytes, void* stream);
 
@@ -310,7 +317,8 @@ size_t migan_norm_workspace(int G, int P, int C);
 int migan_norm_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
                      long long* num_batches_tracked, float momentum, float eps, int G, int P, int C, float* ws,
                      size_t ws_bytes, void* stream);
-/* y = act((x-mean)*invstd*gamma+beta) [+ res]; gamma/beta/res may be NULL. */
+/* y = act((x-mean)*invstd*gamma+beta) [+ res]; gamma/beta/res may be NULL.  The normalise + activation (+ residual add) of
+ * dcgan.py:53-61, cyclegan/models.py:28-37, srgan/models.py:22-30 in one pass. */
 int migan_norm_apply(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* beta, const float* res, int G, int P, int C, int act, float slope,
                      void* stream);
@@ -328,7 +336,8 @@ int migan_norm_bwd_prelu(const float* x, const float* dy, const float* mean, con
                          const float* beta, const float* prelu_weight, float* dx, float* dgamma, float* dbeta, float* dprelu,
                          int G, int P, int C, float* ws, size_t ws_bytes, int accumulate, int dprelu_accumulate, float* csum,
                          int shuffle_H, int shuffle_W, void* stream);
-/* backward through the batch statistics and the fused activation; dgamma/dbeta [C] written when G==1.
+/* backward through the batch statistics and the fused activation (native_batch_norm_backward + the activation's backward behind
+ * dcgan.py:168,182, cyclegan.py:204, srgan.py:128,144); dgamma/dbeta [C] written when G==1.
  * csum (optional): migan_norm_colsum_slabs(G,P,C) x [C] per-block column sums of dx - the bias gradient of the conv in
  * front of the norm layer is reduced from them inside that conv's wgrad launch (migan_conv2d_wgrad db_slabs). */
 int migan_norm_colsum_slabs(int G, int P, int C);
@@ -352,7 +361,8 @@ int migan_norm_moments(const float* x, float* mean, float* var, int G, int P, in
 int migan_norm_sync_finalize(const float* gathered, int world, long long P_local, float* mean, float* invstd,
                              float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                              float eps, int C, void* stream);
-/* eval-mode BatchNorm: invstd[c] = 1/sqrt(running_var[c] + eps). */
+/* eval-mode BatchNorm (sampling with the generators in eval(), cyclegan.py:138-139; esrgan test_on_image.py:24-37):
+ * invstd[c] = 1/sqrt(running_var[c] + eps). */
 int migan_rsqrt_eps(const float* var, float* invstd, int C, float eps, void* stream);
 /* Backward of `activation [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y)
  * (mask_gc may be NULL, act may be 0, y = the layer output) AND migan_norm_colsum_slabs(G,P,C) x [C] column-sum slabs
@@ -411,7 +421,8 @@ int migan_pixel_shuffle(const float* src, float* dst, int N, int H, int W, int C
 /* MaxPool2d(2,2) inside vgg19.features[:18] (srgan/models.py:11-12). */
 int migan_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int migan_maxpool2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
-/* ... with the backward of the ReLU in front of the pool (vgg19.features[3:5], [8:10]) applied to dx: x is that ReLU's output. */
+/* ... with the backward of the ReLU in front of the pool (vgg19.features[3:5], [8:10] behind srgan/models.py:11-12, differentiated
+ * by srgan.py:128) applied to dx: x is that ReLU's output. */
 int migan_maxpool2_relu_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* torch.cat((a,b),1) pix2pix/models.py:50,132 (forward=1) and its backward split (forward=0). */
 int migan_cat_channels(float* a, float* b, float* y, size_t P, int Ca, int Cb, int forward, void* stream);
@@ -427,7 +438,8 @@ int migan_select_rows(const float* a, const float* b, float* dst, const int* sel
 int migan_transpose_batched(const float* src, float* dst, int B, int R, int Cc, void* stream);
 int migan_permute4d(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                     void* stream);
-/* Multi-tensor migan_permute4d: one launch for a table of permute copies (all weight packs of a training step).
+/* Multi-tensor migan_permute4d: one launch for a table of permute copies (all weight packs of a training step - the layout
+ * changes ATen makes per convolution call of dcgan.py:143-183 / cyclegan.py:159-239, here once per step).
  * entries: device array of { const float* src; float* dst; unsigned o1, o2, o3, pad; long long s[4]; long long n; } (72 bytes):
  * dst is contiguous with extents (n/(o1*o2*o3), o1, o2, o3) and dst[i0][i1][i2][i3] = src[i0*s[0] + i1*s[1] + i2*s[2] + i3*s[3]];
  * blocks: device array of { int entry; int chunk; }, ceil(n / 1024) consecutive chunks per entry. */
@@ -448,7 +460,8 @@ int migan_u8_to_f32(const unsigned char* src, float* dst, const int* crop_yx, co
                     const float* stdv, int N, int Hi, int Wi, int C, int h, int w, int nchw, void* stream);
 
 /* ---- Reductions, losses, gradient penalty, optimiser (csrc/reduce_loss_adam.hip) -----------------------
- * bias gradients: out[c] = sum_p x[p][c]. */
+ * bias gradients: out[c] = sum_p x[p][c] (aten::convolution_backward grad_bias / the sum of AddmmBackward under every
+ * loss.backward() of the path: dcgan.py:168,182, cyclegan.py:204,221,238, srgan.py:128,144). */
 size_t migan_colsum_workspace(size_t P, int C);
 int migan_colsum(const float* x, float* out, size_t P, int C, float* ws, size_t ws_bytes, int accumulate,
                  void* stream);

@@ -252,6 +252,64 @@ def _toeplitz_case_guarded(N, Ci, H, W, Co, k, gather):
     assert K._rel(dx.permute(0, 3, 1, 2), x.grad) < 3e-6, "toeplitz dgrad %g" % K._rel(dx.permute(0, 3, 1, 2), x.grad)
 
 
+def _rgb_case_guarded(N, H, W, Co, k, pad, gather, act):
+    """Image-input layers (3 source channels: srgan/models.py:85, vgg19.features[0], cyclegan/models.py:49-50) on csrc/rgb_conv.hip: forward
+    from staged image rows (the next tile's rows are fetched under the current tile's MFMAs - the fetch that could run past the image) and the
+    weight gradient with the activation backward and the bias column sums inside - x, w, bias, dy, y, the slab workspace against guard
+    pages, outputs NaN-filled, results against torch."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(13)
+    P = K._ptr
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = (torch.randn(Co, 3, k, k, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True)
+    f = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, 0.2), 2: torch.relu}[act]
+    y_ref = f(TF.conv2d(K._gather_ref(x, (pad,) * 4, gather), w, b, 1))
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    Ho, Wo = y_ref.shape[2:]
+    assert emu.migan_rgb_conv_ok(3, Co, k, k, 1, gather, N * Ho * Wo) == 1, (Co, k, gather)
+    xn = guarded(x.permute(0, 2, 3, 1).contiguous())
+    wk = guarded(w.detach().permute(2, 3, 1, 0).contiguous())
+    bg = guarded(b.detach().clone())
+    y = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
+    assert emu.migan_rgb_conv_fwd(P(xn), P(wk), P(bg), P(y), N, H, W, 3, Ho, Wo, Co, k, k, pad, pad, gather, act, 0.2, 0, None) == 0
+    assert K._rel(y.permute(0, 3, 1, 2), y_ref.detach()) < 3e-6, "rgb fwd %g" % K._rel(y.permute(0, 3, 1, 2), y_ref.detach())
+    if emu.migan_rgb_conv_wgrad_ok(3, Co, k, k, 1, gather, N * Ho * Wo) == 1:
+        nb = emu.migan_rgb_conv_wgrad_workspace(Co, k, k)
+        ws = guarded(torch.full((nb // 4,), float("nan")))
+        gyn = guarded(gy.permute(0, 2, 3, 1).contiguous())
+        dw = guarded(torch.full((Co, 3, k, k), float("nan")))
+        db = guarded(torch.full((Co,), float("nan")))
+        assert emu.migan_rgb_conv_wgrad(P(xn), P(gyn), P(y) if act else None, P(dw), P(db), P(ws), nb, N, H, W, Ho, Wo, Co, k, k, pad, pad,
+                                        gather, act, 0.2, 0, 0, None) == 0
+        assert K._rel(dw, w.grad) < 1e-5, "rgb wgrad %g" % K._rel(dw, w.grad)
+        assert K._rel(db, b.grad) < 2e-5, "rgb bias gradient %g" % K._rel(db, b.grad)
+        # accumulate form: dw += gradient, db += gradient
+        assert emu.migan_rgb_conv_wgrad(P(xn), P(gyn), P(y) if act else None, P(dw), P(db), P(ws), nb, N, H, W, Ho, Wo, Co, k, k, pad, pad,
+                                        gather, act, 0.2, 1, 1, None) == 0
+        assert K._rel(dw, 2 * w.grad) < 1e-5 and K._rel(db, 2 * b.grad) < 2e-5, "rgb wgrad (accumulate)"
+
+
+def _thin_out_dgrad_case_guarded(N, H, W, c):
+    """Input gradient of a thin-OUTPUT 3x3 layer (dcgan.py:62 Conv2d(64, channels, 3, 1, 1)) through migan_rgb_conv_fwd with reversed taps:
+    x = dy [N][H][W][c], w = the layer's OIHW weight [c][64][3][3] permuted (2,3,0,1)."""
+    import torch.nn.functional as TF
+    g = torch.Generator().manual_seed(17)
+    P = K._ptr
+    dy = torch.randn(N, c, H, W, generator=g)
+    w = torch.randn(c, 64, 3, 3, generator=g) * 0.2
+    if emu.migan_rgb_conv_ok(c, 64, 3, 3, 1, 0, N * H * W) != 1:
+        print("   (not taken: c = %d)" % c, flush=True)
+        return
+    dx_ref = TF.conv_transpose2d(dy, w, None, 1, 1)
+    dyn = guarded(dy.permute(0, 2, 3, 1).contiguous())
+    wk = guarded(w.permute(2, 3, 0, 1).contiguous())
+    dx = guarded(torch.full((N, H, W, 64), float("nan")))
+    assert emu.migan_rgb_conv_fwd(P(dyn), P(wk), None, P(dx), N, H, W, c, H, W, 64, 3, 3, 1, 1, 0, 0, 0.0, 1, None) == 0
+    assert K._rel(dx.permute(0, 3, 1, 2), dx_ref) < 3e-6, "thin-output dgrad %g" % K._rel(dx.permute(0, 3, 1, 2), dx_ref)
+
+
 def _eltwise_case_guarded(N, H, W, C):
     """The elementwise / index kernels of csrc/eltwise.hip on shapes whose element counts are NOT multiples of a vector width: activation
     forward / backward, axpby, MaxPool2d(2) forward / backward / backward-through-ReLU, gather (zero pad, reflection pad, upsample), channel
@@ -569,6 +627,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "eltwise":
     for c in [(1, 3, 5, 1), (2, 6, 10, 3), (1, 8, 8, 4), (3, 7, 9, 5), (2, 12, 4, 8), (1, 16, 18, 66), (1, 30, 30, 64)]:
         print("eltwise", c, flush=True)
         _eltwise_case_guarded(*c)
+        keep.clear()
+    print("ALL OK")
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "rgb":
+    # (the entries take >= 16384 output pixels; widths around the 128-pixel row tile: ragged, exact, a 5-pixel image of tails only)
+    for c in [(1, 110, 150, 64, 3, 1, 0, 1), (2, 64, 130, 32, 3, 1, 0, 0), (1, 128, 131, 64, 7, 3, 1, 2), (1, 3300, 5, 64, 3, 1, 0, 2),
+              (2, 64, 128, 64, 3, 1, 0, 2)]:
+        print("rgb", c, flush=True)
+        _rgb_case_guarded(*c)
+        keep.clear()
+    for c in [(2, 64, 130, 1), (1, 130, 127, 3), (1, 128, 128, 1)]:
+        print("thin-output dgrad", c, flush=True)
+        _thin_out_dgrad_case_guarded(*c)
         keep.clear()
     print("ALL OK")
     sys.exit(0)

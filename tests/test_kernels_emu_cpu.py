@@ -271,13 +271,14 @@ def test_fewpix_kernels_stay_inside_their_tensors(emu):
     assert r.returncode == 0 and r.stdout.strip().endswith("ALL OK"), (r.returncode, r.stdout[-400:], r.stderr[-800:])
 
 
-@pytest.mark.parametrize("family", ["upconv", "norm", "norm_prelu", "toeplitz", "eltwise", "loss", "adam", "skinny", "classify"])
+@pytest.mark.parametrize("family", ["upconv", "norm", "norm_prelu", "toeplitz", "rgb", "eltwise", "loss", "adam", "skinny", "classify"])
 def test_upconv_and_norm_kernels_stay_inside_their_tensors(emu, family):
     """The same for the phase-collapsed up-conv (pack, forward, input gradient, weight gradient + its four-class slab reduction over
     1 ... 20 splits) and for the norm / column-sum passes (chunked partial kernels + one-wave-per-channel finalize kernels over 1 ... > 256
     chunks): the reductions load several slabs / records per round through a CLAMPED index - an index one past the range would read the
     guard page here and nothing a GPU run notices; and for the width-Toeplitz path of the image-output 7x7 / 9x9 convs (pack, forward,
-    expansion, both gradients; odd widths, 2-4 output channels, zero and reflection padding) and the elementwise / index kernels of
+    expansion, both gradients; odd widths, 2-4 output channels, zero and reflection padding), the image-input convs of csrc/rgb_conv.hip
+    (forward with its row prefetch, the fused weight gradient, the thin-output layer's input gradient) and the elementwise / index kernels of
     csrc/eltwise.hip on element counts that are no multiple of a vector width; and the mean-reduced losses with their gradients, the
     per-row norm and the row scaling of the gradient penalty; and the one-launch Adam over parameters of 1 ... 12800 elements (16-byte
     accesses on whole chunks, scalar tails) against torch.optim.Adam; the <= 64-row GEMMs behind nn.Linear at small batch; BatchNorm2d [PixelShuffle] PReLU inside the norm launches; and softmax / cross entropy / embedding, a weight pack and a mask draw."""
