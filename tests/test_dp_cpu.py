@@ -1,4 +1,4 @@
-"""Data-parallel logic on the CPU (gloo, world_size 2): sharding + ONE summed all-reduce of the flat gradient
+"""Data-parallel logic on the CPU (gloo, world_size 2 and 4): sharding + ONE summed all-reduce of the flat gradient
 bucket per optimiser + 1/world scaling in the update reproduces the single-process full-batch step
 (SURVEY.md §8e).  The HIP optimiser's update kernel needs a GPU, so a CPU optimiser with the SAME bucket
 (`pytorch_gan_amd.optim.bucket_layout`: 256-byte aligned slots, padding included in the all-reduce), the same interface
@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -69,10 +70,10 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     D = M.MlpCritic((1, 8, 8))          # no BatchNorm: shards are exactly independent samples
     G = M.CycleDiscriminator((3, 32, 32))  # InstanceNorm: per-sample statistics, also exactly shardable
-    if rank == 1:  # replicas start from rank 0's weights
+    if rank >= 1:  # replicas start from rank 0's weights
         with torch.no_grad():
             for p in list(D.parameters()) + list(G.parameters()):
-                p.add_(1.0)
+                p.add_(float(rank))
     dp.broadcast_parameters(D, G)
     opt_D, opt_G = FlatAdam(D.parameters()), FlatAdam(G.parameters())
     g = torch.Generator().manual_seed(5)
@@ -113,13 +114,14 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_full_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_equals_full_batch(tmp_path, world):
     sys.path.insert(0, ROOT)
     from oracle import reference_models as M
 
     out = str(tmp_path / "dp_state.pt")
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = torch.load(out)
     # single-process reference on the full batch
     torch.manual_seed(0)
