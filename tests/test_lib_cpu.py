@@ -206,3 +206,24 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert same.get(r_want, r_want) == same.get(r_got, r_got), (name, "return", r_want, r_got)
         checked += 1
     assert checked == len(_lib.EXPORTS), (checked, len(_lib.EXPORTS))
+
+
+def test_integration_md_ctypes_stubs_match_the_signature_table():
+    """The reference-side binding stubs INTEGRATION.md shows (`lib.<entry>.argtypes = ...`, `.restype = ...`) are the signatures of
+    the product's own ctypes table - a stub that drifts from the ABI (a removed sync word, an added phase argument) fails here."""
+    import ctypes
+
+    from pytorch_gan_amd import _lib
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    ns = {"ctypes": ctypes, "P": ctypes.c_void_p, "I": ctypes.c_int, "F": ctypes.c_float}
+    found = 0
+    for name, expr in re.findall(r"^lib\.(migan_\w+)\.argtypes = ([^#\n]+)", text, flags=re.M):
+        want = _lib._SIGS[name][1]
+        got = eval(expr, ns)   # noqa: S307 - our own document
+        assert [t for t in got] == [t for t in want], (name, got, want)
+        found += 1
+    for name, expr in re.findall(r"^lib\.(migan_\w+)\.restype = ([^#\n]+)", text, flags=re.M):
+        assert eval(expr, ns) is _lib._SIGS[name][0], name   # noqa: S307
+        found += 1
+    assert found >= 4, found
