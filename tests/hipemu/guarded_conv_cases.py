@@ -44,6 +44,14 @@ def _conv_case_guarded(case):
     rc = emu.migan_conv2d_fwd_ws(P(xn), P(wo), P(bg), None, P(y), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, act, 0.2, P(sk), sk.numel() * 4, None)
     assert rc == 0
     assert not torch.isnan(y).any(), 'fwd NaN'
+    if Co % 4 == 0:
+        # the same launch with the [N][Co] multiplier of the fused nn.Dropout2d (dcgan.py:77-78; 16-byte loads of the mask in the channel-quad
+        # epilogue): the mask against a guard page, y2 == y * mask
+        mk = guarded((torch.rand(N, Co, generator=g) > 0.25).float() * (1 / 0.75))
+        y2 = guarded(torch.full((N, Ho, Wo, Co), float("nan")))
+        rc = emu.migan_conv2d_fwd_ws(P(xn), P(wo), P(bg), P(mk), P(y2), N, H, W, Ci, Ho, Wo, Co, k, k, stride, pads[0], pads[1], gather, act, 0.2, P(sk), sk.numel() * 4, None)
+        assert rc == 0
+        assert torch.allclose(y2, y * mk.view(N, 1, 1, Co), rtol=1e-6, atol=0), 'fwd with the [N][Co] mask'
     if gather == 0:
         gy = guarded(torch.randn(N, Ho, Wo, Co, generator=g))
         if pads[0] == pads[2] and pads[1] == pads[3]:
