@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
     const bool linear_out = (ostep == 1 && g.ncls == 1 && !m2d) && !oscale;
     const bool simple = act <= ACT_RELU;
     const float ns = act == ACT_NONE ? 1.f : (act == ACT_LRELU ? slope : 0.f);   // negative-side factor of the simple activations
+    const bool relu = act == ACT_RELU;   // its negative side is the constant 0, not v * 0 (-inf * 0 = NaN; act_apply() and torch give 0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (TM * 32) + i * 32 + l31;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc[i][j][4 * k + e] + bq[j][k][e];
-                    o[e] = simple ? (v > 0.f ? v : v * ns) : act_apply(v, act, slope);
+                    o[e] = simple ? (v > 0.f ? v : (relu ? 0.f : v * ns)) : act_apply(v, act, slope);
                 }
                 if (vec) {
                     if (oscale) {

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
     const int a_base = (wave * 32 + l31) * C;
     // none / LeakyReLU / ReLU as one select: negative-side factor 1 / slope / 0
     const float ns = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);
+    const bool relu = g.act == ACT_RELU;   // negative side = the constant 0 (v * 0 would turn -inf into NaN)
 
     RgbStage<R, S, C> stage;
     if (oh_begin < oh_end) stage.load(g, x, n, oh_begin, ow0);
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const float v = acc[nb][r];
-                    o[nb * 32] = v > 0.f ? v : v * ns;
+                    o[nb * 32] = v > 0.f ? v : (relu ? 0.f : v * ns);
                 }
             }
         } else {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void rgb_conv_fwd_kernel(const RgbGeom g, cons
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const float v = acc[nb][r];
-                    if (ow < g.Wo) o[nb * 32] = v > 0.f ? v : v * ns;
+                    if (ow < g.Wo) o[nb * 32] = v > 0.f ? v : (relu ? 0.f : v * ns);
                 }
             }
         }
@@ -192,11 +193,15 @@ MIGAN_API int migan_rgb_conv_fwd(const float* x, const float* w_hwio, const floa
     const size_t lds = rgb_fwd_lds(R, S, Co, Ci);
 #define RGB_FWD(R_, NB_, C_)                                                                                                   \
     do {                                                                                                                       \
-        static bool attr_set = false;                                                                                          \
-        if (!attr_set && lds > 48 * 1024) {                                                                                    \
+        /* once per DEVICE (the attribute is per device: a second GPU of the same process needs it too) */                     \
+        static bool attr_set[64] = {};                                                                                         \
+        int dev__ = 0;                                                                                                         \
+        (void)hipGetDevice(&dev__);                                                                                            \
+        dev__ &= 63;                                                                                                           \
+        if (!attr_set[dev__] && lds > 48 * 1024) {                                                                             \
             hipFuncSetAttribute((const void*)rgb_conv_fwd_kernel<R_, R_, NB_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                                     \
-            attr_set = true;                                                                                                   \
+            attr_set[dev__] = true;                                                                                            \
         }                                                                                                                      \
         MIGAN_LAUNCH((rgb_conv_fwd_kernel<R_, R_, NB_, C_>), grid, dim3(256), lds, (hipStream_t)stream, g, x, w_hwio, bias, y); \
     } while (0)

@@ -314,6 +314,15 @@ def weight_cache_scope(owner=None):
         yield
     finally:
         _CACHE_SCOPE, _SCOPE_OWNER = prev, prev_owner
+        if prev is None and _STREAM_PACKS:
+            # the per-stream pack copies a recording made (see _packed): no later scope overwrites a (kind, stream) key, so without this
+            # the capture pool's tensors would stay referenced for the Parameter's lifetime - one leaked copy per recording
+            for cache, key in _STREAM_PACKS:
+                cache.pop(key, None)
+            del _STREAM_PACKS[:]
+
+
+_STREAM_PACKS = []   # (pack cache dict, (kind, stream) key) entries made inside the scope in progress
 
 
 def _packed(param, w, kind, make):
@@ -343,6 +352,7 @@ def _packed(param, w, kind, make):
                         return own[1]
                     t = make()
                     cache[(kind, cur.cuda_stream)] = (stamp, t, None)
+                    _STREAM_PACKS.append((cache, (kind, cur.cuda_stream)))
                     return t
                 cur.wait_event(hit[2][1])
         return hit[1]
@@ -628,6 +638,16 @@ def _fewpix_nt(a, w, b, out, M, N, K, act, slope, st, what):
     check(lib.migan_fewpix_nt(a.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), _ptr(ws), nb, M, N, K, act, slope, st), what)
 
 
+def _rgb_limits_ok(N, H, W, Ho, Wo, R, S, pt, pl, gather):
+    """What migan_rgb_conv_fwd / _wgrad refuse beyond migan_rgb_conv_ok(): more images than grid.z holds, and reflection pads that
+    reach past the image on either side.  Checked here so that such a layer falls through to the general kernels instead of raising."""
+    if N > 65535:
+        return False
+    if gather == GATHER_REFLECT and (pt >= H or pl >= W or Ho + R - 1 - pt - H >= H or Wo + S - 1 - pl - W >= W):
+        return False
+    return True
+
+
 class _Conv2d(Function):
     """y = act(conv2d(gather(x), w) + b); gather folds ReflectionPad2d / ZeroPad2d / Upsample(2) into the loader."""
 
@@ -675,6 +695,7 @@ class _Conv2d(Function):
             return y
         ctx.rgb = False
         if (_RGB and mask is None and stats_buf is None and w.is_contiguous() and Ci == 3 and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
+                and _rgb_limits_ok(N, H, W, Ho, Wo, R, S, pt, pl, gather)
                 and lib.migan_rgb_conv_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
             # image-input layer (3 source channels: srgan/models.py:85, vgg19.features[0], cyclegan/models.py:50): K = R*S*3 as it is
             # on the MFMA units, operands straight from staged image rows (csrc/rgb_conv.hip)
@@ -757,7 +778,7 @@ class _Conv2d(Function):
                                              st), "col2im_small")
             return dx, dw, db, None, None, None, None, None, None, None, None, None
         if (getattr(ctx, "rgb", False) and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-                and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
+                and act in (ACT_NONE, ACT_LRELU, ACT_RELU) and _rgb_limits_ok(N, H, W, Ho, Wo, R, S, pt, pl, gather)
                 and lib.migan_rgb_conv_wgrad_ok(Ci, Co, R, S, stride, gather, N * Ho * Wo) == 1):
             # image-input layer, weights only (the discriminator's first conv in its own update, srgan.py:129-141): the activation
             # backward, the bias column sums and the weight gradient in ONE launch that reads dy and y once (csrc/rgb_conv.hip) -

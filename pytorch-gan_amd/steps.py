@@ -776,12 +776,16 @@ class ReplayBuffer:
         (CycleGanRunner) launches the two row-selection kernels over this table every replay: the host RNG draws - the
         reference's, in the reference's order - happen here, before the replay, and only the table's contents change."""
         self.reserve(B)
+        self.table.copy_(torch.tensor(self.plan_rows(B), dtype=torch.int32))
+        self._planned = B
+
+    def plan_rows(self, B):
+        """The 3*B table entries of plan() as a python list (draws the picks; the caller owns the copy to the device table and
+        sets `_planned` - CycleGanRunner puts both buffers' rows into ONE pinned staging tensor and one asynchronous copy)."""
         out_src, slot_src = self._draw(B)
         slots = sorted(slot_src)
         pad = B - len(slots)
-        table = out_src + [-1 - slot_src[j] for j in slots] + [-1] * pad + slots + [-1] * pad
-        self.table.copy_(torch.tensor(table, dtype=torch.int32))
-        self._planned = B
+        return out_src + [-1 - slot_src[j] for j in slots] + [-1] * pad + slots + [-1] * pad
 
     def push_and_pop(self, batch):
         if not F.on_device(batch):
@@ -978,9 +982,20 @@ class CycleGanRunner:
         self.runner = StepRunner(lambda: cyclegan_step(s, self.a, self.b), s.dp, use_graph, max(1, warmup), before_capture=self._reserve)
 
     def _reserve(self):
+        # both buffers' static pick tables are the two halves of ONE device tensor, filled by one host-to-device copy per replay
         B = self.a.shape[0]
-        self.s.buf_A.reserve(B)
-        self.s.buf_B.reserve(B)
+        for buf in (self.s.buf_A, self.s.buf_B):
+            if buf.pool is None:
+                raise RuntimeError("ReplayBuffer.reserve(): no device pool yet (run one eager push_and_pop first)")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ReplayBuffer: the static table must exist before a capture")
+        self._tab = torch.full((6 * B,), -1, dtype=torch.int32, device=self.a.device)
+        self.s.buf_A.table, self.s.buf_B.table = self._tab[:3 * B], self._tab[3 * B:]
+        # two pinned staging tensors in rotation: the copy of replay i+1 is enqueued while replay i runs (a pageable source made
+        # every plan() a host synchronisation with all queued GPU work - the launch-bound batch-1 regime the recording is for)
+        self._stage = [torch.empty(6 * B, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._stage_ev = [None, None]
+        self._stage_k = 0
 
     def prepare(self):
         self.runner.prepare()
@@ -996,8 +1011,22 @@ class CycleGanRunner:
             self.b.copy_(real_B)
         if self.runner.graphed:
             B = self.a.shape[0]
-            self.s.buf_A.plan(B)   # cyclegan.py:216 fake_A_buffer.push_and_pop(fake_A) draws first ...
-            self.s.buf_B.plan(B)   # ... cyclegan.py:233 fake_B_buffer.push_and_pop(fake_B) second
+            # cyclegan.py:216 fake_A_buffer.push_and_pop(fake_A) draws first, cyclegan.py:233 fake_B_buffer.push_and_pop(fake_B) second
+            rows = self.s.buf_A.plan_rows(B) + self.s.buf_B.plan_rows(B)
+            k = self._stage_k
+            self._stage_k ^= 1
+            if self._stage_ev[k] is not None:
+                self._stage_ev[k].synchronize()   # the copy that last read this staging tensor (two replays ago) is over
+            self._stage[k].copy_(torch.tensor(rows, dtype=torch.int32))
+            self._tab.copy_(self._stage[k], non_blocking=True)   # on the stream the replay is launched on
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_ev[k] = ev
+            out = self.runner.run()
+            # the replay consumed the tables (its push_and_pop launches are recorded, no Python ran): a later EAGER push_and_pop on this
+            # state must draw its own picks instead of finding a stale plan
+            self.s.buf_A._planned = self.s.buf_B._planned = None
+            return out
         return self.runner.run()
 
 

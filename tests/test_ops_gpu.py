@@ -923,7 +923,10 @@ def test_cpu_tensor_raises(pg):
 @pytest.mark.parametrize("cfg", [(2, 128, 16, 16, 128, 0, True), (2, 128, 8, 12, 64, 1, True), (1, 256, 6, 5, 128, 2, False),
                                  (2, 32, 7, 9, 20, 0, True), (1, 64, 4, 4, 3, 3, True),
                                  (8, 128, 48, 48, 64, 0, True),   # 128x64 tiles, tap-inner K order; weight gradient on 64x256 tiles
-                                 (1, 64, 8, 16, 64, 1, True)])    # ... 64x256 weight-gradient tiles, one N-tile per class
+                                 (1, 64, 8, 16, 64, 1, True),     # ... 64x256 weight-gradient tiles, one N-tile per class
+                                 # the two up-conv layers of the bench line at its exact geometry (dcgan.py:55,59 at --img_size 64, batch 128):
+                                 # upconv_wgrad[128x 128->64 @64] is the dominant launch - its split plan at 524 288 pixels runs here
+                                 (128, 128, 32, 32, 64, 0, True), (128, 128, 16, 16, 128, 0, True)])
 def test_upconv3x3_phase_collapsed(pg, cfg):
     """Upsample(2) -> Conv3x3(p=1) in the phase-collapsed form (dcgan.py:54-55,58-59; cyclegan/models.py:74-75)
     against the dense reference: forward, dgrad, wgrad (collapsed when Co%4==0 and Ci%4==0, dense fallback else)."""

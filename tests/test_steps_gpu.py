@@ -909,6 +909,51 @@ def test_bench_config_one_step_matches_oracle():
     assert err < 2e-5, err
     valid, fake = s_gpu.labels[((128, 1), str(imgs.to(DEV).device))]
     assert torch.equal(valid.cpu(), torch.ones(128, 1)) and torch.equal(fake.cpu(), torch.zeros(128, 1))
+    # The same step in fp64 (same weights, inputs, masks): every parameter gradient still in the optimiser buckets - the generator's
+    # from g_loss, the discriminator's from d_loss - against it with the noise-aware bound of test_models_gpu._noise_aware
+    # (5e-3 * |f64| + 8 * |cpu32 - f64| per tensor), NOT a flat whole-network bound: this is where the dominant launches of the bench line
+    # (upconv_wgrad[128x 128->64 @64] = wgrad_dma_kernel<64,256,...> with its split plan at 524 288 pixels, upconv_wgrad[128x 128->128 @32],
+    # both up-conv input gradients) have their outputs checked at the benchmarked size (dcgan.py:143-183).
+    s_f64 = S.make_dcgan(64)
+    _seed(0)
+    ref0 = S.make_dcgan(64)   # the seeded construction s_cpu started from
+    s_f64.G.load_state_dict(ref0.G.state_dict())
+    s_f64.D.load_state_dict(ref0.D.state_dict())
+    s_f64.G.double()
+    s_f64.D.double()
+    s_f64.opt_G, s_f64.opt_D = S._adam(s_f64.G.parameters()), S._adam(s_f64.D.parameters())
+    torch.set_default_dtype(torch.float64)   # the oracle step's own label tensors (torch.ones / zeros) in fp64 as well
+    try:
+        with M.feed_masks(masks=[m.numpy() for m in rec]):
+            S.dcgan_step(s_f64, imgs.double(), z.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    checked = 0
+    for net in ("G", "D"):
+        gp = dict(getattr(s_gpu, net).named_parameters())
+        dp = dict(getattr(s_f64, net).named_parameters())
+        for k, p in getattr(s_cpu, net).named_parameters():
+            assert (p.grad is None) == (gp[k].grad is None), "%s.%s: gradient presence differs" % (net, k)
+            if p.grad is None:
+                continue
+            g, c, t = gp[k].grad.detach().double().cpu(), p.grad.detach().double(), dp[k].grad.detach().double()
+            err_g, err_c, ref = (g - t).norm().item(), (c - t).norm().item(), t.norm().item()
+            bound = 5e-3 * ref + 8.0 * err_c + 1e-12
+            assert err_g <= bound, "%s.%s grad at 64x64 bs 128: |hip-f64| %.3e > %.3e (|cpu32-f64| %.3e, |f64| %.3e)" % (
+                net, k, err_g, bound, err_c, ref)
+            checked += 1
+    assert checked == len(list(s_cpu.G.parameters())) + len(list(s_cpu.D.parameters()))
+    # Adam'd weights: as close to the fp64 step as the fp32 oracle's are (x4) + 2 % of the step an update moves
+    _params_close_vs_f64(s_gpu.G, s_cpu.G, s_f64.G, 1, "dcgan 64x64 bs128 G")
+    _params_close_vs_f64(s_gpu.D, s_cpu.D, s_f64.D, 1, "dcgan 64x64 bs128 D")
+    # BatchNorm side effects at size: running statistics (three discriminator forwards, one generator forward) and counters
+    for net in ("G", "D"):
+        gb = dict(getattr(s_gpu, net).named_buffers())
+        for k, b in getattr(s_cpu, net).named_buffers():
+            if b.dtype.is_floating_point:
+                assert rel_fro(gb[k], b) < 1e-5, "%s.%s" % (net, k)
+            else:
+                assert int(b) == int(gb[k]), "%s.%s" % (net, k)
 
 
 def test_bench_two_ranks_on_one_gpu():
