@@ -39,7 +39,7 @@ import torch  # noqa: E402
 IMG, BATCH, LATENT, CH = 64, 128, 100, 1
 PEAK_TFLOPS = 157.3  # fp32-input MFMA, MI355X_MICROARCH.md chip table
 UP_EXEC = 16.0 / 36.0  # executed share of the dense FLOPs in the phase-collapsed Upsample(2)+Conv3x3 kernels
-PROFILE_ROUND = "r05"  # profiles/r05_pmc_kernels.json: the rocprofv3 --pmc passes over `bench.py --pmc-log` (tools/gpu_r05.sh pmcstep)
+PROFILE_ROUND = "r06"  # profiles/r06_pmc_kernels.json: the rocprofv3 --pmc passes over `bench.py --pmc-log` (tools/gpu_r06.sh pmcstep)
 
 
 def dcgan_flops_per_image(ch=None):
@@ -517,7 +517,7 @@ def pmc_table():
     (FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, separate passes) and MFMA-busy cycles,
     keyed by the roofline group names used here.  The PMC passes cannot run inside bench.py (counter collection
     serialises the launches), so they are taken on `bench.py --no-graph` by tools/round_measure.sh and committed."""
-    for rnd in (PROFILE_ROUND, "r04"):   # the newest committed pass; the previous round's until this round's has been taken
+    for rnd in (PROFILE_ROUND, "r05"):   # the newest committed pass; the previous round's until this round's has been taken
         path = os.path.join(ROOT, "profiles", "%s_pmc_kernels.json" % rnd)
         try:
             with open(path) as f:
@@ -525,6 +525,23 @@ def pmc_table():
         except (OSError, ValueError):
             continue
     return {}, None
+
+
+def lib_digest():
+    """Digest of the kernel sources + flags the loaded libmigan.so was built from (csrc/build.py writes it next to the library)."""
+    try:
+        with open(os.path.join(ROOT, "pytorch-gan_amd", "csrc", ".libmigan.stamp")) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def pmc_stale(tab):
+    """True when the committed counter table was NOT taken on the library this process runs (or does not say which library it was
+    taken on): its traffic / MFMA-busy columns then describe other device code than the one being timed."""
+    src = tab.get("_source") if isinstance(tab.get("_source"), dict) else {}
+    have, mine = src.get("lib_digests") or ([src["lib_digest"]] if src.get("lib_digest") else []), lib_digest()
+    return not (mine is not None and have == [mine])
 
 
 def roofline(w, rank, nprof, segments=None):
@@ -565,6 +582,7 @@ def roofline(w, rank, nprof, segments=None):
         "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / PEAK_TFLOPS, 4), "achieved_dense": round(dense, 2), "frac_dense": round(dense / PEAK_TFLOPS, 4),
         "traffic": ent.get("hbm_bytes_per_launch"), "traffic_source": src if ent else None,
+        "counters_stale": pmc_stale(tab) if ent else None, "lib_digest": (lib_digest() or "")[:16],
         "symbol": ent.get("symbol"), "mfma_busy_frac": ent.get("mfma_busy_frac"),
         "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_step": d["launches"] // nprof,
         "executed_gflop_per_launch": round(d["exec"] / d["launches"] / 1e9, 3),
@@ -588,7 +606,7 @@ def roofline(w, rank, nprof, segments=None):
         out["hbm"] = {
             "bound": "hbm", "kernel": hk, "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
             "frac_of_achievable_6290": round(gbs / 6290.0, 4), "traffic": hent.get("hbm_bytes_per_launch"),
-            "traffic_source": src if hent else None,
+            "traffic_source": src if hent else None, "counters_stale": pmc_stale(tab) if hent else None,
             "avg_call_ms": round(h["ms"] / h["launches"], 4), "calls_per_step": h["launches"] // nprof,
             "algorithmic_mb_per_call": round(h["bytes"] / h["launches"] / 1e6, 2),
             "note": "one call = the launches of that C entry point (stats: partial + finalize; bwd: partial + finalize + apply)",

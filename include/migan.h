@@ -352,6 +352,16 @@ int migan_norm_bwd_sums(const float* x, const float* dy, const float* mean, cons
 int migan_norm_bwd_apply(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, const float* sums, int G, int P, int C, int act,
                          float slope, long long P_total, float* csum, void* stream);
+/* ... and of migan_norm_bwd_prelu (BatchNorm2d [-> PixelShuffle(2)] -> PReLU, srgan/models.py:23-24,55-57, under cross-replica
+ * statistics - srgan.py:97-145 at 2 images per rank): dprelu (+)= this rank's part of the slope gradient; ws for the first half:
+ * migan_norm_workspace_prelu() bytes. */
+int migan_norm_bwd_sums_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, const float* prelu_weight, float* sums, float* dgamma, float* dbeta,
+                              float* dprelu, int G, int P, int C, float* ws, size_t ws_bytes, int accumulate,
+                              int dprelu_accumulate, int shuffle_H, int shuffle_W, void* stream);
+int migan_norm_bwd_apply_prelu(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* prelu_weight, const float* sums, int G,
+                               int P, int C, long long P_total, float* csum, int shuffle_H, int shuffle_W, void* stream);
 /* Cross-replica BatchNorm forward: migan_norm_moments = this rank's mean and BIASED variance [C] (no eps, no running
  * statistics); after an all_gather into [world][2][C], migan_norm_sync_finalize combines the equal shards (Chan, in
  * double) into the global-batch mean / invstd and updates the running statistics with the global unbiased variance -

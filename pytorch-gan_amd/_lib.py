@@ -122,6 +122,8 @@ _SIGS = {
     "migan_norm_bwd": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, c_int, P, P]),
     "migan_norm_bwd_sums": (c_int, [P] * 9 + [c_int] * 4 + [c_float, P, c_size_t, c_int, P]),
     "migan_norm_bwd_apply": (c_int, [P] * 8 + [c_int] * 4 + [c_float, ctypes.c_longlong, P, P]),
+    "migan_norm_bwd_sums_prelu": (c_int, [P] * 11 + [c_int] * 3 + [P, c_size_t, c_int, c_int, c_int, c_int, P]),
+    "migan_norm_bwd_apply_prelu": (c_int, [P] * 9 + [c_int] * 3 + [ctypes.c_longlong, P, c_int, c_int, P]),
     "migan_norm_moments": (c_int, [P, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "migan_norm_sync_finalize": (c_int, [P, c_int, ctypes.c_longlong, P, P, P, P, P, c_float, c_float, c_int, P]),
     "migan_rsqrt_eps": (c_int, [P, P, c_int, c_float, P]),

@@ -975,6 +975,39 @@ MIGAN_API int migan_norm_bwd_prelu(const float* x, const float* dy, const float*
     return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, act_, 0.f, P, csum, prelu_weight, st, ps);
 }
 
+// The two halves of migan_norm_bwd_prelu, for cross-replica BatchNorm (data parallel; srgan/models.py:23-24,55-57 at
+// 2 images per rank): sums [G][C][2] over this rank's pixels are all-reduced (SUM) between them and P_total = world * P.  dprelu
+// (+)= this rank's part of the slope gradient (the ranks' parts are summed with the rest of the gradient bucket).
+// ws: migan_norm_workspace_prelu() bytes (the first half only).
+MIGAN_API int migan_norm_bwd_sums_prelu(const float* x, const float* dy, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, const float* prelu_weight, float* sums, float* dgamma, float* dbeta,
+                                        float* dprelu, int G, int P, int C, float* ws, size_t ws_bytes, int accumulate,
+                                        int dprelu_accumulate, int shuffle_H, int shuffle_W, void* stream) {
+    const bool shuf = shuffle_H > 0 && shuffle_W > 0;
+    if ((!prelu_weight && !shuf) || !sums || ws_bytes < migan_norm_workspace_prelu(G, P, C)) return (int)hipErrorInvalidValue;
+    const PShuf ps = shuf ? pshuf_make(shuffle_H, shuffle_W, C) : PShuf{};
+    hipStream_t st = (hipStream_t)stream;
+    float* dsl = ws + migan_norm_workspace(G, P, C) / sizeof(float);
+    int rc = norm_bwd_sums_impl(x, dy, mean, invstd, gamma, beta, sums, dgamma, dbeta, G, P, C, prelu_weight ? ACT_LRELU : ACT_NONE, 0.f,
+                                ws, migan_norm_workspace(G, P, C), accumulate, prelu_weight, (dprelu && prelu_weight) ? dsl : nullptr,
+                                st, ps);
+    if (rc) return rc;
+    if (dprelu && prelu_weight) {
+        MIGAN_LAUNCH(sum_small_kernel, dim3(1), dim3(256), 0, st, dsl, G * C, dprelu, dprelu_accumulate);
+        HIP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+MIGAN_API int migan_norm_bwd_apply_prelu(const float* x, const float* dy, float* dx, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, const float* prelu_weight, const float* sums, int G,
+                                         int P, int C, long long P_total, float* csum, int shuffle_H, int shuffle_W, void* stream) {
+    const bool shuf = shuffle_H > 0 && shuffle_W > 0;
+    if (!prelu_weight && !shuf) return (int)hipErrorInvalidValue;
+    const PShuf ps = shuf ? pshuf_make(shuffle_H, shuffle_W, C) : PShuf{};
+    return norm_bwd_apply_impl(x, dy, dx, mean, invstd, gamma, beta, sums, G, P, C, prelu_weight ? ACT_LRELU : ACT_NONE, 0.f, P_total,
+                               csum, prelu_weight, (hipStream_t)stream, ps);
+}
+
 // Backward of `act [-> Dropout2d]` behind a conv, viewed [G = N][P = H*W][C]: dx = dy * mask[g][c] * act'(y) (mask may
 // be NULL, act may be 0) plus migan_norm_colsum_slabs(G, P, C) x [C] per-block column sums of dx (see above).
 MIGAN_API int migan_act_bwd_colsum(const float* dy, const float* y, const float* mask_gc, float* dx, float* csum, int G,

@@ -1555,9 +1555,6 @@ class _Norm(Function):
             raise ValueError("norm: expected 2-D or 4-D input")
         st = _stream()
         sync = _SYNC_BN if (use_batch_stats and not instance and _SYNC_BN is not None and _SYNC_BN.world > 1) else None
-        if sync is not None and (pw is not None or shuffle):
-            # the fused backward (norm_bwd_prelu) takes the two batch sums over this rank's rows only; nn.Sequential does not fuse in this mode
-            raise NotImplementedError("cross-replica BatchNorm with a fused PReLU / PixelShuffle: use the separate layers")
         # batch_groups(k): this BatchNorm call stands for k calls on k consecutive sub-batches (statistics, running-statistics
         # updates and num_batches_tracked per sub-batch, in order) - [G = k][P / k][C] in the kernels' group view
         ctx.bn_groups = 1
@@ -1628,10 +1625,7 @@ class _Norm(Function):
             check(lib.migan_norm_apply(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                        _ptr(beta), _ptr(rs), G, P, C, act, slope, st), "norm_apply")
         else:
-            if sync is not None:
-                raise NotImplementedError("norm: fused PReLU / PixelShuffle under cross-replica BatchNorm (nn.Sequential does "
-                                          "not fuse them then)")
-            sh, sw = ctx.shuffle or (0, 0)
+            sh, sw = ctx.shuffle or (0, 0)   # (cross-replica statistics: mean / invstd above are the global batch's; the launch is the same)
             check(lib.migan_norm_apply_prelu(xs.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
                                              _ptr(beta), _ptr(rs), _ptr(pw), G, P, C, sh, sw, st), "norm_apply_prelu")
         ctx.cfg = (G, P, C, act, slope, use_batch_stats, gamma is not None, res is not None)
@@ -1699,10 +1693,23 @@ class _Norm(Function):
             dpt = pslot if pslot is not None else (torch.empty(1, device=xs.device, dtype=torch.float32) if want_dp else None)
             nbp = lib.migan_norm_workspace_prelu(G, P, C)
             wsp = _ws(nbp, xs)
-            check(lib.migan_norm_bwd_prelu(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
-                                           _ptr(beta), _ptr(pw), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
-                                           wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, _ptr(slabs), sh, sw, st),
-                  "norm_bwd_prelu")
+            if ctx.sync is None:
+                check(lib.migan_norm_bwd_prelu(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                               _ptr(beta), _ptr(pw), dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
+                                               wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, _ptr(slabs), sh, sw, st),
+                      "norm_bwd_prelu")
+            else:
+                # cross-replica BatchNorm (srgan.py:97-145 sharded 2 images per rank): the two batch sums cover the global batch -
+                # all-reduce of 2*C floats between the halves; dgamma / dbeta / dprelu stay this rank's sums (the bucket exchange adds them)
+                sums = torch.empty(2 * C, device=xs.device, dtype=torch.float32)
+                check(lib.migan_norm_bwd_sums_prelu(xs.data_ptr(), dy.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+                                                    _ptr(beta), _ptr(pw), sums.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), G, P, C,
+                                                    wsp.data_ptr(), nbp, acc, 1 if pslot is not None else 0, sh, sw, st),
+                      "norm_bwd_sums_prelu")
+                ctx.sync.all_reduce_sum(sums)
+                check(lib.migan_norm_bwd_apply_prelu(xs.data_ptr(), dy.data_ptr(), dx.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                     _ptr(gamma), _ptr(beta), _ptr(pw), sums.data_ptr(), G, P, C, P * ctx.sync.world,
+                                                     _ptr(slabs), sh, sw, st), "norm_bwd_apply_prelu")
             if want_dp and pslot is None:
                 dprelu = dpt.view(ctx.prelu.shape)
         elif ctx.sync is None:

@@ -592,7 +592,7 @@ class Sequential(tnn.Sequential):
                 # BatchNorm2d [PixelShuffle] PReLU (srgan/models.py:23-24, 55-57): the single-slope PReLU commutes with the
                 # shuffle, so it is applied (and differentiated) inside the norm launches and the shuffle moves behind it
                 if _PRELU_FUSE and act == F.ACT_NONE and type(m) is BatchNorm2d and x.dim() == 4 \
-                        and (m.training or not m.track_running_stats) and not (F._SYNC_BN is not None and F._SYNC_BN.world > 1) \
+                        and (m.training or not m.track_running_stats) \
                         and F._BN_GROUPS == 1:   # paired batches (functional.batch_groups): the plain BatchNorm path, PReLU / shuffle as their own launches
                     q = k + 1 if (k < n and type(mods[k]) is PixelShuffle) else k
                     if q < n and type(mods[q]) is PReLU and mods[q].num_parameters == 1:

@@ -5,6 +5,7 @@
                                                    MIGAN_TEST_STEPS=k: k steps;  MIGAN_TEST_GRAPH=1: step 1 eager, the rest replays of
                                                    the recorded step (hipGraph segments cut at every BatchNorm collective);
                                                    MIGAN_TEST_GRAPH=cuts: the recording protocol without a capture (CPU)
+    python tests/dp_worker.py srgan <out.pt>       N ranks (gloo, all on cuda:0): one SRGAN step, the batch sharded, cross-replica BatchNorm
     python tests/dp_worker.py order <out.pt>       N ranks (gloo, all on cuda:0): CycleGAN steps, one image pair per rank, under
                                                    MIGAN_TEST_ORDER=sequential|fork (steps.set_dp_order)
 """
@@ -198,12 +199,54 @@ def order(out):
     del pg
 
 
+def srgan(out):
+    """Row N3 (config 5's per-GPU shard, srgan.py:97-145): every rank runs its shard of an SRGAN batch with cross-replica BatchNorm on
+    (generator BatchNorm2d(64, 0.8) + PReLU / PixelShuffle fused launches and the discriminator's BatchNorm layers all take the GLOBAL
+    batch's statistics); rank 0 stores the rank-averaged losses, every parameter's gradient (divided by world) and the BatchNorm buffers.
+    MIGAN_TEST_HR = high-resolution side (384), MIGAN_TEST_NRES = residual blocks (16), MIGAN_TEST_BATCH = GLOBAL batch (4)."""
+    import pytorch_gan_amd as pg
+    from oracle import reference_steps as S
+    from pytorch_gan_amd import dp as dpmod
+    from pytorch_gan_amd import steps
+    from util import gpu_copy
+
+    dp = dpmod.init_from_env()
+    if os.environ.get("MIGAN_TEST_SYNCBN", "1") == "1":
+        dp.enable_sync_batchnorm()
+    hr, nres, batch = (int(os.environ.get(k, d)) for k, d in (("MIGAN_TEST_HR", "384"), ("MIGAN_TEST_NRES", "16"), ("MIGAN_TEST_BATCH", "4")))
+    _seed(0)
+    base = S.make_srgan((hr, hr), n_res=nres)
+    s = steps.make_srgan_state(gpu_copy(base.G), gpu_copy(base.D), gpu_copy(base.V), dp=dp)
+    _seed(12)
+    lr_imgs, hr_imgs = torch.randn(batch, 3, hr // 4, hr // 4), torch.randn(batch, 3, hr, hr)
+    dev = next(s.G.parameters()).device
+    a, b = dp.shard(lr_imgs.to(dev)).clone(), dp.shard(hr_imgs.to(dev)).clone()
+    dp.begin_step()
+    o = steps.srgan_step(s, a, b)
+    dp.end_step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    keys = ("loss_G", "loss_D", "loss_content", "loss_GAN")
+    losses = torch.stack([o[k] for k in keys]).clone()
+    dist.all_reduce(losses)
+    losses /= dp.world
+    if dp.rank == 0:
+        torch.save({"losses": losses.cpu(),
+                    "grads": {n: {k: (p.grad.detach().cpu() / dp.world) for k, p in getattr(s, n).named_parameters() if p.grad is not None}
+                              for n in ("G", "D")},
+                    "buffers": {n: {k: v.detach().cpu() for k, v in getattr(s, n).named_buffers()} for n in ("G", "D")},
+                    "weights": {n: {k: v.detach().cpu() for k, v in getattr(s, n).named_parameters()} for n in ("G", "D")}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+    del pg
+
+
 if __name__ == "__main__":
     if os.environ.get("MIGAN_TEST_EMU") == "1":
         # the same worker on the host execution model of the kernels (tests/hipemu): CPU tensors, gloo, no GPU
         import hipemu.host
 
         with hipemu.host.emulated_device():
-            {"syncbn": syncbn, "order": order}[sys.argv[1]](sys.argv[2])
+            {"syncbn": syncbn, "order": order, "srgan": srgan}[sys.argv[1]](sys.argv[2])
     else:
-        {"nccl1": nccl1, "syncbn": syncbn, "order": order}[sys.argv[1]](sys.argv[2])
+        {"nccl1": nccl1, "syncbn": syncbn, "order": order, "srgan": srgan}[sys.argv[1]](sys.argv[2])

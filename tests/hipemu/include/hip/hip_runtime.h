@@ -72,6 +72,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 // dynamic LDS beyond 64 KB needs this opt-in on the hardware; the model's dynamic LDS is sized per launch
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }   // the model is one device
 
 #define __global__
 #define __device__

@@ -152,3 +152,52 @@ def test_both_step_orders_of_the_data_parallel_step_equal_the_full_batch(tmp_pat
     for name in ("opt_G", "opt_D_A", "opt_D_B"):
         a, b = one["grads"][name].double(), getattr(s, name).flat_grad.cpu().double()
         assert float((a - b).norm() / b.norm()) < tol, name
+
+
+def test_srgan_two_images_per_rank_with_cross_replica_batchnorm_equals_the_full_batch_oracle(tmp_path):
+    """Row N3: BASELINE.json configs[4] sharded over 8 GPUs is 2 images per rank with BatchNorm coupled across ranks (SURVEY.md 7 "hard
+    parts").  Two ranks x 2 images at 96 -> 384 with 16 residual blocks and enable_sync_batchnorm() against the ORACLE's single-process step
+    on the 4 images (srgan.py:97-145; srgan/models.py:23,26,47,87-90): losses, the rank-averaged gradients of both networks, the
+    BatchNorm running statistics.  The generator's BatchNorm2d -> PReLU and BatchNorm2d -> PixelShuffle -> PReLU groups stay on their
+    fused launches under cross-replica statistics (migan_norm_bwd_sums_prelu / _apply_prelu).  With per-rank statistics the running
+    variance differs measurably - the comparison is not vacuous.  (32x32 -> 128, 2 blocks on the execution model.)"""
+    from oracle import reference_steps as S
+    from util import suite_budget
+
+    emu = os.environ.get("MIGAN_TEST_EMU") == "1"
+    hr, nres = (32, 2) if emu else (384, 16)
+    suite_budget(150, "test_srgan_two_images_per_rank")
+    env = {"MIGAN_TEST_HR": str(hr), "MIGAN_TEST_NRES": str(nres), "MIGAN_TEST_BATCH": "4"}
+    got = _run_ranks("srgan", str(tmp_path / "sync.pt"), 2, env)
+    local = _run_ranks("srgan", str(tmp_path / "local.pt"), 2, dict(env, MIGAN_TEST_SYNCBN="0"))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    s = S.make_srgan((hr, hr), n_res=nres)
+    torch.manual_seed(12)
+    np.random.seed(12)
+    lr_imgs, hr_imgs = torch.randn(4, 3, hr // 4, hr // 4), torch.randn(4, 3, hr, hr)
+    o = S.srgan_step(s, lr_imgs, hr_imgs)
+    want = torch.stack([o[k] for k in ("loss_G", "loss_D", "loss_content", "loss_GAN")])
+    assert torch.allclose(got["losses"], want, rtol=2e-4, atol=2e-6), (got["losses"], want)
+    for n in ("G", "D"):
+        num = den = 0.0
+        for k, p in getattr(s, n).named_parameters():
+            assert (p.grad is None) == (k not in got["grads"][n]), (n, k)
+            if p.grad is None:
+                continue
+            d = got["grads"][n][k].double() - p.grad.double()
+            num += float((d * d).sum())
+            den += float((p.grad.double() ** 2).sum())
+        # whole-network bound as in test_fullsize_gpu (LeakyReLU / PReLU kink flips between two fp32 evaluations); 4 images instead of 16
+        # weigh every flip 4x as much
+        assert (num / max(den, 1e-300)) ** 0.5 <= (3e-2 if emu else 1e-2), (n, (num / den) ** 0.5)
+        for k, b in getattr(s, n).named_buffers():
+            v = got["buffers"][n][k]
+            if b.dtype.is_floating_point:
+                assert torch.allclose(v, b, rtol=2e-4, atol=2e-6), (n, k)
+            else:
+                assert int(v) == int(b), (n, k)
+    # per-rank statistics are another computation: the first trunk BatchNorm's running variance moves away from the oracle's
+    k = "res_blocks.0.conv_block.1.running_var"
+    ref = dict(s.G.named_buffers())[k]
+    assert not torch.allclose(local["buffers"]["G"][k], ref, rtol=2e-4, atol=2e-6)

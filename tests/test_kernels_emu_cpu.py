@@ -572,27 +572,64 @@ def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monk
     _run_gpu_test_body("test_dp_gpu", "test_cross_replica_batchnorm_equals_full_batch", tmp_path)
 
 
-def test_cross_replica_batchnorm_refuses_the_fused_prelu_form(emu, monkeypatch):
-    """The fused BatchNorm2d + PReLU [+ PixelShuffle] launches (srgan/models.py:23-24,55-57) take their backward batch sums over one
-    rank's rows: with cross-replica BatchNorm on, nn.Sequential keeps the layers apart and a direct functional call raises instead of
-    computing per-rank sums silently; with world size 1 the fused form runs."""
-    import types
-
+def test_cross_replica_batchnorm_keeps_the_fused_prelu_form(emu, monkeypatch):
+    """The fused BatchNorm2d + PReLU [+ PixelShuffle] launches (srgan/models.py:23-24,55-57) under cross-replica statistics: forward
+    from the gathered moments, backward in two halves around the all-reduce of the two batch sums (migan_norm_bwd_sums_prelu /
+    migan_norm_bwd_apply_prelu).  A stand-in exchange for TWO ranks holding the SAME shard (all_gather = the moments twice, all_reduce =
+    twice the sums, P_total = 2 P): the global statistics then equal the local ones, so output, input gradient, affine gradients and the
+    slope gradient must equal the single-rank fused launches'."""
     import hipemu.host
     from pytorch_gan_amd import functional as F
 
-    x = torch.randn(2, 8, 4, 4).contiguous(memory_format=torch.channels_last)
-    gamma, beta, pw = torch.ones(8), torch.zeros(8), torch.full((1,), 0.25)
+    class TwoEqualShards:
+        world = 2
+
+        def all_gather(self, t):
+            return torch.cat([t, t])
+
+        def all_reduce_sum(self, t):
+            t.mul_(2.0)
+            return t
+
+    torch.manual_seed(3)
+    x0 = (torch.randn(2, 8, 6, 4) * 1.5 + 0.3).contiguous(memory_format=torch.channels_last)
+    g0, b0 = torch.rand(8) + 0.5, torch.randn(8)
+    for shuffle in (0, 2):
+        res = []
+        for sync in (None, TwoEqualShards()):
+            x = x0.clone().requires_grad_(True)
+            gamma, beta = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            pw = torch.full((1,), 0.25).requires_grad_(True)
+            with hipemu.host.emulated_device():
+                monkeypatch.setattr(F, "_SYNC_BN", sync)
+                y = F.norm(x, gamma, beta, eps=0.8, prelu=pw, shuffle=shuffle)
+                g = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).contiguous(memory_format=torch.channels_last)
+                y.backward(g)
+            res.append([t.detach().clone() for t in (y, x.grad, gamma.grad, beta.grad, pw.grad)])
+        monkeypatch.setattr(F, "_SYNC_BN", None)
+        for a, b, what in zip(res[0], res[1], ("y", "dx", "dgamma", "dbeta", "dprelu")):
+            assert _rel(b.detach(), a.detach()) <= 2e-6, (shuffle, what, _rel(b.detach(), a.detach()))
+    # and against torch: BatchNorm2d(8, 0.8) -> PReLU
+    ref_x = x0.clone().requires_grad_(True)
+    ref = TF.prelu(TF.batch_norm(ref_x, None, None, gamma.detach(), beta.detach(), True, 0.1, 0.8), torch.full((1,), 0.25))
+    x = x0.clone().requires_grad_(True)
     with hipemu.host.emulated_device():
-        monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=2))
-        with pytest.raises(NotImplementedError):
-            F.norm(x, gamma, beta, prelu=pw)
-        with pytest.raises(NotImplementedError):
-            F.norm(x, gamma, beta, prelu=pw, shuffle=2)
-        monkeypatch.setattr(F, "_SYNC_BN", types.SimpleNamespace(world=1))
-        y = F.norm(x, gamma, beta, prelu=pw)
-        ref = TF.prelu(TF.batch_norm(x, None, None, gamma, beta, True), pw)
-        assert _rel(y, ref) <= 1e-5
+        monkeypatch.setattr(F, "_SYNC_BN", TwoEqualShards())
+        y = F.norm(x, gamma.detach(), beta.detach(), eps=0.8, prelu=torch.full((1,), 0.25))
+    monkeypatch.setattr(F, "_SYNC_BN", None)
+    assert _rel(y, ref) <= 1e-5
+
+
+def test_srgan_two_ranks_cross_replica_batchnorm_on_the_execution_model(tmp_path, monkeypatch):
+    """Row N3 without a GPU: test_dp_gpu.py::test_srgan_two_images_per_rank_... at 8 -> 32 pixels with 2 residual blocks - two gloo
+    ranks x 2 images, cross-replica BatchNorm with the fused PReLU / PixelShuffle launches, against the oracle's 4-image step."""
+    monkeypatch.setenv("MIGAN_TEST_EMU", "1")
+    monkeypatch.setenv("MIGAN_TEST_DEVICE", "cpu")
+    _load_or_skip()
+    import test_dp_gpu
+
+    # every kernel runs in the rank processes; the parent holds the oracle's step
+    test_dp_gpu.test_srgan_two_images_per_rank_with_cross_replica_batchnorm_equals_the_full_batch_oracle(tmp_path)
 
 
 def test_cross_replica_batchnorm_recording_protocol_on_the_execution_model(tmp_path, monkeypatch):

@@ -115,7 +115,15 @@ def main():
                         "counted_mb (2 x FETCH + WRITE)": round(ent["hbm_bytes_per_launch"] / 1e6, 2)})
     out["_calibration"] = {"note": "norm_apply reads and writes its tensor once: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB reproduces 8 B per element",
                            "samples": cal[:8]}
-    out["_source"] = {"passes": sorted(set(sources)), "tool": "tools/pmc_step.py"}
+    # the library the passes ran on: bench.py compares this digest with the one it loads and flags the counters `stale` otherwise
+    stamp = os.path.join(ROOT, "pytorch-gan_amd", "csrc", ".libmigan.stamp")
+    digest = open(stamp).read().strip() if os.path.exists(stamp) else None
+    prev = out.get("_source", {}) if isinstance(out.get("_source"), dict) else {}
+    digests = sorted(set(([digest] if digest else []) + [d for d in prev.get("lib_digests", []) if d]))
+    out["_source"] = {"passes": sorted(set(sources) | set(prev.get("passes", []))), "tool": "tools/pmc_step.py",
+                      "lib_digest": digest, "lib_digests": digests,
+                      "note": "lib_digest = sha256 of the kernel sources + flags (csrc/build.py) of the library the newest passes profiled; "
+                              "lib_digests = every digest that contributed groups to this table (more than one = mixed trees)"}
     out.move_to_end("_calibration")
     out.move_to_end("_source")
     json.dump(out, open(path, "w"), indent=1)
