@@ -652,14 +652,18 @@ __device__ __forceinline__ float frag_get(float v, int) { return v; }
 __device__ __forceinline__ float frag_get(f32x2 v, int e) { return v[e]; }
 __device__ __forceinline__ float frag_get(f32x4 v, int e) { return v[e]; }
 
-template <int BM, int BN, int BK, bool DYS, bool REFL, int OCC>
-__global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, const float* __restrict__ X,
+// NW: waves per workgroup (4, or 8 = a 2 x 4 wave grid: twice the waves per SIMD at the same LDS footprint, half the DMA instructions and
+// MFMAs per wave and K-tile - for tiles whose LDS stage allows only two workgroups per CU)
+template <int BM, int BN, int BK, bool DYS, bool REFL, int OCC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, OCC) void wgrad_dma_kernel(const WgradGeom g, const float* __restrict__ X,
                                                              const float* __restrict__ DY, float* __restrict__ part,
                                                              unsigned x_bytes, unsigned dy_bytes) {
-    constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+    constexpr int WN_ = NW / 2;                    // wave grid 2 x WN_
+    constexpr int TM = BM / 2 / 32, TN = BN / WN_ / 32;
     constexpr int CPA = BM / 4, CPB = BN / 4;      // 16-B chunks per pixel row
     constexpr int RPA = 64 / CPA, RPB = 64 / CPB;  // pixel rows per DMA instruction
-    constexpr int PPW = BK / 4;                    // consecutive pixel rows of a K-tile owned by one wave (8 or 4)
+    constexpr int PPW = BK / NW;                   // consecutive pixel rows of a K-tile owned by one wave (8 or 4)
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
     constexpr int IA = PPW / RPA, IB = PPW / RPB;  // DMA instructions per wave per K-tile
     static_assert((BK == 32 || BK == 16) && IA >= 1 && IB >= 1, "BK");
     constexpr int A_FL = BK * BM, B_FL = BK * BN, ST_FL = A_FL + B_FL;
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_dma_kernel(const WgradGeom g, 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN_, wn = wave % WN_;
     const int cls = DYS ? (int)blockIdx.y : 0;
     const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
     const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
@@ -874,6 +878,19 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
     // per layer in profiles/r03_wgrad_dma.txt (differences <= 3 %).
     // wgrad_occ() in conv_igemm.hip (the split planner's slot count) follows this choice.
     const int bk = bm == 128 ? 16 : 32;
+    // 64 x 256 (80 KB of LDS: two workgroups per CU): eight waves per workgroup - four per SIMD instead of two cover each other's DMA issue,
+    // fragment reads and barriers (MIGAN_WGRAD_NW=4: the four-wave form, A/B knob)
+    static const int nw_env = getenv("MIGAN_WGRAD_NW") ? atoi(getenv("MIGAN_WGRAD_NW")) : 8;
+    if (bk == 32 && bm == 64 && bn == 256 && nw_env == 8) {
+        if (dys) MIGAN_LAUNCH((wgrad_dma_kernel<64, 256, 32, true, false, 4, 8>), grid, dim3(512), 0, st, gg, x, dy, ws, (unsigned)xb,
+                              (unsigned)db);
+        else if (refl) MIGAN_LAUNCH((wgrad_dma_kernel<64, 256, 32, false, true, 4, 8>), grid, dim3(512), 0, st, gg, x, dy, ws, (unsigned)xb,
+                                    (unsigned)db);
+        else MIGAN_LAUNCH((wgrad_dma_kernel<64, 256, 32, false, false, 4, 8>), grid, dim3(512), 0, st, gg, x, dy, ws, (unsigned)xb,
+                          (unsigned)db);
+        HIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (bk == 32) {
         if (bm == 128 && bn == 128) WGD(128, 128, 32, 2);
         else if (bm == 64 && bn == 256) WGD(64, 256, 32, 2);

@@ -197,7 +197,8 @@ def test_srgan_two_images_per_rank_with_cross_replica_batchnorm_equals_the_full_
                 assert torch.allclose(v, b, rtol=2e-4, atol=2e-6), (n, k)
             else:
                 assert int(v) == int(b), (n, k)
-    # per-rank statistics are another computation: the first trunk BatchNorm's running variance moves away from the oracle's
-    k = "res_blocks.0.conv_block.1.running_var"
-    ref = dict(s.G.named_buffers())[k]
-    assert not torch.allclose(local["buffers"]["G"][k], ref, rtol=2e-4, atol=2e-6)
+    # per-rank statistics are another computation: some running statistic of the discriminator (BatchNorm2d with the default eps, on
+    # 2 images per rank) moves away from the oracle's by more than the bound above
+    moved = [k for k, b in s.D.named_buffers() if b.dtype.is_floating_point
+             and not torch.allclose(local["buffers"]["D"][k], b, rtol=2e-4, atol=2e-6)]
+    assert moved, "per-rank and cross-replica statistics cannot be told apart: the comparison above would be vacuous"
