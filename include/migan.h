@@ -516,6 +516,22 @@ int migan_adam_chunk(void);
 int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, unsigned* ticket,
                     const float* lr_dev, float lr, float b1, float b2, float eps, float grad_scale, void* stream);
 
+/* Weight-stationary Conv2d(64, 64, 3, 1, 1) (csrc/conv_c64.hip): the residual trunk of srgan/models.py:22-30,47 - forward, and with
+ * migan_c64_pack(flip = 1) the input gradient of the same layer (aten::convolution_backward's grad_input behind srgan.py:128).  The
+ * weights stay in registers, the input rows in an LDS ring: every input element enters a CU once.
+ * migan_c64_conv_ok: 1 when the kernel takes the geometry (W % 32 == 0, >= 1024 row-steps); wp: migan_c64_pack_floats() floats from
+ * migan_c64_pack(w_oihw [64][64][3][3]).
+ * in_scale / in_shift [64] (optional, both or neither): x is read through T(v) = in_act(v * in_scale[c] + in_shift[c]) - the
+ * BatchNorm2d(64, 0.8) -> PReLU of srgan/models.py:23-24 folded into the consumer conv's operand path (in_act = ACT_LRELU with the slope
+ * read from in_slope_ptr, or in_slope when in_slope_ptr == NULL); zero padding is applied after T.  accumulate != 0: y +=. */
+int migan_c64_conv_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int pad_b, int pad_r,
+                      int gather);
+size_t migan_c64_pack_floats(void);
+int migan_c64_pack(const float* w_oihw, float* wp, int flip, void* stream);
+int migan_c64_conv_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int act, float slope,
+                       int accumulate, const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                       const float* in_slope_ptr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

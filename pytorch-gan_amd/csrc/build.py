@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["conv_igemm.hip", "conv_dma.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "rgb_conv.hip", "image_pipeline.hip", "critic_fused.hip", "mlp_fused.hip", "fewpix.hip"]
+SOURCES = ["conv_igemm.hip", "conv_dma.hip", "norm.hip", "eltwise.hip", "reduce_loss_adam.hip", "classify.hip", "skinny_mm.hip", "thin_toeplitz.hip", "rgb_conv.hip", "image_pipeline.hip", "critic_fused.hip", "mlp_fused.hip", "fewpix.hip", "conv_c64.hip"]
 HEADERS = ["common.h", "conv_geom.h", "conv_valu_fwd.inc", "conv_wgrad_mfma.inc", "conv_valu_wgrad.inc"]   # .inc: pieces of conv_igemm.hip (same translation unit)
 OUT = os.path.join(HERE, "libmigan.so")
 STAMP = os.path.join(HERE, ".libmigan.stamp")

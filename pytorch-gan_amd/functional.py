@@ -638,6 +638,16 @@ def _fewpix_nt(a, w, b, out, M, N, K, act, slope, st, what):
     check(lib.migan_fewpix_nt(a.data_ptr(), w.data_ptr(), _ptr(b), out.data_ptr(), _ptr(ws), nb, M, N, K, act, slope, st), what)
 
 
+_C64 = __import__("os").environ.get("MIGAN_C64", "1") == "1"   # A/B knob (round 6): 0 = the general kernels for Conv2d(64, 64, 3, 1, 1)
+
+
+def _c64_pack(w, flip):
+    """Register-slice pack of an OIHW [64][64][3][3] weight for csrc/conv_c64.hip (flip = 1: the input-gradient form)."""
+    wp = torch.empty(lib.migan_c64_pack_floats(), device=w.device, dtype=torch.float32)
+    check(lib.migan_c64_pack(w.data_ptr(), wp.data_ptr(), int(flip), _stream()), "c64_pack")
+    return wp
+
+
 def _rgb_limits_ok(N, H, W, Ho, Wo, R, S, pt, pl, gather):
     """What migan_rgb_conv_fwd / _wgrad refuse beyond migan_rgb_conv_ok(): more images than grid.z holds, and reflection pads that
     reach past the image on either side.  Checked here so that such a layer falls through to the general kernels instead of raising."""
@@ -704,6 +714,16 @@ class _Conv2d(Function):
             check(lib.migan_rgb_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, Ci, Ho, Wo, Co, R, S, pt, pl,
                                          gather, act, slope, 0, _stream()), "rgb_conv_fwd")
             ctx.rgb = True
+            ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
+            return y
+        if (_C64 and mask is None and stats_buf is None and w.is_contiguous() and act in (ACT_NONE, ACT_LRELU, ACT_RELU)
+                and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
+            # Conv2d(64, 64, 3, 1, 1) on a large map (the residual trunk, srgan/models.py:22-30,47; vgg19.features[2]): the
+            # weight-stationary kernel - weights in registers, input rows in an LDS ring (csrc/conv_c64.hip)
+            wk = _packed(w_in, w, "c64f", lambda: _c64_pack(w, 0))
+            y = _empty_nhwc((N, Co, Ho, Wo), xs)
+            check(lib.migan_c64_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, act, slope, 0, None, None, 0, 0.0,
+                                         None, _stream()), "c64_conv_fwd")
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
             return y
         wp = _packed_perm(w_in, w, "ohwi", (0, 2, 3, 1))
@@ -871,8 +891,15 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
     correction on the side stream; join() makes the current stream wait for it."""
     N, H, W, Ci, Ho, Wo, Co, R, S, stride, pt, pl, pb, pr, gather, act, slope = ctx.geom
     st = _stream()
-    wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
     dx = _empty_nhwc((N, Ci, H, W), xs)
+    if (gather == GATHER_ZERO and _C64 and not ctx.relu_in and not ring_on_side and w.is_contiguous()
+            and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
+        # the input gradient of Conv2d(64, 64, 3, 1, 1) IS that convolution with the taps reversed and the channel roles swapped
+        wk = _packed(ctx.params[0], w, "c64d", lambda: _c64_pack(w, 1))
+        check(lib.migan_c64_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, None, None, 0, 0.0, None,
+                                     st), "c64_conv_dgrad")
+        return dx
+    wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
     if ring_on_side:
         skp, skb = _splitk_ws(dy, N * H * W, Ci, Co)
         check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), N, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, 0.0,

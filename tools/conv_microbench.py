@@ -189,6 +189,32 @@ def main():
                 calls["xwgrad"] = lambda: lib.migan_rgb_conv_wgrad(x.data_ptr(), dy.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(),
                                                                    wsx.data_ptr(), nbx, N, H, W, Ho, Wo, Co, k, k, p, p, gth, 1, 0.2, 0, 0, st)
                 dirs += ["xwgrad"]
+        if lib.migan_c64_conv_ok(N, H, W, Ci, Co, k, k, s, p, p, p, p, gth) == 1:
+            # weight-stationary 64 -> 64 kernel (csrc/conv_c64.hip): cfwd = forward, cdgrad = input gradient (flipped pack); both are checked
+            # against the general kernels' results here before they are timed
+            wo = w.view(Co, k, k, Ci).permute(0, 3, 1, 2).contiguous()   # `w` above is OHWI for the general forward: OIHW for the pack
+            wpf = torch.empty(lib.migan_c64_pack_floats(), device=dev)
+            wpd = torch.empty_like(wpf)
+            check(lib.migan_c64_pack(wo.data_ptr(), wpf.data_ptr(), 0, st), "c64 pack")
+            yc = torch.empty_like(y)
+            check(lib.migan_c64_conv_fwd(x.data_ptr(), wpf.data_ptr(), None, yc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, 0, 0.0, None, st), "c64")
+            check(calls["fwd"](), "fwd")
+            torch.cuda.synchronize()
+            print("   c64 fwd vs general kernel: rel %.2e" % float((yc - y).norm() / y.norm()))
+            # the general dgrad takes IHWO weights; interpret `w` as OIHW-permuted for a consistent pair: w_ihwo[i][r][s][o] := wo[o][i][r][s]
+            wi = wo.permute(1, 2, 3, 0).contiguous()
+            check(lib.migan_c64_pack(wo.data_ptr(), wpd.data_ptr(), 1, st), "c64 pack flip")
+            dxc = torch.empty_like(dx)
+            check(lib.migan_c64_conv_fwd(dy.data_ptr(), wpd.data_ptr(), None, dxc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, 0, 0.0, None, st), "c64d")
+            check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wi.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho, Wo, Co, k, k, s, pd, pd, 0, 0.0,
+                                            skp, skb, st), "dgrad")
+            torch.cuda.synchronize()
+            print("   c64 dgrad vs general kernel: rel %.2e" % float((dxc - dx).norm() / dx.norm()))
+            calls["cfwd"] = lambda: lib.migan_c64_conv_fwd(x.data_ptr(), wpf.data_ptr(), None, y.data_ptr(), N, H, W, 0, 0.0, 0, None, None,
+                                                           0, 0.0, None, st)
+            calls["cdgrad"] = lambda: lib.migan_c64_conv_fwd(dy.data_ptr(), wpd.data_ptr(), None, dx.data_ptr(), N, H, W, 0, 0.0, 0, None,
+                                                             None, 0, 0.0, None, st)
+            dirs += ["cfwd", "cdgrad"]
         if Co <= 3 and lib.migan_rgb_conv_ok(Co, Ci, k, k, s, gth, N * H * W) == 1 and p == 1 and gth == 0:
             # thin-OUTPUT layer (dcgan.py:62): odgrad = its input gradient on the image-input forward kernel, taps reversed
             wko = w.view(Co, Ci, k, k).permute(2, 3, 0, 1).contiguous()
@@ -205,7 +231,7 @@ def main():
             elif d[0] == "t" and d[1:] in ("fwd", "wgrad", "dgrad"):
                 if d[1:] not in only:
                     continue
-            elif d.lstrip("urxo") not in only and not (d == "fold" and "dgrad" in only):
+            elif d.lstrip("urxoc") not in only and not (d == "fold" and "dgrad" in only):
                 continue
             fn = calls[d]
             if plog:
