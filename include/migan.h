@@ -528,6 +528,9 @@ int migan_c64_conv_ok(int N, int H, int W, int Ci, int Co, int R, int S, int str
                       int gather);
 size_t migan_c64_pack_floats(void);
 int migan_c64_pack(const float* w_oihw, float* wp, int flip, void* stream);
+/* every such layer of a step in one launch: tab = device array of n records {const float* w_oihw; float* wp_fwd; float* wp_dgrad}
+ * (a pack pointer may be NULL) */
+int migan_c64_pack_multi(const void* tab, int n, void* stream);
 int migan_c64_conv_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int act, float slope,
                        int accumulate, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                        const float* in_slope_ptr, void* stream);

@@ -54,6 +54,15 @@ __device__ __forceinline__ bool map_coord(int v, int L, int mode, int& src) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Integer A/B knob from the environment, read ONCE per call site - unless MIGAN_TEST_KNOBS is set when the library is first used: then every
+// call re-reads it, so that one test process can run a kernel family under several settings (tests/conftest.py sets it).
+#define MIGAN_KNOB(name, dflt)                                                                       \
+    ([]() -> int {                                                                                   \
+        static const bool dyn__ = getenv("MIGAN_TEST_KNOBS") != nullptr;                            \
+        static const int cached__ = getenv(name) ? atoi(getenv(name)) : (dflt);                      \
+        return dyn__ ? (getenv(name) ? atoi(getenv(name)) : (dflt)) : cached__;                      \
+    }())
+
 // q = n / d for 0 <= n < 2^31 without a divide: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery, s = ceil(log2 d))
 static inline void fastdiv_magic(unsigned d, unsigned& m, int& s) {
     s = 0;

@@ -51,6 +51,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p, unsign
 // TAPS_IN: 1 = tap-outer K order (tap, then 32-channel chunks), 4 = channel-chunk outer / tap inner for classes of
 // exactly 4 taps (collapsed up-conv forward, 4x4 stride-2 dgrad): the 4 taps' A tiles of one channel chunk overlap by all
 // but one pixel row/column and are fetched back to back (L2 hits) - see igemm_pipe_kernel.
+// 9 = the same order for 3x3 kernels (one class, nine taps).  Tap-outer, a tile's nine A tiles are the same pixels +-1 re-read 9 x (Ci / BK)
+// K-tiles apart - with 160 workgroups per XCD walking 131 KB each per tap (256 channels) nothing is left in the 4 MB L2: SRGAN's
+// dgrad 64 -> 256 @192 moved 5.93 GB for a 0.755 GB problem (7.9 x, profiles/r05_pmc_kernels.json) and ran at HBM speed, not at the MFMA
+// rate.  Channel-chunk outer, the nine fetches of one 64-byte channel slice of the tile's pixel neighbourhood follow each other.
 // NS: LDS stages.  2 = tile kt+1 is fetched while tile kt is multiplied, `vmcnt(0)` + barrier per K-tile (what the
 // compiler emits for __syncthreads() with an LDS-DMA in flight) - right whenever several workgroups share a CU.  NS > 2:
 // NS-1 tiles in flight, COUNTED `s_waitcnt vmcnt((NS-2) * loads per tile)` + raw s_barrier, so the DMA queue is never
@@ -242,7 +246,19 @@ __global__ __launch_bounds__(256, OCC) void igemm_dma_kernel(const ConvGeom g, c
             __syncthreads();  // (the compiler drains the LDS-DMA queue, vmcnt(0), in front of the barrier)
         };
         if (KT > 0) __syncthreads();
-        if (TAPS_IN > 1) {
+        if (TAPS_IN == 9) {
+            for (int kt = 0; kt < KT; kt += 9) {
+                k_tile(kt, std::integral_constant<int, 1 % TAPS_IN>{});
+                k_tile(kt + 1, std::integral_constant<int, 2 % TAPS_IN>{});
+                k_tile(kt + 2, std::integral_constant<int, 3 % TAPS_IN>{});
+                k_tile(kt + 3, std::integral_constant<int, 4 % TAPS_IN>{});
+                k_tile(kt + 4, std::integral_constant<int, 5 % TAPS_IN>{});
+                k_tile(kt + 5, std::integral_constant<int, 6 % TAPS_IN>{});
+                k_tile(kt + 6, std::integral_constant<int, 7 % TAPS_IN>{});
+                k_tile(kt + 7, std::integral_constant<int, 8 % TAPS_IN>{});
+                k_tile(kt + 8, std::integral_constant<int, 0>{});
+            }
+        } else if (TAPS_IN > 1) {
             for (int kt = 0; kt < KT; kt += 4) {
                 k_tile(kt, std::integral_constant<int, 1 % TAPS_IN>{});
                 k_tile(kt + 1, std::integral_constant<int, 2 % TAPS_IN>{});
@@ -450,12 +466,18 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     bool tapin = true;
     for (int c = 0; tapin && c < g.ncls; ++c) tapin = g.ntap[c] == 4;
     const bool ktail = g.Ci % BK != 0;
+    // nine taps inner: stride-1 3x3 layers on large maps whose source has more channels than one K-tile (MIGAN_DMA_TAPS9=0: tap-outer, A/B knob)
+    // (2 = also below 65 536 pixels: the parity tests run small shapes through this order)
+    const int taps9_env = MIGAN_KNOB("MIGAN_DMA_TAPS9", 1);
+    const bool tap9 = taps9_env && g.ncls == 1 && g.ntap[0] == 9 && !ktail && g.Ci >= 2 * BK && (maxM >= 65536 || taps9_env == 2);
     // (Three LDS stages with counted waits - two K-tiles in flight, one workgroup of occupancy less - were measured on whole steps for
     // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
 #define DMA_LAUNCH(TI_, KT_)                                                                                         \
     MIGAN_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, BK, TI_, KT_, OCC>), grid, dim3(256), 0, st, g, A, Bw, bias, C, \
                        a_bytes, b_bytes)
-    if (tapin) {
+    if (tap9) {
+        DMA_LAUNCH(9, false);
+    } else if (tapin) {
         if (ktail) DMA_LAUNCH(4, true); else DMA_LAUNCH(4, false);
     } else {
         if (ktail) DMA_LAUNCH(1, true); else DMA_LAUNCH(1, false);
@@ -612,6 +634,9 @@ int launch_igemm_dma(const ConvGeom& g_in, const float* A, const float* Bw, cons
         // reuse: 70 us forward, the step 39.2 vs 35.2 ms, profiles/r05_ab.txt call 14.  Neither occupancy nor L2 -> LDS traffic is what
         // holds this launch back; removed.)
     }
+    // (Four LDS stages without a K split for launches of at most one 64 x 64 tile per CU - CycleGAN's trunk at one image: 256 tiles x 72 K-tiles -
+    // were measured in round 6: 54.0 vs 54.2 us stand-alone, the recorded step 33.7 vs 32.7 ms: more K-tiles in flight do not help, the launch
+    // is bound by the CU's operand path (16 KB per K-tile against 1024 MFMA clocks), not by the latency of one fetch.)
     switch (dma_select(maxM, g.Co, g.ncls)) {
 #define DMA_CASE(BK_, BM_, BN_, WM_, WN_, OCC_) \
     case BK_ * 1000000 + BM_ * 1000 + BN_:      \

@@ -421,16 +421,18 @@ class _PackPlan:
             prev, self.scope, self.seq = self.seq, scope, {}
             if prev:
                 self._prefill(prev, w.device)
-        self.seq[(id(param), kind)] = (__import__("weakref").ref(param), kind, tuple(perm))
+        self.seq[(id(param), kind)] = (__import__("weakref").ref(param), kind, perm if isinstance(perm, str) else tuple(perm))
 
     def _prefill(self, prev, device):
         import numpy as np
 
-        live = []
+        live, c64 = [], []
         for ref, kind, perm in prev.values():
             p = ref()
             if p is not None and on_device(p) and p.dtype == torch.float32 and p.is_contiguous():
-                live.append((p, kind, perm))
+                (c64 if perm == "c64" else live).append((p, kind, perm))
+        if c64:
+            self._prefill_c64([p for p, _, _ in c64], device)
         if not live:
             return
         sig = tuple((p.data_ptr(), tuple(p.shape), kind, perm) for p, kind, perm in live)
@@ -465,6 +467,39 @@ class _PackPlan:
             off += n
             stamp = (_CACHE_SCOPE, getattr(p, "_migan_epoch", None), p._version, p.data_ptr())
             p.__dict__.setdefault("_migan_pack", {})[kind] = (stamp, view)
+
+
+def _prefill_c64(self, params, device):
+    """Both register-slice packs (forward, input gradient) of every Conv2d(64, 64, 3, 1, 1) weight the last step used, from ONE launch
+    (csrc/conv_c64.hip c64_pack_multi_kernel): table and arena are rebuilt only when the set of weights changes."""
+    import numpy as np
+
+    n1 = lib.migan_c64_pack_floats()
+    sig = tuple(p.data_ptr() for p in params)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if sig != getattr(self, "c64_sig", None):
+        if capturing:
+            return
+        if getattr(self, "c64_captured", False):
+            _PackPlan.keep_alive.append((self.c64_tab, self.c64_arena))
+            self.c64_captured = False
+        self.c64_arena = torch.empty(2 * n1 * len(params), device=device, dtype=torch.float32)
+        ent = np.zeros((len(params), 3), dtype=np.uint64)
+        for i, p in enumerate(params):
+            base = self.c64_arena.data_ptr() + 4 * (2 * i) * n1
+            ent[i] = (p.data_ptr(), base, base + 4 * n1)
+        self.c64_tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
+        self.c64_sig = sig
+    self.c64_captured = getattr(self, "c64_captured", False) or capturing
+    check(lib.migan_c64_pack_multi(self.c64_tab.data_ptr(), len(params), _stream()), "c64_pack_multi")
+    for i, p in enumerate(params):
+        stamp = (_CACHE_SCOPE, getattr(p, "_migan_epoch", None), p._version, p.data_ptr())
+        cache = p.__dict__.setdefault("_migan_pack", {})
+        cache["c64f"] = (stamp, self.c64_arena[2 * i * n1:(2 * i + 1) * n1])
+        cache["c64d"] = (stamp, self.c64_arena[(2 * i + 1) * n1:(2 * i + 2) * n1])
+
+
+_PackPlan._prefill_c64 = _prefill_c64
 
 
 def prefill_packs(device):
@@ -641,6 +676,13 @@ def _fewpix_nt(a, w, b, out, M, N, K, act, slope, st, what):
 _C64 = __import__("os").environ.get("MIGAN_C64", "1") == "1"   # A/B knob (round 6): 0 = the general kernels for Conv2d(64, 64, 3, 1, 1)
 
 
+def _packed_c64(param, w, flip):
+    """The forward (flip = 0) / input-gradient (flip = 1) register-slice pack of a Conv2d(64, 64, 3, 1, 1) weight: from the step's one
+    multi-tensor launch when planned (the plan learns the layer here), else its own launch."""
+    _PackPlan.get(w.device).note(param, w, "c64", "c64")
+    return _packed(param, w, "c64d" if flip else "c64f", lambda: _c64_pack(w, flip))
+
+
 def _c64_pack(w, flip):
     """Register-slice pack of an OIHW [64][64][3][3] weight for csrc/conv_c64.hip (flip = 1: the input-gradient form)."""
     wp = torch.empty(lib.migan_c64_pack_floats(), device=w.device, dtype=torch.float32)
@@ -720,7 +762,7 @@ class _Conv2d(Function):
                 and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
             # Conv2d(64, 64, 3, 1, 1) on a large map (the residual trunk, srgan/models.py:22-30,47; vgg19.features[2]): the
             # weight-stationary kernel - weights in registers, input rows in an LDS ring (csrc/conv_c64.hip)
-            wk = _packed(w_in, w, "c64f", lambda: _c64_pack(w, 0))
+            wk = _packed_c64(w_in, w, 0)
             y = _empty_nhwc((N, Co, Ho, Wo), xs)
             check(lib.migan_c64_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, act, slope, 0, None, None, 0, 0.0,
                                          None, _stream()), "c64_conv_fwd")
@@ -895,7 +937,7 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
     if (gather == GATHER_ZERO and _C64 and not ctx.relu_in and not ring_on_side and w.is_contiguous()
             and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
         # the input gradient of Conv2d(64, 64, 3, 1, 1) IS that convolution with the taps reversed and the channel roles swapped
-        wk = _packed(ctx.params[0], w, "c64d", lambda: _c64_pack(w, 1))
+        wk = _packed_c64(ctx.params[0], w, 1)
         check(lib.migan_c64_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, None, None, 0, 0.0, None,
                                      st), "c64_conv_dgrad")
         return dx

@@ -562,6 +562,15 @@ def test_step_parity_bodies_on_the_execution_model(name, args):
             assert lib.hipemu_launch_count(sym) > 0, sym
 
 
+@pytest.mark.parametrize("idx", [0, 2, 3])
+def test_conv3x3_tap_inner_k_order_on_the_execution_model(idx, monkeypatch):
+    """test_ops_gpu.py::test_conv3x3_tap_inner_k_order without a GPU: the nine-taps-inner K order of igemm_dma_kernel (TAPS_IN = 9) and the
+    tap-outer order on the same shapes - reflection gather on 128 x 128 tiles, stride 2, ragged M / N."""
+    import test_ops_gpu
+
+    _run_gpu_test_body("test_ops_gpu", "test_conv3x3_tap_inner_k_order", __import__("pytorch_gan_amd"), test_ops_gpu.TAP9_CASES[idx], monkeypatch)
+
+
 def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monkeypatch):
     """SURVEY.md 8e with real kernels and no GPU: the body of test_dp_gpu.py::test_cross_replica_batchnorm_equals_full_batch -
     two torch.distributed.run ranks (gloo) each run half of a DCGAN batch with enable_sync_batchnorm() (local moments ->

@@ -103,6 +103,40 @@ def test_conv2d_fwd_bwd(pg, case):
         assert_close(bg.grad, b.grad, TOL_BIAS, "conv bias grad")
 
 
+TAP9_CASES = [   # (more than 128 tiles of 64 x 64: below that the split-K form of the kernel - tap-outer only - takes the layer)
+    (2, 64, 48, 48, 128, 1, 1, "ReflectionPad2d(1)+Conv3x3 (cyclegan/models.py:26-33)"),
+    (2, 64, 48, 48, 128, 1, 0, "zero pad"),
+    (2, 64, 96, 96, 128, 2, 0, "srgan/models.py:89 stride-2 block"),
+    (3, 96, 40, 36, 80, 1, 0, "ragged M / N"),
+]
+
+
+@pytest.mark.parametrize("case", TAP9_CASES, ids=["ci%d_co%d_s%d_g%d" % (c[1], c[4], c[5], c[6]) for c in TAP9_CASES])
+def test_conv3x3_tap_inner_k_order(pg, case, monkeypatch):
+    """3x3 layers on the LDS-DMA kernel in both K orders - tap-outer (MIGAN_DMA_TAPS9=0) and channel-chunk outer / nine taps inner (= 2: also
+    below the 65 536-pixel gate of production) - forward and input gradient against torch, and the launch counters say the nine-tap
+    instantiation really served the second run (csrc/conv_dma.hip TAPS_IN = 9; dcgan / cyclegan / srgan / vgg19 3x3 layers at size)."""
+    N, Ci, H, W, Co, stride, gather, _ = case
+    F = pg.functional
+    pads = (1, 1, 1, 1)
+    x = _leaf(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = _leaf(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+    y_ref = TF.conv2d(_ref_gather(x, pads, gather), w, None, stride)
+    gy = _leaf(*y_ref.shape, seed=4)
+    y_ref.backward(gy)
+    for knob in ("0", "2"):
+        monkeypatch.setenv("MIGAN_DMA_TAPS9", knob)
+        xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+        with Launches() as nl:
+            y = F.conv2d(xg, wg, None, stride, pads, gather, 0, 0.0)
+            y.backward(gy.to(DEV))
+            nine = nl(", 9, false")   # igemm_dma_kernel<BM, BN, WM, WN, BK, 9, false, ...>
+        assert (nine >= 1) == (knob == "2"), (knob, nine)
+        assert_close(y, y_ref, TOL_FWD, "conv fwd, TAPS9=" + knob)
+        assert_close(xg.grad, x.grad, TOL_FWD, "conv dgrad, TAPS9=" + knob)
+        assert_close(wg.grad, w.grad, TOL_WGRAD, "conv wgrad, TAPS9=" + knob)
+
+
 RGB_CASES = [
     # N, H, W, Co, k, pad, gather, act, what
     (1, 110, 150, 64, 3, 1, 0, 1, "srgan/models.py:85 Conv2d(3,64,3,1,1)+LeakyReLU, ragged row tiles"),

@@ -112,6 +112,17 @@ task_micro() {
   timeout 600 python tools/conv_microbench.py "$@" 2>&1 | tee -a $O/micro.txt | grep " us " | cut -c1-160
 }
 
+# same-box A/B of environment knobs on the tree itself:  abenv <outdir> <workload> <steps> <reps> [--flag ...] -- ENV=a ENV=b ...
+task_abenv() {
+  local O=gpurun_out/${1:-r6ab}; local w=$2 k=$3 reps=$4; shift 4; mkdir -p $O
+  local flags=()
+  while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
+  for r in $(seq $reps); do
+    for e in "$@"; do bl $O/bench.txt $w $k $e "${flags[@]}"; done
+  done
+  cat $O/bench.txt
+}
+
 t=${1:-}; shift || true
 case "$t" in
   prof) task_prof "$@" ;;
