@@ -469,7 +469,11 @@ static int launch_dma_cfg(const ConvGeom& g, const float* A, const float* Bw, co
     // nine taps inner: stride-1 3x3 layers on large maps whose source has more channels than one K-tile (MIGAN_DMA_TAPS9=0: tap-outer, A/B knob)
     // (2 = also below 65 536 pixels: the parity tests run small shapes through this order)
     const int taps9_env = MIGAN_KNOB("MIGAN_DMA_TAPS9", 1);
-    const bool tap9 = taps9_env && g.ncls == 1 && g.ntap[0] == 9 && !ktail && g.Ci >= 2 * BK && (maxM >= 65536 || taps9_env == 2);
+    // Measured per layer (profiles/r06_ab.txt call 14): 64 -> 256 @192 input gradient 1313 -> 1242 us, vgg 64 -> 64 @384 1430 / 1394 -> 1358 / 1338 us;
+    // neutral at 256 channels on 64 x 64 / 96 x 96 maps (their pixel neighbourhoods stay in L2 either way); SLOWER for the stride-2 blocks
+    // (128 -> 128 @192: 343 -> 368 us) and for 64 x 64 tiles on 96 x 96 maps (106 -> 126 us) - so: stride 1, maps of >= 262 144 pixels.
+    const bool tap9 = taps9_env && g.ncls == 1 && g.ntap[0] == 9 && !ktail && g.Ci >= 2 * BK &&
+                      ((g.istride == 1 && g.ostep == 1 && maxM >= 262144) || taps9_env == 2);
     // (Three LDS stages with counted waits - two K-tiles in flight, one workgroup of occupancy less - were measured on whole steps for
     // the tap-outer BK = 16 tiles and rejected: DCGAN -0.9 %, CycleGAN -1.6 %, SRGAN -2.8 %, profiles/r04_ab.txt.)
 #define DMA_LAUNCH(TI_, KT_)                                                                                         \
