@@ -182,6 +182,7 @@ _SIGS = {
     "migan_norm_small_ok": (c_int, [c_int, c_int, c_int]),
     "migan_norm_fwd_small": (c_int, [P] * 8 + [c_int] * 4 + [c_float, c_float, P]),
     "migan_norm_bwd_small": (c_int, [P] * 8 + [c_int] * 4 + [c_float, P, P]),
+    "migan_zero": (c_int, [P, c_size_t, P]),
     "migan_adam_chunk": (c_int, []),
     "migan_adam_step": (c_int, [P, P, c_int, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
 }

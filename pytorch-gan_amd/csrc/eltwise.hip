@@ -720,3 +720,9 @@ MIGAN_API int migan_multi_permute4d(const void* entries, const void* blocks, int
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// p[0 .. bytes) = 0 on `stream` (a memset node when captured): optim.Adam.zero_grad() on the flat gradient bucket (dcgan.py:157,175).
+MIGAN_API int migan_zero(void* p, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    return (int)hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+}

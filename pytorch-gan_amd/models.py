@@ -163,7 +163,8 @@ class CycleResidualBlock(nn.Module):
                              ("rpad", 1), ("conv", c, c, 3, 1, 0), ("in2", c)])
 
     def forward(self, x):
-        return self.block(x, res=x)   # x + self.block(x), the add inside the last InstanceNorm launch
+        a, b = F.fork2(x)   # the block's input has two consumers: their gradients meet in the library's add, not in autograd's
+        return self.block(a, res=b)   # x + self.block(x), the add inside the last InstanceNorm launch
 
 
 class CycleGenerator(nn.Module):
@@ -250,9 +251,14 @@ class Pix2pixGenerator(nn.Module):
         self.final = _build([("up2",), ("zpad", (1, 0, 1, 0)), ("conv", 128, out_channels, 4, 1, 1), ("tanh",)])
 
     def forward(self, x):
-        d = [x]
+        d, cur = [x], x
         for i in range(1, 9):
-            d.append(getattr(self, "down%d" % i)(d[-1]))
+            cur = getattr(self, "down%d" % i)(cur)
+            if i < 8:   # d1 .. d7 feed the next level AND a skip connection (pix2pix/models.py:84-98)
+                cur, skip = F.fork2(cur)
+                d.append(skip)
+            else:
+                d.append(cur)
         u = d[8]
         for i in range(1, 8):
             u = getattr(self, "up%d" % i)(u, d[8 - i])
@@ -299,7 +305,8 @@ class SrganResidualBlock(nn.Module):
                                   ("conv", c, c, 3, 1, 1), ("bn2", c, 0.8)])
 
     def forward(self, x):
-        return self.conv_block(x, res=x)   # x + self.conv_block(x), the add inside the last BatchNorm launch
+        a, b = F.fork2(x)
+        return self.conv_block(a, res=b)   # x + self.conv_block(x), the add inside the last BatchNorm launch
 
 
 class SrganGenerator(nn.Module):
@@ -312,9 +319,9 @@ class SrganGenerator(nn.Module):
         self.conv3 = _build([("conv", 64, out_channels, 9, 1, 4), ("tanh",)])
 
     def forward(self, x):
-        o1 = self.conv1(x)
+        o1, o1s = F.fork2(self.conv1(x))
         o2 = self.conv2(self.res_blocks(o1))
-        return self.conv3(self.upsampling(torch.add(o1, o2)))
+        return self.conv3(self.upsampling(torch.add(o1s, o2)))
 
 
 class SrganDiscriminator(nn.Module):

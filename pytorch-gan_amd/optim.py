@@ -108,7 +108,12 @@ class Adam:
         """Zero the flat bucket.  Deviation from torch: grads stay views of the bucket (`set_to_none` is accepted for
         API parity and ignored), because the wgrad kernels and the all-reduce work on the bucket in place."""
         self.wait_pending()  # a side-stream update may still be reading the bucket
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            from . import functional as F
+
+            F.zero_(self.flat_grad)   # hipMemsetAsync through the C ABI (torch's fill is an ATen kernel)
+        else:
+            self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:

@@ -1041,6 +1041,10 @@ def make_pix2pix_state(G, D, img_size=256, skip_dead_grads=True, dp=None):
 @_scoped
 def pix2pix_step(s, real_A, real_B):
     """pix2pix.py:123-172 (real_A = condition image, real_B = target)."""
+    # the batch as activations of this package (NHWC, GanTensor): `torch.cat((img_A, img_B), 1)` of pix2pix/models.py:132 then runs on the
+    # library's concat kernel for the real pair as well (plain tensors took ATen's), and the condition image is re-laid once, not per pass
+    if F.on_device(real_A) and real_A.dim() == 4:
+        real_A, real_B = gnn._wrap(F.to_nhwc(real_A)), gnn._wrap(F.to_nhwc(real_B))
     valid, fake = _labels(s, (real_A.size(0), *s.patch), real_A.device)
     s.dp.begin_step()
     s.opt_G.zero_grad()

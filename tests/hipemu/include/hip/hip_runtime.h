@@ -73,6 +73,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }   // the model is one device
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }   // streams are synchronous here
 
 #define __global__
 #define __device__

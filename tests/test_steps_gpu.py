@@ -1076,3 +1076,52 @@ def test_device_replay_buffer_matches_reference_logic():
             assert got.shape == want.shape and torch.equal(got.cpu(), want), (max_size, call)
         assert len(dev) == len(ref.data)
         assert torch.equal(torch.cat(dev.samples()).cpu(), torch.cat(ref.data))
+
+
+@pytest.mark.parametrize("name", ["dcgan", "cyclegan", "srgan", "pix2pix"])
+def test_step_bodies_launch_no_aten_kernels(name):
+    """"every layer forward / backward runs in hand-written HIP kernels" checked on the device's own record.  One eager step
+    of each image workload on the PRODUCT models (pytorch_gan_amd.models, what bench.py times) under torch.profiler: no kernel of the step may
+    come from ATen (`at::native::*`: autograd's gradient accumulation where a tensor has two consumers - functional.fork2 -, torch.cat on plain
+    inputs, the buckets' zero fill - migan_zero) or from a vendor library.  dcgan.py:143-183, cyclegan.py:159-239, srgan.py:97-145,
+    pix2pix.py:123-172."""
+    import random
+
+    from torch.profiler import ProfilerActivity, profile
+
+    from pytorch_gan_amd import models, steps
+
+    torch.manual_seed(0)
+    random.seed(0)
+    if name == "dcgan":
+        G, D = models.DcganGenerator(32, 100, 1).to(DEV), models.DcganDiscriminator(32, 1).to(DEV)
+        s = steps.make_gan_state(G, D)
+        x, z = (torch.rand(8, 1, 32, 32) * 2 - 1).to(DEV), torch.randn(8, 100).to(DEV)
+        run = lambda: steps.dcgan_step(s, x, z)   # noqa: E731
+    elif name == "cyclegan":
+        shape = (3, 64, 64)
+        nets = [models.CycleGenerator(shape, 2).to(DEV), models.CycleGenerator(shape, 2).to(DEV), models.CycleDiscriminator(shape).to(DEV),
+                models.CycleDiscriminator(shape).to(DEV)]
+        s = steps.make_cyclegan_state(*nets)
+        a, b = (torch.rand(2, *shape) * 2 - 1).to(DEV), (torch.rand(2, *shape) * 2 - 1).to(DEV)
+        run = lambda: steps.cyclegan_step(s, a, b)   # noqa: E731
+    elif name == "srgan":
+        G, D, V = models.SrganGenerator(3, 3, 2).to(DEV), models.SrganDiscriminator((3, 64, 64)).to(DEV), models.SrganFeatureExtractor().to(DEV)
+        s = steps.make_srgan_state(G, D, V)
+        lr, hr = torch.randn(2, 3, 16, 16).to(DEV), torch.randn(2, 3, 64, 64).to(DEV)
+        run = lambda: steps.srgan_step(s, lr, hr)   # noqa: E731
+    else:
+        G, D = models.Pix2pixGenerator().to(DEV), models.Pix2pixDiscriminator().to(DEV)
+        s = steps.make_pix2pix_state(G, D, 256)
+        a, b = (torch.rand(1, 3, 256, 256) * 2 - 1).to(DEV), (torch.rand(1, 3, 256, 256) * 2 - 1).to(DEV)
+        run = lambda: steps.pix2pix_step(s, a, b)   # noqa: E731
+    for _ in range(2):   # first steps: label tensors, plans, workspaces
+        run()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
+    assert any("_kernel" in n for n in names), names[:5]   # the library's kernels are in the record
+    foreign = sorted({n for n in names if any(t in n for t in ("at::native", "at::cuda", "at_cuda_detail", "rocprim", "hipcub", "Cijk_", "MIOpen"))})
+    assert not foreign, "%s step launched kernels that are not the library's: %s" % (name, foreign)
