@@ -709,6 +709,28 @@ def _safe_cpu_baseline(init):
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
+def run_strong(other, global_batch, k, wu, dp, rank, dev, args, world):
+    """N > 1: `other` at a FIXED global batch sharded over the ranks (strong scaling) beside the headline's weak-scaling line, so that one
+    `bench.py --gpus N` launch yields both figures.  Every rank runs it (the step contains the bucket all-reduces); rank 0 reports."""
+    w = None
+    try:
+        if global_batch % world:
+            return {"skipped": "global batch %d is not divisible by %d ranks" % (global_batch, world)}
+        ns = argparse.Namespace(**vars(args))
+        ns.batch = global_batch // world
+        w = BUILDERS[other](dp, rank, dev, ns, wu + k)
+        blocks, out = timed_blocks(w, world, dev, k, wu, 1.0, max_blocks=6)
+        summ = summarise(other, w.batch, world, k, blocks)
+        return {"images_per_s": summ["images_per_s"], "ms_per_step": summ["ms_per_step"], "scaling": "strong", "global_batch": global_batch,
+                "per_gpu_batch": w.batch, "n_gpus": world, "workload": WORKLOAD_NAME[other], "steps": k, "warmup": wu, "hipgraph": w.graphed,
+                "blocks": summ["blocks"], "losses": {kk: float(v) for kk, v in out.items() if "loss" in kk}}
+    except Exception as ex:  # noqa: BLE001 - deterministic failures (shapes, memory) hit every rank alike
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    finally:
+        del w
+        torch.cuda.empty_cache()
+
+
 def run_extra(other, k, wu, dp, rank, dev, args, batch=0, eager_too=False):
     """One of the other BASELINE configs, briefly (headline section only), after the headline workload has been released.
     `batch`: per-GPU batch other than the config's (cyclegan at 1 image per GPU = the shard of the 8-GPU configuration);
@@ -919,6 +941,12 @@ def main():
         result["config"]["batch_slicing"] = "one globally seeded draw of the global batch, sliced by rank"
         if exchange:
             result["exchange"] = exchange
+        if name == "dcgan" and not args.no_extra and not args.global_batch:
+            # BASELINE.json configs[3] as written - CycleGAN 256x256 at a GLOBAL batch of 8 over the N GPUs (one image per GPU at N = 8) - next
+            # to the weak-scaling headline: strong scaling from the same launch
+            del w, out
+            torch.cuda.empty_cache()
+            result["extra"] = {"cyclegan_global_batch_8": run_strong("cyclegan", 8, 4, 2, dp, rank, dev, args, world)}
     if rank == 0 and world == 1 and name == "dcgan" and not args.no_extra:
         # the other GPU configs of BASELINE.json, briefly (north_star names CycleGAN 256x256 bs 8 as the second target)
         init = w.init
@@ -934,6 +962,8 @@ def main():
         # config 4's per-GPU shard at N = 8: one image per GPU (= the reference's default batch, cyclegan.py:28) - the recorded step
         # beside the same step launched kernel by kernel
         extra["cyclegan_bs1"] = run_extra("cyclegan", 10, 3, dp, rank, dev, args, batch=1, eager_too=True)
+        # config 5's per-GPU shard at N = 8: two images per GPU (row N3; with cross-replica BatchNorm at N > 1: --sync-bn)
+        extra["srgan_bs2"] = run_extra("srgan", 10, 3, dp, rank, dev, args, batch=2)
     elif rank == 0 and world == 1 and name == "dcgan" and not args.no_cpu_baseline:
         result["cpu_baseline"] = _safe_cpu_baseline(w.init)
     if rank == 0:
