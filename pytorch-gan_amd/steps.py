@@ -919,14 +919,16 @@ def cyclegan_step(s, real_A, real_B):
                     id_A = s.l1(s.G_BA(real_A), real_A)
                     with torch.cuda.stream(side):
                         id_B = s.l1(s.G_AB(real_B), real_B)
-                    fake_B = s.G_AB(real_A)
+                    # (fake_B / fake_A feed a discriminator AND the other generator: functional.fork2 - their two gradients meet in the
+                    # library's add, not in autograd's ATen accumulation)
+                    fake_B, fake_B2 = F.fork2(s.G_AB(real_A))
                     loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
                     with torch.cuda.stream(side):
-                        fake_A = s.G_BA(real_B)
+                        fake_A, fake_A2 = F.fork2(s.G_BA(real_B))
                         loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
-                    cyc_A = s.l1(s.G_BA(fake_B), real_A)
+                    cyc_A = s.l1(s.G_BA(fake_B2), real_A)
                     with torch.cuda.stream(side):
-                        cyc_B = s.l1(s.G_AB(fake_A), real_B)
+                        cyc_B = s.l1(s.G_AB(fake_A2), real_B)
             finally:
                 main.wait_stream(side)
             loss_id = half_sum(id_A, id_B)
@@ -935,12 +937,12 @@ def cyclegan_step(s, real_A, real_B):
         else:
             loss_id = half_sum(s.l1(s.G_BA(real_A), real_A), s.l1(s.G_AB(real_B), real_B))
             with frozen(s.D_A, s.D_B, enabled=s.skip):
-                fake_B = s.G_AB(real_A)
+                fake_B, fake_B2 = F.fork2(s.G_AB(real_A))
                 loss_GAN_AB = s.mse(s.D_B(fake_B), valid)
-                fake_A = s.G_BA(real_B)
+                fake_A, fake_A2 = F.fork2(s.G_BA(real_B))
                 loss_GAN_BA = s.mse(s.D_A(fake_A), valid)
             loss_GAN = half_sum(loss_GAN_AB, loss_GAN_BA)
-            loss_cycle = half_sum(s.l1(s.G_BA(fake_B), real_A), s.l1(s.G_AB(fake_A), real_B))
+            loss_cycle = half_sum(s.l1(s.G_BA(fake_B2), real_A), s.l1(s.G_AB(fake_A2), real_B))
         loss_G = F.axpby(F.axpby(loss_GAN, loss_cycle, 1.0, s.lambda_cyc), loss_id, 1.0, s.lambda_id)
         if under:
             # both discriminator updates underneath the generators' backward (see dcgan_step): they need fake_A / fake_B of the forward
@@ -1048,10 +1050,10 @@ def pix2pix_step(s, real_A, real_B):
     valid, fake = _labels(s, (real_A.size(0), *s.patch), real_A.device)
     s.dp.begin_step()
     s.opt_G.zero_grad()
-    fake_B = s.G(real_A)
+    fake_B, fake_B2 = F.fork2(s.G(real_A))   # two consumers (discriminator, pixel loss)
     with frozen(s.D, enabled=s.skip):
         loss_GAN = s.mse(s.D(fake_B, real_A), valid)
-    loss_pixel = s.l1(fake_B, real_B)
+    loss_pixel = s.l1(fake_B2, real_B)
     loss_G = F.axpby(loss_GAN, loss_pixel, 1.0, s.lambda_pixel)
 
     def d_half():   # pix2pix.py:151-165 up to loss_D.backward()
@@ -1104,10 +1106,10 @@ def srgan_step(s, imgs_lr, imgs_hr):
             if vside:
                 with torch.cuda.stream(side), torch.no_grad():
                     real_features = s.V(imgs_hr)
-            gen_hr = s.G(imgs_lr)
+            gen_hr, gen_hr2 = F.fork2(s.G(imgs_lr))   # two consumers (discriminator, VGG): their gradients meet in the library's add
             with frozen(s.D, s.V, enabled=s.skip):
                 loss_GAN = s.mse(s.D(gen_hr), valid)
-                gen_features = s.V(gen_hr)
+                gen_features = s.V(gen_hr2)
     finally:
         if vside:
             main.wait_stream(side)   # join - also when a forward raised: no stream stays forked
