@@ -1551,6 +1551,7 @@ class _PReLU(Function):
     @staticmethod
     def forward(ctx, x, a):
         xs = canon(x)
+        ctx.param = a
         a = _plain(a)
         if a.numel() != 1:
             raise ValueError("PReLU: only the single shared slope of nn.PReLU() is supported")
@@ -1569,6 +1570,10 @@ class _PReLU(Function):
         ws = _ws(lib.migan_reduce_workspace(), xs)
         check(lib.migan_prelu_bwd(xs.data_ptr(), g.data_ptr(), a.data_ptr(), dx.data_ptr(), da.data_ptr(),
                                   ws.data_ptr(), xs.numel(), _stream()), "prelu_bwd")
+        slot = _grad_slot(ctx.param) if ctx.needs_input_grad[1] else None
+        if slot is not None:   # into the optimiser's bucket with the library's add (autograd's AccumulateGrad would launch an ATen add_)
+            check(lib.migan_axpby(slot.data_ptr(), 1.0, da.data_ptr(), 1.0, slot.data_ptr(), 1, _stream()), "prelu dweight")
+            da = None
         return dx, da
 
 
