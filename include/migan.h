@@ -535,7 +535,8 @@ int migan_c64_conv_fwd(const float* x, const float* wp, const float* bias, float
                        int accumulate, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                        const float* in_slope_ptr, void* stream);
 
-/* optimizer.zero_grad() on the flat gradient bucket (dcgan.py:157,175; cyclegan.py:177,211,228): hipMemsetAsync on `stream` */
+/* optimizer.zero_grad() on the flat gradient bucket (dcgan.py:157,175; cyclegan.py:177,211,228): p[0 .. bytes) = 0, 16-byte stores (p and
+ * bytes multiples of 4) */
 int migan_zero(void* p, size_t bytes, void* stream);
 
 #ifdef __cplusplus

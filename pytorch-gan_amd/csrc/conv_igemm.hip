@@ -1184,6 +1184,60 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float* _
     }
 }
 
+// The same reduction with every slab element read ONCE: a block owns 32 source channels of one output channel, a thread sums the splits
+// of the 16 (class, tap) columns of its channel (8 split lanes per channel, 32 loads in flight), the 8 lanes meet in LDS in lane order, and
+// the block writes its 32 x 9 outputs as one contiguous run.  (upconv_wgrad_reduce_kernel computes each of the 9 outputs from scratch: the
+// 16 columns are read 36 times - 2.25 x the slab bytes through L2, 25.8 us behind the dominant launch of the DCGAN step.)  Ci % 32 == 0.
+__global__ __launch_bounds__(256) void upconv_wgrad_reduce2_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits,
+                                                                   int Co, int Ci, int accum, const BiasRed br) {
+    __shared__ float red[8][16][33];
+    if ((int)blockIdx.x < br.nbias) {  // block-uniform: leading blocks reduce the bias slabs
+        bias_slab_reduce(br.bpart, br.db, br.nslab, Co, br.accum, blockIdx.x);
+        return;
+    }
+    const int b = (int)blockIdx.x - br.nbias, cib = Ci >> 5;
+    const int co = b / cib, ci0 = (b - co * cib) << 5;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t slab = (size_t)Co * 4 * Ci;
+    float a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = 0.f;
+    const float* src = part + (size_t)co * 4 * Ci + ci0 + lane;
+    int k = grp;
+    for (; k + 8 < splits; k += 16) {   // two splits of all 16 columns per round: 32 loads in flight
+        float v[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[u][c] = src[((size_t)(c >> 2) * splits + k + 8 * u) * slab + (size_t)(c & 3) * Ci];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] += v[u][c];
+    }
+    for (; k < splits; k += 8) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] += src[((size_t)(c >> 2) * splits + k) * slab + (size_t)(c & 3) * Ci];
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[grp][c][lane] = a[c];
+    __syncthreads();
+    float* out = dw + ((size_t)co * Ci + ci0) * 9;
+    for (int e = threadIdx.x; e < 32 * 9; e += 256) {
+        const int cl = e / 9, rs = e - cl * 9, r = rs / 3, q = rs - r * 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {   // classes in order, split lanes in order: a fixed summation order
+            const int c = ab * 4 + up_idx(ab >> 1, r) * 2 + up_idx(ab & 1, q);
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += red[g][c][cl];
+            acc += t;
+        }
+        out[e] = accum ? out[e] + acc : acc;
+    }
+}
+
 MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4, upw_bn(N, H, W, Co, Ci));
@@ -1235,8 +1289,13 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
     BiasRed br = {g.bpart, db, 4 * g.splits, db_accumulate, cdiv((long)total, 64), 0};
     if (db && db_slabs) { br.bpart = db_slabs; br.nslab = db_nslab; }
     br.nbias = br.bpart ? cdiv(Co, BIAS_CB) : 0;
-    MIGAN_LAUNCH(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws,
-                       dw_oihw, g.splits, Co, Ci, accumulate, br);
+    if (Ci % 32 == 0 && g.splits >= 8 && MIGAN_KNOB("MIGAN_UPW_REDUCE2", 1)) {
+        br.main_blocks = Co * (Ci / 32);
+        MIGAN_LAUNCH(upconv_wgrad_reduce2_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws, dw_oihw, g.splits, Co, Ci,
+                     accumulate, br);
+    } else
+        MIGAN_LAUNCH(upconv_wgrad_reduce_kernel, dim3(br.main_blocks + br.nbias), dim3(256), 0, st, ws,
+                           dw_oihw, g.splits, Co, Ci, accumulate, br);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -2101,7 +2101,12 @@ class _Fork2(Function):
         return add(ga, gb)
 
 
+_FORK2 = __import__("os").environ.get("MIGAN_FORK2", "1") == "1"   # A/B knob: 0 = autograd's own accumulation (an ATen add)
+
+
 def fork2(x):
+    if not _FORK2:
+        return x, x
     a, b = _Fork2.apply(x)
     return a, b
 
@@ -2109,8 +2114,13 @@ def fork2(x):
 def zero_(t):
     """t.zero_() through the C ABI (hipMemsetAsync on the current stream): the optimisers' gradient buckets (torch's fill is an ATen kernel)."""
     if t.numel():
+        if not _ZERO_ABI:
+            return t.zero_()
         check(lib.migan_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "zero")
     return t
+
+
+_ZERO_ABI = __import__("os").environ.get("MIGAN_ZERO", "1") == "1"   # A/B knob: 0 = torch's fill kernel
 
 
 class _SubBatchMean(Function):

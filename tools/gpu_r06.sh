@@ -112,6 +112,16 @@ task_micro() {
   timeout 600 python tools/conv_microbench.py "$@" 2>&1 | tee -a $O/micro.txt | grep " us " | cut -c1-160
 }
 
+# whole-step A/B against the round-start tree with bench flags:  abf <outdir> <workload> <steps> <reps> [--flag ...]
+task_abf() {
+  local O=gpurun_out/${1:-r6abf}; local w=$2 k=$3 reps=$4; shift 4; mkdir -p $O
+  for r in $(seq $reps); do
+    (cd ab_base && echo "== base $w $*" >> $R/$O/bench.txt && timeout 300 python bench.py --workload $w --steps $k --warmup 2 --no-cpu-baseline --no-extra --no-roofline "$@" 2>>$R/$O/bench.txt.err | line >> $R/$O/bench.txt)
+    bl $O/bench.txt $w $k "$@"
+  done
+  cat $O/bench.txt
+}
+
 # same-box A/B of environment knobs on the tree itself:  abenv <outdir> <workload> <steps> <reps> [--flag ...] -- ENV=a ENV=b ...
 task_abenv() {
   local O=gpurun_out/${1:-r6ab}; local w=$2 k=$3 reps=$4; shift 4; mkdir -p $O
