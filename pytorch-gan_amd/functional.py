@@ -400,10 +400,12 @@ class _PackPlan:
 
     plans = {}
     keep_alive = []   # (table, blocks, arena) of plans a captured hipGraph still launches
+    instances = __import__("weakref").WeakSet()   # every live plan (they hang on their step-state owners): prebuild_pack_tables()
 
     def __init__(self):
         self.scope, self.seq, self.sig, self.tab, self.blk, self.arena, self.nblocks = None, {}, None, None, None, None, 0
         self.captured = False
+        _PackPlan.instances.add(self)
 
     @classmethod
     def get(cls, device):
@@ -435,29 +437,9 @@ class _PackPlan:
             self._prefill_c64([p for p, _, _ in c64], device)
         if not live:
             return
-        sig = tuple((p.data_ptr(), tuple(p.shape), kind, perm) for p, kind, perm in live)
         capturing = torch.cuda.is_current_stream_capturing()
-        if sig != self.sig:
-            if capturing:  # tables need a host->device copy: not inside a capture
-                return
-            if self.captured:  # a live hipGraph replays a launch that reads these tables and writes this arena: never free them
-                _PackPlan.keep_alive.append((self.tab, self.blk, self.arena))
-                self.captured = False
-            total = sum(p.numel() for p, _, _ in live)
-            self.arena = torch.empty(total, device=device, dtype=torch.float32)
-            ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("o", "<u4", 4), ("s", "<i8", 4), ("n", "<i8")]))
-            blocks, off = [], 0
-            for i, (p, kind, perm) in enumerate(live):
-                n = p.numel()
-                d = tuple(p.shape)
-                st = (d[1] * d[2] * d[3], d[2] * d[3], d[3], 1)
-                ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, (d[perm[1]], d[perm[2]], d[perm[3]], 0),
-                          tuple(st[q] for q in perm), n)
-                blocks += [(i, c) for c in range((n + 1023) // 1024)]
-                off += n
-            self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
-            self.blk = torch.tensor(blocks, dtype=torch.int32).to(device)
-            self.nblocks, self.sig = len(blocks), sig
+        if not self._tables(live, device):
+            return
         self.captured = self.captured or capturing
         check(lib.migan_multi_permute4d(self.tab.data_ptr(), self.blk.data_ptr(), self.nblocks, _stream()), "multi_permute4d")
         off = 0
@@ -469,27 +451,74 @@ class _PackPlan:
             p.__dict__.setdefault("_migan_pack", {})[kind] = (stamp, view)
 
 
+def _pack_tables(self, live, device):
+    """Device tables + arena of the multi-tensor permute launch for `live` = [(param, kind, perm)]; False when they would have to be built
+    inside a capture (a host->device copy)."""
+    import numpy as np
+
+    sig = tuple((p.data_ptr(), tuple(p.shape), kind, perm) for p, kind, perm in live)
+    if sig == self.sig:
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    if self.captured:  # a live hipGraph replays a launch that reads these tables and writes this arena: never free them
+        _PackPlan.keep_alive.append((self.tab, self.blk, self.arena))
+        self.captured = False
+    total = sum(p.numel() for p, _, _ in live)
+    self.arena = torch.empty(total, device=device, dtype=torch.float32)
+    ent = np.zeros(len(live), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("o", "<u4", 4), ("s", "<i8", 4), ("n", "<i8")]))
+    blocks, off = [], 0
+    for i, (p, kind, perm) in enumerate(live):
+        n = p.numel()
+        d = tuple(p.shape)
+        st = (d[1] * d[2] * d[3], d[2] * d[3], d[3], 1)
+        ent[i] = (p.data_ptr(), self.arena.data_ptr() + 4 * off, (d[perm[1]], d[perm[2]], d[perm[3]], 0),
+                  tuple(st[q] for q in perm), n)
+        blocks += [(i, c) for c in range((n + 1023) // 1024)]
+        off += n
+    self.tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
+    self.blk = torch.tensor(blocks, dtype=torch.int32).to(device)
+    self.nblocks, self.sig = len(blocks), sig
+    return True
+
+
+_PackPlan._tables = _pack_tables
+
+
+def _plan_live(seq):
+    live, c64 = [], []
+    for ref, kind, perm in seq.values():
+        p = ref()
+        if p is not None and on_device(p) and p.dtype == torch.float32 and p.is_contiguous():
+            (c64 if perm == "c64" else live).append((p, kind, perm))
+    return live, c64
+
+
+def prebuild_pack_tables():
+    """Build the device tables of every pack plan from the request sequence of the step that just ran (graph.StepRunner, in front of a
+    recording): the recording's first pack request then finds them and issues the ONE multi-tensor launch."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for plan in list(_PackPlan.instances):
+        if not plan.seq:
+            continue
+        live, c64 = _plan_live(plan.seq)
+        dev = (live or c64)[0][0].device if (live or c64) else None
+        if live:
+            plan._tables(live, dev)
+        if c64:
+            plan._tables_c64([p for p, _, _ in c64], dev)
+
+
 def _prefill_c64(self, params, device):
     """Both register-slice packs (forward, input gradient) of every Conv2d(64, 64, 3, 1, 1) weight the last step used, from ONE launch
     (csrc/conv_c64.hip c64_pack_multi_kernel): table and arena are rebuilt only when the set of weights changes."""
     import numpy as np
 
     n1 = lib.migan_c64_pack_floats()
-    sig = tuple(p.data_ptr() for p in params)
     capturing = torch.cuda.is_current_stream_capturing()
-    if sig != getattr(self, "c64_sig", None):
-        if capturing:
-            return
-        if getattr(self, "c64_captured", False):
-            _PackPlan.keep_alive.append((self.c64_tab, self.c64_arena))
-            self.c64_captured = False
-        self.c64_arena = torch.empty(2 * n1 * len(params), device=device, dtype=torch.float32)
-        ent = np.zeros((len(params), 3), dtype=np.uint64)
-        for i, p in enumerate(params):
-            base = self.c64_arena.data_ptr() + 4 * (2 * i) * n1
-            ent[i] = (p.data_ptr(), base, base + 4 * n1)
-        self.c64_tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
-        self.c64_sig = sig
+    if not self._tables_c64(params, device):
+        return
     self.c64_captured = getattr(self, "c64_captured", False) or capturing
     check(lib.migan_c64_pack_multi(self.c64_tab.data_ptr(), len(params), _stream()), "c64_pack_multi")
     for i, p in enumerate(params):
@@ -499,7 +528,30 @@ def _prefill_c64(self, params, device):
         cache["c64d"] = (stamp, self.c64_arena[(2 * i + 1) * n1:(2 * i + 2) * n1])
 
 
+def _tables_c64(self, params, device):
+    import numpy as np
+
+    n1 = lib.migan_c64_pack_floats()
+    sig = tuple(p.data_ptr() for p in params)
+    if sig == getattr(self, "c64_sig", None):
+        return True
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    if getattr(self, "c64_captured", False):
+        _PackPlan.keep_alive.append((self.c64_tab, self.c64_arena))
+        self.c64_captured = False
+    self.c64_arena = torch.empty(2 * n1 * len(params), device=device, dtype=torch.float32)
+    ent = np.zeros((len(params), 3), dtype=np.uint64)
+    for i, p in enumerate(params):
+        base = self.c64_arena.data_ptr() + 4 * (2 * i) * n1
+        ent[i] = (p.data_ptr(), base, base + 4 * n1)
+    self.c64_tab = torch.from_numpy(ent.view(np.uint8).copy()).to(device)
+    self.c64_sig = sig
+    return True
+
+
 _PackPlan._prefill_c64 = _prefill_c64
+_PackPlan._tables_c64 = _tables_c64
 
 
 def prefill_packs(device):

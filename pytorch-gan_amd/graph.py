@@ -95,6 +95,12 @@ class StepRunner:
         try:
             if self.before_capture is not None:
                 self.before_capture()
+            # the weight-pack plan learns a step's requests in one step and builds its device tables at the start of the NEXT - which cannot
+            # happen inside a capture: behind a single warm-up step the recording would hold every pack as its own launch (and, with forked
+            # streams, one copy per stream: 238 pack launches in the recorded one-image CycleGAN step instead of 20).  Build the tables now.
+            from . import functional as F
+
+            F.prebuild_pack_tables()
             self._capture(side)
             self.graphed = True
         except Exception as e:  # capture is an optimisation: fall back to eager launches, but say so
