@@ -553,11 +553,11 @@ static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3&
 // in a fixed order in double, pass 2 re-reads the (L2-resident) pixels and writes.  No cross-workgroup reduction exists.
 // Measured (profiles/r03_abi_check.txt): 6.3-18.6 us per launch, 4e-8 / 5e-8 from a host fp64 evaluation.
 // ---------------------------------------------------------------------------------------------
-// QUADS = channel quads (16 B) per workgroup: 4 (16 channels, 64 pixel lanes) for up to 1024 pixels per group; 1 (4 channels, 256 pixel lanes)
-// for 1025 .. 4096 pixels - the 64 x 64 maps of CycleGAN's residual trunk at ONE image per GPU (cyclegan/models.py:26-33, cyclegan.py:28) and
-// of the U-Net's second level: 19 of the 23 InstanceNorm layers of a generator pass there were three launches forward and three backward
-// (~17 / ~21 us for 4 MB of tensor), 44 % of the launches of the recorded one-image step.
-template <int QUADS>
+// (Round 6 measured the same kernels with 4 channels per workgroup for 1025 .. 4096 pixels per group - the 64 x 64 maps of CycleGAN's trunk at
+// one image per GPU, 19 of the 23 InstanceNorm layers of a generator pass: the recorded step went from 33.0 to 38.0 ms, pix2pix from 2.93 to 3.05
+// (profiles/r06_ab.txt calls 25, 26).  A workgroup's lanes then read 16 bytes at a 1 KB stride - an eighth of every cache line - and 64
+// workgroups walk 64 KB each: the three streaming launches with channel-contiguous lanes on the whole chip are faster.  Removed.)
+#define NS_CH 16
 __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              float* __restrict__ mean, float* __restrict__ invstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -565,14 +565,13 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
                                                              float eps, const float* __restrict__ mask) {
     // mask (optional, same [G][P][C] layout): the nn.Dropout behind the activation (pix2pix/models.py:27,44) - y = act(..) * mask
     __shared__ float red[2][256 * 4];
-    constexpr int NS_CH = 4 * QUADS, LANES = 256 / QUADS;
     __shared__ float st[2][NS_CH];
-    const int tid = threadIdx.x, tx = tid % QUADS, ty = tid / QUADS;
+    const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
     const int g = blockIdx.z, c = blockIdx.x * NS_CH + tx * 4;
     const float* xb = x + (size_t)g * P * C + c;
     const f32x4 shift = *reinterpret_cast<const f32x4*>(xb);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    for (int p = ty; p < P; p += LANES) {
+    for (int p = ty; p < P; p += 64) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C) - shift;
         s0 += d;
         s1 += d * d;
@@ -586,9 +585,9 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
     if (tid < NS_CH) {  // thread = channel tid of the slab: quad tid >> 2, element tid & 3
         const int q = tid >> 2, v = tid & 3;
         double sd = 0.0, sq = 0.0;
-        for (int l = 0; l < LANES; ++l) {
-            sd += (double)red[0][(l * QUADS + q) * 4 + v];
-            sq += (double)red[1][(l * QUADS + q) * 4 + v];
+        for (int l = 0; l < 64; ++l) {
+            sd += (double)red[0][(l * 4 + q) * 4 + v];
+            sq += (double)red[1][(l * 4 + q) * 4 + v];
         }
         const double K = (double)xb[tid - tx * 4];   // the group's first pixel, channel blockIdx.x * 16 + tid
         const double md = sd / P;
@@ -610,7 +609,7 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
     float* yb = y + (size_t)g * P * C + c;
     const float* rb = res ? res + (size_t)g * P * C + c : nullptr;
     const float* mb = mask ? mask + (size_t)g * P * C + c : nullptr;
-    for (int p = ty; p < P; p += LANES) {
+    for (int p = ty; p < P; p += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C);
         f32x4 r = {0.f, 0.f, 0.f, 0.f}, mk = {1.f, 1.f, 1.f, 1.f};
         if (rb) r = *reinterpret_cast<const f32x4*>(rb + (size_t)p * C);
@@ -624,16 +623,14 @@ __global__ __launch_bounds__(256) void norm_small_fwd_kernel(const float* __rest
 // backward: dx = gamma*invstd*(dyz - s0/P - xhat*s1/P), (s0, s1) = sums over the group's pixels of (dyz, dyz*xhat), dyz = dy*act'(z);
 // csum (optional): the column-sum slabs of dx the preceding conv's bias gradient is reduced from - row (g, 0) holds the group's
 // sums, rows (g, 1 .. rows_per_g - 1) are zeroed (the consumer adds all migan_norm_colsum_slabs() rows)
-template <int QUADS>
 __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              float* __restrict__ dx, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int P, int C, int act, float slope,
                                                              float* __restrict__ csum, int rows_per_g, const float* __restrict__ mask) {
     __shared__ float red[2][256 * 4];
-    constexpr int NS_CH = 4 * QUADS, LANES = 256 / QUADS;
     __shared__ float st[2][NS_CH];
-    const int tid = threadIdx.x, tx = tid % QUADS, ty = tid / QUADS;
+    const int tid = threadIdx.x, tx = tid & 3, ty = tid >> 2;
     const int g = blockIdx.z, c = blockIdx.x * NS_CH + tx * 4;
     const size_t base = (size_t)g * P * C + c;
     float mu[4], is[4], ga[4], be[4];
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
         be[v] = beta ? beta[c + v] : 0.f;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    for (int p = ty; p < P; p += LANES) {
+    for (int p = ty; p < P; p += 64) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
         f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
         if (mask) dv *= *reinterpret_cast<const f32x4*>(mask + base + (size_t)p * C);
@@ -671,16 +668,16 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
     if (tid < NS_CH) {
         const int q = tid >> 2, v = tid & 3;
         double a = 0.0, b = 0.0;
-        for (int l = 0; l < LANES; ++l) {
-            a += (double)red[0][(l * QUADS + q) * 4 + v];
-            b += (double)red[1][(l * QUADS + q) * 4 + v];
+        for (int l = 0; l < 64; ++l) {
+            a += (double)red[0][(l * 4 + q) * 4 + v];
+            b += (double)red[1][(l * 4 + q) * 4 + v];
         }
         st[0][tid] = (float)a / (float)P;
         st[1][tid] = (float)b / (float)P;
     }
     __syncthreads();
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
-    for (int p = ty; p < P; p += LANES) {
+    for (int p = ty; p < P; p += 64) {
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (size_t)p * C);
         f32x4 dv = *reinterpret_cast<const f32x4*>(dy + base + (size_t)p * C);
         if (mask) dv *= *reinterpret_cast<const f32x4*>(mask + base + (size_t)p * C);
@@ -707,37 +704,25 @@ __global__ __launch_bounds__(256) void norm_small_bwd_kernel(const float* __rest
         if (tid < NS_CH) {
             const int q = tid >> 2, v = tid & 3;
             float a = 0.f;
-            for (int l = 0; l < LANES; ++l) a += red[0][(l * QUADS + q) * 4 + v];
+            for (int l = 0; l < 64; ++l) a += red[0][(l * 4 + q) * 4 + v];
             const int ch = blockIdx.x * NS_CH + tid;
             csum[((size_t)g * rows_per_g) * C + ch] = a;
             for (int r = 1; r < rows_per_g; ++r) csum[((size_t)g * rows_per_g + r) * C + ch] = 0.f;
         }
     }
 }
-// 0: the streaming kernels; 4 / 1: channel quads per workgroup of the one-launch kernels
-static int norm_small_quads(int G, int P, int C) {
-    if (G > 65535 || P < 2) return 0;
-    if (C % 16 == 0 && P <= 1024 && (long)G * (C / 16) >= 8 && (long)G * P * C <= (1L << 20)) return 4;
-    // 1025 .. 4096 pixels per group: 4 channels per workgroup (64 KB per pass and workgroup at 4096 pixels), at least 32 workgroups
-    if (MIGAN_KNOB("MIGAN_NORM_SMALL4K", 1) && C % 4 == 0 && P > 1024 && P <= 4096 && (long)G * (C / 4) >= 32 && (long)G * P * C <= (1L << 22))
-        return 1;
-    return 0;
+static bool norm_small_ok(int G, int P, int C) {
+    return C % NS_CH == 0 && P >= 2 && P <= 1024 && (long)G * (C / NS_CH) >= 8 && (long)G * P * C <= (1L << 20) && G <= 65535;
 }
-static bool norm_small_ok(int G, int P, int C) { return norm_small_quads(G, P, C) != 0; }
 // 1: migan_norm_fwd_small takes the shape (instance-style statistics: no running statistics, no cross-replica exchange)
 MIGAN_API int migan_norm_small_ok(int G, int P, int C) { return norm_small_ok(G, P, C) ? 1 : 0; }
 // Statistics + normalisation (+ affine, activation, residual) in one launch; mean / invstd [G][C] are written for the backward.
 MIGAN_API int migan_norm_fwd_small(const float* x, float* y, float* mean, float* invstd, const float* gamma, const float* beta,
                                    const float* res, const float* mask, int G, int P, int C, int act, float slope, float eps,
                                    void* stream) {
-    const int quads = norm_small_quads(G, P, C);
-    if (!quads) return (int)hipErrorInvalidValue;
-    if (quads == 4)
-        MIGAN_LAUNCH((norm_small_fwd_kernel<4>), dim3(C / 16, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma, beta,
-                     res, P, C, act, slope, eps, mask);
-    else
-        MIGAN_LAUNCH((norm_small_fwd_kernel<1>), dim3(C / 4, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma, beta,
-                     res, P, C, act, slope, eps, mask);
+    if (!norm_small_ok(G, P, C)) return (int)hipErrorInvalidValue;
+    MIGAN_LAUNCH(norm_small_fwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, y, mean, invstd, gamma,
+                       beta, res, P, C, act, slope, eps, mask);
     HIP_LAUNCH_CHECK();
     return 0;
 }
@@ -938,12 +923,8 @@ MIGAN_API int migan_norm_bwd(const float* x, const float* dy, const float* mean,
     if (!dgamma && !dbeta && norm_small_ok(G, P, C) && (act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) {
         // small instance-style tensor: both halves in one launch (see norm_small_fwd_kernel)
         const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
-        if (norm_small_quads(G, P, C) == 4)
-            MIGAN_LAUNCH((norm_small_bwd_kernel<4>), dim3(C / 16, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
-                         gamma, beta, P, C, act, slope, csum, rows_per_g, (const float*)nullptr);
-        else
-            MIGAN_LAUNCH((norm_small_bwd_kernel<1>), dim3(C / 4, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
-                         gamma, beta, P, C, act, slope, csum, rows_per_g, (const float*)nullptr);
+        MIGAN_LAUNCH(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+                           gamma, beta, P, C, act, slope, csum, rows_per_g, (const float*)nullptr);
         HIP_LAUNCH_CHECK();
         return 0;
     }
@@ -961,12 +942,8 @@ MIGAN_API int migan_norm_bwd_small(const float* x, const float* dy, const float*
                                    float* csum, void* stream) {
     if (!norm_small_ok(G, P, C) || !(act == ACT_NONE || act == ACT_LRELU || act == ACT_RELU)) return (int)hipErrorInvalidValue;
     const int rows_per_g = csum ? migan_norm_colsum_slabs(G, P, C) / G : 0;
-    if (norm_small_quads(G, P, C) == 4)
-        MIGAN_LAUNCH((norm_small_bwd_kernel<4>), dim3(C / 16, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd, gamma,
-                     beta, P, C, act, slope, csum, rows_per_g, mask);
-    else
-        MIGAN_LAUNCH((norm_small_bwd_kernel<1>), dim3(C / 4, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd, gamma,
-                     beta, P, C, act, slope, csum, rows_per_g, mask);
+    MIGAN_LAUNCH(norm_small_bwd_kernel, dim3(C / NS_CH, 1, G), dim3(256), 0, (hipStream_t)stream, x, dy, dx, mean, invstd,
+                       gamma, beta, P, C, act, slope, csum, rows_per_g, mask);
     HIP_LAUNCH_CHECK();
     return 0;
 }

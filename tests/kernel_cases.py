@@ -37,9 +37,6 @@ NORM = [
     ("in_4x4", (1, 512, 4, 4, 0, False, False, False), ("norm_small_fwd_kernel", "norm_small_bwd_kernel")),
     ("in_16x16_lrelu_mask", (2, 64, 16, 16, 1, False, True, False), ("norm_small_fwd_kernel", "norm_small_bwd_kernel")),
     ("in_32x32_res", (2, 64, 32, 32, 0, False, False, True), ("norm_small_fwd_kernel", "norm_small_bwd_kernel")),
-    # 4096 pixels per group (cyclegan/models.py:26-33 at one image per GPU): the 4-channels-per-workgroup form of the one-launch kernels
-    ("in_64x64_relu", (1, 128, 64, 64, 2, False, False, False), ("norm_small_fwd_kernel<1>", "norm_small_bwd_kernel<1>")),
-    ("in_64x48_res", (2, 64, 64, 48, 0, False, False, True), ("norm_small_fwd_kernel<1>", "norm_small_bwd_kernel<1>")),
 ]
 
 
