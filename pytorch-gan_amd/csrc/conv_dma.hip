@@ -681,6 +681,10 @@ __device__ __forceinline__ float frag_get(float v, int) { return v; }
 __device__ __forceinline__ float frag_get(f32x2 v, int e) { return v[e]; }
 __device__ __forceinline__ float frag_get(f32x4 v, int e) { return v[e]; }
 
+// (Round 6 also measured three / four LDS stages with counted waits on the 64 x 256 tile - BK 16, four waves, four stages (80 KB, two workgroups
+// per CU) and BK 32, eight waves, three stages (120 KB, one workgroup per CU, half the slabs): 282.7 / 294.0 us against 275.1 us, the DCGAN step
+// 2.505 / 2.498 against 2.463 ms (profiles/r06_ab.txt call 28).  Under the counters a wave of this kernel is parked 28.5 % of its cycles at the
+// tile barrier (igemm_dma_kernel: 8.5-12 %) with an L2 hit rate of 0.667 - but more K-tiles in flight do not shorten that: removed.)
 // NW: waves per workgroup (4, or 8 = a 2 x 4 wave grid: twice the waves per SIMD at the same LDS footprint, half the DMA instructions and
 // MFMAs per wave and K-tile - for tiles whose LDS stage allows only two workgroups per CU)
 template <int BM, int BN, int BK, bool DYS, bool REFL, int OCC, int NW = 4>
