@@ -185,10 +185,11 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
             state.buf_B.push_and_pop(state.G_AB(a))
     # the recorded step: the replay buffers' host draws (python `random`, the reference's order) happen in front of every replay
     # into static device tables (steps.CycleGanRunner); --no-graph launches the same step eagerly
-    # Recorded where the step is bound by launches (one or two images per GPU: 34.5 ms recorded vs 40.9 ms launched one by one at
-    # batch 1); at batch 8 the ~2000 launches are 30-1000 us each and the recorded step measured SLOWER than the eager one (147.8 vs
-    # 140-146 ms, profiles/r05_ab.txt calls 4, 6, 15): eager there.  --graph-always / --no-graph override.
-    use_graph = (not args.no_graph) and (batch <= 2 or getattr(args, "graph_always", False))
+    # Recorded at every batch size.  (Round 5 timed batch 8 eagerly: its recording measured slower, 147.8 vs 140-146 ms.  Round 6 found why -
+    # behind ONE warm-up step the recording held every weight pack as its own launch, one copy per forked stream, 238 launches per step;
+    # graph.StepRunner now builds the pack plan's tables in front of the capture - and measured 142.1 / 142.5 ms recorded against 143.6 /
+    # 140.8 ms eager, profiles/r06_ab.txt call 29.)  --no-graph: eager.
+    use_graph = not args.no_graph
     runner = steps.CycleGanRunner(state, a, b, use_graph=use_graph, warmup=1).prepare()
     w = Workload("cyclegan", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)
