@@ -521,9 +521,11 @@ int migan_adam_step(const void* tab, const void* blk, int nblocks, float* step, 
  * weights stay in registers, the input rows in an LDS ring: every input element enters a CU once.
  * migan_c64_conv_ok: 1 when the kernel takes the geometry (W % 32 == 0, >= 1024 row-steps); wp: migan_c64_pack_floats() floats from
  * migan_c64_pack(w_oihw [64][64][3][3]).
- * in_scale / in_shift [64] (optional, both or neither): x is read through T(v) = in_act(v * in_scale[c] + in_shift[c]) - the
- * BatchNorm2d(64, 0.8) -> PReLU of srgan/models.py:23-24 folded into the consumer conv's operand path (in_act = ACT_LRELU with the slope
- * read from in_slope_ptr, or in_slope when in_slope_ptr == NULL); zero padding is applied after T.  accumulate != 0: y +=. */
+ * in_mean / in_invstd [64] (optional, both or neither; migan_norm_stats' outputs) with in_gamma / in_beta [64] (each optional = 1 / 0):
+ * x is read through T(v) = in_act(fma(v, sc, sh)), sc = in_invstd[c] * in_gamma[c], sh = in_beta[c] - in_mean[c] * sc - the
+ * BatchNorm2d(64, 0.8) -> PReLU of srgan/models.py:23-24 folded into the consumer conv's operand path, in migan_norm_apply's arithmetic
+ * (in_act = ACT_LRELU with the slope read from in_slope_ptr, or in_slope when in_slope_ptr == NULL); zero padding is applied after T.
+ * accumulate != 0: y +=. */
 int migan_c64_conv_ok(int N, int H, int W, int Ci, int Co, int R, int S, int stride, int pad_t, int pad_l, int pad_b, int pad_r,
                       int gather);
 size_t migan_c64_pack_floats(void);
@@ -532,9 +534,18 @@ int migan_c64_pack(const float* w_oihw, float* wp, int flip, void* stream);
  * (a pack pointer may be NULL) */
 int migan_c64_pack_multi(const void* tab, int n, void* stream);
 int migan_c64_conv_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int act, float slope,
-                       int accumulate, const float* in_scale, const float* in_shift, int in_act, float in_slope,
-                       const float* in_slope_ptr, void* stream);
+                       int accumulate, const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta,
+                       int in_act, float in_slope, const float* in_slope_ptr, void* stream);
 
+/* Weight gradient of the same layer, accumulators stationary (csrc/conv_c64.hip c64_wgrad_kernel): dw_oihw [64][64][3][3] (accumulate: +=)
+ * from x [N][H][W][64] - read through the same input map T as the forward - and dy [N][H][W][64]; one [64][576] slab per workgroup in ws
+ * (migan_c64_wgrad_workspace() bytes), added in a fixed order; db (optional) from the caller's column-sum slabs of dy, as migan_conv2d_wgrad.
+ * aten::convolution_backward's grad_weight behind srgan.py:128 for srgan/models.py:22-27. */
+size_t migan_c64_wgrad_workspace(int N, int H, int W);
+int migan_c64_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H, int W,
+                         int accumulate, float* db, int db_accumulate, const float* db_slabs, int db_nslab,
+                         const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta, int in_act,
+                         float in_slope, const float* in_slope_ptr, void* stream);
 /* optimizer.zero_grad() on the flat gradient bucket (dcgan.py:157,175; cyclegan.py:177,211,228): p[0 .. bytes) = 0, 16-byte stores (p and
  * bytes multiples of 4) */
 int migan_zero(void* p, size_t bytes, void* stream);

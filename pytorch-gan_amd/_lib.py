@@ -94,7 +94,9 @@ _SIGS = {
     "migan_c64_pack_floats": (c_size_t, []),
     "migan_c64_pack": (c_int, [P, P, c_int, P]),
     "migan_c64_pack_multi": (c_int, [P, c_int, P]),
-    "migan_c64_conv_fwd": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, c_int, P, P, c_int, c_float, P, P]),
+    "migan_c64_wgrad_workspace": (c_size_t, [c_int] * 3),
+    "migan_c64_conv_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 4 + [P, c_int, P, c_int, P, P, P, P, c_int, c_float, P, P]),
+    "migan_c64_conv_fwd": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, c_int, P, P, P, P, c_int, c_float, P, P]),
     "migan_fewpix_ok": (c_int, [c_int] * 3),
     "migan_fewpix_nt_workspace": (c_size_t, [c_int] * 3),
     "migan_fewpix_nt": (c_int, [P, P, P, P, P, c_size_t, c_int, c_int, c_int, c_int, c_float, P]),

@@ -50,8 +50,9 @@ template <int INMAP>
 // the memory clobber that follows them)
 __global__ __launch_bounds__(256, 2) void c64_conv_kernel(const C64Geom g, const float* x,
                                                            const f32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                           float* __restrict__ y, const float* __restrict__ in_scale,
-                                                           const float* __restrict__ in_shift,
+                                                           float* __restrict__ y, const float* __restrict__ in_mean,
+                                                           const float* __restrict__ in_invstd, const float* __restrict__ in_gamma,
+                                                           const float* __restrict__ in_beta,
                                                            const float* __restrict__ in_slope_ptr) {
     __shared__ __attribute__((aligned(16))) float smem[C64_RING + C64_XBUF + C64_C];
     float* ring = smem;
@@ -92,8 +93,15 @@ __global__ __launch_bounds__(256, 2) void c64_conv_kernel(const C64Geom g, const
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     float in_slope = g.in_slope;
     if (INMAP) {
-        sc = *reinterpret_cast<const f32x4*>(in_scale + st_c * 4);
-        sh = *reinterpret_cast<const f32x4*>(in_shift + st_c * 4);
+        // scale / shift of this thread's four channels from the normalisation's statistics and affine parameters - the arithmetic of
+        // norm_apply_kernel (sc = invstd * gamma, sh = beta - mean * sc, then fmaf(x, sc, sh)): the values that enter the ring are bit for
+        // bit the ones the separate apply pass would have written
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(in_mean + st_c * 4), is = *reinterpret_cast<const f32x4*>(in_invstd + st_c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = is[e] * (in_gamma ? in_gamma[st_c * 4 + e] : 1.f);
+            sh[e] = (in_beta ? in_beta[st_c * 4 + e] : 0.f) - mu[e] * sc[e];
+        }
         if (in_slope_ptr) in_slope = *in_slope_ptr;
     }
 
@@ -278,6 +286,166 @@ __global__ void c64_pack_kernel(const float* __restrict__ w, float* __restrict__
     wp[i] = flip ? w[((size_t)(ci * 64 + co) * 3 + (2 - r)) * 3 + (2 - s_)] : w[((size_t)(co * 64 + ci) * 3 + r) * 3 + s_];
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer with the ACCUMULATORS stationary: dW[co][t][ci] = sum over pixels of dy[p][co] * T(x)[p + tap t][ci].
+// GEMM M = 64 (co), N = 576 (tap, ci), K = pixels.  A workgroup owns ALL of dW (64 x 576 = 36 accumulator tiles of 32 x 32: nine per wave,
+// wave = (co block mb) x (ci half kh), 144 registers) for its share of the pixels and walks them exactly as the forward kernel does: a strip
+// of 32 columns, one row per step, the input rows in the four-slot LDS ring, the nine taps reading the ring at shifted pixels - and dy's row
+// beside it.  Per pixel pair: one fragment of dy (co along the lanes) and nine of x, nine MFMAs.  Every x and dy element enters the CU once;
+// igemm-style 64 x 128 tiles re-read x 4.5 times and dy 5 times (tiles_n).  The input map T (BatchNorm -> PReLU of the layer in front) is
+// applied where x enters the ring, as in the forward kernel: the normalised tensor never exists in memory (srgan/models.py:22-27).
+// Output: one [64][576] slab per workgroup; the fixed-order reduction of the general weight-gradient path adds them (deterministic).
+template <int INMAP>
+__global__ __launch_bounds__(256, 2) void c64_wgrad_kernel(const C64Geom g, const float* x, const float* dy, float* __restrict__ part,
+                                                            const float* __restrict__ in_mean, const float* __restrict__ in_invstd,
+                                                            const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
+                                                            const float* __restrict__ in_slope_ptr) {
+    constexpr int DYF = C64_TW * C64_C;   // floats of one dy row slot
+    __shared__ __attribute__((aligned(16))) float smem[C64_RING + 2 * DYF];
+    float* ring = smem;
+    float* dyl = smem + C64_RING;
+    const int tid = threadIdx.x;
+    int L = (int)blockIdx.x * g.spw;
+    const int L1 = L + g.spw < g.steps ? L + g.spw : g.steps;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int mb = wave & 1, kh = wave >> 1;
+    const int H = g.H, W = g.W;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int st_c = tid & 15, st_p = tid >> 4;
+    const int st_off = st_p * C64_PS + st_c * 4;
+    const int st_n = tid < (C64_HW * 16 - 512) ? 3 : 2;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    float in_slope = g.in_slope;
+    if (INMAP) {
+        // scale / shift of this thread's four channels from the normalisation's statistics and affine parameters - the arithmetic of
+        // norm_apply_kernel (sc = invstd * gamma, sh = beta - mean * sc, then fmaf(x, sc, sh)): the values that enter the ring are bit for
+        // bit the ones the separate apply pass would have written
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(in_mean + st_c * 4), is = *reinterpret_cast<const f32x4*>(in_invstd + st_c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = is[e] * (in_gamma ? in_gamma[st_c * 4 + e] : 1.f);
+            sh[e] = (in_beta ? in_beta[st_c * 4 + e] : 0.f) - mu[e] * sc[e];
+        }
+        if (in_slope_ptr) in_slope = *in_slope_ptr;
+    }
+    int q1 = fastdiv(L < g.steps ? L : 0, g.mg_h, g.sh_h);
+    int oi = (L < g.steps ? L : 0) - q1 * H;
+    int n = fastdiv(q1, g.mg_s, g.sh_s);
+    int j0 = (q1 - n * g.strips) * C64_TW;
+
+    auto load_row = [&](int row, f32x4 (&v)[3], bool (&ok)[3]) {
+        const bool rok = (unsigned)row < (unsigned)H;
+        const int rc = row < 0 ? 0 : (row >= H ? H - 1 : row);
+        const float* src = x + ((size_t)(n * H + rc) * W) * C64_C + st_c * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int col = j0 - 1 + st_p + 16 * k;
+            ok[k] = rok && (unsigned)col < (unsigned)W && k < st_n;
+            const int cc = col < 0 ? 0 : (col >= W ? W - 1 : col);
+            v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)cc * C64_C);
+        }
+    };
+    auto store_row = [&](int row, const f32x4 (&v)[3], const bool (&ok)[3]) {
+        float* dst = ring + ((row + 1) & 3) * C64_ROWF + st_off;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            f32x4 o = v[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = o[e];
+                if (INMAP) t = fmaf(t, sc[e], sh[e]);
+                if (INMAP == 2) t = t > 0.f ? t : t * in_slope;
+                o[e] = ok[k] ? t : 0.f;
+            }
+            if (k < 2 || st_n == 3) *reinterpret_cast<f32x4*>(dst + k * 16 * C64_PS) = o;
+        }
+    };
+    // dy row oi of the strip: 32 pixels x 16 chunks = 512 chunks, two per thread (pixel (t >> 4) + 16 k, chunk t & 15)
+    auto load_dy = [&](int row, f32x4 (&v)[2]) {
+        const float* src = dy + ((size_t)(n * H + row) * W + j0 + st_p) * C64_C + st_c * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) v[k] = *reinterpret_cast<const f32x4*>(src + (size_t)(16 * k) * C64_C);
+    };
+    auto store_dy = [&](int slot, const f32x4 (&v)[2]) {
+        float* dst = dyl + slot * DYF + st_p * C64_C + st_c * 4;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<f32x4*>(dst + k * 16 * C64_C) = v[k];
+    };
+
+    const int a_rd = h * C64_C + mb * 32 + l31;                 // dy fragment: pixel 2s + h, co mb*32 + l31
+    const int b_rd = h * C64_PS + kh * 32 + l31;                // x fragment: halo pixel 2s + h (+ tap column), ci kh*32 + l31
+    bool prime = true;
+    int dslot = 0;
+    for (; L < L1; ++L) {
+        if (prime) {
+            f32x4 v[3][3], dv[2];
+            bool ok[3][3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) load_row(oi + d - 1, v[d], ok[d]);
+            load_dy(oi, dv);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) store_row(oi + d - 1, v[d], ok[d]);
+            store_dy(dslot, dv);
+            __syncthreads();
+            prime = false;
+        }
+        const bool pf = (L + 1 < L1) && (oi + 1 < H);
+        f32x4 pv[3], pdv[2];
+        bool pok[3];
+        load_row(oi + 2, pv, pok);
+        load_dy(pf ? oi + 1 : oi, pdv);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+
+        const float* ap = dyl + dslot * DYF + a_rd;
+#define C64_WG_STEPS(S0, S1)                                                                                            \
+    _Pragma("unroll") for (int s_ = S0; s_ < S1; ++s_) {                                                                \
+        const float a = ap[2 * s_ * C64_C];                                                                             \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                 \
+            const float b = ring[((oi + t / 3) & 3) * C64_ROWF + (2 * s_ + t % 3) * C64_PS + b_rd];                     \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);                                       \
+        }                                                                                                               \
+    }
+        C64_WG_STEPS(0, 8)
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) {
+            store_row(oi + 2, pv, pok);
+            store_dy(dslot ^ 1, pdv);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        C64_WG_STEPS(8, 16)
+#undef C64_WG_STEPS
+        __syncthreads();
+        dslot ^= 1;
+        if (++oi == H) {
+            oi = 0;
+            prime = true;
+            j0 += C64_TW;
+            if (j0 == W) {
+                j0 = 0;
+                ++n;
+            }
+        }
+    }
+    // slab [workgroup][co][tap * 64 + ci]: register r of tile t = row (r & 3) + 8 (r >> 2) + 4 h of block mb, column kh * 32 + l31
+    float* out = part + (size_t)blockIdx.x * (C64_C * 9 * C64_C);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)co * (9 * C64_C) + t * C64_C + kh * 32 + l31] = acc[t][r];
+        }
+}
+
 // All the Conv2d(64, 64, 3, 1, 1) layers of a step in ONE launch: tab[i] = {w_oihw, wp_fwd, wp_dgrad} (either pack pointer may be NULL);
 // grid (144, n).  A residual trunk (srgan/models.py:42-47) is 33 such layers, each needing both forms every step: 66 launches otherwise.
 struct C64PackEntry { const float* w; float* wf; float* wd; };
@@ -318,15 +486,16 @@ MIGAN_API int migan_c64_pack_multi(const void* tab, int n, void* stream) {
     HIP_LAUNCH_CHECK();
     return 0;
 }
-// y[N][H][W][64] = act(conv3x3(T(x), w) + bias), T(v) = in_act(v * in_scale[c] + in_shift[c]) when in_scale != NULL (in_act: ACT_NONE or
-// ACT_LRELU with slope *in_slope_ptr, or in_slope when in_slope_ptr == NULL), zero padding applied after T.  wp: migan_c64_pack().
+// y[N][H][W][64] = act(conv3x3(T(x), w) + bias), T(v) = in_act((v - in_mean[c]) * in_invstd[c] * in_gamma[c] + in_beta[c]) when in_mean != NULL
+// (the statistics of migan_norm_stats; in_gamma / in_beta may be NULL = 1 / 0; in_act: ACT_NONE or ACT_LRELU with slope *in_slope_ptr, or in_slope
+// when in_slope_ptr == NULL), zero padding applied after T.  wp: migan_c64_pack().
 // accumulate != 0: y += (the residual sum of srgan/models.py:30 on the input-gradient side).
 MIGAN_API int migan_c64_conv_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int H, int W, int act, float slope,
-                                 int accumulate, const float* in_scale, const float* in_shift, int in_act, float in_slope,
-                                 const float* in_slope_ptr, void* stream) {
+                                 int accumulate, const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta,
+                                 int in_act, float in_slope, const float* in_slope_ptr, void* stream) {
     if (!c64_geom_ok(N, H, W)) return (int)hipErrorInvalidValue;   // (any number of row-steps: migan_c64_conv_ok() is the host's size gate)
     if (act != ACT_NONE && act != ACT_LRELU && act != ACT_RELU) return (int)hipErrorInvalidValue;
-    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_act != ACT_NONE && in_act != ACT_LRELU)) return (int)hipErrorInvalidValue;
+    if ((in_mean == nullptr) != (in_invstd == nullptr) || (in_act != ACT_NONE && in_act != ACT_LRELU)) return (int)hipErrorInvalidValue;
     C64Geom g = {};
     g.N = N; g.H = H; g.W = W; g.strips = W / 32;
     g.steps = N * g.strips * H;
@@ -337,13 +506,58 @@ MIGAN_API int migan_c64_conv_fwd(const float* x, const float* wp, const float* b
     fastdiv_magic((unsigned)H, g.mg_h, g.sh_h);
     fastdiv_magic((unsigned)g.strips, g.mg_s, g.sh_s);
     g.act = act; g.slope = slope; g.accum = accumulate;
-    g.in_on = in_scale != nullptr; g.in_act = in_act; g.in_slope = in_slope;
+    g.in_on = in_mean != nullptr; g.in_act = in_act; g.in_slope = in_slope;
     const dim3 grid(cdiv(g.steps, g.spw));
     const f32x4* wq = reinterpret_cast<const f32x4*>(wp);
     hipStream_t st = (hipStream_t)stream;
-    if (!in_scale) MIGAN_LAUNCH((c64_conv_kernel<0>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_scale, in_shift, in_slope_ptr);
-    else if (in_act == ACT_NONE) MIGAN_LAUNCH((c64_conv_kernel<1>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_scale, in_shift, in_slope_ptr);
-    else MIGAN_LAUNCH((c64_conv_kernel<2>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_scale, in_shift, in_slope_ptr);
+    if (!in_mean) MIGAN_LAUNCH((c64_conv_kernel<0>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
+    else if (in_act == ACT_NONE)
+        MIGAN_LAUNCH((c64_conv_kernel<1>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
+    else MIGAN_LAUNCH((c64_conv_kernel<2>), grid, dim3(256), 0, st, g, x, wq, bias, y, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
     HIP_LAUNCH_CHECK();
     return 0;
+}
+
+int wgrad_reduce_slabs(const float* ws, float* dw, int nslabs, int Co, int T, int Ci, int accum, const float* db_slabs, float* db,
+                       int db_nslab, int db_accum, hipStream_t st);   // conv_igemm.hip
+
+static int c64_wgrad_wgs(int N, int H, int W) {
+    // one slab (147 KB) per workgroup: on the 96 x 96 trunk (4608 row-steps) 256 workgroups measured 103.4 us against 116.3 us with 512 (the
+    // fixed-order reduction reads half the slabs) and 120.3 us for the general kernel; on 384 x 384 maps (73 728 steps) the reduction is noise and
+    // two workgroups per CU win: 1284 vs 1328 us (general kernel 1505) - profiles/r06_ab.txt calls 30, 31
+    const long steps = (long)N * (W / 32) * H;
+    const int knob = MIGAN_KNOB("MIGAN_C64_WGRAD_WGS", 0);
+    const int want = knob > 0 ? knob : (steps >= 16384 ? 512 : 256);
+    return (int)(steps < want ? steps : want);
+}
+MIGAN_API size_t migan_c64_wgrad_workspace(int N, int H, int W) {
+    if (!c64_geom_ok(N, H, W)) return 0;
+    return (size_t)c64_wgrad_wgs(N, H, W) * 64 * 576 * sizeof(float);
+}
+// dw_oihw [64][64][3][3] (accumulate: +=) = weight gradient of y = conv3x3(T(x), w) from dy [N][H][W][64]; T as in migan_c64_conv_fwd.  db
+// (optional) from the caller's column-sum slabs of dy (db_slabs [db_nslab][64], as migan_conv2d_wgrad).  ws: migan_c64_wgrad_workspace().
+MIGAN_API int migan_c64_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float* ws, size_t ws_bytes, int N, int H, int W,
+                                   int accumulate, float* db, int db_accumulate, const float* db_slabs, int db_nslab,
+                                   const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta, int in_act,
+                                   float in_slope, const float* in_slope_ptr, void* stream) {
+    if (!c64_geom_ok(N, H, W) || ws_bytes < migan_c64_wgrad_workspace(N, H, W)) return (int)hipErrorInvalidValue;
+    if ((in_mean == nullptr) != (in_invstd == nullptr) || (in_act != ACT_NONE && in_act != ACT_LRELU)) return (int)hipErrorInvalidValue;
+    if (db && !db_slabs) return (int)hipErrorInvalidValue;
+    C64Geom g = {};
+    g.N = N; g.H = H; g.W = W; g.strips = W / 32;
+    g.steps = N * g.strips * H;
+    const int wgs = c64_wgrad_wgs(N, H, W);
+    g.spw = cdiv(g.steps, wgs);
+    fastdiv_magic((unsigned)H, g.mg_h, g.sh_h);
+    fastdiv_magic((unsigned)g.strips, g.mg_s, g.sh_s);
+    g.in_on = in_mean != nullptr; g.in_act = in_act; g.in_slope = in_slope;
+    const int nwg = cdiv(g.steps, g.spw);   // every one of them writes its slab (possibly all zeros)
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nwg);
+    if (!in_mean) MIGAN_LAUNCH((c64_wgrad_kernel<0>), grid, dim3(256), 0, st, g, x, dy, ws, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
+    else if (in_act == ACT_NONE)
+        MIGAN_LAUNCH((c64_wgrad_kernel<1>), grid, dim3(256), 0, st, g, x, dy, ws, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
+    else MIGAN_LAUNCH((c64_wgrad_kernel<2>), grid, dim3(256), 0, st, g, x, dy, ws, in_mean, in_invstd, in_gamma, in_beta, in_slope_ptr);
+    HIP_LAUNCH_CHECK();
+    return wgrad_reduce_slabs(ws, dw_oihw, nwg, 64, 9, 64, accumulate, db_slabs, db, db_nslab, db_accumulate, st);
 }

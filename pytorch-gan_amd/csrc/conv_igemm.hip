@@ -1302,6 +1302,13 @@ MIGAN_API int migan_upconv3x3_wgrad(const float* x, const float* dy, float* dw_o
 
 #include "conv_valu_wgrad.inc"   // thin / small / tiled-thin VALU weight-gradient kernels + their planners
 
+// the fixed-order slab reduction (+ bias column sums from external slabs) for weight-gradient kernels of other translation units (conv_c64.hip)
+int wgrad_reduce_slabs(const float* ws, float* dw, int nslabs, int Co, int T, int Ci, int accum, const float* db_slabs, float* db,
+                       int db_nslab, int db_accum, hipStream_t st) {
+    const BiasRed ext = (db && db_slabs) ? BiasRed{db_slabs, db, db_nslab, db_accum, 0, 0} : BiasRed{};
+    return launch_wgrad_reduce(ws, dw, nslabs, Co, T, Ci, accum, st, ext);
+}
+
 MIGAN_API size_t migan_conv2d_wgrad_workspace(int N, int Ho, int Wo, int Co, int R, int S, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, Ho, Wo, Co, R * S * Ci, bm, splits, pps);

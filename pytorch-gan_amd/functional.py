@@ -816,7 +816,7 @@ class _Conv2d(Function):
             # weight-stationary kernel - weights in registers, input rows in an LDS ring (csrc/conv_c64.hip)
             wk = _packed_c64(w_in, w, 0)
             y = _empty_nhwc((N, Co, Ho, Wo), xs)
-            check(lib.migan_c64_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, act, slope, 0, None, None, 0, 0.0,
+            check(lib.migan_c64_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(b), y.data_ptr(), N, H, W, act, slope, 0, None, None, None, None, 0, 0.0,
                                          None, _stream()), "c64_conv_fwd")
             ctx.save_for_backward(xs, w, y if act != ACT_NONE else None, None, None)
             return y
@@ -954,9 +954,18 @@ class _Conv2d(Function):
                 elif want_db and _FUSE_BIAS and lib.migan_conv2d_wgrad_fuses_bias(Co, R, S, Ci, stride, gather):
                     dbt, dba, db = _bias_out(ctx.params[1], Co, xs)
                     dbp, want_db = dbt.data_ptr(), False
-                check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
-                                             Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1,
-                                             dbp, dba, sl, nsl, st), "conv2d_wgrad")
+                if (_C64 and (dbp is None or sl is not None)
+                        and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
+                    # Conv2d(64, 64, 3, 1, 1): accumulators stationary, x and dy read once (csrc/conv_c64.hip c64_wgrad_kernel)
+                    nbc = lib.migan_c64_wgrad_workspace(N, H, W)
+                    wsc = _ws(nbc, xs)
+                    check(lib.migan_c64_conv_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsc.data_ptr(), nbc, N, H, W,
+                                                   0 if slot is None else 1, dbp, dba, sl, nsl, None, None, None, None, 0, 0.0, None, st),
+                          "c64_conv_wgrad")
+                else:
+                    check(lib.migan_conv2d_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, N, H, W, Ci,
+                                                 Ho, Wo, Co, R, S, stride, pt, pl, gather, 0 if slot is None else 1,
+                                                 dbp, dba, sl, nsl, st), "conv2d_wgrad")
                 if slot is not None:
                     dw = None
             if want_db:
@@ -990,7 +999,7 @@ def _conv2d_dgrad_raw(ctx, dy, xs, w, ring_on_side=False):
             and lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, stride, pt, pl, pb, pr, gather) == 1):
         # the input gradient of Conv2d(64, 64, 3, 1, 1) IS that convolution with the taps reversed and the channel roles swapped
         wk = _packed_c64(ctx.params[0], w, 1)
-        check(lib.migan_c64_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, None, None, 0, 0.0, None,
+        check(lib.migan_c64_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, dx.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, None, None, None, None, 0, 0.0, None,
                                      st), "c64_conv_dgrad")
         return dx
     wt = _packed_perm(ctx.params[0], w, "ihwo", (1, 2, 3, 0))
@@ -1970,6 +1979,128 @@ def norm(x, gamma=None, beta=None, res=None, running_mean=None, running_var=None
     as the store index map of the same launches (output (N, C/4, 2H, 2W))."""
     return _Norm.apply(x, gamma, beta, res, running_mean, running_var, bool(use_batch_stats), float(momentum),
                        float(eps), bool(instance), int(act), float(slope), num_batches_tracked, prelu, int(shuffle), mask)
+
+
+_BN_FOLD = __import__("os").environ.get("MIGAN_BN_FOLD", "1") == "1"   # A/B knob (round 6): 0 = BatchNorm+PReLU as launches of their own
+
+
+def bn_prelu_conv64_takes(x, w, stride, pads, dilation=(1, 1), groups=1):
+    """True when bn_prelu_conv64(x, ...) serves the chain: local-batch BatchNorm statistics, first-order backward, the geometry of
+    csrc/conv_c64.hip."""
+    if not (_BN_FOLD and _C64) or x.dim() != 4 or w.dim() != 4:
+        return False
+    if (_SYNC_BN is not None and _SYNC_BN.world > 1) or _BN_GROUPS != 1 or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    Co, Ci, R, S = w.shape
+    if Ci != C or not w.is_contiguous() or N * H * W <= 1:
+        return False
+    pt, pl, pb, pr = pads
+    return lib.migan_c64_conv_ok(N, H, W, Ci, Co, R, S, int(stride), pt, pl, pb, pr, GATHER_ZERO) == 1
+
+
+class _BnPreluConv64(Function):
+    """conv2d(prelu(batch_norm(x)), w, b) for BatchNorm2d(64, 0.8) -> PReLU() -> Conv2d(64, 64, 3, 1, 1) (srgan/models.py:23-25) with the
+    normalised, activated tensor never stored: one statistics pass over x, then the convolution reads x through the affine map + PReLU
+    on its way into LDS (csrc/conv_c64.hip, INMAP), and so does its weight gradient.  Backward: input gradient of the conv -> the
+    BatchNorm+PReLU backward launches of _Norm.  First order only (the reference never differentiates srgan's generator twice)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, momentum, eps, prelu, w, b):
+        xs = canon(x)
+        N, C, H, W = xs.shape
+        P = N * H * W
+        ctx.x_nchw = x.is_contiguous() and not x.is_contiguous(memory_format=CL)
+        ctx.params = (gamma, beta, prelu, w, b)
+        gm, bt, pw, wt, bs = _plain(gamma), _plain(beta), _plain(prelu), _plain(w), _plain(b)
+        st = _stream()
+        mean = torch.empty(C, device=xs.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        nb = lib.migan_norm_workspace(1, P, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                   momentum, eps, 1, P, C, ws.data_ptr(), nb, st), "norm_stats")
+        wk = _packed_c64(w, wt, 0)
+        y = _empty_nhwc((N, C, H, W), xs)
+        check(lib.migan_c64_conv_fwd(xs.data_ptr(), wk.data_ptr(), _ptr(bs), y.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, mean.data_ptr(),
+                                     invstd.data_ptr(), _ptr(gm), _ptr(bt), ACT_LRELU, 0.0, pw.data_ptr(), st), "c64_conv_fwd")
+        ctx.save_for_backward(xs, gm, bt, mean, invstd, pw, wt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _first_order_only("BatchNorm2d -> PReLU -> Conv2d(64, 64, 3, 1, 1) folded into one convolution")
+        xs, gm, bt, mean, invstd, pw, wt = ctx.saved_tensors
+        gamma, beta, prelu, w, b = ctx.params
+        N, C, H, W = xs.shape
+        P = N * H * W
+        dy = to_nhwc(dy)
+        st = _stream()
+        dw = db = dgamma = dbeta = dprelu = dx = None
+        # -- the conv's parameter gradients: x read through the same map as the forward
+        if ctx.needs_input_grad[9]:
+            slot = _grad_slot(w)
+            dw = torch.empty_like(wt) if slot is None else slot
+            dbp, dba, sl, nsl = None, 0, None, 0
+            side = _colsum_side(dy, C) if (b is not None and ctx.needs_input_grad[10]) else None
+            if side is not None:
+                dbt, dba, db = _bias_out(b, C, xs)
+                dbp, sl, nsl = dbt.data_ptr(), side[0].data_ptr(), side[1]
+            nbc = lib.migan_c64_wgrad_workspace(N, H, W)
+            wsc = _ws(nbc, xs)
+            check(lib.migan_c64_conv_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsc.data_ptr(), nbc, N, H, W, 0 if slot is None else 1,
+                                           dbp, dba, sl, nsl, mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt), ACT_LRELU, 0.0,
+                                           pw.data_ptr(), st), "c64_conv_wgrad")
+            if slot is not None:
+                dw = None
+            if b is not None and ctx.needs_input_grad[10] and side is None:
+                db = _colsum(dy, P, C, _grad_slot(b))
+        elif b is not None and ctx.needs_input_grad[10]:
+            db = _colsum(dy, P, C, _grad_slot(b))
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[8]):
+            return (None,) * 9 + (dw, db)
+        # -- gradient at the conv's input (= behind the PReLU): the same convolution with reversed taps
+        wk = _packed_c64(w, wt, 1)
+        g = _empty_nhwc((N, C, H, W), xs)
+        check(lib.migan_c64_conv_fwd(dy.data_ptr(), wk.data_ptr(), None, g.data_ptr(), N, H, W, ACT_NONE, 0.0, 0, None, None, None, None, 0,
+                                     0.0, None, st), "c64_conv_dgrad")
+        # -- BatchNorm + PReLU backward, as _Norm.backward's fused-PReLU branch
+        dx = torch.empty_like(xs)
+        acc = 0
+        if gm is not None:
+            sg, sb = _grad_slot(gamma), _grad_slot(beta)
+            if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+                dgamma, dbeta, acc = sg, sb, 1
+            else:
+                dgamma = torch.empty(C, device=xs.device, dtype=torch.float32)
+                dbeta = torch.empty_like(dgamma)
+        slabs, nslab = None, 0
+        if _COLSUM_FUSE and not ctx.x_nchw:
+            nslab = lib.migan_norm_colsum_slabs(1, P, C)
+            slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
+        want_dp = ctx.needs_input_grad[8]
+        pslot = _grad_slot(prelu) if want_dp else None
+        dpt = pslot if pslot is not None else (torch.empty(1, device=xs.device, dtype=torch.float32) if want_dp else None)
+        nbp = lib.migan_norm_workspace_prelu(1, P, C)
+        wsp = _ws(nbp, xs)
+        check(lib.migan_norm_bwd_prelu(xs.data_ptr(), g.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt), pw.data_ptr(),
+                                       dx.data_ptr(), _ptr(dgamma), _ptr(dbeta), _ptr(dpt), 1, P, C, wsp.data_ptr(), nbp, acc,
+                                       1 if pslot is not None else 0, _ptr(slabs), 0, 0, st), "norm_bwd_prelu")
+        if want_dp and pslot is None:
+            dprelu = dpt.view(prelu.shape)
+        if acc:
+            dgamma = dbeta = None
+        if ctx.x_nchw:
+            dx = to_nchw(dx)
+        elif slabs is not None:
+            _attach_colsum(dx, slabs, nslab, C)
+        return dx, dgamma, dbeta, None, None, None, None, None, dprelu, dw, db
+
+
+def bn_prelu_conv64(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, prelu, w, b):
+    """Training-mode BatchNorm2d (local batch statistics; running statistics and num_batches_tracked updated by the statistics kernel)
+    -> single-slope PReLU -> Conv2d(64, 64, 3, 1, 1), the activated tensor never stored (see _BnPreluConv64)."""
+    return _BnPreluConv64.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), prelu, w, b)
 
 
 # ---------------------------------------------------------------------------------------------- index remaps

@@ -596,6 +596,19 @@ class Sequential(tnn.Sequential):
                         and F._BN_GROUPS == 1:   # paired batches (functional.batch_groups): the plain BatchNorm path, PReLU / shuffle as their own launches
                     q = k + 1 if (k < n and type(mods[k]) is PixelShuffle) else k
                     if q < n and type(mods[q]) is PReLU and mods[q].num_parameters == 1:
+                        cv = mods[q + 1] if (q == k and q + 1 < n and type(mods[q + 1]) is Conv2d) else None
+                        if (cv is not None and m.training and m.momentum is not None and cv.padding_mode == "zeros"
+                                and not isinstance(cv.padding, str) and _pair(cv.stride) == (1, 1)
+                                and F.bn_prelu_conv64_takes(x, cv.weight, 1, _pair(cv.padding) * 2, _pair(cv.dilation), cv.groups)):
+                            # BatchNorm2d(64, 0.8), PReLU(), Conv2d(64, 64, 3, 1, 1) (srgan/models.py:23-25): the conv reads the block's
+                            # first conv output through the normalisation and the PReLU - the tensor between them is never stored
+                            trk = m.track_running_stats
+                            x = _wrap(F.bn_prelu_conv64(x, m.weight if m.affine else None, m.bias if m.affine else None,
+                                                        m.running_mean if trk else None, m.running_var if trk else None,
+                                                        m.num_batches_tracked if trk else None, m.momentum, m.eps, mods[q].weight,
+                                                        cv.weight, cv.bias))
+                            i = q + 2
+                            continue
                         if q > k and mods[k].upscale_factor == 2 and x.shape[1] % 4 == 0 and _SHUFFLE_FUSE:
                             x = m.fused_forward(x, F.ACT_NONE, 0.0, None, mods[q].weight, 2)   # shuffle = store index map
                         else:

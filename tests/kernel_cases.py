@@ -21,9 +21,9 @@ CONV = [
     ("fewpix_3x3_s1", (2, 256, 2, 2, 512, 3, 1, (1, 1, 1, 1), 0, 2, True), ("im2col_small_kernel", "col2im_small_kernel")),
     # 512 k-element weight at 64 pixels: tiled OHWI / IHWO packs, split-K slabs
     ("unet_mid", (1, 128, 16, 16, 256, 4, 2, (1, 1, 1, 1), 0, 0, False), ("pack_transpose_kernel",)),
-    # Conv2d(64, 64, 3, 1, 1) on W % 32 == 0 columns (srgan/models.py:22-30: the residual trunk): weight-stationary kernel, forward and input
-    # gradient (tests/conftest.py lowers its size gate, MIGAN_C64_MIN_STEPS, so that this small shape takes it); 3 strips x 2 images x 13 rows
-    ("trunk_c64", (2, 64, 13, 96, 64, 3, 1, (1, 1, 1, 1), 0, 1, True), ("c64_conv_kernel<0>",)),
+    # Conv2d(64, 64, 3, 1, 1) on W % 32 == 0 columns (srgan/models.py:22-30: the residual trunk): weight-stationary kernels - forward, input
+    # gradient, weight gradient (tests/conftest.py lowers its size gate, MIGAN_C64_MIN_STEPS, so that this small shape takes it); 3 strips x 2 images x 13 rows
+    ("trunk_c64", (2, 64, 13, 96, 64, 3, 1, (1, 1, 1, 1), 0, 1, True), ("c64_conv_kernel<0>", "c64_wgrad_kernel<0>")),
     # 4 M-element weight at 81 output pixels (above the few-pixel path): tiled packs + the transposing slab reduction
     ("unet_81px", (1, 512, 18, 18, 512, 4, 2, (1, 1, 1, 1), 0, 0, False), ("pack_transpose_kernel", "wgrad_reduce_tr_kernel")),
 ]

@@ -571,6 +571,15 @@ def test_conv3x3_tap_inner_k_order_on_the_execution_model(idx, monkeypatch):
     _run_gpu_test_body("test_ops_gpu", "test_conv3x3_tap_inner_k_order", __import__("pytorch_gan_amd"), test_ops_gpu.TAP9_CASES[idx], monkeypatch)
 
 
+def test_trunk_block_batchnorm_prelu_folded_into_the_conv_on_the_execution_model(monkeypatch):
+    """test_ops_gpu.py::test_trunk_block_batchnorm_prelu_folded_into_the_conv without a GPU: the input map of c64_conv_kernel<2> /
+    c64_wgrad_kernel<2> (BatchNorm2d(64, 0.8) -> PReLU applied on the way into the LDS row ring) inside the srgan residual block,
+    against torch in fp64 and against the separate norm launches."""
+    lib = _run_gpu_test_body("test_ops_gpu", "test_trunk_block_batchnorm_prelu_folded_into_the_conv", __import__("pytorch_gan_amd"), (1, 9, 64),
+                             monkeypatch)
+    assert lib.hipemu_launch_count(b"c64_wgrad_kernel<2>") > 0
+
+
 def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monkeypatch):
     """SURVEY.md 8e with real kernels and no GPU: the body of test_dp_gpu.py::test_cross_replica_batchnorm_equals_full_batch -
     two torch.distributed.run ranks (gloo) each run half of a DCGAN batch with enable_sync_batchnorm() (local moments ->

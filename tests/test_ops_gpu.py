@@ -779,6 +779,63 @@ def test_sequential_bn_shuffle_prelu_equals_unfused(pg):
         assert_close(ga, gb, 5e-5, "gradient of " + k)
 
 
+@pytest.mark.parametrize("shape", [(1, 9, 64), (2, 13, 96)], ids=["1x9x64", "2x13x96"])
+def test_trunk_block_batchnorm_prelu_folded_into_the_conv(pg, shape, monkeypatch):
+    """srgan/models.py:19-31 ResidualBlock: conv, BatchNorm2d(64, 0.8), PReLU, conv, BatchNorm2d(64, 0.8), + x.  nn.Sequential hands
+    BatchNorm -> PReLU -> Conv2d(64, 64, 3, 1, 1) to one Function: the second conv (forward and weight gradient) reads the first conv's
+    output through the normalisation and the PReLU (csrc/conv_c64.hip INMAP = 2), no launch stores the activated tensor.  Against torch in
+    fp64 on the host: output, input gradient, every parameter gradient, the running statistics and num_batches_tracked; then against
+    the same block with the fold switched off (the separate norm launches)."""
+    import copy
+
+    N, H, W = shape
+    nn, F = pg.nn, pg.functional
+    torch.manual_seed(5)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(64, 64, 3, 1, 1), torch.nn.BatchNorm2d(64, 0.8), torch.nn.PReLU(), torch.nn.Conv2d(64, 64, 3, 1, 1),
+                              torch.nn.BatchNorm2d(64, 0.8))
+    with torch.no_grad():
+        for bn in (ref[1], ref[4]):
+            bn.weight.copy_(_leaf(64, seed=21) * 0.5 + 1.0)
+            bn.bias.copy_(_leaf(64, seed=22) * 0.5)
+    x = _leaf(N, 64, H, W, seed=7)
+    gy = _leaf(N, 64, H, W, seed=8)
+    ref64 = copy.deepcopy(ref).double()
+    x64 = x.double().requires_grad_(True)
+    y64 = x64 + ref64(x64)
+    y64.backward(gy.double())
+    outs = []
+    for fold in (True, False):
+        monkeypatch.setattr(F, "_BN_FOLD", fold)
+        seq = pg.swap(copy.deepcopy(ref)).to(DEV)
+        assert type(seq) is nn.Sequential
+        xin = x.to(DEV).clone().requires_grad_(True)
+        with Launches() as n:
+            y = seq(xin, res=xin)
+            y.backward(gy.to(DEV))
+            if fold:
+                assert n("c64_conv_kernel<2>") == 1 and n("c64_wgrad_kernel<2>") == 1, "the folded kernels did not run"
+                assert n("norm_apply") == 1, "the activated tensor was stored"   # (the one launch: the block's last BatchNorm + x)
+            else:
+                assert n("c64_conv_kernel<2>") == 0 and n("norm_apply") == 2
+        outs.append((y.detach(), xin.grad, {k: p.grad.clone() for k, p in seq.named_parameters()},
+                     {k: b.clone() for k, b in seq.named_buffers()}))
+    for tag, (y, dx, grads, bufs) in zip(("folded", "separate"), outs):
+        assert_close(y, y64.float(), 2e-5, tag + " output")
+        assert_close(dx, x64.grad.float(), 1e-4, tag + " input gradient")
+        for k, p in ref64.named_parameters():
+            if k in ("0.bias", "3.bias"):   # a conv bias in front of BatchNorm: zero true gradient, rounding noise on both sides
+                assert float(grads[k].abs().max()) <= 1e-3 * float(gy.abs().sum()) / 64, k
+                continue
+            assert_close(grads[k], p.grad.float(), 1e-4, tag + " gradient of " + k)
+        for k, b in ref64.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                assert int(bufs[k]) == int(b) == 1, k
+            else:
+                assert_close(bufs[k], b.float(), 1e-5, tag + " " + k)
+    assert_close(outs[0][0], outs[1][0], 2e-6, "folded vs separate launches: output")
+    assert_close(outs[0][1], outs[1][1], 2e-5, "folded vs separate launches: input gradient")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 32, 40)], ids=["64-128ch", "k-tail-40ch"])
 def test_relu_backward_handed_to_the_consumer(pg, shape):
     """vgg19.features[:18] (srgan/models.py:8-15): conv ReLU conv ReLU MaxPool conv ReLU.  nn.Sequential hands the ReLU backward of a

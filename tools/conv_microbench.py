@@ -197,7 +197,7 @@ def main():
             wpd = torch.empty_like(wpf)
             check(lib.migan_c64_pack(wo.data_ptr(), wpf.data_ptr(), 0, st), "c64 pack")
             yc = torch.empty_like(y)
-            check(lib.migan_c64_conv_fwd(x.data_ptr(), wpf.data_ptr(), None, yc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, 0, 0.0, None, st), "c64")
+            check(lib.migan_c64_conv_fwd(x.data_ptr(), wpf.data_ptr(), None, yc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, None, None, 0, 0.0, None, st), "c64")
             check(calls["fwd"](), "fwd")
             torch.cuda.synchronize()
             print("   c64 fwd vs general kernel: rel %.2e" % float((yc - y).norm() / y.norm()))
@@ -205,16 +205,26 @@ def main():
             wi = wo.permute(1, 2, 3, 0).contiguous()
             check(lib.migan_c64_pack(wo.data_ptr(), wpd.data_ptr(), 1, st), "c64 pack flip")
             dxc = torch.empty_like(dx)
-            check(lib.migan_c64_conv_fwd(dy.data_ptr(), wpd.data_ptr(), None, dxc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, 0, 0.0, None, st), "c64d")
+            check(lib.migan_c64_conv_fwd(dy.data_ptr(), wpd.data_ptr(), None, dxc.data_ptr(), N, H, W, 0, 0.0, 0, None, None, None, None, 0, 0.0, None, st), "c64d")
             check(lib.migan_conv2d_dgrad_ws(dy.data_ptr(), wi.data_ptr(), None, dx.data_ptr(), N, Hd, Wd, Ci, Ho, Wo, Co, k, k, s, pd, pd, 0, 0.0,
                                             skp, skb, st), "dgrad")
             torch.cuda.synchronize()
             print("   c64 dgrad vs general kernel: rel %.2e" % float((dxc - dx).norm() / dx.norm()))
             calls["cfwd"] = lambda: lib.migan_c64_conv_fwd(x.data_ptr(), wpf.data_ptr(), None, y.data_ptr(), N, H, W, 0, 0.0, 0, None, None,
-                                                           0, 0.0, None, st)
+                                                           None, None, 0, 0.0, None, st)
             calls["cdgrad"] = lambda: lib.migan_c64_conv_fwd(dy.data_ptr(), wpd.data_ptr(), None, dx.data_ptr(), N, H, W, 0, 0.0, 0, None,
-                                                             None, 0, 0.0, None, st)
-            dirs += ["cfwd", "cdgrad"]
+                                                             None, None, None, 0, 0.0, None, st)
+            nbc = lib.migan_c64_wgrad_workspace(N, H, W)
+            wsc = torch.empty(nbc // 4, device=dev)
+            dwc = torch.empty(Co * Ci * k * k, device=dev)
+            check(lib.migan_c64_conv_wgrad(x.data_ptr(), dy.data_ptr(), dwc.data_ptr(), wsc.data_ptr(), nbc, N, H, W, 0, None, 0, None, 0, None, None,
+                                           None, None, 0, 0.0, None, st), "c64w")
+            check(calls["wgrad"](), "wgrad")
+            torch.cuda.synchronize()
+            print("   c64 wgrad vs general kernel: rel %.2e" % float((dwc - dw).norm() / dw.norm()))
+            calls["cwgrad"] = lambda: lib.migan_c64_conv_wgrad(x.data_ptr(), dy.data_ptr(), dwc.data_ptr(), wsc.data_ptr(), nbc, N, H, W, 0, None, 0,
+                                                               None, 0, None, None, None, None, 0, 0.0, None, st)
+            dirs += ["cfwd", "cdgrad", "cwgrad"]
         if Co <= 3 and lib.migan_rgb_conv_ok(Co, Ci, k, k, s, gth, N * H * W) == 1 and p == 1 and gth == 0:
             # thin-OUTPUT layer (dcgan.py:62): odgrad = its input gradient on the image-input forward kernel, taps reversed
             wko = w.view(Co, Ci, k, k).permute(2, 3, 0, 1).contiguous()
