@@ -2037,26 +2037,29 @@ class _BnPreluConv64(Function):
         dy = to_nhwc(dy)
         st = _stream()
         dw = db = dgamma = dbeta = dprelu = dx = None
-        # -- the conv's parameter gradients: x read through the same map as the forward
-        if ctx.needs_input_grad[9]:
-            slot = _grad_slot(w)
-            dw = torch.empty_like(wt) if slot is None else slot
-            dbp, dba, sl, nsl = None, 0, None, 0
-            side = _colsum_side(dy, C) if (b is not None and ctx.needs_input_grad[10]) else None
-            if side is not None:
-                dbt, dba, db = _bias_out(b, C, xs)
-                dbp, sl, nsl = dbt.data_ptr(), side[0].data_ptr(), side[1]
-            nbc = lib.migan_c64_wgrad_workspace(N, H, W)
-            wsc = _ws(nbc, xs)
-            check(lib.migan_c64_conv_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsc.data_ptr(), nbc, N, H, W, 0 if slot is None else 1,
-                                           dbp, dba, sl, nsl, mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt), ACT_LRELU, 0.0,
-                                           pw.data_ptr(), st), "c64_conv_wgrad")
-            if slot is not None:
-                dw = None
-            if b is not None and ctx.needs_input_grad[10] and side is None:
+        # -- the conv's parameter gradients: x read through the same map as the forward; on the weight-gradient stream inside a step body,
+        #    as _Conv2d's (the launch has one workgroup per CU at the trunk size: the input gradient that follows shares the CUs with it)
+        side = _colsum_side(dy, C) if (b is not None and ctx.needs_input_grad[10]) else None
+        fork = _Fork(xs.device, dy.numel(), ctx.needs_input_grad[9])
+        with fork:
+            stw = _stream()
+            if ctx.needs_input_grad[9]:
+                slot = _grad_slot(w)
+                dw = torch.empty_like(wt) if slot is None else slot
+                dbp, dba, sl, nsl = None, 0, None, 0
+                if side is not None:
+                    dbt, dba, db = _bias_out(b, C, xs)
+                    dbp, sl, nsl = dbt.data_ptr(), side[0].data_ptr(), side[1]
+                nbc = lib.migan_c64_wgrad_workspace(N, H, W)
+                wsc = _ws(nbc, xs)
+                check(lib.migan_c64_conv_wgrad(xs.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsc.data_ptr(), nbc, N, H, W,
+                                               0 if slot is None else 1, dbp, dba, sl, nsl, mean.data_ptr(), invstd.data_ptr(), _ptr(gm),
+                                               _ptr(bt), ACT_LRELU, 0.0, pw.data_ptr(), stw), "c64_conv_wgrad")
+                if slot is not None:
+                    dw = None
+            if b is not None and ctx.needs_input_grad[10] and (side is None or not ctx.needs_input_grad[9]):
                 db = _colsum(dy, P, C, _grad_slot(b))
-        elif b is not None and ctx.needs_input_grad[10]:
-            db = _colsum(dy, P, C, _grad_slot(b))
+        fork.join((dw, db), (dy, xs, side[0] if side is not None else None, mean, invstd))
         if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or ctx.needs_input_grad[8]):
             return (None,) * 9 + (dw, db)
         # -- gradient at the conv's input (= behind the PReLU): the same convolution with reversed taps
