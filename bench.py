@@ -185,11 +185,12 @@ def build_cyclegan(dp, rank, dev, args, nsteps):
             state.buf_B.push_and_pop(state.G_AB(a))
     # the recorded step: the replay buffers' host draws (python `random`, the reference's order) happen in front of every replay
     # into static device tables (steps.CycleGanRunner); --no-graph launches the same step eagerly
-    # Recorded at every batch size.  (Round 5 timed batch 8 eagerly: its recording measured slower, 147.8 vs 140-146 ms.  Round 6 found why -
-    # behind ONE warm-up step the recording held every weight pack as its own launch, one copy per forked stream, 238 launches per step;
-    # graph.StepRunner now builds the pack plan's tables in front of the capture - and measured 142.1 / 142.5 ms recorded against 143.6 /
-    # 140.8 ms eager, profiles/r06_ab.txt call 29.)  --no-graph: eager.
-    use_graph = not args.no_graph
+    # Recorded where the step is launch-bound (<= 2 images per GPU: 33.0 ms recorded against 45 ms eager at one image), eager at batch 8.
+    # Round 6 removed the 238 per-step pack launches the batch-8 recording held (graph.StepRunner builds the pack plan's tables in front of
+    # the capture) and re-measured on one box: 142.3 ms recorded against 136.1 / 136.5 ms eager (profiles/r06_ab.txt calls 38-39) - with
+    # ~2200 kernel nodes of 60 us on three forked streams the replay's node-to-node hand-over costs more than the CPU launches it saves,
+    # which the GPU hides at this size anyway.  --graph-always records at every batch size, --no-graph never.
+    use_graph = (not args.no_graph) and (batch <= 2 or args.graph_always)
     runner = steps.CycleGanRunner(state, a, b, use_graph=use_graph, warmup=1).prepare()
     w = Workload("cyclegan", batch, lambda i: runner.run(), state, None, runner.graphed, runner.capture_error, tuple(nets))
     w.eager = lambda: steps.cyclegan_step(state, a, b)

@@ -146,29 +146,35 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
                 if (BWD) dv[0] = dyb[(size_t)p * C + c];
             }
         };
-        // four pixels' loads in flight per thread (a thread walks 9-512 pixels: one load at a time left the pass latency-bound at
-        // 2.2 TB/s on the 38-75 MB tensors of SRGAN's trunk against 4-5 TB/s for the apply pass, profiles/r04_srgan_kernel_stats.txt)
-        // (round 5: eight where the thread has eight left - the 144-pixel chunks of SRGAN's trunk are 9 pixels per thread: one round + one
-        // instead of three dependent round trips)
+        // Software-pipelined walk over the thread's pixels (round 6): batches of U pixels, the NEXT batch's loads issued before the current
+        // batch is accumulated, so one memory round trip is exposed per workgroup instead of one per batch (a thread of SRGAN's trunk
+        // walks 9 pixels = three dependent rounds of 4 + 4 + 1 before: 34 us for 75 MB, 2.2 TB/s, profiles/r06_ab.txt call 33).  Loads
+        // past the chunk are clamped to its last pixel and their accumulation skipped; a thread adds its pixels in ascending order as before.
+        constexpr int U = BWD ? 4 : 8;
+        auto load_batch = [&](int pb, float (&xv)[U][VW], float (&dv)[U][VW]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = pb + u * TY;
+                load(q < p1 ? q : p1 - 1, xv[u], dv[u]);
+            }
+        };
+        auto accum_batch = [&](int pb, const float (&xv)[U][VW], const float (&dv)[U][VW]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (pb + u * TY < p1) accum(xv[u], dv[u]);
+        };
         int p = p0 + ty;
-        for (; !BWD && p + 7 * TY < p1; p += 8 * TY) {   // (the backward form would need 179 registers: two waves per SIMD)
-            float xv[8][VW], dv[8][VW];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) load(p + u * TY, xv[u], dv[u]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) accum(xv[u], dv[u]);
-        }
-        for (; p + 3 * TY < p1; p += 4 * TY) {
-            float xv[4][VW], dv[4][VW];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) load(p + u * TY, xv[u], dv[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) accum(xv[u], dv[u]);
-        }
-        for (; p < p1; p += TY) {
-            float xv[VW], dv[VW];
-            load(p, xv, dv);
-            accum(xv, dv);
+        if (p < p1) {
+            float xa[U][VW], da[U][VW], xq[U][VW], dq[U][VW];
+            load_batch(p, xa, da);
+            for (; p < p1; p += 2 * U * TY) {
+                const bool more = p + U * TY < p1;
+                if (more) load_batch(p + U * TY, xq, dq);
+                accum_batch(p, xa, da);
+                if (!more) break;
+                if (p + 2 * U * TY < p1) load_batch(p + 2 * U * TY, xa, da);
+                accum_batch(p + U * TY, xq, dq);
+            }
         }
     }
 #pragma unroll
@@ -514,9 +520,12 @@ static void norm_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, int& n
     while (CTX < cv && CTX < 64) CTX <<= 1;
     gx = cdiv(cv, CTX);
     int TY = 256 / CTX;
-    // aim for ~2048 blocks total, at least 4 pixels per ty lane
+    // ~512 blocks in total (two per CU), at least 4 pixels per ty lane.  Round 6, with the pipelined pixel walk of norm_partial_kernel
+    // (tools/norm_microbench.py, profiles/r06_ab.txt call 36): 1024 -> 512 blocks = statistics 15.6 -> 12.7 us and backward 49.3 -> 45.8 us
+    // on SRGAN's trunk tensor, 307 -> 283 us on its 604 MB discriminator tensor, 124.6 -> 121.4 / 64.9 -> 61.8 us on DCGAN's; 256 and 128
+    // blocks lose on the backward (the sums pass no longer covers the chip), 2048 / 4096 lose everywhere.
     long blocks_other = (long)gx * G;
-    long want = cdiv(1024, blocks_other);
+    long want = cdiv((long)MIGAN_KNOB("MIGAN_NORM_CHUNKS", 512), blocks_other);
     long maxc = cdiv(P, (long)TY * 4);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
@@ -535,7 +544,7 @@ static void apply_plan(int G, int P, int C, int& VW, int& CTX, int& chunk, dim3&
     int nchunks_stats, chunk_stats, gx;
     norm_plan(G, P, C, VW, CTX, chunk_stats, nchunks_stats, gx);
     int TY = 256 / CTX;
-    long want = cdiv(4096, (long)gx * G);
+    long want = cdiv((long)MIGAN_KNOB("MIGAN_NORM_APPLY_CHUNKS", 4096), (long)gx * G);
     long maxc = cdiv(P, (long)TY * 8);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;

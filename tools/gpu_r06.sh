@@ -35,6 +35,7 @@ task_prof() {
   for spec in "$@"; do
     local b=; case $spec in *@*) b=${spec##*@}; spec=${spec%@*} ;; esac
     w=${spec%%:*}; mode=eager; flag="--no-graph --no-overlap"; [ "$spec" != "$w" ] && { mode=graph; flag=; }
+    [ "$spec" = "$w:ov" ] && { mode=eagerov; flag="--no-graph"; }   # eager WITH the weight-gradient / second-discriminator streams
     k=3; [ $w = dcgan ] && k=20; [ $w = pix2pix ] && k=20; [ $w = wgan_gp ] && k=50
     tag=$w; [ -n "$b" ] && { flag="$flag --batch $b"; tag=${w}_bs$b; k=10; }
     (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_${tag}_$mode -o $w -- python $R/bench.py --workload $w --steps $k --warmup 2 \
@@ -131,6 +132,15 @@ task_abenv() {
     for e in "$@"; do bl $O/bench.txt $w $k $e "${flags[@]}"; done
   done
   cat $O/bench.txt
+}
+
+# stand-alone normalisation passes under knob settings:  normab <outdir> "<microbench args>" ENV=a ENV=b ...
+task_normab() {
+  local O=gpurun_out/${1:-r6norm}; local margs=$2; shift 2; mkdir -p $O
+  for e in "$@"; do
+    echo "== $e" | tee -a $O/norm.txt
+    env $e timeout 300 python tools/norm_microbench.py $margs 2>&1 | grep " us " | tee -a $O/norm.txt | cut -c1-150
+  done
 }
 
 t=${1:-}; shift || true
