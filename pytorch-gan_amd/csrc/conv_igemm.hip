@@ -786,6 +786,41 @@ static int conv2d_geom(ConvGeom& g, int N, int Hi, int Wi, int Ci, int Ho, int W
         }
     return 0;
 }
+// Image-output conv behind a normalisation (dcgan.py:60-62: BatchNorm2d(64, 0.8), LeakyReLU(0.2), Conv2d(64, channels, 3, 1, 1), Tanh):
+// y = act(conv(T(x), w) + bias) with T(v) = in_act((v - in_mean[c]) * in_invstd[c] * in_gamma[c] + in_beta[c]) applied while the thin-N
+// kernel stages its window - the normalised, activated tensor (134 MB at the headline batch) is never stored.  in_gamma / in_beta may be
+// NULL (1 / 0).  migan_conv2d_fwd_normed_ok: 1 when the geometry is served (<= 4 output channels, zero padding, Ci % 4 == 0, Ci <= 256).
+static bool thin_normed_plan(ConvGeom& g, ThinConv& tc, size_t& lds, int& max_tiles, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                             int R, int S, int stride, int pad_t, int pad_l) {
+    if (Co > 4 || Ci > THIN_INMAP_MAXC || N > 65535 || Ho <= 0 || Wo <= 0) return false;
+    if (conv2d_geom(g, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l, GATHER_ZERO)) return false;
+    if ((long)N * Ho * Wo < 64L * N) return false;
+    if (!thin_conv_plan(g, tc, lds, max_tiles)) return false;
+    return lds + 2 * THIN_INMAP_MAXC * sizeof(float) <= 64 * 1024;
+}
+MIGAN_API int migan_conv2d_fwd_normed_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t,
+                                         int pad_l) {
+    ConvGeom g = {};
+    ThinConv tc = {};
+    size_t lds = 0;
+    int mt = 0;
+    return thin_normed_plan(g, tc, lds, mt, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l) ? 1 : 0;
+}
+MIGAN_API int migan_conv2d_fwd_normed(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int Hi, int Wi, int Ci,
+                                      int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l, int act, float slope,
+                                      const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta,
+                                      int in_act, float in_slope, void* stream) {
+    ConvGeom g = {};
+    ThinConv tc = {};
+    size_t lds = 0;
+    int mt = 0;
+    if (!in_mean || !in_invstd || (in_act != ACT_NONE && in_act != ACT_LRELU && in_act != ACT_RELU)) return (int)hipErrorInvalidValue;
+    if (!thin_normed_plan(g, tc, lds, mt, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad_t, pad_l)) return (int)hipErrorNotSupported;
+    g.act = act; g.slope = slope;
+    tc.in_mean = in_mean; tc.in_invstd = in_invstd; tc.in_gamma = in_gamma; tc.in_beta = in_beta; tc.in_act = in_act; tc.in_slope = in_slope;
+    return launch_thin_conv(g, tc, lds, mt, x, w_ohwi, bias, y, (hipStream_t)stream);
+}
+
 // How many per-tile statistics chunks per group migan_conv2d_fwd_stats will write for this geometry (the caller sizes the
 // buffer: groups * chunks * Co * 3 floats; groups = N for instance != 0, else 1); 0 = this geometry does not run on the
 // pipelined MFMA kernel (or a tile would straddle two images): use migan_conv2d_fwd and migan_norm_stats.

@@ -1341,3 +1341,232 @@ MIGAN_API int migan_norm_stats_from_conv(const float* part, int nchunks, float* 
     HIP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of  BatchNorm2d(C) -> LeakyReLU / ReLU -> Conv2d(C, 1, 3, 1, 1)  (the generator's last block, dcgan.py:60-62) with the conv's
+// input gradient never stored.  g = conv_transpose(dz, w) at a pixel is nine products of the one-channel dz around it with the pixel's
+// own weight column - cheaper to recompute from the 2 MB dz than to write and re-read as a C-channel tensor (134 MB at the headline batch).
+//   pass A (bn_conv1_bwd_sums_kernel): ONE walk over x yields the conv's weight-gradient partials (x read through the normalisation and the
+//     activation, as the forward read it) AND the two batch sums of the BatchNorm backward; the nine dz taps of a pixel are shared by both.
+//   pass B (bn_conv1_bwd_apply_kernel): dx = gamma * invstd * (g * act'(z) - s0/P - xhat * s1/P), g recomputed; column-sum slabs of dx for
+//     the bias gradient of the conv in front, as norm_bwd_apply_kernel writes them.
+// Before (profiles/r06_dcgan_kernel_stats.txt): input-gradient launch 51 us (writes g) + weight gradient 43 + sums 30 + apply 67 us.
+// Thread layout of both: tx = tid % CTX owns four channels, ty = tid / CTX walks the pixels of the block's chunk (thin_wgrad_kernel's walk).
+// ---------------------------------------------------------------------------------------------
+struct BnConv1Geom {
+    int N, H, W, C, CTX, chunk, nchunks, act;
+    float slope, invP;
+};
+
+// the nine dz taps of input pixel (n, ih, iw): dv[r * 3 + s] = dz[n][ih + 1 - r][iw + 1 - s] (0 outside the image); branch-free clamped loads
+__device__ __forceinline__ void bn_conv1_taps(const BnConv1Geom& g, const float* __restrict__ dz, int n, int ih, int iw, float (&dv)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int oh = ih + 1 - t / 3, ow = iw + 1 - t % 3;
+        const bool ok = (unsigned)oh < (unsigned)g.H && (unsigned)ow < (unsigned)g.W;
+        const int ohc = oh < 0 ? 0 : (oh > g.H - 1 ? g.H - 1 : oh);
+        const int owc = ow < 0 ? 0 : (ow > g.W - 1 ? g.W - 1 : ow);
+        const float v = dz[(long)(n * g.H + ohc) * g.W + owc];
+        dv[t] = ok ? v : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geom g, const float* __restrict__ x, const float* __restrict__ dz,
+                                                                const float* __restrict__ w, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ wpart,
+                                                                float* __restrict__ npart) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int tid = threadIdx.x;
+    const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
+    const int c = (blockIdx.y * g.CTX + tx) * 4;
+    const bool cok = c < g.C;
+    f32x4 acc[9], wv[9], s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mu = s0, is = s0, ga = s0, be = s0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wv[t] = cok ? *reinterpret_cast<const f32x4*>(w + (size_t)t * g.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};   // w: [1][3][3][C]
+    }
+    if (cok) {
+        mu = *reinterpret_cast<const f32x4*>(mean + c);
+        is = *reinterpret_cast<const f32x4*>(invstd + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ga[k] = gamma ? gamma[c + k] : 1.f;
+            be[k] = beta ? beta[c + k] : 0.f;
+        }
+    }
+    const int P = g.N * g.H * g.W;
+    int q0 = blockIdx.x * g.chunk, q1 = q0 + g.chunk;
+    if (q1 > P) q1 = P;
+    if (cok && q0 + ty < q1) {
+        int q = q0 + ty;
+        int n = q / (g.H * g.W);
+        int rem = q - n * g.H * g.W;
+        int ih = rem / g.W, iw = rem - ih * g.W;
+        for (; q < q1; q += TY, iw += TY) {
+            while (iw >= g.W) {
+                iw -= g.W;
+                if (++ih >= g.H) { ih = 0; ++n; }
+            }
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
+            float dv[9];
+            bn_conv1_taps(g, dz, n, ih, iw, dv);
+            f32x4 a, xh, da;   // activated input of the conv, normalised value, act'(z)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xh[k] = (xv[k] - mu[k]) * is[k];
+                // the forward's arithmetic (norm_apply_kernel / thin_conv_kernel INMAP): sc = invstd * gamma, sh = beta - mean * sc
+                const float sc = is[k] * ga[k];
+                const float z = fmaf(xv[k], sc, be[k] - mu[k] * sc);
+                a[k] = act_apply(z, g.act, g.slope);
+                da[k] = g.act == ACT_NONE ? 1.f : (z > 0.f ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f));
+            }
+            f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                acc[t] += a * dv[t];
+                gq += wv[t] * dv[t];
+            }
+            const f32x4 d = gq * da;
+            s0 += d;
+            s1 += d * xh;
+        }
+    }
+    // reduce over the TY pixel lanes through LDS, one slab at a time (fixed order)
+    float* wout = wpart + (size_t)blockIdx.x * 9 * g.C;
+    for (int a_ = 0; a_ < 11; ++a_) {
+        f32x4 v = acc[0];
+#pragma unroll
+        for (int i = 1; i < 9; ++i)
+            if (i == a_) v = acc[i];
+        if (a_ == 9) v = s0;
+        if (a_ == 10) v = s1;
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(red + tid * 4) = v;
+        __syncthreads();
+        if (ty == 0 && cok) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < TY; ++y) s += *reinterpret_cast<const f32x4*>(red + (y * g.CTX + tx) * 4);
+            if (a_ < 9) {
+                *reinterpret_cast<f32x4*>(wout + (size_t)a_ * g.C + c) = s;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const size_t o = ((size_t)blockIdx.x * g.C + c + k) * 3;   // norm_finalize_bwd_kernel's records
+                    npart[o + (a_ - 9)] = s[k];
+                    if (a_ == 10) npart[o + 2] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Geom g, const float* __restrict__ x, const float* __restrict__ dz,
+                                                                 const float* __restrict__ w, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ sums,
+                                                                 float* __restrict__ dx, float* __restrict__ csum) {
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x;
+    const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
+    const int c = (blockIdx.x * g.CTX + tx) * 4;
+    const bool cok = c < g.C;
+    if (!cok && !csum) return;
+    f32x4 wv[9];
+    float mu[4], is[4], ga[4], be[4], k0[4], k1[4], cs[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = cok ? *reinterpret_cast<const f32x4*>(w + (size_t)t * g.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cs[k] = 0.f;
+        const int cc = cok ? c + k : 0;
+        mu[k] = mean[cc];
+        is[k] = invstd[cc];
+        ga[k] = (gamma && cok) ? gamma[cc] : 1.f;
+        be[k] = (beta && cok) ? beta[cc] : 0.f;
+        k0[k] = sums[(size_t)cc * 2] * g.invP;
+        k1[k] = sums[(size_t)cc * 2 + 1] * g.invP;
+    }
+    const int P = g.N * g.H * g.W;
+    int q0 = blockIdx.y * g.chunk, q1 = cok ? q0 + g.chunk : q0;
+    if (q1 > P) q1 = P;
+    if (q0 + ty < q1) {
+        int q = q0 + ty;
+        int n = q / (g.H * g.W);
+        int rem = q - n * g.H * g.W;
+        int ih = rem / g.W, iw = rem - ih * g.W;
+        for (; q < q1; q += TY, iw += TY) {
+            while (iw >= g.W) {
+                iw -= g.W;
+                if (++ih >= g.H) { ih = 0; ++n; }
+            }
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
+            float dv[9];
+            bn_conv1_taps(g, dz, n, ih, iw, dv);
+            f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gq += wv[t] * dv[t];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - mu[k]) * is[k];
+                const float sc = is[k] * ga[k];
+                const float z = fmaf(xv[k], sc, be[k] - mu[k] * sc);
+                const float da = g.act == ACT_NONE ? 1.f : (z > 0.f ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f));
+                o[k] = ga[k] * is[k] * (gq[k] * da - k0[k] - xh * k1[k]);
+                cs[k] += o[k];
+            }
+            *reinterpret_cast<f32x4*>(dx + (size_t)q * g.C + c) = o;
+        }
+    }
+    if (csum) colsum_slab_store<4>(cs, red, csum, tid, tx, g.CTX, TY, cok, c, g.C);
+}
+
+int wgrad_reduce_slabs(const float* ws, float* dw, int nslabs, int Co, int T, int Ci, int accum, const float* db_slabs, float* db, int db_nslab,
+                       int db_accum, hipStream_t st);   // conv_igemm.hip
+
+static bool bn_conv1_ok(int N, int H, int W, int C) {
+    return N >= 1 && H >= 1 && W >= 1 && C % 4 == 0 && C >= 16 && C <= 256 && (long)N * H * W * C < (1L << 31) && (long)N * H * W >= 2;
+}
+MIGAN_API int migan_bn_conv1_bwd_ok(int N, int H, int W, int C) { return bn_conv1_ok(N, H, W, C) ? 1 : 0; }
+// ws: weight-gradient partials [nchunks][9][C] + sums records [nchunks][C][3] + sums [C][2]
+MIGAN_API size_t migan_bn_conv1_bwd_workspace(int N, int H, int W, int C) {
+    if (!bn_conv1_ok(N, H, W, C)) return 0;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(1, N * H * W, C, VW, CTX, chunk, nchunks, gx);
+    return ((size_t)nchunks * C * 12 + (size_t)C * 2) * sizeof(float);
+}
+// x [N][H][W][C] (the BatchNorm input), dz [N][H][W] (gradient at the conv's pre-activation output), w_ohwi [1][3][3][C], mean / invstd [C]
+// (migan_norm_stats), gamma / beta [C] or NULL; act: ACT_NONE / ACT_LRELU / ACT_RELU between the two.
+// Writes dx [N][H][W][C], dw_oihw [1][C][3][3] (dw_accumulate: +=), dgamma / dbeta [C] (optional; affine_accumulate: +=), and - csum != NULL -
+// migan_norm_colsum_slabs(1, N*H*W, C) x [C] column-sum slabs of dx.
+MIGAN_API int migan_bn_conv1_bwd(const float* x, const float* dz, const float* w_ohwi, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int act, float slope, float* dx, float* dw_oihw, int dw_accumulate,
+                                 float* dgamma, float* dbeta, int affine_accumulate, float* csum, float* ws, size_t ws_bytes, int N, int H,
+                                 int W, int C, void* stream) {
+    if (!bn_conv1_ok(N, H, W, C) || (act != ACT_NONE && act != ACT_LRELU && act != ACT_RELU)) return (int)hipErrorInvalidValue;
+    if (ws_bytes < migan_bn_conv1_bwd_workspace(N, H, W, C)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = N * H * W;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(1, P, C, VW, CTX, chunk, nchunks, gx);
+    BnConv1Geom g = {N, H, W, C, CTX, chunk, nchunks, act, slope, 1.f / (float)P};
+    float* wpart = ws;
+    float* npart = ws + (size_t)nchunks * C * 9;
+    float* sums = npart + (size_t)nchunks * C * 3;
+    MIGAN_LAUNCH(bn_conv1_bwd_sums_kernel, dim3(nchunks, gx), dim3(256), 0, st, g, x, dz, w_ohwi, mean, invstd, gamma, beta, wpart, npart);
+    HIP_LAUNCH_CHECK();
+    MIGAN_LAUNCH(norm_finalize_bwd_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, npart, sums, dgamma, dbeta, 1, C, nchunks,
+                 affine_accumulate, (float*)nullptr, 0);
+    HIP_LAUNCH_CHECK();
+    if (int rc = wgrad_reduce_slabs(wpart, dw_oihw, nchunks, 1, 9, C, dw_accumulate, nullptr, nullptr, 0, 0, st)) return rc;
+    int chunkB;
+    dim3 gridB;
+    apply_plan(1, P, C, VW, CTX, chunkB, gridB);
+    g.chunk = chunkB;
+    MIGAN_LAUNCH(bn_conv1_bwd_apply_kernel, gridB, dim3(256), 0, st, g, x, dz, w_ohwi, mean, invstd, gamma, beta, sums, dx, csum);
+    HIP_LAUNCH_CHECK();
+    return 0;
+}

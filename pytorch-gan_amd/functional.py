@@ -2106,6 +2106,106 @@ def bn_prelu_conv64(x, gamma, beta, running_mean, running_var, num_batches_track
     return _BnPreluConv64.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), prelu, w, b)
 
 
+def bn_act_conv1_takes(x, w, stride, pads, dilation=(1, 1), groups=1):
+    """True when bn_act_conv1(x, ...) serves the chain BatchNorm2d -> [LeakyReLU | ReLU] -> Conv2d(C, 1, 3, 1, 1): local-batch statistics,
+    first-order backward, the geometry of migan_conv2d_fwd_normed / migan_bn_conv1_bwd."""
+    if not _BN_FOLD or x.dim() != 4 or w.dim() != 4 or not on_device(x):
+        return False
+    if (_SYNC_BN is not None and _SYNC_BN.world > 1) or _BN_GROUPS != 1 or tuple(dilation) != (1, 1) or groups != 1:
+        return False
+    N, C, H, W = x.shape
+    Co, Ci, R, S = w.shape
+    if (Co, Ci, R, S, int(stride)) != (1, C, 3, 3, 1) or tuple(pads) != (1, 1, 1, 1) or not w.is_contiguous():
+        return False
+    return (lib.migan_conv2d_fwd_normed_ok(N, H, W, C, H, W, 1, 3, 3, 1, 1, 1) == 1 and lib.migan_bn_conv1_bwd_ok(N, H, W, C) == 1)
+
+
+class _BnActConv1(Function):
+    """act_out(conv2d(act_in(batch_norm(x)), w, b)) for the generator's last block (dcgan.py:60-62: BatchNorm2d(64, 0.8), LeakyReLU(0.2),
+    Conv2d(64, 1, 3, 1, 1), Tanh) with neither the normalised tensor nor the conv's input gradient stored: one statistics pass over x, the
+    thin-N conv reads x through the normalisation; backward = one walk over x for the conv's weight gradient AND the BatchNorm sums, one for
+    dx - the C-channel input gradient of the conv is nine products with the one-channel dz, recomputed in both (csrc/norm.hip
+    bn_conv1_bwd_*_kernel).  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, momentum, eps, act_in, slope_in, w, b, act_out, slope_out):
+        xs = canon(x)
+        N, C, H, W = xs.shape
+        P = N * H * W
+        ctx.x_nchw = x.is_contiguous() and not x.is_contiguous(memory_format=CL)
+        ctx.params = (gamma, beta, w, b)
+        ctx.cfg = (act_in, slope_in, act_out, slope_out)
+        gm, bt, wt, bs = _plain(gamma), _plain(beta), _plain(w), _plain(b)
+        st = _stream()
+        mean = torch.empty(C, device=xs.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        nb = lib.migan_norm_workspace(1, P, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_norm_stats(xs.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                   momentum, eps, 1, P, C, ws.data_ptr(), nb, st), "norm_stats")
+        wp = _packed_perm(w, wt, "ohwi", (0, 2, 3, 1))
+        y = _empty_nhwc((N, 1, H, W), xs)
+        check(lib.migan_conv2d_fwd_normed(xs.data_ptr(), wp.data_ptr(), _ptr(bs), y.data_ptr(), N, H, W, C, H, W, 1, 3, 3, 1, 1, 1, act_out,
+                                          slope_out, mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt), act_in, slope_in, st),
+              "conv2d_fwd_normed")
+        ctx.save_for_backward(xs, gm, bt, mean, invstd, wt, y if act_out != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _first_order_only("BatchNorm2d -> activation -> Conv2d(C, 1, 3, 1, 1) folded into one convolution")
+        xs, gm, bt, mean, invstd, wt, y = ctx.saved_tensors
+        gamma, beta, w, b = ctx.params
+        act_in, slope_in, act_out, slope_out = ctx.cfg
+        N, C, H, W = xs.shape
+        P = N * H * W
+        dz = to_nhwc(dy)
+        if act_out != ACT_NONE:
+            dz = _act_bwd_raw(dz, y, act_out, slope_out)
+        st = _stream()
+        db = None
+        if b is not None and ctx.needs_input_grad[11]:
+            db = _colsum(dz, P, 1, _grad_slot(b))
+        wslot = _grad_slot(w) if ctx.needs_input_grad[10] else None
+        dw = wslot if wslot is not None else torch.empty_like(wt)
+        dgamma = dbeta = None
+        acc = 0
+        if gm is not None:
+            sg, sb = _grad_slot(gamma), _grad_slot(beta)
+            if sg is not None and sb is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+                dgamma, dbeta, acc = sg, sb, 1
+            else:
+                dgamma = torch.empty(C, device=xs.device, dtype=torch.float32)
+                dbeta = torch.empty_like(dgamma)
+        slabs, nslab = None, 0
+        if _COLSUM_FUSE and not ctx.x_nchw:
+            nslab = lib.migan_norm_colsum_slabs(1, P, C)
+            slabs = torch.empty(max(nslab * C, 1), device=xs.device, dtype=torch.float32)
+        wp = _packed_perm(w, wt, "ohwi", (0, 2, 3, 1))
+        dx = torch.empty_like(xs)
+        nb = lib.migan_bn_conv1_bwd_workspace(N, H, W, C)
+        ws = _ws(nb, xs)
+        check(lib.migan_bn_conv1_bwd(xs.data_ptr(), dz.data_ptr(), wp.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt),
+                                     act_in, slope_in, dx.data_ptr(), dw.data_ptr(), 1 if wslot is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                     acc, _ptr(slabs), ws.data_ptr(), nb, N, H, W, C, st), "bn_conv1_bwd")
+        if wslot is not None or not ctx.needs_input_grad[10]:
+            dw = None
+        if acc:
+            dgamma = dbeta = None
+        if ctx.x_nchw:
+            dx = to_nchw(dx)
+        elif slabs is not None:
+            _attach_colsum(dx, slabs, nslab, C)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, dw, db, None, None
+
+
+def bn_act_conv1(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act_in, slope_in, w, b, act_out=ACT_NONE,
+                 slope_out=0.0):
+    """Training-mode BatchNorm2d -> act_in -> Conv2d(C, 1, 3, 1, 1) -> act_out as one Function (see _BnActConv1)."""
+    return _BnActConv1.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), int(act_in),
+                             float(slope_in), w, b, int(act_out), float(slope_out))
+
+
 # ---------------------------------------------------------------------------------------------- index remaps
 class _Gather2d(Function):
     """Standalone ReflectionPad2d / ZeroPad2d / Upsample(scale_factor=2)."""

@@ -589,6 +589,23 @@ class Sequential(tnn.Sequential):
                     (act, slope), k = _act_of(mods[k]), k + 1
                 if isinstance(m, (BatchNorm2d, BatchNorm1d)):
                     m._check_input_dim(x)
+                # BatchNorm2d(64, 0.8), LeakyReLU(0.2), Conv2d(64, 1, 3, 1, 1), Tanh (dcgan.py:60-62): the image-output conv reads the
+                # BatchNorm input through the normalisation; its backward recomputes the conv's input gradient from the one-channel dz
+                cv = mods[k] if (k < n and type(mods[k]) is Conv2d) else None
+                if (cv is not None and type(m) is BatchNorm2d and m.training and m.momentum is not None and res is None
+                        and act in (F.ACT_NONE, F.ACT_LRELU, F.ACT_RELU) and cv.padding_mode == "zeros"
+                        and not isinstance(cv.padding, str) and _pair(cv.stride) == (1, 1)
+                        and F.bn_act_conv1_takes(x, cv.weight, 1, _pair(cv.padding) * 2, _pair(cv.dilation), cv.groups)):
+                    oact, oslope, kk = F.ACT_NONE, 0.0, k + 1
+                    if kk < n and _act_of(mods[kk]) is not None and type(mods[kk]) in _OURS:
+                        (oact, oslope), kk = _act_of(mods[kk]), kk + 1
+                    trk = m.track_running_stats
+                    x = _wrap(F.bn_act_conv1(x, m.weight if m.affine else None, m.bias if m.affine else None,
+                                             m.running_mean if trk else None, m.running_var if trk else None,
+                                             m.num_batches_tracked if trk else None, m.momentum, m.eps, act, slope, cv.weight, cv.bias,
+                                             oact, oslope))
+                    i = kk
+                    continue
                 # BatchNorm2d [PixelShuffle] PReLU (srgan/models.py:23-24, 55-57): the single-slope PReLU commutes with the
                 # shuffle, so it is applied (and differentiated) inside the norm launches and the shuffle moves behind it
                 if _PRELU_FUSE and act == F.ACT_NONE and type(m) is BatchNorm2d and x.dim() == 4 \

@@ -580,6 +580,17 @@ def test_trunk_block_batchnorm_prelu_folded_into_the_conv_on_the_execution_model
     assert lib.hipemu_launch_count(b"c64_wgrad_kernel<2>") > 0
 
 
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_generator_tail_batchnorm_folded_into_the_image_conv_on_the_execution_model(idx, monkeypatch):
+    """test_ops_gpu.py::test_generator_tail_batchnorm_folded_into_the_image_conv without a GPU: thin_conv_kernel<1, true>'s input map and the
+    two backward walks that recompute the conv's input gradient (csrc/norm.hip bn_conv1_bwd_*), ragged maps and image borders included."""
+    import test_ops_gpu
+
+    lib = _run_gpu_test_body("test_ops_gpu", "test_generator_tail_batchnorm_folded_into_the_image_conv", __import__("pytorch_gan_amd"),
+                             test_ops_gpu.BN_CONV1_CASES[idx], monkeypatch)
+    assert lib.hipemu_launch_count(b"bn_conv1_bwd_apply_kernel") > 0
+
+
 def test_cross_replica_batchnorm_two_ranks_on_the_execution_model(tmp_path, monkeypatch):
     """SURVEY.md 8e with real kernels and no GPU: the body of test_dp_gpu.py::test_cross_replica_batchnorm_equals_full_batch -
     two torch.distributed.run ranks (gloo) each run half of a DCGAN batch with enable_sync_batchnorm() (local moments ->

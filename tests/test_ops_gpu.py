@@ -836,6 +836,67 @@ def test_trunk_block_batchnorm_prelu_folded_into_the_conv(pg, shape, monkeypatch
     assert_close(outs[0][1], outs[1][1], 2e-5, "folded vs separate launches: input gradient")
 
 
+BN_CONV1_CASES = [(2, 64, 16, 16, "lrelu", True), (3, 64, 13, 20, "lrelu", True), (2, 32, 9, 24, "relu", False), (1, 128, 8, 8, "none", True)]
+
+
+@pytest.mark.parametrize("cfg", BN_CONV1_CASES, ids=["2x64x16x16", "3x64x13x20-ragged", "2x32x9x24-relu-nobias", "1x128x8x8-noact"])
+def test_generator_tail_batchnorm_folded_into_the_image_conv(pg, cfg, monkeypatch):
+    """dcgan.py:60-62: BatchNorm2d(64, 0.8), LeakyReLU(0.2), Conv2d(64, 1, 3, 1, 1), Tanh as ONE Function (nn.Sequential's peephole): the thin-N
+    conv reads the BatchNorm input through the normalisation (thin_conv_kernel<1, true>), the backward walks x twice (bn_conv1_bwd_sums_kernel:
+    the conv's weight gradient + the BatchNorm sums; bn_conv1_bwd_apply_kernel: dx) and recomputes the conv's input gradient from dz - neither
+    the normalised tensor nor that gradient is stored.  Against torch in fp64 on the host (output, input gradient, every parameter gradient,
+    running statistics) and against the separate launches."""
+    import copy
+
+    N, C, H, W, act, bias = cfg
+    F = pg.functional
+    torch.manual_seed(11)
+    mods = [torch.nn.BatchNorm2d(C, 0.8)]
+    if act != "none":
+        mods.append(torch.nn.LeakyReLU(0.2) if act == "lrelu" else torch.nn.ReLU())
+    mods += [torch.nn.Conv2d(C, 1, 3, 1, 1, bias=bias), torch.nn.Tanh()]
+    ref = torch.nn.Sequential(*mods)
+    with torch.no_grad():
+        ref[0].weight.copy_(_leaf(C, seed=21) * 0.5 + 1.0)
+        ref[0].bias.copy_(_leaf(C, seed=22) * 0.5)
+    x = _leaf(N, C, H, W, seed=7) * 2 + 0.25
+    gy = _leaf(N, 1, H, W, seed=8)
+    ref64 = copy.deepcopy(ref).double()
+    x64 = x.double().requires_grad_(True)
+    y64 = ref64(x64)
+    y64.backward(gy.double())
+    outs = []
+    for fold in (True, False):
+        monkeypatch.setattr(F, "_BN_FOLD", fold)
+        seq = pg.swap(copy.deepcopy(ref)).to(DEV)
+        xin = x.to(DEV).clone().requires_grad_(True)
+        with Launches() as n:
+            y = seq(xin)
+            y.backward(gy.to(DEV))
+            if fold:
+                assert n("thin_conv_kernel<1, true>") == 1 and n("bn_conv1_bwd_sums_kernel") == 1 and n("bn_conv1_bwd_apply_kernel") == 1
+                assert n("norm_apply") == 0 and n("norm_bwd_apply") == 0, "the normalised tensor / the conv's input gradient was stored"
+            else:
+                assert n("bn_conv1") == 0 and n("norm_apply") == 1
+        outs.append((y.detach(), xin.grad, {k: p.grad.clone() for k, p in seq.named_parameters()},
+                     {k: b.clone() for k, b in seq.named_buffers()}))
+    # a pre-activation within rounding of the kink may take the other branch: compare the input gradient away from it
+    pre = TF.batch_norm(x, None, None, ref[0].weight.detach(), ref[0].bias.detach(), True, 0.1, ref[0].eps)
+    keep = (pre.abs() > 1e-5).float() if act != "none" else torch.ones_like(pre)
+    for tag, (y, dx, grads, bufs) in zip(("folded", "separate"), outs):
+        assert_close(y, y64.float(), 2e-5, tag + " output")
+        assert_close(dx.cpu() * keep, x64.grad.float() * keep, 1e-4, tag + " input gradient")
+        for k, p in ref64.named_parameters():
+            assert_close(grads[k], p.grad.float(), 1e-4, tag + " gradient of " + k)
+        for k, b in ref64.named_buffers():
+            if k.endswith("num_batches_tracked"):
+                assert int(bufs[k]) == int(b) == 1, k
+            else:
+                assert_close(bufs[k], b.float(), 1e-5, tag + " " + k)
+    assert_close(outs[0][0], outs[1][0], 2e-6, "folded vs separate launches: output")
+    assert_close(outs[0][1], outs[1][1], 2e-5, "folded vs separate launches: input gradient")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 128), (1, 12, 20, 32, 40)], ids=["64-128ch", "k-tail-40ch"])
 def test_relu_backward_handed_to_the_consumer(pg, shape):
     """vgg19.features[:18] (srgan/models.py:8-15): conv ReLU conv ReLU MaxPool conv ReLU.  nn.Sequential hands the ReLU backward of a
