@@ -552,7 +552,7 @@ int migan_c64_conv_wgrad(const float* x, const float* dy, float* dw_oihw, float*
  * while the thin-N kernel stages its window (migan_norm_apply's arithmetic; zero padding after T; in_gamma / in_beta may be NULL): the
  * normalised, activated tensor is never stored.  _ok: 1 when the geometry is served (<= 4 output channels, Ci % 4 == 0, Ci <= 256).
  * migan_bn_conv1_bwd (one output channel, 3x3, stride 1, padding 1): from x (the BatchNorm input), dz [N][H][W] (gradient at the conv's
- * pre-activation output), the statistics and the weights - dx, dw_oihw [1][C][3][3], dgamma, dbeta and (csum != NULL) the
+ * pre-activation output), the statistics and the weights - dx, dw_oihw [1][C][3][3], db [1] (optional), dgamma, dbeta and (csum != NULL) the
  * migan_norm_colsum_slabs(1, N*H*W, C) column-sum slabs of dx; the conv's input gradient is recomputed from dz where it is used, never
  * stored.  aten::convolution_backward + native_batch_norm_backward + leaky_relu_backward behind dcgan.py:168. */
 int migan_conv2d_fwd_normed_ok(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int stride, int pad_t, int pad_l);
@@ -562,8 +562,9 @@ int migan_conv2d_fwd_normed(const float* x, const float* w_ohwi, const float* bi
 int migan_bn_conv1_bwd_ok(int N, int H, int W, int C);
 size_t migan_bn_conv1_bwd_workspace(int N, int H, int W, int C);
 int migan_bn_conv1_bwd(const float* x, const float* dz, const float* w_ohwi, const float* mean, const float* invstd, const float* gamma,
-                       const float* beta, int act, float slope, float* dx, float* dw_oihw, int dw_accumulate, float* dgamma, float* dbeta,
-                       int affine_accumulate, float* csum, float* ws, size_t ws_bytes, int N, int H, int W, int C, void* stream);
+                       const float* beta, int act, float slope, float* dx, float* dw_oihw, int dw_accumulate, float* db, int db_accumulate,
+                       float* dgamma, float* dbeta, int affine_accumulate, float* csum, float* ws, size_t ws_bytes, int N, int H, int W, int C,
+                       void* stream);
 /* optimizer.zero_grad() on the flat gradient bucket (dcgan.py:157,175; cyclegan.py:177,211,228): p[0 .. bytes) = 0, 16-byte stores (p and
  * bytes multiples of 4) */
 int migan_zero(void* p, size_t bytes, void* stream);

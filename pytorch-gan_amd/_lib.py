@@ -99,7 +99,7 @@ _SIGS = {
     "migan_conv2d_fwd_normed": (c_int, [P] * 4 + [c_int] * 13 + [c_float, P, P, P, P, c_int, c_float, P]),
     "migan_bn_conv1_bwd_ok": (c_int, [c_int] * 4),
     "migan_bn_conv1_bwd_workspace": (c_size_t, [c_int] * 4),
-    "migan_bn_conv1_bwd": (c_int, [P] * 7 + [c_int, c_float, P, P, c_int, P, P, c_int, P, P, c_size_t] + [c_int] * 4 + [P]),
+    "migan_bn_conv1_bwd": (c_int, [P] * 7 + [c_int, c_float, P, P, c_int, P, c_int, P, P, c_int, P, P, c_size_t] + [c_int] * 4 + [P]),
     "migan_c64_conv_wgrad": (c_int, [P, P, P, P, c_size_t] + [c_int] * 4 + [P, c_int, P, c_int, P, P, P, P, c_int, c_float, P, P]),
     "migan_c64_conv_fwd": (c_int, [P, P, P, P] + [c_int] * 4 + [c_float, c_int, P, P, P, P, c_int, c_float, P, P]),
     "migan_fewpix_ok": (c_int, [c_int] * 3),

@@ -1358,16 +1358,26 @@ struct BnConv1Geom {
     float slope, invP;
 };
 
-// the nine dz taps of input pixel (n, ih, iw): dv[r * 3 + s] = dz[n][ih + 1 - r][iw + 1 - s] (0 outside the image); branch-free clamped loads
-__device__ __forceinline__ void bn_conv1_taps(const BnConv1Geom& g, const float* __restrict__ dz, int n, int ih, int iw, float (&dv)[9]) {
+// The dz rows a block's pixel chunk [q0, q1) touches, one halo row above and below, one zero halo column left and right, staged in LDS:
+// row k of the window is global row (q0 / W) - 1 + k of the [N * H][W] image stack (zero outside the stack).  Rows of a NEIGHBOURING image
+// are real data there - a pixel in the first / last row of its image masks the tap row above / below it (mt / mb in the walks).
+// (First form of these kernels: nine clamped, predicated global loads per pixel and thread - the address arithmetic of the taps made both
+// walks VALU-bound, 69 / 62 us for 134 MB, profiles/r06_ab.txt call 41.)
+__device__ __forceinline__ void bn_conv1_stage(const BnConv1Geom& g, const float* __restrict__ dz, float* dzw, int q0, int q1, int tid) {
+    const int W2 = g.W + 2, row0 = q0 / g.W - 1, nrows = (q1 - 1) / g.W - row0 + 2, NH = g.N * g.H;
+    for (int i = tid; i < nrows * W2; i += 256) {
+        const int rr = i / W2, col = i - rr * W2 - 1, R = row0 + rr;
+        dzw[i] = (R >= 0 && R < NH && col >= 0 && col < g.W) ? dz[(long)R * g.W + col] : 0.f;
+    }
+}
+// taps of the pixel at window row wr, column iw: dv[r * 3 + s] = dz[ih + 1 - r][iw + 1 - s], rows outside the pixel's image masked
+__device__ __forceinline__ void bn_conv1_taps(const float* dzw, int W2, int wr, int iw, float mt, float mb, float (&dv)[9]) {
+    const float* p = dzw + wr * W2 + iw + 1;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int oh = ih + 1 - t / 3, ow = iw + 1 - t % 3;
-        const bool ok = (unsigned)oh < (unsigned)g.H && (unsigned)ow < (unsigned)g.W;
-        const int ohc = oh < 0 ? 0 : (oh > g.H - 1 ? g.H - 1 : oh);
-        const int owc = ow < 0 ? 0 : (ow > g.W - 1 ? g.W - 1 : ow);
-        const float v = dz[(long)(n * g.H + ohc) * g.W + owc];
-        dv[t] = ok ? v : 0.f;
+    for (int s_ = 0; s_ < 3; ++s_) {
+        dv[0 + s_] = p[W2 + 1 - s_] * mb;
+        dv[3 + s_] = p[1 - s_];
+        dv[6 + s_] = p[-W2 + 1 - s_] * mt;
     }
 }
 
@@ -1377,12 +1387,14 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geo
                                                                 const float* __restrict__ beta, float* __restrict__ wpart,
                                                                 float* __restrict__ npart) {
     __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    extern __shared__ __attribute__((aligned(16))) float dzw[];
     const int tid = threadIdx.x;
     const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
     const int c = (blockIdx.y * g.CTX + tx) * 4;
     const bool cok = c < g.C;
     f32x4 acc[9], wv[9], s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 mu = s0, is = s0, ga = s0, be = s0;
+    f32x4 mu = s0, is = s0, sc = s0, sh = s0;
+    float sdz = 0.f;   // sum of dz over the chunk (lane tx == 0 of channel block 0): the conv's bias gradient
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1392,36 +1404,40 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geo
         mu = *reinterpret_cast<const f32x4*>(mean + c);
         is = *reinterpret_cast<const f32x4*>(invstd + c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            ga[k] = gamma ? gamma[c + k] : 1.f;
-            be[k] = beta ? beta[c + k] : 0.f;
+        for (int k = 0; k < 4; ++k) {   // the forward's arithmetic (norm_apply_kernel / thin_conv_kernel INMAP)
+            sc[k] = is[k] * (gamma ? gamma[c + k] : 1.f);
+            sh[k] = (beta ? beta[c + k] : 0.f) - mu[k] * sc[k];
         }
     }
-    const int P = g.N * g.H * g.W;
+    const float nslope = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);   // act'(z) for z <= 0
+    const int P = g.N * g.H * g.W, W2 = g.W + 2;
     int q0 = blockIdx.x * g.chunk, q1 = q0 + g.chunk;
     if (q1 > P) q1 = P;
+    bn_conv1_stage(g, dz, dzw, q0, q1, tid);
+    __syncthreads();
     if (cok && q0 + ty < q1) {
         int q = q0 + ty;
-        int n = q / (g.H * g.W);
-        int rem = q - n * g.H * g.W;
-        int ih = rem / g.W, iw = rem - ih * g.W;
+        const int row0 = q0 / g.W - 1;
+        int R = q / g.W, iw = q - R * g.W;
+        int ih = R % g.H, wr = R - row0;
+        const bool lead = tx == 0 && blockIdx.y == 0;
         for (; q < q1; q += TY, iw += TY) {
             while (iw >= g.W) {
                 iw -= g.W;
-                if (++ih >= g.H) { ih = 0; ++n; }
+                ++wr;
+                if (++ih >= g.H) ih = 0;
             }
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
             float dv[9];
-            bn_conv1_taps(g, dz, n, ih, iw, dv);
+            bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
+            if (lead) sdz += dv[4];
             f32x4 a, xh, da;   // activated input of the conv, normalised value, act'(z)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 xh[k] = (xv[k] - mu[k]) * is[k];
-                // the forward's arithmetic (norm_apply_kernel / thin_conv_kernel INMAP): sc = invstd * gamma, sh = beta - mean * sc
-                const float sc = is[k] * ga[k];
-                const float z = fmaf(xv[k], sc, be[k] - mu[k] * sc);
-                a[k] = act_apply(z, g.act, g.slope);
-                da[k] = g.act == ACT_NONE ? 1.f : (z > 0.f ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f));
+                const float z = fmaf(xv[k], sc[k], sh[k]);
+                da[k] = z > 0.f ? 1.f : nslope;
+                a[k] = z * da[k];
             }
             f32x4 gq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1436,13 +1452,14 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geo
     }
     // reduce over the TY pixel lanes through LDS, one slab at a time (fixed order)
     float* wout = wpart + (size_t)blockIdx.x * 9 * g.C;
-    for (int a_ = 0; a_ < 11; ++a_) {
+    for (int a_ = 0; a_ < 12; ++a_) {
         f32x4 v = acc[0];
 #pragma unroll
         for (int i = 1; i < 9; ++i)
             if (i == a_) v = acc[i];
         if (a_ == 9) v = s0;
         if (a_ == 10) v = s1;
+        if (a_ == 11) v = f32x4{sdz, 0.f, 0.f, 0.f};
         __syncthreads();
         *reinterpret_cast<f32x4*>(red + tid * 4) = v;
         __syncthreads();
@@ -1451,13 +1468,14 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geo
             for (int y = 0; y < TY; ++y) s += *reinterpret_cast<const f32x4*>(red + (y * g.CTX + tx) * 4);
             if (a_ < 9) {
                 *reinterpret_cast<f32x4*>(wout + (size_t)a_ * g.C + c) = s;
-            } else {
+            } else if (a_ < 11) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const size_t o = ((size_t)blockIdx.x * g.C + c + k) * 3;   // norm_finalize_bwd_kernel's records
-                    npart[o + (a_ - 9)] = s[k];
-                    if (a_ == 10) npart[o + 2] = 0.f;
-                }
+                for (int k = 0; k < 4; ++k) npart[((size_t)blockIdx.x * g.C + c + k) * 3 + (a_ - 9)] = s[k];   // norm_finalize_bwd_kernel's records
+            } else {
+                // third field of the records: the chunk's sum of dz in channel 0's record, zero elsewhere - the finalize kernel's
+                // per-channel third sum (the PReLU-slope slot) then holds the conv's bias gradient in element 0
+#pragma unroll
+                for (int k = 0; k < 4; ++k) npart[((size_t)blockIdx.x * g.C + c + k) * 3 + 2] = (c + k == 0) ? s[0] : 0.f;
             }
         }
     }
@@ -1469,13 +1487,13 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Ge
                                                                  const float* __restrict__ beta, const float* __restrict__ sums,
                                                                  float* __restrict__ dx, float* __restrict__ csum) {
     __shared__ float red[256 * 4];
+    extern __shared__ __attribute__((aligned(16))) float dzw[];
     const int tid = threadIdx.x;
     const int tx = tid % g.CTX, ty = tid / g.CTX, TY = 256 / g.CTX;
     const int c = (blockIdx.x * g.CTX + tx) * 4;
     const bool cok = c < g.C;
-    if (!cok && !csum) return;
     f32x4 wv[9];
-    float mu[4], is[4], ga[4], be[4], k0[4], k1[4], cs[4];
+    float mu[4], is[4], sc[4], sh[4], gi[4], k0[4], k1[4], cs[4];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = cok ? *reinterpret_cast<const f32x4*>(w + (size_t)t * g.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1484,27 +1502,33 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Ge
         const int cc = cok ? c + k : 0;
         mu[k] = mean[cc];
         is[k] = invstd[cc];
-        ga[k] = (gamma && cok) ? gamma[cc] : 1.f;
-        be[k] = (beta && cok) ? beta[cc] : 0.f;
+        const float ga = (gamma && cok) ? gamma[cc] : 1.f;
+        sc[k] = is[k] * ga;
+        sh[k] = ((beta && cok) ? beta[cc] : 0.f) - mu[k] * sc[k];
+        gi[k] = ga * is[k];
         k0[k] = sums[(size_t)cc * 2] * g.invP;
         k1[k] = sums[(size_t)cc * 2 + 1] * g.invP;
     }
-    const int P = g.N * g.H * g.W;
-    int q0 = blockIdx.y * g.chunk, q1 = cok ? q0 + g.chunk : q0;
+    const float nslope = g.act == ACT_NONE ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f);
+    const int P = g.N * g.H * g.W, W2 = g.W + 2;
+    int q0 = blockIdx.y * g.chunk, q1 = q0 + g.chunk;
     if (q1 > P) q1 = P;
-    if (q0 + ty < q1) {
+    if (q0 < q1) bn_conv1_stage(g, dz, dzw, q0, q1, tid);
+    __syncthreads();
+    if (cok && q0 + ty < q1) {
         int q = q0 + ty;
-        int n = q / (g.H * g.W);
-        int rem = q - n * g.H * g.W;
-        int ih = rem / g.W, iw = rem - ih * g.W;
+        const int row0 = q0 / g.W - 1;
+        int R = q / g.W, iw = q - R * g.W;
+        int ih = R % g.H, wr = R - row0;
         for (; q < q1; q += TY, iw += TY) {
             while (iw >= g.W) {
                 iw -= g.W;
-                if (++ih >= g.H) { ih = 0; ++n; }
+                ++wr;
+                if (++ih >= g.H) ih = 0;
             }
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
             float dv[9];
-            bn_conv1_taps(g, dz, n, ih, iw, dv);
+            bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
             f32x4 gq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t) gq += wv[t] * dv[t];
@@ -1512,10 +1536,9 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Ge
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xh = (xv[k] - mu[k]) * is[k];
-                const float sc = is[k] * ga[k];
-                const float z = fmaf(xv[k], sc, be[k] - mu[k] * sc);
-                const float da = g.act == ACT_NONE ? 1.f : (z > 0.f ? 1.f : (g.act == ACT_LRELU ? g.slope : 0.f));
-                o[k] = ga[k] * is[k] * (gq[k] * da - k0[k] - xh * k1[k]);
+                const float z = fmaf(xv[k], sc[k], sh[k]);
+                const float da = z > 0.f ? 1.f : nslope;
+                o[k] = gi[k] * (gq[k] * da - k0[k] - xh * k1[k]);
                 cs[k] += o[k];
             }
             *reinterpret_cast<f32x4*>(dx + (size_t)q * g.C + c) = o;
@@ -1527,25 +1550,33 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Ge
 int wgrad_reduce_slabs(const float* ws, float* dw, int nslabs, int Co, int T, int Ci, int accum, const float* db_slabs, float* db, int db_nslab,
                        int db_accum, hipStream_t st);   // conv_igemm.hip
 
+static size_t bn_conv1_lds(int chunk, int W) { return (size_t)(chunk / W + 4) * (W + 2) * sizeof(float); }   // window rows of a chunk
 static bool bn_conv1_ok(int N, int H, int W, int C) {
-    return N >= 1 && H >= 1 && W >= 1 && C % 4 == 0 && C >= 16 && C <= 256 && (long)N * H * W * C < (1L << 31) && (long)N * H * W >= 2;
+    if (!(N >= 1 && H >= 1 && W >= 1 && C % 4 == 0 && C >= 16 && C <= 256 && (long)N * H * W * C < (1L << 31) && (long)N * H * W >= 2))
+        return false;
+    int VW, CTX, chunk, nchunks, gx;
+    norm_plan(1, N * H * W, C, VW, CTX, chunk, nchunks, gx);
+    dim3 gridB;
+    int chunkB;
+    apply_plan(1, N * H * W, C, VW, CTX, chunkB, gridB);
+    return bn_conv1_lds(chunk, W) <= 48 * 1024 && bn_conv1_lds(chunkB, W) <= 48 * 1024;
 }
 MIGAN_API int migan_bn_conv1_bwd_ok(int N, int H, int W, int C) { return bn_conv1_ok(N, H, W, C) ? 1 : 0; }
-// ws: weight-gradient partials [nchunks][9][C] + sums records [nchunks][C][3] + sums [C][2]
+// ws: weight-gradient partials [nchunks][9][C] + sums records [nchunks][C][3] + sums [C][2] + third sums [C]
 MIGAN_API size_t migan_bn_conv1_bwd_workspace(int N, int H, int W, int C) {
     if (!bn_conv1_ok(N, H, W, C)) return 0;
     int VW, CTX, chunk, nchunks, gx;
     norm_plan(1, N * H * W, C, VW, CTX, chunk, nchunks, gx);
-    return ((size_t)nchunks * C * 12 + (size_t)C * 2) * sizeof(float);
+    return ((size_t)nchunks * C * 12 + (size_t)C * 3) * sizeof(float);
 }
 // x [N][H][W][C] (the BatchNorm input), dz [N][H][W] (gradient at the conv's pre-activation output), w_ohwi [1][3][3][C], mean / invstd [C]
 // (migan_norm_stats), gamma / beta [C] or NULL; act: ACT_NONE / ACT_LRELU / ACT_RELU between the two.
-// Writes dx [N][H][W][C], dw_oihw [1][C][3][3] (dw_accumulate: +=), dgamma / dbeta [C] (optional; affine_accumulate: +=), and - csum != NULL -
-// migan_norm_colsum_slabs(1, N*H*W, C) x [C] column-sum slabs of dx.
+// Writes dx [N][H][W][C], dw_oihw [1][C][3][3] (dw_accumulate: +=), db [1] = sum of dz (optional; db_accumulate: +=), dgamma / dbeta [C]
+// (optional; affine_accumulate: +=), and - csum != NULL - migan_norm_colsum_slabs(1, N*H*W, C) x [C] column-sum slabs of dx.
 MIGAN_API int migan_bn_conv1_bwd(const float* x, const float* dz, const float* w_ohwi, const float* mean, const float* invstd,
                                  const float* gamma, const float* beta, int act, float slope, float* dx, float* dw_oihw, int dw_accumulate,
-                                 float* dgamma, float* dbeta, int affine_accumulate, float* csum, float* ws, size_t ws_bytes, int N, int H,
-                                 int W, int C, void* stream) {
+                                 float* db, int db_accumulate, float* dgamma, float* dbeta, int affine_accumulate, float* csum, float* ws,
+                                 size_t ws_bytes, int N, int H, int W, int C, void* stream) {
     if (!bn_conv1_ok(N, H, W, C) || (act != ACT_NONE && act != ACT_LRELU && act != ACT_RELU)) return (int)hipErrorInvalidValue;
     if (ws_bytes < migan_bn_conv1_bwd_workspace(N, H, W, C)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
@@ -1556,17 +1587,24 @@ MIGAN_API int migan_bn_conv1_bwd(const float* x, const float* dz, const float* w
     float* wpart = ws;
     float* npart = ws + (size_t)nchunks * C * 9;
     float* sums = npart + (size_t)nchunks * C * 3;
-    MIGAN_LAUNCH(bn_conv1_bwd_sums_kernel, dim3(nchunks, gx), dim3(256), 0, st, g, x, dz, w_ohwi, mean, invstd, gamma, beta, wpart, npart);
+    float* third = sums + (size_t)C * 2;
+    MIGAN_LAUNCH(bn_conv1_bwd_sums_kernel, dim3(nchunks, gx), dim3(256), bn_conv1_lds(chunk, W), st, g, x, dz, w_ohwi, mean, invstd, gamma,
+                 beta, wpart, npart);
     HIP_LAUNCH_CHECK();
     MIGAN_LAUNCH(norm_finalize_bwd_kernel, dim3(cdiv((long)C * 64, 256)), dim3(256), 0, st, npart, sums, dgamma, dbeta, 1, C, nchunks,
-                 affine_accumulate, (float*)nullptr, 0);
+                 affine_accumulate, db ? third : (float*)nullptr, 0);
     HIP_LAUNCH_CHECK();
+    if (db) {   // third[0] = sum over the chunks of their dz sums
+        MIGAN_LAUNCH(sum_small_kernel, dim3(1), dim3(256), 0, st, third, 1, db, db_accumulate);
+        HIP_LAUNCH_CHECK();
+    }
     if (int rc = wgrad_reduce_slabs(wpart, dw_oihw, nchunks, 1, 9, C, dw_accumulate, nullptr, nullptr, 0, 0, st)) return rc;
     int chunkB;
     dim3 gridB;
     apply_plan(1, P, C, VW, CTX, chunkB, gridB);
     g.chunk = chunkB;
-    MIGAN_LAUNCH(bn_conv1_bwd_apply_kernel, gridB, dim3(256), 0, st, g, x, dz, w_ohwi, mean, invstd, gamma, beta, sums, dx, csum);
+    MIGAN_LAUNCH(bn_conv1_bwd_apply_kernel, gridB, dim3(256), bn_conv1_lds(chunkB, W), st, g, x, dz, w_ohwi, mean, invstd, gamma, beta, sums,
+                 dx, csum);
     HIP_LAUNCH_CHECK();
     return 0;
 }

@@ -2163,9 +2163,9 @@ class _BnActConv1(Function):
         if act_out != ACT_NONE:
             dz = _act_bwd_raw(dz, y, act_out, slope_out)
         st = _stream()
-        db = None
+        db, dbt, dba = None, None, 0
         if b is not None and ctx.needs_input_grad[11]:
-            db = _colsum(dz, P, 1, _grad_slot(b))
+            dbt, dba, db = _bias_out(b, 1, xs)   # the sum of dz comes out of the first walk
         wslot = _grad_slot(w) if ctx.needs_input_grad[10] else None
         dw = wslot if wslot is not None else torch.empty_like(wt)
         dgamma = dbeta = None
@@ -2186,8 +2186,8 @@ class _BnActConv1(Function):
         nb = lib.migan_bn_conv1_bwd_workspace(N, H, W, C)
         ws = _ws(nb, xs)
         check(lib.migan_bn_conv1_bwd(xs.data_ptr(), dz.data_ptr(), wp.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gm), _ptr(bt),
-                                     act_in, slope_in, dx.data_ptr(), dw.data_ptr(), 1 if wslot is not None else 0, _ptr(dgamma), _ptr(dbeta),
-                                     acc, _ptr(slabs), ws.data_ptr(), nb, N, H, W, C, st), "bn_conv1_bwd")
+                                     act_in, slope_in, dx.data_ptr(), dw.data_ptr(), 1 if wslot is not None else 0, _ptr(dbt), dba, _ptr(dgamma),
+                                     _ptr(dbeta), acc, _ptr(slabs), ws.data_ptr(), nb, N, H, W, C, st), "bn_conv1_bwd")
         if wslot is not None or not ctx.needs_input_grad[10]:
             dw = None
         if acc:
