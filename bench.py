@@ -484,6 +484,26 @@ class ConvProfiler:
         self._wrap("migan_norm_apply_prelu", norm("apply", 8, 2))
         self._wrap("migan_norm_bwd", norm("bwd", 9, 5))
         self._wrap("migan_norm_bwd_prelu", norm("bwd", 11, 5))
+        # the generator tail of dcgan.py:60-62 (BatchNorm read by the image-output conv): the forward is the thin-N conv launch; the backward
+        # (csrc/norm.hip bn_conv1_bwd_*) is HBM-bound - x read by both walks, dx written: 12 B per element
+        self._wrap("migan_conv2d_fwd_normed", lambda a: ("fwd_normed" + fwd(a)[0][3:],) + fwd(a)[1:])
+
+        def bn_conv1_bwd(a):
+            N, H, W, C = a[20:24]
+            return ("bn_conv1_bwd[1x%dx%d]" % (N * H * W, C), 4.0 * N * H * W * C * 3, -1.0)
+
+        self._wrap("migan_bn_conv1_bwd", bn_conv1_bwd)
+
+        # weight-stationary Conv2d(64, 64, 3, 1, 1) (csrc/conv_c64.hip): forward and (flipped pack) input gradient are the same entry
+        def c64(kind, off):
+            def describe(a):
+                N, H, W = a[off:off + 3]
+                f = 2.0 * N * H * W * 64 * 64 * 9
+                return ("c64_%s[%dx 64->64 k3 @%d]" % (kind, N, H), f, f)
+            return describe
+
+        self._wrap("migan_c64_conv_fwd", c64("conv", 4))
+        self._wrap("migan_c64_conv_wgrad", c64("wgrad", 5))
         self._wrap("migan_conv2d_wgrad", wgrad)
         self._wrap("migan_upconv3x3_fwd", up_fwd)
         self._wrap("migan_upconv3x3_dgrad", up_dgrad)

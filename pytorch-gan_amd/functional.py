@@ -1987,7 +1987,7 @@ _BN_FOLD = __import__("os").environ.get("MIGAN_BN_FOLD", "1") == "1"   # A/B kno
 def bn_prelu_conv64_takes(x, w, stride, pads, dilation=(1, 1), groups=1):
     """True when bn_prelu_conv64(x, ...) serves the chain: local-batch BatchNorm statistics, first-order backward, the geometry of
     csrc/conv_c64.hip."""
-    if not (_BN_FOLD and _C64) or x.dim() != 4 or w.dim() != 4:
+    if not (_BN_FOLD and _C64) or x.dim() != 4 or w.dim() != 4 or not on_device(x):
         return False
     if (_SYNC_BN is not None and _SYNC_BN.world > 1) or _BN_GROUPS != 1 or tuple(dilation) != (1, 1) or groups != 1:
         return False

@@ -103,15 +103,15 @@ def test_bench_flop_accounting_and_pmc_table():
     # the current round's table (tools/pmc_step.py over the rocprofv3 --pmc passes of `bench.py --pmc-log`: counters of the kernels IN the
     # training step); the committed table of round 2 (tools/pmc_kernels.py, stand-alone microbench passes, register-staged kernels)
     # is kept as history - the arithmetic of both is checked
-    assert bench.PROFILE_ROUND == "r05"
-    tab4, src4 = bench.pmc_table()   # this round's table, or round 4's until this round's passes have been taken
+    assert bench.PROFILE_ROUND == "r06"
+    tab4, src4 = bench.pmc_table()   # this round's table, or the previous round's until this round's passes have been taken
     if src4 is not None:
-        assert src4 in ("profiles/r05_pmc_kernels.json", "profiles/r04_pmc_kernels.json") and any(k.startswith("upconv_wgrad[") for k in tab4)
+        assert src4 in ("profiles/r06_pmc_kernels.json", "profiles/r05_pmc_kernels.json") and any(k.startswith("upconv_wgrad[") for k in tab4)
     bench.PROFILE_ROUND = "r02"
     try:
         tab, src = bench.pmc_table()
     finally:
-        bench.PROFILE_ROUND = "r05"
+        bench.PROFILE_ROUND = "r06"
     assert src == "profiles/r02_pmc_kernels.json" and "upconv_fwd[128x 128->64 @64]" in tab and "_calibration" in tab
     for name, ent in list(tab.items()) + [kv for kv in tab4.items() if "hbm_bytes_per_launch" in kv[1]]:
         if name.startswith("_"):
