@@ -709,14 +709,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void wgrad_dma_kernel(const WgradGeom
     const int HoWo = g.Ho * g.Wo;
     const int Mpix = g.N * HoWo;
     int split, tile;  // XCD-aware block order, see wgrad_pipe_kernel
+    int cls_x = 0;    // DYS with gridDim.y == 1: the phase class rides in blockIdx.x, between split and tile (see launch_wgrad_dma)
     {
         const int tiles = g.tiles_m * g.tiles_n;
-        const int total = tiles * g.splits, per = (total + 7) >> 3;
+        const int ncx = (DYS && gridDim.y == 1) ? 4 : 1;
+        const int total = tiles * g.splits * ncx, per = (total + 7) >> 3;
         const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
         const int lin = xcd * per + k;
         if (k >= per || lin >= total) return;
-        split = lin / tiles;
-        tile = lin - split * tiles;
+        split = lin / (tiles * ncx);
+        const int rem = lin - split * tiles * ncx;
+        cls_x = rem / tiles;
+        tile = rem - cls_x * tiles;
     }
     const int co0 = (tile % g.tiles_m) * BM, nc0 = (tile / g.tiles_m) * BN;
     const int p_begin = split * g.pix_per_split < Mpix ? split * g.pix_per_split : Mpix;
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wgrad_dma_kernel(const WgradGeom
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN_, wn = wave % WN_;
-    const int cls = DYS ? (int)blockIdx.y : 0;
+    const int cls = DYS ? (gridDim.y == 1 ? cls_x : (int)blockIdx.y) : 0;
     const int pad_t = DYS ? 1 - (cls >> 1) : g.pad_t, pad_l = DYS ? 1 - (cls & 1) : g.pad_l;
     const int dy_oh0 = cls >> 1, dy_ow0 = cls & 1;
     const __amdgpu_buffer_rsrc_t rX = dma_rsrc(X, x_bytes), rD = dma_rsrc(DY, dy_bytes);
@@ -897,7 +901,13 @@ int launch_wgrad_dma(const WgradGeom& g, int bm, int bn, bool dys, const float* 
     WgradGeom gg = g;
     gg.tiles_m = cdiv(g.Co, bm);
     gg.tiles_n = cdiv(Ncol, bn);
-    dim3 grid(cdiv(gg.tiles_m * gg.tiles_n * gg.splits, 8) * 8, dys ? 4 : 1);
+    // Up-conv (dys): the four phase classes of one pixel range read the SAME x pixels (their 2x2 taps differ) - with the class in grid.y
+    // the four launches-worth of workgroups are a whole grid apart and x comes back from the Infinity Cache four times (328.6 MB
+    // HBM-side against 201 MB of operands, profiles/r06_pmc_kernels.json).  MIGAN_WGRAD_CLSX=1: the class rides in blockIdx.x between split
+    // and tile, so the 4 x tiles_n workgroups of a pixel range are neighbours on ONE XCD and share that XCD's L2.
+    static const int clsx_env = getenv("MIGAN_WGRAD_CLSX") ? atoi(getenv("MIGAN_WGRAD_CLSX")) : 1;
+    const bool clsx = dys && clsx_env != 0;
+    dim3 grid(cdiv(gg.tiles_m * gg.tiles_n * gg.splits * (clsx ? 4 : 1), 8) * 8, dys && !clsx ? 4 : 1);
 #define WGD(BM_, BN_, BK_, OCC_)                                                                                             \
     do {                                                                                                                 \
         if (dys) MIGAN_LAUNCH((wgrad_dma_kernel<BM_, BN_, BK_, true, false, OCC_>), grid, dim3(256), 0, st, gg, x, dy, ws, \
