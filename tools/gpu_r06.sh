@@ -143,6 +143,18 @@ task_normab() {
   done
 }
 
+# closing pass of the final tree: PMC passes over the steps (so that the bench line that follows reads THIS library's counter table),
+# default bench line, kernel traces of all workloads
+task_final() {
+  rm -f profiles/r06_pmc_kernels.json   # (the box's copy: the table is rebuilt from this library's passes alone)
+  task_pmcstep dcgan 3 sq l2 fetch write
+  task_pmcstep cyclegan 1 sq fetch write
+  task_pmcstep srgan 1 sq fetch write
+  task_pmcstep pix2pix 3 sq fetch write
+  task_bench
+  task_prof r6final dcgan dcgan:graph cyclegan srgan wgan_gp:graph pix2pix pix2pix:graph cyclegan:graph@1
+}
+
 t=${1:-}; shift || true
 case "$t" in
   prof) task_prof "$@" ;;
