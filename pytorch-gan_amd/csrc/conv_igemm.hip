@@ -1273,6 +1273,9 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce2_kernel(const float* 
     }
 }
 
+// (Round 6 measured the same reduction with 16-byte loads and 32 split lanes - the 64 splits of the DCGAN layer in ONE round of 32 loads
+// per thread instead of four: 25.7 vs 24 us in the step, the whole step 2.2756 / 2.2792 vs 2.2792 / 2.2778 ms, profiles/r06_ab.txt call 47.
+// The launch is not bound by its dependent load rounds: the slabs come back from the other XCDs' write-backs.  Removed.)
 MIGAN_API size_t migan_upconv3x3_wgrad_workspace(int N, int H, int W, int Co, int Ci) {
     int bm, splits, pps;
     wgrad_plan(N, H, W, Co, 4 * Ci, bm, splits, pps, 4, upw_bn(N, H, W, Co, Ci));

@@ -170,6 +170,26 @@ def test_split_count_sweep_of_the_weight_gradient_reductions(emu):
         assert _rel(dw, w.grad) <= 2e-6, (N, _rel(dw, w.grad))
         seen_up.add(wsb // (4 * Co * (4 * Ci + 1) * 4))   # 4 classes x splits x (Co x 4 Ci partials + Co bias slab)
     assert len(seen_up) >= 6 and max(seen_up) >= 17, seen_up   # 17+: a whole round of eight on every split lane
+    # 32 source channels: the form that reads every slab element once (upconv_wgrad_reduce2_kernel: 8 split lanes, two splits per lane and
+    # round); 10 / 33 / 75 splits leave lanes with one split of a pair or none
+    Ci, seen32 = 32, set()
+    emu.hipemu_reset_counts()
+    for N in (40, 132, 160, 300):
+        g = torch.Generator().manual_seed(200 + N)
+        x = torch.randn(N, Ci, 8, 8, generator=g)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.2).requires_grad_(True)
+        y = TF.conv2d(TF.interpolate(x, scale_factor=2, mode="nearest"), w, None, 1, 1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xn, gyn = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
+        wsb = emu.migan_upconv3x3_wgrad_workspace(N, 8, 8, Co, Ci)
+        ws, dw = torch.empty(wsb // 4), torch.full((Co, Ci, 3, 3), 0.5)
+        rc = emu.migan_upconv3x3_wgrad(_ptr(xn), _ptr(gyn), _ptr(dw), _ptr(ws), wsb, N, 8, 8, Ci, Co, 1, None, 0, None, 0, None)   # accumulate
+        assert rc == 0, (N, emu.hipemu_last_message())
+        assert _rel(dw - 0.5, w.grad) <= 2e-6, (N, _rel(dw - 0.5, w.grad))
+        seen32.add(wsb // (4 * Co * (4 * Ci + 1) * 4))
+    assert min(seen32) < 32 <= max(seen32) and any(s_ % 32 for s_ in seen32 if s_ > 32), seen32
+    assert emu.hipemu_launch_count(b"upconv_wgrad_reduce2_kernel") == 4
 
 
 def test_results_do_not_depend_on_the_wave_schedule(emu):
