@@ -1421,33 +1421,52 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_sums_kernel(const BnConv1Geo
         int R = q / g.W, iw = q - R * g.W;
         int ih = R % g.H, wr = R - row0;
         const bool lead = tx == 0 && blockIdx.y == 0;
-        for (; q < q1; q += TY, iw += TY) {
-            while (iw >= g.W) {
-                iw -= g.W;
-                ++wr;
-                if (++ih >= g.H) ih = 0;
-            }
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
-            float dv[9];
-            bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
-            if (lead) sdz += dv[4];
-            f32x4 a, xh, da;   // activated input of the conv, normalised value, act'(z)
+        // the x loads run BN_C1_U pixels ahead of the arithmetic (clamped index; the loop body is unrolled over the BN_C1_U slots): with one
+        // 16-byte load per thread and iteration in flight the walk was bound by the round trip, 51 us for 134 MB (profiles/r06_ab.txt call 50)
+        constexpr int BN_C1_U = 4;
+        f32x4 xq[BN_C1_U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                xh[k] = (xv[k] - mu[k]) * is[k];
-                const float z = fmaf(xv[k], sc[k], sh[k]);
-                da[k] = z > 0.f ? 1.f : nslope;
-                a[k] = z * da[k];
-            }
-            f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < BN_C1_U; ++u) {
+            const int qq = q + u * TY;
+            xq[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(qq < q1 ? qq : q1 - 1) * g.C + c);
+        }
+        while (q < q1) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                acc[t] += a * dv[t];
-                gq += wv[t] * dv[t];
+            for (int u = 0; u < BN_C1_U; ++u) {
+                if (q >= q1) break;
+                while (iw >= g.W) {
+                    iw -= g.W;
+                    ++wr;
+                    if (++ih >= g.H) ih = 0;
+                }
+                const f32x4 xv = xq[u];
+                {
+                    const int qn = q + BN_C1_U * TY;
+                    xq[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(qn < q1 ? qn : q1 - 1) * g.C + c);
+                }
+                float dv[9];
+                bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
+                if (lead) sdz += dv[4];
+                f32x4 a, xh, da;   // activated input of the conv, normalised value, act'(z)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xh[k] = (xv[k] - mu[k]) * is[k];
+                    const float z = fmaf(xv[k], sc[k], sh[k]);
+                    da[k] = z > 0.f ? 1.f : nslope;
+                    a[k] = z * da[k];
+                }
+                f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc[t] += a * dv[t];
+                    gq += wv[t] * dv[t];
+                }
+                const f32x4 d = gq * da;
+                s0 += d;
+                s1 += d * xh;
+                q += TY;
+                iw += TY;
             }
-            const f32x4 d = gq * da;
-            s0 += d;
-            s1 += d * xh;
         }
     }
     // reduce over the TY pixel lanes through LDS, one slab at a time (fixed order)
@@ -1520,28 +1539,45 @@ __global__ __launch_bounds__(256) void bn_conv1_bwd_apply_kernel(const BnConv1Ge
         const int row0 = q0 / g.W - 1;
         int R = q / g.W, iw = q - R * g.W;
         int ih = R % g.H, wr = R - row0;
-        for (; q < q1; q += TY, iw += TY) {
-            while (iw >= g.W) {
-                iw -= g.W;
-                ++wr;
-                if (++ih >= g.H) ih = 0;
-            }
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)q * g.C + c);
-            float dv[9];
-            bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
-            f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+        constexpr int BN_C1_U = 4;   // x loads four pixels ahead, as in the first walk
+        f32x4 xq[BN_C1_U];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) gq += wv[t] * dv[t];
-            f32x4 o;
+        for (int u = 0; u < BN_C1_U; ++u) {
+            const int qq = q + u * TY;
+            xq[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(qq < q1 ? qq : q1 - 1) * g.C + c);
+        }
+        while (q < q1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xh = (xv[k] - mu[k]) * is[k];
-                const float z = fmaf(xv[k], sc[k], sh[k]);
-                const float da = z > 0.f ? 1.f : nslope;
-                o[k] = gi[k] * (gq[k] * da - k0[k] - xh * k1[k]);
-                cs[k] += o[k];
+            for (int u = 0; u < BN_C1_U; ++u) {
+                if (q >= q1) break;
+                while (iw >= g.W) {
+                    iw -= g.W;
+                    ++wr;
+                    if (++ih >= g.H) ih = 0;
+                }
+                const f32x4 xv = xq[u];
+                {
+                    const int qn = q + BN_C1_U * TY;
+                    xq[u] = *reinterpret_cast<const f32x4*>(x + (size_t)(qn < q1 ? qn : q1 - 1) * g.C + c);
+                }
+                float dv[9];
+                bn_conv1_taps(dzw, W2, wr, iw, ih > 0 ? 1.f : 0.f, ih < g.H - 1 ? 1.f : 0.f, dv);
+                f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 9; ++t) gq += wv[t] * dv[t];
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - mu[k]) * is[k];
+                    const float z = fmaf(xv[k], sc[k], sh[k]);
+                    const float da = z > 0.f ? 1.f : nslope;
+                    o[k] = gi[k] * (gq[k] * da - k0[k] - xh * k1[k]);
+                    cs[k] += o[k];
+                }
+                *reinterpret_cast<f32x4*>(dx + (size_t)q * g.C + c) = o;
+                q += TY;
+                iw += TY;
             }
-            *reinterpret_cast<f32x4*>(dx + (size_t)q * g.C + c) = o;
         }
     }
     if (csum) colsum_slab_store<4>(cs, red, csum, tid, tx, g.CTX, TY, cok, c, g.C);
